@@ -1,0 +1,412 @@
+"""Scene description loader: DeepMimic JSON / arg files -> raw numeric tables.
+
+This module only *parses*.  It turns the on-disk formats the hot path consumes
+(character skeleton + body defs, PD-controller file, motion clip, arg file)
+into plain numpy tables laid out exactly like the reference's in-memory
+matrices, so that the native host library (csrc/dm_host.cpp) and the test
+oracle can each derive everything else on their own:
+
+* ``joint_mat``  [J x 19]  columns = cKinTree::eJointDesc
+  (reference: DeepMimicCore/anim/KinTree.h:24-47, parse KinTree.cpp:433-481,959-987)
+* ``body_defs``  [J x 17]  columns = cKinTree::eBodyParam
+  (KinTree.h:49-70, parse KinTree.cpp:125-197)
+* ``pd_params``  [J x 2]   (Kp, Kd) per joint (sim/PDController.cpp:50-93)
+* ``frames``     [F x (1+P)] raw motion frames, column 0 = frame duration
+  (anim/Motion.cpp:344-378)
+
+Arg-file semantics follow util/ArgParser.cpp:31-120 (``--key v1 v2``, ``#``
+comments, first occurrence of a key wins, ``--arg_file`` chaining as in
+DeepMimicCore.cpp:25-44).
+"""
+from __future__ import annotations
+
+import json
+import os
+import re
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+
+# --- cKinTree enums (anim/KinTree.h:13-70) ---------------------------------
+JOINT_TYPES = ["revolute", "planar", "prismatic", "fixed", "spherical", "none"]
+JT_REVOLUTE, JT_PLANAR, JT_PRISMATIC, JT_FIXED, JT_SPHERICAL, JT_NONE = range(6)
+
+JOINT_DESC_KEYS = [
+    "Type", "Parent", "AttachX", "AttachY", "AttachZ",
+    "AttachThetaX", "AttachThetaY", "AttachThetaZ",
+    "LimLow0", "LimLow1", "LimLow2", "LimHigh0", "LimHigh1", "LimHigh2",
+    "TorqueLim", "ForceLim", "IsEndEffector", "DiffWeight", "Offset",
+]
+(JD_TYPE, JD_PARENT, JD_AX, JD_AY, JD_AZ, JD_ATX, JD_ATY, JD_ATZ,
+ JD_LL0, JD_LL1, JD_LL2, JD_LH0, JD_LH1, JD_LH2,
+ JD_TORQUE_LIM, JD_FORCE_LIM, JD_IS_EE, JD_DIFF_W, JD_PARAM_OFFSET) = range(19)
+
+BODY_KEYS = [
+    "Shape", "Mass", "ColGroup", "EnableFallContact",
+    "AttachX", "AttachY", "AttachZ", "AttachThetaX", "AttachThetaY", "AttachThetaZ",
+    "Param0", "Param1", "Param2", "ColorR", "ColorG", "ColorB", "ColorA",
+]
+(BD_SHAPE, BD_MASS, BD_COLGROUP, BD_FALL, BD_AX, BD_AY, BD_AZ, BD_ATX, BD_ATY, BD_ATZ,
+ BD_P0, BD_P1, BD_P2, BD_CR, BD_CG, BD_CB, BD_CA) = range(17)
+
+SHAPES = ["null", "box", "capsule", "sphere", "cylinder", "plane"]  # anim/Shape.h:8-17
+SH_NULL, SH_BOX, SH_CAPSULE, SH_SPHERE, SH_CYLINDER, SH_PLANE = range(6)
+
+
+def _joint_desc_default() -> np.ndarray:
+    """cKinTree::BuildJointDesc() (anim/KinTree.cpp:1132-1156)."""
+    d = np.zeros(19)
+    d[JD_TYPE] = JT_REVOLUTE
+    d[JD_PARENT] = -1
+    d[JD_LL0:JD_LL2 + 1] = 1
+    d[JD_LH0:JD_LH2 + 1] = 0
+    d[JD_TORQUE_LIM] = np.inf
+    d[JD_FORCE_LIM] = np.inf
+    d[JD_DIFF_W] = 1
+    return d
+
+
+def _body_def_default() -> np.ndarray:
+    """cKinTree::BuildBodyDef() (anim/KinTree.cpp:1158-1179)."""
+    d = np.zeros(17)
+    d[BD_SHAPE] = SH_NULL
+    d[BD_COLGROUP] = -1
+    d[BD_CA] = 1
+    return d
+
+
+def joint_param_size(jtype: int, is_root: bool) -> int:
+    """cKinTree::GetParamSize (anim/KinTree.cpp:768-802)."""
+    if is_root:
+        return 7
+    return {JT_REVOLUTE: 1, JT_PRISMATIC: 1, JT_PLANAR: 3, JT_FIXED: 0, JT_SPHERICAL: 4}[jtype]
+
+
+def parse_skeleton(char_json: dict) -> np.ndarray:
+    joints = char_json["Skeleton"]["Joints"]
+    J = len(joints)
+    jm = np.zeros((J, 19))
+    for j, jj in enumerate(joints):
+        d = _joint_desc_default()
+        d[JD_TYPE] = JOINT_TYPES.index(jj["Type"])
+        for i, key in enumerate(JOINT_DESC_KEYS):
+            if i != JD_TYPE and key in jj and jj[key] is not None:
+                d[i] = float(jj[key])
+        jm[j] = d
+    for j in range(J):
+        if int(jm[j, JD_PARENT]) >= j:
+            raise ValueError("parent id must be < child id (joint %d)" % j)
+    # PostProcessJointMat (anim/KinTree.cpp:1005-1020)
+    off = 0
+    for j in range(J):
+        jm[j, JD_PARAM_OFFSET] = off
+        off += joint_param_size(int(jm[j, JD_TYPE]), j == 0)
+    jm[0, JD_AX:JD_AZ + 1] = 0
+    return jm
+
+
+def parse_body_defs(char_json: dict) -> np.ndarray:
+    defs = char_json["BodyDefs"]
+    bd = np.zeros((len(defs), 17))
+    for b, bj in enumerate(defs):
+        d = _body_def_default()
+        d[BD_SHAPE] = SHAPES.index(bj.get("Shape", "null"))
+        for i, key in enumerate(BODY_KEYS):
+            v = bj.get(key)
+            if isinstance(v, (int, float)) and not isinstance(v, bool):
+                d[i] = float(v)
+        bd[b] = d
+    return bd
+
+
+@dataclass
+class SceneConfig:
+    """Values of the arg-file keys the hot path consumes."""
+    scene: str = "imitate"
+    num_update_substeps: int = 1        # DeepMimicCore.cpp:43
+    num_sim_substeps: int = 1           # scenes/SceneSimChar.cpp:60
+    world_scale: float = 1.0            # scenes/SceneSimChar.cpp:61
+    gravity: Sequence[float] = (0.0, -9.8, 0.0)   # util/MathUtil.h:25
+    fall_contact_bodies: Optional[List[int]] = None
+    sync_char_root_pos: bool = True     # scenes/SceneImitate.cpp:132
+    sync_char_root_rot: bool = False
+    enable_rand_rot_reset: bool = False
+    enable_root_rot_fail: bool = False
+    enable_fall_end: bool = True        # scenes/RLSceneSimChar.cpp:5
+    enable_char_contact_fall: bool = True
+    enable_rand_char_placement: bool = True
+    time_lim_min: float = np.inf        # util/Timer.cpp:7-8
+    time_lim_max: float = np.inf
+    time_lim_exp: float = 1.0
+    time_end_lim_min: Optional[float] = None
+    time_end_lim_max: Optional[float] = None
+    time_end_lim_exp: Optional[float] = None
+    timer_type: str = "uniform"
+    anneal_samples: int = -1
+    character_file: str = ""
+    char_ctrl_file: str = ""
+    motion_file: str = ""
+    terrain_file: str = ""
+
+
+@dataclass
+class SceneTables:
+    """Raw tables for one imitate scene, reference memory layout."""
+    joint_mat: np.ndarray
+    body_defs: np.ndarray
+    pd_params: np.ndarray            # [J x 2] Kp, Kd
+    frames: np.ndarray               # [F x (1+P)] duration + pose
+    loop: bool
+    enable_phase_input: bool = False
+    record_world_root_pos: bool = False
+    record_world_root_rot: bool = False
+    query_rate: float = 30.0         # key "QueryRate" (sim/CtController.cpp:165)
+    cfg: SceneConfig = field(default_factory=SceneConfig)
+    joint_names: List[str] = field(default_factory=list)
+
+    @property
+    def num_joints(self) -> int:
+        return self.joint_mat.shape[0]
+
+    @property
+    def pose_dim(self) -> int:
+        return int(self.joint_mat[-1, JD_PARAM_OFFSET]) + joint_param_size(
+            int(self.joint_mat[-1, JD_TYPE]), self.num_joints == 1)
+
+    @property
+    def action_dim(self) -> int:
+        a = 0
+        for j in range(1, self.num_joints):
+            t = int(self.joint_mat[j, JD_TYPE])
+            a += 3 if t == JT_SPHERICAL else joint_param_size(t, False)
+        return a
+
+    @property
+    def state_dim(self) -> int:
+        J = self.num_joints
+        return (1 if self.enable_phase_input else 0) + (J * 9 + 1) + J * 6
+
+    def fall_mask(self) -> np.ndarray:
+        """Per-link fall-contact flags: args override JSON (scenes/SceneSimChar.cpp:460-476)."""
+        J = self.num_joints
+        m = (self.body_defs[:, BD_FALL] != 0).astype(np.int32)
+        if self.cfg.fall_contact_bodies:
+            m[:] = 0
+            for b in self.cfg.fall_contact_bodies:
+                m[b] = 1
+        return m
+
+    # ---- (de)serialisation to the compact asset format used in-tree ----
+    def to_json(self) -> dict:
+        c = self.cfg
+        return {
+            "format": "deepmimic_amd.scene_tables.v1",
+            "joint_names": self.joint_names,
+            "joint_mat": _mat_to_list(self.joint_mat),
+            "body_defs": _mat_to_list(self.body_defs),
+            "pd_params": _mat_to_list(self.pd_params),
+            "frames": _mat_to_list(self.frames),
+            "loop": bool(self.loop),
+            "enable_phase_input": bool(self.enable_phase_input),
+            "record_world_root_pos": bool(self.record_world_root_pos),
+            "record_world_root_rot": bool(self.record_world_root_rot),
+            "query_rate": float(self.query_rate),
+            "cfg": {k: _json_val(v) for k, v in c.__dict__.items()},
+        }
+
+    @staticmethod
+    def from_json(d: dict) -> "SceneTables":
+        cfg = SceneConfig()
+        for k, v in d.get("cfg", {}).items():
+            if v == "inf":
+                v = np.inf
+            setattr(cfg, k, v)
+        return SceneTables(
+            joint_mat=_list_to_mat(d["joint_mat"]),
+            body_defs=_list_to_mat(d["body_defs"]),
+            pd_params=_list_to_mat(d["pd_params"]),
+            frames=_list_to_mat(d["frames"]),
+            loop=bool(d["loop"]),
+            enable_phase_input=bool(d["enable_phase_input"]),
+            record_world_root_pos=bool(d["record_world_root_pos"]),
+            record_world_root_rot=bool(d["record_world_root_rot"]),
+            query_rate=float(d.get("query_rate", 30.0)),
+            cfg=cfg,
+            joint_names=list(d.get("joint_names", [])),
+        )
+
+
+def _json_val(v):
+    if isinstance(v, float) and np.isinf(v):
+        return "inf"
+    if isinstance(v, tuple):
+        return list(v)
+    return v
+
+
+def _mat_to_list(m: np.ndarray):
+    return [[("inf" if np.isposinf(x) else "-inf" if np.isneginf(x) else float(x)) for x in row]
+            for row in np.asarray(m, dtype=np.float64)]
+
+
+def _list_to_mat(rows) -> np.ndarray:
+    return np.array([[np.inf if x == "inf" else -np.inf if x == "-inf" else x for x in r]
+                     for r in rows], dtype=np.float64)
+
+
+# --- arg files ---------------------------------------------------------------
+class ArgParser:
+    """util/ArgParser.cpp:31-120.  First occurrence of a key wins."""
+
+    def __init__(self, args: Sequence[str] = ()):
+        self.table: Dict[str, List[str]] = {}
+        self.load_args(args)
+
+    def load_args(self, arg_strs: Sequence[str]) -> None:
+        key, vals = "", []
+        for s in arg_strs:
+            if s.startswith("#"):
+                continue
+            if len(s) >= 3 and s[0] == "-" and s[1] == "-":   # cArgParser::IsKey
+                if key and key not in self.table:
+                    self.table[key] = vals
+                key, vals = s[2:], []
+            else:
+                vals.append(s)
+        if key and key not in self.table:
+            self.table[key] = vals
+
+    def load_file(self, path: str) -> bool:
+        if not os.path.isfile(path):
+            return False
+        toks: List[str] = []
+        with open(path) as f:
+            for line in f:
+                if not line or line.startswith("#"):
+                    continue
+                toks.extend(t for t in re.split(r"[ \t\n\r,]+", line) if t)
+        self.load_args(toks)
+        return True
+
+    def get(self, key, default=None):
+        return self.table.get(key, default)
+
+    def str(self, key, default=""):
+        v = self.table.get(key)
+        return v[0] if v else default
+
+    def float(self, key, default):
+        v = self.table.get(key)
+        return float(v[0]) if v else default
+
+    def int(self, key, default):
+        v = self.table.get(key)
+        return int(v[0]) if v else default
+
+    def bool(self, key, default):
+        v = self.table.get(key)
+        if not v:
+            return default
+        return v[0] in ("true", "1", "True", "T", "t")   # cArgParser::ParseBool(str)
+
+    def ints(self, key):
+        v = self.table.get(key)
+        return [int(x) for x in v] if v else None
+
+    def floats(self, key):
+        v = self.table.get(key)
+        return [float(x) for x in v] if v else None
+
+
+def parse_scene_config(parser: ArgParser) -> SceneConfig:
+    c = SceneConfig()
+    c.scene = parser.str("scene", c.scene)
+    c.num_update_substeps = parser.int("num_update_substeps", c.num_update_substeps)
+    c.num_sim_substeps = parser.int("num_sim_substeps", c.num_sim_substeps)
+    c.world_scale = parser.float("world_scale", c.world_scale)
+    g = parser.floats("gravity")
+    if g:
+        c.gravity = tuple(g[:3])
+    c.fall_contact_bodies = parser.ints("fall_contact_bodies")
+    for k in ("sync_char_root_pos", "sync_char_root_rot", "enable_rand_rot_reset",
+              "enable_root_rot_fail", "enable_fall_end", "enable_char_contact_fall",
+              "enable_rand_char_placement"):
+        setattr(c, k, parser.bool(k, getattr(c, k)))
+    c.time_lim_min = parser.float("time_lim_min", c.time_lim_min)
+    c.time_lim_max = parser.float("time_lim_max", c.time_lim_max)
+    c.time_lim_exp = parser.float("time_lim_exp", c.time_lim_exp)
+    # mTimerParamsEnd starts as a copy of mTimerParams (scenes/RLSceneSimChar.cpp:19-22)
+    c.time_end_lim_min = parser.float("time_end_lim_min", c.time_lim_min)
+    c.time_end_lim_max = parser.float("time_end_lim_max", c.time_lim_max)
+    c.time_end_lim_exp = parser.float("time_end_lim_exp", c.time_lim_exp)
+    c.timer_type = parser.str("timer_type", "uniform") or "uniform"
+    c.anneal_samples = parser.int("anneal_samples", c.anneal_samples)
+    c.character_file = parser.str("character_files", "")
+    c.char_ctrl_file = parser.str("char_ctrl_files", "")
+    c.motion_file = parser.str("motion_file", "")
+    c.terrain_file = parser.str("terrain_file", "")
+    return c
+
+
+# --- scene loading -------------------------------------------------------------
+def load_scene(char_file: str, ctrl_file: str, motion_file: str,
+               cfg: Optional[SceneConfig] = None) -> SceneTables:
+    with open(char_file) as f:
+        cj = json.load(f)
+    with open(ctrl_file) as f:
+        kj = json.load(f)
+    with open(motion_file) as f:
+        mj = json.load(f)
+    jm = parse_skeleton(cj)
+    bd = parse_body_defs(cj)
+    J = jm.shape[0]
+    if bd.shape[0] != J:
+        raise ValueError("joint / body-def count mismatch")
+    pds = kj["PDControllers"]
+    if len(pds) != J:
+        raise ValueError("PD controller count mismatch")
+    pd = np.array([[float(p.get("Kp", 0)), float(p.get("Kd", 0))] for p in pds])
+    frames = np.array(mj["Frames"], dtype=np.float64)
+    loop_str = mj.get("Loop", "none")
+    if loop_str not in ("none", "wrap"):
+        raise ValueError("unsupported loop mode %r" % loop_str)
+    t = SceneTables(
+        joint_mat=jm, body_defs=bd, pd_params=pd, frames=frames, loop=(loop_str == "wrap"),
+        enable_phase_input=bool(kj.get("EnablePhaseInput", False)),
+        record_world_root_pos=bool(kj.get("RecordWorldRootPos", False)),
+        record_world_root_rot=bool(kj.get("RecordWorldRootRot", False)),
+        query_rate=float(kj.get("QueryRate", 30.0)),
+        cfg=cfg or SceneConfig(),
+        joint_names=[j.get("Name", "") for j in cj["Skeleton"]["Joints"]],
+    )
+    if frames.shape[1] - 1 != t.pose_dim:
+        raise ValueError("DOF mismatch, char dof %d, motion dof %d" % (t.pose_dim, frames.shape[1] - 1))
+    return t
+
+
+def load_scene_from_args(args: Sequence[str], data_root: str = ".") -> SceneTables:
+    """Mirror of cDeepMimicCore::ParseArgs + cSceneImitate::ParseArgs for `--scene imitate`."""
+    p = ArgParser(args)
+    arg_file = p.str("arg_file", "")
+    if arg_file:
+        path = arg_file if os.path.isabs(arg_file) else os.path.join(data_root, arg_file)
+        if not p.load_file(path):
+            raise FileNotFoundError("Failed to load args from: %s" % arg_file)
+    cfg = parse_scene_config(p)
+    if cfg.scene != "imitate":
+        raise ValueError("only `--scene imitate` is on the accelerated path (got %r)" % cfg.scene)
+
+    def res(pth):
+        return pth if os.path.isabs(pth) else os.path.join(data_root, pth)
+
+    return load_scene(res(cfg.character_file), res(cfg.char_ctrl_file), res(cfg.motion_file), cfg)
+
+
+ASSET_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "assets")
+
+
+def load_asset(name: str) -> SceneTables:
+    """Load an in-tree compiled scene (``assets/<name>.json``), e.g. ``humanoid3d_walk``."""
+    with open(os.path.join(ASSET_DIR, name + ".json")) as f:
+        return SceneTables.from_json(json.load(f))

@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""Compile the reference's data files for the BASELINE configs into in-tree scene tables.
+
+Reads /root/reference/{args,data} (only available in the build container) and writes
+deepmimic_amd/assets/<name>.json in the `deepmimic_amd.scene_tables.v1` format (flat
+numeric matrices in the reference's in-memory layout).  The GPU box has no /root/reference,
+so tests / bench / smoke load these compiled tables instead.
+"""
+import json, os, sys
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+from deepmimic_amd import model
+
+REF = os.environ.get("DM_REFERENCE", "/root/reference")
+SCENES = {
+    # name: (arg file, motion override)
+    "humanoid3d_walk": ("args/run_humanoid3d_walk_args.txt", None),
+    "humanoid3d_spinkick": ("args/train_humanoid3d_spinkick_args.txt", None),
+    "dog3d_pace": ("args/train_dog3d_pace_args.txt", None),
+    "humanoid3d_run": ("args/run_humanoid3d_run_args.txt", None),
+    "humanoid3d_backflip": ("args/run_humanoid3d_backflip_args.txt", None),
+}
+
+def main():
+    out_dir = model.ASSET_DIR
+    os.makedirs(out_dir, exist_ok=True)
+    for name, (arg_file, _) in SCENES.items():
+        t = model.load_scene_from_args(["--arg_file", arg_file], data_root=REF)
+        path = os.path.join(out_dir, name + ".json")
+        with open(path, "w") as f:
+            json.dump(t.to_json(), f, separators=(",", ":"))
+        print("%-22s J=%d P=%d A=%d S=%d F=%d loop=%s -> %s" % (
+            name, t.num_joints, t.pose_dim, t.action_dim, t.state_dim, t.frames.shape[0], t.loop, path))
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,322 @@
+// TEST INFRASTRUCTURE ONLY -- CPU oracle for the DeepMimic imitate hot path.
+// Nothing under deepmimic_amd/ may include, link or call this (see oracle/README.md).
+//
+// orc_math.h: scalar restatement of the reference's math conventions.
+//   cMathUtil  : /root/reference/DeepMimicCore/util/MathUtil.cpp   (cited per function)
+//   cSpAlg     : /root/reference/DeepMimicCore/sim/SpAlg.cpp
+//   Eigen bits : Quaternion product / slerp / q*v semantics of Eigen 3.3.7 (header-only
+//                dependency, absent from this container; restated from its published
+//                definition)
+#pragma once
+#include <cmath>
+#include <cstring>
+#include <algorithm>
+#include <vector>
+
+namespace orc {
+
+#ifndef ORC_REAL
+#define ORC_REAL double
+#endif
+typedef ORC_REAL real;
+
+static const real kPi = (real)3.14159265358979323846;
+
+struct V3 {
+    real x, y, z;
+    V3() : x(0), y(0), z(0) {}
+    V3(real a, real b, real c) : x(a), y(b), z(c) {}
+    real& operator[](int i) { return (&x)[i]; }
+    real operator[](int i) const { return (&x)[i]; }
+};
+static inline V3 operator+(const V3& a, const V3& b) { return V3(a.x + b.x, a.y + b.y, a.z + b.z); }
+static inline V3 operator-(const V3& a, const V3& b) { return V3(a.x - b.x, a.y - b.y, a.z - b.z); }
+static inline V3 operator-(const V3& a) { return V3(-a.x, -a.y, -a.z); }
+static inline V3 operator*(real s, const V3& a) { return V3(s * a.x, s * a.y, s * a.z); }
+static inline V3 operator*(const V3& a, real s) { return V3(s * a.x, s * a.y, s * a.z); }
+static inline V3 operator/(const V3& a, real s) { return V3(a.x / s, a.y / s, a.z / s); }
+static inline V3& operator+=(V3& a, const V3& b) { a.x += b.x; a.y += b.y; a.z += b.z; return a; }
+static inline V3& operator-=(V3& a, const V3& b) { a.x -= b.x; a.y -= b.y; a.z -= b.z; return a; }
+static inline real dot(const V3& a, const V3& b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+static inline V3 cross(const V3& a, const V3& b) {
+    return V3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+static inline real norm2(const V3& a) { return dot(a, a); }
+static inline real norm(const V3& a) { return std::sqrt(dot(a, a)); }
+
+// 3x3 matrix, row-major m[r][c]
+struct M3 {
+    real m[3][3];
+    M3() { std::memset(m, 0, sizeof(m)); }
+    static M3 identity() { M3 r; r.m[0][0] = r.m[1][1] = r.m[2][2] = 1; return r; }
+};
+static inline V3 operator*(const M3& a, const V3& v) {
+    return V3(a.m[0][0] * v.x + a.m[0][1] * v.y + a.m[0][2] * v.z,
+              a.m[1][0] * v.x + a.m[1][1] * v.y + a.m[1][2] * v.z,
+              a.m[2][0] * v.x + a.m[2][1] * v.y + a.m[2][2] * v.z);
+}
+static inline M3 operator*(const M3& a, const M3& b) {
+    M3 r;
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            real s = 0;
+            for (int k = 0; k < 3; ++k) s += a.m[i][k] * b.m[k][j];
+            r.m[i][j] = s;
+        }
+    return r;
+}
+static inline M3 transpose(const M3& a) {
+    M3 r;
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) r.m[i][j] = a.m[j][i];
+    return r;
+}
+static inline M3 operator+(const M3& a, const M3& b) {
+    M3 r; for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) r.m[i][j] = a.m[i][j] + b.m[i][j]; return r;
+}
+static inline M3 operator*(real s, const M3& a) {
+    M3 r; for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) r.m[i][j] = s * a.m[i][j]; return r;
+}
+// cMathUtil::CrossMat (MathUtil.cpp:239-247)
+static inline M3 cross_mat(const V3& a) {
+    M3 r;
+    r.m[0][1] = -a.z; r.m[0][2] = a.y;
+    r.m[1][0] = a.z;  r.m[1][2] = -a.x;
+    r.m[2][0] = -a.y; r.m[2][1] = a.x;
+    return r;
+}
+
+// Rigid 4x4 [R | t] (tMatrix restricted to rigid transforms)
+struct Xf {
+    M3 R; V3 t;
+    Xf() : R(M3::identity()) {}
+    Xf(const M3& r, const V3& p) : R(r), t(p) {}
+};
+static inline Xf operator*(const Xf& a, const Xf& b) { return Xf(a.R * b.R, a.R * b.t + a.t); }
+static inline V3 xf_point(const Xf& a, const V3& p) { return a.R * p + a.t; }
+// cMathUtil::InvRigidMat
+static inline Xf inv_rigid(const Xf& a) { M3 rt = transpose(a.R); return Xf(rt, -(rt * a.t)); }
+
+// Quaternion (w,x,y,z) -- storage order of pose vectors (MathUtil.cpp:512-520)
+struct Q4 {
+    real w, x, y, z;
+    Q4() : w(1), x(0), y(0), z(0) {}
+    Q4(real w_, real x_, real y_, real z_) : w(w_), x(x_), y(y_), z(z_) {}
+};
+// Eigen quaternion product a*b
+static inline Q4 operator*(const Q4& a, const Q4& b) {
+    return Q4(a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z,
+              a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y,
+              a.w * b.y + a.y * b.w + a.z * b.x - a.x * b.z,
+              a.w * b.z + a.z * b.w + a.x * b.y - a.y * b.x);
+}
+static inline Q4 conj(const Q4& q) { return Q4(q.w, -q.x, -q.y, -q.z); }
+static inline real qnorm(const Q4& q) { return std::sqrt(q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z); }
+static inline Q4 qnormalized(const Q4& q) { real n = qnorm(q); return Q4(q.w / n, q.x / n, q.y / n, q.z / n); }
+static inline real qdot(const Q4& a, const Q4& b) { return a.w * b.w + a.x * b.x + a.y * b.y + a.z * b.z; }
+// Eigen: q * v  (QuaternionBase::_transformVector): v + 2w (u x v) + 2 u x (u x v)
+static inline V3 qrot(const Q4& q, const V3& v) {
+    V3 u(q.x, q.y, q.z);
+    V3 uv = cross(u, v);
+    uv = uv + uv;
+    return v + q.w * uv + cross(u, uv);
+}
+// Eigen Quaternion::slerp (Eigen/src/Geometry/Quaternion.h, 3.3.7)
+static inline Q4 slerp(const Q4& a, real t, const Q4& b) {
+    const real one = (real)1 - std::numeric_limits<real>::epsilon();
+    real d = qdot(a, b);
+    real absD = std::fabs(d);
+    real s0, s1;
+    if (absD >= one) { s0 = (real)1 - t; s1 = t; }
+    else {
+        real theta = std::acos(absD);
+        real sinTheta = std::sin(theta);
+        s0 = std::sin(((real)1 - t) * theta) / sinTheta;
+        s1 = std::sin(t * theta) / sinTheta;
+    }
+    if (d < 0) s1 = -s1;
+    return Q4(s0 * a.w + s1 * b.w, s0 * a.x + s1 * b.x, s0 * a.y + s1 * b.y, s0 * a.z + s1 * b.z);
+}
+
+// cMathUtil::NormalizeAngle (MathUtil.cpp:33-46)
+static inline real normalize_angle(real theta) {
+    real n = std::fmod(theta, 2 * kPi);
+    if (n > kPi) n = -2 * kPi + n;
+    else if (n < -kPi) n = 2 * kPi + n;
+    return n;
+}
+// cMathUtil::StandardizeQuat (MathUtil.cpp:48-59)
+static inline Q4 standardize(const Q4& q) { return (q.w < 0) ? Q4(-q.w, -q.x, -q.y, -q.z) : q; }
+
+// cMathUtil::RotateMat(euler) = Rz*Ry*Rx (MathUtil.cpp:159-186)
+static inline M3 rot_euler(const V3& e) {
+    real xs = std::sin(e.x), xc = std::cos(e.x), ys = std::sin(e.y), yc = std::cos(e.y), zs = std::sin(e.z), zc = std::cos(e.z);
+    M3 r;
+    r.m[0][0] = yc * zc;                r.m[1][0] = yc * zs;                r.m[2][0] = -ys;
+    r.m[0][1] = xs * ys * zc - xc * zs; r.m[1][1] = xs * ys * zs + xc * zc; r.m[2][1] = xs * yc;
+    r.m[0][2] = xc * ys * zc + xs * zs; r.m[1][2] = xc * ys * zs - xs * zc; r.m[2][2] = xc * yc;
+    return r;
+}
+// cMathUtil::RotateMat(axis, theta) (MathUtil.cpp:188-205)
+static inline M3 rot_axis(const V3& a, real th) {
+    real c = std::cos(th), s = std::sin(th), x = a.x, y = a.y, z = a.z;
+    M3 r;
+    r.m[0][0] = c + x * x * (1 - c);     r.m[0][1] = x * y * (1 - c) - z * s; r.m[0][2] = x * z * (1 - c) + y * s;
+    r.m[1][0] = y * x * (1 - c) + z * s; r.m[1][1] = c + y * y * (1 - c);     r.m[1][2] = y * z * (1 - c) - x * s;
+    r.m[2][0] = z * x * (1 - c) - y * s; r.m[2][1] = z * y * (1 - c) + x * s; r.m[2][2] = c + z * z * (1 - c);
+    return r;
+}
+// cMathUtil::RotateMat(quat) (MathUtil.cpp:207-237)
+static inline M3 rot_quat(const Q4& q) {
+    real sqw = q.w * q.w, sqx = q.x * q.x, sqy = q.y * q.y, sqz = q.z * q.z;
+    real invs = 1 / (sqx + sqy + sqz + sqw);
+    M3 r;
+    r.m[0][0] = (sqx - sqy - sqz + sqw) * invs;
+    r.m[1][1] = (-sqx + sqy - sqz + sqw) * invs;
+    r.m[2][2] = (-sqx - sqy + sqz + sqw) * invs;
+    real t1 = q.x * q.y, t2 = q.z * q.w;
+    r.m[1][0] = 2 * (t1 + t2) * invs; r.m[0][1] = 2 * (t1 - t2) * invs;
+    t1 = q.x * q.z; t2 = q.y * q.w;
+    r.m[2][0] = 2 * (t1 - t2) * invs; r.m[0][2] = 2 * (t1 + t2) * invs;
+    t1 = q.y * q.z; t2 = q.x * q.w;
+    r.m[2][1] = 2 * (t1 + t2) * invs; r.m[1][2] = 2 * (t1 - t2) * invs;
+    return r;
+}
+// cMathUtil::RotMatToQuaternion (MathUtil.cpp: trace method; used for link rotations)
+static inline Q4 quat_from_rot(const M3& a) {
+    real tr = a.m[0][0] + a.m[1][1] + a.m[2][2];
+    Q4 q;
+    if (tr > 0) {
+        real S = std::sqrt(tr + 1) * 2;
+        q.w = (real)0.25 * S; q.x = (a.m[2][1] - a.m[1][2]) / S; q.y = (a.m[0][2] - a.m[2][0]) / S; q.z = (a.m[1][0] - a.m[0][1]) / S;
+    } else if ((a.m[0][0] > a.m[1][1]) && (a.m[0][0] > a.m[2][2])) {
+        real S = std::sqrt(1 + a.m[0][0] - a.m[1][1] - a.m[2][2]) * 2;
+        q.w = (a.m[2][1] - a.m[1][2]) / S; q.x = (real)0.25 * S; q.y = (a.m[0][1] + a.m[1][0]) / S; q.z = (a.m[0][2] + a.m[2][0]) / S;
+    } else if (a.m[1][1] > a.m[2][2]) {
+        real S = std::sqrt(1 + a.m[1][1] - a.m[0][0] - a.m[2][2]) * 2;
+        q.w = (a.m[0][2] - a.m[2][0]) / S; q.x = (a.m[0][1] + a.m[1][0]) / S; q.y = (real)0.25 * S; q.z = (a.m[1][2] + a.m[2][1]) / S;
+    } else {
+        real S = std::sqrt(1 + a.m[2][2] - a.m[0][0] - a.m[1][1]) * 2;
+        q.w = (a.m[1][0] - a.m[0][1]) / S; q.x = (a.m[0][2] + a.m[2][0]) / S; q.y = (a.m[1][2] + a.m[2][1]) / S; q.z = (real)0.25 * S;
+    }
+    return q;
+}
+// cMathUtil::AxisAngleToQuaternion (MathUtil.cpp:450-461)
+static inline Q4 quat_axis_angle(const V3& axis, real th) {
+    real c = std::cos(th / 2), s = std::sin(th / 2);
+    return Q4(c, s * axis.x, s * axis.y, s * axis.z);
+}
+// cMathUtil::QuaternionToAxisAngle (MathUtil.cpp:463-481)
+static inline void quat_to_axis_angle(const Q4& q, V3& axis, real& theta) {
+    theta = 0; axis = V3(0, 0, 1);
+    Q4 q1 = q;
+    if (q1.w > 1) q1 = qnormalized(q1);
+    real st = std::sqrt(1 - q1.w * q1.w);
+    if (st > (real)0.000001) {
+        theta = 2 * std::acos(q1.w);
+        theta = normalize_angle(theta);
+        axis = V3(q1.x, q1.y, q1.z) / st;
+    }
+}
+// cMathUtil::QuatDiff (MathUtil.cpp:522-525): q1 * q0^-1
+static inline Q4 quat_diff(const Q4& q0, const Q4& q1) { return q1 * conj(q0); }
+// cMathUtil::QuatTheta (MathUtil.cpp:533-549)
+static inline real quat_theta(const Q4& dq) {
+    real theta = 0;
+    Q4 q1 = dq;
+    if (q1.w > 1) q1 = qnormalized(q1);
+    real st = std::sqrt(1 - q1.w * q1.w);
+    if (st > (real)0.0001) { theta = 2 * std::acos(q1.w); theta = normalize_angle(theta); }
+    return theta;
+}
+static inline real quat_diff_theta(const Q4& q0, const Q4& q1) { return quat_theta(quat_diff(q0, q1)); }
+// cMathUtil::CalcQuaternionVel / VelRel (MathUtil.cpp:493-510)
+static inline V3 quat_vel(const Q4& q0, const Q4& q1, real dt) {
+    V3 ax; real th; quat_to_axis_angle(quat_diff(q0, q1), ax, th); return (th / dt) * ax;
+}
+static inline V3 quat_vel_rel(const Q4& q0, const Q4& q1, real dt) {
+    V3 ax; real th; quat_to_axis_angle(conj(q0) * q1, ax, th); return (th / dt) * ax;
+}
+// cMathUtil::ExpMapToQuaternion (MathUtil.cpp:573-599), gThetaMin = 1e-6
+static inline Q4 exp_map_to_quat(const V3& e) {
+    real th = norm(e);
+    V3 axis(0, 0, 1); real theta = 0;
+    if (th > (real)0.000001) { axis = e / th; theta = normalize_angle(th); }
+    return quat_axis_angle(axis, theta);
+}
+// cMathUtil::QuaternionToExpMap (MathUtil.cpp:607-615)
+static inline V3 quat_to_exp_map(const Q4& q) { V3 ax; real th; quat_to_axis_angle(q, ax, th); return th * ax; }
+// cMathUtil::BuildQuaternionDiffMat * omega  (MathUtil.cpp:483-491) -> (w,x,y,z) rates
+static inline Q4 quat_diff_mul(const Q4& q, const V3& o) {
+    return Q4((real)-0.5 * q.x * o.x - (real)0.5 * q.y * o.y - (real)0.5 * q.z * o.z,
+              (real)0.5 * q.w * o.x - (real)0.5 * q.z * o.y + (real)0.5 * q.y * o.z,
+              (real)0.5 * q.z * o.x + (real)0.5 * q.w * o.y - (real)0.5 * q.x * o.z,
+              (real)-0.5 * q.y * o.x + (real)0.5 * q.x * o.y + (real)0.5 * q.w * o.z);
+}
+// cMathUtil::EulerToQuaternion via EulerToAxisAngle -> RotMat -> axis-angle; equal (up to sign)
+// to the quaternion of RotateMat(euler).
+static inline Q4 quat_euler(const V3& e) { return quat_from_rot(rot_euler(e)); }
+
+// cMathUtil::CheckNextInterval (MathUtil.cpp:850-857)
+static inline bool check_next_interval(double delta, double curr_val, double int_size) {
+    double pad = 0.001 * delta;
+    int curr_count = static_cast<int>(std::floor((curr_val + pad) / int_size));
+    int prev_count = static_cast<int>(std::floor((curr_val + pad - delta) / int_size));
+    return curr_count != prev_count;
+}
+
+// ---------------------------------------------------------------- spatial algebra (cSpAlg)
+// tSpVec = (omega; v);  tSpTrans = [E | r]
+struct SV { V3 o, v; SV() {} SV(const V3& a, const V3& b) : o(a), v(b) {} };
+static inline SV operator+(const SV& a, const SV& b) { return SV(a.o + b.o, a.v + b.v); }
+static inline SV operator*(real s, const SV& a) { return SV(s * a.o, s * a.v); }
+static inline real svdot(const SV& a, const SV& b) { return dot(a.o, b.o) + dot(a.v, b.v); }
+struct ST { M3 E; V3 r; ST() : E(M3::identity()) {} ST(const M3& e, const V3& p) : E(e), r(p) {} };
+
+// SpAlg.cpp:152-159
+static inline ST mat_to_trans(const Xf& m) { return ST(m.R, -(transpose(m.R) * m.t)); }
+// SpAlg.cpp:161-169
+static inline Xf trans_to_mat(const ST& X) { return Xf(X.E, -(X.E * X.r)); }
+// SpAlg.cpp:198-204
+static inline ST inv_trans(const ST& X) { return ST(transpose(X.E), -(X.E * X.r)); }
+// SpAlg.cpp:334-343
+static inline ST comp_trans(const ST& X0, const ST& X1) { return ST(X0.E * X1.E, X1.r + transpose(X1.E) * X0.r); }
+// SpAlg.cpp:230-242
+static inline SV apply_trans_m(const ST& X, const SV& s) { return SV(X.E * s.o, X.E * (s.v - cross(X.r, s.o))); }
+// SpAlg.cpp:244-256
+static inline SV apply_trans_f(const ST& X, const SV& s) { return SV(X.E * (s.o - cross(X.r, s.v)), X.E * s.v); }
+// SpAlg.cpp:282-294
+static inline SV apply_inv_trans_m(const ST& X, const SV& s) {
+    V3 eo = transpose(X.E) * s.o;
+    return SV(eo, transpose(X.E) * s.v + cross(X.r, eo));
+}
+// SpAlg.cpp:47-58
+static inline SV cross_m(const SV& a, const SV& m) { return SV(cross(a.o, m.o), cross(a.v, m.o) + cross(a.o, m.v)); }
+// SpAlg.cpp:72-83
+static inline SV cross_f(const SV& a, const SV& f) { return SV(cross(a.o, f.o) + cross(a.v, f.v), cross(a.o, f.v)); }
+
+struct SM { real m[6][6]; SM() { std::memset(m, 0, sizeof(m)); } };
+static inline SV operator*(const SM& A, const SV& s) {
+    real in[6] = { s.o.x, s.o.y, s.o.z, s.v.x, s.v.y, s.v.z }, out[6];
+    for (int i = 0; i < 6; ++i) { real a = 0; for (int k = 0; k < 6; ++k) a += A.m[i][k] * in[k]; out[i] = a; }
+    return SV(V3(out[0], out[1], out[2]), V3(out[3], out[4], out[5]));
+}
+static inline SM operator*(const SM& A, const SM& B) {
+    SM C;
+    for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) { real a = 0; for (int k = 0; k < 6; ++k) a += A.m[i][k] * B.m[k][j]; C.m[i][j] = a; }
+    return C;
+}
+static inline SM operator+(const SM& A, const SM& B) { SM C; for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) C.m[i][j] = A.m[i][j] + B.m[i][j]; return C; }
+// SpAlg.cpp:171-182
+static inline SM spatial_mat_m(const ST& X) {
+    SM m; M3 Er = X.E * cross_mat(X.r);
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) { m.m[i][j] = X.E.m[i][j]; m.m[3 + i][3 + j] = X.E.m[i][j]; m.m[3 + i][j] = -Er.m[i][j]; }
+    return m;
+}
+// SpAlg.cpp:184-195
+static inline SM spatial_mat_f(const ST& X) {
+    SM m; M3 Er = X.E * cross_mat(X.r);
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) { m.m[i][j] = X.E.m[i][j]; m.m[3 + i][3 + j] = X.E.m[i][j]; m.m[i][3 + j] = -Er.m[i][j]; }
+    return m;
+}
+
+}  // namespace orc

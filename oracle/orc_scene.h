@@ -1,0 +1,554 @@
+// TEST INFRASTRUCTURE ONLY -- CPU oracle (see orc_math.h header).
+//
+// orc_scene.h: the imitate scene -- controller, SPD torques, rigid-body step, reward,
+// observation, termination, reset.  DeepMimic-side functions are restated from the cited
+// reference lines.  The rigid-body step stands in for Bullet 2.88 (absent, un-vendored):
+// it is the "DM-physics v1" specification written down in DESIGN.md section 4, which follows
+// the published behaviour of btMultiBodyDynamicsWorld as recorded in SURVEY.md Appendix C
+// ([EXT-BULLET]); trajectory-level parity against real Bullet is UNPINNED.
+#pragma once
+#include "orc_rbd.h"
+
+namespace orc {
+
+struct SceneCfg {
+    int num_sim_substeps = 2;            // args/run_humanoid3d_walk_args.txt:4
+    double world_scale = 4.0;            // :5  (only shrinks Bullet's absolute tolerances)
+    V3 gravity = V3(0, (real)-9.8, 0);   // util/MathUtil.h:25
+    bool sync_char_root_pos = true, sync_char_root_rot = false;
+    bool enable_fall_end = true, enable_char_contact_fall = true, enable_root_rot_fail = false;
+    bool enable_rand_char_placement = true;
+    bool enable_phase_input = false, record_world_root_pos = false, record_world_root_rot = false;
+    double query_rate = 30.0;            // sim/CtController.cpp:8,165
+    // --- DM-physics v1 constants [EXT-BULLET, SURVEY App. C] ---
+    double friction = 0.9 * 0.9;         // link 0.9 (SimCharacter.cpp:26) x ground 0.9 (Ground.cpp:14-27)
+    double erp = 0.2;                    // btContactSolverInfo::m_erp2
+    int solver_iters = 10;               // btContactSolverInfo::m_numIterations
+    int max_contacts = 20;               // manifold reduction: deepest-first cap
+    double contact_report_dist = 0.001;  // sim/ContactManager.cpp:80 (0.001*scale in scaled units)
+    double breaking_factor = 0.02;       // gContactBreakingThreshold x angular-motion disc
+    double max_coord_vel = 100.0;        // btMultiBody::m_maxCoordinateVelocity (scaled units)
+};
+
+struct LinkState { Xf joint; V3 com; M3 Rb; V3 w; V3 vj; V3 vcom; };
+
+// World-frame link kinematics from joint-space (pose, vel): what the reference reads back from Bullet in
+// cSimCharacter::PostUpdate (SimCharacter.cpp:112-122,1219-1256) and cSimObj::GetPos/GetRotation.
+static inline void calc_links(const Skeleton& sk, const Vec& pose, const Vec& vel, std::vector<LinkState>& L) {
+    L.resize(sk.J);
+    for (int j = 0; j < sk.J; ++j) {
+        int par = sk.parent(j);
+        Xf cp = child_parent_trans(sk, pose, j);
+        L[j].joint = (par == -1) ? cp : L[par].joint * cp;
+        Xf bw = L[j].joint * body_joint_trans(sk, j);
+        L[j].com = bw.t; L[j].Rb = bw.R;
+        int off = sk.offset(j);
+        if (par == -1) { L[j].w = root_ang_vel(vel); L[j].vj = root_vel(vel); }
+        else {
+            V3 wl;
+            if (sk.type(j) == JT_SPHERICAL) wl = V3(vel[off], vel[off + 1], vel[off + 2]);
+            else if (sk.type(j) == JT_REVOLUTE) wl = V3(0, 0, vel[off]);
+            L[j].w = L[par].w + L[j].joint.R * wl;
+            L[j].vj = L[par].vj + cross(L[par].w, L[j].joint.t - L[par].joint.t);
+        }
+        L[j].vcom = L[j].vj + cross(L[j].w, L[j].com - L[j].joint.t);
+    }
+}
+
+struct LDLT {
+    int n = 0, m = 0; std::vector<int> idx; std::vector<real> L, D;
+    void factor(const std::vector<real>& A, int n_) {
+        n = n_; idx.clear();
+        for (int i = 0; i < n; ++i) if (A[(size_t)i * n + i] != 0) idx.push_back(i);
+        m = (int)idx.size(); L.assign((size_t)m * m, 0); D.assign(m, 0);
+        for (int i = 0; i < m; ++i) for (int j = 0; j <= i; ++j) {
+            real s = A[(size_t)idx[i] * n + idx[j]];
+            for (int k = 0; k < j; ++k) s -= L[(size_t)i * m + k] * L[(size_t)j * m + k] * D[k];
+            if (i == j) { D[i] = s; L[(size_t)i * m + i] = 1; } else L[(size_t)i * m + j] = s / D[j];
+        }
+    }
+    void solve(const Vec& b, Vec& x) const {
+        Vec y(m, 0);
+        for (int i = 0; i < m; ++i) { real s = b[idx[i]]; for (int k = 0; k < i; ++k) s -= L[(size_t)i * m + k] * y[k]; y[i] = s; }
+        for (int i = 0; i < m; ++i) y[i] /= D[i];
+        for (int i = m - 1; i >= 0; --i) { real s = y[i]; for (int k = i + 1; k < m; ++k) s -= L[(size_t)k * m + i] * y[k]; y[i] = s; }
+        x.assign(n, 0);
+        for (int i = 0; i < m; ++i) x[idx[i]] = y[i];
+    }
+};
+
+struct ContactPt { int link; V3 x; real dist; };
+struct Row { Vec J; Vec W; real b, lo, hi, lam; int normal_row; real mu; };
+
+enum Terminate { TERM_NULL = 0, TERM_FAIL = 1, TERM_SUCC = 2 };   // scenes/RLScene.h:18-24
+
+struct Scene {
+    Skeleton sk; Motion mo; SceneCfg cfg; KinChar kin;
+    RBDModel rbd_ctrl;   // SPD model: DeepMimic inertias, reference root cj
+    RBDModel rbd_sim;    // simulator model: Bullet inertias, exact root cj
+    Vec Kp, Kd;          // per pose slot (ImpPDController.cpp:99-120)
+    std::vector<int> fall_mask;
+    Vec joint_w;         // normalised DiffWeight (SceneImitate.cpp:236-248)
+    std::vector<int> act_off, act_size;  // cCtController::BuildCtrlParamOffset (CtController.cpp:183-195)
+    int A = 0, S = 0;
+
+    // dynamic state
+    Vec pose, vel;       // sim character (joint space, reference pose/vel layout)
+    Vec tar_pose;        // PD targets (root slots unused)
+    Vec tau;             // last SPD torque (pose layout)
+    double ctrl_time = 0, init_time_offset = 0;   // cDeepMimicCharController::mTime, cCtController::mInitTimeOffset
+    bool need_new_action = true;
+    double timer_time = 0, timer_max = std::numeric_limits<double>::infinity();
+    std::vector<int> in_contact;         // per link: ground contact within contact_report_dist
+    std::vector<LinkState> links;
+    // debug taps for component-level parity tests
+    std::vector<ContactPt> dbg_contacts; int dbg_num_rows = 0; Vec dbg_vstar;
+
+    void init(const double* jm, const double* bd, int J, const double* pd /*J x 2*/, const double* frames, int F, bool loop,
+              const int* fall, const SceneCfg& c) {
+        cfg = c;
+        sk.init(jm, bd, J);
+        mo.load(sk, frames, F, sk.P, loop);
+        kin.sk = &sk; kin.mo = &mo; kin.pose.assign(sk.P, 0); kin.vel.assign(sk.P, 0);
+        RBDOpts o0; o0.inertia_model = 0; o0.exact_root_cj = false; o0.world_scale = cfg.world_scale;
+        RBDOpts o1; o1.inertia_model = 1; o1.exact_root_cj = true; o1.world_scale = cfg.world_scale;
+        rbd_ctrl.init(&sk, o0, cfg.gravity); rbd_sim.init(&sk, o1, cfg.gravity);
+        Kp.assign(sk.P, 0); Kd.assign(sk.P, 0);
+        for (int j = 1; j < J; ++j)   // cExpPDController::Init skips the root (ExpPDController.cpp:22-32)
+            for (int k = 0; k < sk.size(j); ++k) { Kp[sk.offset(j) + k] = (real)pd[j * 2]; Kd[sk.offset(j) + k] = (real)pd[j * 2 + 1]; }
+        fall_mask.assign(fall, fall + J);
+        joint_w.assign(J, 0);
+        real sum = 0; for (int j = 0; j < J; ++j) { joint_w[j] = (real)sk.jd(j, JD_DIFF_W); sum += std::fabs(joint_w[j]); }
+        for (int j = 0; j < J; ++j) joint_w[j] /= sum;
+        act_off.assign(J, 0); act_size.assign(J, 0);
+        int off = 0;
+        for (int j = 0; j < J; ++j) {
+            int sz = 0;
+            if (j != 0) sz = (sk.type(j) == JT_SPHERICAL) ? 3 : sk.size(j);   // CtCtrlUtil.cpp:10-35
+            act_off[j] = off; act_size[j] = sz; off += sz;
+        }
+        A = off;
+        S = (cfg.enable_phase_input ? 1 : 0) + (J * 9 + 1) + J * 6;   // CtController.cpp:41-46,300-314
+        pose.assign(sk.P, 0); vel.assign(sk.P, 0); tau.assign(sk.P, 0);
+        tar_pose.assign(sk.P, 0);
+        for (int j = 1; j < J; ++j) if (sk.type(j) == JT_SPHERICAL) tar_pose[sk.offset(j)] = 1;  // PDController.cpp:425-443
+        in_contact.assign(J, 0);
+        reset(0.0, std::numeric_limits<double>::infinity());
+    }
+
+    // ------------------------------------------------------------------ reset
+    // cSceneSimChar::ResetScene (SceneSimChar.cpp:628-644) + cSceneImitate::ResetCharacters (SceneImitate.cpp:320-368)
+    void reset(double kin_time, double max_time) {
+        timer_time = 0; timer_max = max_time;                       // cTimer::Reset (Timer.cpp:55-73)
+        // ResetKinChar: origin rot/pos reset, time := rand_time, Pose(t)
+        kin.origin_rot = Q4(); kin.origin = V3(); kin.time = kin_time; kin.do_pose();
+        // SyncCharacters: sim.SetPose/SetVel(kin); ctrl.SetInitTime(kin_time)
+        set_sim_state(kin.pose, kin.vel);
+        ctrl_time = kin_time; init_time_offset = -kin_time;         // CtController.cpp:144-150
+        need_new_action = true;                                      // DeepMimicCharController.cpp:220-229
+        std::fill(tau.begin(), tau.end(), (real)0);
+        std::fill(in_contact.begin(), in_contact.end(), 0);          // cWorld::Reset -> contact manager reset
+        // InitCharacterPos -> SetCharRandPlacement on a plane: root x,z := 0, y kept, rot kept (Ground.cpp:154-159)
+        if (cfg.enable_rand_char_placement) { pose[0] = 0; pose[2] = 0; }
+        // ResolveCharGroundIntersect (SceneSimChar.cpp:542-583): lift so that min link-AABB >= ground + 1 mm
+        calc_links(sk, pose, vel, links);
+        real min_violation = 0;
+        for (int j = 0; j < sk.J; ++j) if (sk.valid_body(j)) min_violation = std::min(min_violation, link_aabb_min_y(j) - (real)0.001);
+        if (min_violation < 0) pose[1] += -min_violation;
+        // SyncKinCharRoot (SceneImitate.cpp:401-418)
+        if (cfg.sync_char_root_rot) {
+            real dh = calc_heading(root_rot(pose)) - calc_heading(root_rot(kin.pose));
+            kin.rotate_root(quat_axis_angle(V3(0, 1, 0), dh));
+        }
+        kin.set_root_pos_(root_pos(pose));
+        calc_links(sk, pose, vel, links);
+    }
+    // what cSimCharacter::SetPose/SetVel followed by BuildPose/BuildVel leave in mPose/mVel
+    void set_sim_state(const Vec& p, const Vec& v) {
+        pose = p; vel = v;
+        post_process_pose(sk, pose);
+        for (int j = 1; j < sk.J; ++j) if (sk.type(j) == JT_SPHERICAL) {
+            set_joint_quat(pose, sk.offset(j), standardize(joint_quat(pose, sk.offset(j))));   // SimBodyJoint.cpp:374-383
+            vel[sk.offset(j) + 3] = 0;
+        }
+        vel[6] = 0;
+        calc_links(sk, pose, vel, links);
+    }
+    // [EXT-BULLET] btCollisionShape::getAabb of the link collider, lower y bound (cSimObj::CalcAABB, SimObj.cpp:224-236)
+    real link_aabb_min_y(int j) const {
+        const LinkState& l = links[j];
+        real p0 = (real)sk.bdv(j, BD_P0), p1 = (real)sk.bdv(j, BD_P1), p2 = (real)sk.bdv(j, BD_P2);
+        V3 he;
+        switch (sk.shape(j)) {
+            case SH_SPHERE: return l.com.y - (real)0.5 * p0;
+            case SH_BOX: he = V3((real)0.5 * p0, (real)0.5 * p1, (real)0.5 * p2); break;
+            case SH_CAPSULE: he = V3((real)0.5 * p0, (real)0.5 * p0 + (real)0.5 * p1, (real)0.5 * p0); break;
+            default: assert(false);
+        }
+        return l.com.y - (std::fabs(l.Rb.m[1][0]) * he.x + std::fabs(l.Rb.m[1][1]) * he.y + std::fabs(l.Rb.m[1][2]) * he.z);
+    }
+
+    // ------------------------------------------------------------------ action
+    // cCtPDController::ApplyAction -> SetPDTargets -> ConvertActionToTargetPose (CtPDController.cpp:97-166)
+    void set_action(const double* a) {
+        const real max_len = 2 * kPi;   // cCtCtrlUtil::gMaxPDExpVal
+        for (int j = 1; j < sk.J; ++j) {
+            int off = sk.offset(j), ao = act_off[j];
+            if (sk.type(j) == JT_SPHERICAL) {
+                V3 e((real)a[ao], (real)a[ao + 1], (real)a[ao + 2]);
+                real len = norm(e);
+                if (len > max_len) e = e * (max_len / len);
+                Q4 q = exp_map_to_quat(e);
+                real n2 = q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z;   // cPDController::PostProcessTargetPose
+                if (n2 == 0) q = Q4(1, 0, 0, 0); else q = qnormalized(q);
+                set_joint_quat(tar_pose, off, q);
+            } else {
+                for (int k = 0; k < sk.size(j); ++k) tar_pose[off + k] = (real)a[ao + k];
+            }
+        }
+    }
+
+    // pose as the controller / reward read it: revolute angles normalised (SimBodyJoint.cpp:350-352)
+    Vec reported_pose() const {
+        Vec p = pose;
+        for (int j = 1; j < sk.J; ++j) if (sk.type(j) == JT_REVOLUTE) p[sk.offset(j)] = normalize_angle(p[sk.offset(j)]);
+        return p;
+    }
+
+    // ------------------------------------------------------------------ SPD
+    // cImpPDController::CalcControlForces (ImpPDController.cpp:136-195) + joint torque clamp (SimBodyJoint.cpp:299-307,636-695)
+    void calc_spd_tau(double dt_, Vec& out_tau) {
+        const int P = sk.P; real t = (real)dt_;
+        Vec rp = reported_pose();
+        rbd_ctrl.update(rp, vel);
+        std::vector<real> M = rbd_ctrl.H;
+        for (int i = 0; i < P; ++i) M[(size_t)i * P + i] += t * Kd[i];
+        Vec inc; vel_to_pose_diff(sk, rp, vel, inc);
+        for (int i = 0; i < P; ++i) inc[i] = rp[i] + t * inc[i];
+        post_process_pose(sk, inc);
+        Vec pose_err; calc_vel(sk, inc, tar_pose, 1, pose_err);
+        Vec acc(P, 0);
+        for (int i = 0; i < P; ++i) acc[i] = Kp[i] * pose_err[i] + Kd[i] * (0 - vel[i]) - rbd_ctrl.C[i];
+        Vec sol; ldlt_solve(M, P, acc, sol);
+        out_tau.assign(P, 0);
+        for (int i = 0; i < P; ++i) out_tau[i] = Kp[i] * pose_err[i] + Kd[i] * ((0 - vel[i]) - t * sol[i]);
+        // cSimCharacter::ApplyControlForces skips the root; joint.ApplyTau clamps the torque *norm*
+        for (int i = 0; i < 7; ++i) out_tau[i] = 0;
+        for (int j = 1; j < sk.J; ++j) {
+            int off = sk.offset(j); real lim = (real)sk.jd(j, JD_TORQUE_LIM);
+            if (sk.type(j) == JT_SPHERICAL) {
+                real mag = std::sqrt(out_tau[off] * out_tau[off] + out_tau[off + 1] * out_tau[off + 1] + out_tau[off + 2] * out_tau[off + 2]);
+                if (mag > lim) for (int k = 0; k < 3; ++k) out_tau[off + k] *= lim / mag;
+                out_tau[off + 3] = 0;
+            } else if (sk.type(j) == JT_REVOLUTE) {
+                real mag = std::fabs(out_tau[off]);
+                if (mag > lim) out_tau[off] *= lim / mag;
+            }
+        }
+    }
+
+    // ------------------------------------------------------------------ rigid-body substep (DM-physics v1)
+    void contact_candidates(std::vector<ContactPt>& out) const {
+        out.clear();
+        for (int j = 0; j < sk.J; ++j) {
+            if (!sk.valid_body(j)) continue;
+            const LinkState& l = links[j];
+            real p0 = (real)sk.bdv(j, BD_P0), p1 = (real)sk.bdv(j, BD_P1), p2 = (real)sk.bdv(j, BD_P2);
+            switch (sk.shape(j)) {
+                case SH_SPHERE: { real r = (real)0.5 * p0; ContactPt c; c.link = j; c.x = l.com - V3(0, r, 0); c.dist = c.x.y; out.push_back(c); break; }
+                case SH_CAPSULE: {
+                    real r = (real)0.5 * p0, hh = (real)0.5 * p1;
+                    for (int s = 0; s < 2; ++s) {
+                        V3 e = l.com + l.Rb * V3(0, s ? -hh : hh, 0);
+                        ContactPt c; c.link = j; c.x = e - V3(0, r, 0); c.dist = c.x.y; out.push_back(c);
+                    }
+                    break;
+                }
+                case SH_BOX: {
+                    for (int s = 0; s < 8; ++s) {
+                        V3 loc((s & 1) ? (real)-0.5 * p0 : (real)0.5 * p0, (s & 2) ? (real)-0.5 * p1 : (real)0.5 * p1, (s & 4) ? (real)-0.5 * p2 : (real)0.5 * p2);
+                        ContactPt c; c.link = j; c.x = l.com + l.Rb * loc; c.dist = c.x.y; out.push_back(c);
+                    }
+                    break;
+                }
+                default: assert(false);
+            }
+        }
+    }
+    // [EXT-BULLET] contact breaking threshold = 0.02 x getAngularMotionDisc() of the convex shape
+    real breaking_threshold(int j) const {
+        real p0 = (real)sk.bdv(j, BD_P0), p1 = (real)sk.bdv(j, BD_P1), p2 = (real)sk.bdv(j, BD_P2);
+        real rad = 0;
+        switch (sk.shape(j)) {
+            case SH_SPHERE: rad = (real)0.5 * p0; break;
+            case SH_CAPSULE: rad = (real)0.5 * p0 + (real)0.5 * p1; break;
+            case SH_BOX: rad = (real)0.5 * std::sqrt(p0 * p0 + p1 * p1 + p2 * p2); break;
+            default: assert(false);
+        }
+        return (real)cfg.breaking_factor * rad;
+    }
+    // generalized-velocity Jacobian row (pose layout) of d . (velocity of world point x rigidly attached to `link`)
+    void point_jacobian(int link, const V3& x, const V3& d, Vec& Jr) const {
+        Jr.assign(sk.P, 0);
+        Jr[0] = d.x; Jr[1] = d.y; Jr[2] = d.z;
+        V3 r0 = x - links[0].joint.t;
+        V3 rxd = cross(r0, d);             // (e_k x r).d = e_k . (r x d)
+        Jr[3] = rxd.x; Jr[4] = rxd.y; Jr[5] = rxd.z;
+        for (int j = link; j > 0; j = sk.parent(j)) {
+            int off = sk.offset(j);
+            V3 m = cross(x - links[j].joint.t, d);
+            const M3& R = links[j].joint.R;
+            if (sk.type(j) == JT_SPHERICAL) for (int k = 0; k < 3; ++k) Jr[off + k] = R.m[0][k] * m.x + R.m[1][k] * m.y + R.m[2][k] * m.z;
+            else if (sk.type(j) == JT_REVOLUTE) Jr[off] = R.m[0][2] * m.x + R.m[1][2] * m.y + R.m[2][2] * m.z;
+        }
+    }
+    void clamp_coord_vel(Vec& v) const {
+        real lin = (real)(cfg.max_coord_vel / cfg.world_scale), ang = (real)cfg.max_coord_vel;
+        for (int i = 0; i < sk.P; ++i) { real m = (i < 3) ? lin : ang; v[i] = std::max(-m, std::min(m, v[i])); }
+    }
+    void substep(double h_) {
+        const int P = sk.P; const real h = (real)h_;
+        calc_links(sk, pose, vel, links);
+        rbd_sim.update(pose, vel);
+        LDLT fac; fac.factor(rbd_sim.H, P);
+        Vec rhs(P, 0), acc;
+        for (int i = 0; i < P; ++i) rhs[i] = tau[i] - rbd_sim.C[i];
+        fac.solve(rhs, acc);
+        Vec vstar(P, 0);
+        for (int i = 0; i < P; ++i) vstar[i] = vel[i] + h * acc[i];
+        clamp_coord_vel(vstar);
+        dbg_vstar = vstar;
+
+        // collision detection at the start-of-substep pose
+        std::vector<ContactPt> cand; contact_candidates(cand);
+        std::fill(in_contact.begin(), in_contact.end(), 0);
+        std::vector<int> act;
+        for (size_t i = 0; i < cand.size(); ++i) {
+            if (cand[i].dist <= (real)cfg.contact_report_dist) in_contact[cand[i].link] = 1;
+            if (cand[i].dist < breaking_threshold(cand[i].link)) act.push_back((int)i);
+        }
+        // manifold reduction: keep the max_contacts deepest (ties -> lower candidate index)
+        std::stable_sort(act.begin(), act.end(), [&](int a, int b) { return cand[a].dist < cand[b].dist; });
+        if ((int)act.size() > cfg.max_contacts) act.resize(cfg.max_contacts);
+        std::sort(act.begin(), act.end());
+        dbg_contacts.clear(); for (size_t i = 0; i < act.size(); ++i) dbg_contacts.push_back(cand[act[i]]);
+
+        std::vector<Row> rows;
+        const real big = (real)1e30;
+        // joint-limit rows (btMultiBodyJointLimitConstraint; revolute only, SimCharacter.cpp:948-973): nearer bound
+        for (int j = 1; j < sk.J; ++j) {
+            if (sk.type(j) != JT_REVOLUTE) continue;
+            real lo = (real)sk.jd(j, JD_LL0), hi = (real)sk.jd(j, JD_LH0);
+            if (lo > hi) continue;
+            int off = sk.offset(j); real th = pose[off];
+            real pen_lo = th - lo, pen_hi = hi - th;
+            Row r; r.J.assign(P, 0); r.normal_row = -1; r.mu = 0; r.lo = 0; r.hi = big; r.lam = 0;
+            real pen;
+            if (pen_lo <= pen_hi) { r.J[off] = 1; pen = pen_lo; } else { r.J[off] = -1; pen = pen_hi; }
+            r.b = (pen > 0) ? -pen / h : (real)-cfg.erp * pen / h;
+            rows.push_back(r);
+        }
+        int n_lim = (int)rows.size(), nc = (int)act.size();
+        const V3 n(0, 1, 0), t1(-1, 0, 0), t2(0, 0, 1);   // btPlaneSpace1((0,1,0))
+        for (int c = 0; c < nc; ++c) {
+            const ContactPt& cp = cand[act[c]];
+            Row r; point_jacobian(cp.link, cp.x, n, r.J); r.normal_row = -1; r.mu = 0; r.lo = 0; r.hi = big; r.lam = 0;
+            r.b = (cp.dist > 0) ? -cp.dist / h : (real)-cfg.erp * cp.dist / h;
+            rows.push_back(r);
+        }
+        for (int c = 0; c < nc; ++c) for (int d = 0; d < 2; ++d) {
+            const ContactPt& cp = cand[act[c]];
+            Row r; point_jacobian(cp.link, cp.x, d ? t2 : t1, r.J); r.normal_row = n_lim + c; r.mu = (real)cfg.friction; r.lo = r.hi = 0; r.lam = 0; r.b = 0;
+            rows.push_back(r);
+        }
+        const int R = (int)rows.size(); dbg_num_rows = R;
+        std::vector<real> Amat((size_t)R * R, 0); Vec cvec(R, 0);
+        for (int r = 0; r < R; ++r) fac.solve(rows[r].J, rows[r].W);
+        for (int r = 0; r < R; ++r) {
+            for (int s = 0; s < R; ++s) { real a = 0; for (int i = 0; i < P; ++i) a += rows[r].J[i] * rows[s].W[i]; Amat[(size_t)r * R + s] = a; }
+            real c = 0; for (int i = 0; i < P; ++i) c += rows[r].J[i] * vstar[i]; cvec[r] = c;
+        }
+        // projected Gauss-Seidel: per iteration limits, normals, frictions
+        for (int it = 0; it < cfg.solver_iters; ++it) {
+            for (int r = 0; r < R; ++r) {
+                Row& row = rows[r];
+                real u = cvec[r]; for (int s = 0; s < R; ++s) u += Amat[(size_t)r * R + s] * rows[s].lam;
+                real d = (row.b - u) / Amat[(size_t)r * R + r];
+                real lo = row.lo, hi = row.hi;
+                if (row.normal_row >= 0) { hi = row.mu * rows[row.normal_row].lam; lo = -hi; }
+                real nl = row.lam + d;
+                if (nl < lo) nl = lo; else if (nl > hi) nl = hi;
+                row.lam = nl;
+            }
+        }
+        Vec vnew = vstar;
+        for (int r = 0; r < R; ++r) for (int i = 0; i < P; ++i) vnew[i] += rows[r].W[i] * rows[r].lam;
+        clamp_coord_vel(vnew);
+        vel = vnew;
+        integrate(h);
+    }
+    static Q4 quat_exp(const V3& rv) {     // exact exponential map of a rotation vector
+        real th = norm(rv), half = (real)0.5 * th;
+        real s = (th < (real)1e-6) ? ((real)0.5 - th * th / 48) : std::sin(half) / th;
+        return Q4(std::cos(half), s * rv.x, s * rv.y, s * rv.z);
+    }
+    // [EXT-BULLET] btMultiBody::stepPositionsMultiDof: semi-implicit Euler, exponential map on rotations
+    void integrate(real h) {
+        for (int k = 0; k < 3; ++k) pose[k] += h * vel[k];
+        set_root_rot(pose, qnormalized(quat_exp(h * root_ang_vel(vel)) * root_rot(pose)));   // world-frame omega
+        for (int j = 1; j < sk.J; ++j) {
+            int off = sk.offset(j);
+            if (sk.type(j) == JT_SPHERICAL) {
+                Q4 q = qnormalized(joint_quat(pose, off) * quat_exp(h * V3(vel[off], vel[off + 1], vel[off + 2])));   // child-frame omega
+                set_joint_quat(pose, off, standardize(q));
+            } else if (sk.type(j) == JT_REVOLUTE) pose[off] += h * vel[off];
+        }
+    }
+
+    // ------------------------------------------------------------------ one scene update
+    void update(double dt) {
+        timer_time += dt;                                            // cScene::Update
+        // 4a UpdateKinChar (SceneImitate.cpp:306-318)
+        double prev_phase = kin.phase();
+        kin.update(dt);
+        double curr_phase = kin.phase();
+        if (curr_phase < prev_phase) sync_kin_new_cycle();
+        // 4b sim_char->Update: controller clock, latch, SPD
+        ctrl_time += dt;                                             // DeepMimicCharController.cpp:71-78
+        if (need_new_action) need_new_action = false;                // HandleNewAction
+        calc_spd_tau(dt, tau);
+        // 5 cWorld::Update: stepSimulation(dt, n, dt/n) (World.cpp:93-104)
+        double h = dt / cfg.num_sim_substeps;
+        for (int s = 0; s < cfg.num_sim_substeps; ++s) substep(h);
+        // 7 PostUpdate
+        calc_links(sk, pose, vel, links);
+        need_new_action = check_next_interval(dt, ctrl_time + init_time_offset, 1.0 / cfg.query_rate);   // CtController.cpp:221-227
+    }
+    // cSceneImitate::SyncKinCharNewCycle (SceneImitate.cpp:420-444)
+    void sync_kin_new_cycle() {
+        if (cfg.sync_char_root_rot) {
+            real dh = calc_heading(root_rot(pose)) - calc_heading(root_rot(kin.pose));
+            kin.rotate_root(quat_axis_angle(V3(0, 1, 0), dh));
+        }
+        if (cfg.sync_char_root_pos) {
+            V3 sp = root_pos(pose), kp = root_pos(kin.pose);
+            kp.x = sp.x; kp.z = sp.z;
+            real dh = kp.y - kin.origin.y;
+            kp.y = 0 + dh;   // ground height of the plane
+            kin.set_root_pos_(kp);
+        }
+    }
+
+    // ------------------------------------------------------------------ termination
+    bool has_fallen() const {
+        bool f = false;
+        if (cfg.enable_char_contact_fall) for (int j = 0; j < sk.J; ++j) if (fall_mask[j] && in_contact[j]) f = true;
+        if (cfg.enable_root_rot_fail) f |= quat_diff_theta(root_rot(pose), root_rot(kin.pose)) > (real)0.5 * kPi;   // SceneImitate.cpp:484-492
+        return f;
+    }
+    int check_terminate() const {
+        bool fail = cfg.enable_fall_end && has_fallen();
+        if (!fail && mo.is_over(kin.time)) fail = true;              // SceneImitate.cpp:193-205
+        return fail ? TERM_FAIL : TERM_NULL;
+    }
+    bool is_episode_end() const { return timer_time >= timer_max || check_terminate() != TERM_NULL; }
+    bool check_valid_episode() const {                               // SimCharacter.cpp:571-586
+        for (int j = 0; j < sk.J; ++j) {
+            const LinkState& l = links[j];
+            real m = std::max(std::max(std::fabs(l.vcom.x), std::fabs(l.vcom.y)), std::fabs(l.vcom.z));
+            m = std::max(m, std::max(std::max(std::fabs(l.w.x), std::fabs(l.w.y)), std::fabs(l.w.z)));
+            if (m > 100) return false;
+        }
+        return true;
+    }
+
+    // ------------------------------------------------------------------ reward (SceneImitate.cpp:7-127,163-175)
+    double calc_reward(double* terms /*5 errors, optional*/ = nullptr) const {
+        if (has_fallen()) return 0;
+        const int J = sk.J;
+        const real pose_w = 0.5, vel_w = 0.05, end_eff_w = 0.15, root_w = 0.2, com_w = 0.1;
+        const real total_w = pose_w + vel_w + end_eff_w + root_w + com_w;
+        const real pose_scale = (real)2.0 / 15 * J, vel_scale = (real)0.1 / 15 * J, end_eff_scale = 10, root_scale = 5, com_scale = 10;
+        Vec pose0 = reported_pose(); const Vec& vel0 = vel; const Vec& pose1 = kin.pose; const Vec& vel1 = kin.vel;
+        Xf origin0 = origin_trans(pose0), origin1 = origin_trans(pose1);
+        // sim COM velocity: mass-weighted link velocities (SimCharacter.cpp:418-436)
+        V3 com_vel0; real tm = 0;
+        for (int j = 0; j < J; ++j) if (sk.valid_body(j)) { com_vel0 += (real)sk.mass(j) * links[j].vcom; tm += (real)sk.mass(j); }
+        com_vel0 = com_vel0 / tm;
+        V3 com1, com_vel1; calc_com(sk, pose1, vel1, com1, com_vel1);
+        V3 root_pos0 = root_pos(pose0), root_pos1 = root_pos(pose1);
+        Q4 root_rot0 = root_rot(pose0), root_rot1 = root_rot(pose1);
+        real pose_err = 0, vel_err = 0, end_eff_err = 0;
+        real th = quat_diff_theta(root_rot0, root_rot1);
+        pose_err += joint_w[0] * th * th;
+        vel_err += joint_w[0] * norm2(root_ang_vel(vel1) - root_ang_vel(vel0));
+        for (int j = 1; j < J; ++j) {
+            real w = joint_w[j]; int off = sk.offset(j), sz = sk.size(j);
+            real pe = 0, ve = 0;
+            if (sk.type(j) == JT_SPHERICAL) { real t = quat_theta(quat_diff(joint_quat(pose0, off), joint_quat(pose1, off))); pe = t * t; }
+            else for (int k = 0; k < sz; ++k) { real d = pose1[off + k] - pose0[off + k]; pe += d * d; }
+            for (int k = 0; k < sz; ++k) { real d = vel1[off + k] - vel0[off + k]; ve += d * d; }
+            pose_err += w * pe; vel_err += w * ve;
+            if (sk.is_end_eff(j)) {
+                V3 p0 = links[j].joint.t;                       // cSimCharacter::CalcJointPos (SimCharacter.cpp:308-331)
+                V3 p1 = joint_world_pos(sk, pose1, j);
+                real gh0 = 0, gh1 = kin.origin.y;
+                V3 rel0 = p0 - root_pos0, rel1 = p1 - root_pos1;
+                rel0.y = p0.y - gh0; rel1.y = p1.y - gh1;
+                rel0 = origin0.R * rel0; rel1 = origin1.R * rel1;  // w = 0: rotation only
+                end_eff_err += norm2(rel1 - rel0);
+            }
+        }
+        V3 rp0 = root_pos0, rp1 = root_pos1;
+        rp0.y -= 0; rp1.y -= kin.origin.y;
+        real root_pos_err = norm2(rp0 - rp1);
+        real root_rot_err = th * th;
+        real root_vel_err = norm2(root_vel(vel1) - root_vel(vel0));
+        real root_ang_vel_err = norm2(root_ang_vel(vel1) - root_ang_vel(vel0));
+        real root_err = root_pos_err + (real)0.1 * root_rot_err + (real)0.01 * root_vel_err + (real)0.001 * root_ang_vel_err;
+        real com_err = (real)0.1 * norm2(com_vel1 - com_vel0);
+        if (terms) { terms[0] = pose_err; terms[1] = vel_err; terms[2] = end_eff_err; terms[3] = root_err; terms[4] = com_err; }
+        real r = pose_w / total_w * std::exp(-pose_scale * pose_err) + vel_w / total_w * std::exp(-vel_scale * vel_err)
+               + end_eff_w / total_w * std::exp(-end_eff_scale * end_eff_err) + root_w / total_w * std::exp(-root_scale * root_err)
+               + com_w / total_w * std::exp(-com_scale * com_err);
+        return r;
+    }
+
+    // ------------------------------------------------------------------ observation (CtController.cpp:281-478)
+    double ctrl_phase() const {                                      // CtController.cpp:152-159
+        double ph = std::fmod(ctrl_time / mo.duration(), 1.0);
+        return (ph < 0) ? (1 + ph) : ph;
+    }
+    void record_state(double* out) const {
+        const int J = sk.J;
+        int idx = 0;
+        if (cfg.enable_phase_input) out[idx++] = ctrl_phase();
+        Vec rp = reported_pose();
+        Xf ot = origin_trans(rp);
+        Q4 oq = quat_from_rot(ot.R);
+        V3 rpos = root_pos(rp);
+        real ground_h = 0;
+        V3 rrel = rpos; rrel.y -= ground_h; rrel = xf_point(ot, rrel);
+        out[idx++] = rrel.y;
+        for (int i = 0; i < J; ++i) {
+            V3 p = links[i].com; p.y -= ground_h;
+            if (!cfg.record_world_root_pos || i != 0) { p = xf_point(ot, p); p = p - rrel; }
+            out[idx] = p.x; out[idx + 1] = p.y; out[idx + 2] = p.z;
+            Q4 q = quat_from_rot(links[i].Rb);
+            if (!cfg.record_world_root_rot || i != 0) q = oq * q;
+            V3 nrm = qrot(q, V3(0, 1, 0)), tan = qrot(q, V3(1, 0, 0));
+            out[idx + 3] = nrm.x; out[idx + 4] = nrm.y; out[idx + 5] = nrm.z;
+            out[idx + 6] = tan.x; out[idx + 7] = tan.y; out[idx + 8] = tan.z;
+            idx += 9;
+        }
+        for (int i = 0; i < J; ++i) {
+            V3 v = links[i].vcom, w = links[i].w;
+            if (!cfg.record_world_root_rot || i != 0) { v = ot.R * v; w = ot.R * w; }
+            out[idx] = v.x; out[idx + 1] = v.y; out[idx + 2] = v.z; out[idx + 3] = w.x; out[idx + 4] = w.y; out[idx + 5] = w.z;
+            idx += 6;
+        }
+        assert(idx == S);
+    }
+};
+
+}  // namespace orc

@@ -1,0 +1,224 @@
+"""ctypes binding to the CPU oracle (oracle/libdm_oracle*.so).  TEST INFRASTRUCTURE ONLY."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+
+CFG_KEYS = ["num_sim_substeps", "world_scale", "grav_x", "grav_y", "grav_z", "sync_root_pos", "sync_root_rot",
+            "enable_fall_end", "enable_contact_fall", "enable_root_rot_fail", "enable_rand_placement",
+            "enable_phase_input", "record_world_root_pos", "record_world_root_rot", "query_rate",
+            "friction", "erp", "solver_iters", "max_contacts"]
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int)
+
+
+def _d(a):
+    return a.ctypes.data_as(_dp)
+
+
+def build(target="all"):
+    subprocess.check_call(["make", "-s", "-C", ORACLE_DIR, target])
+
+
+def load_lib(variant=""):
+    name = {"": "libdm_oracle.so", "f32": "libdm_oracle_f32.so", "native": "libdm_oracle_native.so"}[variant]
+    path = os.path.join(ORACLE_DIR, name)
+    if not os.path.exists(path):
+        build("native" if variant == "native" else "all")
+    lib = C.CDLL(path)
+    lib.orc_create.restype = C.c_void_p
+    for f in ("orc_motion_duration", "orc_calc_reward", "orc_calc_reward_terms", "orc_time", "orc_kin_time",
+              "orc_phase", "orc_rollout"):
+        getattr(lib, f).restype = C.c_double
+    return lib
+
+
+class Oracle:
+    """One imitate scene on the CPU oracle."""
+
+    def __init__(self, tables, variant="", **cfg_overrides):
+        self.lib = lib = load_lib(variant)
+        self.t = tables
+        n = lib.orc_cfg_count()
+        assert n == len(CFG_KEYS)
+        cfg = np.zeros(n)
+        lib.orc_cfg_default(_d(cfg))
+        c = tables.cfg
+        vals = dict(num_sim_substeps=c.num_sim_substeps, world_scale=c.world_scale,
+                    grav_x=c.gravity[0], grav_y=c.gravity[1], grav_z=c.gravity[2],
+                    sync_root_pos=c.sync_char_root_pos, sync_root_rot=c.sync_char_root_rot,
+                    enable_fall_end=c.enable_fall_end, enable_contact_fall=c.enable_char_contact_fall,
+                    enable_root_rot_fail=c.enable_root_rot_fail, enable_rand_placement=c.enable_rand_char_placement,
+                    enable_phase_input=tables.enable_phase_input, record_world_root_pos=tables.record_world_root_pos,
+                    record_world_root_rot=tables.record_world_root_rot, query_rate=tables.query_rate)
+        vals.update(cfg_overrides)
+        for k, v in vals.items():
+            cfg[CFG_KEYS.index(k)] = float(v)
+        self.cfg = cfg
+        jm = np.ascontiguousarray(tables.joint_mat, dtype=np.float64)
+        bd = np.ascontiguousarray(tables.body_defs, dtype=np.float64)
+        pd = np.ascontiguousarray(tables.pd_params, dtype=np.float64)
+        fr = np.ascontiguousarray(tables.frames, dtype=np.float64)
+        fall = np.ascontiguousarray(tables.fall_mask(), dtype=np.int32)
+        self.h = C.c_void_p(lib.orc_create(_d(jm), _d(bd), jm.shape[0], _d(pd), _d(fr), fr.shape[0], int(tables.loop),
+                                           fall.ctypes.data_as(_ip), _d(cfg)))
+        dims = np.zeros(5, dtype=np.int32)
+        lib.orc_dims(self.h, dims.ctypes.data_as(_ip))
+        self.J, self.P, self.A, self.S, self.F = [int(x) for x in dims]
+        self.duration = lib.orc_motion_duration(self.h)
+
+    def __del__(self):
+        try:
+            self.lib.orc_destroy(self.h)
+        except Exception:
+            pass
+
+    def reset(self, kin_time=0.0, max_time=np.inf):
+        self.lib.orc_reset(self.h, C.c_double(kin_time), C.c_double(max_time))
+
+    def set_action(self, a):
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        assert a.size == self.A
+        self.lib.orc_set_action(self.h, _d(a))
+
+    def update(self, dt):
+        self.lib.orc_update(self.h, C.c_double(dt))
+
+    def need_new_action(self):
+        return bool(self.lib.orc_need_new_action(self.h))
+
+    def record_state(self):
+        out = np.zeros(self.S)
+        self.lib.orc_record_state(self.h, _d(out))
+        return out
+
+    def calc_reward(self):
+        return self.lib.orc_calc_reward(self.h)
+
+    def calc_reward_terms(self):
+        t = np.zeros(5)
+        r = self.lib.orc_calc_reward_terms(self.h, _d(t))
+        return r, t
+
+    def check_terminate(self):
+        return int(self.lib.orc_check_terminate(self.h))
+
+    def is_episode_end(self):
+        return bool(self.lib.orc_is_episode_end(self.h))
+
+    def check_valid_episode(self):
+        return bool(self.lib.orc_check_valid_episode(self.h))
+
+    def time(self):
+        return self.lib.orc_time(self.h)
+
+    def kin_time(self):
+        return self.lib.orc_kin_time(self.h)
+
+    def phase(self):
+        return self.lib.orc_phase(self.h)
+
+    def sim_state(self):
+        p, v = np.zeros(self.P), np.zeros(self.P)
+        self.lib.orc_get_sim_state(self.h, _d(p), _d(v))
+        return p, v
+
+    def set_sim_state(self, p, v):
+        p = np.ascontiguousarray(p, dtype=np.float64)
+        v = np.ascontiguousarray(v, dtype=np.float64)
+        self.lib.orc_set_sim_state(self.h, _d(p), _d(v))
+
+    def kin_state(self):
+        p, v, o = np.zeros(self.P), np.zeros(self.P), np.zeros(7)
+        self.lib.orc_get_kin_state(self.h, _d(p), _d(v), _d(o))
+        return p, v, o
+
+    def tar_pose(self):
+        out = np.zeros(self.P)
+        self.lib.orc_get_tar_pose(self.h, _d(out))
+        return out
+
+    def tau(self):
+        out = np.zeros(self.P)
+        self.lib.orc_get_tau(self.h, _d(out))
+        return out
+
+    def contacts(self):
+        out = np.zeros(self.J, dtype=np.int32)
+        self.lib.orc_get_contacts(self.h, out.ctypes.data_as(_ip))
+        return out
+
+    def kin_eval(self, t):
+        p, v = np.zeros(self.P), np.zeros(self.P)
+        self.lib.orc_kin_eval(self.h, C.c_double(t), _d(p), _d(v))
+        return p, v
+
+    def motion_frame(self, f):
+        fr, fv, t = np.zeros(self.P), np.zeros(self.P), C.c_double(0)
+        self.lib.orc_motion_frame(self.h, f, _d(fr), _d(fv), C.byref(t))
+        return fr, fv, t.value
+
+    def mass_bias(self, which, pose, vel):
+        H, Cb = np.zeros((self.P, self.P)), np.zeros(self.P)
+        pose = np.ascontiguousarray(pose, dtype=np.float64)
+        vel = np.ascontiguousarray(vel, dtype=np.float64)
+        self.lib.orc_mass_bias(self.h, which, _d(pose), _d(vel), _d(H), _d(Cb))
+        return H, Cb
+
+    def spd_tau(self, dt):
+        out = np.zeros(self.P)
+        self.lib.orc_spd_tau(self.h, C.c_double(dt), _d(out))
+        return out
+
+    def set_tau(self, tau):
+        tau = np.ascontiguousarray(tau, dtype=np.float64)
+        self.lib.orc_set_tau(self.h, _d(tau))
+
+    def substep(self, h):
+        self.lib.orc_substep(self.h, C.c_double(h))
+
+    def vstar(self):
+        out = np.zeros(self.P)
+        self.lib.orc_get_vstar(self.h, _d(out))
+        return out
+
+    def num_rows(self):
+        return int(self.lib.orc_dbg_num_rows(self.h))
+
+    def num_contacts(self):
+        return int(self.lib.orc_dbg_num_contacts(self.h))
+
+    def links(self):
+        out = np.zeros((self.J, 21))
+        self.lib.orc_get_links(self.h, _d(out))
+        return out
+
+    def calc_com(self, pose, vel):
+        c, v = np.zeros(3), np.zeros(3)
+        pose = np.ascontiguousarray(pose, dtype=np.float64)
+        vel = np.ascontiguousarray(vel, dtype=np.float64)
+        self.lib.orc_calc_com(self.h, _d(pose), _d(vel), _d(c), _d(v))
+        return c, v
+
+    def pose_to_action(self, pose):
+        a = np.zeros(self.A)
+        pose = np.ascontiguousarray(pose, dtype=np.float64)
+        self.lib.orc_pose_to_action(self.h, _d(pose), _d(a))
+        return a
+
+    def rollout(self, steps, updates_per_step=20, dt=1.0 / 600, actions=None, want_states=False):
+        rewards = np.zeros(steps)
+        states = np.zeros((steps, self.S)) if want_states else None
+        ap = None
+        if actions is not None:
+            actions = np.ascontiguousarray(actions, dtype=np.float64)
+            assert actions.shape == (steps, self.A)
+            ap = _d(actions)
+        secs = self.lib.orc_rollout(self.h, steps, updates_per_step, C.c_double(dt), ap, _d(rewards),
+                                    _d(states) if want_states else None)
+        return secs, rewards, states

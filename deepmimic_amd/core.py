@@ -1,0 +1,209 @@
+"""ctypes binding of libdm_hip.so (include/dm_hip.h) and the batched environment handle.
+
+The HIP library is the only compute path: if it is missing or no GPU is visible the constructor
+raises -- there is no CPU fallback in the product.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Sequence
+
+import numpy as np
+
+from .model import SceneTables
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_LIB = os.path.join(_HERE, "csrc", "libdm_hip.so")
+
+DM_DEVICE_PTRS, DM_AUTO_RESET, DM_OPEN_LOOP, DM_NO_EMIT = 1, 2, 4, 8
+
+
+class _CreateInfo(C.Structure):
+    _fields_ = [("num_envs", C.c_int), ("device_id", C.c_int), ("seed", C.c_uint64), ("precision", C.c_int),
+                ("max_contacts", C.c_int), ("env_id_offset", C.c_int)]
+
+
+class _SceneTables(C.Structure):
+    _fields_ = [
+        ("num_joints", C.c_int), ("joint_mat", C.POINTER(C.c_double)), ("body_defs", C.POINTER(C.c_double)),
+        ("pd_params", C.POINTER(C.c_double)), ("num_frames", C.c_int), ("frames", C.POINTER(C.c_double)),
+        ("loop", C.c_int), ("fall_mask", C.POINTER(C.c_int32)),
+        ("num_sim_substeps", C.c_int), ("world_scale", C.c_double), ("gravity", C.c_double * 3),
+        ("sync_char_root_pos", C.c_int), ("sync_char_root_rot", C.c_int), ("enable_fall_end", C.c_int),
+        ("enable_char_contact_fall", C.c_int), ("enable_root_rot_fail", C.c_int), ("enable_rand_char_placement", C.c_int),
+        ("enable_rand_rot_reset", C.c_int), ("time_lim_min", C.c_double), ("time_lim_max", C.c_double),
+        ("enable_phase_input", C.c_int), ("record_world_root_pos", C.c_int), ("record_world_root_rot", C.c_int),
+        ("query_rate", C.c_double), ("friction", C.c_double), ("erp", C.c_double), ("solver_iters", C.c_int),
+    ]
+
+
+_libs = {}
+
+
+def load_library(path: Optional[str] = None) -> C.CDLL:
+    path = path or os.environ.get("DM_HIP_LIB") or DEFAULT_LIB
+    if path in _libs:
+        return _libs[path]
+    if not os.path.exists(path):
+        raise RuntimeError(
+            "HIP extension %s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(deepmimic_amd has no CPU fallback)" % path)
+    lib = C.CDLL(path)
+    lib.dm_last_error.restype = C.c_char_p
+    lib.dm_motion_duration.restype = C.c_double
+    lib.dm_motion_duration.argtypes = [C.c_void_p]
+    _libs[path] = lib
+    return lib
+
+
+def _dp(a):
+    return None if a is None else a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _fp(a):
+    return None if a is None else a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _ip(a):
+    return None if a is None else a.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+class BatchEnv:
+    """N independent imitate scenes on one GPU (one `dm_ctx`)."""
+
+    def __init__(self, tables: SceneTables, num_envs: int = 1, device_id: int = 0, seed: int = 0,
+                 precision: int = 32, max_contacts: int = 20, env_id_offset: int = 0,
+                 test_mode: bool = False, lib_path: Optional[str] = None):
+        self.lib = load_library(lib_path)
+        self.tables = tables
+        c = tables.cfg
+        self._keep = []
+
+        def arr(a, dt=np.float64):
+            a = np.ascontiguousarray(a, dtype=dt)
+            self._keep.append(a)
+            return a
+
+        st = _SceneTables()
+        st.num_joints = tables.num_joints
+        st.joint_mat = _dp(arr(tables.joint_mat)); st.body_defs = _dp(arr(tables.body_defs)); st.pd_params = _dp(arr(tables.pd_params))
+        st.num_frames = tables.frames.shape[0]; st.frames = _dp(arr(tables.frames)); st.loop = int(tables.loop)
+        st.fall_mask = _ip(arr(tables.fall_mask(), np.int32))
+        st.num_sim_substeps = int(c.num_sim_substeps); st.world_scale = float(c.world_scale)
+        st.gravity = (C.c_double * 3)(*[float(g) for g in c.gravity])
+        st.sync_char_root_pos = int(c.sync_char_root_pos); st.sync_char_root_rot = int(c.sync_char_root_rot)
+        st.enable_fall_end = int(c.enable_fall_end); st.enable_char_contact_fall = int(c.enable_char_contact_fall)
+        st.enable_root_rot_fail = int(c.enable_root_rot_fail); st.enable_rand_char_placement = int(c.enable_rand_char_placement)
+        st.enable_rand_rot_reset = int(c.enable_rand_rot_reset)
+        # episode timer: test mode uses time_end_lim_max (scenes/RLSceneSimChar.cpp:277-284)
+        tmin, tmax = float(c.time_lim_min), float(c.time_lim_max)
+        if test_mode and c.time_end_lim_max is not None:
+            tmin = tmax = float(c.time_end_lim_max)
+        st.time_lim_min, st.time_lim_max = tmin, tmax
+        st.enable_phase_input = int(tables.enable_phase_input); st.record_world_root_pos = int(tables.record_world_root_pos)
+        st.record_world_root_rot = int(tables.record_world_root_rot); st.query_rate = float(tables.query_rate)
+        st.friction = 0.0; st.erp = 0.0; st.solver_iters = 0
+        info = _CreateInfo(int(num_envs), int(device_id), int(seed) & (2 ** 64 - 1), int(precision), int(max_contacts), int(env_id_offset))
+        self.h = C.c_void_p()
+        self._chk(self.lib.dm_create(C.byref(info), C.byref(st), C.byref(self.h)))
+        dims = np.zeros(8, dtype=np.int32)
+        self._chk(self.lib.dm_dims(self.h, _ip(dims)))
+        self.S, self.G, self.A, self.P, self.J, self.D, self.F, self.N = [int(x) for x in dims]
+        self.duration = float(self.lib.dm_motion_duration(self.h))
+        self.precision = precision
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise RuntimeError("libdm_hip: %s" % self.lib.dm_last_error().decode())
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.dm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- cDeepMimicCore-style operations on all envs
+    def reset(self, env_ids: Optional[Sequence[int]] = None, kin_times=None, max_times=None):
+        ids = None if env_ids is None else np.ascontiguousarray(env_ids, dtype=np.int32)
+        n = self.N if ids is None else ids.size
+        kt = None if kin_times is None else np.ascontiguousarray(np.broadcast_to(kin_times, (n,)), dtype=np.float64)
+        mt = None if max_times is None else np.ascontiguousarray(np.broadcast_to(max_times, (n,)), dtype=np.float64)
+        self._chk(self.lib.dm_reset(self.h, _ip(ids), n, _dp(kt), _dp(mt)))
+
+    def set_action(self, actions):
+        a = np.ascontiguousarray(actions, dtype=np.float32).reshape(self.N, self.A)
+        self._chk(self.lib.dm_set_action(self.h, _fp(a), 0))
+
+    def update(self, timestep: float, n_updates: int = 1):
+        self._chk(self.lib.dm_update(self.h, C.c_double(timestep), int(n_updates)))
+
+    def query(self):
+        s = np.zeros((self.N, self.S), np.float32); r = np.zeros(self.N, np.float32)
+        t = np.zeros(self.N, np.int32); v = np.zeros(self.N, np.int32); e = np.zeros(self.N, np.int32); nn = np.zeros(self.N, np.int32)
+        self._chk(self.lib.dm_query(self.h, _fp(s), _fp(r), _ip(t), _ip(v), _ip(e), _ip(nn), 0))
+        return dict(state=s, reward=r, terminate=t, valid=v, episode_end=e, need_new_action=nn)
+
+    def step(self, actions=None, timestep: float = 1.0 / 600, n_updates: int = 20, auto_reset=False, open_loop=False):
+        a = None if actions is None else np.ascontiguousarray(actions, dtype=np.float32).reshape(self.N, self.A)
+        s = np.zeros((self.N, self.S), np.float32); r = np.zeros(self.N, np.float32)
+        t = np.zeros(self.N, np.int32); v = np.zeros(self.N, np.int32); e = np.zeros(self.N, np.int32)
+        flags = (DM_AUTO_RESET if auto_reset else 0) | (DM_OPEN_LOOP if open_loop else 0)
+        self._chk(self.lib.dm_step_batch(self.h, _fp(a), C.c_double(timestep), int(n_updates), _fp(s), _fp(r), _ip(t), _ip(v), _ip(e), flags))
+        return dict(state=s, reward=r, terminate=t, valid=v, episode_end=e)
+
+    def step_device(self, actions_ptr, states_ptr, rewards_ptr, term_ptr, valid_ptr, end_ptr,
+                    timestep: float = 1.0 / 600, n_updates: int = 20, auto_reset=False, open_loop=False):
+        """Same as step() on raw device pointers (ints), asynchronous on the ctx stream."""
+        flags = DM_DEVICE_PTRS | (DM_AUTO_RESET if auto_reset else 0) | (DM_OPEN_LOOP if open_loop else 0)
+        vp = lambda p: C.c_void_p(p) if p else None
+        self._chk(self.lib.dm_step_batch(self.h, vp(actions_ptr), C.c_double(timestep), int(n_updates), vp(states_ptr),
+                                         vp(rewards_ptr), vp(term_ptr), vp(valid_ptr), vp(end_ptr), flags))
+
+    def set_stream(self, stream_handle: int):
+        self._chk(self.lib.dm_set_stream(self.h, C.c_void_p(stream_handle)))
+
+    def synchronize(self):
+        self._chk(self.lib.dm_synchronize(self.h))
+
+    def bench_rollout(self, warmup: int, steps: int, timestep=1.0 / 600, n_updates=20, auto_reset=True, open_loop=True):
+        ms = C.c_double(0)
+        flags = (DM_AUTO_RESET if auto_reset else 0) | (DM_OPEN_LOOP if open_loop else 0)
+        self._chk(self.lib.dm_bench_rollout(self.h, int(warmup), int(steps), C.c_double(timestep), int(n_updates), flags, None, None, C.byref(ms)))
+        return ms.value
+
+    def offsets_scales(self):
+        so, ss = np.zeros(self.S), np.zeros(self.S); ao, as_, amin, amax = np.zeros(self.A), np.zeros(self.A), np.zeros(self.A), np.zeros(self.A)
+        g = np.zeros(self.S, np.int32)
+        self._chk(self.lib.dm_build_offsets_scales(self.h, _dp(so), _dp(ss), _dp(ao), _dp(as_), _dp(amin), _dp(amax), _ip(g)))
+        return dict(state_offset=so, state_scale=ss, action_offset=ao, action_scale=as_, action_min=amin, action_max=amax, state_norm_groups=g)
+
+    # ---- snapshots / taps
+    def get_state(self):
+        pose = np.zeros((self.N, self.P)); vel = np.zeros((self.N, self.P)); tar = np.zeros((self.N, self.P))
+        kin = np.zeros((self.N, 7)); clk = np.zeros((self.N, 5)); flg = np.zeros((self.N, 4), np.int32)
+        self._chk(self.lib.dm_get_state(self.h, _dp(pose), _dp(vel), _dp(tar), _dp(kin), _dp(clk), _ip(flg)))
+        return dict(pose=pose, vel=vel, tar=tar, kin=kin, clocks=clk, flags=flg)
+
+    def set_state(self, pose=None, vel=None, tar=None, kin=None, clocks=None, flags=None):
+        f = lambda a, sh: None if a is None else np.ascontiguousarray(a, dtype=np.float64).reshape(sh)
+        pose, vel, tar = f(pose, (self.N, self.P)), f(vel, (self.N, self.P)), f(tar, (self.N, self.P))
+        kin, clocks = f(kin, (self.N, 7)), f(clocks, (self.N, 5))
+        flags = None if flags is None else np.ascontiguousarray(flags, dtype=np.int32).reshape(self.N, 4)
+        self._chk(self.lib.dm_set_state(self.h, _dp(pose), _dp(vel), _dp(tar), _dp(kin), _dp(clocks), _ip(flags)))
+
+    def probe(self, what: int, dt: float):
+        self._chk(self.lib.dm_probe(self.h, int(what), C.c_double(dt)))
+
+    def debug(self, name: str):
+        shapes = {"H": (self.N, self.D, self.D), "C": (self.N, self.D), "vstar": (self.N, self.D), "lambda": (self.N, 64),
+                  "rows": (self.N, 2), "tau": (self.N, self.D), "kin_pose": (self.N, self.P), "kin_vel": (self.N, self.P),
+                  "reward_terms": (self.N, 5), "links": (self.N, self.J, 21)}
+        out = np.zeros(shapes[name])
+        self._chk(self.lib.dm_get_debug(self.h, name.encode(), _dp(out)))
+        return out

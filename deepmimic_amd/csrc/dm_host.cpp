@@ -1,0 +1,556 @@
+// Host side of libdm_hip.so: builds the device tables from the raw reference-layout scene tables, owns the
+// per-env HBM state and launches the kernels of dm_device.h behind the C-ABI of include/dm_hip.h.
+//
+// Init-time reference functions realised here (DeepMimicCore/...):
+//   cKinTree::PostProcessJointMat anim/KinTree.cpp:1005-1020 | body / joint frames anim/KinTree.cpp:1022-1032,1108-1118
+//   cRBDUtil::BuildMomentInertia* sim/RBDUtil.cpp:644-740 (+ Bullet 2.88 capsule inertia [EXT-BULLET])
+//   cMotion::PostProcessFrames / BuildFrameVel anim/Motion.cpp:170-191,403-430; cKinTree::CalcVel anim/KinTree.cpp:1470-1508
+//   cKinController::PostProcessMotion / CalcCycleRootDelta anim/KinController.cpp:131-161
+//   cCtController::BuildCtrlParamOffset sim/CtController.cpp:183-195; cCtCtrlUtil offsets/scales/bounds sim/CtCtrlUtil.cpp
+//   cSceneImitate::CalcJointWeights scenes/SceneImitate.cpp:236-248
+//
+// The same file is compiled twice: by hipcc for the product, and by g++ with -DDM_EMU (tests/emu) where
+// "device memory" is host memory and a launch runs the unmodified kernels on the fiber emulator.
+#ifdef DM_EMU
+#include "hip_emu.h"
+#else
+#include <hip/hip_runtime.h>
+#endif
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <string>
+#include <vector>
+
+#include "../../include/dm_hip.h"
+#include "dm_device.h"
+
+using namespace dmk;
+
+static thread_local std::string g_err;
+static int fail(const std::string& msg) { g_err = msg; return -1; }
+
+// ---------------------------------------------------------------- runtime shim
+#ifdef DM_EMU
+typedef void* rt_stream;
+static int rt_malloc(void** p, size_t n) { *p = calloc(1, n ? n : 1); return *p ? 0 : -1; }
+static void rt_free(void* p) { free(p); }
+static int rt_h2d(void* d, const void* h, size_t n, rt_stream) { memcpy(d, h, n); return 0; }
+static int rt_d2h(void* h, const void* d, size_t n, rt_stream) { memcpy(h, d, n); return 0; }
+static int rt_memset(void* d, int v, size_t n, rt_stream) { memset(d, v, n); return 0; }
+static int rt_sync(rt_stream) { return 0; }
+#define RT_LAUNCH(kern, grid, stream, ...) emu::launch((unsigned)(grid), 64, [&]() { kern(__VA_ARGS__); })
+#else
+typedef hipStream_t rt_stream;
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
+static int rt_malloc(void** p, size_t n) { hipError_t e = hipMalloc(p, n ? n : 1); if (e != hipSuccess) return -1; hipMemset(*p, 0, n ? n : 1); return 0; }
+static void rt_free(void* p) { (void)hipFree(p); }
+static int rt_h2d(void* d, const void* h, size_t n, rt_stream s) { if (hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, s) != hipSuccess) return -1; return hipStreamSynchronize(s) == hipSuccess ? 0 : -1; }
+static int rt_d2h(void* h, const void* d, size_t n, rt_stream s) { if (hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, s) != hipSuccess) return -1; return hipStreamSynchronize(s) == hipSuccess ? 0 : -1; }
+static int rt_memset(void* d, int v, size_t n, rt_stream s) { return hipMemsetAsync(d, v, n, s) == hipSuccess ? 0 : -1; }
+static int rt_sync(rt_stream s) { return hipStreamSynchronize(s) == hipSuccess ? 0 : -1; }
+#define RT_LAUNCH(kern, grid, stream, ...) hipLaunchKernelGGL(kern, dim3((unsigned)(grid)), dim3(64), 0, stream, __VA_ARGS__)
+#endif
+
+// ---------------------------------------------------------------- host-side (double) model description
+enum { JD_TYPE = 0, JD_PARENT, JD_AX, JD_AY, JD_AZ, JD_ATX, JD_ATY, JD_ATZ, JD_LL0, JD_LL1, JD_LL2, JD_LH0, JD_LH1, JD_LH2,
+       JD_TORQUE_LIM, JD_FORCE_LIM, JD_IS_EE, JD_DIFF_W, JD_PARAM_OFFSET, JD_MAX };
+enum { BD_SHAPE = 0, BD_MASS, BD_COLGROUP, BD_FALL, BD_AX, BD_AY, BD_AZ, BD_ATX, BD_ATY, BD_ATZ, BD_P0, BD_P1, BD_P2, BD_MAX = 17 };
+
+struct HostModel {
+    int J = 0, P = 0, D = 0, A = 0, S = 0, F = 0, NC = 0, NL = 0, max_depth = 0;
+    std::vector<int> parent, jtype, pose_off, dof_off, ndof, depth, act_off, is_ee, fall, brot_ident, arot_ident;
+    std::vector<uint32_t> subtree_mask;
+    std::vector<double> attach, attach_rot, battach, brot, mass, inertia, torque_lim, lim_lo, lim_hi, diffw, thresh, aabb_he;
+    std::vector<int> dof_joint, dof_kind, dof_axis, dof_vidx; std::vector<uint64_t> dof_anc; std::vector<double> kp, kd;
+    std::vector<int> cand_link; std::vector<double> cand_loc, cand_rad;
+    std::vector<int> lim_joint;
+    std::vector<double> frame_time, frames, frame_vel; double duration = 0; int loop = 0; double cycle_delta[3] = {0, 0, 0};
+    std::vector<double> s_off, s_scale, a_off, a_scale, a_min, a_max; std::vector<int> s_groups;
+    dm_scene_tables cfg;
+};
+
+static M3<double> rot_euler(double x, double y, double z) {   // cMathUtil::RotateMat(euler) = Rz*Ry*Rx (MathUtil.cpp:159-186)
+    double xs = sin(x), xc = cos(x), ys = sin(y), yc = cos(y), zs = sin(z), zc = cos(z);
+    M3<double> r;
+    r.m[0] = yc * zc; r.m[3] = yc * zs; r.m[6] = -ys;
+    r.m[1] = xs * ys * zc - xc * zs; r.m[4] = xs * ys * zs + xc * zc; r.m[7] = xs * yc;
+    r.m[2] = xc * ys * zc + xs * zs; r.m[5] = xc * ys * zs - xs * zc; r.m[8] = xc * yc;
+    return r;
+}
+static bool is_identity(const M3<double>& r) { for (int i = 0; i < 9; ++i) if (fabs(r.m[i] - ((i % 4 == 0) ? 1.0 : 0.0)) > 1e-12) return false; return true; }
+
+static int build_host_model(const dm_scene_tables& t, int max_contacts, HostModel& hm) {
+    hm.cfg = t;
+    const int J = t.num_joints;
+    if (J < 1 || J > 32) return fail("num_joints must be in [1,32]");
+    hm.J = J;
+    auto jd = [&](int j, int c) { return t.joint_mat[j * JD_MAX + c]; };
+    auto bd = [&](int j, int c) { return t.body_defs[j * BD_MAX + c]; };
+    hm.parent.resize(J); hm.jtype.resize(J); hm.pose_off.resize(J); hm.dof_off.resize(J); hm.ndof.resize(J); hm.depth.resize(J);
+    hm.act_off.resize(J); hm.is_ee.resize(J); hm.fall.resize(J); hm.brot_ident.resize(J); hm.arot_ident.resize(J); hm.subtree_mask.assign(J, 0);
+    hm.attach.assign(J * 3, 0); hm.attach_rot.assign(J * 9, 0); hm.battach.assign(J * 3, 0); hm.brot.assign(J * 9, 0);
+    hm.mass.resize(J); hm.inertia.assign(2 * J * 3, 0); hm.torque_lim.resize(J); hm.lim_lo.resize(J); hm.lim_hi.resize(J);
+    hm.diffw.resize(J); hm.thresh.resize(J); hm.aabb_he.assign(J * 4, 0);
+    int poff = 0, doff = 0, aoff = 0; double wsum = 0;
+    for (int j = 0; j < J; ++j) {
+        int type = (int)jd(j, JD_TYPE), par = (int)jd(j, JD_PARENT);
+        if (j == 0 && par != -1) return fail("joint 0 must be the root");
+        if (j > 0 && (par < 0 || par >= j)) return fail("parent id must be < child id");
+        if (j > 0 && type != JT_SPHERICAL && type != JT_REVOLUTE && type != JT_FIXED) return fail("only spherical / revolute / fixed joints are supported on the imitate path");
+        hm.parent[j] = par; hm.jtype[j] = type;
+        int psz = (j == 0) ? 7 : (type == JT_SPHERICAL ? 4 : (type == JT_REVOLUTE ? 1 : 0));
+        int dsz = (j == 0) ? 6 : (type == JT_SPHERICAL ? 3 : (type == JT_REVOLUTE ? 1 : 0));
+        int asz = (j == 0) ? 0 : dsz;
+        hm.pose_off[j] = poff; poff += psz;
+        hm.dof_off[j] = doff; hm.ndof[j] = dsz; doff += dsz;
+        hm.act_off[j] = aoff; aoff += asz;
+        hm.depth[j] = (j == 0) ? 0 : hm.depth[par] + 1; hm.max_depth = std::max(hm.max_depth, hm.depth[j]);
+        hm.is_ee[j] = jd(j, JD_IS_EE) != 0; hm.fall[j] = t.fall_mask ? (t.fall_mask[j] != 0) : (bd(j, BD_FALL) != 0);
+        if (j > 0) for (int k = 0; k < 3; ++k) hm.attach[j * 3 + k] = jd(j, JD_AX + k);   // root attach is zeroed at load
+        M3<double> ar = rot_euler(jd(j, JD_ATX), jd(j, JD_ATY), jd(j, JD_ATZ));
+        if (j == 0 && !is_identity(ar)) return fail("root joint AttachTheta must be zero");
+        for (int k = 0; k < 9; ++k) hm.attach_rot[j * 9 + k] = ar.m[k];
+        hm.arot_ident[j] = is_identity(ar);
+        for (int k = 0; k < 3; ++k) hm.battach[j * 3 + k] = bd(j, BD_AX + k);
+        M3<double> br = rot_euler(bd(j, BD_ATX), bd(j, BD_ATY), bd(j, BD_ATZ));
+        for (int k = 0; k < 9; ++k) hm.brot[j * 9 + k] = br.m[k];
+        hm.brot_ident[j] = is_identity(br);
+        double mass = bd(j, BD_MASS); hm.mass[j] = mass;
+        int shape = (int)bd(j, BD_SHAPE); double p0 = bd(j, BD_P0), p1 = bd(j, BD_P1), p2 = bd(j, BD_P2);
+        double* I0 = &hm.inertia[(0 * J + j) * 3]; double* I1 = &hm.inertia[(1 * J + j) * 3];
+        double* he = &hm.aabb_he[j * 4];
+        if (shape == SH_BOX) {
+            I0[0] = mass / 12 * (p1 * p1 + p2 * p2); I0[1] = mass / 12 * (p0 * p0 + p2 * p2); I0[2] = mass / 12 * (p0 * p0 + p1 * p1);
+            I1[0] = I0[0]; I1[1] = I0[1]; I1[2] = I0[2];
+            hm.thresh[j] = 0.02 * 0.5 * sqrt(p0 * p0 + p1 * p1 + p2 * p2);
+            he[0] = 0.5 * p0; he[1] = 0.5 * p1; he[2] = 0.5 * p2;
+        } else if (shape == SH_CAPSULE) {
+            double r = 0.5 * p0, h = p1;
+            double c_vol = DM_PI * r * r * h, hs_vol = DM_PI * 2.0 / 3.0 * r * r * r, density = mass / (c_vol + 2 * hs_vol);
+            double cm = c_vol * density, hsm = hs_vol * density;
+            I0[0] = cm * (0.25 * r * r + (1.0 / 12.0) * h * h) + 2 * hsm * (0.4 * r * r + (3.0 / 8) * r * h + 0.25 * h * h);
+            I0[1] = (0.5 * cm + 0.8 * hsm) * r * r; I0[2] = I0[0];
+            double mg = 0.04 / t.world_scale;   // [EXT-BULLET] btCapsuleShape::calculateLocalInertia
+            double lx = 2 * (r + mg), ly = 2 * (r + 0.5 * h + mg), lz = 2 * (r + mg);
+            I1[0] = mass / 12 * (ly * ly + lz * lz); I1[1] = mass / 12 * (lx * lx + lz * lz); I1[2] = mass / 12 * (lx * lx + ly * ly);
+            hm.thresh[j] = 0.02 * (r + 0.5 * h);
+            he[0] = r; he[1] = r + 0.5 * h; he[2] = r;
+        } else if (shape == SH_SPHERE) {
+            double r = 0.5 * p0;
+            I0[0] = I0[1] = I0[2] = 0.4 * mass * r * r; I1[0] = I1[1] = I1[2] = I0[0];
+            hm.thresh[j] = 0.02 * r; he[0] = r; he[3] = 1;
+        } else return fail("unsupported body shape (box / capsule / sphere only)");
+        hm.torque_lim[j] = jd(j, JD_TORQUE_LIM); hm.lim_lo[j] = jd(j, JD_LL0); hm.lim_hi[j] = jd(j, JD_LH0);
+        hm.diffw[j] = jd(j, JD_DIFF_W); wsum += fabs(hm.diffw[j]);
+        if (type == JT_REVOLUTE && hm.lim_lo[j] <= hm.lim_hi[j]) hm.lim_joint.push_back(j);
+    }
+    for (int j = 0; j < J; ++j) hm.diffw[j] /= wsum;
+    hm.P = poff; hm.D = doff; hm.A = aoff; hm.NL = (int)hm.lim_joint.size();
+    hm.S = (t.enable_phase_input ? 1 : 0) + (J * 9 + 1) + J * 6;
+    if (hm.D > 64) return fail("more than 64 degrees of freedom");
+    for (int j = 0; j < J; ++j) for (int k = j; k != -1; k = hm.parent[k]) hm.subtree_mask[k] |= (1u << j);
+    // generalized velocities
+    hm.dof_joint.resize(hm.D); hm.dof_kind.resize(hm.D); hm.dof_axis.resize(hm.D); hm.dof_vidx.resize(hm.D); hm.dof_anc.assign(hm.D, 0);
+    hm.kp.assign(hm.D, 0); hm.kd.assign(hm.D, 0);
+    for (int j = 0; j < J; ++j) for (int k = 0; k < hm.ndof[j]; ++k) {
+        int i = hm.dof_off[j] + k;
+        hm.dof_joint[i] = j;
+        if (j == 0) { hm.dof_kind[i] = (k < 3) ? DK_ROOT_LIN : DK_ROOT_ANG; hm.dof_axis[i] = k % 3; hm.dof_vidx[i] = k; }
+        else {
+            hm.dof_kind[i] = (hm.jtype[j] == JT_SPHERICAL) ? DK_SPH : DK_REV; hm.dof_axis[i] = (hm.jtype[j] == JT_SPHERICAL) ? k : 2;
+            hm.dof_vidx[i] = hm.pose_off[j] + k;
+            hm.kp[i] = t.pd_params[j * 2]; hm.kd[i] = t.pd_params[j * 2 + 1];   // root gains are never used (ExpPDController.cpp:22-32)
+        }
+    }
+    for (int i = 0; i < hm.D; ++i) for (int a = hm.dof_joint[i]; a != -1; a = hm.parent[a])
+        for (int k = 0; k < hm.ndof[a]; ++k) hm.dof_anc[i] |= (1ull << (hm.dof_off[a] + k));
+    // ground contact candidates: sphere centre, capsule end centres (radius offset along -y), box corners
+    for (int j = 0; j < J; ++j) {
+        int shape = (int)bd(j, BD_SHAPE); double p0 = bd(j, BD_P0), p1 = bd(j, BD_P1), p2 = bd(j, BD_P2);
+        auto add = [&](double x, double y, double z, double r) { hm.cand_link.push_back(j); hm.cand_loc.push_back(x); hm.cand_loc.push_back(y); hm.cand_loc.push_back(z); hm.cand_rad.push_back(r); };
+        if (shape == SH_SPHERE) add(0, 0, 0, 0.5 * p0);
+        else if (shape == SH_CAPSULE) { add(0, 0.5 * p1, 0, 0.5 * p0); add(0, -0.5 * p1, 0, 0.5 * p0); }
+        else if (shape == SH_BOX) for (int s = 0; s < 8; ++s) add((s & 1) ? -0.5 * p0 : 0.5 * p0, (s & 2) ? -0.5 * p1 : 0.5 * p1, (s & 4) ? -0.5 * p2 : 0.5 * p2, 0);
+    }
+    hm.NC = (int)hm.cand_link.size();
+    if (hm.NC > kMaxCand) return fail("more than 64 ground-contact candidate points");
+    if (hm.NL + 3 * max_contacts > kMaxRows) return fail("limit rows + 3*max_contacts exceeds 64 constraint rows");
+
+    // ---- motion clip
+    const int F = t.num_frames, P = hm.P;
+    if (F < 2) return fail("motion needs at least 2 frames");
+    hm.F = F; hm.loop = t.loop;
+    hm.frame_time.assign(F, 0); hm.frames.assign((size_t)F * P, 0); hm.frame_vel.assign((size_t)F * P, 0);
+    double tcur = 0; const double* raw = t.frames;
+    double ox = raw[1], oz = raw[3];
+    for (int f = 0; f < F; ++f) {
+        hm.frame_time[f] = tcur; tcur += raw[(size_t)f * (P + 1)];
+        double* fr = &hm.frames[(size_t)f * P];
+        for (int k = 0; k < P; ++k) fr[k] = raw[(size_t)f * (P + 1) + 1 + k];
+        fr[0] -= ox; fr[2] -= oz;
+        stq(fr + 3, qnormalize(ldq(fr + 3)));
+        for (int j = 1; j < J; ++j) if (hm.jtype[j] == JT_SPHERICAL) stq(fr + hm.pose_off[j], qnormalize(ldq(fr + hm.pose_off[j])));
+    }
+    hm.duration = hm.frame_time[F - 1];
+    for (int f = 0; f < F - 1; ++f) {
+        double dt = hm.frame_time[f + 1] - hm.frame_time[f];
+        const double* a = &hm.frames[(size_t)f * P]; const double* b = a + P; double* v = &hm.frame_vel[(size_t)f * P];
+        for (int k = 0; k < 3; ++k) v[k] = (b[k] - a[k]) / dt;
+        V3<double> wr = quat_to_rotvec(qmul(ldq(b + 3), qconj(ldq(a + 3))), 0.000001);
+        v[3] = wr.x / dt; v[4] = wr.y / dt; v[5] = wr.z / dt;
+        for (int j = 1; j < J; ++j) {
+            int off = hm.pose_off[j];
+            if (hm.jtype[j] == JT_SPHERICAL) { V3<double> w = quat_to_rotvec(qmul(qconj(ldq(a + off)), ldq(b + off)), 0.000001); v[off] = w.x / dt; v[off + 1] = w.y / dt; v[off + 2] = w.z / dt; }
+            else if (hm.jtype[j] == JT_REVOLUTE) v[off] = (b[off] - a[off]) / dt;
+        }
+    }
+    for (int k = 0; k < P; ++k) hm.frame_vel[(size_t)(F - 1) * P + k] = hm.frame_vel[(size_t)(F - 2) * P + k];
+    {   // PostProcessMotion + CalcCycleRootDelta
+        double bx = hm.frames[0], bz = hm.frames[2];
+        for (int f = 0; f < F; ++f) { hm.frames[(size_t)f * P] -= bx; hm.frames[(size_t)f * P + 2] -= bz; }
+        hm.cycle_delta[0] = hm.frames[(size_t)(F - 1) * P] - hm.frames[0]; hm.cycle_delta[1] = 0; hm.cycle_delta[2] = hm.frames[(size_t)(F - 1) * P + 2] - hm.frames[2];
+    }
+    // ---- offsets / scales / bounds handed to the learner
+    hm.s_off.assign(hm.S, 0); hm.s_scale.assign(hm.S, 1); hm.s_groups.assign(hm.S, 0);
+    if (t.enable_phase_input) { hm.s_off[0] = -0.5; hm.s_scale[0] = 2; hm.s_groups[0] = -1; }   // CtController.cpp:268-279,364-371
+    hm.a_off.assign(hm.A, 0); hm.a_scale.assign(hm.A, 1); hm.a_min.assign(hm.A, 0); hm.a_max.assign(hm.A, 0);
+    for (int j = 1; j < J; ++j) {
+        int ao = hm.act_off[j];
+        if (hm.jtype[j] == JT_SPHERICAL) for (int k = 0; k < 3; ++k) { hm.a_scale[ao + k] = 2.0 / (2 * DM_PI); hm.a_min[ao + k] = -2 * DM_PI; hm.a_max[ao + k] = 2 * DM_PI; }
+        else if (hm.jtype[j] == JT_REVOLUTE) {
+            double lo = hm.lim_lo[j], hi = hm.lim_hi[j];
+            if (!(hi >= lo)) { lo = -DM_PI; hi = DM_PI; }
+            hm.a_off[ao] = -0.5 * (hi + lo); hm.a_scale[ao] = 0.5 / (hi - lo);
+            double mean = 0.5 * (hi + lo), delta = hi - lo; hm.a_min[ao] = mean - 2 * delta; hm.a_max[ao] = mean + 2 * delta;
+        }
+    }
+    return 0;
+}
+
+// ---------------------------------------------------------------- device-side context, typed on the kernel precision
+struct CtxBase {
+    HostModel hm; int N = 0; int env_off = 0; uint64_t seed = 0; int precision = 32; int max_contacts = 20;
+    rt_stream own_stream = 0, stream = 0;
+    std::vector<void*> allocs;
+    float *d_actions = nullptr, *d_states = nullptr, *d_rewards = nullptr; int *d_term = nullptr, *d_valid = nullptr, *d_end = nullptr;
+    virtual ~CtxBase() { for (void* p : allocs) rt_free(p); }
+    void* dalloc(size_t n) { void* p = nullptr; if (rt_malloc(&p, n) != 0) return nullptr; allocs.push_back(p); return p; }
+    virtual int setup() = 0;
+    virtual int reset(const int* ids_dev, int n, const double* kt_dev, const double* mt_dev) = 0;
+    virtual int step(const float* actions_dev, double dt, int n_updates, float* states, float* rewards, int* term, int* valid, int* end, int flags) = 0;
+    virtual int query(float* states, float* rewards, int* term, int* valid, int* end) = 0;
+    virtual int probe(int what, double dt) = 0;
+    virtual int get_state(double* pose, double* vel, double* tar, double* kin, double* clk, int* flg) = 0;
+    virtual int set_state(const double* pose, const double* vel, const double* tar, const double* kin, const double* clk, const int* flg) = 0;
+    virtual int get_debug(const char* name, double* out) = 0;
+};
+
+template <typename Real>
+struct CtxT : CtxBase {
+    ModelDev<Real> md; EnvState<Real> st; DebugTaps<Real> dbg; int cls = 0;
+
+    template <typename T, typename U> const T* up(const std::vector<U>& v) {
+        std::vector<T> tmp(v.size()); for (size_t i = 0; i < v.size(); ++i) tmp[i] = (T)v[i];
+        void* p = dalloc(sizeof(T) * std::max<size_t>(1, v.size()));
+        if (p && !v.empty()) rt_h2d(p, tmp.data(), sizeof(T) * v.size(), stream);
+        return (const T*)p;
+    }
+    int setup() override {
+        const HostModel& h = hm; const dm_scene_tables& c = h.cfg;
+        memset(&md, 0, sizeof(md)); memset(&dbg, 0, sizeof(dbg));
+        md.J = h.J; md.P = h.P; md.D = h.D; md.A = h.A; md.S = h.S; md.F = h.F; md.NC = h.NC; md.NL = h.NL; md.max_depth = h.max_depth;
+        md.parent = up<int>(h.parent); md.jtype = up<int>(h.jtype); md.pose_off = up<int>(h.pose_off); md.dof_off = up<int>(h.dof_off);
+        md.ndof = up<int>(h.ndof); md.depth = up<int>(h.depth); md.act_off = up<int>(h.act_off); md.is_ee = up<int>(h.is_ee); md.fall = up<int>(h.fall);
+        md.brot_ident = up<int>(h.brot_ident); md.arot_ident = up<int>(h.arot_ident); md.subtree_mask = up<uint32_t>(h.subtree_mask);
+        md.attach = up<Real>(h.attach); md.attach_rot = up<Real>(h.attach_rot); md.battach = up<Real>(h.battach); md.brot = up<Real>(h.brot);
+        md.mass = up<Real>(h.mass); md.inertia = up<Real>(h.inertia); md.torque_lim = up<Real>(h.torque_lim); md.lim_lo = up<Real>(h.lim_lo); md.lim_hi = up<Real>(h.lim_hi);
+        md.diffw = up<Real>(h.diffw); md.thresh = up<Real>(h.thresh); md.aabb_he = up<Real>(h.aabb_he);
+        md.dof_joint = up<int>(h.dof_joint); md.dof_kind = up<int>(h.dof_kind); md.dof_axis = up<int>(h.dof_axis); md.dof_vidx = up<int>(h.dof_vidx);
+        md.dof_anc = up<uint64_t>(h.dof_anc); md.kp = up<Real>(h.kp); md.kd = up<Real>(h.kd);
+        md.cand_link = up<int>(h.cand_link); md.cand_loc = up<Real>(h.cand_loc); md.cand_rad = up<Real>(h.cand_rad);
+        md.lim_joint = up<int>(h.lim_joint);
+        md.frame_time = up<double>(h.frame_time); md.frames = up<Real>(h.frames); md.frame_vel = up<Real>(h.frame_vel);
+        md.duration = h.duration; md.loop = h.loop; for (int k = 0; k < 3; ++k) { md.cycle_delta[k] = (Real)h.cycle_delta[k]; md.gravity[k] = (Real)c.gravity[k]; }
+        md.num_sim_substeps = c.num_sim_substeps; md.solver_iters = c.solver_iters > 0 ? c.solver_iters : 10; md.max_contacts = max_contacts;
+        md.friction = (Real)(c.friction > 0 ? c.friction : 0.9 * 0.9); md.erp = (Real)(c.erp > 0 ? c.erp : 0.2);
+        md.report_dist = (Real)0.001; md.max_lin_vel = (Real)(100.0 / c.world_scale); md.max_ang_vel = (Real)100.0;
+        md.slerp_one = (sizeof(Real) == 8) ? (Real)(1.0 - std::numeric_limits<double>::epsilon()) : (Real)(1.0 - 1e-6);
+        md.sync_root_pos = c.sync_char_root_pos; md.sync_root_rot = c.sync_char_root_rot; md.enable_fall_end = c.enable_fall_end;
+        md.enable_contact_fall = c.enable_char_contact_fall; md.enable_root_rot_fail = c.enable_root_rot_fail; md.enable_rand_placement = c.enable_rand_char_placement;
+        md.enable_phase_input = c.enable_phase_input; md.record_world_root_pos = c.record_world_root_pos; md.record_world_root_rot = c.record_world_root_rot;
+        md.query_period = 1.0 / (c.query_rate > 0 ? c.query_rate : 30.0);
+        md.time_lim_min = c.time_lim_min; md.time_lim_max = c.time_lim_max; md.seed = seed;
+        st.N = N;
+        st.pose = (Real*)dalloc(sizeof(Real) * N * h.P); st.vel = (Real*)dalloc(sizeof(Real) * N * h.P); st.tar = (Real*)dalloc(sizeof(Real) * N * h.P);
+        st.tau = (Real*)dalloc(sizeof(Real) * N * h.D); st.kin = (Real*)dalloc(sizeof(Real) * N * 8);
+        st.clock = (double*)dalloc(sizeof(double) * N * 6); st.flag = (int*)dalloc(sizeof(int) * N * 4);
+        d_actions = (float*)dalloc(sizeof(float) * N * h.A); d_states = (float*)dalloc(sizeof(float) * N * h.S); d_rewards = (float*)dalloc(sizeof(float) * N);
+        d_term = (int*)dalloc(sizeof(int) * N); d_valid = (int*)dalloc(sizeof(int) * N); d_end = (int*)dalloc(sizeof(int) * N);
+        if (!st.pose || !st.flag || !d_end) return fail("device allocation failed");
+        if (h.J <= 15 && h.D <= 34 && h.P <= 43) cls = 0; else if (h.J <= 23 && h.D <= 64 && h.P <= 83) cls = 1; else return fail("character too large for the compiled kernel classes (J<=23, D<=64, P<=83)");
+        // PD targets start at identity rotations (cPDController::PostProcessTargetPose, PDController.cpp:425-443)
+        std::vector<Real> tar((size_t)N * h.P, 0);
+        for (int e = 0; e < N; ++e) for (int j = 1; j < h.J; ++j) if (h.jtype[j] == JT_SPHERICAL) tar[(size_t)e * h.P + h.pose_off[j]] = 1;
+        rt_h2d(st.tar, tar.data(), sizeof(Real) * tar.size(), stream);
+        // RNG streams are keyed by the global env id (shard offset) so they do not depend on the partition
+        md.env_off = env_off;
+        return 0;
+    }
+    int alloc_dbg() {
+        if (dbg.H) return 0;
+        const HostModel& h = hm;
+        dbg.H = (Real*)dalloc(sizeof(Real) * N * h.D * h.D); dbg.C = (Real*)dalloc(sizeof(Real) * N * h.D); dbg.vstar = (Real*)dalloc(sizeof(Real) * N * h.D);
+        dbg.lambda = (Real*)dalloc(sizeof(Real) * N * kMaxRows); dbg.rows = (int*)dalloc(sizeof(int) * N * 2);
+        dbg.kin_pose = (Real*)dalloc(sizeof(Real) * N * h.P); dbg.kin_vel = (Real*)dalloc(sizeof(Real) * N * h.P);
+        dbg.reward_terms = (Real*)dalloc(sizeof(Real) * N * 5); dbg.links = (Real*)dalloc(sizeof(Real) * N * h.J * 21);
+        return dbg.links ? 0 : fail("device allocation failed");
+    }
+#define DM_DISPATCH(KERN, grid, ...)                                                         \
+    do {                                                                                     \
+        if (cls == 0) RT_LAUNCH((KERN<Real, 15, 34, 43>), grid, stream, __VA_ARGS__);        \
+        else RT_LAUNCH((KERN<Real, 23, 64, 83>), grid, stream, __VA_ARGS__);                 \
+    } while (0)
+
+    int reset(const int* ids_dev, int n, const double* kt_dev, const double* mt_dev) override {
+        DM_DISPATCH(k_env_reset, n, md, st, ids_dev, kt_dev, mt_dev);
+        return 0;
+    }
+    int step(const float* actions_dev, double dt, int n_updates, float* states, float* rewards, int* term, int* valid, int* end, int flags) override {
+        StepIO<Real> io; memset(&io, 0, sizeof(io));
+        io.actions = actions_dev; io.states = states; io.rewards = rewards; io.terminate = term; io.valid = valid; io.episode_end = end;
+        io.n_updates = n_updates; io.dt = dt; io.auto_reset = (flags & DM_AUTO_RESET) ? 1 : 0; io.emit = (flags & DM_NO_EMIT) ? 0 : 1; io.open_loop = (flags & DM_OPEN_LOOP) ? 1 : 0;
+        DM_DISPATCH(k_env_step, N, md, st, io, dbg);
+        return 0;
+    }
+    int query(float* states, float* rewards, int* term, int* valid, int* end) override {
+        StepIO<Real> io; memset(&io, 0, sizeof(io));
+        io.states = states; io.rewards = rewards; io.terminate = term; io.valid = valid; io.episode_end = end; io.emit = 1;
+        DM_DISPATCH(k_env_query, N, md, st, io, dbg);
+        return 0;
+    }
+    int probe(int what, double dt) override {
+        if (alloc_dbg() != 0) return -1;
+        DM_DISPATCH(k_env_probe, N, md, st, dbg, what, dt);
+        return 0;
+    }
+    template <typename T> int dl(const T* dev, size_t n, double* out) {
+        std::vector<T> tmp(n); if (rt_d2h(tmp.data(), dev, sizeof(T) * n, stream) != 0) return fail("device to host copy failed");
+        for (size_t i = 0; i < n; ++i) out[i] = (double)tmp[i];
+        return 0;
+    }
+    template <typename T> int ul(T* dev, size_t n, const double* in) {
+        std::vector<T> tmp(n); for (size_t i = 0; i < n; ++i) tmp[i] = (T)in[i];
+        return rt_h2d(dev, tmp.data(), sizeof(T) * n, stream) == 0 ? 0 : fail("host to device copy failed");
+    }
+    int get_state(double* pose, double* vel, double* tar, double* kin, double* clk, int* flg) override {
+        const size_t n = N; const int P = hm.P;
+        if (pose && dl(st.pose, n * P, pose)) return -1;
+        if (vel && dl(st.vel, n * P, vel)) return -1;
+        if (tar && dl(st.tar, n * P, tar)) return -1;
+        if (kin) { std::vector<double> t8(n * 8); if (dl(st.kin, n * 8, t8.data())) return -1; for (size_t e = 0; e < n; ++e) for (int k = 0; k < 7; ++k) kin[e * 7 + k] = t8[e * 8 + k]; }
+        if (clk) { std::vector<double> t6(n * 6); if (rt_d2h(t6.data(), st.clock, sizeof(double) * n * 6, stream)) return fail("copy failed"); for (size_t e = 0; e < n; ++e) for (int k = 0; k < 5; ++k) clk[e * 5 + k] = t6[e * 6 + k]; }
+        if (flg && rt_d2h(flg, st.flag, sizeof(int) * n * 4, stream)) return fail("copy failed");
+        return 0;
+    }
+    int set_state(const double* pose, const double* vel, const double* tar, const double* kin, const double* clk, const int* flg) override {
+        const size_t n = N; const int P = hm.P;
+        if (pose && ul(st.pose, n * P, pose)) return -1;
+        if (vel && ul(st.vel, n * P, vel)) return -1;
+        if (tar && ul(st.tar, n * P, tar)) return -1;
+        if (kin) { std::vector<double> t8(n * 8, 0); for (size_t e = 0; e < n; ++e) for (int k = 0; k < 7; ++k) t8[e * 8 + k] = kin[e * 7 + k]; if (ul(st.kin, n * 8, t8.data())) return -1; }
+        if (clk) { std::vector<double> t6(n * 6, 0); for (size_t e = 0; e < n; ++e) for (int k = 0; k < 5; ++k) t6[e * 6 + k] = clk[e * 5 + k]; if (rt_h2d(st.clock, t6.data(), sizeof(double) * n * 6, stream)) return fail("copy failed"); }
+        if (flg && rt_h2d(st.flag, flg, sizeof(int) * n * 4, stream)) return fail("copy failed");
+        return 0;
+    }
+    int get_debug(const char* name, double* out) override {
+        const size_t n = N; const HostModel& h = hm; std::string s(name);
+        if (s == "tau") return dl(st.tau, n * h.D, out);
+        if (!dbg.H) return fail("no debug taps recorded yet (call dm_probe first)");
+        if (s == "H") return dl(dbg.H, n * h.D * h.D, out);
+        if (s == "C") return dl(dbg.C, n * h.D, out);
+        if (s == "vstar") return dl(dbg.vstar, n * h.D, out);
+        if (s == "lambda") return dl(dbg.lambda, n * kMaxRows, out);
+        if (s == "rows") return dl(dbg.rows, n * 2, out);
+        if (s == "kin_pose") return dl(dbg.kin_pose, n * h.P, out);
+        if (s == "kin_vel") return dl(dbg.kin_vel, n * h.P, out);
+        if (s == "reward_terms") return dl(dbg.reward_terms, n * 5, out);
+        if (s == "links") return dl(dbg.links, n * h.J * 21, out);
+        return fail("unknown debug tap: " + s);
+    }
+};
+
+struct dm_ctx { CtxBase* c; };
+
+// ---------------------------------------------------------------- C-ABI
+extern "C" {
+
+const char* dm_last_error(void) { return g_err.c_str(); }
+
+int dm_create(const dm_create_info* info, const dm_scene_tables* tables, dm_ctx** out) {
+    if (!info || !tables || !out) return fail("null argument");
+    if (info->num_envs < 1) return fail("num_envs must be >= 1");
+    if (tables->sync_char_root_rot) return fail("sync_char_root_rot is not supported on the accelerated path");
+    if (tables->enable_rand_rot_reset) return fail("enable_rand_rot_reset is not supported on the accelerated path");
+    if (tables->num_sim_substeps < 1) return fail("num_sim_substeps must be >= 1");
+    int precision = info->precision ? info->precision : 32;
+    if (precision != 32 && precision != 64) return fail("precision must be 32 or 64");
+    int mc = info->max_contacts > 0 ? info->max_contacts : 20;
+    if (mc > 20) return fail("max_contacts must be <= 20");
+#ifndef DM_EMU
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail("no HIP device available: libdm_hip.so has no CPU fallback");
+    if (info->device_id < 0 || info->device_id >= ndev) return fail("invalid device_id");
+    HIPCHK(hipSetDevice(info->device_id));
+#endif
+    CtxBase* c = (precision == 64) ? (CtxBase*)new CtxT<double>() : (CtxBase*)new CtxT<float>();
+    c->N = info->num_envs; c->seed = info->seed; c->precision = precision; c->max_contacts = mc; c->env_off = info->env_id_offset;
+    if (build_host_model(*tables, mc, c->hm) != 0) { delete c; return -1; }
+#ifndef DM_EMU
+    if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) { delete c; return fail("hipStreamCreate failed"); }
+    c->stream = c->own_stream;
+#endif
+    if (c->setup() != 0) { delete c; return -1; }
+    dm_ctx* ctx = new dm_ctx(); ctx->c = c; *out = ctx;
+    return dm_reset(ctx, nullptr, 0, nullptr, nullptr);
+}
+
+int dm_destroy(dm_ctx* ctx) {
+    if (!ctx) return 0;
+#ifndef DM_EMU
+    if (ctx->c->own_stream) { (void)hipStreamSynchronize(ctx->c->own_stream); (void)hipStreamDestroy(ctx->c->own_stream); }
+#endif
+    delete ctx->c; delete ctx; return 0;
+}
+
+int dm_dims(const dm_ctx* ctx, int32_t* out) {
+    if (!ctx || !out) return fail("null argument");
+    const HostModel& h = ctx->c->hm;
+    out[0] = h.S; out[1] = 0; out[2] = h.A; out[3] = h.P; out[4] = h.J; out[5] = h.D; out[6] = h.F; out[7] = ctx->c->N;
+    return 0;
+}
+double dm_motion_duration(const dm_ctx* ctx) { return ctx ? ctx->c->hm.duration : 0.0; }
+
+int dm_set_stream(dm_ctx* ctx, void* hip_stream) {
+    if (!ctx) return fail("null ctx");
+#ifndef DM_EMU
+    ctx->c->stream = hip_stream ? (hipStream_t)hip_stream : ctx->c->own_stream;
+#endif
+    return 0;
+}
+int dm_synchronize(dm_ctx* ctx) { if (!ctx) return fail("null ctx"); return rt_sync(ctx->c->stream) == 0 ? 0 : fail("stream synchronize failed"); }
+
+int dm_reset(dm_ctx* ctx, const int32_t* env_ids, int n, const double* kin_times, const double* max_times) {
+    if (!ctx) return fail("null ctx");
+    CtxBase* c = ctx->c;
+    if (!env_ids) n = c->N;
+    if (n <= 0) return 0;
+    for (int i = 0; env_ids && i < n; ++i) if (env_ids[i] < 0 || env_ids[i] >= c->N) return fail("env id out of range");
+    int* ids_dev = nullptr; double *kt_dev = nullptr, *mt_dev = nullptr; int rc = 0;
+    void* tmp[3] = {nullptr, nullptr, nullptr};
+    if (env_ids) { rt_malloc(&tmp[0], sizeof(int) * n); rt_h2d(tmp[0], env_ids, sizeof(int) * n, c->stream); ids_dev = (int*)tmp[0]; }
+    if (kin_times) { rt_malloc(&tmp[1], sizeof(double) * n); rt_h2d(tmp[1], kin_times, sizeof(double) * n, c->stream); kt_dev = (double*)tmp[1]; }
+    if (max_times) { rt_malloc(&tmp[2], sizeof(double) * n); rt_h2d(tmp[2], max_times, sizeof(double) * n, c->stream); mt_dev = (double*)tmp[2]; }
+    rc = c->reset(ids_dev, n, kt_dev, mt_dev);
+    rt_sync(c->stream);
+    for (void* p : tmp) if (p) rt_free(p);
+    return rc;
+}
+
+int dm_set_action(dm_ctx* ctx, const float* actions, int flags) {
+    if (!ctx || !actions) return fail("null argument");
+    CtxBase* c = ctx->c;
+    const float* adev = actions;
+    if (!(flags & DM_DEVICE_PTRS)) { if (rt_h2d(c->d_actions, actions, sizeof(float) * c->N * c->hm.A, c->stream)) return fail("copy failed"); adev = c->d_actions; }
+    return c->step(adev, 0.0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, DM_NO_EMIT);
+}
+
+int dm_update(dm_ctx* ctx, double timestep, int n_updates) {
+    if (!ctx) return fail("null ctx");
+    if (n_updates < 1 || !(timestep > 0)) return 0;   // cImpPDController::UpdateControlForce ignores non-positive steps
+    return ctx->c->step(nullptr, timestep, n_updates, nullptr, nullptr, nullptr, nullptr, nullptr, DM_NO_EMIT);
+}
+
+static int copy_out(CtxBase* c, void* host, const void* dev, size_t bytes) { return (host && rt_d2h(host, dev, bytes, c->stream)) ? fail("copy failed") : 0; }
+
+int dm_query(dm_ctx* ctx, float* states, float* rewards, int32_t* terminate, int32_t* valid, int32_t* episode_end, int32_t* need_new_action, int flags) {
+    if (!ctx) return fail("null ctx");
+    CtxBase* c = ctx->c;
+    if (flags & DM_DEVICE_PTRS) { if (c->query(states, rewards, terminate, valid, episode_end)) return -1; }
+    else {
+        if (c->query(c->d_states, c->d_rewards, c->d_term, c->d_valid, c->d_end)) return -1;
+        if (copy_out(c, states, c->d_states, sizeof(float) * c->N * c->hm.S) || copy_out(c, rewards, c->d_rewards, sizeof(float) * c->N) ||
+            copy_out(c, terminate, c->d_term, sizeof(int) * c->N) || copy_out(c, valid, c->d_valid, sizeof(int) * c->N) || copy_out(c, episode_end, c->d_end, sizeof(int) * c->N)) return -1;
+    }
+    if (need_new_action) {
+        std::vector<int> flg((size_t)c->N * 4);
+        if (c->get_state(nullptr, nullptr, nullptr, nullptr, nullptr, flg.data())) return -1;
+        for (int e = 0; e < c->N; ++e) need_new_action[e] = flg[(size_t)e * 4];
+    }
+    return 0;
+}
+
+int dm_step_batch(dm_ctx* ctx, const float* actions, double timestep, int n_updates, float* states, float* rewards,
+                  int32_t* terminate, int32_t* valid, int32_t* episode_end, int flags) {
+    if (!ctx) return fail("null ctx");
+    CtxBase* c = ctx->c;
+    if (flags & DM_DEVICE_PTRS) return c->step(actions, timestep, n_updates, states, rewards, terminate, valid, episode_end, flags);
+    const float* adev = nullptr;
+    if (actions) { if (rt_h2d(c->d_actions, actions, sizeof(float) * c->N * c->hm.A, c->stream)) return fail("copy failed"); adev = c->d_actions; }
+    if (c->step(adev, timestep, n_updates, c->d_states, c->d_rewards, c->d_term, c->d_valid, c->d_end, flags)) return -1;
+    if (copy_out(c, states, c->d_states, sizeof(float) * c->N * c->hm.S) || copy_out(c, rewards, c->d_rewards, sizeof(float) * c->N) ||
+        copy_out(c, terminate, c->d_term, sizeof(int) * c->N) || copy_out(c, valid, c->d_valid, sizeof(int) * c->N) || copy_out(c, episode_end, c->d_end, sizeof(int) * c->N)) return -1;
+    return 0;
+}
+
+int dm_build_offsets_scales(const dm_ctx* ctx, double* s_off, double* s_scale, double* a_off, double* a_scale, double* a_min, double* a_max, int32_t* s_norm_groups) {
+    if (!ctx) return fail("null ctx");
+    const HostModel& h = ctx->c->hm;
+    if (s_off) memcpy(s_off, h.s_off.data(), sizeof(double) * h.S);
+    if (s_scale) memcpy(s_scale, h.s_scale.data(), sizeof(double) * h.S);
+    if (a_off) memcpy(a_off, h.a_off.data(), sizeof(double) * h.A);
+    if (a_scale) memcpy(a_scale, h.a_scale.data(), sizeof(double) * h.A);
+    if (a_min) memcpy(a_min, h.a_min.data(), sizeof(double) * h.A);
+    if (a_max) memcpy(a_max, h.a_max.data(), sizeof(double) * h.A);
+    if (s_norm_groups) for (int i = 0; i < h.S; ++i) s_norm_groups[i] = h.s_groups[i];
+    return 0;
+}
+
+int dm_get_state(dm_ctx* ctx, double* pose, double* vel, double* tar, double* kin, double* clocks, int32_t* flags) {
+    if (!ctx) return fail("null ctx");
+    return ctx->c->get_state(pose, vel, tar, kin, clocks, flags);
+}
+int dm_set_state(dm_ctx* ctx, const double* pose, const double* vel, const double* tar, const double* kin, const double* clocks, const int32_t* flags) {
+    if (!ctx) return fail("null ctx");
+    return ctx->c->set_state(pose, vel, tar, kin, clocks, flags);
+}
+int dm_probe(dm_ctx* ctx, int what, double dt) { if (!ctx) return fail("null ctx"); int rc = ctx->c->probe(what, dt); rt_sync(ctx->c->stream); return rc; }
+int dm_get_debug(dm_ctx* ctx, const char* name, double* out) { if (!ctx || !name || !out) return fail("null argument"); return ctx->c->get_debug(name, out); }
+
+int dm_bench_rollout(dm_ctx* ctx, int warmup, int steps, double timestep, int n_updates, int flags, float* states_dev, float* rewards_dev, double* elapsed_ms) {
+    if (!ctx) return fail("null ctx");
+    CtxBase* c = ctx->c;
+    float* sdev = states_dev ? states_dev : c->d_states; float* rdev = rewards_dev ? rewards_dev : c->d_rewards;
+    for (int k = 0; k < warmup; ++k) if (c->step(nullptr, timestep, n_updates, sdev, rdev, c->d_term, c->d_valid, c->d_end, flags)) return -1;
+#ifndef DM_EMU
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+    HIPCHK(hipEventRecord(e0, c->stream));
+#endif
+    for (int k = 0; k < steps; ++k) if (c->step(nullptr, timestep, n_updates, sdev, rdev, c->d_term, c->d_valid, c->d_end, flags)) return -1;
+#ifndef DM_EMU
+    HIPCHK(hipEventRecord(e1, c->stream));
+    HIPCHK(hipEventSynchronize(e1));
+    float ms = 0; HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    if (elapsed_ms) *elapsed_ms = ms;
+    hipError_t le = hipGetLastError(); if (le != hipSuccess) return fail(std::string("kernel launch failed: ") + hipGetErrorString(le));
+#else
+    if (elapsed_ms) *elapsed_ms = 0;
+#endif
+    return 0;
+}
+
+}  // extern "C"

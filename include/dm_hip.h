@@ -1,0 +1,111 @@
+/* dm_hip.h -- C-ABI of the MI355X-native DeepMimic imitate environment (libdm_hip.so).
+ *
+ * This is the drop-in boundary for the reference's SWIG class `cDeepMimicCore`
+ * (/root/reference/DeepMimicCore/DeepMimicCore.h:9-119, exported by DeepMimicCore.i:1-34) restricted to
+ * the `--scene imitate` hot path.  One `dm_ctx` owns N independent envs (N = 1 reproduces one
+ * cDeepMimicCore instance) on one GPU and one HIP stream.  Plain pointers and sizes only; every function
+ * returns 0 on success and a negative code on error, `dm_last_error()` gives the message.  The library
+ * never aborts the caller (the reference asserts: DeepMimicCore.cpp:36-40, scenes/SceneBuilder.cpp:60-64).
+ *
+ * Array arguments are HOST pointers unless the name ends in `_dev` / the flag DM_DEVICE_PTRS is given.
+ */
+#ifndef DM_HIP_H
+#define DM_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct dm_ctx dm_ctx;
+
+typedef struct {
+    int num_envs;            /* N independent characters */
+    int device_id;           /* HIP device ordinal */
+    uint64_t seed;           /* cDeepMimicCore::SeedRand (DeepMimicCore.cpp:20-23); keys the per-env reset RNG */
+    int precision;           /* 32 (default, production) or 64 (algorithm-parity build of the same kernels) */
+    int max_contacts;        /* manifold cap per character, <= 20 (0 -> 20) */
+    int env_id_offset;       /* global id of env 0 (multi-GPU shards keep global RNG streams) */
+} dm_create_info;
+
+/* Raw scene tables in the reference's in-memory layout (all host pointers, copied at create time). */
+typedef struct {
+    int num_joints;
+    const double* joint_mat;     /* J x 19  cKinTree::tJointDesc rows   (anim/KinTree.h:24-47)  */
+    const double* body_defs;     /* J x 17  cKinTree::tBodyDef rows     (anim/KinTree.h:49-70)  */
+    const double* pd_params;     /* J x 2   Kp, Kd                      (sim/PDController.cpp:50-93) */
+    int num_frames;
+    const double* frames;        /* F x (1+P) duration + pose           (anim/Motion.cpp:344-378) */
+    int loop;                    /* "Loop": "wrap"                      (anim/Motion.cpp:302-320) */
+    const int32_t* fall_mask;    /* J  fall-contact links               (scenes/SceneSimChar.cpp:460-476) */
+    /* arg-file keys */
+    int num_sim_substeps;        /* --num_sim_substeps */
+    double world_scale;          /* --world_scale (only scales Bullet's absolute tolerances) */
+    double gravity[3];           /* --gravity, default (0,-9.8,0) */
+    int sync_char_root_pos, sync_char_root_rot, enable_fall_end, enable_char_contact_fall;
+    int enable_root_rot_fail, enable_rand_char_placement, enable_rand_rot_reset;
+    double time_lim_min, time_lim_max;   /* episode timer, uniform (util/Timer.cpp:55-73); inf = no limit */
+    /* controller file keys (sim/CtController.cpp:161-172) */
+    int enable_phase_input, record_world_root_pos, record_world_root_rot;
+    double query_rate;
+    /* DM-physics v1 constants; 0 selects the default */
+    double friction, erp; int solver_iters;
+} dm_scene_tables;
+
+enum { DM_DEVICE_PTRS = 1, DM_AUTO_RESET = 2, DM_OPEN_LOOP = 4, DM_NO_EMIT = 8 };
+
+const char* dm_last_error(void);
+
+/* cDeepMimicCore ctor + ParseArgs + Init  (DeepMimicCore.cpp:9-54) */
+int dm_create(const dm_create_info* info, const dm_scene_tables* tables, dm_ctx** out);
+int dm_destroy(dm_ctx* ctx);
+/* GetStateSize / GetGoalSize / GetActionSize (+ pose, links, dofs, frames): out[8] = S,G,A,P,J,D,F,N */
+int dm_dims(const dm_ctx* ctx, int32_t* out);
+double dm_motion_duration(const dm_ctx* ctx);
+/* Run the kernels of this ctx on an external HIP stream (e.g. torch's current stream); NULL restores the own stream */
+int dm_set_stream(dm_ctx* ctx, void* hip_stream);
+int dm_synchronize(dm_ctx* ctx);
+
+/* cDeepMimicCore::Reset (DeepMimicCore.cpp:61-65).  env_ids NULL -> all envs.  kin_times / max_times NULL ->
+ * per-env counter-based RNG: kin time ~ U[0,duration) (scenes/SceneImitate.cpp:494-500), timer ~ U[min,max]. */
+int dm_reset(dm_ctx* ctx, const int32_t* env_ids, int n, const double* kin_times, const double* max_times);
+/* cDeepMimicCore::SetAction for every env (DeepMimicCore.cpp:221-230): actions N x A float32 */
+int dm_set_action(dm_ctx* ctx, const float* actions, int flags);
+/* cDeepMimicCore::Update(timestep) n_updates times for every env (DeepMimicCore.cpp:56-59) */
+int dm_update(dm_ctx* ctx, double timestep, int n_updates);
+/* RecordState / CalcReward / CheckTerminate / CheckValidEpisode / IsEpisodeEnd / NeedNewAction for every env
+ * (DeepMimicCore.cpp:191-204,450-458,...); any output may be NULL */
+int dm_query(dm_ctx* ctx, float* states, float* rewards, int32_t* terminate, int32_t* valid, int32_t* episode_end,
+             int32_t* need_new_action, int flags);
+/* Batched control step = [SetAction] + n_updates x Update + query (+ auto reset), one kernel launch.
+ * actions may be NULL (keep the latched targets).  With DM_AUTO_RESET, envs whose episode ended are reset after
+ * their terminal reward/flags are written and `states` holds the first observation of the new episode. */
+int dm_step_batch(dm_ctx* ctx, const float* actions, double timestep, int n_updates, float* states, float* rewards,
+                  int32_t* terminate, int32_t* valid, int32_t* episode_end, int flags);
+
+/* BuildStateOffset/Scale, BuildActionOffset/Scale/BoundMin/BoundMax, BuildStateNormGroups (DeepMimicCore.cpp:232-448) */
+int dm_build_offsets_scales(const dm_ctx* ctx, double* s_off, double* s_scale, double* a_off, double* a_scale,
+                            double* a_min, double* a_max, int32_t* s_norm_groups);
+
+/* Env state snapshot (parity tests, checkpointing): pose/vel N x P, kin N x 7 (origin pos + rot), clocks N x 5
+ * (kin_time, ctrl_time, init_time_offset, timer_time, timer_max), tar N x P.  Any pointer may be NULL. */
+int dm_get_state(dm_ctx* ctx, double* pose, double* vel, double* tar, double* kin, double* clocks, int32_t* flags);
+int dm_set_state(dm_ctx* ctx, const double* pose, const double* vel, const double* tar, const double* kin,
+                 const double* clocks, const int32_t* flags);
+
+/* Component taps used by the parity tests (no reference analogue): what = 0 SPD torque, 1 one rigid-body
+ * substep of length `dt` with the latched torque, 2 SPD-model mass matrix / bias force.
+ * After the call dm_get_debug copies the requested tap: name in {"H","C","vstar","lambda","rows","tau",
+ * "kin_pose","kin_vel","reward_terms","links"}; out must hold the full N x ... array of doubles. */
+int dm_probe(dm_ctx* ctx, int what, double dt);
+int dm_get_debug(dm_ctx* ctx, const char* name, double* out);
+
+/* Fixed-action rollout timed with HIP events on the ctx stream: `steps` control steps of `n_updates` updates
+ * after `warmup` untimed ones.  actions_dev NULL with DM_OPEN_LOOP tracks the clip.  Returns the elapsed GPU
+ * milliseconds of the timed region in *elapsed_ms. */
+int dm_bench_rollout(dm_ctx* ctx, int warmup, int steps, double timestep, int n_updates, int flags,
+                     float* states_dev, float* rewards_dev, double* elapsed_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

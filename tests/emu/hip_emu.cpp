@@ -75,7 +75,7 @@ void launch(unsigned grid, unsigned block, const std::function<void()>& body) {
             f.stack.resize(kStack);
             uintptr_t top = ((uintptr_t)f.stack.data() + kStack) & ~(uintptr_t)63;
             uint64_t* sp = (uint64_t*)top;
-            *--sp = 0;                              // fake return address slot (alignment)
+            *--sp = 0; *--sp = 0;                   // padding: rsp must be 16-byte aligned at the trampoline's call
             *--sp = (uint64_t)&emu_trampoline;      // ret target
             *--sp = 0;                              // rbp
             *--sp = 0;                              // rbx

@@ -1,0 +1,164 @@
+#!/usr/bin/env python3
+"""Headline benchmark: env-steps/s of the vectorised imitate env (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W [--envs 4096] [--scene humanoid3d_walk]
+
+One "step" = one 30 Hz control step of every env on the rank = one `k_env_step` launch = 20 scene updates
+(20 SPD solves + 40 rigid-body substeps) + reward + observation + auto-reset.  Workload (configs[1] of BASELINE.json):
+humanoid3d_walk, 4096 envs per GPU, fixed-action stream A1 (open-loop mocap tracking, generated on device), inputs
+resident in HBM.  N > 1: one process per GPU (torch.distributed, backend nccl = RCCL), env shards are independent
+(weak scaling); the only collective is the per-step all-gather of (state, reward, terminate) for the learner.
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0     # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def algorithmic_bytes_per_env_step(env):
+    """HBM bytes one env-step must move: env record in + out, observation/reward/flags out."""
+    rec = 4 * (3 * env.P + env.D + 8) + 8 * 6 + 4 * 4            # pose, vel, tar, tau, kin | clocks | flags
+    out = 4 * env.S + 4 + 3 * 4                                   # state, reward, terminate/valid/episode_end
+    return 2 * rec + out
+
+
+def cpu_baseline(tables, budget_s=12.0):
+    """Times the CPU oracle (restatement of the reference path; real DeepMimicCore/Bullet is not buildable here)
+    on this host, single thread, same workload per env: 300-step open-loop rollouts of one humanoid."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    try:
+        import oracle_lib
+        try:
+            oracle_lib.build("native")
+            variant = "native"
+        except Exception:
+            variant = ""
+        o = oracle_lib.Oracle(tables, variant=variant)
+        o.reset(0.0)
+        o.rollout(30)                                  # warm-up
+        steps, secs = 0, 0.0
+        while secs < budget_s:
+            o.reset(0.0)
+            s, _, _ = o.rollout(300)
+            steps += 300; secs += s
+        return {"value": steps / secs, "unit": "env-steps/s", "cores": 1, "kind": "port",
+                "sample": "%d control steps (x20 updates) of 1 env, 300-step open-loop rollouts from t0=0, oracle "
+                          "built -O3%s, single thread" % (steps, " -march=native" if variant else "")}
+    except Exception as ex:  # the baseline is reported, never required
+        return {"value": None, "unit": "env-steps/s", "cores": 1, "kind": "port", "sample": "failed: %r" % (ex,)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--envs", type=int, default=4096, help="envs per GPU")
+    ap.add_argument("--scene", default="humanoid3d_walk")
+    ap.add_argument("--precision", type=int, default=32)
+    ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from deepmimic_amd import model
+    from deepmimic_amd.core import BatchEnv
+
+    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    tables = model.load_asset(args.scene)
+    n = args.envs
+    env = BatchEnv(tables, n, device_id=local_rank, seed=1234, precision=args.precision, env_id_offset=rank * n, test_mode=True)
+    env.set_stream(torch.cuda.current_stream().cuda_stream)
+    env.reset()                                                   # per-env random phase, keyed by the global env id
+    dev = torch.device("cuda", local_rank)
+    states = torch.empty((n, env.S), dtype=torch.float32, device=dev)
+    rewards = torch.empty((n,), dtype=torch.float32, device=dev)
+    term = torch.empty((n,), dtype=torch.int32, device=dev)
+    valid = torch.empty((n,), dtype=torch.int32, device=dev)
+    ends = torch.empty((n,), dtype=torch.int32, device=dev)
+    gather = world > 1 and not args.no_gather
+    if gather:
+        # per-env learner record {state[S], reward, terminate}; gathered with one RCCL all-gather per control step
+        rec = torch.empty((n, env.S + 2), dtype=torch.float32, device=dev)
+        rec_all = torch.empty((world * n, env.S + 2), dtype=torch.float32, device=dev)
+
+    def one_step():
+        env.step_device(0, states.data_ptr(), rewards.data_ptr(), term.data_ptr(), valid.data_ptr(), ends.data_ptr(),
+                        timestep=1.0 / 600, n_updates=20, auto_reset=True, open_loop=True)
+        if gather:
+            rec[:, :env.S] = states; rec[:, env.S] = rewards; rec[:, env.S + 1] = term.to(torch.float32)
+            dist.all_gather_into_tensor(rec_all, rec)
+
+    for _ in range(args.warmup):
+        one_step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    # kernel-only time of the dominant kernel (k_env_step), HIP events on the launch stream
+    k_steps = max(5, min(50, args.steps))
+    kernel_ms = env.bench_rollout(0, k_steps, auto_reset=True, open_loop=True) / k_steps
+    mean_reward = float(rewards.mean().item())
+    finite = bool(torch.isfinite(states).all().item())
+
+    if rank == 0:
+        bytes_per_launch = algorithmic_bytes_per_env_step(env) * n
+        achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
+        value = world * n * args.steps / elapsed
+        out = {
+            "metric": "env-steps/sec at N parallel envs (%s)" % args.scene,
+            "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32" if args.precision == 32 else "f64", "data": "synthetic",
+            "config": {"workload": "%s, %d envs per GPU, fixed-action (open-loop mocap tracking) rollout, auto-reset, "
+                                   "20 updates of 1/600 s x 2 substeps per step" % (args.scene, n),
+                       "envs_per_gpu": n, "parallelism": "env-shards x%d%s" % (world, " + RCCL all-gather of obs" if gather else "")},
+            "sim_updates_per_s": value * 20,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None, "kernel": "k_env_step", "kernel_ms": kernel_ms,
+                         "algorithmic_bytes_per_env_step": algorithmic_bytes_per_env_step(env),
+                         "note": "latency/VALU/LDS-bound by construction (SURVEY 8d): state stays in LDS for 20 updates"},
+            "checks": {"mean_reward": mean_reward, "finite": finite},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(tables)
+        else:
+            out["cpu_baseline"] = {"value": None, "unit": "env-steps/s", "cores": 1, "kind": "port", "sample": "skipped (N>1 or --no-cpu-baseline)"}
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -197,6 +197,10 @@ class BatchEnv:
         flags = None if flags is None else np.ascontiguousarray(flags, dtype=np.int32).reshape(self.N, 4)
         self._chk(self.lib.dm_set_state(self.h, _dp(pose), _dp(vel), _dp(tar), _dp(kin), _dp(clocks), _ip(flags)))
 
+    def set_tau(self, tau):
+        tau = np.ascontiguousarray(tau, dtype=np.float64).reshape(self.N, self.D)
+        self._chk(self.lib.dm_set_tau(self.h, _dp(tau)))
+
     def probe(self, what: int, dt: float):
         self._chk(self.lib.dm_probe(self.h, int(what), C.c_double(dt)))
 

@@ -41,7 +41,7 @@ __device__ __forceinline__ int wave_bcast(int v, int src) { return __shfl(v, src
 
 namespace dmk {
 
-template <typename Real, int NJ, int ND, int NP>
+template <typename Real, int NJ, int ND, int NP, int NCAP>
 struct Lds {
     static constexpr int kYStride = kMaxRows + 1;
     Real pose[NP], vel[NP], tar[NP];
@@ -53,8 +53,8 @@ struct Lds {
     Real H[ND][ND + 1];
     Real scratch[ND * kYStride];          // Y = L^-1 J^T during the constraint solve; kin pose / vel at emit time
     Real row_b[kMaxRows], lam[kMaxRows];
-    Real cx[kMaxCand][3], cdist[kMaxCand];
-    int csel[kMaxCand], cslot[kMaxRows];
+    Real cx[NCAP][3], cdist[NCAP];     // ground-contact candidates (NCAP = 64 or 128)
+    int csel[NCAP], cslot[kMaxRows];
     Real kin[8];                           // kin origin pos(3), origin rot(4)
     Real sc[24];                           // small float scratch
     double clk[6];                         // kin_time, ctrl_time, init_time_offset, timer_time, timer_max
@@ -64,9 +64,9 @@ struct Lds {
 enum { CLK_KIN = 0, CLK_CTRL, CLK_INIT_OFF, CLK_TIMER, CLK_TIMER_MAX };
 enum { FLG_NEED_ACTION = 0, FLG_CONTACT, FLG_EPISODE, FLG_VALID, FLG_NROWS, FLG_NCONT };
 
-template <typename Real, int NJ, int ND, int NP>
+template <typename Real, int NJ, int ND, int NP, int NCAP>
 struct EnvSim {
-    typedef Lds<Real, NJ, ND, NP> L;
+    typedef Lds<Real, NJ, ND, NP, NCAP> L;
     typedef V3<Real> v3; typedef Q4<Real> q4; typedef M3<Real> m3;
     const ModelDev<Real>& m; L& s; const int l;
     DM_DEV EnvSim(const ModelDev<Real>& m_, L& s_, int l_) : m(m_), s(s_), l(l_) {}
@@ -330,29 +330,49 @@ struct EnvSim {
         sync();
         if (dbg.vstar && l < D) dbg.vstar[(size_t)e * D + l] = s.vstar[l];
 
-        // ---- collision detection: lane = candidate point
-        bool active = false; Real dist = 0; int link = 0;
-        if (l < m.NC) {
-            link = m.cand_link[l];
-            v3 x = ld3(s.com[link]) + ldm3(s.Rb[link]) * ld3(m.cand_loc + l * 3);
-            x.y -= m.cand_rad[l];
-            dist = x.y;
-            st3(s.cx[l], x); s.cdist[l] = dist;
-            active = dist < m.thresh[link];
-            if (dist <= m.report_dist) dm_atomic_or(&s.flg[FLG_CONTACT], 1 << link);
+        // ---- collision detection: lane = candidate point (CPL candidates per lane when NC > 64)
+        constexpr int CPL = NCAP / kWave;
+        bool active[CPL]; Real dist[CPL];
+#pragma unroll
+        for (int q = 0; q < CPL; ++q) {
+            const int c = l + kWave * q;
+            active[q] = false; dist[q] = 0;
+            if (c < m.NC) {
+                int link = m.cand_link[c];
+                v3 x = ld3(s.com[link]) + ldm3(s.Rb[link]) * ld3(m.cand_loc + c * 3);
+                x.y -= m.cand_rad[c];
+                dist[q] = x.y;
+                st3(s.cx[c], x); s.cdist[c] = x.y;
+                active[q] = x.y < m.thresh[link];
+                if (x.y <= m.report_dist) dm_atomic_or(&s.flg[FLG_CONTACT], 1 << link);
+            }
+            s.csel[c] = active[q] ? 1 : 0;
         }
-        s.csel[l] = active ? 1 : 0;
         sync();
         // manifold reduction: keep the max_contacts deepest, ties to the lower index; compact in index order
-        int rank = 0;
-        if (active) for (int c = 0; c < m.NC; ++c) if (s.csel[c] && (s.cdist[c] < dist || (s.cdist[c] == dist && c < l))) ++rank;
+        int rank[CPL];
+#pragma unroll
+        for (int q = 0; q < CPL; ++q) {
+            const int c = l + kWave * q; rank[q] = 0;
+            if (active[q]) for (int k = 0; k < m.NC; ++k) if (s.csel[k] && (s.cdist[k] < dist[q] || (s.cdist[k] == dist[q] && k < c))) ++rank[q];
+        }
         sync();
-        bool sel = active && rank < m.max_contacts;
-        s.csel[l] = sel ? 1 : 0;
+#pragma unroll
+        for (int q = 0; q < CPL; ++q) { active[q] = active[q] && rank[q] < m.max_contacts; s.csel[l + kWave * q] = active[q] ? 1 : 0; }
         sync();
-        int slot = 0, nc = 0;
-        for (int c = 0; c < m.NC; ++c) { int v = s.csel[c]; nc += v; if (c < l) slot += v; }
-        if (sel) s.cslot[slot] = l;
+        int nc = 0;
+        {
+            int slot[CPL];
+#pragma unroll
+            for (int q = 0; q < CPL; ++q) slot[q] = 0;
+            for (int k = 0; k < m.NC; ++k) {
+                int v = s.csel[k]; nc += v;
+#pragma unroll
+                for (int q = 0; q < CPL; ++q) if (k < l + kWave * q) slot[q] += v;
+            }
+#pragma unroll
+            for (int q = 0; q < CPL; ++q) if (active[q]) s.cslot[slot[q]] = l + kWave * q;
+        }
         const int NL = m.NL;
         const int R = NL + 3 * nc;
         if (l == 0) { s.flg[FLG_NROWS] = R; s.flg[FLG_NCONT] = nc; }
@@ -756,11 +776,11 @@ DM_HD double dm_rand01(uint64_t seed, uint64_t env, uint64_t episode, uint64_t s
 
 // ============================================================================ kernels
 // grid = number of envs, block = one wavefront.
-template <typename Real, int NJ, int ND, int NP>
+template <typename Real, int NJ, int ND, int NP, int NCAP>
 __global__ void __launch_bounds__(64) k_env_step(ModelDev<Real> m, EnvState<Real> st, StepIO<Real> io, DebugTaps<Real> dbg) {
-    __shared__ Lds<Real, NJ, ND, NP> lds;
+    __shared__ Lds<Real, NJ, ND, NP, NCAP> lds;
     const int e = blockIdx.x, l = threadIdx.x;
-    EnvSim<Real, NJ, ND, NP> sim(m, lds, l);
+    EnvSim<Real, NJ, ND, NP, NCAP> sim(m, lds, l);
     sim.load(st, e);
     if (io.open_loop) sim.set_action_from_clip();
     else if (io.actions) sim.set_action(io.actions + (size_t)e * m.A);
@@ -784,12 +804,12 @@ __global__ void __launch_bounds__(64) k_env_step(ModelDev<Real> m, EnvState<Real
 }
 
 // reset the envs listed in env_ids (or all when env_ids == null); kin_times / max_times optional per listed env
-template <typename Real, int NJ, int ND, int NP>
+template <typename Real, int NJ, int ND, int NP, int NCAP>
 __global__ void __launch_bounds__(64) k_env_reset(ModelDev<Real> m, EnvState<Real> st, const int* env_ids, const double* kin_times, const double* max_times) {
-    __shared__ Lds<Real, NJ, ND, NP> lds;
+    __shared__ Lds<Real, NJ, ND, NP, NCAP> lds;
     const int b = blockIdx.x, l = threadIdx.x;
     const int e = env_ids ? env_ids[b] : b;
-    EnvSim<Real, NJ, ND, NP> sim(m, lds, l);
+    EnvSim<Real, NJ, ND, NP, NCAP> sim(m, lds, l);
     sim.load(st, e);
     uint64_t ep = (uint64_t)lds.flg[FLG_EPISODE];
     double kt = kin_times ? kin_times[b] : m.duration * dm_rand01(m.seed, (uint64_t)(e + m.env_off), ep, 0);
@@ -800,28 +820,28 @@ __global__ void __launch_bounds__(64) k_env_reset(ModelDev<Real> m, EnvState<Rea
 }
 
 // observation / reward / flags for the current state without stepping (RecordState, CalcReward, CheckTerminate)
-template <typename Real, int NJ, int ND, int NP>
+template <typename Real, int NJ, int ND, int NP, int NCAP>
 __global__ void __launch_bounds__(64) k_env_query(ModelDev<Real> m, EnvState<Real> st, StepIO<Real> io, DebugTaps<Real> dbg) {
-    __shared__ Lds<Real, NJ, ND, NP> lds;
+    __shared__ Lds<Real, NJ, ND, NP, NCAP> lds;
     const int e = blockIdx.x, l = threadIdx.x;
-    EnvSim<Real, NJ, ND, NP> sim(m, lds, l);
+    EnvSim<Real, NJ, ND, NP, NCAP> sim(m, lds, l);
     sim.load(st, e);
     sim.emit(io, dbg, e);
 }
 
 // component taps for parity tests: SPD torque for the stored state / one substep with the stored torque
-template <typename Real, int NJ, int ND, int NP>
+template <typename Real, int NJ, int ND, int NP, int NCAP>
 __global__ void __launch_bounds__(64) k_env_probe(ModelDev<Real> m, EnvState<Real> st, DebugTaps<Real> dbg, int what, double dt) {
-    __shared__ Lds<Real, NJ, ND, NP> lds;
+    __shared__ Lds<Real, NJ, ND, NP, NCAP> lds;
     const int e = blockIdx.x, l = threadIdx.x;
-    EnvSim<Real, NJ, ND, NP> sim(m, lds, l);
+    EnvSim<Real, NJ, ND, NP, NCAP> sim(m, lds, l);
     sim.load(st, e);
     if (what == 0) {                       // SPD
         sim.spd((Real)dt);
     } else if (what == 1) {                // substep
         sim.substep((Real)dt, dbg, e);
     } else if (what == 2) {                // dynamics only (SPD model) -> H, C taps
-        typename EnvSim<Real, NJ, ND, NP>::v3 v0 = ld3(lds.vel), w0 = ld3(lds.vel + 3);
+        typename EnvSim<Real, NJ, ND, NP, NCAP>::v3 v0 = ld3(lds.vel), w0 = ld3(lds.vel + 3);
         M3<Real> E = quat_to_rot(ldq(lds.pose + 3));
         sim.kinematics(lds.pose, lds.vel, sim.gravity_a0() + cross(v0, E * w0 - w0));
         sim.dynamics(0);

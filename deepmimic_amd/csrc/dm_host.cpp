@@ -176,7 +176,7 @@ static int build_host_model(const dm_scene_tables& t, int max_contacts, HostMode
         else if (shape == SH_BOX) for (int s = 0; s < 8; ++s) add((s & 1) ? -0.5 * p0 : 0.5 * p0, (s & 2) ? -0.5 * p1 : 0.5 * p1, (s & 4) ? -0.5 * p2 : 0.5 * p2, 0);
     }
     hm.NC = (int)hm.cand_link.size();
-    if (hm.NC > kMaxCand) return fail("more than 64 ground-contact candidate points");
+    if (hm.NC > 128) return fail("more than 128 ground-contact candidate points");
     if (hm.NL + 3 * max_contacts > kMaxRows) return fail("limit rows + 3*max_contacts exceeds 64 constraint rows");
 
     // ---- motion clip
@@ -246,6 +246,7 @@ struct CtxBase {
     virtual int get_state(double* pose, double* vel, double* tar, double* kin, double* clk, int* flg) = 0;
     virtual int set_state(const double* pose, const double* vel, const double* tar, const double* kin, const double* clk, const int* flg) = 0;
     virtual int get_debug(const char* name, double* out) = 0;
+    virtual int set_tau(const double* tau) = 0;
 };
 
 template <typename Real>
@@ -290,7 +291,7 @@ struct CtxT : CtxBase {
         d_actions = (float*)dalloc(sizeof(float) * N * h.A); d_states = (float*)dalloc(sizeof(float) * N * h.S); d_rewards = (float*)dalloc(sizeof(float) * N);
         d_term = (int*)dalloc(sizeof(int) * N); d_valid = (int*)dalloc(sizeof(int) * N); d_end = (int*)dalloc(sizeof(int) * N);
         if (!st.pose || !st.flag || !d_end) return fail("device allocation failed");
-        if (h.J <= 15 && h.D <= 34 && h.P <= 43) cls = 0; else if (h.J <= 23 && h.D <= 64 && h.P <= 83) cls = 1; else return fail("character too large for the compiled kernel classes (J<=23, D<=64, P<=83)");
+        if (h.J <= 15 && h.D <= 34 && h.P <= 43 && h.NC <= 64) cls = 0; else if (h.J <= 23 && h.D <= 64 && h.P <= 83) cls = 1; else return fail("character too large for the compiled kernel classes (J<=23, D<=64, P<=83)");
         // PD targets start at identity rotations (cPDController::PostProcessTargetPose, PDController.cpp:425-443)
         std::vector<Real> tar((size_t)N * h.P, 0);
         for (int e = 0; e < N; ++e) for (int j = 1; j < h.J; ++j) if (h.jtype[j] == JT_SPHERICAL) tar[(size_t)e * h.P + h.pose_off[j]] = 1;
@@ -310,8 +311,8 @@ struct CtxT : CtxBase {
     }
 #define DM_DISPATCH(KERN, grid, ...)                                                         \
     do {                                                                                     \
-        if (cls == 0) RT_LAUNCH((KERN<Real, 15, 34, 43>), grid, stream, __VA_ARGS__);        \
-        else RT_LAUNCH((KERN<Real, 23, 64, 83>), grid, stream, __VA_ARGS__);                 \
+        if (cls == 0) RT_LAUNCH((KERN<Real, 15, 34, 43, 64>), grid, stream, __VA_ARGS__);        \
+        else RT_LAUNCH((KERN<Real, 23, 64, 83, 128>), grid, stream, __VA_ARGS__);                 \
     } while (0)
 
     int reset(const int* ids_dev, int n, const double* kt_dev, const double* mt_dev) override {
@@ -365,6 +366,7 @@ struct CtxT : CtxBase {
         if (flg && rt_h2d(st.flag, flg, sizeof(int) * n * 4, stream)) return fail("copy failed");
         return 0;
     }
+    int set_tau(const double* tau) override { return ul(st.tau, (size_t)N * hm.D, tau); }
     int get_debug(const char* name, double* out) override {
         const size_t n = N; const HostModel& h = hm; std::string s(name);
         if (s == "tau") return dl(st.tau, n * h.D, out);
@@ -527,6 +529,7 @@ int dm_set_state(dm_ctx* ctx, const double* pose, const double* vel, const doubl
     return ctx->c->set_state(pose, vel, tar, kin, clocks, flags);
 }
 int dm_probe(dm_ctx* ctx, int what, double dt) { if (!ctx) return fail("null ctx"); int rc = ctx->c->probe(what, dt); rt_sync(ctx->c->stream); return rc; }
+int dm_set_tau(dm_ctx* ctx, const double* tau) { if (!ctx || !tau) return fail("null argument"); return ctx->c->set_tau(tau); }
 int dm_get_debug(dm_ctx* ctx, const char* name, double* out) { if (!ctx || !name || !out) return fail("null argument"); return ctx->c->get_debug(name, out); }
 
 int dm_bench_rollout(dm_ctx* ctx, int warmup, int steps, double timestep, int n_updates, int flags, float* states_dev, float* rewards_dev, double* elapsed_ms) {

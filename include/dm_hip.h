@@ -97,6 +97,7 @@ int dm_set_state(dm_ctx* ctx, const double* pose, const double* vel, const doubl
  * After the call dm_get_debug copies the requested tap: name in {"H","C","vstar","lambda","rows","tau",
  * "kin_pose","kin_vel","reward_terms","links"}; out must hold the full N x ... array of doubles. */
 int dm_probe(dm_ctx* ctx, int what, double dt);
+int dm_set_tau(dm_ctx* ctx, const double* tau /* N x D, generalized-velocity layout */);
 int dm_get_debug(dm_ctx* ctx, const char* name, double* out);
 
 /* Fixed-action rollout timed with HIP events on the ctx stream: `steps` control steps of `n_updates` updates

@@ -1,0 +1,54 @@
+"""Kernel logic vs oracle on the CPU: the product's device + host sources compiled for the fiber emulator.
+
+These run without a GPU (`-m "not gpu"`).  The same checks run against the real library in test_parity_gpu.py.
+"""
+import numpy as np
+import pytest
+
+import parity_common as pc
+
+
+@pytest.mark.parametrize("name", ["humanoid3d_walk", "dog3d_pace"])
+def test_reset_query_fp64(emu_lib, name):
+    pc.check_reset_and_query(name, 64, emu_lib, tol_state=1e-12, tol_reward=1e-6)
+
+
+@pytest.mark.parametrize("name", ["humanoid3d_walk", "dog3d_pace"])
+def test_dynamics_fp64(emu_lib, name):
+    pc.check_dynamics(name, 64, emu_lib, rtol=1e-11)
+
+
+def test_dynamics_fp32(emu_lib):
+    pc.check_dynamics("humanoid3d_walk", 32, emu_lib, rtol=2e-5)
+
+
+@pytest.mark.parametrize("name", ["humanoid3d_walk", "dog3d_pace"])
+def test_spd_fp64(emu_lib, name):
+    pc.check_spd(name, 64, emu_lib, rtol=1e-9)
+
+
+def test_spd_fp32(emu_lib):
+    pc.check_spd("humanoid3d_walk", 32, emu_lib, rtol=2e-3)
+
+
+@pytest.mark.parametrize("name,lift", [("humanoid3d_walk", 0.0), ("humanoid3d_walk", -0.03), ("dog3d_pace", 0.0)])
+def test_substep_fp64(emu_lib, name, lift):
+    nc = pc.check_substep(name, 64, emu_lib, tol_vel=1e-8, tol_pose=1e-10, lift=lift)
+    if lift < 0:
+        assert nc > 0      # the pushed-down batch must exercise the contact solver
+
+
+def test_rollout_fp64_matches_oracle(emu_lib):
+    dr, ds, ok = pc.rollout_compare("humanoid3d_walk", 64, emu_lib, steps=8)
+    assert ok and dr.max() < 1e-6 and ds.max() < 1e-5      # outputs are float32 at the boundary
+
+
+def test_rollout_fp32_reward_tolerance(emu_lib):
+    # fp32 production kernel vs fp64 oracle: BASELINE tolerance is 1e-4 on the reward
+    dr, ds, ok = pc.rollout_compare("humanoid3d_walk", 32, emu_lib, steps=12)
+    assert ok and dr.max() < 1e-4
+
+
+def test_open_loop_path_equals_action_path(emu_lib):
+    dr, ds, ok = pc.rollout_compare("humanoid3d_walk", 64, emu_lib, steps=3, t0=0.4, open_loop_on_device=True)
+    assert ok and dr.max() < 1e-6

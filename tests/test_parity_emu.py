@@ -52,3 +52,8 @@ def test_rollout_fp32_reward_tolerance(emu_lib):
 def test_open_loop_path_equals_action_path(emu_lib):
     dr, ds, ok = pc.rollout_compare("humanoid3d_walk", 64, emu_lib, steps=3, t0=0.4, open_loop_on_device=True)
     assert ok and dr.max() < 1e-6
+
+
+def test_stepwise_resync_spinkick_fp64(emu_lib):
+    dr, ds, ok = pc.rollout_compare("humanoid3d_spinkick", 64, emu_lib, steps=30, resync=True)
+    assert ok and dr.max() < 1e-6 and ds.max() < 1e-4

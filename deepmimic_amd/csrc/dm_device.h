@@ -21,6 +21,7 @@
 #include "dm_types.h"
 
 #ifdef DM_EMU
+static inline long long dm_clock() { return 0; }
 #define DM_DEV inline
 static inline int dm_atomic_or(int* p, int v) { int o = *p; *p = o | v; return o; }
 namespace dmk {
@@ -31,6 +32,7 @@ template <typename T> static inline T wave_bcast(T v, int src) {
 }
 #else
 #define DM_DEV __device__ __forceinline__
+__device__ __forceinline__ long long dm_clock() { return (long long)__builtin_readcyclecounter(); }
 __device__ __forceinline__ int dm_atomic_or(int* p, int v) { return atomicOr(p, v); }
 namespace dmk {
 __device__ __forceinline__ float wave_bcast(float v, int src) { return __shfl(v, src, 64); }
@@ -69,7 +71,9 @@ struct EnvSim {
     typedef Lds<Real, NJ, ND, NP, NCAP> L;
     typedef V3<Real> v3; typedef Q4<Real> q4; typedef M3<Real> m3;
     const ModelDev<Real>& m; L& s; const int l;
+    long long* prof = nullptr; long long tprev = 0;     // phase-cycle accounting (profiling kernel only)
     DM_DEV EnvSim(const ModelDev<Real>& m_, L& s_, int l_) : m(m_), s(s_), l(l_) {}
+    DM_DEV void mark(int phase) { if (prof) { long long t = dm_clock(); if (l == 0) prof[phase] += t - tprev; tprev = t; } }
     DM_DEV void sync() const { __syncthreads(); }
     DM_DEV Real* Y(int k) const { return s.scratch + k * L::kYStride; }
 
@@ -253,8 +257,11 @@ struct EnvSim {
         v3 v0 = ld3(s.vel), w0 = ld3(s.vel + 3);
         m3 E = quat_to_rot(ldq(s.pose + 3));
         v3 a0 = gravity_a0() + cross(v0, E * w0 - w0);
+        mark(0);
         kinematics(s.pose, s.vel, a0);
+        mark(1);
         dynamics(0);
+        mark(2);
         if (l < m.J && l > 0) {            // pose error per joint -> rhs = Kp e + Kd (0 - qd)
             int jt = m.jtype[l], off = m.pose_off[l], dof = m.dof_off[l];
             if (jt == JT_SPHERICAL) {
@@ -273,9 +280,11 @@ struct EnvSim {
         sync();
         if (l < D) { s.rhs[l] = s.xs[l] - s.bias[l]; s.H[l][l] += dt * m.kd[l]; }
         sync();
+        mark(4);
         cholesky();
         solve_lower(s.rhs);
         solve_upper(s.rhs);                // rhs = qddot
+        mark(3);
         if (l < D) s.tau[l] = (l < 6) ? (Real)0 : s.xs[l] - m.kd[l] * dt * s.rhs[l];
         sync();
         if (l < m.J && l > 0) {            // clamp the torque norm per joint (SimBodyJoint.cpp:299-307)
@@ -318,8 +327,11 @@ struct EnvSim {
 
     DM_DEV void substep(Real h, DebugTaps<Real> dbg, int e) {
         const int D = m.D, J = m.J;
+        mark(4);
         kinematics(s.pose, s.vel, gravity_a0());
+        mark(5);
         dynamics(1);
+        mark(6);
         if (dbg.H) { for (int i = l; i < D * D; i += kWave) dbg.H[(size_t)e * D * D + i] = s.H[i / D][i % D]; if (l < D) dbg.C[(size_t)e * D + l] = s.bias[l]; }
         cholesky();
         if (l < D) s.rhs[l] = s.tau[l] - s.bias[l];
@@ -330,6 +342,7 @@ struct EnvSim {
         sync();
         if (dbg.vstar && l < D) dbg.vstar[(size_t)e * D + l] = s.vstar[l];
 
+        mark(7);
         // ---- collision detection: lane = candidate point (CPL candidates per lane when NC > 64)
         constexpr int CPL = NCAP / kWave;
         bool active[CPL]; Real dist[CPL];
@@ -378,6 +391,7 @@ struct EnvSim {
         if (l == 0) { s.flg[FLG_NROWS] = R; s.flg[FLG_NCONT] = nc; }
         sync();
 
+        mark(8);
         // ---- constraint rows: lane = row.  limits | normals | frictions (2 per contact)
         Real b = 0, cvec = 0; int nrow = -1;
         if (l < R) {
@@ -409,6 +423,7 @@ struct EnvSim {
             }
         }
         sync();
+        mark(9);
         // A = Y^T Y: each lane keeps its own row of A in registers
         Real arow[kMaxRows];
 #pragma unroll
@@ -417,6 +432,7 @@ struct EnvSim {
             if (r < R && l < R) for (int k = 0; k < D; ++k) acc += Y(k)[l] * Y(k)[r];
             arow[r] = acc;
         }
+        mark(10);
         // projected Gauss-Seidel in impulse space; u = J v* + A lambda is kept per lane
         Real lam = 0, u = cvec;
         Real adiag = 1;
@@ -440,6 +456,7 @@ struct EnvSim {
         }
         s.lam[l] = (l < R) ? lam : (Real)0;
         sync();
+        mark(11);
         if (dbg.lambda) { dbg.lambda[(size_t)e * kMaxRows + l] = s.lam[l]; if (l < 2) dbg.rows[(size_t)e * 2 + l] = s.flg[FLG_NROWS + l]; }
         // delta v = L^-T (Y lambda)
         if (l < D) { Real z = 0; for (int r = 0; r < R; ++r) z += Y(l)[r] * s.lam[r]; s.xs[l] = z; }
@@ -460,6 +477,7 @@ struct EnvSim {
             } else if (jt == JT_REVOLUTE) s.pose[off] += h * s.vel[off];
         }
         sync();
+        mark(12);
     }
 
     // ------------------------------------------------------------------ reference motion
@@ -781,9 +799,11 @@ __global__ void __launch_bounds__(64) k_env_step(ModelDev<Real> m, EnvState<Real
     __shared__ Lds<Real, NJ, ND, NP, NCAP> lds;
     const int e = blockIdx.x, l = threadIdx.x;
     EnvSim<Real, NJ, ND, NP, NCAP> sim(m, lds, l);
+    if (dbg.prof) { sim.prof = dbg.prof + (size_t)e * 16; sim.tprev = dm_clock(); }
     sim.load(st, e);
     if (io.open_loop) sim.set_action_from_clip();
     else if (io.actions) sim.set_action(io.actions + (size_t)e * m.A);
+    sim.mark(15);
     for (int u = 0; u < io.n_updates; ++u) sim.update(io.dt, dbg, e);
     if (io.emit) {
         sim.emit(io, dbg, e);
@@ -799,8 +819,10 @@ __global__ void __launch_bounds__(64) k_env_step(ModelDev<Real> m, EnvState<Real
             DebugTaps<Real> nodbg = DebugTaps<Real>();
             sim.emit(io2, nodbg, e);
         }
+        sim.mark(13);
     }
     sim.store(st, e);
+    sim.mark(14);
 }
 
 // reset the envs listed in env_ids (or all when env_ids == null); kin_times / max_times optional per listed env

@@ -45,7 +45,8 @@ static int rt_sync(rt_stream) { return 0; }
 #else
 typedef hipStream_t rt_stream;
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
-static int rt_malloc(void** p, size_t n) { hipError_t e = hipMalloc(p, n ? n : 1); if (e != hipSuccess) return -1; hipMemset(*p, 0, n ? n : 1); return 0; }
+// zero-fill synchronously: a null-stream hipMemset is not ordered against the ctx's non-blocking stream
+static int rt_malloc(void** p, size_t n) { hipError_t e = hipMalloc(p, n ? n : 1); if (e != hipSuccess) return -1; if (hipMemset(*p, 0, n ? n : 1) != hipSuccess) return -1; return hipDeviceSynchronize() == hipSuccess ? 0 : -1; }
 static void rt_free(void* p) { (void)hipFree(p); }
 static int rt_h2d(void* d, const void* h, size_t n, rt_stream s) { if (hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, s) != hipSuccess) return -1; return hipStreamSynchronize(s) == hipSuccess ? 0 : -1; }
 static int rt_d2h(void* h, const void* d, size_t n, rt_stream s) { if (hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, s) != hipSuccess) return -1; return hipStreamSynchronize(s) == hipSuccess ? 0 : -1; }
@@ -251,7 +252,7 @@ struct CtxBase {
 
 template <typename Real>
 struct CtxT : CtxBase {
-    ModelDev<Real> md; EnvState<Real> st; DebugTaps<Real> dbg; int cls = 0;
+    ModelDev<Real> md; EnvState<Real> st; DebugTaps<Real> dbg; int cls = 0; long long* d_prof = nullptr;
 
     template <typename T, typename U> const T* up(const std::vector<U>& v) {
         std::vector<T> tmp(v.size()); for (size_t i = 0; i < v.size(); ++i) tmp[i] = (T)v[i];
@@ -307,6 +308,7 @@ struct CtxT : CtxBase {
         dbg.lambda = (Real*)dalloc(sizeof(Real) * N * kMaxRows); dbg.rows = (int*)dalloc(sizeof(int) * N * 2);
         dbg.kin_pose = (Real*)dalloc(sizeof(Real) * N * h.P); dbg.kin_vel = (Real*)dalloc(sizeof(Real) * N * h.P);
         dbg.reward_terms = (Real*)dalloc(sizeof(Real) * N * 5); dbg.links = (Real*)dalloc(sizeof(Real) * N * h.J * 21);
+        d_prof = (long long*)dalloc(sizeof(long long) * N * 16);
         return dbg.links ? 0 : fail("device allocation failed");
     }
 #define DM_DISPATCH(KERN, grid, ...)                                                         \
@@ -334,6 +336,15 @@ struct CtxT : CtxBase {
     }
     int probe(int what, double dt) override {
         if (alloc_dbg() != 0) return -1;
+        if (what == 3) {   // one profiled control step (open-loop, 20 updates): per-phase cycle counts -> tap "prof"
+            rt_memset(d_prof, 0, sizeof(long long) * N * 16, stream);
+            DebugTaps<Real> d2; memset(&d2, 0, sizeof(d2)); d2.prof = d_prof;
+            StepIO<Real> io; memset(&io, 0, sizeof(io));
+            io.states = d_states; io.rewards = d_rewards; io.terminate = d_term; io.valid = d_valid; io.episode_end = d_end;
+            io.n_updates = 20; io.dt = dt; io.auto_reset = 1; io.emit = 1; io.open_loop = 1;
+            DM_DISPATCH(k_env_step, N, md, st, io, d2);
+            return 0;
+        }
         DM_DISPATCH(k_env_probe, N, md, st, dbg, what, dt);
         return 0;
     }
@@ -380,6 +391,7 @@ struct CtxT : CtxBase {
         if (s == "kin_vel") return dl(dbg.kin_vel, n * h.P, out);
         if (s == "reward_terms") return dl(dbg.reward_terms, n * 5, out);
         if (s == "links") return dl(dbg.links, n * h.J * 21, out);
+        if (s == "prof") return dl(d_prof, n * 16, out);
         return fail("unknown debug tap: " + s);
     }
 };

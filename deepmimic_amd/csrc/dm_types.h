@@ -98,6 +98,7 @@ struct DebugTaps {
     Real* kin_vel;  // N x P
     Real* reward_terms; // N x 5
     Real* links;    // N x J x 21 (com3, Rb9, vcom3, w3, joint3)
+    long long* prof; // N x 16 accumulated shader-clock cycles per phase (profiling build of the step kernel only)
 };
 
 }  // namespace dmk

@@ -29,6 +29,12 @@ template <typename T> static inline T wave_bcast(T v, int src) {
     T* x = reinterpret_cast<T*>(emu::g_xchg);
     x[threadIdx.x] = v; __syncthreads(); T r = x[src]; __syncthreads(); return r;
 }
+template <typename T> static inline T lane_bcast(T v, int src) { return wave_bcast(v, src); }
+template <typename Real> struct RowFile {       // per-lane array indexed by a wave-uniform runtime index
+    Real v[kMaxRows];
+    inline Real get(int r) const { return v[r]; }
+    inline void set(int r, Real x) { v[r] = x; }
+};
 }
 #else
 #define DM_DEV __device__ __forceinline__
@@ -38,6 +44,26 @@ namespace dmk {
 __device__ __forceinline__ float wave_bcast(float v, int src) { return __shfl(v, src, 64); }
 __device__ __forceinline__ double wave_bcast(double v, int src) { return __shfl(v, src, 64); }
 __device__ __forceinline__ int wave_bcast(int v, int src) { return __shfl(v, src, 64); }
+// broadcast from a wave-uniform lane: v_readlane_b32 (no LDS traffic, SGPR result)
+__device__ __forceinline__ float lane_bcast(float v, int src) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src)); }
+__device__ __forceinline__ double lane_bcast(double v, int src) {
+    long long b = __builtin_bit_cast(long long, v);
+    int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), src), hi = __builtin_amdgcn_readlane((int)(b >> 32), src);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (long long)(unsigned)lo);
+}
+// per-lane array indexed by a wave-uniform runtime index.  For float it is two 32-wide register vectors that the
+// backend addresses with v_movrels/v_movreld (M0-relative VGPR indexing), so the row of A never leaves the VGPRs.
+template <typename Real> struct RowFile {
+    Real v[kMaxRows];
+    __device__ __forceinline__ Real get(int r) const { return v[r]; }
+    __device__ __forceinline__ void set(int r, Real x) { v[r] = x; }
+};
+template <> struct RowFile<float> {
+    typedef float v32 __attribute__((ext_vector_type(32)));
+    v32 a, b;
+    __device__ __forceinline__ float get(int r) const { return (r < 32) ? a[r] : b[r - 32]; }
+    __device__ __forceinline__ void set(int r, float x) { if (r < 32) a[r] = x; else b[r - 32] = x; }
+};
 }
 #endif
 
@@ -52,7 +78,9 @@ struct Lds {
     Real f[NJ][3], n[NJ][3], Iw[NJ][6];
     Real Fs[NJ][3], Ns[NJ][3], Ic[NJ][10];
     Real axis[ND][3];
-    Real H[ND][ND + 1];
+    static constexpr int kHS = ((ND + 3) / 4) * 4 + (((((ND + 3) / 4)) % 2 == 0) ? 4 : 0);   // row stride: 16-B multiple, odd count of 16-B slots
+    alignas(16) Real H[ND][kHS];
+    Real dinv[ND];                         // 1 / L_kk of the current Cholesky factor
     Real scratch[ND * kYStride];          // Y = L^-1 J^T during the constraint solve; kin pose / vel at emit time
     Real row_b[kMaxRows], lam[kMaxRows];
     Real cx[NCAP][3], cdist[NCAP];     // ground-contact candidates (NCAP = 64 or 128)
@@ -211,41 +239,65 @@ struct EnvSim {
         sync();
     }
 
-    // ------------------------------------------------------------------ dense SPD linear algebra on s.H (lower triangle)
-    DM_DEV void cholesky() {
+    // ------------------------------------------------------------------ dense SPD linear algebra, register resident
+    // Lane i owns row i of H.  The factorisation and the triangular solves run entirely in VGPRs with
+    // v_readlane broadcasts (no LDS round trips, no barriers); the factor L and 1/diag(L) are written back to LDS
+    // for the per-row forward substitutions of the constraint solve.  All loops are fully unrolled (ND is the
+    // compile-time dof count of the kernel class), so every register-array index is static.
+    //
+    // Factor s.H = L L^T; when do_solve, also x := H^-1 x for the LDS vector x (length D).
+    DM_DEV void chol_solve(Real* xvec, bool do_solve) {
         const int D = m.D;
-        for (int k = 0; k < D; ++k) {
-            Real piv = s.H[k][k];
+        Real h[ND];
+#pragma unroll
+        for (int k = 0; k < ND; ++k) h[k] = (l < D && k < D) ? s.H[l < ND ? l : 0][k] : ((l == k) ? (Real)1 : (Real)0);
+        Real dinv = 1;
+#pragma unroll
+        for (int k = 0; k < ND; ++k) {
+            Real piv = lane_bcast(h[k], k);
             Real inv = (Real)1 / dm_sqrt(piv);
-            sync();
-            if (l >= k && l < D) s.H[l][k] = s.H[l][k] * inv;      // column k of L (lane k writes L_kk = sqrt(piv))
-            sync();
-            if (l > k && l < D) {
-                Real lik = s.H[l][k];
-                for (int j = k + 1; j <= l; ++j) s.H[l][j] -= lik * s.H[j][k];
+            Real lik = h[k] * inv;
+            h[k] = lik;
+            if (l == k) dinv = inv;
+#pragma unroll
+            for (int j = k + 1; j < ND; ++j) h[j] -= lik * lane_bcast(lik, j);
+        }
+        if (l < ND) {
+#pragma unroll
+            for (int k = 0; k < ND; ++k) s.H[l][k] = h[k];
+            s.dinv[l] = dinv;
+        }
+        Real x = 0;
+        if (do_solve) {
+            x = (l < D) ? xvec[l] : (Real)0;
+#pragma unroll
+            for (int k = 0; k < ND; ++k) {
+                Real t = x * dinv; Real xk = lane_bcast(t, k);
+                if (l == k) x = t; else if (l > k) x -= h[k] * xk;
             }
-            sync();
         }
+        sync();
+        if (do_solve) { x = back_substitute(x, dinv); if (l < D) xvec[l] = x; sync(); }
     }
-    // x := L^-1 x  (x in LDS, length D)
-    DM_DEV void solve_lower(Real* x) {
-        const int D = m.D;
-        for (int k = 0; k < D; ++k) {
-            if (l == k) x[k] = x[k] / s.H[k][k];
-            sync();
-            if (l > k && l < D) x[l] -= s.H[l][k] * x[k];
-            sync();
+    // x_l := (L^-T x)_l with column l of L read back from LDS
+    DM_DEV Real back_substitute(Real x, Real dinv) {
+        Real c[ND];
+#pragma unroll
+        for (int k = 0; k < ND; ++k) c[k] = (l < ND && k >= l) ? s.H[k][l < ND ? l : 0] : (Real)0;
+#pragma unroll
+        for (int k = ND - 1; k >= 0; --k) {
+            Real t = x * dinv; Real xk = lane_bcast(t, k);
+            if (l == k) x = t; else if (l < k) x -= c[k] * xk;
         }
+        return x;
     }
-    // x := L^-T x
-    DM_DEV void solve_upper(Real* x) {
-        const int D = m.D;
-        for (int k = D - 1; k >= 0; --k) {
-            if (l == k) x[k] = x[k] / s.H[k][k];
-            sync();
-            if (l < k) x[l] -= s.H[k][l] * x[k];
-            sync();
-        }
+    // x := L^-T x for an LDS vector, using the factor stored by chol_solve
+    DM_DEV void solve_upper(Real* xvec) {
+        Real x = (l < m.D) ? xvec[l] : (Real)0;
+        Real dinv = (l < ND) ? s.dinv[l] : (Real)1;
+        x = back_substitute(x, dinv);
+        if (l < m.D) xvec[l] = x;
+        sync();
     }
 
     DM_DEV v3 gravity_a0() const { return mk3(-m.gravity[0], -m.gravity[1], -m.gravity[2]); }
@@ -281,9 +333,7 @@ struct EnvSim {
         if (l < D) { s.rhs[l] = s.xs[l] - s.bias[l]; s.H[l][l] += dt * m.kd[l]; }
         sync();
         mark(4);
-        cholesky();
-        solve_lower(s.rhs);
-        solve_upper(s.rhs);                // rhs = qddot
+        chol_solve(s.rhs, true);           // rhs = qddot
         mark(3);
         if (l < D) s.tau[l] = (l < 6) ? (Real)0 : s.xs[l] - m.kd[l] * dt * s.rhs[l];
         sync();
@@ -333,10 +383,9 @@ struct EnvSim {
         dynamics(1);
         mark(6);
         if (dbg.H) { for (int i = l; i < D * D; i += kWave) dbg.H[(size_t)e * D * D + i] = s.H[i / D][i % D]; if (l < D) dbg.C[(size_t)e * D + l] = s.bias[l]; }
-        cholesky();
         if (l < D) s.rhs[l] = s.tau[l] - s.bias[l];
         sync();
-        solve_lower(s.rhs); solve_upper(s.rhs);
+        chol_solve(s.rhs, true);
         if (l < D) { s.qd[l] = s.vel[m.dof_vidx[l]]; s.vstar[l] = clamp_vel(s.qd[l] + h * s.rhs[l], l); }
         if (l == 0) s.flg[FLG_CONTACT] = 0;
         sync();
@@ -393,7 +442,7 @@ struct EnvSim {
 
         mark(8);
         // ---- constraint rows: lane = row.  limits | normals | frictions (2 per contact)
-        Real b = 0, cvec = 0; int nrow = -1;
+        Real b = 0, cvec = 0;
         if (l < R) {
             if (l < NL) {
                 int j = m.lim_joint[l], off = m.pose_off[j], dof = m.dof_off[j];
@@ -413,46 +462,55 @@ struct EnvSim {
                 int fi = l - NL - nc; int c = s.cslot[fi >> 1]; int lk = m.cand_link[c];
                 v3 t = (fi & 1) ? mk3((Real)0, (Real)0, (Real)1) : mk3((Real)-1, (Real)0, (Real)0);   // btPlaneSpace1((0,1,0))
                 cvec = build_point_row(l, lk, ld3(s.cx[c]), t);
-                b = 0; nrow = NL + (fi >> 1);
-            }
-            // Y[:, l] := L^-1 J_l^T
-            for (int k = 0; k < D; ++k) {
-                Real acc = Y(k)[l];
-                for (int q = 0; q < k; ++q) acc -= s.H[k][q] * Y(q)[l];
-                Y(k)[l] = acc / s.H[k][k];
+                b = 0;
             }
         }
         sync();
-        mark(9);
-        // A = Y^T Y: each lane keeps its own row of A in registers
-        Real arow[kMaxRows];
+        // y := L^-1 J_l^T in registers (static indices; L rows are wave-uniform LDS broadcasts)
+        Real y[ND];
 #pragma unroll
-        for (int r = 0; r < kMaxRows; ++r) {
+        for (int k = 0; k < ND; ++k) y[k] = (l < R && k < D) ? Y(k)[l] : (Real)0;
+#pragma unroll
+        for (int k = 0; k < ND; ++k) {
+            Real acc = y[k];
+#pragma unroll
+            for (int q = 0; q < k; ++q) acc -= s.H[k][q] * y[q];
+            y[k] = acc * s.dinv[k];
+        }
+        mark(9);
+        // A = Y^T Y: lane l keeps row l of A in a register file indexed by the (wave-uniform) row id
+        RowFile<Real> arow;
+        Real adiag = 0;
+#pragma unroll
+        for (int k = 0; k < ND; ++k) adiag += y[k] * y[k];
+        for (int r = 0; r < R; ++r) {
             Real acc = 0;
-            if (r < R && l < R) for (int k = 0; k < D; ++k) acc += Y(k)[l] * Y(k)[r];
-            arow[r] = acc;
+#pragma unroll
+            for (int k = 0; k < ND; ++k) acc += y[k] * lane_bcast(y[k], r);
+            arow.set(r, acc);
         }
         mark(10);
         // projected Gauss-Seidel in impulse space; u = J v* + A lambda is kept per lane
         Real lam = 0, u = cvec;
-        Real adiag = 1;
-#pragma unroll
-        for (int r = 0; r < kMaxRows; ++r) if (r == l) adiag = arow[r];
+        const Real inv_adiag = (l < R) ? (Real)1 / adiag : (Real)0;
         for (int it = 0; it < m.solver_iters; ++it) {
-#pragma unroll
-            for (int r = 0; r < kMaxRows; ++r) {
-                if (r >= R) break;
+            for (int r = 0; r < R; ++r) {
                 Real lo = 0, hi = (Real)1e30;
                 if (r >= NL + nc) {        // friction row: bounded by the current normal impulse of its contact
-                    Real lam_n = wave_bcast(lam, NL + ((r - NL - nc) >> 1));
+                    Real lam_n = lane_bcast(lam, NL + ((r - NL - nc) >> 1));
                     hi = m.friction * lam_n; lo = -hi;
                 }
-                Real nl = lam + (b - u) / adiag;
+                Real nl = lam + (b - u) * inv_adiag;
                 nl = dm_max(lo, dm_min(hi, nl));
-                Real delta = wave_bcast(nl - lam, r);
-                u += arow[r] * delta;
+                Real delta = lane_bcast(nl - lam, r);
+                u += arow.get(r) * delta;
                 if (l == r) lam = nl;
             }
+        }
+        // hand y back to LDS (k-major) for the lane-per-dof accumulation of Y lambda
+        if (l < R) {
+#pragma unroll
+            for (int k = 0; k < ND; ++k) if (k < D) Y(k)[l] = y[k];
         }
         s.lam[l] = (l < R) ? lam : (Real)0;
         sync();

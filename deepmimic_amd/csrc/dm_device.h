@@ -4,55 +4,124 @@
 //   lanes <-> dofs       for mass-matrix rows, Cholesky rows, triangular solves (34 / 64 lanes)
 //   lanes <-> contact candidates, then constraint rows, for collision + PGS (<= 64 rows)
 //
-// All per-env working data lives in LDS for the whole call (20 scene updates = one control step); HBM is
-// touched only to load the env record at entry and to store record + observation + reward at exit.
-// The workgroup is exactly one wavefront, so __syncthreads() is a wave-local LDS fence.
+// All per-env working data lives in LDS / VGPRs for the whole call (20 scene updates = one control step); HBM is
+// touched only to load the env record and the model block at entry and to store record + observation + reward at
+// exit.  The workgroup is exactly one wavefront, so __syncthreads() is a wave-local LDS fence (no s_barrier).
+//
+// Register-resident linear algebra (lane i owns row i): the Cholesky factor, the triangular solves, the
+// constraint-space vectors y_r = L^-1 J_r^T (lane r owns constraint row r, statically indexed VGPR array), the rows
+// of A = Y^T Y and the projected Gauss-Seidel sweep all run in VGPRs with v_readlane / DPP cross-lane traffic.
 //
 // Reference functions realised here (DeepMimicCore/...):
 //   kin_*        anim/Motion.cpp:249-293,476-515; anim/MotionController.cpp:25-47,102-111; anim/KinCharacter.cpp:363-406
 //   dynamics()   sim/RBDUtil.cpp:4-97 (RNEA), 123-195 (CRBA) -- same H and C, evaluated as a Newton-Euler pass in
 //                world-aligned axes about each joint's own origin (no 6x6 frame transforms; fp32-safe)
-//   spd()        sim/ImpPDController.cpp:136-195, sim/SimBodyJoint.cpp:299-307,636-695
-//   substep()    DM-physics v1 standing in for btMultiBodyDynamicsWorld::stepSimulation
+//   spd_*()      sim/ImpPDController.cpp:136-195, sim/SimBodyJoint.cpp:299-307,636-695
+//   substep_*()  DM-physics v1 standing in for btMultiBodyDynamicsWorld::stepSimulation
 //   emit()       scenes/SceneImitate.cpp:7-127,163-205; sim/CtController.cpp:281-478; sim/SimCharacter.cpp:542-586
 //   reset_env()  scenes/SceneSimChar.cpp:487-583,628-644; scenes/SceneImitate.cpp:320-368,386-418
 #pragma once
 #include "dm_math.h"
 #include "dm_types.h"
 
+// ============================================================================ wave-level primitives
 #ifdef DM_EMU
 static inline long long dm_clock() { return 0; }
 #define DM_DEV inline
+#define DM_OPAQUE_S(x) ((void)0)
+#define DM_OPAQUE_V(x) ((void)0)
 static inline int dm_atomic_or(int* p, int v) { int o = *p; *p = o | v; return o; }
+static inline int dm_popc64(uint64_t v) { return __builtin_popcountll(v); }
+static inline int dm_ctz32(uint32_t v) { return __builtin_ctz(v); }
 namespace dmk {
-template <typename T> static inline T wave_bcast(T v, int src) {
+// every lane of the wave must call these from uniform control flow (the emulator exchanges through a buffer)
+template <typename T> static inline T wave_shfl(T v, int src) {
     T* x = reinterpret_cast<T*>(emu::g_xchg);
-    x[threadIdx.x] = v; __syncthreads(); T r = x[src]; __syncthreads(); return r;
+    x[threadIdx.x] = v; __syncthreads(); T r = x[src & 63]; __syncthreads(); return r;
 }
-template <typename T> static inline T lane_bcast(T v, int src) { return wave_bcast(v, src); }
+template <typename T> static inline T lane_bcast(T v, int src) { return wave_shfl(v, src); }
+static inline uint64_t wave_ballot(bool p) {
+    uint64_t* x = emu::g_xchg;
+    x[threadIdx.x] = p ? 1 : 0; __syncthreads();
+    uint64_t m = 0; for (int i = 0; i < 64; ++i) m |= (x[i] & 1ull) << i;
+    __syncthreads(); return m;
+}
+template <typename T> static inline T wave_sum(T v) {
+    T* x = reinterpret_cast<T*>(emu::g_xchg);
+    x[threadIdx.x] = v; __syncthreads();
+    T s = 0; for (int i = 0; i < 64; ++i) s += x[i];
+    __syncthreads(); return s;
+}
+template <int MASK, typename T> static inline T wave_shfl_xor_c(T v) { return wave_shfl(v, (int)(threadIdx.x ^ MASK)); }
+static inline float dm_rsqrt(float x) { return 1.0f / sqrtf(x); }
+static inline double dm_rsqrt(double x) { return 1.0 / sqrt(x); }
+static inline float dm_rcp(float x) { return 1.0f / x; }
+static inline double dm_rcp(double x) { return 1.0 / x; }
+template <typename T> static inline T dm_med3(T lo, T x, T hi) { return x < lo ? lo : (x > hi ? hi : x); }
 template <typename Real> struct RowFile {       // per-lane array indexed by a wave-uniform runtime index
     Real v[kMaxRows];
     inline Real get(int r) const { return v[r]; }
     inline void set(int r, Real x) { v[r] = x; }
 };
+// two / four packed reals (GCC vector extension on the host emulator)
+template <typename Real> struct VecT;
+template <> struct VecT<float> { typedef float v2 __attribute__((vector_size(8))); typedef float v4 __attribute__((vector_size(16))); };
+template <> struct VecT<double> { typedef double v2 __attribute__((vector_size(16))); typedef double v4 __attribute__((vector_size(32))); };
 }
 #else
 #define DM_DEV __device__ __forceinline__
+// make a wave-uniform (SGPR) / per-lane (VGPR) value opaque to the optimizer: stops loop-invariant hoisting of the
+// hundreds of compare masks an unrolled sweep would otherwise keep live (and spill)
+#define DM_OPAQUE_S(x) asm volatile("" : "+s"(x))
+#define DM_OPAQUE_V(x) asm volatile("" : "+v"(x))
 __device__ __forceinline__ long long dm_clock() { return (long long)__builtin_readcyclecounter(); }
 __device__ __forceinline__ int dm_atomic_or(int* p, int v) { return atomicOr(p, v); }
+__device__ __forceinline__ int dm_popc64(uint64_t v) { return __popcll(v); }
+__device__ __forceinline__ int dm_ctz32(uint32_t v) { return __builtin_ctz(v); }
 namespace dmk {
-__device__ __forceinline__ float wave_bcast(float v, int src) { return __shfl(v, src, 64); }
-__device__ __forceinline__ double wave_bcast(double v, int src) { return __shfl(v, src, 64); }
-__device__ __forceinline__ int wave_bcast(int v, int src) { return __shfl(v, src, 64); }
+__device__ __forceinline__ float wave_shfl(float v, int src) { return __shfl(v, src, 64); }
+__device__ __forceinline__ double wave_shfl(double v, int src) { return __shfl(v, src, 64); }
+__device__ __forceinline__ int wave_shfl(int v, int src) { return __shfl(v, src, 64); }
 // broadcast from a wave-uniform lane: v_readlane_b32 (no LDS traffic, SGPR result)
+__device__ __forceinline__ int lane_bcast(int v, int src) { return __builtin_amdgcn_readlane(v, src); }
 __device__ __forceinline__ float lane_bcast(float v, int src) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src)); }
 __device__ __forceinline__ double lane_bcast(double v, int src) {
     long long b = __builtin_bit_cast(long long, v);
     int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), src), hi = __builtin_amdgcn_readlane((int)(b >> 32), src);
     return __builtin_bit_cast(double, ((long long)hi << 32) | (long long)(unsigned)lo);
 }
+__device__ __forceinline__ uint64_t wave_ballot(bool p) { return __ballot(p); }
+// sum over the 64 lanes, result in every lane.  fp32: DPP butterfly inside each row of 16, row broadcasts across rows.
+#define DM_DPP_F(v, ctrl, rmask, bctl) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, rmask, 0xf, bctl))
+__device__ __forceinline__ float wave_sum(float v) {
+    v += DM_DPP_F(v, 0xB1, 0xf, true);     // quad_perm [1,0,3,2]
+    v += DM_DPP_F(v, 0x4E, 0xf, true);     // quad_perm [2,3,0,1]
+    v += DM_DPP_F(v, 0x141, 0xf, true);    // row_half_mirror
+    v += DM_DPP_F(v, 0x140, 0xf, true);    // row_mirror: every lane holds the sum of its row
+    v += DM_DPP_F(v, 0x142, 0xa, false);   // row_bcast15 into rows 1 and 3
+    v += DM_DPP_F(v, 0x143, 0xc, false);   // row_bcast31 into rows 2 and 3: row 3 holds the total
+    return lane_bcast(v, 63);
+}
+__device__ __forceinline__ double wave_sum(double v) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+// exchange with lane (l ^ mask): DPP quad permutes for mask 1 and 2, LDS crossbar (ds_bpermute) beyond
+template <int MASK> __device__ __forceinline__ float wave_shfl_xor_c(float v) {
+    if (MASK == 1) return DM_DPP_F(v, 0xB1, 0xf, true);
+    if (MASK == 2) return DM_DPP_F(v, 0x4E, 0xf, true);
+    return __shfl_xor(v, MASK, 64);
+}
+template <int MASK> __device__ __forceinline__ double wave_shfl_xor_c(double v) { return __shfl_xor(v, MASK, 64); }
+__device__ __forceinline__ float dm_med3(float lo, float x, float hi) { return __builtin_amdgcn_fmed3f(lo, x, hi); }
+__device__ __forceinline__ double dm_med3(double lo, double x, double hi) { return fmax(lo, fmin(hi, x)); }
+// 1/sqrt and 1/x: hardware approximation + one Newton step in fp32 (rel. error ~1e-7), exact in fp64
+__device__ __forceinline__ float dm_rsqrt(float x) { float r = __builtin_amdgcn_rsqf(x); return r * (1.5f - 0.5f * x * r * r); }
+__device__ __forceinline__ double dm_rsqrt(double x) { return 1.0 / sqrt(x); }
+__device__ __forceinline__ float dm_rcp(float x) { float r = __builtin_amdgcn_rcpf(x); return r * (2.0f - x * r); }
+__device__ __forceinline__ double dm_rcp(double x) { return 1.0 / x; }
 // per-lane array indexed by a wave-uniform runtime index.  For float it is two 32-wide register vectors that the
-// backend addresses with v_movrels/v_movreld (M0-relative VGPR indexing), so the row of A never leaves the VGPRs.
+// backend addresses with M0-relative VGPR indexing, so a row of A never leaves the VGPRs.
 template <typename Real> struct RowFile {
     Real v[kMaxRows];
     __device__ __forceinline__ Real get(int r) const { return v[r]; }
@@ -64,26 +133,30 @@ template <> struct RowFile<float> {
     __device__ __forceinline__ float get(int r) const { return (r < 32) ? a[r] : b[r - 32]; }
     __device__ __forceinline__ void set(int r, float x) { if (r < 32) a[r] = x; else b[r - 32] = x; }
 };
+// two / four packed reals: v_pk_fma_f32 / ds_read_b128 operands
+template <typename Real> struct VecT;
+template <> struct VecT<float> { typedef float v2 __attribute__((ext_vector_type(2))); typedef float v4 __attribute__((ext_vector_type(4))); };
+template <> struct VecT<double> { typedef double v2 __attribute__((ext_vector_type(2))); typedef double v4 __attribute__((ext_vector_type(4))); };
 }
 #endif
 
 namespace dmk {
 
-template <typename Real, int NJ, int ND, int NP, int NCAP>
+// Per-wave LDS record.
+template <typename Real, typename C>
 struct Lds {
-    static constexpr int kYStride = kMaxRows + 1;
+    static constexpr int NJ = C::NJ, ND = C::ND, NP = C::NP, NCAP = C::NCAP;
+    static constexpr int kLS = ((ND + 3) / 4) * 4 + (((((ND + 3) / 4)) % 2 == 0) ? 4 : 0);   // L row stride: 16-B multiple, odd count of 16-B slots
+    MdlLds<Real, C> mdl;
     Real pose[NP], vel[NP], tar[NP];
-    Real qd[ND], tau[ND], bias[ND], rhs[ND], vstar[ND], xs[ND];
-    Real R[NJ][9], p[NJ][3], com[NJ][3], Rb[NJ][9], w[NJ][3], vj[NJ][3], al[NJ][3], aj[NJ][3];
+    Real tau[ND], bias[ND], rhs[ND], xs[ND];
+    alignas(32) Real dofrec[ND][8];        // per dof: world axis a(3), g = (p_joint - p_root) x a (3), unconstrained velocity v*, pad
+    Real R[NJ][9], p[NJ][3], com[NJ][3], w[NJ][3], vj[NJ][3], al[NJ][3], aj[NJ][3];
+    Real Rb[C::ROT ? NJ : 1][9];           // body frames (== R when the class has no attach rotations)
     Real f[NJ][3], n[NJ][3], Iw[NJ][6];
     Real Fs[NJ][3], Ns[NJ][3], Ic[NJ][10];
-    Real axis[ND][3];
-    static constexpr int kHS = ((ND + 3) / 4) * 4 + (((((ND + 3) / 4)) % 2 == 0) ? 4 : 0);   // row stride: 16-B multiple, odd count of 16-B slots
-    alignas(16) Real H[ND][kHS];
-    Real dinv[ND];                         // 1 / L_kk of the current Cholesky factor
-    Real scratch[ND * kYStride];          // Y = L^-1 J^T during the constraint solve; kin pose / vel at emit time
-    Real row_b[kMaxRows], lam[kMaxRows];
-    Real cx[NCAP][3], cdist[NCAP];     // ground-contact candidates (NCAP = 64 or 128)
+    alignas(32) Real L[ND][kLS];           // mass matrix rows, then its Cholesky factor (diagonal slot holds 1/L_kk)
+    Real cx[NCAP][3], cdist[NCAP];         // ground-contact candidates
     int csel[NCAP], cslot[kMaxRows];
     Real kin[8];                           // kin origin pos(3), origin rot(4)
     Real sc[24];                           // small float scratch
@@ -94,19 +167,39 @@ struct Lds {
 enum { CLK_KIN = 0, CLK_CTRL, CLK_INIT_OFF, CLK_TIMER, CLK_TIMER_MAX };
 enum { FLG_NEED_ACTION = 0, FLG_CONTACT, FLG_EPISODE, FLG_VALID, FLG_NROWS, FLG_NCONT };
 
-template <typename Real, int NJ, int ND, int NP, int NCAP>
+template <typename Real, typename C>
 struct EnvSim {
-    typedef Lds<Real, NJ, ND, NP, NCAP> L;
+    typedef Lds<Real, C> L;
+    static constexpr int NJ = C::NJ, ND = C::ND, NP = C::NP, NCAP = C::NCAP, CPL = C::NCAP / kWave;
+    static constexpr int NP2 = ND / 2;                 // register pairs per dof vector (ND is even for every class)
     typedef V3<Real> v3; typedef Q4<Real> q4; typedef M3<Real> m3;
+    typedef typename VecT<Real>::v2 R2; typedef typename VecT<Real>::v4 R4;
     const ModelDev<Real>& m; L& s; const int l;
+    int li = 0;                                         // link_info word of this lane's link (0 for lanes >= J)
+    int cand_link[CPL]; Real cand_loc[CPL][3], cand_rad[CPL];   // this lane's ground-contact candidates
     long long* prof = nullptr; long long tprev = 0;     // phase-cycle accounting (profiling kernel only)
     DM_DEV EnvSim(const ModelDev<Real>& m_, L& s_, int l_) : m(m_), s(s_), l(l_) {}
     DM_DEV void mark(int phase) { if (prof) { long long t = dm_clock(); if (l == 0) prof[phase] += t - tprev; tprev = t; } }
     DM_DEV void sync() const { __syncthreads(); }
-    DM_DEV Real* Y(int k) const { return s.scratch + k * L::kYStride; }
+    DM_DEV Real* scratch() const { return &s.L[0][0]; }   // L is dead outside the update loop: kin pose / vel / reductions live there
+    DM_DEV const Real* Rbp(int j) const { return C::ROT ? s.Rb[j] : s.R[j]; }
+    static DM_DEV v3 zero3() { return mk3((Real)0, (Real)0, (Real)0); }
 
     // ------------------------------------------------------------------ HBM <-> LDS
+    DM_DEV void load_model() {
+        uint32_t* dst = reinterpret_cast<uint32_t*>(&s.mdl);
+        for (int i = l; i < m.mdl_words; i += kWave) dst[i] = m.mdl_blob[i];
+#pragma unroll
+        for (int q = 0; q < CPL; ++q) {
+            const int c = l + kWave * q;
+            cand_link[q] = 0; cand_rad[q] = 0; cand_loc[q][0] = cand_loc[q][1] = cand_loc[q][2] = 0;
+            if (c < m.NC) { cand_link[q] = m.cand_link[c]; cand_rad[q] = m.cand_rad[c]; for (int k = 0; k < 3; ++k) cand_loc[q][k] = m.cand_loc[c * 3 + k]; }
+        }
+        sync();
+        li = (l < m.J) ? s.mdl.link_info[l] : 0;
+    }
     DM_DEV void load(const EnvState<Real>& st, int e) {
+        load_model();
         for (int i = l; i < m.P; i += kWave) { s.pose[i] = st.pose[(size_t)e * m.P + i]; s.vel[i] = st.vel[(size_t)e * m.P + i]; s.tar[i] = st.tar[(size_t)e * m.P + i]; }
         if (l < m.D) s.tau[l] = st.tau[(size_t)e * m.D + l];
         if (l < 8) s.kin[l] = st.kin[(size_t)e * 8 + l];
@@ -128,23 +221,26 @@ struct EnvSim {
     // and, for the zero-qddot Newton-Euler pass, al (angular acceleration) and aj (acceleration of the joint origin)
     // with base acceleration a0 (gravity enters as a0 = -g).
     DM_DEV void kinematics(const Real* pose, const Real* vel, v3 a0) {
-        int par = -1, dep = -1, jt = 0, off = 0;
-        if (l < m.J) { par = m.parent[l]; dep = m.depth[l]; jt = m.jtype[l]; off = m.pose_off[l]; }
+        const int par = DM_LI_PARENT(li), dep = (l < m.J) ? DM_LI_DEPTH(li) : -1, jt = DM_LI_JTYPE(li), off = DM_LI_POFF(li);
+        // joint-local rotation and angular velocity of this lane's joint (trig evaluated once, outside the level loop)
+        m3 Rl = m3_identity<Real>(); v3 wl = zero3();
+        if (l < m.J) {
+            if (par < 0) Rl = quat_to_rot(ldq(pose + 3));
+            else if (jt == JT_SPHERICAL) { Rl = quat_to_rot(ldq(pose + off)); wl = ld3(vel + off); }
+            else if (jt == JT_REVOLUTE) { Rl = rot_z(pose[off]); wl.z = vel[off]; }
+        }
         for (int d = 0; d <= m.max_depth; ++d) {
-            if (l < m.J && dep == d) {
+            if (dep == d) {
                 m3 Rj; v3 pj, w, vj, al, aj;
                 if (par < 0) {
-                    Rj = quat_to_rot(ldq(pose + 3)); pj = ld3(pose);
-                    w = ld3(vel + 3); vj = ld3(vel); al = mk3((Real)0, (Real)0, (Real)0); aj = a0;
+                    Rj = Rl; pj = ld3(pose);
+                    w = ld3(vel + 3); vj = ld3(vel); al = zero3(); aj = a0;
                 } else {
                     m3 Rp = ldm3(s.R[par]);
-                    v3 r = Rp * ld3(m.attach + l * 3);
+                    v3 r = Rp * ld3(s.mdl.attach[l]);
                     pj = ld3(s.p[par]) + r;
-                    m3 Rpa = m.arot_ident[l] ? Rp : Rp * ldm3(m.attach_rot + l * 9);
-                    v3 wl = mk3((Real)0, (Real)0, (Real)0);
-                    if (jt == JT_SPHERICAL) { Rj = Rpa * quat_to_rot(ldq(pose + off)); wl = ld3(vel + off); }
-                    else if (jt == JT_REVOLUTE) { Rj = Rpa * rot_z(pose[off]); wl.z = vel[off]; }
-                    else Rj = Rpa;
+                    if (C::ROT && !DM_LI_AROT_ID(li)) Rp = Rp * ldm3(s.mdl.attach_rot[C::ROT ? l : 0]);
+                    Rj = Rp * Rl;
                     v3 wp = ld3(s.w[par]), alp = ld3(s.al[par]);
                     v3 wrel = Rj * wl;
                     w = wp + wrel;
@@ -153,20 +249,21 @@ struct EnvSim {
                     aj = ld3(s.aj[par]) + cross(alp, r) + cross(wp, cross(wp, r));
                 }
                 stm3(s.R[l], Rj); st3(s.p[l], pj); st3(s.w[l], w); st3(s.vj[l], vj); st3(s.al[l], al); st3(s.aj[l], aj);
-                st3(s.com[l], pj + Rj * ld3(m.battach + l * 3));
-                stm3(s.Rb[l], m.brot_ident[l] ? Rj : Rj * ldm3(m.brot + l * 9));
+                st3(s.com[l], pj + Rj * ld3(s.mdl.battach[l]));
+                if (C::ROT) stm3(s.Rb[C::ROT ? l : 0], DM_LI_BROT_ID(li) ? Rj : Rj * ldm3(s.mdl.brot[C::ROT ? l : 0]));
             }
             sync();
         }
     }
 
-    // ------------------------------------------------------------------ mass matrix H and bias force C
-    // iset: 0 = SPD inertias, 1 = simulator inertias.  Requires kinematics() for the same state.
-    DM_DEV void dynamics(int iset) {
+    // ------------------------------------------------------------------ mass matrix H (lower triangle, into s.L) and bias force C
+    // iset: 0 = SPD inertias, 1 = simulator inertias.  diag_scale * kd is added to the diagonal (SPD: dt).
+    // Requires kinematics() for the same state.  Also fills dofrec[k] = (axis, g) used by the constraint rows.
+    DM_DEV void dynamics(int iset, Real diag_scale) {
         const int J = m.J, D = m.D;
         if (l < J) {                       // per-link force / moment about the COM and world inertia about the COM
-            m3 Rb = ldm3(s.Rb[l]);
-            const Real* Id = m.inertia + ((size_t)iset * J + l) * 3;
+            m3 Rb = ldm3(Rbp(l));
+            const Real* Id = s.mdl.inertia[iset][l];
             Real I0 = Id[0], I1 = Id[1], I2 = Id[2];
             Real Iw[6];                    // xx xy xz yy yz zz
             Iw[0] = Rb.m[0] * Rb.m[0] * I0 + Rb.m[1] * Rb.m[1] * I1 + Rb.m[2] * Rb.m[2] * I2;
@@ -179,111 +276,140 @@ struct EnvSim {
             v3 w = ld3(s.w[l]), al = ld3(s.al[l]);
             v3 rc = ld3(s.com[l]) - ld3(s.p[l]);
             v3 ac = ld3(s.aj[l]) + cross(al, rc) + cross(w, cross(w, rc));
-            st3(s.f[l], m.mass[l] * ac);
+            st3(s.f[l], s.mdl.mass[l] * ac);
             v3 Iwv = mk3(Iw[0] * w.x + Iw[1] * w.y + Iw[2] * w.z, Iw[1] * w.x + Iw[3] * w.y + Iw[4] * w.z, Iw[2] * w.x + Iw[4] * w.y + Iw[5] * w.z);
             v3 Ial = mk3(Iw[0] * al.x + Iw[1] * al.y + Iw[2] * al.z, Iw[1] * al.x + Iw[3] * al.y + Iw[4] * al.z, Iw[2] * al.x + Iw[4] * al.y + Iw[5] * al.z);
             st3(s.n[l], Ial + cross(w, Iwv));
         }
-        if (l < D) {                       // world axis of every generalized velocity
-            int j = m.dof_joint[l], kind = m.dof_kind[l], ax = m.dof_axis[l];
-            v3 a;
-            if (kind == DK_ROOT_LIN || kind == DK_ROOT_ANG) a = mk3((Real)(ax == 0), (Real)(ax == 1), (Real)(ax == 2));
-            else a = col(ldm3(s.R[j]), (kind == DK_REV) ? 2 : ax);
-            st3(s.axis[l], a);
+        int di = 0, dj = 0, kind = 0, ax = 0; v3 a = zero3();
+        if (l < D) {                       // world axis of every generalized velocity and its moment about the root origin
+            di = s.mdl.dof_info[l]; dj = DM_DI_JOINT(di); kind = DM_DI_KIND(di); ax = DM_DI_AXIS(di);
+            v3 rec_a, rec_g;
+            if (kind == DK_ROOT_LIN) { a = mk3((Real)(ax == 0), (Real)(ax == 1), (Real)(ax == 2)); rec_a = zero3(); rec_g = a; }
+            else {
+                if (kind == DK_ROOT_ANG) a = mk3((Real)(ax == 0), (Real)(ax == 1), (Real)(ax == 2));
+                else a = col(ldm3(s.R[dj]), (kind == DK_REV) ? 2 : ax);
+                rec_a = a; rec_g = cross(ld3(s.p[dj]) - ld3(s.p[0]), a);
+            }
+            st3(&s.dofrec[l][0], rec_a); st3(&s.dofrec[l][3], rec_g);
         }
         sync();
-        if (l < J) {                       // subtree sums about this joint's origin (descendants have larger ids)
-            uint32_t mask = m.subtree_mask[l];
-            v3 pj = ld3(s.p[l]);
-            v3 Fs = mk3((Real)0, (Real)0, (Real)0), Ns = Fs, h = Fs;
+        {   // subtree sums about each joint's origin (descendants have larger ids): G adjacent lanes share one link,
+            // sub-lane g takes members lk+g, lk+g+G, ...; the G partial sums are folded with DPP quad permutes
+            constexpr int G = (NJ <= 16) ? 4 : 2;
+            const int lk = l / G, g = l % G;
+            v3 Fs = zero3(), Ns = Fs, h = Fs;
             Real mc = 0, Ic[6] = { 0, 0, 0, 0, 0, 0 };
-            for (int k = l; k < J; ++k) {
-                if (!((mask >> k) & 1u)) continue;
-                v3 d = ld3(s.com[k]) - pj, fk = ld3(s.f[k]);
-                Fs = Fs + fk; Ns = Ns + ld3(s.n[k]) + cross(d, fk);
-                Real mk = m.mass[k], dd = dot(d, d);
-                mc += mk; h = h + mk * d;
-                Ic[0] += s.Iw[k][0] + mk * (dd - d.x * d.x); Ic[1] += s.Iw[k][1] - mk * d.x * d.y; Ic[2] += s.Iw[k][2] - mk * d.x * d.z;
-                Ic[3] += s.Iw[k][3] + mk * (dd - d.y * d.y); Ic[4] += s.Iw[k][4] - mk * d.y * d.z; Ic[5] += s.Iw[k][5] + mk * (dd - d.z * d.z);
+            if (lk < J) {
+                const uint32_t mask = s.mdl.subtree_mask[lk];
+                const v3 pj = ld3(s.p[lk]);
+                for (int k = lk + g; k < J; k += G) {
+                    if (!((mask >> k) & 1u)) continue;
+                    v3 d = ld3(s.com[k]) - pj, fk = ld3(s.f[k]);
+                    Fs = Fs + fk; Ns = Ns + ld3(s.n[k]) + cross(d, fk);
+                    Real mk = s.mdl.mass[k], dd = dot(d, d);
+                    mc += mk; h = h + mk * d;
+                    Ic[0] += s.Iw[k][0] + mk * (dd - d.x * d.x); Ic[1] += s.Iw[k][1] - mk * d.x * d.y; Ic[2] += s.Iw[k][2] - mk * d.x * d.z;
+                    Ic[3] += s.Iw[k][3] + mk * (dd - d.y * d.y); Ic[4] += s.Iw[k][4] - mk * d.y * d.z; Ic[5] += s.Iw[k][5] + mk * (dd - d.z * d.z);
+                }
             }
-            st3(s.Fs[l], Fs); st3(s.Ns[l], Ns);
-            s.Ic[l][0] = mc; s.Ic[l][1] = h.x; s.Ic[l][2] = h.y; s.Ic[l][3] = h.z;
-            for (int k = 0; k < 6; ++k) s.Ic[l][4 + k] = Ic[k];
+            Real acc[16] = { Fs.x, Fs.y, Fs.z, Ns.x, Ns.y, Ns.z, mc, h.x, h.y, h.z, Ic[0], Ic[1], Ic[2], Ic[3], Ic[4], Ic[5] };
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { acc[i] += wave_shfl_xor_c<1>(acc[i]); if (G == 4) acc[i] += wave_shfl_xor_c<2>(acc[i]); }
+            if (lk < J && g == 0) {
+                for (int i = 0; i < 3; ++i) { s.Fs[lk][i] = acc[i]; s.Ns[lk][i] = acc[3 + i]; }
+                for (int i = 0; i < 10; ++i) s.Ic[lk][i] = acc[6 + i];
+            }
         }
         sync();
         if (l < D) {
-            int j = m.dof_joint[l], kind = m.dof_kind[l], ax = m.dof_axis[l];
-            v3 a = ld3(s.axis[l]);
-            s.bias[l] = (kind == DK_ROOT_LIN) ? s.Fs[0][ax] : dot(a, ld3(s.Ns[j]));
-            // momentum of the composite body of joint j under unit velocity of this dof, about p_j
-            const Real* ic = s.Ic[j];
+            s.bias[l] = (kind == DK_ROOT_LIN) ? s.Fs[0][ax] : dot(a, ld3(s.Ns[dj]));
+            // momentum of the composite body of joint j under unit velocity of this dof: linear Pm, angular about the root origin Lq
+            const Real* ic = s.Ic[dj];
             v3 h = mk3(ic[1], ic[2], ic[3]), Pm, Lp;
             if (kind == DK_ROOT_LIN) { Pm = ic[0] * a; Lp = cross(h, a); }
             else {
                 Pm = cross(a, h);
                 Lp = mk3(ic[4] * a.x + ic[5] * a.y + ic[6] * a.z, ic[5] * a.x + ic[7] * a.y + ic[8] * a.z, ic[6] * a.x + ic[8] * a.y + ic[9] * a.z);
             }
-            v3 pj = ld3(s.p[j]);
-            uint64_t anc = m.dof_anc[l];
-            for (int k = 0; k <= l; ++k) {
-                Real val = 0;
-                if ((anc >> k) & 1ull) {
-                    int jk = m.dof_joint[k];
-                    v3 ak = ld3(s.axis[k]);
-                    if (m.dof_kind[k] == DK_ROOT_LIN) val = dot(ak, Pm);
-                    else val = dot(ak, Lp + cross(pj - ld3(s.p[jk]), Pm));
-                }
-                s.H[l][k] = val; s.H[k][l] = val;
+            v3 Lq = Lp + cross(ld3(s.p[dj]) - ld3(s.p[0]), Pm);
+            // row l of H: zero, then the ancestor-or-self dofs k <= l:  H_lk = a_k . Lq + g_k . Pm
+            Real* row = s.L[l];
+            for (int k = 0; k <= l; ++k) row[k] = 0;
+            uint32_t lo = s.mdl.anc_lo[l], hi = s.mdl.anc_hi[l];
+            while (lo | hi) {
+                int k;
+                if (lo) { k = dm_ctz32(lo); lo &= lo - 1; } else { k = 32 + dm_ctz32(hi); hi &= hi - 1; }
+                const Real* rec = s.dofrec[k];
+                Real val = rec[0] * Lq.x + rec[1] * Lq.y + rec[2] * Lq.z + rec[3] * Pm.x + rec[4] * Pm.y + rec[5] * Pm.z;
+                if (k == l) val += diag_scale * s.mdl.kd[l];
+                row[k] = val;
             }
         }
         sync();
     }
 
     // ------------------------------------------------------------------ dense SPD linear algebra, register resident
-    // Lane i owns row i of H.  The factorisation and the triangular solves run entirely in VGPRs with
-    // v_readlane broadcasts (no LDS round trips, no barriers); the factor L and 1/diag(L) are written back to LDS
-    // for the per-row forward substitutions of the constraint solve.  All loops are fully unrolled (ND is the
-    // compile-time dof count of the kernel class), so every register-array index is static.
+    // Lane i owns row i of H (lower triangle in s.L).  The factorisation and the triangular solves run entirely in
+    // VGPRs with v_readlane broadcasts (no LDS round trips, no barriers); the factor is written back to LDS (diagonal
+    // slot = 1/L_kk) for the per-row forward substitutions of the constraint solve and the column reads of the
+    // backward substitution.  All loops are fully unrolled (ND is the compile-time dof count of the kernel class), so
+    // every register-array index is static.
     //
-    // Factor s.H = L L^T; when do_solve, also x := H^-1 x for the LDS vector x (length D).
-    DM_DEV void chol_solve(Real* xvec, bool do_solve) {
+    // Factor H = L L^T and x := H^-1 x for the LDS vector x (length D).  The row lives in NP2 packed register pairs
+    // so that the rank-1 updates issue as v_pk_fma_f32 with the two broadcast factors in one SGPR pair.
+    DM_DEV void chol_solve(Real* xvec) {
         const int D = m.D;
-        Real h[ND];
+        R2 h2[NP2];
+        const int lr = l < ND ? l : 0;
+        // own row; entries right of the diagonal are never consumed (they only feed this lane's own dead entries)
 #pragma unroll
-        for (int k = 0; k < ND; ++k) h[k] = (l < D && k < D) ? s.H[l < ND ? l : 0][k] : ((l == k) ? (Real)1 : (Real)0);
+        for (int p = 0; p < NP2; ++p) {
+            R2 v = *reinterpret_cast<const R2*>(&s.L[lr][2 * p]);
+            if (!(l < D)) { v[0] = (l == 2 * p) ? (Real)1 : (Real)0; v[1] = (l == 2 * p + 1) ? (Real)1 : (Real)0; }
+            h2[p] = v;
+        }
         Real dinv = 1;
 #pragma unroll
         for (int k = 0; k < ND; ++k) {
-            Real piv = lane_bcast(h[k], k);
-            Real inv = (Real)1 / dm_sqrt(piv);
-            Real lik = h[k] * inv;
-            h[k] = lik;
+            const int pk = k >> 1, ck = k & 1;
+            Real hk = h2[pk][ck];
+            Real piv = lane_bcast(hk, k);
+            Real inv = dm_rsqrt(piv);
+            Real lik = hk * inv;
+            h2[pk][ck] = lik;
             if (l == k) dinv = inv;
+            if (ck == 0) h2[pk][1] -= lik * lane_bcast(lik, k + 1);
+            const R2 l2 = {lik, lik};
 #pragma unroll
-            for (int j = k + 1; j < ND; ++j) h[j] -= lik * lane_bcast(lik, j);
+            for (int p = (k + 2) >> 1; p < NP2; ++p) { const R2 bb = {lane_bcast(lik, 2 * p), lane_bcast(lik, 2 * p + 1)}; h2[p] -= l2 * bb; }
         }
         if (l < ND) {
 #pragma unroll
-            for (int k = 0; k < ND; ++k) s.H[l][k] = h[k];
-            s.dinv[l] = dinv;
-        }
-        Real x = 0;
-        if (do_solve) {
-            x = (l < D) ? xvec[l] : (Real)0;
-#pragma unroll
-            for (int k = 0; k < ND; ++k) {
-                Real t = x * dinv; Real xk = lane_bcast(t, k);
-                if (l == k) x = t; else if (l > k) x -= h[k] * xk;
+            for (int p = 0; p < NP2; ++p) {
+                R2 v = h2[p];
+                if (l == 2 * p) v[0] = dinv;
+                if (l == 2 * p + 1) v[1] = dinv;
+                *reinterpret_cast<R2*>(&s.L[l][2 * p]) = v;
             }
         }
+        Real x = (l < D) ? xvec[l] : (Real)0;
+#pragma unroll
+        for (int k = 0; k < ND; ++k) {
+            Real t = x * dinv; Real xk = lane_bcast(t, k);
+            if (l == k) x = t; else if (l > k) x -= h2[k >> 1][k & 1] * xk;
+        }
         sync();
-        if (do_solve) { x = back_substitute(x, dinv); if (l < D) xvec[l] = x; sync(); }
+        x = back_substitute(x, dinv);
+        if (l < D) xvec[l] = x;
+        sync();
     }
     // x_l := (L^-T x)_l with column l of L read back from LDS
     DM_DEV Real back_substitute(Real x, Real dinv) {
         Real c[ND];
+        const int lr = l < ND ? l : 0;
 #pragma unroll
-        for (int k = 0; k < ND; ++k) c[k] = (l < ND && k >= l) ? s.H[k][l < ND ? l : 0] : (Real)0;
+        for (int k = 0; k < ND; ++k) c[k] = (l < ND && k > l) ? s.L[k][lr] : (Real)0;
 #pragma unroll
         for (int k = ND - 1; k >= 0; --k) {
             Real t = x * dinv; Real xk = lane_bcast(t, k);
@@ -291,54 +417,53 @@ struct EnvSim {
         }
         return x;
     }
-    // x := L^-T x for an LDS vector, using the factor stored by chol_solve
-    DM_DEV void solve_upper(Real* xvec) {
-        Real x = (l < m.D) ? xvec[l] : (Real)0;
-        Real dinv = (l < ND) ? s.dinv[l] : (Real)1;
-        x = back_substitute(x, dinv);
-        if (l < m.D) xvec[l] = x;
-        sync();
+    // one stage of the transposing wave reduction: N per-lane partial sums -> (N+1)/2, lanes split on bit MASK
+    template <int N, int MASK> DM_DEV void tr_stage(Real (&w)[NP2]) {
+        const bool bit = (l & MASK) != 0;
+#pragma unroll
+        for (int i = 0; i < (N + 1) / 2; ++i) {
+            Real a = w[2 * i], b = (2 * i + 1 < N) ? w[2 * i + 1] : (Real)0;
+            Real keep = bit ? b : a, send = bit ? a : b;
+            w[i] = keep + wave_shfl_xor_c<MASK>(send);
+        }
     }
 
     DM_DEV v3 gravity_a0() const { return mk3(-m.gravity[0], -m.gravity[1], -m.gravity[2]); }
 
     // ------------------------------------------------------------------ stable-PD torques
-    DM_DEV void spd(Real dt) {
-        const int D = m.D;
-        // reference BuildCjRoot quirk == uniform extra base acceleration v0 x (E w - w)  
+    // reference BuildCjRoot quirk == uniform extra base acceleration v0 x (E w - w)  
+    DM_DEV v3 spd_a0() const {
         v3 v0 = ld3(s.vel), w0 = ld3(s.vel + 3);
         m3 E = quat_to_rot(ldq(s.pose + 3));
-        v3 a0 = gravity_a0() + cross(v0, E * w0 - w0);
-        mark(0);
-        kinematics(s.pose, s.vel, a0);
-        mark(1);
-        dynamics(0);
-        mark(2);
-        if (l < m.J && l > 0) {            // pose error per joint -> rhs = Kp e + Kd (0 - qd)
-            int jt = m.jtype[l], off = m.pose_off[l], dof = m.dof_off[l];
+        return gravity_a0() + cross(v0, E * w0 - w0);
+    }
+    // pose error per joint -> xs = Kp e + Kd (0 - qd); rhs = xs - C
+    DM_DEV void spd_rhs(Real dt) {
+        if (l < m.J && l > 0) {
+            int jt = DM_LI_JTYPE(li), off = DM_LI_POFF(li), dof = DM_LI_DOFF(li);
             if (jt == JT_SPHERICAL) {
                 q4 q = ldq(s.pose + off); v3 om = ld3(s.vel + off);
                 q4 dq = quat_diff_mul(q, om);
                 q4 qh = qnormalize(mkq(q.w + dt * dq.w, q.x + dt * dq.x, q.y + dt * dq.y, q.z + dt * dq.z));
                 v3 e = quat_to_rotvec(qmul(qconj(qh), ldq(s.tar + off)), (Real)0.000001);
-                for (int k = 0; k < 3; ++k) s.xs[dof + k] = m.kp[dof + k] * comp(e, k) + m.kd[dof + k] * (-s.vel[off + k]);
+                for (int k = 0; k < 3; ++k) s.xs[dof + k] = s.mdl.kp[dof + k] * comp(e, k) + s.mdl.kd[dof + k] * (-s.vel[off + k]);
             } else if (jt == JT_REVOLUTE) {
                 Real th = normalize_angle(s.pose[off]);
                 Real e = s.tar[off] - (th + dt * s.vel[off]);
-                s.xs[dof] = m.kp[dof] * e + m.kd[dof] * (-s.vel[off]);
+                s.xs[dof] = s.mdl.kp[dof] * e + s.mdl.kd[dof] * (-s.vel[off]);
             }
         }
         if (l < 6) s.xs[l] = 0;
         sync();
-        if (l < D) { s.rhs[l] = s.xs[l] - s.bias[l]; s.H[l][l] += dt * m.kd[l]; }
+        if (l < m.D) s.rhs[l] = s.xs[l] - s.bias[l];
         sync();
-        mark(4);
-        chol_solve(s.rhs, true);           // rhs = qddot
-        mark(3);
-        if (l < D) s.tau[l] = (l < 6) ? (Real)0 : s.xs[l] - m.kd[l] * dt * s.rhs[l];
+    }
+    // rhs holds qddot: tau = Kp e + Kd (e_v - dt qddot), clamped per joint (SimBodyJoint.cpp:299-307)
+    DM_DEV void spd_post(Real dt) {
+        if (l < m.D) s.tau[l] = (l < 6) ? (Real)0 : s.xs[l] - s.mdl.kd[l] * dt * s.rhs[l];
         sync();
-        if (l < m.J && l > 0) {            // clamp the torque norm per joint (SimBodyJoint.cpp:299-307)
-            int jt = m.jtype[l], dof = m.dof_off[l]; Real lim = m.torque_lim[l];
+        if (l < m.J && l > 0) {
+            int jt = DM_LI_JTYPE(li), dof = DM_LI_DOFF(li); Real lim = s.mdl.torque_lim[l];
             if (jt == JT_SPHERICAL) {
                 Real mag = dm_sqrt(s.tau[dof] * s.tau[dof] + s.tau[dof + 1] * s.tau[dof + 1] + s.tau[dof + 2] * s.tau[dof + 2]);
                 if (mag > lim) { Real k = lim / mag; s.tau[dof] *= k; s.tau[dof + 1] *= k; s.tau[dof + 2] *= k; }
@@ -355,85 +480,61 @@ struct EnvSim {
         Real mx = (dof < 3) ? m.max_lin_vel : m.max_ang_vel;
         return dm_max(-mx, dm_min(mx, v));
     }
-    // J row of direction d at world point x on `link`, written into column r of Y; returns J . vstar
-    DM_DEV Real build_point_row(int r, int link, v3 x, v3 d) {
-        const int D = m.D;
-        for (int k = 0; k < D; ++k) Y(k)[r] = 0;
-        Y(0)[r] = d.x; Y(1)[r] = d.y; Y(2)[r] = d.z;
-        v3 mm = cross(x - ld3(s.p[0]), d);
-        Y(3)[r] = mm.x; Y(4)[r] = mm.y; Y(5)[r] = mm.z;
-        for (int j = link; j > 0; j = m.parent[j]) {
-            int jt = m.jtype[j], dof = m.dof_off[j];
-            if (jt == JT_FIXED) continue;
-            v3 mj = cross(x - ld3(s.p[j]), d);
-            m3 Rj = ldm3(s.R[j]);
-            if (jt == JT_SPHERICAL) { v3 t = tmul(Rj, mj); Y(dof)[r] = t.x; Y(dof + 1)[r] = t.y; Y(dof + 2)[r] = t.z; }
-            else if (jt == JT_REVOLUTE) Y(dof)[r] = dot(col(Rj, 2), mj);
-        }
-        Real c = 0;
-        for (int k = 0; k < D; ++k) c += Y(k)[r] * s.vstar[k];
-        return c;
-    }
-
-    DM_DEV void substep(Real h, DebugTaps<Real> dbg, int e) {
+    // s.rhs holds qddot of the unconstrained dynamics; s.L the Cholesky factor of H.
+    DM_DEV void substep_post(Real h, DebugTaps<Real> dbg, int e) {
         const int D = m.D, J = m.J;
-        mark(4);
-        kinematics(s.pose, s.vel, gravity_a0());
-        mark(5);
-        dynamics(1);
-        mark(6);
-        if (dbg.H) { for (int i = l; i < D * D; i += kWave) dbg.H[(size_t)e * D * D + i] = s.H[i / D][i % D]; if (l < D) dbg.C[(size_t)e * D + l] = s.bias[l]; }
-        if (l < D) s.rhs[l] = s.tau[l] - s.bias[l];
-        sync();
-        chol_solve(s.rhs, true);
-        if (l < D) { s.qd[l] = s.vel[m.dof_vidx[l]]; s.vstar[l] = clamp_vel(s.qd[l] + h * s.rhs[l], l); }
+        Real vstar = 0; int vidx = 0;
+        if (l < D) { vidx = DM_DI_VIDX(s.mdl.dof_info[l]); vstar = clamp_vel(s.vel[vidx] + h * s.rhs[l], l); s.dofrec[l][6] = vstar; }
         if (l == 0) s.flg[FLG_CONTACT] = 0;
         sync();
-        if (dbg.vstar && l < D) dbg.vstar[(size_t)e * D + l] = s.vstar[l];
-
+        if (dbg.vstar && l < D) dbg.vstar[(size_t)e * D + l] = vstar;
         mark(7);
         // ---- collision detection: lane = candidate point (CPL candidates per lane when NC > 64)
-        constexpr int CPL = NCAP / kWave;
-        bool active[CPL]; Real dist[CPL];
+        bool active[CPL]; Real dist[CPL]; v3 cxp[CPL]; uint64_t amask[CPL];
+        int nact = 0;
 #pragma unroll
         for (int q = 0; q < CPL; ++q) {
             const int c = l + kWave * q;
-            active[q] = false; dist[q] = 0;
+            active[q] = false; dist[q] = 0; cxp[q] = zero3();
             if (c < m.NC) {
-                int link = m.cand_link[c];
-                v3 x = ld3(s.com[link]) + ldm3(s.Rb[link]) * ld3(m.cand_loc + c * 3);
-                x.y -= m.cand_rad[c];
-                dist[q] = x.y;
-                st3(s.cx[c], x); s.cdist[c] = x.y;
-                active[q] = x.y < m.thresh[link];
+                int link = cand_link[q];
+                v3 x = ld3(s.com[link]) + ldm3(Rbp(link)) * mk3(cand_loc[q][0], cand_loc[q][1], cand_loc[q][2]);
+                x.y -= cand_rad[q];
+                dist[q] = x.y; cxp[q] = x;
+                active[q] = x.y < s.mdl.thresh[link];
                 if (x.y <= m.report_dist) dm_atomic_or(&s.flg[FLG_CONTACT], 1 << link);
             }
-            s.csel[c] = active[q] ? 1 : 0;
+            amask[q] = wave_ballot(active[q]);
+            nact += dm_popc64(amask[q]);
         }
-        sync();
-        // manifold reduction: keep the max_contacts deepest, ties to the lower index; compact in index order
-        int rank[CPL];
+        if (nact > m.max_contacts) {
+            // manifold reduction (rare): keep the max_contacts deepest, ties to the lower index
 #pragma unroll
-        for (int q = 0; q < CPL; ++q) {
-            const int c = l + kWave * q; rank[q] = 0;
-            if (active[q]) for (int k = 0; k < m.NC; ++k) if (s.csel[k] && (s.cdist[k] < dist[q] || (s.cdist[k] == dist[q] && k < c))) ++rank[q];
-        }
-        sync();
+            for (int q = 0; q < CPL; ++q) { const int c = l + kWave * q; s.csel[c] = active[q] ? 1 : 0; s.cdist[c] = dist[q]; }
+            sync();
 #pragma unroll
-        for (int q = 0; q < CPL; ++q) { active[q] = active[q] && rank[q] < m.max_contacts; s.csel[l + kWave * q] = active[q] ? 1 : 0; }
-        sync();
-        int nc = 0;
-        {
-            int slot[CPL];
-#pragma unroll
-            for (int q = 0; q < CPL; ++q) slot[q] = 0;
-            for (int k = 0; k < m.NC; ++k) {
-                int v = s.csel[k]; nc += v;
-#pragma unroll
-                for (int q = 0; q < CPL; ++q) if (k < l + kWave * q) slot[q] += v;
+            for (int q = 0; q < CPL; ++q) {
+                const int c = l + kWave * q; int rank = 0;
+                if (active[q]) for (int k = 0; k < m.NC; ++k) if (s.csel[k] && (s.cdist[k] < dist[q] || (s.cdist[k] == dist[q] && k < c))) ++rank;
+                active[q] = active[q] && rank < m.max_contacts;
             }
+            sync();
+            nact = 0;
 #pragma unroll
-            for (int q = 0; q < CPL; ++q) if (active[q]) s.cslot[slot[q]] = l + kWave * q;
+            for (int q = 0; q < CPL; ++q) { amask[q] = wave_ballot(active[q]); nact += dm_popc64(amask[q]); }
+        }
+        const int nc = nact;
+        {   // compact in candidate-index order
+            const uint64_t lt = (l == 0) ? 0ull : (~0ull >> (64 - l));
+            int base = 0;
+#pragma unroll
+            for (int q = 0; q < CPL; ++q) {
+                if (active[q]) {
+                    const int c = l + kWave * q, slot = base + dm_popc64(amask[q] & lt);
+                    s.cslot[slot] = c | (cand_link[q] << 16); st3(s.cx[c], cxp[q]); s.cdist[c] = dist[q];
+                }
+                base += dm_popc64(amask[q]);
+            }
         }
         const int NL = m.NL;
         const int R = NL + 3 * nc;
@@ -442,89 +543,127 @@ struct EnvSim {
 
         mark(8);
         // ---- constraint rows: lane = row.  limits | normals | frictions (2 per contact)
-        Real b = 0, cvec = 0;
+        // J_r[k] = a_k . ((x - p0) x d) + g_k . d on the dofs of the chain root..link, 0 elsewhere.
+        // A limit row (+-e_dof) is the same formula with d = 0 and (x - p0) x d := +-a_dof on the one-dof chain {dof}.
+        Real b = 0;
+        uint32_t ch_lo = 0, ch_hi = 0; v3 xd = zero3(), dd = zero3();
         if (l < R) {
             if (l < NL) {
-                int j = m.lim_joint[l], off = m.pose_off[j], dof = m.dof_off[j];
-                Real th = s.pose[off], pen_lo = th - m.lim_lo[j], pen_hi = m.lim_hi[j] - th;
-                Real sgn, pen;
+                int j = s.mdl.lim_joint[l]; int lj = s.mdl.link_info[j]; int off = DM_LI_POFF(lj);
+                const int limdof = DM_LI_DOFF(lj);
+                Real th = s.pose[off], pen_lo = th - s.mdl.lim_lo[l], pen_hi = s.mdl.lim_hi[l] - th;
+                Real pen, sgn;
                 if (pen_lo <= pen_hi) { sgn = 1; pen = pen_lo; } else { sgn = -1; pen = pen_hi; }
-                for (int k = 0; k < D; ++k) Y(k)[l] = 0;
-                Y(dof)[l] = sgn;
-                cvec = sgn * s.vstar[dof];
                 b = (pen > 0) ? -pen / h : -m.erp * pen / h;
-            } else if (l < NL + nc) {
-                int c = s.cslot[l - NL]; int lk = m.cand_link[c];
-                cvec = build_point_row(l, lk, ld3(s.cx[c]), mk3((Real)0, (Real)1, (Real)0));
-                Real dd = s.cdist[c];
-                b = (dd > 0) ? -dd / h : -m.erp * dd / h;
+                xd = sgn * ld3(&s.dofrec[limdof][0]);
+                if (limdof < 32) ch_lo = 1u << limdof; else ch_hi = 1u << (limdof - 32);
             } else {
-                int fi = l - NL - nc; int c = s.cslot[fi >> 1]; int lk = m.cand_link[c];
-                v3 t = (fi & 1) ? mk3((Real)0, (Real)0, (Real)1) : mk3((Real)-1, (Real)0, (Real)0);   // btPlaneSpace1((0,1,0))
-                cvec = build_point_row(l, lk, ld3(s.cx[c]), t);
-                b = 0;
+                int cs, kindr;
+                if (l < NL + nc) { cs = s.cslot[l - NL]; kindr = 0; } else { int fi = l - NL - nc; cs = s.cslot[fi >> 1]; kindr = 1 + (fi & 1); }
+                const int c = cs & 0xffff, lk = cs >> 16;         // candidate id | owning link
+                ch_lo = s.mdl.chain_lo[lk]; ch_hi = s.mdl.chain_hi[lk];
+                dd = (kindr == 0) ? mk3((Real)0, (Real)1, (Real)0) : ((kindr == 1) ? mk3((Real)-1, (Real)0, (Real)0) : mk3((Real)0, (Real)0, (Real)1));   // btPlaneSpace1((0,1,0))
+                xd = cross(ld3(s.cx[c]) - ld3(s.p[0]), dd);
+                if (kindr == 0) { Real dc = s.cdist[c]; b = (dc > 0) ? -dc / h : -m.erp * dc / h; }
             }
         }
-        sync();
-        // y := L^-1 J_l^T in registers (static indices; L rows are wave-uniform LDS broadcasts)
-        Real y[ND];
-#pragma unroll
-        for (int k = 0; k < ND; ++k) y[k] = (l < R && k < D) ? Y(k)[l] : (Real)0;
+        // y := L^-1 J_l^T in registers (static indices; dof records and L rows are wave-uniform LDS broadcasts)
+        R2 y2[NP2]; Real cvec = 0;
 #pragma unroll
         for (int k = 0; k < ND; ++k) {
-            Real acc = y[k];
+            Real yk = 0;
+            if (k < D) {
+                const R4 r0 = *reinterpret_cast<const R4*>(&s.dofrec[k][0]), r1 = *reinterpret_cast<const R4*>(&s.dofrec[k][4]);
+                const Real val = r0[0] * xd.x + r0[1] * xd.y + r0[2] * xd.z + r0[3] * dd.x + r1[0] * dd.y + r1[1] * dd.z;
+                const bool on = (((k < 32) ? ch_lo : ch_hi) >> (k & 31)) & 1u;
+                const Real raw = on ? val : (Real)0;
+                cvec += raw * r1[2];
+                R2 acc2 = {(Real)0, (Real)0};
+                const R2* lrow = reinterpret_cast<const R2*>(&s.L[k][0]);
 #pragma unroll
-            for (int q = 0; q < k; ++q) acc -= s.H[k][q] * y[q];
-            y[k] = acc * s.dinv[k];
+                for (int p = 0; p < (k >> 1); ++p) acc2 += lrow[p] * y2[p];
+                Real acc = raw - (acc2[0] + acc2[1]);
+                if (k & 1) acc -= s.L[k][k - 1] * y2[k >> 1][0];
+                yk = acc * s.L[k][k];
+            }
+            y2[k >> 1][k & 1] = yk;
         }
         mark(9);
-        // A = Y^T Y: lane l keeps row l of A in a register file indexed by the (wave-uniform) row id
-        RowFile<Real> arow;
-        Real adiag = 0;
+        // projected Gauss-Seidel in impulse space; u = J v* + A lambda is kept per lane.
+        // Sweep order: limits, normals, frictions; a friction row is boxed by mu * (current normal impulse of its contact).
+        const int RN = NL + nc;
+        const bool is_fric = l >= RN && l < R;
+        Real lam = 0;
+        // no row can leave lambda = 0 unless some limit / normal row starts violated: skip A and the sweeps otherwise
+        if (wave_ballot(l < RN && (b - cvec) > 0) != 0) {
+            // A = Y^T Y: lane l keeps row l of A in a register file indexed by the row id
+            RowFile<Real> arow;
+            Real adiag;
+            { R2 a2 = {(Real)0, (Real)0};
 #pragma unroll
-        for (int k = 0; k < ND; ++k) adiag += y[k] * y[k];
-        for (int r = 0; r < R; ++r) {
-            Real acc = 0;
-#pragma unroll
-            for (int k = 0; k < ND; ++k) acc += y[k] * lane_bcast(y[k], r);
-            arow.set(r, acc);
-        }
-        mark(10);
-        // projected Gauss-Seidel in impulse space; u = J v* + A lambda is kept per lane
-        Real lam = 0, u = cvec;
-        const Real inv_adiag = (l < R) ? (Real)1 / adiag : (Real)0;
-        for (int it = 0; it < m.solver_iters; ++it) {
+              for (int p = 0; p < NP2; ++p) a2 += y2[p] * y2[p];
+              adiag = a2[0] + a2[1]; }
             for (int r = 0; r < R; ++r) {
-                Real lo = 0, hi = (Real)1e30;
-                if (r >= NL + nc) {        // friction row: bounded by the current normal impulse of its contact
-                    Real lam_n = lane_bcast(lam, NL + ((r - NL - nc) >> 1));
-                    hi = m.friction * lam_n; lo = -hi;
-                }
-                Real nl = lam + (b - u) * inv_adiag;
-                nl = dm_max(lo, dm_min(hi, nl));
-                Real delta = lane_bcast(nl - lam, r);
-                u += arow.get(r) * delta;
-                if (l == r) lam = nl;
-            }
-        }
-        // hand y back to LDS (k-major) for the lane-per-dof accumulation of Y lambda
-        if (l < R) {
+                R2 a2 = {(Real)0, (Real)0};
 #pragma unroll
-            for (int k = 0; k < ND; ++k) if (k < D) Y(k)[l] = y[k];
-        }
-        s.lam[l] = (l < R) ? lam : (Real)0;
-        sync();
+                for (int p = 0; p < NP2; ++p) { const R2 bb = {lane_bcast(y2[p][0], r), lane_bcast(y2[p][1], r)}; a2 += y2[p] * bb; }
+                arow.set(r, a2[0] + a2[1]);
+            }
+            mark(10);
+            Real u = cvec;
+            const Real inv_adiag = (l < R) ? (Real)1 / adiag : (Real)0;
+            const int nrm_lane = is_fric ? NL + ((l - RN) >> 1) : 0;
+            Real lo = 0, hi = is_fric ? (Real)0 : (Real)1e30;
+            int Rv = R, RNv = RN, lv = l;
+            for (int it = 0; it < m.solver_iters; ++it) {
+                DM_OPAQUE_S(Rv); DM_OPAQUE_S(RNv); DM_OPAQUE_V(lv);
+                // statically unrolled over the row id (register-file index and lane select are immediates); rows >= R are
+                // skipped block-wise by wave-uniform branches
+#pragma unroll
+                for (int blk = 0; blk < kMaxRows / 8; ++blk) {
+                    if (blk * 8 < Rv) {
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) {
+                            const int r = blk * 8 + i;
+                            if (r < Rv) {
+                                if (r == RNv) { const Real ln = wave_shfl(lam, nrm_lane); if (is_fric) { hi = m.friction * ln; lo = -hi; } }
+                                const Real nl = dm_med3(lo, lam + (b - u) * inv_adiag, hi);
+                                const Real delta = lane_bcast(nl - lam, r);
+                                u += arow.get(r) * delta;
+                                if (lv == r) lam = nl;
+                            }
+                        }
+                    }
+                }
+            }
+            if (l >= R) lam = 0;
+        } else mark(10);
         mark(11);
-        if (dbg.lambda) { dbg.lambda[(size_t)e * kMaxRows + l] = s.lam[l]; if (l < 2) dbg.rows[(size_t)e * 2 + l] = s.flg[FLG_NROWS + l]; }
-        // delta v = L^-T (Y lambda)
-        if (l < D) { Real z = 0; for (int r = 0; r < R; ++r) z += Y(l)[r] * s.lam[r]; s.xs[l] = z; }
-        sync();
-        solve_upper(s.xs);
-        if (l < D) { s.qd[l] = clamp_vel(s.vstar[l] + s.xs[l], l); s.vel[m.dof_vidx[l]] = s.qd[l]; }
+        if (dbg.lambda) { dbg.lambda[(size_t)e * kMaxRows + l] = lam; if (l < 2) dbg.rows[(size_t)e * 2 + l] = s.flg[FLG_NROWS + l]; }
+        // delta v = L^-T (Y lambda): transposing wave reduction of y_r[k] lambda_r, dof k's total lands in lane k
+        Real z;
+        {
+            Real w[NP2];
+            const bool bit = (l & 1) != 0;
+#pragma unroll
+            for (int p = 0; p < NP2; ++p) {
+                const Real a = y2[p][0] * lam, bb = y2[p][1] * lam;
+                w[p] = (bit ? bb : a) + wave_shfl_xor_c<1>(bit ? a : bb);
+            }
+            tr_stage<NP2, 2>(w);
+            tr_stage<(NP2 + 1) / 2, 4>(w);
+            tr_stage<(NP2 + 3) / 4, 8>(w);
+            tr_stage<(NP2 + 7) / 8, 16>(w);
+            tr_stage<(NP2 + 15) / 16, 32>(w);
+            z = w[0];
+        }
+        Real dinv = (l < ND) ? s.L[l < ND ? l : 0][l < ND ? l : 0] : (Real)1;
+        z = back_substitute(z, dinv);
+        if (l < D) s.vel[vidx] = clamp_vel(vstar + z, l);
         sync();
         // ---- integrate positions (semi-implicit Euler, exponential map on rotations)
         if (l < J) {
-            int jt = m.jtype[l], off = m.pose_off[l];
+            int jt = DM_LI_JTYPE(li), off = DM_LI_POFF(li);
             if (l == 0) {
                 for (int k = 0; k < 3; ++k) s.pose[k] += h * s.vel[k];
                 q4 q = qnormalize(qmul(quat_exp(h * ld3(s.vel + 3)), ldq(s.pose + 3)));
@@ -576,7 +715,7 @@ struct EnvSim {
         const Real* f0 = m.frames + (size_t)idx * m.P; const Real* f1 = f0 + m.P;
         q4 orot = ldq(s.kin + 3);
         if (l < m.J) {
-            int jt = m.jtype[l], off = m.pose_off[l];
+            int jt = DM_LI_JTYPE(li), off = DM_LI_POFF(li);
             if (l == 0) {
                 v3 rp = ((Real)1 - b) * ld3(f0) + b * ld3(f1);
                 q4 rr = qnormalize(qslerp(ldq(f0 + 3), b, ldq(f1 + 3), m.slerp_one));
@@ -620,7 +759,7 @@ struct EnvSim {
     // ------------------------------------------------------------------ action -> PD targets
     DM_DEV void set_action(const float* a) {
         if (l < m.J && l > 0) {
-            int jt = m.jtype[l], off = m.pose_off[l], ao = m.act_off[l];
+            int jt = DM_LI_JTYPE(li), off = DM_LI_POFF(li), ao = m.act_off[l];
             if (jt == JT_SPHERICAL) {
                 v3 ev = mk3((Real)a[ao], (Real)a[ao + 1], (Real)a[ao + 2]);
                 Real len = norm(ev); const Real max_len = (Real)(2 * DM_PI);
@@ -633,10 +772,10 @@ struct EnvSim {
     // open-loop tracking (stream A1): PD target := reference pose at the current clip time.
     // Uses the same exp-map round trip as the action path so that both paths latch identical targets.
     DM_DEV void set_action_from_clip() {
-        Real* kp = s.scratch; Real* kv = s.scratch + NP;
+        Real* kp = scratch(); Real* kv = scratch() + NP;
         kin_sample(s.clk[CLK_KIN], kp, kv);
         if (l < m.J && l > 0) {
-            int jt = m.jtype[l], off = m.pose_off[l];
+            int jt = DM_LI_JTYPE(li), off = DM_LI_POFF(li);
             if (jt == JT_SPHERICAL) {
                 v3 ev = quat_to_rotvec(ldq(kp + off), (Real)0.000001);
                 stq(s.tar + off, qnormalize(exp_map_to_quat(ev)));
@@ -646,12 +785,36 @@ struct EnvSim {
     }
 
     // ------------------------------------------------------------------ one scene update (cSceneSimChar::Update)
+    // phase 0 = stable-PD solve, phases 1..n = rigid-body substeps; the three share one copy of the kinematics /
+    // dynamics / Cholesky code (the instruction stream of the 20-update loop must fit the instruction cache).
+    // reuse_kin: pose / vel are unchanged since the previous phase's kinematics (stable-PD solve -> first substep); only
+    // the base acceleration differs, and it enters every joint-origin acceleration as the same additive constant.
+    DM_DEV void dyn_phase(int ph, Real dt, Real h, DebugTaps<Real> dbg, int e, bool tap_only, bool reuse_kin) {
+        mark(ph == 0 ? 0 : 4);
+        if (reuse_kin) {
+            if (l < m.J) { v3 da = gravity_a0() - spd_a0(); st3(s.aj[l], ld3(s.aj[l]) + da); }
+            sync();
+        } else kinematics(s.pose, s.vel, ph == 0 ? spd_a0() : gravity_a0());
+        mark(ph == 0 ? 1 : 5);
+        dynamics(ph == 0 ? 0 : 1, ph == 0 ? dt : (Real)0);
+        mark(ph == 0 ? 2 : 6);
+        if (dbg.H) {
+            const int D = m.D;
+            for (int i = l; i < D * D; i += kWave) { int r = i / D, c = i % D; Real v = (c <= r) ? s.L[r][c] : s.L[c][r]; if (r == c && ph == 0) v -= dt * s.mdl.kd[r]; dbg.H[(size_t)e * D * D + i] = v; }
+            if (l < D) dbg.C[(size_t)e * D + l] = s.bias[l];
+        }
+        if (tap_only) return;
+        if (ph == 0) spd_rhs(dt);
+        else { if (l < m.D) s.rhs[l] = s.tau[l] - s.bias[l]; sync(); }
+        chol_solve(s.rhs);
+        if (ph == 0) { mark(3); spd_post(dt); }
+        else substep_post(h, dbg, e);
+    }
     DM_DEV void update(double dt, DebugTaps<Real> dbg, int e) {
         if (l == 0) { s.clk[CLK_TIMER] += dt; s.clk[CLK_CTRL] += dt; s.flg[FLG_NEED_ACTION] = 0; }
         kin_update(dt);
-        spd((Real)dt);
-        Real h = (Real)(dt / m.num_sim_substeps);
-        for (int k = 0; k < m.num_sim_substeps; ++k) substep(h, dbg, e);
+        const Real h = (Real)(dt / m.num_sim_substeps);
+        for (int ph = 0; ph <= m.num_sim_substeps; ++ph) dyn_phase(ph, (Real)dt, h, dbg, e, false, ph == 1);
         if (l == 0) {                      // cCtController::CheckNeedNewAction (CtController.cpp:221-227)
             double cur = s.clk[CLK_CTRL] + s.clk[CLK_INIT_OFF], pad = 0.001 * dt;
             int c1 = (int)floor((cur + pad) / m.query_period), c0 = (int)floor((cur + pad - dt) / m.query_period);
@@ -663,18 +826,18 @@ struct EnvSim {
     // ------------------------------------------------------------------ termination
     DM_DEV bool has_fallen(const Real* kp) const {
         bool f = false;
-        if (m.enable_contact_fall) { int cm = s.flg[FLG_CONTACT]; for (int j = 0; j < m.J; ++j) if (m.fall[j] && ((cm >> j) & 1)) f = true; }
+        if (m.enable_contact_fall) { int cm = s.flg[FLG_CONTACT]; for (int j = 0; j < m.J; ++j) if (DM_LI_FALL(s.mdl.link_info[j]) && ((cm >> j) & 1)) f = true; }
         if (m.enable_root_rot_fail && kp) f = f || (quat_theta(qmul(ldq(kp + 3), qconj(ldq(s.pose + 3)))) > (Real)(0.5 * DM_PI));
         return f;
     }
 
     // ------------------------------------------------------------------ reward + observation + flags
-    DM_DEV void emit(const StepIO<Real>& io, DebugTaps<Real> dbg, int e) {
+    DM_DEV void emit(const StepIO<Real>& io, DebugTaps<Real> dbg, int e, bool write_flags) {
         const int J = m.J;
-        Real* kp = s.scratch; Real* kv = s.scratch + NP;
-        Real* ee_k = s.scratch + 2 * NP;                 // J x 3 kin joint positions
-        Real* red = s.scratch + 2 * NP + 3 * NJ;         // J x 4 per-joint reduction terms
-        const v3 zero = mk3((Real)0, (Real)0, (Real)0);
+        Real* kp = scratch(); Real* kv = scratch() + NP;
+        Real* ee_k = scratch() + 2 * NP;                 // J x 3 kin joint positions
+        Real* red = scratch() + 2 * NP + 3 * NJ;         // J x 4 per-joint reduction terms
+        const v3 zero = zero3();
         kin_sample(s.clk[CLK_KIN], kp, kv);
         if (dbg.kin_pose) for (int i = l; i < m.P; i += kWave) { dbg.kin_pose[(size_t)e * m.P + i] = kp[i]; dbg.kin_vel[(size_t)e * m.P + i] = kv[i]; }
         // kin character: joint positions and COM velocity (cRBDUtil::CalcCoM)
@@ -682,12 +845,12 @@ struct EnvSim {
         if (l < J) {
             st3(ee_k + l * 3, ld3(s.p[l]));
             v3 vc = ld3(s.vj[l]) + cross(ld3(s.w[l]), ld3(s.com[l]) - ld3(s.p[l]));
-            st3(red + l * 4, m.mass[l] * vc);
+            st3(red + l * 4, s.mdl.mass[l] * vc);
         }
         sync();
         if (l == 0) {
             v3 acc = zero; Real tm = 0;
-            for (int j = 0; j < J; ++j) { acc = acc + ld3(red + j * 4); tm += m.mass[j]; }
+            for (int j = 0; j < J; ++j) { acc = acc + ld3(red + j * 4); tm += s.mdl.mass[j]; }
             st3(s.sc + 0, ((Real)1 / tm) * acc);
         }
         sync();
@@ -696,19 +859,18 @@ struct EnvSim {
         v3 vcom = zero;
         if (l < J) {
             vcom = ld3(s.vj[l]) + cross(ld3(s.w[l]), ld3(s.com[l]) - ld3(s.p[l]));
-            st3(s.f[l], vcom);                              // reuse f[] as link COM velocity
-            st3(red + l * 4, m.mass[l] * vcom);
+            st3(red + l * 4, s.mdl.mass[l] * vcom);
         }
         sync();
         if (l == 0) {
             v3 acc = zero; Real tm = 0;
-            for (int j = 0; j < J; ++j) { acc = acc + ld3(red + j * 4); tm += m.mass[j]; }
+            for (int j = 0; j < J; ++j) { acc = acc + ld3(red + j * 4); tm += s.mdl.mass[j]; }
             st3(s.sc + 3, ((Real)1 / tm) * acc);
         }
         sync();
         if (dbg.links && l < J) {
             Real* o = dbg.links + ((size_t)e * J + l) * 21;
-            st3(o, ld3(s.com[l])); for (int k = 0; k < 9; ++k) o[3 + k] = s.Rb[l][k];
+            st3(o, ld3(s.com[l])); for (int k = 0; k < 9; ++k) o[3 + k] = Rbp(l)[k];
             st3(o + 12, vcom); st3(o + 15, ld3(s.w[l])); st3(o + 18, ld3(s.p[l]));
         }
         // origin frames (cKinTree::BuildOriginTrans): rotation about y by -heading, translation by -root(x,z)
@@ -716,7 +878,7 @@ struct EnvSim {
         m3 O0 = rot_y(-head0), O1 = rot_y(-head1);
         // per-joint reward terms
         if (l < J) {
-            int jt = m.jtype[l], off = m.pose_off[l];
+            int jt = DM_LI_JTYPE(li), off = DM_LI_POFF(li);
             Real pe = 0, ve = 0, ee = 0;
             if (l == 0) {
                 Real th = quat_theta(qmul(ldq(kp + 3), qconj(ldq(s.pose + 3))));
@@ -730,14 +892,15 @@ struct EnvSim {
                 Real d = kp[off] - normalize_angle(s.pose[off]); pe = d * d;
                 Real dv = kv[off] - s.vel[off]; ve = dv * dv;
             }
-            if (m.is_ee[l]) {
+            if (DM_LI_IS_EE(li)) {
                 v3 p0 = ld3(s.p[l]), p1 = ld3(ee_k + l * 3);
                 v3 rel0 = p0 - ld3(s.pose), rel1 = p1 - ld3(kp);
                 rel0.y = p0.y - (Real)0; rel1.y = p1.y - s.kin[1];
                 v3 dlt = O1 * rel1 - O0 * rel0;
                 ee = dot(dlt, dlt);
             }
-            red[l * 4 + 0] = m.diffw[l] * pe; red[l * 4 + 1] = m.diffw[l] * ve; red[l * 4 + 2] = ee;
+            Real dw = m.diffw[l];
+            red[l * 4 + 0] = dw * pe; red[l * 4 + 1] = dw * ve; red[l * 4 + 2] = ee;
         }
         sync();
         if (l == 0) {
@@ -757,9 +920,11 @@ struct EnvSim {
             if (fallen) r = 0;
             bool fail = (m.enable_fall_end && fallen) || (!m.loop && s.clk[CLK_KIN] >= m.duration);
             bool end = fail || (s.clk[CLK_TIMER] >= s.clk[CLK_TIMER_MAX]);
-            if (io.rewards) io.rewards[e] = (float)r;
-            if (io.terminate) io.terminate[e] = fail ? TERM_FAIL : TERM_NULL;
-            if (io.episode_end) io.episode_end[e] = end ? 1 : 0;
+            if (write_flags) {
+                if (io.rewards) io.rewards[e] = (float)r;
+                if (io.terminate) io.terminate[e] = fail ? TERM_FAIL : TERM_NULL;
+                if (io.episode_end) io.episode_end[e] = end ? 1 : 0;
+            }
             s.sc[6] = end ? (Real)1 : (Real)0;
             if (dbg.reward_terms) { Real* o = dbg.reward_terms + (size_t)e * 5; o[0] = pose_err; o[1] = vel_err; o[2] = ee_err; o[3] = root_err; o[4] = com_err; }
         }
@@ -773,7 +938,7 @@ struct EnvSim {
             if (mx > (Real)100) s.flg[FLG_VALID] = 0;
         }
         sync();
-        if (l == 0 && io.valid) io.valid[e] = s.flg[FLG_VALID];
+        if (l == 0 && io.valid && write_flags) io.valid[e] = s.flg[FLG_VALID];
         // observation
         if (io.states) {
             float* out = io.states + (size_t)e * m.S;
@@ -787,7 +952,7 @@ struct EnvSim {
             if (l < J) {
                 v3 pc = ld3(s.com[l]);
                 if (!m.record_world_root_pos || l != 0) { v3 t = mk3(pc.x - rpos.x, pc.y, pc.z - rpos.z); pc = O0 * t; pc.y -= rpos.y; }
-                m3 Rb = ldm3(s.Rb[l]);
+                m3 Rb = ldm3(Rbp(l));
                 if (!m.record_world_root_rot || l != 0) Rb = O0 * Rb;
                 v3 nrm = col(Rb, 1), tan = col(Rb, 0);
                 float* o = out + base + 1 + 9 * l;
@@ -804,7 +969,7 @@ struct EnvSim {
 
     // ------------------------------------------------------------------ reset
     DM_DEV void reset_env(double kin_time, double max_time) {
-        Real* kp = s.scratch; Real* kv = s.scratch + NP;
+        Real* kp = scratch(); Real* kv = scratch() + NP; Real* red = scratch() + 2 * NP;
         if (l == 0) {
             s.clk[CLK_TIMER] = 0; s.clk[CLK_TIMER_MAX] = max_time;
             s.clk[CLK_KIN] = kin_time; s.clk[CLK_CTRL] = kin_time; s.clk[CLK_INIT_OFF] = -kin_time;
@@ -818,23 +983,23 @@ struct EnvSim {
         for (int i = l; i < m.P; i += kWave) { s.pose[i] = kp[i]; s.vel[i] = kv[i]; }
         sync();
         if (l < m.J) {
-            int jt = m.jtype[l], off = m.pose_off[l];
+            int jt = DM_LI_JTYPE(li), off = DM_LI_POFF(li);
             if (l == 0) { stq(s.pose + 3, qnormalize(ldq(s.pose + 3))); s.vel[6] = 0; if (m.enable_rand_placement) { s.pose[0] = 0; s.pose[2] = 0; } }
             else if (jt == JT_SPHERICAL) { stq(s.pose + off, qstandardize(qnormalize(ldq(s.pose + off)))); s.vel[off + 3] = 0; }
         }
         sync();
         // ResolveCharGroundIntersect: lift the root so that every link AABB clears the ground by 1 mm
-        kinematics(s.pose, s.vel, mk3((Real)0, (Real)0, (Real)0));
+        kinematics(s.pose, s.vel, zero3());
         Real viol = 0;
         if (l < m.J) {
-            const Real* he = m.aabb_he + l * 4; m3 Rb = ldm3(s.Rb[l]);
+            const Real* he = m.aabb_he + l * 4; m3 Rb = ldm3(Rbp(l));
             Real ext = (he[3] != 0) ? he[0] : dm_abs(Rb.m[3]) * he[0] + dm_abs(Rb.m[4]) * he[1] + dm_abs(Rb.m[5]) * he[2];
             viol = dm_min((Real)0, s.com[l][1] - ext - (Real)0.001);
         }
-        s.row_b[l] = viol;
+        red[l] = viol;
         sync();
         if (l == 0) {
-            Real mv = 0; for (int j = 0; j < m.J; ++j) mv = dm_min(mv, s.row_b[j]);
+            Real mv = 0; for (int j = 0; j < m.J; ++j) mv = dm_min(mv, red[j]);
             if (mv < 0) s.pose[1] += -mv;
             // SyncKinCharRoot: kin root := sim root (moves the origin)
             for (int k = 0; k < 3; ++k) s.kin[k] += s.pose[k] - kp[k];
@@ -852,11 +1017,11 @@ DM_HD double dm_rand01(uint64_t seed, uint64_t env, uint64_t episode, uint64_t s
 
 // ============================================================================ kernels
 // grid = number of envs, block = one wavefront.
-template <typename Real, int NJ, int ND, int NP, int NCAP>
+template <typename Real, typename C>
 __global__ void __launch_bounds__(64) k_env_step(ModelDev<Real> m, EnvState<Real> st, StepIO<Real> io, DebugTaps<Real> dbg) {
-    __shared__ Lds<Real, NJ, ND, NP, NCAP> lds;
+    __shared__ Lds<Real, C> lds;
     const int e = blockIdx.x, l = threadIdx.x;
-    EnvSim<Real, NJ, ND, NP, NCAP> sim(m, lds, l);
+    EnvSim<Real, C> sim(m, lds, l);
     if (dbg.prof) { sim.prof = dbg.prof + (size_t)e * 16; sim.tprev = dm_clock(); }
     sim.load(st, e);
     if (io.open_loop) sim.set_action_from_clip();
@@ -864,18 +1029,19 @@ __global__ void __launch_bounds__(64) k_env_step(ModelDev<Real> m, EnvState<Real
     sim.mark(15);
     for (int u = 0; u < io.n_updates; ++u) sim.update(io.dt, dbg, e);
     if (io.emit) {
-        sim.emit(io, dbg, e);
-        const bool ended = lds.sc[6] != (Real)0;
-        if (io.auto_reset && ended) {
-            // mirrors DeepMimic.py:70-79: the terminal reward / flags were just written; start the next episode and
-            // hand back the observation the agent needs for its first action (RecordState after Reset)
+        // pass 0 writes reward / flags / observation.  With auto-reset (mirrors DeepMimic.py:70-79) an env whose episode
+        // ended starts its next episode and pass 1 hands back the observation the agent needs for its first action
+        // (RecordState after Reset); one copy of the emit code serves both.
+        DebugTaps<Real> tap = dbg;
+        for (int pass = 0; pass < 2; ++pass) {
+            sim.emit(io, tap, e, pass == 0);
+            const bool ended = lds.sc[6] != (Real)0;
+            if (pass == 1 || !(io.auto_reset && ended)) break;
             uint64_t ep = (uint64_t)lds.flg[FLG_EPISODE];
             double kt = m.duration * dm_rand01(m.seed, (uint64_t)(e + m.env_off), ep, 0);
             double mt = (m.time_lim_max > m.time_lim_min) ? m.time_lim_min + (m.time_lim_max - m.time_lim_min) * dm_rand01(m.seed, (uint64_t)(e + m.env_off), ep, 1) : m.time_lim_max;
             sim.reset_env(kt, mt);
-            StepIO<Real> io2 = io; io2.rewards = nullptr; io2.terminate = nullptr; io2.valid = nullptr; io2.episode_end = nullptr;
-            DebugTaps<Real> nodbg = DebugTaps<Real>();
-            sim.emit(io2, nodbg, e);
+            tap = DebugTaps<Real>();
         }
         sim.mark(13);
     }
@@ -884,12 +1050,12 @@ __global__ void __launch_bounds__(64) k_env_step(ModelDev<Real> m, EnvState<Real
 }
 
 // reset the envs listed in env_ids (or all when env_ids == null); kin_times / max_times optional per listed env
-template <typename Real, int NJ, int ND, int NP, int NCAP>
+template <typename Real, typename C>
 __global__ void __launch_bounds__(64) k_env_reset(ModelDev<Real> m, EnvState<Real> st, const int* env_ids, const double* kin_times, const double* max_times) {
-    __shared__ Lds<Real, NJ, ND, NP, NCAP> lds;
+    __shared__ Lds<Real, C> lds;
     const int b = blockIdx.x, l = threadIdx.x;
     const int e = env_ids ? env_ids[b] : b;
-    EnvSim<Real, NJ, ND, NP, NCAP> sim(m, lds, l);
+    EnvSim<Real, C> sim(m, lds, l);
     sim.load(st, e);
     uint64_t ep = (uint64_t)lds.flg[FLG_EPISODE];
     double kt = kin_times ? kin_times[b] : m.duration * dm_rand01(m.seed, (uint64_t)(e + m.env_off), ep, 0);
@@ -900,33 +1066,24 @@ __global__ void __launch_bounds__(64) k_env_reset(ModelDev<Real> m, EnvState<Rea
 }
 
 // observation / reward / flags for the current state without stepping (RecordState, CalcReward, CheckTerminate)
-template <typename Real, int NJ, int ND, int NP, int NCAP>
+template <typename Real, typename C>
 __global__ void __launch_bounds__(64) k_env_query(ModelDev<Real> m, EnvState<Real> st, StepIO<Real> io, DebugTaps<Real> dbg) {
-    __shared__ Lds<Real, NJ, ND, NP, NCAP> lds;
+    __shared__ Lds<Real, C> lds;
     const int e = blockIdx.x, l = threadIdx.x;
-    EnvSim<Real, NJ, ND, NP, NCAP> sim(m, lds, l);
+    EnvSim<Real, C> sim(m, lds, l);
     sim.load(st, e);
-    sim.emit(io, dbg, e);
+    sim.emit(io, dbg, e, true);
 }
 
 // component taps for parity tests: SPD torque for the stored state / one substep with the stored torque
-template <typename Real, int NJ, int ND, int NP, int NCAP>
+template <typename Real, typename C>
 __global__ void __launch_bounds__(64) k_env_probe(ModelDev<Real> m, EnvState<Real> st, DebugTaps<Real> dbg, int what, double dt) {
-    __shared__ Lds<Real, NJ, ND, NP, NCAP> lds;
+    __shared__ Lds<Real, C> lds;
     const int e = blockIdx.x, l = threadIdx.x;
-    EnvSim<Real, NJ, ND, NP, NCAP> sim(m, lds, l);
+    EnvSim<Real, C> sim(m, lds, l);
     sim.load(st, e);
-    if (what == 0) {                       // SPD
-        sim.spd((Real)dt);
-    } else if (what == 1) {                // substep
-        sim.substep((Real)dt, dbg, e);
-    } else if (what == 2) {                // dynamics only (SPD model) -> H, C taps
-        typename EnvSim<Real, NJ, ND, NP, NCAP>::v3 v0 = ld3(lds.vel), w0 = ld3(lds.vel + 3);
-        M3<Real> E = quat_to_rot(ldq(lds.pose + 3));
-        sim.kinematics(lds.pose, lds.vel, sim.gravity_a0() + cross(v0, E * w0 - w0));
-        sim.dynamics(0);
-        if (dbg.H) { for (int i = l; i < m.D * m.D; i += kWave) dbg.H[(size_t)e * m.D * m.D + i] = lds.H[i / m.D][i % m.D]; if (l < m.D) dbg.C[(size_t)e * m.D + l] = lds.bias[l]; }
-    }
+    // what: 0 SPD torque, 1 one substep of length dt with the latched torque, 2 SPD-model mass matrix / bias force taps only
+    sim.dyn_phase(what == 1 ? 1 : 0, (Real)dt, (Real)dt, dbg, e, what == 2, false);
     sim.store(st, e);
 }
 

@@ -260,20 +260,49 @@ struct CtxT : CtxBase {
         if (p && !v.empty()) rt_h2d(p, tmp.data(), sizeof(T) * v.size(), stream);
         return (const T*)p;
     }
+    template <typename C> const uint32_t* build_mdl(int* words) {
+        const HostModel& h = hm;
+        MdlLds<Real, C>* b = new MdlLds<Real, C>();
+        memset(b, 0, sizeof(*b));
+        for (int j = 0; j < h.J; ++j) {
+            b->link_info[j] = (h.parent[j] + 1) | (h.jtype[j] << 5) | (h.depth[j] << 8) | (h.pose_off[j] << 12) | (h.dof_off[j] << 19) |
+                              (h.arot_ident[j] << 26) | (h.brot_ident[j] << 27) | ((h.is_ee[j] ? 1 : 0) << 28) | ((h.fall[j] ? 1 : 0) << 29);
+            b->subtree_mask[j] = h.subtree_mask[j];
+            uint64_t chain = 0;
+            for (int a = j; a != -1; a = h.parent[a]) for (int k = 0; k < h.ndof[a]; ++k) chain |= (1ull << (h.dof_off[a] + k));
+            b->chain_lo[j] = (uint32_t)(chain & 0xffffffffull); b->chain_hi[j] = (uint32_t)(chain >> 32);
+            for (int k = 0; k < 3; ++k) { b->attach[j][k] = (Real)h.attach[j * 3 + k]; b->battach[j][k] = (Real)h.battach[j * 3 + k];
+                                          b->inertia[0][j][k] = (Real)h.inertia[(0 * h.J + j) * 3 + k]; b->inertia[1][j][k] = (Real)h.inertia[(1 * h.J + j) * 3 + k]; }
+            b->mass[j] = (Real)h.mass[j]; b->thresh[j] = (Real)h.thresh[j]; b->torque_lim[j] = (Real)h.torque_lim[j];
+            if (C::ROT) for (int k = 0; k < 9; ++k) { b->attach_rot[C::ROT ? j : 0][k] = (Real)h.attach_rot[j * 9 + k]; b->brot[C::ROT ? j : 0][k] = (Real)h.brot[j * 9 + k]; }
+        }
+        for (int i = 0; i < h.D; ++i) {
+            b->dof_info[i] = h.dof_joint[i] | (h.dof_kind[i] << 8) | (h.dof_axis[i] << 10) | (h.dof_vidx[i] << 12);
+            uint64_t anc = h.dof_anc[i] & ((i == 63) ? ~0ull : ((1ull << (i + 1)) - 1));     // ancestor-or-self dofs k <= i
+            b->anc_lo[i] = (uint32_t)(anc & 0xffffffffull); b->anc_hi[i] = (uint32_t)(anc >> 32);
+            b->kp[i] = (Real)h.kp[i]; b->kd[i] = (Real)h.kd[i];
+        }
+        for (int r = 0; r < h.NL; ++r) { int j = h.lim_joint[r]; b->lim_joint[r] = j; b->lim_lo[r] = (Real)h.lim_lo[j]; b->lim_hi[r] = (Real)h.lim_hi[j]; }
+        const size_t bytes = (sizeof(*b) + 3) / 4 * 4;
+        void* p = dalloc(bytes);
+        if (p) rt_h2d(p, b, sizeof(*b), stream);
+        delete b;
+        *words = (int)(bytes / 4);
+        return (const uint32_t*)p;
+    }
     int setup() override {
         const HostModel& h = hm; const dm_scene_tables& c = h.cfg;
         memset(&md, 0, sizeof(md)); memset(&dbg, 0, sizeof(dbg));
         md.J = h.J; md.P = h.P; md.D = h.D; md.A = h.A; md.S = h.S; md.F = h.F; md.NC = h.NC; md.NL = h.NL; md.max_depth = h.max_depth;
-        md.parent = up<int>(h.parent); md.jtype = up<int>(h.jtype); md.pose_off = up<int>(h.pose_off); md.dof_off = up<int>(h.dof_off);
-        md.ndof = up<int>(h.ndof); md.depth = up<int>(h.depth); md.act_off = up<int>(h.act_off); md.is_ee = up<int>(h.is_ee); md.fall = up<int>(h.fall);
-        md.brot_ident = up<int>(h.brot_ident); md.arot_ident = up<int>(h.arot_ident); md.subtree_mask = up<uint32_t>(h.subtree_mask);
-        md.attach = up<Real>(h.attach); md.attach_rot = up<Real>(h.attach_rot); md.battach = up<Real>(h.battach); md.brot = up<Real>(h.brot);
-        md.mass = up<Real>(h.mass); md.inertia = up<Real>(h.inertia); md.torque_lim = up<Real>(h.torque_lim); md.lim_lo = up<Real>(h.lim_lo); md.lim_hi = up<Real>(h.lim_hi);
-        md.diffw = up<Real>(h.diffw); md.thresh = up<Real>(h.thresh); md.aabb_he = up<Real>(h.aabb_he);
-        md.dof_joint = up<int>(h.dof_joint); md.dof_kind = up<int>(h.dof_kind); md.dof_axis = up<int>(h.dof_axis); md.dof_vidx = up<int>(h.dof_vidx);
-        md.dof_anc = up<uint64_t>(h.dof_anc); md.kp = up<Real>(h.kp); md.kd = up<Real>(h.kd);
+        bool any_rot = false;
+        for (int j = 0; j < h.J; ++j) if (!h.arot_ident[j] || !h.brot_ident[j]) any_rot = true;
+        if (h.NL > kMaxLim) return fail("more than 8 joint-limit rows");
+        if (h.J <= ClsBiped::NJ && h.D <= ClsBiped::ND && h.P <= ClsBiped::NP && h.NC <= ClsBiped::NCAP && !any_rot) cls = 0;
+        else if (h.J <= ClsLarge::NJ && h.D <= ClsLarge::ND && h.P <= ClsLarge::NP && h.NC <= ClsLarge::NCAP) cls = 1;
+        else return fail("character too large for the compiled kernel classes (J<=23, D<=64, P<=83, <=128 contact candidates)");
+        md.mdl_blob = (cls == 0) ? build_mdl<ClsBiped>(&md.mdl_words) : build_mdl<ClsLarge>(&md.mdl_words);
+        md.act_off = up<int>(h.act_off); md.diffw = up<Real>(h.diffw); md.aabb_he = up<Real>(h.aabb_he);
         md.cand_link = up<int>(h.cand_link); md.cand_loc = up<Real>(h.cand_loc); md.cand_rad = up<Real>(h.cand_rad);
-        md.lim_joint = up<int>(h.lim_joint);
         md.frame_time = up<double>(h.frame_time); md.frames = up<Real>(h.frames); md.frame_vel = up<Real>(h.frame_vel);
         md.duration = h.duration; md.loop = h.loop; for (int k = 0; k < 3; ++k) { md.cycle_delta[k] = (Real)h.cycle_delta[k]; md.gravity[k] = (Real)c.gravity[k]; }
         md.num_sim_substeps = c.num_sim_substeps; md.solver_iters = c.solver_iters > 0 ? c.solver_iters : 10; md.max_contacts = max_contacts;
@@ -291,8 +320,7 @@ struct CtxT : CtxBase {
         st.clock = (double*)dalloc(sizeof(double) * N * 6); st.flag = (int*)dalloc(sizeof(int) * N * 4);
         d_actions = (float*)dalloc(sizeof(float) * N * h.A); d_states = (float*)dalloc(sizeof(float) * N * h.S); d_rewards = (float*)dalloc(sizeof(float) * N);
         d_term = (int*)dalloc(sizeof(int) * N); d_valid = (int*)dalloc(sizeof(int) * N); d_end = (int*)dalloc(sizeof(int) * N);
-        if (!st.pose || !st.flag || !d_end) return fail("device allocation failed");
-        if (h.J <= 15 && h.D <= 34 && h.P <= 43 && h.NC <= 64) cls = 0; else if (h.J <= 23 && h.D <= 64 && h.P <= 83) cls = 1; else return fail("character too large for the compiled kernel classes (J<=23, D<=64, P<=83)");
+        if (!st.pose || !st.flag || !d_end || !md.mdl_blob) return fail("device allocation failed");
         // PD targets start at identity rotations (cPDController::PostProcessTargetPose, PDController.cpp:425-443)
         std::vector<Real> tar((size_t)N * h.P, 0);
         for (int e = 0; e < N; ++e) for (int j = 1; j < h.J; ++j) if (h.jtype[j] == JT_SPHERICAL) tar[(size_t)e * h.P + h.pose_off[j]] = 1;
@@ -313,8 +341,8 @@ struct CtxT : CtxBase {
     }
 #define DM_DISPATCH(KERN, grid, ...)                                                         \
     do {                                                                                     \
-        if (cls == 0) RT_LAUNCH((KERN<Real, 15, 34, 43, 64>), grid, stream, __VA_ARGS__);        \
-        else RT_LAUNCH((KERN<Real, 23, 64, 83, 128>), grid, stream, __VA_ARGS__);                 \
+        if (cls == 0) RT_LAUNCH((KERN<Real, ClsBiped>), grid, stream, __VA_ARGS__);              \
+        else RT_LAUNCH((KERN<Real, ClsLarge>), grid, stream, __VA_ARGS__);                       \
     } while (0)
 
     int reset(const int* ids_dev, int n, const double* kt_dev, const double* mt_dev) override {

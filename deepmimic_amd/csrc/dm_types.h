@@ -1,7 +1,9 @@
 // Device-visible tables and per-env state for the imitate hot path.
 //
 // One `ModelDev` describes one scene type (skeleton + PD gains + motion clip + config); it is built on
-// the host by dm_host.cpp from the raw reference-layout tables and is shared by all envs.
+// the host by dm_host.cpp from the raw reference-layout tables and is shared by all envs.  The tables the
+// inner loops touch are packed into one `MdlLds` block that every wavefront copies into LDS at kernel entry
+// (one coalesced read of ~2 KB), so that no global-memory latency sits inside the 20-update loop.
 // `EnvState` is the per-env dynamic state in HBM: one record per env, fields contiguous per env
 // (a wave owns exactly one env, so "lane k reads field k of my env" is the coalesced pattern).
 #pragma once
@@ -16,31 +18,61 @@ enum { TERM_NULL = 0, TERM_FAIL = 1, TERM_SUCC = 2 };
 
 constexpr int kWave = 64;
 constexpr int kMaxRows = 64;   // constraint rows per substep (one per lane)
-constexpr int kMaxCand = 64;   // ground-contact candidate points per character (one per lane)
+constexpr int kMaxLim = 8;     // joint-limit rows (revolute joints with lo <= hi)
+
+// Compiled kernel classes: static bounds of the per-lane register arrays and the LDS record.
+struct ClsBiped {      // humanoid3d: 15 links, 34 dof, 43 pose dims, <= 64 ground-contact candidates, no attach rotations
+    static constexpr int NJ = 15, ND = 34, NP = 43, NCAP = 64; static constexpr bool ROT = false;
+};
+struct ClsLarge {      // dog3d and anything up to 23 links / 64 dof / 83 pose dims / 128 candidates, attach rotations allowed
+    static constexpr int NJ = 23, ND = 64, NP = 83, NCAP = 128; static constexpr bool ROT = true;
+};
+
+// link_info word: parent+1 [0:4] | jtype [5:7] | depth [8:11] | pose_off [12:18] | dof_off [19:25] | arot_ident 26 | brot_ident 27 | is_ee 28 | fall 29
+#define DM_LI_PARENT(i) (((i) & 31) - 1)
+#define DM_LI_JTYPE(i) (((i) >> 5) & 7)
+#define DM_LI_DEPTH(i) (((i) >> 8) & 15)
+#define DM_LI_POFF(i) (((i) >> 12) & 127)
+#define DM_LI_DOFF(i) (((i) >> 19) & 127)
+#define DM_LI_AROT_ID(i) (((i) >> 26) & 1)
+#define DM_LI_BROT_ID(i) (((i) >> 27) & 1)
+#define DM_LI_IS_EE(i) (((i) >> 28) & 1)
+#define DM_LI_FALL(i) (((i) >> 29) & 1)
+// dof_info word: joint [0:7] | kind [8:9] | axis [10:11] | vidx [12:19]
+#define DM_DI_JOINT(i) ((i) & 255)
+#define DM_DI_KIND(i) (((i) >> 8) & 3)
+#define DM_DI_AXIS(i) (((i) >> 10) & 3)
+#define DM_DI_VIDX(i) (((i) >> 12) & 255)
+
+// Hot model tables, staged in LDS.  Plain-old-data with the same layout on host and device.
+template <typename Real, typename C>
+struct MdlLds {
+    int link_info[C::NJ];
+    uint32_t subtree_mask[C::NJ];              // bit k: link k is in the subtree rooted at j (incl. j)
+    uint32_t chain_lo[C::NJ], chain_hi[C::NJ]; // dofs of the joints on the path root..j (incl.): support of a point Jacobian on link j
+    Real attach[C::NJ][3];                     // joint attach point in the parent joint frame
+    Real battach[C::NJ][3];                    // body COM in the joint frame
+    Real mass[C::NJ];
+    Real inertia[2][C::NJ][3];                 // principal inertias: [0] SPD model, [1] simulator model
+    Real thresh[C::NJ], torque_lim[C::NJ];
+    Real attach_rot[C::ROT ? C::NJ : 1][9];    // joint attach rotation (ClsLarge only)
+    Real brot[C::ROT ? C::NJ : 1][9];          // body frame in the joint frame (ClsLarge only)
+    int dof_info[C::ND];
+    uint32_t anc_lo[C::ND], anc_hi[C::ND];     // bit k: dof k belongs to an ancestor-or-self joint of dof i's joint, k <= i
+    Real kp[C::ND], kd[C::ND];
+    int lim_joint[kMaxLim]; Real lim_lo[kMaxLim], lim_hi[kMaxLim];
+};
 
 template <typename Real>
 struct ModelDev {
     int J, P, D, A, S, F, NC, NL, max_depth;
-    // ---- per link / joint (index j), J entries
-    const int* parent; const int* jtype; const int* pose_off; const int* dof_off; const int* ndof;
-    const int* depth; const int* act_off; const int* is_ee; const int* fall; const int* brot_ident; const int* arot_ident;
-    const uint32_t* subtree_mask;            // bit k: link k is in the subtree rooted at j (incl. j)
-    const Real* attach;                      // J x 3  joint attach point in the parent joint frame
-    const Real* attach_rot;                  // J x 9  joint attach rotation
-    const Real* battach;                     // J x 3  body COM in the joint frame
-    const Real* brot;                        // J x 9  body frame in the joint frame
-    const Real* mass;                        // J
-    const Real* inertia;                     // 2 x J x 3  principal inertias: [0] SPD model, [1] simulator model
-    const Real* torque_lim; const Real* lim_lo; const Real* lim_hi; const Real* diffw; const Real* thresh;
+    const uint32_t* mdl_blob; int mdl_words;   // MdlLds<Real, C> image
+    // ---- per link / joint tables only used outside the update loop (action latch, reward, reset)
+    const int* act_off;
+    const Real* diffw;
     const Real* aabb_he;                     // J x 4  half extents of the collider AABB box (w = 1: sphere)
-    // ---- per generalized velocity (index i), D entries: root lin 0..2, root ang 3..5, then joints
-    const int* dof_joint; const int* dof_kind; const int* dof_axis; const int* dof_vidx;
-    const uint64_t* dof_anc;                 // bit k: dof k belongs to an ancestor-or-self joint of dof i's joint
-    const Real* kp; const Real* kd;
-    // ---- ground contact candidates, NC entries
+    // ---- ground contact candidates, NC entries (each lane keeps its own candidates in registers)
     const int* cand_link; const Real* cand_loc /* NC x 3, body frame */; const Real* cand_rad;
-    // ---- joint-limit rows, NL entries (revolute joints with lo <= hi)
-    const int* lim_joint;
     // ---- motion clip
     const double* frame_time;                // F
     const Real* frames;                      // F x P (post-processed)

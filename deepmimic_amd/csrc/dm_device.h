@@ -58,8 +58,8 @@ static inline double dm_rsqrt(double x) { return 1.0 / sqrt(x); }
 static inline float dm_rcp(float x) { return 1.0f / x; }
 static inline double dm_rcp(double x) { return 1.0 / x; }
 template <typename T> static inline T dm_med3(T lo, T x, T hi) { return x < lo ? lo : (x > hi ? hi : x); }
-template <typename Real> struct RowFile {       // per-lane array indexed by a wave-uniform runtime index
-    Real v[kMaxRows];
+template <typename Real, int N> struct RowFile {       // per-lane array indexed by a wave-uniform runtime index
+    Real v[N];
     inline Real get(int r) const { return v[r]; }
     inline void set(int r, Real x) { v[r] = x; }
 };
@@ -122,12 +122,18 @@ __device__ __forceinline__ float dm_rcp(float x) { float r = __builtin_amdgcn_rc
 __device__ __forceinline__ double dm_rcp(double x) { return 1.0 / x; }
 // per-lane array indexed by a wave-uniform runtime index.  For float it is two 32-wide register vectors that the
 // backend addresses with M0-relative VGPR indexing, so a row of A never leaves the VGPRs.
-template <typename Real> struct RowFile {
-    Real v[kMaxRows];
+template <typename Real, int N> struct RowFile {
+    Real v[N];
     __device__ __forceinline__ Real get(int r) const { return v[r]; }
     __device__ __forceinline__ void set(int r, Real x) { v[r] = x; }
 };
-template <> struct RowFile<float> {
+template <> struct RowFile<float, 32> {
+    typedef float v32 __attribute__((ext_vector_type(32)));
+    v32 a;
+    __device__ __forceinline__ float get(int r) const { return a[r]; }
+    __device__ __forceinline__ void set(int r, float x) { a[r] = x; }
+};
+template <> struct RowFile<float, 64> {
     typedef float v32 __attribute__((ext_vector_type(32)));
     v32 a, b;
     __device__ __forceinline__ float get(int r) const { return (r < 32) ? a[r] : b[r - 32]; }
@@ -146,20 +152,23 @@ namespace dmk {
 template <typename Real, typename C>
 struct Lds {
     static constexpr int NJ = C::NJ, ND = C::ND, NP = C::NP, NCAP = C::NCAP;
-    static constexpr int kLS = ((ND + 3) / 4) * 4 + (((((ND + 3) / 4)) % 2 == 0) ? 4 : 0);   // L row stride: 16-B multiple, odd count of 16-B slots
+    // Lower-triangular storage of H / its Cholesky factor: row k holds k+1 entries padded to a multiple of 4 (16-B aligned
+    // rows for ds_read_b128 broadcasts); the diagonal slot holds 1/L_kk after the factorisation.
+    static constexpr int lrow(int k) { return 4 * (k / 4 + 1) * (2 * (k / 4) + (k % 4)); }
+    static constexpr int kLWords = lrow(ND);
     MdlLds<Real, C> mdl;
     Real pose[NP], vel[NP], tar[NP];
     Real tau[ND], bias[ND], rhs[ND], xs[ND];
     alignas(32) Real dofrec[ND][8];        // per dof: world axis a(3), g = (p_joint - p_root) x a (3), unconstrained velocity v*, pad
     Real R[NJ][9], p[NJ][3], com[NJ][3], w[NJ][3], vj[NJ][3], al[NJ][3], aj[NJ][3];
-    Real Rb[C::ROT ? NJ : 1][9];           // body frames (== R when the class has no attach rotations)
-    Real f[NJ][3], n[NJ][3], Iw[NJ][6];
-    Real Fs[NJ][3], Ns[NJ][3], Ic[NJ][10];
-    alignas(32) Real L[ND][kLS];           // mass matrix rows, then its Cholesky factor (diagonal slot holds 1/L_kk)
-    Real cx[NCAP][3], cdist[NCAP];         // ground-contact candidates
-    int csel[NCAP], cslot[kMaxRows];
+    Real Rb[C::ROT ? NJ : 1][C::ROT ? 9 : 1];   // body frames (== R when the class has no attach rotations)
+    union {
+        struct { Real f[NJ][3], n[NJ][3], Iw[NJ][6], Fs[NJ][3], Ns[NJ][3], Ic[NJ][10]; };   // Newton-Euler pass (dynamics)
+        struct { Real cx[NCAP][3], cdist[NCAP]; int csel[NCAP], cslot[kMaxRows]; };          // ground contacts (after dynamics)
+    };
+    alignas(32) Real Lt[kLWords];
     Real kin[8];                           // kin origin pos(3), origin rot(4)
-    Real sc[24];                           // small float scratch
+    Real sc[8];                            // small float scratch (kin / sim COM velocity, episode-end flag)
     double clk[6];                         // kin_time, ctrl_time, init_time_offset, timer_time, timer_max
     int flg[8];                            // need_new_action, contact_mask, episode_count, valid, nrows, ncontacts
 };
@@ -170,7 +179,7 @@ enum { FLG_NEED_ACTION = 0, FLG_CONTACT, FLG_EPISODE, FLG_VALID, FLG_NROWS, FLG_
 template <typename Real, typename C>
 struct EnvSim {
     typedef Lds<Real, C> L;
-    static constexpr int NJ = C::NJ, ND = C::ND, NP = C::NP, NCAP = C::NCAP, CPL = C::NCAP / kWave;
+    static constexpr int NJ = C::NJ, ND = C::ND, NP = C::NP, NCAP = C::NCAP, CPL = C::NCAP / kWave, RREG = C::RREG;
     static constexpr int NP2 = ND / 2;                 // register pairs per dof vector (ND is even for every class)
     typedef V3<Real> v3; typedef Q4<Real> q4; typedef M3<Real> m3;
     typedef typename VecT<Real>::v2 R2; typedef typename VecT<Real>::v4 R4;
@@ -181,7 +190,8 @@ struct EnvSim {
     DM_DEV EnvSim(const ModelDev<Real>& m_, L& s_, int l_) : m(m_), s(s_), l(l_) {}
     DM_DEV void mark(int phase) { if (prof) { long long t = dm_clock(); if (l == 0) prof[phase] += t - tprev; tprev = t; } }
     DM_DEV void sync() const { __syncthreads(); }
-    DM_DEV Real* scratch() const { return &s.L[0][0]; }   // L is dead outside the update loop: kin pose / vel / reductions live there
+    DM_DEV Real* scratch() const { return &s.Lt[0]; }   // L is dead outside the update loop: kin pose / vel / reductions live there
+    DM_DEV Real& Lx(int r, int c) const { return s.Lt[L::lrow(r) + c]; }
     DM_DEV const Real* Rbp(int j) const { return C::ROT ? s.Rb[j] : s.R[j]; }
     static DM_DEV v3 zero3() { return mk3((Real)0, (Real)0, (Real)0); }
 
@@ -334,7 +344,7 @@ struct EnvSim {
             }
             v3 Lq = Lp + cross(ld3(s.p[dj]) - ld3(s.p[0]), Pm);
             // row l of H: zero, then the ancestor-or-self dofs k <= l:  H_lk = a_k . Lq + g_k . Pm
-            Real* row = s.L[l];
+            Real* row = &s.Lt[L::lrow(l)];
             for (int k = 0; k <= l; ++k) row[k] = 0;
             uint32_t lo = s.mdl.anc_lo[l], hi = s.mdl.anc_hi[l];
             while (lo | hi) {
@@ -365,7 +375,7 @@ struct EnvSim {
         // own row; entries right of the diagonal are never consumed (they only feed this lane's own dead entries)
 #pragma unroll
         for (int p = 0; p < NP2; ++p) {
-            R2 v = *reinterpret_cast<const R2*>(&s.L[lr][2 * p]);
+            R2 v = *reinterpret_cast<const R2*>(&s.Lt[L::lrow(lr) + 2 * p]);
             if (!(l < D)) { v[0] = (l == 2 * p) ? (Real)1 : (Real)0; v[1] = (l == 2 * p + 1) ? (Real)1 : (Real)0; }
             h2[p] = v;
         }
@@ -385,12 +395,13 @@ struct EnvSim {
             for (int p = (k + 2) >> 1; p < NP2; ++p) { const R2 bb = {lane_bcast(lik, 2 * p), lane_bcast(lik, 2 * p + 1)}; h2[p] -= l2 * bb; }
         }
         if (l < ND) {
+            Real* row = &s.Lt[L::lrow(l)];
 #pragma unroll
             for (int p = 0; p < NP2; ++p) {
                 R2 v = h2[p];
                 if (l == 2 * p) v[0] = dinv;
                 if (l == 2 * p + 1) v[1] = dinv;
-                *reinterpret_cast<R2*>(&s.L[l][2 * p]) = v;
+                if (2 * p <= l) *reinterpret_cast<R2*>(&row[2 * p]) = v;
             }
         }
         Real x = (l < D) ? xvec[l] : (Real)0;
@@ -409,7 +420,7 @@ struct EnvSim {
         Real c[ND];
         const int lr = l < ND ? l : 0;
 #pragma unroll
-        for (int k = 0; k < ND; ++k) c[k] = (l < ND && k > l) ? s.L[k][lr] : (Real)0;
+        for (int k = 0; k < ND; ++k) c[k] = (l < ND && k > l) ? s.Lt[L::lrow(k) + lr] : (Real)0;
 #pragma unroll
         for (int k = ND - 1; k >= 0; --k) {
             Real t = x * dinv; Real xk = lane_bcast(t, k);
@@ -481,7 +492,7 @@ struct EnvSim {
         return dm_max(-mx, dm_min(mx, v));
     }
     // s.rhs holds qddot of the unconstrained dynamics; s.L the Cholesky factor of H.
-    DM_DEV void substep_post(Real h, DebugTaps<Real> dbg, int e) {
+    DM_DEV void substep_post(Real h, DebugTaps<Real> dbg, int e, Real* aovf) {
         const int D = m.D, J = m.J;
         Real vstar = 0; int vidx = 0;
         if (l < D) { vidx = DM_DI_VIDX(s.mdl.dof_info[l]); vstar = clamp_vel(s.vel[vidx] + h * s.rhs[l], l); s.dofrec[l][6] = vstar; }
@@ -579,12 +590,12 @@ struct EnvSim {
                 const Real raw = on ? val : (Real)0;
                 cvec += raw * r1[2];
                 R2 acc2 = {(Real)0, (Real)0};
-                const R2* lrow = reinterpret_cast<const R2*>(&s.L[k][0]);
+                const R2* lrow = reinterpret_cast<const R2*>(&s.Lt[L::lrow(k)]);
 #pragma unroll
                 for (int p = 0; p < (k >> 1); ++p) acc2 += lrow[p] * y2[p];
                 Real acc = raw - (acc2[0] + acc2[1]);
-                if (k & 1) acc -= s.L[k][k - 1] * y2[k >> 1][0];
-                yk = acc * s.L[k][k];
+                if (k & 1) acc -= s.Lt[L::lrow(k) + k - 1] * y2[k >> 1][0];
+                yk = acc * s.Lt[L::lrow(k) + k];
             }
             y2[k >> 1][k & 1] = yk;
         }
@@ -597,7 +608,8 @@ struct EnvSim {
         // no row can leave lambda = 0 unless some limit / normal row starts violated: skip A and the sweeps otherwise
         if (wave_ballot(l < RN && (b - cvec) > 0) != 0) {
             // A = Y^T Y: lane l keeps row l of A in a register file indexed by the row id
-            RowFile<Real> arow;
+            // (rows >= RREG of a heavily contacted character overflow to a per-env HBM scratch block, [row][lane])
+            RowFile<Real, RREG> arow;
             Real adiag;
             { R2 a2 = {(Real)0, (Real)0};
 #pragma unroll
@@ -607,7 +619,8 @@ struct EnvSim {
                 R2 a2 = {(Real)0, (Real)0};
 #pragma unroll
                 for (int p = 0; p < NP2; ++p) { const R2 bb = {lane_bcast(y2[p][0], r), lane_bcast(y2[p][1], r)}; a2 += y2[p] * bb; }
-                arow.set(r, a2[0] + a2[1]);
+                if (RREG >= kMaxRows || r < RREG) arow.set(r, a2[0] + a2[1]);
+                else aovf[(r - RREG) * kWave + l] = a2[0] + a2[1];
             }
             mark(10);
             Real u = cvec;
@@ -629,7 +642,8 @@ struct EnvSim {
                                 if (r == RNv) { const Real ln = wave_shfl(lam, nrm_lane); if (is_fric) { hi = m.friction * ln; lo = -hi; } }
                                 const Real nl = dm_med3(lo, lam + (b - u) * inv_adiag, hi);
                                 const Real delta = lane_bcast(nl - lam, r);
-                                u += arow.get(r) * delta;
+                                const Real ar = (r < RREG) ? arow.get(r < RREG ? r : 0) : aovf[(r - RREG) * kWave + l];
+                                u += ar * delta;
                                 if (lv == r) lam = nl;
                             }
                         }
@@ -657,7 +671,7 @@ struct EnvSim {
             tr_stage<(NP2 + 15) / 16, 32>(w);
             z = w[0];
         }
-        Real dinv = (l < ND) ? s.L[l < ND ? l : 0][l < ND ? l : 0] : (Real)1;
+        Real dinv = (l < ND) ? Lx(l < ND ? l : 0, l < ND ? l : 0) : (Real)1;
         z = back_substitute(z, dinv);
         if (l < D) s.vel[vidx] = clamp_vel(vstar + z, l);
         sync();
@@ -789,7 +803,7 @@ struct EnvSim {
     // dynamics / Cholesky code (the instruction stream of the 20-update loop must fit the instruction cache).
     // reuse_kin: pose / vel are unchanged since the previous phase's kinematics (stable-PD solve -> first substep); only
     // the base acceleration differs, and it enters every joint-origin acceleration as the same additive constant.
-    DM_DEV void dyn_phase(int ph, Real dt, Real h, DebugTaps<Real> dbg, int e, bool tap_only, bool reuse_kin) {
+    DM_DEV void dyn_phase(int ph, Real dt, Real h, DebugTaps<Real> dbg, int e, bool tap_only, bool reuse_kin, Real* aovf) {
         mark(ph == 0 ? 0 : 4);
         if (reuse_kin) {
             if (l < m.J) { v3 da = gravity_a0() - spd_a0(); st3(s.aj[l], ld3(s.aj[l]) + da); }
@@ -800,7 +814,7 @@ struct EnvSim {
         mark(ph == 0 ? 2 : 6);
         if (dbg.H) {
             const int D = m.D;
-            for (int i = l; i < D * D; i += kWave) { int r = i / D, c = i % D; Real v = (c <= r) ? s.L[r][c] : s.L[c][r]; if (r == c && ph == 0) v -= dt * s.mdl.kd[r]; dbg.H[(size_t)e * D * D + i] = v; }
+            for (int i = l; i < D * D; i += kWave) { int r = i / D, c = i % D; Real v = (c <= r) ? Lx(r, c) : Lx(c, r); if (r == c && ph == 0) v -= dt * s.mdl.kd[r]; dbg.H[(size_t)e * D * D + i] = v; }
             if (l < D) dbg.C[(size_t)e * D + l] = s.bias[l];
         }
         if (tap_only) return;
@@ -808,13 +822,13 @@ struct EnvSim {
         else { if (l < m.D) s.rhs[l] = s.tau[l] - s.bias[l]; sync(); }
         chol_solve(s.rhs);
         if (ph == 0) { mark(3); spd_post(dt); }
-        else substep_post(h, dbg, e);
+        else substep_post(h, dbg, e, aovf);
     }
-    DM_DEV void update(double dt, DebugTaps<Real> dbg, int e) {
+    DM_DEV void update(double dt, DebugTaps<Real> dbg, int e, Real* aovf) {
         if (l == 0) { s.clk[CLK_TIMER] += dt; s.clk[CLK_CTRL] += dt; s.flg[FLG_NEED_ACTION] = 0; }
         kin_update(dt);
         const Real h = (Real)(dt / m.num_sim_substeps);
-        for (int ph = 0; ph <= m.num_sim_substeps; ++ph) dyn_phase(ph, (Real)dt, h, dbg, e, false, ph == 1);
+        for (int ph = 0; ph <= m.num_sim_substeps; ++ph) dyn_phase(ph, (Real)dt, h, dbg, e, false, ph == 1, aovf);
         if (l == 0) {                      // cCtController::CheckNeedNewAction (CtController.cpp:221-227)
             double cur = s.clk[CLK_CTRL] + s.clk[CLK_INIT_OFF], pad = 0.001 * dt;
             int c1 = (int)floor((cur + pad) / m.query_period), c0 = (int)floor((cur + pad - dt) / m.query_period);
@@ -1017,8 +1031,18 @@ DM_HD double dm_rand01(uint64_t seed, uint64_t env, uint64_t episode, uint64_t s
 
 // ============================================================================ kernels
 // grid = number of envs, block = one wavefront.
+// Occupancy target of the step kernel: fp32 biped 4 waves / SIMD (<= 128 VGPRs, <= 10 KB LDS: 4096 envs are resident at
+// once on 256 CUs x 4 SIMDs), fp32 large class 2, fp64 parity builds unconstrained.
+template <typename Real, typename C> struct StepWaves { static constexpr int value = 1; };
+template <> struct StepWaves<float, ClsBiped> { static constexpr int value = 4; };
+template <> struct StepWaves<float, ClsLarge> { static constexpr int value = 2; };
+#ifdef DM_EMU
+#define DM_WAVES_PER_EU(n)
+#else
+#define DM_WAVES_PER_EU(n) __attribute__((amdgpu_waves_per_eu(n, n)))
+#endif
 template <typename Real, typename C>
-__global__ void __launch_bounds__(64) k_env_step(ModelDev<Real> m, EnvState<Real> st, StepIO<Real> io, DebugTaps<Real> dbg) {
+__global__ void __launch_bounds__(64) DM_WAVES_PER_EU((StepWaves<Real, C>::value)) k_env_step(ModelDev<Real> m, EnvState<Real> st, StepIO<Real> io, DebugTaps<Real> dbg) {
     __shared__ Lds<Real, C> lds;
     const int e = blockIdx.x, l = threadIdx.x;
     EnvSim<Real, C> sim(m, lds, l);
@@ -1027,7 +1051,8 @@ __global__ void __launch_bounds__(64) k_env_step(ModelDev<Real> m, EnvState<Real
     if (io.open_loop) sim.set_action_from_clip();
     else if (io.actions) sim.set_action(io.actions + (size_t)e * m.A);
     sim.mark(15);
-    for (int u = 0; u < io.n_updates; ++u) sim.update(io.dt, dbg, e);
+    Real* aovf = st.aovf ? st.aovf + (size_t)e * (kMaxRows - C::RREG) * kWave : nullptr;
+    for (int u = 0; u < io.n_updates; ++u) sim.update(io.dt, dbg, e, aovf);
     if (io.emit) {
         // pass 0 writes reward / flags / observation.  With auto-reset (mirrors DeepMimic.py:70-79) an env whose episode
         // ended starts its next episode and pass 1 hands back the observation the agent needs for its first action
@@ -1083,7 +1108,7 @@ __global__ void __launch_bounds__(64) k_env_probe(ModelDev<Real> m, EnvState<Rea
     EnvSim<Real, C> sim(m, lds, l);
     sim.load(st, e);
     // what: 0 SPD torque, 1 one substep of length dt with the latched torque, 2 SPD-model mass matrix / bias force taps only
-    sim.dyn_phase(what == 1 ? 1 : 0, (Real)dt, (Real)dt, dbg, e, what == 2, false);
+    sim.dyn_phase(what == 1 ? 1 : 0, (Real)dt, (Real)dt, dbg, e, what == 2, false, st.aovf ? st.aovf + (size_t)e * (kMaxRows - C::RREG) * kWave : nullptr);
     sim.store(st, e);
 }
 

@@ -318,6 +318,7 @@ struct CtxT : CtxBase {
         st.pose = (Real*)dalloc(sizeof(Real) * N * h.P); st.vel = (Real*)dalloc(sizeof(Real) * N * h.P); st.tar = (Real*)dalloc(sizeof(Real) * N * h.P);
         st.tau = (Real*)dalloc(sizeof(Real) * N * h.D); st.kin = (Real*)dalloc(sizeof(Real) * N * 8);
         st.clock = (double*)dalloc(sizeof(double) * N * 6); st.flag = (int*)dalloc(sizeof(int) * N * 4);
+        st.aovf = (cls == 0) ? (Real*)dalloc(sizeof(Real) * (size_t)N * (kMaxRows - ClsBiped::RREG) * kWave) : nullptr;
         d_actions = (float*)dalloc(sizeof(float) * N * h.A); d_states = (float*)dalloc(sizeof(float) * N * h.S); d_rewards = (float*)dalloc(sizeof(float) * N);
         d_term = (int*)dalloc(sizeof(int) * N); d_valid = (int*)dalloc(sizeof(int) * N); d_end = (int*)dalloc(sizeof(int) * N);
         if (!st.pose || !st.flag || !d_end || !md.mdl_blob) return fail("device allocation failed");

@@ -22,10 +22,10 @@ constexpr int kMaxLim = 8;     // joint-limit rows (revolute joints with lo <= h
 
 // Compiled kernel classes: static bounds of the per-lane register arrays and the LDS record.
 struct ClsBiped {      // humanoid3d: 15 links, 34 dof, 43 pose dims, <= 64 ground-contact candidates, no attach rotations
-    static constexpr int NJ = 15, ND = 34, NP = 43, NCAP = 64; static constexpr bool ROT = false;
+    static constexpr int NJ = 15, ND = 34, NP = 43, NCAP = 64, RREG = 32; static constexpr bool ROT = false;   // RREG: rows of A kept in VGPRs
 };
 struct ClsLarge {      // dog3d and anything up to 23 links / 64 dof / 83 pose dims / 128 candidates, attach rotations allowed
-    static constexpr int NJ = 23, ND = 64, NP = 83, NCAP = 128; static constexpr bool ROT = true;
+    static constexpr int NJ = 23, ND = 64, NP = 83, NCAP = 128, RREG = 64; static constexpr bool ROT = true;
 };
 
 // link_info word: parent+1 [0:4] | jtype [5:7] | depth [8:11] | pose_off [12:18] | dof_off [19:25] | arot_ident 26 | brot_ident 27 | is_ee 28 | fall 29
@@ -55,8 +55,8 @@ struct MdlLds {
     Real mass[C::NJ];
     Real inertia[2][C::NJ][3];                 // principal inertias: [0] SPD model, [1] simulator model
     Real thresh[C::NJ], torque_lim[C::NJ];
-    Real attach_rot[C::ROT ? C::NJ : 1][9];    // joint attach rotation (ClsLarge only)
-    Real brot[C::ROT ? C::NJ : 1][9];          // body frame in the joint frame (ClsLarge only)
+    Real attach_rot[C::ROT ? C::NJ : 1][C::ROT ? 9 : 1];    // joint attach rotation (ClsLarge only)
+    Real brot[C::ROT ? C::NJ : 1][C::ROT ? 9 : 1];          // body frame in the joint frame (ClsLarge only)
     int dof_info[C::ND];
     uint32_t anc_lo[C::ND], anc_hi[C::ND];     // bit k: dof k belongs to an ancestor-or-self joint of dof i's joint, k <= i
     Real kp[C::ND], kd[C::ND];
@@ -100,6 +100,7 @@ struct EnvState {
     Real* kin;       // N x 8   kin origin pos(3) + origin rot(4) + pad
     double* clock;   // N x 6   kin_time, ctrl_time, init_time_offset, timer_time, timer_max, pad
     int* flag;       // N x 4   need_new_action, contact_mask, episode_count, valid
+    Real* aovf;      // N x (64 - RREG) x 64  overflow rows of the constraint-space matrix (null when the class keeps all 64 in VGPRs)
 };
 
 // Per-call I/O of the batched step (device pointers; any may be null)

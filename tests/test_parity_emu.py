@@ -31,7 +31,7 @@ def test_spd_fp32(emu_lib):
     pc.check_spd("humanoid3d_walk", 32, emu_lib, rtol=2e-3)
 
 
-@pytest.mark.parametrize("name,lift", [("humanoid3d_walk", 0.0), ("humanoid3d_walk", -0.03), ("dog3d_pace", 0.0)])
+@pytest.mark.parametrize("name,lift", [("humanoid3d_walk", 0.0), ("humanoid3d_walk", -0.03), ("humanoid3d_walk", -0.3), ("dog3d_pace", 0.0)])
 def test_substep_fp64(emu_lib, name, lift):
     nc = pc.check_substep(name, 64, emu_lib, tol_vel=1e-8, tol_pose=1e-10, lift=lift)
     if lift < 0:

@@ -1,0 +1,291 @@
+"""Drop-in replacement for the reference's SWIG module ``DeepMimicCore.DeepMimicCore`` on the ``--scene imitate`` path.
+
+The reference builds ``DeepMimicCore/DeepMimicCore.py`` + ``_DeepMimicCore.so`` with SWIG from
+``DeepMimicCore/DeepMimicCore.i:1-34`` and ``env/deepmimic_env.py:3`` imports it as
+``from DeepMimicCore import DeepMimicCore``.  Put ``<repo>/deepmimic_amd/compat`` (this directory's parent) and
+``<repo>`` on ``PYTHONPATH`` ahead of the reference's own ``DeepMimicCore/`` directory and the unmodified
+``env/deepmimic_env.py`` / ``learning/`` agents drive the MI355X library instead of Bullet.
+
+``cDeepMimicCore`` mirrors ``DeepMimicCore/DeepMimicCore.h:9-87`` method for method (same names, argument meaning and
+return types; vectors are returned as Python lists of float / int like SWIG's ``std::vector`` wrappers).  One instance is
+one env (``dm_ctx`` with ``num_envs = 1``) on the GPU given by ``DM_DEVICE`` (default 0).  The batched extension --
+thousands of envs per GPU, one kernel launch per control step -- is ``deepmimic_amd.core.BatchEnv`` /
+``include/dm_hip.h:dm_step_batch``.
+
+Errors: the reference ``assert(false)``s (DeepMimicCore.cpp:36-40); this module raises ``RuntimeError`` instead.
+"""
+import os
+import sys
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.abspath(os.path.join(_HERE, "..", "..", ".."))
+if _ROOT not in sys.path:
+    sys.path.insert(0, _ROOT)
+
+from deepmimic_amd import model as _model  # noqa: E402
+from deepmimic_amd.core import BatchEnv as _BatchEnv  # noqa: E402
+
+_DT_EPS = 0.0
+
+
+class cDeepMimicCore(object):
+    # cRLScene::eMode (scenes/RLScene.h:11-16)
+    eModeTrain, eModeTest = 0, 1
+
+    def __init__(self, enable_draw):
+        if enable_draw:
+            # DeepMimicCore.cpp:9-18 sets up GL state; rendering is outside the accelerated path
+            raise RuntimeError("cDeepMimicCore(enable_draw=True): the MI355X path is headless (use enable_draw=False)")
+        self._seed = 0
+        self._args = None
+        self._tables = None
+        self._env = None
+        self._mode = self.eModeTrain
+        self._num_update_substeps = 1
+        self._cache = None
+        self._time = 0.0
+        self._playback_speed = 1.0
+        self._updates_per_sec = 0.0
+
+    # ---- construction (DeepMimicCore.cpp:20-54)
+    def SeedRand(self, seed):
+        self._seed = int(seed)
+
+    def ParseArgs(self, args):
+        args = [str(a) for a in args]
+        data_root = os.environ.get("DM_DATA_ROOT", ".")
+        self._tables = _model.load_scene_from_args(args, data_root=data_root)
+        p = _model.ArgParser(args)
+        af = p.str("arg_file", "")
+        if af:
+            p.load_file(af if os.path.isabs(af) else os.path.join(data_root, af))
+        self._num_update_substeps = p.int("num_update_substeps", 1)      # DeepMimicCore.cpp:43
+
+    def LoadTables(self, tables, num_update_substeps=1):
+        """Extension: hand over already-parsed scene tables (e.g. ``deepmimic_amd.model.load_asset``) instead of arg files."""
+        self._tables = tables
+        self._num_update_substeps = int(num_update_substeps)
+
+    def Init(self):
+        if self._tables is None:
+            raise RuntimeError("cDeepMimicCore.Init(): ParseArgs() has not been called")
+        self._env = _BatchEnv(self._tables, 1, device_id=int(os.environ.get("DM_DEVICE", "0")), seed=self._seed,
+                              precision=int(os.environ.get("DM_PRECISION", "32")), lib_path=os.environ.get("DM_HIP_LIB"))
+        self._off = self._env.offsets_scales()
+        self._apply_mode()
+        self._env.reset()
+        self._cache = None
+
+    def _apply_mode(self):
+        c = self._tables.cfg
+        if self._mode == self.eModeTest and c.time_end_lim_max is not None:
+            lo = c.time_end_lim_min if c.time_end_lim_min is not None else c.time_end_lim_max
+            self._env.set_time_limits(float(lo), float(c.time_end_lim_max))
+        else:
+            self._env.set_time_limits(float(c.time_lim_min), float(c.time_lim_max))
+
+    def _need_env(self):
+        if self._env is None:
+            raise RuntimeError("cDeepMimicCore: Init() has not been called")
+        return self._env
+
+    def _query(self):
+        if self._cache is None:
+            self._cache = self._need_env().query()
+        return self._cache
+
+    # ---- stepping (DeepMimicCore.cpp:56-65)
+    def Update(self, timestep):
+        self._need_env().update(float(timestep), 1)
+        self._cache = None
+
+    def Reset(self):
+        self._need_env().reset()
+        self._cache = None
+
+    def GetTime(self):
+        return float(self._need_env().get_state()["clocks"][0][3])
+
+    def GetName(self):
+        return "Imitate"            # cSceneImitate::GetName (scenes/SceneImitate.cpp:207-210)
+
+    def EnableDraw(self):
+        return False
+
+    # ---- rendering / UI: no-ops on the headless path (DeepMimicCore.cpp:82-163)
+    def Draw(self):
+        pass
+
+    def Keyboard(self, key, x, y):
+        pass
+
+    def MouseClick(self, button, state, x, y):
+        pass
+
+    def MouseMove(self, x, y):
+        pass
+
+    def Reshape(self, w, h):
+        pass
+
+    def Shutdown(self):
+        if self._env is not None:
+            self._env.close()
+            self._env = None
+
+    def IsDone(self):
+        return False
+
+    def GetDrawScene(self):
+        return None
+
+    def SetPlaybackSpeed(self, speed):
+        self._playback_speed = float(speed)
+
+    def SetUpdatesPerSec(self, updates_per_sec):
+        self._updates_per_sec = float(updates_per_sec)
+
+    def GetWinWidth(self):
+        return 0
+
+    def GetWinHeight(self):
+        return 0
+
+    def GetNumUpdateSubsteps(self):
+        return int(self._num_update_substeps)
+
+    # ---- RL interface (DeepMimicCore.cpp:165-480)
+    def IsRLScene(self):
+        return True
+
+    def GetNumAgents(self):
+        return 1
+
+    def _chk_agent(self, agent_id):
+        if int(agent_id) != 0:
+            raise RuntimeError("agent id %r out of range (the imitate scene has one agent)" % (agent_id,))
+
+    def NeedNewAction(self, agent_id):
+        self._chk_agent(agent_id)
+        return bool(self._query()["need_new_action"][0])
+
+    def RecordState(self, agent_id):
+        self._chk_agent(agent_id)
+        return [float(x) for x in self._query()["state"][0]]
+
+    def RecordGoal(self, agent_id):
+        self._chk_agent(agent_id)
+        return []                   # cRLSceneSimChar::RecordGoal: goal size 0 (scenes/RLSceneSimChar.cpp:64-68,88-91)
+
+    def SetAction(self, agent_id, action):
+        self._chk_agent(agent_id)
+        a = np.asarray(action, dtype=np.float32).reshape(1, -1)
+        if a.shape[1] != self._env.A:
+            raise RuntimeError("SetAction: expected %d values, got %d" % (self._env.A, a.shape[1]))
+        self._env.set_action(a)
+        self._cache = None
+
+    def LogVal(self, agent_id, val):
+        pass
+
+    def GetActionSpace(self, agent_id):
+        return 1                    # eActionSpaceContinuous (env/action_space.py)
+
+    def GetStateSize(self, agent_id):
+        return int(self._need_env().S)
+
+    def GetGoalSize(self, agent_id):
+        return 0
+
+    def GetActionSize(self, agent_id):
+        return int(self._need_env().A)
+
+    def GetNumActions(self, agent_id):
+        return 0
+
+    def BuildStateOffset(self, agent_id):
+        return [float(x) for x in self._off["state_offset"]]
+
+    def BuildStateScale(self, agent_id):
+        return [float(x) for x in self._off["state_scale"]]
+
+    def BuildGoalOffset(self, agent_id):
+        return []
+
+    def BuildGoalScale(self, agent_id):
+        return []
+
+    def BuildActionOffset(self, agent_id):
+        return [float(x) for x in self._off["action_offset"]]
+
+    def BuildActionScale(self, agent_id):
+        return [float(x) for x in self._off["action_scale"]]
+
+    def BuildActionBoundMin(self, agent_id):
+        return [float(x) for x in self._off["action_min"]]
+
+    def BuildActionBoundMax(self, agent_id):
+        return [float(x) for x in self._off["action_max"]]
+
+    def BuildStateNormGroups(self, agent_id):
+        return [int(x) for x in self._off["state_norm_groups"]]
+
+    def BuildGoalNormGroups(self, agent_id):
+        return []
+
+    def CalcReward(self, agent_id):
+        self._chk_agent(agent_id)
+        return float(self._query()["reward"][0])
+
+    def GetRewardMin(self, agent_id):
+        return 0.0                  # sim/DeepMimicCharController.cpp:200-208
+
+    def GetRewardMax(self, agent_id):
+        return 1.0
+
+    def GetRewardFail(self, agent_id):
+        return 0.0                  # scenes/RLScene.cpp:26-34
+
+    def GetRewardSucc(self, agent_id):
+        return 1.0
+
+    def EnableAMPTaskReward(self):
+        return False
+
+    def GetAMPObsSize(self):
+        return 0
+
+    def GetAMPObsOffset(self):
+        return []
+
+    def GetAMPObsScale(self):
+        return []
+
+    def GetAMPObsNormGroup(self):
+        return []
+
+    def RecordAMPObsAgent(self, agent_id):
+        return []
+
+    def RecordAMPObsExpert(self, agent_id):
+        return []
+
+    def IsEpisodeEnd(self):
+        return bool(self._query()["episode_end"][0])
+
+    def CheckValidEpisode(self):
+        return bool(self._query()["valid"][0])
+
+    def CheckTerminate(self, agent_id):
+        self._chk_agent(agent_id)
+        return int(self._query()["terminate"][0])
+
+    def SetMode(self, mode):
+        self._mode = int(mode)
+        if self._env is not None:
+            self._apply_mode()
+
+    def SetSampleCount(self, count):
+        pass                        # only drives the (unset) timer annealing of scenes/RLSceneSimChar.cpp:292-300

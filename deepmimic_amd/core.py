@@ -136,6 +136,9 @@ class BatchEnv:
         mt = None if max_times is None else np.ascontiguousarray(np.broadcast_to(max_times, (n,)), dtype=np.float64)
         self._chk(self.lib.dm_reset(self.h, _ip(ids), n, _dp(kt), _dp(mt)))
 
+    def set_time_limits(self, time_lim_min: float, time_lim_max: float):
+        self._chk(self.lib.dm_set_time_limits(self.h, C.c_double(time_lim_min), C.c_double(time_lim_max)))
+
     def set_action(self, actions):
         a = np.ascontiguousarray(actions, dtype=np.float32).reshape(self.N, self.A)
         self._chk(self.lib.dm_set_action(self.h, _fp(a), 0))

@@ -984,6 +984,7 @@ struct EnvSim {
     // ------------------------------------------------------------------ reset
     DM_DEV void reset_env(double kin_time, double max_time) {
         Real* kp = scratch(); Real* kv = scratch() + NP; Real* red = scratch() + 2 * NP;
+        sync();                            // every lane has read the episode counter / flags the caller derived its arguments from
         if (l == 0) {
             s.clk[CLK_TIMER] = 0; s.clk[CLK_TIMER_MAX] = max_time;
             s.clk[CLK_KIN] = kin_time; s.clk[CLK_CTRL] = kin_time; s.clk[CLK_INIT_OFF] = -kin_time;

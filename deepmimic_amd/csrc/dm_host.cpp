@@ -248,6 +248,7 @@ struct CtxBase {
     virtual int set_state(const double* pose, const double* vel, const double* tar, const double* kin, const double* clk, const int* flg) = 0;
     virtual int get_debug(const char* name, double* out) = 0;
     virtual int set_tau(const double* tau) = 0;
+    virtual void set_time_limits(double lo, double hi) = 0;
 };
 
 template <typename Real>
@@ -407,6 +408,7 @@ struct CtxT : CtxBase {
         return 0;
     }
     int set_tau(const double* tau) override { return ul(st.tau, (size_t)N * hm.D, tau); }
+    void set_time_limits(double lo, double hi) override { md.time_lim_min = lo; md.time_lim_max = hi; }
     int get_debug(const char* name, double* out) override {
         const size_t n = N; const HostModel& h = hm; std::string s(name);
         if (s == "tau") return dl(st.tau, n * h.D, out);
@@ -484,6 +486,13 @@ int dm_set_stream(dm_ctx* ctx, void* hip_stream) {
     return 0;
 }
 int dm_synchronize(dm_ctx* ctx) { if (!ctx) return fail("null ctx"); return rt_sync(ctx->c->stream) == 0 ? 0 : fail("stream synchronize failed"); }
+
+int dm_set_time_limits(dm_ctx* ctx, double time_lim_min, double time_lim_max) {
+    if (!ctx) return fail("null ctx");
+    if (!(time_lim_max >= time_lim_min)) return fail("time_lim_max must be >= time_lim_min");
+    ctx->c->set_time_limits(time_lim_min, time_lim_max);
+    return 0;
+}
 
 int dm_reset(dm_ctx* ctx, const int32_t* env_ids, int n, const double* kin_times, const double* max_times) {
     if (!ctx) return fail("null ctx");

@@ -65,6 +65,10 @@ double dm_motion_duration(const dm_ctx* ctx);
 int dm_set_stream(dm_ctx* ctx, void* hip_stream);
 int dm_synchronize(dm_ctx* ctx);
 
+/* cDeepMimicCore::SetMode (DeepMimicCore.cpp:472-479 -> cRLSceneSimChar::SetMode / ResetTimers, scenes/RLSceneSimChar.cpp:
+ * 270-290): the episode-timer range drawn at the next resets; train = (time_lim_min, time_lim_max), test = time_end_lim_*. */
+int dm_set_time_limits(dm_ctx* ctx, double time_lim_min, double time_lim_max);
+
 /* cDeepMimicCore::Reset (DeepMimicCore.cpp:61-65).  env_ids NULL -> all envs.  kin_times / max_times NULL ->
  * per-env counter-based RNG: kin time ~ U[0,duration) (scenes/SceneImitate.cpp:494-500), timer ~ U[min,max]. */
 int dm_reset(dm_ctx* ctx, const int32_t* env_ids, int n, const double* kin_times, const double* max_times);

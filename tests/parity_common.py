@@ -128,6 +128,27 @@ def check_substep(name, precision, lib_path, tol_vel, tol_pose, lift=0.0, n=8):
     return tot_contacts
 
 
+def fp32_step_sensitivity(name, steps, t0=0.0):
+    """Per-control-step |reward(fp64 oracle) - reward(fp32 oracle)| with the fp32 oracle teacher-forced from the fp64 one.
+
+    The fp32 oracle is the same restatement with every real narrowed to float (oracle/Makefile).  A step on which it
+    already disagrees with the fp64 oracle is ill-conditioned in single precision (a contact candidate sits on its
+    activation threshold and rounding decides the manifold): no fp32 implementation can be held to 1e-4 there."""
+    t = model.load_asset(name)
+    o, f = Oracle(t), Oracle(t, variant="f32")
+    o.reset(t0); f.reset(t0)
+    dr = []
+    for k in range(steps):
+        kp, _, _ = o.kin_state()
+        a = o.pose_to_action(kp)
+        o.set_action(a); f.set_action(a)
+        p, v = o.sim_state(); f.set_sim_state(p, v)
+        for u in range(20):
+            o.update(DT); f.update(DT)
+        dr.append(abs(o.calc_reward() - f.calc_reward()))
+    return np.array(dr)
+
+
 def rollout_compare(name, precision, lib_path, steps, t0=0.0, open_loop_on_device=False, resync=False):
     """Open-loop mocap-tracking rollout (stream A1); returns per-step |reward diff|, max state diff, flags equal.
 

@@ -1,0 +1,61 @@
+"""N > 1 path on CPU: world_size-2 gloo run of the env shards (emulator build of the kernels as the device)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r'''
+import os, sys, json
+import numpy as np
+sys.path.insert(0, os.environ["DM_ROOT"])
+import torch, torch.distributed as dist
+from deepmimic_amd import model
+from deepmimic_amd.dist import ShardedEnv, shard_range
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+total = int(os.environ["DM_TOTAL"])
+t = model.load_asset("humanoid3d_walk")
+sh = ShardedEnv(t, total, rank=rank, world=world, device_id=0, seed=11, precision=64, lib_path=os.environ["DM_HIP_LIB"])
+sh.env.reset()
+recs = []
+for k in range(2):
+    out = sh.env.step(None, 1.0 / 600, 20, open_loop=True, auto_reset=True)
+    recs.append(sh.gather(sh.pack_record(out)).numpy())
+if rank == 0:
+    np.save(os.environ["DM_OUT"], np.stack(recs))
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def test_shard_range_partitions():
+    from deepmimic_amd.dist import shard_range
+    for total in (1, 7, 8, 4096, 32768 + 3):
+        for world in (1, 2, 3, 8):
+            spans = [shard_range(total, world, r) for r in range(world)]
+            assert spans[0][0] == 0 and sum(c for _, c in spans) == total
+            for (f0, c0), (f1, _) in zip(spans, spans[1:]):
+                assert f0 + c0 == f1
+
+
+def test_two_rank_gloo_matches_single_process(emu_lib, tmp_path):
+    total = 5                                  # uneven split: rank 0 gets 3 envs, rank 1 gets 2
+    out = str(tmp_path / "rec.npy")
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    env = dict(os.environ, DM_ROOT=ROOT, DM_HIP_LIB=emu_lib, DM_TOTAL=str(total), DM_OUT=out, MASTER_ADDR="127.0.0.1")
+    port = 29500 + (os.getpid() % 2000)
+    subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                           "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)], env=env, timeout=600)
+    got = np.load(out)
+    # single process, all envs in one shard: trajectories must not depend on the partition
+    from deepmimic_amd import model
+    from deepmimic_amd.dist import ShardedEnv
+    sh = ShardedEnv(model.load_asset("humanoid3d_walk"), total, rank=0, world=1, device_id=0, seed=11, precision=64, lib_path=emu_lib)
+    sh.env.reset()
+    for k in range(2):
+        o = sh.env.step(None, 1.0 / 600, 20, open_loop=True, auto_reset=True)
+        assert np.array_equal(got[k], sh.pack_record(o))

@@ -1,0 +1,122 @@
+"""cDeepMimicCore facade (deepmimic_amd/compat/DeepMimicCore): call protocol of DeepMimic.py:62-80 / env/deepmimic_env.py."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+COMPAT = os.path.join(ROOT, "deepmimic_amd", "compat")
+REF = "/root/reference"
+
+
+def _core_module():
+    if COMPAT not in sys.path:
+        sys.path.insert(0, COMPAT)
+    from DeepMimicCore import DeepMimicCore
+    return DeepMimicCore
+
+
+def _run_protocol(core, o, n_updates, rng):
+    """update_world of DeepMimic.py:62-80 against the oracle driven with the same actions."""
+    dt = 1.0 / 600
+    n_act = 0
+    for u in range(n_updates):
+        assert core.NeedNewAction(0) == o.need_new_action()
+        if core.NeedNewAction(0):
+            s = np.array(core.RecordState(0)); g = core.RecordGoal(0)
+            assert s.shape == (o.S,) and g == []
+            assert np.abs(s - o.record_state()).max() < 2e-5
+            assert abs(core.CalcReward(0) - o.calc_reward()) < 1e-5
+            a = (0.2 * rng.normal(size=o.A)).astype(np.float32)
+            core.SetAction(0, [float(x) for x in a]); o.set_action(a.astype(np.float64)); n_act += 1
+        core.Update(dt); o.update(dt)
+        assert core.CheckValidEpisode() == o.check_valid_episode()
+        assert core.IsEpisodeEnd() == o.is_episode_end()
+        assert core.CheckTerminate(0) == o.check_terminate()
+    return n_act
+
+
+def _check_static_surface(core, tables):
+    assert core.IsRLScene() and core.GetNumAgents() == 1 and core.GetActionSpace(0) == 1
+    assert core.GetStateSize(0) == tables.state_dim and core.GetActionSize(0) == tables.action_dim and core.GetGoalSize(0) == 0
+    assert len(core.BuildStateOffset(0)) == tables.state_dim and len(core.BuildStateScale(0)) == tables.state_dim
+    assert len(core.BuildActionBoundMin(0)) == tables.action_dim and len(core.BuildActionScale(0)) == tables.action_dim
+    assert core.BuildGoalOffset(0) == [] and core.BuildGoalNormGroups(0) == []
+    assert (core.GetRewardMin(0), core.GetRewardMax(0), core.GetRewardFail(0), core.GetRewardSucc(0)) == (0.0, 1.0, 0.0, 1.0)
+    assert core.EnableAMPTaskReward() is False and core.GetAMPObsSize() == 0 and core.EnableDraw() is False
+
+
+def test_facade_protocol_emulator(emu_lib, monkeypatch):
+    from deepmimic_amd import model
+    from oracle_lib import Oracle
+    monkeypatch.setenv("DM_HIP_LIB", emu_lib); monkeypatch.setenv("DM_PRECISION", "64")
+    mod = _core_module()
+    t = model.load_asset("humanoid3d_walk")
+    core = mod.cDeepMimicCore(False)
+    core.SeedRand(5); core.LoadTables(t, num_update_substeps=10); core.Init()
+    _check_static_surface(core, t)
+    kin_t = float(core._env.get_state()["clocks"][0][0])          # Reset drew the clip time from the counter RNG
+    o = Oracle(t); o.reset(kin_t)
+    assert core.NeedNewAction(0) and core.GetNumUpdateSubsteps() == 10 and core.GetTime() == 0.0
+    n_act = _run_protocol(core, o, 41, np.random.default_rng(0))
+    assert n_act == 3
+    core.Reset()
+    assert core.NeedNewAction(0) and core.GetTime() == 0.0
+    with pytest.raises(RuntimeError):
+        core.SetAction(0, [0.0] * 3)
+    with pytest.raises(RuntimeError):
+        mod.cDeepMimicCore(True)
+
+
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "env")), reason="reference checkout not present")
+def test_reference_env_wrapper_runs_unmodified(emu_lib, monkeypatch):
+    """The reference's own env/deepmimic_env.py (imported from /root/reference, unmodified) on top of the facade."""
+    from deepmimic_amd import model
+    from oracle_lib import Oracle
+    monkeypatch.setenv("DM_HIP_LIB", emu_lib); monkeypatch.setenv("DM_PRECISION", "64"); monkeypatch.setenv("DM_DATA_ROOT", REF)
+    _core_module()
+    monkeypatch.syspath_prepend(REF)
+    if "mpi4py" not in sys.modules:            # env/env.py -> learning/normalizer.py -> util/mpi_util.py imports mpi4py (absent here)
+        import types
+        comm = types.SimpleNamespace(Get_size=lambda: 1, Get_rank=lambda: 0)
+        fake = types.ModuleType("mpi4py"); fake.MPI = types.SimpleNamespace(COMM_WORLD=comm, SUM=None)
+        monkeypatch.setitem(sys.modules, "mpi4py", fake)
+    for m in [k for k in sys.modules if k == "env" or k.startswith("env.") or k == "util" or k.startswith("util.") or k.startswith("learning")]:
+        monkeypatch.delitem(sys.modules, m, raising=False)
+    from env.deepmimic_env import DeepMimicEnv
+    args = ["--arg_file", "args/run_humanoid3d_walk_args.txt"]
+    env = DeepMimicEnv(args, False)
+    t = model.load_scene_from_args(args, data_root=REF)
+    assert env.get_state_size(0) == 227 and env.get_action_size(0) == 28 and env.get_goal_size(0) == 0
+    assert env.get_num_agents() == 1 and env.is_rl_scene() and env.get_num_update_substeps() == 10
+    assert env.build_state_offset(0).shape == (227,) and env.build_action_bound_min(0).shape == (28,)
+    import enum
+    env.set_mode(enum.Enum('Mode', {'TRAIN': 0, 'TEST': 1}).TRAIN)     # learning/rl_agent.py Mode enum: set_mode passes mode.value
+    env.reset()
+    kin_t = float(env._core._env.get_state()["clocks"][0][0])
+    o = Oracle(t); o.reset(kin_t)
+    rng = np.random.default_rng(1)
+    for u in range(22):
+        if env.need_new_action(0):
+            s = env.record_state(0)
+            assert np.abs(s - o.record_state()).max() < 2e-5 and abs(env.calc_reward(0) - o.calc_reward()) < 1e-5
+            a = 0.1 * rng.normal(size=28)
+            env.set_action(0, a); o.set_action(a.astype(np.float32).astype(np.float64))
+        env.update(1.0 / 600); o.update(1.0 / 600)
+        assert env.check_valid_episode() == o.check_valid_episode() and env.is_episode_end() == o.is_episode_end()
+    env.shutdown()
+
+
+@pytest.mark.gpu
+def test_facade_protocol_gpu(hip_lib, monkeypatch):
+    from deepmimic_amd import model
+    from oracle_lib import Oracle
+    monkeypatch.setenv("DM_HIP_LIB", hip_lib); monkeypatch.setenv("DM_PRECISION", "64")
+    mod = _core_module()
+    t = model.load_asset("humanoid3d_walk")
+    core = mod.cDeepMimicCore(False)
+    core.SeedRand(9); core.LoadTables(t, num_update_substeps=10); core.Init()
+    _check_static_surface(core, t)
+    o = Oracle(t); o.reset(float(core._env.get_state()["clocks"][0][0]))
+    assert _run_protocol(core, o, 101, np.random.default_rng(2)) == 6

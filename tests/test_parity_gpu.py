@@ -71,13 +71,24 @@ def test_rollout_spinkick_free_running_prefix(hip_lib):
 @pytest.mark.parametrize("name,prec,tol", [("humanoid3d_spinkick", 64, 1e-6), ("humanoid3d_spinkick", 32, 1e-4),
                                            ("humanoid3d_walk", 32, 1e-4), ("dog3d_pace", 32, 1e-4)])
 def test_rollout_stepwise_300_steps(hip_lib, name, prec, tol):
-    """teacher-forced: every one of the 300 control steps (20 updates, 40 substeps each) from the oracle's state."""
+    """teacher-forced: every one of the 300 control steps (20 updates, 40 substeps each) from the oracle's state.
+
+    fp32: a control step is held to `tol` unless the fp32 *oracle* itself misses tol/4 on that step (spinkick step 92:
+    a foot-corner candidate sits on its activation threshold, rounding picks the manifold; the float restatement of
+    the oracle is off by 2e-3 there).  Such ill-conditioned steps must be rare and stay within 20x the oracle's own
+    fp32 error."""
     dr, ds, ok = pc.rollout_compare(name, prec, hip_lib, steps=300, resync=True)
     assert dr.mean() < tol, (dr.mean(), dr.max())
-    # single chaotic steps (spinkick foot scuff) may amplify fp32 rounding within one control step
-    assert dr.max() < (tol if name != "humanoid3d_spinkick" else 10 * tol), (dr.mean(), dr.max())
     if prec == 64:
+        assert dr.max() < tol, (dr.mean(), dr.max())
         assert ok and ds.max() < 1e-4
+        return
+    sens = pc.fp32_step_sensitivity(name, 300)
+    ill = sens > tol / 4
+    assert ill.sum() <= 3, np.nonzero(ill)[0]
+    assert dr[~ill].max() < tol, (int(np.argmax(np.where(ill, 0, dr))), dr[~ill].max())
+    if ill.any():
+        assert dr[ill].max() < 20 * max(sens[ill].max(), tol), (dr[ill].max(), sens[ill].max())
 
 
 def test_batch_invariance_and_shard_offset(hip_lib):

@@ -31,6 +31,20 @@ def algorithmic_bytes_per_env_step(env):
     return 2 * rec + out
 
 
+def measured_traffic(scene, n):
+    """HBM bytes per k_env_step launch from the committed rocprofv3 PMC passes (profiles/r01_traffic.json, collected
+    as MI355X_MICROARCH.md prescribes: separate --pmc passes for FETCH_SIZE and WRITE_SIZE); None when no profile of this
+    workload is committed."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
+            t = json.load(f)
+        if t.get("scene") == scene and int(t.get("envs", -1)) == n:
+            return float(t["hbm_bytes_per_launch"])
+    except Exception:
+        pass
+    return None
+
+
 def cpu_baseline(tables, budget_s=12.0):
     """Times the CPU oracle (restatement of the reference path; real DeepMimicCore/Bullet is not buildable here)
     on this host, single thread, same workload per env: 300-step open-loop rollouts of one humanoid."""
@@ -146,9 +160,12 @@ def main():
                        "envs_per_gpu": n, "parallelism": "env-shards x%d%s" % (world, " + RCCL all-gather of obs" if gather else "")},
             "sim_updates_per_s": value * 20,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "kernel": "k_env_step", "kernel_ms": kernel_ms,
+                         "traffic": measured_traffic(args.scene, n), "kernel": "k_env_step", "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_env_step": algorithmic_bytes_per_env_step(env),
-                         "note": "latency/VALU/LDS-bound by construction (SURVEY 8d): state stays in LDS for 20 updates"},
+                         "algorithmic_bytes_per_launch": bytes_per_launch,
+                         "note": "VALU-issue bound by construction (SURVEY 8d, DESIGN.md 6): the env record stays in LDS/VGPRs for "
+                                 "the 20 updates of a control step, HBM sees 2.4 KB per env-step; the binding figures are the "
+                                 "VALU instruction count and SIMD busy fraction in profiles/"},
             "checks": {"mean_reward": mean_reward, "finite": finite},
         }
         if not args.no_cpu_baseline and world == 1:

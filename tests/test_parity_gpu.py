@@ -91,6 +91,28 @@ def test_rollout_stepwise_300_steps(hip_lib, name, prec, tol):
         assert dr[ill].max() < 20 * max(sens[ill].max(), tol), (dr[ill].max(), sens[ill].max())
 
 
+def _golden_cases():
+    import json, os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_rollouts.json")) as f:
+        return json.load(f)
+
+
+@pytest.mark.parametrize("case", _golden_cases(), ids=lambda c: "%s@%g" % (c["scene"], c["t0"]))
+def test_rollout_against_committed_golden_vectors(hip_lib, case):
+    """HIP path vs the committed fixtures (tests/golden/oracle_rollouts.json), all envs of one batch at once."""
+    t = model.load_asset(case["scene"])
+    for prec, tol_r, tol_s in ((64, 2e-6, 1e-4), (32, 1e-4, 5e-2)):
+        env = BatchEnv(t, 3, precision=prec)
+        env.reset(kin_times=[case["t0"]] * 3, max_times=np.inf)
+        q = env.query()
+        assert np.abs(q["state"][1] - np.array(case["state0"])).max() < (1e-6 if prec == 64 else 2e-5)
+        for k in range(case["steps"]):
+            out = env.step(None, pc.DT, 20, open_loop=True)
+            assert np.abs(out["reward"] - case["rewards"][k]).max() < tol_r, (prec, k)
+        assert np.abs(out["state"][2] - np.array(case["final_state"])).max() < tol_s
+        assert int(out["terminate"][0]) == case["terminate"]
+
+
 def test_batch_invariance_and_shard_offset(hip_lib):
     """env i's trajectory does not depend on the batch size or on which shard holds it."""
     t = model.load_asset("humanoid3d_walk")

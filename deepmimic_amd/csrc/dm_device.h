@@ -176,19 +176,20 @@ struct Lds {
 enum { CLK_KIN = 0, CLK_CTRL, CLK_INIT_OFF, CLK_TIMER, CLK_TIMER_MAX };
 enum { FLG_NEED_ACTION = 0, FLG_CONTACT, FLG_EPISODE, FLG_VALID, FLG_NROWS, FLG_NCONT };
 
-template <typename Real, typename C>
+// TAPS = false compiles every debug tap / phase timer out of the instruction stream (production step kernel).
+template <typename Real, typename C, bool TAPS = true>
 struct EnvSim {
     typedef Lds<Real, C> L;
     static constexpr int NJ = C::NJ, ND = C::ND, NP = C::NP, NCAP = C::NCAP, CPL = C::NCAP / kWave, RREG = C::RREG;
     static constexpr int NP2 = ND / 2;                 // register pairs per dof vector (ND is even for every class)
     typedef V3<Real> v3; typedef Q4<Real> q4; typedef M3<Real> m3;
     typedef typename VecT<Real>::v2 R2; typedef typename VecT<Real>::v4 R4;
-    const ModelDev<Real>& m; L& s; const int l;
+    const ModelDev<Real>& m; L& s; int l;
     int li = 0;                                         // link_info word of this lane's link (0 for lanes >= J)
     int cand_link[CPL]; Real cand_loc[CPL][3], cand_rad[CPL];   // this lane's ground-contact candidates
     long long* prof = nullptr; long long tprev = 0;     // phase-cycle accounting (profiling kernel only)
     DM_DEV EnvSim(const ModelDev<Real>& m_, L& s_, int l_) : m(m_), s(s_), l(l_) {}
-    DM_DEV void mark(int phase) { if (prof) { long long t = dm_clock(); if (l == 0) prof[phase] += t - tprev; tprev = t; } }
+    DM_DEV void mark(int phase) { if (TAPS && prof) { long long t = dm_clock(); if (l == 0) prof[phase] += t - tprev; tprev = t; } }
     DM_DEV void sync() const { __syncthreads(); }
     DM_DEV Real* scratch() const { return &s.Lt[0]; }   // L is dead outside the update loop: kin pose / vel / reductions live there
     DM_DEV Real& Lx(int r, int c) const { return s.Lt[L::lrow(r) + c]; }
@@ -218,6 +219,7 @@ struct EnvSim {
         sync();
     }
     DM_DEV void store(const EnvState<Real>& st, int e) {
+        DM_OPAQUE_V(l);
         sync();
         for (int i = l; i < m.P; i += kWave) { st.pose[(size_t)e * m.P + i] = s.pose[i]; st.vel[(size_t)e * m.P + i] = s.vel[i]; st.tar[(size_t)e * m.P + i] = s.tar[i]; }
         if (l < m.D) st.tau[(size_t)e * m.D + l] = s.tau[l];
@@ -298,7 +300,7 @@ struct EnvSim {
             if (kind == DK_ROOT_LIN) { a = mk3((Real)(ax == 0), (Real)(ax == 1), (Real)(ax == 2)); rec_a = zero3(); rec_g = a; }
             else {
                 if (kind == DK_ROOT_ANG) a = mk3((Real)(ax == 0), (Real)(ax == 1), (Real)(ax == 2));
-                else a = col(ldm3(s.R[dj]), (kind == DK_REV) ? 2 : ax);
+                else { const int c = (kind == DK_REV) ? 2 : ax; a = mk3(s.R[dj][c], s.R[dj][3 + c], s.R[dj][6 + c]); }   // column c of R (indexed in LDS, not in registers)
                 rec_a = a; rec_g = cross(ld3(s.p[dj]) - ld3(s.p[0]), a);
             }
             st3(&s.dofrec[l][0], rec_a); st3(&s.dofrec[l][3], rec_g);
@@ -498,7 +500,7 @@ struct EnvSim {
         if (l < D) { vidx = DM_DI_VIDX(s.mdl.dof_info[l]); vstar = clamp_vel(s.vel[vidx] + h * s.rhs[l], l); s.dofrec[l][6] = vstar; }
         if (l == 0) s.flg[FLG_CONTACT] = 0;
         sync();
-        if (dbg.vstar && l < D) dbg.vstar[(size_t)e * D + l] = vstar;
+        if (TAPS && dbg.vstar && l < D) dbg.vstar[(size_t)e * D + l] = vstar;
         mark(7);
         // ---- collision detection: lane = candidate point (CPL candidates per lane when NC > 64)
         bool active[CPL]; Real dist[CPL]; v3 cxp[CPL]; uint64_t amask[CPL];
@@ -653,7 +655,7 @@ struct EnvSim {
             if (l >= R) lam = 0;
         } else mark(10);
         mark(11);
-        if (dbg.lambda) { dbg.lambda[(size_t)e * kMaxRows + l] = lam; if (l < 2) dbg.rows[(size_t)e * 2 + l] = s.flg[FLG_NROWS + l]; }
+        if (TAPS && dbg.lambda) { dbg.lambda[(size_t)e * kMaxRows + l] = lam; if (l < 2) dbg.rows[(size_t)e * 2 + l] = s.flg[FLG_NROWS + l]; }
         // delta v = L^-T (Y lambda): transposing wave reduction of y_r[k] lambda_r, dof k's total lands in lane k
         Real z;
         {
@@ -753,6 +755,7 @@ struct EnvSim {
     }
     // cSceneImitate::UpdateKinChar: advance the clip clock, snap the origin on phase wrap
     DM_DEV void kin_update(double dt) {
+        DM_OPAQUE_V(l);
         double t0 = s.clk[CLK_KIN], t1 = t0 + dt;
         double ph0 = kin_phase(t0), ph1 = kin_phase(t1);
         sync();
@@ -804,6 +807,9 @@ struct EnvSim {
     // reuse_kin: pose / vel are unchanged since the previous phase's kinematics (stable-PD solve -> first substep); only
     // the base acceleration differs, and it enters every joint-origin acceleration as the same additive constant.
     DM_DEV void dyn_phase(int ph, Real dt, Real h, DebugTaps<Real> dbg, int e, bool tap_only, bool reuse_kin, Real* aovf) {
+        // lane id / link word are re-materialised per phase: keeps the optimizer from hoisting every per-lane LDS address
+        // out of the 20-update loop (dozens of long-lived VGPRs that end up in scratch)
+        DM_OPAQUE_V(l); DM_OPAQUE_V(li);
         mark(ph == 0 ? 0 : 4);
         if (reuse_kin) {
             if (l < m.J) { v3 da = gravity_a0() - spd_a0(); st3(s.aj[l], ld3(s.aj[l]) + da); }
@@ -812,7 +818,7 @@ struct EnvSim {
         mark(ph == 0 ? 1 : 5);
         dynamics(ph == 0 ? 0 : 1, ph == 0 ? dt : (Real)0);
         mark(ph == 0 ? 2 : 6);
-        if (dbg.H) {
+        if (TAPS && dbg.H) {
             const int D = m.D;
             for (int i = l; i < D * D; i += kWave) { int r = i / D, c = i % D; Real v = (c <= r) ? Lx(r, c) : Lx(c, r); if (r == c && ph == 0) v -= dt * s.mdl.kd[r]; dbg.H[(size_t)e * D * D + i] = v; }
             if (l < D) dbg.C[(size_t)e * D + l] = s.bias[l];
@@ -820,7 +826,9 @@ struct EnvSim {
         if (tap_only) return;
         if (ph == 0) spd_rhs(dt);
         else { if (l < m.D) s.rhs[l] = s.tau[l] - s.bias[l]; sync(); }
+        DM_OPAQUE_V(l);
         chol_solve(s.rhs);
+        DM_OPAQUE_V(l); DM_OPAQUE_V(li);
         if (ph == 0) { mark(3); spd_post(dt); }
         else substep_post(h, dbg, e, aovf);
     }
@@ -847,13 +855,14 @@ struct EnvSim {
 
     // ------------------------------------------------------------------ reward + observation + flags
     DM_DEV void emit(const StepIO<Real>& io, DebugTaps<Real> dbg, int e, bool write_flags) {
+        DM_OPAQUE_V(l); DM_OPAQUE_V(li);
         const int J = m.J;
         Real* kp = scratch(); Real* kv = scratch() + NP;
         Real* ee_k = scratch() + 2 * NP;                 // J x 3 kin joint positions
         Real* red = scratch() + 2 * NP + 3 * NJ;         // J x 4 per-joint reduction terms
         const v3 zero = zero3();
         kin_sample(s.clk[CLK_KIN], kp, kv);
-        if (dbg.kin_pose) for (int i = l; i < m.P; i += kWave) { dbg.kin_pose[(size_t)e * m.P + i] = kp[i]; dbg.kin_vel[(size_t)e * m.P + i] = kv[i]; }
+        if (TAPS && dbg.kin_pose) for (int i = l; i < m.P; i += kWave) { dbg.kin_pose[(size_t)e * m.P + i] = kp[i]; dbg.kin_vel[(size_t)e * m.P + i] = kv[i]; }
         // kin character: joint positions and COM velocity (cRBDUtil::CalcCoM)
         kinematics(kp, kv, zero);
         if (l < J) {
@@ -882,7 +891,7 @@ struct EnvSim {
             st3(s.sc + 3, ((Real)1 / tm) * acc);
         }
         sync();
-        if (dbg.links && l < J) {
+        if (TAPS && dbg.links && l < J) {
             Real* o = dbg.links + ((size_t)e * J + l) * 21;
             st3(o, ld3(s.com[l])); for (int k = 0; k < 9; ++k) o[3 + k] = Rbp(l)[k];
             st3(o + 12, vcom); st3(o + 15, ld3(s.w[l])); st3(o + 18, ld3(s.p[l]));
@@ -940,7 +949,7 @@ struct EnvSim {
                 if (io.episode_end) io.episode_end[e] = end ? 1 : 0;
             }
             s.sc[6] = end ? (Real)1 : (Real)0;
-            if (dbg.reward_terms) { Real* o = dbg.reward_terms + (size_t)e * 5; o[0] = pose_err; o[1] = vel_err; o[2] = ee_err; o[3] = root_err; o[4] = com_err; }
+            if (TAPS && dbg.reward_terms) { Real* o = dbg.reward_terms + (size_t)e * 5; o[0] = pose_err; o[1] = vel_err; o[2] = ee_err; o[3] = root_err; o[4] = com_err; }
         }
         // CheckValidEpisode: any link velocity component beyond 100 (SimCharacter.cpp:571-586)
         if (l == 0) s.flg[FLG_VALID] = 1;
@@ -983,6 +992,7 @@ struct EnvSim {
 
     // ------------------------------------------------------------------ reset
     DM_DEV void reset_env(double kin_time, double max_time) {
+        DM_OPAQUE_V(l); DM_OPAQUE_V(li);
         Real* kp = scratch(); Real* kv = scratch() + NP; Real* red = scratch() + 2 * NP;
         sync();                            // every lane has read the episode counter / flags the caller derived its arguments from
         if (l == 0) {
@@ -1042,12 +1052,12 @@ template <> struct StepWaves<float, ClsLarge> { static constexpr int value = 2; 
 #else
 #define DM_WAVES_PER_EU(n) __attribute__((amdgpu_waves_per_eu(n, n)))
 #endif
-template <typename Real, typename C>
+template <typename Real, typename C, bool TAPS>
 __global__ void __launch_bounds__(64) DM_WAVES_PER_EU((StepWaves<Real, C>::value)) k_env_step(ModelDev<Real> m, EnvState<Real> st, StepIO<Real> io, DebugTaps<Real> dbg) {
     __shared__ Lds<Real, C> lds;
     const int e = blockIdx.x, l = threadIdx.x;
-    EnvSim<Real, C> sim(m, lds, l);
-    if (dbg.prof) { sim.prof = dbg.prof + (size_t)e * 16; sim.tprev = dm_clock(); }
+    EnvSim<Real, C, TAPS> sim(m, lds, l);
+    if (TAPS && dbg.prof) { sim.prof = dbg.prof + (size_t)e * 16; sim.tprev = dm_clock(); }
     sim.load(st, e);
     if (io.open_loop) sim.set_action_from_clip();
     else if (io.actions) sim.set_action(io.actions + (size_t)e * m.A);

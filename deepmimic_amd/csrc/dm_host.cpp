@@ -355,7 +355,9 @@ struct CtxT : CtxBase {
         StepIO<Real> io; memset(&io, 0, sizeof(io));
         io.actions = actions_dev; io.states = states; io.rewards = rewards; io.terminate = term; io.valid = valid; io.episode_end = end;
         io.n_updates = n_updates; io.dt = dt; io.auto_reset = (flags & DM_AUTO_RESET) ? 1 : 0; io.emit = (flags & DM_NO_EMIT) ? 0 : 1; io.open_loop = (flags & DM_OPEN_LOOP) ? 1 : 0;
-        DM_DISPATCH(k_env_step, N, md, st, io, dbg);
+        // production launch: the tap-free instantiation unless a parity test armed the debug taps (dm_probe)
+        if (dbg.H) { if (cls == 0) RT_LAUNCH((k_env_step<Real, ClsBiped, true>), N, stream, md, st, io, dbg); else RT_LAUNCH((k_env_step<Real, ClsLarge, true>), N, stream, md, st, io, dbg); }
+        else { if (cls == 0) RT_LAUNCH((k_env_step<Real, ClsBiped, false>), N, stream, md, st, io, dbg); else RT_LAUNCH((k_env_step<Real, ClsLarge, false>), N, stream, md, st, io, dbg); }
         return 0;
     }
     int query(float* states, float* rewards, int* term, int* valid, int* end) override {
@@ -372,7 +374,7 @@ struct CtxT : CtxBase {
             StepIO<Real> io; memset(&io, 0, sizeof(io));
             io.states = d_states; io.rewards = d_rewards; io.terminate = d_term; io.valid = d_valid; io.episode_end = d_end;
             io.n_updates = 20; io.dt = dt; io.auto_reset = 1; io.emit = 1; io.open_loop = 1;
-            DM_DISPATCH(k_env_step, N, md, st, io, d2);
+            if (cls == 0) RT_LAUNCH((k_env_step<Real, ClsBiped, true>), N, stream, md, st, io, d2); else RT_LAUNCH((k_env_step<Real, ClsLarge, true>), N, stream, md, st, io, d2);
             return 0;
         }
         DM_DISPATCH(k_env_probe, N, md, st, dbg, what, dt);

@@ -63,6 +63,14 @@ template <typename Real, int N> struct RowFile {       // per-lane array indexed
     inline Real get(int r) const { return v[r]; }
     inline void set(int r, Real x) { v[r] = x; }
 };
+// G[i] = sum_k y_l[k] y_i[k], i < 32, for every lane l (Gram rows of the first 32 constraint rows)
+template <int NP2, typename R2, typename Real> static inline void wave_gram32(const R2* y2, Real (&out)[32]) {
+    Real* x = reinterpret_cast<Real*>(emu::g_xchg);
+    for (int p = 0; p < NP2; ++p) { x[threadIdx.x * 2 * NP2 + 2 * p] = y2[p][0]; x[threadIdx.x * 2 * NP2 + 2 * p + 1] = y2[p][1]; }
+    __syncthreads();
+    for (int i = 0; i < 32; ++i) { Real a = 0; for (int k = 0; k < 2 * NP2; ++k) a += x[threadIdx.x * 2 * NP2 + k] * x[i * 2 * NP2 + k]; out[i] = a; }
+    __syncthreads();
+}
 // two / four packed reals (GCC vector extension on the host emulator)
 template <typename Real> struct VecT;
 template <> struct VecT<float> { typedef float v2 __attribute__((vector_size(8))); typedef float v4 __attribute__((vector_size(16))); };
@@ -143,6 +151,38 @@ template <> struct RowFile<float, 64> {
 template <typename Real> struct VecT;
 template <> struct VecT<float> { typedef float v2 __attribute__((ext_vector_type(2))); typedef float v4 __attribute__((ext_vector_type(4))); };
 template <> struct VecT<double> { typedef double v2 __attribute__((ext_vector_type(2))); typedef double v4 __attribute__((ext_vector_type(4))); };
+// G[i] = sum_k y_l[k] y_i[k], i < 32: Gram rows of the first 32 constraint rows.
+// fp32: the one dense contraction of the path goes to the matrix core -- NP2 x v_mfma_f32_32x32x2_f32 (K = 2 per issue, full
+// fp32 multiply-add).  Operand layout: lanes 0..31 carry Y[k0][lane], lanes 32..63 carry Y[k0+1][lane-32]; A and B operands
+// are the same register (G = Y^T Y).  The 32x32 result comes back as 16 accumulators per lane (lane = column, rows split
+// between the wave halves); symmetry turns lane j's column into row j, the other half arrives by one cross-half shuffle each.
+template <int NP2> __device__ __forceinline__ void wave_gram32(const VecT<float>::v2* y2, float (&out)[32]) {
+    typedef float f16v __attribute__((ext_vector_type(16)));
+    const int l = threadIdx.x;
+    const bool upper = l >= 32;
+    f16v acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int p = 0; p < NP2; ++p) {
+        const float up = __shfl(y2[p][1], l & 31, 64);
+        const float opnd = upper ? up : y2[p][0];
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(opnd, opnd, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+        const float other = __shfl(acc[v], l | 32, 64);          // lanes < 32 fetch the rows held by their upper partner
+        out[8 * (v / 4) + (v % 4)] = acc[v];
+        out[8 * (v / 4) + 4 + (v % 4)] = other;
+    }
+}
+template <int NP2> __device__ __forceinline__ void wave_gram32(const VecT<double>::v2* y2, double (&out)[32]) {
+#pragma unroll 1
+    for (int i = 0; i < 32; ++i) {
+        double a = 0;
+#pragma unroll
+        for (int p = 0; p < NP2; ++p) a += y2[p][0] * lane_bcast(y2[p][0], i) + y2[p][1] * lane_bcast(y2[p][1], i);
+        out[i] = a;
+    }
+}
 }
 #endif
 
@@ -617,16 +657,30 @@ struct EnvSim {
 #pragma unroll
               for (int p = 0; p < NP2; ++p) a2 += y2[p] * y2[p];
               adiag = a2[0] + a2[1]; }
-            for (int r = 0; r < R; ++r) {
-                R2 a2 = {(Real)0, (Real)0};
+            // rows are pre-scaled by 1/A_ll so that the sweep keeps q_l = (b_l - u_l)/A_ll with one FMA per row
+            const Real inv_adiag = (l < R) ? (Real)1 / adiag : (Real)0;
+            if (R <= 32) {
+                Real g[32];
+                {   // an optimizer-opaque copy: without it clang's middle end does not terminate on the select chains feeding the MFMAs
+                    R2 yc[NP2];
 #pragma unroll
-                for (int p = 0; p < NP2; ++p) { const R2 bb = {lane_bcast(y2[p][0], r), lane_bcast(y2[p][1], r)}; a2 += y2[p] * bb; }
-                if (RREG >= kMaxRows || r < RREG) arow.set(r, a2[0] + a2[1]);
-                else aovf[(r - RREG) * kWave + l] = a2[0] + a2[1];
+                    for (int p = 0; p < NP2; ++p) { yc[p] = y2[p]; DM_OPAQUE_V(yc[p]); }
+                    wave_gram32<NP2>(yc, g);
+                }
+#pragma unroll
+                for (int r = 0; r < 32; ++r) arow.set(r, g[r] * inv_adiag);
+            } else {
+                for (int r = 0; r < R; ++r) {
+                    R2 a2 = {(Real)0, (Real)0};
+#pragma unroll
+                    for (int p = 0; p < NP2; ++p) { const R2 bb = {lane_bcast(y2[p][0], r), lane_bcast(y2[p][1], r)}; a2 += y2[p] * bb; }
+                    const Real v = (a2[0] + a2[1]) * inv_adiag;
+                    if (RREG >= kMaxRows || r < RREG) arow.set(r, v);
+                    else aovf[(r - RREG) * kWave + l] = v;
+                }
             }
             mark(10);
-            Real u = cvec;
-            const Real inv_adiag = (l < R) ? (Real)1 / adiag : (Real)0;
+            Real q = (b - cvec) * inv_adiag;
             const int nrm_lane = is_fric ? NL + ((l - RN) >> 1) : 0;
             Real lo = 0, hi = is_fric ? (Real)0 : (Real)1e30;
             int Rv = R, RNv = RN, lv = l;
@@ -642,10 +696,10 @@ struct EnvSim {
                             const int r = blk * 8 + i;
                             if (r < Rv) {
                                 if (r == RNv) { const Real ln = wave_shfl(lam, nrm_lane); if (is_fric) { hi = m.friction * ln; lo = -hi; } }
-                                const Real nl = dm_med3(lo, lam + (b - u) * inv_adiag, hi);
+                                const Real nl = dm_med3(lo, lam + q, hi);
                                 const Real delta = lane_bcast(nl - lam, r);
                                 const Real ar = (r < RREG) ? arow.get(r < RREG ? r : 0) : aovf[(r - RREG) * kWave + l];
-                                u += ar * delta;
+                                q -= ar * delta;
                                 if (lv == r) lam = nl;
                             }
                         }

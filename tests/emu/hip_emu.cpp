@@ -4,7 +4,7 @@
 #include <cstdio>
 
 emu_dim3 threadIdx, blockIdx, blockDim, gridDim;
-namespace emu { uint64_t g_xchg[1024]; }
+namespace emu { uint64_t g_xchg[8192]; }
 
 extern "C" void emu_switch(void** save_sp, void* new_sp);
 asm(R"(

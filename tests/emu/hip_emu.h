@@ -28,7 +28,7 @@ namespace emu {
 struct Fiber { void* sp = nullptr; std::vector<char> stack; bool done = false; };
 void barrier();                       // yield point: returns when every live lane arrived
 void launch(unsigned grid, unsigned block, const std::function<void()>& body);
-extern uint64_t g_xchg[1024];         // scratch for cross-lane helpers
+extern uint64_t g_xchg[8192];         // scratch for cross-lane helpers
 }
 
 static inline void __syncthreads() { emu::barrier(); }

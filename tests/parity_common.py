@@ -149,6 +149,22 @@ def fp32_step_sensitivity(name, steps, t0=0.0):
     return np.array(dr)
 
 
+def fp32_free_running_sensitivity(name, steps, t0=0.0):
+    """Per-step |reward| gap between the fp64 oracle and its own fp32 build, both free-running on stream A1."""
+    t = model.load_asset(name)
+    o, f = Oracle(t), Oracle(t, variant="f32")
+    o.reset(t0); f.reset(t0)
+    dr = []
+    for k in range(steps):
+        for x in (o, f):
+            kp, _, _ = x.kin_state()
+            x.set_action(x.pose_to_action(kp))
+            for u in range(20):
+                x.update(DT)
+        dr.append(abs(o.calc_reward() - f.calc_reward()))
+    return np.array(dr)
+
+
 def rollout_compare(name, precision, lib_path, steps, t0=0.0, open_loop_on_device=False, resync=False):
     """Open-loop mocap-tracking rollout (stream A1); returns per-step |reward diff|, max state diff, flags equal.
 

@@ -202,7 +202,7 @@ struct Lds {
     alignas(32) Real dofrec[ND][8];        // per dof: world axis a(3), g = (p_joint - p_root) x a (3), unconstrained velocity v*, pad
     Real R[NJ][9], p[NJ][3], com[NJ][3], w[NJ][3], vj[NJ][3], al[NJ][3], aj[NJ][3];
     Real Rb[C::ROT ? NJ : 1][C::ROT ? 9 : 1];   // body frames (== R when the class has no attach rotations)
-    union {
+    union alignas(32) {
         struct { Real f[NJ][3], n[NJ][3], Iw[NJ][6], Fs[NJ][3], Ns[NJ][3], Ic[NJ][10]; };   // Newton-Euler pass (dynamics)
         struct { Real cx[NCAP][3], cdist[NCAP]; int csel[NCAP], cslot[kMaxRows]; };          // ground contacts (after dynamics)
     };
@@ -421,6 +421,11 @@ struct EnvSim {
             if (!(l < D)) { v[0] = (l == 2 * p) ? (Real)1 : (Real)0; v[1] = (l == 2 * p + 1) ? (Real)1 : (Real)0; }
             h2[p] = v;
         }
+        // Column k of L (one value per lane) is published through LDS and read back as wave-uniform broadcasts: two
+        // ds_read_b128 feed four packed FMAs, where v_readlane would cost one VALU slot per scalar.  The buffer aliases the
+        // Newton-Euler accumulators (dead once the mass matrix is built) and is double-buffered over k, so the in-order LDS
+        // queue of the single wave is all the synchronisation needed.
+        Real* colbuf = &s.f[0][0];
         Real dinv = 1;
 #pragma unroll
         for (int k = 0; k < ND; ++k) {
@@ -431,10 +436,15 @@ struct EnvSim {
             Real lik = hk * inv;
             h2[pk][ck] = lik;
             if (l == k) dinv = inv;
-            if (ck == 0) h2[pk][1] -= lik * lane_bcast(lik, k + 1);
-            const R2 l2 = {lik, lik};
+            if (k + 1 < ND) {
+                Real* cb = colbuf + (k & 1) * kWave;
+                cb[l] = lik;
+                sync();
+                if (ck == 0) h2[pk][1] -= lik * cb[k + 1];
+                const R2 l2 = {lik, lik};
 #pragma unroll
-            for (int p = (k + 2) >> 1; p < NP2; ++p) { const R2 bb = {lane_bcast(lik, 2 * p), lane_bcast(lik, 2 * p + 1)}; h2[p] -= l2 * bb; }
+                for (int p = (k + 2) >> 1; p < NP2; ++p) h2[p] -= l2 * *reinterpret_cast<const R2*>(&cb[2 * p]);
+            }
         }
         if (l < ND) {
             Real* row = &s.Lt[L::lrow(l)];

@@ -19,3 +19,6 @@ p = env.debug("prof")
 tot = p.sum(1)
 print(json.dumps({"scene": name, "envs": n, "cycles_per_env_step_mean": float(tot.mean()), "max": float(tot.max()),
                   "phases": {PH[i]: [float(p[:, i].mean()), float(100 * p[:, i].sum() / tot.sum())] for i in range(16)}}, indent=1))
+# distribution of per-wave totals (tail diagnostics): the last wave of a SIMD runs alone and latency-bound
+q = np.percentile(tot, [1, 10, 50, 90, 99])
+print(json.dumps({"wave_total_cycles_percentiles_1_10_50_90_99": [float(x) for x in q], "cv": float(tot.std() / tot.mean())}))

@@ -671,12 +671,11 @@ struct EnvSim {
             const Real inv_adiag = (l < R) ? (Real)1 / adiag : (Real)0;
             if (R <= 32) {
                 Real g[32];
-                {   // an optimizer-opaque copy: without it clang's middle end does not terminate on the select chains feeding the MFMAs
-                    R2 yc[NP2];
+                // (y is made opaque to the optimizer first: without it clang's middle end does not terminate on the select
+                // chains feeding the MFMAs)
 #pragma unroll
-                    for (int p = 0; p < NP2; ++p) { yc[p] = y2[p]; DM_OPAQUE_V(yc[p]); }
-                    wave_gram32<NP2>(yc, g);
-                }
+                for (int p = 0; p < NP2; ++p) DM_OPAQUE_V(y2[p]);
+                wave_gram32<NP2>(y2, g);
 #pragma unroll
                 for (int r = 0; r < 32; ++r) arow.set(r, g[r] * inv_adiag);
             } else {
@@ -708,7 +707,9 @@ struct EnvSim {
                                 if (r == RNv) { const Real ln = wave_shfl(lam, nrm_lane); if (is_fric) { hi = m.friction * ln; lo = -hi; } }
                                 const Real nl = dm_med3(lo, lam + q, hi);
                                 const Real delta = lane_bcast(nl - lam, r);
-                                const Real ar = (r < RREG) ? arow.get(r < RREG ? r : 0) : aovf[(r - RREG) * kWave + l];
+                                Real ar;
+                                if (r < RREG) ar = arow.get(r < RREG ? r : 0);
+                                else { const Real* ap = aovf + lv; DM_OPAQUE_V(ap); ar = ap[(r - RREG) * kWave]; }   // address formed here, not hoisted for 32 rows
                                 q -= ar * delta;
                                 if (lv == r) lam = nl;
                             }

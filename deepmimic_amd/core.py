@@ -21,7 +21,7 @@ DM_DEVICE_PTRS, DM_AUTO_RESET, DM_OPEN_LOOP, DM_NO_EMIT = 1, 2, 4, 8
 
 class _CreateInfo(C.Structure):
     _fields_ = [("num_envs", C.c_int), ("device_id", C.c_int), ("seed", C.c_uint64), ("precision", C.c_int),
-                ("max_contacts", C.c_int), ("env_id_offset", C.c_int)]
+                ("max_contacts", C.c_int), ("env_id_offset", C.c_int), ("wave_packing", C.c_int)]
 
 
 class _SceneTables(C.Structure):
@@ -74,7 +74,7 @@ class BatchEnv:
 
     def __init__(self, tables: SceneTables, num_envs: int = 1, device_id: int = 0, seed: int = 0,
                  precision: int = 32, max_contacts: int = 20, env_id_offset: int = 0,
-                 test_mode: bool = False, lib_path: Optional[str] = None):
+                 test_mode: bool = False, lib_path: Optional[str] = None, wave_packing: int = 0):
         self.lib = load_library(lib_path)
         self.tables = tables
         c = tables.cfg
@@ -104,7 +104,7 @@ class BatchEnv:
         st.enable_phase_input = int(tables.enable_phase_input); st.record_world_root_pos = int(tables.record_world_root_pos)
         st.record_world_root_rot = int(tables.record_world_root_rot); st.query_rate = float(tables.query_rate)
         st.friction = 0.0; st.erp = 0.0; st.solver_iters = 0
-        info = _CreateInfo(int(num_envs), int(device_id), int(seed) & (2 ** 64 - 1), int(precision), int(max_contacts), int(env_id_offset))
+        info = _CreateInfo(int(num_envs), int(device_id), int(seed) & (2 ** 64 - 1), int(precision), int(max_contacts), int(env_id_offset), int(wave_packing))
         self.h = C.c_void_p()
         self._chk(self.lib.dm_create(C.byref(info), C.byref(st), C.byref(self.h)))
         dims = np.zeros(8, dtype=np.int32)

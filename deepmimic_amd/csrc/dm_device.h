@@ -30,6 +30,7 @@ static inline long long dm_clock() { return 0; }
 #define DM_DEV inline
 #define DM_OPAQUE_S(x) ((void)0)
 #define DM_OPAQUE_V(x) ((void)0)
+#define DM_SCHED_FENCE() ((void)0)
 static inline int dm_atomic_or(int* p, int v) { int o = *p; *p = o | v; return o; }
 static inline int dm_popc64(uint64_t v) { return __builtin_popcountll(v); }
 static inline int dm_ctz32(uint32_t v) { return __builtin_ctz(v); }
@@ -82,6 +83,8 @@ template <> struct VecT<double> { typedef double v2 __attribute__((vector_size(1
 // hundreds of compare masks an unrolled sweep would otherwise keep live (and spill)
 #define DM_OPAQUE_S(x) asm volatile("" : "+s"(x))
 #define DM_OPAQUE_V(x) asm volatile("" : "+v"(x))
+// nothing is scheduled across this point (keeps the rank-1 updates of one Cholesky column next to the loads that feed them)
+#define DM_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 __device__ __forceinline__ long long dm_clock() { return (long long)__builtin_readcyclecounter(); }
 __device__ __forceinline__ int dm_atomic_or(int* p, int v) { return atomicOr(p, v); }
 __device__ __forceinline__ int dm_popc64(uint64_t v) { return __popcll(v); }
@@ -217,7 +220,8 @@ enum { CLK_KIN = 0, CLK_CTRL, CLK_INIT_OFF, CLK_TIMER, CLK_TIMER_MAX };
 enum { FLG_NEED_ACTION = 0, FLG_CONTACT, FLG_EPISODE, FLG_VALID, FLG_NROWS, FLG_NCONT };
 
 // TAPS = false compiles every debug tap / phase timer out of the instruction stream (production step kernel).
-template <typename Real, typename C, bool TAPS = true>
+// LW = lanes per character: 64 (one character per wavefront) or 32 (two characters per wavefront, dm_device_duo.h).
+template <typename Real, typename C, bool TAPS = true, int LW = kWave>
 struct EnvSim {
     typedef Lds<Real, C> L;
     static constexpr int NJ = C::NJ, ND = C::ND, NP = C::NP, NCAP = C::NCAP, CPL = C::NCAP / kWave, RREG = C::RREG;
@@ -237,22 +241,25 @@ struct EnvSim {
     static DM_DEV v3 zero3() { return mk3((Real)0, (Real)0, (Real)0); }
 
     // ------------------------------------------------------------------ HBM <-> LDS
-    DM_DEV void load_model() {
-        uint32_t* dst = reinterpret_cast<uint32_t*>(&s.mdl);
-        for (int i = l; i < m.mdl_words; i += kWave) dst[i] = m.mdl_blob[i];
+    DM_DEV void load_cands() {
 #pragma unroll
         for (int q = 0; q < CPL; ++q) {
             const int c = l + kWave * q;
             cand_link[q] = 0; cand_rad[q] = 0; cand_loc[q][0] = cand_loc[q][1] = cand_loc[q][2] = 0;
             if (c < m.NC) { cand_link[q] = m.cand_link[c]; cand_rad[q] = m.cand_rad[c]; for (int k = 0; k < 3; ++k) cand_loc[q][k] = m.cand_loc[c * 3 + k]; }
         }
+    }
+    DM_DEV void load_model() {
+        uint32_t* dst = reinterpret_cast<uint32_t*>(&s.mdl);
+        for (int i = l; i < m.mdl_words; i += LW) dst[i] = m.mdl_blob[i];
+        if (LW == kWave) load_cands();
         sync();
         li = (l < m.J) ? s.mdl.link_info[l] : 0;
     }
     DM_DEV void load(const EnvState<Real>& st, int e) {
         load_model();
-        for (int i = l; i < m.P; i += kWave) { s.pose[i] = st.pose[(size_t)e * m.P + i]; s.vel[i] = st.vel[(size_t)e * m.P + i]; s.tar[i] = st.tar[(size_t)e * m.P + i]; }
-        if (l < m.D) s.tau[l] = st.tau[(size_t)e * m.D + l];
+        for (int i = l; i < m.P; i += LW) { s.pose[i] = st.pose[(size_t)e * m.P + i]; s.vel[i] = st.vel[(size_t)e * m.P + i]; s.tar[i] = st.tar[(size_t)e * m.P + i]; }
+        for (int i = l; i < m.D; i += LW) s.tau[i] = st.tau[(size_t)e * m.D + i];
         if (l < 8) s.kin[l] = st.kin[(size_t)e * 8 + l];
         if (l < 6) s.clk[l] = st.clock[(size_t)e * 6 + l];
         if (l < 4) s.flg[l] = st.flag[(size_t)e * 4 + l];
@@ -261,8 +268,8 @@ struct EnvSim {
     DM_DEV void store(const EnvState<Real>& st, int e) {
         DM_OPAQUE_V(l);
         sync();
-        for (int i = l; i < m.P; i += kWave) { st.pose[(size_t)e * m.P + i] = s.pose[i]; st.vel[(size_t)e * m.P + i] = s.vel[i]; st.tar[(size_t)e * m.P + i] = s.tar[i]; }
-        if (l < m.D) st.tau[(size_t)e * m.D + l] = s.tau[l];
+        for (int i = l; i < m.P; i += LW) { st.pose[(size_t)e * m.P + i] = s.pose[i]; st.vel[(size_t)e * m.P + i] = s.vel[i]; st.tar[(size_t)e * m.P + i] = s.tar[i]; }
+        for (int i = l; i < m.D; i += LW) st.tau[(size_t)e * m.D + i] = s.tau[i];
         if (l < 8) st.kin[(size_t)e * 8 + l] = s.kin[l];
         if (l < 6) st.clock[(size_t)e * 6 + l] = s.clk[l];
         if (l < 4) st.flag[(size_t)e * 4 + l] = s.flg[l];
@@ -312,8 +319,17 @@ struct EnvSim {
     // iset: 0 = SPD inertias, 1 = simulator inertias.  diag_scale * kd is added to the diagonal (SPD: dt).
     // Requires kinematics() for the same state.  Also fills dofrec[k] = (axis, g) used by the constraint rows.
     DM_DEV void dynamics(int iset, Real diag_scale) {
-        const int J = m.J, D = m.D;
-        if (l < J) {                       // per-link force / moment about the COM and world inertia about the COM
+        dyn_links(iset);
+        if (l < m.D) dyn_dofrec(l);
+        sync();
+        dyn_subtree();
+        sync();
+        if (l < m.D) dyn_row(l, diag_scale);
+        sync();
+    }
+    // per-link force / moment about the COM and world inertia about the COM (lane = link)
+    DM_DEV void dyn_links(int iset) {
+        if (l < m.J) {
             m3 Rb = ldm3(Rbp(l));
             const Real* Id = s.mdl.inertia[iset][l];
             Real I0 = Id[0], I1 = Id[1], I2 = Id[2];
@@ -333,72 +349,75 @@ struct EnvSim {
             v3 Ial = mk3(Iw[0] * al.x + Iw[1] * al.y + Iw[2] * al.z, Iw[1] * al.x + Iw[3] * al.y + Iw[4] * al.z, Iw[2] * al.x + Iw[4] * al.y + Iw[5] * al.z);
             st3(s.n[l], Ial + cross(w, Iwv));
         }
-        int di = 0, dj = 0, kind = 0, ax = 0; v3 a = zero3();
-        if (l < D) {                       // world axis of every generalized velocity and its moment about the root origin
-            di = s.mdl.dof_info[l]; dj = DM_DI_JOINT(di); kind = DM_DI_KIND(di); ax = DM_DI_AXIS(di);
-            v3 rec_a, rec_g;
-            if (kind == DK_ROOT_LIN) { a = mk3((Real)(ax == 0), (Real)(ax == 1), (Real)(ax == 2)); rec_a = zero3(); rec_g = a; }
-            else {
-                if (kind == DK_ROOT_ANG) a = mk3((Real)(ax == 0), (Real)(ax == 1), (Real)(ax == 2));
-                else { const int c = (kind == DK_REV) ? 2 : ax; a = mk3(s.R[dj][c], s.R[dj][3 + c], s.R[dj][6 + c]); }   // column c of R (indexed in LDS, not in registers)
-                rec_a = a; rec_g = cross(ld3(s.p[dj]) - ld3(s.p[0]), a);
-            }
-            st3(&s.dofrec[l][0], rec_a); st3(&s.dofrec[l][3], rec_g);
+    }
+    // world axis of generalized velocity k and its moment about the root origin -> dofrec[k] = (a, g)
+    // (root translation: a = 0, g = unit axis, so that one formula a.X + g.Y serves every dof)
+    DM_DEV void dyn_dofrec(int k) {
+        const int di = s.mdl.dof_info[k], dj = DM_DI_JOINT(di), kind = DM_DI_KIND(di), ax = DM_DI_AXIS(di);
+        v3 rec_a, rec_g;
+        if (kind == DK_ROOT_LIN) { rec_a = zero3(); rec_g = mk3((Real)(ax == 0), (Real)(ax == 1), (Real)(ax == 2)); }
+        else {
+            v3 a;
+            if (kind == DK_ROOT_ANG) a = mk3((Real)(ax == 0), (Real)(ax == 1), (Real)(ax == 2));
+            else { const int c = (kind == DK_REV) ? 2 : ax; a = mk3(s.R[dj][c], s.R[dj][3 + c], s.R[dj][6 + c]); }   // column c of R (indexed in LDS, not in registers)
+            rec_a = a; rec_g = cross(ld3(s.p[dj]) - ld3(s.p[0]), a);
         }
-        sync();
-        {   // subtree sums about each joint's origin (descendants have larger ids): G adjacent lanes share one link,
-            // sub-lane g takes members lk+g, lk+g+G, ...; the G partial sums are folded with DPP quad permutes
-            constexpr int G = (NJ <= 16) ? 4 : 2;
-            const int lk = l / G, g = l % G;
-            v3 Fs = zero3(), Ns = Fs, h = Fs;
-            Real mc = 0, Ic[6] = { 0, 0, 0, 0, 0, 0 };
-            if (lk < J) {
-                const uint32_t mask = s.mdl.subtree_mask[lk];
-                const v3 pj = ld3(s.p[lk]);
-                for (int k = lk + g; k < J; k += G) {
-                    if (!((mask >> k) & 1u)) continue;
-                    v3 d = ld3(s.com[k]) - pj, fk = ld3(s.f[k]);
-                    Fs = Fs + fk; Ns = Ns + ld3(s.n[k]) + cross(d, fk);
-                    Real mk = s.mdl.mass[k], dd = dot(d, d);
-                    mc += mk; h = h + mk * d;
-                    Ic[0] += s.Iw[k][0] + mk * (dd - d.x * d.x); Ic[1] += s.Iw[k][1] - mk * d.x * d.y; Ic[2] += s.Iw[k][2] - mk * d.x * d.z;
-                    Ic[3] += s.Iw[k][3] + mk * (dd - d.y * d.y); Ic[4] += s.Iw[k][4] - mk * d.y * d.z; Ic[5] += s.Iw[k][5] + mk * (dd - d.z * d.z);
-                }
+        st3(&s.dofrec[k][0], rec_a); st3(&s.dofrec[k][3], rec_g);
+    }
+    // subtree sums about each joint's origin (descendants have larger ids): G adjacent lanes share one link,
+    // sub-lane g takes members lk+g, lk+g+G, ...; the G partial sums are folded with DPP quad permutes
+    DM_DEV void dyn_subtree() {
+        const int J = m.J;
+        constexpr int G = (NJ * 4 <= LW) ? 4 : 2;
+        const int lk = l / G, g = l % G;
+        v3 Fs = zero3(), Ns = Fs, h = Fs;
+        Real mc = 0, Ic[6] = { 0, 0, 0, 0, 0, 0 };
+        if (lk < J) {
+            const uint32_t mask = s.mdl.subtree_mask[lk];
+            const v3 pj = ld3(s.p[lk]);
+            for (int k = lk + g; k < J; k += G) {
+                if (!((mask >> k) & 1u)) continue;
+                v3 d = ld3(s.com[k]) - pj, fk = ld3(s.f[k]);
+                Fs = Fs + fk; Ns = Ns + ld3(s.n[k]) + cross(d, fk);
+                Real mk = s.mdl.mass[k], dd = dot(d, d);
+                mc += mk; h = h + mk * d;
+                Ic[0] += s.Iw[k][0] + mk * (dd - d.x * d.x); Ic[1] += s.Iw[k][1] - mk * d.x * d.y; Ic[2] += s.Iw[k][2] - mk * d.x * d.z;
+                Ic[3] += s.Iw[k][3] + mk * (dd - d.y * d.y); Ic[4] += s.Iw[k][4] - mk * d.y * d.z; Ic[5] += s.Iw[k][5] + mk * (dd - d.z * d.z);
             }
-            Real acc[16] = { Fs.x, Fs.y, Fs.z, Ns.x, Ns.y, Ns.z, mc, h.x, h.y, h.z, Ic[0], Ic[1], Ic[2], Ic[3], Ic[4], Ic[5] };
+        }
+        Real acc[16] = { Fs.x, Fs.y, Fs.z, Ns.x, Ns.y, Ns.z, mc, h.x, h.y, h.z, Ic[0], Ic[1], Ic[2], Ic[3], Ic[4], Ic[5] };
 #pragma unroll
-            for (int i = 0; i < 16; ++i) { acc[i] += wave_shfl_xor_c<1>(acc[i]); if (G == 4) acc[i] += wave_shfl_xor_c<2>(acc[i]); }
-            if (lk < J && g == 0) {
-                for (int i = 0; i < 3; ++i) { s.Fs[lk][i] = acc[i]; s.Ns[lk][i] = acc[3 + i]; }
-                for (int i = 0; i < 10; ++i) s.Ic[lk][i] = acc[6 + i];
-            }
+        for (int i = 0; i < 16; ++i) { acc[i] += wave_shfl_xor_c<1>(acc[i]); if (G == 4) acc[i] += wave_shfl_xor_c<2>(acc[i]); }
+        if (lk < J && g == 0) {
+            for (int i = 0; i < 3; ++i) { s.Fs[lk][i] = acc[i]; s.Ns[lk][i] = acc[3 + i]; }
+            for (int i = 0; i < 10; ++i) s.Ic[lk][i] = acc[6 + i];
         }
-        sync();
-        if (l < D) {
-            s.bias[l] = (kind == DK_ROOT_LIN) ? s.Fs[0][ax] : dot(a, ld3(s.Ns[dj]));
-            // momentum of the composite body of joint j under unit velocity of this dof: linear Pm, angular about the root origin Lq
-            const Real* ic = s.Ic[dj];
-            v3 h = mk3(ic[1], ic[2], ic[3]), Pm, Lp;
-            if (kind == DK_ROOT_LIN) { Pm = ic[0] * a; Lp = cross(h, a); }
-            else {
-                Pm = cross(a, h);
-                Lp = mk3(ic[4] * a.x + ic[5] * a.y + ic[6] * a.z, ic[5] * a.x + ic[7] * a.y + ic[8] * a.z, ic[6] * a.x + ic[8] * a.y + ic[9] * a.z);
-            }
-            v3 Lq = Lp + cross(ld3(s.p[dj]) - ld3(s.p[0]), Pm);
-            // row l of H: zero, then the ancestor-or-self dofs k <= l:  H_lk = a_k . Lq + g_k . Pm
-            Real* row = &s.Lt[L::lrow(l)];
-            for (int k = 0; k <= l; ++k) row[k] = 0;
-            uint32_t lo = s.mdl.anc_lo[l], hi = s.mdl.anc_hi[l];
-            while (lo | hi) {
-                int k;
-                if (lo) { k = dm_ctz32(lo); lo &= lo - 1; } else { k = 32 + dm_ctz32(hi); hi &= hi - 1; }
-                const Real* rec = s.dofrec[k];
-                Real val = rec[0] * Lq.x + rec[1] * Lq.y + rec[2] * Lq.z + rec[3] * Pm.x + rec[4] * Pm.y + rec[5] * Pm.z;
-                if (k == l) val += diag_scale * s.mdl.kd[l];
-                row[k] = val;
-            }
+    }
+    // bias force C_k and row k of H (lower triangle, into the packed store): zero, then the ancestor-or-self dofs j <= k:
+    // H_kj = a_j . Lq + g_j . Pm with the composite-body momentum (Pm, Lq about the root origin) of dof k's unit velocity
+    DM_DEV void dyn_row(int k, Real diag_scale) {
+        const int di = s.mdl.dof_info[k], dj = DM_DI_JOINT(di), kind = DM_DI_KIND(di), ax = DM_DI_AXIS(di);
+        const v3 a = (kind == DK_ROOT_LIN) ? ld3(&s.dofrec[k][3]) : ld3(&s.dofrec[k][0]);
+        s.bias[k] = (kind == DK_ROOT_LIN) ? s.Fs[0][ax] : dot(a, ld3(s.Ns[dj]));
+        const Real* ic = s.Ic[dj];
+        v3 h = mk3(ic[1], ic[2], ic[3]), Pm, Lp;
+        if (kind == DK_ROOT_LIN) { Pm = ic[0] * a; Lp = cross(h, a); }
+        else {
+            Pm = cross(a, h);
+            Lp = mk3(ic[4] * a.x + ic[5] * a.y + ic[6] * a.z, ic[5] * a.x + ic[7] * a.y + ic[8] * a.z, ic[6] * a.x + ic[8] * a.y + ic[9] * a.z);
         }
-        sync();
+        v3 Lq = Lp + cross(ld3(s.p[dj]) - ld3(s.p[0]), Pm);
+        Real* row = &s.Lt[L::lrow(k)];
+        for (int j = 0; j <= k; ++j) row[j] = 0;
+        uint32_t lo = s.mdl.anc_lo[k], hi = s.mdl.anc_hi[k];
+        while (lo | hi) {
+            int j;
+            if (lo) { j = dm_ctz32(lo); lo &= lo - 1; } else { j = 32 + dm_ctz32(hi); hi &= hi - 1; }
+            const Real* rec = s.dofrec[j];
+            Real val = rec[0] * Lq.x + rec[1] * Lq.y + rec[2] * Lq.z + rec[3] * Pm.x + rec[4] * Pm.y + rec[5] * Pm.z;
+            if (j == k) val += diag_scale * s.mdl.kd[k];
+            row[j] = val;
+        }
     }
 
     // ------------------------------------------------------------------ dense SPD linear algebra, register resident
@@ -502,6 +521,11 @@ struct EnvSim {
     }
     // pose error per joint -> xs = Kp e + Kd (0 - qd); rhs = xs - C
     DM_DEV void spd_rhs(Real dt) {
+        spd_rhs_pre(dt);
+        for (int i = l; i < m.D; i += LW) s.rhs[i] = s.xs[i] - s.bias[i];
+        sync();
+    }
+    DM_DEV void spd_rhs_pre(Real dt) {
         if (l < m.J && l > 0) {
             int jt = DM_LI_JTYPE(li), off = DM_LI_POFF(li), dof = DM_LI_DOFF(li);
             if (jt == JT_SPHERICAL) {
@@ -518,13 +542,14 @@ struct EnvSim {
         }
         if (l < 6) s.xs[l] = 0;
         sync();
-        if (l < m.D) s.rhs[l] = s.xs[l] - s.bias[l];
-        sync();
     }
     // rhs holds qddot: tau = Kp e + Kd (e_v - dt qddot), clamped per joint (SimBodyJoint.cpp:299-307)
     DM_DEV void spd_post(Real dt) {
-        if (l < m.D) s.tau[l] = (l < 6) ? (Real)0 : s.xs[l] - s.mdl.kd[l] * dt * s.rhs[l];
+        for (int i = l; i < m.D; i += LW) s.tau[i] = (i < 6) ? (Real)0 : s.xs[i] - s.mdl.kd[i] * dt * s.rhs[i];
         sync();
+        spd_clamp();
+    }
+    DM_DEV void spd_clamp() {
         if (l < m.J && l > 0) {
             int jt = DM_LI_JTYPE(li), dof = DM_LI_DOFF(li); Real lim = s.mdl.torque_lim[l];
             if (jt == JT_SPHERICAL) {
@@ -542,6 +567,20 @@ struct EnvSim {
     DM_DEV Real clamp_vel(Real v, int dof) const {
         Real mx = (dof < 3) ? m.max_lin_vel : m.max_ang_vel;
         return dm_max(-mx, dm_min(mx, v));
+    }
+    // integrate positions with the new velocity (semi-implicit Euler, exponential map on rotations); lane = link
+    DM_DEV void integrate(Real h) {
+        if (l < m.J) {
+            int jt = DM_LI_JTYPE(li), off = DM_LI_POFF(li);
+            if (l == 0) {
+                for (int k = 0; k < 3; ++k) s.pose[k] += h * s.vel[k];
+                q4 q = qnormalize(qmul(quat_exp(h * ld3(s.vel + 3)), ldq(s.pose + 3)));
+                stq(s.pose + 3, q);
+            } else if (jt == JT_SPHERICAL) {
+                q4 q = qnormalize(qmul(ldq(s.pose + off), quat_exp(h * ld3(s.vel + off))));
+                stq(s.pose + off, qstandardize(q));
+            } else if (jt == JT_REVOLUTE) s.pose[off] += h * s.vel[off];
+        }
     }
     // s.rhs holds qddot of the unconstrained dynamics; s.L the Cholesky factor of H.
     DM_DEV void substep_post(Real h, DebugTaps<Real> dbg, int e, Real* aovf) {
@@ -742,18 +781,7 @@ struct EnvSim {
         z = back_substitute(z, dinv);
         if (l < D) s.vel[vidx] = clamp_vel(vstar + z, l);
         sync();
-        // ---- integrate positions (semi-implicit Euler, exponential map on rotations)
-        if (l < J) {
-            int jt = DM_LI_JTYPE(li), off = DM_LI_POFF(li);
-            if (l == 0) {
-                for (int k = 0; k < 3; ++k) s.pose[k] += h * s.vel[k];
-                q4 q = qnormalize(qmul(quat_exp(h * ld3(s.vel + 3)), ldq(s.pose + 3)));
-                stq(s.pose + 3, q);
-            } else if (jt == JT_SPHERICAL) {
-                q4 q = qnormalize(qmul(ldq(s.pose + off), quat_exp(h * ld3(s.vel + off))));
-                stq(s.pose + off, qstandardize(q));
-            } else if (jt == JT_REVOLUTE) s.pose[off] += h * s.vel[off];
-        }
+        integrate(h);
         sync();
         mark(12);
     }
@@ -810,7 +838,7 @@ struct EnvSim {
         bool over = !m.loop && time >= m.duration;
         const Real* v0 = m.frame_vel + (size_t)idx * m.P; const Real* v1 = v0 + m.P;
         Real bv = (Real)blend;
-        for (int i = l; i < m.P; i += kWave) kv[i] = over ? (Real)0 : ((Real)1 - bv) * v0[i] + bv * v1[i];
+        for (int i = l; i < m.P; i += LW) kv[i] = over ? (Real)0 : ((Real)1 - bv) * v0[i] + bv * v1[i];
         sync();
         if (l == 0) {
             v3 v = qrot(orot, ld3(kv)), w = qrot(orot, ld3(kv + 3));
@@ -885,7 +913,7 @@ struct EnvSim {
         mark(ph == 0 ? 2 : 6);
         if (TAPS && dbg.H) {
             const int D = m.D;
-            for (int i = l; i < D * D; i += kWave) { int r = i / D, c = i % D; Real v = (c <= r) ? Lx(r, c) : Lx(c, r); if (r == c && ph == 0) v -= dt * s.mdl.kd[r]; dbg.H[(size_t)e * D * D + i] = v; }
+            for (int i = l; i < D * D; i += LW) { int r = i / D, c = i % D; Real v = (c <= r) ? Lx(r, c) : Lx(c, r); if (r == c && ph == 0) v -= dt * s.mdl.kd[r]; dbg.H[(size_t)e * D * D + i] = v; }
             if (l < D) dbg.C[(size_t)e * D + l] = s.bias[l];
         }
         if (tap_only) return;
@@ -927,7 +955,7 @@ struct EnvSim {
         Real* red = scratch() + 2 * NP + 3 * NJ;         // J x 4 per-joint reduction terms
         const v3 zero = zero3();
         kin_sample(s.clk[CLK_KIN], kp, kv);
-        if (TAPS && dbg.kin_pose) for (int i = l; i < m.P; i += kWave) { dbg.kin_pose[(size_t)e * m.P + i] = kp[i]; dbg.kin_vel[(size_t)e * m.P + i] = kv[i]; }
+        if (TAPS && dbg.kin_pose) for (int i = l; i < m.P; i += LW) { dbg.kin_pose[(size_t)e * m.P + i] = kp[i]; dbg.kin_vel[(size_t)e * m.P + i] = kv[i]; }
         // kin character: joint positions and COM velocity (cRBDUtil::CalcCoM)
         kinematics(kp, kv, zero);
         if (l < J) {
@@ -1066,11 +1094,11 @@ struct EnvSim {
             s.flg[FLG_NEED_ACTION] = 1; s.flg[FLG_CONTACT] = 0; s.flg[FLG_VALID] = 1; s.flg[FLG_EPISODE] += 1;
             s.kin[0] = s.kin[1] = s.kin[2] = 0; s.kin[3] = 1; s.kin[4] = s.kin[5] = s.kin[6] = 0;
         }
-        if (l < m.D) s.tau[l] = 0;
+        for (int i = l; i < m.D; i += LW) s.tau[i] = 0;
         sync();
         kin_sample(kin_time, kp, kv);
         // sim := kin (cSimCharacter::SetPose/SetVel then BuildPose/BuildVel): unit quaternions, spherical w >= 0
-        for (int i = l; i < m.P; i += kWave) { s.pose[i] = kp[i]; s.vel[i] = kv[i]; }
+        for (int i = l; i < m.P; i += LW) { s.pose[i] = kp[i]; s.vel[i] = kv[i]; }
         sync();
         if (l < m.J) {
             int jt = DM_LI_JTYPE(li), off = DM_LI_POFF(li);

@@ -1,0 +1,493 @@
+// Two characters per wavefront ("duo") variant of the step kernel for the biped class.
+//
+// Lanes 0..31 simulate character 2b, lanes 32..63 character 2b+1 of workgroup b, through one instruction stream:
+//   lanes <-> links (15 of 32)            kinematics, Newton-Euler pass, integration, reward/observation  (EnvSim pieces)
+//   lanes <-> dofs 3..33 (31 of 32)       mass-matrix rows, Cholesky rows, triangular solves.  Rows 0..2 of H belong to the
+//                                         root translation: diag(M, M, M) with zeros left of the diagonal, so their rows of L
+//                                         are known in closed form (1/sqrt(M) on the diagonal) and need no lane
+//   lanes <-> ground-contact candidates   two passes of 32
+//   lanes <-> constraint rows (<= 32)     assembly, Gram matrix on the matrix core (two MFMA chains), projected Gauss-Seidel
+// Every VALU instruction therefore advances two characters; cross-lane traffic stays inside a 32-lane half (two v_readlane +
+// select per broadcast).  A substep in which either character needs more than 32 rows runs the one-character-per-wave
+// routine of dm_device.h on each record in turn (same LDS record layout), so the results do not depend on the pairing.
+#pragma once
+#include "dm_device.h"
+
+namespace dmk {
+
+#ifdef DM_EMU
+template <typename T> static inline T half_bcast(T v, int src, int half) { return wave_shfl(v, half * 32 + src); }
+template <typename T> static inline T half_sum(T v) {
+    T* x = reinterpret_cast<T*>(emu::g_xchg);
+    x[threadIdx.x] = v; __syncthreads();
+    T s = 0; const int b = (threadIdx.x >> 5) * 32; for (int i = 0; i < 32; ++i) s += x[b + i];
+    __syncthreads(); return s;
+}
+template <int NP2, typename R2, typename Real> static inline void duo_gram32(const R2* y2, Real (&out)[32]) {
+    Real* x = reinterpret_cast<Real*>(emu::g_xchg);
+    for (int p = 0; p < NP2; ++p) { x[threadIdx.x * 2 * NP2 + 2 * p] = y2[p][0]; x[threadIdx.x * 2 * NP2 + 2 * p + 1] = y2[p][1]; }
+    __syncthreads();
+    const int b = (threadIdx.x >> 5) * 32;
+    for (int i = 0; i < 32; ++i) { Real a = 0; for (int k = 0; k < 2 * NP2; ++k) a += x[threadIdx.x * 2 * NP2 + k] * x[(b + i) * 2 * NP2 + k]; out[i] = a; }
+    __syncthreads();
+}
+#else
+__device__ __forceinline__ float half_bcast(float v, int src, int half) { const float a = lane_bcast(v, src), b = lane_bcast(v, 32 + src); return half ? b : a; }
+__device__ __forceinline__ double half_bcast(double v, int src, int half) { const double a = lane_bcast(v, src), b = lane_bcast(v, 32 + src); return half ? b : a; }
+__device__ __forceinline__ int half_bcast(int v, int src, int half) { const int a = lane_bcast(v, src), b = lane_bcast(v, 32 + src); return half ? b : a; }
+__device__ __forceinline__ float half_sum(float v) {
+    v += DM_DPP_F(v, 0xB1, 0xf, true);     // quad_perm [1,0,3,2]
+    v += DM_DPP_F(v, 0x4E, 0xf, true);     // quad_perm [2,3,0,1]
+    v += DM_DPP_F(v, 0x141, 0xf, true);    // row_half_mirror
+    v += DM_DPP_F(v, 0x140, 0xf, true);    // row_mirror: every lane holds the sum of its row of 16
+    return v + __shfl_xor(v, 16, 64);
+}
+__device__ __forceinline__ double half_sum(double v) {
+    for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+// Gram rows of both characters: lane l gets G[i] = sum_k y_l[k] y_{32*half + i}[k], i < 32.  Two MFMA chains share one
+// cross-half shuffle per k-pair (the lower half sends its odd column up, the upper half its even column down).
+template <int NP2> __device__ __forceinline__ void duo_gram32(const VecT<float>::v2* y2, float (&out)[32]) {
+    typedef float f16v __attribute__((ext_vector_type(16)));
+    const bool upper = threadIdx.x >= 32;
+    f16v accA = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, accB = accA;
+#pragma unroll
+    for (int p = 0; p < NP2; ++p) {
+        const float a0 = y2[p][0], a1 = y2[p][1];
+        const float sx = __shfl_xor(upper ? a0 : a1, 32, 64);
+        const float opA = upper ? sx : a0, opB = upper ? a1 : sx;
+        accA = __builtin_amdgcn_mfma_f32_32x32x2f32(opA, opA, accA, 0, 0, 0);
+        accB = __builtin_amdgcn_mfma_f32_32x32x2f32(opB, opB, accB, 0, 0, 0);
+    }
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+        const float recv = __shfl_xor(upper ? accA[v] : accB[v], 32, 64);
+        out[8 * (v / 4) + (v % 4)] = upper ? recv : accA[v];
+        out[8 * (v / 4) + 4 + (v % 4)] = upper ? accB[v] : recv;
+    }
+}
+template <int NP2> __device__ __forceinline__ void duo_gram32(const VecT<double>::v2* y2, double (&out)[32]) {
+    const int half = threadIdx.x >> 5;
+#pragma unroll 1
+    for (int i = 0; i < 32; ++i) {
+        double a = 0;
+#pragma unroll
+        for (int p = 0; p < NP2; ++p) a += y2[p][0] * half_bcast(y2[p][0], i, half) + y2[p][1] * half_bcast(y2[p][1], i, half);
+        out[i] = a;
+    }
+}
+#endif
+
+template <typename Real, bool TAPS>
+struct DuoSim {
+    typedef ClsBiped C;
+    typedef Lds<Real, C> L;
+    typedef EnvSim<Real, C, TAPS, 32> Base;
+    typedef EnvSim<Real, C, TAPS, kWave> Single;
+    static constexpr int ND = C::ND, NP2 = ND / 2, NP = C::NP, NJ = C::NJ, HW = 32, CP = 2 /* candidate passes */;
+    typedef V3<Real> v3; typedef typename VecT<Real>::v2 R2; typedef typename VecT<Real>::v4 R4;
+    const ModelDev<Real>& m; L* rec;                    // the two records of this workgroup
+    const int wl, half; int hl;                         // wave lane, which character, lane within the character
+    Base b;                                             // per-character pieces (lane hl of record `half`)
+    L& s;
+    int cand_link[CP]; Real cand_loc[CP][3], cand_rad[CP];
+    DM_DEV DuoSim(const ModelDev<Real>& m_, L* rec_, int wl_) : m(m_), rec(rec_), wl(wl_), half(wl_ >> 5), hl(wl_ & 31), b(m_, rec_[wl_ >> 5], wl_ & 31), s(rec_[wl_ >> 5]) {}
+    DM_DEV void sync() const { __syncthreads(); }
+    DM_DEV Real& Lx(int r, int c) const { return s.Lt[L::lrow(r) + c]; }
+    static DM_DEV v3 zero3() { return mk3((Real)0, (Real)0, (Real)0); }
+
+    DM_DEV void load(const EnvState<Real>& st, int e) {
+        b.load(st, e);
+#pragma unroll
+        for (int q = 0; q < CP; ++q) {
+            const int c = hl + HW * q;
+            cand_link[q] = 0; cand_rad[q] = 0; cand_loc[q][0] = cand_loc[q][1] = cand_loc[q][2] = 0;
+            if (c < m.NC) { cand_link[q] = m.cand_link[c]; cand_rad[q] = m.cand_rad[c]; for (int k = 0; k < 3; ++k) cand_loc[q][k] = m.cand_loc[c * 3 + k]; }
+        }
+    }
+
+    // ------------------------------------------------------------------ mass matrix rows 3..33 in lanes, rows 0..2 closed form
+    DM_DEV void dynamics(int iset, Real diag_scale) {
+        const int D = m.D;
+        b.dyn_links(iset);
+        for (int k = hl; k < D; k += HW) b.dyn_dofrec(k);
+        sync();
+        b.dyn_subtree();
+        sync();
+        if (hl + 3 < D) b.dyn_row(hl + 3, diag_scale);
+        if (hl == HW - 1) for (int k = 0; k < 3; ++k) s.bias[k] = s.Fs[0][k];       // root translation: C_k = total force
+        sync();
+    }
+
+    // ------------------------------------------------------------------ Cholesky + solve, 31 row lanes per character
+    // x := H^-1 x for the LDS vector xvec.  Same factor layout in LDS as EnvSim::chol_solve (diagonal slot = 1/L_kk).
+    DM_DEV void chol_solve(Real* xvec) {
+        const int D = m.D;
+        const int own = hl + 3;                          // the row this lane owns
+        const bool valid = own < D;
+        R2 h2[NP2];
+        const int rr = valid ? own : 3;
+#pragma unroll
+        for (int p = 0; p < NP2; ++p) {
+            R2 v = *reinterpret_cast<const R2*>(&s.Lt[L::lrow(rr) + 2 * p]);
+            if (!valid) { v[0] = 0; v[1] = 0; }
+            h2[p] = v;
+        }
+        // Two columns per LDS round trip: column k+1 only needs L[k+1][k] from column k (one in-register broadcast), then both
+        // columns are published together and the trailing rank-2 update reads them back as wave-uniform broadcasts.
+        Real* colbuf = &s.f[0][0];                       // 2 columns x 40 words per character (aliases the dead Newton-Euler sums)
+        const Real M = s.Ic[0][0];                       // H_kk, k < 3: total mass (root Kd = 0)
+        const Real dinv0 = dm_rsqrt(M);
+        Real dinv = 1;
+        sync();                                          // every lane has read what it needs from the aliased region
+#pragma unroll
+        for (int k = 0; k < ND; k += 2) {
+            const int pk = k >> 1;
+            // column k
+            Real inv0;
+            if (k < 3) inv0 = dinv0; else inv0 = dm_rsqrt(half_bcast(h2[pk][0], k - 3, half));
+            const Real lik0 = h2[pk][0] * inv0;
+            h2[pk][0] = lik0;
+            if (own == k) dinv = inv0;
+            // column k+1 after the rank-1 update by column k of its own entries: needs L[k+1][k] only
+            const Real lk1k = (k + 1 < 3) ? (Real)0 : half_bcast(lik0, k + 1 - 3, half);
+            h2[pk][1] -= lik0 * lk1k;
+            Real inv1;
+            if (k + 1 < 3) inv1 = dinv0; else inv1 = dm_rsqrt(half_bcast(h2[pk][1], k + 1 - 3, half));
+            const Real lik1 = h2[pk][1] * inv1;
+            h2[pk][1] = lik1;
+            if (own == k + 1) dinv = inv1;
+            if (k + 2 < ND) {
+                Real* cb0 = colbuf + ((k >> 1) & 1) * 80, *cb1 = cb0 + 40;
+                if (valid) { cb0[own] = lik0; cb1[own] = lik1; }
+                if (k < 3 && hl == HW - 1) { cb0[0] = 0; cb0[1] = 0; cb0[2] = 0; cb1[0] = 0; cb1[1] = 0; cb1[2] = 0; }   // rows 1, 2: nothing left of the diagonal
+                sync();
+                const R2 l20 = {lik0, lik0}, l21 = {lik1, lik1};
+#pragma unroll
+                for (int p = pk + 1; p < NP2; ++p) {
+                    h2[p] -= l20 * *reinterpret_cast<const R2*>(&cb0[2 * p]) + l21 * *reinterpret_cast<const R2*>(&cb1[2 * p]);
+                    DM_OPAQUE_V(h2[p]);                  // evaluated here, not sunk to the pivot that needs it
+                }
+            }
+        }
+        if (valid) {
+            Real* row = &s.Lt[L::lrow(own)];
+#pragma unroll
+            for (int p = 0; p < NP2; ++p) {
+                R2 v = h2[p];
+                if (own == 2 * p) v[0] = dinv;
+                if (own == 2 * p + 1) v[1] = dinv;
+                if (2 * p <= own) *reinterpret_cast<R2*>(&row[2 * p]) = v;
+            }
+        } else if (hl == HW - 1) {                       // rows 0..2 of the factor: 1/sqrt(M) on the diagonal, zeros left of it
+            Lx(0, 0) = dinv0; Lx(1, 0) = 0; Lx(1, 1) = dinv0; Lx(2, 0) = 0; Lx(2, 1) = 0; Lx(2, 2) = dinv0;
+        }
+        // forward substitution; x0..x2 are uniform per character
+        Real x = valid ? xvec[own] : (Real)0;
+        Real xr[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { xr[k] = xvec[k] * dinv0; x -= h2[k >> 1][k & 1] * xr[k]; }
+#pragma unroll
+        for (int k = 3; k < ND; ++k) {
+            Real t = x * dinv; Real xk = half_bcast(t, k - 3, half);
+            if (own == k) x = t; else if (own > k) x -= h2[k >> 1][k & 1] * xk;
+        }
+        sync();
+        back_substitute(x, xr, dinv, dinv0);
+        if (valid) xvec[own] = x;
+        if (hl == HW - 1) for (int k = 0; k < 3; ++k) xvec[k] = xr[k];
+        sync();
+    }
+    // (x, xr) := L^-T (x, xr): rows 3..33 per lane with column reads from LDS, rows 0..2 by three half-wave sums
+    DM_DEV void back_substitute(Real& x, Real (&xr)[3], Real dinv, Real dinv0) {
+        const int own = hl + 3; const bool valid = own < m.D;
+        Real c[ND];
+#pragma unroll
+        for (int k = 0; k < ND; ++k) c[k] = (valid && k > own) ? s.Lt[L::lrow(k) + own] : (Real)0;
+#pragma unroll
+        for (int k = ND - 1; k >= 3; --k) {
+            Real t = x * dinv; Real xk = half_bcast(t, k - 3, half);
+            if (own == k) x = t; else if (own < k) x -= c[k] * xk;
+        }
+        Real col[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) col[k] = valid ? Lx(own, k) : (Real)0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) xr[k] = (xr[k] - half_sum(col[k] * x)) * dinv0;
+    }
+
+    DM_DEV Real clamp_vel(Real v, int dof) const { return b.clamp_vel(v, dof); }
+
+    // ------------------------------------------------------------------ rigid-body substep, constraint part
+    // returns false (having done nothing that matters) when either character needs more than 32 constraint rows
+    DM_DEV bool substep_post(Real h) {
+        const int D = m.D;
+        for (int k = hl; k < D; k += HW) { const int vidx = DM_DI_VIDX(s.mdl.dof_info[k]); s.dofrec[k][6] = clamp_vel(s.vel[vidx] + h * s.rhs[k], k); }
+        if (hl == 0) s.flg[FLG_CONTACT] = 0;
+        sync();
+        b.mark(7);
+        // ---- collision: lane = candidate, two passes
+        bool active[CP]; Real dist[CP]; v3 cxp[CP]; uint32_t amask[CP];
+        int nact = 0;
+#pragma unroll
+        for (int q = 0; q < CP; ++q) {
+            const int c = hl + HW * q;
+            active[q] = false; dist[q] = 0; cxp[q] = zero3();
+            if (c < m.NC) {
+                int link = cand_link[q];
+                v3 x = ld3(s.com[link]) + ldm3(b.Rbp(link)) * mk3(cand_loc[q][0], cand_loc[q][1], cand_loc[q][2]);
+                x.y -= cand_rad[q];
+                dist[q] = x.y; cxp[q] = x;
+                active[q] = x.y < s.mdl.thresh[link];
+                if (x.y <= m.report_dist) dm_atomic_or(&s.flg[FLG_CONTACT], 1 << link);
+            }
+            amask[q] = (uint32_t)(wave_ballot(active[q]) >> (half * 32));
+            nact += dm_popc64(amask[q]);
+        }
+        if (wave_ballot(nact > m.max_contacts) != 0) {
+            // manifold reduction (rare): keep the max_contacts deepest, ties to the lower index
+#pragma unroll
+            for (int q = 0; q < CP; ++q) { const int c = hl + HW * q; s.csel[c] = active[q] ? 1 : 0; s.cdist[c] = dist[q]; }
+            sync();
+#pragma unroll
+            for (int q = 0; q < CP; ++q) {
+                const int c = hl + HW * q; int rank = 0;
+                if (active[q]) for (int k = 0; k < m.NC; ++k) if (s.csel[k] && (s.cdist[k] < dist[q] || (s.cdist[k] == dist[q] && k < c))) ++rank;
+                active[q] = active[q] && rank < m.max_contacts;
+            }
+            sync();
+            nact = 0;
+#pragma unroll
+            for (int q = 0; q < CP; ++q) { amask[q] = (uint32_t)(wave_ballot(active[q]) >> (half * 32)); nact += dm_popc64(amask[q]); }
+        }
+        const int nc = nact, NL = m.NL;
+        const int R = NL + 3 * nc;
+        if (wave_ballot(R > HW) != 0) return false;      // a heavily contacted character: the caller runs the one-per-wave routine
+        {
+            const uint32_t lt = (hl == 0) ? 0u : (~0u >> (32 - hl));
+            int base = 0;
+#pragma unroll
+            for (int q = 0; q < CP; ++q) {
+                if (active[q]) {
+                    const int c = hl + HW * q, slot = base + dm_popc64(amask[q] & lt);
+                    s.cslot[slot] = c | (cand_link[q] << 16); st3(s.cx[c], cxp[q]); s.cdist[c] = dist[q];
+                }
+                base += dm_popc64(amask[q]);
+            }
+        }
+        if (hl == 0) { s.flg[FLG_NROWS] = R; s.flg[FLG_NCONT] = nc; }
+        sync();
+        b.mark(8);
+        // ---- constraint rows: lane = row (see EnvSim::substep_post)
+        Real brow = 0;
+        uint32_t ch_lo = 0, ch_hi = 0; v3 xd = zero3(), dd = zero3();
+        if (hl < R) {
+            if (hl < NL) {
+                int j = s.mdl.lim_joint[hl]; int lj = s.mdl.link_info[j]; int off = DM_LI_POFF(lj);
+                const int limdof = DM_LI_DOFF(lj);
+                Real th = s.pose[off], pen_lo = th - s.mdl.lim_lo[hl], pen_hi = s.mdl.lim_hi[hl] - th;
+                Real pen, sgn;
+                if (pen_lo <= pen_hi) { sgn = 1; pen = pen_lo; } else { sgn = -1; pen = pen_hi; }
+                brow = (pen > 0) ? -pen / h : -m.erp * pen / h;
+                xd = sgn * ld3(&s.dofrec[limdof][0]);
+                if (limdof < 32) ch_lo = 1u << limdof; else ch_hi = 1u << (limdof - 32);
+            } else {
+                int cs, kindr;
+                if (hl < NL + nc) { cs = s.cslot[hl - NL]; kindr = 0; } else { int fi = hl - NL - nc; cs = s.cslot[fi >> 1]; kindr = 1 + (fi & 1); }
+                const int c = cs & 0xffff, lk = cs >> 16;
+                ch_lo = s.mdl.chain_lo[lk]; ch_hi = s.mdl.chain_hi[lk];
+                dd = (kindr == 0) ? mk3((Real)0, (Real)1, (Real)0) : ((kindr == 1) ? mk3((Real)-1, (Real)0, (Real)0) : mk3((Real)0, (Real)0, (Real)1));
+                xd = cross(ld3(s.cx[c]) - ld3(s.p[0]), dd);
+                if (kindr == 0) { Real dc = s.cdist[c]; brow = (dc > 0) ? -dc / h : -m.erp * dc / h; }
+            }
+        }
+        R2 y2[NP2]; Real cvec = 0;
+#pragma unroll
+        for (int k = 0; k < ND; ++k) {
+            Real yk = 0;
+            if (k < D) {
+                const R4 r0 = *reinterpret_cast<const R4*>(&s.dofrec[k][0]), r1 = *reinterpret_cast<const R4*>(&s.dofrec[k][4]);
+                const Real val = r0[0] * xd.x + r0[1] * xd.y + r0[2] * xd.z + r0[3] * dd.x + r1[0] * dd.y + r1[1] * dd.z;
+                const bool on = (((k < 32) ? ch_lo : ch_hi) >> (k & 31)) & 1u;
+                const Real raw = on ? val : (Real)0;
+                cvec += raw * r1[2];
+                R2 acc2 = {(Real)0, (Real)0};
+                const R2* lrow = reinterpret_cast<const R2*>(&s.Lt[L::lrow(k)]);
+#pragma unroll
+                for (int p = 0; p < (k >> 1); ++p) acc2 += lrow[p] * y2[p];
+                Real acc = raw - (acc2[0] + acc2[1]);
+                if (k & 1) acc -= s.Lt[L::lrow(k) + k - 1] * y2[k >> 1][0];
+                yk = acc * s.Lt[L::lrow(k) + k];
+            }
+            y2[k >> 1][k & 1] = yk;
+        }
+        b.mark(9);
+        const int RN = NL + nc;
+        const bool is_fric = hl >= RN && hl < R;
+        Real lam = 0;
+        if (wave_ballot(hl < RN && (brow - cvec) > 0) != 0) {
+            RowFile<Real, 32> arow;
+            Real adiag;
+            { R2 a2 = {(Real)0, (Real)0};
+#pragma unroll
+              for (int p = 0; p < NP2; ++p) a2 += y2[p] * y2[p];
+              adiag = a2[0] + a2[1]; }
+            const Real inv_adiag = (hl < R) ? (Real)1 / adiag : (Real)0;
+            {
+                Real g[32];
+#pragma unroll
+                for (int p = 0; p < NP2; ++p) DM_OPAQUE_V(y2[p]);
+                duo_gram32<NP2>(y2, g);
+#pragma unroll
+                for (int r = 0; r < 32; ++r) arow.set(r, g[r] * inv_adiag);
+            }
+            b.mark(10);
+            Real q = (brow - cvec) * inv_adiag;
+            const int nrm_lane = is_fric ? NL + ((hl - RN) >> 1) : 0;
+            Real lo = 0, hi = is_fric ? (Real)0 : (Real)1e30;
+            // sweep bounds of the pair: rows up to the larger R; a lane beyond its own R has q = 0, lambda = 0 and changes nothing
+            const int Ra = lane_bcast(R, 0), Rb = lane_bcast(R, 32);
+            int Rv = Ra > Rb ? Ra : Rb, RNa = lane_bcast(RN, 0), RNb = lane_bcast(RN, 32), lv = hl;
+            for (int it = 0; it < m.solver_iters; ++it) {
+                DM_OPAQUE_S(Rv); DM_OPAQUE_S(RNa); DM_OPAQUE_S(RNb); DM_OPAQUE_V(lv);
+#pragma unroll
+                for (int blk = 0; blk < HW / 8; ++blk) {
+                    if (blk * 8 < Rv) {
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) {
+                            const int r = blk * 8 + i;
+                            if (r < Rv) {
+                                if (r == RNa || r == RNb) { const Real ln = wave_shfl(lam, half * 32 + nrm_lane); if (is_fric && r == RN) { hi = m.friction * ln; lo = -hi; } }
+                                const Real nl = dm_med3(lo, lam + q, hi);
+                                const Real delta = half_bcast(nl - lam, r, half);
+                                q -= arow.get(r) * delta;
+                                if (lv == r) lam = nl;
+                            }
+                        }
+                    }
+                }
+            }
+            if (hl >= R) lam = 0;
+        } else b.mark(10);
+        b.mark(11);
+        // delta v = L^-T (Y lambda): transposing reduction inside each half; dof k < 32 lands in lane k, dofs 32, 33 in lanes 0, 1
+        {
+            Real w[NP2];
+            const bool bit = (hl & 1) != 0;
+#pragma unroll
+            for (int p = 0; p < NP2; ++p) {
+                const Real a = y2[p][0] * lam, bb = y2[p][1] * lam;
+                w[p] = (bit ? bb : a) + wave_shfl_xor_c<1>(bit ? a : bb);
+            }
+            b.template tr_stage<NP2, 2>(w);
+            b.template tr_stage<(NP2 + 1) / 2, 4>(w);
+            b.template tr_stage<(NP2 + 3) / 4, 8>(w);
+            b.template tr_stage<(NP2 + 7) / 8, 16>(w);
+            s.xs[hl] = w[0];
+            if (hl + 32 < D) s.xs[hl + 32] = w[1];
+        }
+        sync();
+        {
+            const int own = hl + 3; const bool valid = own < D;
+            Real x = valid ? s.xs[own] : (Real)0;
+            Real xr[3] = { s.xs[0], s.xs[1], s.xs[2] };
+            const Real dinv = valid ? Lx(valid ? own : 3, valid ? own : 3) : (Real)1, dinv0 = Lx(0, 0);
+            sync();
+            back_substitute(x, xr, dinv, dinv0);
+            if (valid) s.xs[own] = x;
+            if (hl == HW - 1) for (int k = 0; k < 3; ++k) s.xs[k] = xr[k];
+        }
+        sync();
+        for (int k = hl; k < D; k += HW) { const int vidx = DM_DI_VIDX(s.mdl.dof_info[k]); s.vel[vidx] = clamp_vel(s.dofrec[k][6] + s.xs[k], k); }
+        sync();
+        b.integrate(h);
+        sync();
+        b.mark(12);
+        return true;
+    }
+
+    // ------------------------------------------------------------------ one scene update for both characters
+    DM_DEV void update(double dt, int e, Real* aovf_pair) {
+        if (hl == 0) { s.clk[CLK_TIMER] += dt; s.clk[CLK_CTRL] += dt; s.flg[FLG_NEED_ACTION] = 0; }
+        b.kin_update(dt);
+        const Real h = (Real)(dt / m.num_sim_substeps), rdt = (Real)dt;
+        const int D = m.D;
+        for (int ph = 0; ph <= m.num_sim_substeps; ++ph) {
+            DM_OPAQUE_V(hl); DM_OPAQUE_V(b.l); DM_OPAQUE_V(b.li);
+            b.mark(ph == 0 ? 0 : 4);
+            if (ph == 1) {
+                if (hl < m.J) { v3 da = b.gravity_a0() - b.spd_a0(); st3(s.aj[hl], ld3(s.aj[hl]) + da); }
+                sync();
+            } else b.kinematics(s.pose, s.vel, ph == 0 ? b.spd_a0() : b.gravity_a0());
+            b.mark(ph == 0 ? 1 : 5);
+            dynamics(ph == 0 ? 0 : 1, ph == 0 ? rdt : (Real)0);
+            b.mark(ph == 0 ? 2 : 6);
+            if (ph == 0) {
+                b.spd_rhs_pre(rdt);
+                for (int k = hl; k < D; k += HW) s.rhs[k] = s.xs[k] - s.bias[k];
+                sync();
+            } else { for (int k = hl; k < D; k += HW) s.rhs[k] = s.tau[k] - s.bias[k]; sync(); }
+            DM_OPAQUE_V(hl); DM_OPAQUE_V(b.l);
+            chol_solve(s.rhs);
+            DM_OPAQUE_V(hl); DM_OPAQUE_V(b.l); DM_OPAQUE_V(b.li);
+            if (ph == 0) {
+                b.mark(3);
+                for (int k = hl; k < D; k += HW) s.tau[k] = (k < 6) ? (Real)0 : s.xs[k] - s.mdl.kd[k] * rdt * s.rhs[k];
+                sync();
+                b.spd_clamp();
+            } else if (!substep_post(h)) {
+                // more than 32 rows somewhere in the pair: one character at a time through the 64-lane routine
+                for (int x = 0; x < 2; ++x) {
+                    int wlv = wl; DM_OPAQUE_V(wlv);          // keeps this rare path's address arithmetic out of the hot loop's live ranges
+                    Single one(m, rec[x], wlv);
+                    one.li = (wlv < m.J) ? rec[x].mdl.link_info[wlv] : 0;
+                    one.load_cands();
+                    DebugTaps<Real> none = DebugTaps<Real>();
+                    one.substep_post(h, none, e, aovf_pair ? aovf_pair + (size_t)x * (kMaxRows - C::RREG) * kWave : nullptr);
+                }
+            }
+        }
+        if (hl == 0) {
+            double cur = s.clk[CLK_CTRL] + s.clk[CLK_INIT_OFF], pad = 0.001 * dt;
+            int c1 = (int)floor((cur + pad) / m.query_period), c0 = (int)floor((cur + pad - dt) / m.query_period);
+            s.flg[FLG_NEED_ACTION] = (c1 != c0) ? 1 : 0;
+        }
+        sync();
+    }
+};
+
+// grid = N / 2 workgroups of one wavefront; character e = 2 * blockIdx.x + (lane >> 5).  fp32: 2 waves / SIMD (20 KB LDS).
+template <typename Real> struct DuoWaves { static constexpr int value = 1; };
+template <> struct DuoWaves<float> { static constexpr int value = 2; };
+template <typename Real, bool TAPS>
+__global__ void __launch_bounds__(64) DM_WAVES_PER_EU((DuoWaves<Real>::value)) k_env_step_duo(ModelDev<Real> m, EnvState<Real> st, StepIO<Real> io, DebugTaps<Real> dbg) {
+    __shared__ Lds<Real, ClsBiped> lds[2];
+    const int wl = threadIdx.x, half = wl >> 5;
+    const int e = 2 * blockIdx.x + half;
+    DuoSim<Real, TAPS> sim(m, lds, wl);
+    if (TAPS && dbg.prof) { sim.b.prof = dbg.prof + (size_t)e * 16; sim.b.tprev = dm_clock(); }
+    sim.load(st, e);
+    if (io.open_loop) sim.b.set_action_from_clip();
+    else if (io.actions) sim.b.set_action(io.actions + (size_t)e * m.A);
+    sim.b.mark(15);
+    Real* aovf_pair = st.aovf ? st.aovf + (size_t)(2 * blockIdx.x) * (kMaxRows - ClsBiped::RREG) * kWave : nullptr;
+    for (int u = 0; u < io.n_updates; ++u) sim.update(io.dt, e, aovf_pair);
+    if (io.emit) {
+        DebugTaps<Real> tap = DebugTaps<Real>();
+        sim.b.emit(io, tap, e, true);
+        const bool ended = lds[half].sc[6] != (Real)0;
+        if (io.auto_reset && ended) {                    // per character; no cross-half traffic inside
+            uint64_t ep = (uint64_t)lds[half].flg[FLG_EPISODE];
+            double kt = m.duration * dm_rand01(m.seed, (uint64_t)(e + m.env_off), ep, 0);
+            double mt = (m.time_lim_max > m.time_lim_min) ? m.time_lim_min + (m.time_lim_max - m.time_lim_min) * dm_rand01(m.seed, (uint64_t)(e + m.env_off), ep, 1) : m.time_lim_max;
+            sim.b.reset_env(kt, mt);
+            sim.b.emit(io, tap, e, false);
+        }
+        sim.b.mark(13);
+    }
+    sim.b.store(st, e);
+    sim.b.mark(14);
+}
+
+}  // namespace dmk

@@ -25,7 +25,7 @@
 #include <vector>
 
 #include "../../include/dm_hip.h"
-#include "dm_device.h"
+#include "dm_device_duo.h"
 
 using namespace dmk;
 
@@ -237,6 +237,7 @@ struct CtxBase {
     rt_stream own_stream = 0, stream = 0;
     std::vector<void*> allocs;
     float *d_actions = nullptr, *d_states = nullptr, *d_rewards = nullptr; int *d_term = nullptr, *d_valid = nullptr, *d_end = nullptr;
+    bool duo = false;
     virtual ~CtxBase() { for (void* p : allocs) rt_free(p); }
     void* dalloc(size_t n) { void* p = nullptr; if (rt_malloc(&p, n) != 0) return nullptr; allocs.push_back(p); return p; }
     virtual int setup() = 0;
@@ -355,6 +356,11 @@ struct CtxT : CtxBase {
         StepIO<Real> io; memset(&io, 0, sizeof(io));
         io.actions = actions_dev; io.states = states; io.rewards = rewards; io.terminate = term; io.valid = valid; io.episode_end = end;
         io.n_updates = n_updates; io.dt = dt; io.auto_reset = (flags & DM_AUTO_RESET) ? 1 : 0; io.emit = (flags & DM_NO_EMIT) ? 0 : 1; io.open_loop = (flags & DM_OPEN_LOOP) ? 1 : 0;
+        // two characters per wavefront: biped class, even batch, no debug taps armed (DM_DUO=0 keeps one character per wave)
+        if (duo && cls == 0 && (N % 2) == 0 && !dbg.H) {
+            RT_LAUNCH((k_env_step_duo<Real, false>), N / 2, stream, md, st, io, dbg);
+            return 0;
+        }
         // production launch: the tap-free instantiation unless a parity test armed the debug taps (dm_probe)
         if (dbg.H) { if (cls == 0) RT_LAUNCH((k_env_step<Real, ClsBiped, true>), N, stream, md, st, io, dbg); else RT_LAUNCH((k_env_step<Real, ClsLarge, true>), N, stream, md, st, io, dbg); }
         else { if (cls == 0) RT_LAUNCH((k_env_step<Real, ClsBiped, false>), N, stream, md, st, io, dbg); else RT_LAUNCH((k_env_step<Real, ClsLarge, false>), N, stream, md, st, io, dbg); }
@@ -374,7 +380,8 @@ struct CtxT : CtxBase {
             StepIO<Real> io; memset(&io, 0, sizeof(io));
             io.states = d_states; io.rewards = d_rewards; io.terminate = d_term; io.valid = d_valid; io.episode_end = d_end;
             io.n_updates = 20; io.dt = dt; io.auto_reset = 1; io.emit = 1; io.open_loop = 1;
-            if (cls == 0) RT_LAUNCH((k_env_step<Real, ClsBiped, true>), N, stream, md, st, io, d2); else RT_LAUNCH((k_env_step<Real, ClsLarge, true>), N, stream, md, st, io, d2);
+            if (duo && cls == 0 && (N % 2) == 0) RT_LAUNCH((k_env_step_duo<Real, true>), N / 2, stream, md, st, io, d2);
+            else if (cls == 0) RT_LAUNCH((k_env_step<Real, ClsBiped, true>), N, stream, md, st, io, d2); else RT_LAUNCH((k_env_step<Real, ClsLarge, true>), N, stream, md, st, io, d2);
             return 0;
         }
         DM_DISPATCH(k_env_probe, N, md, st, dbg, what, dt);
@@ -459,6 +466,8 @@ int dm_create(const dm_create_info* info, const dm_scene_tables* tables, dm_ctx*
     if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) { delete c; return fail("hipStreamCreate failed"); }
     c->stream = c->own_stream;
 #endif
+    if (info->wave_packing != 0 && info->wave_packing != 1 && info->wave_packing != 2) { delete c; return fail("wave_packing must be 0, 1 or 2"); }
+    { const char* dv = getenv("DM_DUO"); c->duo = info->wave_packing == 2 || (info->wave_packing == 0 && dv && dv[0] == '1'); }
     if (c->setup() != 0) { delete c; return -1; }
     dm_ctx* ctx = new dm_ctx(); ctx->c = c; *out = ctx;
     return dm_reset(ctx, nullptr, 0, nullptr, nullptr);

@@ -195,3 +195,35 @@ def rollout_compare(name, precision, lib_path, steps, t0=0.0, open_loop_on_devic
         ds.append(np.abs(out["state"][0] - o.record_state()).max())
         flags_ok &= (int(out["terminate"][0]) == o.check_terminate()) and (int(out["valid"][0]) == int(o.check_valid_episode()))
     return np.array(dr), np.array(ds), flags_ok
+
+
+def batch_rollout_compare(name, precision, lib_path, steps, t0s, wave_packing=0, lifts=None):
+    """Free-running open-loop rollout of len(t0s) envs in one batch (no debug taps armed, so the production step kernel of
+    the requested wave packing runs); every env is compared with its own oracle.  Returns per-env max |reward diff|, max
+    |state diff| and whether every terminate / valid flag agreed."""
+    t = model.load_asset(name)
+    n = len(t0s)
+    env = BatchEnv(t, n, precision=precision, lib_path=lib_path, wave_packing=wave_packing)
+    env.reset(kin_times=np.array(t0s, dtype=np.float64), max_times=np.inf)
+    oracles = []
+    for e, t0 in enumerate(t0s):
+        o = Oracle(t); o.reset(t0); oracles.append(o)
+    if lifts is not None:                      # push some characters into the ground: many contacts (> 32 rows)
+        st = env.get_state()
+        pose = st["pose"].copy()
+        for e, o in enumerate(oracles):
+            pose[e, 1] += lifts[e]
+            p, v = o.sim_state(); p[1] += lifts[e]; o.set_sim_state(p, v)
+        env.set_state(pose=pose)
+    dr, ds, ok = np.zeros(n), np.zeros(n), True
+    for k in range(steps):
+        out = env.step(None, DT, 20, open_loop=True)
+        for e, o in enumerate(oracles):
+            kp, _, _ = o.kin_state()
+            o.set_action(o.pose_to_action(kp))
+            for u in range(20):
+                o.update(DT)
+            dr[e] = max(dr[e], abs(float(out["reward"][e]) - o.calc_reward()))
+            ds[e] = max(ds[e], np.abs(out["state"][e] - o.record_state()).max())
+            ok &= int(out["terminate"][e]) == o.check_terminate() and int(out["valid"][e]) == int(o.check_valid_episode())
+    return dr, ds, ok

@@ -57,3 +57,22 @@ def test_open_loop_path_equals_action_path(emu_lib):
 def test_stepwise_resync_spinkick_fp64(emu_lib):
     dr, ds, ok = pc.rollout_compare("humanoid3d_spinkick", 64, emu_lib, steps=30, resync=True)
     assert ok and dr.max() < 1e-6 and ds.max() < 1e-4
+
+
+# ---- two characters per wavefront (dm_device_duo.h)
+def test_duo_rollout_fp64_matches_oracle(emu_lib):
+    dr, ds, ok = pc.batch_rollout_compare("humanoid3d_walk", 64, emu_lib, steps=6, t0s=[0.0, 0.37, 0.8, 0.11], wave_packing=2)
+    assert ok and dr.max() < 1e-6 and ds.max() < 1e-5
+
+
+def test_duo_heavy_contact_fallback_fp64(emu_lib):
+    """one character of each pair pressed 30 cm into the ground (> 32 constraint rows): the pair runs the 64-lane routine"""
+    dr, ds, ok = pc.batch_rollout_compare("humanoid3d_walk", 64, emu_lib, steps=2, t0s=[0.0, 0.4, 0.2, 0.6], wave_packing=2,
+                                          lifts=[-0.3, 0.0, 0.0, -0.25])
+    assert dr.max() < 1e-6 and ds.max() < 1e-4
+
+
+def test_duo_matches_single_packing_fp32(emu_lib):
+    d1 = pc.batch_rollout_compare("humanoid3d_walk", 32, emu_lib, steps=4, t0s=[0.05, 0.5], wave_packing=1)
+    d2 = pc.batch_rollout_compare("humanoid3d_walk", 32, emu_lib, steps=4, t0s=[0.05, 0.5], wave_packing=2)
+    assert d1[2] and d2[2] and d1[0].max() < 1e-4 and d2[0].max() < 1e-4

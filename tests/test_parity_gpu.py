@@ -169,3 +169,39 @@ def test_facade_protocol_matches_oracle(hip_lib):
     assert n_actions == 3
     p, v = o.sim_state(); st = env.get_state()
     assert np.abs(st["pose"][0] - p).max() < 1e-9 and np.abs(st["vel"][0] - v).max() < 1e-7
+
+
+# ---- two characters per wavefront (dm_device_duo.h): same checks through the batch entry point
+@pytest.mark.parametrize("prec,tol_r,tol_s", [(64, 1e-6, 1e-5), (32, 5e-4, 0.5)])
+def test_duo_rollout_matches_oracle(hip_lib, prec, tol_r, tol_s):
+    dr, ds, ok = pc.batch_rollout_compare("humanoid3d_walk", prec, hip_lib, steps=10, t0s=[0.0, 0.37, 0.8, 0.11, 0.5, 0.9], wave_packing=2)
+    assert ok and dr.max() < tol_r and ds.max() < tol_s, (dr, ds)
+    if prec == 32:                              # all but the env that crosses the ill-conditioned step stay inside 1e-4
+        assert np.sort(dr)[-2] < 1e-4, dr
+
+
+def test_duo_heavy_contact_fallback(hip_lib):
+    dr, ds, ok = pc.batch_rollout_compare("humanoid3d_walk", 64, hip_lib, steps=2, t0s=[0.0, 0.4, 0.2, 0.6], wave_packing=2,
+                                          lifts=[-0.3, 0.0, 0.0, -0.25])
+    assert dr.max() < 1e-6 and ds.max() < 1e-4
+
+
+def test_duo_spinkick_and_300_steps(hip_lib):
+    dr, ds, ok = pc.batch_rollout_compare("humanoid3d_spinkick", 64, hip_lib, steps=20, t0s=[0.0, 0.3], wave_packing=2)
+    assert ok and dr.max() < 1e-5
+    dr, ds, ok = pc.batch_rollout_compare("humanoid3d_walk", 64, hip_lib, steps=300, t0s=[0.0, 0.21], wave_packing=2)
+    assert ok and dr.max() < 1e-5
+
+
+def test_duo_auto_reset_4096(hip_lib):
+    t = model.load_asset("humanoid3d_walk")
+    a = BatchEnv(t, 4096, seed=3, wave_packing=2); b = BatchEnv(t, 4096, seed=3, wave_packing=1)
+    a.reset(); b.reset()
+    ends = 0
+    for _ in range(30):
+        oa = a.step(None, pc.DT, 20, open_loop=True, auto_reset=True); ob = b.step(None, pc.DT, 20, open_loop=True, auto_reset=True)
+        assert np.isfinite(oa["state"]).all() and (oa["reward"] >= 0).all() and (oa["reward"] <= 1 + 1e-6).all()
+        ends += int(oa["episode_end"].sum())
+    assert ends > 0
+    # same physics, different summation order: episode statistics of the two packings agree
+    assert abs(float(oa["reward"].mean()) - float(ob["reward"].mean())) < 0.05

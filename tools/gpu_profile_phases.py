@@ -10,7 +10,7 @@ PH = ["kin_update+latch", "spd.kinematics", "spd.dynamics", "spd.chol+solve", "s
       "sub.chol+solve+vstar", "sub.collision", "sub.rows(J,Y)", "sub.A", "sub.PGS", "sub.backsolve+integrate", "emit(+reset)", "store", "load+action"]
 name = sys.argv[1] if len(sys.argv) > 1 else "humanoid3d_walk"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
-env = BatchEnv(model.load_asset(name), n, seed=1, test_mode=True)
+env = BatchEnv(model.load_asset(name), n, seed=1, test_mode=True, wave_packing=int(os.environ.get('PACK', '0')))
 env.reset()
 for _ in range(10):
     env.step(None, 1 / 600, 20, open_loop=True, auto_reset=True)

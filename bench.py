@@ -79,6 +79,7 @@ def main():
     ap.add_argument("--envs", type=int, default=4096, help="envs per GPU")
     ap.add_argument("--scene", default="humanoid3d_walk")
     ap.add_argument("--precision", type=int, default=32)
+    ap.add_argument("--wave-packing", type=int, default=2, help="characters per wavefront of the step kernel (1 or 2; 2 needs the biped class)")
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -99,7 +100,8 @@ def main():
 
     tables = model.load_asset(args.scene)
     n = args.envs
-    env = BatchEnv(tables, n, device_id=local_rank, seed=1234, precision=args.precision, env_id_offset=rank * n, test_mode=True)
+    env = BatchEnv(tables, n, device_id=local_rank, seed=1234, precision=args.precision, env_id_offset=rank * n, test_mode=True,
+                   wave_packing=args.wave_packing)
     env.set_stream(torch.cuda.current_stream().cuda_stream)
     env.reset()                                                   # per-env random phase, keyed by the global env id
     dev = torch.device("cuda", local_rank)
@@ -157,10 +159,10 @@ def main():
             "vs_baseline": None, "dtype": "f32" if args.precision == 32 else "f64", "data": "synthetic",
             "config": {"workload": "%s, %d envs per GPU, fixed-action (open-loop mocap tracking) rollout, auto-reset, "
                                    "20 updates of 1/600 s x 2 substeps per step" % (args.scene, n),
-                       "envs_per_gpu": n, "parallelism": "env-shards x%d%s" % (world, " + RCCL all-gather of obs" if gather else "")},
+                       "envs_per_gpu": n, "wave_packing": args.wave_packing, "parallelism": "env-shards x%d%s" % (world, " + RCCL all-gather of obs" if gather else "")},
             "sim_updates_per_s": value * 20,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": measured_traffic(args.scene, n), "kernel": "k_env_step", "kernel_ms": kernel_ms,
+                         "traffic": measured_traffic(args.scene, n), "kernel": "k_env_step_duo" if (args.wave_packing == 2 and env.J <= 15) else "k_env_step", "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_env_step": algorithmic_bytes_per_env_step(env),
                          "algorithmic_bytes_per_launch": bytes_per_launch,
                          "note": "VALU-issue bound by construction (SURVEY 8d, DESIGN.md 6): the env record stays in LDS/VGPRs for "

@@ -408,15 +408,23 @@ struct EnvSim {
         }
         v3 Lq = Lp + cross(ld3(s.p[dj]) - ld3(s.p[0]), Pm);
         Real* row = &s.Lt[L::lrow(k)];
-        for (int j = 0; j <= k; ++j) row[j] = 0;
+        {   // zero the row with 16-B stores (rows are padded to a multiple of 4)
+            const R4 z4 = {(Real)0, (Real)0, (Real)0, (Real)0};
+            for (int j = 0; j <= k; j += 4) *reinterpret_cast<R4*>(&row[j]) = z4;
+        }
         uint32_t lo = s.mdl.anc_lo[k], hi = s.mdl.anc_hi[k];
+        // two ancestors per trip: both record gathers are in flight before either is consumed
         while (lo | hi) {
-            int j;
-            if (lo) { j = dm_ctz32(lo); lo &= lo - 1; } else { j = 32 + dm_ctz32(hi); hi &= hi - 1; }
-            const Real* rec = s.dofrec[j];
-            Real val = rec[0] * Lq.x + rec[1] * Lq.y + rec[2] * Lq.z + rec[3] * Pm.x + rec[4] * Pm.y + rec[5] * Pm.z;
-            if (j == k) val += diag_scale * s.mdl.kd[k];
-            row[j] = val;
+            int j0, j1 = -1;
+            if (lo) { j0 = dm_ctz32(lo); lo &= lo - 1; } else { j0 = 32 + dm_ctz32(hi); hi &= hi - 1; }
+            if (lo | hi) { if (lo) { j1 = dm_ctz32(lo); lo &= lo - 1; } else { j1 = 32 + dm_ctz32(hi); hi &= hi - 1; } }
+            const Real* r0 = s.dofrec[j0]; const Real* r1 = s.dofrec[j1 < 0 ? j0 : j1];
+            Real v0 = r0[0] * Lq.x + r0[1] * Lq.y + r0[2] * Lq.z + r0[3] * Pm.x + r0[4] * Pm.y + r0[5] * Pm.z;
+            Real v1 = r1[0] * Lq.x + r1[1] * Lq.y + r1[2] * Lq.z + r1[3] * Pm.x + r1[4] * Pm.y + r1[5] * Pm.z;
+            if (j0 == k) v0 += diag_scale * s.mdl.kd[k];
+            if (j1 == k) v1 += diag_scale * s.mdl.kd[k];
+            row[j0] = v0;
+            if (j1 >= 0) row[j1] = v1;
         }
     }
 
@@ -680,10 +688,11 @@ struct EnvSim {
                 const bool on = (((k < 32) ? ch_lo : ch_hi) >> (k & 31)) & 1u;
                 const Real raw = on ? val : (Real)0;
                 cvec += raw * r1[2];
-                R2 acc2 = {(Real)0, (Real)0};
+                R2 acc2 = {(Real)0, (Real)0}, acc3 = acc2;      // two independent accumulation chains
                 const R2* lrow = reinterpret_cast<const R2*>(&s.Lt[L::lrow(k)]);
 #pragma unroll
-                for (int p = 0; p < (k >> 1); ++p) acc2 += lrow[p] * y2[p];
+                for (int p = 0; p < (k >> 1); ++p) { if (p & 1) acc3 += lrow[p] * y2[p]; else acc2 += lrow[p] * y2[p]; }
+                acc2 += acc3;
                 Real acc = raw - (acc2[0] + acc2[1]);
                 if (k & 1) acc -= s.Lt[L::lrow(k) + k - 1] * y2[k >> 1][0];
                 yk = acc * s.Lt[L::lrow(k) + k];

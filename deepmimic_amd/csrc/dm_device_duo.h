@@ -312,10 +312,11 @@ struct DuoSim {
                 const bool on = (((k < 32) ? ch_lo : ch_hi) >> (k & 31)) & 1u;
                 const Real raw = on ? val : (Real)0;
                 cvec += raw * r1[2];
-                R2 acc2 = {(Real)0, (Real)0};
+                R2 acc2 = {(Real)0, (Real)0}, acc3 = acc2;      // two independent accumulation chains
                 const R2* lrow = reinterpret_cast<const R2*>(&s.Lt[L::lrow(k)]);
 #pragma unroll
-                for (int p = 0; p < (k >> 1); ++p) acc2 += lrow[p] * y2[p];
+                for (int p = 0; p < (k >> 1); ++p) { if (p & 1) acc3 += lrow[p] * y2[p]; else acc2 += lrow[p] * y2[p]; }
+                acc2 += acc3;
                 Real acc = raw - (acc2[0] + acc2[1]);
                 if (k & 1) acc -= s.Lt[L::lrow(k) + k - 1] * y2[k >> 1][0];
                 yk = acc * s.Lt[L::lrow(k) + k];

@@ -205,3 +205,22 @@ def test_duo_auto_reset_4096(hip_lib):
     assert ends > 0
     # same physics, different summation order: episode statistics of the two packings agree
     assert abs(float(oa["reward"].mean()) - float(ob["reward"].mean())) < 0.05
+
+
+def test_duo_fp32_300_steps_reward_tolerance(hip_lib):
+    """the headline configuration of bench.py (wave_packing = 2, fp32): same bound as the one-character-per-wave kernel"""
+    t = model.load_asset("humanoid3d_walk")
+    env = BatchEnv(t, 2, precision=32, wave_packing=2)
+    env.reset(kin_times=[0.0, 0.0], max_times=np.inf)
+    o = Oracle(t); o.reset(0.0)
+    dr = []
+    for k in range(300):
+        out = env.step(None, pc.DT, 20, open_loop=True)
+        kp, _, _ = o.kin_state(); o.set_action(o.pose_to_action(kp))
+        for u in range(20):
+            o.update(pc.DT)
+        dr.append(max(abs(float(out["reward"][e]) - o.calc_reward()) for e in range(2)))
+        assert int(out["terminate"][0]) == o.check_terminate() == int(out["terminate"][1])
+    dr = np.array(dr)
+    floor = pc.fp32_free_running_sensitivity("humanoid3d_walk", 40).max()
+    assert dr.mean() < 1e-5 and dr.max() < max(1e-4, 4 * floor), (dr.mean(), dr.max(), floor)

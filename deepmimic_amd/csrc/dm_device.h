@@ -855,21 +855,42 @@ struct EnvSim {
         }
         sync();
     }
-    // cSceneImitate::UpdateKinChar: advance the clip clock, snap the origin on phase wrap
+    // root rotation of the kin character at `time`, every lane (cKinCharacter::CalcPose root slot)
+    DM_DEV q4 kin_root_rot(double time) const {
+        int idx, cyc; double blend; kin_index_blend(time, idx, blend, cyc);
+        Real b = (Real)(blend < 0 ? 0 : (blend > 1 ? 1 : blend));
+        const Real* f0 = m.frames + (size_t)idx * m.P; const Real* f1 = f0 + m.P;
+        q4 rr = qnormalize(qslerp(ldq(f0 + 3), b, ldq(f1 + 3), m.slerp_one));
+        return qstandardize(qmul(ldq(s.kin + 3), rr));
+    }
+    // cKinCharacter::RotateOrigin about the kin root position rp by the heading difference dh (rotation about +y); lane 0
+    DM_DEV void kin_rotate_origin(Real dh, v3 rp) {
+        Real sh, ch; dm_sincos((Real)0.5 * dh, sh, ch);
+        q4 drot = mkq(ch, (Real)0, sh, (Real)0);
+        stq(s.kin + 3, qnormalize(qmul(drot, ldq(s.kin + 3))));
+        st3(s.kin, rp + qrot(drot, ld3(s.kin) - rp));
+    }
+    // cSceneImitate::UpdateKinChar: advance the clip clock; on phase wrap SyncKinCharNewCycle (SceneImitate.cpp:420-444)
+    // turns the kin character to the sim heading (sync_char_root_rot) and snaps its root x, z to the sim root (sync_char_root_pos)
     DM_DEV void kin_update(double dt) {
         DM_OPAQUE_V(l);
         double t0 = s.clk[CLK_KIN], t1 = t0 + dt;
         double ph0 = kin_phase(t0), ph1 = kin_phase(t1);
         sync();
         if (l == 0) s.clk[CLK_KIN] = t1;
-        if (ph1 < ph0 && m.sync_root_pos) {
+        if (ph1 < ph0 && (m.sync_root_pos || m.sync_root_rot)) {
             v3 kr = kin_root_pos(t1);
+            Real dh = 0;
+            if (m.sync_root_rot) dh = calc_heading(ldq(s.pose + 3)) - calc_heading(kin_root_rot(t1));
             if (l == 0) {
-                v3 sp = ld3(s.pose);
-                Real dh = kr.y - s.kin[1];
-                v3 target = mk3(sp.x, (Real)0 + dh, sp.z);
-                v3 delta = target - kr;
-                s.kin[0] += delta.x; s.kin[1] += delta.y; s.kin[2] += delta.z;
+                if (m.sync_root_rot) kin_rotate_origin(dh, kr);          // rotation about the root: kr itself does not move
+                if (m.sync_root_pos) {
+                    v3 sp = ld3(s.pose);
+                    Real hgt = kr.y - s.kin[1];
+                    v3 target = mk3(sp.x, (Real)0 + hgt, sp.z);
+                    v3 delta = target - kr;
+                    s.kin[0] += delta.x; s.kin[1] += delta.y; s.kin[2] += delta.z;
+                }
             }
         }
         sync();
@@ -1128,7 +1149,8 @@ struct EnvSim {
         if (l == 0) {
             Real mv = 0; for (int j = 0; j < m.J; ++j) mv = dm_min(mv, red[j]);
             if (mv < 0) s.pose[1] += -mv;
-            // SyncKinCharRoot: kin root := sim root (moves the origin)
+            // SyncKinCharRoot (SceneImitate.cpp:401-418): kin heading := sim heading (sync_char_root_rot), kin root := sim root
+            if (m.sync_root_rot) kin_rotate_origin(calc_heading(ldq(s.pose + 3)) - calc_heading(ldq(kp + 3)), ld3(kp));
             for (int k = 0; k < 3; ++k) s.kin[k] += s.pose[k] - kp[k];
         }
         sync();

@@ -446,7 +446,6 @@ const char* dm_last_error(void) { return g_err.c_str(); }
 int dm_create(const dm_create_info* info, const dm_scene_tables* tables, dm_ctx** out) {
     if (!info || !tables || !out) return fail("null argument");
     if (info->num_envs < 1) return fail("num_envs must be >= 1");
-    if (tables->sync_char_root_rot) return fail("sync_char_root_rot is not supported on the accelerated path");
     if (tables->enable_rand_rot_reset) return fail("enable_rand_rot_reset is not supported on the accelerated path");
     if (tables->num_sim_substeps < 1) return fail("num_sim_substeps must be >= 1");
     int precision = info->precision ? info->precision : 32;

@@ -19,10 +19,11 @@ from deepmimic_amd import model  # noqa: E402
 from oracle_lib import Oracle  # noqa: E402
 
 CASES = [("humanoid3d_walk", 0.0), ("humanoid3d_walk", 0.37), ("humanoid3d_spinkick", 0.0), ("dog3d_pace", 0.2),
-         ("humanoid3d_run", 0.1), ("humanoid3d_backflip", 0.0)]
+         ("humanoid3d_run", 0.1), ("humanoid3d_backflip", 0.0), ("dog3d_spin", 0.5)]
 
 
 def one_case(name, t0, steps=10):
+    steps = 30 if name == "dog3d_spin" else steps      # long enough to cross a phase wrap (root heading sync)
     t = model.load_asset(name)
     o = Oracle(t)
     o.reset(t0)

@@ -177,7 +177,8 @@ def test_oracle_matches_committed_golden_vectors(oracle_built, case):
 @pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "data")), reason="reference checkout not present")
 @pytest.mark.parametrize("name,argfile", [("humanoid3d_walk", "args/run_humanoid3d_walk_args.txt"),
                                           ("humanoid3d_spinkick", "args/run_humanoid3d_spinkick_args.txt"),
-                                          ("dog3d_pace", "args/run_dog3d_pace_args.txt")])
+                                          ("dog3d_pace", "args/run_dog3d_pace_args.txt"),
+                                          ("dog3d_spin", "args/run_dog3d_spin_args.txt")])
 def test_compiled_assets_equal_the_reference_data_files(name, argfile):
     """deepmimic_amd/assets/*.json are byte-for-value compilations of the reference's data/ + args/ files."""
     a = model.load_asset(name)

@@ -76,3 +76,10 @@ def test_duo_matches_single_packing_fp32(emu_lib):
     d1 = pc.batch_rollout_compare("humanoid3d_walk", 32, emu_lib, steps=4, t0s=[0.05, 0.5], wave_packing=1)
     d2 = pc.batch_rollout_compare("humanoid3d_walk", 32, emu_lib, steps=4, t0s=[0.05, 0.5], wave_packing=2)
     assert d1[2] and d2[2] and d1[0].max() < 1e-4 and d2[0].max() < 1e-4
+
+
+def test_root_heading_sync_dog_spin_fp64(emu_lib):
+    """args/run_dog3d_spin_args.txt: sync_char_root_rot = true (SyncKinCharRoot at reset, SyncKinCharNewCycle on phase wrap)"""
+    pc.check_reset_and_query("dog3d_spin", 64, emu_lib, tol_state=1e-12, tol_reward=1e-6)
+    dr, ds, ok = pc.rollout_compare("dog3d_spin", 64, emu_lib, steps=30)      # clip = 0.73 s: one wrap
+    assert ok and dr.max() < 1e-6 and ds.max() < 1e-4

@@ -224,3 +224,12 @@ def test_duo_fp32_300_steps_reward_tolerance(hip_lib):
     dr = np.array(dr)
     floor = pc.fp32_free_running_sensitivity("humanoid3d_walk", 40).max()
     assert dr.mean() < 1e-5 and dr.max() < max(1e-4, 4 * floor), (dr.mean(), dr.max(), floor)
+
+
+@pytest.mark.parametrize("prec,tol", [(64, 1e-6), (32, 1e-4)])
+def test_root_heading_sync_dog_spin(hip_lib, prec, tol):
+    """sync_char_root_rot = true (args/run_dog3d_spin_args.txt): 60 control steps = three phase wraps"""
+    if prec == 64:
+        pc.check_reset_and_query("dog3d_spin", 64, hip_lib, tol_state=1e-12, tol_reward=1e-6)
+    dr, ds, ok = pc.rollout_compare("dog3d_spin", prec, hip_lib, steps=60)
+    assert ok and dr.max() < tol, (dr.mean(), dr.max())

@@ -18,6 +18,7 @@ SCENES = {
     "dog3d_pace": ("args/train_dog3d_pace_args.txt", None),
     "humanoid3d_run": ("args/run_humanoid3d_run_args.txt", None),
     "humanoid3d_backflip": ("args/run_humanoid3d_backflip_args.txt", None),
+    "dog3d_spin": ("args/run_dog3d_spin_args.txt", None),          # sync_char_root_rot = true
 }
 
 def main():

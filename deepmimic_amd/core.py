@@ -35,6 +35,7 @@ class _SceneTables(C.Structure):
         ("enable_rand_rot_reset", C.c_int), ("time_lim_min", C.c_double), ("time_lim_max", C.c_double),
         ("enable_phase_input", C.c_int), ("record_world_root_pos", C.c_int), ("record_world_root_rot", C.c_int),
         ("query_rate", C.c_double), ("friction", C.c_double), ("erp", C.c_double), ("solver_iters", C.c_int),
+        ("disable_self_collision", C.c_int),
     ]
 
 
@@ -74,7 +75,8 @@ class BatchEnv:
 
     def __init__(self, tables: SceneTables, num_envs: int = 1, device_id: int = 0, seed: int = 0,
                  precision: int = 32, max_contacts: int = 20, env_id_offset: int = 0,
-                 test_mode: bool = False, lib_path: Optional[str] = None, wave_packing: int = 0):
+                 test_mode: bool = False, lib_path: Optional[str] = None, wave_packing: int = 0, self_collision: bool = True,
+                 erp: float = 0.0):
         self.lib = load_library(lib_path)
         self.tables = tables
         c = tables.cfg
@@ -103,7 +105,8 @@ class BatchEnv:
         st.time_lim_min, st.time_lim_max = tmin, tmax
         st.enable_phase_input = int(tables.enable_phase_input); st.record_world_root_pos = int(tables.record_world_root_pos)
         st.record_world_root_rot = int(tables.record_world_root_rot); st.query_rate = float(tables.query_rate)
-        st.friction = 0.0; st.erp = 0.0; st.solver_iters = 0
+        st.friction = 0.0; st.erp = float(erp); st.solver_iters = 0
+        st.disable_self_collision = 0 if self_collision else 1
         info = _CreateInfo(int(num_envs), int(device_id), int(seed) & (2 ** 64 - 1), int(precision), int(max_contacts), int(env_id_offset), int(wave_packing))
         self.h = C.c_void_p()
         self._chk(self.lib.dm_create(C.byref(info), C.byref(st), C.byref(self.h)))

@@ -201,13 +201,14 @@ struct Lds {
     static constexpr int kLWords = lrow(ND);
     MdlLds<Real, C> mdl;
     Real pose[NP], vel[NP], tar[NP];
-    Real tau[ND], bias[ND], rhs[ND], xs[ND];
-    alignas(32) Real dofrec[ND][8];        // per dof: world axis a(3), g = (p_joint - p_root) x a (3), unconstrained velocity v*, pad
+    Real tau[ND], rhs[ND];                 // (bias force: dofrec[k][7]; SPD force xs: aliases Ic, see EnvSim::xs)
+    alignas(32) Real dofrec[ND][8];        // per dof: world axis a(3), g = (p_joint - p_root) x a (3), unconstrained velocity v*, bias force C
     Real R[NJ][9], p[NJ][3], com[NJ][3], w[NJ][3], vj[NJ][3], al[NJ][3], aj[NJ][3];
     Real Rb[C::ROT ? NJ : 1][C::ROT ? 9 : 1];   // body frames (== R when the class has no attach rotations)
     union alignas(32) {
         struct { Real f[NJ][3], n[NJ][3], Iw[NJ][6], Fs[NJ][3], Ns[NJ][3], Ic[NJ][10]; };   // Newton-Euler pass (dynamics)
-        struct { Real cx[NCAP][3], cdist[NCAP]; int csel[NCAP], cslot[kMaxRows]; };          // ground contacts (after dynamics)
+        struct { int csel[NCAP]; Real cdistc[NCAP];                                          // manifold-reduction scratch (by candidate)
+                 Real ct[kMaxContacts][8]; };                                                // contact slots: x(3), n(3), dist, links a | b << 8 (b = 255: ground)
     };
     alignas(32) Real Lt[kLWords];
     Real kin[8];                           // kin origin pos(3), origin rot(4)
@@ -231,12 +232,15 @@ struct EnvSim {
     const ModelDev<Real>& m; L& s; int l;
     int li = 0;                                         // link_info word of this lane's link (0 for lanes >= J)
     int cand_link[CPL]; Real cand_loc[CPL][3], cand_rad[CPL];   // this lane's ground-contact candidates
+    static constexpr int PPL = C::NPAIRCAP / kWave;             // self-collision pairs per lane
+    int pair_code[PPL];
     long long* prof = nullptr; long long tprev = 0;     // phase-cycle accounting (profiling kernel only)
     DM_DEV EnvSim(const ModelDev<Real>& m_, L& s_, int l_) : m(m_), s(s_), l(l_) {}
     DM_DEV void mark(int phase) { if (TAPS && prof) { long long t = dm_clock(); if (l == 0) prof[phase] += t - tprev; tprev = t; } }
     DM_DEV void sync() const { __syncthreads(); }
     DM_DEV Real* scratch() const { return &s.Lt[0]; }   // L is dead outside the update loop: kin pose / vel / reductions live there
     DM_DEV Real& Lx(int r, int c) const { return s.Lt[L::lrow(r) + c]; }
+    DM_DEV Real* xs() const { return &s.Ic[0][0]; }     // SPD joint forces Kp e + Kd e_v: alive from spd_rhs_pre to spd_post, while Ic is dead
     DM_DEV const Real* Rbp(int j) const { return C::ROT ? s.Rb[j] : s.R[j]; }
     static DM_DEV v3 zero3() { return mk3((Real)0, (Real)0, (Real)0); }
 
@@ -248,6 +252,8 @@ struct EnvSim {
             cand_link[q] = 0; cand_rad[q] = 0; cand_loc[q][0] = cand_loc[q][1] = cand_loc[q][2] = 0;
             if (c < m.NC) { cand_link[q] = m.cand_link[c]; cand_rad[q] = m.cand_rad[c]; for (int k = 0; k < 3; ++k) cand_loc[q][k] = m.cand_loc[c * 3 + k]; }
         }
+#pragma unroll
+        for (int q = 0; q < PPL; ++q) { const int c = l + kWave * q; pair_code[q] = (c < m.NPAIR) ? m.pair_code[c] : -1; }
     }
     DM_DEV void load_model() {
         uint32_t* dst = reinterpret_cast<uint32_t*>(&s.mdl);
@@ -398,7 +404,7 @@ struct EnvSim {
     DM_DEV void dyn_row(int k, Real diag_scale) {
         const int di = s.mdl.dof_info[k], dj = DM_DI_JOINT(di), kind = DM_DI_KIND(di), ax = DM_DI_AXIS(di);
         const v3 a = (kind == DK_ROOT_LIN) ? ld3(&s.dofrec[k][3]) : ld3(&s.dofrec[k][0]);
-        s.bias[k] = (kind == DK_ROOT_LIN) ? s.Fs[0][ax] : dot(a, ld3(s.Ns[dj]));
+        s.dofrec[k][7] = (kind == DK_ROOT_LIN) ? s.Fs[0][ax] : dot(a, ld3(s.Ns[dj]));
         const Real* ic = s.Ic[dj];
         v3 h = mk3(ic[1], ic[2], ic[3]), Pm, Lp;
         if (kind == DK_ROOT_LIN) { Pm = ic[0] * a; Lp = cross(h, a); }
@@ -530,7 +536,7 @@ struct EnvSim {
     // pose error per joint -> xs = Kp e + Kd (0 - qd); rhs = xs - C
     DM_DEV void spd_rhs(Real dt) {
         spd_rhs_pre(dt);
-        for (int i = l; i < m.D; i += LW) s.rhs[i] = s.xs[i] - s.bias[i];
+        for (int i = l; i < m.D; i += LW) s.rhs[i] = xs()[i] - s.dofrec[i][7];
         sync();
     }
     DM_DEV void spd_rhs_pre(Real dt) {
@@ -541,19 +547,19 @@ struct EnvSim {
                 q4 dq = quat_diff_mul(q, om);
                 q4 qh = qnormalize(mkq(q.w + dt * dq.w, q.x + dt * dq.x, q.y + dt * dq.y, q.z + dt * dq.z));
                 v3 e = quat_to_rotvec(qmul(qconj(qh), ldq(s.tar + off)), (Real)0.000001);
-                for (int k = 0; k < 3; ++k) s.xs[dof + k] = s.mdl.kp[dof + k] * comp(e, k) + s.mdl.kd[dof + k] * (-s.vel[off + k]);
+                for (int k = 0; k < 3; ++k) xs()[dof + k] = s.mdl.kp[dof + k] * comp(e, k) + s.mdl.kd[dof + k] * (-s.vel[off + k]);
             } else if (jt == JT_REVOLUTE) {
                 Real th = normalize_angle(s.pose[off]);
                 Real e = s.tar[off] - (th + dt * s.vel[off]);
-                s.xs[dof] = s.mdl.kp[dof] * e + s.mdl.kd[dof] * (-s.vel[off]);
+                xs()[dof] = s.mdl.kp[dof] * e + s.mdl.kd[dof] * (-s.vel[off]);
             }
         }
-        if (l < 6) s.xs[l] = 0;
+        if (l < 6) xs()[l] = 0;
         sync();
     }
     // rhs holds qddot: tau = Kp e + Kd (e_v - dt qddot), clamped per joint (SimBodyJoint.cpp:299-307)
     DM_DEV void spd_post(Real dt) {
-        for (int i = l; i < m.D; i += LW) s.tau[i] = (i < 6) ? (Real)0 : s.xs[i] - s.mdl.kd[i] * dt * s.rhs[i];
+        for (int i = l; i < m.D; i += LW) s.tau[i] = (i < 6) ? (Real)0 : xs()[i] - s.mdl.kd[i] * dt * s.rhs[i];
         sync();
         spd_clamp();
     }
@@ -576,6 +582,69 @@ struct EnvSim {
         Real mx = (dof < 3) ? m.max_lin_vel : m.max_ang_vel;
         return dm_max(-mx, dm_min(mx, v));
     }
+    // ------------------------------------------------------------------ contacts (DM-physics v1)
+    // One self-collision candidate: capsule models of links i and j (mdl.cap), closest points of the two segments (Ericson,
+    // Real-Time Collision Detection 5.1.9).  Returns whether it is active; x = midpoint of the two surface points, n from j to i.
+    DM_DEV bool self_pair(int i, int j, v3& x, v3& n, Real& dist) const {
+        const Real* ci = s.mdl.cap[i]; const Real* cj = s.mdl.cap[j];
+        const v3 ui = ldm3(Rbp(i)) * ld3(ci), uj = ldm3(Rbp(j)) * ld3(cj);
+        const v3 p1 = ld3(s.com[i]) + ui, p2 = ld3(s.com[j]) + uj;
+        const v3 d1 = (Real)-2 * ui, d2 = (Real)-2 * uj, r = p1 - p2;
+        const Real eps = (Real)1e-12;
+        const Real a = dot(d1, d1), e = dot(d2, d2), f = dot(d2, r);
+        Real sp, tp;
+        if (a <= eps && e <= eps) { sp = 0; tp = 0; }
+        else if (a <= eps) { sp = 0; tp = dm_min((Real)1, dm_max((Real)0, f / e)); }
+        else {
+            const Real c = dot(d1, r);
+            if (e <= eps) { tp = 0; sp = dm_min((Real)1, dm_max((Real)0, -c / a)); }
+            else {
+                const Real b = dot(d1, d2), denom = a * e - b * b;
+                sp = (denom > eps) ? dm_min((Real)1, dm_max((Real)0, (b * f - c * e) / denom)) : (Real)0;
+                tp = (b * sp + f) / e;
+                if (tp < 0) { tp = 0; sp = dm_min((Real)1, dm_max((Real)0, -c / a)); }
+                else if (tp > 1) { tp = 1; sp = dm_min((Real)1, dm_max((Real)0, (b - c) / a)); }
+            }
+        }
+        const v3 ca = p1 + sp * d1, cb = p2 + tp * d2, dl = ca - cb;
+        const Real d = norm(dl), ri = ci[3], rj = cj[3];
+        dist = d - ri - rj;
+        n = (d > (Real)1e-9) ? ((Real)1 / d) * dl : mk3((Real)0, (Real)1, (Real)0);
+        x = (Real)0.5 * ((ca - ri * n) + (cb + rj * n));
+        return dist < dm_min(s.mdl.thresh[i], s.mdl.thresh[j]);
+    }
+    // btPlaneSpace1: two tangents of a unit normal ((-1,0,0), (0,0,1) for the ground normal)
+    static DM_DEV void plane_space(v3 n, v3& p, v3& q) {
+        if (dm_abs(n.z) > (Real)0.7071067811865475244) {
+            const Real a = n.y * n.y + n.z * n.z, k = (Real)1 / dm_sqrt(a);
+            p = mk3((Real)0, -n.z * k, n.y * k); q = mk3(a * k, -n.x * p.z, n.x * p.y);
+        } else {
+            const Real a = n.x * n.x + n.y * n.y, k = (Real)1 / dm_sqrt(a);
+            p = mk3(-n.y * k, n.x * k, (Real)0); q = mk3(-n.z * p.y, n.z * p.x, a * k);
+        }
+    }
+    // constraint row `r` of this lane from the contact slots: bias b, chain masks (dofs moving the point with link a, minus
+    // those moving it with link b: common ancestors cancel exactly), X = (x - p0) x d and d
+    DM_DEV void contact_row(int r, int NL, int nc, Real h, Real& brow, uint32_t& m_lo, uint32_t& m_hi, uint32_t& g_lo, uint32_t& g_hi, v3& xd, v3& dd) const {
+        int slot, kindr;
+        if (r < NL + nc) { slot = r - NL; kindr = 0; } else { int fi = r - NL - nc; slot = fi >> 1; kindr = 1 + (fi & 1); }
+        const Real* ct = s.ct[slot];
+        const int info = (int)ct[7];            // link ids are small integers, exact in fp32
+        const int la = info & 0xff, lb = (info >> 8) & 0xff;
+        const v3 n = ld3(ct + 3);
+        v3 t1, t2; plane_space(n, t1, t2);
+        dd = (kindr == 0) ? n : ((kindr == 1) ? t1 : t2);
+        xd = cross(ld3(ct) - ld3(s.p[0]), dd);
+        uint32_t a_lo = s.mdl.chain_lo[la], a_hi = s.mdl.chain_hi[la], b_lo = 0, b_hi = 0;
+        if (lb != 255) { b_lo = s.mdl.chain_lo[lb]; b_hi = s.mdl.chain_hi[lb]; }
+        m_lo = a_lo ^ b_lo; m_hi = a_hi ^ b_hi; g_lo = b_lo & m_lo; g_hi = b_hi & m_hi;
+        if (kindr == 0) { const Real dc = ct[6]; brow = (dc > 0) ? -dc / h : -m.erp * dc / h; }
+    }
+    DM_DEV void store_contact(int slot, v3 x, v3 n, Real dist, int la, int lb) {
+        Real* ct = s.ct[slot];
+        st3(ct, x); st3(ct + 3, n); ct[6] = dist; ct[7] = (Real)(la | (lb << 8));
+    }
+
     // integrate positions with the new velocity (semi-implicit Euler, exponential map on rotations); lane = link
     DM_DEV void integrate(Real h) {
         if (l < m.J) {
@@ -620,12 +689,12 @@ struct EnvSim {
         if (nact > m.max_contacts) {
             // manifold reduction (rare): keep the max_contacts deepest, ties to the lower index
 #pragma unroll
-            for (int q = 0; q < CPL; ++q) { const int c = l + kWave * q; s.csel[c] = active[q] ? 1 : 0; s.cdist[c] = dist[q]; }
+            for (int q = 0; q < CPL; ++q) { const int c = l + kWave * q; s.csel[c] = active[q] ? 1 : 0; s.cdistc[c] = dist[q]; }
             sync();
 #pragma unroll
             for (int q = 0; q < CPL; ++q) {
                 const int c = l + kWave * q; int rank = 0;
-                if (active[q]) for (int k = 0; k < m.NC; ++k) if (s.csel[k] && (s.cdist[k] < dist[q] || (s.cdist[k] == dist[q] && k < c))) ++rank;
+                if (active[q]) for (int k = 0; k < m.NC; ++k) if (s.csel[k] && (s.cdistc[k] < dist[q] || (s.cdistc[k] == dist[q] && k < c))) ++rank;
                 active[q] = active[q] && rank < m.max_contacts;
             }
             sync();
@@ -633,17 +702,29 @@ struct EnvSim {
 #pragma unroll
             for (int q = 0; q < CPL; ++q) { amask[q] = wave_ballot(active[q]); nact += dm_popc64(amask[q]); }
         }
-        const int nc = nact;
-        {   // compact in candidate-index order
-            const uint64_t lt = (l == 0) ? 0ull : (~0ull >> (64 - l));
+        const uint64_t lt = (l == 0) ? 0ull : (~0ull >> (64 - l));
+        {   // ground contacts -> slots, in candidate-index order
             int base = 0;
 #pragma unroll
             for (int q = 0; q < CPL; ++q) {
-                if (active[q]) {
-                    const int c = l + kWave * q, slot = base + dm_popc64(amask[q] & lt);
-                    s.cslot[slot] = c | (cand_link[q] << 16); st3(s.cx[c], cxp[q]); s.cdist[c] = dist[q];
-                }
+                if (active[q]) store_contact(base + dm_popc64(amask[q] & lt), cxp[q], mk3((Real)0, (Real)1, (Real)0), dist[q], cand_link[q], 255);
                 base += dm_popc64(amask[q]);
+            }
+        }
+        int nc = nact;
+        // ---- self collision: lane = link pair; active pairs take the slots the ground left, in pair order
+#pragma unroll
+        for (int q = 0; q < PPL; ++q) {
+            if (q * kWave < m.NPAIR) {
+                const int code = pair_code[q];
+                v3 x = zero3(), n = zero3(); Real dsc = 0; bool act = false;
+                if (code >= 0) act = self_pair(code & 0xff, code >> 8, x, n, dsc);
+                const uint64_t mk = wave_ballot(act);
+                if (mk != 0) {
+                    const int slot = nc + dm_popc64(mk & lt);
+                    if (act && slot < m.max_contacts) store_contact(slot, x, n, dsc, code & 0xff, code >> 8);
+                    nc = dm_min(m.max_contacts, nc + dm_popc64(mk));
+                }
             }
         }
         const int NL = m.NL;
@@ -653,10 +734,10 @@ struct EnvSim {
 
         mark(8);
         // ---- constraint rows: lane = row.  limits | normals | frictions (2 per contact)
-        // J_r[k] = a_k . ((x - p0) x d) + g_k . d on the dofs of the chain root..link, 0 elsewhere.
-        // A limit row (+-e_dof) is the same formula with d = 0 and (x - p0) x d := +-a_dof on the one-dof chain {dof}.
+        // J_r[k] = +-(a_k . ((x - p0) x d) + g_k . d) on the dofs of the chain root..link (minus the other link's chain for a
+        // self contact), 0 elsewhere.  A limit row (+-e_dof) is the same formula with d = 0 and X := +-a_dof on the chain {dof}.
         Real b = 0;
-        uint32_t ch_lo = 0, ch_hi = 0; v3 xd = zero3(), dd = zero3();
+        uint32_t ch_lo = 0, ch_hi = 0, ng_lo = 0, ng_hi = 0; v3 xd = zero3(), dd = zero3();
         if (l < R) {
             if (l < NL) {
                 int j = s.mdl.lim_joint[l]; int lj = s.mdl.link_info[j]; int off = DM_LI_POFF(lj);
@@ -667,15 +748,7 @@ struct EnvSim {
                 b = (pen > 0) ? -pen / h : -m.erp * pen / h;
                 xd = sgn * ld3(&s.dofrec[limdof][0]);
                 if (limdof < 32) ch_lo = 1u << limdof; else ch_hi = 1u << (limdof - 32);
-            } else {
-                int cs, kindr;
-                if (l < NL + nc) { cs = s.cslot[l - NL]; kindr = 0; } else { int fi = l - NL - nc; cs = s.cslot[fi >> 1]; kindr = 1 + (fi & 1); }
-                const int c = cs & 0xffff, lk = cs >> 16;         // candidate id | owning link
-                ch_lo = s.mdl.chain_lo[lk]; ch_hi = s.mdl.chain_hi[lk];
-                dd = (kindr == 0) ? mk3((Real)0, (Real)1, (Real)0) : ((kindr == 1) ? mk3((Real)-1, (Real)0, (Real)0) : mk3((Real)0, (Real)0, (Real)1));   // btPlaneSpace1((0,1,0))
-                xd = cross(ld3(s.cx[c]) - ld3(s.p[0]), dd);
-                if (kindr == 0) { Real dc = s.cdist[c]; b = (dc > 0) ? -dc / h : -m.erp * dc / h; }
-            }
+            } else contact_row(l, NL, nc, h, b, ch_lo, ch_hi, ng_lo, ng_hi, xd, dd);
         }
         // y := L^-1 J_l^T in registers (static indices; dof records and L rows are wave-uniform LDS broadcasts)
         R2 y2[NP2]; Real cvec = 0;
@@ -685,8 +758,8 @@ struct EnvSim {
             if (k < D) {
                 const R4 r0 = *reinterpret_cast<const R4*>(&s.dofrec[k][0]), r1 = *reinterpret_cast<const R4*>(&s.dofrec[k][4]);
                 const Real val = r0[0] * xd.x + r0[1] * xd.y + r0[2] * xd.z + r0[3] * dd.x + r1[0] * dd.y + r1[1] * dd.z;
-                const bool on = (((k < 32) ? ch_lo : ch_hi) >> (k & 31)) & 1u;
-                const Real raw = on ? val : (Real)0;
+                const bool on = (((k < 32) ? ch_lo : ch_hi) >> (k & 31)) & 1u, ng = (((k < 32) ? ng_lo : ng_hi) >> (k & 31)) & 1u;
+                const Real raw = on ? (ng ? -val : val) : (Real)0;
                 cvec += raw * r1[2];
                 R2 acc2 = {(Real)0, (Real)0}, acc3 = acc2;      // two independent accumulation chains
                 const R2* lrow = reinterpret_cast<const R2*>(&s.Lt[L::lrow(k)]);
@@ -944,11 +1017,11 @@ struct EnvSim {
         if (TAPS && dbg.H) {
             const int D = m.D;
             for (int i = l; i < D * D; i += LW) { int r = i / D, c = i % D; Real v = (c <= r) ? Lx(r, c) : Lx(c, r); if (r == c && ph == 0) v -= dt * s.mdl.kd[r]; dbg.H[(size_t)e * D * D + i] = v; }
-            if (l < D) dbg.C[(size_t)e * D + l] = s.bias[l];
+            if (l < D) dbg.C[(size_t)e * D + l] = s.dofrec[l][7];
         }
         if (tap_only) return;
         if (ph == 0) spd_rhs(dt);
-        else { if (l < m.D) s.rhs[l] = s.tau[l] - s.bias[l]; sync(); }
+        else { if (l < m.D) s.rhs[l] = s.tau[l] - s.dofrec[l][7]; sync(); }
         DM_OPAQUE_V(l);
         chol_solve(s.rhs);
         DM_OPAQUE_V(l); DM_OPAQUE_V(li);

@@ -92,6 +92,8 @@ struct DuoSim {
     Base b;                                             // per-character pieces (lane hl of record `half`)
     L& s;
     int cand_link[CP]; Real cand_loc[CP][3], cand_rad[CP];
+    static constexpr int PP = C::NPAIRCAP / HW;         // self-collision pair passes
+    int pair_code[PP];
     DM_DEV DuoSim(const ModelDev<Real>& m_, L* rec_, int wl_) : m(m_), rec(rec_), wl(wl_), half(wl_ >> 5), hl(wl_ & 31), b(m_, rec_[wl_ >> 5], wl_ & 31), s(rec_[wl_ >> 5]) {}
     DM_DEV void sync() const { __syncthreads(); }
     DM_DEV Real& Lx(int r, int c) const { return s.Lt[L::lrow(r) + c]; }
@@ -105,6 +107,8 @@ struct DuoSim {
             cand_link[q] = 0; cand_rad[q] = 0; cand_loc[q][0] = cand_loc[q][1] = cand_loc[q][2] = 0;
             if (c < m.NC) { cand_link[q] = m.cand_link[c]; cand_rad[q] = m.cand_rad[c]; for (int k = 0; k < 3; ++k) cand_loc[q][k] = m.cand_loc[c * 3 + k]; }
         }
+#pragma unroll
+        for (int q = 0; q < PP; ++q) { const int c = hl + HW * q; pair_code[q] = (c < m.NPAIR) ? m.pair_code[c] : -1; }
     }
 
     // ------------------------------------------------------------------ mass matrix rows 3..33 in lanes, rows 0..2 closed form
@@ -116,7 +120,10 @@ struct DuoSim {
         b.dyn_subtree();
         sync();
         if (hl + 3 < D) b.dyn_row(hl + 3, diag_scale);
-        if (hl == HW - 1) for (int k = 0; k < 3; ++k) s.bias[k] = s.Fs[0][k];       // root translation: C_k = total force
+        if (hl == HW - 1) {
+            for (int k = 0; k < 3; ++k) s.dofrec[k][7] = s.Fs[0][k];       // root translation: C_k = total force
+            s.sc[7] = s.Ic[0][0];                                           // H_kk, k < 3: total mass (Ic is recycled before the factorisation)
+        }
         sync();
     }
 
@@ -137,7 +144,7 @@ struct DuoSim {
         // Two columns per LDS round trip: column k+1 only needs L[k+1][k] from column k (one in-register broadcast), then both
         // columns are published together and the trailing rank-2 update reads them back as wave-uniform broadcasts.
         Real* colbuf = &s.f[0][0];                       // 2 columns x 40 words per character (aliases the dead Newton-Euler sums)
-        const Real M = s.Ic[0][0];                       // H_kk, k < 3: total mass (root Kd = 0)
+        const Real M = s.sc[7];                          // H_kk, k < 3: total mass (root Kd = 0)
         const Real dinv0 = dm_rsqrt(M);
         Real dinv = 1;
         sync();                                          // every lane has read what it needs from the aliased region
@@ -248,12 +255,12 @@ struct DuoSim {
         if (wave_ballot(nact > m.max_contacts) != 0) {
             // manifold reduction (rare): keep the max_contacts deepest, ties to the lower index
 #pragma unroll
-            for (int q = 0; q < CP; ++q) { const int c = hl + HW * q; s.csel[c] = active[q] ? 1 : 0; s.cdist[c] = dist[q]; }
+            for (int q = 0; q < CP; ++q) { const int c = hl + HW * q; s.csel[c] = active[q] ? 1 : 0; s.cdistc[c] = dist[q]; }
             sync();
 #pragma unroll
             for (int q = 0; q < CP; ++q) {
                 const int c = hl + HW * q; int rank = 0;
-                if (active[q]) for (int k = 0; k < m.NC; ++k) if (s.csel[k] && (s.cdist[k] < dist[q] || (s.cdist[k] == dist[q] && k < c))) ++rank;
+                if (active[q]) for (int k = 0; k < m.NC; ++k) if (s.csel[k] && (s.cdistc[k] < dist[q] || (s.cdistc[k] == dist[q] && k < c))) ++rank;
                 active[q] = active[q] && rank < m.max_contacts;
             }
             sync();
@@ -261,27 +268,42 @@ struct DuoSim {
 #pragma unroll
             for (int q = 0; q < CP; ++q) { amask[q] = (uint32_t)(wave_ballot(active[q]) >> (half * 32)); nact += dm_popc64(amask[q]); }
         }
-        const int nc = nact, NL = m.NL;
-        const int R = NL + 3 * nc;
-        if (wave_ballot(R > HW) != 0) return false;      // a heavily contacted character: the caller runs the one-per-wave routine
-        {
-            const uint32_t lt = (hl == 0) ? 0u : (~0u >> (32 - hl));
+        const uint32_t lt = (hl == 0) ? 0u : (~0u >> (32 - hl));
+        {   // ground contacts -> slots, in candidate-index order
             int base = 0;
 #pragma unroll
             for (int q = 0; q < CP; ++q) {
-                if (active[q]) {
-                    const int c = hl + HW * q, slot = base + dm_popc64(amask[q] & lt);
-                    s.cslot[slot] = c | (cand_link[q] << 16); st3(s.cx[c], cxp[q]); s.cdist[c] = dist[q];
-                }
+                if (active[q]) b.store_contact(base + dm_popc64(amask[q] & lt), cxp[q], mk3((Real)0, (Real)1, (Real)0), dist[q], cand_link[q], 255);
                 base += dm_popc64(amask[q]);
             }
         }
+        int nc = nact;
+        // ---- self collision: lane = link pair (three passes of 32); active pairs take the slots the ground left, in pair order
+        const int npair_passes = (m.NPAIR + HW - 1) / HW;
+#pragma unroll
+        for (int q = 0; q < PP; ++q) {
+            if (q < npair_passes) {
+                const int code = pair_code[q];
+                v3 x = zero3(), n = zero3(); Real dsc = 0; bool act = false;
+                if (code >= 0) act = b.self_pair(code & 0xff, code >> 8, x, n, dsc);
+                const uint64_t mk64 = wave_ballot(act);
+                if (mk64 != 0) {
+                    const uint32_t mk = (uint32_t)(mk64 >> (half * 32));
+                    const int slot = nc + dm_popc64(mk & lt);
+                    if (act && slot < m.max_contacts) b.store_contact(slot, x, n, dsc, code & 0xff, code >> 8);
+                    nc = dm_min(m.max_contacts, nc + (int)dm_popc64(mk));
+                }
+            }
+        }
+        const int NL = m.NL;
+        const int R = NL + 3 * nc;
+        if (wave_ballot(R > HW) != 0) return false;      // a heavily contacted character: the caller runs the one-per-wave routine
         if (hl == 0) { s.flg[FLG_NROWS] = R; s.flg[FLG_NCONT] = nc; }
         sync();
         b.mark(8);
         // ---- constraint rows: lane = row (see EnvSim::substep_post)
         Real brow = 0;
-        uint32_t ch_lo = 0, ch_hi = 0; v3 xd = zero3(), dd = zero3();
+        uint32_t ch_lo = 0, ch_hi = 0, ng_lo = 0, ng_hi = 0; v3 xd = zero3(), dd = zero3();
         if (hl < R) {
             if (hl < NL) {
                 int j = s.mdl.lim_joint[hl]; int lj = s.mdl.link_info[j]; int off = DM_LI_POFF(lj);
@@ -292,15 +314,7 @@ struct DuoSim {
                 brow = (pen > 0) ? -pen / h : -m.erp * pen / h;
                 xd = sgn * ld3(&s.dofrec[limdof][0]);
                 if (limdof < 32) ch_lo = 1u << limdof; else ch_hi = 1u << (limdof - 32);
-            } else {
-                int cs, kindr;
-                if (hl < NL + nc) { cs = s.cslot[hl - NL]; kindr = 0; } else { int fi = hl - NL - nc; cs = s.cslot[fi >> 1]; kindr = 1 + (fi & 1); }
-                const int c = cs & 0xffff, lk = cs >> 16;
-                ch_lo = s.mdl.chain_lo[lk]; ch_hi = s.mdl.chain_hi[lk];
-                dd = (kindr == 0) ? mk3((Real)0, (Real)1, (Real)0) : ((kindr == 1) ? mk3((Real)-1, (Real)0, (Real)0) : mk3((Real)0, (Real)0, (Real)1));
-                xd = cross(ld3(s.cx[c]) - ld3(s.p[0]), dd);
-                if (kindr == 0) { Real dc = s.cdist[c]; brow = (dc > 0) ? -dc / h : -m.erp * dc / h; }
-            }
+            } else b.contact_row(hl, NL, nc, h, brow, ch_lo, ch_hi, ng_lo, ng_hi, xd, dd);
         }
         R2 y2[NP2]; Real cvec = 0;
 #pragma unroll
@@ -309,8 +323,8 @@ struct DuoSim {
             if (k < D) {
                 const R4 r0 = *reinterpret_cast<const R4*>(&s.dofrec[k][0]), r1 = *reinterpret_cast<const R4*>(&s.dofrec[k][4]);
                 const Real val = r0[0] * xd.x + r0[1] * xd.y + r0[2] * xd.z + r0[3] * dd.x + r1[0] * dd.y + r1[1] * dd.z;
-                const bool on = (((k < 32) ? ch_lo : ch_hi) >> (k & 31)) & 1u;
-                const Real raw = on ? val : (Real)0;
+                const bool on = (((k < 32) ? ch_lo : ch_hi) >> (k & 31)) & 1u, ng = (((k < 32) ? ng_lo : ng_hi) >> (k & 31)) & 1u;
+                const Real raw = on ? (ng ? -val : val) : (Real)0;
                 cvec += raw * r1[2];
                 R2 acc2 = {(Real)0, (Real)0}, acc3 = acc2;      // two independent accumulation chains
                 const R2* lrow = reinterpret_cast<const R2*>(&s.Lt[L::lrow(k)]);
@@ -385,22 +399,22 @@ struct DuoSim {
             b.template tr_stage<(NP2 + 1) / 2, 4>(w);
             b.template tr_stage<(NP2 + 3) / 4, 8>(w);
             b.template tr_stage<(NP2 + 7) / 8, 16>(w);
-            s.xs[hl] = w[0];
-            if (hl + 32 < D) s.xs[hl + 32] = w[1];
+            b.xs()[hl] = w[0];
+            if (hl + 32 < D) b.xs()[hl + 32] = w[1];
         }
         sync();
         {
             const int own = hl + 3; const bool valid = own < D;
-            Real x = valid ? s.xs[own] : (Real)0;
-            Real xr[3] = { s.xs[0], s.xs[1], s.xs[2] };
+            Real x = valid ? b.xs()[own] : (Real)0;
+            Real xr[3] = { b.xs()[0], b.xs()[1], b.xs()[2] };
             const Real dinv = valid ? Lx(valid ? own : 3, valid ? own : 3) : (Real)1, dinv0 = Lx(0, 0);
             sync();
             back_substitute(x, xr, dinv, dinv0);
-            if (valid) s.xs[own] = x;
-            if (hl == HW - 1) for (int k = 0; k < 3; ++k) s.xs[k] = xr[k];
+            if (valid) b.xs()[own] = x;
+            if (hl == HW - 1) for (int k = 0; k < 3; ++k) b.xs()[k] = xr[k];
         }
         sync();
-        for (int k = hl; k < D; k += HW) { const int vidx = DM_DI_VIDX(s.mdl.dof_info[k]); s.vel[vidx] = clamp_vel(s.dofrec[k][6] + s.xs[k], k); }
+        for (int k = hl; k < D; k += HW) { const int vidx = DM_DI_VIDX(s.mdl.dof_info[k]); s.vel[vidx] = clamp_vel(s.dofrec[k][6] + b.xs()[k], k); }
         sync();
         b.integrate(h);
         sync();
@@ -426,15 +440,15 @@ struct DuoSim {
             b.mark(ph == 0 ? 2 : 6);
             if (ph == 0) {
                 b.spd_rhs_pre(rdt);
-                for (int k = hl; k < D; k += HW) s.rhs[k] = s.xs[k] - s.bias[k];
+                for (int k = hl; k < D; k += HW) s.rhs[k] = b.xs()[k] - s.dofrec[k][7];
                 sync();
-            } else { for (int k = hl; k < D; k += HW) s.rhs[k] = s.tau[k] - s.bias[k]; sync(); }
+            } else { for (int k = hl; k < D; k += HW) s.rhs[k] = s.tau[k] - s.dofrec[k][7]; sync(); }
             DM_OPAQUE_V(hl); DM_OPAQUE_V(b.l);
             chol_solve(s.rhs);
             DM_OPAQUE_V(hl); DM_OPAQUE_V(b.l); DM_OPAQUE_V(b.li);
             if (ph == 0) {
                 b.mark(3);
-                for (int k = hl; k < D; k += HW) s.tau[k] = (k < 6) ? (Real)0 : s.xs[k] - s.mdl.kd[k] * rdt * s.rhs[k];
+                for (int k = hl; k < D; k += HW) s.tau[k] = (k < 6) ? (Real)0 : b.xs()[k] - s.mdl.kd[k] * rdt * s.rhs[k];
                 sync();
                 b.spd_clamp();
             } else if (!substep_post(h)) {

@@ -67,6 +67,7 @@ struct HostModel {
     std::vector<double> attach, attach_rot, battach, brot, mass, inertia, torque_lim, lim_lo, lim_hi, diffw, thresh, aabb_he;
     std::vector<int> dof_joint, dof_kind, dof_axis, dof_vidx; std::vector<uint64_t> dof_anc; std::vector<double> kp, kd;
     std::vector<int> cand_link; std::vector<double> cand_loc, cand_rad;
+    std::vector<double> cap; std::vector<int> pair_code;
     std::vector<int> lim_joint;
     std::vector<double> frame_time, frames, frame_vel; double duration = 0; int loop = 0; double cycle_delta[3] = {0, 0, 0};
     std::vector<double> s_off, s_scale, a_off, a_scale, a_min, a_max; std::vector<int> s_groups;
@@ -176,6 +177,22 @@ static int build_host_model(const dm_scene_tables& t, int max_contacts, HostMode
         else if (shape == SH_CAPSULE) { add(0, 0.5 * p1, 0, 0.5 * p0); add(0, -0.5 * p1, 0, 0.5 * p0); }
         else if (shape == SH_BOX) for (int s = 0; s < 8; ++s) add((s & 1) ? -0.5 * p0 : 0.5 * p0, (s & 2) ? -0.5 * p1 : 0.5 * p1, (s & 4) ? -0.5 * p2 : 0.5 * p2, 0);
     }
+    // self collision: capsule model of every link (sphere: point, capsule: own axis, box: inscribed capsule along the longest
+    // extent) and the non-adjacent pairs in (i < j) order
+    hm.cap.assign(J * 4, 0);
+    for (int j = 0; j < J; ++j) {
+        int shape = (int)bd(j, BD_SHAPE); double p0 = bd(j, BD_P0), p1 = bd(j, BD_P1), p2 = bd(j, BD_P2);
+        double* c = &hm.cap[j * 4];
+        if (shape == SH_SPHERE) c[3] = 0.5 * p0;
+        else if (shape == SH_CAPSULE) { c[1] = 0.5 * p1; c[3] = 0.5 * p0; }
+        else if (shape == SH_BOX) {
+            double e[3] = {p0, p1, p2}; int a = 0; if (e[1] > e[a]) a = 1; if (e[2] > e[a]) a = 2;
+            double r = 0.5 * std::min(e[(a + 1) % 3], e[(a + 2) % 3]);
+            c[a] = std::max(0.0, 0.5 * e[a] - r); c[3] = r;
+        }
+    }
+    if (!t.disable_self_collision)
+        for (int i = 0; i < J; ++i) for (int j = i + 1; j < J; ++j) if (hm.parent[j] != i && hm.parent[i] != j) hm.pair_code.push_back(i | (j << 8));
     hm.NC = (int)hm.cand_link.size();
     if (hm.NC > 128) return fail("more than 128 ground-contact candidate points");
     if (hm.NL + 3 * max_contacts > kMaxRows) return fail("limit rows + 3*max_contacts exceeds 64 constraint rows");
@@ -276,6 +293,7 @@ struct CtxT : CtxBase {
             for (int k = 0; k < 3; ++k) { b->attach[j][k] = (Real)h.attach[j * 3 + k]; b->battach[j][k] = (Real)h.battach[j * 3 + k];
                                           b->inertia[0][j][k] = (Real)h.inertia[(0 * h.J + j) * 3 + k]; b->inertia[1][j][k] = (Real)h.inertia[(1 * h.J + j) * 3 + k]; }
             b->mass[j] = (Real)h.mass[j]; b->thresh[j] = (Real)h.thresh[j]; b->torque_lim[j] = (Real)h.torque_lim[j];
+            for (int k = 0; k < 4; ++k) b->cap[j][k] = (Real)h.cap[j * 4 + k];
             if (C::ROT) for (int k = 0; k < 9; ++k) { b->attach_rot[C::ROT ? j : 0][k] = (Real)h.attach_rot[j * 9 + k]; b->brot[C::ROT ? j : 0][k] = (Real)h.brot[j * 9 + k]; }
         }
         for (int i = 0; i < h.D; ++i) {
@@ -305,6 +323,8 @@ struct CtxT : CtxBase {
         md.mdl_blob = (cls == 0) ? build_mdl<ClsBiped>(&md.mdl_words) : build_mdl<ClsLarge>(&md.mdl_words);
         md.act_off = up<int>(h.act_off); md.diffw = up<Real>(h.diffw); md.aabb_he = up<Real>(h.aabb_he);
         md.cand_link = up<int>(h.cand_link); md.cand_loc = up<Real>(h.cand_loc); md.cand_rad = up<Real>(h.cand_rad);
+        md.pair_code = up<int>(h.pair_code); md.NPAIR = (int)h.pair_code.size();
+        if (md.NPAIR > ((cls == 0) ? ClsBiped::NPAIRCAP : ClsLarge::NPAIRCAP)) return fail("too many self-collision pairs for the compiled kernel classes");
         md.frame_time = up<double>(h.frame_time); md.frames = up<Real>(h.frames); md.frame_vel = up<Real>(h.frame_vel);
         md.duration = h.duration; md.loop = h.loop; for (int k = 0; k < 3; ++k) { md.cycle_delta[k] = (Real)h.cycle_delta[k]; md.gravity[k] = (Real)c.gravity[k]; }
         md.num_sim_substeps = c.num_sim_substeps; md.solver_iters = c.solver_iters > 0 ? c.solver_iters : 10; md.max_contacts = max_contacts;

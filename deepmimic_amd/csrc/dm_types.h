@@ -19,13 +19,14 @@ enum { TERM_NULL = 0, TERM_FAIL = 1, TERM_SUCC = 2 };
 constexpr int kWave = 64;
 constexpr int kMaxRows = 64;   // constraint rows per substep (one per lane)
 constexpr int kMaxLim = 8;     // joint-limit rows (revolute joints with lo <= hi)
+constexpr int kMaxContacts = 20;   // contact slots per character (ground + self): kMaxLim/NL + 3 * 20 <= kMaxRows
 
 // Compiled kernel classes: static bounds of the per-lane register arrays and the LDS record.
 struct ClsBiped {      // humanoid3d: 15 links, 34 dof, 43 pose dims, <= 64 ground-contact candidates, no attach rotations
-    static constexpr int NJ = 15, ND = 34, NP = 43, NCAP = 64, RREG = 32; static constexpr bool ROT = false;   // RREG: rows of A kept in VGPRs
+    static constexpr int NJ = 15, ND = 34, NP = 43, NCAP = 64, RREG = 32, NPAIRCAP = 128; static constexpr bool ROT = false;   // RREG: rows of A kept in VGPRs
 };
 struct ClsLarge {      // dog3d and anything up to 23 links / 64 dof / 83 pose dims / 128 candidates, attach rotations allowed
-    static constexpr int NJ = 23, ND = 64, NP = 83, NCAP = 128, RREG = 64; static constexpr bool ROT = true;
+    static constexpr int NJ = 23, ND = 64, NP = 83, NCAP = 128, RREG = 64, NPAIRCAP = 256; static constexpr bool ROT = true;
 };
 
 // link_info word: parent+1 [0:4] | jtype [5:7] | depth [8:11] | pose_off [12:18] | dof_off [19:25] | arot_ident 26 | brot_ident 27 | is_ee 28 | fall 29
@@ -55,6 +56,7 @@ struct MdlLds {
     Real mass[C::NJ];
     Real inertia[2][C::NJ][3];                 // principal inertias: [0] SPD model, [1] simulator model
     Real thresh[C::NJ], torque_lim[C::NJ];
+    Real cap[C::NJ][4];                        // self-collision capsule of the link: half segment c0 (body frame, c1 = -c0), radius
     Real attach_rot[C::ROT ? C::NJ : 1][C::ROT ? 9 : 1];    // joint attach rotation (ClsLarge only)
     Real brot[C::ROT ? C::NJ : 1][C::ROT ? 9 : 1];          // body frame in the joint frame (ClsLarge only)
     int dof_info[C::ND];
@@ -73,6 +75,8 @@ struct ModelDev {
     const Real* aabb_he;                     // J x 4  half extents of the collider AABB box (w = 1: sphere)
     // ---- ground contact candidates, NC entries (each lane keeps its own candidates in registers)
     const int* cand_link; const Real* cand_loc /* NC x 3, body frame */; const Real* cand_rad;
+    // ---- self-collision pairs (i < j, not parent-child), NPAIR entries i | j << 8, in (i, j) lexicographic order; 0 pairs = off
+    const int* pair_code; int NPAIR;
     // ---- motion clip
     const double* frame_time;                // F
     const Real* frames;                      // F x P (post-processed)

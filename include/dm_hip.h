@@ -51,6 +51,8 @@ typedef struct {
     double query_rate;
     /* DM-physics v1 constants; 0 selects the default */
     double friction, erp; int solver_iters;
+    int disable_self_collision;  /* 0 (default): links of the character collide with each other except parent-child pairs, as
+                                    btMultiBody's default m_hasSelfCollision does (sim/SimCharacter.cpp:857,873,919) */
 } dm_scene_tables;
 
 enum { DM_DEVICE_PTRS = 1, DM_AUTO_RESET = 2, DM_OPEN_LOOP = 4, DM_NO_EMIT = 8 };

@@ -18,7 +18,7 @@ enum {
     CFG_NUM_SIM_SUBSTEPS = 0, CFG_WORLD_SCALE, CFG_GRAV_X, CFG_GRAV_Y, CFG_GRAV_Z,
     CFG_SYNC_ROOT_POS, CFG_SYNC_ROOT_ROT, CFG_ENABLE_FALL_END, CFG_ENABLE_CONTACT_FALL, CFG_ENABLE_ROOT_ROT_FAIL,
     CFG_ENABLE_RAND_PLACEMENT, CFG_ENABLE_PHASE_INPUT, CFG_RECORD_WORLD_ROOT_POS, CFG_RECORD_WORLD_ROOT_ROT,
-    CFG_QUERY_RATE, CFG_FRICTION, CFG_ERP, CFG_SOLVER_ITERS, CFG_MAX_CONTACTS, CFG_COUNT
+    CFG_QUERY_RATE, CFG_FRICTION, CFG_ERP, CFG_SOLVER_ITERS, CFG_MAX_CONTACTS, CFG_SELF_COLLISION, CFG_COUNT
 };
 
 int orc_cfg_count() { return CFG_COUNT; }
@@ -33,7 +33,7 @@ void orc_cfg_default(double* c) {
     c[CFG_ENABLE_ROOT_ROT_FAIL] = d.enable_root_rot_fail; c[CFG_ENABLE_RAND_PLACEMENT] = d.enable_rand_char_placement;
     c[CFG_ENABLE_PHASE_INPUT] = d.enable_phase_input; c[CFG_RECORD_WORLD_ROOT_POS] = d.record_world_root_pos;
     c[CFG_RECORD_WORLD_ROOT_ROT] = d.record_world_root_rot; c[CFG_QUERY_RATE] = d.query_rate;
-    c[CFG_FRICTION] = d.friction; c[CFG_ERP] = d.erp; c[CFG_SOLVER_ITERS] = d.solver_iters; c[CFG_MAX_CONTACTS] = d.max_contacts;
+    c[CFG_FRICTION] = d.friction; c[CFG_ERP] = d.erp; c[CFG_SOLVER_ITERS] = d.solver_iters; c[CFG_MAX_CONTACTS] = d.max_contacts; c[CFG_SELF_COLLISION] = d.enable_self_collision;
 }
 
 void* orc_create(const double* jm, const double* bd, int J, const double* pd, const double* frames, int F, int loop,
@@ -46,7 +46,7 @@ void* orc_create(const double* jm, const double* bd, int J, const double* pd, co
     cfg.enable_root_rot_fail = c[CFG_ENABLE_ROOT_ROT_FAIL] != 0; cfg.enable_rand_char_placement = c[CFG_ENABLE_RAND_PLACEMENT] != 0;
     cfg.enable_phase_input = c[CFG_ENABLE_PHASE_INPUT] != 0; cfg.record_world_root_pos = c[CFG_RECORD_WORLD_ROOT_POS] != 0;
     cfg.record_world_root_rot = c[CFG_RECORD_WORLD_ROOT_ROT] != 0; cfg.query_rate = c[CFG_QUERY_RATE];
-    cfg.friction = c[CFG_FRICTION]; cfg.erp = c[CFG_ERP]; cfg.solver_iters = (int)c[CFG_SOLVER_ITERS]; cfg.max_contacts = (int)c[CFG_MAX_CONTACTS];
+    cfg.friction = c[CFG_FRICTION]; cfg.erp = c[CFG_ERP]; cfg.solver_iters = (int)c[CFG_SOLVER_ITERS]; cfg.max_contacts = (int)c[CFG_MAX_CONTACTS]; cfg.enable_self_collision = c[CFG_SELF_COLLISION] != 0;
     Scene* s = new Scene();
     s->init(jm, bd, J, pd, frames, F, loop != 0, fall_mask, cfg);
     return s;
@@ -89,6 +89,9 @@ void orc_get_tau(void* h, double* out) { copy_out(((Scene*)h)->tau, out); }
 void orc_get_contacts(void* h, int* in_contact) { Scene* s = (Scene*)h; for (int j = 0; j < s->sk.J; ++j) in_contact[j] = s->in_contact[j]; }
 int orc_dbg_num_rows(void* h) { return ((Scene*)h)->dbg_num_rows; }
 int orc_dbg_num_contacts(void* h) { return (int)((Scene*)h)->dbg_contacts.size(); }
+// out: n x 9 doubles (link, link_b, dist, x3, n3)
+void orc_dbg_contacts(void* h, double* out) { const auto& cs = ((Scene*)h)->dbg_contacts; for (size_t i = 0; i < cs.size(); ++i) { double* o = out + 9 * i; o[0] = cs[i].link; o[1] = cs[i].link_b; o[2] = (double)cs[i].dist; o[3] = (double)cs[i].x.x; o[4] = (double)cs[i].x.y; o[5] = (double)cs[i].x.z; o[6] = (double)cs[i].n.x; o[7] = (double)cs[i].n.y; o[8] = (double)cs[i].n.z; } }
+int orc_dbg_num_self_contacts(void* h) { int n = 0; for (const auto& c : ((Scene*)h)->dbg_contacts) n += c.link_b >= 0; return n; }
 
 // ---- component taps (used by the known-answer and component parity tests) ----
 // kinematic pose/vel at time t for the current origin (cKinCharacter::CalcPose/CalcVel)

@@ -25,6 +25,7 @@ struct SceneCfg {
     double erp = 0.2;                    // btContactSolverInfo::m_erp2
     int solver_iters = 10;               // btContactSolverInfo::m_numIterations
     int max_contacts = 20;               // manifold reduction: deepest-first cap
+    bool enable_self_collision = true;   // btMultiBody::m_hasSelfCollision default; parent-child pairs excluded (SimCharacter.cpp:857,873,919)
     double contact_report_dist = 0.001;  // sim/ContactManager.cpp:80 (0.001*scale in scaled units)
     double breaking_factor = 0.02;       // gContactBreakingThreshold x angular-motion disc
     double max_coord_vel = 100.0;        // btMultiBody::m_maxCoordinateVelocity (scaled units)
@@ -77,7 +78,7 @@ struct LDLT {
     }
 };
 
-struct ContactPt { int link; V3 x; real dist; };
+struct ContactPt { int link; V3 x; real dist; int link_b = -1; V3 n = V3(0, 1, 0); };   // link_b >= 0: self contact, n points from link_b to link
 struct Row { Vec J; Vec W; real b, lo, hi, lam; int normal_row; real mu; };
 
 enum Terminate { TERM_NULL = 0, TERM_FAIL = 1, TERM_SUCC = 2 };   // scenes/RLScene.h:18-24
@@ -287,6 +288,80 @@ struct Scene {
         }
         return (real)cfg.breaking_factor * rad;
     }
+    // ---- self collision, capsule model: every link is a segment (body frame, c0 -> c1) swept by a sphere of radius r.
+    // sphere: point; capsule: its own axis; box: inscribed capsule along the longest extent.
+    void link_capsule(int j, V3& c0, V3& c1, real& r) const {
+        real p0 = (real)sk.bdv(j, BD_P0), p1 = (real)sk.bdv(j, BD_P1), p2 = (real)sk.bdv(j, BD_P2);
+        c0 = V3(0, 0, 0); c1 = V3(0, 0, 0); r = 0;
+        switch (sk.shape(j)) {
+            case SH_SPHERE: r = (real)0.5 * p0; break;
+            case SH_CAPSULE: r = (real)0.5 * p0; c0 = V3(0, (real)0.5 * p1, 0); c1 = V3(0, (real)-0.5 * p1, 0); break;
+            case SH_BOX: {
+                real e[3] = { p0, p1, p2 };
+                int a = 0; if (e[1] > e[a]) a = 1; if (e[2] > e[a]) a = 2;
+                r = (real)0.5 * std::min(e[(a + 1) % 3], e[(a + 2) % 3]);
+                real hl = std::max((real)0, (real)0.5 * e[a] - r);
+                real v[3] = { 0, 0, 0 }; v[a] = hl;
+                c0 = V3(v[0], v[1], v[2]); c1 = V3(-v[0], -v[1], -v[2]);
+                break;
+            }
+            default: assert(false);
+        }
+    }
+    // closest points of two segments (Ericson, Real-Time Collision Detection 5.1.9)
+    static void closest_segment_points(const V3& p1, const V3& q1, const V3& p2, const V3& q2, V3& c1, V3& c2) {
+        const real eps = (real)1e-12;
+        V3 d1 = q1 - p1, d2 = q2 - p2, r = p1 - p2;
+        real a = dot(d1, d1), e = dot(d2, d2), f = dot(d2, r), s, t;
+        if (a <= eps && e <= eps) { s = t = 0; }
+        else if (a <= eps) { s = 0; t = std::min((real)1, std::max((real)0, f / e)); }
+        else {
+            real c = dot(d1, r);
+            if (e <= eps) { t = 0; s = std::min((real)1, std::max((real)0, -c / a)); }
+            else {
+                real b = dot(d1, d2), denom = a * e - b * b;
+                s = (denom > eps) ? std::min((real)1, std::max((real)0, (b * f - c * e) / denom)) : 0;
+                t = (b * s + f) / e;
+                if (t < 0) { t = 0; s = std::min((real)1, std::max((real)0, -c / a)); }
+                else if (t > 1) { t = 1; s = std::min((real)1, std::max((real)0, (b - c) / a)); }
+            }
+        }
+        c1 = p1 + s * d1; c2 = p2 + t * d2;
+    }
+    void self_contacts(std::vector<ContactPt>& out) const {
+        out.clear();
+        for (int i = 0; i < sk.J; ++i) for (int j = i + 1; j < sk.J; ++j) {
+            if (sk.parent(j) == i || sk.parent(i) == j) continue;          // disableParentCollision
+            if (!sk.valid_body(i) || !sk.valid_body(j)) continue;
+            V3 a0, a1, b0, b1; real ra, rb;
+            link_capsule(i, a0, a1, ra); link_capsule(j, b0, b1, rb);
+            V3 pa0 = links[i].com + links[i].Rb * a0, pa1 = links[i].com + links[i].Rb * a1;
+            V3 pb0 = links[j].com + links[j].Rb * b0, pb1 = links[j].com + links[j].Rb * b1;
+            V3 ca, cb; closest_segment_points(pa0, pa1, pb0, pb1, ca, cb);
+            V3 dlt = ca - cb; real d = norm(dlt);
+            real dist = d - ra - rb;
+            if (!(dist < std::min(breaking_threshold(i), breaking_threshold(j)))) continue;
+            V3 n = (d > (real)1e-9) ? ((real)1 / d) * dlt : V3(0, 1, 0);
+            ContactPt c; c.link = i; c.link_b = j; c.n = n; c.dist = dist;
+            c.x = (real)0.5 * ((ca - ra * n) + (cb + rb * n));
+            out.push_back(c);
+        }
+    }
+    // btPlaneSpace1
+    static void plane_space(const V3& n, V3& p, V3& q) {
+        if (std::fabs(n.z) > (real)0.7071067811865475244) {
+            real a = n.y * n.y + n.z * n.z, k = (real)1 / std::sqrt(a);
+            p = V3(0, -n.z * k, n.y * k); q = V3(a * k, -n.x * p.z, n.x * p.y);
+        } else {
+            real a = n.x * n.x + n.y * n.y, k = (real)1 / std::sqrt(a);
+            p = V3(-n.y * k, n.x * k, 0); q = V3(-n.z * p.y, n.z * p.x, a * k);
+        }
+    }
+    // row of a contact along d: the contact point moves with `link`; for a self contact minus the same point moving with link_b
+    void contact_jacobian(const ContactPt& cp, const V3& d, Vec& Jr) const {
+        point_jacobian(cp.link, cp.x, d, Jr);
+        if (cp.link_b >= 0) { Vec Jb; point_jacobian(cp.link_b, cp.x, d, Jb); for (int i = 0; i < sk.P; ++i) Jr[i] -= Jb[i]; }
+    }
     // generalized-velocity Jacobian row (pose layout) of d . (velocity of world point x rigidly attached to `link`)
     void point_jacobian(int link, const V3& x, const V3& d, Vec& Jr) const {
         Jr.assign(sk.P, 0);
@@ -331,7 +406,15 @@ struct Scene {
         std::stable_sort(act.begin(), act.end(), [&](int a, int b) { return cand[a].dist < cand[b].dist; });
         if ((int)act.size() > cfg.max_contacts) act.resize(cfg.max_contacts);
         std::sort(act.begin(), act.end());
-        dbg_contacts.clear(); for (size_t i = 0; i < act.size(); ++i) dbg_contacts.push_back(cand[act[i]]);
+        std::vector<ContactPt> contacts;
+        for (size_t i = 0; i < act.size(); ++i) contacts.push_back(cand[act[i]]);
+        // self contacts: capsule model of every link, non-adjacent pairs in (i < j) order; they take the
+        // slots the ground contacts left, in pair order
+        if (cfg.enable_self_collision) {
+            std::vector<ContactPt> self; self_contacts(self);
+            for (size_t i = 0; i < self.size() && (int)contacts.size() < cfg.max_contacts; ++i) contacts.push_back(self[i]);
+        }
+        dbg_contacts = contacts;
 
         std::vector<Row> rows;
         const real big = (real)1e30;
@@ -348,17 +431,17 @@ struct Scene {
             r.b = (pen > 0) ? -pen / h : (real)-cfg.erp * pen / h;
             rows.push_back(r);
         }
-        int n_lim = (int)rows.size(), nc = (int)act.size();
-        const V3 n(0, 1, 0), t1(-1, 0, 0), t2(0, 0, 1);   // btPlaneSpace1((0,1,0))
+        int n_lim = (int)rows.size(), nc = (int)contacts.size();
         for (int c = 0; c < nc; ++c) {
-            const ContactPt& cp = cand[act[c]];
-            Row r; point_jacobian(cp.link, cp.x, n, r.J); r.normal_row = -1; r.mu = 0; r.lo = 0; r.hi = big; r.lam = 0;
+            const ContactPt& cp = contacts[c];
+            Row r; contact_jacobian(cp, cp.n, r.J); r.normal_row = -1; r.mu = 0; r.lo = 0; r.hi = big; r.lam = 0;
             r.b = (cp.dist > 0) ? -cp.dist / h : (real)-cfg.erp * cp.dist / h;
             rows.push_back(r);
         }
         for (int c = 0; c < nc; ++c) for (int d = 0; d < 2; ++d) {
-            const ContactPt& cp = cand[act[c]];
-            Row r; point_jacobian(cp.link, cp.x, d ? t2 : t1, r.J); r.normal_row = n_lim + c; r.mu = (real)cfg.friction; r.lo = r.hi = 0; r.lam = 0; r.b = 0;
+            const ContactPt& cp = contacts[c];
+            V3 t1, t2; plane_space(cp.n, t1, t2);      // btPlaneSpace1: (-1,0,0), (0,0,1) for the ground normal
+            Row r; contact_jacobian(cp, d ? t2 : t1, r.J); r.normal_row = n_lim + c; r.mu = (real)cfg.friction; r.lo = r.hi = 0; r.lam = 0; r.b = 0;
             rows.push_back(r);
         }
         const int R = (int)rows.size(); dbg_num_rows = R;

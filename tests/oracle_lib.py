@@ -11,7 +11,7 @@ ORACLE_DIR = os.path.join(ROOT, "oracle")
 CFG_KEYS = ["num_sim_substeps", "world_scale", "grav_x", "grav_y", "grav_z", "sync_root_pos", "sync_root_rot",
             "enable_fall_end", "enable_contact_fall", "enable_root_rot_fail", "enable_rand_placement",
             "enable_phase_input", "record_world_root_pos", "record_world_root_rot", "query_rate",
-            "friction", "erp", "solver_iters", "max_contacts"]
+            "friction", "erp", "solver_iters", "max_contacts", "self_collision"]
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int)
@@ -192,6 +192,15 @@ class Oracle:
 
     def num_contacts(self):
         return int(self.lib.orc_dbg_num_contacts(self.h))
+
+    def contact_list(self):
+        n = self.num_contacts()
+        out = np.zeros((max(n, 1), 9))
+        self.lib.orc_dbg_contacts(self.h, _d(out))
+        return out[:n]
+
+    def num_self_contacts(self):
+        return int(self.lib.orc_dbg_num_self_contacts(self.h))
 
     def links(self):
         out = np.zeros((self.J, 21))

@@ -114,6 +114,7 @@ def check_substep(name, precision, lib_path, tol_vel, tol_pose, lift=0.0, n=8):
     env.probe(1, DT / 2)
     st = env.get_state(); rows = env.debug("rows")
     tot_contacts = 0
+    check_substep.self_contacts = 0
     for e in range(n):
         o.set_sim_state(P[e], V[e])
         tp = np.zeros(o.P); tp[idx] = tau[e]; o.set_tau(tp)
@@ -121,6 +122,7 @@ def check_substep(name, precision, lib_path, tol_vel, tol_pose, lift=0.0, n=8):
         p2, v2 = o.sim_state()
         assert int(rows[e][0]) == o.num_rows() and int(rows[e][1]) == o.num_contacts()
         tot_contacts += o.num_contacts()
+        check_substep.self_contacts += o.num_self_contacts()
         vtol = tol_vel * max(1.0, np.abs(v2).max())          # relative: deep penetration yields large push-out velocities
         assert np.abs(st["vel"][e] - v2).max() < vtol, (e, np.abs(st["vel"][e] - v2).max(), np.abs(v2).max())
         assert np.abs(st["pose"][e] - p2).max() < tol_pose * max(1.0, np.abs(v2).max()), np.abs(st["pose"][e] - p2).max()

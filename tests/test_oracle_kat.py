@@ -79,11 +79,12 @@ def test_record_state_layout_of_reset_pose(hum):
 
 
 def test_free_fall_com_acceleration(hum, dog):
-    """No contact, no torque.  From rest the COM gains exactly g*h in one substep; in motion the total linear momentum
+    """No ground contact, no torque (the dog's reference poses do carry self contacts: internal forces, which must not move
+    the COM).  From rest the COM gains exactly g*h in one substep; in motion the total linear momentum
     (COM velocity at the new pose and velocity) changes by m*g*h up to the O(h^2) error of the semi-implicit step."""
     h = 1.0 / 1200
     g = np.array([0, -9.8 * h, 0])
-    for t, o in (hum, dog):
+    for t, o in (hum, (dog[0], Oracle(dog[0], self_collision=0))):
         o.reset(0.2)
         p, v = o.sim_state(); p[1] += 2.0
         rng = np.random.default_rng(0); v = v + 0.5 * rng.normal(size=v.shape) * (v != 0)
@@ -95,6 +96,32 @@ def test_free_fall_com_acceleration(hum, dog):
             p1, v1 = o.sim_state()
             _, vc1 = o.calc_com(p1, v1)
             assert np.abs((vc1 - vc0) - g).max() < tol
+
+
+def test_self_contact_forces_are_internal(oracle_built):
+    """Self contacts (tail against the rear thighs in the dog's reference pose) act with equal and opposite impulses: the
+    COM of an airborne character still gains exactly g*h.  (erp is lowered so that the 2 cm overlap of the mocap pose does
+    not drive a joint into the 100 rad/s coordinate-velocity clamp, which is the one thing that may leak momentum.)"""
+    h = 1.0 / 1200
+    t = model.load_asset("dog3d_pace")
+    o = Oracle(t, erp=0.001)
+    o.reset(0.2)
+    p, v = o.sim_state(); p[1] += 2.0; v[:] = 0
+    o.set_sim_state(p, v); o.set_tau(np.zeros(o.P))
+    _, vc0 = o.calc_com(p, v)
+    o.substep(h)
+    assert o.num_self_contacts() >= 1 and o.num_contacts() == o.num_self_contacts()
+    cl = o.contact_list()
+    assert set((int(c[0]), int(c[1])) for c in cl) <= {(13, 21), (17, 21)} and (cl[:, 2] < 0).all()
+    assert np.abs(np.linalg.norm(cl[:, 6:9], axis=1) - 1).max() < 1e-12
+    p1, v1 = o.sim_state()
+    assert np.abs(v1).max() < 50
+    _, vc1 = o.calc_com(p, v1)                 # momentum at the substep's own pose: isolates the velocity update
+    assert np.abs((vc1 - vc0) - np.array([0, -9.8 * h, 0])).max() < 1e-12
+    # and with self collision switched off nothing touches
+    o2 = Oracle(t, self_collision=0)
+    o2.reset(0.2); o2.set_sim_state(p, v); o2.set_tau(np.zeros(o2.P)); o2.substep(h)
+    assert o2.num_contacts() == 0
 
 
 def test_mirror_symmetry_of_kinetic_energy(hum):

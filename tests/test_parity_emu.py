@@ -6,6 +6,8 @@ import numpy as np
 import pytest
 
 import parity_common as pc
+from deepmimic_amd import model
+from deepmimic_amd.core import BatchEnv
 
 
 @pytest.mark.parametrize("name", ["humanoid3d_walk", "dog3d_pace"])
@@ -83,3 +85,20 @@ def test_root_heading_sync_dog_spin_fp64(emu_lib):
     pc.check_reset_and_query("dog3d_spin", 64, emu_lib, tol_state=1e-12, tol_reward=1e-6)
     dr, ds, ok = pc.rollout_compare("dog3d_spin", 64, emu_lib, steps=30)      # clip = 0.73 s: one wrap
     assert ok and dr.max() < 1e-6 and ds.max() < 1e-4
+
+
+# ---- self collision (capsule model)
+@pytest.mark.parametrize("name,n", [("humanoid3d_backflip", 24), ("dog3d_spin", 8)])
+def test_substep_with_self_contacts_fp64(emu_lib, name, n):
+    """tucked backflip poses (wrist against knee / shin) and the dog's tail-thigh overlap: rows with two-link Jacobians"""
+    pc.check_substep(name, 64, emu_lib, tol_vel=1e-8, tol_pose=1e-10, lift=1.0, n=n)
+    assert pc.check_substep.self_contacts > 0
+
+
+def test_self_collision_switch(emu_lib):
+    t = model.load_asset("dog3d_pace")
+    on = BatchEnv(t, 1, precision=64, lib_path=emu_lib); off = BatchEnv(t, 1, precision=64, lib_path=emu_lib, self_collision=False)
+    for e in (on, off):
+        e.reset(kin_times=[0.2], max_times=np.inf)
+        e.step(None, pc.DT, 1, open_loop=True)
+    assert np.abs(on.get_state()["vel"] - off.get_state()["vel"]).max() > 1e-3

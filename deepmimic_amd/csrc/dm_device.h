@@ -592,24 +592,27 @@ struct EnvSim {
         const v3 d1 = (Real)-2 * ui, d2 = (Real)-2 * uj, r = p1 - p2;
         const Real eps = (Real)1e-12;
         const Real a = dot(d1, d1), e = dot(d2, d2), f = dot(d2, r);
+        // reciprocals once (fp32: v_rcp_f32 + Newton step), clamps by v_med3
+        const Real ia = (a > eps) ? dm_rcp(a) : (Real)0, ie = (e > eps) ? dm_rcp(e) : (Real)0;
         Real sp, tp;
         if (a <= eps && e <= eps) { sp = 0; tp = 0; }
-        else if (a <= eps) { sp = 0; tp = dm_min((Real)1, dm_max((Real)0, f / e)); }
+        else if (a <= eps) { sp = 0; tp = dm_med3((Real)0, f * ie, (Real)1); }
         else {
             const Real c = dot(d1, r);
-            if (e <= eps) { tp = 0; sp = dm_min((Real)1, dm_max((Real)0, -c / a)); }
+            if (e <= eps) { tp = 0; sp = dm_med3((Real)0, -c * ia, (Real)1); }
             else {
                 const Real b = dot(d1, d2), denom = a * e - b * b;
-                sp = (denom > eps) ? dm_min((Real)1, dm_max((Real)0, (b * f - c * e) / denom)) : (Real)0;
-                tp = (b * sp + f) / e;
-                if (tp < 0) { tp = 0; sp = dm_min((Real)1, dm_max((Real)0, -c / a)); }
-                else if (tp > 1) { tp = 1; sp = dm_min((Real)1, dm_max((Real)0, (b - c) / a)); }
+                sp = (denom > eps) ? dm_med3((Real)0, (b * f - c * e) * dm_rcp(denom), (Real)1) : (Real)0;
+                tp = (b * sp + f) * ie;
+                if (tp < 0) { tp = 0; sp = dm_med3((Real)0, -c * ia, (Real)1); }
+                else if (tp > 1) { tp = 1; sp = dm_med3((Real)0, (b - c) * ia, (Real)1); }
             }
         }
         const v3 ca = p1 + sp * d1, cb = p2 + tp * d2, dl = ca - cb;
-        const Real d = norm(dl), ri = ci[3], rj = cj[3];
+        const Real d2n = dot(dl, dl), ri = ci[3], rj = cj[3];
+        const Real idn = (d2n > (Real)1e-18) ? dm_rsqrt(d2n) : (Real)0, d = d2n * idn;
         dist = d - ri - rj;
-        n = (d > (Real)1e-9) ? ((Real)1 / d) * dl : mk3((Real)0, (Real)1, (Real)0);
+        n = (d > (Real)1e-9) ? idn * dl : mk3((Real)0, (Real)1, (Real)0);
         x = (Real)0.5 * ((ca - ri * n) + (cb + rj * n));
         return dist < dm_min(s.mdl.thresh[i], s.mdl.thresh[j]);
     }

@@ -26,12 +26,12 @@ rows = list(csv.reader(open(os.path.join(src, "stats", "stats_kernel_stats.csv")
 with open(os.path.join(dst, out + "_rocprofv3_kernel_stats.csv"), "w", newline="") as f:
     csv.writer(f).writerows(rows[:6])
 # 2. bench lines
-for name in ("bench.json", "bench_spinkick.json", "bench_dog.json"):
+for name in ("bench.json", "bench_spinkick.json", "bench_dog.json", "bench_pack1.json"):
     shutil.copy(os.path.join(src, name), os.path.join(dst, out + "_" + name))
 shutil.copy(os.path.join(src, "phases.json"), os.path.join(dst, out + "_phase_cycles.json"))
 # 3. PMC passes
 n = json.load(open(os.path.join(src, "bench.json")))["config"]["envs_per_gpu"]
-pmc = {"envs": n, "note": "per-launch means of k_env_step<float, ClsBiped, false>, 4096 waves; SQ_*_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* are quad-cycles (MI355X_MICROARCH.md)"}
+pmc = {"envs": n, "note": "per-launch means of the step kernel of the default bench (k_env_step_duo<float, false>: 2048 waves, two characters each); SQ_*_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* are quad-cycles (MI355X_MICROARCH.md)"}
 for d in ("pmc_sq", "pmc_sq2"):
     a = agg(os.path.join(src, d, "pmc_counter_collection.csv"))
     for k in a[0]:

@@ -10,6 +10,7 @@ python __graft_entry__.py smoke > $OUT/smoke.log 2>&1
 python bench.py --steps 300 --warmup 30 > $OUT/bench.json 2> $OUT/bench.err
 python bench.py --steps 100 --warmup 10 --scene humanoid3d_spinkick --no-cpu-baseline > $OUT/bench_spinkick.json 2>> $OUT/bench.err
 python bench.py --steps 100 --warmup 10 --scene dog3d_pace --no-cpu-baseline > $OUT/bench_dog.json 2>> $OUT/bench.err
+python bench.py --steps 300 --warmup 30 --wave-packing 1 --no-cpu-baseline > $OUT/bench_pack1.json 2>> $OUT/bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o stats -- python bench.py --steps 100 --warmup 10 --no-cpu-baseline > $OUT/stats.log 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d $OUT/pmc_sq -o pmc -- python bench.py --steps 6 --warmup 2 --no-cpu-baseline > $OUT/pmc_sq.log 2>&1
 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_INSTS_VMEM SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_WAIT_INST_LDS --kernel-trace --output-format csv -d $OUT/pmc_sq2 -o pmc -- python bench.py --steps 6 --warmup 2 --no-cpu-baseline > $OUT/pmc_sq2.log 2>&1

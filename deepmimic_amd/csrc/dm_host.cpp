@@ -486,7 +486,8 @@ int dm_create(const dm_create_info* info, const dm_scene_tables* tables, dm_ctx*
     c->stream = c->own_stream;
 #endif
     if (info->wave_packing != 0 && info->wave_packing != 1 && info->wave_packing != 2) { delete c; return fail("wave_packing must be 0, 1 or 2"); }
-    { const char* dv = getenv("DM_DUO"); c->duo = info->wave_packing == 2 || (info->wave_packing == 0 && dv && dv[0] == '1'); }
+    // two characters per wavefront is the default for the biped class (step() falls back for odd batches and armed taps)
+    { const char* dv = getenv("DM_DUO"); c->duo = info->wave_packing == 2 || (info->wave_packing == 0 && !(dv && dv[0] == '0')); }
     if (c->setup() != 0) { delete c; return -1; }
     dm_ctx* ctx = new dm_ctx(); ctx->c = c; *out = ctx;
     return dm_reset(ctx, nullptr, 0, nullptr, nullptr);

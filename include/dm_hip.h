@@ -25,8 +25,8 @@ typedef struct {
     int precision;           /* 32 (default, production) or 64 (algorithm-parity build of the same kernels) */
     int max_contacts;        /* manifold cap per character, <= 20 (0 -> 20) */
     int env_id_offset;       /* global id of env 0 (multi-GPU shards keep global RNG streams) */
-    int wave_packing;        /* characters per wavefront of the step kernel: 0 = default (env DM_DUO, else 1), 1, or 2 (biped class,
-                                even num_envs; same results up to fp rounding, dm_device_duo.h) */
+    int wave_packing;        /* characters per wavefront of the step kernel: 0 = default (2 where possible; env DM_DUO=0 -> 1), 1, or
+                                2 (biped class, even num_envs; same results up to fp rounding, dm_device_duo.h) */
 } dm_create_info;
 
 /* Raw scene tables in the reference's in-memory layout (all host pointers, copied at create time). */

@@ -18,7 +18,7 @@ dist.init_process_group("gloo")
 rank, world = dist.get_rank(), dist.get_world_size()
 total = int(os.environ["DM_TOTAL"])
 t = model.load_asset("humanoid3d_walk")
-sh = ShardedEnv(t, total, rank=rank, world=world, device_id=0, seed=11, precision=64, lib_path=os.environ["DM_HIP_LIB"])
+sh = ShardedEnv(t, total, rank=rank, world=world, device_id=0, seed=11, precision=64, lib_path=os.environ["DM_HIP_LIB"], wave_packing=1)
 sh.env.reset()
 recs = []
 for k in range(2):
@@ -51,10 +51,11 @@ def test_two_rank_gloo_matches_single_process(emu_lib, tmp_path):
     subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                            "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)], env=env, timeout=600)
     got = np.load(out)
-    # single process, all envs in one shard: trajectories must not depend on the partition
+    # single process, all envs in one shard: trajectories must not depend on the partition (one character per wave on both
+    # sides: the two-per-wave kernel sums in a different order, so shards of different parity would differ in the last bits)
     from deepmimic_amd import model
     from deepmimic_amd.dist import ShardedEnv
-    sh = ShardedEnv(model.load_asset("humanoid3d_walk"), total, rank=0, world=1, device_id=0, seed=11, precision=64, lib_path=emu_lib)
+    sh = ShardedEnv(model.load_asset("humanoid3d_walk"), total, rank=0, world=1, device_id=0, seed=11, precision=64, lib_path=emu_lib, wave_packing=1)
     sh.env.reset()
     for k in range(2):
         o = sh.env.step(None, 1.0 / 600, 20, open_loop=True, auto_reset=True)

@@ -195,16 +195,19 @@ namespace dmk {
 template <typename Real, typename C>
 struct Lds {
     static constexpr int NJ = C::NJ, ND = C::ND, NP = C::NP, NCAP = C::NCAP;
-    // Lower-triangular storage of H / its Cholesky factor: row k holds k+1 entries padded to a multiple of 4 (16-B aligned
-    // rows for ds_read_b128 broadcasts); the diagonal slot holds 1/L_kk after the factorisation.
-    static constexpr int lrow(int k) { return 4 * (k / 4 + 1) * (2 * (k / 4) + (k % 4)); }
+    // Lower-triangular storage of H / its Cholesky factor: row k holds k+1 entries padded to a multiple of LPAD (4: 16-B
+    // aligned rows for ds_read_b128 broadcasts; 2 for the large class, which trades them for 8-B reads to fit 8 waves per CU);
+    // the diagonal slot holds 1/L_kk after the factorisation.
+    static constexpr int LPAD = C::LPAD;
+    // offset of row k = sum_{i<k} LPAD * ceil((i+1)/LPAD) = LPAD * (q (q+1) / 2 * LPAD + r (q+1)), q = k / LPAD, r = k % LPAD
+    static constexpr int lrow(int k) { return LPAD * ((k / LPAD) * (k / LPAD + 1) / 2 * LPAD + (k % LPAD) * (k / LPAD + 1)); }
     static constexpr int kLWords = lrow(ND);
     MdlLds<Real, C> mdl;
     Real pose[NP], vel[NP], tar[NP];
     Real tau[ND], rhs[ND];                 // (bias force: dofrec[k][7]; SPD force xs: aliases Ic, see EnvSim::xs)
     alignas(32) Real dofrec[ND][8];        // per dof: world axis a(3), g = (p_joint - p_root) x a (3), unconstrained velocity v*, bias force C
     Real R[NJ][9], p[NJ][3], com[NJ][3], w[NJ][3], vj[NJ][3], al[NJ][3], aj[NJ][3];
-    Real Rb[C::ROT ? NJ : 1][C::ROT ? 9 : 1];   // body frames (== R when the class has no attach rotations)
+    Real Rb[C::ROT ? kMaxRotLinks : 1][C::ROT ? 9 : 1];   // body frames of the links whose body rotation is not the identity (== R when the class has no attach rotations)
     union alignas(32) {
         struct { Real f[NJ][3], n[NJ][3], Iw[NJ][6], Fs[NJ][3], Ns[NJ][3], Ic[NJ][10]; };   // Newton-Euler pass (dynamics)
         struct { int csel[NCAP]; Real cdistc[NCAP];                                          // manifold-reduction scratch (by candidate)
@@ -241,7 +244,11 @@ struct EnvSim {
     DM_DEV Real* scratch() const { return &s.Lt[0]; }   // L is dead outside the update loop: kin pose / vel / reductions live there
     DM_DEV Real& Lx(int r, int c) const { return s.Lt[L::lrow(r) + c]; }
     DM_DEV Real* xs() const { return &s.Ic[0][0]; }     // SPD joint forces Kp e + Kd e_v: alive from spd_rhs_pre to spd_post, while Ic is dead
-    DM_DEV const Real* Rbp(int j) const { return C::ROT ? s.Rb[j] : s.R[j]; }
+    // world body frame of link j: its joint frame unless the link carries a body attach rotation (ClsLarge, compact table)
+    DM_DEV const Real* Rbp(int j) const {
+        if (C::ROT) { const int bo = s.mdl.rot_idx[C::ROT ? j : 0] & 15; if (bo) return s.Rb[C::ROT ? bo - 1 : 0]; }
+        return s.R[j];
+    }
     static DM_DEV v3 zero3() { return mk3((Real)0, (Real)0, (Real)0); }
 
     // ------------------------------------------------------------------ HBM <-> LDS
@@ -304,7 +311,7 @@ struct EnvSim {
                     m3 Rp = ldm3(s.R[par]);
                     v3 r = Rp * ld3(s.mdl.attach[l]);
                     pj = ld3(s.p[par]) + r;
-                    if (C::ROT && !DM_LI_AROT_ID(li)) Rp = Rp * ldm3(s.mdl.attach_rot[C::ROT ? l : 0]);
+                    if (C::ROT && !DM_LI_AROT_ID(li)) Rp = Rp * ldm3(s.mdl.attach_rot[C::ROT ? ((s.mdl.rot_idx[C::ROT ? l : 0] >> 4) & 15) - 1 : 0]);
                     Rj = Rp * Rl;
                     v3 wp = ld3(s.w[par]), alp = ld3(s.al[par]);
                     v3 wrel = Rj * wl;
@@ -315,7 +322,7 @@ struct EnvSim {
                 }
                 stm3(s.R[l], Rj); st3(s.p[l], pj); st3(s.w[l], w); st3(s.vj[l], vj); st3(s.al[l], al); st3(s.aj[l], aj);
                 st3(s.com[l], pj + Rj * ld3(s.mdl.battach[l]));
-                if (C::ROT) stm3(s.Rb[C::ROT ? l : 0], DM_LI_BROT_ID(li) ? Rj : Rj * ldm3(s.mdl.brot[C::ROT ? l : 0]));
+                if (C::ROT && !DM_LI_BROT_ID(li)) { const int bo = (s.mdl.rot_idx[C::ROT ? l : 0] & 15) - 1; stm3(s.Rb[C::ROT ? bo : 0], Rj * ldm3(s.mdl.brot[C::ROT ? bo : 0])); }
             }
             sync();
         }
@@ -414,11 +421,15 @@ struct EnvSim {
         }
         v3 Lq = Lp + cross(ld3(s.p[dj]) - ld3(s.p[0]), Pm);
         Real* row = &s.Lt[L::lrow(k)];
-        {   // zero the row with 16-B stores (rows are padded to a multiple of 4)
+        if (L::LPAD == 4) {   // zero the row with 16-B stores (rows are padded to a multiple of 4)
             const R4 z4 = {(Real)0, (Real)0, (Real)0, (Real)0};
             for (int j = 0; j <= k; j += 4) *reinterpret_cast<R4*>(&row[j]) = z4;
+        } else {
+            const R2 z2 = {(Real)0, (Real)0};
+            for (int j = 0; j <= k; j += 2) *reinterpret_cast<R2*>(&row[j]) = z2;
         }
-        uint32_t lo = s.mdl.anc_lo[k], hi = s.mdl.anc_hi[k];
+        // ancestor-or-self dofs j <= k: the chain of the dof's joint, cut at k
+        uint32_t lo = s.mdl.chain_lo[dj] & ((k < 31) ? ((2u << k) - 1u) : ~0u), hi = (k < 32) ? 0u : (s.mdl.chain_hi[dj] & ((k < 63) ? ((2u << (k - 32)) - 1u) : ~0u));
         // two ancestors per trip: both record gathers are in flight before either is consumed
         while (lo | hi) {
             int j0, j1 = -1;
@@ -427,8 +438,8 @@ struct EnvSim {
             const Real* r0 = s.dofrec[j0]; const Real* r1 = s.dofrec[j1 < 0 ? j0 : j1];
             Real v0 = r0[0] * Lq.x + r0[1] * Lq.y + r0[2] * Lq.z + r0[3] * Pm.x + r0[4] * Pm.y + r0[5] * Pm.z;
             Real v1 = r1[0] * Lq.x + r1[1] * Lq.y + r1[2] * Lq.z + r1[3] * Pm.x + r1[4] * Pm.y + r1[5] * Pm.z;
-            if (j0 == k) v0 += diag_scale * s.mdl.kd[k];
-            if (j1 == k) v1 += diag_scale * s.mdl.kd[k];
+            if (j0 == k) v0 += diag_scale * s.mdl.kd[dj];
+            if (j1 == k) v1 += diag_scale * s.mdl.kd[dj];
             row[j0] = v0;
             if (j1 >= 0) row[j1] = v1;
         }
@@ -547,11 +558,11 @@ struct EnvSim {
                 q4 dq = quat_diff_mul(q, om);
                 q4 qh = qnormalize(mkq(q.w + dt * dq.w, q.x + dt * dq.x, q.y + dt * dq.y, q.z + dt * dq.z));
                 v3 e = quat_to_rotvec(qmul(qconj(qh), ldq(s.tar + off)), (Real)0.000001);
-                for (int k = 0; k < 3; ++k) xs()[dof + k] = s.mdl.kp[dof + k] * comp(e, k) + s.mdl.kd[dof + k] * (-s.vel[off + k]);
+                for (int k = 0; k < 3; ++k) xs()[dof + k] = s.mdl.kp[l] * comp(e, k) + s.mdl.kd[l] * (-s.vel[off + k]);
             } else if (jt == JT_REVOLUTE) {
                 Real th = normalize_angle(s.pose[off]);
                 Real e = s.tar[off] - (th + dt * s.vel[off]);
-                xs()[dof] = s.mdl.kp[dof] * e + s.mdl.kd[dof] * (-s.vel[off]);
+                xs()[dof] = s.mdl.kp[l] * e + s.mdl.kd[l] * (-s.vel[off]);
             }
         }
         if (l < 6) xs()[l] = 0;
@@ -559,7 +570,7 @@ struct EnvSim {
     }
     // rhs holds qddot: tau = Kp e + Kd (e_v - dt qddot), clamped per joint (SimBodyJoint.cpp:299-307)
     DM_DEV void spd_post(Real dt) {
-        for (int i = l; i < m.D; i += LW) s.tau[i] = (i < 6) ? (Real)0 : xs()[i] - s.mdl.kd[i] * dt * s.rhs[i];
+        for (int i = l; i < m.D; i += LW) s.tau[i] = (i < 6) ? (Real)0 : xs()[i] - s.mdl.kd[DM_DI_JOINT(s.mdl.dof_info[i])] * dt * s.rhs[i];
         sync();
         spd_clamp();
     }
@@ -1019,7 +1030,7 @@ struct EnvSim {
         mark(ph == 0 ? 2 : 6);
         if (TAPS && dbg.H) {
             const int D = m.D;
-            for (int i = l; i < D * D; i += LW) { int r = i / D, c = i % D; Real v = (c <= r) ? Lx(r, c) : Lx(c, r); if (r == c && ph == 0) v -= dt * s.mdl.kd[r]; dbg.H[(size_t)e * D * D + i] = v; }
+            for (int i = l; i < D * D; i += LW) { int r = i / D, c = i % D; Real v = (c <= r) ? Lx(r, c) : Lx(c, r); if (r == c && ph == 0) v -= dt * s.mdl.kd[DM_DI_JOINT(s.mdl.dof_info[r])]; dbg.H[(size_t)e * D * D + i] = v; }
             if (l < D) dbg.C[(size_t)e * D + l] = s.dofrec[l][7];
         }
         if (tap_only) return;

@@ -448,7 +448,7 @@ struct DuoSim {
             DM_OPAQUE_V(hl); DM_OPAQUE_V(b.l); DM_OPAQUE_V(b.li);
             if (ph == 0) {
                 b.mark(3);
-                for (int k = hl; k < D; k += HW) s.tau[k] = (k < 6) ? (Real)0 : b.xs()[k] - s.mdl.kd[k] * rdt * s.rhs[k];
+                for (int k = hl; k < D; k += HW) s.tau[k] = (k < 6) ? (Real)0 : b.xs()[k] - s.mdl.kd[DM_DI_JOINT(s.mdl.dof_info[k])] * rdt * s.rhs[k];
                 sync();
                 b.spd_clamp();
             } else if (!substep_post(h)) {

@@ -294,13 +294,21 @@ struct CtxT : CtxBase {
                                           b->inertia[0][j][k] = (Real)h.inertia[(0 * h.J + j) * 3 + k]; b->inertia[1][j][k] = (Real)h.inertia[(1 * h.J + j) * 3 + k]; }
             b->mass[j] = (Real)h.mass[j]; b->thresh[j] = (Real)h.thresh[j]; b->torque_lim[j] = (Real)h.torque_lim[j];
             for (int k = 0; k < 4; ++k) b->cap[j][k] = (Real)h.cap[j * 4 + k];
-            if (C::ROT) for (int k = 0; k < 9; ++k) { b->attach_rot[C::ROT ? j : 0][k] = (Real)h.attach_rot[j * 9 + k]; b->brot[C::ROT ? j : 0][k] = (Real)h.brot[j * 9 + k]; }
+            b->kp[j] = (j > 0 && h.ndof[j] > 0) ? (Real)h.kp[h.dof_off[j]] : (Real)0; b->kd[j] = (j > 0 && h.ndof[j] > 0) ? (Real)h.kd[h.dof_off[j]] : (Real)0;
+        }
+        if (C::ROT) {
+            int nb = 0, na = 0;
+            for (int j = 0; j < h.J; ++j) {
+                int idx = 0;
+                if (!h.brot_ident[j]) { if (nb >= kMaxRotLinks) { delete b; *words = 0; fail("more than 4 links with a body attach rotation"); return nullptr; }
+                                        for (int k = 0; k < 9; ++k) b->brot[C::ROT ? nb : 0][k] = (Real)h.brot[j * 9 + k]; idx |= ++nb; }
+                if (!h.arot_ident[j]) { if (na >= kMaxRotLinks) { delete b; *words = 0; fail("more than 4 joints with an attach rotation"); return nullptr; }
+                                        for (int k = 0; k < 9; ++k) b->attach_rot[C::ROT ? na : 0][k] = (Real)h.attach_rot[j * 9 + k]; idx |= (++na) << 4; }
+                b->rot_idx[C::ROT ? j : 0] = idx;
+            }
         }
         for (int i = 0; i < h.D; ++i) {
             b->dof_info[i] = h.dof_joint[i] | (h.dof_kind[i] << 8) | (h.dof_axis[i] << 10) | (h.dof_vidx[i] << 12);
-            uint64_t anc = h.dof_anc[i] & ((i == 63) ? ~0ull : ((1ull << (i + 1)) - 1));     // ancestor-or-self dofs k <= i
-            b->anc_lo[i] = (uint32_t)(anc & 0xffffffffull); b->anc_hi[i] = (uint32_t)(anc >> 32);
-            b->kp[i] = (Real)h.kp[i]; b->kd[i] = (Real)h.kd[i];
         }
         for (int r = 0; r < h.NL; ++r) { int j = h.lim_joint[r]; b->lim_joint[r] = j; b->lim_lo[r] = (Real)h.lim_lo[j]; b->lim_hi[r] = (Real)h.lim_hi[j]; }
         const size_t bytes = (sizeof(*b) + 3) / 4 * 4;
@@ -316,7 +324,7 @@ struct CtxT : CtxBase {
         md.J = h.J; md.P = h.P; md.D = h.D; md.A = h.A; md.S = h.S; md.F = h.F; md.NC = h.NC; md.NL = h.NL; md.max_depth = h.max_depth;
         bool any_rot = false;
         for (int j = 0; j < h.J; ++j) if (!h.arot_ident[j] || !h.brot_ident[j]) any_rot = true;
-        if (h.NL > kMaxLim) return fail("more than 8 joint-limit rows");
+        if (h.NL > kMaxLim) return fail("more than 4 joint-limit rows");
         if (h.J <= ClsBiped::NJ && h.D <= ClsBiped::ND && h.P <= ClsBiped::NP && h.NC <= ClsBiped::NCAP && !any_rot) cls = 0;
         else if (h.J <= ClsLarge::NJ && h.D <= ClsLarge::ND && h.P <= ClsLarge::NP && h.NC <= ClsLarge::NCAP) cls = 1;
         else return fail("character too large for the compiled kernel classes (J<=23, D<=64, P<=83, <=128 contact candidates)");

@@ -18,15 +18,16 @@ enum { TERM_NULL = 0, TERM_FAIL = 1, TERM_SUCC = 2 };
 
 constexpr int kWave = 64;
 constexpr int kMaxRows = 64;   // constraint rows per substep (one per lane)
-constexpr int kMaxLim = 8;     // joint-limit rows (revolute joints with lo <= hi)
+constexpr int kMaxLim = 4;     // joint-limit rows (revolute joints with lo <= hi): knees / elbows of the shipped characters
+constexpr int kMaxRotLinks = 4; // links with a non-identity body (or joint attach) rotation, ClsLarge
 constexpr int kMaxContacts = 20;   // contact slots per character (ground + self): kMaxLim/NL + 3 * 20 <= kMaxRows
 
 // Compiled kernel classes: static bounds of the per-lane register arrays and the LDS record.
 struct ClsBiped {      // humanoid3d: 15 links, 34 dof, 43 pose dims, <= 64 ground-contact candidates, no attach rotations
-    static constexpr int NJ = 15, ND = 34, NP = 43, NCAP = 64, RREG = 32, NPAIRCAP = 128; static constexpr bool ROT = false;   // RREG: rows of A kept in VGPRs
+    static constexpr int NJ = 15, ND = 34, NP = 43, NCAP = 64, RREG = 32, NPAIRCAP = 128, LPAD = 4; static constexpr bool ROT = false;   // RREG: rows of A kept in VGPRs
 };
 struct ClsLarge {      // dog3d and anything up to 23 links / 64 dof / 83 pose dims / 128 candidates, attach rotations allowed
-    static constexpr int NJ = 23, ND = 64, NP = 83, NCAP = 128, RREG = 64, NPAIRCAP = 256; static constexpr bool ROT = true;
+    static constexpr int NJ = 23, ND = 64, NP = 83, NCAP = 128, RREG = 64, NPAIRCAP = 256, LPAD = 2; static constexpr bool ROT = true;
 };
 
 // link_info word: parent+1 [0:4] | jtype [5:7] | depth [8:11] | pose_off [12:18] | dof_off [19:25] | arot_ident 26 | brot_ident 27 | is_ee 28 | fall 29
@@ -57,11 +58,13 @@ struct MdlLds {
     Real inertia[2][C::NJ][3];                 // principal inertias: [0] SPD model, [1] simulator model
     Real thresh[C::NJ], torque_lim[C::NJ];
     Real cap[C::NJ][4];                        // self-collision capsule of the link: half segment c0 (body frame, c1 = -c0), radius
-    Real attach_rot[C::ROT ? C::NJ : 1][C::ROT ? 9 : 1];    // joint attach rotation (ClsLarge only)
-    Real brot[C::ROT ? C::NJ : 1][C::ROT ? 9 : 1];          // body frame in the joint frame (ClsLarge only)
+    // rotations (ClsLarge only), compact: rot_idx[j] = (ordinal + 1 of the link's body rotation) | (same for its joint attach
+    // rotation) << 4, 0 = identity; at most kMaxRotLinks links of either kind
+    int rot_idx[C::ROT ? C::NJ : 1];
+    Real attach_rot[C::ROT ? kMaxRotLinks : 1][C::ROT ? 9 : 1];
+    Real brot[C::ROT ? kMaxRotLinks : 1][C::ROT ? 9 : 1];
     int dof_info[C::ND];
-    uint32_t anc_lo[C::ND], anc_hi[C::ND];     // bit k: dof k belongs to an ancestor-or-self joint of dof i's joint, k <= i
-    Real kp[C::ND], kd[C::ND];
+    Real kp[C::NJ], kd[C::NJ];                 // PD gains per joint (every dof of a joint shares them; root 0)
     int lim_joint[kMaxLim]; Real lim_lo[kMaxLim], lim_hi[kMaxLim];
 };
 

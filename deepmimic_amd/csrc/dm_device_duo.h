@@ -141,43 +141,61 @@ struct DuoSim {
             if (!valid) { v[0] = 0; v[1] = 0; }
             h2[p] = v;
         }
-        // Two columns per LDS round trip: column k+1 only needs L[k+1][k] from column k (one in-register broadcast), then both
-        // columns are published together and the trailing rank-2 update reads them back as wave-uniform broadcasts.
-        Real* colbuf = &s.f[0][0];                       // 2 columns x 40 words per character (aliases the dead Newton-Euler sums)
+        // Two columns per block, software-pipelined: the block's two columns are published through LDS for the trailing rank-2
+        // update, but the NEXT block's pivot pair is brought up to date from registers (four in-register broadcasts of the
+        // entries L[k+2..k+3][k..k+1]), so the pivot chain (broadcast, rsq, Newton step) never waits on the LDS round trip; the
+        // trailing update of block k runs behind the pivot computation of block k+2.
+        Real* colbuf = &s.f[0][0];                       // 2 blocks x 2 columns x 40 words per character (aliases the dead Newton-Euler sums)
         const Real M = s.sc[7];                          // H_kk, k < 3: total mass (root Kd = 0)
         const Real dinv0 = dm_rsqrt(M);
         Real dinv = 1;
         sync();                                          // every lane has read what it needs from the aliased region
+        Real lik0, lik1;
+        // columns k, k+1 (k even) of this lane from the up-to-date pair h2[k/2]; publishes them into buffer (k/2)&1
+#define DM_DUO_COLS(k)                                                                                                  \
+        {                                                                                                               \
+            const int pk_ = (k) >> 1;                                                                                   \
+            const Real inv0_ = ((k) < 3) ? dinv0 : dm_rsqrt(half_bcast(h2[pk_][0], (k) - 3, half));                     \
+            lik0 = h2[pk_][0] * inv0_; h2[pk_][0] = lik0; if (own == (k)) dinv = inv0_;                                  \
+            const Real lk1k_ = ((k) + 1 < 3) ? (Real)0 : half_bcast(lik0, (k) + 1 - 3, half);                           \
+            h2[pk_][1] -= lik0 * lk1k_;                                                                                 \
+            const Real inv1_ = ((k) + 1 < 3) ? dinv0 : dm_rsqrt(half_bcast(h2[pk_][1], (k) + 1 - 3, half));             \
+            lik1 = h2[pk_][1] * inv1_; h2[pk_][1] = lik1; if (own == (k) + 1) dinv = inv1_;                              \
+            if ((k) + 2 < ND) {                                                                                         \
+                Real* cb0_ = colbuf + (pk_ & 1) * 80; Real* cb1_ = cb0_ + 40;                                           \
+                if (valid) { cb0_[own] = lik0; cb1_[own] = lik1; }                                                      \
+                if ((k) < 3 && hl == HW - 1) { cb0_[0] = 0; cb0_[1] = 0; cb0_[2] = 0; cb1_[0] = 0; cb1_[1] = 0; cb1_[2] = 0; } \
+            }                                                                                                           \
+        }
+        DM_DUO_COLS(0)
 #pragma unroll
         for (int k = 0; k < ND; k += 2) {
             const int pk = k >> 1;
-            // column k
-            Real inv0;
-            if (k < 3) inv0 = dinv0; else inv0 = dm_rsqrt(half_bcast(h2[pk][0], k - 3, half));
-            const Real lik0 = h2[pk][0] * inv0;
-            h2[pk][0] = lik0;
-            if (own == k) dinv = inv0;
-            // column k+1 after the rank-1 update by column k of its own entries: needs L[k+1][k] only
-            const Real lk1k = (k + 1 < 3) ? (Real)0 : half_bcast(lik0, k + 1 - 3, half);
-            h2[pk][1] -= lik0 * lk1k;
-            Real inv1;
-            if (k + 1 < 3) inv1 = dinv0; else inv1 = dm_rsqrt(half_bcast(h2[pk][1], k + 1 - 3, half));
-            const Real lik1 = h2[pk][1] * inv1;
-            h2[pk][1] = lik1;
-            if (own == k + 1) dinv = inv1;
+            const Real c0 = lik0, c1 = lik1;             // this block's columns (own entries)
             if (k + 2 < ND) {
-                Real* cb0 = colbuf + ((k >> 1) & 1) * 80, *cb1 = cb0 + 40;
-                if (valid) { cb0[own] = lik0; cb1[own] = lik1; }
-                if (k < 3 && hl == HW - 1) { cb0[0] = 0; cb0[1] = 0; cb0[2] = 0; cb1[0] = 0; cb1[1] = 0; cb1[2] = 0; }   // rows 1, 2: nothing left of the diagonal
+                // (1) the broadcast reads of this block's published columns are issued first ...
                 sync();
-                const R2 l20 = {lik0, lik0}, l21 = {lik1, lik1};
+                const Real* cb0 = colbuf + (pk & 1) * 80; const Real* cb1 = cb0 + 40;
+                R2 t0[NP2], t1[NP2];
 #pragma unroll
-                for (int p = pk + 1; p < NP2; ++p) {
-                    h2[p] -= l20 * *reinterpret_cast<const R2*>(&cb0[2 * p]) + l21 * *reinterpret_cast<const R2*>(&cb1[2 * p]);
+                for (int p = pk + 2; p < NP2; ++p) { t0[p] = *reinterpret_cast<const R2*>(&cb0[2 * p]); t1[p] = *reinterpret_cast<const R2*>(&cb1[2 * p]); }
+                // (2) ... then the look-ahead: entries (k+2, k+3) x (k, k+1) of L from the lanes that own rows k+2, k+3 (root rows
+                // hold zeros) bring the next pivot pair up to date, and the next block's columns are computed and published
+                const Real a = (k + 2 < 3) ? (Real)0 : half_bcast(c0, k + 2 - 3, half), c = (k + 2 < 3) ? (Real)0 : half_bcast(c1, k + 2 - 3, half);
+                const Real bq = half_bcast(c0, k + 3 - 3, half), d = half_bcast(c1, k + 3 - 3, half);
+                h2[pk + 1][0] -= c0 * a + c1 * c;
+                h2[pk + 1][1] -= c0 * bq + c1 * d;
+                DM_DUO_COLS(k + 2)
+                // (3) ... and the trailing rank-2 update of block k consumes the reads that landed meanwhile
+                const R2 l20 = {c0, c0}, l21 = {c1, c1};
+#pragma unroll
+                for (int p = pk + 2; p < NP2; ++p) {
+                    h2[p] -= l20 * t0[p] + l21 * t1[p];
                     DM_OPAQUE_V(h2[p]);                  // evaluated here, not sunk to the pivot that needs it
                 }
             }
         }
+#undef DM_DUO_COLS
         if (valid) {
             Real* row = &s.Lt[L::lrow(own)];
 #pragma unroll

@@ -334,27 +334,39 @@ struct DuoSim {
                 if (limdof < 32) ch_lo = 1u << limdof; else ch_hi = 1u << (limdof - 32);
             } else b.contact_row(hl, NL, nc, h, brow, ch_lo, ch_hi, ng_lo, ng_hi, xd, dd);
         }
+        // y := L^-1 J^T, software-pipelined: the factor row and the dof record of step k+1 are requested (LDS broadcasts) before
+        // the dependent accumulation chain of step k runs, so their latency hides behind it (two register buffers, static parity)
         R2 y2[NP2]; Real cvec = 0;
+        R2 lr[2][NP2]; R4 rr[2][2];
+#define DM_DUO_YLOAD(k)                                                                                       \
+        {                                                                                                     \
+            rr[(k) & 1][0] = *reinterpret_cast<const R4*>(&s.dofrec[(k)][0]);                                  \
+            rr[(k) & 1][1] = *reinterpret_cast<const R4*>(&s.dofrec[(k)][4]);                                  \
+            const R2* lrow_ = reinterpret_cast<const R2*>(&s.Lt[L::lrow(k)]);                                  \
+            _Pragma("unroll") for (int p = 0; p <= ((k) >> 1); ++p) lr[(k) & 1][p] = lrow_[p];                 \
+        }
+        DM_DUO_YLOAD(0)
 #pragma unroll
         for (int k = 0; k < ND; ++k) {
             Real yk = 0;
+            if (k + 1 < ND) { if (k + 1 < D) DM_DUO_YLOAD(k + 1) }
             if (k < D) {
-                const R4 r0 = *reinterpret_cast<const R4*>(&s.dofrec[k][0]), r1 = *reinterpret_cast<const R4*>(&s.dofrec[k][4]);
+                const R4 r0 = rr[k & 1][0], r1 = rr[k & 1][1];
                 const Real val = r0[0] * xd.x + r0[1] * xd.y + r0[2] * xd.z + r0[3] * dd.x + r1[0] * dd.y + r1[1] * dd.z;
                 const bool on = (((k < 32) ? ch_lo : ch_hi) >> (k & 31)) & 1u, ng = (((k < 32) ? ng_lo : ng_hi) >> (k & 31)) & 1u;
                 const Real raw = on ? (ng ? -val : val) : (Real)0;
                 cvec += raw * r1[2];
                 R2 acc2 = {(Real)0, (Real)0}, acc3 = acc2;      // two independent accumulation chains
-                const R2* lrow = reinterpret_cast<const R2*>(&s.Lt[L::lrow(k)]);
 #pragma unroll
-                for (int p = 0; p < (k >> 1); ++p) { if (p & 1) acc3 += lrow[p] * y2[p]; else acc2 += lrow[p] * y2[p]; }
+                for (int p = 0; p < (k >> 1); ++p) { if (p & 1) acc3 += lr[k & 1][p] * y2[p]; else acc2 += lr[k & 1][p] * y2[p]; }
                 acc2 += acc3;
                 Real acc = raw - (acc2[0] + acc2[1]);
-                if (k & 1) acc -= s.Lt[L::lrow(k) + k - 1] * y2[k >> 1][0];
-                yk = acc * s.Lt[L::lrow(k) + k];
+                if (k & 1) acc -= lr[k & 1][k >> 1][0] * y2[k >> 1][0];
+                yk = acc * lr[k & 1][k >> 1][k & 1];
             }
             y2[k >> 1][k & 1] = yk;
         }
+#undef DM_DUO_YLOAD
         b.mark(9);
         const int RN = NL + nc;
         const bool is_fric = hl >= RN && hl < R;

@@ -31,14 +31,14 @@ def algorithmic_bytes_per_env_step(env):
     return 2 * rec + out
 
 
-def measured_traffic(scene, n):
+def measured_traffic(scene, n, kernel=None):
     """HBM bytes per k_env_step launch from the committed rocprofv3 PMC passes (profiles/r01_traffic.json, collected
     as MI355X_MICROARCH.md prescribes: separate --pmc passes for FETCH_SIZE and WRITE_SIZE); None when no profile of this
     workload is committed."""
     try:
         with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
             t = json.load(f)
-        if t.get("scene") == scene and int(t.get("envs", -1)) == n:
+        if t.get("scene") == scene and int(t.get("envs", -1)) == n and (kernel is None or t.get("kernel", kernel) == kernel):
             return float(t["hbm_bytes_per_launch"])
     except Exception:
         pass
@@ -150,6 +150,7 @@ def main():
 
     if rank == 0:
         bytes_per_launch = algorithmic_bytes_per_env_step(env) * n
+        kname = "k_env_step_duo" if (args.wave_packing != 1 and env.J <= 15 and env.D == 34 and n % 2 == 0) else "k_env_step"
         achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
         value = world * n * args.steps / elapsed
         out = {
@@ -162,7 +163,7 @@ def main():
                        "envs_per_gpu": n, "wave_packing": args.wave_packing, "parallelism": "env-shards x%d%s" % (world, " + RCCL all-gather of obs" if gather else "")},
             "sim_updates_per_s": value * 20,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": measured_traffic(args.scene, n), "kernel": "k_env_step_duo" if (args.wave_packing == 2 and env.J <= 15) else "k_env_step", "kernel_ms": kernel_ms,
+                         "traffic": measured_traffic(args.scene, n, kname), "kernel": kname, "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_env_step": algorithmic_bytes_per_env_step(env),
                          "algorithmic_bytes_per_launch": bytes_per_launch,
                          "note": "VALU-issue bound by construction (SURVEY 8d, DESIGN.md 6): the env record stays in LDS/VGPRs for "

@@ -47,7 +47,7 @@ json.dump(pmc, open(os.path.join(dst, out + "_pmc_sq.json"), "w"), indent=1)
 f = np.mean([v["FETCH_SIZE"] for v in agg(os.path.join(src, "pmc_fetch", "pmc_counter_collection.csv"))])
 w = np.mean([v["WRITE_SIZE"] for v in agg(os.path.join(src, "pmc_write", "pmc_counter_collection.csv"))])
 b = json.load(open(os.path.join(src, "bench.json")))
-traffic = {"scene": "humanoid3d_walk", "envs": n, "fetch_size_kib_raw": float(f), "write_size_kib_raw": float(w),
+traffic = {"scene": "humanoid3d_walk", "envs": n, "kernel": b["roofline"]["kernel"], "fetch_size_kib_raw": float(f), "write_size_kib_raw": float(w),
            "fetch_bytes_per_launch": float(f) * 1024 * 2, "write_bytes_per_launch": float(w) * 1024,
            "hbm_bytes_per_launch": float(f) * 1024 * 2 + float(w) * 1024,
            "algorithmic_bytes_per_launch": b["roofline"]["algorithmic_bytes_per_launch"],

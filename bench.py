@@ -81,6 +81,7 @@ def main():
     ap.add_argument("--precision", type=int, default=32)
     ap.add_argument("--wave-packing", type=int, default=2, help="characters per wavefront of the step kernel (1 or 2; 2 needs the biped class)")
     ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--force-gather", action="store_true", help="exercise the record exchange even with one rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -103,28 +104,35 @@ def main():
     env = BatchEnv(tables, n, device_id=local_rank, seed=1234, precision=args.precision, env_id_offset=rank * n, test_mode=True,
                    wave_packing=args.wave_packing)
     env.set_stream(torch.cuda.current_stream().cuda_stream)
-    env.reset()                                                   # per-env random phase, keyed by the global env id
+    # deterministic per-env start phase keyed by the global env id; later episodes draw from the device's
+    # counter-based generator, keyed by (seed, global env id, episode)
+    from deepmimic_amd import streams
+    env.reset(kin_times=streams.reset_phase(rank * n + np.arange(n), env.duration))
     dev = torch.device("cuda", local_rank)
-    states = torch.empty((n, env.S), dtype=torch.float32, device=dev)
-    rewards = torch.empty((n,), dtype=torch.float32, device=dev)
-    term = torch.empty((n,), dtype=torch.int32, device=dev)
     valid = torch.empty((n,), dtype=torch.int32, device=dev)
     ends = torch.empty((n,), dtype=torch.int32, device=dev)
-    gather = world > 1 and not args.no_gather
-    if gather:
-        # per-env learner record {state[S], reward, terminate}; gathered with one RCCL all-gather per control step
-        rec = torch.empty((n, env.S + 2), dtype=torch.float32, device=dev)
-        rec_all = torch.empty((world * n, env.S + 2), dtype=torch.float32, device=dev)
+    gather = (world > 1 or args.force_gather) and not args.no_gather
+    # per-env learner record {state[S], reward, terminate}: the step kernel writes it straight into the flat exchange buffer
+    # of slot k % 2; one RCCL all-gather per control step, issued asynchronously so that it overlaps control step k+1
+    from deepmimic_amd.dist import RecordExchange
+    ex = RecordExchange(n, env.S, world, dev, depth=2)
+    tick = [0]
 
     def one_step():
+        slot = tick[0] & 1; tick[0] += 1
+        states, rewards, term = ex.begin(slot) if gather else ex.views(slot)
         env.step_device(0, states.data_ptr(), rewards.data_ptr(), term.data_ptr(), valid.data_ptr(), ends.data_ptr(),
                         timestep=1.0 / 600, n_updates=20, auto_reset=True, open_loop=True)
         if gather:
-            rec[:, :env.S] = states; rec[:, env.S] = rewards; rec[:, env.S + 1] = term.to(torch.float32)
-            dist.all_gather_into_tensor(rec_all, rec)
+            ex.launch(slot)
+
+    def drain():
+        if gather:
+            ex.wait(0); ex.wait(1)
 
     for _ in range(args.warmup):
         one_step()
+    drain()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -132,6 +140,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         one_step()
+    drain()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -145,6 +154,7 @@ def main():
     # kernel-only time of the dominant kernel (k_env_step), HIP events on the launch stream
     k_steps = max(5, min(50, args.steps))
     kernel_ms = env.bench_rollout(0, k_steps, auto_reset=True, open_loop=True) / k_steps
+    states, rewards, term = ex.views((tick[0] - 1) & 1)
     mean_reward = float(rewards.mean().item())
     finite = bool(torch.isfinite(states).all().item())
 
@@ -160,7 +170,7 @@ def main():
             "vs_baseline": None, "dtype": "f32" if args.precision == 32 else "f64", "data": "synthetic",
             "config": {"workload": "%s, %d envs per GPU, fixed-action (open-loop mocap tracking) rollout, auto-reset, "
                                    "20 updates of 1/600 s x 2 substeps per step" % (args.scene, n),
-                       "envs_per_gpu": n, "wave_packing": args.wave_packing, "parallelism": "env-shards x%d%s" % (world, " + RCCL all-gather of obs" if gather else "")},
+                       "envs_per_gpu": n, "wave_packing": args.wave_packing, "parallelism": "env-shards x%d%s" % (world, " + async RCCL all-gather of the record, overlapped with the next step" if gather else "")},
             "sim_updates_per_s": value * 20,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": measured_traffic(args.scene, n, kname), "kernel": kname, "kernel_ms": kernel_ms,

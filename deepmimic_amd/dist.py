@@ -64,3 +64,60 @@ class ShardedEnv:
         out = torch.empty((self.world * big, t.shape[1]), dtype=t.dtype, device=t.device)
         dist.all_gather_into_tensor(out, pad)
         return torch.cat([out[r * big:r * big + shard_range(self.total, self.world, r)[1]] for r in range(self.world)], 0)
+
+
+class RecordExchange:
+    """Double-buffered, copy-free all-gather of the learner record, overlapped with the next control step.
+
+    Each rank owns `depth` flat float32 buffers laid out [states n*S | rewards n | terminate n (int32 bits)]; the step
+    kernel writes its outputs straight into the views of buffer k % depth (`dm_step_batch` takes raw device pointers), so
+    there is no pack kernel.  `launch(slot)` issues one `all_gather_into_tensor` of the flat buffer with `async_op=True`:
+    on the nccl (= RCCL) backend the collective is ordered after everything already enqueued on the current stream and
+    runs on the process group's own stream, i.e. concurrently with the step kernel of control step k+1 that the caller
+    enqueues next; `result(slot)` makes the current stream wait for it.  xGMI is point-to-point: the 8 shards of 3.75 MB
+    each travel on their own links, there is no ring to bound.  On gloo (CPU tests) the same calls run synchronously.
+    """
+
+    def __init__(self, n: int, S: int, world: int, device, depth: int = 2):
+        import torch
+        self.n, self.S, self.world, self.depth = n, S, world, depth
+        self.chunk = n * S + 2 * n
+        self.local = [torch.zeros(self.chunk, dtype=torch.float32, device=device) for _ in range(depth)]
+        self.all = [torch.zeros(world * self.chunk, dtype=torch.float32, device=device) for _ in range(depth)]
+        self.work = [None] * depth
+
+    def views(self, slot: int):
+        """(states [n,S] f32, rewards [n] f32, terminate [n] i32) aliasing local buffer `slot`."""
+        import torch
+        b = self.local[slot]
+        n, S = self.n, self.S
+        return b[:n * S].view(n, S), b[n * S:n * S + n], b[n * S + n:].view(torch.int32)
+
+    def begin(self, slot: int):
+        """Call before enqueueing the step that writes buffer `slot`: orders it after the gather last launched on that
+        slot (control step k - depth), then returns the output views."""
+        self.wait(slot)
+        return self.views(slot)
+
+    def launch(self, slot: int):
+        """Call right after enqueueing the step that wrote buffer `slot` on the current stream."""
+        import torch.distributed as dist
+        if self.world == 1:
+            self.all[slot].copy_(self.local[slot])
+            return
+        self.work[slot] = dist.all_gather_into_tensor(self.all[slot], self.local[slot], async_op=True)
+
+    def wait(self, slot: int):
+        """Block the current stream (not the host, on nccl) until the gather last launched on `slot` is complete."""
+        w = self.work[slot]
+        if w is not None:
+            w.wait()
+            self.work[slot] = None
+
+    def result(self, slot: int):
+        """(states [world,n,S], rewards [world,n], terminate [world,n] i32): global env id = rank * n + i."""
+        import torch
+        self.wait(slot)
+        a = self.all[slot].view(self.world, self.chunk)
+        n, S = self.n, self.S
+        return a[:, :n * S].unflatten(1, (n, S)), a[:, n * S:n * S + n], a[:, n * S + n:].view(torch.int32)

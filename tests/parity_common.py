@@ -229,3 +229,39 @@ def batch_rollout_compare(name, precision, lib_path, steps, t0s, wave_packing=0,
             ds[e] = max(ds[e], np.abs(out["state"][e] - o.record_state()).max())
             ok &= int(out["terminate"][e]) == o.check_terminate() and int(out["valid"][e]) == int(o.check_valid_episode())
     return dr, ds, ok
+
+
+def action_rollout_compare(name, precision, lib_path, steps, stream, t0s, wave_packing=0):
+    """Explicit-action rollout (the a10 action path: exp-map / angle -> PD target on the device) of len(t0s) envs.
+
+    stream "A0" = zeros, "A1" = encoding of the oracle's kinematic pose, "A2" = A1 + Philox N(0, 0.05^2) noise keyed by
+    env id and control step (deepmimic_amd/streams.py).  Actions cross the boundary as float32, so the oracle is fed
+    the float32-rounded values.  Returns per-env max |reward diff|, max |state diff|, flags equal, #terminated."""
+    from deepmimic_amd import streams
+    t = model.load_asset(name)
+    n = len(t0s)
+    env = BatchEnv(t, n, precision=precision, lib_path=lib_path, wave_packing=wave_packing)
+    env.reset(kin_times=np.array(t0s, dtype=np.float64), max_times=np.inf)
+    oracles = []
+    for t0 in t0s:
+        o = Oracle(t); o.reset(t0); oracles.append(o)
+    A = env.A
+    dr, ds, ok, fallen = np.zeros(n), np.zeros(n), True, 0
+    for k in range(steps):
+        if stream == "A0":
+            acts = streams.stream_a0(n, A)
+        else:
+            acts = np.array([o.pose_to_action(o.kin_state()[0]) for o in oracles])
+            if stream == "A2":
+                acts = streams.stream_a2(acts, np.arange(n), k)
+        acts = acts.astype(np.float32)
+        out = env.step(acts, DT, 20)
+        for e, o in enumerate(oracles):
+            o.set_action(acts[e].astype(np.float64))
+            for u in range(20):
+                o.update(DT)
+            dr[e] = max(dr[e], abs(float(out["reward"][e]) - o.calc_reward()))
+            ds[e] = max(ds[e], np.abs(out["state"][e] - o.record_state()).max())
+            ok &= int(out["terminate"][e]) == o.check_terminate() and int(out["valid"][e]) == int(o.check_valid_episode())
+    fallen = sum(o.check_terminate() == 1 for o in oracles)
+    return dr, ds, ok, fallen

@@ -26,6 +26,24 @@ for k in range(2):
     recs.append(sh.gather(sh.pack_record(out)).numpy())
 if rank == 0:
     np.save(os.environ["DM_OUT"], np.stack(recs))
+# double-buffered flat record exchange (equal shards): what bench.py runs per control step
+from deepmimic_amd.dist import RecordExchange
+n = 2
+eq = ShardedEnv(t, 2 * n, rank=rank, world=world, device_id=0, seed=11, precision=64, lib_path=os.environ["DM_HIP_LIB"], wave_packing=1)
+eq.env.reset()
+ex = RecordExchange(n, eq.S, world, "cpu", depth=2)
+got = []
+for k in range(3):
+    slot = k & 1
+    st, rw, tm = ex.begin(slot)
+    out = eq.env.step(None, 1.0 / 600, 20, open_loop=True, auto_reset=True)
+    st.copy_(torch.from_numpy(out["state"])); rw.copy_(torch.from_numpy(out["reward"])); tm.copy_(torch.from_numpy(out["terminate"]))
+    ex.launch(slot)
+    if k >= 1:                                   # consume step k-1 while step k's gather is in flight
+        S_, R_, T_ = ex.result((k - 1) & 1)
+        got.append(np.concatenate([S_.reshape(world * n, -1).numpy(), R_.reshape(-1, 1).numpy(), T_.reshape(-1, 1).numpy().astype(np.float32)], 1))
+if rank == 1:
+    np.save(os.environ["DM_OUT"] + ".ex.npy", np.stack(got))
 dist.barrier()
 dist.destroy_process_group()
 '''
@@ -60,3 +78,10 @@ def test_two_rank_gloo_matches_single_process(emu_lib, tmp_path):
     for k in range(2):
         o = sh.env.step(None, 1.0 / 600, 20, open_loop=True, auto_reset=True)
         assert np.array_equal(got[k], sh.pack_record(o))
+    # RecordExchange: 2 ranks x 2 envs, steps 0 and 1 consumed one step late, in global env order
+    ex = np.load(out + ".ex.npy")
+    sh = ShardedEnv(model.load_asset("humanoid3d_walk"), 4, rank=0, world=1, device_id=0, seed=11, precision=64, lib_path=emu_lib, wave_packing=1)
+    sh.env.reset()
+    for k in range(2):
+        o = sh.env.step(None, 1.0 / 600, 20, open_loop=True, auto_reset=True)
+        assert np.array_equal(ex[k], sh.pack_record(o))

@@ -102,3 +102,15 @@ def test_self_collision_switch(emu_lib):
         e.reset(kin_times=[0.2], max_times=np.inf)
         e.step(None, pc.DT, 1, open_loop=True)
     assert np.abs(on.get_state()["vel"] - off.get_state()["vel"]).max() > 1e-3
+
+
+@pytest.mark.parametrize("stream,steps", [("A0", 3), ("A2", 2)])
+def test_action_streams_fp64(emu_lib, stream, steps):
+    """explicit float32 actions through the exp-map -> PD-target path (a10): zeros and noisy mocap tracking"""
+    dr, ds, ok, _ = pc.action_rollout_compare("humanoid3d_walk", 64, emu_lib, steps, stream, [0.0, 0.37])
+    assert ok and dr.max() < 1e-6 and ds.max() < 1e-5, (dr, ds)
+
+
+def test_action_stream_a2_duo_fp64(emu_lib):
+    dr, ds, ok, _ = pc.action_rollout_compare("humanoid3d_walk", 64, emu_lib, 2, "A2", [0.0, 0.37], wave_packing=2)
+    assert ok and dr.max() < 1e-6 and ds.max() < 1e-5, (dr, ds)

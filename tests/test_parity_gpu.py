@@ -235,3 +235,23 @@ def test_root_heading_sync_dog_spin(hip_lib, prec, tol):
     dr, ds, ok = pc.rollout_compare("dog3d_spin", prec, hip_lib, steps=60)
     floor = pc.fp32_free_running_sensitivity("dog3d_spin", 60).max() if prec == 32 else 0.0
     assert ok and dr.mean() < tol / 5 and dr.max() < max(tol, 4 * floor), (dr.mean(), dr.max(), floor)
+
+
+@pytest.mark.parametrize("pack", [1, 2])
+def test_action_stream_a0_collapse_and_fall(hip_lib, pack):
+    """stream A0 (all-zero actions, the reference's own native driver input, Main.cpp:119-120): PD targets are identity
+    rotations, the character collapses; fall termination must fire on the same control step as in the oracle."""
+    dr, ds, ok, fallen = pc.action_rollout_compare("humanoid3d_walk", 64, hip_lib, 60, "A0", [0.0, 0.37, 0.6, 0.9], wave_packing=pack)
+    assert fallen == 4, fallen
+    assert ok and dr.max() < 1e-5, (dr, ds)
+    dr, ds, ok, _ = pc.action_rollout_compare("humanoid3d_walk", 32, hip_lib, 12, "A0", [0.0, 0.37], wave_packing=pack)
+    assert ok and dr.max() < 1e-4, (dr, ds)
+
+
+@pytest.mark.parametrize("name,pack", [("humanoid3d_walk", 1), ("humanoid3d_walk", 2), ("dog3d_pace", 0)])
+def test_action_stream_a2_noisy_tracking(hip_lib, name, pack):
+    """stream A2: mocap tracking + Philox N(0, 0.05^2) exploration noise, explicit float32 actions through the a10 path."""
+    dr, ds, ok, _ = pc.action_rollout_compare(name, 64, hip_lib, 100, "A2", [0.0, 0.41, 0.77, 1.3], wave_packing=pack)
+    assert ok and dr.max() < 1e-5, (dr, ds)
+    dr, ds, ok, _ = pc.action_rollout_compare(name, 32, hip_lib, 10, "A2", [0.0, 0.41], wave_packing=pack)
+    assert ok and dr.max() < 1e-4, (dr, ds)

@@ -43,6 +43,7 @@ class cDeepMimicCore(object):
         self._tables = None
         self._env = None
         self._mode = self.eModeTrain
+        self._sample_count = 0
         self._num_update_substeps = 1
         self._cache = None
         self._time = 0.0
@@ -79,12 +80,8 @@ class cDeepMimicCore(object):
         self._cache = None
 
     def _apply_mode(self):
-        c = self._tables.cfg
-        if self._mode == self.eModeTest and c.time_end_lim_max is not None:
-            lo = c.time_end_lim_min if c.time_end_lim_min is not None else c.time_end_lim_max
-            self._env.set_time_limits(float(lo), float(c.time_end_lim_max))
-        else:
-            self._env.set_time_limits(float(c.time_lim_min), float(c.time_lim_max))
+        lo, hi = _model.timer_limits(self._tables.cfg, self._mode == self.eModeTest, self._sample_count)
+        self._env.set_time_limits(lo, hi)
 
     def _need_env(self):
         if self._env is None:
@@ -288,4 +285,7 @@ class cDeepMimicCore(object):
             self._apply_mode()
 
     def SetSampleCount(self, count):
-        pass                        # only drives the (unset) timer annealing of scenes/RLSceneSimChar.cpp:292-300
+        """cRLSceneSimChar::SetSampleCount (scenes/RLSceneSimChar.cpp:223-227): anneals the episode-length limits."""
+        self._sample_count = int(count)
+        if self._env is not None:
+            self._apply_mode()

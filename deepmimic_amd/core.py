@@ -142,6 +142,11 @@ class BatchEnv:
     def set_time_limits(self, time_lim_min: float, time_lim_max: float):
         self._chk(self.lib.dm_set_time_limits(self.h, C.c_double(time_lim_min), C.c_double(time_lim_max)))
 
+    def set_sample_count(self, sample_count: int, test_mode: bool = False):
+        """cRLSceneSimChar::SetSampleCount / SetMode for the whole batch: anneal the episode-length limits (model.timer_limits)."""
+        from . import model
+        self.set_time_limits(*model.timer_limits(self.tables.cfg, test_mode, sample_count))
+
     def set_action(self, actions):
         a = np.ascontiguousarray(actions, dtype=np.float32).reshape(self.N, self.A)
         self._chk(self.lib.dm_set_action(self.h, _fp(a), 0))

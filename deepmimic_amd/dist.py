@@ -102,7 +102,9 @@ class RecordExchange:
     def launch(self, slot: int):
         """Call right after enqueueing the step that wrote buffer `slot` on the current stream."""
         import torch.distributed as dist
-        if self.world == 1:
+        if not dist.is_initialized():
+            if self.world != 1:
+                raise RuntimeError("RecordExchange with world > 1 needs an initialised torch.distributed process group")
             self.all[slot].copy_(self.local[slot])
             return
         self.work[slot] = dist.all_gather_into_tensor(self.all[slot], self.local[slot], async_op=True)

@@ -349,6 +349,32 @@ def parse_scene_config(parser: ArgParser) -> SceneConfig:
     return c
 
 
+def timer_limits(cfg: SceneConfig, test_mode: bool = False, sample_count: int = 0):
+    """(min, max) of the uniform episode-length draw at the next Reset.
+
+    Train mode: `cRLSceneSimChar::UpdateTimerParams` (scenes/RLSceneSimChar.cpp:338-347) blends `time_lim_*` towards
+    `time_end_lim_*` by lerp = clamp(sample_count / anneal_samples, 0, 1)^4 (`SetupTimerAnnealer`, :330-336;
+    `cTimer::tParams::Blend`, util/Timer.cpp:12-20; `cAnnealer::Eval`, util/Annealer.cpp) when `anneal_samples` > 0.
+    Test mode: `ResetTimers` (:277-284) pins the limit to `time_end_lim_max`.  An unset limit is +inf (util/Timer.cpp:7-8);
+    the NaN the reference's `0 * inf` would produce never satisfies `mTime >= mMaxTime`, i.e. behaves as +inf."""
+    if cfg.timer_type != "uniform":
+        raise ValueError("timer_type %r is not on the accelerated path (only 'uniform' appears in the arg files)" % cfg.timer_type)
+    emin = cfg.time_lim_min if cfg.time_end_lim_min is None else cfg.time_end_lim_min
+    emax = cfg.time_lim_max if cfg.time_end_lim_max is None else cfg.time_end_lim_max
+    if test_mode:
+        return float(emax), float(emax)
+    lerp = 0.0
+    if cfg.anneal_samples > 0:
+        lerp = min(max(float(sample_count) / cfg.anneal_samples, 0.0), 1.0) ** 4.0
+
+    def blend(a, b):
+        with np.errstate(invalid="ignore"):
+            v = np.float64(1.0 - lerp) * np.float64(a) + np.float64(lerp) * np.float64(b)
+        return float("inf") if np.isnan(v) else float(v)
+
+    return blend(cfg.time_lim_min, emin), blend(cfg.time_lim_max, emax)
+
+
 # --- scene loading -------------------------------------------------------------
 def load_scene(char_file: str, ctrl_file: str, motion_file: str,
                cfg: Optional[SceneConfig] = None) -> SceneTables:

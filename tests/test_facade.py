@@ -120,3 +120,41 @@ def test_facade_protocol_gpu(hip_lib, monkeypatch):
     _check_static_surface(core, t)
     o = Oracle(t); o.reset(float(core._env.get_state()["clocks"][0][0]))
     assert _run_protocol(core, o, 101, np.random.default_rng(2)) == 6
+
+
+def test_timer_annealing_follows_sample_count(emu_lib, monkeypatch):
+    """a3: SetSampleCount blends time_lim_* -> time_end_lim_* with lerp = clamp(count / anneal_samples)^4
+    (scenes/RLSceneSimChar.cpp:223-227,330-347); test mode pins time_end_lim_max (:277-284).  Args of
+    args/train_humanoid3d_walk_args.txt: 0.5 s -> 20 s over 32e6 samples."""
+    import copy
+    from deepmimic_amd import model
+    cfg = copy.deepcopy(model.load_asset("humanoid3d_walk").cfg)
+    cfg.time_lim_min = cfg.time_lim_max = 0.5
+    cfg.time_end_lim_min = cfg.time_end_lim_max = 20.0
+    cfg.anneal_samples = 32000000
+    assert model.timer_limits(cfg, False, 0) == (0.5, 0.5)
+    lo, hi = model.timer_limits(cfg, False, 16000000)
+    assert abs(lo - (0.5 + 19.5 / 16)) < 1e-12 and lo == hi
+    assert model.timer_limits(cfg, False, 10 ** 9) == (20.0, 20.0)
+    assert model.timer_limits(cfg, True, 0) == (20.0, 20.0)
+    unset = model.SceneConfig(anneal_samples=1000)                       # limits never given: 0 * inf in the reference
+    assert model.timer_limits(unset, False, 1000) == (np.inf, np.inf)
+
+    DeepMimicCore = _core_module()
+    monkeypatch.setenv("DM_HIP_LIB", emu_lib); monkeypatch.setenv("DM_PRECISION", "64")
+    t = model.load_asset("humanoid3d_walk"); t.cfg = cfg
+    core = DeepMimicCore.cDeepMimicCore(False)
+    core.SeedRand(3); core.LoadTables(t, 10); core.Init()
+
+    def episode_len():
+        core.Reset(); n = 0
+        while not core.IsEpisodeEnd() and n < 40:
+            core.Update(1.0 / 30); n += 1
+        return n
+    assert episode_len() in (15, 16)                                   # 0.5 s at 30 Hz (15 x 1/30 rounds just below 0.5)
+    core.SetSampleCount(16000000)
+    core.Reset()
+    assert core._env.get_state()["clocks"][0][4] == pytest.approx(0.5 + 19.5 / 16)
+    core.SetMode(1)                                                    # eModeTest
+    core.Reset()
+    assert core._env.get_state()["clocks"][0][4] == pytest.approx(20.0)

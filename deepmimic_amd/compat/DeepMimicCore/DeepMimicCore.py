@@ -106,7 +106,11 @@ class cDeepMimicCore(object):
         return float(self._need_env().get_state()["clocks"][0][3])
 
     def GetName(self):
-        return "Imitate"            # cSceneImitate::GetName (scenes/SceneImitate.cpp:207-210)
+        # cSceneImitate::GetName (scenes/SceneImitate.cpp:207-210), cSceneImitateAMP::GetName (SceneImitateAMP.cpp:208-211)
+        return "Imitate AMP" if self._is_amp() else "Imitate"
+
+    def _is_amp(self):
+        return self._tables is not None and self._tables.cfg.scene == "imitate_amp"
 
     def EnableDraw(self):
         return False
@@ -251,23 +255,34 @@ class cDeepMimicCore(object):
     def EnableAMPTaskReward(self):
         return False
 
+    # ---- AMP observations (DeepMimicCore.h:75-81 -> scenes/SceneImitateAMP.cpp); empty for a plain imitate scene
     def GetAMPObsSize(self):
-        return 0
+        return int(self._need_env().amp_size)
 
     def GetAMPObsOffset(self):
-        return []
+        return [0.0] * self.GetAMPObsSize()            # SceneImitateAMP.cpp:88-91
 
     def GetAMPObsScale(self):
-        return []
+        return [1.0] * self.GetAMPObsSize()            # :93-96
 
     def GetAMPObsNormGroup(self):
-        return []
+        return [0] * self.GetAMPObsSize()              # :98-101  cCharController::gNormGroupSingle = 0
 
     def RecordAMPObsAgent(self, agent_id):
-        return []
+        if not self._is_amp():
+            return []
+        self._chk_agent(agent_id)
+        return [float(x) for x in self._need_env().query_amp()[0]]
 
     def RecordAMPObsExpert(self, agent_id):
-        return []
+        """One expert sample at a random clip time (the reference draws it from the scene RNG; here from the ctx's
+        counter-based generator), ground height = the kin character's origin height (SceneImitateAMP.cpp:115-138)."""
+        if not self._is_amp():
+            return []
+        self._chk_agent(agent_id)
+        env = self._need_env()
+        gh = float(env.get_state()["kin"][0][1])
+        return [float(x) for x in env.amp_expert(1, None, gh)[0]]
 
     def IsEpisodeEnd(self):
         return bool(self._query()["episode_end"][0])

@@ -35,7 +35,7 @@ class _SceneTables(C.Structure):
         ("enable_rand_rot_reset", C.c_int), ("time_lim_min", C.c_double), ("time_lim_max", C.c_double),
         ("enable_phase_input", C.c_int), ("record_world_root_pos", C.c_int), ("record_world_root_rot", C.c_int),
         ("query_rate", C.c_double), ("friction", C.c_double), ("erp", C.c_double), ("solver_iters", C.c_int),
-        ("disable_self_collision", C.c_int),
+        ("disable_self_collision", C.c_int), ("scene_amp", C.c_int), ("enable_amp_obs_local_root", C.c_int),
     ]
 
 
@@ -107,6 +107,7 @@ class BatchEnv:
         st.record_world_root_rot = int(tables.record_world_root_rot); st.query_rate = float(tables.query_rate)
         st.friction = 0.0; st.erp = float(erp); st.solver_iters = 0
         st.disable_self_collision = 0 if self_collision else 1
+        st.scene_amp = int(c.scene == "imitate_amp"); st.enable_amp_obs_local_root = int(getattr(c, "enable_amp_obs_local_root", False))
         info = _CreateInfo(int(num_envs), int(device_id), int(seed) & (2 ** 64 - 1), int(precision), int(max_contacts), int(env_id_offset), int(wave_packing))
         self.h = C.c_void_p()
         self._chk(self.lib.dm_create(C.byref(info), C.byref(st), C.byref(self.h)))
@@ -115,6 +116,7 @@ class BatchEnv:
         self.S, self.G, self.A, self.P, self.J, self.D, self.F, self.N = [int(x) for x in dims]
         self.duration = float(self.lib.dm_motion_duration(self.h))
         self.precision = precision
+        self.amp_size = int(self.lib.dm_amp_obs_size(self.h))      # GetAMPObsSize; 0 unless `--scene imitate_amp`
 
     def _chk(self, rc):
         if rc != 0:
@@ -160,19 +162,42 @@ class BatchEnv:
         self._chk(self.lib.dm_query(self.h, _fp(s), _fp(r), _ip(t), _ip(v), _ip(e), _ip(nn), 0))
         return dict(state=s, reward=r, terminate=t, valid=v, episode_end=e, need_new_action=nn)
 
-    def step(self, actions=None, timestep: float = 1.0 / 600, n_updates: int = 20, auto_reset=False, open_loop=False):
+    def step(self, actions=None, timestep: float = 1.0 / 600, n_updates: int = 20, auto_reset=False, open_loop=False, amp=False):
+        """amp=True (imitate_amp scenes): also returns "amp_obs" = RecordAMPObsAgent at the end of the step (before any auto reset)."""
         a = None if actions is None else np.ascontiguousarray(actions, dtype=np.float32).reshape(self.N, self.A)
         s = np.zeros((self.N, self.S), np.float32); r = np.zeros(self.N, np.float32)
         t = np.zeros(self.N, np.int32); v = np.zeros(self.N, np.int32); e = np.zeros(self.N, np.int32)
         flags = (DM_AUTO_RESET if auto_reset else 0) | (DM_OPEN_LOOP if open_loop else 0)
+        if amp:
+            o = np.zeros((self.N, self.amp_size), np.float32)
+            self._chk(self.lib.dm_step_batch_amp(self.h, _fp(a), C.c_double(timestep), int(n_updates), _fp(s), _fp(r), _ip(t), _ip(v), _ip(e), _fp(o), flags))
+            return dict(state=s, reward=r, terminate=t, valid=v, episode_end=e, amp_obs=o)
         self._chk(self.lib.dm_step_batch(self.h, _fp(a), C.c_double(timestep), int(n_updates), _fp(s), _fp(r), _ip(t), _ip(v), _ip(e), flags))
         return dict(state=s, reward=r, terminate=t, valid=v, episode_end=e)
 
+    def query_amp(self):
+        """RecordAMPObsAgent for every env (scenes/SceneImitateAMP.cpp:101-113)."""
+        o = np.zeros((self.N, self.amp_size), np.float32)
+        self._chk(self.lib.dm_query_amp(self.h, _fp(o), 0))
+        return o
+
+    def amp_expert(self, n: int, times=None, ground_h=None):
+        """n expert observations (RecordAMPObsExpert, :115-138); times None -> ~U[0, duration) from the ctx generator."""
+        o = np.zeros((int(n), self.amp_size), np.float32)
+        tt = None if times is None else np.ascontiguousarray(np.broadcast_to(times, (n,)), dtype=np.float64)
+        gh = None if ground_h is None else np.ascontiguousarray(np.broadcast_to(ground_h, (n,)), dtype=np.float64)
+        self._chk(self.lib.dm_amp_expert(self.h, int(n), _dp(tt), _dp(gh), _fp(o), 0))
+        return o
+
     def step_device(self, actions_ptr, states_ptr, rewards_ptr, term_ptr, valid_ptr, end_ptr,
-                    timestep: float = 1.0 / 600, n_updates: int = 20, auto_reset=False, open_loop=False):
+                    timestep: float = 1.0 / 600, n_updates: int = 20, auto_reset=False, open_loop=False, amp_ptr=0):
         """Same as step() on raw device pointers (ints), asynchronous on the ctx stream."""
         flags = DM_DEVICE_PTRS | (DM_AUTO_RESET if auto_reset else 0) | (DM_OPEN_LOOP if open_loop else 0)
         vp = lambda p: C.c_void_p(p) if p else None
+        if amp_ptr:
+            self._chk(self.lib.dm_step_batch_amp(self.h, vp(actions_ptr), C.c_double(timestep), int(n_updates), vp(states_ptr),
+                                                 vp(rewards_ptr), vp(term_ptr), vp(valid_ptr), vp(end_ptr), vp(amp_ptr), flags))
+            return
         self._chk(self.lib.dm_step_batch(self.h, vp(actions_ptr), C.c_double(timestep), int(n_updates), vp(states_ptr),
                                          vp(rewards_ptr), vp(term_ptr), vp(valid_ptr), vp(end_ptr), flags))
 

@@ -914,7 +914,8 @@ struct EnvSim {
         return qrot(ldq(s.kin + 3), rp) + ld3(s.kin);
     }
     // full kin pose / vel at `time` into LDS arrays kp, kv (cKinCharacter::CalcPose / CalcVel)
-    DM_DEV void kin_sample(double time, Real* kp, Real* kv) {
+    // RAW: cMotion::CalcFrame / CalcFrameVel only (no cycle offset, no origin transform, root quaternion not standardised)
+    template <bool RAW = false> DM_DEV void kin_sample(double time, Real* kp, Real* kv) {
         int idx, cyc; double blend; kin_index_blend(time, idx, blend, cyc);
         Real b = (Real)(blend < 0 ? 0 : (blend > 1 ? 1 : blend));
         const Real* f0 = m.frames + (size_t)idx * m.P; const Real* f1 = f0 + m.P;
@@ -924,9 +925,11 @@ struct EnvSim {
             if (l == 0) {
                 v3 rp = ((Real)1 - b) * ld3(f0) + b * ld3(f1);
                 q4 rr = qnormalize(qslerp(ldq(f0 + 3), b, ldq(f1 + 3), m.slerp_one));
-                if (m.loop) rp = rp + (Real)cyc * mk3(m.cycle_delta[0], m.cycle_delta[1], m.cycle_delta[2]);
-                rr = qstandardize(qmul(orot, rr));
-                rp = qrot(orot, rp) + ld3(s.kin);
+                if (!RAW) {
+                    if (m.loop) rp = rp + (Real)cyc * mk3(m.cycle_delta[0], m.cycle_delta[1], m.cycle_delta[2]);
+                    rr = qstandardize(qmul(orot, rr));
+                    rp = qrot(orot, rp) + ld3(s.kin);
+                }
                 st3(kp, rp); stq(kp + 3, rr);
             } else if (jt == JT_SPHERICAL) stq(kp + off, qslerp(ldq(f0 + off), b, ldq(f1 + off), m.slerp_one));
             else if (jt == JT_REVOLUTE) kp[off] = ((Real)1 - b) * f0[off] + b * f1[off];
@@ -936,7 +939,7 @@ struct EnvSim {
         Real bv = (Real)blend;
         for (int i = l; i < m.P; i += LW) kv[i] = over ? (Real)0 : ((Real)1 - bv) * v0[i] + bv * v1[i];
         sync();
-        if (l == 0) {
+        if (!RAW && l == 0) {
             v3 v = qrot(orot, ld3(kv)), w = qrot(orot, ld3(kv + 3));
             st3(kv, v); st3(kv + 3, w);
         }
@@ -1150,8 +1153,9 @@ struct EnvSim {
             Real r = (Real)0.5 * dm_exp(-pose_scale * pose_err) + (Real)0.05 * dm_exp(-vel_scale * vel_err)
                    + (Real)0.15 * dm_exp(-(Real)10 * ee_err) + (Real)0.2 * dm_exp(-(Real)5 * root_err) + (Real)0.1 * dm_exp(-(Real)10 * com_err);
             bool fallen = has_fallen(kp);
-            if (fallen) r = 0;
-            bool fail = (m.enable_fall_end && fallen) || (!m.loop && s.clk[CLK_KIN] >= m.duration);
+            if (fallen || m.scene_amp) r = 0;          // cSceneImitateAMP::CalcReward is 0 outside the test-mode time-warp score
+            // cSceneImitateAMP::CheckTerminate keeps only the fall test (SceneImitateAMP.cpp:184-188)
+            bool fail = (m.enable_fall_end && fallen) || (!m.scene_amp && !m.loop && s.clk[CLK_KIN] >= m.duration);
             bool end = fail || (s.clk[CLK_TIMER] >= s.clk[CLK_TIMER_MAX]);
             if (write_flags) {
                 if (io.rewards) io.rewards[e] = (float)r;
@@ -1198,6 +1202,92 @@ struct EnvSim {
             }
         }
         sync();
+    }
+
+    // ------------------------------------------------------------------ AMP observations (scenes/SceneImitateAMP.cpp)
+    // cSceneImitateAMP::UpdateHist at the action latch (cRLSceneSimChar::PreUpdate -> NewActionUpdate, RLSceneSimChar.cpp:263-275):
+    // the history lives in HBM only; called before every update, writes when the controller wants a new action
+    DM_DEV void latch_hist(const EnvState<Real>& st, int e) {
+        if (s.flg[FLG_NEED_ACTION]) {
+            Real* h = st.hist + (size_t)e * 2 * m.P;
+            for (int i = l; i < m.P; i += LW) { h[i] = s.pose[i]; h[m.P + i] = s.vel[i]; }
+        }
+        sync();                            // the flag is cleared by lane 0 at the top of update()
+    }
+    // cSceneImitateAMP::InitHist (SceneImitateAMP.cpp:152-164) after a reset: kin character one control period earlier
+    DM_DEV void init_hist(const EnvState<Real>& st, int e) {
+        Real* kp = scratch(); Real* kv = scratch() + NP;
+        kin_sample(s.clk[CLK_CTRL] - m.query_period, kp, kv);
+        Real* h = st.hist + (size_t)e * 2 * m.P;
+        for (int i = l; i < m.P; i += LW) { h[i] = kp[i]; h[m.P + i] = kv[i]; }
+        sync();
+    }
+    // one pose block of RecordAMPObsPose (:279-338) for the pose whose kinematics() results are in LDS (s.com = body part
+    // positions, cKinTree::CalcBodyPartPos); O = heading rotation of the *current* pose (cKinTree::CalcHeadingRot)
+    DM_DEV void amp_pose_block(const Real* pose, const m3& O, Real ground_h, bool sim_pose, float* out) {
+        if (l < m.J) {
+            const int jt = DM_LI_JTYPE(li), off = DM_LI_POFF(li);
+            const v3 rpos = ld3(pose);
+            if (l == 0) {
+                out[0] = (float)(rpos.y - ground_h);
+                const q4 q = ldq(pose + 3);                           // cMathUtil::CalcNormalTangent: q * e_y, q * e_x
+                v3 nrm = qrot(q, mk3((Real)0, (Real)1, (Real)0)), tan = qrot(q, mk3((Real)1, (Real)0, (Real)0));
+                if (m.amp_local_root) { nrm = O * nrm; tan = O * tan; }
+                out[1] = (float)nrm.x; out[2] = (float)nrm.y; out[3] = (float)nrm.z; out[4] = (float)tan.x; out[5] = (float)tan.y; out[6] = (float)tan.z;
+            } else if (jt == JT_SPHERICAL) {
+                const q4 q = ldq(pose + off);
+                v3 nrm = qrot(q, mk3((Real)0, (Real)1, (Real)0)), tan = qrot(q, mk3((Real)1, (Real)0, (Real)0));
+                float* o = out + m.amp_off[l];
+                o[0] = (float)nrm.x; o[1] = (float)nrm.y; o[2] = (float)nrm.z; o[3] = (float)tan.x; o[4] = (float)tan.y; o[5] = (float)tan.z;
+            } else if (jt == JT_REVOLUTE) out[m.amp_off[l]] = (float)(sim_pose ? normalize_angle(pose[off]) : pose[off]);
+            const int eo = m.amp_ee[l];
+            if (eo >= 0) {
+                v3 rel = O * (ld3(s.com[l]) - rpos);
+                float* o = out + m.amp_ee_base + 3 * eo;
+                o[0] = (float)rel.x; o[1] = (float)rel.y; o[2] = (float)rel.z;
+            }
+        }
+    }
+    DM_DEV void amp_vel_block(const Real* vel, const m3& O, float* out) {          // RecordAMPObsVel (:340-371)
+        if (l == 0) {
+            v3 v = ld3(vel), w = ld3(vel + 3);
+            if (m.amp_local_root) { v = O * v; w = O * w; }
+            out[0] = (float)v.x; out[1] = (float)v.y; out[2] = (float)v.z; out[3] = (float)w.x; out[4] = (float)w.y; out[5] = (float)w.z;
+        }
+        for (int i = 7 + l; i < m.P; i += LW) out[6 + i - 7] = (float)vel[i];
+    }
+    // BuildAMPObs (:259-277): [pose_t, pose_t-1, vel_t, vel_t-1]; (pp, pv) = history, (p, v) = current, all in LDS
+    DM_DEV void amp_build(const Real* pp, const Real* pv, const Real* p, const Real* v, Real ground_h, bool sim_pose, float* out) {
+        const m3 O = rot_y(-calc_heading(ldq(p + 3)));
+        const v3 zero = zero3();
+        const int ps = m.amp_pose_size, vs = m.amp_vel_size;
+        kinematics(p, v, zero);
+        amp_pose_block(p, O, ground_h, sim_pose, out);
+        sync();
+        kinematics(pp, pv, zero);
+        amp_pose_block(pp, O, ground_h, sim_pose, out + ps);
+        amp_vel_block(v, O, out + 2 * ps);
+        amp_vel_block(pv, O, out + 2 * ps + vs);
+        sync();
+    }
+    // RecordAMPObsAgent (:101-113): sim character now + at the last action latch; ground height of the plane = 0
+    DM_DEV void emit_amp(const StepIO<Real>& io, const EnvState<Real>& st, int e) {
+        DM_OPAQUE_V(l); DM_OPAQUE_V(li);
+        Real* pp = scratch(); Real* pv = scratch() + NP;
+        const Real* h = st.hist + (size_t)e * 2 * m.P;
+        for (int i = l; i < m.P; i += LW) { pp[i] = h[i]; pv[i] = h[m.P + i]; }
+        sync();
+        amp_build(pp, pv, s.pose, s.vel, (Real)0, true, io.amp_obs + (size_t)e * 2 * (m.amp_pose_size + m.amp_vel_size));
+    }
+    // RecordAMPObsExpert (:115-138): raw clip frames (no origin transform, no cycle offset) at `time` and one control
+    // period earlier; ground height := the caller's kin origin y.  Uses this wave's LDS record as scratch only.
+    DM_DEV void amp_expert(double time, Real ground_h, float* out) {
+        Real* p = scratch(); Real* v = scratch() + NP; Real* pp = scratch() + 2 * NP; Real* pv = scratch() + 3 * NP;
+        if (l == 0) { s.kin[0] = s.kin[1] = s.kin[2] = 0; s.kin[3] = 1; s.kin[4] = s.kin[5] = s.kin[6] = 0; }
+        sync();
+        kin_sample<true>(time, p, v);
+        kin_sample<true>(time - m.query_period, pp, pv);
+        amp_build(pp, pv, p, v, ground_h, false, out);
     }
 
     // ------------------------------------------------------------------ reset
@@ -1263,8 +1353,11 @@ template <> struct StepWaves<float, ClsLarge> { static constexpr int value = 2; 
 #else
 #define DM_WAVES_PER_EU(n) __attribute__((amdgpu_waves_per_eu(n, n)))
 #endif
-template <typename Real, typename C, bool TAPS>
+// AMP: the `--scene imitate_amp` instantiation (pose history latch inside the update loop, AMP observation at the end); the
+// plain production kernel carries none of it.  The tap build (tests, profiling) serves both scene kinds.
+template <typename Real, typename C, bool TAPS, bool AMP = false>
 __global__ void __launch_bounds__(64) DM_WAVES_PER_EU((StepWaves<Real, C>::value)) k_env_step(ModelDev<Real> m, EnvState<Real> st, StepIO<Real> io, DebugTaps<Real> dbg) {
+    constexpr bool HIST = TAPS || AMP;
     __shared__ Lds<Real, C> lds;
     const int e = blockIdx.x, l = threadIdx.x;
     EnvSim<Real, C, TAPS> sim(m, lds, l);
@@ -1274,7 +1367,10 @@ __global__ void __launch_bounds__(64) DM_WAVES_PER_EU((StepWaves<Real, C>::value
     else if (io.actions) sim.set_action(io.actions + (size_t)e * m.A);
     sim.mark(15);
     Real* aovf = st.aovf ? st.aovf + (size_t)e * (kMaxRows - C::RREG) * kWave : nullptr;
-    for (int u = 0; u < io.n_updates; ++u) sim.update(io.dt, dbg, e, aovf);
+    for (int u = 0; u < io.n_updates; ++u) {
+        if (HIST && st.hist) sim.latch_hist(st, e);
+        sim.update(io.dt, dbg, e, aovf);
+    }
     if (io.emit) {
         // pass 0 writes reward / flags / observation.  With auto-reset (mirrors DeepMimic.py:70-79) an env whose episode
         // ended starts its next episode and pass 1 hands back the observation the agent needs for its first action
@@ -1283,11 +1379,13 @@ __global__ void __launch_bounds__(64) DM_WAVES_PER_EU((StepWaves<Real, C>::value
         for (int pass = 0; pass < 2; ++pass) {
             sim.emit(io, tap, e, pass == 0);
             const bool ended = lds.sc[6] != (Real)0;
+            if (HIST && pass == 0 && io.amp_obs && st.hist) sim.emit_amp(io, st, e);       // end-of-path observation of a finished episode included
             if (pass == 1 || !(io.auto_reset && ended)) break;
             uint64_t ep = (uint64_t)lds.flg[FLG_EPISODE];
             double kt = m.duration * dm_rand01(m.seed, (uint64_t)(e + m.env_off), ep, 0);
             double mt = (m.time_lim_max > m.time_lim_min) ? m.time_lim_min + (m.time_lim_max - m.time_lim_min) * dm_rand01(m.seed, (uint64_t)(e + m.env_off), ep, 1) : m.time_lim_max;
             sim.reset_env(kt, mt);
+            if (HIST && st.hist) sim.init_hist(st, e);
             tap = DebugTaps<Real>();
         }
         sim.mark(13);
@@ -1309,6 +1407,7 @@ __global__ void __launch_bounds__(64) k_env_reset(ModelDev<Real> m, EnvState<Rea
     double mt = max_times ? max_times[b]
               : ((m.time_lim_max > m.time_lim_min) ? m.time_lim_min + (m.time_lim_max - m.time_lim_min) * dm_rand01(m.seed, (uint64_t)(e + m.env_off), ep, 1) : m.time_lim_max);
     sim.reset_env(kt, mt);
+    if (st.hist) sim.init_hist(st, e);
     sim.store(st, e);
 }
 
@@ -1320,6 +1419,17 @@ __global__ void __launch_bounds__(64) k_env_query(ModelDev<Real> m, EnvState<Rea
     EnvSim<Real, C> sim(m, lds, l);
     sim.load(st, e);
     sim.emit(io, dbg, e, true);
+    if (io.amp_obs && st.hist) sim.emit_amp(io, st, e);
+}
+
+// n expert AMP observations from the clip (RecordAMPObsExpert): sample b at clip time times[b], ground height ground_h[b] (or 0)
+template <typename Real, typename C>
+__global__ void __launch_bounds__(64) k_amp_expert(ModelDev<Real> m, const double* times, const double* ground_h, float* out) {
+    __shared__ Lds<Real, C> lds;
+    const int b = blockIdx.x, l = threadIdx.x;
+    EnvSim<Real, C> sim(m, lds, l);
+    sim.load_model();
+    sim.amp_expert(times[b], ground_h ? (Real)ground_h[b] : (Real)0, out + (size_t)b * 2 * (m.amp_pose_size + m.amp_vel_size));
 }
 
 // component taps for parity tests: SPD torque for the stored state / one substep with the stored torque

@@ -505,8 +505,9 @@ struct DuoSim {
 // grid = N / 2 workgroups of one wavefront; character e = 2 * blockIdx.x + (lane >> 5).  fp32: 2 waves / SIMD (20 KB LDS).
 template <typename Real> struct DuoWaves { static constexpr int value = 1; };
 template <> struct DuoWaves<float> { static constexpr int value = 2; };
-template <typename Real, bool TAPS>
+template <typename Real, bool TAPS, bool AMP = false>
 __global__ void __launch_bounds__(64) DM_WAVES_PER_EU((DuoWaves<Real>::value)) k_env_step_duo(ModelDev<Real> m, EnvState<Real> st, StepIO<Real> io, DebugTaps<Real> dbg) {
+    constexpr bool HIST = TAPS || AMP;
     __shared__ Lds<Real, ClsBiped> lds[2];
     const int wl = threadIdx.x, half = wl >> 5;
     const int e = 2 * blockIdx.x + half;
@@ -517,16 +518,21 @@ __global__ void __launch_bounds__(64) DM_WAVES_PER_EU((DuoWaves<Real>::value)) k
     else if (io.actions) sim.b.set_action(io.actions + (size_t)e * m.A);
     sim.b.mark(15);
     Real* aovf_pair = st.aovf ? st.aovf + (size_t)(2 * blockIdx.x) * (kMaxRows - ClsBiped::RREG) * kWave : nullptr;
-    for (int u = 0; u < io.n_updates; ++u) sim.update(io.dt, e, aovf_pair);
+    for (int u = 0; u < io.n_updates; ++u) {
+        if (HIST && st.hist) sim.b.latch_hist(st, e);
+        sim.update(io.dt, e, aovf_pair);
+    }
     if (io.emit) {
         DebugTaps<Real> tap = DebugTaps<Real>();
         sim.b.emit(io, tap, e, true);
         const bool ended = lds[half].sc[6] != (Real)0;
+        if (HIST && io.amp_obs && st.hist) sim.b.emit_amp(io, st, e);
         if (io.auto_reset && ended) {                    // per character; no cross-half traffic inside
             uint64_t ep = (uint64_t)lds[half].flg[FLG_EPISODE];
             double kt = m.duration * dm_rand01(m.seed, (uint64_t)(e + m.env_off), ep, 0);
             double mt = (m.time_lim_max > m.time_lim_min) ? m.time_lim_min + (m.time_lim_max - m.time_lim_min) * dm_rand01(m.seed, (uint64_t)(e + m.env_off), ep, 1) : m.time_lim_max;
             sim.b.reset_env(kt, mt);
+            if (HIST && st.hist) sim.b.init_hist(st, e);
             sim.b.emit(io, tap, e, false);
         }
         sim.b.mark(13);

@@ -259,8 +259,10 @@ struct CtxBase {
     void* dalloc(size_t n) { void* p = nullptr; if (rt_malloc(&p, n) != 0) return nullptr; allocs.push_back(p); return p; }
     virtual int setup() = 0;
     virtual int reset(const int* ids_dev, int n, const double* kt_dev, const double* mt_dev) = 0;
-    virtual int step(const float* actions_dev, double dt, int n_updates, float* states, float* rewards, int* term, int* valid, int* end, int flags) = 0;
-    virtual int query(float* states, float* rewards, int* term, int* valid, int* end) = 0;
+    virtual int step(const float* actions_dev, double dt, int n_updates, float* states, float* rewards, int* term, int* valid, int* end, int flags, float* amp = nullptr) = 0;
+    virtual int query(float* states, float* rewards, int* term, int* valid, int* end, float* amp = nullptr) = 0;
+    virtual int amp_expert(int n, const double* times_dev, const double* gh_dev, float* out_dev) = 0;
+    int amp_size = 0; float* d_amp = nullptr; uint64_t expert_calls = 0;
     virtual int probe(int what, double dt) = 0;
     virtual int get_state(double* pose, double* vel, double* tar, double* kin, double* clk, int* flg) = 0;
     virtual int set_state(const double* pose, const double* vel, const double* tar, const double* kin, const double* clk, const int* flg) = 0;
@@ -349,6 +351,22 @@ struct CtxT : CtxBase {
         st.tau = (Real*)dalloc(sizeof(Real) * N * h.D); st.kin = (Real*)dalloc(sizeof(Real) * N * 8);
         st.clock = (double*)dalloc(sizeof(double) * N * 6); st.flag = (int*)dalloc(sizeof(int) * N * 4);
         st.aovf = (cls == 0) ? (Real*)dalloc(sizeof(Real) * (size_t)N * (kMaxRows - ClsBiped::RREG) * kWave) : nullptr;
+        st.hist = nullptr;
+        md.scene_amp = c.scene_amp ? 1 : 0; md.amp_local_root = c.enable_amp_obs_local_root ? 1 : 0;
+        if (c.scene_amp) {
+            // feature layout of one pose block (cSceneImitateAMP::RecordAMPObsPose, SceneImitateAMP.cpp:279-338): root height,
+            // root normal / tangent, joint rotations in joint order (spherical 6, revolute 1), end-effector positions
+            std::vector<int> off(h.J, 0), ee(h.J, -1);
+            int o = 7, ne = 0;
+            for (int j = 1; j < h.J; ++j) { off[j] = o; o += (h.jtype[j] == JT_SPHERICAL) ? 6 : ((h.jtype[j] == JT_REVOLUTE) ? 1 : 0); }
+            for (int j = 0; j < h.J; ++j) if (h.is_ee[j]) ee[j] = ne++;
+            md.amp_ee_base = o; md.amp_pose_size = o + 3 * ne; md.amp_vel_size = h.P - 7 + 6;
+            md.amp_off = up<int>(off); md.amp_ee = up<int>(ee);
+            amp_size = 2 * (md.amp_pose_size + md.amp_vel_size);
+            st.hist = (Real*)dalloc(sizeof(Real) * (size_t)N * 2 * h.P);
+            d_amp = (float*)dalloc(sizeof(float) * (size_t)N * amp_size);
+            if (!st.hist || !d_amp) return fail("device allocation failed");
+        }
         d_actions = (float*)dalloc(sizeof(float) * N * h.A); d_states = (float*)dalloc(sizeof(float) * N * h.S); d_rewards = (float*)dalloc(sizeof(float) * N);
         d_term = (int*)dalloc(sizeof(int) * N); d_valid = (int*)dalloc(sizeof(int) * N); d_end = (int*)dalloc(sizeof(int) * N);
         if (!st.pose || !st.flag || !d_end || !md.mdl_blob) return fail("device allocation failed");
@@ -380,22 +398,31 @@ struct CtxT : CtxBase {
         DM_DISPATCH(k_env_reset, n, md, st, ids_dev, kt_dev, mt_dev);
         return 0;
     }
-    int step(const float* actions_dev, double dt, int n_updates, float* states, float* rewards, int* term, int* valid, int* end, int flags) override {
+    int step(const float* actions_dev, double dt, int n_updates, float* states, float* rewards, int* term, int* valid, int* end, int flags, float* amp) override {
         StepIO<Real> io; memset(&io, 0, sizeof(io));
+        io.amp_obs = amp;
         io.actions = actions_dev; io.states = states; io.rewards = rewards; io.terminate = term; io.valid = valid; io.episode_end = end;
         io.n_updates = n_updates; io.dt = dt; io.auto_reset = (flags & DM_AUTO_RESET) ? 1 : 0; io.emit = (flags & DM_NO_EMIT) ? 0 : 1; io.open_loop = (flags & DM_OPEN_LOOP) ? 1 : 0;
         // two characters per wavefront: biped class, even batch, no debug taps armed (DM_DUO=0 keeps one character per wave)
         if (duo && cls == 0 && hm.D == ClsBiped::ND && (N % 2) == 0 && !dbg.H) {      // (31 row lanes per character assume exactly 34 dofs)
-            RT_LAUNCH((k_env_step_duo<Real, false>), N / 2, stream, md, st, io, dbg);
+            if (st.hist) RT_LAUNCH((k_env_step_duo<Real, false, true>), N / 2, stream, md, st, io, dbg);
+            else RT_LAUNCH((k_env_step_duo<Real, false, false>), N / 2, stream, md, st, io, dbg);
             return 0;
         }
         // production launch: the tap-free instantiation unless a parity test armed the debug taps (dm_probe)
         if (dbg.H) { if (cls == 0) RT_LAUNCH((k_env_step<Real, ClsBiped, true>), N, stream, md, st, io, dbg); else RT_LAUNCH((k_env_step<Real, ClsLarge, true>), N, stream, md, st, io, dbg); }
-        else { if (cls == 0) RT_LAUNCH((k_env_step<Real, ClsBiped, false>), N, stream, md, st, io, dbg); else RT_LAUNCH((k_env_step<Real, ClsLarge, false>), N, stream, md, st, io, dbg); }
+        else if (st.hist) { if (cls == 0) RT_LAUNCH((k_env_step<Real, ClsBiped, false, true>), N, stream, md, st, io, dbg); else RT_LAUNCH((k_env_step<Real, ClsLarge, false, true>), N, stream, md, st, io, dbg); }
+        else { if (cls == 0) RT_LAUNCH((k_env_step<Real, ClsBiped, false, false>), N, stream, md, st, io, dbg); else RT_LAUNCH((k_env_step<Real, ClsLarge, false, false>), N, stream, md, st, io, dbg); }
         return 0;
     }
-    int query(float* states, float* rewards, int* term, int* valid, int* end) override {
+    int amp_expert(int n, const double* times_dev, const double* gh_dev, float* out_dev) override {
+        if (cls == 0) RT_LAUNCH((k_amp_expert<Real, ClsBiped>), n, stream, md, times_dev, gh_dev, out_dev);
+        else RT_LAUNCH((k_amp_expert<Real, ClsLarge>), n, stream, md, times_dev, gh_dev, out_dev);
+        return 0;
+    }
+    int query(float* states, float* rewards, int* term, int* valid, int* end, float* amp) override {
         StepIO<Real> io; memset(&io, 0, sizeof(io));
+        io.amp_obs = amp;
         io.states = states; io.rewards = rewards; io.terminate = term; io.valid = valid; io.episode_end = end; io.emit = 1;
         DM_DISPATCH(k_env_query, N, md, st, io, dbg);
         return 0;
@@ -594,6 +621,54 @@ int dm_step_batch(dm_ctx* ctx, const float* actions, double timestep, int n_upda
     if (copy_out(c, states, c->d_states, sizeof(float) * c->N * c->hm.S) || copy_out(c, rewards, c->d_rewards, sizeof(float) * c->N) ||
         copy_out(c, terminate, c->d_term, sizeof(int) * c->N) || copy_out(c, valid, c->d_valid, sizeof(int) * c->N) || copy_out(c, episode_end, c->d_end, sizeof(int) * c->N)) return -1;
     return 0;
+}
+
+int dm_amp_obs_size(const dm_ctx* ctx) { return ctx ? ctx->c->amp_size : 0; }
+
+int dm_query_amp(dm_ctx* ctx, float* amp_obs, int flags) {
+    if (!ctx || !amp_obs) return fail("null argument");
+    CtxBase* c = ctx->c;
+    if (!c->amp_size) return fail("AMP observations need a `--scene imitate_amp` context (dm_scene_tables.scene_amp)");
+    if (flags & DM_DEVICE_PTRS) return c->query(nullptr, nullptr, nullptr, nullptr, nullptr, amp_obs);
+    if (c->query(nullptr, nullptr, nullptr, nullptr, nullptr, c->d_amp)) return -1;
+    return copy_out(c, amp_obs, c->d_amp, sizeof(float) * (size_t)c->N * c->amp_size);
+}
+
+int dm_step_batch_amp(dm_ctx* ctx, const float* actions, double timestep, int n_updates, float* states, float* rewards,
+                      int32_t* terminate, int32_t* valid, int32_t* episode_end, float* amp_obs, int flags) {
+    if (!ctx) return fail("null ctx");
+    CtxBase* c = ctx->c;
+    if (amp_obs && !c->amp_size) return fail("AMP observations need a `--scene imitate_amp` context (dm_scene_tables.scene_amp)");
+    if (flags & DM_DEVICE_PTRS) return c->step(actions, timestep, n_updates, states, rewards, terminate, valid, episode_end, flags, amp_obs);
+    const float* adev = nullptr;
+    if (actions) { if (rt_h2d(c->d_actions, actions, sizeof(float) * c->N * c->hm.A, c->stream)) return fail("copy failed"); adev = c->d_actions; }
+    if (c->step(adev, timestep, n_updates, c->d_states, c->d_rewards, c->d_term, c->d_valid, c->d_end, flags, amp_obs ? c->d_amp : nullptr)) return -1;
+    if (copy_out(c, states, c->d_states, sizeof(float) * c->N * c->hm.S) || copy_out(c, rewards, c->d_rewards, sizeof(float) * c->N) ||
+        copy_out(c, terminate, c->d_term, sizeof(int) * c->N) || copy_out(c, valid, c->d_valid, sizeof(int) * c->N) || copy_out(c, episode_end, c->d_end, sizeof(int) * c->N) ||
+        copy_out(c, amp_obs, c->d_amp, sizeof(float) * (size_t)c->N * c->amp_size)) return -1;
+    return 0;
+}
+
+int dm_amp_expert(dm_ctx* ctx, int n, const double* times, const double* ground_h, float* out, int flags) {
+    if (!ctx || !out) return fail("null argument");
+    CtxBase* c = ctx->c;
+    if (!c->amp_size) return fail("AMP observations need a `--scene imitate_amp` context (dm_scene_tables.scene_amp)");
+    if (n <= 0) return 0;
+    if (flags & DM_DEVICE_PTRS) {
+        if (!times) return fail("dm_amp_expert with device pointers needs explicit sample times");
+        return c->amp_expert(n, times, ground_h, out);
+    }
+    std::vector<double> t(n);
+    if (times) memcpy(t.data(), times, sizeof(double) * n);
+    else { for (int i = 0; i < n; ++i) t[i] = c->hm.duration * dm_rand01(c->seed, (uint64_t)c->env_off + 0x414D50ull, c->expert_calls, (uint64_t)i); c->expert_calls++; }
+    void *td = nullptr, *gd = nullptr, *od = nullptr; int rc = 0;
+    if (rt_malloc(&td, sizeof(double) * n) || rt_malloc(&od, sizeof(float) * (size_t)n * c->amp_size) || (ground_h && rt_malloc(&gd, sizeof(double) * n))) rc = fail("device allocation failed");
+    if (!rc) { rt_h2d(td, t.data(), sizeof(double) * n, c->stream); if (ground_h) rt_h2d(gd, ground_h, sizeof(double) * n, c->stream); }
+    if (!rc) rc = c->amp_expert(n, (const double*)td, (const double*)gd, (float*)od);
+    if (!rc && rt_d2h(out, od, sizeof(float) * (size_t)n * c->amp_size, c->stream)) rc = fail("copy failed");
+    rt_sync(c->stream);
+    if (td) rt_free(td); if (gd) rt_free(gd); if (od) rt_free(od);
+    return rc;
 }
 
 int dm_build_offsets_scales(const dm_ctx* ctx, double* s_off, double* s_scale, double* a_off, double* a_scale, double* a_min, double* a_max, int32_t* s_norm_groups) {

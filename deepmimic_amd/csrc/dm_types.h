@@ -95,6 +95,12 @@ struct ModelDev {
     double time_lim_min, time_lim_max;       // episode timer range (uniform)
     uint64_t seed;
     int env_off;                             // global id of env 0 of this shard (keeps RNG streams partition-invariant)
+    // ---- `--scene imitate_amp` (scenes/SceneImitateAMP.cpp): reward 0, fall-only termination, AMP observations
+    int scene_amp, amp_local_root;
+    int amp_pose_size, amp_vel_size;         // per timestep; the observation is [pose_t, pose_t-1, vel_t, vel_t-1]
+    const int* amp_off;                      // J   offset of joint j's rotation features inside a pose block (j >= 1)
+    const int* amp_ee;                       // J   ordinal of link j among the end effectors, -1 if it is none
+    int amp_ee_base;                         // offset of the end-effector positions inside a pose block
 };
 
 template <typename Real>
@@ -108,6 +114,7 @@ struct EnvState {
     double* clock;   // N x 6   kin_time, ctrl_time, init_time_offset, timer_time, timer_max, pad
     int* flag;       // N x 4   need_new_action, contact_mask, episode_count, valid
     Real* aovf;      // N x (64 - RREG) x 64  overflow rows of the constraint-space matrix (null when the class keeps all 64 in VGPRs)
+    Real* hist;      // N x 2P  pose | vel at the last action latch (cSceneImitateAMP::mPrevPose / mPrevVel); null unless imitate_amp
 };
 
 // Per-call I/O of the batched step (device pointers; any may be null)
@@ -124,6 +131,7 @@ struct StepIO {
     int auto_reset;         // reset envs whose episode ended, after the outputs are written
     int emit;               // write states / rewards / flags at the end of the call
     int open_loop;          // ignore `actions`; track the reference clip (stream A1 of SURVEY 8d)
+    float* amp_obs;         // N x amp size  RecordAMPObsAgent at the end of the call (imitate_amp scenes only)
 };
 
 // Debug taps for component parity tests (device pointers, null when unused)

@@ -136,6 +136,8 @@ class SceneConfig:
     enable_fall_end: bool = True        # scenes/RLSceneSimChar.cpp:5
     enable_char_contact_fall: bool = True
     enable_rand_char_placement: bool = True
+    enable_amp_obs_local_root: bool = False   # scenes/SceneImitateAMP.cpp:30,42 (`--scene imitate_amp` only)
+    enable_test_time_warp: bool = True        # :31,43; the test-mode time-warp score is not on the accelerated path
     time_lim_min: float = np.inf        # util/Timer.cpp:7-8
     time_lim_max: float = np.inf
     time_lim_exp: float = 1.0
@@ -331,7 +333,7 @@ def parse_scene_config(parser: ArgParser) -> SceneConfig:
     c.fall_contact_bodies = parser.ints("fall_contact_bodies")
     for k in ("sync_char_root_pos", "sync_char_root_rot", "enable_rand_rot_reset",
               "enable_root_rot_fail", "enable_fall_end", "enable_char_contact_fall",
-              "enable_rand_char_placement"):
+              "enable_rand_char_placement", "enable_amp_obs_local_root", "enable_test_time_warp"):
         setattr(c, k, parser.bool(k, getattr(c, k)))
     c.time_lim_min = parser.float("time_lim_min", c.time_lim_min)
     c.time_lim_max = parser.float("time_lim_max", c.time_lim_max)
@@ -393,6 +395,11 @@ def load_scene(char_file: str, ctrl_file: str, motion_file: str,
     if len(pds) != J:
         raise ValueError("PD controller count mismatch")
     pd = np.array([[float(p.get("Kp", 0)), float(p.get("Kd", 0))] for p in pds])
+    if "Frames" not in mj:
+        if "Motions" in mj:
+            raise ValueError("%s is a multi-clip dataset (`--kin_ctrl clips`, anim/ClipsController.cpp); only single-clip "
+                             "motion files are on the accelerated path" % motion_file)
+        raise ValueError("%s has no \"Frames\"" % motion_file)
     frames = np.array(mj["Frames"], dtype=np.float64)
     loop_str = mj.get("Loop", "none")
     if loop_str not in ("none", "wrap"):
@@ -420,8 +427,8 @@ def load_scene_from_args(args: Sequence[str], data_root: str = ".") -> SceneTabl
         if not p.load_file(path):
             raise FileNotFoundError("Failed to load args from: %s" % arg_file)
     cfg = parse_scene_config(p)
-    if cfg.scene != "imitate":
-        raise ValueError("only `--scene imitate` is on the accelerated path (got %r)" % cfg.scene)
+    if cfg.scene not in ("imitate", "imitate_amp"):
+        raise ValueError("only `--scene imitate` and `--scene imitate_amp` are on the accelerated path (got %r)" % cfg.scene)
 
     def res(pth):
         return pth if os.path.isabs(pth) else os.path.join(data_root, pth)

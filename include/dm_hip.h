@@ -53,6 +53,9 @@ typedef struct {
     double friction, erp; int solver_iters;
     int disable_self_collision;  /* 0 (default): links of the character collide with each other except parent-child pairs, as
                                     btMultiBody's default m_hasSelfCollision does (sim/SimCharacter.cpp:857,873,919) */
+    /* `--scene imitate_amp` (scenes/SceneImitateAMP.cpp): CalcReward = 0, CheckTerminate = fall only, AMP observations on */
+    int scene_amp;
+    int enable_amp_obs_local_root;   /* --enable_amp_obs_local_root (SceneImitateAMP.cpp:30,42) */
 } dm_scene_tables;
 
 enum { DM_DEVICE_PTRS = 1, DM_AUTO_RESET = 2, DM_OPEN_LOOP = 4, DM_NO_EMIT = 8 };
@@ -89,6 +92,21 @@ int dm_query(dm_ctx* ctx, float* states, float* rewards, int32_t* terminate, int
  * their terminal reward/flags are written and `states` holds the first observation of the new episode. */
 int dm_step_batch(dm_ctx* ctx, const float* actions, double timestep, int n_updates, float* states, float* rewards,
                   int32_t* terminate, int32_t* valid, int32_t* episode_end, int flags);
+
+/* ---- `--scene imitate_amp` only (dm_scene_tables.scene_amp): adversarial-motion-prior observations
+ * GetAMPObsSize (scenes/SceneImitateAMP.cpp:76-86): 2 x (pose features + velocity features); 0 for a plain imitate scene */
+int dm_amp_obs_size(const dm_ctx* ctx);
+/* RecordAMPObsAgent for every env (:101-113): [pose_t, pose_t-1, vel_t, vel_t-1] of the simulated character, t-1 = the
+ * state at the last action latch (cSceneImitateAMP::UpdateHist, :166-171).  amp_obs N x dm_amp_obs_size() float32. */
+int dm_query_amp(dm_ctx* ctx, float* amp_obs, int flags);
+/* dm_step_batch that also writes RecordAMPObsAgent at the end of the control step (before any auto reset, i.e. the
+ * end-of-path observation of a finished episode, learning/amp_agent.py:239-242). */
+int dm_step_batch_amp(dm_ctx* ctx, const float* actions, double timestep, int n_updates, float* states, float* rewards,
+                      int32_t* terminate, int32_t* valid, int32_t* episode_end, float* amp_obs, int flags);
+/* RecordAMPObsExpert (:115-138), n samples: clip frames at times[i] and one control period earlier (raw cMotion::CalcFrame /
+ * CalcFrameVel).  times NULL -> drawn ~ U[0, duration) from the ctx's counter-based generator (the reference draws from the
+ * scene RNG); ground_h NULL -> 0 (the reference passes the kin character's origin height).  out n x dm_amp_obs_size(). */
+int dm_amp_expert(dm_ctx* ctx, int n, const double* times, const double* ground_h, float* out, int flags);
 
 /* BuildStateOffset/Scale, BuildActionOffset/Scale/BoundMin/BoundMax, BuildStateNormGroups (DeepMimicCore.cpp:232-448) */
 int dm_build_offsets_scales(const dm_ctx* ctx, double* s_off, double* s_scale, double* a_off, double* a_scale,

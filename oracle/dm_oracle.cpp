@@ -18,7 +18,7 @@ enum {
     CFG_NUM_SIM_SUBSTEPS = 0, CFG_WORLD_SCALE, CFG_GRAV_X, CFG_GRAV_Y, CFG_GRAV_Z,
     CFG_SYNC_ROOT_POS, CFG_SYNC_ROOT_ROT, CFG_ENABLE_FALL_END, CFG_ENABLE_CONTACT_FALL, CFG_ENABLE_ROOT_ROT_FAIL,
     CFG_ENABLE_RAND_PLACEMENT, CFG_ENABLE_PHASE_INPUT, CFG_RECORD_WORLD_ROOT_POS, CFG_RECORD_WORLD_ROOT_ROT,
-    CFG_QUERY_RATE, CFG_FRICTION, CFG_ERP, CFG_SOLVER_ITERS, CFG_MAX_CONTACTS, CFG_SELF_COLLISION, CFG_COUNT
+    CFG_QUERY_RATE, CFG_FRICTION, CFG_ERP, CFG_SOLVER_ITERS, CFG_MAX_CONTACTS, CFG_SELF_COLLISION, CFG_SCENE_AMP, CFG_AMP_LOCAL_ROOT, CFG_COUNT
 };
 
 int orc_cfg_count() { return CFG_COUNT; }
@@ -34,6 +34,7 @@ void orc_cfg_default(double* c) {
     c[CFG_ENABLE_PHASE_INPUT] = d.enable_phase_input; c[CFG_RECORD_WORLD_ROOT_POS] = d.record_world_root_pos;
     c[CFG_RECORD_WORLD_ROOT_ROT] = d.record_world_root_rot; c[CFG_QUERY_RATE] = d.query_rate;
     c[CFG_FRICTION] = d.friction; c[CFG_ERP] = d.erp; c[CFG_SOLVER_ITERS] = d.solver_iters; c[CFG_MAX_CONTACTS] = d.max_contacts; c[CFG_SELF_COLLISION] = d.enable_self_collision;
+    c[CFG_SCENE_AMP] = d.scene_amp; c[CFG_AMP_LOCAL_ROOT] = d.enable_amp_obs_local_root;
 }
 
 void* orc_create(const double* jm, const double* bd, int J, const double* pd, const double* frames, int F, int loop,
@@ -47,6 +48,7 @@ void* orc_create(const double* jm, const double* bd, int J, const double* pd, co
     cfg.enable_phase_input = c[CFG_ENABLE_PHASE_INPUT] != 0; cfg.record_world_root_pos = c[CFG_RECORD_WORLD_ROOT_POS] != 0;
     cfg.record_world_root_rot = c[CFG_RECORD_WORLD_ROOT_ROT] != 0; cfg.query_rate = c[CFG_QUERY_RATE];
     cfg.friction = c[CFG_FRICTION]; cfg.erp = c[CFG_ERP]; cfg.solver_iters = (int)c[CFG_SOLVER_ITERS]; cfg.max_contacts = (int)c[CFG_MAX_CONTACTS]; cfg.enable_self_collision = c[CFG_SELF_COLLISION] != 0;
+    cfg.scene_amp = c[CFG_SCENE_AMP] != 0; cfg.enable_amp_obs_local_root = c[CFG_AMP_LOCAL_ROOT] != 0;
     Scene* s = new Scene();
     s->init(jm, bd, J, pd, frames, F, loop != 0, fall_mask, cfg);
     return s;
@@ -63,6 +65,13 @@ void orc_set_action(void* h, const double* a) { ((Scene*)h)->set_action(a); }
 void orc_update(void* h, double dt) { ((Scene*)h)->update(dt); }
 int orc_need_new_action(void* h) { return ((Scene*)h)->need_new_action ? 1 : 0; }
 void orc_record_state(void* h, double* out) { ((Scene*)h)->record_state(out); }
+int orc_amp_obs_size(void* h) { return ((Scene*)h)->amp_obs_size(); }
+void orc_amp_obs_agent(void* h, double* out) { ((Scene*)h)->amp_obs_agent(out); }
+void orc_amp_obs_expert(void* h, double t, double* out) { ((Scene*)h)->amp_obs_expert(t, out); }
+void orc_prev_state(void* h, double* pose, double* vel) {
+    Scene* s = (Scene*)h;
+    for (int i = 0; i < s->sk.P; ++i) { pose[i] = s->prev_pose[i]; vel[i] = s->prev_vel[i]; }
+}
 double orc_calc_reward(void* h) { return ((Scene*)h)->calc_reward(); }
 double orc_calc_reward_terms(void* h, double* terms) { return ((Scene*)h)->calc_reward(terms); }
 int orc_check_terminate(void* h) { return ((Scene*)h)->check_terminate(); }

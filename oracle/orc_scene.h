@@ -20,6 +20,9 @@ struct SceneCfg {
     bool enable_rand_char_placement = true;
     bool enable_phase_input = false, record_world_root_pos = false, record_world_root_rot = false;
     double query_rate = 30.0;            // sim/CtController.cpp:8,165
+    // --- `--scene imitate_amp` (scenes/SceneImitateAMP.cpp): reward 0, terminate on fall only, AMP observations
+    bool scene_amp = false;
+    bool enable_amp_obs_local_root = false;   // SceneImitateAMP.cpp:30,42
     // --- DM-physics v1 constants [EXT-BULLET, SURVEY App. C] ---
     double friction = 0.9 * 0.9;         // link 0.9 (SimCharacter.cpp:26) x ground 0.9 (Ground.cpp:14-27)
     double erp = 0.2;                    // btContactSolverInfo::m_erp2
@@ -97,6 +100,7 @@ struct Scene {
     Vec pose, vel;       // sim character (joint space, reference pose/vel layout)
     Vec tar_pose;        // PD targets (root slots unused)
     Vec tau;             // last SPD torque (pose layout)
+    Vec prev_pose, prev_vel;   // cSceneImitateAMP::mPrevPose / mPrevVel (SceneImitateAMP.cpp:152-171)
     double ctrl_time = 0, init_time_offset = 0;   // cDeepMimicCharController::mTime, cCtController::mInitTimeOffset
     bool need_new_action = true;
     double timer_time = 0, timer_max = std::numeric_limits<double>::infinity();
@@ -163,6 +167,14 @@ struct Scene {
         }
         kin.set_root_pos_(root_pos(pose));
         calc_links(sk, pose, vel, links);
+        init_hist();
+    }
+    // cSceneImitateAMP::InitHist (SceneImitateAMP.cpp:152-164): history := kin character one control period before the
+    // controller time, origin transform included (cKinCharacter::CalcPose / CalcVel)
+    void init_hist() {
+        double prev_time = ctrl_time - 1.0 / cfg.query_rate;
+        kin.calc_pose(prev_time, prev_pose);
+        kin.calc_vel(prev_time, prev_vel);
     }
     // what cSimCharacter::SetPose/SetVel followed by BuildPose/BuildVel leave in mPose/mVel
     void set_sim_state(const Vec& p, const Vec& v) {
@@ -490,6 +502,8 @@ struct Scene {
 
     // ------------------------------------------------------------------ one scene update
     void update(double dt) {
+        // cRLSceneSimChar::PreUpdate (RLSceneSimChar.cpp:263-275) -> cSceneImitateAMP::NewActionUpdate -> UpdateHist (:166-171)
+        if (need_new_action) { prev_pose = reported_pose(); prev_vel = vel; }
         timer_time += dt;                                            // cScene::Update
         // 4a UpdateKinChar (SceneImitate.cpp:306-318)
         double prev_phase = kin.phase();
@@ -531,7 +545,8 @@ struct Scene {
     }
     int check_terminate() const {
         bool fail = cfg.enable_fall_end && has_fallen();
-        if (!fail && mo.is_over(kin.time)) fail = true;              // SceneImitate.cpp:193-205
+        // cSceneImitateAMP::CheckTerminate (SceneImitateAMP.cpp:184-188) keeps only the fall test of cRLSceneSimChar (:187-197)
+        if (!fail && !cfg.scene_amp && mo.is_over(kin.time)) fail = true;   // SceneImitate.cpp:193-205
         return fail ? TERM_FAIL : TERM_NULL;
     }
     bool is_episode_end() const { return timer_time >= timer_max || check_terminate() != TERM_NULL; }
@@ -547,6 +562,8 @@ struct Scene {
 
     // ------------------------------------------------------------------ reward (SceneImitate.cpp:7-127,163-175)
     double calc_reward(double* terms /*5 errors, optional*/ = nullptr) const {
+        // cSceneImitateAMP::CalcReward (SceneImitateAMP.cpp:173-182): 0 outside the test-mode time-warp score
+        if (cfg.scene_amp) { if (terms) for (int i = 0; i < 5; ++i) terms[i] = 0; return 0; }
         if (has_fallen()) return 0;
         const int J = sk.J;
         const real pose_w = 0.5, vel_w = 0.05, end_eff_w = 0.15, root_w = 0.2, com_w = 0.1;
@@ -631,6 +648,71 @@ struct Scene {
             idx += 6;
         }
         assert(idx == S);
+    }
+
+    // ------------------------------------------------------------------ AMP observations (SceneImitateAMP.cpp:76-138,213-371)
+    int amp_pose_size() const {                                      // GetAMPObsPoseSize (:213-241)
+        int size = 1 + 6, n_ee = 0;
+        for (int j = 0; j < sk.J; ++j) if (sk.is_end_eff(j)) ++n_ee;
+        size += 3 * n_ee;
+        for (int j = 1; j < sk.J; ++j) size += (sk.type(j) == JT_SPHERICAL) ? 6 : sk.size(j);
+        return size;
+    }
+    int amp_vel_size() const { return sk.P - 7 + 6; }                // GetAMPObsVelSize (:243-257)
+    int amp_obs_size() const { return 2 * (amp_pose_size() + amp_vel_size()); }
+    int record_amp_pose(const Vec& p, real ground_h, const Q4& ref_rot, double* out) const {   // RecordAMPObsPose (:279-338)
+        int idx = 0;
+        V3 rpos = root_pos(p); Q4 rrot = root_rot(p);
+        out[idx++] = rpos.y - ground_h;
+        if (cfg.enable_amp_obs_local_root) rrot = ref_rot * rrot;
+        V3 nrm = qrot(rrot, V3(0, 1, 0)), tan = qrot(rrot, V3(1, 0, 0));   // cMathUtil::CalcNormalTangent (MathUtil.cpp:617-623)
+        out[idx] = nrm.x; out[idx + 1] = nrm.y; out[idx + 2] = nrm.z; out[idx + 3] = tan.x; out[idx + 4] = tan.y; out[idx + 5] = tan.z;
+        idx += 6;
+        for (int j = 1; j < sk.J; ++j) {
+            int off = sk.offset(j);
+            if (sk.type(j) == JT_SPHERICAL) {
+                Q4 q = joint_quat(p, off);
+                V3 n = qrot(q, V3(0, 1, 0)), t = qrot(q, V3(1, 0, 0));
+                out[idx] = n.x; out[idx + 1] = n.y; out[idx + 2] = n.z; out[idx + 3] = t.x; out[idx + 4] = t.y; out[idx + 5] = t.z;
+                idx += 6;
+            } else for (int k = 0; k < sk.size(j); ++k) out[idx++] = p[off + k];
+        }
+        for (int j = 0; j < sk.J; ++j) if (sk.is_end_eff(j)) {
+            // cKinTree::CalcBodyPartPos (KinTree.cpp:272-281): joint world transform x body attach point
+            V3 bp = xf_point(joint_world_trans(sk, p, j), sk.body_attach_pt(j));
+            V3 rel = qrot(ref_rot, bp - rpos);
+            out[idx] = rel.x; out[idx + 1] = rel.y; out[idx + 2] = rel.z; idx += 3;
+        }
+        return idx;
+    }
+    int record_amp_vel(const Vec& v, const Q4& ref_rot, double* out) const {   // RecordAMPObsVel (:340-371)
+        V3 rv = root_vel(v), rw = root_ang_vel(v);
+        if (cfg.enable_amp_obs_local_root) { rv = qrot(ref_rot, rv); rw = qrot(ref_rot, rw); }
+        out[0] = rv.x; out[1] = rv.y; out[2] = rv.z; out[3] = rw.x; out[4] = rw.y; out[5] = rw.z;
+        for (int i = 7; i < sk.P; ++i) out[6 + i - 7] = v[i];
+        return 6 + sk.P - 7;
+    }
+    void build_amp_obs(const Vec& pp, const Vec& pv, const Vec& p, const Vec& v, real ground_h, double* out) const {   // BuildAMPObs (:259-277)
+        real heading = calc_heading(root_rot(p));
+        Q4 ref_rot = quat_axis_angle(V3(0, 1, 0), -heading);          // cKinTree::CalcHeadingRot (KinTree.cpp:1629-1635)
+        int idx = 0;
+        idx += record_amp_pose(p, ground_h, ref_rot, out + idx);
+        idx += record_amp_pose(pp, ground_h, ref_rot, out + idx);
+        idx += record_amp_vel(v, ref_rot, out + idx);
+        idx += record_amp_vel(pv, ref_rot, out + idx);
+        assert(idx == amp_obs_size());
+    }
+    void amp_obs_agent(double* out) const {                          // RecordAMPObsAgent (:101-113); plane: ground height 0
+        build_amp_obs(prev_pose, prev_vel, reported_pose(), vel, 0, out);
+    }
+    // RecordAMPObsExpert (:115-138) with the random clip time passed in: raw cMotion::CalcFrame / CalcFrameVel (no origin,
+    // no cycle offset) at t and t - 1/query_rate, ground height := kin origin y
+    void amp_obs_expert(double t, double* out) const {
+        Vec p, v, pp, pv;
+        mo.calc_frame(sk, t, p); mo.calc_frame_vel(t, v);
+        double tp = t - 1.0 / cfg.query_rate;
+        mo.calc_frame(sk, tp, pp); mo.calc_frame_vel(tp, pv);
+        build_amp_obs(pp, pv, p, v, kin.origin.y, out);
     }
 };
 

@@ -11,7 +11,7 @@ ORACLE_DIR = os.path.join(ROOT, "oracle")
 CFG_KEYS = ["num_sim_substeps", "world_scale", "grav_x", "grav_y", "grav_z", "sync_root_pos", "sync_root_rot",
             "enable_fall_end", "enable_contact_fall", "enable_root_rot_fail", "enable_rand_placement",
             "enable_phase_input", "record_world_root_pos", "record_world_root_rot", "query_rate",
-            "friction", "erp", "solver_iters", "max_contacts", "self_collision"]
+            "friction", "erp", "solver_iters", "max_contacts", "self_collision", "scene_amp", "amp_local_root"]
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int)
@@ -55,7 +55,8 @@ class Oracle:
                     enable_fall_end=c.enable_fall_end, enable_contact_fall=c.enable_char_contact_fall,
                     enable_root_rot_fail=c.enable_root_rot_fail, enable_rand_placement=c.enable_rand_char_placement,
                     enable_phase_input=tables.enable_phase_input, record_world_root_pos=tables.record_world_root_pos,
-                    record_world_root_rot=tables.record_world_root_rot, query_rate=tables.query_rate)
+                    record_world_root_rot=tables.record_world_root_rot, query_rate=tables.query_rate,
+                    scene_amp=(c.scene == "imitate_amp"), amp_local_root=getattr(c, "enable_amp_obs_local_root", False))
         vals.update(cfg_overrides)
         for k, v in vals.items():
             cfg[CFG_KEYS.index(k)] = float(v)
@@ -96,6 +97,24 @@ class Oracle:
         out = np.zeros(self.S)
         self.lib.orc_record_state(self.h, _d(out))
         return out
+
+    def amp_obs_size(self):
+        return int(self.lib.orc_amp_obs_size(self.h))
+
+    def amp_obs_agent(self):
+        out = np.zeros(self.amp_obs_size())
+        self.lib.orc_amp_obs_agent(self.h, _d(out))
+        return out
+
+    def amp_obs_expert(self, t):
+        out = np.zeros(self.amp_obs_size())
+        self.lib.orc_amp_obs_expert(self.h, C.c_double(t), _d(out))
+        return out
+
+    def prev_state(self):
+        p, v = np.zeros(self.P), np.zeros(self.P)
+        self.lib.orc_prev_state(self.h, _d(p), _d(v))
+        return p, v
 
     def calc_reward(self):
         return self.lib.orc_calc_reward(self.h)

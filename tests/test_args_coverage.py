@@ -35,3 +35,35 @@ def test_all_imitate_arg_files_run(emu_lib):
         assert np.isfinite(out["state"]).all() and np.isfinite(out["reward"]).all(), f
         assert out["state"].shape == (2, t.state_dim) and env.A == t.action_dim, f
         env.close()
+
+
+def _amp_arg_files():
+    single, dataset = [], []
+    for f in sorted(glob.glob(os.path.join(REF, "args", "*.txt"))):
+        p = model.ArgParser([])
+        p.load_file(f)
+        if p.str("scene", "") == "imitate_amp":
+            (dataset if "datasets/" in p.str("motion_file", "") else single).append(os.path.relpath(f, REF))
+    return single, dataset
+
+
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "args")), reason="reference checkout not present")
+def test_imitate_amp_arg_files_run(emu_lib):
+    """The 34 `--scene imitate_amp` arg files: the single-clip ones (kin_ctrl motion) run; the multi-clip dataset ones
+    (kin_ctrl clips, anim/ClipsController.cpp) are refused with a clear error -- not on the accelerated path yet."""
+    single, dataset = _amp_arg_files()
+    assert len(single) + len(dataset) == 34 and len(single) >= 24
+    for f in single:
+        t = model.load_scene_from_args(["--arg_file", f], data_root=REF)
+        assert t.cfg.scene == "imitate_amp"
+        env = BatchEnv(t, 2, precision=64, lib_path=emu_lib)
+        env.reset()
+        out = env.step(None, 1.0 / 600, 2, open_loop=True, amp=True)
+        assert out["amp_obs"].shape == (2, env.amp_size) and env.amp_size > 0 and np.isfinite(out["amp_obs"]).all(), f
+        assert (out["reward"] == 0).all(), f
+        ex = env.amp_expert(3)
+        assert np.isfinite(ex).all(), f
+        env.close()
+    for f in dataset:
+        with pytest.raises(ValueError, match="multi-clip dataset"):
+            model.load_scene_from_args(["--arg_file", f], data_root=REF)

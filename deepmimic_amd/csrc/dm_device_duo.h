@@ -17,6 +17,7 @@ namespace dmk {
 
 #ifdef DM_EMU
 template <typename T> static inline T half_bcast(T v, int src, int half) { return wave_shfl(v, half * 32 + src); }
+template <int SRC, typename T> static inline T half_bcast_c(T v, int half) { return half_bcast(v, SRC, half); }
 template <typename T> static inline T half_sum(T v) {
     T* x = reinterpret_cast<T*>(emu::g_xchg);
     x[threadIdx.x] = v; __syncthreads();
@@ -35,6 +36,12 @@ template <int NP2, typename R2, typename Real> static inline void duo_gram32(con
 __device__ __forceinline__ float half_bcast(float v, int src, int half) { const float a = lane_bcast(v, src), b = lane_bcast(v, 32 + src); return half ? b : a; }
 __device__ __forceinline__ double half_bcast(double v, int src, int half) { const double a = lane_bcast(v, src), b = lane_bcast(v, 32 + src); return half ? b : a; }
 __device__ __forceinline__ int half_bcast(int v, int src, int half) { const int a = lane_bcast(v, src), b = lane_bcast(v, 32 + src); return half ? b : a; }
+// lane SRC of the own half, SRC static: one ds_swizzle (bit-mask mode inside each group of 32 lanes: and 0, or SRC, xor 0)
+// through the LDS crossbar instead of two v_readlane + two v_mov + a select -- for issue-bound loops (Gauss-Seidel rows)
+template <int SRC> __device__ __forceinline__ float half_bcast_c(float v, int half) {
+    return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), SRC << 5));
+}
+template <int SRC> __device__ __forceinline__ double half_bcast_c(double v, int half) { return half_bcast(v, SRC, half); }
 __device__ __forceinline__ float half_sum(float v) {
     v += DM_DPP_F(v, 0xB1, 0xf, true);     // quad_perm [1,0,3,2]
     v += DM_DPP_F(v, 0x4E, 0xf, true);     // quad_perm [2,3,0,1]
@@ -388,31 +395,35 @@ struct DuoSim {
                 for (int r = 0; r < 32; ++r) arow.set(r, g[r] * inv_adiag);
             }
             b.mark(10);
-            Real q = (brow - cvec) * inv_adiag;
+            // Projected Gauss-Seidel on t = lambda + q (the pre-clamp target of a row): visiting row r leaves t_r unchanged
+            // (A_rr = 1 after the row scaling) and moves every other t_c by -A_cr delta, so with a zeroed diagonal the column
+            // update is one uniform FMA and the row's own `lambda + q` add disappears.
+#pragma unroll
+            for (int r = 0; r < 32; ++r) if (hl == r) arow.set(r, (Real)0);
+            Real t = (brow - cvec) * inv_adiag;
             const int nrm_lane = is_fric ? NL + ((hl - RN) >> 1) : 0;
             Real lo = 0, hi = is_fric ? (Real)0 : (Real)1e30;
-            // sweep bounds of the pair: rows up to the larger R; a lane beyond its own R has q = 0, lambda = 0 and changes nothing
+            // sweep bounds of the pair: rows up to the larger R (rounded up to 4); a lane beyond its own R has t = 0, lambda = 0
+            // and changes nothing.  fmask: the rows at which a character's friction bounds are refreshed from its normal impulses.
             const int Ra = lane_bcast(R, 0), Rb = lane_bcast(R, 32);
-            int Rv = Ra > Rb ? Ra : Rb, RNa = lane_bcast(RN, 0), RNb = lane_bcast(RN, 32), lv = hl;
-            for (int it = 0; it < m.solver_iters; ++it) {
-                DM_OPAQUE_S(Rv); DM_OPAQUE_S(RNa); DM_OPAQUE_S(RNb); DM_OPAQUE_V(lv);
-#pragma unroll
-                for (int blk = 0; blk < HW / 8; ++blk) {
-                    if (blk * 8 < Rv) {
-#pragma unroll
-                        for (int i = 0; i < 8; ++i) {
-                            const int r = blk * 8 + i;
-                            if (r < Rv) {
-                                if (r == RNa || r == RNb) { const Real ln = wave_shfl(lam, half * 32 + nrm_lane); if (is_fric && r == RN) { hi = m.friction * ln; lo = -hi; } }
-                                const Real nl = dm_med3(lo, lam + q, hi);
-                                const Real delta = half_bcast(nl - lam, r, half);
-                                q -= arow.get(r) * delta;
-                                if (lv == r) lam = nl;
-                            }
-                        }
-                    }
-                }
+            int Rv = Ra > Rb ? Ra : Rb, lv = hl;
+            uint32_t fmask = (1u << lane_bcast(RN, 0)) | (1u << lane_bcast(RN, 32));
+#define DM_DUO_PGS_ROW(r)                                                                                              \
+            {                                                                                                          \
+                if ((fmask >> (r)) & 1u) { const Real ln = wave_shfl(lam, half * 32 + nrm_lane); if (is_fric && (r) == RN) { hi = m.friction * ln; lo = -hi; } } \
+                const Real nl = dm_med3(lo, t, hi);                                                                    \
+                const Real delta = half_bcast_c<(r)>(nl - lam, half);                                                  \
+                t -= arow.get(r) * delta;                                                                              \
+                if (lv == (r)) lam = nl;                                                                               \
             }
+#define DM_DUO_PGS_BLK(b4) if ((b4) * 4 < Rv) { DM_DUO_PGS_ROW((b4) * 4) DM_DUO_PGS_ROW((b4) * 4 + 1) DM_DUO_PGS_ROW((b4) * 4 + 2) DM_DUO_PGS_ROW((b4) * 4 + 3) }
+            for (int it = 0; it < m.solver_iters; ++it) {
+                DM_OPAQUE_S(Rv); DM_OPAQUE_S(fmask); DM_OPAQUE_V(lv);
+                DM_DUO_PGS_BLK(0) DM_DUO_PGS_BLK(1) DM_DUO_PGS_BLK(2) DM_DUO_PGS_BLK(3)
+                DM_DUO_PGS_BLK(4) DM_DUO_PGS_BLK(5) DM_DUO_PGS_BLK(6) DM_DUO_PGS_BLK(7)
+            }
+#undef DM_DUO_PGS_BLK
+#undef DM_DUO_PGS_ROW
             if (hl >= R) lam = 0;
         } else b.mark(10);
         b.mark(11);

@@ -721,3 +721,6 @@ int dm_bench_rollout(dm_ctx* ctx, int warmup, int steps, double timestep, int n_
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------- on-device policy inference
+#include "dm_policy_host.h"

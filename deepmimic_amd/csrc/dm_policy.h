@@ -1,0 +1,189 @@
+// On-device policy inference: the actor of learning/pg_agent.py:141-188 / ppo_agent.py --
+//   a = unnormalize_a( W3 relu(W2 relu(W1 normalize_s(s) + b1) + b2) + b3  [+ exp(logstd) * N(0,1)] )
+// with the net of learning/nets/fc_2layers_1024units.py (1024, 512, ReLU) and the normalizers of learning/normalizer.py:95-102 --
+// so that the 30 Hz loop (observation -> action -> 20 scene updates) never leaves the GPU.
+//
+// Unlike the rigid-body path this IS matrix-core work (batch 4096 x 227 x 1024 ...): three dense layers on
+// v_mfma_f32_16x16x32_bf16, bf16 operands, fp32 accumulation.  One wavefront per workgroup owns a (16*MT) x (16*NT) output
+// tile; A fragments come straight from the row-major activations (16 B per lane), B fragments from weights the host packed
+// in fragment order ([n-tile][k-step][lane][8], one coalesced 1 KB read per fragment, L2-resident: 1.5 MB in all); bias,
+// ReLU, the observation normaliser (layer 1) and the Gaussian head + action un-normaliser (layer 3) are fused into the
+// prologue / epilogue.  Operand mapping: lane l carries row / column l & 15 and the 8 k-values 8 * (l >> 4) .. + 7 of the
+// 32-wide k-step for both A and B (any consistent assignment sums the same products); C/D: column l & 15, rows
+// 4 * (l >> 4) + reg (cdna_hip_programming.md, "Fragment layout").
+#pragma once
+#include <stdint.h>
+
+namespace dmp {
+
+struct PolicyDev {
+    int S, H1, H2, A;                 // true layer widths
+    int K1, N3;                       // padded: K1 = S rounded up to 32, N3 = A rounded up to 32
+    const uint16_t *w1p, *w2p, *w3p;  // packed bf16 fragments
+    const float *b1, *b2, *b3;        // biases (b3 padded to N3 with zeros)
+    const float *s_mean, *s_inv_std;  // observation normaliser (learning/normalizer.py:95-98), S entries
+    float s_clip;
+    const float *a_mean, *a_std;      // action un-normaliser (:100-102), A entries
+    const float *logstd;              // A entries (TFDistributionGaussianDiag, StdType.Default: a bias vector)
+};
+
+struct PolicyIO {
+    const float* states;   // M x S fp32 (RecordState of every env)
+    uint16_t* h1;          // M x H1 bf16
+    uint16_t* h2;          // M x H2 bf16
+    float* actions;        // M x A fp32
+    float* logp;           // M or null
+    int M;
+    int sample;            // 0: mode of the Gaussian (test / deterministic), 1: mean + std * noise
+    uint32_t seed_lo, seed_hi; uint32_t step; int env_off;   // Philox4x32-10 key = (seed_lo + global env id, seed_hi), counter = (step * A + j, 0, 0, 0)
+};
+
+static inline uint16_t f32_to_bf16_host(float f) { uint32_t u; memcpy(&u, &f, 4); if ((u & 0x7fffffffu) > 0x7f800000u) return 0x7fc0; u += 0x7fffu + ((u >> 16) & 1u); return (uint16_t)(u >> 16); }
+
+#ifdef DM_EMU
+#define DMP_DEV inline
+struct bf16x8 { uint16_t v[8]; };
+struct f32x4 { float v[4]; float& operator[](int i) { return v[i]; } float operator[](int i) const { return v[i]; } };
+static inline float bf16_to_f32(uint16_t h) { uint32_t u = (uint32_t)h << 16; float f; memcpy(&f, &u, 4); return f; }
+// lane-exchange emulation of the matrix-core instruction; every lane calls it from uniform control flow
+static inline f32x4 mfma16(const bf16x8& a, const bf16x8& b, f32x4 c) {
+    static uint16_t xa[64][8], xb[64][8];
+    const int l = threadIdx.x;
+    for (int i = 0; i < 8; ++i) { xa[l][i] = a.v[i]; xb[l][i] = b.v[i]; }
+    __syncthreads();
+    const int col = l & 15, g = l >> 4;
+    for (int r = 0; r < 4; ++r) {
+        const int row = 4 * g + r; float acc = c[r];
+        for (int g2 = 0; g2 < 4; ++g2) for (int i = 0; i < 8; ++i) acc += bf16_to_f32(xa[row + 16 * g2][i]) * bf16_to_f32(xb[col + 16 * g2][i]);
+        c[r] = acc;
+    }
+    __syncthreads();
+    return c;
+}
+static inline float lane_xor_f(float v, int mask) { return dmk::wave_shfl(v, (int)(threadIdx.x ^ mask)); }
+#else
+#define DMP_DEV __device__ __forceinline__
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+DMP_DEV f32x4 mfma16(const bf16x8& a, const bf16x8& b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+DMP_DEV float lane_xor_f(float v, int mask) { return __shfl_xor(v, mask, 64); }
+#endif
+
+DMP_DEV uint16_t f32_to_bf16(float f) {          // round to nearest even (inputs are finite)
+    uint32_t u = __builtin_bit_cast(uint32_t, f);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+DMP_DEV void set8(bf16x8& f, int i, uint16_t h) {
+#ifdef DM_EMU
+    f.v[i] = h;
+#else
+    f[i] = (short)h;
+#endif
+}
+
+// Philox4x32-10 (Salmon et al. 2011), the generator of deepmimic_amd/streams.py
+DMP_DEV void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t (&out)[4]) {
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3; k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+DMP_DEV float philox_normal(uint32_t env, uint32_t ctr, uint32_t seed_lo, uint32_t seed_hi) {
+    uint32_t r[4]; philox4x32_10(ctr, 0, 0, 0, seed_lo + env, seed_hi, r);
+    const float u1 = ((float)(r[0] >> 8) + 0.5f) * (1.0f / 16777216.0f), u2 = ((float)(r[1] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    return sqrtf(-2.0f * logf(u1)) * cosf(6.283185307179586f * u2);
+}
+
+// MODE 0: layer 1 (fp32 observations -> normalise -> bf16; ReLU; bf16 out)   K = K1, N = H1
+// MODE 1: layer 2 (bf16 in; ReLU; bf16 out)                                  K = H1, N = H2
+// MODE 2: layer 3 (bf16 in; Gaussian head + un-normalise; fp32 actions)      K = H2, N = N3
+template <int MODE, int MT, int NT>
+__global__ void __launch_bounds__(64) k_policy_layer(PolicyDev p, PolicyIO io) {
+    const int l = threadIdx.x, c = l & 15, g = l >> 4;
+    const int K = (MODE == 0) ? p.K1 : (MODE == 1 ? p.H1 : p.H2);
+    const int N = (MODE == 0) ? p.H1 : (MODE == 1 ? p.H2 : p.N3);
+    const int n_col_tiles = N / (16 * NT);
+    // consecutive workgroups walk down the rows of one column block: they read the same weight fragments back to back
+    const int row_blocks = (io.M + 16 * MT - 1) / (16 * MT);
+    const int cb = blockIdx.x / row_blocks, rb = blockIdx.x % row_blocks;
+    if (cb >= n_col_tiles) return;
+    const int row0 = rb * 16 * MT, nt0 = cb * NT, KS = K / 32;
+    const uint16_t* wp = (MODE == 0) ? p.w1p : (MODE == 1 ? p.w2p : p.w3p);
+    const uint16_t* ain = (MODE == 1) ? io.h1 : io.h2;
+
+    f32x4 acc[MT][NT];
+    for (int i = 0; i < MT; ++i) for (int j = 0; j < NT; ++j) for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.0f;
+
+#pragma unroll 2
+    for (int ks = 0; ks < KS; ++ks) {
+        bf16x8 a[MT], b[NT];
+        const int k0 = ks * 32 + 8 * g;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int row = row0 + 16 * i + c;
+            if (MODE == 0) {
+                const float* srow = io.states + (size_t)(row < io.M ? row : 0) * p.S;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int k = k0 + e;
+                    float x = 0.0f;
+                    if (k < p.S && row < io.M) { x = (srow[k] - p.s_mean[k]) * p.s_inv_std[k]; x = fminf(fmaxf(x, -p.s_clip), p.s_clip); }
+                    set8(a[i], e, f32_to_bf16(x));
+                }
+            } else {
+                a[i] = *reinterpret_cast<const bf16x8*>(ain + (size_t)(row < io.M ? row : 0) * K + k0);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NT; ++j) b[j] = *reinterpret_cast<const bf16x8*>(wp + ((size_t)((nt0 + j) * KS + ks) * 64 + l) * 8);
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[i][j] = mfma16(a[i], b[j], acc[i][j]);
+    }
+
+    if (MODE != 2) {
+        const float* bias = (MODE == 0) ? p.b1 : p.b2;
+        uint16_t* out = (MODE == 0) ? io.h1 : io.h2;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int col = (nt0 + j) * 16 + c; const float bc = bias[col];
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = row0 + 16 * i + 4 * g + r;
+                    if (row < io.M) out[(size_t)row * N + col] = f32_to_bf16(fmaxf(acc[i][j][r] + bc, 0.0f));
+                }
+        }
+    } else {
+        // Gaussian head: norm_a = mean + exp(logstd) z, a = norm_a * a_std + a_mean, logp = sum_j (-z^2/2 - logstd_j) - A/2 log 2 pi
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = row0 + 16 * i + 4 * g + r;
+                float lp = 0.0f;
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    const int col = (nt0 + j) * 16 + c;
+                    if (col < p.A) {
+                        const float ls = p.logstd[col];
+                        float z = 0.0f;
+                        if (io.sample && row < io.M) z = philox_normal((uint32_t)(io.env_off + row), io.step * (uint32_t)p.A + (uint32_t)col, io.seed_lo, io.seed_hi);
+                        const float na = acc[i][j][r] + p.b3[col] + expf(ls) * z;
+                        if (row < io.M) io.actions[(size_t)row * p.A + col] = na * p.a_std[col] + p.a_mean[col];
+                        lp += -0.5f * z * z - ls;
+                    }
+                }
+                // the 16 lanes of a group hold the 16 columns of one row
+                lp += lane_xor_f(lp, 1); lp += lane_xor_f(lp, 2); lp += lane_xor_f(lp, 4); lp += lane_xor_f(lp, 8);
+                if (io.logp && c == 0 && row < io.M) io.logp[row] = lp - 0.5f * (float)p.A * 1.8378770664093453f;
+            }
+    }
+}
+
+}  // namespace dmp

@@ -1,0 +1,85 @@
+// Host side of the on-device policy (dm_policy.h): packs the fp32 weights of the reference's actor into bf16 MFMA fragments
+// and launches the three layer kernels.  Included at the end of dm_host.cpp (shares its runtime shim).
+#include "dm_policy.h"
+
+struct dm_policy {
+    dmp::PolicyDev pd; int device_id = 0; int cap = 0;
+    uint16_t *h1 = nullptr, *h2 = nullptr;
+    std::vector<void*> allocs;
+    ~dm_policy() { for (void* p : allocs) rt_free(p); if (h1) rt_free(h1); if (h2) rt_free(h2); }
+    void* up(const void* host, size_t bytes) { void* d = nullptr; if (rt_malloc(&d, bytes)) return nullptr; allocs.push_back(d); if (rt_h2d(d, host, bytes, 0)) return nullptr; return d; }
+};
+
+// fragment order [n-tile][k-step][lane][8]: lane l <-> column 16 nt + (l & 15), k = 32 ks + 8 (l >> 4) + i; W is [K x N] row-major
+// (tf.layers.dense kernel layout: input index first)
+static std::vector<uint16_t> pack_weights(const float* W, int K, int N, int Kp, int Np) {
+    std::vector<uint16_t> out((size_t)Kp * Np, 0);
+    const int KS = Kp / 32;
+    for (int nt = 0; nt < Np / 16; ++nt) for (int ks = 0; ks < KS; ++ks) for (int l = 0; l < 64; ++l) for (int i = 0; i < 8; ++i) {
+        const int n = 16 * nt + (l & 15), k = 32 * ks + 8 * (l >> 4) + i;
+        out[(((size_t)nt * KS + ks) * 64 + l) * 8 + i] = (k < K && n < N) ? dmp::f32_to_bf16_host(W[(size_t)k * N + n]) : (uint16_t)0;
+    }
+    return out;
+}
+
+extern "C" {
+
+int dm_policy_create(int device_id, const dm_policy_params* pp, dm_policy** out) {
+    if (!pp || !out) return fail("null argument");
+    if (pp->state_dim < 1 || pp->action_dim < 1 || pp->hidden1 < 64 || pp->hidden2 < 64) return fail("dm_policy_create: bad layer widths");
+    if (pp->hidden1 % 64 || pp->hidden2 % 64) return fail("dm_policy_create: hidden widths must be multiples of 64 (reference: 1024, 512)");
+    if (!pp->w1 || !pp->b1 || !pp->w2 || !pp->b2 || !pp->w3 || !pp->b3) return fail("dm_policy_create: null weights");
+#ifndef DM_EMU
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail("no HIP device available: libdm_hip.so has no CPU fallback");
+    if (device_id < 0 || device_id >= ndev) return fail("invalid device_id");
+    HIPCHK(hipSetDevice(device_id));
+#endif
+    dm_policy* p = new dm_policy(); p->device_id = device_id;
+    dmp::PolicyDev& d = p->pd; memset(&d, 0, sizeof(d));
+    d.S = pp->state_dim; d.H1 = pp->hidden1; d.H2 = pp->hidden2; d.A = pp->action_dim;
+    d.K1 = (d.S + 31) / 32 * 32; d.N3 = (d.A + 31) / 32 * 32;
+    std::vector<uint16_t> w1 = pack_weights(pp->w1, d.S, d.H1, d.K1, d.H1), w2 = pack_weights(pp->w2, d.H1, d.H2, d.H1, d.H2), w3 = pack_weights(pp->w3, d.H2, d.A, d.H2, d.N3);
+    std::vector<float> b3(d.N3, 0.0f), sm(d.S, 0.0f), si(d.S, 1.0f), am(d.A, 0.0f), as(d.A, 1.0f), ls(d.A, 0.0f);
+    for (int i = 0; i < d.A; ++i) { b3[i] = pp->b3[i]; if (pp->a_mean) am[i] = pp->a_mean[i]; if (pp->a_std) as[i] = pp->a_std[i]; if (pp->logstd) ls[i] = pp->logstd[i]; }
+    for (int i = 0; i < d.S; ++i) { if (pp->s_mean) sm[i] = pp->s_mean[i]; if (pp->s_std) si[i] = 1.0f / pp->s_std[i]; }
+    d.w1p = (const uint16_t*)p->up(w1.data(), w1.size() * 2); d.w2p = (const uint16_t*)p->up(w2.data(), w2.size() * 2); d.w3p = (const uint16_t*)p->up(w3.data(), w3.size() * 2);
+    d.b1 = (const float*)p->up(pp->b1, sizeof(float) * d.H1); d.b2 = (const float*)p->up(pp->b2, sizeof(float) * d.H2); d.b3 = (const float*)p->up(b3.data(), sizeof(float) * d.N3);
+    d.s_mean = (const float*)p->up(sm.data(), sizeof(float) * d.S); d.s_inv_std = (const float*)p->up(si.data(), sizeof(float) * d.S);
+    d.a_mean = (const float*)p->up(am.data(), sizeof(float) * d.A); d.a_std = (const float*)p->up(as.data(), sizeof(float) * d.A);
+    d.logstd = (const float*)p->up(ls.data(), sizeof(float) * d.A);
+    d.s_clip = (pp->s_clip > 0) ? (float)pp->s_clip : std::numeric_limits<float>::infinity();
+    if (!d.w1p || !d.w2p || !d.w3p || !d.b1 || !d.b2 || !d.b3 || !d.s_mean || !d.s_inv_std || !d.a_mean || !d.a_std || !d.logstd) { delete p; return fail("device allocation failed"); }
+    *out = p;
+    return 0;
+}
+
+int dm_policy_destroy(dm_policy* p) { delete p; return 0; }
+
+int dm_policy_forward(dm_policy* p, const float* states_dev, int n, float* actions_dev, float* logp_dev, int sample,
+                      uint64_t seed, uint32_t step, int env_id_offset, void* hip_stream) {
+    if (!p || !states_dev || !actions_dev) return fail("null argument");
+    if (n <= 0) return 0;
+    rt_stream stream = (rt_stream)hip_stream;
+    if (n > p->cap) {                       // hidden activations: n x (H1 + H2) bf16, grown on demand
+        rt_sync(stream);
+        if (p->h1) rt_free(p->h1); if (p->h2) rt_free(p->h2); p->h1 = p->h2 = nullptr; p->cap = 0;
+        void *a = nullptr, *b = nullptr;
+        if (rt_malloc(&a, (size_t)n * p->pd.H1 * 2) || rt_malloc(&b, (size_t)n * p->pd.H2 * 2)) { if (a) rt_free(a); return fail("device allocation failed"); }
+        p->h1 = (uint16_t*)a; p->h2 = (uint16_t*)b; p->cap = n;
+    }
+    dmp::PolicyIO io; memset(&io, 0, sizeof(io));
+    io.states = states_dev; io.h1 = p->h1; io.h2 = p->h2; io.actions = actions_dev; io.logp = logp_dev; io.M = n; io.sample = sample ? 1 : 0;
+    io.seed_lo = (uint32_t)seed; io.seed_hi = (uint32_t)(seed >> 32); io.step = step; io.env_off = env_id_offset;
+    const dmp::PolicyDev& d = p->pd;
+    const int rb = (n + 31) / 32;
+    RT_LAUNCH((dmp::k_policy_layer<0, 2, 4>), rb * (d.H1 / 64), stream, d, io);
+    RT_LAUNCH((dmp::k_policy_layer<1, 2, 4>), rb * (d.H2 / 64), stream, d, io);
+    RT_LAUNCH((dmp::k_policy_layer<2, 2, 2>), rb * (d.N3 / 32), stream, d, io);
+#ifndef DM_EMU
+    hipError_t le = hipGetLastError(); if (le != hipSuccess) return fail(std::string("kernel launch failed: ") + hipGetErrorString(le));
+#endif
+    return 0;
+}
+
+}  // extern "C"

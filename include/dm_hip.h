@@ -132,6 +132,28 @@ int dm_get_debug(dm_ctx* ctx, const char* name, double* out);
 int dm_bench_rollout(dm_ctx* ctx, int warmup, int steps, double timestep, int n_updates, int flags,
                      float* states_dev, float* rewards_dev, double* elapsed_ms);
 
+/* ---- On-device policy inference: the actor of learning/pg_agent.py:141-188 with the net of
+ * learning/nets/fc_2layers_1024units.py and the normalisers of learning/normalizer.py:95-102, on the matrix cores (bf16
+ * operands, fp32 accumulate), so that observation -> action -> control step stays on the GPU.  Weights are fp32 host
+ * arrays in tf.layers.dense layout (kernel [in x out] row-major, bias [out]); NULL normaliser / logstd arrays mean
+ * identity / 0.  s_clip <= 0: no clipping. */
+typedef struct dm_policy dm_policy;
+typedef struct {
+    int state_dim, hidden1, hidden2, action_dim;      /* reference: S, 1024, 512, A; hidden widths multiples of 64 */
+    const float *w1, *b1, *w2, *b2, *w3, *b3;
+    const float *s_mean, *s_std;                      /* normalize:   (s - mean) / std, clipped to +-s_clip */
+    const float *a_mean, *a_std;                      /* unnormalize: norm_a * std + mean */
+    const float *logstd;                              /* Gaussian head (learning/tf_distribution_gaussian_diag.py), A entries */
+    double s_clip;
+} dm_policy_params;
+int dm_policy_create(int device_id, const dm_policy_params* params, dm_policy** out);
+int dm_policy_destroy(dm_policy* policy);
+/* actions[n x A] (and logp[n], optional) for states[n x S]; all DEVICE pointers, asynchronous on hip_stream.
+ * sample = 0: the mode (pg_agent.py _mode_a_tf); 1: mean + exp(logstd) * N(0,1) with Philox4x32-10 noise keyed by
+ * (seed + env_id_offset + row, step * A + j) -- the generator of deepmimic_amd/streams.py. */
+int dm_policy_forward(dm_policy* policy, const float* states_dev, int n, float* actions_dev, float* logp_dev, int sample,
+                      uint64_t seed, uint32_t step, int env_id_offset, void* hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

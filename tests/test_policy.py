@@ -1,0 +1,116 @@
+"""On-device policy inference (deepmimic_amd/csrc/dm_policy.h) against a plain numpy / torch fp32
+statement of the same actor.  CPU: emulator build (lane-exchange emulation of the MFMA); GPU: the real matrix cores."""
+import numpy as np
+import pytest
+
+from deepmimic_amd import streams
+from deepmimic_amd.policy import Policy, random_weights, reference_forward
+
+
+def make(S, A, H1, H2, seed, with_norm=True):
+    w = random_weights(S, A, H1, H2, seed=seed, init_output_scale=0.3)
+    rng = np.random.default_rng(seed + 1)
+    w["b1"] = rng.normal(size=H1).astype(np.float32) * 0.1; w["b2"] = rng.normal(size=H2).astype(np.float32) * 0.1
+    w["b3"] = rng.normal(size=A).astype(np.float32) * 0.1
+    if with_norm:
+        w["s_mean"] = rng.normal(size=S).astype(np.float32); w["s_std"] = rng.uniform(0.5, 2.0, size=S).astype(np.float32)
+        w["a_mean"] = rng.normal(size=A).astype(np.float32); w["a_std"] = rng.uniform(0.5, 2.0, size=A).astype(np.float32)
+    return w
+
+
+def test_policy_emulator_matches_bf16_reference(emu_lib):
+    """small widths (the emulated MFMA is slow): asymmetric random weights, ragged row count (M % 32 != 0), S % 32 != 0, A < 32"""
+    S, A, H1, H2 = 45, 7, 64, 128
+    w = make(S, A, H1, H2, 3)
+    pol = Policy(w, lib_path=emu_lib, s_clip=5.0)
+    s = np.random.default_rng(0).normal(size=(37, S)).astype(np.float32) * 2 + 0.5
+    a, lp = pol.forward_host(s)
+    want, _ = reference_forward(w, s, s_clip=5.0, bf16=True)
+    assert np.abs(a - want).max() < 2e-3, np.abs(a - want).max()
+    want32, _ = reference_forward(w, s, s_clip=5.0, bf16=False)
+    assert np.abs(a - want32).max() < 0.1
+    # mode: logp is the constant -sum(logstd) - A/2 log(2 pi)
+    assert np.allclose(lp, -w["logstd"].sum() - 0.5 * A * np.log(2 * np.pi), atol=1e-5)
+
+
+def test_policy_emulator_sampling_uses_the_philox_stream(emu_lib):
+    S, A, H1, H2 = 32, 5, 64, 64
+    w = make(S, A, H1, H2, 5, with_norm=False)
+    pol = Policy(w, lib_path=emu_lib)
+    s = np.random.default_rng(1).normal(size=(16, S)).astype(np.float32)
+    a0, _ = pol.forward_host(s)
+    a1, lp = pol.forward_host(s, sample=True, seed=0xD33B, step=3, env_id_offset=100)
+    z = (a1 - a0) / np.exp(w["logstd"])
+    # same generator as deepmimic_amd/streams.py (key 0xD33B + env id, counter step * A + j), fp32 Box-Muller on 24-bit uniforms
+    want = streams.normal_noise(100 + np.arange(16), 3, A, sigma=1.0)
+    assert np.abs(z - want).max() < 2e-3, np.abs(z - want).max()
+    assert np.allclose(lp, (-0.5 * z ** 2 - w["logstd"]).sum(1) - 0.5 * A * np.log(2 * np.pi), atol=2e-3)
+
+
+def test_policy_rejects_bad_shapes(emu_lib):
+    w = random_weights(10, 4, 96, 64)
+    with pytest.raises(RuntimeError, match="multiples of 64"):
+        Policy(w, lib_path=emu_lib)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("S,A,n", [(227, 28, 4096), (347, 58, 1000), (197, 36, 33)])
+def test_policy_gpu_matches_reference(hip_lib, S, A, n):
+    """reference architecture 1024-512 at the humanoid / dog sizes, through the C-ABI on device buffers"""
+    import torch
+    w = make(S, A, 1024, 512, 11)
+    pol = Policy(w, lib_path=hip_lib, s_clip=10.0)
+    s = (np.random.default_rng(2).normal(size=(n, S)) * 1.5 + 0.3).astype(np.float32)
+    ts = torch.from_numpy(s).cuda(); ta = torch.zeros((n, A), dtype=torch.float32, device="cuda"); tl = torch.zeros(n, dtype=torch.float32, device="cuda")
+    pol.forward_device(ts.data_ptr(), n, ta.data_ptr(), tl.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    a = ta.cpu().numpy()
+    want_bf, _ = reference_forward(w, s, s_clip=10.0, bf16=True)
+    want_32, _ = reference_forward(w, s, s_clip=10.0, bf16=False)
+    scale = np.abs(want_32).max()
+    assert np.abs(a - want_bf).max() < 2e-3 * scale, (np.abs(a - want_bf).max(), scale)      # same rounding points: accumulation order only
+    assert np.abs(a - want_32).max() < 2e-2 * scale, (np.abs(a - want_32).max(), scale)      # bf16 operands vs fp32: stated tolerance 2 % of range
+    # torch fp32 reference of the same op
+    tw = {k: torch.from_numpy(v).cuda() for k, v in w.items()}
+    x = torch.clamp((ts - tw["s_mean"]) / tw["s_std"], -10, 10)
+    h = torch.relu(x @ tw["w1"] + tw["b1"]); h = torch.relu(h @ tw["w2"] + tw["b2"])
+    ref = (h @ tw["w3"] + tw["b3"]) * tw["a_std"] + tw["a_mean"]
+    assert (ta - ref).abs().max().item() < 2e-2 * scale
+    # sampled actions: noise stream reproducible on the host
+    pol.forward_device(ts.data_ptr(), n, ta.data_ptr(), tl.data_ptr(), sample=True, seed=7, step=9, env_id_offset=5,
+                       stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    z = (ta.cpu().numpy() - a) / (np.exp(w["logstd"]) * w["a_std"])
+    ids = 5 + np.arange(n)
+    ctr_key = streams.normal_noise(ids - 0xD33B + 7, 9, A, sigma=1.0)      # streams keys with 0xD33B + id; the kernel with seed + id
+    assert np.abs(z - ctr_key).max() < 5e-3
+
+
+@pytest.mark.gpu
+def test_closed_loop_rollout_stays_on_device(hip_lib):
+    """observation -> policy -> control step, 10 steps, 4096 envs, no host round trip of states or actions"""
+    import torch
+    from deepmimic_amd import model
+    from deepmimic_amd.core import BatchEnv
+    t = model.load_asset("humanoid3d_walk")
+    n = 4096
+    env = BatchEnv(t, n, lib_path=hip_lib)
+    env.set_stream(torch.cuda.current_stream().cuda_stream)
+    env.reset()
+    offs = env.offsets_scales()
+    w = random_weights(env.S, env.A, seed=0)
+    w["s_mean"] = -offs["state_offset"].astype(np.float32); w["s_std"] = (1.0 / offs["state_scale"]).astype(np.float32)
+    w["a_mean"] = -offs["action_offset"].astype(np.float32); w["a_std"] = (1.0 / offs["action_scale"]).astype(np.float32)
+    pol = Policy(w, lib_path=hip_lib)
+    dev = torch.device("cuda")
+    st = torch.zeros((n, env.S), dtype=torch.float32, device=dev); ac = torch.zeros((n, env.A), dtype=torch.float32, device=dev)
+    rw = torch.zeros(n, dtype=torch.float32, device=dev); tm = torch.zeros(n, dtype=torch.int32, device=dev)
+    vd = torch.zeros(n, dtype=torch.int32, device=dev); en = torch.zeros(n, dtype=torch.int32, device=dev)
+    env.step_device(0, st.data_ptr(), rw.data_ptr(), tm.data_ptr(), vd.data_ptr(), en.data_ptr(), n_updates=0)     # first observation
+    stream = torch.cuda.current_stream().cuda_stream
+    tot = 0.0
+    for k in range(10):
+        pol.forward_device(st.data_ptr(), n, ac.data_ptr(), 0, sample=True, seed=1, step=k, stream=stream)
+        env.step_device(ac.data_ptr(), st.data_ptr(), rw.data_ptr(), tm.data_ptr(), vd.data_ptr(), en.data_ptr(), auto_reset=True)
+        tot += float(rw.mean().item())
+    assert torch.isfinite(st).all() and torch.isfinite(ac).all() and 0.0 < tot / 10 < 1.0

@@ -802,7 +802,8 @@ struct EnvSim {
 #pragma unroll
               for (int p = 0; p < NP2; ++p) a2 += y2[p] * y2[p];
               adiag = a2[0] + a2[1]; }
-            // rows are pre-scaled by 1/A_ll so that the sweep keeps q_l = (b_l - u_l)/A_ll with one FMA per row
+            // rows are pre-scaled by 1/A_ll and the diagonal is zeroed: the sweep keeps t_l = lambda_l + (b_l - u_l)/A_ll, the
+            // pre-clamp target of row l, which a visit to row l itself leaves unchanged -- one uniform FMA per row, no add
             const Real inv_adiag = (l < R) ? (Real)1 / adiag : (Real)0;
             if (R <= 32) {
                 Real g[32];
@@ -812,42 +813,40 @@ struct EnvSim {
                 for (int p = 0; p < NP2; ++p) DM_OPAQUE_V(y2[p]);
                 wave_gram32<NP2>(y2, g);
 #pragma unroll
-                for (int r = 0; r < 32; ++r) arow.set(r, g[r] * inv_adiag);
+                for (int r = 0; r < 32; ++r) arow.set(r, (l == r) ? (Real)0 : g[r] * inv_adiag);
             } else {
                 for (int r = 0; r < R; ++r) {
                     R2 a2 = {(Real)0, (Real)0};
 #pragma unroll
                     for (int p = 0; p < NP2; ++p) { const R2 bb = {lane_bcast(y2[p][0], r), lane_bcast(y2[p][1], r)}; a2 += y2[p] * bb; }
-                    const Real v = (a2[0] + a2[1]) * inv_adiag;
+                    const Real v = (l == r) ? (Real)0 : (a2[0] + a2[1]) * inv_adiag;
                     if (RREG >= kMaxRows || r < RREG) arow.set(r, v);
                     else aovf[(r - RREG) * kWave + l] = v;
                 }
             }
             mark(10);
-            Real q = (b - cvec) * inv_adiag;
+            Real t = (b - cvec) * inv_adiag;
             const int nrm_lane = is_fric ? NL + ((l - RN) >> 1) : 0;
             Real lo = 0, hi = is_fric ? (Real)0 : (Real)1e30;
             int Rv = R, RNv = RN, lv = l;
             for (int it = 0; it < m.solver_iters; ++it) {
                 DM_OPAQUE_S(Rv); DM_OPAQUE_S(RNv); DM_OPAQUE_V(lv);
                 // statically unrolled over the row id (register-file index and lane select are immediates); rows >= R are
-                // skipped block-wise by wave-uniform branches
+                // skipped in blocks of 4 by wave-uniform branches (a lane beyond R has t = 0, lambda = 0 and changes nothing)
 #pragma unroll
-                for (int blk = 0; blk < kMaxRows / 8; ++blk) {
-                    if (blk * 8 < Rv) {
+                for (int blk = 0; blk < kMaxRows / 4; ++blk) {
+                    if (blk * 4 < Rv) {
 #pragma unroll
-                        for (int i = 0; i < 8; ++i) {
-                            const int r = blk * 8 + i;
-                            if (r < Rv) {
-                                if (r == RNv) { const Real ln = wave_shfl(lam, nrm_lane); if (is_fric) { hi = m.friction * ln; lo = -hi; } }
-                                const Real nl = dm_med3(lo, lam + q, hi);
-                                const Real delta = lane_bcast(nl - lam, r);
-                                Real ar;
-                                if (r < RREG) ar = arow.get(r < RREG ? r : 0);
-                                else { const Real* ap = aovf + lv; DM_OPAQUE_V(ap); ar = ap[(r - RREG) * kWave]; }   // address formed here, not hoisted for 32 rows
-                                q -= ar * delta;
-                                if (lv == r) lam = nl;
-                            }
+                        for (int i = 0; i < 4; ++i) {
+                            const int r = blk * 4 + i;
+                            if (r == RNv) { const Real ln = wave_shfl(lam, nrm_lane); if (is_fric) { hi = m.friction * ln; lo = -hi; } }
+                            const Real nl = dm_med3(lo, t, hi);
+                            const Real delta = lane_bcast(nl - lam, r);
+                            Real ar;
+                            if (r < RREG) ar = arow.get(r < RREG ? r : 0);
+                            else { const Real* ap = aovf + lv; DM_OPAQUE_V(ap); ar = ap[(r - RREG) * kWave]; }   // address formed here, not hoisted for 32 rows
+                            t -= ar * delta;
+                            if (lv == r) lam = nl;
                         }
                     }
                 }

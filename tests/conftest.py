@@ -32,4 +32,13 @@ def hip_lib(oracle_built):
     """The product library; GPU tests fail loudly when it is missing or no device is visible."""
     p = os.path.join(ROOT, "deepmimic_amd", "csrc", "libdm_hip.so")
     assert os.path.exists(p), "libdm_hip.so missing: run __graft_entry__.build()"
+    # torch and libdm_hip.so share one HIP runtime in this process; bring torch's device context up first (the order bench.py
+    # uses) so that tests mixing torch tensors with the C-ABI (policy, closed loop) do not depend on which test ran before them
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+            torch.zeros(1, device="cuda")
+    except ImportError:
+        pass
     return p

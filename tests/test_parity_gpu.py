@@ -103,6 +103,19 @@ def _golden_cases():
         return json.load(f)
 
 
+def _golden_fp32_floor(case):
+    from oracle_lib import Oracle
+    f = Oracle(model.load_asset(case["scene"]), variant="f32")
+    f.reset(case["t0"])
+    d = []
+    for k in range(case["steps"]):
+        f.set_action(f.pose_to_action(f.kin_state()[0]))
+        for u in range(20):
+            f.update(pc.DT)
+        d.append(abs(f.calc_reward() - case["rewards"][k]))
+    return np.array(d)
+
+
 @pytest.mark.parametrize("case", _golden_cases(), ids=lambda c: "%s@%g" % (c["scene"], c["t0"]))
 def test_rollout_against_committed_golden_vectors(hip_lib, case):
     """HIP path vs the committed fixtures (tests/golden/oracle_rollouts.json), all envs of one batch at once."""
@@ -112,9 +125,12 @@ def test_rollout_against_committed_golden_vectors(hip_lib, case):
         env.reset(kin_times=[case["t0"]] * 3, max_times=np.inf)
         q = env.query()
         assert np.abs(q["state"][1] - np.array(case["state0"])).max() < (1e-6 if prec == 64 else 2e-5)
+        # fp32: a step on which the float build of the oracle itself is further than tol/2 from the fixture (the stiff self contacts
+        # at the end of the 30-step dog case: 3.2e-4) is held to 2x that floor instead
+        floor = _golden_fp32_floor(case) if prec == 32 else np.zeros(case["steps"])
         for k in range(case["steps"]):
             out = env.step(None, pc.DT, 20, open_loop=True)
-            assert np.abs(out["reward"] - case["rewards"][k]).max() < tol_r, (prec, k)
+            assert np.abs(out["reward"] - case["rewards"][k]).max() < max(tol_r, 2 * floor[k]), (prec, k, floor[k])
         assert np.abs(out["state"][2] - np.array(case["final_state"])).max() < tol_s
         assert int(out["terminate"][0]) == case["terminate"]
 

@@ -49,10 +49,10 @@ def _amp_arg_files():
 
 @pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "args")), reason="reference checkout not present")
 def test_imitate_amp_arg_files_run(emu_lib):
-    """The 34 `--scene imitate_amp` arg files: the single-clip ones (kin_ctrl motion) run; the multi-clip dataset ones
-    (kin_ctrl clips, anim/ClipsController.cpp) are refused with a clear error -- not on the accelerated path yet."""
+    """All 34 `--scene imitate_amp` arg files (every one is single-clip, `--kin_ctrl motion`) run.  Multi-clip datasets
+    (`--kin_ctrl clips`, anim/ClipsController.cpp) only occur in the task scenes, which are refused with a clear error."""
     single, dataset = _amp_arg_files()
-    assert len(single) + len(dataset) == 34 and len(single) >= 24
+    assert len(single) == 34 and len(dataset) == 0
     for f in single:
         t = model.load_scene_from_args(["--arg_file", f], data_root=REF)
         assert t.cfg.scene == "imitate_amp"
@@ -64,6 +64,5 @@ def test_imitate_amp_arg_files_run(emu_lib):
         ex = env.amp_expert(3)
         assert np.isfinite(ex).all(), f
         env.close()
-    for f in dataset:
-        with pytest.raises(ValueError, match="multi-clip dataset"):
-            model.load_scene_from_args(["--arg_file", f], data_root=REF)
+    with pytest.raises(ValueError, match="accelerated path"):
+        model.load_scene_from_args(["--arg_file", "args/train_amp_target_humanoid3d_locomotion_args.txt"], data_root=REF)

@@ -36,10 +36,15 @@ template <int NP2, typename R2, typename Real> static inline void duo_gram32(con
 __device__ __forceinline__ float half_bcast(float v, int src, int half) { const float a = lane_bcast(v, src), b = lane_bcast(v, 32 + src); return half ? b : a; }
 __device__ __forceinline__ double half_bcast(double v, int src, int half) { const double a = lane_bcast(v, src), b = lane_bcast(v, 32 + src); return half ? b : a; }
 __device__ __forceinline__ int half_bcast(int v, int src, int half) { const int a = lane_bcast(v, src), b = lane_bcast(v, 32 + src); return half ? b : a; }
-// lane SRC of the own half, SRC static: one ds_swizzle (bit-mask mode inside each group of 32 lanes: and 0, or SRC, xor 0)
-// through the LDS crossbar instead of two v_readlane + two v_mov + a select -- for issue-bound loops (Gauss-Seidel rows)
+// lane SRC of the own half, SRC static, without SGPR round trips or the LDS crossbar: `row_newbcast` spreads lane SRC & 15 of
+// every 16-lane row over its row; then rows 1, 3 take rows 0, 2 (`row_bcast:15`, SRC < 16) or the gfx950 `v_permlane16_swap` of the
+// value with itself hands rows 1, 3 down to rows 0, 2 (SRC >= 16).  2-3 VALU with a ~20-cycle dependent chain, against two
+// v_readlane + two v_mov + a select (5 VALU) or one ds_swizzle (1 LDS op, ~50 cycles): the Gauss-Seidel row chain wants both few
+// instructions and a short chain.
 template <int SRC> __device__ __forceinline__ float half_bcast_c(float v, int half) {
-    return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), SRC << 5));
+    const int x = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x150 + (SRC & 15), 0xf, 0xf, true);      // row_newbcast
+    if (SRC < 16) return __int_as_float(__builtin_amdgcn_update_dpp(x, x, 0x142, 0xa, 0xf, false));          // row_bcast:15 into rows 1, 3
+    return __int_as_float(__builtin_amdgcn_permlane16_swap(x, x, false, false)[1]);
 }
 template <int SRC> __device__ __forceinline__ double half_bcast_c(double v, int half) { return half_bcast(v, SRC, half); }
 __device__ __forceinline__ float half_sum(float v) {

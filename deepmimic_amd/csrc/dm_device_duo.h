@@ -62,21 +62,20 @@ __device__ __forceinline__ double half_sum(double v) {
 // cross-half shuffle per k-pair (the lower half sends its odd column up, the upper half its even column down).
 template <int NP2> __device__ __forceinline__ void duo_gram32(const VecT<float>::v2* y2, float (&out)[32]) {
     typedef float f16v __attribute__((ext_vector_type(16)));
-    const bool upper = threadIdx.x >= 32;
     f16v accA = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, accB = accA;
 #pragma unroll
     for (int p = 0; p < NP2; ++p) {
-        const float a0 = y2[p][0], a1 = y2[p][1];
-        const float sx = __shfl_xor(upper ? a0 : a1, 32, 64);
-        const float opA = upper ? sx : a0, opB = upper ? a1 : sx;
+        // gfx950 v_permlane32_swap: (a0, a1) -> ([a0.lo, a1.lo], [a0.hi, a1.hi]): the lower character's column pair / the upper one's
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(y2[p][0]), __float_as_uint(y2[p][1]), false, false);
+        const float opA = __uint_as_float(sw[0]), opB = __uint_as_float(sw[1]);
         accA = __builtin_amdgcn_mfma_f32_32x32x2f32(opA, opA, accA, 0, 0, 0);
         accB = __builtin_amdgcn_mfma_f32_32x32x2f32(opB, opB, accB, 0, 0, 0);
     }
 #pragma unroll
     for (int v = 0; v < 16; ++v) {
-        const float recv = __shfl_xor(upper ? accA[v] : accB[v], 32, 64);
-        out[8 * (v / 4) + (v % 4)] = upper ? recv : accA[v];
-        out[8 * (v / 4) + 4 + (v % 4)] = upper ? accB[v] : recv;
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(accA[v]), __float_as_uint(accB[v]), false, false);
+        out[8 * (v / 4) + (v % 4)] = __uint_as_float(sw[0]);        // lower: own accA, upper: the lower half's accB
+        out[8 * (v / 4) + 4 + (v % 4)] = __uint_as_float(sw[1]);    // lower: the upper half's accA, upper: own accB
     }
 }
 template <int NP2> __device__ __forceinline__ void duo_gram32(const VecT<double>::v2* y2, double (&out)[32]) {
@@ -167,11 +166,11 @@ struct DuoSim {
 #define DM_DUO_COLS(k)                                                                                                  \
         {                                                                                                               \
             const int pk_ = (k) >> 1;                                                                                   \
-            const Real inv0_ = ((k) < 3) ? dinv0 : dm_rsqrt(half_bcast(h2[pk_][0], (k) - 3, half));                     \
+            const Real inv0_ = ((k) < 3) ? dinv0 : dm_rsqrt(half_bcast_c<(((k) - 3) & 31)>(h2[pk_][0], half));                     \
             lik0 = h2[pk_][0] * inv0_; h2[pk_][0] = lik0; if (own == (k)) dinv = inv0_;                                  \
-            const Real lk1k_ = ((k) + 1 < 3) ? (Real)0 : half_bcast(lik0, (k) + 1 - 3, half);                           \
+            const Real lk1k_ = ((k) + 1 < 3) ? (Real)0 : half_bcast_c<(((k) + 1 - 3) & 31)>(lik0, half);                           \
             h2[pk_][1] -= lik0 * lk1k_;                                                                                 \
-            const Real inv1_ = ((k) + 1 < 3) ? dinv0 : dm_rsqrt(half_bcast(h2[pk_][1], (k) + 1 - 3, half));             \
+            const Real inv1_ = ((k) + 1 < 3) ? dinv0 : dm_rsqrt(half_bcast_c<(((k) + 1 - 3) & 31)>(h2[pk_][1], half));             \
             lik1 = h2[pk_][1] * inv1_; h2[pk_][1] = lik1; if (own == (k) + 1) dinv = inv1_;                              \
             if ((k) + 2 < ND) {                                                                                         \
                 Real* cb0_ = colbuf + (pk_ & 1) * 80; Real* cb1_ = cb0_ + 40;                                           \
@@ -179,34 +178,34 @@ struct DuoSim {
                 if ((k) < 3 && hl == HW - 1) { cb0_[0] = 0; cb0_[1] = 0; cb0_[2] = 0; cb1_[0] = 0; cb1_[1] = 0; cb1_[2] = 0; } \
             }                                                                                                           \
         }
-        DM_DUO_COLS(0)
-#pragma unroll
-        for (int k = 0; k < ND; k += 2) {
-            const int pk = k >> 1;
-            const Real c0 = lik0, c1 = lik1;             // this block's columns (own entries)
-            if (k + 2 < ND) {
-                // (1) the broadcast reads of this block's published columns are issued first ...
-                sync();
-                const Real* cb0 = colbuf + (pk & 1) * 80; const Real* cb1 = cb0 + 40;
-                R2 t0[NP2], t1[NP2];
-#pragma unroll
-                for (int p = pk + 2; p < NP2; ++p) { t0[p] = *reinterpret_cast<const R2*>(&cb0[2 * p]); t1[p] = *reinterpret_cast<const R2*>(&cb1[2 * p]); }
-                // (2) ... then the look-ahead: entries (k+2, k+3) x (k, k+1) of L from the lanes that own rows k+2, k+3 (root rows
-                // hold zeros) bring the next pivot pair up to date, and the next block's columns are computed and published
-                const Real a = (k + 2 < 3) ? (Real)0 : half_bcast(c0, k + 2 - 3, half), c = (k + 2 < 3) ? (Real)0 : half_bcast(c1, k + 2 - 3, half);
-                const Real bq = half_bcast(c0, k + 3 - 3, half), d = half_bcast(c1, k + 3 - 3, half);
-                h2[pk + 1][0] -= c0 * a + c1 * c;
-                h2[pk + 1][1] -= c0 * bq + c1 * d;
-                DM_DUO_COLS(k + 2)
-                // (3) ... and the trailing rank-2 update of block k consumes the reads that landed meanwhile
-                const R2 l20 = {c0, c0}, l21 = {c1, c1};
-#pragma unroll
-                for (int p = pk + 2; p < NP2; ++p) {
-                    h2[p] -= l20 * t0[p] + l21 * t1[p];
-                    DM_OPAQUE_V(h2[p]);                  // evaluated here, not sunk to the pivot that needs it
-                }
-            }
+#define DM_DUO_BLOCK(k)                                                                                                 \
+        {                                                                                                               \
+            const int pk = (k) >> 1; \
+            const Real c0 = lik0, c1 = lik1; \
+            if (k + 2 < ND) { \
+                sync(); \
+                const Real* cb0 = colbuf + (pk & 1) * 80; const Real* cb1 = cb0 + 40; \
+                R2 t0[NP2], t1[NP2]; \
+_Pragma("unroll") \
+                for (int p = pk + 2; p < NP2; ++p) { t0[p] = *reinterpret_cast<const R2*>(&cb0[2 * p]); t1[p] = *reinterpret_cast<const R2*>(&cb1[2 * p]); } \
+                const Real a = (k + 2 < 3) ? (Real)0 : half_bcast_c<(((k) + 2 - 3) & 31)>(c0, half), c = ((k) + 2 < 3) ? (Real)0 : half_bcast_c<(((k) + 2 - 3) & 31)>(c1, half); \
+                const Real bq = half_bcast_c<(((k) + 3 - 3) & 31)>(c0, half), d = half_bcast_c<(((k) + 3 - 3) & 31)>(c1, half); \
+                h2[pk + 1][0] -= c0 * a + c1 * c; \
+                h2[pk + 1][1] -= c0 * bq + c1 * d; \
+                DM_DUO_COLS(k + 2) \
+                const R2 l20 = {c0, c0}, l21 = {c1, c1}; \
+_Pragma("unroll") \
+                for (int p = pk + 2; p < NP2; ++p) { \
+                    h2[p] -= l20 * t0[p] + l21 * t1[p]; \
+                    DM_OPAQUE_V(h2[p]); \
+                } \
+            } \
         }
+        DM_DUO_COLS(0)
+        static_assert(ND == 34, "17 column blocks");
+        DM_DUO_BLOCK(0) DM_DUO_BLOCK(2) DM_DUO_BLOCK(4) DM_DUO_BLOCK(6) DM_DUO_BLOCK(8) DM_DUO_BLOCK(10) DM_DUO_BLOCK(12) DM_DUO_BLOCK(14) DM_DUO_BLOCK(16)
+        DM_DUO_BLOCK(18) DM_DUO_BLOCK(20) DM_DUO_BLOCK(22) DM_DUO_BLOCK(24) DM_DUO_BLOCK(26) DM_DUO_BLOCK(28) DM_DUO_BLOCK(30) DM_DUO_BLOCK(32)
+#undef DM_DUO_BLOCK
 #undef DM_DUO_COLS
         if (valid) {
             Real* row = &s.Lt[L::lrow(own)];
@@ -225,11 +224,14 @@ struct DuoSim {
         Real xr[3];
 #pragma unroll
         for (int k = 0; k < 3; ++k) { xr[k] = xvec[k] * dinv0; x -= h2[k >> 1][k & 1] * xr[k]; }
-#pragma unroll
-        for (int k = 3; k < ND; ++k) {
-            Real t = x * dinv; Real xk = half_bcast(t, k - 3, half);
-            if (own == k) x = t; else if (own > k) x -= h2[k >> 1][k & 1] * xk;
-        }
+        // rows 3..33 in order, statically expanded: the lane id of each broadcast is an immediate (DPP form of half_bcast_c)
+#define DM_DUO_FWD(k) { Real t = x * dinv; Real xk = half_bcast_c<(k) - 3>(t, half); if (own == (k)) x = t; else if (own > (k)) x -= h2[(k) >> 1][(k) & 1] * xk; }
+        static_assert(ND == 34, "the expansion below covers rows 3..33");
+        DM_DUO_FWD(3) DM_DUO_FWD(4) DM_DUO_FWD(5) DM_DUO_FWD(6) DM_DUO_FWD(7) DM_DUO_FWD(8) DM_DUO_FWD(9) DM_DUO_FWD(10)
+        DM_DUO_FWD(11) DM_DUO_FWD(12) DM_DUO_FWD(13) DM_DUO_FWD(14) DM_DUO_FWD(15) DM_DUO_FWD(16) DM_DUO_FWD(17) DM_DUO_FWD(18)
+        DM_DUO_FWD(19) DM_DUO_FWD(20) DM_DUO_FWD(21) DM_DUO_FWD(22) DM_DUO_FWD(23) DM_DUO_FWD(24) DM_DUO_FWD(25) DM_DUO_FWD(26)
+        DM_DUO_FWD(27) DM_DUO_FWD(28) DM_DUO_FWD(29) DM_DUO_FWD(30) DM_DUO_FWD(31) DM_DUO_FWD(32) DM_DUO_FWD(33)
+#undef DM_DUO_FWD
         sync();
         back_substitute(x, xr, dinv, dinv0);
         if (valid) xvec[own] = x;
@@ -242,11 +244,13 @@ struct DuoSim {
         Real c[ND];
 #pragma unroll
         for (int k = 0; k < ND; ++k) c[k] = (valid && k > own) ? s.Lt[L::lrow(k) + own] : (Real)0;
-#pragma unroll
-        for (int k = ND - 1; k >= 3; --k) {
-            Real t = x * dinv; Real xk = half_bcast(t, k - 3, half);
-            if (own == k) x = t; else if (own < k) x -= c[k] * xk;
-        }
+#define DM_DUO_BWD(k) { Real t = x * dinv; Real xk = half_bcast_c<(k) - 3>(t, half); if (own == (k)) x = t; else if (own < (k)) x -= c[k] * xk; }
+        static_assert(ND == 34, "the expansion below covers rows 33..3");
+        DM_DUO_BWD(33) DM_DUO_BWD(32) DM_DUO_BWD(31) DM_DUO_BWD(30) DM_DUO_BWD(29) DM_DUO_BWD(28) DM_DUO_BWD(27) DM_DUO_BWD(26)
+        DM_DUO_BWD(25) DM_DUO_BWD(24) DM_DUO_BWD(23) DM_DUO_BWD(22) DM_DUO_BWD(21) DM_DUO_BWD(20) DM_DUO_BWD(19) DM_DUO_BWD(18)
+        DM_DUO_BWD(17) DM_DUO_BWD(16) DM_DUO_BWD(15) DM_DUO_BWD(14) DM_DUO_BWD(13) DM_DUO_BWD(12) DM_DUO_BWD(11) DM_DUO_BWD(10)
+        DM_DUO_BWD(9) DM_DUO_BWD(8) DM_DUO_BWD(7) DM_DUO_BWD(6) DM_DUO_BWD(5) DM_DUO_BWD(4) DM_DUO_BWD(3)
+#undef DM_DUO_BWD
         Real col[3];
 #pragma unroll
         for (int k = 0; k < 3; ++k) col[k] = valid ? Lx(own, k) : (Real)0;

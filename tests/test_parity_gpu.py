@@ -190,10 +190,16 @@ def test_facade_protocol_matches_oracle(hip_lib):
 # ---- two characters per wavefront (dm_device_duo.h): same checks through the batch entry point
 @pytest.mark.parametrize("prec,tol_r,tol_s", [(64, 1e-6, 1e-5), (32, 5e-4, 0.5)])
 def test_duo_rollout_matches_oracle(hip_lib, prec, tol_r, tol_s):
-    dr, ds, ok = pc.batch_rollout_compare("humanoid3d_walk", prec, hip_lib, steps=10, t0s=[0.0, 0.37, 0.8, 0.11, 0.5, 0.9], wave_packing=2)
-    assert ok and dr.max() < tol_r and ds.max() < tol_s, (dr, ds)
-    if prec == 32:                              # all but the env that crosses the ill-conditioned step stay inside 1e-4
+    t0s = [0.0, 0.37, 0.8, 0.11, 0.5, 0.9]
+    dr, ds, ok = pc.batch_rollout_compare("humanoid3d_walk", prec, hip_lib, steps=10, t0s=t0s, wave_packing=2)
+    if prec == 32:
+        # the env started at 0.11 crosses an ill-conditioned step inside the 10 steps: the float build of the oracle is itself 3.2e-4
+        # away from the fp64 oracle there, so every env is held to max(1e-4, 2 x its own fp32 floor); the others stay inside 1e-4
+        floor = np.array([pc.fp32_free_running_sensitivity("humanoid3d_walk", 10, t0).max() for t0 in t0s])
+        assert ok and (dr < np.maximum(1e-4, 2 * floor)).all() and ds.max() < tol_s, (dr, floor, ds)
         assert np.sort(dr)[-2] < 1e-4, dr
+    else:
+        assert ok and dr.max() < tol_r and ds.max() < tol_s, (dr, ds)
 
 
 def test_duo_heavy_contact_fallback(hip_lib):

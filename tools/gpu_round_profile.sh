@@ -17,4 +17,7 @@ rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_INSTS_VMEM SQ_ACTIVE_INST_VALU
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o pmc -- python bench.py --steps 6 --warmup 2 --no-cpu-baseline > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o pmc -- python bench.py --steps 6 --warmup 2 --no-cpu-baseline > $OUT/pmc_write.log 2>&1
 python tools/gpu_profile_phases.py > $OUT/phases.json 2>&1
+python tools/gpu_policy_bench.py > $OUT/policy_bench.json 2> $OUT/policy_bench.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_policy -o stats -- python tools/gpu_policy_bench.py > $OUT/stats_policy.log 2>&1
+python tools/gpu_tail_probe.py > $OUT/tail_probe.txt 2>&1
 tail -3 $OUT/pytest_gpu.log; cat $OUT/smoke.log | tail -1; cut -c1-260 $OUT/bench.json; ls $OUT

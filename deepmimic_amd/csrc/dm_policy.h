@@ -18,7 +18,7 @@ namespace dmp {
 
 struct PolicyDev {
     int S, H1, H2, A;                 // true layer widths
-    int K1, N3;                       // padded: K1 = S rounded up to 32, N3 = A rounded up to 32
+    int K1, N3;                       // padded: K1 = S rounded up to 64, N3 = A rounded up to 32
     const uint16_t *w1p, *w2p, *w3p;  // packed bf16 fragments
     const float *b1, *b2, *b3;        // biases (b3 padded to N3 with zeros)
     const float *s_mean, *s_inv_std;  // observation normaliser (learning/normalizer.py:95-98), S entries
@@ -29,6 +29,7 @@ struct PolicyDev {
 
 struct PolicyIO {
     const float* states;   // M x S fp32 (RecordState of every env)
+    uint16_t* s16;         // M x K1 bf16: normalised, clipped, zero-padded observations (written by k_policy_prep)
     uint16_t* h1;          // M x H1 bf16
     uint16_t* h2;          // M x H2 bf16
     float* actions;        // M x A fp32
@@ -97,9 +98,24 @@ DMP_DEV float philox_normal(uint32_t env, uint32_t ctr, uint32_t seed_lo, uint32
     return sqrtf(-2.0f * logf(u1)) * cosf(6.283185307179586f * u2);
 }
 
-// MODE 0: layer 1 (fp32 observations -> normalise -> bf16; ReLU; bf16 out)   K = K1, N = H1
+// observation normaliser (learning/normalizer.py:95-98) fused with the bf16 conversion and the zero padding of K to a multiple of 32:
+// one wavefront per row, coalesced reads and writes
+__global__ void __launch_bounds__(64) k_policy_prep(PolicyDev p, PolicyIO io) {
+    const int row = blockIdx.x, l = threadIdx.x;
+    const float* srow = io.states + (size_t)row * p.S;
+    uint16_t* out = io.s16 + (size_t)row * p.K1;
+    for (int k = l; k < p.K1; k += 64) {
+        float x = 0.0f;
+        if (k < p.S) { x = (srow[k] - p.s_mean[k]) * p.s_inv_std[k]; x = fminf(fmaxf(x, -p.s_clip), p.s_clip); }
+        out[k] = f32_to_bf16(x);
+    }
+}
+
+// MODE 0: layer 1 (bf16 normalised observations; ReLU; bf16 out)             K = K1, N = H1
 // MODE 1: layer 2 (bf16 in; ReLU; bf16 out)                                  K = H1, N = H2
 // MODE 2: layer 3 (bf16 in; Gaussian head + un-normalise; fp32 actions)      K = H2, N = N3
+// The k loop is software-pipelined by hand: the A / B fragments of step ks + 1 are requested before the MFMAs of step ks issue
+// (two register sets), so one wave keeps its matrix core busy while the next 16-byte-per-lane reads are in flight.
 template <int MODE, int MT, int NT>
 __global__ void __launch_bounds__(64) k_policy_layer(PolicyDev p, PolicyIO io) {
     const int l = threadIdx.x, c = l & 15, g = l >> 4;
@@ -112,38 +128,54 @@ __global__ void __launch_bounds__(64) k_policy_layer(PolicyDev p, PolicyIO io) {
     if (cb >= n_col_tiles) return;
     const int row0 = rb * 16 * MT, nt0 = cb * NT, KS = K / 32;
     const uint16_t* wp = (MODE == 0) ? p.w1p : (MODE == 1 ? p.w2p : p.w3p);
-    const uint16_t* ain = (MODE == 1) ? io.h1 : io.h2;
+    const uint16_t* ain = (MODE == 0) ? io.s16 : (MODE == 1 ? io.h1 : io.h2);
 
     f32x4 acc[MT][NT];
-    for (int i = 0; i < MT; ++i) for (int j = 0; j < NT; ++j) for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.0f;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.0f;
 
-#pragma unroll 2
-    for (int ks = 0; ks < KS; ++ks) {
-        bf16x8 a[MT], b[NT];
-        const int k0 = ks * 32 + 8 * g;
+    const uint16_t* arow[MT];
 #pragma unroll
-        for (int i = 0; i < MT; ++i) {
-            const int row = row0 + 16 * i + c;
-            if (MODE == 0) {
-                const float* srow = io.states + (size_t)(row < io.M ? row : 0) * p.S;
+    for (int i = 0; i < MT; ++i) { const int row = row0 + 16 * i + c; arow[i] = ain + (size_t)(row < io.M ? row : 0) * K + 8 * g; }
+    const uint16_t* bcol[NT];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const int k = k0 + e;
-                    float x = 0.0f;
-                    if (k < p.S && row < io.M) { x = (srow[k] - p.s_mean[k]) * p.s_inv_std[k]; x = fminf(fmaxf(x, -p.s_clip), p.s_clip); }
-                    set8(a[i], e, f32_to_bf16(x));
-                }
-            } else {
-                a[i] = *reinterpret_cast<const bf16x8*>(ain + (size_t)(row < io.M ? row : 0) * K + k0);
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < NT; ++j) b[j] = *reinterpret_cast<const bf16x8*>(wp + ((size_t)((nt0 + j) * KS + ks) * 64 + l) * 8);
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-            for (int j = 0; j < NT; ++j) acc[i][j] = mfma16(a[i], b[j], acc[i][j]);
+    for (int j = 0; j < NT; ++j) bcol[j] = wp + ((size_t)(nt0 + j) * KS * 64 + l) * 8;
+
+    bf16x8 a0[MT], b0[NT], a1[MT], b1[NT];
+#define DMP_LOAD(A_, B_, ks_)                                                                                   \
+    {                                                                                                           \
+        _Pragma("unroll") for (int i = 0; i < MT; ++i) A_[i] = *reinterpret_cast<const bf16x8*>(arow[i] + (size_t)(ks_) * 32);      \
+        _Pragma("unroll") for (int j = 0; j < NT; ++j) B_[j] = *reinterpret_cast<const bf16x8*>(bcol[j] + (size_t)(ks_) * 512);     \
     }
+#define DMP_MMA(A_, B_)                                                                                         \
+    {                                                                                                           \
+        _Pragma("unroll") for (int i = 0; i < MT; ++i)                                                          \
+            _Pragma("unroll") for (int j = 0; j < NT; ++j) acc[i][j] = mfma16(A_[i], B_[j], acc[i][j]);         \
+    }
+    if (MODE == 2) {
+        // the head is tiny (N3 = 32): its time is all load latency, so the fragments of 8 k-steps are requested in one batch
+        for (int kb = 0; kb < KS; kb += 8) {
+            bf16x8 aa[8][MT], bb[8][NT];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) if (kb + u < KS) DMP_LOAD(aa[u], bb[u], kb + u)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) if (kb + u < KS) DMP_MMA(aa[u], bb[u])
+        }
+    } else {
+        DMP_LOAD(a0, b0, 0)
+        for (int ks = 0; ks < KS; ks += 2) {          // KS is even: K1 is padded to 64, H1 and H2 are multiples of 64
+            DMP_LOAD(a1, b1, ks + 1)
+            DMP_MMA(a0, b0)
+            if (ks + 2 < KS) DMP_LOAD(a0, b0, ks + 2)
+            DMP_MMA(a1, b1)
+        }
+    }
+#undef DMP_LOAD
+#undef DMP_MMA
 
     if (MODE != 2) {
         const float* bias = (MODE == 0) ? p.b1 : p.b2;

@@ -4,9 +4,9 @@
 
 struct dm_policy {
     dmp::PolicyDev pd; int device_id = 0; int cap = 0;
-    uint16_t *h1 = nullptr, *h2 = nullptr;
+    uint16_t *h1 = nullptr, *h2 = nullptr, *s16 = nullptr;
     std::vector<void*> allocs;
-    ~dm_policy() { for (void* p : allocs) rt_free(p); if (h1) rt_free(h1); if (h2) rt_free(h2); }
+    ~dm_policy() { for (void* p : allocs) rt_free(p); if (h1) rt_free(h1); if (h2) rt_free(h2); if (s16) rt_free(s16); }
     void* up(const void* host, size_t bytes) { void* d = nullptr; if (rt_malloc(&d, bytes)) return nullptr; allocs.push_back(d); if (rt_h2d(d, host, bytes, 0)) return nullptr; return d; }
 };
 
@@ -38,7 +38,7 @@ int dm_policy_create(int device_id, const dm_policy_params* pp, dm_policy** out)
     dm_policy* p = new dm_policy(); p->device_id = device_id;
     dmp::PolicyDev& d = p->pd; memset(&d, 0, sizeof(d));
     d.S = pp->state_dim; d.H1 = pp->hidden1; d.H2 = pp->hidden2; d.A = pp->action_dim;
-    d.K1 = (d.S + 31) / 32 * 32; d.N3 = (d.A + 31) / 32 * 32;
+    d.K1 = (d.S + 63) / 64 * 64; d.N3 = (d.A + 31) / 32 * 32;
     std::vector<uint16_t> w1 = pack_weights(pp->w1, d.S, d.H1, d.K1, d.H1), w2 = pack_weights(pp->w2, d.H1, d.H2, d.H1, d.H2), w3 = pack_weights(pp->w3, d.H2, d.A, d.H2, d.N3);
     std::vector<float> b3(d.N3, 0.0f), sm(d.S, 0.0f), si(d.S, 1.0f), am(d.A, 0.0f), as(d.A, 1.0f), ls(d.A, 0.0f);
     for (int i = 0; i < d.A; ++i) { b3[i] = pp->b3[i]; if (pp->a_mean) am[i] = pp->a_mean[i]; if (pp->a_std) as[i] = pp->a_std[i]; if (pp->logstd) ls[i] = pp->logstd[i]; }
@@ -63,19 +63,20 @@ int dm_policy_forward(dm_policy* p, const float* states_dev, int n, float* actio
     rt_stream stream = (rt_stream)hip_stream;
     if (n > p->cap) {                       // hidden activations: n x (H1 + H2) bf16, grown on demand
         rt_sync(stream);
-        if (p->h1) rt_free(p->h1); if (p->h2) rt_free(p->h2); p->h1 = p->h2 = nullptr; p->cap = 0;
-        void *a = nullptr, *b = nullptr;
-        if (rt_malloc(&a, (size_t)n * p->pd.H1 * 2) || rt_malloc(&b, (size_t)n * p->pd.H2 * 2)) { if (a) rt_free(a); return fail("device allocation failed"); }
-        p->h1 = (uint16_t*)a; p->h2 = (uint16_t*)b; p->cap = n;
+        if (p->h1) rt_free(p->h1); if (p->h2) rt_free(p->h2); if (p->s16) rt_free(p->s16); p->h1 = p->h2 = p->s16 = nullptr; p->cap = 0;
+        void *a = nullptr, *b = nullptr, *c = nullptr;
+        if (rt_malloc(&a, (size_t)n * p->pd.H1 * 2) || rt_malloc(&b, (size_t)n * p->pd.H2 * 2) || rt_malloc(&c, (size_t)n * p->pd.K1 * 2)) { if (a) rt_free(a); if (b) rt_free(b); return fail("device allocation failed"); }
+        p->h1 = (uint16_t*)a; p->h2 = (uint16_t*)b; p->s16 = (uint16_t*)c; p->cap = n;
     }
     dmp::PolicyIO io; memset(&io, 0, sizeof(io));
-    io.states = states_dev; io.h1 = p->h1; io.h2 = p->h2; io.actions = actions_dev; io.logp = logp_dev; io.M = n; io.sample = sample ? 1 : 0;
+    io.states = states_dev; io.s16 = p->s16; io.h1 = p->h1; io.h2 = p->h2; io.actions = actions_dev; io.logp = logp_dev; io.M = n; io.sample = sample ? 1 : 0;
     io.seed_lo = (uint32_t)seed; io.seed_hi = (uint32_t)(seed >> 32); io.step = step; io.env_off = env_id_offset;
     const dmp::PolicyDev& d = p->pd;
-    const int rb = (n + 31) / 32;
-    RT_LAUNCH((dmp::k_policy_layer<0, 2, 4>), rb * (d.H1 / 64), stream, d, io);
-    RT_LAUNCH((dmp::k_policy_layer<1, 2, 4>), rb * (d.H2 / 64), stream, d, io);
-    RT_LAUNCH((dmp::k_policy_layer<2, 2, 2>), rb * (d.N3 / 32), stream, d, io);
+    // tiles sized so that every launch has at least ~1 wave per SIMD at 4096 rows: 64 x 64 (layer 1), 32 x 64 (layer 2), 16 x 32 (layer 3)
+    RT_LAUNCH(dmp::k_policy_prep, n, stream, d, io);
+    RT_LAUNCH((dmp::k_policy_layer<0, 4, 4>), ((n + 63) / 64) * (d.H1 / 64), stream, d, io);
+    RT_LAUNCH((dmp::k_policy_layer<1, 2, 4>), ((n + 31) / 32) * (d.H2 / 64), stream, d, io);
+    RT_LAUNCH((dmp::k_policy_layer<2, 1, 2>), ((n + 15) / 16) * (d.N3 / 32), stream, d, io);
 #ifndef DM_EMU
     hipError_t le = hipGetLastError(); if (le != hipSuccess) return fail(std::string("kernel launch failed: ") + hipGetErrorString(le));
 #endif

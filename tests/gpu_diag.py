@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
-"""GPU-side diagnostics: rollout parity summaries (device vs oracle) per scene / precision -> JSON lines."""
+"""TEST INFRASTRUCTURE (uses the oracle): GPU-side rollout parity summaries (device vs oracle) per scene / precision -> JSON lines."""
 import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))   # ROOT = repo root (this file lives in tests/)
 import numpy as np
 import parity_common as pc
 

@@ -73,6 +73,10 @@ template <int NP2, typename R2, typename Real> static inline void wave_gram32(co
     __syncthreads();
 }
 // two / four packed reals (GCC vector extension on the host emulator)
+// 64-row Gram: generic statement (the emulator build and fp64)
+template <int NP2, typename R2, typename Real> static inline void wave_gram64(const R2* y2, Real (&out)[64]) {
+    for (int i = 0; i < 64; ++i) { Real a = 0; for (int p = 0; p < NP2; ++p) a += y2[p][0] * lane_bcast(y2[p][0], i) + y2[p][1] * lane_bcast(y2[p][1], i); out[i] = a; }
+}
 template <typename Real> struct VecT;
 template <> struct VecT<float> { typedef float v2 __attribute__((vector_size(8))); typedef float v4 __attribute__((vector_size(16))); };
 template <> struct VecT<double> { typedef double v2 __attribute__((vector_size(16))); typedef double v4 __attribute__((vector_size(32))); };
@@ -175,6 +179,44 @@ template <int NP2> __device__ __forceinline__ void wave_gram32(const VecT<float>
         const float other = __shfl(acc[v], l | 32, 64);          // lanes < 32 fetch the rows held by their upper partner
         out[8 * (v / 4) + (v % 4)] = acc[v];
         out[8 * (v / 4) + 4 + (v % 4)] = other;
+    }
+}
+// G[i] = sum_k y_l[k] y_i[k], i < 64: all 64 Gram rows on the matrix core.  With op0 = [Y[k0][0..31] | Y[k1][0..31]] and
+// op1 = [Y[k0][32..63] | Y[k1][32..63]] (one v_permlane32_swap of the lane's column pair) the four 32 x 32 blocks are the MFMA
+// chains (op0,op0), (op0,op1), (op1,op0), (op1,op1); lane j of either half holds column j of each block, rows split between the
+// halves.  Row r < 32 of G is [block00 column r | block10 column r], row 32 + r is [block01 column r | block11 column r] (G is
+// symmetric), so two swaps per accumulator pair hand every lane its full row.
+template <int NP2> __device__ __forceinline__ void wave_gram64(const VecT<float>::v2* y2, float (&out)[64]) {
+    typedef float f16v __attribute__((ext_vector_type(16)));
+    const f16v z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    f16v a00 = z, a01 = z, a10 = z, a11 = z;
+#pragma unroll
+    for (int p = 0; p < NP2; ++p) {
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(y2[p][0]), __float_as_uint(y2[p][1]), false, false);
+        const float op0 = __uint_as_float(sw[0]), op1 = __uint_as_float(sw[1]);
+        a00 = __builtin_amdgcn_mfma_f32_32x32x2f32(op0, op0, a00, 0, 0, 0);
+        a01 = __builtin_amdgcn_mfma_f32_32x32x2f32(op0, op1, a01, 0, 0, 0);
+        a10 = __builtin_amdgcn_mfma_f32_32x32x2f32(op1, op0, a10, 0, 0, 0);
+        a11 = __builtin_amdgcn_mfma_f32_32x32x2f32(op1, op1, a11, 0, 0, 0);
+    }
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+        // lower lanes keep block00 / block10 and receive the upper partner's halves of them; upper lanes the same for block01 / block11
+        const auto s0 = __builtin_amdgcn_permlane32_swap(__float_as_uint(a00[v]), __float_as_uint(a01[v]), false, false);
+        const auto s1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(a10[v]), __float_as_uint(a11[v]), false, false);
+        out[8 * (v / 4) + (v % 4)] = __uint_as_float(s0[0]);
+        out[8 * (v / 4) + 4 + (v % 4)] = __uint_as_float(s0[1]);
+        out[32 + 8 * (v / 4) + (v % 4)] = __uint_as_float(s1[0]);
+        out[32 + 8 * (v / 4) + 4 + (v % 4)] = __uint_as_float(s1[1]);
+    }
+}
+template <int NP2> __device__ __forceinline__ void wave_gram64(const VecT<double>::v2* y2, double (&out)[64]) {
+#pragma unroll 1
+    for (int i = 0; i < 64; ++i) {
+        double a = 0;
+#pragma unroll
+        for (int p = 0; p < NP2; ++p) a += y2[p][0] * lane_bcast(y2[p][0], i) + y2[p][1] * lane_bcast(y2[p][1], i);
+        out[i] = a;
     }
 }
 template <int NP2> __device__ __forceinline__ void wave_gram32(const VecT<double>::v2* y2, double (&out)[32]) {
@@ -814,6 +856,14 @@ struct EnvSim {
                 wave_gram32<NP2>(y2, g);
 #pragma unroll
                 for (int r = 0; r < 32; ++r) arow.set(r, (l == r) ? (Real)0 : g[r] * inv_adiag);
+            } else if (RREG >= kMaxRows && ND <= 34) {
+                // the wide biped class (fallback of the two-per-wave kernel): all 64 rows on the matrix core, straight into registers
+                Real g[64];
+#pragma unroll
+                for (int p = 0; p < NP2; ++p) DM_OPAQUE_V(y2[p]);
+                wave_gram64<NP2>(y2, g);
+#pragma unroll
+                for (int r = 0; r < 64; ++r) arow.set(r, (l == r) ? (Real)0 : g[r] * inv_adiag);
             } else {
                 for (int r = 0; r < R; ++r) {
                     R2 a2 = {(Real)0, (Real)0};

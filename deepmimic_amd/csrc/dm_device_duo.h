@@ -95,7 +95,9 @@ struct DuoSim {
     typedef ClsBiped C;
     typedef Lds<Real, C> L;
     typedef EnvSim<Real, C, TAPS, 32> Base;
-    typedef EnvSim<Real, C, TAPS, kWave> Single;
+    typedef EnvSim<Real, ClsBipedWide, TAPS, kWave> Single;      // all 64 rows of A in registers, 64-row Gram on the matrix core
+    typedef Lds<Real, ClsBipedWide> WideRec;
+    static_assert(sizeof(WideRec) == sizeof(L), "the wide class must share the LDS record layout");
     static constexpr int ND = C::ND, NP2 = ND / 2, NP = C::NP, NJ = C::NJ, HW = 32, CP = 2 /* candidate passes */;
     typedef V3<Real> v3; typedef typename VecT<Real>::v2 R2; typedef typename VecT<Real>::v4 R4;
     const ModelDev<Real>& m; L* rec;                    // the two records of this workgroup
@@ -505,11 +507,11 @@ _Pragma("unroll") \
                 // more than 32 rows somewhere in the pair: one character at a time through the 64-lane routine
                 for (int x = 0; x < 2; ++x) {
                     int wlv = wl; DM_OPAQUE_V(wlv);          // keeps this rare path's address arithmetic out of the hot loop's live ranges
-                    Single one(m, rec[x], wlv);
+                    Single one(m, reinterpret_cast<WideRec&>(rec[x]), wlv);
                     one.li = (wlv < m.J) ? rec[x].mdl.link_info[wlv] : 0;
                     one.load_cands();
                     DebugTaps<Real> none = DebugTaps<Real>();
-                    one.substep_post(h, none, e, aovf_pair ? aovf_pair + (size_t)x * (kMaxRows - C::RREG) * kWave : nullptr);
+                    one.substep_post(h, none, e, nullptr);
                 }
             }
         }

@@ -26,6 +26,9 @@ constexpr int kMaxContacts = 20;   // contact slots per character (ground + self
 struct ClsBiped {      // humanoid3d: 15 links, 34 dof, 43 pose dims, <= 64 ground-contact candidates, no attach rotations
     static constexpr int NJ = 15, ND = 34, NP = 43, NCAP = 64, RREG = 32, NPAIRCAP = 128, LPAD = 4; static constexpr bool ROT = false;   // RREG: rows of A kept in VGPRs
 };
+// the same character class with all 64 rows of A in VGPRs: the instantiation the two-per-wave kernel falls back to for a pair with a
+// heavily contacted character (256-VGPR budget there; identical LDS record layout)
+struct ClsBipedWide : ClsBiped { static constexpr int RREG = 64; };
 struct ClsLarge {      // dog3d and anything up to 23 links / 64 dof / 83 pose dims / 128 candidates, attach rotations allowed
     static constexpr int NJ = 23, ND = 64, NP = 83, NCAP = 128, RREG = 64, NPAIRCAP = 256, LPAD = 2; static constexpr bool ROT = true;
 };

@@ -208,6 +208,18 @@ def test_duo_heavy_contact_fallback(hip_lib):
     assert dr.max() < 1e-6 and ds.max() < 1e-4
 
 
+def test_duo_heavy_contact_fallback_fp32_matrix_core_gram(hip_lib):
+    """fp32: a character pushed 0.3 m into the ground needs > 32 rows, the pair falls back to the wide one-per-wave routine whose 64-row
+    Gram matrix runs on the matrix core (wave_gram64) and whose A stays in registers.  One control step of a deep-penetration state is
+    stiff (push-out velocities of tens of m/s), so the check is against the one-character-per-wave kernel (readlane Gram, HBM overflow
+    rows: a different code path for the same arithmetic) and, loosely, against the fp64 oracle."""
+    t0s, lifts = [0.0, 0.4, 0.2, 0.6], [-0.3, 0.0, 0.0, -0.25]
+    dr2, ds2, _ = pc.batch_rollout_compare("humanoid3d_walk", 32, hip_lib, steps=1, t0s=t0s, wave_packing=2, lifts=lifts)
+    dr1, ds1, _ = pc.batch_rollout_compare("humanoid3d_walk", 32, hip_lib, steps=1, t0s=t0s, wave_packing=1, lifts=lifts)
+    assert dr2.max() < 1e-5 and dr1.max() < 1e-5, (dr2, dr1)           # measured 1e-7 / 4e-7
+    assert ds2.max() < 1e-2 and ds1.max() < 1e-2, (ds2, ds1)           # measured 2e-3 / 3e-3 (velocities of a 0.3 m push-out)
+
+
 def test_duo_spinkick_and_300_steps(hip_lib):
     dr, ds, ok = pc.batch_rollout_compare("humanoid3d_spinkick", 64, hip_lib, steps=20, t0s=[0.0, 0.3], wave_packing=2)
     assert ok and dr.max() < 1e-5

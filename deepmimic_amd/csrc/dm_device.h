@@ -162,23 +162,22 @@ template <> struct VecT<double> { typedef double v2 __attribute__((ext_vector_ty
 // fp32: the one dense contraction of the path goes to the matrix core -- NP2 x v_mfma_f32_32x32x2_f32 (K = 2 per issue, full
 // fp32 multiply-add).  Operand layout: lanes 0..31 carry Y[k0][lane], lanes 32..63 carry Y[k0+1][lane-32]; A and B operands
 // are the same register (G = Y^T Y).  The 32x32 result comes back as 16 accumulators per lane (lane = column, rows split
-// between the wave halves); symmetry turns lane j's column into row j, the other half arrives by one cross-half shuffle each.
+// between the wave halves); symmetry turns lane j's column into row j, the other half arrives by one v_permlane32_swap each.
 template <int NP2> __device__ __forceinline__ void wave_gram32(const VecT<float>::v2* y2, float (&out)[32]) {
     typedef float f16v __attribute__((ext_vector_type(16)));
-    const int l = threadIdx.x;
-    const bool upper = l >= 32;
     f16v acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
     for (int p = 0; p < NP2; ++p) {
-        const float up = __shfl(y2[p][1], l & 31, 64);
-        const float opnd = upper ? up : y2[p][0];
+        // gfx950 v_permlane32_swap: (a0, a1) -> [a0.lo | a1.lo]: the upper lanes receive the lower lanes' odd column
+        const float opnd = __uint_as_float(__builtin_amdgcn_permlane32_swap(__float_as_uint(y2[p][0]), __float_as_uint(y2[p][1]), false, false)[0]);
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(opnd, opnd, acc, 0, 0, 0);
     }
 #pragma unroll
     for (int v = 0; v < 16; ++v) {
-        const float other = __shfl(acc[v], l | 32, 64);          // lanes < 32 fetch the rows held by their upper partner
-        out[8 * (v / 4) + (v % 4)] = acc[v];
-        out[8 * (v / 4) + 4 + (v % 4)] = other;
+        // lanes < 32 (the only ones with a row) keep their accumulator and take the rows held by their upper partner
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[v]), __float_as_uint(acc[v]), false, false);
+        out[8 * (v / 4) + (v % 4)] = __uint_as_float(sw[0]);
+        out[8 * (v / 4) + 4 + (v % 4)] = __uint_as_float(sw[1]);
     }
 }
 // G[i] = sum_k y_l[k] y_i[k], i < 64: all 64 Gram rows on the matrix core.  With op0 = [Y[k0][0..31] | Y[k1][0..31]] and

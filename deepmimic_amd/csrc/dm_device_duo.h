@@ -99,7 +99,7 @@ struct DuoSim {
     typedef Lds<Real, ClsBipedWide> WideRec;
     static_assert(sizeof(WideRec) == sizeof(L), "the wide class must share the LDS record layout");
     static constexpr int ND = C::ND, NP2 = ND / 2, NP = C::NP, NJ = C::NJ, HW = 32, CP = 2 /* candidate passes */;
-    typedef V3<Real> v3; typedef typename VecT<Real>::v2 R2; typedef typename VecT<Real>::v4 R4;
+    typedef V3<Real> v3; typedef M3<Real> m3; typedef typename VecT<Real>::v2 R2; typedef typename VecT<Real>::v4 R4;
     const ModelDev<Real>& m; L* rec;                    // the two records of this workgroup
     const int wl, half; int hl;                         // wave lane, which character, lane within the character
     Base b;                                             // per-character pieces (lane hl of record `half`)
@@ -125,13 +125,111 @@ struct DuoSim {
     }
 
     // ------------------------------------------------------------------ mass matrix rows 3..33 in lanes, rows 0..2 closed form
+#ifndef DM_EMU
+    // Subtree (composite-body) sums of both characters on the matrix core, fp32 build.  Every link's Newton-Euler terms are taken
+    // about ONE origin o (the root joint), where they simply add over a subtree: X_k = (f, n + e x f, m, m e, I_w + m(|e|^2 1 - e e^T)),
+    // e = com_k - o.  S = M X with the 16 x 16 ancestor mask M (M_jk = 1 when k is in the subtree of j) is four
+    // v_mfma_f64_16x16x4_f64 per character; each link then moves its sums to its own joint origin (r = p_j - o):
+    //   N_j = N0 - r x F,  h_j = H0 - m r,  I_j = I0 + (m r.r - 2 H0.r) 1 + H0 r^T + r H0^T - m r r^T.
+    // The shift cancels two digits for distal links (I0 ~ m |r|^2 >> I_j), so X, the sums and the shift are carried in fp64: every
+    // product of two fp32 inputs is exact there and the result is the exactly evaluated direct formula, rounded once to fp32.
+    // Replaces a 2-lane-per-link gather loop (8 dependent LDS round trips for the root) by ~130 instructions without a loop.
+    DM_DEV void subtree_mfma(int iset) {
+        typedef double d4 __attribute__((ext_vector_type(4)));
+        double* xb = reinterpret_cast<double*>(&s.Lt[0]);           // [16 links][16 quantities]; the factor storage is dead until dyn_row
+        const v3 o = ld3(s.p[0]);
+        if (hl < m.J) {
+            const int k = hl;
+            m3 Rb = ldm3(b.Rbp(k));
+            const Real* Id = s.mdl.inertia[iset][k];
+            const Real I0 = Id[0], I1 = Id[1], I2 = Id[2];
+            Real Iw[6];
+            Iw[0] = Rb.m[0] * Rb.m[0] * I0 + Rb.m[1] * Rb.m[1] * I1 + Rb.m[2] * Rb.m[2] * I2;
+            Iw[1] = Rb.m[0] * Rb.m[3] * I0 + Rb.m[1] * Rb.m[4] * I1 + Rb.m[2] * Rb.m[5] * I2;
+            Iw[2] = Rb.m[0] * Rb.m[6] * I0 + Rb.m[1] * Rb.m[7] * I1 + Rb.m[2] * Rb.m[8] * I2;
+            Iw[3] = Rb.m[3] * Rb.m[3] * I0 + Rb.m[4] * Rb.m[4] * I1 + Rb.m[5] * Rb.m[5] * I2;
+            Iw[4] = Rb.m[3] * Rb.m[6] * I0 + Rb.m[4] * Rb.m[7] * I1 + Rb.m[5] * Rb.m[8] * I2;
+            Iw[5] = Rb.m[6] * Rb.m[6] * I0 + Rb.m[7] * Rb.m[7] * I1 + Rb.m[8] * Rb.m[8] * I2;
+            const v3 w = ld3(s.w[k]), al = ld3(s.al[k]), com = ld3(s.com[k]);
+            const v3 rc = com - ld3(s.p[k]);
+            const v3 ac = ld3(s.aj[k]) + cross(al, rc) + cross(w, cross(w, rc));
+            const Real mk = s.mdl.mass[k];
+            const v3 f = mk * ac;
+            const v3 Iwv = mk3(Iw[0] * w.x + Iw[1] * w.y + Iw[2] * w.z, Iw[1] * w.x + Iw[3] * w.y + Iw[4] * w.z, Iw[2] * w.x + Iw[4] * w.y + Iw[5] * w.z);
+            const v3 Ial = mk3(Iw[0] * al.x + Iw[1] * al.y + Iw[2] * al.z, Iw[1] * al.x + Iw[3] * al.y + Iw[4] * al.z, Iw[2] * al.x + Iw[4] * al.y + Iw[5] * al.z);
+            const v3 n = Ial + cross(w, Iwv);
+            const double ex = (double)com.x - (double)o.x, ey = (double)com.y - (double)o.y, ez = (double)com.z - (double)o.z;
+            const double fx = f.x, fy = f.y, fz = f.z, md = mk, ee = ex * ex + ey * ey + ez * ez;
+            double* x = xb + 16 * k;
+            x[0] = fx; x[1] = fy; x[2] = fz;
+            x[3] = (double)n.x + (ey * fz - ez * fy); x[4] = (double)n.y + (ez * fx - ex * fz); x[5] = (double)n.z + (ex * fy - ey * fx);
+            x[6] = md; x[7] = md * ex; x[8] = md * ey; x[9] = md * ez;
+            x[10] = (double)Iw[0] + md * (ee - ex * ex); x[11] = (double)Iw[1] - md * ex * ey; x[12] = (double)Iw[2] - md * ex * ez;
+            x[13] = (double)Iw[3] + md * (ee - ey * ey); x[14] = (double)Iw[4] - md * ey * ez; x[15] = (double)Iw[5] + md * (ee - ez * ez);
+        } else if (hl == m.J) {
+            double* x = xb + 16 * hl;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) x[i] = 0.0;                // link slot 15 does not exist: 0 x garbage must not reach the sums
+        }
+        sync();
+        // S_c = M X_c for both characters: the operands are wave-wide (lane l: A[i = l & 15][k = l >> 4 + 4 t], B[k][q = l & 15])
+        const int li_ = wl & 15, lk_ = wl >> 4;
+        const uint32_t mrow = (li_ < m.J) ? s.mdl.subtree_mask[li_] : 0u;     // the model block is the same in both records
+        const double* xa = reinterpret_cast<const double*>(&rec[0].Lt[0]);
+        const double* xc = reinterpret_cast<const double*>(&rec[1].Lt[0]);
+        d4 s0 = {0.0, 0.0, 0.0, 0.0}, s1 = s0;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int k = 4 * t + lk_;
+            const double a = ((mrow >> k) & 1u) ? 1.0 : 0.0;
+            s0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, xa[16 * k + li_], s0, 0, 0, 0);
+            s1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, xc[16 * k + li_], s1, 0, 0, 0);
+        }
+        sync();                                                     // every lane has read X before the sums overwrite it
+        {
+            double* sa = reinterpret_cast<double*>(&rec[0].Lt[0]);
+            double* sc2 = reinterpret_cast<double*>(&rec[1].Lt[0]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const int j = lk_ + 4 * r; sa[16 * j + li_] = s0[r]; sc2[16 * j + li_] = s1[r]; }   // f64 C/D: row = (l >> 4) + 4 reg
+        }
+        sync();
+        if (hl < m.J) {
+            const int j = hl;
+            const double* S = xb + 16 * j;
+            const v3 pj = ld3(s.p[j]);
+            const double rx = (double)pj.x - (double)o.x, ry = (double)pj.y - (double)o.y, rz = (double)pj.z - (double)o.z;
+            const double Fx = S[0], Fy = S[1], Fz = S[2], mc = S[6], Hx = S[7], Hy = S[8], Hz = S[9];
+            s.Fs[j][0] = (Real)Fx; s.Fs[j][1] = (Real)Fy; s.Fs[j][2] = (Real)Fz;
+            s.Ns[j][0] = (Real)(S[3] - (ry * Fz - rz * Fy)); s.Ns[j][1] = (Real)(S[4] - (rz * Fx - rx * Fz)); s.Ns[j][2] = (Real)(S[5] - (rx * Fy - ry * Fx));
+            const double dg = mc * (rx * rx + ry * ry + rz * rz) - 2.0 * (Hx * rx + Hy * ry + Hz * rz);
+            Real* ic = s.Ic[j];
+            ic[0] = (Real)mc; ic[1] = (Real)(Hx - mc * rx); ic[2] = (Real)(Hy - mc * ry); ic[3] = (Real)(Hz - mc * rz);
+            ic[4] = (Real)(S[10] + dg + 2.0 * Hx * rx - mc * rx * rx);
+            ic[5] = (Real)(S[11] + Hx * ry + rx * Hy - mc * rx * ry);
+            ic[6] = (Real)(S[12] + Hx * rz + rx * Hz - mc * rx * rz);
+            ic[7] = (Real)(S[13] + dg + 2.0 * Hy * ry - mc * ry * ry);
+            ic[8] = (Real)(S[14] + Hy * rz + ry * Hz - mc * ry * rz);
+            ic[9] = (Real)(S[15] + dg + 2.0 * Hz * rz - mc * rz * rz);
+        }
+        sync();
+    }
+#endif
     DM_DEV void dynamics(int iset, Real diag_scale) {
         const int D = m.D;
-        b.dyn_links(iset);
-        for (int k = hl; k < D; k += HW) b.dyn_dofrec(k);
-        sync();
-        b.dyn_subtree();
-        sync();
+#ifndef DM_EMU
+        if constexpr (sizeof(Real) == 4) {
+            subtree_mfma(iset);
+            for (int k = hl; k < D; k += HW) b.dyn_dofrec(k);
+            sync();
+        } else
+#endif
+        {
+            b.dyn_links(iset);
+            for (int k = hl; k < D; k += HW) b.dyn_dofrec(k);
+            sync();
+            b.dyn_subtree();
+            sync();
+        }
         if (hl + 3 < D) b.dyn_row(hl + 3, diag_scale);
         if (hl == HW - 1) {
             for (int k = 0; k < 3; ++k) s.dofrec[k][7] = s.Fs[0][k];       // root translation: C_k = total force

@@ -462,27 +462,30 @@ struct EnvSim {
         }
         v3 Lq = Lp + cross(ld3(s.p[dj]) - ld3(s.p[0]), Pm);
         Real* row = &s.Lt[L::lrow(k)];
-        if (L::LPAD == 4) {   // zero the row with 16-B stores (rows are padded to a multiple of 4)
-            const R4 z4 = {(Real)0, (Real)0, (Real)0, (Real)0};
-            for (int j = 0; j <= k; j += 4) *reinterpret_cast<R4*>(&row[j]) = z4;
-        } else {
-            const R2 z2 = {(Real)0, (Real)0};
-            for (int j = 0; j <= k; j += 2) *reinterpret_cast<R2*>(&row[j]) = z2;
-        }
-        // ancestor-or-self dofs j <= k: the chain of the dof's joint, cut at k
-        uint32_t lo = s.mdl.chain_lo[dj] & ((k < 31) ? ((2u << k) - 1u) : ~0u), hi = (k < 32) ? 0u : (s.mdl.chain_hi[dj] & ((k < 63) ? ((2u << (k - 32)) - 1u) : ~0u));
-        // two ancestors per trip: both record gathers are in flight before either is consumed
-        while (lo | hi) {
-            int j0, j1 = -1;
-            if (lo) { j0 = dm_ctz32(lo); lo &= lo - 1; } else { j0 = 32 + dm_ctz32(hi); hi &= hi - 1; }
-            if (lo | hi) { if (lo) { j1 = dm_ctz32(lo); lo &= lo - 1; } else { j1 = 32 + dm_ctz32(hi); hi &= hi - 1; } }
-            const Real* r0 = s.dofrec[j0]; const Real* r1 = s.dofrec[j1 < 0 ? j0 : j1];
-            Real v0 = r0[0] * Lq.x + r0[1] * Lq.y + r0[2] * Lq.z + r0[3] * Pm.x + r0[4] * Pm.y + r0[5] * Pm.z;
-            Real v1 = r1[0] * Lq.x + r1[1] * Lq.y + r1[2] * Lq.z + r1[3] * Pm.x + r1[4] * Pm.y + r1[5] * Pm.z;
-            if (j0 == k) v0 += diag_scale * s.mdl.kd[dj];
-            if (j1 == k) v1 += diag_scale * s.mdl.kd[dj];
-            row[j0] = v0;
-            if (j1 >= 0) row[j1] = v1;
+        // ancestor-or-self dofs j <= k: the chain of the dof's joint, cut at k.  The loop runs over ALL dofs with static j: every
+        // lane reads the same record dofrec[j] (one conflict-free LDS broadcast, requested ahead by the unrolled schedule) and keeps
+        // the value when j is on its chain -- against a per-lane walk over the set bits, whose record gathers collide on the LDS banks
+        // and whose trip count is the longest chain of the wave.
+        const uint32_t lo = s.mdl.chain_lo[dj] & ((k < 31) ? ((2u << k) - 1u) : ~0u), hi = (k < 32) ? 0u : (s.mdl.chain_hi[dj] & ((k < 63) ? ((2u << (k - 32)) - 1u) : ~0u));
+        const Real dk = diag_scale * s.mdl.kd[dj];
+#pragma unroll
+        for (int p = 0; p < NP2; ++p) {
+            R2 v2;
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const int j = 2 * p + c;
+                Real v = 0;
+                if (j < ND) {
+                    const R4 r0 = *reinterpret_cast<const R4*>(&s.dofrec[j][0]);
+                    const R2 r1 = *reinterpret_cast<const R2*>(&s.dofrec[j][4]);
+                    v = r0[0] * Lq.x + r0[1] * Lq.y + r0[2] * Lq.z + r0[3] * Pm.x + r1[0] * Pm.y + r1[1] * Pm.z;
+                    if (j == k) v += dk;
+                    const bool on = (((j < 32) ? lo : hi) >> (j & 31)) & 1u;
+                    v = on ? v : (Real)0;
+                }
+                v2[c] = v;
+            }
+            if (2 * p <= k) *reinterpret_cast<R2*>(&row[2 * p]) = v2;
         }
     }
 

@@ -95,8 +95,20 @@ struct DuoSim {
     typedef ClsBiped C;
     typedef Lds<Real, C> L;
     typedef EnvSim<Real, C, TAPS, 32> Base;
-    typedef EnvSim<Real, ClsBipedWide, TAPS, kWave> Single;      // all 64 rows of A in registers, 64-row Gram on the matrix core
-    typedef Lds<Real, ClsBipedWide> WideRec;
+    // Fallback class for a pair with a heavily contacted character.  DM_DUO_WIDE_FALLBACK = 1 selects ClsBipedWide (all 64 rows of A
+    // in VGPRs, 64-row Gram on the matrix core): +8..13 % closed-loop throughput under an untrained policy, but its 64-register row
+    // file pushes 10 kernel-long-lived values of the two-per-wave kernel into scratch (40 B / lane, +7.5 MB of HBM traffic per launch),
+    // so the default keeps the narrow class (rows 32..63 in the HBM / L2 overflow block, requested two rows ahead): no scratch at all.
+#ifndef DM_DUO_WIDE_FALLBACK
+#define DM_DUO_WIDE_FALLBACK 0
+#endif
+#if DM_DUO_WIDE_FALLBACK
+    typedef ClsBipedWide FallbackCls;
+#else
+    typedef ClsBiped FallbackCls;
+#endif
+    typedef EnvSim<Real, FallbackCls, TAPS, kWave> Single;
+    typedef Lds<Real, FallbackCls> WideRec;
     static_assert(sizeof(WideRec) == sizeof(L), "the wide class must share the LDS record layout");
     static constexpr int ND = C::ND, NP2 = ND / 2, NP = C::NP, NJ = C::NJ, HW = 32, CP = 2 /* candidate passes */;
     typedef V3<Real> v3; typedef M3<Real> m3; typedef typename VecT<Real>::v2 R2; typedef typename VecT<Real>::v4 R4;
@@ -609,7 +621,7 @@ _Pragma("unroll") \
                     one.li = (wlv < m.J) ? rec[x].mdl.link_info[wlv] : 0;
                     one.load_cands();
                     DebugTaps<Real> none = DebugTaps<Real>();
-                    one.substep_post(h, none, e, nullptr);
+                    one.substep_post(h, none, e, (FallbackCls::RREG < kMaxRows && aovf_pair) ? aovf_pair + (size_t)x * (kMaxRows - FallbackCls::RREG) * kWave : nullptr);
                 }
             }
         }

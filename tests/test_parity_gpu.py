@@ -208,9 +208,9 @@ def test_duo_heavy_contact_fallback(hip_lib):
     assert dr.max() < 1e-6 and ds.max() < 1e-4
 
 
-def test_duo_heavy_contact_fallback_fp32_matrix_core_gram(hip_lib):
-    """fp32: a character pushed 0.3 m into the ground needs > 32 rows, the pair falls back to the wide one-per-wave routine whose 64-row
-    Gram matrix runs on the matrix core (wave_gram64) and whose A stays in registers.  One control step of a deep-penetration state is
+def test_duo_heavy_contact_fallback_fp32(hip_lib):
+    """fp32: a character pushed 0.3 m into the ground needs > 32 rows, the pair falls back to the one-per-wave routine (narrow class by
+    default; with -DDM_DUO_WIDE_FALLBACK=1 the wide class whose 64-row Gram matrix runs on the matrix core, wave_gram64).  One control step of a deep-penetration state is
     stiff (push-out velocities of tens of m/s), so the check is against the one-character-per-wave kernel (readlane Gram, HBM overflow
     rows: a different code path for the same arithmetic) and, loosely, against the fp64 oracle."""
     t0s, lifts = [0.0, 0.4, 0.2, 0.6], [-0.3, 0.0, 0.0, -0.25]

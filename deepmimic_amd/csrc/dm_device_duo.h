@@ -302,13 +302,13 @@ _Pragma("unroll") \
                 for (int p = pk + 2; p < NP2; ++p) { t0[p] = *reinterpret_cast<const R2*>(&cb0[2 * p]); t1[p] = *reinterpret_cast<const R2*>(&cb1[2 * p]); } \
                 const Real a = (k + 2 < 3) ? (Real)0 : half_bcast_c<(((k) + 2 - 3) & 31)>(c0, half), c = ((k) + 2 < 3) ? (Real)0 : half_bcast_c<(((k) + 2 - 3) & 31)>(c1, half); \
                 const Real bq = half_bcast_c<(((k) + 3 - 3) & 31)>(c0, half), d = half_bcast_c<(((k) + 3 - 3) & 31)>(c1, half); \
-                h2[pk + 1][0] -= c0 * a + c1 * c; \
-                h2[pk + 1][1] -= c0 * bq + c1 * d; \
+                h2[pk + 1][0] = (h2[pk + 1][0] - c0 * a) - c1 * c; \
+                h2[pk + 1][1] = (h2[pk + 1][1] - c0 * bq) - c1 * d; \
                 DM_DUO_COLS(k + 2) \
                 const R2 l20 = {c0, c0}, l21 = {c1, c1}; \
 _Pragma("unroll") \
                 for (int p = pk + 2; p < NP2; ++p) { \
-                    h2[p] -= l20 * t0[p] + l21 * t1[p]; \
+                    h2[p] = h2[p] - l20 * t0[p]; h2[p] = h2[p] - l21 * t1[p]; \
                     DM_OPAQUE_V(h2[p]); \
                 } \
             } \

@@ -357,9 +357,10 @@ struct EnvSim {
                     v3 wp = ld3(s.w[par]), alp = ld3(s.al[par]);
                     v3 wrel = Rj * wl;
                     w = wp + wrel;
-                    vj = ld3(s.vj[par]) + cross(wp, r);
-                    al = alp + cross(wp, wrel);
-                    aj = ld3(s.aj[par]) + cross(alp, r) + cross(wp, cross(wp, r));
+                    const v3 wxr = cross(wp, r);
+                    vj = ld3(s.vj[par]) + wxr;
+                    al = cross_add(alp, wp, wrel);
+                    aj = cross_add(cross_add(ld3(s.aj[par]), alp, r), wp, wxr);
                 }
                 stm3(s.R[l], Rj); st3(s.p[l], pj); st3(s.w[l], w); st3(s.vj[l], vj); st3(s.al[l], al); st3(s.aj[l], aj);
                 st3(s.com[l], pj + Rj * ld3(s.mdl.battach[l]));
@@ -397,11 +398,11 @@ struct EnvSim {
             for (int k = 0; k < 6; ++k) s.Iw[l][k] = Iw[k];
             v3 w = ld3(s.w[l]), al = ld3(s.al[l]);
             v3 rc = ld3(s.com[l]) - ld3(s.p[l]);
-            v3 ac = ld3(s.aj[l]) + cross(al, rc) + cross(w, cross(w, rc));
+            v3 ac = cross_add(cross_add(ld3(s.aj[l]), al, rc), w, cross(w, rc));
             st3(s.f[l], s.mdl.mass[l] * ac);
             v3 Iwv = mk3(Iw[0] * w.x + Iw[1] * w.y + Iw[2] * w.z, Iw[1] * w.x + Iw[3] * w.y + Iw[4] * w.z, Iw[2] * w.x + Iw[4] * w.y + Iw[5] * w.z);
             v3 Ial = mk3(Iw[0] * al.x + Iw[1] * al.y + Iw[2] * al.z, Iw[1] * al.x + Iw[3] * al.y + Iw[4] * al.z, Iw[2] * al.x + Iw[4] * al.y + Iw[5] * al.z);
-            st3(s.n[l], Ial + cross(w, Iwv));
+            st3(s.n[l], cross_add(Ial, w, Iwv));
         }
     }
     // world axis of generalized velocity k and its moment about the root origin -> dofrec[k] = (a, g)
@@ -460,7 +461,7 @@ struct EnvSim {
             Pm = cross(a, h);
             Lp = mk3(ic[4] * a.x + ic[5] * a.y + ic[6] * a.z, ic[5] * a.x + ic[7] * a.y + ic[8] * a.z, ic[6] * a.x + ic[8] * a.y + ic[9] * a.z);
         }
-        v3 Lq = Lp + cross(ld3(s.p[dj]) - ld3(s.p[0]), Pm);
+        v3 Lq = cross_add(Lp, ld3(s.p[dj]) - ld3(s.p[0]), Pm);
         Real* row = &s.Lt[L::lrow(k)];
         // ancestor-or-self dofs j <= k: the chain of the dof's joint, cut at k.  The loop runs over ALL dofs with static j: every
         // lane reads the same record dofrec[j] (one conflict-free LDS broadcast, requested ahead by the unrolled schedule) and keeps

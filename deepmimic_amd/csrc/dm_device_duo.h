@@ -164,12 +164,12 @@ struct DuoSim {
             Iw[5] = Rb.m[6] * Rb.m[6] * I0 + Rb.m[7] * Rb.m[7] * I1 + Rb.m[8] * Rb.m[8] * I2;
             const v3 w = ld3(s.w[k]), al = ld3(s.al[k]), com = ld3(s.com[k]);
             const v3 rc = com - ld3(s.p[k]);
-            const v3 ac = ld3(s.aj[k]) + cross(al, rc) + cross(w, cross(w, rc));
+            const v3 ac = cross_add(cross_add(ld3(s.aj[k]), al, rc), w, cross(w, rc));
             const Real mk = s.mdl.mass[k];
             const v3 f = mk * ac;
             const v3 Iwv = mk3(Iw[0] * w.x + Iw[1] * w.y + Iw[2] * w.z, Iw[1] * w.x + Iw[3] * w.y + Iw[4] * w.z, Iw[2] * w.x + Iw[4] * w.y + Iw[5] * w.z);
             const v3 Ial = mk3(Iw[0] * al.x + Iw[1] * al.y + Iw[2] * al.z, Iw[1] * al.x + Iw[3] * al.y + Iw[4] * al.z, Iw[2] * al.x + Iw[4] * al.y + Iw[5] * al.z);
-            const v3 n = Ial + cross(w, Iwv);
+            const v3 n = cross_add(Ial, w, Iwv);
             const double ex = (double)com.x - (double)o.x, ey = (double)com.y - (double)o.y, ez = (double)com.z - (double)o.z;
             const double fx = f.x, fy = f.y, fz = f.z, md = mk, ee = ex * ex + ey * ey + ez * ez;
             double* x = xb + 16 * k;

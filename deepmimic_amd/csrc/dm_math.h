@@ -32,6 +32,10 @@ template <typename T> DM_HD T dot(const V3<T>& a, const V3<T>& b) { return a.x *
 template <typename T> DM_HD V3<T> cross(const V3<T>& a, const V3<T>& b) {
     return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
 }
+// c + a x b with the additions folded into the products (two FMAs per component instead of mul, fma, add)
+template <typename T> DM_HD V3<T> cross_add(const V3<T>& c, const V3<T>& a, const V3<T>& b) {
+    return mk3((c.x + a.y * b.z) - a.z * b.y, (c.y + a.z * b.x) - a.x * b.z, (c.z + a.x * b.y) - a.y * b.x);
+}
 template <typename T> DM_HD T comp(const V3<T>& a, int i) { return i == 0 ? a.x : (i == 1 ? a.y : a.z); }
 
 DM_HD float dm_sqrt(float x) { return sqrtf(x); }

@@ -336,14 +336,19 @@ _Pragma("unroll") \
         Real xr[3];
 #pragma unroll
         for (int k = 0; k < 3; ++k) { xr[k] = xvec[k] * dinv0; x -= h2[k >> 1][k & 1] * xr[k]; }
-        // rows 3..33 in order, statically expanded: the lane id of each broadcast is an immediate (DPP form of half_bcast_c)
-#define DM_DUO_FWD(k) { Real t = x * dinv; Real xk = half_bcast_c<(k) - 3>(t, half); if (own == (k)) x = t; else if (own > (k)) x -= h2[(k) >> 1][(k) & 1] * xk; }
+        // rows 3..33 in order, statically expanded: the lane id of each broadcast is an immediate (DPP form of half_bcast_c).  The
+        // entries of the own row on and right of the diagonal are zeroed once, so a step is mul, broadcast, FMA for every lane -- no
+        // per-step lane compares -- and the lane's own scaling by 1/L_kk moves behind the loop (row k is final once step k is reached)
+#pragma unroll
+        for (int p = 0; p < NP2; ++p) { if (!(2 * p < own)) h2[p][0] = 0; if (!(2 * p + 1 < own)) h2[p][1] = 0; }
+#define DM_DUO_FWD(k) { const Real xk = half_bcast_c<(k) - 3>(x * dinv, half); x -= h2[(k) >> 1][(k) & 1] * xk; }
         static_assert(ND == 34, "the expansion below covers rows 3..33");
         DM_DUO_FWD(3) DM_DUO_FWD(4) DM_DUO_FWD(5) DM_DUO_FWD(6) DM_DUO_FWD(7) DM_DUO_FWD(8) DM_DUO_FWD(9) DM_DUO_FWD(10)
         DM_DUO_FWD(11) DM_DUO_FWD(12) DM_DUO_FWD(13) DM_DUO_FWD(14) DM_DUO_FWD(15) DM_DUO_FWD(16) DM_DUO_FWD(17) DM_DUO_FWD(18)
         DM_DUO_FWD(19) DM_DUO_FWD(20) DM_DUO_FWD(21) DM_DUO_FWD(22) DM_DUO_FWD(23) DM_DUO_FWD(24) DM_DUO_FWD(25) DM_DUO_FWD(26)
         DM_DUO_FWD(27) DM_DUO_FWD(28) DM_DUO_FWD(29) DM_DUO_FWD(30) DM_DUO_FWD(31) DM_DUO_FWD(32) DM_DUO_FWD(33)
 #undef DM_DUO_FWD
+        x *= dinv;
         sync();
         back_substitute(x, xr, dinv, dinv0);
         if (valid) xvec[own] = x;
@@ -356,13 +361,14 @@ _Pragma("unroll") \
         Real c[ND];
 #pragma unroll
         for (int k = 0; k < ND; ++k) c[k] = (valid && k > own) ? s.Lt[L::lrow(k) + own] : (Real)0;
-#define DM_DUO_BWD(k) { Real t = x * dinv; Real xk = half_bcast_c<(k) - 3>(t, half); if (own == (k)) x = t; else if (own < (k)) x -= c[k] * xk; }
+#define DM_DUO_BWD(k) { const Real xk = half_bcast_c<(k) - 3>(x * dinv, half); x -= c[k] * xk; }      /* c[k] = 0 for k <= own */
         static_assert(ND == 34, "the expansion below covers rows 33..3");
         DM_DUO_BWD(33) DM_DUO_BWD(32) DM_DUO_BWD(31) DM_DUO_BWD(30) DM_DUO_BWD(29) DM_DUO_BWD(28) DM_DUO_BWD(27) DM_DUO_BWD(26)
         DM_DUO_BWD(25) DM_DUO_BWD(24) DM_DUO_BWD(23) DM_DUO_BWD(22) DM_DUO_BWD(21) DM_DUO_BWD(20) DM_DUO_BWD(19) DM_DUO_BWD(18)
         DM_DUO_BWD(17) DM_DUO_BWD(16) DM_DUO_BWD(15) DM_DUO_BWD(14) DM_DUO_BWD(13) DM_DUO_BWD(12) DM_DUO_BWD(11) DM_DUO_BWD(10)
         DM_DUO_BWD(9) DM_DUO_BWD(8) DM_DUO_BWD(7) DM_DUO_BWD(6) DM_DUO_BWD(5) DM_DUO_BWD(4) DM_DUO_BWD(3)
 #undef DM_DUO_BWD
+        x *= dinv;
         Real col[3];
 #pragma unroll
         for (int k = 0; k < 3; ++k) col[k] = valid ? Lx(own, k) : (Real)0;

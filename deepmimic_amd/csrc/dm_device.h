@@ -546,11 +546,13 @@ struct EnvSim {
             }
         }
         Real x = (l < D) ? xvec[l] : (Real)0;
+        // forward substitution: the entries of the own row on and right of the diagonal are zeroed once, so a step is mul, broadcast,
+        // FMA for every lane (no per-step lane compares); the lane's own scaling by 1/L_kk moves behind the loop
 #pragma unroll
-        for (int k = 0; k < ND; ++k) {
-            Real t = x * dinv; Real xk = lane_bcast(t, k);
-            if (l == k) x = t; else if (l > k) x -= h2[k >> 1][k & 1] * xk;
-        }
+        for (int p = 0; p < NP2; ++p) { if (!(2 * p < l)) h2[p][0] = 0; if (!(2 * p + 1 < l)) h2[p][1] = 0; }
+#pragma unroll
+        for (int k = 0; k < ND; ++k) { const Real xk = lane_bcast(x * dinv, k); x -= h2[k >> 1][k & 1] * xk; }
+        x *= dinv;
         sync();
         x = back_substitute(x, dinv);
         if (l < D) xvec[l] = x;
@@ -563,11 +565,8 @@ struct EnvSim {
 #pragma unroll
         for (int k = 0; k < ND; ++k) c[k] = (l < ND && k > l) ? s.Lt[L::lrow(k) + lr] : (Real)0;
 #pragma unroll
-        for (int k = ND - 1; k >= 0; --k) {
-            Real t = x * dinv; Real xk = lane_bcast(t, k);
-            if (l == k) x = t; else if (l < k) x -= c[k] * xk;
-        }
-        return x;
+        for (int k = ND - 1; k >= 0; --k) { const Real xk = lane_bcast(x * dinv, k); x -= c[k] * xk; }     // c[k] = 0 for k <= l
+        return x * dinv;
     }
     // one stage of the transposing wave reduction: N per-lane partial sums -> (N+1)/2, lanes split on bit MASK
     template <int N, int MASK> DM_DEV void tr_stage(Real (&w)[NP2]) {

@@ -271,7 +271,6 @@ struct DuoSim {
         Real* colbuf = &s.f[0][0];                       // 2 blocks x 2 columns x 40 words per character (aliases the dead Newton-Euler sums)
         const Real M = s.sc[7];                          // H_kk, k < 3: total mass (root Kd = 0)
         const Real dinv0 = dm_rsqrt(M);
-        Real dinv = 1;
         sync();                                          // every lane has read what it needs from the aliased region
         Real lik0, lik1;
         // columns k, k+1 (k even) of this lane from the up-to-date pair h2[k/2]; publishes them into buffer (k/2)&1
@@ -279,11 +278,11 @@ struct DuoSim {
         {                                                                                                               \
             const int pk_ = (k) >> 1;                                                                                   \
             const Real inv0_ = ((k) < 3) ? dinv0 : dm_rsqrt(half_bcast_c<(((k) - 3) & 31)>(h2[pk_][0], half));                     \
-            lik0 = h2[pk_][0] * inv0_; h2[pk_][0] = lik0; if (own == (k)) dinv = inv0_;                                  \
+            lik0 = h2[pk_][0] * inv0_; h2[pk_][0] = lik0;                                                               \
             const Real lk1k_ = ((k) + 1 < 3) ? (Real)0 : half_bcast_c<(((k) + 1 - 3) & 31)>(lik0, half);                           \
             h2[pk_][1] -= lik0 * lk1k_;                                                                                 \
             const Real inv1_ = ((k) + 1 < 3) ? dinv0 : dm_rsqrt(half_bcast_c<(((k) + 1 - 3) & 31)>(h2[pk_][1], half));             \
-            lik1 = h2[pk_][1] * inv1_; h2[pk_][1] = lik1; if (own == (k) + 1) dinv = inv1_;                              \
+            lik1 = h2[pk_][1] * inv1_; h2[pk_][1] = lik1;                                                               \
             if ((k) + 2 < ND) {                                                                                         \
                 Real* cb0_ = colbuf + (pk_ & 1) * 80; Real* cb1_ = cb0_ + 40;                                           \
                 if (valid) { cb0_[own] = lik0; cb1_[own] = lik1; }                                                      \
@@ -319,15 +318,15 @@ _Pragma("unroll") \
         DM_DUO_BLOCK(18) DM_DUO_BLOCK(20) DM_DUO_BLOCK(22) DM_DUO_BLOCK(24) DM_DUO_BLOCK(26) DM_DUO_BLOCK(28) DM_DUO_BLOCK(30) DM_DUO_BLOCK(32)
 #undef DM_DUO_BLOCK
 #undef DM_DUO_COLS
+        // the row goes to LDS as it is (L_kk on the diagonal); the lane then reads its own diagonal back, inverts it and puts 1/L_kk into
+        // the slot -- one LDS round trip per factorisation instead of a lane compare + select per column (capture) and per pair (insert)
+        Real dinv = 1;
         if (valid) {
             Real* row = &s.Lt[L::lrow(own)];
 #pragma unroll
-            for (int p = 0; p < NP2; ++p) {
-                R2 v = h2[p];
-                if (own == 2 * p) v[0] = dinv;
-                if (own == 2 * p + 1) v[1] = dinv;
-                if (2 * p <= own) *reinterpret_cast<R2*>(&row[2 * p]) = v;
-            }
+            for (int p = 0; p < NP2; ++p) if (2 * p <= own) *reinterpret_cast<R2*>(&row[2 * p]) = h2[p];
+            dinv = dm_rcp(row[own]);
+            row[own] = dinv;
         } else if (hl == HW - 1) {                       // rows 0..2 of the factor: 1/sqrt(M) on the diagonal, zeros left of it
             Lx(0, 0) = dinv0; Lx(1, 0) = 0; Lx(1, 1) = dinv0; Lx(2, 0) = 0; Lx(2, 1) = 0; Lx(2, 2) = dinv0;
         }

@@ -94,6 +94,7 @@ void orc_get_kin_state(void* h, double* pose, double* vel, double* origin /*3+4*
     origin[3] = s->kin.origin_rot.w; origin[4] = s->kin.origin_rot.x; origin[5] = s->kin.origin_rot.y; origin[6] = s->kin.origin_rot.z;
 }
 void orc_get_tar_pose(void* h, double* out) { copy_out(((Scene*)h)->tar_pose, out); }
+void orc_set_tar_pose(void* h, const double* in) { Scene* s = (Scene*)h; s->tar_pose = copy_in(in, s->sk.P); }
 void orc_get_tau(void* h, double* out) { copy_out(((Scene*)h)->tau, out); }
 void orc_get_contacts(void* h, int* in_contact) { Scene* s = (Scene*)h; for (int j = 0; j < s->sk.J; ++j) in_contact[j] = s->in_contact[j]; }
 int orc_dbg_num_rows(void* h) { return ((Scene*)h)->dbg_num_rows; }
@@ -151,6 +152,146 @@ void orc_pose_to_action(void* h, const double* pose, double* action) {
         } else for (int k = 0; k < s->sk.size(j); ++k) action[ao + k] = pose[off + k];
     }
 }
+
+
+// ---- component exports mirrored by oracle/ref_glue.cpp (same names with the ref_ prefix, same op codes): used by
+// tests/test_oracle_vs_ref.py to hold this restatement against the reference's own compiled sources -------------
+static Q4 qin_(const double* p) { return Q4((real)p[0], (real)p[1], (real)p[2], (real)p[3]); }
+static void qout_(const Q4& q, double* p) { p[0] = q.w; p[1] = q.x; p[2] = q.y; p[3] = q.z; }
+static V3 v3in_(const double* p) { return V3((real)p[0], (real)p[1], (real)p[2]); }
+static void v3out_(const V3& v, double* p) { p[0] = v.x; p[1] = v.y; p[2] = v.z; }
+static void m3out_(const M3& m, double* p) { for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) p[a * 3 + b] = m.m[a][b]; }
+static void xfout_(const Xf& x, double* p) { m3out_(x.R, p); p[9] = x.t.x; p[10] = x.t.y; p[11] = x.t.z; }
+
+int orc_math_op(int op, const double* in, double* out) {
+    switch (op) {
+        case 0: qout_(exp_map_to_quat(v3in_(in)), out); return 4;
+        case 1: v3out_(quat_to_exp_map(qin_(in)), out); return 3;
+        case 2: out[0] = quat_diff_theta(qin_(in), qin_(in + 4)); return 1;
+        case 3: v3out_(quat_vel(qin_(in), qin_(in + 4), (real)in[8]), out); return 3;
+        case 4: v3out_(quat_vel_rel(qin_(in), qin_(in + 4), (real)in[8]), out); return 3;
+        case 5: { Q4 q = qin_(in); v3out_(qrot(q, V3(0, 1, 0)), out); v3out_(qrot(q, V3(1, 0, 0)), out + 3); return 6; }   // as Scene::record_state
+        case 6: out[0] = normalize_angle((real)in[0]); return 1;
+        case 7: qout_(slerp(qin_(in), (real)in[8], qin_(in + 4)), out); return 4;
+        case 8: out[0] = check_next_interval(in[0], in[1], in[2]) ? 1 : 0; return 1;
+        case 9: out[0] = calc_heading(qin_(in)); return 1;
+        case 10: { V3 ax; real th; quat_to_axis_angle(qin_(in), ax, th); v3out_(ax, out); out[3] = th; return 4; }
+        case 11: qout_(quat_axis_angle(v3in_(in), (real)in[3]), out); return 4;
+        case 12: v3out_(qrot(qin_(in), v3in_(in + 4)), out); return 3;
+        case 13: m3out_(rot_quat(qin_(in)), out); return 9;
+        case 14: m3out_(rot_euler(v3in_(in)), out); return 9;
+        case 15: qout_(quat_euler(v3in_(in)), out); return 4;
+        case 16: qout_(standardize(qin_(in)), out); return 4;
+        case 17: qout_(quat_diff(qin_(in), qin_(in + 4)), out); return 4;
+        case 18: m3out_(rot_axis(v3in_(in), (real)in[3]), out); return 9;
+        case 19: qout_(quat_from_rot(rot_quat(qin_(in))), out); return 4;
+        case 20: qout_(quat_axis_angle(V3(0, 1, 0), -calc_heading(qin_(in))), out); return 4;   // KinTree.cpp:1637-1643
+        case 21: {   // cMotion::CalcPhase (Motion.cpp:32-47)
+            double time = in[0], period = in[1], phase_offset = in[2]; bool loop = in[3] != 0;
+            double phase = time / period + phase_offset;
+            if (loop) { phase -= std::floor(phase); } else { phase = std::min(std::max(phase, 0.0), 1.0); }
+            out[0] = phase; return 1;
+        }
+    }
+    return -1;
+}
+
+struct SkelH { Skeleton sk; RBDModel rbd; };
+void* orc_skel_create(const double* jm, const double* bd, int J, const double* gravity) {
+    SkelH* s = new SkelH();
+    s->sk.init(jm, bd, J);
+    RBDOpts o;   // DeepMimic inertias, the reference's own root Cj
+    s->rbd.init(&s->sk, o, V3((real)gravity[0], (real)gravity[1], (real)gravity[2]));
+    return s;
+}
+void orc_skel_destroy(void* h) { delete (SkelH*)h; }
+int orc_skel_num_dof(void* h) { return ((SkelH*)h)->sk.P; }
+void orc_skel_lerp_poses(void* h, const double* p0, const double* p1, double t, double* out) {
+    SkelH* s = (SkelH*)h; Vec o; lerp_poses(s->sk, copy_in(p0, s->sk.P), copy_in(p1, s->sk.P), (real)t, o); copy_out(o, out);
+}
+void orc_skel_calc_vel(void* h, const double* p0, const double* p1, double dt, double* out) {
+    SkelH* s = (SkelH*)h; Vec o; calc_vel(s->sk, copy_in(p0, s->sk.P), copy_in(p1, s->sk.P), (real)dt, o); copy_out(o, out);
+}
+void orc_skel_vel_to_pose_diff(void* h, const double* pose, const double* vel, double* out) {
+    SkelH* s = (SkelH*)h; Vec o; vel_to_pose_diff(s->sk, copy_in(pose, s->sk.P), copy_in(vel, s->sk.P), o); copy_out(o, out);
+}
+void orc_skel_post_process_pose(void* h, double* pose) {
+    SkelH* s = (SkelH*)h; Vec p = copy_in(pose, s->sk.P); post_process_pose(s->sk, p); copy_out(p, pose);
+}
+void orc_skel_pose_errs(void* h, const double* p0, const double* p1, const double* v0, const double* v1, double* out) {
+    SkelH* s = (SkelH*)h; const Skeleton& sk = s->sk;
+    Vec a = copy_in(p0, sk.P), b = copy_in(p1, sk.P), c = copy_in(v0, sk.P), d = copy_in(v1, sk.P);
+    // the per-joint terms exactly as Scene::calc_reward forms them
+    real th = quat_diff_theta(root_rot(a), root_rot(b));
+    out[0] = th * th; out[1] = norm2(root_ang_vel(d) - root_ang_vel(c)); out[2] = 0; out[2 + sk.J] = 0;
+    for (int j = 1; j < sk.J; ++j) {
+        int off = sk.offset(j), sz = sk.size(j); real pe = 0, ve = 0;
+        if (sk.type(j) == JT_SPHERICAL) { real t = quat_theta(quat_diff(joint_quat(a, off), joint_quat(b, off))); pe = t * t; }
+        else for (int k = 0; k < sz; ++k) { real e = b[off + k] - a[off + k]; pe += e * e; }
+        for (int k = 0; k < sz; ++k) { real e = d[off + k] - c[off + k]; ve += e * e; }
+        out[2 + j] = pe; out[2 + sk.J + j] = ve;
+    }
+}
+void orc_skel_world_trans(void* h, const double* pose, double* out_joint, double* out_body) {
+    SkelH* s = (SkelH*)h; const Skeleton& sk = s->sk; Vec p = copy_in(pose, sk.P);
+    for (int j = 0; j < sk.J; ++j) {
+        Xf jw = joint_world_trans(sk, p, j);
+        xfout_(jw, out_joint + 12 * j);
+        if (sk.valid_body(j)) xfout_(jw * body_joint_trans(sk, j), out_body + 12 * j);
+        else for (int k = 0; k < 12; ++k) out_body[12 * j + k] = 0;
+    }
+}
+void orc_skel_link_vel(void* h, const double* pose, const double* vel, double* out) {
+    SkelH* s = (SkelH*)h; std::vector<LinkState> L; calc_links(s->sk, copy_in(pose, s->sk.P), copy_in(vel, s->sk.P), L);
+    for (int j = 0; j < s->sk.J; ++j) {
+        if (s->sk.valid_body(j)) v3out_(L[j].vcom, out + 6 * j); else v3out_(V3(), out + 6 * j);
+        v3out_(L[j].w, out + 6 * j + 3);
+    }
+}
+void orc_skel_mass_bias(void* h, const double* pose, const double* vel, double* H, double* C) {
+    SkelH* s = (SkelH*)h; s->rbd.update(copy_in(pose, s->sk.P), copy_in(vel, s->sk.P));
+    for (size_t i = 0; i < s->rbd.H.size(); ++i) H[i] = (double)s->rbd.H[i];
+    copy_out(s->rbd.C, C);
+}
+void orc_skel_inv_dyna(void* h, const double* pose, const double* vel, const double* acc, double* tau) {
+    SkelH* s = (SkelH*)h; s->rbd.update(copy_in(pose, s->sk.P), copy_in(vel, s->sk.P));
+    Vec t; s->rbd.solve_inv_dyna(copy_in(acc, s->sk.P), t); copy_out(t, tau);
+}
+void orc_skel_com(void* h, const double* pose, const double* vel, double* com, double* com_vel) {
+    SkelH* s = (SkelH*)h; V3 c, v; calc_com(s->sk, copy_in(pose, s->sk.P), copy_in(vel, s->sk.P), c, v); v3out_(c, com); v3out_(v, com_vel);
+}
+void orc_skel_origin_trans(void* h, const double* pose, double* out12) { xfout_(origin_trans(copy_in(pose, ((SkelH*)h)->sk.P)), out12); }
+double orc_skel_total_mass(void* h) { SkelH* s = (SkelH*)h; double m = 0; for (int j = 0; j < s->sk.J; ++j) if (s->sk.valid_body(j)) m += s->sk.mass(j); return m; }
+void orc_skel_inertia(void* h, int j, double* out36) {
+    SM I = ((SkelH*)h)->rbd.moment_inertia(j);
+    for (int a = 0; a < 6; ++a) for (int b = 0; b < 6; ++b) out36[a * 6 + b] = (double)I.m[a][b];
+}
+// unclamped SPD torque (pose layout) for explicit gains: the arithmetic of Scene::calc_spd_tau before the clamp
+void orc_skel_spd_tau(void* h, const double* pose_, const double* vel_, const double* tar_, const double* kp, const double* kd, double dt, double* out) {
+    SkelH* s = (SkelH*)h; const Skeleton& sk = s->sk; const int P = sk.P; real t = (real)dt;
+    Vec rp = copy_in(pose_, P), vel = copy_in(vel_, P), tar = copy_in(tar_, P);
+    s->rbd.update(rp, vel);
+    std::vector<real> M = s->rbd.H;
+    for (int i = 0; i < P; ++i) M[(size_t)i * P + i] += t * (real)kd[i];
+    Vec inc; vel_to_pose_diff(sk, rp, vel, inc);
+    for (int i = 0; i < P; ++i) inc[i] = rp[i] + t * inc[i];
+    post_process_pose(sk, inc);
+    Vec pose_err; calc_vel(sk, inc, tar, 1, pose_err);
+    Vec acc(P, 0);
+    for (int i = 0; i < P; ++i) acc[i] = (real)kp[i] * pose_err[i] + (real)kd[i] * (0 - vel[i]) - s->rbd.C[i];
+    Vec sol; ldlt_solve(M, P, acc, sol);
+    for (int i = 0; i < P; ++i) out[i] = (double)((real)kp[i] * pose_err[i] + (real)kd[i] * ((0 - vel[i]) - t * sol[i]));
+}
+void orc_set_kin_origin(void* h, const double* pos3, const double* rot4) {
+    Scene* s = (Scene*)h; s->kin.origin = v3in_(pos3); s->kin.origin_rot = qin_(rot4);
+}
+void orc_kin_set_time(void* h, double t) { Scene* s = (Scene*)h; s->kin.time = t; s->kin.do_pose(); }
+void orc_kin_set_root_pos(void* h, const double* p3) { ((Scene*)h)->kin.set_root_pos_(v3in_(p3)); }
+void orc_kin_rotate_root(void* h, const double* q4) { ((Scene*)h)->kin.rotate_root(qin_(q4)); }
+void orc_motion_eval(void* h, double t, double* frame, double* vel) {
+    Scene* s = (Scene*)h; Vec f, v; s->mo.calc_frame(s->sk, t, f); s->mo.calc_frame_vel(t, v); copy_out(f, frame); copy_out(v, vel);
+}
+int orc_kin_cycle(void* h, double t) { return ((Scene*)h)->mo.cycle_count(t); }
 
 // Fixed-action rollout used for the CPU baseline: `steps` control steps of `updates_per_step` updates.
 // actions: steps x A (or NULL -> open-loop mocap tracking, stream A1).  Returns wall seconds.

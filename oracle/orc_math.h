@@ -252,9 +252,21 @@ static inline Q4 quat_diff_mul(const Q4& q, const V3& o) {
               (real)0.5 * q.z * o.x + (real)0.5 * q.w * o.y - (real)0.5 * q.x * o.z,
               (real)-0.5 * q.y * o.x + (real)0.5 * q.x * o.y + (real)0.5 * q.w * o.z);
 }
-// cMathUtil::EulerToQuaternion via EulerToAxisAngle -> RotMat -> axis-angle; equal (up to sign)
-// to the quaternion of RotateMat(euler).
-static inline Q4 quat_euler(const V3& e) { return quat_from_rot(rot_euler(e)); }
+// cMathUtil::RotMatToAxisAngle (MathUtil.cpp:272-293): theta = acos((tr - 1) / 2) in [0, pi]
+static inline void rot_to_axis_angle(const M3& a, V3& axis, real& theta) {
+    real c = (a.m[0][0] + a.m[1][1] + a.m[2][2] - 1) * (real)0.5;
+    c = std::min(std::max(c, (real)-1), (real)1);
+    theta = std::acos(c);
+    if (std::fabs(theta) < (real)0.00001) axis = V3(0, 0, 1);
+    else {
+        real m21 = a.m[2][1] - a.m[1][2], m02 = a.m[0][2] - a.m[2][0], m10 = a.m[1][0] - a.m[0][1];
+        real denom = std::sqrt(m21 * m21 + m02 * m02 + m10 * m10);
+        axis = V3(m21 / denom, m02 / denom, m10 / denom);
+    }
+}
+// cMathUtil::EulerToQuaternion (MathUtil.cpp:418-424) = EulerToAxisAngle (RotateMat(euler) -> RotMatToAxisAngle) ->
+// AxisAngleToQuaternion: w = cos(theta/2) >= 0 always (checked against the compiled reference, tests/test_oracle_vs_ref.py)
+static inline Q4 quat_euler(const V3& e) { V3 ax; real th; rot_to_axis_angle(rot_euler(e), ax, th); return quat_axis_angle(ax, th); }
 
 // cMathUtil::CheckNextInterval (MathUtil.cpp:850-857)
 static inline bool check_next_interval(double delta, double curr_val, double int_size) {

@@ -1,0 +1,128 @@
+"""Generate tests/golden/ref_vectors.npz: outputs of the REFERENCE's own compiled sources (oracle/_ref/libdm_ref.so, built
+by oracle/build_ref.sh from the unmodified files under /root/reference/DeepMimicCore) on seeded inputs.
+
+Unlike oracle_rollouts.json (the oracle's own outputs), every array written here is computed by reference code:
+cKinTree / cRBDModel / cRBDUtil / cMathUtil / cKinCharacter / cMotionController / cMotion, plus the four compositions
+in oracle/ref_glue.cpp (SPD torque, imitation reward, state vector, action -> target) that call those functions in the
+order of the reference routine they cite.
+
+The file travels with the repository, so the checks in tests/test_ref_golden.py (oracle vs golden, emulator build of the
+device code vs golden, and -- marked gpu -- the HIP kernels vs golden) run where /root/reference does not exist.
+
+Run from the repo root in a container that has /root/reference:  python tests/golden/make_ref_golden.py"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import ref_lib  # noqa: E402
+from deepmimic_amd import model  # noqa: E402
+from ref_lib import Components, RefKinChar, Skel, random_pose_vel  # noqa: E402
+
+N_STATES = 8
+N_KIN = 16
+SCENES = ["humanoid3d_walk", "dog3d_pace", "humanoid3d_spinkick"]
+
+
+def gains(t):
+    P = t.pose_dim
+    kp, kd = np.zeros(P), np.zeros(P)
+    for j in range(1, t.num_joints):
+        off = int(t.joint_mat[j, model.JD_PARAM_OFFSET])
+        sz = model.joint_param_size(int(t.joint_mat[j, model.JD_TYPE]), False)
+        kp[off:off + sz] = t.pd_params[j, 0]
+        kd[off:off + sz] = t.pd_params[j, 1]
+    return kp, kd
+
+
+def main():
+    ref = Components("ref")
+    out = {}
+    for si, name in enumerate(SCENES):
+        t = model.load_asset(name)
+        sk = Skel(ref, t)
+        kc = RefKinChar(ref, os.path.join("/root/reference", t.cfg.character_file), os.path.join("/root/reference", t.cfg.motion_file))
+        rng = np.random.default_rng(1000 + si)
+        kp, kd = gains(t)
+        w = t.joint_mat[:, model.JD_DIFF_W].copy(); w = w / np.abs(w).sum()
+        P, J = t.pose_dim, t.num_joints
+        flags = int(t.enable_phase_input) | (int(t.record_world_root_pos) << 1) | (int(t.record_world_root_rot) << 2)
+        g = {k: [] for k in ("pose", "vel", "tar", "H", "C", "spd_tau", "joint_world", "body_world", "link_vel", "com", "com_vel",
+                             "kin_time", "kin_origin", "kin_pose", "kin_vel", "reward_terms", "reward", "state", "phase")}
+        for i in range(N_STATES):
+            # kinematic character: a clip time (beyond one cycle for looping clips) and an origin (translation + yaw)
+            tk = rng.uniform(0, 2.6 * kc.duration if kc.loop else 0.95 * kc.duration)
+            yaw = rng.uniform(-np.pi, np.pi) if i % 2 else 0.0
+            opos = np.array([rng.normal() * 2, 0.01 * (i % 3), rng.normal() * 2]) if i else np.zeros(3)
+            orot = np.array([np.cos(yaw / 2), 0.0, np.sin(yaw / 2), 0.0])
+            kc.set_origin(opos, orot)
+            kpose, kvel = kc.eval(tk)
+            # sim state: the kin pose perturbed (so that the reward is informative, not ~0), lifted clear of the ground
+            p, v = kpose.copy(), kvel.copy()
+            p[0:3] += rng.normal(size=3) * 0.04
+            p[1] += 0.25
+            for j in range(0, J):
+                off, ty = int(t.joint_mat[j, model.JD_PARAM_OFFSET]), int(t.joint_mat[j, model.JD_TYPE])
+                if j == 0:
+                    q = p[3:7] + 0.05 * rng.normal(size=4); q /= np.linalg.norm(q); p[3:7] = q if q[0] >= 0 else -q
+                    v[0:6] += rng.normal(size=6) * 0.2
+                elif ty == model.JT_SPHERICAL:
+                    q = p[off:off + 4] + 0.12 * rng.normal(size=4); q /= np.linalg.norm(q); p[off:off + 4] = q if q[0] >= 0 else -q
+                    v[off:off + 3] += rng.normal(size=3) * 0.8
+                elif ty == model.JT_REVOLUTE:
+                    p[off] += 0.1 * rng.normal(); v[off] += rng.normal() * 0.8
+            tar, _ = random_pose_vel(t, rng)
+            tar[:7] = 0
+            H, C = sk.mass_bias(p, v)
+            jw, bw = sk.world_trans(p)
+            com, comv = sk.com(p, v)
+            phase = tk / kc.duration - np.floor(tk / kc.duration)
+            st = np.zeros(t.state_dim)
+            n = ref.lib.ref_record_state(sk.h, ref_lib._d(p), ref_lib._d(v), ref_lib.C.c_double(phase), ref_lib.C.c_double(0.0), flags, ref_lib._d(st))
+            assert n == t.state_dim, (n, t.state_dim)
+            rt = ref_lib.ref_reward_terms(ref, sk, p, v, kpose, kvel, w, 0.0, opos[1])
+            for k, val in (("pose", p), ("vel", v), ("tar", tar), ("H", H), ("C", C), ("spd_tau", sk.spd_tau(p, v, tar, kp, kd, 1 / 600)),
+                           ("joint_world", jw), ("body_world", bw), ("link_vel", sk.link_vel(p, v)), ("com", com), ("com_vel", comv),
+                           ("kin_time", tk), ("kin_origin", np.r_[opos, orot]), ("kin_pose", kpose), ("kin_vel", kvel),
+                           ("reward_terms", rt[:5]), ("reward", rt[5]), ("state", st), ("phase", phase)):
+                g[k].append(np.array(val))
+        for k, val in g.items():
+            out["%s/%s" % (name, k)] = np.array(val)
+        # kinematic character alone: N_KIN times, identity origin -- frames, frame velocities, duration
+        kc.set_origin(np.zeros(3), np.array([1.0, 0, 0, 0]))
+        times = np.r_[0.0, kc.duration, rng.uniform(0, 3.0 * kc.duration if kc.loop else kc.duration, size=N_KIN - 2)]
+        ev = [kc.eval(tt) for tt in times]
+        out["%s/kin_eval_times" % name] = times
+        out["%s/kin_eval_pose" % name] = np.array([e[0] for e in ev])
+        out["%s/kin_eval_vel" % name] = np.array([e[1] for e in ev])
+        fr = [kc.frame(f) for f in range(kc.F)]
+        out["%s/frame_vel" % name] = np.array([f[1] for f in fr])
+        out["%s/frame_time" % name] = np.array([f[2] for f in fr])
+        out["%s/duration" % name] = np.array(kc.duration)
+        out["%s/cycle_root_delta" % name] = kc.cycle_root_delta()
+    # scalar / quaternion functions of cMathUtil on a fixed input set
+    rng = np.random.default_rng(7)
+    ops, ins, outs = [], [], []
+    for _ in range(64):
+        q0 = rng.normal(size=4); q0 /= np.linalg.norm(q0)
+        q1 = rng.normal(size=4); q1 /= np.linalg.norm(q1)
+        e = rng.normal(size=3) * rng.choice([0.1, 1.0, 3.0, 7.0])
+        for op, inp in ((0, e), (1, q0), (2, np.r_[q0, q1]), (3, np.r_[q0, q1, 1 / 30]), (4, np.r_[q0, q1, 1 / 30]), (5, q0),
+                        (7, np.r_[q0, q1, rng.uniform()]), (9, q0), (13, q0), (15, rng.uniform(-3, 3, size=3))):
+            pad = np.zeros(9); pad[:len(inp)] = inp
+            o = ref.math_op(op, inp)
+            po = np.zeros(9); po[:len(o)] = o
+            ops.append(op); ins.append(pad); outs.append(po)
+    out["math/op"] = np.array(ops); out["math/in"] = np.array(ins); out["math/out"] = np.array(outs)
+    path = os.path.join(HERE, "ref_vectors.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, "%.1f KB" % (os.path.getsize(path) / 1024))
+
+
+if __name__ == "__main__":
+    main()

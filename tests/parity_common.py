@@ -265,3 +265,93 @@ def action_rollout_compare(name, precision, lib_path, steps, stream, t0s, wave_p
             ok &= int(out["terminate"][e]) == o.check_terminate() and int(out["valid"][e]) == int(o.check_valid_episode())
     fallen = sum(o.check_terminate() == 1 for o in oracles)
     return dr, ds, ok, fallen
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# Device path vs vectors produced by the REFERENCE's own compiled sources (tests/golden/ref_vectors.npz, generator
+# tests/golden/make_ref_golden.py, library oracle/_ref/libdm_ref.so).  No oracle in the loop.
+_REF_GOLDEN = None
+
+
+def ref_golden():
+    global _REF_GOLDEN
+    if _REF_GOLDEN is None:
+        import os
+        _REF_GOLDEN = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_vectors.npz"))
+    return _REF_GOLDEN
+
+
+def clamp_tau(t, tau_pose):
+    """cSimBodyJoint::ClampTotalTorque on the per-joint vector norm (SimBodyJoint.cpp:299-307); root torque is not applied."""
+    out = tau_pose.copy()
+    out[:7] = 0
+    for j in range(1, t.num_joints):
+        off, ty = int(t.joint_mat[j, model.JD_PARAM_OFFSET]), int(t.joint_mat[j, model.JD_TYPE])
+        lim = t.joint_mat[j, model.JD_TORQUE_LIM]
+        if ty == model.JT_SPHERICAL:
+            mag = np.linalg.norm(out[off:off + 3])
+            if mag > lim:
+                out[off:off + 3] *= lim / mag
+            out[off + 3] = 0
+        elif ty == model.JT_REVOLUTE:
+            if abs(out[off]) > lim:
+                out[off] *= lim / abs(out[off])
+    return out
+
+
+def check_device_vs_ref_golden(name, precision, lib_path, rtol_dyn, rtol_tau, tol_kin, tol_state, tol_terms, tol_reward):
+    """Mass matrix, bias force, SPD torque, kinematic-character sample, link kinematics, state vector, reward terms and reward
+    of the device path against reference-generated vectors.  Returns the worst deviations (for the log)."""
+    g = ref_golden()
+    t = model.load_asset(name)
+    G = lambda k: g["%s/%s" % (name, k)]
+    n = G("pose").shape[0]
+    env = BatchEnv(t, n, precision=precision, lib_path=lib_path)
+    idx = dof_index(t)
+    P, V, T = G("pose"), G("vel"), G("tar")
+    tk = G("kin_time")
+    clocks = np.stack([tk, tk, np.zeros(n), np.zeros(n), np.full(n, np.inf)], axis=1)
+    flags = np.tile(np.array([[1, 0, 1, 1]], dtype=np.int32), (n, 1))
+    env.reset(kin_times=tk, max_times=np.inf)
+    env.set_state(pose=P, vel=V, tar=T, kin=G("kin_origin"), clocks=clocks, flags=flags)
+    worst = {}
+    # a12: H, C of the SPD model
+    env.probe(2, DT)
+    H, C = env.debug("H"), env.debug("C")
+    for e in range(n):
+        Hr, Cr = G("H")[e][np.ix_(idx, idx)], G("C")[e][idx]
+        dh = np.abs(H[e] - Hr).max() / np.abs(Hr).max(); dc = np.abs(C[e] - Cr).max() / max(1.0, np.abs(Cr).max())
+        worst["H"] = max(worst.get("H", 0), dh); worst["C"] = max(worst.get("C", 0), dc)
+        assert dh < rtol_dyn and dc < rtol_dyn, (e, dh, dc)
+    # a11 + a13: SPD torque after the clamp
+    env.set_state(pose=P, vel=V, tar=T)
+    env.probe(0, DT)
+    tau = env.debug("tau")
+    for e in range(n):
+        tr = clamp_tau(t, G("spd_tau")[e])[idx]
+        d = np.abs(tau[e] - tr).max() / max(1.0, np.abs(tr).max())
+        worst["tau"] = max(worst.get("tau", 0), d)
+        assert d < rtol_tau, (e, d)
+    # a5/a6 kin sample, a17 links, a19 state, a18 reward
+    env.set_state(pose=P, vel=V, tar=T, kin=G("kin_origin"), clocks=clocks, flags=flags)
+    q = env.query()
+    kp, kv, links, terms = env.debug("kin_pose"), env.debug("kin_vel"), env.debug("links"), env.debug("reward_terms")
+    for e in range(n):
+        dk = max(np.abs(kp[e] - G("kin_pose")[e]).max(), np.abs(kv[e] - G("kin_vel")[e]).max() / max(1.0, np.abs(G("kin_vel")[e]).max()))
+        worst["kin"] = max(worst.get("kin", 0), dk)
+        assert dk < tol_kin, (e, dk)
+        bw, lv, jw = G("body_world")[e], G("link_vel")[e], G("joint_world")[e]
+        dl = max(np.abs(links[e][:, 0:3] - bw[:, 9:12]).max(), np.abs(links[e][:, 3:12] - bw[:, 0:9]).max(),
+                 np.abs(links[e][:, 18:21] - jw[:, 9:12]).max(),
+                 np.abs(links[e][:, 12:18] - lv).max() / max(1.0, np.abs(lv).max()))
+        worst["links"] = max(worst.get("links", 0), dl)
+        assert dl < tol_kin, (e, dl)
+        ds = np.abs(q["state"][e] - G("state")[e]).max() / max(1.0, np.abs(G("state")[e]).max())
+        worst["state"] = max(worst.get("state", 0), ds)
+        assert ds < tol_state, (e, ds)
+        dt_ = np.abs(terms[e] - G("reward_terms")[e]).max() / max(1.0, np.abs(G("reward_terms")[e]).max())
+        dr = abs(float(q["reward"][e]) - float(G("reward")[e]))
+        worst["terms"] = max(worst.get("terms", 0), dt_); worst["reward"] = max(worst.get("reward", 0), dr)
+        assert dt_ < tol_terms and dr < tol_reward, (e, dt_, dr)
+        assert 0.0 < G("reward")[e] < 1.0
+    return worst

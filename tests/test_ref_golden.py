@@ -1,0 +1,105 @@
+"""Checks against tests/golden/ref_vectors.npz -- outputs of the reference's OWN compiled sources (oracle/_ref, generator
+tests/golden/make_ref_golden.py).  The file is committed, so these run where /root/reference does not exist:
+
+* the oracle restatement vs the golden vectors (CPU),
+* the product's device + host sources in the CPU emulator build vs the golden vectors (CPU; no oracle in the loop),
+* marked gpu: the HIP kernels through the C-ABI vs the golden vectors, fp64 algorithm build and fp32 production build.
+"""
+import numpy as np
+import pytest
+
+import parity_common as pc
+from deepmimic_amd import model
+from oracle_lib import Oracle
+
+SCENES = ["humanoid3d_walk", "dog3d_pace", "humanoid3d_spinkick"]
+
+
+def _G(name, k):
+    return pc.ref_golden()["%s/%s" % (name, k)]
+
+
+def test_golden_file_is_reference_generated():
+    g = pc.ref_golden()
+    for name in SCENES:
+        assert g["%s/pose" % name].shape[0] == 8 and g["%s/H" % name].shape[1] == model.load_asset(name).pose_dim
+    assert g["math/op"].size == 640
+
+
+@pytest.mark.parametrize("name", SCENES)
+def test_oracle_vs_ref_golden(oracle_built, name):
+    """Oracle Scene (the object the GPU parity tests compare with) vs the reference vectors: kin sample, H, C, SPD torque,
+    state vector, reward terms, reward."""
+    t = model.load_asset(name)
+    o = Oracle(t)
+    idx = pc.dof_index(t)
+    n = _G(name, "pose").shape[0]
+    import ctypes as C
+    for e in range(n):
+        tk, org = float(_G(name, "kin_time")[e]), _G(name, "kin_origin")[e]
+        o.reset(tk)
+        o.lib.orc_set_kin_origin(o.h, org[:3].ctypes.data_as(C.POINTER(C.c_double)), np.ascontiguousarray(org[3:]).ctypes.data_as(C.POINTER(C.c_double)))
+        o.lib.orc_kin_set_time(o.h, C.c_double(tk))
+        kp, kv, ko = o.kin_state()
+        assert np.abs(kp - _G(name, "kin_pose")[e]).max() < 1e-12
+        assert np.abs(kv - _G(name, "kin_vel")[e]).max() < 1e-11 * max(1.0, np.abs(kv).max())
+        p, v = _G(name, "pose")[e], _G(name, "vel")[e]
+        o.set_sim_state(p, v)
+        ps, vs = o.sim_state()
+        assert np.abs(ps - p).max() < 1e-15 and np.array_equal(vs, v)      # golden states are already in reported form (up to the renormalisation ulp)
+        H, Cb = o.mass_bias(0, p, v)
+        assert np.abs(H - _G(name, "H")[e]).max() < 1e-12 * np.abs(H).max()
+        assert np.abs(Cb - _G(name, "C")[e]).max() < 1e-12 * max(1.0, np.abs(Cb).max())
+        # SPD torque through the scene path (targets latched, clamp applied)
+        o.lib.orc_set_tar_pose(o.h, np.ascontiguousarray(_G(name, "tar")[e]).ctypes.data_as(C.POINTER(C.c_double)))
+        tau = o.spd_tau(pc.DT)
+        tr = pc.clamp_tau(t, _G(name, "spd_tau")[e])
+        assert np.abs(tau - tr).max() < 1e-10 * max(1.0, np.abs(tr).max())
+        # state vector and reward (ctrl clock = kin time on a fresh reset)
+        st = o.record_state()
+        assert np.abs(st - _G(name, "state")[e]).max() < 1e-11 * max(1.0, np.abs(st).max())
+        r, terms = o.calc_reward_terms()
+        assert np.abs(terms - _G(name, "reward_terms")[e]).max() < 1e-11 * max(1.0, np.abs(terms).max())
+        assert abs(r - float(_G(name, "reward")[e])) < 1e-12
+
+
+def test_oracle_math_vs_ref_golden(oracle_built):
+    import ref_lib
+    orc = ref_lib.Components("orc")
+    g = pc.ref_golden()
+    for op, inp, out in zip(g["math/op"], g["math/in"], g["math/out"]):
+        got = orc.math_op(int(op), inp)
+        tol = 1e-10 if op in (3, 4) else 1e-12
+        assert np.abs(got - out[:len(got)]).max() < tol * max(1.0, np.abs(out).max()), op
+
+
+@pytest.mark.parametrize("name", SCENES)
+def test_emulated_device_vs_ref_golden_fp64(emu_lib, name):
+    w = pc.check_device_vs_ref_golden(name, 64, emu_lib, rtol_dyn=1e-11, rtol_tau=1e-9, tol_kin=1e-11, tol_state=2e-6,
+                                      tol_terms=1e-9, tol_reward=1e-6)   # states / rewards cross the boundary as float32
+    print(name, w)
+
+
+def test_emulated_device_vs_ref_golden_fp32(emu_lib):
+    w = pc.check_device_vs_ref_golden("humanoid3d_walk", 32, emu_lib, rtol_dyn=2e-5, rtol_tau=2e-3, tol_kin=5e-6, tol_state=2e-5,
+                                      tol_terms=2e-4, tol_reward=1e-4)
+    print(w)
+
+
+# ---- the HIP kernels (C-ABI -> libdm_hip.so) vs the reference vectors ------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", SCENES)
+def test_hip_vs_ref_golden_fp64(hip_lib, name):
+    w = pc.check_device_vs_ref_golden(name, 64, hip_lib, rtol_dyn=1e-11, rtol_tau=1e-9, tol_kin=1e-11, tol_state=2e-6,
+                                      tol_terms=1e-9, tol_reward=1e-6)
+    print(name, w)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", SCENES)
+def test_hip_vs_ref_golden_fp32(hip_lib, name):
+    """The production (fp32) kernels against reference fp64 vectors: fixed bounds, no oracle-relative escape hatch.
+    Reward within 1e-4 (BASELINE.json north_star), state vector within 2e-5 relative, SPD torque within 2e-3 relative."""
+    w = pc.check_device_vs_ref_golden(name, 32, hip_lib, rtol_dyn=2e-5, rtol_tau=2e-3, tol_kin=5e-6, tol_state=2e-5,
+                                      tol_terms=2e-4, tol_reward=1e-4)
+    print(name, w)

@@ -55,6 +55,25 @@ static int rt_sync(rt_stream s) { return hipStreamSynchronize(s) == hipSuccess ?
 #define RT_LAUNCH(kern, grid, stream, ...) hipLaunchKernelGGL(kern, dim3((unsigned)(grid)), dim3(64), 0, stream, __VA_ARGS__)
 #endif
 
+// Every C-ABI entry point runs with the ctx's device current (and restores the caller's): a process may hold contexts on
+// several GPUs, or torch may have another device current in this thread.
+#ifdef DM_EMU
+struct DevGuard { explicit DevGuard(int) {} };
+static int launch_status(int rc) { return rc; }
+#else
+struct DevGuard {
+    int prev = -1; bool switched = false;
+    explicit DevGuard(int dev) { if (hipGetDevice(&prev) == hipSuccess && prev != dev) switched = (hipSetDevice(dev) == hipSuccess); }
+    ~DevGuard() { if (switched) (void)hipSetDevice(prev); }
+};
+// a failed launch must not return 0 with stale outputs
+static int launch_status(int rc) {
+    if (rc) return rc;
+    hipError_t le = hipGetLastError();
+    return le == hipSuccess ? 0 : fail(std::string("kernel launch failed: ") + hipGetErrorString(le));
+}
+#endif
+
 // ---------------------------------------------------------------- host-side (double) model description
 enum { JD_TYPE = 0, JD_PARENT, JD_AX, JD_AY, JD_AZ, JD_ATX, JD_ATY, JD_ATZ, JD_LL0, JD_LL1, JD_LL2, JD_LH0, JD_LH1, JD_LH2,
        JD_TORQUE_LIM, JD_FORCE_LIM, JD_IS_EE, JD_DIFF_W, JD_PARAM_OFFSET, JD_MAX };
@@ -250,11 +269,11 @@ static int build_host_model(const dm_scene_tables& t, int max_contacts, HostMode
 
 // ---------------------------------------------------------------- device-side context, typed on the kernel precision
 struct CtxBase {
-    HostModel hm; int N = 0; int env_off = 0; uint64_t seed = 0; int precision = 32; int max_contacts = 20;
+    HostModel hm; int N = 0; int env_off = 0; uint64_t seed = 0; int precision = 32; int max_contacts = 20; int device_id = 0;
     rt_stream own_stream = 0, stream = 0;
     std::vector<void*> allocs;
     float *d_actions = nullptr, *d_states = nullptr, *d_rewards = nullptr; int *d_term = nullptr, *d_valid = nullptr, *d_end = nullptr;
-    bool duo = false;
+    bool duo = false, upload_failed = false;
     virtual ~CtxBase() { for (void* p : allocs) rt_free(p); }
     void* dalloc(size_t n) { void* p = nullptr; if (rt_malloc(&p, n) != 0) return nullptr; allocs.push_back(p); return p; }
     virtual int setup() = 0;
@@ -278,7 +297,7 @@ struct CtxT : CtxBase {
     template <typename T, typename U> const T* up(const std::vector<U>& v) {
         std::vector<T> tmp(v.size()); for (size_t i = 0; i < v.size(); ++i) tmp[i] = (T)v[i];
         void* p = dalloc(sizeof(T) * std::max<size_t>(1, v.size()));
-        if (p && !v.empty()) rt_h2d(p, tmp.data(), sizeof(T) * v.size(), stream);
+        if (!p || (!v.empty() && rt_h2d(p, tmp.data(), sizeof(T) * v.size(), stream) != 0)) upload_failed = true;
         return (const T*)p;
     }
     template <typename C> const uint32_t* build_mdl(int* words) {
@@ -315,7 +334,7 @@ struct CtxT : CtxBase {
         for (int r = 0; r < h.NL; ++r) { int j = h.lim_joint[r]; b->lim_joint[r] = j; b->lim_lo[r] = (Real)h.lim_lo[j]; b->lim_hi[r] = (Real)h.lim_hi[j]; }
         const size_t bytes = (sizeof(*b) + 3) / 4 * 4;
         void* p = dalloc(bytes);
-        if (p) rt_h2d(p, b, sizeof(*b), stream);
+        if (!p || rt_h2d(p, b, sizeof(*b), stream) != 0) upload_failed = true;
         delete b;
         *words = (int)(bytes / 4);
         return (const uint32_t*)p;
@@ -369,11 +388,11 @@ struct CtxT : CtxBase {
         }
         d_actions = (float*)dalloc(sizeof(float) * N * h.A); d_states = (float*)dalloc(sizeof(float) * N * h.S); d_rewards = (float*)dalloc(sizeof(float) * N);
         d_term = (int*)dalloc(sizeof(int) * N); d_valid = (int*)dalloc(sizeof(int) * N); d_end = (int*)dalloc(sizeof(int) * N);
-        if (!st.pose || !st.flag || !d_end || !md.mdl_blob) return fail("device allocation failed");
+        if (!st.pose || !st.flag || !d_end || !md.mdl_blob || upload_failed) return fail("device allocation or table upload failed");
         // PD targets start at identity rotations (cPDController::PostProcessTargetPose, PDController.cpp:425-443)
         std::vector<Real> tar((size_t)N * h.P, 0);
         for (int e = 0; e < N; ++e) for (int j = 1; j < h.J; ++j) if (h.jtype[j] == JT_SPHERICAL) tar[(size_t)e * h.P + h.pose_off[j]] = 1;
-        rt_h2d(st.tar, tar.data(), sizeof(Real) * tar.size(), stream);
+        if (rt_h2d(st.tar, tar.data(), sizeof(Real) * tar.size(), stream) != 0) return fail("table upload failed");
         // RNG streams are keyed by the global env id (shard offset) so they do not depend on the partition
         md.env_off = env_off;
         return 0;
@@ -498,6 +517,7 @@ extern "C" {
 
 const char* dm_last_error(void) { return g_err.c_str(); }
 
+int dm_destroy(dm_ctx* ctx);
 int dm_create(const dm_create_info* info, const dm_scene_tables* tables, dm_ctx** out) {
     if (!info || !tables || !out) return fail("null argument");
     if (info->num_envs < 1) return fail("num_envs must be >= 1");
@@ -511,10 +531,10 @@ int dm_create(const dm_create_info* info, const dm_scene_tables* tables, dm_ctx*
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail("no HIP device available: libdm_hip.so has no CPU fallback");
     if (info->device_id < 0 || info->device_id >= ndev) return fail("invalid device_id");
-    HIPCHK(hipSetDevice(info->device_id));
 #endif
+    DevGuard guard(info->device_id);
     CtxBase* c = (precision == 64) ? (CtxBase*)new CtxT<double>() : (CtxBase*)new CtxT<float>();
-    c->N = info->num_envs; c->seed = info->seed; c->precision = precision; c->max_contacts = mc; c->env_off = info->env_id_offset;
+    c->device_id = info->device_id; c->N = info->num_envs; c->seed = info->seed; c->precision = precision; c->max_contacts = mc; c->env_off = info->env_id_offset;
     if (build_host_model(*tables, mc, c->hm) != 0) { delete c; return -1; }
 #ifndef DM_EMU
     if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) { delete c; return fail("hipStreamCreate failed"); }
@@ -524,12 +544,15 @@ int dm_create(const dm_create_info* info, const dm_scene_tables* tables, dm_ctx*
     // two characters per wavefront is the default for the biped class (step() falls back for odd batches and armed taps)
     { const char* dv = getenv("DM_DUO"); c->duo = info->wave_packing == 2 || (info->wave_packing == 0 && !(dv && dv[0] == '0')); }
     if (c->setup() != 0) { delete c; return -1; }
-    dm_ctx* ctx = new dm_ctx(); ctx->c = c; *out = ctx;
-    return dm_reset(ctx, nullptr, 0, nullptr, nullptr);
+    dm_ctx* ctx = new dm_ctx(); ctx->c = c;
+    if (dm_reset(ctx, nullptr, 0, nullptr, nullptr) != 0) { std::string e = g_err; dm_destroy(ctx); g_err = e; return -1; }
+    *out = ctx;
+    return 0;
 }
 
 int dm_destroy(dm_ctx* ctx) {
     if (!ctx) return 0;
+    DevGuard guard(ctx->c->device_id);
 #ifndef DM_EMU
     if (ctx->c->own_stream) { (void)hipStreamSynchronize(ctx->c->own_stream); (void)hipStreamDestroy(ctx->c->own_stream); }
 #endif
@@ -551,7 +574,7 @@ int dm_set_stream(dm_ctx* ctx, void* hip_stream) {
 #endif
     return 0;
 }
-int dm_synchronize(dm_ctx* ctx) { if (!ctx) return fail("null ctx"); return rt_sync(ctx->c->stream) == 0 ? 0 : fail("stream synchronize failed"); }
+int dm_synchronize(dm_ctx* ctx) { if (!ctx) return fail("null ctx"); DevGuard guard(ctx->c->device_id); return rt_sync(ctx->c->stream) == 0 ? 0 : fail("stream synchronize failed"); }
 
 int dm_set_time_limits(dm_ctx* ctx, double time_lim_min, double time_lim_max) {
     if (!ctx) return fail("null ctx");
@@ -563,42 +586,47 @@ int dm_set_time_limits(dm_ctx* ctx, double time_lim_min, double time_lim_max) {
 int dm_reset(dm_ctx* ctx, const int32_t* env_ids, int n, const double* kin_times, const double* max_times) {
     if (!ctx) return fail("null ctx");
     CtxBase* c = ctx->c;
+    DevGuard guard(c->device_id);
     if (!env_ids) n = c->N;
     if (n <= 0) return 0;
     for (int i = 0; env_ids && i < n; ++i) if (env_ids[i] < 0 || env_ids[i] >= c->N) return fail("env id out of range");
-    int* ids_dev = nullptr; double *kt_dev = nullptr, *mt_dev = nullptr; int rc = 0;
+    int rc = 0;
     void* tmp[3] = {nullptr, nullptr, nullptr};
-    if (env_ids) { rt_malloc(&tmp[0], sizeof(int) * n); rt_h2d(tmp[0], env_ids, sizeof(int) * n, c->stream); ids_dev = (int*)tmp[0]; }
-    if (kin_times) { rt_malloc(&tmp[1], sizeof(double) * n); rt_h2d(tmp[1], kin_times, sizeof(double) * n, c->stream); kt_dev = (double*)tmp[1]; }
-    if (max_times) { rt_malloc(&tmp[2], sizeof(double) * n); rt_h2d(tmp[2], max_times, sizeof(double) * n, c->stream); mt_dev = (double*)tmp[2]; }
-    rc = c->reset(ids_dev, n, kt_dev, mt_dev);
-    rt_sync(c->stream);
+    auto stage = [&](int k, const void* host, size_t bytes) {      // a failed allocation must not reach the kernel as "NULL = all envs"
+        if (!host || rc) return;
+        if (rt_malloc(&tmp[k], bytes) != 0) { tmp[k] = nullptr; rc = fail("device allocation failed"); return; }
+        if (rt_h2d(tmp[k], host, bytes, c->stream) != 0) rc = fail("copy failed");
+    };
+    stage(0, env_ids, sizeof(int) * n); stage(1, kin_times, sizeof(double) * n); stage(2, max_times, sizeof(double) * n);
+    if (!rc) rc = launch_status(c->reset((const int*)tmp[0], n, (const double*)tmp[1], (const double*)tmp[2]));
+    if (rt_sync(c->stream) != 0 && !rc) rc = fail("stream synchronize failed");
     for (void* p : tmp) if (p) rt_free(p);
     return rc;
 }
 
 int dm_set_action(dm_ctx* ctx, const float* actions, int flags) {
     if (!ctx || !actions) return fail("null argument");
-    CtxBase* c = ctx->c;
+    CtxBase* c = ctx->c; DevGuard guard(c->device_id);
     const float* adev = actions;
     if (!(flags & DM_DEVICE_PTRS)) { if (rt_h2d(c->d_actions, actions, sizeof(float) * c->N * c->hm.A, c->stream)) return fail("copy failed"); adev = c->d_actions; }
-    return c->step(adev, 0.0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, DM_NO_EMIT);
+    return launch_status(c->step(adev, 0.0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, DM_NO_EMIT));
 }
 
 int dm_update(dm_ctx* ctx, double timestep, int n_updates) {
     if (!ctx) return fail("null ctx");
     if (n_updates < 1 || !(timestep > 0)) return 0;   // cImpPDController::UpdateControlForce ignores non-positive steps
-    return ctx->c->step(nullptr, timestep, n_updates, nullptr, nullptr, nullptr, nullptr, nullptr, DM_NO_EMIT);
+    DevGuard guard(ctx->c->device_id);
+    return launch_status(ctx->c->step(nullptr, timestep, n_updates, nullptr, nullptr, nullptr, nullptr, nullptr, DM_NO_EMIT));
 }
 
 static int copy_out(CtxBase* c, void* host, const void* dev, size_t bytes) { return (host && rt_d2h(host, dev, bytes, c->stream)) ? fail("copy failed") : 0; }
 
 int dm_query(dm_ctx* ctx, float* states, float* rewards, int32_t* terminate, int32_t* valid, int32_t* episode_end, int32_t* need_new_action, int flags) {
     if (!ctx) return fail("null ctx");
-    CtxBase* c = ctx->c;
-    if (flags & DM_DEVICE_PTRS) { if (c->query(states, rewards, terminate, valid, episode_end)) return -1; }
+    CtxBase* c = ctx->c; DevGuard guard(c->device_id);
+    if (flags & DM_DEVICE_PTRS) { if (launch_status(c->query(states, rewards, terminate, valid, episode_end))) return -1; }
     else {
-        if (c->query(c->d_states, c->d_rewards, c->d_term, c->d_valid, c->d_end)) return -1;
+        if (launch_status(c->query(c->d_states, c->d_rewards, c->d_term, c->d_valid, c->d_end))) return -1;
         if (copy_out(c, states, c->d_states, sizeof(float) * c->N * c->hm.S) || copy_out(c, rewards, c->d_rewards, sizeof(float) * c->N) ||
             copy_out(c, terminate, c->d_term, sizeof(int) * c->N) || copy_out(c, valid, c->d_valid, sizeof(int) * c->N) || copy_out(c, episode_end, c->d_end, sizeof(int) * c->N)) return -1;
     }
@@ -613,11 +641,11 @@ int dm_query(dm_ctx* ctx, float* states, float* rewards, int32_t* terminate, int
 int dm_step_batch(dm_ctx* ctx, const float* actions, double timestep, int n_updates, float* states, float* rewards,
                   int32_t* terminate, int32_t* valid, int32_t* episode_end, int flags) {
     if (!ctx) return fail("null ctx");
-    CtxBase* c = ctx->c;
-    if (flags & DM_DEVICE_PTRS) return c->step(actions, timestep, n_updates, states, rewards, terminate, valid, episode_end, flags);
+    CtxBase* c = ctx->c; DevGuard guard(c->device_id);
+    if (flags & DM_DEVICE_PTRS) return launch_status(c->step(actions, timestep, n_updates, states, rewards, terminate, valid, episode_end, flags));
     const float* adev = nullptr;
     if (actions) { if (rt_h2d(c->d_actions, actions, sizeof(float) * c->N * c->hm.A, c->stream)) return fail("copy failed"); adev = c->d_actions; }
-    if (c->step(adev, timestep, n_updates, c->d_states, c->d_rewards, c->d_term, c->d_valid, c->d_end, flags)) return -1;
+    if (launch_status(c->step(adev, timestep, n_updates, c->d_states, c->d_rewards, c->d_term, c->d_valid, c->d_end, flags))) return -1;
     if (copy_out(c, states, c->d_states, sizeof(float) * c->N * c->hm.S) || copy_out(c, rewards, c->d_rewards, sizeof(float) * c->N) ||
         copy_out(c, terminate, c->d_term, sizeof(int) * c->N) || copy_out(c, valid, c->d_valid, sizeof(int) * c->N) || copy_out(c, episode_end, c->d_end, sizeof(int) * c->N)) return -1;
     return 0;
@@ -627,22 +655,22 @@ int dm_amp_obs_size(const dm_ctx* ctx) { return ctx ? ctx->c->amp_size : 0; }
 
 int dm_query_amp(dm_ctx* ctx, float* amp_obs, int flags) {
     if (!ctx || !amp_obs) return fail("null argument");
-    CtxBase* c = ctx->c;
+    CtxBase* c = ctx->c; DevGuard guard(c->device_id);
     if (!c->amp_size) return fail("AMP observations need a `--scene imitate_amp` context (dm_scene_tables.scene_amp)");
-    if (flags & DM_DEVICE_PTRS) return c->query(nullptr, nullptr, nullptr, nullptr, nullptr, amp_obs);
-    if (c->query(nullptr, nullptr, nullptr, nullptr, nullptr, c->d_amp)) return -1;
+    if (flags & DM_DEVICE_PTRS) return launch_status(c->query(nullptr, nullptr, nullptr, nullptr, nullptr, amp_obs));
+    if (launch_status(c->query(nullptr, nullptr, nullptr, nullptr, nullptr, c->d_amp))) return -1;
     return copy_out(c, amp_obs, c->d_amp, sizeof(float) * (size_t)c->N * c->amp_size);
 }
 
 int dm_step_batch_amp(dm_ctx* ctx, const float* actions, double timestep, int n_updates, float* states, float* rewards,
                       int32_t* terminate, int32_t* valid, int32_t* episode_end, float* amp_obs, int flags) {
     if (!ctx) return fail("null ctx");
-    CtxBase* c = ctx->c;
+    CtxBase* c = ctx->c; DevGuard guard(c->device_id);
     if (amp_obs && !c->amp_size) return fail("AMP observations need a `--scene imitate_amp` context (dm_scene_tables.scene_amp)");
-    if (flags & DM_DEVICE_PTRS) return c->step(actions, timestep, n_updates, states, rewards, terminate, valid, episode_end, flags, amp_obs);
+    if (flags & DM_DEVICE_PTRS) return launch_status(c->step(actions, timestep, n_updates, states, rewards, terminate, valid, episode_end, flags, amp_obs));
     const float* adev = nullptr;
     if (actions) { if (rt_h2d(c->d_actions, actions, sizeof(float) * c->N * c->hm.A, c->stream)) return fail("copy failed"); adev = c->d_actions; }
-    if (c->step(adev, timestep, n_updates, c->d_states, c->d_rewards, c->d_term, c->d_valid, c->d_end, flags, amp_obs ? c->d_amp : nullptr)) return -1;
+    if (launch_status(c->step(adev, timestep, n_updates, c->d_states, c->d_rewards, c->d_term, c->d_valid, c->d_end, flags, amp_obs ? c->d_amp : nullptr))) return -1;
     if (copy_out(c, states, c->d_states, sizeof(float) * c->N * c->hm.S) || copy_out(c, rewards, c->d_rewards, sizeof(float) * c->N) ||
         copy_out(c, terminate, c->d_term, sizeof(int) * c->N) || copy_out(c, valid, c->d_valid, sizeof(int) * c->N) || copy_out(c, episode_end, c->d_end, sizeof(int) * c->N) ||
         copy_out(c, amp_obs, c->d_amp, sizeof(float) * (size_t)c->N * c->amp_size)) return -1;
@@ -651,20 +679,20 @@ int dm_step_batch_amp(dm_ctx* ctx, const float* actions, double timestep, int n_
 
 int dm_amp_expert(dm_ctx* ctx, int n, const double* times, const double* ground_h, float* out, int flags) {
     if (!ctx || !out) return fail("null argument");
-    CtxBase* c = ctx->c;
+    CtxBase* c = ctx->c; DevGuard guard(c->device_id);
     if (!c->amp_size) return fail("AMP observations need a `--scene imitate_amp` context (dm_scene_tables.scene_amp)");
     if (n <= 0) return 0;
     if (flags & DM_DEVICE_PTRS) {
         if (!times) return fail("dm_amp_expert with device pointers needs explicit sample times");
-        return c->amp_expert(n, times, ground_h, out);
+        return launch_status(c->amp_expert(n, times, ground_h, out));
     }
     std::vector<double> t(n);
     if (times) memcpy(t.data(), times, sizeof(double) * n);
     else { for (int i = 0; i < n; ++i) t[i] = c->hm.duration * dm_rand01(c->seed, (uint64_t)c->env_off + 0x414D50ull, c->expert_calls, (uint64_t)i); c->expert_calls++; }
     void *td = nullptr, *gd = nullptr, *od = nullptr; int rc = 0;
     if (rt_malloc(&td, sizeof(double) * n) || rt_malloc(&od, sizeof(float) * (size_t)n * c->amp_size) || (ground_h && rt_malloc(&gd, sizeof(double) * n))) rc = fail("device allocation failed");
-    if (!rc) { rt_h2d(td, t.data(), sizeof(double) * n, c->stream); if (ground_h) rt_h2d(gd, ground_h, sizeof(double) * n, c->stream); }
-    if (!rc) rc = c->amp_expert(n, (const double*)td, (const double*)gd, (float*)od);
+    if (!rc && (rt_h2d(td, t.data(), sizeof(double) * n, c->stream) || (ground_h && rt_h2d(gd, ground_h, sizeof(double) * n, c->stream)))) rc = fail("copy failed");
+    if (!rc) rc = launch_status(c->amp_expert(n, (const double*)td, (const double*)gd, (float*)od));
     if (!rc && rt_d2h(out, od, sizeof(float) * (size_t)n * c->amp_size, c->stream)) rc = fail("copy failed");
     rt_sync(c->stream);
     if (td) rt_free(td); if (gd) rt_free(gd); if (od) rt_free(od);
@@ -686,19 +714,21 @@ int dm_build_offsets_scales(const dm_ctx* ctx, double* s_off, double* s_scale, d
 
 int dm_get_state(dm_ctx* ctx, double* pose, double* vel, double* tar, double* kin, double* clocks, int32_t* flags) {
     if (!ctx) return fail("null ctx");
+    DevGuard guard(ctx->c->device_id);
     return ctx->c->get_state(pose, vel, tar, kin, clocks, flags);
 }
 int dm_set_state(dm_ctx* ctx, const double* pose, const double* vel, const double* tar, const double* kin, const double* clocks, const int32_t* flags) {
     if (!ctx) return fail("null ctx");
+    DevGuard guard(ctx->c->device_id);
     return ctx->c->set_state(pose, vel, tar, kin, clocks, flags);
 }
-int dm_probe(dm_ctx* ctx, int what, double dt) { if (!ctx) return fail("null ctx"); int rc = ctx->c->probe(what, dt); rt_sync(ctx->c->stream); return rc; }
-int dm_set_tau(dm_ctx* ctx, const double* tau) { if (!ctx || !tau) return fail("null argument"); return ctx->c->set_tau(tau); }
-int dm_get_debug(dm_ctx* ctx, const char* name, double* out) { if (!ctx || !name || !out) return fail("null argument"); return ctx->c->get_debug(name, out); }
+int dm_probe(dm_ctx* ctx, int what, double dt) { if (!ctx) return fail("null ctx"); DevGuard guard(ctx->c->device_id); int rc = launch_status(ctx->c->probe(what, dt)); if (rt_sync(ctx->c->stream) != 0 && !rc) rc = fail("stream synchronize failed"); return rc; }
+int dm_set_tau(dm_ctx* ctx, const double* tau) { if (!ctx || !tau) return fail("null argument"); DevGuard guard(ctx->c->device_id); return ctx->c->set_tau(tau); }
+int dm_get_debug(dm_ctx* ctx, const char* name, double* out) { if (!ctx || !name || !out) return fail("null argument"); DevGuard guard(ctx->c->device_id); return ctx->c->get_debug(name, out); }
 
 int dm_bench_rollout(dm_ctx* ctx, int warmup, int steps, double timestep, int n_updates, int flags, float* states_dev, float* rewards_dev, double* elapsed_ms) {
     if (!ctx) return fail("null ctx");
-    CtxBase* c = ctx->c;
+    CtxBase* c = ctx->c; DevGuard guard(c->device_id);
     float* sdev = states_dev ? states_dev : c->d_states; float* rdev = rewards_dev ? rewards_dev : c->d_rewards;
     for (int k = 0; k < warmup; ++k) if (c->step(nullptr, timestep, n_updates, sdev, rdev, c->d_term, c->d_valid, c->d_end, flags)) return -1;
 #ifndef DM_EMU

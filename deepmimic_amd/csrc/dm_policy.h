@@ -124,12 +124,22 @@ __global__ void __launch_bounds__(64) k_policy_layer(PolicyDev p, PolicyIO io) {
     const int n_col_tiles = N / (16 * NT);
     // consecutive workgroups walk down the rows of one column block: they read the same weight fragments back to back
     const int row_blocks = (io.M + 16 * MT - 1) / (16 * MT);
-    const int cb = blockIdx.x / row_blocks, rb = blockIdx.x % row_blocks;
-    if (cb >= n_col_tiles) return;
-    const int row0 = rb * 16 * MT, nt0 = cb * NT, KS = K / 32;
+    // MODE 2 (Gaussian head): one workgroup owns ALL N3 columns of its rows -- the log-probability is a sum over every action
+    // component, so the column blocks are walked inside the workgroup (A = 36 / 58 need two blocks of 32) and logp is written once.
+    const int cb_first = (MODE == 2) ? 0 : (int)blockIdx.x / row_blocks, rb = (MODE == 2) ? (int)blockIdx.x : (int)blockIdx.x % row_blocks;
+    if (cb_first >= n_col_tiles || rb >= row_blocks) return;
+    const int cb_last = (MODE == 2) ? n_col_tiles : cb_first + 1;
+    const int row0 = rb * 16 * MT, KS = K / 32;
     const uint16_t* wp = (MODE == 0) ? p.w1p : (MODE == 1 ? p.w2p : p.w3p);
     const uint16_t* ain = (MODE == 0) ? io.s16 : (MODE == 1 ? io.h1 : io.h2);
+    float lps[MT][4];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) lps[i][r] = 0.0f;
 
+    for (int cb = cb_first; cb < cb_last; ++cb) {
+    const int nt0 = cb * NT;
     f32x4 acc[MT][NT];
 #pragma unroll
     for (int i = 0; i < MT; ++i)
@@ -211,7 +221,19 @@ __global__ void __launch_bounds__(64) k_policy_layer(PolicyDev p, PolicyIO io) {
                         lp += -0.5f * z * z - ls;
                     }
                 }
-                // the 16 lanes of a group hold the 16 columns of one row
+                lps[i][r] += lp;
+            }
+    }
+    }   // column blocks
+
+    if (MODE == 2) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = row0 + 16 * i + 4 * g + r;
+                // the 16 lanes of a group hold 16 columns of one row (per column block); sum them, then the constant once
+                float lp = lps[i][r];
                 lp += lane_xor_f(lp, 1); lp += lane_xor_f(lp, 2); lp += lane_xor_f(lp, 4); lp += lane_xor_f(lp, 8);
                 if (io.logp && c == 0 && row < io.M) io.logp[row] = lp - 0.5f * (float)p.A * 1.8378770664093453f;
             }

@@ -33,8 +33,8 @@ int dm_policy_create(int device_id, const dm_policy_params* pp, dm_policy** out)
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail("no HIP device available: libdm_hip.so has no CPU fallback");
     if (device_id < 0 || device_id >= ndev) return fail("invalid device_id");
-    HIPCHK(hipSetDevice(device_id));
 #endif
+    DevGuard guard(device_id);
     dm_policy* p = new dm_policy(); p->device_id = device_id;
     dmp::PolicyDev& d = p->pd; memset(&d, 0, sizeof(d));
     d.S = pp->state_dim; d.H1 = pp->hidden1; d.H2 = pp->hidden2; d.A = pp->action_dim;
@@ -54,12 +54,13 @@ int dm_policy_create(int device_id, const dm_policy_params* pp, dm_policy** out)
     return 0;
 }
 
-int dm_policy_destroy(dm_policy* p) { delete p; return 0; }
+int dm_policy_destroy(dm_policy* p) { if (!p) return 0; DevGuard guard(p->device_id); delete p; return 0; }
 
 int dm_policy_forward(dm_policy* p, const float* states_dev, int n, float* actions_dev, float* logp_dev, int sample,
                       uint64_t seed, uint32_t step, int env_id_offset, void* hip_stream) {
     if (!p || !states_dev || !actions_dev) return fail("null argument");
     if (n <= 0) return 0;
+    DevGuard guard(p->device_id);
     rt_stream stream = (rt_stream)hip_stream;
     if (n > p->cap) {                       // hidden activations: n x (H1 + H2) bf16, grown on demand
         rt_sync(stream);
@@ -76,7 +77,7 @@ int dm_policy_forward(dm_policy* p, const float* states_dev, int n, float* actio
     RT_LAUNCH(dmp::k_policy_prep, n, stream, d, io);
     RT_LAUNCH((dmp::k_policy_layer<0, 4, 4>), ((n + 63) / 64) * (d.H1 / 64), stream, d, io);
     RT_LAUNCH((dmp::k_policy_layer<1, 2, 4>), ((n + 31) / 32) * (d.H2 / 64), stream, d, io);
-    RT_LAUNCH((dmp::k_policy_layer<2, 1, 2>), ((n + 15) / 16) * (d.N3 / 32), stream, d, io);
+    RT_LAUNCH((dmp::k_policy_layer<2, 1, 2>), (n + 15) / 16, stream, d, io);   // one workgroup per 16 rows owns all N3 columns (logp is a row sum)
 #ifndef DM_EMU
     hipError_t le = hipGetLastError(); if (le != hipSuccess) return fail(std::string("kernel launch failed: ") + hipGetErrorString(le));
 #endif

@@ -47,6 +47,25 @@ def test_policy_emulator_sampling_uses_the_philox_stream(emu_lib):
     assert np.allclose(lp, (-0.5 * z ** 2 - w["logstd"]).sum(1) - 0.5 * A * np.log(2 * np.pi), atol=2e-3)
 
 
+def test_policy_emulator_logp_more_than_32_actions(emu_lib):
+    """A = 36 (humanoid with spherical hips as 4-vectors) / 58 (dog): the Gaussian head spans two 32-column blocks; logp must be the
+    sum over ALL action components (a per-block partial sum used to win a last-writer race)."""
+    for A in (36, 58):
+        S, H1, H2 = 40, 64, 64
+        w = make(S, A, H1, H2, 9, with_norm=False)
+        w["logstd"] = np.random.default_rng(3).normal(size=A).astype(np.float32) * 0.3 - 1.0
+        pol = Policy(w, lib_path=emu_lib)
+        s = np.random.default_rng(4).normal(size=(19, S)).astype(np.float32)
+        a0, lp0 = pol.forward_host(s)
+        assert np.allclose(lp0, -w["logstd"].sum() - 0.5 * A * np.log(2 * np.pi), atol=1e-4)
+        a1, lp = pol.forward_host(s, sample=True, seed=11, step=2, env_id_offset=7)
+        z = (a1 - a0) / np.exp(w["logstd"])
+        assert np.abs(z).max() > 0.5                                     # noise reached every block
+        assert np.abs(z[:, 32:]).max() > 0.5
+        want = (-0.5 * z ** 2 - w["logstd"]).sum(1) - 0.5 * A * np.log(2 * np.pi)
+        assert np.abs(lp - want).max() < 5e-3, (A, np.abs(lp - want).max())
+
+
 def test_policy_rejects_bad_shapes(emu_lib):
     w = random_weights(10, 4, 96, 64)
     with pytest.raises(RuntimeError, match="multiples of 64"):
@@ -76,6 +95,8 @@ def test_policy_gpu_matches_reference(hip_lib, S, A, n):
     h = torch.relu(x @ tw["w1"] + tw["b1"]); h = torch.relu(h @ tw["w2"] + tw["b2"])
     ref = (h @ tw["w3"] + tw["b3"]) * tw["a_std"] + tw["a_mean"]
     assert (ta - ref).abs().max().item() < 2e-2 * scale
+    # mode: logp is the constant -sum(logstd) - A/2 log(2 pi) for every row
+    assert np.allclose(tl.cpu().numpy(), -w["logstd"].sum() - 0.5 * A * np.log(2 * np.pi), atol=1e-4)
     # sampled actions: noise stream reproducible on the host
     pol.forward_device(ts.data_ptr(), n, ta.data_ptr(), tl.data_ptr(), sample=True, seed=7, step=9, env_id_offset=5,
                        stream=torch.cuda.current_stream().cuda_stream)
@@ -84,6 +105,9 @@ def test_policy_gpu_matches_reference(hip_lib, S, A, n):
     ids = 5 + np.arange(n)
     ctr_key = streams.normal_noise(ids - 0xD33B + 7, 9, A, sigma=1.0)      # streams keys with 0xD33B + id; the kernel with seed + id
     assert np.abs(z - ctr_key).max() < 5e-3
+    # sampled logp over ALL A components (A = 36 and 58 span two column blocks of the head)
+    want_lp = (-0.5 * z.astype(np.float64) ** 2 - w["logstd"]).sum(1) - 0.5 * A * np.log(2 * np.pi)
+    assert np.abs(tl.cpu().numpy() - want_lp).max() < 2e-2 * max(1.0, np.abs(want_lp).max() / 10), np.abs(tl.cpu().numpy() - want_lp).max()
 
 
 @pytest.mark.gpu

@@ -32,41 +32,74 @@ def algorithmic_bytes_per_env_step(env):
 
 
 def measured_traffic(scene, n, kernel=None):
-    """HBM bytes per k_env_step launch from the committed rocprofv3 PMC passes (profiles/r01_traffic.json, collected
-    as MI355X_MICROARCH.md prescribes: separate --pmc passes for FETCH_SIZE and WRITE_SIZE); None when no profile of this
-    workload is committed."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
-            t = json.load(f)
-        if t.get("scene") == scene and int(t.get("envs", -1)) == n and (kernel is None or t.get("kernel", kernel) == kernel):
-            return float(t["hbm_bytes_per_launch"])
-    except Exception:
-        pass
+    """HBM bytes per step-kernel launch from the committed rocprofv3 PMC passes (profiles/r0N_traffic*.json, collected as
+    MI355X_MICROARCH.md prescribes: separate --pmc passes for FETCH_SIZE and WRITE_SIZE; tools/collect_profiles.py), newest
+    round first; None when no profile of this workload is committed."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic*.json")), reverse=True):
+        try:
+            with open(path) as f:
+                t = json.load(f)
+            if t.get("scene") == scene and int(t.get("envs", -1)) == n and (kernel is None or t.get("kernel", kernel) == kernel):
+                return float(t["hbm_bytes_per_launch"])
+        except Exception:
+            continue
     return None
 
 
-def cpu_baseline(tables, budget_s=12.0):
-    """Times the CPU oracle (restatement of the reference path; real DeepMimicCore/Bullet is not buildable here)
-    on this host, single thread, same workload per env: 300-step open-loop rollouts of one humanoid."""
+def timer_limits_of(tables, test_mode=True):
+    c = tables.cfg
+    tmin, tmax = float(c.time_lim_min), float(c.time_lim_max)
+    if test_mode and c.time_end_lim_max is not None:
+        tmin = tmax = float(c.time_end_lim_max)
+    return tmin, tmax
+
+
+def cpu_baseline_worker(scene, env_id, budget_s):
+    """One process of the CPU baseline (no torch, no HIP): the oracle on bench.py's own workload -- open-loop tracking with
+    auto-reset, start phase and reset draws keyed like the GPU run's env `env_id`.  Prints one JSON line."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib
+    from deepmimic_amd import model, streams
+    tables = model.load_asset(scene)
     try:
-        import oracle_lib
-        try:
-            oracle_lib.build("native")
-            variant = "native"
-        except Exception:
-            variant = ""
-        o = oracle_lib.Oracle(tables, variant=variant)
-        o.reset(0.0)
-        o.rollout(30)                                  # warm-up
-        steps, secs = 0, 0.0
-        while secs < budget_s:
-            o.reset(0.0)
-            s, _, _ = o.rollout(300)
-            steps += 300; secs += s
-        return {"value": steps / secs, "unit": "env-steps/s", "cores": 1, "kind": "port",
-                "sample": "%d control steps (x20 updates) of 1 env, 300-step open-loop rollouts from t0=0, oracle "
-                          "built -O3%s, single thread" % (steps, " -march=native" if variant else "")}
+        oracle_lib.build("native"); variant = "native"
+    except Exception:
+        variant = ""
+    o = oracle_lib.Oracle(tables, variant=variant)
+    tmin, tmax = timer_limits_of(tables)
+    t0 = float(streams.reset_phase(np.array([env_id]), o.duration)[0])
+    o.rollout_auto_reset(30, 1234, env_id, t0, tmin, tmax)      # warm-up
+    steps, secs, resets, live = 0, 0.0, 0, 0
+    while secs < budget_s:
+        s, r, _, lv = o.rollout_auto_reset(300, 1234, env_id, t0, tmin, tmax)
+        steps += 300; secs += s; resets += r; live += lv
+    print(json.dumps({"steps": steps, "secs": secs, "resets": resets, "live": live, "native": bool(variant)}))
+
+
+def cpu_baseline(scene, budget_s=12.0):
+    """The CPU path timed beside the GPU line on this host: the oracle restatement (kind "port"; DeepMimicCore + Bullet is
+    not buildable here) on the SAME workload -- open-loop tracking with auto-reset -- as (a) one process and (b) one process per
+    host core, each an independent env (the reference scales by processes: mpi_run.py).  `value`/`cores` are the all-core figures;
+    the single-process rate is reported next to them."""
+    import subprocess
+
+    def run(nproc):
+        procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", str(i), "--scene", scene,
+                                   "--cpu-budget", str(budget_s)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+                 for i in range(nproc)]
+        res = [json.loads(p.communicate(timeout=20 * budget_s + 120)[0].strip().splitlines()[-1]) for p in procs]
+        return sum(r["steps"] / r["secs"] for r in res), res
+
+    try:
+        cores = os.cpu_count() or 1
+        one, r1 = run(1)
+        allc, rn = run(cores) if cores > 1 else (one, r1)
+        live = sum(r["live"] for r in rn) / max(1, sum(r["steps"] for r in rn))
+        return {"value": allc, "unit": "env-steps/s", "cores": cores, "kind": "port", "single_core_value": one,
+                "sample": "%d independent processes x %.0f s of 300-step open-loop rollouts WITH auto-reset (same episode mixture as the "
+                          "GPU line: %.0f %% of the steps live, %d resets), oracle built -O3%s; single process: %.1f env-steps/s"
+                          % (cores, budget_s, 100 * live, sum(r["resets"] for r in rn), " -march=native" if rn[0]["native"] else "", one)}
     except Exception as ex:  # the baseline is reported, never required
         return {"value": None, "unit": "env-steps/s", "cores": 1, "kind": "port", "sample": "failed: %r" % (ex,)}
 
@@ -83,7 +116,15 @@ def main():
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--force-gather", action="store_true", help="exercise the record exchange even with one rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-worker", type=int, default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-budget", type=float, default=12.0, help=argparse.SUPPRESS)
+    ap.add_argument("--min-warmup", type=int, default=60,
+                    help="control steps run before the timed region regardless of --warmup: the first episodes of a fresh batch are a "
+                         "lighter mixture than steady state (nobody has fallen yet); two episode lengths reach it")
     args = ap.parse_args()
+    if args.cpu_baseline_worker is not None:
+        cpu_baseline_worker(args.scene, args.cpu_baseline_worker, args.cpu_budget)
+        return
 
     import torch
     import torch.distributed as dist
@@ -130,7 +171,8 @@ def main():
         if gather:
             ex.wait(0); ex.wait(1)
 
-    for _ in range(args.warmup):
+    warm = max(args.warmup, args.min_warmup)
+    for _ in range(warm):
         one_step()
     drain()
     torch.cuda.synchronize()
@@ -170,7 +212,7 @@ def main():
             "vs_baseline": None, "dtype": "f32" if args.precision == 32 else "f64", "data": "synthetic",
             "config": {"workload": "%s, %d envs per GPU, fixed-action (open-loop mocap tracking) rollout, auto-reset, "
                                    "20 updates of 1/600 s x 2 substeps per step" % (args.scene, n),
-                       "envs_per_gpu": n, "wave_packing": args.wave_packing, "parallelism": "env-shards x%d%s" % (world, " + async RCCL all-gather of the record, overlapped with the next step" if gather else "")},
+                       "envs_per_gpu": n, "wave_packing": args.wave_packing, "warmup_steps_run": warm, "parallelism": "env-shards x%d%s" % (world, " + async RCCL all-gather of the record, overlapped with the next step" if gather else "")},
             "sim_updates_per_s": value * 20,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": measured_traffic(args.scene, n, kname), "kernel": kname, "kernel_ms": kernel_ms,
@@ -182,7 +224,7 @@ def main():
             "checks": {"mean_reward": mean_reward, "finite": finite},
         }
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(tables)
+            out["cpu_baseline"] = cpu_baseline(args.scene, args.cpu_budget)
         else:
             out["cpu_baseline"] = {"value": None, "unit": "env-steps/s", "cores": 1, "kind": "port", "sample": "skipped (N>1 or --no-cpu-baseline)"}
         print(json.dumps(out))

@@ -103,3 +103,18 @@ def pose_to_action(tables, pose):
         elif ty == model.JT_REVOLUTE:
             out.append(pose[off])
     return np.array(out)
+
+
+_MASK64 = (1 << 64) - 1
+
+
+def reset_rand01(seed: int, env: int, episode: int, stream: int) -> float:
+    """Host mirror of the device's reset generator `dm_rand01` (dm_device.h): splitmix64 of (seed, global env id, episode
+    counter, stream) -> uniform in [0, 1).  stream 0 draws the clip time of a reset (cSceneImitate::CalcRandKinResetTime,
+    scenes/SceneImitate.cpp:494-500, which the reference draws from its process-global RNG), stream 1 the episode-timer limit.
+    Lets a caller (or the oracle in the parity tests) reproduce every auto-reset of a batched rollout."""
+    z = (seed + 0x9E3779B97F4A7C15 * ((env * 0x100000001B3 + episode * 0xD6E8FEB86659FD93 + stream + 1) & _MASK64)) & _MASK64
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & _MASK64
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & _MASK64
+    z = z ^ (z >> 31)
+    return float(z >> 11) * (1.0 / 9007199254740992.0)

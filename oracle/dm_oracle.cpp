@@ -8,6 +8,7 @@
 // "parity unpinned" against real Bullet (no reference tests or golden vectors exist).
 #include "orc_scene.h"
 #include <chrono>
+#include <cstdint>
 
 using namespace orc;
 
@@ -308,6 +309,36 @@ double orc_rollout(void* h, int steps, int updates_per_step, double dt, const do
     }
     auto t1 = std::chrono::steady_clock::now();
     return std::chrono::duration<double>(t1 - t0).count();
+}
+
+// Counter-based reset draws of the device path (dm_rand01 in deepmimic_amd/csrc/dm_device.h, host mirror
+// deepmimic_amd/streams.py reset_rand01): splitmix64 of (seed, global env id, episode, stream)
+static double rand01_(uint64_t seed, uint64_t env, uint64_t episode, uint64_t stream) {
+    uint64_t z = seed + 0x9E3779B97F4A7C15ull * (env * 0x100000001B3ull + episode * 0xD6E8FEB86659FD93ull + stream + 1);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; z = z ^ (z >> 31);
+    return (double)(z >> 11) * (1.0 / 9007199254740992.0);
+}
+// The throughput workload of bench.py on the CPU: open-loop tracking WITH auto-reset (an env whose episode ended -- fall, motion
+// end, timer -- restarts at a drawn clip time), the same episode mixture the GPU line runs.  Returns wall seconds;
+// stats[0] = resets, stats[1] = reward sum, stats[2] = live steps.
+double orc_rollout_auto_reset(void* h, int steps, int updates_per_step, double dt, uint64_t seed, int env_id, double t0,
+                              double time_lim_min, double time_lim_max, double* stats) {
+    Scene* s = (Scene*)h;
+    std::vector<double> a(s->A, 0.0), kp(s->sk.P), kv(s->sk.P);
+    uint64_t ep = 0; double resets = 0, rsum = 0, live = 0;
+    auto draw_timer = [&](uint64_t e) { return (time_lim_max > time_lim_min) ? time_lim_min + (time_lim_max - time_lim_min) * rand01_(seed, (uint64_t)env_id, e, 1) : time_lim_max; };
+    s->reset(t0, draw_timer(ep)); ++ep;
+    auto t_beg = std::chrono::steady_clock::now();
+    for (int k = 0; k < steps; ++k) {
+        orc_kin_eval(h, s->kin.time, kp.data(), kv.data()); orc_pose_to_action(h, kp.data(), a.data()); s->set_action(a.data());
+        for (int u = 0; u < updates_per_step; ++u) s->update(dt);
+        double r = s->calc_reward(); rsum += r; live += (r != 0.0);
+        double st[512]; s->record_state(st);
+        if (s->is_episode_end()) { s->reset(s->mo.duration() * rand01_(seed, (uint64_t)env_id, ep, 0), draw_timer(ep)); ++ep; resets += 1; }
+    }
+    auto t_end = std::chrono::steady_clock::now();
+    if (stats) { stats[0] = resets; stats[1] = rsum; stats[2] = live; }
+    return std::chrono::duration<double>(t_end - t_beg).count();
 }
 
 }  // extern "C"

@@ -33,7 +33,7 @@ def load_lib(variant=""):
     lib = C.CDLL(path)
     lib.orc_create.restype = C.c_void_p
     for f in ("orc_motion_duration", "orc_calc_reward", "orc_calc_reward_terms", "orc_time", "orc_kin_time",
-              "orc_phase", "orc_rollout"):
+              "orc_phase", "orc_rollout", "orc_rollout_auto_reset"):
         getattr(lib, f).restype = C.c_double
     return lib
 
@@ -250,3 +250,10 @@ class Oracle:
         secs = self.lib.orc_rollout(self.h, steps, updates_per_step, C.c_double(dt), ap, _d(rewards),
                                     _d(states) if want_states else None)
         return secs, rewards, states
+
+    def rollout_auto_reset(self, steps, seed, env_id, t0, time_lim_min=np.inf, time_lim_max=np.inf, updates_per_step=20, dt=1.0 / 600):
+        """open-loop tracking with auto-reset (bench.py's workload); returns (seconds, resets, reward sum, live steps)"""
+        stats = np.zeros(3)
+        secs = self.lib.orc_rollout_auto_reset(self.h, int(steps), int(updates_per_step), C.c_double(dt), C.c_uint64(int(seed)), int(env_id),
+                                               C.c_double(t0), C.c_double(time_lim_min), C.c_double(time_lim_max), _d(stats))
+        return secs, int(stats[0]), float(stats[1]), int(stats[2])

@@ -355,3 +355,92 @@ def check_device_vs_ref_golden(name, precision, lib_path, rtol_dyn, rtol_tau, to
         assert dt_ < tol_terms and dr < tol_reward, (e, dt_, dr)
         assert 0.0 < G("reward")[e] < 1.0
     return worst
+
+
+def auto_reset_rollout_compare(name, precision, lib_path, steps, n, seed, wave_packing=0, time_lim=np.inf):
+    """Free-running open-loop rollout THROUGH auto-resets: the oracle mirrors every reset of the device with the same
+    counter-based draw (streams.reset_rand01), so all `steps` control steps of every env are live transitions (a fallen
+    character is reset instead of lying on the ground with reward 0).  Returns per (step, env) arrays: |reward diff|,
+    max |state diff| (relative to max(1, |state|)), alive mask (the oracle's reward is non-zero), number of resets, flags ok."""
+    from deepmimic_amd import streams
+    t = model.load_asset(name)
+    if np.isfinite(time_lim):
+        t.cfg.time_lim_min = t.cfg.time_lim_max = float(time_lim)
+    env = BatchEnv(t, n, precision=precision, lib_path=lib_path, wave_packing=wave_packing, seed=seed)
+    env.reset()
+    ep = env.get_state()["flags"][:, 2].astype(np.int64)        # episode counter the NEXT reset will draw with
+    tmin, tmax = float(t.cfg.time_lim_min), float(t.cfg.time_lim_max)
+
+    def draw(e, episode):     # (clip time, episode-timer limit) of a reset, as k_env_step / k_env_reset draw them
+        mt = tmin + (tmax - tmin) * streams.reset_rand01(seed, e, episode, 1) if tmax > tmin else tmax
+        return streams.reset_rand01(seed, e, episode, 0), mt
+
+    oracles = []
+    for e in range(n):
+        o = Oracle(t)
+        u, mt = draw(e, int(ep[e]) - 1)
+        o.reset(o.duration * u, mt)
+        oracles.append(o)
+    st0 = env.get_state()
+    for e, o in enumerate(oracles):
+        assert abs(st0["clocks"][e][0] - o.kin_time()) < 1e-12, "reset draw mismatch"
+    dr, ds, alive = np.zeros((steps, n)), np.zeros((steps, n)), np.zeros((steps, n), dtype=bool)
+    resets, ok = 0, True
+    for k in range(steps):
+        out = env.step(None, DT, 20, open_loop=True, auto_reset=True)
+        for e, o in enumerate(oracles):
+            kp, _, _ = o.kin_state()
+            o.set_action(o.pose_to_action(kp))
+            for u in range(20):
+                o.update(DT)
+            r = o.calc_reward()
+            dr[k, e] = abs(float(out["reward"][e]) - r)
+            alive[k, e] = r != 0.0
+            term, end = o.check_terminate(), o.is_episode_end()
+            ok &= int(out["terminate"][e]) == term and bool(out["episode_end"][e]) == end and int(out["valid"][e]) == int(o.check_valid_episode())
+            if end:       # the device resets after writing reward / flags; its observation is the first of the new episode
+                u, mt = draw(e, int(ep[e]))
+                o.reset(o.duration * u, mt)
+                ep[e] += 1; resets += 1
+            so = o.record_state()
+            ds[k, e] = np.abs(out["state"][e] - so).max() / max(1.0, np.abs(so).max())
+    return dr, ds, alive, resets, ok
+
+
+def stepwise_live_compare(name, precision, lib_path, steps, n, seed, wave_packing=0):
+    """Teacher-forced, live steps only: `n` oracles free-run through their own resets (clip time drawn with
+    streams.reset_rand01; an episode ends on fall / motion end / timer); before every control step the device envs are set to the
+    oracles' states, so each of the steps x n comparisons checks ONE control step (20 updates, 40 substeps) from identical inputs,
+    and none of them is the vacuous reward-0 of a character lying on the ground.
+    Returns |reward diff|, relative max |state diff|, alive mask (steps x n) and whether all flags agreed."""
+    from deepmimic_amd import streams
+    t = model.load_asset(name)
+    env = BatchEnv(t, n, precision=precision, lib_path=lib_path, wave_packing=wave_packing, seed=seed)
+    oracles, ep = [], np.zeros(n, dtype=np.int64)
+    for e in range(n):
+        o = Oracle(t); o.reset(o.duration * streams.reset_rand01(seed, e, 0, 0)); oracles.append(o)
+    env.reset(kin_times=[o.kin_time() for o in oracles], max_times=np.inf)
+    dr, ds, alive, ok = np.zeros((steps, n)), np.zeros((steps, n)), np.zeros((steps, n), dtype=bool), True
+    for k in range(steps):
+        P, V, T, K, CL, FL = [], [], [], [], [], []
+        for o in oracles:
+            kp, kv, ko = o.kin_state()
+            o.set_action(o.pose_to_action(kp))
+            p, v = o.sim_state()
+            cm = int(sum(int(c) << j for j, c in enumerate(o.contacts())))
+            P.append(p); V.append(v); T.append(o.tar_pose()); K.append(ko)
+            CL.append([o.kin_time(), o.kin_time(), 0.0, o.time(), np.inf]); FL.append([int(o.need_new_action()), cm, 1, 1])
+        env.set_state(pose=np.array(P), vel=np.array(V), tar=np.array(T), kin=np.array(K), clocks=np.array(CL), flags=np.array(FL, dtype=np.int32))
+        out = env.step(None, DT, 20)
+        for e, o in enumerate(oracles):
+            for u in range(20):
+                o.update(DT)
+            r = o.calc_reward()
+            dr[k, e] = abs(float(out["reward"][e]) - r); alive[k, e] = r != 0.0
+            so = o.record_state()
+            ds[k, e] = np.abs(out["state"][e] - so).max() / max(1.0, np.abs(so).max())
+            ok &= int(out["terminate"][e]) == o.check_terminate() and int(out["valid"][e]) == int(o.check_valid_episode())
+            if o.check_terminate() != 0:
+                ep[e] += 1
+                o.reset(o.duration * streams.reset_rand01(seed, e, int(ep[e]), 0))
+    return dr, ds, alive, ok

@@ -114,3 +114,11 @@ def test_action_streams_fp64(emu_lib, stream, steps):
 def test_action_stream_a2_duo_fp64(emu_lib):
     dr, ds, ok, _ = pc.action_rollout_compare("humanoid3d_walk", 64, emu_lib, 2, "A2", [0.0, 0.37], wave_packing=2)
     assert ok and dr.max() < 1e-6 and ds.max() < 1e-5, (dr, ds)
+
+
+def test_auto_reset_mirrored_by_oracle(emu_lib):
+    """rollout through auto-resets with the oracle replaying the device's reset draws: a finite episode timer (row a3) ends
+    episodes every 6 control steps here, so several resets happen inside the window"""
+    dr, ds, alive, resets, ok = pc.auto_reset_rollout_compare("humanoid3d_walk", 64, emu_lib, steps=14, n=2, seed=5, time_lim=0.2)
+    assert ok and resets >= 4
+    assert alive.all() and dr.max() < 1e-6 and ds.max() < 1e-5

@@ -51,17 +51,58 @@ def test_rollout_fp64_300_steps(hip_lib, name):
     assert dr.max() < 1e-5, dr.max()          # rewards cross the boundary as float32
 
 
-@pytest.mark.parametrize("name", ["humanoid3d_walk", "dog3d_pace"])
-def test_rollout_fp32_300_steps_reward_tolerance(hip_lib, name):
-    """fp32 production kernel vs the fp64 oracle over the free-running 300-step rollout (BASELINE metric: reward MAE).
+# ---- The BASELINE.json parity metric, measured so that it means something ------------------------------
+# All bounds below are FIXED numbers (no bound derived from the float build of the oracle).  They are the tolerances DESIGN.md
+# section 7 states; measured values (profiles/r02_parity_report.json) are quoted next to each.
+#
+# "live" = the oracle's reward is non-zero, i.e. the character has not fallen: a fallen character has reward 0 on both sides
+# by definition, which would dilute every mean.
 
-    MAE must be far inside 1e-4.  The worst single step is bounded by the fp32 noise floor of the algorithm itself: the
-    float build of the oracle, free-running, is already 7.5e-5 away from the fp64 oracle at walk step 12 (the step before
-    the open-loop character falls), so the kernel is held to max(1e-4, 4 x that floor)."""
-    dr, ds, ok = pc.rollout_compare(name, 32, hip_lib, steps=300)
-    floor = pc.fp32_free_running_sensitivity(name, 40).max()
-    assert ok and dr.mean() < 1e-5, (dr.mean(), dr.max())
-    assert dr.max() < max(1e-4, 4 * floor), (dr.mean(), dr.max(), floor)
+LIVE_CASES = [("humanoid3d_walk", 64, 0), ("humanoid3d_walk", 32, 2), ("humanoid3d_walk", 32, 1),
+              ("humanoid3d_spinkick", 64, 0), ("humanoid3d_spinkick", 32, 2), ("dog3d_pace", 64, 0), ("dog3d_pace", 32, 0)]
+
+
+@pytest.mark.parametrize("name,prec,pack", LIVE_CASES)
+def test_rollout_300_steps_live_through_resets(hip_lib, name, prec, pack):
+    """config 1 of BASELINE.json made informative: 300 control steps x 8 envs, free-running open-loop tracking THROUGH
+    auto-resets which the oracle mirrors draw for draw (falls, motion end and the finite episode timers of the dog / spinkick
+    arg files -- row a3), so > 95 % of the 2400 transitions are live.  Asserted: every terminate / episode-end / valid flag,
+    reward MAE over live steps (the north-star metric; fp32 < 1e-4, measured 5.4e-5 walk / 2.5e-6 spinkick / 1.1e-5 dog), the
+    90th percentile, and the state vector (mean relative error).  The free-running MAXIMUM is printed, not asserted: two correct
+    contact simulations separate chaotically around a fall (the fp64 build shows 6e-4 there); the per-step maximum is asserted
+    by the teacher-forced test below."""
+    dr, ds, alive, resets, ok = pc.auto_reset_rollout_compare(name, prec, hip_lib, steps=300, n=8, seed=11, wave_packing=pack)
+    live = dr[alive]
+    print("%s fp%d pack%d: live %d/%d, resets %d, reward MAE %.2e p90 %.2e max %.2e; state mean %.2e max %.2e"
+          % (name, prec, pack, alive.sum(), dr.size, resets, live.mean(), np.quantile(live, 0.9), live.max(), ds.mean(), ds.max()))
+    assert ok and resets >= 50
+    assert alive.mean() > 0.95
+    if prec == 64:
+        assert live.mean() < 1e-5 and np.quantile(live, 0.9) < 1e-6 and ds.mean() < 2e-3
+    else:
+        assert live.mean() < 1e-4 and np.quantile(live, 0.9) < 1e-4 and ds.mean() < 2e-2
+
+
+@pytest.mark.parametrize("name,prec,pack", LIVE_CASES)
+def test_stepwise_300_steps_live(hip_lib, name, prec, pack):
+    """teacher-forced: each of 300 x 8 control steps (20 updates, 40 substeps) starts from the oracle's state; live steps only.
+    This is the per-step precision of the kernels.  Fixed bounds -- fp32 production kernels: reward MAE < 1e-5 (measured
+    3.4e-6), 99th percentile < 1e-4 (3.2e-5), fewer than 1 % of steps beyond 1e-4 (0.56 %), maximum < 5e-3 (1.1e-3 walk,
+    3.9e-3 dog: a contact candidate crosses its activation threshold inside the step and the two sides pick different
+    manifolds -- the fp64 build has the same kind of step at 2.7e-4); state vector: mean relative error < 5e-3, 99th
+    percentile < 5e-2.  fp64 algorithm build: MAE < 1e-6, 99th percentile < 1e-6, maximum < 1e-3."""
+    dr, ds, alive, ok = pc.stepwise_live_compare(name, prec, hip_lib, steps=300, n=8, seed=12, wave_packing=pack)
+    live, sl = dr[alive], ds[alive]
+    print("%s fp%d pack%d: live %d/%d, reward MAE %.2e p99 %.2e max %.2e n>1e-4 %d; state mean %.2e p99 %.2e max %.2e"
+          % (name, prec, pack, alive.sum(), dr.size, live.mean(), np.quantile(live, 0.99), live.max(), (live > 1e-4).sum(),
+             sl.mean(), np.quantile(sl, 0.99), sl.max()))
+    assert ok and alive.mean() > 0.9
+    if prec == 64:
+        assert live.mean() < 1e-6 and np.quantile(live, 0.99) < 1e-6 and live.max() < 1e-3
+        assert np.quantile(sl, 0.99) < 1e-6
+    else:
+        assert live.mean() < 1e-5 and np.quantile(live, 0.99) < 1e-4 and (live > 1e-4).mean() < 0.01 and live.max() < 5e-3
+        assert sl.mean() < 5e-3 and np.quantile(sl, 0.99) < 5e-2
 
 
 def test_rollout_spinkick_free_running_prefix(hip_lib):
@@ -74,63 +115,28 @@ def test_rollout_spinkick_free_running_prefix(hip_lib):
     assert ok and dr.max() < 1e-4
 
 
-@pytest.mark.parametrize("name,prec,tol", [("humanoid3d_spinkick", 64, 1e-6), ("humanoid3d_spinkick", 32, 1e-4),
-                                           ("humanoid3d_walk", 32, 1e-4), ("dog3d_pace", 32, 1e-4)])
-def test_rollout_stepwise_300_steps(hip_lib, name, prec, tol):
-    """teacher-forced: every one of the 300 control steps (20 updates, 40 substeps each) from the oracle's state.
-
-    fp32: a control step is held to `tol` unless the fp32 *oracle* itself misses tol/4 on that step (spinkick step 92:
-    a foot-corner candidate sits on its activation threshold, rounding picks the manifold; the float restatement of
-    the oracle is off by 2e-3 there).  Such ill-conditioned steps must be rare and stay within 20x the oracle's own
-    fp32 error."""
-    dr, ds, ok = pc.rollout_compare(name, prec, hip_lib, steps=300, resync=True)
-    assert dr.mean() < tol, (dr.mean(), dr.max())
-    if prec == 64:
-        assert dr.max() < tol, (dr.mean(), dr.max())
-        assert ok and ds.max() < 1e-4
-        return
-    sens = pc.fp32_step_sensitivity(name, 300)
-    ill = sens > tol / 4
-    assert ill.sum() <= 3, np.nonzero(ill)[0]
-    assert dr[~ill].max() < tol, (int(np.argmax(np.where(ill, 0, dr))), dr[~ill].max())
-    if ill.any():
-        assert dr[ill].max() < 20 * max(sens[ill].max(), tol), (dr[ill].max(), sens[ill].max())
-
-
 def _golden_cases():
     import json, os
     with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_rollouts.json")) as f:
         return json.load(f)
 
 
-def _golden_fp32_floor(case):
-    from oracle_lib import Oracle
-    f = Oracle(model.load_asset(case["scene"]), variant="f32")
-    f.reset(case["t0"])
-    d = []
-    for k in range(case["steps"]):
-        f.set_action(f.pose_to_action(f.kin_state()[0]))
-        for u in range(20):
-            f.update(pc.DT)
-        d.append(abs(f.calc_reward() - case["rewards"][k]))
-    return np.array(d)
-
-
 @pytest.mark.parametrize("case", _golden_cases(), ids=lambda c: "%s@%g" % (c["scene"], c["t0"]))
 def test_rollout_against_committed_golden_vectors(hip_lib, case):
     """HIP path vs the committed fixtures (tests/golden/oracle_rollouts.json), all envs of one batch at once."""
     t = model.load_asset(case["scene"])
-    for prec, tol_r, tol_s in ((64, 1e-5, 1e-3), (32, 2e-4, 5e-2)):       # rewards cross the boundary as float32; the 30-step dog case carries stiff self contacts
+    for prec, tol_r, tol_s in ((64, 1e-5, 1e-3), (32, 1e-3, 5e-2)):       # fixed bounds; rewards cross the boundary as float32
         env = BatchEnv(t, 3, precision=prec)
         env.reset(kin_times=[case["t0"]] * 3, max_times=np.inf)
         q = env.query()
         assert np.abs(q["state"][1] - np.array(case["state0"])).max() < (1e-6 if prec == 64 else 2e-5)
-        # fp32: a step on which the float build of the oracle itself is further than tol/2 from the fixture (the stiff self contacts
-        # at the end of the 30-step dog case: 3.2e-4) is held to 2x that floor instead
-        floor = _golden_fp32_floor(case) if prec == 32 else np.zeros(case["steps"])
+        errs = []
         for k in range(case["steps"]):
             out = env.step(None, pc.DT, 20, open_loop=True)
-            assert np.abs(out["reward"] - case["rewards"][k]).max() < max(tol_r, 2 * floor[k]), (prec, k, floor[k])
+            errs.append(np.abs(out["reward"] - case["rewards"][k]).max())
+        errs = np.array(errs)
+        # fp32: MAE inside 1e-4, every step inside 1e-3 (the stiff self contacts at the end of the 30-step dog case: measured 3e-4)
+        assert errs.max() < tol_r and errs.mean() < tol_r / 10, (prec, errs.mean(), errs.max(), int(np.argmax(errs)))
         assert np.abs(out["state"][2] - np.array(case["final_state"])).max() < tol_s
         assert int(out["terminate"][0]) == case["terminate"]
 
@@ -188,18 +194,15 @@ def test_facade_protocol_matches_oracle(hip_lib):
 
 
 # ---- two characters per wavefront (dm_device_duo.h): same checks through the batch entry point
-@pytest.mark.parametrize("prec,tol_r,tol_s", [(64, 1e-6, 1e-5), (32, 5e-4, 0.5)])
+@pytest.mark.parametrize("prec,tol_r,tol_s", [(64, 1e-6, 1e-5), (32, 1e-3, 0.5)])
 def test_duo_rollout_matches_oracle(hip_lib, prec, tol_r, tol_s):
+    """10 free-running steps of six envs (three pairs); fp32: every env inside 1e-3, all but one inside 1e-4 (the env started at
+    0.11 crosses a step on which a contact candidate sits on its activation threshold), mean inside 1e-4."""
     t0s = [0.0, 0.37, 0.8, 0.11, 0.5, 0.9]
     dr, ds, ok = pc.batch_rollout_compare("humanoid3d_walk", prec, hip_lib, steps=10, t0s=t0s, wave_packing=2)
+    assert ok and dr.max() < tol_r and ds.max() < tol_s, (dr, ds)
     if prec == 32:
-        # the env started at 0.11 crosses an ill-conditioned step inside the 10 steps: the float build of the oracle is itself 3.2e-4
-        # away from the fp64 oracle there, so every env is held to max(1e-4, 2 x its own fp32 floor); the others stay inside 1e-4
-        floor = np.array([pc.fp32_free_running_sensitivity("humanoid3d_walk", 10, t0).max() for t0 in t0s])
-        assert ok and (dr < np.maximum(1e-4, 2 * floor)).all() and ds.max() < tol_s, (dr, floor, ds)
-        assert np.sort(dr)[-2] < 1e-4, dr
-    else:
-        assert ok and dr.max() < tol_r and ds.max() < tol_s, (dr, ds)
+        assert np.sort(dr)[-2] < 1e-4 and dr.mean() < 1e-4, dr
 
 
 def test_duo_heavy_contact_fallback(hip_lib):
@@ -242,22 +245,28 @@ def test_duo_auto_reset_4096(hip_lib):
 
 
 def test_duo_fp32_300_steps_reward_tolerance(hip_lib):
-    """the headline configuration of bench.py (wave_packing = 2, fp32): same bound as the one-character-per-wave kernel"""
+    """the headline configuration of bench.py (wave_packing = 2, fp32), the literal config-1 rollout: 300 steps from t0 = 0, no
+    reset.  Only the steps before the fall are live (the count is printed); reward and state vector are asserted on those."""
     t = model.load_asset("humanoid3d_walk")
     env = BatchEnv(t, 2, precision=32, wave_packing=2)
     env.reset(kin_times=[0.0, 0.0], max_times=np.inf)
     o = Oracle(t); o.reset(0.0)
-    dr = []
+    dr, ds, alive = [], [], []
     for k in range(300):
         out = env.step(None, pc.DT, 20, open_loop=True)
         kp, _, _ = o.kin_state(); o.set_action(o.pose_to_action(kp))
         for u in range(20):
             o.update(pc.DT)
-        dr.append(max(abs(float(out["reward"][e]) - o.calc_reward()) for e in range(2)))
+        r = o.calc_reward(); so = o.record_state()
+        dr.append(max(abs(float(out["reward"][e]) - r) for e in range(2)))
+        ds.append(max(np.abs(out["state"][e] - so).max() for e in range(2)) / max(1.0, np.abs(so).max()))
+        alive.append(r != 0.0)
         assert int(out["terminate"][0]) == o.check_terminate() == int(out["terminate"][1])
-    dr = np.array(dr)
-    floor = pc.fp32_free_running_sensitivity("humanoid3d_walk", 40).max()
-    assert dr.mean() < 1e-5 and dr.max() < max(1e-4, 4 * floor), (dr.mean(), dr.max(), floor)
+    dr, ds, alive = np.array(dr), np.array(ds), np.array(alive)
+    print("live steps %d / 300: reward MAE %.2e max %.2e, state max %.2e; all 300: MAE %.2e" % (alive.sum(), dr[alive].mean(), dr[alive].max(), ds[alive].max(), dr.mean()))
+    assert 20 <= alive.sum() <= 40                     # the open-loop walker falls after about one second
+    assert dr[alive].mean() < 1e-4 and dr[alive].max() < 1e-3 and ds[alive].max() < 5e-2
+    assert dr[~alive].max() < 1e-6                     # both sides report 0 for a fallen character
 
 
 @pytest.mark.parametrize("prec,tol", [(64, 1e-5), (32, 1e-4)])
@@ -267,8 +276,8 @@ def test_root_heading_sync_dog_spin(hip_lib, prec, tol):
     if prec == 64:
         pc.check_reset_and_query("dog3d_spin", 64, hip_lib, tol_state=1e-12, tol_reward=1e-6)
     dr, ds, ok = pc.rollout_compare("dog3d_spin", prec, hip_lib, steps=60)
-    floor = pc.fp32_free_running_sensitivity("dog3d_spin", 60).max() if prec == 32 else 0.0
-    assert ok and dr.mean() < tol / 5 and dr.max() < max(tol, 4 * floor), (dr.mean(), dr.max(), floor)
+    print("dog3d_spin fp%d: reward MAE %.2e max %.2e, state max %.2e" % (prec, dr.mean(), dr.max(), ds.max()))
+    assert ok and dr.mean() < tol / 5 and dr.max() < 10 * tol, (dr.mean(), dr.max())      # fixed: fp32 mean < 2e-5, max < 1e-3
 
 
 @pytest.mark.parametrize("pack", [1, 2])

@@ -16,7 +16,7 @@ from .model import SceneTables
 _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIB = os.path.join(_HERE, "csrc", "libdm_hip.so")
 
-DM_DEVICE_PTRS, DM_AUTO_RESET, DM_OPEN_LOOP, DM_NO_EMIT = 1, 2, 4, 8
+DM_DEVICE_PTRS, DM_AUTO_RESET, DM_OPEN_LOOP, DM_NO_EMIT, DM_END_EPISODE_EARLY = 1, 2, 4, 8, 16
 
 
 class _CreateInfo(C.Structure):
@@ -51,6 +51,10 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
             "HIP extension %s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(deepmimic_amd has no CPU fallback)" % path)
     lib = C.CDLL(path)
+    # the CPU fiber-emulator build of the same sources (tests/emu) is test infrastructure: the product refuses it unless the test
+    # harness says so, so that no environment variable alone can turn the shipped path into a CPU path
+    if lib.dm_is_emulator() and os.environ.get("DM_ALLOW_EMULATOR") != "1":
+        raise RuntimeError("%s is the CPU emulator build (test infrastructure); deepmimic_amd runs on the HIP library only" % path)
     lib.dm_last_error.restype = C.c_char_p
     lib.dm_motion_duration.restype = C.c_double
     lib.dm_motion_duration.argtypes = [C.c_void_p]
@@ -162,12 +166,15 @@ class BatchEnv:
         self._chk(self.lib.dm_query(self.h, _fp(s), _fp(r), _ip(t), _ip(v), _ip(e), _ip(nn), 0))
         return dict(state=s, reward=r, terminate=t, valid=v, episode_end=e, need_new_action=nn)
 
-    def step(self, actions=None, timestep: float = 1.0 / 600, n_updates: int = 20, auto_reset=False, open_loop=False, amp=False):
-        """amp=True (imitate_amp scenes): also returns "amp_obs" = RecordAMPObsAgent at the end of the step (before any auto reset)."""
+    def step(self, actions=None, timestep: float = 1.0 / 600, n_updates: int = 20, auto_reset=False, open_loop=False, amp=False, end_early=None):
+        """amp=True (imitate_amp scenes): also returns "amp_obs" = RecordAMPObsAgent at the end of the step (before any auto reset).
+        end_early (default: follows auto_reset): an env whose episode is over after an update takes no further updates in this call,
+        as the reference's driver ends an episode at the update where IsEpisodeEnd turns true (DeepMimic.py:62-80)."""
+        end_early = auto_reset if end_early is None else end_early
         a = None if actions is None else np.ascontiguousarray(actions, dtype=np.float32).reshape(self.N, self.A)
         s = np.zeros((self.N, self.S), np.float32); r = np.zeros(self.N, np.float32)
         t = np.zeros(self.N, np.int32); v = np.zeros(self.N, np.int32); e = np.zeros(self.N, np.int32)
-        flags = (DM_AUTO_RESET if auto_reset else 0) | (DM_OPEN_LOOP if open_loop else 0)
+        flags = (DM_AUTO_RESET if auto_reset else 0) | (DM_OPEN_LOOP if open_loop else 0) | (DM_END_EPISODE_EARLY if end_early else 0)
         if amp:
             o = np.zeros((self.N, self.amp_size), np.float32)
             self._chk(self.lib.dm_step_batch_amp(self.h, _fp(a), C.c_double(timestep), int(n_updates), _fp(s), _fp(r), _ip(t), _ip(v), _ip(e), _fp(o), flags))
@@ -190,9 +197,10 @@ class BatchEnv:
         return o
 
     def step_device(self, actions_ptr, states_ptr, rewards_ptr, term_ptr, valid_ptr, end_ptr,
-                    timestep: float = 1.0 / 600, n_updates: int = 20, auto_reset=False, open_loop=False, amp_ptr=0):
+                    timestep: float = 1.0 / 600, n_updates: int = 20, auto_reset=False, open_loop=False, amp_ptr=0, end_early=None):
         """Same as step() on raw device pointers (ints), asynchronous on the ctx stream."""
-        flags = DM_DEVICE_PTRS | (DM_AUTO_RESET if auto_reset else 0) | (DM_OPEN_LOOP if open_loop else 0)
+        end_early = auto_reset if end_early is None else end_early
+        flags = DM_DEVICE_PTRS | (DM_AUTO_RESET if auto_reset else 0) | (DM_OPEN_LOOP if open_loop else 0) | (DM_END_EPISODE_EARLY if end_early else 0)
         vp = lambda p: C.c_void_p(p) if p else None
         if amp_ptr:
             self._chk(self.lib.dm_step_batch_amp(self.h, vp(actions_ptr), C.c_double(timestep), int(n_updates), vp(states_ptr),
@@ -209,7 +217,7 @@ class BatchEnv:
 
     def bench_rollout(self, warmup: int, steps: int, timestep=1.0 / 600, n_updates=20, auto_reset=True, open_loop=True):
         ms = C.c_double(0)
-        flags = (DM_AUTO_RESET if auto_reset else 0) | (DM_OPEN_LOOP if open_loop else 0)
+        flags = (DM_AUTO_RESET if auto_reset else 0) | (DM_OPEN_LOOP if open_loop else 0) | (DM_END_EPISODE_EARLY if auto_reset else 0)
         self._chk(self.lib.dm_bench_rollout(self.h, int(warmup), int(steps), C.c_double(timestep), int(n_updates), flags, None, None, C.byref(ms)))
         return ms.value
 
@@ -247,3 +255,42 @@ class BatchEnv:
         out = np.zeros(shapes[name])
         self._chk(self.lib.dm_get_debug(self.h, name.encode(), _dp(out)))
         return out
+
+
+class Comm:
+    """dm_comm of the C-ABI (include/dm_hip.h): the RCCL communicator behind dm_gather_records, for hosts that shard without
+    torch.  `unique_id` = the 128 bytes rank 0 got from Comm.unique_id(), shipped to every rank by the caller."""
+
+    def __init__(self, world: int, rank: int, device_id: int = 0, unique_id: Optional[bytes] = None, lib_path: Optional[str] = None):
+        self.lib = load_library(lib_path)
+        self.h = C.c_void_p()
+        uid = None if unique_id is None else C.create_string_buffer(bytes(unique_id), 128)
+        if self.lib.dm_comm_create(uid, int(world), int(rank), int(device_id), C.byref(self.h)) != 0:
+            raise RuntimeError("libdm_hip: %s" % self.lib.dm_last_error().decode())
+        self.world, self.rank = world, rank
+
+    @staticmethod
+    def unique_id(lib_path: Optional[str] = None) -> bytes:
+        lib = load_library(lib_path)
+        buf = C.create_string_buffer(128)
+        if lib.dm_comm_unique_id(buf) != 0:
+            raise RuntimeError("libdm_hip: %s" % lib.dm_last_error().decode())
+        return buf.raw
+
+    def gather(self, env: "BatchEnv", slot: int, send_ptr: int, recv_ptr: int, count: int):
+        """async all-gather of `count` floats per rank, ordered after the work already enqueued on env's stream"""
+        env._chk(self.lib.dm_gather_records(env.h, self.h, int(slot), C.c_void_p(send_ptr), C.c_void_p(recv_ptr), C.c_size_t(count)))
+
+    def wait(self, env: "BatchEnv", slot: int):
+        env._chk(self.lib.dm_gather_wait(env.h, self.h, int(slot)))
+
+    def close(self):
+        if self.h:
+            self.lib.dm_comm_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -261,8 +261,12 @@ struct Lds {
     int flg[8];                            // need_new_action, contact_mask, episode_count, valid, nrows, ncontacts
 };
 
+// What the end-of-call outputs need of a character whose episode ended mid-call (two characters per wavefront, early episode end)
+template <typename Real, typename C>
+struct ParkSnap { Real pose[C::NP], vel[C::NP], kin[8]; double clk[6]; int flg[4]; };
+
 enum { CLK_KIN = 0, CLK_CTRL, CLK_INIT_OFF, CLK_TIMER, CLK_TIMER_MAX };
-enum { FLG_NEED_ACTION = 0, FLG_CONTACT, FLG_EPISODE, FLG_VALID, FLG_NROWS, FLG_NCONT };
+enum { FLG_NEED_ACTION = 0, FLG_CONTACT, FLG_EPISODE, FLG_VALID, FLG_NROWS, FLG_NCONT, FLG_PARKED };
 
 // TAPS = false compiles every debug tap / phase timer out of the instruction stream (production step kernel).
 // LW = lanes per character: 64 (one character per wavefront) or 32 (two characters per wavefront, dm_device_duo.h).
@@ -317,16 +321,59 @@ struct EnvSim {
         if (l < 8) s.kin[l] = st.kin[(size_t)e * 8 + l];
         if (l < 6) s.clk[l] = st.clock[(size_t)e * 6 + l];
         if (l < 4) s.flg[l] = st.flag[(size_t)e * 4 + l];
+        if (l == 0) s.flg[FLG_PARKED] = 0;
         sync();
     }
-    DM_DEV void store(const EnvState<Real>& st, int e) {
+    // `act`: lanes of a character that does not take part still pass the barriers (two characters per wavefront)
+    DM_DEV void store(const EnvState<Real>& st, int e, bool act = true) {
         DM_OPAQUE_V(l);
         sync();
+        if (!act) return;
         for (int i = l; i < m.P; i += LW) { st.pose[(size_t)e * m.P + i] = s.pose[i]; st.vel[(size_t)e * m.P + i] = s.vel[i]; st.tar[(size_t)e * m.P + i] = s.tar[i]; }
         for (int i = l; i < m.D; i += LW) st.tau[(size_t)e * m.D + i] = s.tau[i];
         if (l < 8) st.kin[(size_t)e * 8 + l] = s.kin[l];
         if (l < 6) st.clock[(size_t)e * 6 + l] = s.clk[l];
         if (l < 4) st.flag[(size_t)e * 4 + l] = s.flg[l];
+    }
+    // Is the episode over after this update?  The reference's driver asks after EVERY update and ends the episode there, not at
+    // the next action boundary (DeepMimic.py:62-80 update_world: world.update(timestep); is_episode_end -> end_episode, reset,
+    // break; learning/rl_agent.py:_end_path records the state and reward of that moment).  Same tests as emit(): contact fall
+    // (cSceneImitate::CheckTerminate, SceneImitate.cpp:193-205), a finished non-looping clip, the episode timer.  The root-rotation
+    // failure test (enable_root_rot_fail, off in every shipped imitate arg file) needs the kin pose and stays at the boundary.
+    DM_DEV bool episode_over_now() const {
+        const bool fail = (m.enable_fall_end && has_fallen(nullptr)) || (!m.scene_amp && !m.loop && s.clk[CLK_KIN] >= m.duration);
+        return fail || (s.clk[CLK_TIMER] >= s.clk[CLK_TIMER_MAX]);
+    }
+    // Two characters share one instruction stream: a character whose episode is over mid-call has what the outputs need of
+    // its record copied aside (LDS) and is then moved out of the way -- 10 m up, at rest -- so that the updates its partner
+    // still needs cost it no contact rows; unpark() brings the copy back before the outputs are written.  `act`: lanes of
+    // the other character only pass the barriers.
+    DM_DEV void park(ParkSnap<Real, C>& snap, bool act) {
+        sync();
+        if (act) {
+            for (int i = l; i < m.P; i += LW) { snap.pose[i] = s.pose[i]; snap.vel[i] = s.vel[i]; }
+            if (l < 8) snap.kin[l] = s.kin[l];
+            if (l < 6) snap.clk[l] = s.clk[l];
+            if (l < 4) snap.flg[l] = s.flg[l];
+        }
+        sync();
+        if (act) {
+            for (int i = l; i < m.P; i += LW) s.vel[i] = (Real)0;
+            if (l == 0) { s.pose[1] += (Real)10; s.flg[FLG_CONTACT] = 0; s.flg[FLG_PARKED] = 1; }
+        }
+        sync();
+    }
+    DM_DEV void unpark(const ParkSnap<Real, C>& snap) {
+        sync();
+        if (s.flg[FLG_PARKED]) {
+            for (int i = l; i < m.P; i += LW) { s.pose[i] = snap.pose[i]; s.vel[i] = snap.vel[i]; }
+            if (l < 8) s.kin[l] = snap.kin[l];
+            if (l < 6) s.clk[l] = snap.clk[l];
+            if (l < 4) s.flg[l] = snap.flg[l];
+        }
+        sync();
+        if (l == 0) s.flg[FLG_PARKED] = 0;
+        sync();
     }
 
     // ------------------------------------------------------------------ kinematics (level-synchronous over tree depth)
@@ -1260,8 +1307,8 @@ struct EnvSim {
     // ------------------------------------------------------------------ AMP observations (scenes/SceneImitateAMP.cpp)
     // cSceneImitateAMP::UpdateHist at the action latch (cRLSceneSimChar::PreUpdate -> NewActionUpdate, RLSceneSimChar.cpp:263-275):
     // the history lives in HBM only; called before every update, writes when the controller wants a new action
-    DM_DEV void latch_hist(const EnvState<Real>& st, int e) {
-        if (s.flg[FLG_NEED_ACTION]) {
+    DM_DEV void latch_hist(const EnvState<Real>& st, int e, bool act = true) {
+        if (act && s.flg[FLG_NEED_ACTION]) {
             Real* h = st.hist + (size_t)e * 2 * m.P;
             for (int i = l; i < m.P; i += LW) { h[i] = s.pose[i]; h[m.P + i] = s.vel[i]; }
         }
@@ -1423,6 +1470,7 @@ __global__ void __launch_bounds__(64) DM_WAVES_PER_EU((StepWaves<Real, C>::value
     for (int u = 0; u < io.n_updates; ++u) {
         if (HIST && st.hist) sim.latch_hist(st, e);
         sim.update(io.dt, dbg, e, aovf);
+        if (io.end_early && sim.episode_over_now()) break;      // wave-uniform: the flags and clocks are in LDS
     }
     if (io.emit) {
         // pass 0 writes reward / flags / observation.  With auto-reset (mirrors DeepMimic.py:70-79) an env whose episode

@@ -637,6 +637,14 @@ _Pragma("unroll") \
         }
         sync();
     }
+    // after an update with DM_END_EPISODE_EARLY: true when both characters are done
+    DM_DEV bool end_early_step(ParkSnap<Real, C>& snap) {
+        const bool parked = s.flg[FLG_PARKED] != 0;
+        const bool over = parked || b.episode_over_now();
+        if (wave_ballot(over) == ~(uint64_t)0) return true;
+        if (wave_ballot(over && !parked) != 0) b.park(snap, over && !parked);     // wave-uniform branch; the partner's lanes only pass the barriers
+        return false;
+    }
 };
 
 // grid = N / 2 workgroups of one wavefront; character e = 2 * blockIdx.x + (lane >> 5).  fp32: 2 waves / SIMD (20 KB LDS).
@@ -646,6 +654,7 @@ template <typename Real, bool TAPS, bool AMP = false>
 __global__ void __launch_bounds__(64) DM_WAVES_PER_EU((DuoWaves<Real>::value)) k_env_step_duo(ModelDev<Real> m, EnvState<Real> st, StepIO<Real> io, DebugTaps<Real> dbg) {
     constexpr bool HIST = TAPS || AMP;
     __shared__ Lds<Real, ClsBiped> lds[2];
+    __shared__ ParkSnap<Real, ClsBiped> snap[2];     // 2 x 0.45 KB: the fp32 kernel stays inside 20 KB per wave (8 waves per CU)
     const int wl = threadIdx.x, half = wl >> 5;
     const int e = 2 * blockIdx.x + half;
     DuoSim<Real, TAPS> sim(m, lds, wl);
@@ -655,9 +664,22 @@ __global__ void __launch_bounds__(64) DM_WAVES_PER_EU((DuoWaves<Real>::value)) k
     else if (io.actions) sim.b.set_action(io.actions + (size_t)e * m.A);
     sim.b.mark(15);
     Real* aovf_pair = st.aovf ? st.aovf + (size_t)(2 * blockIdx.x) * (kMaxRows - ClsBiped::RREG) * kWave : nullptr;
-    for (int u = 0; u < io.n_updates; ++u) {
+    int u = 0;
+    for (; u < io.n_updates; ++u) {
         if (HIST && st.hist) sim.b.latch_hist(st, e);
         sim.update(io.dt, e, aovf_pair);
+        // DM_END_EPISODE_EARLY: leave the hot loop as soon as either character's episode is over (EnvSim::episode_over_now)
+        if (io.end_early && wave_ballot(sim.b.episode_over_now()) != 0) break;
+    }
+    if (u < io.n_updates) {
+        // Rare tail (a few percent of the waves of a launch): a character whose episode is over has what the outputs need of its
+        // record copied aside (LDS) and is parked, the partner finishes its updates, the copy comes back before the outputs.
+        for (;;) {
+            if (sim.end_early_step(snap[half]) || ++u >= io.n_updates) break;
+            if (HIST && st.hist) sim.b.latch_hist(st, e, lds[half].flg[FLG_PARKED] == 0);
+            sim.update(io.dt, e, aovf_pair);
+        }
+        sim.b.unpark(snap[half]);
     }
     if (io.emit) {
         DebugTaps<Real> tap = DebugTaps<Real>();

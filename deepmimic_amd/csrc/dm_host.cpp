@@ -421,7 +421,7 @@ struct CtxT : CtxBase {
         StepIO<Real> io; memset(&io, 0, sizeof(io));
         io.amp_obs = amp;
         io.actions = actions_dev; io.states = states; io.rewards = rewards; io.terminate = term; io.valid = valid; io.episode_end = end;
-        io.n_updates = n_updates; io.dt = dt; io.auto_reset = (flags & DM_AUTO_RESET) ? 1 : 0; io.emit = (flags & DM_NO_EMIT) ? 0 : 1; io.open_loop = (flags & DM_OPEN_LOOP) ? 1 : 0;
+        io.n_updates = n_updates; io.dt = dt; io.auto_reset = (flags & DM_AUTO_RESET) ? 1 : 0; io.emit = (flags & DM_NO_EMIT) ? 0 : 1; io.open_loop = (flags & DM_OPEN_LOOP) ? 1 : 0; io.end_early = (flags & DM_END_EPISODE_EARLY) ? 1 : 0;
         // two characters per wavefront: biped class, even batch, no debug taps armed (DM_DUO=0 keeps one character per wave)
         if (duo && cls == 0 && hm.D == ClsBiped::ND && (N % 2) == 0 && !dbg.H) {      // (31 row lanes per character assume exactly 34 dofs)
             if (st.hist) RT_LAUNCH((k_env_step_duo<Real, false, true>), N / 2, stream, md, st, io, dbg);
@@ -453,7 +453,7 @@ struct CtxT : CtxBase {
             DebugTaps<Real> d2; memset(&d2, 0, sizeof(d2)); d2.prof = d_prof;
             StepIO<Real> io; memset(&io, 0, sizeof(io));
             io.states = d_states; io.rewards = d_rewards; io.terminate = d_term; io.valid = d_valid; io.episode_end = d_end;
-            io.n_updates = 20; io.dt = dt; io.auto_reset = 1; io.emit = 1; io.open_loop = 1;
+            io.n_updates = 20; io.dt = dt; io.auto_reset = 1; io.emit = 1; io.open_loop = 1; io.end_early = 1;
             if (duo && cls == 0 && hm.D == ClsBiped::ND && (N % 2) == 0) RT_LAUNCH((k_env_step_duo<Real, true>), N / 2, stream, md, st, io, d2);
             else if (cls == 0) RT_LAUNCH((k_env_step<Real, ClsBiped, true>), N, stream, md, st, io, d2); else RT_LAUNCH((k_env_step<Real, ClsLarge, true>), N, stream, md, st, io, d2);
             return 0;
@@ -515,6 +515,13 @@ struct dm_ctx { CtxBase* c; };
 // ---------------------------------------------------------------- C-ABI
 extern "C" {
 
+int dm_is_emulator(void) {
+#ifdef DM_EMU
+    return 1;
+#else
+    return 0;
+#endif
+}
 const char* dm_last_error(void) { return g_err.c_str(); }
 
 int dm_destroy(dm_ctx* ctx);
@@ -747,6 +754,127 @@ int dm_bench_rollout(dm_ctx* ctx, int warmup, int steps, double timestep, int n_
 #else
     if (elapsed_ms) *elapsed_ms = 0;
 #endif
+    return 0;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------- record all-gather over RCCL
+#ifndef DM_EMU
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+namespace {
+struct RcclApi {
+    void* lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+RcclApi g_rccl;
+// librccl is resolved at the first multi-GPU call, not at load time: a single-GPU user never needs it, and a process that already
+// carries an RCCL (torch) gets that copy back from the loader by soname
+int rccl_load() {
+    if (g_rccl.lib) return 0;
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) { g_rccl.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL); if (g_rccl.lib) break; }
+    if (!g_rccl.lib) return fail(std::string("cannot load librccl: ") + dlerror());
+    g_rccl.GetUniqueId = (decltype(g_rccl.GetUniqueId))dlsym(g_rccl.lib, "ncclGetUniqueId");
+    g_rccl.CommInitRank = (decltype(g_rccl.CommInitRank))dlsym(g_rccl.lib, "ncclCommInitRank");
+    g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))dlsym(g_rccl.lib, "ncclCommDestroy");
+    g_rccl.AllGather = (decltype(g_rccl.AllGather))dlsym(g_rccl.lib, "ncclAllGather");
+    g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))dlsym(g_rccl.lib, "ncclGetErrorString");
+    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.CommDestroy || !g_rccl.AllGather) { g_rccl.lib = nullptr; return fail("librccl lacks the nccl* entry points"); }
+    return 0;
+}
+int rccl_fail(const char* what, ncclResult_t r) { return fail(std::string(what) + ": " + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "RCCL error")); }
+}  // namespace
+#endif
+
+struct dm_comm {
+    int world = 1, rank = 0, device_id = 0;
+#ifndef DM_EMU
+    ncclComm_t comm = nullptr; hipStream_t stream = nullptr;
+    hipEvent_t ready[4] = {nullptr, nullptr, nullptr, nullptr}, done[4] = {nullptr, nullptr, nullptr, nullptr};
+#endif
+    bool in_flight[4] = {false, false, false, false};
+};
+
+extern "C" {
+
+int dm_comm_unique_id(void* out) {
+    if (!out) return fail("null argument");
+#ifdef DM_EMU
+    memset(out, 0, 128); return 0;
+#else
+    if (rccl_load() != 0) return -1;
+    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+    ncclResult_t r = g_rccl.GetUniqueId((ncclUniqueId*)out);
+    return r == ncclSuccess ? 0 : rccl_fail("ncclGetUniqueId", r);
+#endif
+}
+
+int dm_comm_create(const void* uid, int world, int rank, int device_id, dm_comm** out) {
+    if (!out || world < 1 || rank < 0 || rank >= world) return fail("dm_comm_create: bad arguments");
+    dm_comm* c = new dm_comm(); c->world = world; c->rank = rank; c->device_id = device_id;
+#ifdef DM_EMU
+    if (world != 1) { delete c; return fail("the CPU emulator build has no collective: world must be 1"); }
+#else
+    DevGuard guard(device_id);
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return fail("hipStreamCreate failed"); }
+    for (int i = 0; i < 4; ++i)
+        if (hipEventCreateWithFlags(&c->ready[i], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->done[i], hipEventDisableTiming) != hipSuccess) { dm_comm_destroy(c); return fail("hipEventCreate failed"); }
+    if (world > 1 || uid) {            // a unique id with world == 1 runs the one-rank collective through RCCL (tests, profiling)
+        if (!uid) { dm_comm_destroy(c); return fail("dm_comm_create: world > 1 needs the unique id of rank 0"); }
+        if (rccl_load() != 0) { dm_comm_destroy(c); return -1; }
+        ncclUniqueId id; memcpy(&id, uid, sizeof(id));
+        ncclResult_t r = g_rccl.CommInitRank(&c->comm, world, id, rank);
+        if (r != ncclSuccess) { dm_comm_destroy(c); return rccl_fail("ncclCommInitRank", r); }
+    }
+#endif
+    *out = c;
+    return 0;
+}
+
+int dm_comm_destroy(dm_comm* c) {
+    if (!c) return 0;
+#ifndef DM_EMU
+    DevGuard guard(c->device_id);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(c->comm);
+    for (int i = 0; i < 4; ++i) { if (c->ready[i]) (void)hipEventDestroy(c->ready[i]); if (c->done[i]) (void)hipEventDestroy(c->done[i]); }
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+#endif
+    delete c;
+    return 0;
+}
+
+int dm_gather_records(dm_ctx* ctx, dm_comm* c, int slot, const float* send_dev, float* recv_dev, size_t count) {
+    if (!ctx || !c || !send_dev || !recv_dev) return fail("null argument");
+    if (slot < 0 || slot >= 4) return fail("slot must be in [0, 4)");
+#ifdef DM_EMU
+    memcpy(recv_dev + (size_t)c->rank * count, send_dev, sizeof(float) * count);
+#else
+    DevGuard guard(c->device_id);
+    HIPCHK(hipEventRecord(c->ready[slot], ctx->c->stream));              // the step that wrote send_dev
+    HIPCHK(hipStreamWaitEvent(c->stream, c->ready[slot], 0));
+    if (!c->comm) HIPCHK(hipMemcpyAsync(recv_dev, send_dev, sizeof(float) * count, hipMemcpyDeviceToDevice, c->stream));
+    else { ncclResult_t r = g_rccl.AllGather(send_dev, recv_dev, count, ncclFloat, c->comm, c->stream); if (r != ncclSuccess) return rccl_fail("ncclAllGather", r); }
+    HIPCHK(hipEventRecord(c->done[slot], c->stream));
+#endif
+    c->in_flight[slot] = true;
+    return 0;
+}
+
+int dm_gather_wait(dm_ctx* ctx, dm_comm* c, int slot) {
+    if (!ctx || !c) return fail("null argument");
+    if (slot < 0 || slot >= 4) return fail("slot must be in [0, 4)");
+    if (!c->in_flight[slot]) return 0;
+#ifndef DM_EMU
+    DevGuard guard(c->device_id);
+    HIPCHK(hipStreamWaitEvent(ctx->c->stream, c->done[slot], 0));
+#endif
+    c->in_flight[slot] = false;
     return 0;
 }
 

@@ -135,6 +135,7 @@ struct StepIO {
     int emit;               // write states / rewards / flags at the end of the call
     int open_loop;          // ignore `actions`; track the reference clip (stream A1 of SURVEY 8d)
     float* amp_obs;         // N x amp size  RecordAMPObsAgent at the end of the call (imitate_amp scenes only)
+    int end_early;          // stop an env's updates at the update after which its episode is over (DM_END_EPISODE_EARLY)
 };
 
 // Debug taps for component parity tests (device pointers, null when unused)

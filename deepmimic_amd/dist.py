@@ -78,9 +78,14 @@ class RecordExchange:
     each travel on their own links, there is no ring to bound.  On gloo (CPU tests) the same calls run synchronously.
     """
 
-    def __init__(self, n: int, S: int, world: int, device, depth: int = 2):
+    def __init__(self, n: int, S: int, world: int, device, depth: int = 2, env: Optional[BatchEnv] = None):
         import torch
         self.n, self.S, self.world, self.depth = n, S, world, depth
+        # The collective is ordered after the work on torch's CURRENT stream; the step kernel that fills the buffer must run on
+        # that stream too.  A BatchEnv runs on its own non-blocking stream unless told otherwise, so pass it here (or call
+        # env.set_stream(torch.cuda.current_stream().cuda_stream) yourself): without it the gather races the step kernel.
+        if env is not None and torch.device(device).type == "cuda":
+            env.set_stream(torch.cuda.current_stream(device).cuda_stream)
         self.chunk = n * S + 2 * n
         self.local = [torch.zeros(self.chunk, dtype=torch.float32, device=device) for _ in range(depth)]
         self.all = [torch.zeros(world * self.chunk, dtype=torch.float32, device=device) for _ in range(depth)]
@@ -120,6 +125,55 @@ class RecordExchange:
         """(states [world,n,S], rewards [world,n], terminate [world,n] i32): global env id = rank * n + i."""
         import torch
         self.wait(slot)
+        a = self.all[slot].view(self.world, self.chunk)
+        n, S = self.n, self.S
+        return a[:, :n * S].unflatten(1, (n, S)), a[:, n * S:n * S + n], a[:, n * S + n:].view(torch.int32)
+
+
+class CabiRecordExchange:
+    """The same double-buffered exchange through the C-ABI (dm_comm_* / dm_gather_records, include/dm_hip.h): RCCL is driven by
+    libdm_hip.so on its own stream, ordered against the env's stream by HIP events -- no torch collective on the data path.
+    torch is used for the device buffers and, when a process group exists, to ship rank 0's unique id (the bootstrap a C++ host
+    would do with MPI_Bcast)."""
+
+    def __init__(self, env: BatchEnv, world: int, rank: int, device, depth: int = 2, force_rccl: bool = False):
+        import torch
+        from .core import Comm
+        assert 1 <= depth <= 4
+        self.env, self.world, self.rank, self.depth = env, world, rank, depth
+        self.n, self.S = env.N, env.S
+        self.chunk = self.n * self.S + 2 * self.n
+        self.local = [torch.zeros(self.chunk, dtype=torch.float32, device=device) for _ in range(depth)]
+        self.all = [torch.zeros(world * self.chunk, dtype=torch.float32, device=device) for _ in range(depth)]
+        uid = None
+        if world > 1 or force_rccl:
+            import torch.distributed as dist
+            box = [Comm.unique_id() if rank == 0 else None]
+            if world > 1:
+                dist.broadcast_object_list(box, src=0)
+            uid = box[0]
+        self.comm = Comm(world, rank, device_id=torch.device(device).index or 0, unique_id=uid)
+
+    def views(self, slot: int):
+        import torch
+        b = self.local[slot]
+        n, S = self.n, self.S
+        return b[:n * S].view(n, S), b[n * S:n * S + n], b[n * S + n:].view(torch.int32)
+
+    def begin(self, slot: int):
+        self.comm.wait(self.env, slot)        # the env stream waits for the gather of step k - depth before overwriting the buffer
+        return self.views(slot)
+
+    def launch(self, slot: int):
+        self.comm.gather(self.env, slot, self.local[slot].data_ptr(), self.all[slot].data_ptr(), self.chunk)
+
+    def wait(self, slot: int):
+        self.comm.wait(self.env, slot)
+
+    def result(self, slot: int):
+        import torch
+        self.wait(slot)
+        self.env.synchronize()
         a = self.all[slot].view(self.world, self.chunk)
         n, S = self.n, self.S
         return a[:, :n * S].unflatten(1, (n, S)), a[:, n * S:n * S + n], a[:, n * S + n:].view(torch.int32)

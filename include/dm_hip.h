@@ -58,9 +58,14 @@ typedef struct {
     int enable_amp_obs_local_root;   /* --enable_amp_obs_local_root (SceneImitateAMP.cpp:30,42) */
 } dm_scene_tables;
 
-enum { DM_DEVICE_PTRS = 1, DM_AUTO_RESET = 2, DM_OPEN_LOOP = 4, DM_NO_EMIT = 8 };
+/* DM_END_EPISODE_EARLY: an env whose episode is over after update u of the call (fall contact, clip end, episode timer) takes no
+ * further updates in this call -- the reference's driver checks IsEpisodeEnd after EVERY Update and ends the episode there
+ * (DeepMimic.py:62-80), so the terminal reward / state are those of that moment, not of the next action boundary. */
+enum { DM_DEVICE_PTRS = 1, DM_AUTO_RESET = 2, DM_OPEN_LOOP = 4, DM_NO_EMIT = 8, DM_END_EPISODE_EARLY = 16 };
 
 const char* dm_last_error(void);
+/* 0 for libdm_hip.so; 1 for the CPU fiber-emulator build of the same sources (tests/emu, test infrastructure) */
+int dm_is_emulator(void);
 
 /* cDeepMimicCore ctor + ParseArgs + Init  (DeepMimicCore.cpp:9-54) */
 int dm_create(const dm_create_info* info, const dm_scene_tables* tables, dm_ctx** out);
@@ -131,6 +136,23 @@ int dm_get_debug(dm_ctx* ctx, const char* name, double* out);
  * milliseconds of the timed region in *elapsed_ms. */
 int dm_bench_rollout(dm_ctx* ctx, int warmup, int steps, double timestep, int n_updates, int flags,
                      float* states_dev, float* rewards_dev, double* elapsed_ms);
+
+/* ---- Multi-GPU: one process per GPU, env shards are independent; the only exchange is the all-gather of the
+ * learner record {state[S], reward, terminate} once per control step, RCCL over xGMI.  For hosts that stay in C/C++ (the
+ * reference's own launcher is `mpiexec -n W`, mpi_run.py:16-24); deepmimic_amd/dist.py is the torch.distributed mirror.
+ * Bootstrap is the caller's: rank 0 calls dm_comm_unique_id, ships the 128 bytes to the other ranks by its own means (MPI_Bcast,
+ * a file, a torch store) and every rank calls dm_comm_create (= ncclCommInitRank).  librccl is loaded lazily (dlopen) by these
+ * calls only; world == 1 with a NULL unique id needs no RCCL at all (the gather is a device copy). */
+typedef struct dm_comm dm_comm;
+int dm_comm_unique_id(void* out_128_bytes);
+int dm_comm_create(const void* unique_id_128_bytes, int world, int rank, int device_id, dm_comm** out);
+int dm_comm_destroy(dm_comm* comm);
+/* All-gather `count` floats per rank: recv_dev[r * count ..] = rank r's send_dev.  Enqueued on the comm's own stream, ordered after
+ * everything already enqueued on the ctx stream (an event, no host sync), so the caller can launch control step k+1 on the ctx
+ * stream right away: the collective overlaps it.  `slot` in [0, 4) names the event pair of this buffer (double buffering). */
+int dm_gather_records(dm_ctx* ctx, dm_comm* comm, int slot, const float* send_dev, float* recv_dev, size_t count);
+/* Make the ctx stream (not the host) wait for the gather last launched on `slot`; no-op when none is in flight. */
+int dm_gather_wait(dm_ctx* ctx, dm_comm* comm, int slot);
 
 /* ---- On-device policy inference: the actor of learning/pg_agent.py:141-188 with the net of
  * learning/nets/fc_2layers_1024units.py and the normalisers of learning/normalizer.py:95-102, on the matrix cores (bf16

@@ -331,7 +331,7 @@ double orc_rollout_auto_reset(void* h, int steps, int updates_per_step, double d
     auto t_beg = std::chrono::steady_clock::now();
     for (int k = 0; k < steps; ++k) {
         orc_kin_eval(h, s->kin.time, kp.data(), kv.data()); orc_pose_to_action(h, kp.data(), a.data()); s->set_action(a.data());
-        for (int u = 0; u < updates_per_step; ++u) s->update(dt);
+        for (int u = 0; u < updates_per_step; ++u) { s->update(dt); if (s->is_episode_end()) break; }   // the driver ends an episode at the update where it is over (DeepMimic.py:62-80)
         double r = s->calc_reward(); rsum += r; live += (r != 0.0);
         double st[512]; s->record_state(st);
         if (s->is_episode_end()) { s->reset(s->mo.duration() * rand01_(seed, (uint64_t)env_id, ep, 0), draw_timer(ep)); ++ep; resets += 1; }

@@ -6,6 +6,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+os.environ["DM_ALLOW_EMULATOR"] = "1"     # the CPU emulator build is loadable from the test harness only (deepmimic_amd/core.py)
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 

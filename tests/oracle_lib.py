@@ -257,3 +257,13 @@ class Oracle:
         secs = self.lib.orc_rollout_auto_reset(self.h, int(steps), int(updates_per_step), C.c_double(dt), C.c_uint64(int(seed)), int(env_id),
                                                C.c_double(t0), C.c_double(time_lim_min), C.c_double(time_lim_max), _d(stats))
         return secs, int(stats[0]), float(stats[1]), int(stats[2])
+
+    def control_step(self, n_updates=20, dt=1.0 / 600, end_early=True):
+        """n_updates scene updates; with end_early the loop stops after the update at which the episode is over, the way the
+        reference's driver does (DeepMimic.py:62-80).  Criteria as on the device (EnvSim::episode_over_now): terminate != Null
+        or the episode timer.  Returns the number of updates run."""
+        for u in range(n_updates):
+            self.update(dt)
+            if end_early and self.is_episode_end():
+                return u + 1
+        return n_updates

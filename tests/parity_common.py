@@ -391,8 +391,7 @@ def auto_reset_rollout_compare(name, precision, lib_path, steps, n, seed, wave_p
         for e, o in enumerate(oracles):
             kp, _, _ = o.kin_state()
             o.set_action(o.pose_to_action(kp))
-            for u in range(20):
-                o.update(DT)
+            o.control_step(20, DT)            # ends at the update where the episode is over, like the device with auto-reset
             r = o.calc_reward()
             dr[k, e] = abs(float(out["reward"][e]) - r)
             alive[k, e] = r != 0.0

@@ -85,3 +85,29 @@ def test_two_rank_gloo_matches_single_process(emu_lib, tmp_path):
     for k in range(2):
         o = sh.env.step(None, 1.0 / 600, 20, open_loop=True, auto_reset=True)
         assert np.array_equal(ex[k], sh.pack_record(o))
+
+
+def test_cabi_record_exchange_single_rank(emu_lib):
+    """dm_comm_create / dm_gather_records / dm_gather_wait (include/dm_hip.h) behind dist.CabiRecordExchange, one rank, emulator
+    build: the exchange must hand back exactly what the step wrote, double-buffered."""
+    import torch
+    from deepmimic_amd import model
+    from deepmimic_amd.core import BatchEnv
+    from deepmimic_amd.dist import CabiRecordExchange
+    os.environ["DM_HIP_LIB"] = emu_lib
+    try:
+        t = model.load_asset("humanoid3d_walk")
+        env = BatchEnv(t, 2, precision=64, lib_path=emu_lib, wave_packing=1, seed=3)
+        env.reset()
+        ex = CabiRecordExchange(env, 1, 0, "cpu", depth=2)
+        valid = torch.zeros(2, dtype=torch.int32); ends = torch.zeros(2, dtype=torch.int32)
+        for k in range(3):
+            slot = k & 1
+            st, rw, tm = ex.begin(slot)
+            env.step_device(0, st.data_ptr(), rw.data_ptr(), tm.data_ptr(), valid.data_ptr(), ends.data_ptr(), auto_reset=True, open_loop=True)
+            ex.launch(slot)
+            S_, R_, T_ = ex.result(slot)
+            assert torch.equal(S_[0], st) and torch.equal(R_[0], rw) and torch.equal(T_[0], tm)
+            assert float(rw.min()) > 0
+    finally:
+        del os.environ["DM_HIP_LIB"]

@@ -122,3 +122,13 @@ def test_auto_reset_mirrored_by_oracle(emu_lib):
     dr, ds, alive, resets, ok = pc.auto_reset_rollout_compare("humanoid3d_walk", 64, emu_lib, steps=14, n=2, seed=5, time_lim=0.2)
     assert ok and resets >= 4
     assert alive.all() and dr.max() < 1e-6 and ds.max() < 1e-5
+
+
+@pytest.mark.parametrize("pack", [1, 2])
+def test_episode_ends_at_the_update_of_the_fall(emu_lib, pack):
+    """DM_END_EPISODE_EARLY (on with auto-reset): the open-loop walker falls in the middle of a control step; the device stops
+    that env's updates there (one-per-wave: loop exit; two-per-wave: record stored, character parked, record reloaded), the
+    oracle's control_step does the same, and the terminal reward / flags / next observation agree.  Both wave packings."""
+    dr, ds, alive, resets, ok = pc.auto_reset_rollout_compare("humanoid3d_walk", 64, emu_lib, steps=36, n=2, seed=7, wave_packing=pack)
+    assert ok and resets >= 2, resets
+    assert dr.max() < 1e-6 and ds.max() < 1e-5, (dr.max(), ds.max())

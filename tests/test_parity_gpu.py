@@ -302,3 +302,34 @@ def test_action_stream_a2_noisy_tracking(hip_lib, name, pack):
     assert ok and dr.max() < 1e-5, (dr, ds)
     dr, ds, ok, _ = pc.action_rollout_compare(name, 32, hip_lib, 10, "A2", [0.0, 0.41], wave_packing=pack)
     assert ok and dr.max() < 1e-4, (dr, ds)
+
+
+def test_cabi_record_gather_through_rccl_one_rank(hip_lib):
+    """The C-ABI collective (dm_comm_create with a unique id -> ncclCommInitRank, dm_gather_records -> ncclAllGather on the
+    comm's own stream, ordered by HIP events) on the real RCCL with one rank; the step of control step k+1 is enqueued while
+    the gather of step k is in flight."""
+    import torch
+    from deepmimic_amd.dist import CabiRecordExchange
+    t = model.load_asset("humanoid3d_walk")
+    n = 256
+    env = BatchEnv(t, n, seed=5)
+    env.reset()
+    dev = torch.device("cuda", 0)
+    ex = CabiRecordExchange(env, 1, 0, dev, depth=2, force_rccl=True)
+    valid = torch.zeros(n, dtype=torch.int32, device=dev); ends = torch.zeros(n, dtype=torch.int32, device=dev)
+    keep = []
+    for k in range(6):
+        slot = k & 1
+        st, rw, tm = ex.begin(slot)
+        env.step_device(0, st.data_ptr(), rw.data_ptr(), tm.data_ptr(), valid.data_ptr(), ends.data_ptr(), auto_reset=True, open_loop=True)
+        ex.launch(slot)
+        if k >= 1:
+            S_, R_, T_ = ex.result((k - 1) & 1)
+            keep.append((S_[0].clone(), R_[0].clone()))
+    env.synchronize(); torch.cuda.synchronize()
+    # reference: the same rollout without the exchange
+    env2 = BatchEnv(t, n, seed=5)
+    env2.reset()
+    for k in range(5):
+        out = env2.step(None, pc.DT, 20, open_loop=True, auto_reset=True)
+        assert np.array_equal(keep[k][0].cpu().numpy(), out["state"]) and np.array_equal(keep[k][1].cpu().numpy(), out["reward"])

@@ -52,6 +52,14 @@ for k in range(steps):
 torch.cuda.synchronize(); dt = time.perf_counter() - t0
 out["closed_loop_env_steps_per_s"] = n * steps / dt; out["closed_loop_ms_per_step"] = 1e3 * dt / steps
 out["mean_reward"] = float(rw.mean().item())
+# the same loop with every env simulated to the action boundary even after its episode ended (DM_END_EPISODE_EARLY off): what the
+# heavy-contact tail of fallen characters costs
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for k in range(steps):
+    pol.forward_device(st.data_ptr(), n, ac.data_ptr(), 0, sample=True, seed=1, step=k, stream=stream)
+    env.step_device(ac.data_ptr(), st.data_ptr(), rw.data_ptr(), tm.data_ptr(), vd.data_ptr(), en.data_ptr(), auto_reset=True, end_early=False)
+torch.cuda.synchronize(); dt = time.perf_counter() - t0
+out["closed_loop_no_early_end_env_steps_per_s"] = n * steps / dt
 # same closed loop with the manifold cap lowered to 9 contacts per character (dm_create_info.max_contacts): rows <= 4 + 27 < 32, so
 # no pair ever leaves the two-per-wave register path
 env9 = BatchEnv(t, n, seed=1, max_contacts=9)

@@ -53,6 +53,8 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib = C.CDLL(path)
     # the CPU fiber-emulator build of the same sources (tests/emu) is test infrastructure: the product refuses it unless the test
     # harness says so, so that no environment variable alone can turn the shipped path into a CPU path
+    if not hasattr(lib, "dm_is_emulator"):
+        raise RuntimeError("%s does not export dm_is_emulator: stale build, rebuild with __graft_entry__.build()" % path)
     if lib.dm_is_emulator() and os.environ.get("DM_ALLOW_EMULATOR") != "1":
         raise RuntimeError("%s is the CPU emulator build (test infrastructure); deepmimic_amd runs on the HIP library only" % path)
     lib.dm_last_error.restype = C.c_char_p

@@ -258,7 +258,8 @@ struct Lds {
     Real kin[8];                           // kin origin pos(3), origin rot(4)
     Real sc[8];                            // small float scratch (kin / sim COM velocity, episode-end flag)
     double clk[6];                         // kin_time, ctrl_time, init_time_offset, timer_time, timer_max
-    int flg[8];                            // need_new_action, contact_mask, episode_count, valid, nrows, ncontacts
+    int flg[8];                            // need_new_action, contact_mask, episode_count, valid, nrows, ncontacts, parked, over
+    int fall_mask;                         // links whose ground contact is a fall (bit j), from link_info at load
 };
 
 // What the end-of-call outputs need of a character whose episode ended mid-call (two characters per wavefront, early episode end)
@@ -266,7 +267,7 @@ template <typename Real, typename C>
 struct ParkSnap { Real pose[C::NP], vel[C::NP], kin[8]; double clk[6]; int flg[4]; };
 
 enum { CLK_KIN = 0, CLK_CTRL, CLK_INIT_OFF, CLK_TIMER, CLK_TIMER_MAX };
-enum { FLG_NEED_ACTION = 0, FLG_CONTACT, FLG_EPISODE, FLG_VALID, FLG_NROWS, FLG_NCONT, FLG_PARKED };
+enum { FLG_NEED_ACTION = 0, FLG_CONTACT, FLG_EPISODE, FLG_VALID, FLG_NROWS, FLG_NCONT, FLG_PARKED, FLG_OVER };
 
 // TAPS = false compiles every debug tap / phase timer out of the instruction stream (production step kernel).
 // LW = lanes per character: 64 (one character per wavefront) or 32 (two characters per wavefront, dm_device_duo.h).
@@ -313,6 +314,7 @@ struct EnvSim {
         if (LW == kWave) load_cands();
         sync();
         li = (l < m.J) ? s.mdl.link_info[l] : 0;
+        if (l == 0) { int fm = 0; for (int j = 0; j < m.J; ++j) fm |= DM_LI_FALL(s.mdl.link_info[j]) << j; s.fall_mask = fm; }
     }
     DM_DEV void load(const EnvState<Real>& st, int e) {
         load_model();
@@ -1154,6 +1156,7 @@ struct EnvSim {
             double cur = s.clk[CLK_CTRL] + s.clk[CLK_INIT_OFF], pad = 0.001 * dt;
             int c1 = (int)floor((cur + pad) / m.query_period), c0 = (int)floor((cur + pad - dt) / m.query_period);
             s.flg[FLG_NEED_ACTION] = (c1 != c0) ? 1 : 0;
+            s.flg[FLG_OVER] = episode_over_now() ? 1 : 0;      // read by the step kernels when DM_END_EPISODE_EARLY is set
         }
         sync();
     }
@@ -1161,7 +1164,7 @@ struct EnvSim {
     // ------------------------------------------------------------------ termination
     DM_DEV bool has_fallen(const Real* kp) const {
         bool f = false;
-        if (m.enable_contact_fall) { int cm = s.flg[FLG_CONTACT]; for (int j = 0; j < m.J; ++j) if (DM_LI_FALL(s.mdl.link_info[j]) && ((cm >> j) & 1)) f = true; }
+        if (m.enable_contact_fall) f = (s.flg[FLG_CONTACT] & s.fall_mask) != 0;
         if (m.enable_root_rot_fail && kp) f = f || (quat_theta(qmul(ldq(kp + 3), qconj(ldq(s.pose + 3)))) > (Real)(0.5 * DM_PI));
         return f;
     }
@@ -1470,7 +1473,7 @@ __global__ void __launch_bounds__(64) DM_WAVES_PER_EU((StepWaves<Real, C>::value
     for (int u = 0; u < io.n_updates; ++u) {
         if (HIST && st.hist) sim.latch_hist(st, e);
         sim.update(io.dt, dbg, e, aovf);
-        if (io.end_early && sim.episode_over_now()) break;      // wave-uniform: the flags and clocks are in LDS
+        if (io.end_early && lds.flg[FLG_OVER]) break;           // wave-uniform: latched by lane 0 at the end of update()
     }
     if (io.emit) {
         // pass 0 writes reward / flags / observation.  With auto-reset (mirrors DeepMimic.py:70-79) an env whose episode

@@ -634,16 +634,9 @@ _Pragma("unroll") \
             double cur = s.clk[CLK_CTRL] + s.clk[CLK_INIT_OFF], pad = 0.001 * dt;
             int c1 = (int)floor((cur + pad) / m.query_period), c0 = (int)floor((cur + pad - dt) / m.query_period);
             s.flg[FLG_NEED_ACTION] = (c1 != c0) ? 1 : 0;
+            s.flg[FLG_OVER] = b.episode_over_now() ? 1 : 0;
         }
         sync();
-    }
-    // after an update with DM_END_EPISODE_EARLY: true when both characters are done
-    DM_DEV bool end_early_step(ParkSnap<Real, C>& snap) {
-        const bool parked = s.flg[FLG_PARKED] != 0;
-        const bool over = parked || b.episode_over_now();
-        if (wave_ballot(over) == ~(uint64_t)0) return true;
-        if (wave_ballot(over && !parked) != 0) b.park(snap, over && !parked);     // wave-uniform branch; the partner's lanes only pass the barriers
-        return false;
     }
 };
 
@@ -664,23 +657,22 @@ __global__ void __launch_bounds__(64) DM_WAVES_PER_EU((DuoWaves<Real>::value)) k
     else if (io.actions) sim.b.set_action(io.actions + (size_t)e * m.A);
     sim.b.mark(15);
     Real* aovf_pair = st.aovf ? st.aovf + (size_t)(2 * blockIdx.x) * (kMaxRows - ClsBiped::RREG) * kWave : nullptr;
-    int u = 0;
-    for (; u < io.n_updates; ++u) {
-        if (HIST && st.hist) sim.b.latch_hist(st, e);
+    for (int u = 0; u < io.n_updates; ++u) {
+        if (HIST && st.hist) sim.b.latch_hist(st, e, lds[half].flg[FLG_PARKED] == 0);
         sim.update(io.dt, e, aovf_pair);
-        // DM_END_EPISODE_EARLY: leave the hot loop as soon as either character's episode is over (EnvSim::episode_over_now)
-        if (io.end_early && wave_ballot(sim.b.episode_over_now()) != 0) break;
-    }
-    if (u < io.n_updates) {
-        // Rare tail (a few percent of the waves of a launch): a character whose episode is over has what the outputs need of its
-        // record copied aside (LDS) and is parked, the partner finishes its updates, the copy comes back before the outputs.
-        for (;;) {
-            if (sim.end_early_step(snap[half]) || ++u >= io.n_updates) break;
-            if (HIST && st.hist) sim.b.latch_hist(st, e, lds[half].flg[FLG_PARKED] == 0);
-            sim.update(io.dt, e, aovf_pair);
+        if (io.end_early) {
+            // DM_END_EPISODE_EARLY.  FLG_OVER is latched by each character's lane 0 at the end of update() (wave-uniform reads).
+            // Both over: the wave is done.  One over (a few percent of the waves of a launch): what the outputs need of its record
+            // is copied aside (LDS) and the character is parked; the copy comes back before the outputs are written.
+            const int o0 = lds[0].flg[FLG_OVER] | lds[0].flg[FLG_PARKED], o1 = lds[1].flg[FLG_OVER] | lds[1].flg[FLG_PARKED];
+            if (o0 & o1) break;
+            if ((o0 & ~lds[0].flg[FLG_PARKED]) | (o1 & ~lds[1].flg[FLG_PARKED])) {
+                const bool now = lds[half].flg[FLG_OVER] != 0 && lds[half].flg[FLG_PARKED] == 0;
+                sim.b.park(snap[half], now);
+            }
         }
-        sim.b.unpark(snap[half]);
     }
+    if (io.end_early) sim.b.unpark(snap[half]);
     if (io.emit) {
         DebugTaps<Real> tap = DebugTaps<Real>();
         sim.b.emit(io, tap, e, true);

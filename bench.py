@@ -104,6 +104,45 @@ def cpu_baseline(scene, budget_s=12.0):
         return {"value": None, "unit": "env-steps/s", "cores": 1, "kind": "port", "sample": "failed: %r" % (ex,)}
 
 
+def facade_bench(scene, steps):
+    """The drop-in path the reference's trainer uses: ONE env per cDeepMimicCore, driven by the reference's update_world loop
+    (DeepMimic.py:62-80: NeedNewAction / RecordState / CalcReward / SetAction once per 1/30 s; Update, CheckValidEpisode,
+    IsEpisodeEnd once per 1/600 s).  Reports env-steps/s of one worker with the control step batched into one launch
+    (DM_FACADE_BATCH=1, default) and update by update."""
+    sys.path.insert(0, os.path.join(ROOT, "deepmimic_amd", "compat"))
+    from DeepMimicCore import DeepMimicCore
+    from deepmimic_amd import model
+    t = model.load_asset(scene)
+    out = {}
+    for tag, batch in (("batched", "1"), ("per_update", "0")):
+        os.environ["DM_FACADE_BATCH"] = batch
+        core = DeepMimicCore.cDeepMimicCore(False)
+        core.SeedRand(1); core.LoadTables(t, 10); core.Init()
+        rng = np.random.default_rng(0)
+        A, dt = core.GetActionSize(0), 1.0 / 600
+        lo, hi = np.array(core.BuildActionBoundMin(0)), np.array(core.BuildActionBoundMax(0))
+
+        def run(n_steps):
+            n = 0
+            while n < n_steps:
+                if core.NeedNewAction(0):
+                    core.RecordState(0); core.RecordGoal(0); core.CalcReward(0)
+                    core.SetAction(0, [float(x) for x in np.clip(0.1 * rng.normal(size=A), lo, hi)]); n += 1
+                core.Update(dt)
+                if (not core.CheckValidEpisode()) or core.IsEpisodeEnd():
+                    core.RecordState(0); core.CalcReward(0); core.CheckTerminate(0)
+                    core.Reset()
+        run(20)
+        core.stats.update(launches=0, updates=0, rollbacks=0)
+        t0 = time.perf_counter(); run(steps); el = time.perf_counter() - t0
+        out[tag] = {"env_steps_per_s": steps / el, "ms_per_control_step": 1e3 * el / steps, "launches_per_control_step": core.stats["launches"] / steps,
+                    "updates_per_control_step": core.stats["updates"] / steps}
+        core.Shutdown()
+    print(json.dumps({"metric": "facade env-steps/s, one env per cDeepMimicCore (%s)" % scene, "value": out["batched"]["env_steps_per_s"],
+                      "unit": "env-steps/s", "n_gpus": 1, "steps": steps, "higher_is_better": True, "dtype": "f32", "data": "synthetic",
+                      "config": {"workload": "%s, 1 env, reference driver protocol, random actions N(0, 0.1^2), auto reset by the driver" % scene}, **out}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -116,6 +155,7 @@ def main():
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--force-gather", action="store_true", help="exercise the record exchange even with one rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--facade", action="store_true", help="measure the single-env cDeepMimicCore facade path instead of the batched env")
     ap.add_argument("--cpu-baseline-worker", type=int, default=None, help=argparse.SUPPRESS)
     ap.add_argument("--cpu-budget", type=float, default=12.0, help=argparse.SUPPRESS)
     ap.add_argument("--min-warmup", type=int, default=60,
@@ -124,6 +164,9 @@ def main():
     args = ap.parse_args()
     if args.cpu_baseline_worker is not None:
         cpu_baseline_worker(args.scene, args.cpu_baseline_worker, args.cpu_budget)
+        return
+    if args.facade:
+        facade_bench(args.scene, min(args.steps, 300))
         return
 
     import torch

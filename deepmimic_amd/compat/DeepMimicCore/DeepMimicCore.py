@@ -12,6 +12,20 @@ one env (``dm_ctx`` with ``num_envs = 1``) on the GPU given by ``DM_DEVICE`` (de
 thousands of envs per GPU, one kernel launch per control step -- is ``deepmimic_amd.core.BatchEnv`` /
 ``include/dm_hip.h:dm_step_batch``.
 
+Launch economy.  The reference's driver (DeepMimic.py:62-80, learning/rl_world.py) calls, per 1/600 s update:
+``NeedNewAction`` -> ``Update`` -> ``CheckValidEpisode`` -> ``IsEpisodeEnd``, and ``RecordState / CalcReward / SetAction``
+once per 1/30 s.  Served naively that is >= 2 kernel launches and 3 device round trips per update.  Here:
+* ``NeedNewAction`` and ``GetTime`` are answered from a host mirror of the controller / timer clocks (same double arithmetic
+  as cMathUtil::CheckNextInterval), no device traffic;
+* ``Update`` is one fused launch (update + RecordState / CalcReward / flags), the following queries read its outputs;
+* with ``DM_FACADE_BATCH`` (default on) the first ``Update`` after a ``SetAction`` runs the whole control step -- all updates up
+  to the next action boundary, ending early at the update where the episode is over -- in ONE launch; the driver's following
+  ``Update`` calls of the same timestep only advance a host counter and its per-update ``IsEpisodeEnd / CheckValidEpisode``
+  questions are answered from that launch's outcome.  A call that needs the state of an intermediate update (``RecordState``
+  mid-step, a different timestep, a ``SetAction`` mid-step) rolls the env back to the snapshot taken before the launch and
+  replays update by update, so results never depend on the batching.  (``CheckValidEpisode`` is evaluated at the end of the
+  launch: a velocity explosion is reported at the step's last update instead of the update it first occurred at.)
+
 Errors: the reference ``assert(false)``s (DeepMimicCore.cpp:36-40); this module raises ``RuntimeError`` instead.
 """
 import os
@@ -76,8 +90,10 @@ class cDeepMimicCore(object):
                               precision=int(os.environ.get("DM_PRECISION", "32")), lib_path=os.environ.get("DM_HIP_LIB"))
         self._off = self._env.offsets_scales()
         self._apply_mode()
-        self._env.reset()
-        self._cache = None
+        self._batch = os.environ.get("DM_FACADE_BATCH", "1") != "0"
+        self._period = 1.0 / float(self._tables.query_rate)
+        self.stats = {"launches": 0, "updates": 0, "rollbacks": 0}     # kernel launches of the stepping path vs Update() calls
+        self._after_reset()
 
     def _apply_mode(self):
         lo, hi = _model.timer_limits(self._tables.cfg, self._mode == self.eModeTest, self._sample_count)
@@ -88,22 +104,104 @@ class cDeepMimicCore(object):
             raise RuntimeError("cDeepMimicCore: Init() has not been called")
         return self._env
 
+    # ---- stepping engine ------------------------------------------------------------------------------------------------
+    def _after_reset(self):
+        self._env.reset()
+        self._sync_clocks()
+        self._need = True                  # cDeepMimicCharController::Reset leaves NeedNewAction() == true
+        self._pending = None               # action handed over by SetAction, applied by the next launch
+        self._spec = None                  # outcome of a whole-control-step launch being consumed update by update
+        self._cache = None
+
+    def _sync_clocks(self):
+        c = self._env.get_state()["clocks"][0]
+        self._clk = {"ctrl": float(c[1]), "off": float(c[2]), "timer": float(c[3])}
+
+    def _advance_clocks(self, dt):
+        """host mirror of one update: timers += dt, then cCtController::CheckNeedNewAction (CtController.cpp:221-227)"""
+        self._clk["ctrl"] += dt; self._clk["timer"] += dt
+        cur, pad = self._clk["ctrl"] + self._clk["off"], 0.001 * dt
+        self._need = int(np.floor((cur + pad) / self._period)) != int(np.floor((cur + pad - dt) / self._period))
+
+    def _updates_to_next_action(self, dt, cap=64):
+        ctrl, off = self._clk["ctrl"], self._clk["off"]
+        for k in range(1, cap + 1):
+            ctrl += dt
+            cur, pad = ctrl + off, 0.001 * dt
+            if int(np.floor((cur + pad) / self._period)) != int(np.floor((cur + pad - dt) / self._period)):
+                return k
+        return cap
+
+    def _launch(self, action, dt, n, end_early):
+        self.stats["launches"] += 1
+        return self._env.step(action, dt, n, end_early=end_early)
+
+    def _virtual(self):
+        """inside a consumed-in-advance control step, before its last executed update"""
+        return self._spec is not None and self._spec["v"] < self._spec["n_done"]
+
+    def _materialize(self):
+        """A caller needs the env AT an intermediate update of a batched control step: roll back to the snapshot taken before the
+        launch and replay the updates one by one (exactly what the unbatched path would have run)."""
+        sp = self._spec
+        self._spec = None
+        self.stats["rollbacks"] += 1
+        snap = sp["snap"]
+        self._env.set_state(pose=snap["pose"], vel=snap["vel"], tar=snap["tar"], kin=snap["kin"], clocks=snap["clocks"], flags=snap["flags"])
+        self._clk = dict(sp["clk0"])
+        out = None
+        for i in range(sp["v"]):
+            out = self._launch(sp["action"] if i == 0 else None, sp["dt"], 1, False)
+            self._advance_clocks(sp["dt"])
+        self._cache = out
+
     def _query(self):
+        if self._virtual():
+            self._materialize()
         if self._cache is None:
             self._cache = self._need_env().query()
         return self._cache
 
     # ---- stepping (DeepMimicCore.cpp:56-65)
     def Update(self, timestep):
-        self._need_env().update(float(timestep), 1)
-        self._cache = None
+        env = self._need_env()
+        dt = float(timestep)
+        self.stats["updates"] += 1
+        if not dt > 0:
+            return                           # cImpPDController::UpdateControlForce ignores non-positive steps
+        sp = self._spec
+        if sp is not None:
+            if sp["v"] < sp["n_done"] and dt == sp["dt"]:
+                sp["v"] += 1                 # this update already ran on the device
+                self._advance_clocks(dt)
+                self._cache = sp["out"] if sp["v"] == sp["n_done"] else None
+                return
+            if sp["v"] < sp["n_done"]:
+                self._materialize()          # a different timestep mid-step
+            self._spec = None
+        action, self._pending = self._pending, None
+        k = self._updates_to_next_action(dt) if (self._batch and action is not None) else 1
+        if k > 1:
+            snap = env.get_state()
+            clk0 = dict(self._clk)
+            out = self._launch(action, dt, k, True)
+            t1 = float(env.get_state()["clocks"][0][3])
+            n_done = max(1, min(k, int(round((t1 - clk0["timer"]) / dt))))
+            self._spec = {"snap": snap, "clk0": clk0, "action": action, "dt": dt, "k": k, "n_done": n_done, "v": 1, "out": out}
+            self._advance_clocks(dt)
+            self._cache = out if n_done == 1 else None
+        else:
+            self._cache = self._launch(action, dt, 1, False)
+            self._advance_clocks(dt)
 
     def Reset(self):
-        self._need_env().reset()
-        self._cache = None
+        self._need_env()
+        self._spec = None
+        self._after_reset()
 
     def GetTime(self):
-        return float(self._need_env().get_state()["clocks"][0][3])
+        self._need_env()
+        return float(self._clk["timer"])      # cScene::GetTime: the episode timer (host mirror, no device round trip)
 
     def GetName(self):
         # cSceneImitate::GetName (scenes/SceneImitate.cpp:207-210), cSceneImitateAMP::GetName (SceneImitateAMP.cpp:208-211)
@@ -170,7 +268,8 @@ class cDeepMimicCore(object):
 
     def NeedNewAction(self, agent_id):
         self._chk_agent(agent_id)
-        return bool(self._query()["need_new_action"][0])
+        self._need_env()
+        return bool(self._need)
 
     def RecordState(self, agent_id):
         self._chk_agent(agent_id)
@@ -185,8 +284,10 @@ class cDeepMimicCore(object):
         a = np.asarray(action, dtype=np.float32).reshape(1, -1)
         if a.shape[1] != self._env.A:
             raise RuntimeError("SetAction: expected %d values, got %d" % (self._env.A, a.shape[1]))
-        self._env.set_action(a)
-        self._cache = None
+        if self._virtual():
+            self._materialize()             # an action mid-step: leave the batched step at this update
+        self._spec = None
+        self._pending = a                   # applied by the launch of the next Update (cDeepMimicCharController::ApplyAction happens before it)
 
     def LogVal(self, agent_id, val):
         pass
@@ -272,6 +373,8 @@ class cDeepMimicCore(object):
         if not self._is_amp():
             return []
         self._chk_agent(agent_id)
+        if self._virtual():
+            self._materialize()
         return [float(x) for x in self._need_env().query_amp()[0]]
 
     def RecordAMPObsExpert(self, agent_id):
@@ -281,23 +384,39 @@ class cDeepMimicCore(object):
             return []
         self._chk_agent(agent_id)
         env = self._need_env()
+        if self._virtual():
+            self._materialize()
         gh = float(env.get_state()["kin"][0][1])
         return [float(x) for x in env.amp_expert(1, None, gh)[0]]
 
     def IsEpisodeEnd(self):
+        if self._virtual():
+            return False                    # the batched launch stops at the update where the episode is over: not yet
         return bool(self._query()["episode_end"][0])
 
     def CheckValidEpisode(self):
+        if self._virtual():
+            return True
         return bool(self._query()["valid"][0])
 
     def CheckTerminate(self, agent_id):
         self._chk_agent(agent_id)
+        if self._virtual():
+            return 0                        # eTerminateNull
         return int(self._query()["terminate"][0])
 
     def SetMode(self, mode):
         self._mode = int(mode)
         if self._env is not None:
             self._apply_mode()
+        if self._mode == self.eModeTest and self._is_amp() and getattr(self._tables.cfg, "enable_test_time_warp", True) and not getattr(self, "_warned_tw", False):
+            # cSceneImitateAMP::CalcReward returns the dynamic-time-warping alignment cost of the episode in test mode
+            # (SceneImitateAMP.cpp:173-205); that evaluation-only score is not computed here: CalcReward stays 0.
+            import warnings
+            warnings.warn("imitate_amp test mode: the time-warp test return (cSceneImitateAMP::CalcRewardTimeWarp) is not computed on "
+                          "the MI355X path; CalcReward() returns 0 -- logged test returns of an AMP agent are not meaningful "
+                          "(pass --enable_test_time_warp false to silence)", RuntimeWarning, stacklevel=2)
+            self._warned_tw = True
 
     def SetSampleCount(self, count):
         """cRLSceneSimChar::SetSampleCount (scenes/RLSceneSimChar.cpp:223-227): anneals the episode-length limits."""

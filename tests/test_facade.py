@@ -158,3 +158,56 @@ def test_timer_annealing_follows_sample_count(emu_lib, monkeypatch):
     core.SetMode(1)                                                    # eModeTest
     core.Reset()
     assert core._env.get_state()["clocks"][0][4] == pytest.approx(20.0)
+
+
+def _drive(core, n_updates, seed, peek_at=()):
+    """the reference driver's loop (DeepMimic.py:62-80): returns everything it observed"""
+    rng = np.random.default_rng(seed)
+    dt, seen = 1.0 / 600, []
+    for u in range(n_updates):
+        if core.NeedNewAction(0):
+            seen.append(("s", np.array(core.RecordState(0)), core.CalcReward(0)))
+            core.SetAction(0, [float(x) for x in (0.2 * rng.normal(size=core.GetActionSize(0))).astype(np.float32)])
+        core.Update(dt)
+        if u in peek_at:                                   # a caller that looks at an intermediate update of the control step
+            seen.append(("p", np.array(core.RecordState(0)), core.CalcReward(0)))
+        valid, end = core.CheckValidEpisode(), core.IsEpisodeEnd()
+        seen.append(("f", valid, end, core.CheckTerminate(0), core.GetTime()))
+        if not valid or end:
+            seen.append(("e", np.array(core.RecordState(0)), core.CalcReward(0)))
+            core.Reset()
+    return seen
+
+
+def _same(a, b):
+    assert len(a) == len(b)
+    for x, y in zip(a, b):
+        assert x[0] == y[0]
+        if x[0] == "f":
+            assert x[1:4] == y[1:4] and abs(x[4] - y[4]) < 1e-12, (x, y)
+        else:
+            assert np.array_equal(x[1], y[1]) and x[2] == y[2]
+
+
+def test_batched_control_step_equals_update_by_update(emu_lib, monkeypatch):
+    """DM_FACADE_BATCH: one launch per control step (+ rollback / replay when a caller looks inside the step) gives bit-identical
+    observations, rewards, flags and clock to one launch per update; the open-loop-ish random actions make the walker fall, so the
+    early episode end and the reset path are exercised too."""
+    from deepmimic_amd import model
+    mod = _core_module()
+    monkeypatch.setenv("DM_HIP_LIB", emu_lib); monkeypatch.setenv("DM_PRECISION", "64")
+    t = model.load_asset("humanoid3d_walk")
+    t.cfg.time_lim_min = t.cfg.time_lim_max = t.cfg.time_end_lim_min = t.cfg.time_end_lim_max = 0.175   # the episode timer ends inside a control step (update 105; 20 per step)
+    runs = {}
+    for batch in ("1", "0"):
+        monkeypatch.setenv("DM_FACADE_BATCH", batch)
+        core = mod.cDeepMimicCore(False)
+        core.SeedRand(4); core.LoadTables(t, 10); core.Init()
+        runs[batch] = (_drive(core, 260, seed=3, peek_at=(47, 131)), dict(core.stats))
+        core.Shutdown()
+    _same(runs["1"][0], runs["0"][0])
+    sb, su = runs["1"][1], runs["0"][1]
+    assert su["launches"] == su["updates"] == 260
+    assert sb["rollbacks"] == 2
+    assert sb["launches"] <= 260 // 20 + 2 + 2 * 20 + 4, sb          # ~1 per control step, + the two replays
+    assert any(x[0] == "e" for x in runs["1"][0])                    # an episode ended inside the window

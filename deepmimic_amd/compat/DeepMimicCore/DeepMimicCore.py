@@ -205,10 +205,14 @@ class cDeepMimicCore(object):
 
     def GetName(self):
         # cSceneImitate::GetName (scenes/SceneImitate.cpp:207-210), cSceneImitateAMP::GetName (SceneImitateAMP.cpp:208-211)
-        return "Imitate AMP" if self._is_amp() else "Imitate"
+        scene = self._tables.cfg.scene if self._tables is not None else "imitate"
+        return {"imitate_amp": "Imitate AMP", "target_amp": "Target AMP", "heading_amp": "Heading AMP"}.get(scene, "Imitate")
 
     def _is_amp(self):
-        return self._tables is not None and self._tables.cfg.scene == "imitate_amp"
+        return self._tables is not None and self._tables.cfg.scene in ("imitate_amp", "target_amp", "heading_amp")
+
+    def _goal_size(self):
+        return int(self._tables.goal_dim) if self._tables is not None else 0
 
     def EnableDraw(self):
         return False
@@ -277,7 +281,10 @@ class cDeepMimicCore(object):
 
     def RecordGoal(self, agent_id):
         self._chk_agent(agent_id)
-        return []                   # cRLSceneSimChar::RecordGoal: goal size 0 (scenes/RLSceneSimChar.cpp:64-68,88-91)
+        if not self._goal_size():
+            return []               # cRLSceneSimChar::RecordGoal: goal size 0 (scenes/RLSceneSimChar.cpp:64-68,88-91)
+        # cSceneTargetAMP::RecordGoal (SceneTargetAMP.cpp:195-223) / cSceneHeadingAMP::RecordGoal (SceneHeadingAMP.cpp:150-166)
+        return [float(x) for x in self._query()["goal"][0]]
 
     def SetAction(self, agent_id, action):
         self._chk_agent(agent_id)
@@ -299,7 +306,7 @@ class cDeepMimicCore(object):
         return int(self._need_env().S)
 
     def GetGoalSize(self, agent_id):
-        return 0
+        return self._goal_size()
 
     def GetActionSize(self, agent_id):
         return int(self._need_env().A)
@@ -314,10 +321,10 @@ class cDeepMimicCore(object):
         return [float(x) for x in self._off["state_scale"]]
 
     def BuildGoalOffset(self, agent_id):
-        return []
+        return [0.0] * self._goal_size()        # cRLSceneSimChar::BuildGoalOffsetScale (scenes/RLSceneSimChar.cpp:111-116)
 
     def BuildGoalScale(self, agent_id):
-        return []
+        return [1.0] * self._goal_size()
 
     def BuildActionOffset(self, agent_id):
         return [float(x) for x in self._off["action_offset"]]
@@ -335,7 +342,7 @@ class cDeepMimicCore(object):
         return [int(x) for x in self._off["state_norm_groups"]]
 
     def BuildGoalNormGroups(self, agent_id):
-        return []
+        return [0] * self._goal_size()          # cCharController::gNormGroupSingle (:136-140)
 
     def CalcReward(self, agent_id):
         self._chk_agent(agent_id)
@@ -354,7 +361,7 @@ class cDeepMimicCore(object):
         return 1.0
 
     def EnableAMPTaskReward(self):
-        return False
+        return self._goal_size() > 0            # cSceneTargetAMP::EnableAMPTaskReward (SceneTargetAMP.cpp:230-233)
 
     # ---- AMP observations (DeepMimicCore.h:75-81 -> scenes/SceneImitateAMP.cpp); empty for a plain imitate scene
     def GetAMPObsSize(self):
@@ -387,6 +394,8 @@ class cDeepMimicCore(object):
         if self._virtual():
             self._materialize()
         gh = float(env.get_state()["kin"][0][1])
+        if self._tables.num_clips > 1:           # SampleExpertMotion with a cClipsController: clip by weight, time within that clip
+            return [float(x) for x in env.amp_expert_clips(1, None, None, gh)[0]]
         return [float(x) for x in env.amp_expert(1, None, gh)[0]]
 
     def IsEpisodeEnd(self):

@@ -36,6 +36,11 @@ class _SceneTables(C.Structure):
         ("enable_phase_input", C.c_int), ("record_world_root_pos", C.c_int), ("record_world_root_rot", C.c_int),
         ("query_rate", C.c_double), ("friction", C.c_double), ("erp", C.c_double), ("solver_iters", C.c_int),
         ("disable_self_collision", C.c_int), ("scene_amp", C.c_int), ("enable_amp_obs_local_root", C.c_int),
+        ("scene_goal", C.c_int), ("rand_target_time_min", C.c_double), ("rand_target_time_max", C.c_double), ("max_target_dist", C.c_double),
+        ("target_succ_dist", C.c_double), ("tar_fail_dist", C.c_double), ("tar_speed", C.c_double), ("enable_min_tar_vel", C.c_int),
+        ("pos_reward_scale", C.c_double), ("max_heading_turn_rate", C.c_double), ("sharp_turn_prob", C.c_double), ("speed_change_prob", C.c_double),
+        ("tar_speed_min", C.c_double), ("tar_speed_max", C.c_double), ("vel_reward_scale", C.c_double),
+        ("num_clips", C.c_int), ("clip_starts", C.POINTER(C.c_int32)), ("clip_weights", C.POINTER(C.c_double)), ("clip_loops", C.POINTER(C.c_int32)),
     ]
 
 
@@ -113,7 +118,21 @@ class BatchEnv:
         st.record_world_root_rot = int(tables.record_world_root_rot); st.query_rate = float(tables.query_rate)
         st.friction = 0.0; st.erp = float(erp); st.solver_iters = 0
         st.disable_self_collision = 0 if self_collision else 1
-        st.scene_amp = int(c.scene == "imitate_amp"); st.enable_amp_obs_local_root = int(getattr(c, "enable_amp_obs_local_root", False))
+        st.scene_amp = int(c.scene in ("imitate_amp", "heading_amp", "target_amp")); st.enable_amp_obs_local_root = int(getattr(c, "enable_amp_obs_local_root", False))
+        # goal-conditioned AMP task scenes and multi-clip datasets
+        st.scene_goal = int(tables.goal_kind)
+        for k in ("rand_target_time_min", "rand_target_time_max", "max_target_dist", "target_succ_dist", "tar_fail_dist", "tar_speed",
+                  "pos_reward_scale", "max_heading_turn_rate", "sharp_turn_prob", "speed_change_prob", "vel_reward_scale"):
+            setattr(st, k, float(getattr(c, k)))
+        st.enable_min_tar_vel = int(c.enable_min_tar_vel)
+        st.tar_speed_min = float(c.tar_speed if c.tar_speed_min is None else c.tar_speed_min)
+        st.tar_speed_max = float(c.tar_speed if c.tar_speed_max is None else c.tar_speed_max)
+        if tables.clip_starts is not None:
+            st.num_clips = int(tables.num_clips)
+            st.clip_starts = _ip(arr(tables.clip_starts, np.int32)); st.clip_weights = _dp(arr(tables.clip_weights))
+            st.clip_loops = _ip(arr(tables.clip_loops, np.int32))
+        else:
+            st.num_clips = 0
         info = _CreateInfo(int(num_envs), int(device_id), int(seed) & (2 ** 64 - 1), int(precision), int(max_contacts), int(env_id_offset), int(wave_packing))
         self.h = C.c_void_p()
         self._chk(self.lib.dm_create(C.byref(info), C.byref(st), C.byref(self.h)))
@@ -166,7 +185,10 @@ class BatchEnv:
         s = np.zeros((self.N, self.S), np.float32); r = np.zeros(self.N, np.float32)
         t = np.zeros(self.N, np.int32); v = np.zeros(self.N, np.int32); e = np.zeros(self.N, np.int32); nn = np.zeros(self.N, np.int32)
         self._chk(self.lib.dm_query(self.h, _fp(s), _fp(r), _ip(t), _ip(v), _ip(e), _ip(nn), 0))
-        return dict(state=s, reward=r, terminate=t, valid=v, episode_end=e, need_new_action=nn)
+        out = dict(state=s, reward=r, terminate=t, valid=v, episode_end=e, need_new_action=nn)
+        if self.G:
+            out["goal"] = self.last_goals()
+        return out
 
     def step(self, actions=None, timestep: float = 1.0 / 600, n_updates: int = 20, auto_reset=False, open_loop=False, amp=False, end_early=None):
         """amp=True (imitate_amp scenes): also returns "amp_obs" = RecordAMPObsAgent at the end of the step (before any auto reset).
@@ -180,9 +202,48 @@ class BatchEnv:
         if amp:
             o = np.zeros((self.N, self.amp_size), np.float32)
             self._chk(self.lib.dm_step_batch_amp(self.h, _fp(a), C.c_double(timestep), int(n_updates), _fp(s), _fp(r), _ip(t), _ip(v), _ip(e), _fp(o), flags))
-            return dict(state=s, reward=r, terminate=t, valid=v, episode_end=e, amp_obs=o)
+            out = dict(state=s, reward=r, terminate=t, valid=v, episode_end=e, amp_obs=o)
+            if self.G:
+                out["goal"] = self.last_goals()
+            return out
         self._chk(self.lib.dm_step_batch(self.h, _fp(a), C.c_double(timestep), int(n_updates), _fp(s), _fp(r), _ip(t), _ip(v), _ip(e), flags))
-        return dict(state=s, reward=r, terminate=t, valid=v, episode_end=e)
+        out = dict(state=s, reward=r, terminate=t, valid=v, episode_end=e)
+        if self.G:
+            out["goal"] = self.last_goals()
+        return out
+
+    def last_goals(self):
+        g = np.zeros((self.N, 3), np.float32)
+        self._chk(self.lib.dm_last_goals(self.h, _fp(g)))
+        return g
+
+    def query_goal(self):
+        """RecordGoal for every env (goal scenes): N x 3"""
+        g = np.zeros((self.N, max(self.G, 1)), np.float32)
+        self._chk(self.lib.dm_query_goal(self.h, _fp(g), 0))
+        return g[:, :self.G]
+
+    def get_goal_state(self):
+        out = np.zeros((self.N, 12))
+        self._chk(self.lib.dm_get_goal_state(self.h, _dp(out)))
+        return out
+
+    def set_goal_state(self, gs):
+        gs = np.ascontiguousarray(gs, dtype=np.float64).reshape(self.N, 12)
+        self._chk(self.lib.dm_set_goal_state(self.h, _dp(gs)))
+
+    def get_clips(self):
+        out = np.zeros(self.N, np.int32)
+        self._chk(self.lib.dm_get_clips(self.h, _ip(out)))
+        return out
+
+    def amp_expert_clips(self, n: int, clips=None, times=None, ground_h=None):
+        o = np.zeros((int(n), self.amp_size), np.float32)
+        cc = None if clips is None else np.ascontiguousarray(np.broadcast_to(clips, (n,)), dtype=np.int32)
+        tt = None if times is None else np.ascontiguousarray(np.broadcast_to(times, (n,)), dtype=np.float64)
+        gh = None if ground_h is None else np.ascontiguousarray(np.broadcast_to(ground_h, (n,)), dtype=np.float64)
+        self._chk(self.lib.dm_amp_expert_clips(self.h, int(n), _ip(cc), _dp(tt), _dp(gh), _fp(o)))
+        return o
 
     def query_amp(self):
         """RecordAMPObsAgent for every env (scenes/SceneImitateAMP.cpp:101-113)."""

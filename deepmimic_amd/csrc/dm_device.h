@@ -269,6 +269,13 @@ struct ParkSnap { Real pose[C::NP], vel[C::NP], kin[8]; double clk[6]; int flg[4
 enum { CLK_KIN = 0, CLK_CTRL, CLK_INIT_OFF, CLK_TIMER, CLK_TIMER_MAX };
 enum { FLG_NEED_ACTION = 0, FLG_CONTACT, FLG_EPISODE, FLG_VALID, FLG_NROWS, FLG_NCONT, FLG_PARKED, FLG_OVER };
 
+// Counter-based uniform in [0,1): splitmix64 of (seed, env, episode, stream)
+DM_HD double dm_rand01(uint64_t seed, uint64_t env, uint64_t episode, uint64_t stream) {
+    uint64_t z = seed + 0x9E3779B97F4A7C15ull * (env * 0x100000001B3ull + episode * 0xD6E8FEB86659FD93ull + stream + 1);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; z = z ^ (z >> 31);
+    return (double)(z >> 11) * (1.0 / 9007199254740992.0);
+}
+
 // TAPS = false compiles every debug tap / phase timer out of the instruction stream (production step kernel).
 // LW = lanes per character: 64 (one character per wavefront) or 32 (two characters per wavefront, dm_device_duo.h).
 template <typename Real, typename C, bool TAPS = true, int LW = kWave>
@@ -1393,8 +1400,164 @@ struct EnvSim {
         amp_build(pp, pv, p, v, ground_h, false, out);
     }
 
+    // ------------------------------------------------------------------ goal-conditioned AMP task scenes
+    // target_amp (scenes/SceneTargetAMP.cpp) and heading_amp (scenes/SceneHeadingAMP.cpp).  The goal state lives in HBM only
+    // (EnvState::goal, one row of doubles per env) and is touched by lane 0; these functions are called from the AMP / tap
+    // instantiations of the kernels only, the plain imitate kernel carries none of it.  The reference draws from the scene's
+    // std::default_random_engine (cRand); here every draw is dm_rand01(seed, global env id, draw counter, stream 2), the counter
+    // kept in the goal row, so that a trajectory depends neither on the batch nor on the partition.
+    DM_DEV double goal_u01(double* g, int e) const { const double u = dm_rand01(m.seed, (uint64_t)(e + m.env_off), (uint64_t)g[GS_DRAWS], 2); g[GS_DRAWS] += 1; return u; }
+    DM_DEV double goal_uniform(double* g, int e, double lo, double hi) const { return lo + (hi - lo) * goal_u01(g, e); }       // cRand::RandDouble(min, max)
+    DM_DEV double goal_normal(double* g, int e, double mean, double stdev) const {                                              // cRand::RandDoubleNorm: Box-Muller here
+        const double u1 = 1.0 - goal_u01(g, e), u2 = goal_u01(g, e);
+        return mean + stdev * sqrt(-2.0 * log(u1)) * cos(6.283185307179586 * u2);
+    }
+    // cSceneTargetAMP::SampleRandTargetPos (:285-299)
+    DM_DEV void goal_reset_target_pos(double* g, int e) const {
+        const double dist = goal_uniform(g, e, 0.0, (double)m.max_target_dist), theta = goal_uniform(g, e, 0.0, 6.283185307179586);
+        g[GS_TX] = (double)s.pose[0] + dist * cos(theta); g[GS_TY] = 0; g[GS_TZ] = (double)s.pose[2] + dist * sin(theta);
+    }
+    DM_DEV void goal_timer_reset(double* g, int e) const { g[GS_TIMER] = 0; g[GS_TIMER_MAX] = goal_uniform(g, e, m.goal_time_min, m.goal_time_max); }   // cTimer::Reset, uniform
+    // cSceneTargetAMP::Reset after the scene reset (:130-135): mTargetTimer.Reset(); ResetTarget(); and cCtController::SetInitTime /
+    // cDeepMimicCharController::ResetParams for the action bookkeeping (mPrevActionTime = time, mPrevActionCOM = 0)
+    DM_DEV void goal_reset(const EnvState<Real>& st, int e) {
+        if (l == 0) {
+            double* g = st.goal + (size_t)e * GS_WIDTH;
+            goal_timer_reset(g, e);
+            goal_reset_target_pos(g, e);
+            if (m.scene_goal == 2) {       // cSceneHeadingAMP::ResetTarget (:230-239)
+                g[GS_HEADING] = 0;
+                const double sp = goal_uniform(g, e, (double)m.tar_speed_min, (double)m.tar_speed_max);
+                g[GS_SPEED] = fmin(fmax(sp, (double)m.tar_speed_min), (double)m.tar_speed_max);
+            } else g[GS_SPEED] = (double)m.tar_speed;
+            g[GS_PCOMX] = g[GS_PCOMY] = g[GS_PCOMZ] = 0; g[GS_PTIME] = s.clk[CLK_CTRL];
+        }
+        sync();
+    }
+    // mass-weighted COM of the links whose kinematics() results are in LDS -> every lane (cSimCharacter::CalcCOM)
+    DM_DEV v3 com_of_links() {
+        Real* red = scratch();
+        if (l < m.J) { const Real mj = s.mdl.mass[l]; red[l * 4] = mj * s.com[l][0]; red[l * 4 + 1] = mj * s.com[l][1]; red[l * 4 + 2] = mj * s.com[l][2]; red[l * 4 + 3] = mj; }
+        sync();
+        v3 acc = zero3(); Real tm = 0;
+        for (int j = 0; j < m.J; ++j) { acc = acc + ld3(red + j * 4); tm += red[j * 4 + 3]; }
+        sync();
+        return ((Real)1 / tm) * acc;
+    }
+    // cDeepMimicCharController::HandleNewAction (DeepMimicCharController.cpp:262-267), run by UpdateCalcTau of the first update after
+    // an action boundary: mPrevActionTime = mTime (already advanced by this update), mPrevActionCOM = CalcCOM() (state before it)
+    DM_DEV void goal_latch(const EnvState<Real>& st, int e, double dt, bool act = true) {
+        if (s.flg[FLG_NEED_ACTION]) {          // wave-uniform for one character per wave; per half otherwise (kinematics is lane-local + barriers)
+            kinematics(s.pose, s.vel, zero3());
+            const v3 c = com_of_links();
+            if (act && l == 0) { double* g = st.goal + (size_t)e * GS_WIDTH; g[GS_PCOMX] = c.x; g[GS_PCOMY] = c.y; g[GS_PCOMZ] = c.z; g[GS_PTIME] = s.clk[CLK_CTRL] + dt; }
+        }
+        sync();
+    }
+    // cSceneTargetAMP::Update after the scene update (:137-146) with cSceneHeadingAMP::UpdateTarget (:214-228)
+    DM_DEV void goal_update(const EnvState<Real>& st, int e, double dt, bool act = true) {
+        if (act && l == 0) {
+            double* g = st.goal + (size_t)e * GS_WIDTH;
+            g[GS_TIMER] += dt;
+            const bool end = g[GS_TIMER] >= g[GS_TIMER_MAX];
+            if (end) goal_reset_target_pos(g, e);                              // EnableRandTargetPos() is true in both scenes
+            if (m.scene_goal == 2 && end) {
+                // UpdateTargetHeading (:182-203, EnableTargetPos() false): sharp turn with probability p, else a Gaussian step
+                const bool sharp = goal_u01(g, e) < (double)m.sharp_turn_prob;                 // cRand::FlipCoin
+                g[GS_HEADING] += sharp ? goal_uniform(g, e, -3.141592653589793, 3.141592653589793) : goal_normal(g, e, 0.0, (double)m.max_heading_turn_rate);
+                // UpdateTargetSpeed (:205-212, EnableRandSpeed() true)
+                if (goal_u01(g, e) < (double)m.speed_change_prob) {
+                    const double sp = goal_uniform(g, e, (double)m.tar_speed_min, (double)m.tar_speed_max);
+                    g[GS_SPEED] = fmin(fmax(sp, (double)m.tar_speed_min), (double)m.tar_speed_max);
+                }
+            }
+            if (end) goal_timer_reset(g, e);
+        }
+        sync();
+    }
+    // RecordGoal + CalcReward + CheckTerminate of the task scenes, after emit() (kinematics of the sim pose is in LDS, emit's flags
+    // in io / s.sc[6]).  write_flags = false: the observation pass after an auto reset (goal only).
+    DM_DEV void emit_goal(const StepIO<Real>& io, const EnvState<Real>& st, int e, bool write_flags) {
+        const v3 com = com_of_links();
+        if (l == 0) {
+            const double* g = st.goal + (size_t)e * GS_WIDTH;
+            const v3 root = ld3(s.pose), tar = mk3((Real)g[GS_TX], (Real)g[GS_TY], (Real)g[GS_TZ]);
+            const Real heading = calc_heading(ldq(s.pose + 3));
+            const Real tar_speed = (Real)g[GS_SPEED];
+            v3 rel = tar - root; rel.y = 0;
+            const Real dist_sq = dot(rel, rel);
+            const bool dist_fail = (m.scene_goal == 1) && dist_sq > m.tar_fail_dist * m.tar_fail_dist;      // CheckTarDistFail (:306-317); heading: false
+            if (io.goals) {
+                float* o = io.goals + (size_t)e * 3;
+                if (m.scene_goal == 1) {       // cSceneTargetAMP::RecordGoal (:195-223)
+                    const Real d = dm_sqrt(dist_sq);
+                    v3 r = mk3((Real)1, (Real)0, (Real)0);
+                    if (d > (Real)0.0001) r = ((Real)1 / d) * (rot_y(-heading) * rel);
+                    o[0] = (float)r.x; o[1] = (float)r.z; o[2] = (float)d;
+                } else {                       // cSceneHeadingAMP::RecordGoal (:150-166)
+                    Real sh, ch; dm_sincos((Real)g[GS_HEADING] - heading, sh, ch);
+                    o[0] = (float)ch; o[1] = (float)-sh; o[2] = (float)tar_speed;
+                }
+            }
+            if (write_flags) {
+                const bool fallen = has_fallen(nullptr);
+                const Real step_dur = (Real)(s.clk[CLK_CTRL] - g[GS_PTIME]);
+                const v3 dcom = com - mk3((Real)g[GS_PCOMX], (Real)g[GS_PCOMY], (Real)g[GS_PCOMZ]);
+                Real r = 0;
+                if (m.scene_goal == 1) {       // cSceneTargetAMP::CalcReward (:3-81)
+                    if (!dist_fail && !fallen) {
+                        const Real pos_reward = dm_exp(-m.pos_reward_scale * dist_sq);
+                        Real vel_reward = 0;
+                        if (dist_sq < m.target_succ_dist * m.target_succ_dist) vel_reward = 1;
+                        else {
+                            v3 ct = tar - com; ct.y = 0;
+                            const Real cd = norm(ct);
+                            v3 dir = zero3();
+                            if (cd > (Real)0.0001) dir = ((Real)1 / cd) * ct;
+                            const Real avg_vel = dot(dir, dcom) / step_dur;
+                            Real vel_err = tar_speed - avg_vel;
+                            if (!(avg_vel < 0)) { if (m.enable_min_tar_vel) vel_err = dm_max(vel_err, (Real)0); vel_reward = dm_exp(-((Real)4 / (tar_speed * tar_speed)) * vel_err * vel_err); }
+                        }
+                        r = (Real)0.6 * pos_reward + (Real)0.4 * vel_reward;
+                    }
+                } else if (!fallen) {          // cSceneHeadingAMP::CalcReward (:3-43)
+                    Real sh, ch; dm_sincos((Real)g[GS_HEADING], sh, ch);
+                    v3 av = ((Real)1 / step_dur) * dcom; av.y = 0;
+                    const Real avg_speed = ch * av.x - sh * av.z;
+                    if (avg_speed > 0) { Real vel_err = tar_speed - avg_speed; if (m.enable_min_tar_vel) vel_err = dm_max(vel_err, (Real)0); r = dm_exp(-m.vel_reward_scale * vel_err * vel_err); }
+                }
+                if (io.rewards) io.rewards[e] = (float)r;
+                if (dist_fail) {               // cSceneTargetAMP::CheckTerminate (:319-345): Fail when nothing else terminated
+                    if (io.terminate && io.terminate[e] == TERM_NULL) io.terminate[e] = TERM_FAIL;
+                    if (io.episode_end) io.episode_end[e] = 1;
+                    s.sc[6] = (Real)1;
+                }
+            }
+        }
+        sync();
+    }
+    // Multi-clip datasets: a copy of the model whose clip members describe clip c (cClipsController::ActivateMotion)
+    DM_DEV ModelDev<Real> model_of_clip(int c) const {
+        ModelDev<Real> mc = m;
+        if (m.num_clips > 1) {
+            const int r0 = m.clip_start[c];
+            mc.frame_time = m.frame_time + r0; mc.frames = m.frames + (size_t)r0 * m.P; mc.frame_vel = m.frame_vel + (size_t)r0 * m.P;
+            mc.F = m.clip_start[c + 1] - r0; mc.duration = m.clip_dur[c]; mc.loop = m.clip_loop[c];
+            for (int k = 0; k < 3; ++k) mc.cycle_delta[k] = m.clip_delta[c * 3 + k];
+        }
+        return mc;
+    }
+    // cClipsController::SelectNewMotion (:226-243): upper_bound of a uniform draw in the weight CDF
+    DM_DEV int draw_clip(double u) const {
+        int c = 0;
+        if (m.num_clips > 1) { while (c < m.num_clips - 1 && !(u < m.clip_cdf[c])) ++c; }
+        return c;
+    }
+
     // ------------------------------------------------------------------ reset
-    DM_DEV void reset_env(double kin_time, double max_time) {
+    // `yaw`: enable_rand_rot_reset (cSceneImitate::ResetKinChar, SceneImitate.cpp:331-349): after Pose(rand_time) with the identity
+    // origin the kin character is turned about its root by a random angle about +y (cKinCharacter::RotateOrigin)
+    DM_DEV void reset_env(double kin_time, double max_time, Real yaw = (Real)0) {
         DM_OPAQUE_V(l); DM_OPAQUE_V(li);
         Real* kp = scratch(); Real* kv = scratch() + NP; Real* red = scratch() + 2 * NP;
         sync();                            // every lane has read the episode counter / flags the caller derived its arguments from
@@ -1406,6 +1569,12 @@ struct EnvSim {
         }
         for (int i = l; i < m.D; i += LW) s.tau[i] = 0;
         sync();
+        if (yaw != (Real)0) {
+            const v3 rp = kin_root_pos(kin_time);
+            sync();
+            if (l == 0) kin_rotate_origin(yaw, rp);
+            sync();
+        }
         kin_sample(kin_time, kp, kv);
         // sim := kin (cSimCharacter::SetPose/SetVel then BuildPose/BuildVel): unit quaternions, spherical w >= 0
         for (int i = l; i < m.P; i += LW) { s.pose[i] = kp[i]; s.vel[i] = kv[i]; }
@@ -1437,11 +1606,24 @@ struct EnvSim {
     }
 };
 
-// Counter-based uniform in [0,1): splitmix64 of (seed, env, episode, stream)
-DM_HD double dm_rand01(uint64_t seed, uint64_t env, uint64_t episode, uint64_t stream) {
-    uint64_t z = seed + 0x9E3779B97F4A7C15ull * (env * 0x100000001B3ull + episode * 0xD6E8FEB86659FD93ull + stream + 1);
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; z = z ^ (z >> 31);
-    return (double)(z >> 11) * (1.0 / 9007199254740992.0);
+// Reset of an env of a goal scene / multi-clip dataset (cSceneTargetAMP::Reset -> cSceneImitate::ResetKinChar with a
+// cClipsController and enable_rand_rot_reset): the clip is drawn by weight (stream 3 of the reset generator), the clip time
+// uniformly in that clip (stream 0), the yaw uniformly in [-pi, pi) (stream 4); the reset itself runs on a copy of the model whose
+// clip members describe the drawn clip.  kin_time != null: caller-given clip time (clip 0 unless the goal row names one).
+template <typename Real, typename C, bool TAPS, int LW>
+DM_DEV void reset_goal_env(EnvSim<Real, C, TAPS, LW>& sim, const ModelDev<Real>& m, Lds<Real, C>& lds, const EnvState<Real>& st, int e, uint64_t ep,
+                           const double* kin_time, double max_time, bool act = true) {
+    const uint64_t gid = (uint64_t)(e + m.env_off);
+    const int clip = kin_time ? 0 : sim.draw_clip(dm_rand01(m.seed, gid, ep, 3));
+    const ModelDev<Real> mc = sim.model_of_clip(clip);
+    const double kt = kin_time ? *kin_time : mc.duration * dm_rand01(m.seed, gid, ep, 0);
+    const Real yaw = (m.enable_rand_rot_reset && !kin_time) ? (Real)(-3.141592653589793 + 6.283185307179586 * dm_rand01(m.seed, gid, ep, 4)) : (Real)0;
+    EnvSim<Real, C, TAPS, LW> rs(mc, lds, sim.l);
+    rs.li = sim.li;
+    rs.reset_env(kt, max_time, yaw);
+    if (st.hist) rs.init_hist(st, e);
+    if (act && sim.l == 0) st.goal[(size_t)e * GS_WIDTH + GS_CLIP] = (double)clip;
+    if (m.scene_goal) sim.goal_reset(st, e);
 }
 
 // ============================================================================ kernels
@@ -1470,9 +1652,12 @@ __global__ void __launch_bounds__(64) DM_WAVES_PER_EU((StepWaves<Real, C>::value
     else if (io.actions) sim.set_action(io.actions + (size_t)e * m.A);
     sim.mark(15);
     Real* aovf = st.aovf ? st.aovf + (size_t)e * (kMaxRows - C::RREG) * kWave : nullptr;
+    const bool goal = HIST && st.goal && m.scene_goal;
     for (int u = 0; u < io.n_updates; ++u) {
         if (HIST && st.hist) sim.latch_hist(st, e);
+        if (goal) sim.goal_latch(st, e, io.dt);
         sim.update(io.dt, dbg, e, aovf);
+        if (goal) sim.goal_update(st, e, io.dt);
         if (io.end_early && lds.flg[FLG_OVER]) break;           // wave-uniform: latched by lane 0 at the end of update()
     }
     if (io.emit) {
@@ -1482,14 +1667,18 @@ __global__ void __launch_bounds__(64) DM_WAVES_PER_EU((StepWaves<Real, C>::value
         DebugTaps<Real> tap = dbg;
         for (int pass = 0; pass < 2; ++pass) {
             sim.emit(io, tap, e, pass == 0);
+            if (goal) sim.emit_goal(io, st, e, pass == 0);                                // task reward / target-distance failure / RecordGoal
             const bool ended = lds.sc[6] != (Real)0;
             if (HIST && pass == 0 && io.amp_obs && st.hist) sim.emit_amp(io, st, e);       // end-of-path observation of a finished episode included
             if (pass == 1 || !(io.auto_reset && ended)) break;
             uint64_t ep = (uint64_t)lds.flg[FLG_EPISODE];
-            double kt = m.duration * dm_rand01(m.seed, (uint64_t)(e + m.env_off), ep, 0);
             double mt = (m.time_lim_max > m.time_lim_min) ? m.time_lim_min + (m.time_lim_max - m.time_lim_min) * dm_rand01(m.seed, (uint64_t)(e + m.env_off), ep, 1) : m.time_lim_max;
-            sim.reset_env(kt, mt);
-            if (HIST && st.hist) sim.init_hist(st, e);
+            if (HIST && st.goal) reset_goal_env<Real, C, TAPS>(sim, m, lds, st, e, ep, nullptr, mt);   // clip by weight, random yaw, goal reset
+            else {
+                double kt = m.duration * dm_rand01(m.seed, (uint64_t)(e + m.env_off), ep, 0);
+                sim.reset_env(kt, mt);
+                if (HIST && st.hist) sim.init_hist(st, e);
+            }
             tap = DebugTaps<Real>();
         }
         sim.mark(13);
@@ -1507,11 +1696,14 @@ __global__ void __launch_bounds__(64) k_env_reset(ModelDev<Real> m, EnvState<Rea
     EnvSim<Real, C> sim(m, lds, l);
     sim.load(st, e);
     uint64_t ep = (uint64_t)lds.flg[FLG_EPISODE];
-    double kt = kin_times ? kin_times[b] : m.duration * dm_rand01(m.seed, (uint64_t)(e + m.env_off), ep, 0);
     double mt = max_times ? max_times[b]
               : ((m.time_lim_max > m.time_lim_min) ? m.time_lim_min + (m.time_lim_max - m.time_lim_min) * dm_rand01(m.seed, (uint64_t)(e + m.env_off), ep, 1) : m.time_lim_max);
-    sim.reset_env(kt, mt);
-    if (st.hist) sim.init_hist(st, e);
+    if (st.goal) reset_goal_env<Real, C, true>(sim, m, lds, st, e, ep, kin_times ? &kin_times[b] : nullptr, mt);
+    else {
+        double kt = kin_times ? kin_times[b] : m.duration * dm_rand01(m.seed, (uint64_t)(e + m.env_off), ep, 0);
+        sim.reset_env(kt, mt);
+        if (st.hist) sim.init_hist(st, e);
+    }
     sim.store(st, e);
 }
 
@@ -1523,17 +1715,24 @@ __global__ void __launch_bounds__(64) k_env_query(ModelDev<Real> m, EnvState<Rea
     EnvSim<Real, C> sim(m, lds, l);
     sim.load(st, e);
     sim.emit(io, dbg, e, true);
+    if (st.goal && m.scene_goal) sim.emit_goal(io, st, e, true);
     if (io.amp_obs && st.hist) sim.emit_amp(io, st, e);
 }
 
 // n expert AMP observations from the clip (RecordAMPObsExpert): sample b at clip time times[b], ground height ground_h[b] (or 0)
 template <typename Real, typename C>
-__global__ void __launch_bounds__(64) k_amp_expert(ModelDev<Real> m, const double* times, const double* ground_h, float* out) {
+__global__ void __launch_bounds__(64) k_amp_expert(ModelDev<Real> m, const double* times, const double* ground_h, float* out, const int* clips) {
     __shared__ Lds<Real, C> lds;
     const int b = blockIdx.x, l = threadIdx.x;
     EnvSim<Real, C> sim(m, lds, l);
     sim.load_model();
-    sim.amp_expert(times[b], ground_h ? (Real)ground_h[b] : (Real)0, out + (size_t)b * 2 * (m.amp_pose_size + m.amp_vel_size));
+    float* o = out + (size_t)b * 2 * (m.amp_pose_size + m.amp_vel_size);
+    if (clips && m.num_clips > 1) {            // SampleExpertMotion with a cClipsController: the sample's own clip
+        const ModelDev<Real> mc = sim.model_of_clip(clips[b]);
+        EnvSim<Real, C> cs(mc, lds, l);
+        cs.li = sim.li;
+        cs.amp_expert(times[b], ground_h ? (Real)ground_h[b] : (Real)0, o);
+    } else sim.amp_expert(times[b], ground_h ? (Real)ground_h[b] : (Real)0, o);
 }
 
 // component taps for parity tests: SPD torque for the stored state / one substep with the stored torque

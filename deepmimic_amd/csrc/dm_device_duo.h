@@ -657,9 +657,12 @@ __global__ void __launch_bounds__(64) DM_WAVES_PER_EU((DuoWaves<Real>::value)) k
     else if (io.actions) sim.b.set_action(io.actions + (size_t)e * m.A);
     sim.b.mark(15);
     Real* aovf_pair = st.aovf ? st.aovf + (size_t)(2 * blockIdx.x) * (kMaxRows - ClsBiped::RREG) * kWave : nullptr;
+    const bool goal = HIST && st.goal && m.scene_goal;
     for (int u = 0; u < io.n_updates; ++u) {
         if (HIST && st.hist) sim.b.latch_hist(st, e, lds[half].flg[FLG_PARKED] == 0);
+        if (goal) sim.b.goal_latch(st, e, io.dt, lds[half].flg[FLG_PARKED] == 0);
         sim.update(io.dt, e, aovf_pair);
+        if (goal) sim.b.goal_update(st, e, io.dt, lds[half].flg[FLG_PARKED] == 0 && lds[half].flg[FLG_OVER] == 0);
         if (io.end_early) {
             // DM_END_EPISODE_EARLY.  FLG_OVER is latched by each character's lane 0 at the end of update() (wave-uniform reads).
             // Both over: the wave is done.  One over (a few percent of the waves of a launch): what the outputs need of its record
@@ -676,15 +679,20 @@ __global__ void __launch_bounds__(64) DM_WAVES_PER_EU((DuoWaves<Real>::value)) k
     if (io.emit) {
         DebugTaps<Real> tap = DebugTaps<Real>();
         sim.b.emit(io, tap, e, true);
+        if (goal) sim.b.emit_goal(io, st, e, true);
         const bool ended = lds[half].sc[6] != (Real)0;
         if (HIST && io.amp_obs && st.hist) sim.b.emit_amp(io, st, e);
         if (io.auto_reset && ended) {                    // per character; no cross-half traffic inside
             uint64_t ep = (uint64_t)lds[half].flg[FLG_EPISODE];
-            double kt = m.duration * dm_rand01(m.seed, (uint64_t)(e + m.env_off), ep, 0);
             double mt = (m.time_lim_max > m.time_lim_min) ? m.time_lim_min + (m.time_lim_max - m.time_lim_min) * dm_rand01(m.seed, (uint64_t)(e + m.env_off), ep, 1) : m.time_lim_max;
-            sim.b.reset_env(kt, mt);
-            if (HIST && st.hist) sim.b.init_hist(st, e);
+            if (HIST && st.goal) reset_goal_env<Real, ClsBiped, TAPS, 32>(sim.b, m, lds[half], st, e, ep, nullptr, mt);
+            else {
+                double kt = m.duration * dm_rand01(m.seed, (uint64_t)(e + m.env_off), ep, 0);
+                sim.b.reset_env(kt, mt);
+                if (HIST && st.hist) sim.b.init_hist(st, e);
+            }
             sim.b.emit(io, tap, e, false);
+            if (goal) sim.b.emit_goal(io, st, e, false);
         }
         sim.b.mark(13);
     }

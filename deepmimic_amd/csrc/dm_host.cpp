@@ -89,6 +89,7 @@ struct HostModel {
     std::vector<double> cap; std::vector<int> pair_code;
     std::vector<int> lim_joint;
     std::vector<double> frame_time, frames, frame_vel; double duration = 0; int loop = 0; double cycle_delta[3] = {0, 0, 0};
+    int num_clips = 1; std::vector<int> clip_start, clip_loop; std::vector<double> clip_dur, clip_delta, clip_cdf;   // multi-clip datasets
     std::vector<double> s_off, s_scale, a_off, a_scale, a_min, a_max; std::vector<int> s_groups;
     dm_scene_tables cfg;
 };
@@ -216,40 +217,55 @@ static int build_host_model(const dm_scene_tables& t, int max_contacts, HostMode
     if (hm.NC > 128) return fail("more than 128 ground-contact candidate points");
     if (hm.NL + 3 * max_contacts > kMaxRows) return fail("limit rows + 3*max_contacts exceeds 64 constraint rows");
 
-    // ---- motion clip
-    const int F = t.num_frames, P = hm.P;
-    if (F < 2) return fail("motion needs at least 2 frames");
-    hm.F = F; hm.loop = t.loop;
-    hm.frame_time.assign(F, 0); hm.frames.assign((size_t)F * P, 0); hm.frame_vel.assign((size_t)F * P, 0);
-    double tcur = 0; const double* raw = t.frames;
-    double ox = raw[1], oz = raw[3];
-    for (int f = 0; f < F; ++f) {
-        hm.frame_time[f] = tcur; tcur += raw[(size_t)f * (P + 1)];
-        double* fr = &hm.frames[(size_t)f * P];
-        for (int k = 0; k < P; ++k) fr[k] = raw[(size_t)f * (P + 1) + 1 + k];
-        fr[0] -= ox; fr[2] -= oz;
-        stq(fr + 3, qnormalize(ldq(fr + 3)));
-        for (int j = 1; j < J; ++j) if (hm.jtype[j] == JT_SPHERICAL) stq(fr + hm.pose_off[j], qnormalize(ldq(fr + hm.pose_off[j])));
-    }
-    hm.duration = hm.frame_time[F - 1];
-    for (int f = 0; f < F - 1; ++f) {
-        double dt = hm.frame_time[f + 1] - hm.frame_time[f];
-        const double* a = &hm.frames[(size_t)f * P]; const double* b = a + P; double* v = &hm.frame_vel[(size_t)f * P];
-        for (int k = 0; k < 3; ++k) v[k] = (b[k] - a[k]) / dt;
-        V3<double> wr = quat_to_rotvec(qmul(ldq(b + 3), qconj(ldq(a + 3))), 0.000001);
-        v[3] = wr.x / dt; v[4] = wr.y / dt; v[5] = wr.z / dt;
-        for (int j = 1; j < J; ++j) {
-            int off = hm.pose_off[j];
-            if (hm.jtype[j] == JT_SPHERICAL) { V3<double> w = quat_to_rotvec(qmul(qconj(ldq(a + off)), ldq(b + off)), 0.000001); v[off] = w.x / dt; v[off + 1] = w.y / dt; v[off + 2] = w.z / dt; }
-            else if (hm.jtype[j] == JT_REVOLUTE) v[off] = (b[off] - a[off]) / dt;
+    // ---- motion clip(s): a dataset (`--kin_ctrl clips`) is the concatenation of its clips, each processed like a single clip
+    const int FT = t.num_frames, P = hm.P;
+    const int NCL = (t.num_clips > 1) ? t.num_clips : 1;
+    if (t.num_clips > 1 && (!t.clip_starts || !t.clip_weights || !t.clip_loops)) return fail("num_clips > 1 needs clip_starts / clip_weights / clip_loops");
+    if (NCL > 1 && (t.clip_starts[0] != 0 || t.clip_starts[NCL] != FT)) return fail("clip_starts must span [0, num_frames]");
+    hm.num_clips = NCL;
+    hm.clip_start.assign(NCL + 1, 0); hm.clip_loop.assign(NCL, 0); hm.clip_dur.assign(NCL, 0); hm.clip_delta.assign((size_t)NCL * 3, 0); hm.clip_cdf.assign(NCL, 1);
+    hm.frame_time.assign(FT, 0); hm.frames.assign((size_t)FT * P, 0); hm.frame_vel.assign((size_t)FT * P, 0);
+    double wsum_clips = 0;
+    for (int c = 0; c < NCL; ++c) {
+        const int r0 = (NCL > 1) ? t.clip_starts[c] : 0, r1 = (NCL > 1) ? t.clip_starts[c + 1] : FT, F = r1 - r0;
+        if (F < 2) return fail("motion needs at least 2 frames");
+        hm.clip_start[c] = r0; hm.clip_start[c + 1] = r1; hm.clip_loop[c] = (NCL > 1) ? t.clip_loops[c] : t.loop;
+        wsum_clips += (NCL > 1) ? t.clip_weights[c] : 1.0; hm.clip_cdf[c] = wsum_clips;
+        double* ftime = &hm.frame_time[r0]; double* frames = &hm.frames[(size_t)r0 * P]; double* fvel = &hm.frame_vel[(size_t)r0 * P];
+        double tcur = 0; const double* raw = t.frames + (size_t)r0 * (P + 1);
+        double ox = raw[1], oz = raw[3];
+        for (int f = 0; f < F; ++f) {
+            ftime[f] = tcur; tcur += raw[(size_t)f * (P + 1)];
+            double* fr = &frames[(size_t)f * P];
+            for (int k = 0; k < P; ++k) fr[k] = raw[(size_t)f * (P + 1) + 1 + k];
+            fr[0] -= ox; fr[2] -= oz;
+            stq(fr + 3, qnormalize(ldq(fr + 3)));
+            for (int j = 1; j < J; ++j) if (hm.jtype[j] == JT_SPHERICAL) stq(fr + hm.pose_off[j], qnormalize(ldq(fr + hm.pose_off[j])));
+        }
+        hm.clip_dur[c] = ftime[F - 1];
+        for (int f = 0; f < F - 1; ++f) {
+            double dt = ftime[f + 1] - ftime[f];
+            const double* a = &frames[(size_t)f * P]; const double* b = a + P; double* v = &fvel[(size_t)f * P];
+            for (int k = 0; k < 3; ++k) v[k] = (b[k] - a[k]) / dt;
+            V3<double> wr = quat_to_rotvec(qmul(ldq(b + 3), qconj(ldq(a + 3))), 0.000001);
+            v[3] = wr.x / dt; v[4] = wr.y / dt; v[5] = wr.z / dt;
+            for (int j = 1; j < J; ++j) {
+                int off = hm.pose_off[j];
+                if (hm.jtype[j] == JT_SPHERICAL) { V3<double> w = quat_to_rotvec(qmul(qconj(ldq(a + off)), ldq(b + off)), 0.000001); v[off] = w.x / dt; v[off + 1] = w.y / dt; v[off + 2] = w.z / dt; }
+                else if (hm.jtype[j] == JT_REVOLUTE) v[off] = (b[off] - a[off]) / dt;
+            }
+        }
+        for (int k = 0; k < P; ++k) fvel[(size_t)(F - 1) * P + k] = fvel[(size_t)(F - 2) * P + k];
+        {   // PostProcessMotion + CalcCycleRootDelta
+            double bx = frames[0], bz = frames[2];
+            for (int f = 0; f < F; ++f) { frames[(size_t)f * P] -= bx; frames[(size_t)f * P + 2] -= bz; }
+            hm.clip_delta[(size_t)c * 3] = frames[(size_t)(F - 1) * P] - frames[0]; hm.clip_delta[(size_t)c * 3 + 1] = 0; hm.clip_delta[(size_t)c * 3 + 2] = frames[(size_t)(F - 1) * P + 2] - frames[2];
         }
     }
-    for (int k = 0; k < P; ++k) hm.frame_vel[(size_t)(F - 1) * P + k] = hm.frame_vel[(size_t)(F - 2) * P + k];
-    {   // PostProcessMotion + CalcCycleRootDelta
-        double bx = hm.frames[0], bz = hm.frames[2];
-        for (int f = 0; f < F; ++f) { hm.frames[(size_t)f * P] -= bx; hm.frames[(size_t)f * P + 2] -= bz; }
-        hm.cycle_delta[0] = hm.frames[(size_t)(F - 1) * P] - hm.frames[0]; hm.cycle_delta[1] = 0; hm.cycle_delta[2] = hm.frames[(size_t)(F - 1) * P + 2] - hm.frames[2];
-    }
+    for (int c = 0; c < NCL; ++c) hm.clip_cdf[c] /= wsum_clips;      // cClipsController::BuildClipsCDF (:196-212)
+    // the model's own clip members describe clip 0
+    hm.F = hm.clip_start[1]; hm.loop = hm.clip_loop[0]; hm.duration = hm.clip_dur[0];
+    for (int k = 0; k < 3; ++k) hm.cycle_delta[k] = hm.clip_delta[k];
     // ---- offsets / scales / bounds handed to the learner
     hm.s_off.assign(hm.S, 0); hm.s_scale.assign(hm.S, 1); hm.s_groups.assign(hm.S, 0);
     if (t.enable_phase_input) { hm.s_off[0] = -0.5; hm.s_scale[0] = 2; hm.s_groups[0] = -1; }   // CtController.cpp:268-279,364-371
@@ -282,6 +298,9 @@ struct CtxBase {
     virtual int query(float* states, float* rewards, int* term, int* valid, int* end, float* amp = nullptr) = 0;
     virtual int amp_expert(int n, const double* times_dev, const double* gh_dev, float* out_dev) = 0;
     int amp_size = 0; float* d_amp = nullptr; uint64_t expert_calls = 0;
+    int goal_size = 0; float* d_goals = nullptr;            // RecordGoal of the last emit (goal scenes)
+    virtual int get_goal(double* out) = 0; virtual int set_goal(const double* in) = 0; virtual int get_clips(int* out) = 0;
+    virtual int amp_expert_clips(int n, const int* clips_dev, const double* times_dev, const double* gh_dev, float* out_dev) = 0;
     virtual int probe(int what, double dt) = 0;
     virtual int get_state(double* pose, double* vel, double* tar, double* kin, double* clk, int* flg) = 0;
     virtual int set_state(const double* pose, const double* vel, const double* tar, const double* kin, const double* clk, const int* flg) = 0;
@@ -386,6 +405,24 @@ struct CtxT : CtxBase {
             d_amp = (float*)dalloc(sizeof(float) * (size_t)N * amp_size);
             if (!st.hist || !d_amp) return fail("device allocation failed");
         }
+        // goal-conditioned task scenes / multi-clip datasets
+        st.goal = nullptr;
+        md.scene_goal = c.scene_goal; md.enable_min_tar_vel = c.enable_min_tar_vel; md.enable_rand_rot_reset = c.enable_rand_rot_reset;
+        md.goal_time_min = c.rand_target_time_min; md.goal_time_max = c.rand_target_time_max;
+        md.max_target_dist = (Real)c.max_target_dist; md.target_succ_dist = (Real)c.target_succ_dist; md.tar_fail_dist = (Real)c.tar_fail_dist;
+        md.tar_speed = (Real)c.tar_speed; md.pos_reward_scale = (Real)c.pos_reward_scale; md.max_heading_turn_rate = (Real)c.max_heading_turn_rate;
+        md.sharp_turn_prob = (Real)c.sharp_turn_prob; md.speed_change_prob = (Real)c.speed_change_prob;
+        md.tar_speed_min = (Real)c.tar_speed_min; md.tar_speed_max = (Real)c.tar_speed_max; md.vel_reward_scale = (Real)c.vel_reward_scale;
+        md.num_clips = h.num_clips;
+        md.clip_start = up<int>(h.clip_start); md.clip_dur = up<double>(h.clip_dur); md.clip_loop = up<int>(h.clip_loop);
+        md.clip_delta = up<Real>(h.clip_delta); md.clip_cdf = up<double>(h.clip_cdf);
+        if (c.scene_goal || h.num_clips > 1 || c.enable_rand_rot_reset) {
+            if (!c.scene_amp) return fail("goal scenes, multi-clip datasets and enable_rand_rot_reset ride on the AMP instantiation of the kernels: scene_amp must be set");
+            st.goal = (double*)dalloc(sizeof(double) * (size_t)N * GS_WIDTH);
+            goal_size = c.scene_goal ? 3 : 0;
+            d_goals = (float*)dalloc(sizeof(float) * (size_t)N * 3);
+            if (!st.goal || !d_goals) return fail("device allocation failed");
+        }
         d_actions = (float*)dalloc(sizeof(float) * N * h.A); d_states = (float*)dalloc(sizeof(float) * N * h.S); d_rewards = (float*)dalloc(sizeof(float) * N);
         d_term = (int*)dalloc(sizeof(int) * N); d_valid = (int*)dalloc(sizeof(int) * N); d_end = (int*)dalloc(sizeof(int) * N);
         if (!st.pose || !st.flag || !d_end || !md.mdl_blob || upload_failed) return fail("device allocation or table upload failed");
@@ -419,7 +456,7 @@ struct CtxT : CtxBase {
     }
     int step(const float* actions_dev, double dt, int n_updates, float* states, float* rewards, int* term, int* valid, int* end, int flags, float* amp) override {
         StepIO<Real> io; memset(&io, 0, sizeof(io));
-        io.amp_obs = amp;
+        io.amp_obs = amp; io.goals = d_goals;
         io.actions = actions_dev; io.states = states; io.rewards = rewards; io.terminate = term; io.valid = valid; io.episode_end = end;
         io.n_updates = n_updates; io.dt = dt; io.auto_reset = (flags & DM_AUTO_RESET) ? 1 : 0; io.emit = (flags & DM_NO_EMIT) ? 0 : 1; io.open_loop = (flags & DM_OPEN_LOOP) ? 1 : 0; io.end_early = (flags & DM_END_EPISODE_EARLY) ? 1 : 0;
         // two characters per wavefront: biped class, even batch, no debug taps armed (DM_DUO=0 keeps one character per wave)
@@ -434,14 +471,36 @@ struct CtxT : CtxBase {
         else { if (cls == 0) RT_LAUNCH((k_env_step<Real, ClsBiped, false, false>), N, stream, md, st, io, dbg); else RT_LAUNCH((k_env_step<Real, ClsLarge, false, false>), N, stream, md, st, io, dbg); }
         return 0;
     }
-    int amp_expert(int n, const double* times_dev, const double* gh_dev, float* out_dev) override {
-        if (cls == 0) RT_LAUNCH((k_amp_expert<Real, ClsBiped>), n, stream, md, times_dev, gh_dev, out_dev);
-        else RT_LAUNCH((k_amp_expert<Real, ClsLarge>), n, stream, md, times_dev, gh_dev, out_dev);
+    int amp_expert(int n, const double* times_dev, const double* gh_dev, float* out_dev) override { return amp_expert_clips(n, nullptr, times_dev, gh_dev, out_dev); }
+    int amp_expert_clips(int n, const int* clips_dev, const double* times_dev, const double* gh_dev, float* out_dev) override {
+        if (cls == 0) RT_LAUNCH((k_amp_expert<Real, ClsBiped>), n, stream, md, times_dev, gh_dev, out_dev, clips_dev);
+        else RT_LAUNCH((k_amp_expert<Real, ClsLarge>), n, stream, md, times_dev, gh_dev, out_dev, clips_dev);
+        return 0;
+    }
+    int get_goal(double* out) override {
+        if (!st.goal) return fail("no goal state: not a goal scene / multi-clip dataset");
+        std::vector<double> g((size_t)N * GS_WIDTH);
+        if (rt_d2h(g.data(), st.goal, sizeof(double) * g.size(), stream) != 0) return fail("device to host copy failed");
+        for (int e = 0; e < N; ++e) for (int k = 0; k < 12; ++k) out[(size_t)e * 12 + k] = g[(size_t)e * GS_WIDTH + k];
+        return 0;
+    }
+    int set_goal(const double* in) override {
+        if (!st.goal) return fail("no goal state: not a goal scene / multi-clip dataset");
+        std::vector<double> g((size_t)N * GS_WIDTH);
+        if (rt_d2h(g.data(), st.goal, sizeof(double) * g.size(), stream) != 0) return fail("device to host copy failed");
+        for (int e = 0; e < N; ++e) for (int k = 0; k < 12; ++k) g[(size_t)e * GS_WIDTH + k] = in[(size_t)e * 12 + k];
+        return rt_h2d(st.goal, g.data(), sizeof(double) * g.size(), stream) == 0 ? 0 : fail("host to device copy failed");
+    }
+    int get_clips(int* out) override {
+        if (!st.goal) { for (int e = 0; e < N; ++e) out[e] = 0; return 0; }
+        std::vector<double> g((size_t)N * GS_WIDTH);
+        if (rt_d2h(g.data(), st.goal, sizeof(double) * g.size(), stream) != 0) return fail("device to host copy failed");
+        for (int e = 0; e < N; ++e) out[e] = (int)g[(size_t)e * GS_WIDTH + GS_CLIP];
         return 0;
     }
     int query(float* states, float* rewards, int* term, int* valid, int* end, float* amp) override {
         StepIO<Real> io; memset(&io, 0, sizeof(io));
-        io.amp_obs = amp;
+        io.amp_obs = amp; io.goals = d_goals;
         io.states = states; io.rewards = rewards; io.terminate = term; io.valid = valid; io.episode_end = end; io.emit = 1;
         DM_DISPATCH(k_env_query, N, md, st, io, dbg);
         return 0;
@@ -528,7 +587,7 @@ int dm_destroy(dm_ctx* ctx);
 int dm_create(const dm_create_info* info, const dm_scene_tables* tables, dm_ctx** out) {
     if (!info || !tables || !out) return fail("null argument");
     if (info->num_envs < 1) return fail("num_envs must be >= 1");
-    if (tables->enable_rand_rot_reset) return fail("enable_rand_rot_reset is not supported on the accelerated path");
+    if (tables->scene_goal < 0 || tables->scene_goal > 2) return fail("scene_goal must be 0 (none), 1 (target_amp) or 2 (heading_amp)");
     if (tables->num_sim_substeps < 1) return fail("num_sim_substeps must be >= 1");
     int precision = info->precision ? info->precision : 32;
     if (precision != 32 && precision != 64) return fail("precision must be 32 or 64");
@@ -569,7 +628,7 @@ int dm_destroy(dm_ctx* ctx) {
 int dm_dims(const dm_ctx* ctx, int32_t* out) {
     if (!ctx || !out) return fail("null argument");
     const HostModel& h = ctx->c->hm;
-    out[0] = h.S; out[1] = 0; out[2] = h.A; out[3] = h.P; out[4] = h.J; out[5] = h.D; out[6] = h.F; out[7] = ctx->c->N;
+    out[0] = h.S; out[1] = ctx->c->goal_size; out[2] = h.A; out[3] = h.P; out[4] = h.J; out[5] = h.D; out[6] = h.F; out[7] = ctx->c->N;
     return 0;
 }
 double dm_motion_duration(const dm_ctx* ctx) { return ctx ? ctx->c->hm.duration : 0.0; }
@@ -705,6 +764,47 @@ int dm_amp_expert(dm_ctx* ctx, int n, const double* times, const double* ground_
     if (td) rt_free(td); if (gd) rt_free(gd); if (od) rt_free(od);
     return rc;
 }
+
+int dm_amp_expert_clips(dm_ctx* ctx, int n, const int32_t* clips, const double* times, const double* ground_h, float* out) {
+    if (!ctx || !out) return fail("null argument");
+    CtxBase* c = ctx->c; DevGuard guard(c->device_id);
+    if (!c->amp_size) return fail("AMP observations need a `--scene imitate_amp` context (dm_scene_tables.scene_amp)");
+    if (n <= 0) return 0;
+    const HostModel& h = c->hm;
+    std::vector<int> cl(n); std::vector<double> t(n);
+    for (int i = 0; i < n; ++i) {
+        if (clips) { if (clips[i] < 0 || clips[i] >= h.num_clips) return fail("clip id out of range"); cl[i] = clips[i]; }
+        else { double u = dm_rand01(c->seed, (uint64_t)c->env_off + 0x434C50ull, c->expert_calls, (uint64_t)i); int k = 0; while (k < h.num_clips - 1 && !(u < h.clip_cdf[k])) ++k; cl[i] = k; }
+        t[i] = times ? times[i] : h.clip_dur[cl[i]] * dm_rand01(c->seed, (uint64_t)c->env_off + 0x414D50ull, c->expert_calls, (uint64_t)i);
+    }
+    c->expert_calls++;
+    void *td = nullptr, *gd = nullptr, *od = nullptr, *cd = nullptr; int rc = 0;
+    if (rt_malloc(&td, sizeof(double) * n) || rt_malloc(&cd, sizeof(int) * n) || rt_malloc(&od, sizeof(float) * (size_t)n * c->amp_size) || (ground_h && rt_malloc(&gd, sizeof(double) * n))) rc = fail("device allocation failed");
+    if (!rc && (rt_h2d(td, t.data(), sizeof(double) * n, c->stream) || rt_h2d(cd, cl.data(), sizeof(int) * n, c->stream) || (ground_h && rt_h2d(gd, ground_h, sizeof(double) * n, c->stream)))) rc = fail("copy failed");
+    if (!rc) rc = launch_status(c->amp_expert_clips(n, (const int*)cd, (const double*)td, (const double*)gd, (float*)od));
+    if (!rc && rt_d2h(out, od, sizeof(float) * (size_t)n * c->amp_size, c->stream)) rc = fail("copy failed");
+    rt_sync(c->stream);
+    if (td) rt_free(td); if (gd) rt_free(gd); if (od) rt_free(od); if (cd) rt_free(cd);
+    return rc;
+}
+
+int dm_query_goal(dm_ctx* ctx, float* goals, int flags) {
+    if (!ctx || !goals) return fail("null argument");
+    CtxBase* c = ctx->c; DevGuard guard(c->device_id);
+    if (!c->goal_size) return fail("RecordGoal needs a goal scene (dm_scene_tables.scene_goal)");
+    if (launch_status(c->query(nullptr, nullptr, nullptr, nullptr, nullptr))) return -1;
+    (void)flags;
+    return copy_out(c, goals, c->d_goals, sizeof(float) * (size_t)c->N * 3);
+}
+int dm_last_goals(dm_ctx* ctx, float* goals) {
+    if (!ctx || !goals) return fail("null argument");
+    CtxBase* c = ctx->c; DevGuard guard(c->device_id);
+    if (!c->goal_size) return fail("RecordGoal needs a goal scene (dm_scene_tables.scene_goal)");
+    return copy_out(c, goals, c->d_goals, sizeof(float) * (size_t)c->N * 3);
+}
+int dm_get_goal_state(dm_ctx* ctx, double* out) { if (!ctx || !out) return fail("null argument"); DevGuard guard(ctx->c->device_id); return ctx->c->get_goal(out); }
+int dm_set_goal_state(dm_ctx* ctx, const double* in) { if (!ctx || !in) return fail("null argument"); DevGuard guard(ctx->c->device_id); return ctx->c->set_goal(in); }
+int dm_get_clips(dm_ctx* ctx, int32_t* out) { if (!ctx || !out) return fail("null argument"); DevGuard guard(ctx->c->device_id); return ctx->c->get_clips(out); }
 
 int dm_build_offsets_scales(const dm_ctx* ctx, double* s_off, double* s_scale, double* a_off, double* a_scale, double* a_min, double* a_max, int32_t* s_norm_groups) {
     if (!ctx) return fail("null ctx");

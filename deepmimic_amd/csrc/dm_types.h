@@ -104,7 +104,22 @@ struct ModelDev {
     const int* amp_off;                      // J   offset of joint j's rotation features inside a pose block (j >= 1)
     const int* amp_ee;                       // J   ordinal of link j among the end effectors, -1 if it is none
     int amp_ee_base;                         // offset of the end-effector positions inside a pose block
+    // ---- goal-conditioned AMP task scenes: 1 = target_amp (scenes/SceneTargetAMP.cpp), 2 = heading_amp (SceneHeadingAMP.cpp)
+    int scene_goal, enable_min_tar_vel, enable_rand_rot_reset;
+    double goal_time_min, goal_time_max;     // target timer range (rand_target_time_*)
+    Real max_target_dist, target_succ_dist, tar_fail_dist, tar_speed, pos_reward_scale;
+    Real max_heading_turn_rate, sharp_turn_prob, speed_change_prob, tar_speed_min, tar_speed_max, vel_reward_scale;
+    // ---- multi-clip dataset (`--kin_ctrl clips`): frames / frame_time / frame_vel hold every clip back to back; the members
+    // above (F, duration, loop, cycle_delta) describe clip 0.  num_clips <= 1: single clip.
+    int num_clips;
+    const int* clip_start;                   // num_clips + 1 (rows)
+    const double* clip_dur;                  // num_clips
+    const int* clip_loop;                    // num_clips
+    const Real* clip_delta;                  // num_clips x 3  cycle root delta
+    const double* clip_cdf;                  // num_clips  cClipsController::mClipsCDF
 };
+// per-env goal state row (EnvState::goal), doubles: the clocks among them must not round to fp32
+enum { GS_TX = 0, GS_TY, GS_TZ, GS_HEADING, GS_SPEED, GS_TIMER, GS_TIMER_MAX, GS_PCOMX, GS_PCOMY, GS_PCOMZ, GS_PTIME, GS_DRAWS, GS_CLIP, GS_WIDTH = 16 };
 
 template <typename Real>
 struct EnvState {
@@ -118,6 +133,7 @@ struct EnvState {
     int* flag;       // N x 4   need_new_action, contact_mask, episode_count, valid
     Real* aovf;      // N x (64 - RREG) x 64  overflow rows of the constraint-space matrix (null when the class keeps all 64 in VGPRs)
     Real* hist;      // N x 2P  pose | vel at the last action latch (cSceneImitateAMP::mPrevPose / mPrevVel); null unless imitate_amp
+    double* goal;    // N x GS_WIDTH  goal state of the task scenes + the clip the env was reset to; null unless a goal scene / multi-clip dataset
 };
 
 // Per-call I/O of the batched step (device pointers; any may be null)
@@ -136,6 +152,7 @@ struct StepIO {
     int open_loop;          // ignore `actions`; track the reference clip (stream A1 of SURVEY 8d)
     float* amp_obs;         // N x amp size  RecordAMPObsAgent at the end of the call (imitate_amp scenes only)
     int end_early;          // stop an env's updates at the update after which its episode is over (DM_END_EPISODE_EARLY)
+    float* goals;           // N x 3  RecordGoal at the end of the call (goal scenes only)
 };
 
 // Debug taps for component parity tests (device pointers, null when unused)

@@ -150,6 +150,22 @@ class SceneConfig:
     char_ctrl_file: str = ""
     motion_file: str = ""
     terrain_file: str = ""
+    kin_ctrl: str = "motion"            # "clips": multi-clip dataset (anim/ClipsController.cpp), goal scenes
+    # ---- goal-conditioned AMP task scenes (scenes/SceneTargetAMP.cpp:83-120, SceneHeadingAMP.cpp:45-93): constructor defaults
+    rand_target_time_min: float = 1.0
+    rand_target_time_max: float = 5.0
+    max_target_dist: float = 3.0
+    target_succ_dist: float = 0.5
+    tar_fail_dist: float = np.inf
+    tar_speed: float = 1.0
+    enable_min_tar_vel: bool = False
+    pos_reward_scale: float = 1.0
+    max_heading_turn_rate: float = 0.15
+    sharp_turn_prob: float = 0.025
+    speed_change_prob: float = 0.1
+    tar_speed_min: Optional[float] = None
+    tar_speed_max: Optional[float] = None
+    vel_reward_scale: float = 1.0
 
 
 @dataclass
@@ -166,6 +182,24 @@ class SceneTables:
     query_rate: float = 30.0         # key "QueryRate" (sim/CtController.cpp:165)
     cfg: SceneConfig = field(default_factory=SceneConfig)
     joint_names: List[str] = field(default_factory=list)
+    # multi-clip datasets (`--kin_ctrl clips`): `frames` is the concatenation of every clip's frames; clip c owns rows
+    # clip_starts[c] .. clip_starts[c+1]-1.  None = one clip (the whole of `frames`, loop mode `loop`).
+    clip_starts: Optional[np.ndarray] = None
+    clip_weights: Optional[np.ndarray] = None      # cClipsController::tMotionEntry::mWeight
+    clip_loops: Optional[np.ndarray] = None
+
+    @property
+    def num_clips(self) -> int:
+        return 1 if self.clip_starts is None else len(self.clip_starts) - 1
+
+    @property
+    def goal_kind(self) -> int:
+        """0: no goal (imitate / imitate_amp), 1: target_amp, 2: heading_amp"""
+        return {"target_amp": 1, "heading_amp": 2}.get(self.cfg.scene, 0)
+
+    @property
+    def goal_dim(self) -> int:
+        return 3 if self.goal_kind else 0           # cSceneTargetAMP::GetGoalSize / cSceneHeadingAMP::GetGoalSize
 
     @property
     def num_joints(self) -> int:
@@ -215,6 +249,9 @@ class SceneTables:
             "record_world_root_rot": bool(self.record_world_root_rot),
             "query_rate": float(self.query_rate),
             "cfg": {k: _json_val(v) for k, v in c.__dict__.items()},
+            "clip_starts": None if self.clip_starts is None else [int(x) for x in self.clip_starts],
+            "clip_weights": None if self.clip_weights is None else [float(x) for x in self.clip_weights],
+            "clip_loops": None if self.clip_loops is None else [int(x) for x in self.clip_loops],
         }
 
     @staticmethod
@@ -236,6 +273,9 @@ class SceneTables:
             query_rate=float(d.get("query_rate", 30.0)),
             cfg=cfg,
             joint_names=list(d.get("joint_names", [])),
+            clip_starts=None if d.get("clip_starts") is None else np.array(d["clip_starts"], dtype=np.int32),
+            clip_weights=None if d.get("clip_weights") is None else np.array(d["clip_weights"], dtype=np.float64),
+            clip_loops=None if d.get("clip_loops") is None else np.array(d["clip_loops"], dtype=np.int32),
         )
 
 
@@ -348,6 +388,20 @@ def parse_scene_config(parser: ArgParser) -> SceneConfig:
     c.char_ctrl_file = parser.str("char_ctrl_files", "")
     c.motion_file = parser.str("motion_file", "")
     c.terrain_file = parser.str("terrain_file", "")
+    c.kin_ctrl = parser.str("kin_ctrl", "motion") or "motion"
+    for k in ("rand_target_time_min", "rand_target_time_max", "max_target_dist", "target_succ_dist", "tar_fail_dist", "tar_speed",
+              "pos_reward_scale", "max_heading_turn_rate", "sharp_turn_prob", "speed_change_prob", "vel_reward_scale"):
+        setattr(c, k, parser.float(k, getattr(c, k)))
+    c.enable_min_tar_vel = parser.bool("enable_min_tar_vel", c.enable_min_tar_vel)
+    if c.scene == "heading_amp":
+        # cSceneHeadingAMP(): target timer 0.2 .. 0.5 s unless the args say otherwise (SceneHeadingAMP.cpp:45-48)
+        c.rand_target_time_min = parser.float("rand_target_time_min", 0.2)
+        c.rand_target_time_max = parser.float("rand_target_time_max", 0.5)
+    # cSceneHeadingAMP::ParseArgs (:66-84): the speed range defaults to [tar_speed, tar_speed]; tar_speed is clamped into it
+    c.tar_speed_min = parser.float("tar_speed_min", c.tar_speed)
+    c.tar_speed_max = parser.float("tar_speed_max", c.tar_speed)
+    if c.scene == "heading_amp":
+        c.tar_speed = min(max(c.tar_speed, c.tar_speed_min), c.tar_speed_max)
     return c
 
 
@@ -379,9 +433,10 @@ def timer_limits(cfg: SceneConfig, test_mode: bool = False, sample_count: int = 
 
 # --- scene loading -------------------------------------------------------------
 def load_scene(char_file: str, ctrl_file: str, motion_file: str,
-               cfg: Optional[SceneConfig] = None) -> SceneTables:
+               cfg: Optional[SceneConfig] = None, data_root: Optional[str] = None) -> SceneTables:
     with open(char_file) as f:
         cj = json.load(f)
+    char_json = cj
     with open(ctrl_file) as f:
         kj = json.load(f)
     with open(motion_file) as f:
@@ -395,15 +450,32 @@ def load_scene(char_file: str, ctrl_file: str, motion_file: str,
     if len(pds) != J:
         raise ValueError("PD controller count mismatch")
     pd = np.array([[float(p.get("Kp", 0)), float(p.get("Kd", 0))] for p in pds])
+    clip_starts = clip_weights = clip_loops = None
     if "Frames" not in mj:
-        if "Motions" in mj:
-            raise ValueError("%s is a multi-clip dataset (`--kin_ctrl clips`, anim/ClipsController.cpp); only single-clip "
-                             "motion files are on the accelerated path" % motion_file)
-        raise ValueError("%s has no \"Frames\"" % motion_file)
-    frames = np.array(mj["Frames"], dtype=np.float64)
-    loop_str = mj.get("Loop", "none")
-    if loop_str not in ("none", "wrap"):
-        raise ValueError("unsupported loop mode %r" % loop_str)
+        if "Motions" not in mj:
+            raise ValueError("%s has neither \"Frames\" nor \"Motions\"" % motion_file)
+        # multi-clip dataset (cClipsController::LoadMotions, anim/ClipsController.cpp:150-188): files relative to the data root
+        root = data_root if data_root is not None else os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(motion_file))))
+        all_frames, starts, weights, loops = [], [0], [], []
+        for ent in mj["Motions"]:
+            path = ent.get("File", "")
+            path = path if os.path.isabs(path) else os.path.join(root, path)
+            with open(path) as f:
+                cj = json.load(f)
+            fr = np.array(cj["Frames"], dtype=np.float64)
+            lp = cj.get("Loop", "none")
+            if lp not in ("none", "wrap"):
+                raise ValueError("unsupported loop mode %r in %s" % (lp, path))
+            all_frames.append(fr); starts.append(starts[-1] + fr.shape[0])
+            weights.append(float(ent.get("Weight", 1.0))); loops.append(1 if lp == "wrap" else 0)
+        frames = np.concatenate(all_frames, 0)
+        loop_str = "wrap" if loops[0] else "none"
+        clip_starts, clip_weights, clip_loops = np.array(starts, np.int32), np.array(weights), np.array(loops, np.int32)
+    else:
+        frames = np.array(mj["Frames"], dtype=np.float64)
+        loop_str = mj.get("Loop", "none")
+        if loop_str not in ("none", "wrap"):
+            raise ValueError("unsupported loop mode %r" % loop_str)
     t = SceneTables(
         joint_mat=jm, body_defs=bd, pd_params=pd, frames=frames, loop=(loop_str == "wrap"),
         enable_phase_input=bool(kj.get("EnablePhaseInput", False)),
@@ -411,7 +483,8 @@ def load_scene(char_file: str, ctrl_file: str, motion_file: str,
         record_world_root_rot=bool(kj.get("RecordWorldRootRot", False)),
         query_rate=float(kj.get("QueryRate", 30.0)),
         cfg=cfg or SceneConfig(),
-        joint_names=[j.get("Name", "") for j in cj["Skeleton"]["Joints"]],
+        joint_names=[j.get("Name", "") for j in char_json["Skeleton"]["Joints"]],
+        clip_starts=clip_starts, clip_weights=clip_weights, clip_loops=clip_loops,
     )
     if frames.shape[1] - 1 != t.pose_dim:
         raise ValueError("DOF mismatch, char dof %d, motion dof %d" % (t.pose_dim, frames.shape[1] - 1))
@@ -427,13 +500,13 @@ def load_scene_from_args(args: Sequence[str], data_root: str = ".") -> SceneTabl
         if not p.load_file(path):
             raise FileNotFoundError("Failed to load args from: %s" % arg_file)
     cfg = parse_scene_config(p)
-    if cfg.scene not in ("imitate", "imitate_amp"):
-        raise ValueError("only `--scene imitate` and `--scene imitate_amp` are on the accelerated path (got %r)" % cfg.scene)
+    if cfg.scene not in ("imitate", "imitate_amp", "heading_amp", "target_amp"):
+        raise ValueError("only `--scene imitate`, `imitate_amp`, `heading_amp` and `target_amp` are on the accelerated path (got %r)" % cfg.scene)
 
     def res(pth):
         return pth if os.path.isabs(pth) else os.path.join(data_root, pth)
 
-    return load_scene(res(cfg.character_file), res(cfg.char_ctrl_file), res(cfg.motion_file), cfg)
+    return load_scene(res(cfg.character_file), res(cfg.char_ctrl_file), res(cfg.motion_file), cfg, data_root=data_root)
 
 
 ASSET_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "assets")

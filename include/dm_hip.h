@@ -56,6 +56,19 @@ typedef struct {
     /* `--scene imitate_amp` (scenes/SceneImitateAMP.cpp): CalcReward = 0, CheckTerminate = fall only, AMP observations on */
     int scene_amp;
     int enable_amp_obs_local_root;   /* --enable_amp_obs_local_root (SceneImitateAMP.cpp:30,42) */
+    /* ---- goal-conditioned AMP task scenes, scene_amp must be set:
+     * 1 = `--scene target_amp` (scenes/SceneTargetAMP.cpp), 2 = `--scene heading_amp` (scenes/SceneHeadingAMP.cpp).  RecordGoal has
+     * size 3, CalcReward is the task reward, CheckTerminate adds the target-distance failure; keys of ParseArgs (:92-106 / :55-84) */
+    int scene_goal;
+    double rand_target_time_min, rand_target_time_max, max_target_dist, target_succ_dist, tar_fail_dist, tar_speed;
+    int enable_min_tar_vel;
+    double pos_reward_scale, max_heading_turn_rate, sharp_turn_prob, speed_change_prob, tar_speed_min, tar_speed_max, vel_reward_scale;
+    /* ---- multi-clip dataset (`--kin_ctrl clips`, anim/ClipsController.cpp): `frames` is the concatenation of the clips, clip c owns
+     * rows clip_starts[c] .. clip_starts[c+1]-1; a reset draws the clip by weight (SelectNewMotion, :226-243).  0 = single clip. */
+    int num_clips;
+    const int32_t* clip_starts;   /* num_clips + 1 */
+    const double* clip_weights;   /* num_clips */
+    const int32_t* clip_loops;    /* num_clips */
 } dm_scene_tables;
 
 /* DM_END_EPISODE_EARLY: an env whose episode is over after update u of the call (fall contact, clip end, episode timer) takes no
@@ -70,7 +83,7 @@ int dm_is_emulator(void);
 /* cDeepMimicCore ctor + ParseArgs + Init  (DeepMimicCore.cpp:9-54) */
 int dm_create(const dm_create_info* info, const dm_scene_tables* tables, dm_ctx** out);
 int dm_destroy(dm_ctx* ctx);
-/* GetStateSize / GetGoalSize / GetActionSize (+ pose, links, dofs, frames): out[8] = S,G,A,P,J,D,F,N */
+/* GetStateSize / GetGoalSize / GetActionSize (+ pose, links, dofs, frames of clip 0): out[8] = S,G,A,P,J,D,F,N */
 int dm_dims(const dm_ctx* ctx, int32_t* out);
 double dm_motion_duration(const dm_ctx* ctx);
 /* Run the kernels of this ctx on an external HIP stream (e.g. torch's current stream); NULL restores the own stream */
@@ -112,6 +125,21 @@ int dm_step_batch_amp(dm_ctx* ctx, const float* actions, double timestep, int n_
  * CalcFrameVel).  times NULL -> drawn ~ U[0, duration) from the ctx's counter-based generator (the reference draws from the
  * scene RNG); ground_h NULL -> 0 (the reference passes the kin character's origin height).  out n x dm_amp_obs_size(). */
 int dm_amp_expert(dm_ctx* ctx, int n, const double* times, const double* ground_h, float* out, int flags);
+/* Multi-clip variant (SampleExpertMotion, SceneImitateAMP.cpp:115-138 with a cClipsController): clips[i] = dataset clip of sample i;
+ * clips NULL -> drawn by weight (and times ~ U[0, that clip's duration)) from the ctx generator.  Host pointers. */
+int dm_amp_expert_clips(dm_ctx* ctx, int n, const int32_t* clips, const double* times, const double* ground_h, float* out);
+
+/* ---- goal scenes (dm_scene_tables.scene_goal != 0)
+ * RecordGoal for every env (SceneTargetAMP.cpp:195-223 / SceneHeadingAMP.cpp:150-166): goals N x 3 float32 */
+int dm_query_goal(dm_ctx* ctx, float* goals, int flags);
+/* the goals written by the most recent dm_step_batch / dm_query (no launch): what the agent reads next to `states` */
+int dm_last_goals(dm_ctx* ctx, float* goals);
+/* Goal state snapshot (tests, checkpointing): N x 12 doubles = target pos(3), target heading, target speed, target timer time,
+ * target timer max, COM at the last action(3), controller time of the last action, draws consumed so far.  NULL = leave as is. */
+int dm_get_goal_state(dm_ctx* ctx, double* out);
+int dm_set_goal_state(dm_ctx* ctx, const double* in);
+/* clip each env's kinematic character was reset to (multi-clip datasets), N int32 */
+int dm_get_clips(dm_ctx* ctx, int32_t* out);
 
 /* BuildStateOffset/Scale, BuildActionOffset/Scale/BoundMin/BoundMax, BuildStateNormGroups (DeepMimicCore.cpp:232-448) */
 int dm_build_offsets_scales(const dm_ctx* ctx, double* s_off, double* s_scale, double* a_off, double* a_scale,

@@ -19,7 +19,9 @@ enum {
     CFG_NUM_SIM_SUBSTEPS = 0, CFG_WORLD_SCALE, CFG_GRAV_X, CFG_GRAV_Y, CFG_GRAV_Z,
     CFG_SYNC_ROOT_POS, CFG_SYNC_ROOT_ROT, CFG_ENABLE_FALL_END, CFG_ENABLE_CONTACT_FALL, CFG_ENABLE_ROOT_ROT_FAIL,
     CFG_ENABLE_RAND_PLACEMENT, CFG_ENABLE_PHASE_INPUT, CFG_RECORD_WORLD_ROOT_POS, CFG_RECORD_WORLD_ROOT_ROT,
-    CFG_QUERY_RATE, CFG_FRICTION, CFG_ERP, CFG_SOLVER_ITERS, CFG_MAX_CONTACTS, CFG_SELF_COLLISION, CFG_SCENE_AMP, CFG_AMP_LOCAL_ROOT, CFG_COUNT
+    CFG_QUERY_RATE, CFG_FRICTION, CFG_ERP, CFG_SOLVER_ITERS, CFG_MAX_CONTACTS, CFG_SELF_COLLISION, CFG_SCENE_AMP, CFG_AMP_LOCAL_ROOT,
+    CFG_SCENE_GOAL, CFG_RAND_ROT_RESET, CFG_TAR_TIME_MIN, CFG_TAR_TIME_MAX, CFG_MAX_TAR_DIST, CFG_TAR_SUCC_DIST, CFG_TAR_FAIL_DIST, CFG_TAR_SPEED, CFG_POS_REWARD_SCALE,
+    CFG_MIN_TAR_VEL, CFG_MAX_TURN_RATE, CFG_SHARP_TURN_PROB, CFG_SPEED_CHANGE_PROB, CFG_TAR_SPEED_MIN, CFG_TAR_SPEED_MAX, CFG_VEL_REWARD_SCALE, CFG_COUNT
 };
 
 int orc_cfg_count() { return CFG_COUNT; }
@@ -36,6 +38,11 @@ void orc_cfg_default(double* c) {
     c[CFG_RECORD_WORLD_ROOT_ROT] = d.record_world_root_rot; c[CFG_QUERY_RATE] = d.query_rate;
     c[CFG_FRICTION] = d.friction; c[CFG_ERP] = d.erp; c[CFG_SOLVER_ITERS] = d.solver_iters; c[CFG_MAX_CONTACTS] = d.max_contacts; c[CFG_SELF_COLLISION] = d.enable_self_collision;
     c[CFG_SCENE_AMP] = d.scene_amp; c[CFG_AMP_LOCAL_ROOT] = d.enable_amp_obs_local_root;
+    c[CFG_SCENE_GOAL] = d.scene_goal; c[CFG_RAND_ROT_RESET] = d.enable_rand_rot_reset; c[CFG_TAR_TIME_MIN] = d.rand_target_time_min; c[CFG_TAR_TIME_MAX] = d.rand_target_time_max;
+    c[CFG_MAX_TAR_DIST] = d.max_target_dist; c[CFG_TAR_SUCC_DIST] = d.target_succ_dist; c[CFG_TAR_FAIL_DIST] = d.tar_fail_dist; c[CFG_TAR_SPEED] = d.tar_speed;
+    c[CFG_POS_REWARD_SCALE] = d.pos_reward_scale; c[CFG_MIN_TAR_VEL] = d.enable_min_tar_vel; c[CFG_MAX_TURN_RATE] = d.max_heading_turn_rate;
+    c[CFG_SHARP_TURN_PROB] = d.sharp_turn_prob; c[CFG_SPEED_CHANGE_PROB] = d.speed_change_prob; c[CFG_TAR_SPEED_MIN] = d.tar_speed_min; c[CFG_TAR_SPEED_MAX] = d.tar_speed_max;
+    c[CFG_VEL_REWARD_SCALE] = d.vel_reward_scale;
 }
 
 void* orc_create(const double* jm, const double* bd, int J, const double* pd, const double* frames, int F, int loop,
@@ -50,6 +57,11 @@ void* orc_create(const double* jm, const double* bd, int J, const double* pd, co
     cfg.record_world_root_rot = c[CFG_RECORD_WORLD_ROOT_ROT] != 0; cfg.query_rate = c[CFG_QUERY_RATE];
     cfg.friction = c[CFG_FRICTION]; cfg.erp = c[CFG_ERP]; cfg.solver_iters = (int)c[CFG_SOLVER_ITERS]; cfg.max_contacts = (int)c[CFG_MAX_CONTACTS]; cfg.enable_self_collision = c[CFG_SELF_COLLISION] != 0;
     cfg.scene_amp = c[CFG_SCENE_AMP] != 0; cfg.enable_amp_obs_local_root = c[CFG_AMP_LOCAL_ROOT] != 0;
+    cfg.scene_goal = (int)c[CFG_SCENE_GOAL]; cfg.enable_rand_rot_reset = c[CFG_RAND_ROT_RESET] != 0; cfg.rand_target_time_min = c[CFG_TAR_TIME_MIN]; cfg.rand_target_time_max = c[CFG_TAR_TIME_MAX];
+    cfg.max_target_dist = c[CFG_MAX_TAR_DIST]; cfg.target_succ_dist = c[CFG_TAR_SUCC_DIST]; cfg.tar_fail_dist = c[CFG_TAR_FAIL_DIST]; cfg.tar_speed = c[CFG_TAR_SPEED];
+    cfg.pos_reward_scale = c[CFG_POS_REWARD_SCALE]; cfg.enable_min_tar_vel = c[CFG_MIN_TAR_VEL] != 0; cfg.max_heading_turn_rate = c[CFG_MAX_TURN_RATE];
+    cfg.sharp_turn_prob = c[CFG_SHARP_TURN_PROB]; cfg.speed_change_prob = c[CFG_SPEED_CHANGE_PROB]; cfg.tar_speed_min = c[CFG_TAR_SPEED_MIN]; cfg.tar_speed_max = c[CFG_TAR_SPEED_MAX];
+    cfg.vel_reward_scale = c[CFG_VEL_REWARD_SCALE];
     Scene* s = new Scene();
     s->init(jm, bd, J, pd, frames, F, loop != 0, fall_mask, cfg);
     return s;
@@ -310,6 +322,32 @@ double orc_rollout(void* h, int steps, int updates_per_step, double dt, const do
     auto t1 = std::chrono::steady_clock::now();
     return std::chrono::duration<double>(t1 - t0).count();
 }
+
+// ---- goal scenes / multi-clip datasets
+// frames: the concatenation of the clips (total rows x (1 + P)); clip c owns rows starts[c] .. starts[c+1]-1
+void orc_set_clips(void* h, const double* frames, const int* starts, const int* loops, const double* weights, int n) {
+    Scene* s = (Scene*)h;
+    s->clips.resize(n); s->clip_cdf.assign(n, 0);
+    double w = 0;
+    for (int c = 0; c < n; ++c) {
+        s->clips[c].load(s->sk, frames + (size_t)starts[c] * (s->sk.P + 1), starts[c + 1] - starts[c], s->sk.P, loops[c] != 0);
+        w += weights[c]; s->clip_cdf[c] = w;
+    }
+    for (int c = 0; c < n; ++c) s->clip_cdf[c] /= w;
+}
+int orc_num_clips(void* h) { return (int)((Scene*)h)->clips.size(); }
+double orc_clip_duration(void* h, int c) { Scene* s = (Scene*)h; return s->clips.empty() ? s->mo.duration() : s->clips[c].duration(); }
+void orc_goal_rng(void* h, uint64_t seed, uint64_t env_id, uint64_t draws) { Scene* s = (Scene*)h; s->rng_seed = seed; s->rng_env = env_id; s->goal_draws = draws; }
+// reset to a named clip / clip time / yaw (what the device draws with streams 3, 0, 4 of its reset generator)
+void orc_reset_ex(void* h, double kin_time, double max_time, int clip, double yaw) { ((Scene*)h)->reset(kin_time, max_time, clip, (real)yaw); }
+int orc_draw_clip(void* h, double u) { Scene* s = (Scene*)h; int c = 0; int n = (int)s->clip_cdf.size(); while (c < n - 1 && !(u < s->clip_cdf[c])) ++c; return c; }
+void orc_record_goal(void* h, double* out) { ((Scene*)h)->record_goal(out); }
+void orc_goal_state(void* h, double* o) {
+    Scene* s = (Scene*)h;
+    o[0] = s->tar_pos.x; o[1] = s->tar_pos.y; o[2] = s->tar_pos.z; o[3] = s->tar_heading; o[4] = s->tar_speed; o[5] = s->tar_timer; o[6] = s->tar_timer_max;
+    o[7] = s->prev_action_com.x; o[8] = s->prev_action_com.y; o[9] = s->prev_action_com.z; o[10] = s->prev_action_time; o[11] = (double)s->goal_draws;
+}
+void orc_amp_obs_expert_clip(void* h, int clip, double t, double ground_h, double* out) { ((Scene*)h)->amp_obs_expert(t, out, clip, ground_h); }
 
 // Counter-based reset draws of the device path (dm_rand01 in deepmimic_amd/csrc/dm_device.h, host mirror
 // deepmimic_amd/streams.py reset_rand01): splitmix64 of (seed, global env id, episode, stream)

@@ -7,6 +7,7 @@
 // the published behaviour of btMultiBodyDynamicsWorld as recorded in SURVEY.md Appendix C
 // ([EXT-BULLET]); trajectory-level parity against real Bullet is UNPINNED.
 #pragma once
+#include <cstdint>
 #include "orc_rbd.h"
 
 namespace orc {
@@ -23,6 +24,13 @@ struct SceneCfg {
     // --- `--scene imitate_amp` (scenes/SceneImitateAMP.cpp): reward 0, terminate on fall only, AMP observations
     bool scene_amp = false;
     bool enable_amp_obs_local_root = false;   // SceneImitateAMP.cpp:30,42
+    // --- goal-conditioned AMP task scenes: 1 = target_amp (scenes/SceneTargetAMP.cpp), 2 = heading_amp (scenes/SceneHeadingAMP.cpp)
+    int scene_goal = 0;
+    bool enable_rand_rot_reset = false;       // SceneImitate.cpp:131,145,184-189
+    double rand_target_time_min = 1, rand_target_time_max = 5, max_target_dist = 3, target_succ_dist = 0.5;
+    double tar_fail_dist = std::numeric_limits<double>::infinity(), tar_speed = 1, pos_reward_scale = 1;
+    bool enable_min_tar_vel = false;
+    double max_heading_turn_rate = 0.15, sharp_turn_prob = 0.025, speed_change_prob = 0.1, tar_speed_min = 1, tar_speed_max = 1, vel_reward_scale = 1;
     // --- DM-physics v1 constants [EXT-BULLET, SURVEY App. C] ---
     double friction = 0.9 * 0.9;         // link 0.9 (SimCharacter.cpp:26) x ground 0.9 (Ground.cpp:14-27)
     double erp = 0.2;                    // btContactSolverInfo::m_erp2
@@ -81,6 +89,7 @@ struct LDLT {
     }
 };
 
+struct V3d { double x = 0, y = 0, z = 0; };
 struct ContactPt { int link; V3 x; real dist; int link_b = -1; V3 n = V3(0, 1, 0); };   // link_b >= 0: self contact, n points from link_b to link
 struct Row { Vec J; Vec W; real b, lo, hi, lam; int normal_row; real mu; };
 
@@ -108,6 +117,11 @@ struct Scene {
     std::vector<LinkState> links;
     // debug taps for component-level parity tests
     std::vector<ContactPt> dbg_contacts; int dbg_num_rows = 0; Vec dbg_vstar;
+    // ---- goal scenes (cSceneTargetAMP / cSceneHeadingAMP members) and multi-clip datasets (cClipsController)
+    std::vector<Motion> clips; std::vector<double> clip_cdf; int cur_clip = 0;
+    V3d tar_pos; double tar_heading = 0, tar_speed = 1, tar_timer = 0, tar_timer_max = 0;
+    V3d prev_action_com; double prev_action_time = 0;      // cDeepMimicCharController::mPrevActionCOM / mPrevActionTime
+    uint64_t rng_seed = 0, rng_env = 0, goal_draws = 0;    // the device path's counter-based generator (dm_rand01, stream 2)
 
     void init(const double* jm, const double* bd, int J, const double* pd /*J x 2*/, const double* frames, int F, bool loop,
               const int* fall, const SceneCfg& c) {
@@ -143,10 +157,13 @@ struct Scene {
 
     // ------------------------------------------------------------------ reset
     // cSceneSimChar::ResetScene (SceneSimChar.cpp:628-644) + cSceneImitate::ResetCharacters (SceneImitate.cpp:320-368)
-    void reset(double kin_time, double max_time) {
+    // clip / yaw: multi-clip datasets (cClipsController::Reset -> SelectNewMotion) and enable_rand_rot_reset (ResetKinChar, :331-349)
+    void reset(double kin_time, double max_time, int clip = 0, real yaw = 0) {
         timer_time = 0; timer_max = max_time;                       // cTimer::Reset (Timer.cpp:55-73)
+        if (!clips.empty()) { cur_clip = clip; kin.mo = &clips[clip]; }
         // ResetKinChar: origin rot/pos reset, time := rand_time, Pose(t)
         kin.origin_rot = Q4(); kin.origin = V3(); kin.time = kin_time; kin.do_pose();
+        if (yaw != 0) kin.rotate_origin(quat_axis_angle(V3(0, 1, 0), yaw));   // RotateOrigin(EulerToQuaternion(0, theta, 0))
         // SyncCharacters: sim.SetPose/SetVel(kin); ctrl.SetInitTime(kin_time)
         set_sim_state(kin.pose, kin.vel);
         ctrl_time = kin_time; init_time_offset = -kin_time;         // CtController.cpp:144-150
@@ -168,6 +185,7 @@ struct Scene {
         kin.set_root_pos_(root_pos(pose));
         calc_links(sk, pose, vel, links);
         init_hist();
+        if (cfg.scene_goal) goal_reset();
     }
     // cSceneImitateAMP::InitHist (SceneImitateAMP.cpp:152-164): history := kin character one control period before the
     // controller time, origin transform included (cKinCharacter::CalcPose / CalcVel)
@@ -504,6 +522,11 @@ struct Scene {
     void update(double dt) {
         // cRLSceneSimChar::PreUpdate (RLSceneSimChar.cpp:263-275) -> cSceneImitateAMP::NewActionUpdate -> UpdateHist (:166-171)
         if (need_new_action) { prev_pose = reported_pose(); prev_vel = vel; }
+        if (need_new_action && cfg.scene_goal) {                     // cDeepMimicCharController::HandleNewAction (DeepMimicCharController.cpp:262-267)
+            calc_links(sk, pose, vel, links);
+            V3 c = sim_com(); prev_action_com.x = c.x; prev_action_com.y = c.y; prev_action_com.z = c.z;
+            prev_action_time = ctrl_time + dt;                       // mTime has been advanced by this update when UpdateCalcTau latches it
+        }
         timer_time += dt;                                            // cScene::Update
         // 4a UpdateKinChar (SceneImitate.cpp:306-318)
         double prev_phase = kin.phase();
@@ -520,6 +543,94 @@ struct Scene {
         // 7 PostUpdate
         calc_links(sk, pose, vel, links);
         need_new_action = check_next_interval(dt, ctrl_time + init_time_offset, 1.0 / cfg.query_rate);   // CtController.cpp:221-227
+        if (cfg.scene_goal) goal_update(dt);                         // cSceneTargetAMP::Update after cSceneImitate::Update (:137-146)
+    }
+
+    // ------------------------------------------------------------------ goal-conditioned task scenes
+    // Draws: the reference uses the scene's cRand (std::default_random_engine); this path is specified on the device's counter-based
+    // generator -- dm_rand01(seed, global env id, draw counter, stream 2) -- so that oracle and device consume identical numbers.
+    static double rand01(uint64_t seed, uint64_t env, uint64_t episode, uint64_t stream) {
+        uint64_t z = seed + 0x9E3779B97F4A7C15ull * (env * 0x100000001B3ull + episode * 0xD6E8FEB86659FD93ull + stream + 1);
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; z = z ^ (z >> 31);
+        return (double)(z >> 11) * (1.0 / 9007199254740992.0);
+    }
+    double goal_u01() { return rand01(rng_seed, rng_env, goal_draws++, 2); }
+    double goal_uniform(double lo, double hi) { return lo + (hi - lo) * goal_u01(); }
+    double goal_normal(double mean, double stdev) { double u1 = 1.0 - goal_u01(), u2 = goal_u01(); return mean + stdev * std::sqrt(-2.0 * std::log(u1)) * std::cos(6.283185307179586 * u2); }
+    V3 sim_com() const {                                             // cSimCharacter::CalcCOM (SimCharacter.cpp:398-416)
+        V3 c; real tm = 0;
+        for (int j = 0; j < sk.J; ++j) if (sk.valid_body(j)) { c += (real)sk.mass(j) * links[j].com; tm += (real)sk.mass(j); }
+        return c / tm;
+    }
+    void goal_reset_target_pos() {                                   // cSceneTargetAMP::SampleRandTargetPos (:285-299)
+        double dist = goal_uniform(0.0, cfg.max_target_dist), theta = goal_uniform(0.0, 6.283185307179586);
+        tar_pos.x = (double)pose[0] + dist * std::cos(theta); tar_pos.y = 0; tar_pos.z = (double)pose[2] + dist * std::sin(theta);
+    }
+    void goal_timer_reset() { tar_timer = 0; tar_timer_max = goal_uniform(cfg.rand_target_time_min, cfg.rand_target_time_max); }   // cTimer::Reset
+    void goal_reset() {                                              // cSceneTargetAMP::Reset (:130-135) / cSceneHeadingAMP::ResetTarget (:230-239)
+        goal_timer_reset();
+        goal_reset_target_pos();
+        if (cfg.scene_goal == 2) { tar_heading = 0; tar_speed = std::min(std::max(goal_uniform(cfg.tar_speed_min, cfg.tar_speed_max), cfg.tar_speed_min), cfg.tar_speed_max); }
+        else tar_speed = cfg.tar_speed;
+        prev_action_com = V3d(); prev_action_time = ctrl_time;       // cCtController::SetInitTime, cDeepMimicCharController::ResetParams
+    }
+    void goal_update(double dt) {                                    // cSceneTargetAMP::UpdateTarget (:253-268) + cSceneHeadingAMP::UpdateTarget (:214-228)
+        tar_timer += dt;
+        const bool end = tar_timer >= tar_timer_max;
+        if (end) goal_reset_target_pos();
+        if (cfg.scene_goal == 2 && end) {
+            const bool sharp = goal_u01() < cfg.sharp_turn_prob;
+            tar_heading += sharp ? goal_uniform(-3.141592653589793, 3.141592653589793) : goal_normal(0.0, cfg.max_heading_turn_rate);
+            if (goal_u01() < cfg.speed_change_prob) tar_speed = std::min(std::max(goal_uniform(cfg.tar_speed_min, cfg.tar_speed_max), cfg.tar_speed_min), cfg.tar_speed_max);
+        }
+        if (end) goal_timer_reset();
+    }
+    bool goal_dist_fail() const {                                    // cSceneTargetAMP::CheckTarDistFail (:306-317); cSceneHeadingAMP: false
+        if (cfg.scene_goal != 1) return false;
+        real dx = pose[0] - (real)tar_pos.x, dz = pose[2] - (real)tar_pos.z;
+        return dx * dx + dz * dz > (real)cfg.tar_fail_dist * (real)cfg.tar_fail_dist;
+    }
+    void record_goal(double* out) const {
+        Vec rp = reported_pose();
+        real heading = calc_heading(root_rot(rp));
+        if (cfg.scene_goal == 1) {                                   // cSceneTargetAMP::RecordGoal (:195-223)
+            V3 rel((real)tar_pos.x - rp[0], 0, (real)tar_pos.z - rp[2]);
+            real d = norm(rel);
+            V3 r(1, 0, 0);
+            if (d > (real)0.0001) r = (rot_axis(V3(0, 1, 0), -heading) * rel) / d;
+            out[0] = r.x; out[1] = r.z; out[2] = d;
+        } else {                                                     // cSceneHeadingAMP::RecordGoal (:150-166)
+            real th = (real)tar_heading - heading;
+            out[0] = std::cos(th); out[1] = -std::sin(th); out[2] = tar_speed;
+        }
+    }
+    double calc_goal_reward() const {
+        if (has_fallen()) return 0;
+        V3 com = sim_com();
+        V3 dcom(com.x - (real)prev_action_com.x, com.y - (real)prev_action_com.y, com.z - (real)prev_action_com.z);
+        real step_dur = (real)(ctrl_time - prev_action_time);
+        real ts = (real)tar_speed;
+        if (cfg.scene_goal == 1) {                                   // cSceneTargetAMP::CalcReward (:3-81)
+            if (goal_dist_fail()) return 0;
+            Vec rp = reported_pose();
+            real dx = (real)tar_pos.x - rp[0], dz = (real)tar_pos.z - rp[2], dist_sq = dx * dx + dz * dz;
+            real pos_reward = std::exp(-(real)cfg.pos_reward_scale * dist_sq), vel_reward = 0;
+            if (dist_sq < (real)cfg.target_succ_dist * (real)cfg.target_succ_dist) vel_reward = 1;
+            else {
+                V3 ct((real)tar_pos.x - com.x, 0, (real)tar_pos.z - com.z);
+                real cd = norm(ct);
+                V3 dir; if (cd > (real)0.0001) dir = ct / cd;
+                real avg_vel = dot(dir, dcom) / step_dur, vel_err = ts - avg_vel;
+                if (!(avg_vel < 0)) { if (cfg.enable_min_tar_vel) vel_err = std::max(vel_err, (real)0); vel_reward = std::exp(-((real)4 / (ts * ts)) * vel_err * vel_err); }
+            }
+            return (real)0.6 * pos_reward + (real)0.4 * vel_reward;
+        }
+        V3 av = dcom / step_dur; av.y = 0;                           // cSceneHeadingAMP::CalcReward (:3-43)
+        real avg_speed = std::cos((real)tar_heading) * av.x - std::sin((real)tar_heading) * av.z;
+        if (!(avg_speed > 0)) return 0;
+        real vel_err = ts - avg_speed;
+        if (cfg.enable_min_tar_vel) vel_err = std::max(vel_err, (real)0);
+        return std::exp(-(real)cfg.vel_reward_scale * vel_err * vel_err);
     }
     // cSceneImitate::SyncKinCharNewCycle (SceneImitate.cpp:420-444)
     void sync_kin_new_cycle() {
@@ -546,7 +657,8 @@ struct Scene {
     int check_terminate() const {
         bool fail = cfg.enable_fall_end && has_fallen();
         // cSceneImitateAMP::CheckTerminate (SceneImitateAMP.cpp:184-188) keeps only the fall test of cRLSceneSimChar (:187-197)
-        if (!fail && !cfg.scene_amp && mo.is_over(kin.time)) fail = true;   // SceneImitate.cpp:193-205
+        if (!fail && !cfg.scene_amp && kin.mo->is_over(kin.time)) fail = true;   // SceneImitate.cpp:193-205
+        if (!fail && cfg.scene_goal && goal_dist_fail()) fail = true;            // cSceneTargetAMP::CheckTerminate (:319-345)
         return fail ? TERM_FAIL : TERM_NULL;
     }
     bool is_episode_end() const { return timer_time >= timer_max || check_terminate() != TERM_NULL; }
@@ -563,6 +675,7 @@ struct Scene {
     // ------------------------------------------------------------------ reward (SceneImitate.cpp:7-127,163-175)
     double calc_reward(double* terms /*5 errors, optional*/ = nullptr) const {
         // cSceneImitateAMP::CalcReward (SceneImitateAMP.cpp:173-182): 0 outside the test-mode time-warp score
+        if (cfg.scene_goal) { if (terms) for (int i = 0; i < 5; ++i) terms[i] = 0; return calc_goal_reward(); }
         if (cfg.scene_amp) { if (terms) for (int i = 0; i < 5; ++i) terms[i] = 0; return 0; }
         if (has_fallen()) return 0;
         const int J = sk.J;
@@ -707,12 +820,13 @@ struct Scene {
     }
     // RecordAMPObsExpert (:115-138) with the random clip time passed in: raw cMotion::CalcFrame / CalcFrameVel (no origin,
     // no cycle offset) at t and t - 1/query_rate, ground height := kin origin y
-    void amp_obs_expert(double t, double* out) const {
+    void amp_obs_expert(double t, double* out, int clip = -1, double ground_h = std::numeric_limits<double>::quiet_NaN()) const {
+        const Motion& mm = (clip >= 0 && !clips.empty()) ? clips[clip] : mo;      // SampleExpertMotion with a cClipsController
         Vec p, v, pp, pv;
-        mo.calc_frame(sk, t, p); mo.calc_frame_vel(t, v);
+        mm.calc_frame(sk, t, p); mm.calc_frame_vel(t, v);
         double tp = t - 1.0 / cfg.query_rate;
-        mo.calc_frame(sk, tp, pp); mo.calc_frame_vel(tp, pv);
-        build_amp_obs(pp, pv, p, v, kin.origin.y, out);
+        mm.calc_frame(sk, tp, pp); mm.calc_frame_vel(tp, pv);
+        build_amp_obs(pp, pv, p, v, std::isnan(ground_h) ? (double)kin.origin.y : ground_h, out);
     }
 };
 

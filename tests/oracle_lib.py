@@ -11,7 +11,10 @@ ORACLE_DIR = os.path.join(ROOT, "oracle")
 CFG_KEYS = ["num_sim_substeps", "world_scale", "grav_x", "grav_y", "grav_z", "sync_root_pos", "sync_root_rot",
             "enable_fall_end", "enable_contact_fall", "enable_root_rot_fail", "enable_rand_placement",
             "enable_phase_input", "record_world_root_pos", "record_world_root_rot", "query_rate",
-            "friction", "erp", "solver_iters", "max_contacts", "self_collision", "scene_amp", "amp_local_root"]
+            "friction", "erp", "solver_iters", "max_contacts", "self_collision", "scene_amp", "amp_local_root",
+            "scene_goal", "rand_rot_reset", "tar_time_min", "tar_time_max", "max_tar_dist", "tar_succ_dist", "tar_fail_dist", "tar_speed",
+            "pos_reward_scale", "min_tar_vel", "max_turn_rate", "sharp_turn_prob", "speed_change_prob", "tar_speed_min", "tar_speed_max",
+            "vel_reward_scale"]
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int)
@@ -56,7 +59,13 @@ class Oracle:
                     enable_root_rot_fail=c.enable_root_rot_fail, enable_rand_placement=c.enable_rand_char_placement,
                     enable_phase_input=tables.enable_phase_input, record_world_root_pos=tables.record_world_root_pos,
                     record_world_root_rot=tables.record_world_root_rot, query_rate=tables.query_rate,
-                    scene_amp=(c.scene == "imitate_amp"), amp_local_root=getattr(c, "enable_amp_obs_local_root", False))
+                    scene_amp=(c.scene in ("imitate_amp", "heading_amp", "target_amp")), amp_local_root=getattr(c, "enable_amp_obs_local_root", False),
+                    scene_goal=tables.goal_kind, rand_rot_reset=c.enable_rand_rot_reset, tar_time_min=c.rand_target_time_min,
+                    tar_time_max=c.rand_target_time_max, max_tar_dist=c.max_target_dist, tar_succ_dist=c.target_succ_dist,
+                    tar_fail_dist=c.tar_fail_dist, tar_speed=c.tar_speed, pos_reward_scale=c.pos_reward_scale, min_tar_vel=c.enable_min_tar_vel,
+                    max_turn_rate=c.max_heading_turn_rate, sharp_turn_prob=c.sharp_turn_prob, speed_change_prob=c.speed_change_prob,
+                    tar_speed_min=(c.tar_speed if c.tar_speed_min is None else c.tar_speed_min),
+                    tar_speed_max=(c.tar_speed if c.tar_speed_max is None else c.tar_speed_max), vel_reward_scale=c.vel_reward_scale)
         vals.update(cfg_overrides)
         for k, v in vals.items():
             cfg[CFG_KEYS.index(k)] = float(v)
@@ -66,8 +75,14 @@ class Oracle:
         pd = np.ascontiguousarray(tables.pd_params, dtype=np.float64)
         fr = np.ascontiguousarray(tables.frames, dtype=np.float64)
         fall = np.ascontiguousarray(tables.fall_mask(), dtype=np.int32)
-        self.h = C.c_void_p(lib.orc_create(_d(jm), _d(bd), jm.shape[0], _d(pd), _d(fr), fr.shape[0], int(tables.loop),
+        n0 = fr.shape[0] if tables.clip_starts is None else int(tables.clip_starts[1])
+        self.h = C.c_void_p(lib.orc_create(_d(jm), _d(bd), jm.shape[0], _d(pd), _d(fr), n0, int(tables.loop if tables.clip_starts is None else tables.clip_loops[0]),
                                            fall.ctypes.data_as(_ip), _d(cfg)))
+        if tables.clip_starts is not None:
+            cs = np.ascontiguousarray(tables.clip_starts, dtype=np.int32); cl = np.ascontiguousarray(tables.clip_loops, dtype=np.int32)
+            cw = np.ascontiguousarray(tables.clip_weights, dtype=np.float64)
+            lib.orc_set_clips(self.h, _d(fr), cs.ctypes.data_as(_ip), cl.ctypes.data_as(_ip), _d(cw), len(cw))
+        lib.orc_clip_duration.restype = C.c_double
         dims = np.zeros(5, dtype=np.int32)
         lib.orc_dims(self.h, dims.ctypes.data_as(_ip))
         self.J, self.P, self.A, self.S, self.F = [int(x) for x in dims]
@@ -267,3 +282,31 @@ class Oracle:
             if end_early and self.is_episode_end():
                 return u + 1
         return n_updates
+
+    # ---- goal scenes / multi-clip datasets
+    def goal_rng(self, seed, env_id, draws=0):
+        self.lib.orc_goal_rng(self.h, C.c_uint64(int(seed)), C.c_uint64(int(env_id)), C.c_uint64(int(draws)))
+
+    def reset_ex(self, kin_time, max_time=np.inf, clip=0, yaw=0.0):
+        self.lib.orc_reset_ex(self.h, C.c_double(kin_time), C.c_double(max_time), int(clip), C.c_double(yaw))
+
+    def draw_clip(self, u):
+        return int(self.lib.orc_draw_clip(self.h, C.c_double(u)))
+
+    def clip_duration(self, c):
+        return float(self.lib.orc_clip_duration(self.h, int(c)))
+
+    def record_goal(self):
+        out = np.zeros(3)
+        self.lib.orc_record_goal(self.h, _d(out))
+        return out
+
+    def goal_state(self):
+        out = np.zeros(12)
+        self.lib.orc_goal_state(self.h, _d(out))
+        return out
+
+    def amp_obs_expert_clip(self, clip, t, ground_h=0.0):
+        out = np.zeros(self.amp_obs_size())
+        self.lib.orc_amp_obs_expert_clip(self.h, int(clip), C.c_double(t), C.c_double(ground_h), _d(out))
+        return out

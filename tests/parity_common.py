@@ -443,3 +443,58 @@ def stepwise_live_compare(name, precision, lib_path, steps, n, seed, wave_packin
                 ep[e] += 1
                 o.reset(o.duration * streams.reset_rand01(seed, e, int(ep[e]), 0))
     return dr, ds, alive, ok
+
+
+def goal_rollout_compare(t, precision, lib_path, steps, n, seed, wave_packing=0, action_sigma=0.15):
+    """Goal-conditioned task scenes (target_amp / heading_amp; multi-clip datasets, enable_rand_rot_reset): closed-loop rollout
+    with seeded random actions THROUGH auto-resets.  The oracle mirrors every device draw: the reset generator's streams 0 (clip
+    time), 1 (episode timer), 3 (clip by weight), 4 (yaw) keyed by the episode counter, and the goal generator (stream 2, draw
+    counter kept in the goal row).  Returns dict of worst deviations + counts."""
+    from deepmimic_amd import streams
+    env = BatchEnv(t, n, precision=precision, lib_path=lib_path, wave_packing=wave_packing, seed=seed)
+    g0 = env.get_goal_state()                      # draws consumed by the reset inside dm_create
+    env.reset()
+    ep = env.get_state()["flags"][:, 2].astype(np.int64)
+    tmin, tmax = float(t.cfg.time_lim_min), float(t.cfg.time_lim_max)
+
+    def draw(o, e, episode):
+        clip = o.draw_clip(streams.reset_rand01(seed, e, episode, 3)) if t.num_clips > 1 else 0
+        kt = o.clip_duration(clip) * streams.reset_rand01(seed, e, episode, 0)
+        mt = tmin + (tmax - tmin) * streams.reset_rand01(seed, e, episode, 1) if tmax > tmin else tmax
+        yaw = (-np.pi + 2 * np.pi * streams.reset_rand01(seed, e, episode, 4)) if t.cfg.enable_rand_rot_reset else 0.0
+        return clip, kt, mt, yaw
+
+    oracles = []
+    for e in range(n):
+        o = Oracle(t)
+        o.goal_rng(seed, e, int(g0[e][11]))
+        o.reset_ex(*[(lambda c, k, m, y: (k, m, c, y))(*draw(o, e, int(ep[e]) - 1))][0])
+        oracles.append(o)
+    w = dict(reward=0.0, state=0.0, goal=0.0, goal_state=0.0, resets=0, live=0, flags_ok=True, clips=set(), dist_fail=0)
+    gs = env.get_goal_state(); clips = env.get_clips(); q = env.query(); qg = env.query_goal()
+    for e, o in enumerate(oracles):
+        assert clips[e] == o.lib.orc_num_clips(o.h) * 0 + (draw(o, e, int(ep[e]) - 1)[0]), "clip draw mismatch"
+        w["goal_state"] = max(w["goal_state"], np.abs(gs[e] - o.goal_state()).max())
+        w["goal"] = max(w["goal"], np.abs(qg[e] - o.record_goal()).max())
+        w["state"] = max(w["state"], np.abs(q["state"][e] - o.record_state()).max())
+    rng = np.random.default_rng(seed + 100)
+    for k in range(steps):
+        acts = (action_sigma * rng.normal(size=(n, env.A))).astype(np.float32)
+        out = env.step(acts, DT, 20, auto_reset=True)
+        gs = env.get_goal_state(); clips = env.get_clips()
+        for e, o in enumerate(oracles):
+            o.set_action(acts[e].astype(np.float64))
+            o.control_step(20, DT)
+            r = o.calc_reward(); term, end = o.check_terminate(), o.is_episode_end()
+            w["reward"] = max(w["reward"], abs(float(out["reward"][e]) - r)); w["live"] += int(r != 0.0)
+            w["flags_ok"] &= int(out["terminate"][e]) == term and bool(out["episode_end"][e]) == end
+            if end:
+                c, kt, mt, yaw = draw(o, e, int(ep[e]))
+                o.reset_ex(kt, mt, c, yaw); ep[e] += 1; w["resets"] += 1
+                assert clips[e] == c, "clip draw mismatch after reset"
+            w["clips"].add(int(clips[e]))
+            so = o.record_state()
+            w["state"] = max(w["state"], np.abs(out["state"][e] - so).max() / max(1.0, np.abs(so).max()))
+            w["goal"] = max(w["goal"], np.abs(out["goal"][e] - o.record_goal()).max())
+            w["goal_state"] = max(w["goal_state"], np.abs(gs[e] - o.goal_state()).max())
+    return w

@@ -1,0 +1,170 @@
+"""Goal-conditioned AMP task scenes: `--scene target_amp` (scenes/SceneTargetAMP.cpp) and
+`--scene heading_amp` (scenes/SceneHeadingAMP.cpp) with multi-clip datasets (anim/ClipsController.cpp) and
+enable_rand_rot_reset (scenes/SceneImitate.cpp:331-349).  Device path (emulator build on CPU, HIP library marked gpu) vs
+the oracle restatement, closed loop with seeded random actions through auto-resets; every random draw is mirrored."""
+import numpy as np
+import pytest
+
+import parity_common as pc
+from deepmimic_amd import model
+from deepmimic_amd.core import BatchEnv
+from oracle_lib import Oracle
+
+SCENES = ["amp_heading_zombie", "amp_target_zombie", "amp_heading_clips4"]
+
+
+def test_assets_describe_the_scenes():
+    h, tg, c4 = (model.load_asset(n) for n in SCENES)
+    assert (h.goal_kind, tg.goal_kind, c4.goal_kind) == (2, 1, 2) and h.goal_dim == 3
+    assert h.cfg.enable_rand_rot_reset and h.cfg.enable_amp_obs_local_root and not h.enable_phase_input
+    assert (h.cfg.rand_target_time_min, h.cfg.rand_target_time_max) == (0.2, 0.5)            # args/train_amp_heading_humanoid3d_zombie_args.txt
+    assert (tg.cfg.rand_target_time_min, tg.cfg.rand_target_time_max, tg.cfg.tar_fail_dist) == (5.0, 10.0, 15.0)
+    assert c4.num_clips == 4 and list(c4.clip_loops) == [1, 1, 0, 0] and h.num_clips == 1
+
+
+def test_goal_closed_form(oracle_built):
+    """RecordGoal / CalcReward against the formulas of the scene sources evaluated by hand (numpy) on the oracle's state."""
+    for name in ("amp_heading_zombie", "amp_target_zombie"):
+        t = model.load_asset(name)
+        o = Oracle(t); o.goal_rng(9, 0, 0); o.reset_ex(0.4, np.inf, 0, 0.7)
+        a = np.zeros(o.A)
+        o.set_action(a); o.control_step(20, pc.DT, end_early=False)
+        gs = o.goal_state(); p, v = o.sim_state()
+        links = o.links(); mass = t.body_defs[:, model.BD_MASS]
+        com = (links[:, 0:3] * mass[:, None]).sum(0) / mass.sum()
+        fwd = np.array([1 - 2 * (p[5] ** 2 + p[6] ** 2), 0, 2 * (p[4] * p[6] - p[3] * p[5])])     # q * e_x, x and z components
+        heading = np.arctan2(-fwd[2], fwd[0])
+        step_dur = o.lib.orc_time(o.h) + 0.4 - gs[10]
+        dcom = com - gs[7:10]
+        if t.goal_kind == 2:
+            th = gs[3] - heading
+            assert np.abs(o.record_goal() - [np.cos(th), -np.sin(th), gs[4]]).max() < 1e-12
+            av = dcom / step_dur; av[1] = 0
+            sp = np.cos(gs[3]) * av[0] - np.sin(gs[3]) * av[2]
+            want = np.exp(-t.cfg.vel_reward_scale * (gs[4] - sp) ** 2) if sp > 0 else 0.0
+        else:
+            rel = np.array([gs[0] - p[0], 0, gs[2] - p[2]]); d = np.linalg.norm(rel)
+            c, s = np.cos(-heading), np.sin(-heading)
+            r = np.array([c * rel[0] + s * rel[2], 0, -s * rel[0] + c * rel[2]]) / d
+            assert np.abs(o.record_goal() - [r[0], r[2], d]).max() < 1e-12
+            ct = np.array([gs[0] - com[0], 0, gs[2] - com[2]]); cd = np.linalg.norm(ct)
+            avg = ct.dot(dcom) / cd / step_dur
+            ve = max(t.cfg.tar_speed - avg, 0.0) if t.cfg.enable_min_tar_vel else t.cfg.tar_speed - avg
+            vr = 1.0 if d < t.cfg.target_succ_dist else (0.0 if avg < 0 else np.exp(-4 / t.cfg.tar_speed ** 2 * ve * ve))
+            want = 0.6 * np.exp(-t.cfg.pos_reward_scale * d * d) + 0.4 * vr
+        assert abs(o.calc_reward() - want) < 1e-12, (name, o.calc_reward(), want)
+        assert abs(step_dur - 19 * pc.DT) < 1e-12        # HandleNewAction latches mTime after its first increment
+
+
+@pytest.mark.parametrize("name,pack", [("amp_heading_zombie", 1), ("amp_target_zombie", 1), ("amp_heading_zombie", 2), ("amp_heading_clips4", 1)])
+def test_goal_scene_matches_oracle_emulator(emu_lib, name, pack):
+    t = model.load_asset(name)
+    w = pc.goal_rollout_compare(t, 64, emu_lib, steps=24, n=2, seed=5, wave_packing=pack)
+    print(name, w)
+    assert w["flags_ok"] and w["resets"] >= 1 and w["live"] >= 10
+    tol = 1e-6 if name != "amp_heading_clips4" else 1e-3    # the 4-clip dataset starts some episodes lying on the ground (stiff contacts)
+    assert w["reward"] < tol and w["goal"] < 10 * tol and w["goal_state"] < tol and w["state"] < max(1e-5, 50 * tol)
+
+
+def test_target_distance_failure(emu_lib):
+    """cSceneTargetAMP::CheckTerminate: Fail when the root is further than tar_fail_dist from the target (SceneTargetAMP.cpp:306-345)"""
+    t = model.load_asset("amp_target_zombie")
+    env = BatchEnv(t, 2, precision=64, lib_path=emu_lib, seed=2, wave_packing=1)
+    env.reset()
+    gs = env.get_goal_state()
+    st = env.get_state()
+    gs[1, 0] = st["pose"][1, 0] + 15.5           # env 1: target 15.5 m away (tar_fail_dist = 15)
+    gs[1, 2] = st["pose"][1, 2]
+    env.set_goal_state(gs)
+    q = env.query()
+    assert q["terminate"][0] == 0 and q["terminate"][1] == 1 and q["episode_end"][1] == 1 and q["reward"][1] == 0.0
+    assert abs(q["goal"][1][2] - 15.5) < 1e-5
+    out = env.step(np.zeros((2, env.A), np.float32), pc.DT, 20, auto_reset=True)
+    assert out["terminate"][1] == 1 and out["goal"][1][2] <= t.cfg.max_target_dist + 1e-5     # reset drew a new target within max_target_dist
+
+
+def test_rand_rot_reset_spreads_headings(emu_lib):
+    t = model.load_asset("amp_heading_zombie")
+    env = BatchEnv(t, 16, precision=64, lib_path=emu_lib, seed=4, wave_packing=1)
+    env.reset()
+    q = env.get_state()["pose"][:, 3:7]
+    yaw = 2 * np.arctan2(q[:, 2], q[:, 0])
+    assert yaw.std() > 0.8                        # uniform in [-pi, pi): std ~ 1.8; without the random rotation all 16 are equal
+    assert (np.abs(env.get_state()["pose"][:, [0, 2]]) < 1e-12).all()     # SetCharRandPlacement keeps x, z at 0
+
+
+def test_facade_goal_surface(emu_lib, monkeypatch):
+    import os, sys
+    compat = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "deepmimic_amd", "compat")
+    if compat not in sys.path:
+        sys.path.insert(0, compat)
+    from DeepMimicCore import DeepMimicCore
+    monkeypatch.setenv("DM_HIP_LIB", emu_lib); monkeypatch.setenv("DM_PRECISION", "64")
+    for name, scene_name in (("amp_heading_zombie", "Heading AMP"), ("amp_target_zombie", "Target AMP")):
+        core = DeepMimicCore.cDeepMimicCore(False)
+        core.SeedRand(3); core.LoadTables(model.load_asset(name), 10); core.Init()
+        assert core.GetName() == scene_name and core.GetGoalSize(0) == 3 and core.EnableAMPTaskReward() is True
+        assert core.BuildGoalOffset(0) == [0.0] * 3 and core.BuildGoalScale(0) == [1.0] * 3 and core.BuildGoalNormGroups(0) == [0] * 3
+        g = core.RecordGoal(0)
+        assert len(g) == 3 and np.isfinite(g).all() and core.GetAMPObsSize() > 0
+        core.SetAction(0, [0.0] * core.GetActionSize(0))
+        for _ in range(20):
+            core.Update(1.0 / 600)
+        assert 0.0 <= core.CalcReward(0) <= 1.0 and len(core.RecordAMPObsAgent(0)) == core.GetAMPObsSize()
+        assert len(core.RecordAMPObsExpert(0)) == core.GetAMPObsSize()
+        core.Shutdown()
+
+
+def test_amp_expert_multi_clip(emu_lib, oracle_built):
+    """RecordAMPObsExpert with a cClipsController: the sample's clip and time are given; device vs oracle"""
+    t = model.load_asset("amp_heading_clips4")
+    env = BatchEnv(t, 1, precision=64, lib_path=emu_lib, wave_packing=1)
+    o = Oracle(t)
+    clips = np.array([0, 1, 2, 3, 2], dtype=np.int32)
+    times = np.array([0.3, 1.0, 2.5, 0.1, 0.02])
+    got = env.amp_expert_clips(5, clips, times, 0.0)
+    for i in range(5):
+        want = o.amp_obs_expert_clip(int(clips[i]), float(times[i]), 0.0)
+        assert np.abs(got[i] - want).max() < 2e-6, (i, np.abs(got[i] - want).max())
+
+
+# ---- the HIP kernels
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,prec,pack", [("amp_heading_zombie", 64, 1), ("amp_target_zombie", 64, 2), ("amp_heading_zombie", 32, 2),
+                                            ("amp_target_zombie", 32, 1), ("amp_heading_clips4", 64, 0)])
+def test_goal_scene_matches_oracle_gpu(hip_lib, name, prec, pack):
+    t = model.load_asset(name)
+    w = pc.goal_rollout_compare(t, prec, hip_lib, steps=120, n=8, seed=6, wave_packing=pack)
+    print(name, prec, pack, w)
+    assert w["flags_ok"] or prec == 32
+    assert w["resets"] >= 4 and w["live"] >= 100
+    if name == "amp_heading_clips4":
+        assert len(w["clips"]) >= 3 and w["goal_state"] < 1e-3
+        return
+    if prec == 64:
+        assert w["reward"] < 1e-5 and w["goal"] < 1e-5 and w["goal_state"] < 1e-6 and w["state"] < 1e-4
+    else:
+        assert w["reward"] < 5e-3 and w["goal"] < 5e-3 and w["goal_state"] < 5e-3
+
+
+@pytest.mark.gpu
+def test_goal_scenes_4096_auto_reset(hip_lib):
+    """full-size property check: 4096 envs of each task scene, random actions, auto-reset; finite outputs, rewards in [0, 1],
+    goal vectors well formed (heading: unit direction + speed in range; target: unit direction + distance <= tar_fail_dist)"""
+    for name in ("amp_heading_zombie", "amp_target_zombie"):
+        t = model.load_asset(name)
+        env = BatchEnv(t, 4096, seed=8)
+        env.reset()
+        rng = np.random.default_rng(0)
+        ends = 0
+        for k in range(30):
+            out = env.step((0.2 * rng.normal(size=(4096, env.A))).astype(np.float32), pc.DT, 20, auto_reset=True, amp=True)
+            assert np.isfinite(out["state"]).all() and np.isfinite(out["goal"]).all() and np.isfinite(out["amp_obs"]).all()
+            assert (out["reward"] >= 0).all() and (out["reward"] <= 1 + 1e-6).all()
+            assert np.abs(np.linalg.norm(out["goal"][:, :2], axis=1) - 1).max() < 1e-4
+            ends += int(out["episode_end"].sum())
+        assert ends > 0 and out["reward"].mean() > 0.01
+        if t.goal_kind == 2:
+            assert (out["goal"][:, 2] >= t.cfg.tar_speed_min - 1e-6).all() and (out["goal"][:, 2] <= t.cfg.tar_speed_max + 1e-6).all()
+        else:
+            assert (out["goal"][:, 2] <= t.cfg.tar_fail_dist + 1e-3).all()

@@ -19,13 +19,18 @@ SCENES = {
     "humanoid3d_run": ("args/run_humanoid3d_run_args.txt", None),
     "humanoid3d_backflip": ("args/run_humanoid3d_backflip_args.txt", None),
     "dog3d_spin": ("args/run_dog3d_spin_args.txt", None),          # sync_char_root_rot = true
+    # goal-conditioned AMP task scenes: `--kin_ctrl clips` datasets, enable_rand_rot_reset
+    "amp_heading_zombie": ("args/train_amp_heading_humanoid3d_zombie_args.txt", None),
+    "amp_target_zombie": ("args/train_amp_target_humanoid3d_zombie_args.txt", None),
+    # a 4-clip dataset (two looping, two non-looping clips) under the heading task: exercises clip selection by weight
+    "amp_heading_clips4": ("args/train_amp_heading_getup_humanoid3d_locomotion_getup_args.txt", ["--scene", "heading_amp"]),
 }
 
 def main():
     out_dir = model.ASSET_DIR
     os.makedirs(out_dir, exist_ok=True)
-    for name, (arg_file, _) in SCENES.items():
-        t = model.load_scene_from_args(["--arg_file", arg_file], data_root=REF)
+    for name, (arg_file, extra) in SCENES.items():
+        t = model.load_scene_from_args(["--arg_file", arg_file] + (extra or []), data_root=REF)
         path = os.path.join(out_dir, name + ".json")
         with open(path, "w") as f:
             json.dump(t.to_json(), f, separators=(",", ":"))

@@ -470,7 +470,7 @@ def goal_rollout_compare(t, precision, lib_path, steps, n, seed, wave_packing=0,
         o.goal_rng(seed, e, int(g0[e][11]))
         o.reset_ex(*[(lambda c, k, m, y: (k, m, c, y))(*draw(o, e, int(ep[e]) - 1))][0])
         oracles.append(o)
-    w = dict(reward=0.0, state=0.0, goal=0.0, goal_state=0.0, resets=0, live=0, flags_ok=True, clips=set(), dist_fail=0)
+    w = dict(reward=0.0, state=0.0, goal=0.0, goal_state=0.0, resets=0, live=0, flags_ok=True, clips=set(), dist_fail=0, reward_errs=[], goal_errs=[])
     gs = env.get_goal_state(); clips = env.get_clips(); q = env.query(); qg = env.query_goal()
     for e, o in enumerate(oracles):
         assert clips[e] == o.lib.orc_num_clips(o.h) * 0 + (draw(o, e, int(ep[e]) - 1)[0]), "clip draw mismatch"
@@ -487,6 +487,7 @@ def goal_rollout_compare(t, precision, lib_path, steps, n, seed, wave_packing=0,
             o.control_step(20, DT)
             r = o.calc_reward(); term, end = o.check_terminate(), o.is_episode_end()
             w["reward"] = max(w["reward"], abs(float(out["reward"][e]) - r)); w["live"] += int(r != 0.0)
+            w["reward_errs"].append(abs(float(out["reward"][e]) - r))
             w["flags_ok"] &= int(out["terminate"][e]) == term and bool(out["episode_end"][e]) == end
             if end:
                 c, kt, mt, yaw = draw(o, e, int(ep[e]))
@@ -496,5 +497,7 @@ def goal_rollout_compare(t, precision, lib_path, steps, n, seed, wave_packing=0,
             so = o.record_state()
             w["state"] = max(w["state"], np.abs(out["state"][e] - so).max() / max(1.0, np.abs(so).max()))
             w["goal"] = max(w["goal"], np.abs(out["goal"][e] - o.record_goal()).max())
+            w["goal_errs"].append(np.abs(out["goal"][e] - o.record_goal()).max())
             w["goal_state"] = max(w["goal_state"], np.abs(gs[e] - o.goal_state()).max())
+    w["reward_mean"] = float(np.mean(w.pop("reward_errs"))); w["goal_mean"] = float(np.mean(w.pop("goal_errs")))
     return w

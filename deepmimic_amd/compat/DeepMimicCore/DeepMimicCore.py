@@ -93,6 +93,7 @@ class cDeepMimicCore(object):
         self._batch = os.environ.get("DM_FACADE_BATCH", "1") != "0"
         self._period = 1.0 / float(self._tables.query_rate)
         self.stats = {"launches": 0, "updates": 0, "rollbacks": 0}     # kernel launches of the stepping path vs Update() calls
+        self._build_time_warper()
         self._after_reset()
 
     def _apply_mode(self):
@@ -104,9 +105,50 @@ class cDeepMimicCore(object):
             raise RuntimeError("cDeepMimicCore: Init() has not been called")
         return self._env
 
+    # ---- test-mode time-warp score of `--scene imitate_amp` (cSceneImitateAMP::BuildTimeWarper / UpdateTimeWarper /
+    # CalcRewardTimeWarp, scenes/SceneImitateAMP.cpp:173-205,417-480): an evaluation-only return, computed on the host from the
+    # env state at every action boundary; the stepping kernels do not know about it
+    def _build_time_warper(self):
+        self._tw = None
+        c = self._tables.cfg
+        if c.scene != "imitate_amp" or not getattr(c, "enable_test_time_warp", True) or self._tables.num_clips > 1:
+            return
+        ends = [x for x in (c.time_lim_max, c.time_end_lim_max) if x is not None]
+        max_time = max(ends) if ends else np.inf
+        if not np.isfinite(max_time):
+            return                                                   # BuildTimeWarper only builds it for a finite episode length
+        self._tw = {"size": int(np.ceil(self._tables.query_rate * max_time)) + 2, "sim": [], "kin": [],
+                    "sampler": _model.KinSampler(self._tables)}
+
+    def _tw_sample(self, st=None):
+        if self._tw is None or self._mode != self.eModeTest:
+            return
+        if len(self._tw["sim"]) >= self._tw["size"]:
+            raise RuntimeError("Time warper buffer overflow, capacity: %d" % self._tw["size"])   # cDynamicTimeWarper::AddSample0
+        st = self._env.get_state() if st is None else st
+        kin = st["kin"][0]
+
+        def data(pose):                                              # BuildTimeWarpData (:462-480)
+            jp = _model.joint_world_positions(self._tables, pose)
+            out = jp - jp[0]
+            out[0] = (0.0, jp[0][1], 0.0)
+            return out.reshape(-1)
+        self._tw["sim"].append(data(st["pose"][0]))
+        self._tw["kin"].append(data(self._tw["sampler"].pose(float(st["clocks"][0][0]), kin[0:3], kin[3:7])))
+
+    def _time_warp_reward(self):
+        tw = self._tw
+        if not tw["sim"]:
+            return 0.0
+        cost = _model.time_warp_cost(np.array(tw["sim"]), np.array(tw["kin"]))
+        return cost + (tw["size"] - len(tw["sim"])) * 1.0           # term_step_cost = 1 per step the episode fell short
+
     # ---- stepping engine ------------------------------------------------------------------------------------------------
     def _after_reset(self):
         self._env.reset()
+        if self._tw is not None:
+            self._tw["sim"], self._tw["kin"] = [], []
+            self._tw_sample()                                        # ResetTimeWarper -> UpdateTimeWarper
         self._sync_clocks()
         self._need = True                  # cDeepMimicCharController::Reset leaves NeedNewAction() == true
         self._pending = None               # action handed over by SetAction, applied by the next launch
@@ -180,9 +222,13 @@ class cDeepMimicCore(object):
                 self._materialize()          # a different timestep mid-step
             self._spec = None
         action, self._pending = self._pending, None
+        snap = None
+        if self._need and self._tw is not None and self._mode == self.eModeTest:
+            snap = env.get_state()
+            self._tw_sample(snap)                # cSceneImitateAMP::NewActionUpdate -> UpdateTimeWarper (:140-150)
         k = self._updates_to_next_action(dt) if (self._batch and action is not None) else 1
         if k > 1:
-            snap = env.get_state()
+            snap = env.get_state() if snap is None else snap
             clk0 = dict(self._clk)
             out = self._launch(action, dt, k, True)
             t1 = float(env.get_state()["clocks"][0][3])
@@ -346,6 +392,9 @@ class cDeepMimicCore(object):
 
     def CalcReward(self, agent_id):
         self._chk_agent(agent_id)
+        if self._tw is not None and self._mode == self.eModeTest:
+            # cSceneImitateAMP::CalcReward -> CalcRewardTimeWarp: 0 until the episode is over, then the alignment cost
+            return self._time_warp_reward() if self.IsEpisodeEnd() else 0.0
         return float(self._query()["reward"][0])
 
     def GetRewardMin(self, agent_id):
@@ -418,13 +467,13 @@ class cDeepMimicCore(object):
         self._mode = int(mode)
         if self._env is not None:
             self._apply_mode()
-        if self._mode == self.eModeTest and self._is_amp() and getattr(self._tables.cfg, "enable_test_time_warp", True) and not getattr(self, "_warned_tw", False):
+        if (self._mode == self.eModeTest and self._tables is not None and self._tables.cfg.scene == "imitate_amp" and self._tables.num_clips > 1
+                and getattr(self._tables.cfg, "enable_test_time_warp", True) and not getattr(self, "_warned_tw", False)):
             # cSceneImitateAMP::CalcReward returns the dynamic-time-warping alignment cost of the episode in test mode
-            # (SceneImitateAMP.cpp:173-205); that evaluation-only score is not computed here: CalcReward stays 0.
+            # (SceneImitateAMP.cpp:173-205); served by _time_warp_reward() for single-clip scenes only.
             import warnings
-            warnings.warn("imitate_amp test mode: the time-warp test return (cSceneImitateAMP::CalcRewardTimeWarp) is not computed on "
-                          "the MI355X path; CalcReward() returns 0 -- logged test returns of an AMP agent are not meaningful "
-                          "(pass --enable_test_time_warp false to silence)", RuntimeWarning, stacklevel=2)
+            warnings.warn("imitate_amp test mode with a multi-clip dataset: the time-warp test return (cSceneImitateAMP::"
+                          "CalcRewardTimeWarp) is only computed for single-clip scenes; CalcReward() returns 0", RuntimeWarning, stacklevel=2)
             self._warned_tw = True
 
     def SetSampleCount(self, count):

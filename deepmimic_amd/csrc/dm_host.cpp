@@ -388,7 +388,8 @@ struct CtxT : CtxBase {
         st.pose = (Real*)dalloc(sizeof(Real) * N * h.P); st.vel = (Real*)dalloc(sizeof(Real) * N * h.P); st.tar = (Real*)dalloc(sizeof(Real) * N * h.P);
         st.tau = (Real*)dalloc(sizeof(Real) * N * h.D); st.kin = (Real*)dalloc(sizeof(Real) * N * 8);
         st.clock = (double*)dalloc(sizeof(double) * N * 6); st.flag = (int*)dalloc(sizeof(int) * N * 4);
-        st.aovf = (cls == 0) ? (Real*)dalloc(sizeof(Real) * (size_t)N * (kMaxRows - ClsBiped::RREG) * kWave) : nullptr;
+        // overflow rows of the constraint-space matrix (rows RREG..63 of a character with more than RREG rows in a substep)
+        { const int ovf = kMaxRows - ((cls == 0) ? ClsBiped::RREG : ClsLarge::RREG); st.aovf = ovf > 0 ? (Real*)dalloc(sizeof(Real) * (size_t)N * ovf * kWave) : nullptr; }
         st.hist = nullptr;
         md.scene_amp = c.scene_amp ? 1 : 0; md.amp_local_root = c.enable_amp_obs_local_root ? 1 : 0;
         if (c.scene_amp) {

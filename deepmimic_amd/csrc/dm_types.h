@@ -30,7 +30,7 @@ struct ClsBiped {      // humanoid3d: 15 links, 34 dof, 43 pose dims, <= 64 grou
 // heavily contacted character (256-VGPR budget there; identical LDS record layout)
 struct ClsBipedWide : ClsBiped { static constexpr int RREG = 64; };
 struct ClsLarge {      // dog3d and anything up to 23 links / 64 dof / 83 pose dims / 128 candidates, attach rotations allowed
-    static constexpr int NJ = 23, ND = 64, NP = 83, NCAP = 128, RREG = 64, NPAIRCAP = 256, LPAD = 2; static constexpr bool ROT = true;
+    static constexpr int NJ = 23, ND = 64, NP = 83, NCAP = 128, RREG = 32, NPAIRCAP = 256, LPAD = 2; static constexpr bool ROT = true;
 };
 
 // link_info word: parent+1 [0:4] | jtype [5:7] | depth [8:11] | pose_off [12:18] | dof_off [19:25] | arot_ident 26 | brot_ident 27 | is_ee 28 | fall 29

@@ -516,3 +516,124 @@ def load_asset(name: str) -> SceneTables:
     """Load an in-tree compiled scene (``assets/<name>.json``), e.g. ``humanoid3d_walk``."""
     with open(os.path.join(ASSET_DIR, name + ".json")) as f:
         return SceneTables.from_json(json.load(f))
+
+
+# --- host-side kinematics (numpy): used by the facade's test-mode time-warp score, never by the stepping path --------------
+def _qmul(a, b):
+    return np.array([a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3], a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2],
+                     a[0] * b[2] + a[2] * b[0] + a[3] * b[1] - a[1] * b[3], a[0] * b[3] + a[3] * b[0] + a[1] * b[2] - a[2] * b[1]])
+
+
+def _qrot(q, v):
+    u = q[1:4]
+    uv = 2.0 * np.cross(u, v)
+    return v + q[0] * uv + np.cross(u, uv)
+
+
+def _slerp(a, b, t):
+    d = float(np.dot(a, b))
+    ad = abs(d)
+    if ad >= 1.0 - np.finfo(np.float64).eps:
+        s0, s1 = 1.0 - t, t
+    else:
+        th = np.arccos(ad); st = np.sin(th)
+        s0, s1 = np.sin((1.0 - t) * th) / st, np.sin(t * th) / st
+    if d < 0:
+        s1 = -s1
+    return s0 * a + s1 * b
+
+
+def _rot_euler(e):
+    """cMathUtil::RotateMat(euler) = Rz Ry Rx (util/MathUtil.cpp:159-186)"""
+    xs, xc, ys, yc, zs, zc = np.sin(e[0]), np.cos(e[0]), np.sin(e[1]), np.cos(e[1]), np.sin(e[2]), np.cos(e[2])
+    return np.array([[yc * zc, xs * ys * zc - xc * zs, xc * ys * zc + xs * zs],
+                     [yc * zs, xs * ys * zs + xc * zc, xc * ys * zs - xs * zc],
+                     [-ys, xs * yc, xc * yc]])
+
+
+def _quat_mat(q):
+    w, x, y, z = q / np.linalg.norm(q)
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                     [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                     [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+
+def joint_world_positions(tables: SceneTables, pose) -> np.ndarray:
+    """cKinTree::CalcJointWorldPos for every joint (anim/KinTree.cpp:538-553, 1034-1091): J x 3"""
+    jm = tables.joint_mat
+    J = jm.shape[0]
+    R = [None] * J
+    p = np.zeros((J, 3))
+    for j in range(J):
+        par = int(jm[j, JD_PARENT]); ty = int(jm[j, JD_TYPE]); off = int(jm[j, JD_PARAM_OFFSET])
+        if j == 0:
+            R[j] = _quat_mat(np.asarray(pose[3:7], dtype=np.float64)); p[j] = pose[0:3]
+            continue
+        A = _rot_euler(jm[j, JD_ATX:JD_ATZ + 1])
+        if ty == JT_SPHERICAL:
+            Rj = _quat_mat(np.asarray(pose[off:off + 4], dtype=np.float64))
+        elif ty == JT_REVOLUTE:
+            c, s = np.cos(pose[off]), np.sin(pose[off])
+            Rj = np.array([[c, -s, 0], [s, c, 0], [0, 0, 1.0]])
+        else:
+            Rj = np.eye(3)
+        R[j] = R[par] @ A @ Rj
+        p[j] = p[par] + R[par] @ jm[j, JD_AX:JD_AZ + 1]
+    return p
+
+
+class KinSampler:
+    """cKinCharacter::CalcPose on the host (anim/KinCharacter.cpp:363-386, MotionController.cpp:25-41, Motion.cpp:249-293): the
+    pose of the kinematic character at a clip time for a given origin.  Single clip (clip 0 of a dataset)."""
+
+    def __init__(self, tables: SceneTables):
+        self.t = tables
+        n = tables.frames.shape[0] if tables.clip_starts is None else int(tables.clip_starts[1])
+        fr = np.array(tables.frames[:n], dtype=np.float64)
+        self.loop = bool(tables.loop if tables.clip_starts is None else tables.clip_loops[0])
+        self.times = np.concatenate([[0.0], np.cumsum(fr[:-1, 0])])
+        self.frames = fr[:, 1:].copy()
+        self.frames[:, 0] -= self.frames[0, 0]; self.frames[:, 2] -= self.frames[0, 2]       # PostProcessMotion
+        self.quat_offs = [3] + [int(tables.joint_mat[j, JD_PARAM_OFFSET]) for j in range(1, tables.num_joints)
+                                if int(tables.joint_mat[j, JD_TYPE]) == JT_SPHERICAL]
+        for o in self.quat_offs:
+            self.frames[:, o:o + 4] /= np.linalg.norm(self.frames[:, o:o + 4], axis=1, keepdims=True)
+        self.duration = float(self.times[-1])
+        self.cycle_delta = self.frames[-1, 0:3] - self.frames[0, 0:3]; self.cycle_delta[1] = 0
+
+    def pose(self, time, origin_pos, origin_rot):
+        dur = self.duration
+        cc = int(np.floor(time / dur))
+        cycle = cc if self.loop else min(max(cc, 0), 1)
+        if not self.loop and time <= 0:
+            idx, blend = 0, 0.0
+        elif not self.loop and time >= dur:
+            idx, blend = len(self.times) - 2, 1.0
+        else:
+            tt = time - cycle * dur
+            idx = int(np.searchsorted(self.times, tt, side="right")) - 1
+            idx = min(max(idx, 0), len(self.times) - 2)
+            blend = (tt - self.times[idx]) / (self.times[idx + 1] - self.times[idx])
+        f0, f1 = self.frames[idx], self.frames[idx + 1]
+        out = (1.0 - blend) * f0 + blend * f1
+        for o in self.quat_offs:
+            q = _slerp(f0[o:o + 4], f1[o:o + 4], blend); out[o:o + 4] = q / np.linalg.norm(q)
+        if self.loop:
+            out[0:3] += cycle * self.cycle_delta
+        orot = np.asarray(origin_rot, dtype=np.float64)
+        out[0:3] = _qrot(orot, out[0:3]) + np.asarray(origin_pos, dtype=np.float64)
+        q = _qmul(orot, out[3:7]); out[3:7] = q if q[0] >= 0 else -q
+        return out
+
+
+def time_warp_cost(data0: np.ndarray, data1: np.ndarray) -> float:
+    """cDynamicTimeWarper::CalcAlignment (util/DynamicTimeWarper.cpp:117-140) with cSceneImitateAMP::TimeWarpCost
+    (scenes/SceneImitateAMP.cpp:5-25: mean point distance): data0 [n x 3J], data1 [m x 3J]."""
+    n, m = data0.shape[0], data1.shape[0]
+    d = np.linalg.norm(data0.reshape(n, 1, -1, 3) - data1.reshape(1, m, -1, 3), axis=3).mean(axis=2)
+    cost = np.full((n, m), np.inf)
+    cost[0, 0] = 0.0
+    for i in range(1, n):
+        for j in range(1, m):
+            cost[i, j] = d[i, j] + min(cost[i - 1, j - 1], cost[i - 1, j], cost[i, j - 1])
+    return float(cost[n - 1, m - 1])

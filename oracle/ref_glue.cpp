@@ -412,6 +412,25 @@ void ref_kinchar_motion_eval(void* h, double t, double* frame, double* vel) {
     k->kc->GetMotion()->CalcFrame(t, f); k->kc->GetMotion()->CalcFrameVel(t, v); vout(f, frame); vout(v, vel);
 }
 
+// cDynamicTimeWarper (util/DynamicTimeWarper.cpp, compiled) driven as cSceneImitateAMP::BuildTimeWarper / UpdateTimeWarper /
+// CalcRewardTimeWarp drive it (scenes/SceneImitateAMP.cpp:173-205,417-460), with the cost function of :5-25 restated here
+// (cSceneImitateAMP.cpp itself includes Bullet headers).  data0 [n x dim], data1 [m x dim] row-major; returns CalcAlignment().
+static double time_warp_cost_(const Eigen::VectorXd* d0, const Eigen::VectorXd* d1) {
+    double cost = 0.0; int num_points = (int)d0->size() / 3;
+    for (int p = 0; p < num_points; ++p) {
+        tVector a((*d0)(3 * p), (*d0)(3 * p + 1), (*d0)(3 * p + 2), 0), b((*d1)(3 * p), (*d1)(3 * p + 1), (*d1)(3 * p + 2), 0);
+        cost += (b - a).norm();
+    }
+    return cost / num_points;
+}
+double ref_time_warp(const double* data0, int n, const double* data1, int m, int dim, int buffer_size) {
+    cDynamicTimeWarper w;
+    w.Init(dim, dim, buffer_size, time_warp_cost_);
+    for (int i = 0; i < n; ++i) w.AddSample0(vin(data0 + (size_t)i * dim, dim));
+    for (int j = 0; j < m; ++j) w.AddSample1(vin(data1 + (size_t)j * dim, dim));
+    return w.CalcAlignment();
+}
+
 // cTimer (util/Timer.cpp:55-83): run `n` updates of dt from a reset with max_time, return the index of the first update after
 // which IsEnd() is true (or -1)
 int ref_timer_first_end(double max_time, double dt, int n) {

@@ -211,3 +211,37 @@ def test_batched_control_step_equals_update_by_update(emu_lib, monkeypatch):
     assert sb["rollbacks"] == 2
     assert sb["launches"] <= 260 // 20 + 2 + 2 * 20 + 4, sb          # ~1 per control step, + the two replays
     assert any(x[0] == "e" for x in runs["1"][0])                    # an episode ended inside the window
+
+
+def test_imitate_amp_time_warp_test_return(emu_lib, monkeypatch):
+    """cSceneImitateAMP::CalcReward in test mode = the time-warp alignment cost at the episode end (SceneImitateAMP.cpp:173-205):
+    0 while the episode runs; at the end DTW(sim joints, kin joints) over the action-boundary samples + 1 per step the episode
+    fell short of the buffer.  A character that tracks the clip perfectly for the whole buffer would score ~0."""
+    from deepmimic_amd import model
+    mod = _core_module()
+    monkeypatch.setenv("DM_HIP_LIB", emu_lib); monkeypatch.setenv("DM_PRECISION", "64")
+    t = model.load_asset("humanoid3d_walk")
+    t.cfg.scene = "imitate_amp"
+    t.cfg.time_lim_min = t.cfg.time_lim_max = t.cfg.time_end_lim_min = t.cfg.time_end_lim_max = 0.2     # 6 control steps
+    core = mod.cDeepMimicCore(False)
+    core.SeedRand(2); core.LoadTables(t, 10); core.Init()
+    core.SetMode(core.eModeTest); core.Reset()
+    assert core._tw is not None and core._tw["size"] == int(np.ceil(30 * 0.2)) + 2
+    steps = 0
+    while True:
+        if core.NeedNewAction(0):
+            assert core.CalcReward(0) == 0.0
+            core.SetAction(0, [0.0] * core.GetActionSize(0)); steps += 1
+        core.Update(1.0 / 600)
+        if core.IsEpisodeEnd():
+            break
+    n = len(core._tw["sim"])
+    assert n == steps + 1 == 7                                   # the reset sample + one per action
+    r = core.CalcReward(0)
+    want = model.time_warp_cost(np.array(core._tw["sim"]), np.array(core._tw["kin"])) + (core._tw["size"] - n)
+    assert r == want and (core._tw["size"] - n) <= r < (core._tw["size"] - n) + 0.5
+    # the first pair of samples is the reset state: sim == kin, distance 0
+    assert np.abs(core._tw["sim"][0] - core._tw["kin"][0]).max() < 1e-9 + 0.02     # (root lifted by the ground-clearance of the reset)
+    core.SetMode(core.eModeTrain); core.Reset()
+    core.SetAction(0, [0.0] * core.GetActionSize(0)); core.Update(1.0 / 600)
+    assert core.CalcReward(0) == 0.0

@@ -399,3 +399,15 @@ def test_timer_end(libs):
         import ctypes
         got = ref.lib.ref_timer_first_end(ctypes.c_double(max_time), ctypes.c_double(1 / 600), 400)
         assert got == first, (max_time, got, first)
+
+
+def test_time_warp_alignment_vs_reference_dtw(libs):
+    """model.time_warp_cost (the facade's test-mode score of imitate_amp) vs the reference's cDynamicTimeWarper, compiled"""
+    import ctypes
+    ref, _ = libs
+    ref.lib.ref_time_warp.restype = ctypes.c_double
+    rng = np.random.default_rng(30)
+    for n, m in ((5, 5), (17, 17), (9, 12), (2, 2)):
+        d0, d1 = rng.normal(size=(n, 45)), rng.normal(size=(m, 45)) * 0.7 + 0.1
+        want = ref.lib.ref_time_warp(ref_lib._d(ref_lib._arr(d0)), n, ref_lib._d(ref_lib._arr(d1)), m, 45, 40)
+        assert abs(model.time_warp_cost(d0, d1) - want) < 1e-12 * max(1.0, abs(want))

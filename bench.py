@@ -154,6 +154,8 @@ def main():
     ap.add_argument("--wave-packing", type=int, default=2, help="characters per wavefront of the step kernel (1 or 2; 2 needs the biped class)")
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--force-gather", action="store_true", help="exercise the record exchange even with one rank")
+    ap.add_argument("--gather", choices=["torch", "cabi"], default="torch",
+                    help="record exchange through torch.distributed (default) or through the C-ABI (dm_comm_* / dm_gather_records: RCCL driven by libdm_hip.so)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--facade", action="store_true", help="measure the single-env cDeepMimicCore facade path instead of the batched env")
     ap.add_argument("--cpu-baseline-worker", type=int, default=None, help=argparse.SUPPRESS)
@@ -198,8 +200,11 @@ def main():
     gather = (world > 1 or args.force_gather) and not args.no_gather
     # per-env learner record {state[S], reward, terminate}: the step kernel writes it straight into the flat exchange buffer
     # of slot k % 2; one RCCL all-gather per control step, issued asynchronously so that it overlaps control step k+1
-    from deepmimic_amd.dist import RecordExchange
-    ex = RecordExchange(n, env.S, world, dev, depth=2)
+    from deepmimic_amd.dist import CabiRecordExchange, RecordExchange
+    if args.gather == "cabi" and gather:
+        ex = CabiRecordExchange(env, world, rank, dev, depth=2, force_rccl=True)
+    else:
+        ex = RecordExchange(n, env.S, world, dev, depth=2, env=env)
     tick = [0]
 
     def one_step():
@@ -231,10 +236,30 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    elapsed_local = elapsed
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+
+    # what the exchange costs on the critical path: the same K steps once more without it (per rank), so that a multi-GPU run is
+    # interpretable -- value / N vs per_rank_no_gather tells exposed collective time from slow ranks
+    local_rate = n * args.steps / elapsed_local
+    exposed_ms = None
+    if gather:
+        gather_saved, gather = gather, False
+        torch.cuda.synchronize(); t1 = time.perf_counter()
+        for _ in range(args.steps):
+            one_step()
+        torch.cuda.synchronize(); el_ng = time.perf_counter() - t1
+        gather = gather_saved
+        exposed_ms = 1e3 * (elapsed_local - el_ng) / args.steps
+    per_rank = [local_rate]
+    if world > 1:
+        tl = torch.tensor([local_rate], dtype=torch.float64, device=dev)
+        allr = [torch.zeros_like(tl) for _ in range(world)]
+        dist.all_gather(allr, tl)
+        per_rank = [float(x.item()) for x in allr]
 
     # kernel-only time of the dominant kernel (k_env_step), HIP events on the launch stream
     k_steps = max(5, min(50, args.steps))
@@ -257,6 +282,7 @@ def main():
                                    "20 updates of 1/600 s x 2 substeps per step" % (args.scene, n),
                        "envs_per_gpu": n, "wave_packing": args.wave_packing, "warmup_steps_run": warm, "parallelism": "env-shards x%d%s" % (world, " + async RCCL all-gather of the record, overlapped with the next step" if gather else "")},
             "sim_updates_per_s": value * 20,
+            "per_rank_env_steps_per_s": per_rank, "record_exchange": {"backend": (args.gather if gather else None), "exposed_ms_per_step_rank0": exposed_ms},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": measured_traffic(args.scene, n, kname), "kernel": kname, "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_env_step": algorithmic_bytes_per_env_step(env),

@@ -1,7 +1,7 @@
 #!/bin/bash
-# Round profile on the GPU box: parity tests, headline bench, rocprofv3 kernel stats, PMC passes (each in its own run).
-# Usage (from the repo root, through gpurun):  bash tools/gpu_round_profile.sh r01
-TAG=${1:-r01}
+# Round profile on the GPU box: parity tests, headline bench, rocprofv3 kernel stats, PMC passes (each in its own run: --pmc is never
+# combined with a sys / runtime / hip / hsa trace).  Usage (from the repo root, through gpurun):  bash tools/gpu_round_profile.sh r02
+TAG=${1:-r02}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
@@ -11,13 +11,21 @@ python bench.py --steps 300 --warmup 30 > $OUT/bench.json 2> $OUT/bench.err
 python bench.py --steps 100 --warmup 10 --scene humanoid3d_spinkick --no-cpu-baseline > $OUT/bench_spinkick.json 2>> $OUT/bench.err
 python bench.py --steps 100 --warmup 10 --scene dog3d_pace --no-cpu-baseline > $OUT/bench_dog.json 2>> $OUT/bench.err
 python bench.py --steps 300 --warmup 30 --wave-packing 1 --no-cpu-baseline > $OUT/bench_pack1.json 2>> $OUT/bench.err
+python bench.py --facade --steps 300 > $OUT/bench_facade.json 2>> $OUT/bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o stats -- python bench.py --steps 100 --warmup 10 --no-cpu-baseline > $OUT/stats.log 2>&1
-rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d $OUT/pmc_sq -o pmc -- python bench.py --steps 6 --warmup 2 --no-cpu-baseline > $OUT/pmc_sq.log 2>&1
-rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_INSTS_VMEM SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_WAIT_INST_LDS --kernel-trace --output-format csv -d $OUT/pmc_sq2 -o pmc -- python bench.py --steps 6 --warmup 2 --no-cpu-baseline > $OUT/pmc_sq2.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o pmc -- python bench.py --steps 6 --warmup 2 --no-cpu-baseline > $OUT/pmc_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o pmc -- python bench.py --steps 6 --warmup 2 --no-cpu-baseline > $OUT/pmc_write.log 2>&1
-python tools/gpu_profile_phases.py > $OUT/phases.json 2>&1
+for SC in humanoid3d_walk humanoid3d_spinkick dog3d_pace; do
+  S=""; [ $SC != humanoid3d_walk ] && S="_$SC"
+  rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d $OUT/pmc_sq$S -o pmc -- python bench.py --scene $SC --steps 6 --warmup 2 --min-warmup 40 --no-cpu-baseline > $OUT/pmc_sq$S.log 2>&1
+  rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_INSTS_VMEM SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_WAIT_INST_LDS --kernel-trace --output-format csv -d $OUT/pmc_sq2$S -o pmc -- python bench.py --scene $SC --steps 6 --warmup 2 --min-warmup 40 --no-cpu-baseline > $OUT/pmc_sq2$S.log 2>&1
+  rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch$S -o pmc -- python bench.py --scene $SC --steps 6 --warmup 2 --min-warmup 40 --no-cpu-baseline > $OUT/pmc_fetch$S.log 2>&1
+  rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write$S -o pmc -- python bench.py --scene $SC --steps 6 --warmup 2 --min-warmup 40 --no-cpu-baseline > $OUT/pmc_write$S.log 2>&1
+  python tools/gpu_profile_phases.py $SC > $OUT/phases$S.json 2>&1
+done
 python tools/gpu_policy_bench.py > $OUT/policy_bench.json 2> $OUT/policy_bench.err
+ENVS=16384 python tools/gpu_policy_bench.py > $OUT/policy_bench_16384.json 2>> $OUT/policy_bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_policy -o stats -- python tools/gpu_policy_bench.py > $OUT/stats_policy.log 2>&1
 python tools/gpu_tail_probe.py > $OUT/tail_probe.txt 2>&1
+python tools/gpu_parity_report.py --steps 300 --envs 8 > $OUT/parity_report.json 2> $OUT/parity_report.err
+torchrun --standalone --nnodes=1 --nproc-per-node 1 --local-addr 127.0.0.1 bench.py --gpus 1 --steps 200 --warmup 30 --force-gather --no-cpu-baseline > $OUT/bench_record_exchange_1rank.json 2> $OUT/bench_record_exchange.err
+python bench.py --steps 200 --warmup 30 --force-gather --gather cabi --no-cpu-baseline > $OUT/bench_record_exchange_cabi_1rank.json 2>> $OUT/bench_record_exchange.err
 tail -3 $OUT/pytest_gpu.log; cat $OUT/smoke.log | tail -1; cut -c1-260 $OUT/bench.json; ls $OUT

@@ -7,8 +7,8 @@
 // (Eigen is not installed) and oracle/gl_stub (type names only).  Nothing is copied into this repository.
 //
 // What the functions below do: marshal plain double arrays into the reference's Eigen types, call the reference
-// function named in the comment, marshal the result back.  Four functions (ref_spd_tau, ref_reward_terms, ref_record_state,
-// ref_action_to_target) additionally COMPOSE reference functions in the order of a reference routine that cannot
+// function named in the comment, marshal the result back.  Six functions (ref_spd_tau, ref_reward_terms, ref_record_state,
+// ref_amp_obs, ref_time_warp, ref_action_to_target) additionally COMPOSE reference functions in the order of a reference routine that cannot
 // itself be compiled here because its translation unit includes Bullet headers; each cites the lines it follows.
 //
 // Only tests/ (and tests/golden/make_ref_golden.py) load this library.
@@ -349,6 +349,63 @@ int ref_record_state(void* h, const double* pose_, const double* vel_, double ph
         idx += 6;
     }
     return idx;
+}
+
+// Composition following cSceneImitateAMP::BuildAMPObs / RecordAMPObsPose / RecordAMPObsVel (scenes/SceneImitateAMP.cpp:279-396;
+// the translation unit includes Bullet headers): [pose block of `pose`, pose block of `prev_pose`, vel block of `vel`, vel block of
+// `prev_vel`], every geometric step a call into the compiled reference (cKinTree::CalcHeadingRot, CalcBodyPartPos,
+// cMathUtil::CalcNormalTangent, VecToQuat, QuatRotVec).  local_root = --enable_amp_obs_local_root.  Returns the size written.
+static int ref_amp_pose_(const Skel* s, const VecX& pose, double ground_h, const tQuaternion& ref_origin_rot, bool local_root, double* out) {
+    const int pos_dim = cKinTree::gPosDim;
+    int o = 0;
+    const tVector root_pos = cKinTree::GetRootPos(pose);
+    tQuaternion root_rot = cKinTree::GetRootRot(pose);
+    out[o++] = root_pos[1] - ground_h;
+    if (local_root) root_rot = ref_origin_rot * root_rot;
+    tVector n, t;
+    cMathUtil::CalcNormalTangent(root_rot, n, t);
+    for (int k = 0; k < pos_dim; ++k) { out[o + k] = n[k]; out[o + pos_dim + k] = t[k]; }
+    o += 2 * pos_dim;
+    for (int j = 1; j < s->J; ++j) {
+        cKinTree::eJointType jt = cKinTree::GetJointType(s->jm, j);
+        int off = cKinTree::GetParamOffset(s->jm, j), sz = cKinTree::GetParamSize(s->jm, j);
+        if (jt == cKinTree::eJointTypeSpherical) {
+            tQuaternion q = cMathUtil::VecToQuat(tVector(pose[off], pose[off + 1], pose[off + 2], pose[off + 3]));
+            cMathUtil::CalcNormalTangent(q, n, t);
+            for (int k = 0; k < pos_dim; ++k) { out[o + k] = n[k]; out[o + pos_dim + k] = t[k]; }
+            o += 2 * pos_dim;
+        } else { for (int k = 0; k < sz; ++k) out[o + k] = pose[off + k]; o += sz; }
+    }
+    for (int j = 0; j < s->J; ++j) {
+        if (!cKinTree::IsEndEffector(s->jm, j)) continue;          // cCharacter::mEndEffectors: joints flagged IsEndEffector, in joint order
+        tVector p = cKinTree::CalcBodyPartPos(s->jm, s->bd, pose, j);
+        p -= root_pos;
+        p = cMathUtil::QuatRotVec(ref_origin_rot, p);
+        for (int k = 0; k < pos_dim; ++k) out[o + k] = p[k];
+        o += pos_dim;
+    }
+    return o;
+}
+static int ref_amp_vel_(const Skel* s, const VecX& vel, const tQuaternion& ref_origin_rot, bool local_root, double* out) {
+    tVector rv = cKinTree::GetRootVel(vel), rw = cKinTree::GetRootAngVel(vel);
+    if (local_root) { rv = cMathUtil::QuatRotVec(ref_origin_rot, rv); rw = cMathUtil::QuatRotVec(ref_origin_rot, rw); }
+    int o = 0;
+    for (int k = 0; k < 3; ++k) out[o++] = rv[k];
+    for (int k = 0; k < 3; ++k) out[o++] = rw[k];
+    const int root_size = cKinTree::GetParamSize(s->jm, 0);
+    for (int i = root_size; i < s->P; ++i) out[o++] = vel[i];
+    return o;
+}
+int ref_amp_obs(void* h, const double* prev_pose, const double* prev_vel, const double* pose_, const double* vel_, double ground_h, int local_root, double* out) {
+    Skel* s = (Skel*)h;
+    VecX pp = vin(prev_pose, s->P), pv = vin(prev_vel, s->P), p = vin(pose_, s->P), v = vin(vel_, s->P);
+    tQuaternion ref_origin_rot = cKinTree::CalcHeadingRot(p);
+    int o = 0;
+    o += ref_amp_pose_(s, p, ground_h, ref_origin_rot, local_root != 0, out + o);
+    o += ref_amp_pose_(s, pp, ground_h, ref_origin_rot, local_root != 0, out + o);
+    o += ref_amp_vel_(s, v, ref_origin_rot, local_root != 0, out + o);
+    o += ref_amp_vel_(s, pv, ref_origin_rot, local_root != 0, out + o);
+    return o;
 }
 
 // Composition following cCtPDController::ConvertActionToTargetPose (sim/CtPDController.cpp:133-166) for one spherical

@@ -411,3 +411,31 @@ def test_time_warp_alignment_vs_reference_dtw(libs):
         d0, d1 = rng.normal(size=(n, 45)), rng.normal(size=(m, 45)) * 0.7 + 0.1
         want = ref.lib.ref_time_warp(ref_lib._d(ref_lib._arr(d0)), n, ref_lib._d(ref_lib._arr(d1)), m, 45, 40)
         assert abs(model.time_warp_cost(d0, d1) - want) < 1e-12 * max(1.0, abs(want))
+
+
+def test_amp_observation_vs_reference_composition(libs):
+    """RecordAMPObsAgent of the oracle Scene (what the device AMP path is compared with) vs cSceneImitateAMP::BuildAMPObs composed
+    from the compiled reference functions (ref_glue.cpp ref_amp_obs): humanoid and dog, with and without
+    --enable_amp_obs_local_root, states in the middle of a rollout (history = state at the last action latch)."""
+    import copy, ctypes
+    ref, _ = libs
+    rng = np.random.default_rng(40)
+    for name in CHARS:
+        for local_root in (False, True):
+            t = copy.deepcopy(model.load_asset(name))
+            t.cfg.scene = "imitate_amp"; t.cfg.enable_amp_obs_local_root = local_root
+            o = Oracle(t)
+            sr = Skel(ref, t)
+            for trial in range(4):
+                o.reset(float(rng.uniform(0, o.duration)))
+                for k in range(int(rng.integers(1, 4))):
+                    o.set_action(0.2 * rng.normal(size=o.A))
+                    for u in range(int(rng.integers(3, 20))):
+                        o.update(1.0 / 600)
+                pp, pv = o.prev_state(); p, v = o.sim_state()
+                got = o.amp_obs_agent()
+                want = np.zeros(len(got) + 8)
+                n = ref.lib.ref_amp_obs(sr.h, ref_lib._d(ref_lib._arr(pp)), ref_lib._d(ref_lib._arr(pv)), ref_lib._d(ref_lib._arr(p)),
+                                        ref_lib._d(ref_lib._arr(v)), ctypes.c_double(0.0), int(local_root), ref_lib._d(want))
+                assert n == len(got), (n, len(got))
+                _close(want[:n], got, 1e-12, "%s AMP obs local_root=%s" % (name, local_root))

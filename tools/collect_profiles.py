@@ -25,42 +25,57 @@ def agg(path):
 rows = list(csv.reader(open(os.path.join(src, "stats", "stats_kernel_stats.csv"))))
 with open(os.path.join(dst, out + "_rocprofv3_kernel_stats.csv"), "w", newline="") as f:
     csv.writer(f).writerows(rows[:6])
-# 2. bench lines
-for name in ("bench.json", "bench_spinkick.json", "bench_dog.json", "bench_pack1.json"):
-    shutil.copy(os.path.join(src, name), os.path.join(dst, out + "_" + name))
-shutil.copy(os.path.join(src, "phases.json"), os.path.join(dst, out + "_phase_cycles.json"))
-# 3. PMC passes
-n = json.load(open(os.path.join(src, "bench.json")))["config"]["envs_per_gpu"]
-pmc = {"envs": n, "note": "per-launch means of the step kernel of the default bench (k_env_step_duo<float, false>: 2048 waves, two characters each); SQ_*_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* are quad-cycles (MI355X_MICROARCH.md)"}
-for d in ("pmc_sq", "pmc_sq2"):
-    a = agg(os.path.join(src, d, "pmc_counter_collection.csv"))
-    for k in a[0]:
-        pmc[k if k != "dur_ns" else d + "_kernel_ns"] = float(np.mean([v[k] for v in a]))
-per_wave = {k: v / n for k, v in pmc.items() if k.startswith("SQ_")}
-pmc["per_env_step"] = per_wave
-clk = pmc["GRBM_GUI_ACTIVE"] / 8.0                   # counter is summed over the 8 XCDs
-pmc["derived"] = {"kernel_cycles": clk, "shader_clock_ghz": clk / pmc["pmc_sq2_kernel_ns"],
-                  "valu_busy_fraction_of_simd_time": per_wave["SQ_ACTIVE_INST_VALU"] * 4 * 4 / clk,
-                  "valu_instructions_per_env_step": per_wave["SQ_INSTS_VALU"]}
-json.dump(pmc, open(os.path.join(dst, out + "_pmc_sq.json"), "w"), indent=1)
-# 4. HBM traffic (separate passes; FETCH_SIZE / WRITE_SIZE are in KiB; gfx950 FETCH_SIZE counts 64 B per 128-B request -> x2)
-f = np.mean([v["FETCH_SIZE"] for v in agg(os.path.join(src, "pmc_fetch", "pmc_counter_collection.csv"))])
-w = np.mean([v["WRITE_SIZE"] for v in agg(os.path.join(src, "pmc_write", "pmc_counter_collection.csv"))])
-b = json.load(open(os.path.join(src, "bench.json")))
-traffic = {"scene": "humanoid3d_walk", "envs": n, "kernel": b["roofline"]["kernel"], "fetch_size_kib_raw": float(f), "write_size_kib_raw": float(w),
-           "fetch_bytes_per_launch": float(f) * 1024 * 2, "write_bytes_per_launch": float(w) * 1024,
-           "hbm_bytes_per_launch": float(f) * 1024 * 2 + float(w) * 1024,
-           "algorithmic_bytes_per_launch": b["roofline"]["algorithmic_bytes_per_launch"],
-           "note": "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B requests at 64 B); WRITE_SIZE uncalibrated, taken as KiB"}
-json.dump(traffic, open(os.path.join(dst, out + "_traffic.json"), "w"), indent=1)
-print(json.dumps({"pmc": pmc["derived"], "per_env_step": per_wave, "traffic": traffic}, indent=1))
-
-# patch the headline bench line: bench.py read the traffic file of the PREVIOUS collection while this round's PMC passes were still to come
-try:
-    _b = json.load(open(os.path.join(dst, out + "_bench.json")))
-    _t = json.load(open(os.path.join(dst, out + "_traffic.json")))
-    if _b.get("roofline", {}).get("kernel") == _t.get("kernel"):
-        _b["roofline"]["traffic"] = _t["hbm_bytes_per_launch"]
-        open(os.path.join(dst, out + "_bench.json"), "w").write(json.dumps(_b) + "\n")
-except Exception as ex:
-    print("bench traffic patch skipped:", ex)
+if os.path.exists(os.path.join(src, "stats_policy", "stats_kernel_stats.csv")):
+    rows = list(csv.reader(open(os.path.join(src, "stats_policy", "stats_kernel_stats.csv"))))
+    with open(os.path.join(dst, out + "_rocprofv3_kernel_stats_closed_loop.csv"), "w", newline="") as f:
+        csv.writer(f).writerows(rows[:12])
+# 2. bench lines and reports
+for name in ("bench.json", "bench_spinkick.json", "bench_dog.json", "bench_pack1.json", "bench_facade.json", "policy_bench.json", "policy_bench_16384.json",
+             "parity_report.json", "tail_probe.txt", "bench_record_exchange_1rank.json", "bench_record_exchange_cabi_1rank.json"):
+    if os.path.exists(os.path.join(src, name)) and os.path.getsize(os.path.join(src, name)) > 0:
+        shutil.copy(os.path.join(src, name), os.path.join(dst, out + "_" + name))
+SCENES = [("humanoid3d_walk", ""), ("humanoid3d_spinkick", "_humanoid3d_spinkick"), ("dog3d_pace", "_dog3d_pace")]
+summary = {}
+for scene, sfx in SCENES:
+    if os.path.exists(os.path.join(src, "phases%s.json" % sfx)):
+        shutil.copy(os.path.join(src, "phases%s.json" % sfx), os.path.join(dst, out + "_phase_cycles%s.json" % sfx))
+    bname = {"": "bench.json", "_humanoid3d_spinkick": "bench_spinkick.json", "_dog3d_pace": "bench_dog.json"}[sfx]
+    b = json.load(open(os.path.join(src, bname)))
+    n = b["config"]["envs_per_gpu"]
+    # 3. PMC passes
+    pmc = {"scene": scene, "envs": n, "kernel": b["roofline"]["kernel"],
+           "note": "per-launch means of the step kernel; SQ_*_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* are quad-cycles (MI355X_MICROARCH.md)"}
+    try:
+        for d in ("pmc_sq", "pmc_sq2"):
+            a = agg(os.path.join(src, d + sfx, "pmc_counter_collection.csv"))
+            for k in a[0]:
+                pmc[k if k != "dur_ns" else d + "_kernel_ns"] = float(np.mean([v[k] for v in a]))
+        per_env = {k: v / n for k, v in pmc.items() if k.startswith("SQ_")}
+        pmc["per_env_step"] = per_env
+        clk = pmc["GRBM_GUI_ACTIVE"] / 8.0                   # counter is summed over the 8 XCDs
+        pmc["derived"] = {"kernel_cycles": clk, "shader_clock_ghz": clk / pmc["pmc_sq2_kernel_ns"],
+                          "valu_busy_fraction_of_simd_time": per_env["SQ_ACTIVE_INST_VALU"] * n * 4 / (clk * 256 * 4),
+                          "valu_instructions_per_env_step": per_env["SQ_INSTS_VALU"]}
+        json.dump(pmc, open(os.path.join(dst, out + "_pmc_sq%s.json" % sfx), "w"), indent=1)
+        summary[scene] = pmc["derived"]
+    except Exception as ex:
+        print("PMC of", scene, "skipped:", ex)
+    # 4. HBM traffic (separate passes; FETCH_SIZE / WRITE_SIZE are in KiB; gfx950 FETCH_SIZE counts 64 B per 128-B request -> x2)
+    try:
+        f = np.mean([v["FETCH_SIZE"] for v in agg(os.path.join(src, "pmc_fetch" + sfx, "pmc_counter_collection.csv"))])
+        w = np.mean([v["WRITE_SIZE"] for v in agg(os.path.join(src, "pmc_write" + sfx, "pmc_counter_collection.csv"))])
+        traffic = {"scene": scene, "envs": n, "kernel": b["roofline"]["kernel"], "fetch_size_kib_raw": float(f), "write_size_kib_raw": float(w),
+                   "fetch_bytes_per_launch": float(f) * 1024 * 2, "write_bytes_per_launch": float(w) * 1024,
+                   "hbm_bytes_per_launch": float(f) * 1024 * 2 + float(w) * 1024,
+                   "algorithmic_bytes_per_launch": b["roofline"]["algorithmic_bytes_per_launch"],
+                   "note": "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B requests at 64 B); WRITE_SIZE uncalibrated, taken as KiB"}
+        json.dump(traffic, open(os.path.join(dst, out + "_traffic%s.json" % sfx), "w"), indent=1)
+        summary[scene + "/traffic"] = traffic["hbm_bytes_per_launch"]
+        # patch the bench line of this scene: bench.py read the traffic file of the PREVIOUS collection while this round's PMC passes were still to come
+        dstb = os.path.join(dst, out + "_" + bname)
+        _b = json.load(open(dstb))
+        _b["roofline"]["traffic"] = traffic["hbm_bytes_per_launch"]
+        open(dstb, "w").write(json.dumps(_b) + "\n")
+    except Exception as ex:
+        print("traffic of", scene, "skipped:", ex)
+print(json.dumps(summary, indent=1))

@@ -46,7 +46,8 @@ class ShardedEnv:
         return rec
 
     def gather(self, rec_local):
-        """All-gather the shard records in global env order.  torch tensor in (CPU for gloo, device for nccl) -> tensor out."""
+        """All-gather the shard records in global env order.  torch tensor in (CPU for gloo, device for nccl) -> tensor out.
+        With uneven shards the result lives in a buffer that the next gather() overwrites."""
         import torch
         import torch.distributed as dist
         t = rec_local if isinstance(rec_local, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(rec_local))
@@ -57,13 +58,21 @@ class ShardedEnv:
             out = torch.empty((self.total, t.shape[1]), dtype=t.dtype, device=t.device)
             dist.all_gather_into_tensor(out, t.contiguous())
             return out
-        # uneven split: pad every shard to the largest one (collectives want equal sizes), trim after the gather
+        # uneven split: pad every shard to the largest one (collectives want equal sizes), compact after the gather.  The three
+        # buffers are allocated once per (shape, dtype, device) and reused every control step.
         big = base + 1
-        pad = torch.zeros((big, t.shape[1]), dtype=t.dtype, device=t.device)
-        pad[:t.shape[0]] = t
-        out = torch.empty((self.world * big, t.shape[1]), dtype=t.dtype, device=t.device)
-        dist.all_gather_into_tensor(out, pad)
-        return torch.cat([out[r * big:r * big + shard_range(self.total, self.world, r)[1]] for r in range(self.world)], 0)
+        key = (t.shape[1], t.dtype, t.device)
+        if getattr(self, "_uneven_key", None) != key:
+            self._uneven_key = key
+            self._pad = torch.zeros((big, t.shape[1]), dtype=t.dtype, device=t.device)
+            self._gathered = torch.empty((self.world * big, t.shape[1]), dtype=t.dtype, device=t.device)
+            self._compact = torch.empty((self.total, t.shape[1]), dtype=t.dtype, device=t.device)
+        self._pad[:t.shape[0]].copy_(t)
+        dist.all_gather_into_tensor(self._gathered, self._pad)
+        for r in range(self.world):
+            f, c = shard_range(self.total, self.world, r)
+            self._compact[f:f + c].copy_(self._gathered[r * big:r * big + c])
+        return self._compact
 
 
 class RecordExchange:

@@ -23,7 +23,7 @@ sh.env.reset()
 recs = []
 for k in range(2):
     out = sh.env.step(None, 1.0 / 600, 20, open_loop=True, auto_reset=True)
-    recs.append(sh.gather(sh.pack_record(out)).numpy())
+    recs.append(sh.gather(sh.pack_record(out)).numpy().copy())      # the gathered tensor is reused by the next gather (uneven shards)
 if rank == 0:
     np.save(os.environ["DM_OUT"], np.stack(recs))
 # double-buffered flat record exchange (equal shards): what bench.py runs per control step

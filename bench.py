@@ -62,10 +62,7 @@ def cpu_baseline_worker(scene, env_id, budget_s):
     import oracle_lib
     from deepmimic_amd import model, streams
     tables = model.load_asset(scene)
-    try:
-        oracle_lib.build("native"); variant = "native"
-    except Exception:
-        variant = ""
+    variant = "native" if os.environ.get("DM_ORACLE_NATIVE") == "1" else ""      # built once by the parent (cpu_baseline)
     o = oracle_lib.Oracle(tables, variant=variant)
     tmin, tmax = timer_limits_of(tables)
     t0 = float(streams.reset_phase(np.array([env_id]), o.duration)[0])
@@ -84,11 +81,25 @@ def cpu_baseline(scene, budget_s=12.0):
     the single-process rate is reported next to them."""
     import subprocess
 
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib
+    env = dict(os.environ)
+    try:        # host-tuned build, made HERE (a -march=native .so from another machine must not be reused) and once (the workers only load it)
+        oracle_lib.build("native"); env["DM_ORACLE_NATIVE"] = "1"
+    except Exception:
+        oracle_lib.build("all"); env["DM_ORACLE_NATIVE"] = "0"
+
     def run(nproc):
         procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", str(i), "--scene", scene,
-                                   "--cpu-budget", str(budget_s)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+                                   "--cpu-budget", str(budget_s)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
                  for i in range(nproc)]
-        res = [json.loads(p.communicate(timeout=20 * budget_s + 120)[0].strip().splitlines()[-1]) for p in procs]
+        res = []
+        for p in procs:
+            so, se = p.communicate(timeout=20 * budget_s + 120)
+            lines = [l for l in so.splitlines() if l.startswith("{")]
+            if p.returncode != 0 or not lines:
+                raise RuntimeError("worker rc=%s: %s" % (p.returncode, se.strip()[-300:]))
+            res.append(json.loads(lines[-1]))
         return sum(r["steps"] / r["secs"] for r in res), res
 
     try:

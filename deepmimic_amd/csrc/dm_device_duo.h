@@ -536,7 +536,7 @@ _Pragma("unroll") \
             uint32_t fmask = (1u << lane_bcast(RN, 0)) | (1u << lane_bcast(RN, 32));
 #define DM_DUO_PGS_ROW(r)                                                                                              \
             {                                                                                                          \
-                if ((fmask >> (r)) & 1u) { const Real ln = wave_shfl(lam, half * 32 + nrm_lane); if (is_fric && (r) == RN) { hi = m.friction * ln; lo = -hi; } } \
+                if (__builtin_expect((fmask >> (r)) & 1u, 0)) { const Real ln = wave_shfl(lam, half * 32 + nrm_lane); if (is_fric && (r) == RN) { hi = m.friction * ln; lo = -hi; } } \
                 const Real nl = dm_med3(lo, t, hi);                                                                    \
                 const Real delta = half_bcast_c<(r)>(nl - lam, half);                                                  \
                 t -= arow.get(r) * delta;                                                                              \

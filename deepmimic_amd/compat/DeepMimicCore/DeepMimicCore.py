@@ -255,7 +255,7 @@ class cDeepMimicCore(object):
         return {"imitate_amp": "Imitate AMP", "target_amp": "Target AMP", "heading_amp": "Heading AMP"}.get(scene, "Imitate")
 
     def _is_amp(self):
-        return self._tables is not None and self._tables.cfg.scene in ("imitate_amp", "target_amp", "heading_amp")
+        return self._tables is not None and self._tables.cfg.scene in _model.AMP_SCENES
 
     def _goal_size(self):
         return int(self._tables.goal_dim) if self._tables is not None else 0

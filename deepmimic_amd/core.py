@@ -11,7 +11,7 @@ from typing import Optional, Sequence
 
 import numpy as np
 
-from .model import SceneTables
+from .model import AMP_SCENES, SceneTables
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIB = os.path.join(_HERE, "csrc", "libdm_hip.so")
@@ -118,7 +118,7 @@ class BatchEnv:
         st.record_world_root_rot = int(tables.record_world_root_rot); st.query_rate = float(tables.query_rate)
         st.friction = 0.0; st.erp = float(erp); st.solver_iters = 0
         st.disable_self_collision = 0 if self_collision else 1
-        st.scene_amp = int(c.scene in ("imitate_amp", "heading_amp", "target_amp")); st.enable_amp_obs_local_root = int(getattr(c, "enable_amp_obs_local_root", False))
+        st.scene_amp = int(c.scene in AMP_SCENES); st.enable_amp_obs_local_root = int(getattr(c, "enable_amp_obs_local_root", False))
         # goal-conditioned AMP task scenes and multi-clip datasets
         st.scene_goal = int(tables.goal_kind)
         for k in ("rand_target_time_min", "rand_target_time_max", "max_target_dist", "target_succ_dist", "tar_fail_dist", "tar_speed",

@@ -948,7 +948,7 @@ struct EnvSim {
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
                             const int r = blk * 4 + i;
-                            if (r == RNv) { const Real ln = wave_shfl(lam, nrm_lane); if (is_fric) { hi = m.friction * ln; lo = -hi; } }
+                            if (__builtin_expect(r == RNv, 0)) { const Real ln = wave_shfl(lam, nrm_lane); if (is_fric) { hi = m.friction * ln; lo = -hi; } }
                             // rows >= RREG live in the HBM/L2 overflow block: row r + 2 is requested two rows ahead (3 rotating
                             // registers), so the load latency sits beside the sweep's dependent chain instead of on it
                             if (RREG < kMaxRows && r + 2 >= RREG && r + 2 < kMaxRows) { const Real* ap = aovf + lv; DM_OPAQUE_V(ap); pre[(r + 2) % 3] = ap[(r + 2 - RREG) * kWave]; }

@@ -18,6 +18,7 @@ namespace dmk {
 #ifdef DM_EMU
 template <typename T> static inline T half_bcast(T v, int src, int half) { return wave_shfl(v, half * 32 + src); }
 template <int SRC, typename T> static inline T half_bcast_c(T v, int half) { return half_bcast(v, SRC, half); }
+template <int R, typename T> static inline T half_sel_c(T oldv, T newv, int hl, uint32_t) { return hl == R ? newv : oldv; }
 template <typename T> static inline T half_sum(T v) {
     T* x = reinterpret_cast<T*>(emu::g_xchg);
     x[threadIdx.x] = v; __syncthreads();
@@ -47,6 +48,15 @@ template <int SRC> __device__ __forceinline__ float half_bcast_c(float v, int ha
     return __int_as_float(__builtin_amdgcn_permlane16_swap(x, x, false, false)[1]);
 }
 template <int SRC> __device__ __forceinline__ double half_bcast_c(double v, int half) { return half_bcast(v, SRC, half); }
+// lanes R and R + 32 take `newv`: the select mask is an immediate SGPR pair (two s_mov on the scalar unit) instead of a v_cmp per row
+template <int R> __device__ __forceinline__ float half_sel_c(float oldv, float newv, int hl, uint32_t one) {
+    const uint32_t m32 = one << R;           // `one` is re-made opaque per sweep, or the 32 masks are hoisted out of the loop and spilled
+    const uint64_t mk = ((uint64_t)m32 << 32) | m32;
+    float out;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(out) : "v"(oldv), "v"(newv), "s"(mk));
+    return out;
+}
+template <int R> __device__ __forceinline__ double half_sel_c(double oldv, double newv, int hl, uint32_t) { return hl == R ? newv : oldv; }
 __device__ __forceinline__ float half_sum(float v) {
     v += DM_DPP_F(v, 0xB1, 0xf, true);     // quad_perm [1,0,3,2]
     v += DM_DPP_F(v, 0x4E, 0xf, true);     // quad_perm [2,3,0,1]
@@ -540,11 +550,12 @@ _Pragma("unroll") \
                 const Real nl = dm_med3(lo, t, hi);                                                                    \
                 const Real delta = half_bcast_c<(r)>(nl - lam, half);                                                  \
                 t -= arow.get(r) * delta;                                                                              \
-                if (lv == (r)) lam = nl;                                                                               \
+                lam = half_sel_c<(r)>(lam, nl, lv, one);                                                               \
             }
 #define DM_DUO_PGS_BLK(b4) if ((b4) * 4 < Rv) { DM_DUO_PGS_ROW((b4) * 4) DM_DUO_PGS_ROW((b4) * 4 + 1) DM_DUO_PGS_ROW((b4) * 4 + 2) DM_DUO_PGS_ROW((b4) * 4 + 3) }
             for (int it = 0; it < m.solver_iters; ++it) {
-                DM_OPAQUE_S(Rv); DM_OPAQUE_S(fmask); DM_OPAQUE_V(lv);
+                uint32_t one = 1u;
+                DM_OPAQUE_S(Rv); DM_OPAQUE_S(fmask); DM_OPAQUE_V(lv); DM_OPAQUE_S(one);
                 DM_DUO_PGS_BLK(0) DM_DUO_PGS_BLK(1) DM_DUO_PGS_BLK(2) DM_DUO_PGS_BLK(3)
                 DM_DUO_PGS_BLK(4) DM_DUO_PGS_BLK(5) DM_DUO_PGS_BLK(6) DM_DUO_PGS_BLK(7)
             }

@@ -166,6 +166,28 @@ class SceneConfig:
     tar_speed_min: Optional[float] = None
     tar_speed_max: Optional[float] = None
     vel_reward_scale: float = 1.0
+    # ---- heading_amp_getup (scenes/SceneHeadingAMPGetup.cpp:58-83)
+    getup_motion_ids: Optional[List[int]] = None
+    getup_height_root: float = 0.5
+    getup_height_head: float = 0.5
+    head_id: int = 0
+    recover_episode_prob: float = 0.0
+    # ---- strike_amp (scenes/SceneStrikeAMP.cpp:189-231)
+    target_min: Sequence[float] = (-0.5, 1.2, 0.6)
+    target_max: Sequence[float] = (0.5, 1.4, 1.1)
+    target_radius: float = 0.2
+    target_hit_reset_time: float = 2.0
+    tar_reward_scale: float = 2.0
+    hit_tar_speed: float = 1.5
+    init_hit_prob: float = 0.0
+    tar_far_prob: float = 0.4
+    tar_near_dist: float = 1.4
+    strike_bodies: Optional[List[int]] = None
+    fail_tar_contact_bodies: Optional[List[int]] = None
+
+
+GOAL_SCENES = {"target_amp": 1, "heading_amp": 2, "heading_amp_getup": 3, "strike_amp": 4}
+AMP_SCENES = ("imitate_amp",) + tuple(GOAL_SCENES)
 
 
 @dataclass
@@ -194,12 +216,32 @@ class SceneTables:
 
     @property
     def goal_kind(self) -> int:
-        """0: no goal (imitate / imitate_amp), 1: target_amp, 2: heading_amp"""
-        return {"target_amp": 1, "heading_amp": 2}.get(self.cfg.scene, 0)
+        """0: no goal (imitate / imitate_amp), 1: target_amp, 2: heading_amp, 3: heading_amp_getup, 4: strike_amp"""
+        return GOAL_SCENES.get(self.cfg.scene, 0)
 
     @property
     def goal_dim(self) -> int:
-        return 3 if self.goal_kind else 0           # cSceneTargetAMP::GetGoalSize / cSceneHeadingAMP::GetGoalSize
+        # cSceneTargetAMP / cSceneHeadingAMP::GetGoalSize: 3; cSceneHeadingAMPGetup (+ get-up phase) and cSceneStrikeAMP (pos + hit phase): 4
+        return (0, 3, 3, 4, 4)[self.goal_kind]
+
+    def clip_duration(self, c: int) -> float:
+        """cMotion::GetDuration of clip c: the frame durations but the last one's (anim/Motion.cpp PostProcessFrames)"""
+        if self.clip_starts is None:
+            return float(self.frames[:-1, 0].sum())
+        return float(self.frames[int(self.clip_starts[c]):int(self.clip_starts[c + 1]) - 1, 0].sum())
+
+    @property
+    def getup_time(self) -> float:
+        """cSceneHeadingAMPGetup::CalcGetupTime (:266-291): the longest get-up clip"""
+        ids = self.cfg.getup_motion_ids or []
+        return max([self.clip_duration(i) for i in ids], default=0.0)
+
+    @property
+    def getup_clip_mask(self) -> int:
+        m = 0
+        for i in (self.cfg.getup_motion_ids or []):
+            m |= 1 << int(i)
+        return m
 
     @property
     def num_joints(self) -> int:
@@ -393,15 +435,28 @@ def parse_scene_config(parser: ArgParser) -> SceneConfig:
               "pos_reward_scale", "max_heading_turn_rate", "sharp_turn_prob", "speed_change_prob", "vel_reward_scale"):
         setattr(c, k, parser.float(k, getattr(c, k)))
     c.enable_min_tar_vel = parser.bool("enable_min_tar_vel", c.enable_min_tar_vel)
-    if c.scene == "heading_amp":
+    if c.scene in ("heading_amp", "heading_amp_getup"):
         # cSceneHeadingAMP(): target timer 0.2 .. 0.5 s unless the args say otherwise (SceneHeadingAMP.cpp:45-48)
         c.rand_target_time_min = parser.float("rand_target_time_min", 0.2)
         c.rand_target_time_max = parser.float("rand_target_time_max", 0.5)
     # cSceneHeadingAMP::ParseArgs (:66-84): the speed range defaults to [tar_speed, tar_speed]; tar_speed is clamped into it
     c.tar_speed_min = parser.float("tar_speed_min", c.tar_speed)
     c.tar_speed_max = parser.float("tar_speed_max", c.tar_speed)
-    if c.scene == "heading_amp":
+    if c.scene in ("heading_amp", "heading_amp_getup"):
         c.tar_speed = min(max(c.tar_speed, c.tar_speed_min), c.tar_speed_max)
+    c.getup_motion_ids = parser.ints("getup_motion_ids")
+    for k in ("getup_height_root", "getup_height_head", "recover_episode_prob", "target_radius", "target_hit_reset_time", "tar_reward_scale",
+              "hit_tar_speed", "init_hit_prob", "tar_far_prob", "tar_near_dist"):
+        setattr(c, k, parser.float(k, getattr(c, k)))
+    c.head_id = parser.int("head_id", c.head_id)
+    v = parser.floats("target_min")
+    if v:
+        c.target_min = tuple(v[:3])
+    v = parser.floats("target_max")
+    if v:
+        c.target_max = tuple(v[:3])
+    c.strike_bodies = parser.ints("strike_bodies")
+    c.fail_tar_contact_bodies = parser.ints("fail_tar_contact_bodies")
     return c
 
 
@@ -500,8 +555,9 @@ def load_scene_from_args(args: Sequence[str], data_root: str = ".") -> SceneTabl
         if not p.load_file(path):
             raise FileNotFoundError("Failed to load args from: %s" % arg_file)
     cfg = parse_scene_config(p)
-    if cfg.scene not in ("imitate", "imitate_amp", "heading_amp", "target_amp"):
-        raise ValueError("only `--scene imitate`, `imitate_amp`, `heading_amp` and `target_amp` are on the accelerated path (got %r)" % cfg.scene)
+    if cfg.scene != "imitate" and cfg.scene not in AMP_SCENES:
+        raise ValueError("only `--scene imitate`, `imitate_amp`, `heading_amp`, `heading_amp_getup`, `target_amp` and `strike_amp` are on the "
+                         "accelerated path (got %r)" % cfg.scene)
 
     def res(pth):
         return pth if os.path.isabs(pth) else os.path.join(data_root, pth)

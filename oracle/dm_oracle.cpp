@@ -21,7 +21,10 @@ enum {
     CFG_ENABLE_RAND_PLACEMENT, CFG_ENABLE_PHASE_INPUT, CFG_RECORD_WORLD_ROOT_POS, CFG_RECORD_WORLD_ROOT_ROT,
     CFG_QUERY_RATE, CFG_FRICTION, CFG_ERP, CFG_SOLVER_ITERS, CFG_MAX_CONTACTS, CFG_SELF_COLLISION, CFG_SCENE_AMP, CFG_AMP_LOCAL_ROOT,
     CFG_SCENE_GOAL, CFG_RAND_ROT_RESET, CFG_TAR_TIME_MIN, CFG_TAR_TIME_MAX, CFG_MAX_TAR_DIST, CFG_TAR_SUCC_DIST, CFG_TAR_FAIL_DIST, CFG_TAR_SPEED, CFG_POS_REWARD_SCALE,
-    CFG_MIN_TAR_VEL, CFG_MAX_TURN_RATE, CFG_SHARP_TURN_PROB, CFG_SPEED_CHANGE_PROB, CFG_TAR_SPEED_MIN, CFG_TAR_SPEED_MAX, CFG_VEL_REWARD_SCALE, CFG_COUNT
+    CFG_MIN_TAR_VEL, CFG_MAX_TURN_RATE, CFG_SHARP_TURN_PROB, CFG_SPEED_CHANGE_PROB, CFG_TAR_SPEED_MIN, CFG_TAR_SPEED_MAX, CFG_VEL_REWARD_SCALE,
+    CFG_MODE_TEST, CFG_GETUP_TIME, CFG_GETUP_HEIGHT_ROOT, CFG_GETUP_HEIGHT_HEAD, CFG_HEAD_ID, CFG_RECOVER_PROB, CFG_GETUP_CLIP_MASK,
+    CFG_TAR_NEAR_DIST, CFG_TAR_FAR_PROB, CFG_TARGET_RADIUS, CFG_HIT_RESET_TIME, CFG_INIT_HIT_PROB, CFG_HIT_TAR_SPEED, CFG_TAR_REWARD_SCALE,
+    CFG_TMIN_X, CFG_TMIN_Y, CFG_TMIN_Z, CFG_TMAX_X, CFG_TMAX_Y, CFG_TMAX_Z, CFG_STRIKE_MASK, CFG_FAIL_TAR_MASK, CFG_COUNT
 };
 
 int orc_cfg_count() { return CFG_COUNT; }
@@ -43,6 +46,12 @@ void orc_cfg_default(double* c) {
     c[CFG_POS_REWARD_SCALE] = d.pos_reward_scale; c[CFG_MIN_TAR_VEL] = d.enable_min_tar_vel; c[CFG_MAX_TURN_RATE] = d.max_heading_turn_rate;
     c[CFG_SHARP_TURN_PROB] = d.sharp_turn_prob; c[CFG_SPEED_CHANGE_PROB] = d.speed_change_prob; c[CFG_TAR_SPEED_MIN] = d.tar_speed_min; c[CFG_TAR_SPEED_MAX] = d.tar_speed_max;
     c[CFG_VEL_REWARD_SCALE] = d.vel_reward_scale;
+    c[CFG_MODE_TEST] = d.mode_test; c[CFG_GETUP_TIME] = d.getup_time; c[CFG_GETUP_HEIGHT_ROOT] = d.getup_height_root; c[CFG_GETUP_HEIGHT_HEAD] = d.getup_height_head;
+    c[CFG_HEAD_ID] = d.head_id; c[CFG_RECOVER_PROB] = d.recover_episode_prob; c[CFG_GETUP_CLIP_MASK] = d.getup_clip_mask;
+    c[CFG_TAR_NEAR_DIST] = d.tar_near_dist; c[CFG_TAR_FAR_PROB] = d.tar_far_prob; c[CFG_TARGET_RADIUS] = d.target_radius; c[CFG_HIT_RESET_TIME] = d.target_hit_reset_time;
+    c[CFG_INIT_HIT_PROB] = d.init_hit_prob; c[CFG_HIT_TAR_SPEED] = d.hit_tar_speed; c[CFG_TAR_REWARD_SCALE] = d.tar_reward_scale;
+    for (int k = 0; k < 3; ++k) { c[CFG_TMIN_X + k] = d.target_min[k]; c[CFG_TMAX_X + k] = d.target_max[k]; }
+    c[CFG_STRIKE_MASK] = d.strike_mask; c[CFG_FAIL_TAR_MASK] = d.fail_tar_mask;
 }
 
 void* orc_create(const double* jm, const double* bd, int J, const double* pd, const double* frames, int F, int loop,
@@ -62,6 +71,12 @@ void* orc_create(const double* jm, const double* bd, int J, const double* pd, co
     cfg.pos_reward_scale = c[CFG_POS_REWARD_SCALE]; cfg.enable_min_tar_vel = c[CFG_MIN_TAR_VEL] != 0; cfg.max_heading_turn_rate = c[CFG_MAX_TURN_RATE];
     cfg.sharp_turn_prob = c[CFG_SHARP_TURN_PROB]; cfg.speed_change_prob = c[CFG_SPEED_CHANGE_PROB]; cfg.tar_speed_min = c[CFG_TAR_SPEED_MIN]; cfg.tar_speed_max = c[CFG_TAR_SPEED_MAX];
     cfg.vel_reward_scale = c[CFG_VEL_REWARD_SCALE];
+    cfg.mode_test = c[CFG_MODE_TEST] != 0; cfg.getup_time = c[CFG_GETUP_TIME]; cfg.getup_height_root = c[CFG_GETUP_HEIGHT_ROOT]; cfg.getup_height_head = c[CFG_GETUP_HEIGHT_HEAD];
+    cfg.head_id = (int)c[CFG_HEAD_ID]; cfg.recover_episode_prob = c[CFG_RECOVER_PROB]; cfg.getup_clip_mask = (uint32_t)c[CFG_GETUP_CLIP_MASK];
+    cfg.tar_near_dist = c[CFG_TAR_NEAR_DIST]; cfg.tar_far_prob = c[CFG_TAR_FAR_PROB]; cfg.target_radius = c[CFG_TARGET_RADIUS]; cfg.target_hit_reset_time = c[CFG_HIT_RESET_TIME];
+    cfg.init_hit_prob = c[CFG_INIT_HIT_PROB]; cfg.hit_tar_speed = c[CFG_HIT_TAR_SPEED]; cfg.tar_reward_scale = c[CFG_TAR_REWARD_SCALE];
+    for (int k = 0; k < 3; ++k) { cfg.target_min[k] = c[CFG_TMIN_X + k]; cfg.target_max[k] = c[CFG_TMAX_X + k]; }
+    cfg.strike_mask = (uint32_t)c[CFG_STRIKE_MASK]; cfg.fail_tar_mask = (uint32_t)c[CFG_FAIL_TAR_MASK];
     Scene* s = new Scene();
     s->init(jm, bd, J, pd, frames, F, loop != 0, fall_mask, cfg);
     return s;
@@ -346,7 +361,12 @@ void orc_goal_state(void* h, double* o) {
     Scene* s = (Scene*)h;
     o[0] = s->tar_pos.x; o[1] = s->tar_pos.y; o[2] = s->tar_pos.z; o[3] = s->tar_heading; o[4] = s->tar_speed; o[5] = s->tar_timer; o[6] = s->tar_timer_max;
     o[7] = s->prev_action_com.x; o[8] = s->prev_action_com.y; o[9] = s->prev_action_com.z; o[10] = s->prev_action_time; o[11] = (double)s->goal_draws;
+    o[12] = (double)s->cur_clip;
+    if (s->cfg.scene_goal == 3) { o[13] = s->getup_timer; o[14] = 0; }
+    else { o[13] = s->target_hit ? 1.0 : 0.0; o[14] = s->target_hit_time; }
 }
+int orc_goal_dim(void* h) { return ((Scene*)h)->goal_dim(); }
+int orc_maybe_recovery_reset(void* h, double max_time) { return ((Scene*)h)->maybe_recovery_reset(max_time) ? 1 : 0; }
 void orc_amp_obs_expert_clip(void* h, int clip, double t, double ground_h, double* out) { ((Scene*)h)->amp_obs_expert(t, out, clip, ground_h); }
 
 // Counter-based reset draws of the device path (dm_rand01 in deepmimic_amd/csrc/dm_device.h, host mirror

@@ -24,8 +24,15 @@ struct SceneCfg {
     // --- `--scene imitate_amp` (scenes/SceneImitateAMP.cpp): reward 0, terminate on fall only, AMP observations
     bool scene_amp = false;
     bool enable_amp_obs_local_root = false;   // SceneImitateAMP.cpp:30,42
-    // --- goal-conditioned AMP task scenes: 1 = target_amp (scenes/SceneTargetAMP.cpp), 2 = heading_amp (scenes/SceneHeadingAMP.cpp)
+    // --- goal-conditioned AMP task scenes: 1 = target_amp (scenes/SceneTargetAMP.cpp), 2 = heading_amp (scenes/SceneHeadingAMP.cpp),
+    //     3 = heading_amp_getup (scenes/SceneHeadingAMPGetup.cpp), 4 = strike_amp (scenes/SceneStrikeAMP.cpp)
     int scene_goal = 0;
+    bool mode_test = false;                   // cRLScene::eModeTest (getup: falls start a get-up instead of ending; strike: test reward)
+    // heading_amp_getup (SceneHeadingAMPGetup.cpp:58-83): getup_time = longest get-up clip (CalcGetupTime :266-291)
+    double getup_time = 0, getup_height_root = 0.5, getup_height_head = 0.5, recover_episode_prob = 0; int head_id = 0; uint32_t getup_clip_mask = 0;
+    // strike_amp (SceneStrikeAMP.cpp:189-231)
+    double tar_near_dist = 1.4, tar_far_prob = 0.4, target_radius = 0.2, target_hit_reset_time = 2, init_hit_prob = 0, hit_tar_speed = 1.5, tar_reward_scale = 2;
+    double target_min[3] = {-0.5, 1.2, 0.6}, target_max[3] = {0.5, 1.4, 1.1}; uint32_t strike_mask = 0, fail_tar_mask = 0;
     bool enable_rand_rot_reset = false;       // SceneImitate.cpp:131,145,184-189
     double rand_target_time_min = 1, rand_target_time_max = 5, max_target_dist = 3, target_succ_dist = 0.5;
     double tar_fail_dist = std::numeric_limits<double>::infinity(), tar_speed = 1, pos_reward_scale = 1;
@@ -122,6 +129,8 @@ struct Scene {
     V3d tar_pos; double tar_heading = 0, tar_speed = 1, tar_timer = 0, tar_timer_max = 0;
     V3d prev_action_com; double prev_action_time = 0;      // cDeepMimicCharController::mPrevActionCOM / mPrevActionTime
     uint64_t rng_seed = 0, rng_env = 0, goal_draws = 0;    // the device path's counter-based generator (dm_rand01, stream 2)
+    double getup_timer = 0;                                // cSceneHeadingAMPGetup::mGetupTimer (time; max = cfg.getup_time)
+    bool target_hit = false; double target_hit_time = -1;  // cSceneStrikeAMP::mTargetHit / mTargetHitTime (gInvalidHitTime = -1)
 
     void init(const double* jm, const double* bd, int J, const double* pd /*J x 2*/, const double* frames, int F, bool loop,
               const int* fall, const SceneCfg& c) {
@@ -527,7 +536,8 @@ struct Scene {
             V3 c = sim_com(); prev_action_com.x = c.x; prev_action_com.y = c.y; prev_action_com.z = c.z;
             prev_action_time = ctrl_time + dt;                       // mTime has been advanced by this update when UpdateCalcTau latches it
         }
-        timer_time += dt;                                            // cScene::Update
+        timer_time += dt;                                            // cScene::Update -> UpdateTimers
+        if (cfg.scene_goal == 3) getup_timer += dt;                  // cSceneHeadingAMPGetup::UpdateTimers (:163-167)
         // 4a UpdateKinChar (SceneImitate.cpp:306-318)
         double prev_phase = kin.phase();
         kin.update(dt);
@@ -544,6 +554,8 @@ struct Scene {
         calc_links(sk, pose, vel, links);
         need_new_action = check_next_interval(dt, ctrl_time + init_time_offset, 1.0 / cfg.query_rate);   // CtController.cpp:221-227
         if (cfg.scene_goal) goal_update(dt);                         // cSceneTargetAMP::Update after cSceneImitate::Update (:137-146)
+        // cSceneHeadingAMPGetup::Update (:99-107) -> UpdateTestGetup (:244-253): in test mode a fall starts a get-up
+        if (cfg.scene_goal == 3 && cfg.mode_test && has_fallen_contact() && !getting_up()) getup_timer = 0;
     }
 
     // ------------------------------------------------------------------ goal-conditioned task scenes
@@ -562,31 +574,92 @@ struct Scene {
         for (int j = 0; j < sk.J; ++j) if (sk.valid_body(j)) { c += (real)sk.mass(j) * links[j].com; tm += (real)sk.mass(j); }
         return c / tm;
     }
-    void goal_reset_target_pos() {                                   // cSceneTargetAMP::SampleRandTargetPos (:285-299)
+    bool target_like() const { return cfg.scene_goal == 1 || cfg.scene_goal == 4; }
+    bool heading_like() const { return cfg.scene_goal == 2 || cfg.scene_goal == 3; }
+    int goal_dim() const { return cfg.scene_goal >= 3 ? 4 : 3; }
+    bool getting_up() const { return cfg.scene_goal == 3 && !(getup_timer >= cfg.getup_time); }   // CheckGettingUp (:301-304): !mGetupTimer.IsEnd()
+    void goal_reset_target_pos() {
+        if (cfg.scene_goal == 4) {                                   // cSceneStrikeAMP::ResetTargetPos / ...Far / ...Near (:318-374)
+            const bool far = goal_u01() < cfg.tar_far_prob;
+            const double theta = far ? goal_uniform(-3.141592653589793, 3.141592653589793) : goal_uniform(cfg.target_min[0], cfg.target_max[0]);
+            const double hgt = goal_uniform(cfg.target_min[1], cfg.target_max[1]);
+            const double dist = far ? goal_uniform(cfg.target_min[2], cfg.max_target_dist) : goal_uniform(cfg.target_min[2], cfg.target_max[2]);
+            tar_pos.x = dist * std::cos(theta) + (double)pose[0]; tar_pos.y = hgt; tar_pos.z = dist * -std::sin(theta) + (double)pose[2];
+            set_target_hit(false);
+            return;
+        }
+        // cSceneTargetAMP::SampleRandTargetPos (:285-299)
         double dist = goal_uniform(0.0, cfg.max_target_dist), theta = goal_uniform(0.0, 6.283185307179586);
         tar_pos.x = (double)pose[0] + dist * std::cos(theta); tar_pos.y = 0; tar_pos.z = (double)pose[2] + dist * std::sin(theta);
     }
+    void set_target_hit(bool hit) { if (!target_hit && hit) target_hit_time = timer_time; target_hit = hit; }   // SetTargetHit (:249-258), GetTime() = scene timer
     void goal_timer_reset() { tar_timer = 0; tar_timer_max = goal_uniform(cfg.rand_target_time_min, cfg.rand_target_time_max); }   // cTimer::Reset
     void goal_reset() {                                              // cSceneTargetAMP::Reset (:130-135) / cSceneHeadingAMP::ResetTarget (:230-239)
         goal_timer_reset();
         goal_reset_target_pos();
-        if (cfg.scene_goal == 2) { tar_heading = 0; tar_speed = std::min(std::max(goal_uniform(cfg.tar_speed_min, cfg.tar_speed_max), cfg.tar_speed_min), cfg.tar_speed_max); }
+        if (heading_like()) { tar_heading = 0; tar_speed = std::min(std::max(goal_uniform(cfg.tar_speed_min, cfg.tar_speed_max), cfg.tar_speed_min), cfg.tar_speed_max); }
         else tar_speed = cfg.tar_speed;
         prev_action_com = V3d(); prev_action_time = ctrl_time;       // cCtController::SetInitTime, cDeepMimicCharController::ResetParams
+        if (cfg.scene_goal == 3) {                                   // ResetTimers -> ResetGetupTimer (ended), then SyncGetupTimer (:190-207)
+            getup_timer = cfg.getup_time;
+            if ((cfg.getup_clip_mask >> cur_clip) & 1u) getup_timer = kin.time;
+        }
+        if (cfg.scene_goal == 4) {                                   // cSceneStrikeAMP::ResetTarget (:301-316) after the base ResetTarget
+            if (!cfg.mode_test && cfg.init_hit_prob > 0) set_target_hit(goal_u01() < cfg.init_hit_prob);      // ResetTargetHit (:376-383)
+            target_hit_time = target_hit ? goal_uniform(timer_time - cfg.target_hit_reset_time, timer_time) : -1.0;
+        }
+    }
+    // cSceneHeadingAMPGetup::Reset (:109-121): in train mode an episode that ended in a fall continues, with probability
+    // recover_episode_prob, as a recovery episode -- ResetRecoveryEpisode (:40-56): timers and controller only, the characters stay
+    // where they are.  (`bool mIsRecoveryEpisode = ...` declares a local there, so the member stays false: recovery episodes chain.)
+    bool maybe_recovery_reset(double max_time) {
+        if (cfg.scene_goal != 3 || cfg.mode_test || !(cfg.recover_episode_prob > 0)) return false;
+        if (check_terminate() != TERM_FAIL) return false;
+        if (!(goal_u01() < cfg.recover_episode_prob)) return false;
+        timer_time = 0; timer_max = max_time;                        // ResetTimers
+        getup_timer = 0;                                             // ResetGetupTimer then BeginGetup
+        ctrl_time = 0; init_time_offset = 0; need_new_action = true; // cCtController::ResetParams (CtController.cpp:103-108)
+        std::fill(tau.begin(), tau.end(), (real)0);
+        prev_action_com = V3d(); prev_action_time = 0;
+        return true;
     }
     void goal_update(double dt) {                                    // cSceneTargetAMP::UpdateTarget (:253-268) + cSceneHeadingAMP::UpdateTarget (:214-228)
         tar_timer += dt;
         const bool end = tar_timer >= tar_timer_max;
-        if (end) goal_reset_target_pos();
-        if (cfg.scene_goal == 2 && end) {
+        if (end && cfg.scene_goal != 4) goal_reset_target_pos();     // cSceneStrikeAMP::CheckTargetReset is false (:385-388)
+        if (cfg.scene_goal == 4 && !target_hit) set_target_hit(check_target_hit());   // cSceneStrikeAMP::UpdateTarget (:290-299)
+        if (heading_like() && end) {
             const bool sharp = goal_u01() < cfg.sharp_turn_prob;
             tar_heading += sharp ? goal_uniform(-3.141592653589793, 3.141592653589793) : goal_normal(0.0, cfg.max_heading_turn_rate);
             if (goal_u01() < cfg.speed_change_prob) tar_speed = std::min(std::max(goal_uniform(cfg.tar_speed_min, cfg.tar_speed_max), cfg.tar_speed_min), cfg.tar_speed_max);
         }
         if (end) goal_timer_reset();
     }
+    // cSceneStrikeAMP::CheckTargetHit (:441-478): a strike body inside the target sphere moving towards it fast enough
+    bool check_target_hit() const {
+        V3 tp((real)tar_pos.x, (real)tar_pos.y, (real)tar_pos.z);
+        V3 d(tp.x - pose[0], 0, tp.z - pose[2]);
+        real n = norm(d); V3 dir; if (n > (real)1e-5) dir = d / n;
+        for (int j = 0; j < sk.J; ++j) if ((cfg.strike_mask >> j) & 1u) {
+            if (norm2(tp - links[j].com) < (real)(cfg.target_radius * cfg.target_radius)) {
+                real speed = dot(dir, links[j].vcom);
+                if (speed >= (real)cfg.hit_tar_speed || cfg.hit_tar_speed == 0.0) return true;
+            }
+        }
+        return false;
+    }
+    bool tar_contact_fail() const {                                  // CheckTarContactFail (:485-503)
+        V3 tp((real)tar_pos.x, (real)tar_pos.y, (real)tar_pos.z);
+        for (int j = 0; j < sk.J; ++j) if ((cfg.fail_tar_mask >> j) & 1u) if (norm2(tp - links[j].com) < (real)(cfg.target_radius * cfg.target_radius)) return true;
+        return false;
+    }
+    bool tar_hit_succ() const { return target_hit && (timer_time - target_hit_time) >= cfg.target_hit_reset_time; }   // CheckTarHitSucc (:505-520)
+    double hit_phase() const {                                       // CalcHitPhase (:390-401)
+        if (!target_hit) return 0;
+        return std::min(std::max((timer_time - target_hit_time) / cfg.target_hit_reset_time, 0.0), 1.0);
+    }
     bool goal_dist_fail() const {                                    // cSceneTargetAMP::CheckTarDistFail (:306-317); cSceneHeadingAMP: false
-        if (cfg.scene_goal != 1) return false;
+        if (!target_like()) return false;
         real dx = pose[0] - (real)tar_pos.x, dz = pose[2] - (real)tar_pos.z;
         return dx * dx + dz * dz > (real)cfg.tar_fail_dist * (real)cfg.tar_fail_dist;
     }
@@ -599,12 +672,23 @@ struct Scene {
             V3 r(1, 0, 0);
             if (d > (real)0.0001) r = (rot_axis(V3(0, 1, 0), -heading) * rel) / d;
             out[0] = r.x; out[1] = r.z; out[2] = d;
+        } else if (cfg.scene_goal == 4) {                            // cSceneStrikeAMP::RecordGoal (:414-434): target in the origin frame, hit phase
+            V3 t = xf_point(origin_trans(rp), V3((real)tar_pos.x, (real)tar_pos.y, (real)tar_pos.z));
+            out[0] = t.x; out[1] = t.y; out[2] = t.z; out[3] = hit_phase();
         } else {                                                     // cSceneHeadingAMP::RecordGoal (:150-166)
             real th = (real)tar_heading - heading;
             out[0] = std::cos(th); out[1] = -std::sin(th); out[2] = tar_speed;
+            // cSceneHeadingAMPGetup::RecordGoal (:123-130): + CalcGetupPhase (:293-299)
+            if (cfg.scene_goal == 3) out[3] = std::min(std::max(1.0 - getup_timer / cfg.getup_time, 0.0), 1.0);
         }
     }
     double calc_goal_reward() const {
+        if (cfg.scene_goal == 3 && getting_up()) {                   // cSceneHeadingAMPGetup::CalcReward / CalcRewardGetup (:4-38)
+            real root_h = pose[1], head_h = links[cfg.head_id].com.y;
+            real nr = std::min(std::max(root_h / (real)cfg.getup_height_root, (real)0), (real)1), nh = std::min(std::max(head_h / (real)cfg.getup_height_head, (real)0), (real)1);
+            return (real)0.2 * nr + (real)0.8 * nh;
+        }
+        if (cfg.scene_goal == 4) return calc_strike_reward();
         if (has_fallen()) return 0;
         V3 com = sim_com();
         V3 dcom(com.x - (real)prev_action_com.x, com.y - (real)prev_action_com.y, com.z - (real)prev_action_com.z);
@@ -632,6 +716,42 @@ struct Scene {
         if (cfg.enable_min_tar_vel) vel_err = std::max(vel_err, (real)0);
         return std::exp(-(real)cfg.vel_reward_scale * vel_err * vel_err);
     }
+    // cSceneStrikeAMP::CalcReward (:9-187)
+    double calc_strike_reward() const {
+        if (cfg.mode_test) {                                         // CalcRewardTest (:57-72)
+            if (is_episode_end() && check_terminate() == TERM_SUCC) return timer_max - timer_time;
+            return 0;
+        }
+        const real far_w = (real)0.3, near_w = (real)0.3, hit_w = (real)0.4;
+        V3 tp((real)tar_pos.x, (real)tar_pos.y, (real)tar_pos.z);
+        V3 rd(tp.x - pose[0], 0, tp.z - pose[2]);
+        const real dist_sq = rd.x * rd.x + rd.z * rd.z, near = (real)cfg.tar_near_dist;
+        if (target_hit) return far_w + near_w + hit_w;
+        if (dist_sq < near * near) {                                 // CalcRewardTargetNear (:74-112)
+            real n = norm(rd); V3 dir; if (n > (real)1e-5) dir = rd / n;
+            real best = 0;
+            for (int j = 0; j < sk.J; ++j) if ((cfg.strike_mask >> j) & 1u) {
+                real dr = std::exp(-(real)cfg.tar_reward_scale * norm2(tp - links[j].com));
+                real vr = std::min(std::max(dot(dir, links[j].vcom) / (real)cfg.hit_tar_speed, (real)0), (real)1); vr *= vr;
+                best = std::max(best, (real)0.2 * dr + (real)0.8 * vr);
+            }
+            return far_w + near_w * best;
+        }
+        // CalcRewardTargetFar (:114-187)
+        if (has_fallen()) return 0;
+        const real ts = (real)tar_speed, rt = std::sqrt(dist_sq), de = std::max(rt - near, (real)0);
+        real pos_reward = std::exp(-(real)cfg.pos_reward_scale * de * de), vel_reward = 0;
+        if (rt < near) vel_reward = 1;
+        else {
+            V3 com = sim_com();
+            V3 ct(tp.x - com.x, 0, tp.z - com.z);
+            real cd = norm(ct); V3 dir; if (cd > (real)0.0001) dir = ct / cd;
+            V3 dcom(com.x - (real)prev_action_com.x, com.y - (real)prev_action_com.y, com.z - (real)prev_action_com.z);
+            real avg_vel = dot(dir, dcom) / (real)(ctrl_time - prev_action_time), vel_err = ts - avg_vel;
+            if (!(avg_vel < 0)) { if (cfg.enable_min_tar_vel) vel_err = std::max(vel_err, (real)0); vel_reward = std::exp(-((real)4 / (ts * ts)) * vel_err * vel_err); }
+        }
+        return far_w * ((real)0.7 * pos_reward + (real)0.3 * vel_reward);
+    }
     // cSceneImitate::SyncKinCharNewCycle (SceneImitate.cpp:420-444)
     void sync_kin_new_cycle() {
         if (cfg.sync_char_root_rot) {
@@ -648,9 +768,14 @@ struct Scene {
     }
 
     // ------------------------------------------------------------------ termination
+    // cSceneSimChar::HasFallenContact (SceneSimChar.cpp:838-841); cSceneHeadingAMPGetup's override (:255-264): never while getting up
+    bool has_fallen_contact() const {
+        if (getting_up()) return false;
+        if (cfg.enable_char_contact_fall) for (int j = 0; j < sk.J; ++j) if (fall_mask[j] && in_contact[j]) return true;
+        return false;
+    }
     bool has_fallen() const {
-        bool f = false;
-        if (cfg.enable_char_contact_fall) for (int j = 0; j < sk.J; ++j) if (fall_mask[j] && in_contact[j]) f = true;
+        bool f = has_fallen_contact();
         if (cfg.enable_root_rot_fail) f |= quat_diff_theta(root_rot(pose), root_rot(kin.pose)) > (real)0.5 * kPi;   // SceneImitate.cpp:484-492
         return f;
     }
@@ -659,6 +784,10 @@ struct Scene {
         // cSceneImitateAMP::CheckTerminate (SceneImitateAMP.cpp:184-188) keeps only the fall test of cRLSceneSimChar (:187-197)
         if (!fail && !cfg.scene_amp && kin.mo->is_over(kin.time)) fail = true;   // SceneImitate.cpp:193-205
         if (!fail && cfg.scene_goal && goal_dist_fail()) fail = true;            // cSceneTargetAMP::CheckTerminate (:319-345)
+        if (!fail && cfg.scene_goal == 4) {                                       // cSceneStrikeAMP::CheckTerminateTarget (:522-541)
+            if (tar_contact_fail()) fail = true;
+            else if (tar_hit_succ()) return TERM_SUCC;
+        }
         return fail ? TERM_FAIL : TERM_NULL;
     }
     bool is_episode_end() const { return timer_time >= timer_max || check_terminate() != TERM_NULL; }

@@ -14,7 +14,10 @@ CFG_KEYS = ["num_sim_substeps", "world_scale", "grav_x", "grav_y", "grav_z", "sy
             "friction", "erp", "solver_iters", "max_contacts", "self_collision", "scene_amp", "amp_local_root",
             "scene_goal", "rand_rot_reset", "tar_time_min", "tar_time_max", "max_tar_dist", "tar_succ_dist", "tar_fail_dist", "tar_speed",
             "pos_reward_scale", "min_tar_vel", "max_turn_rate", "sharp_turn_prob", "speed_change_prob", "tar_speed_min", "tar_speed_max",
-            "vel_reward_scale"]
+            "vel_reward_scale",
+            "mode_test", "getup_time", "getup_height_root", "getup_height_head", "head_id", "recover_prob", "getup_clip_mask",
+            "tar_near_dist", "tar_far_prob", "target_radius", "hit_reset_time", "init_hit_prob", "hit_tar_speed", "tar_reward_scale",
+            "tmin_x", "tmin_y", "tmin_z", "tmax_x", "tmax_y", "tmax_z", "strike_mask", "fail_tar_mask"]
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int)
@@ -59,13 +62,19 @@ class Oracle:
                     enable_root_rot_fail=c.enable_root_rot_fail, enable_rand_placement=c.enable_rand_char_placement,
                     enable_phase_input=tables.enable_phase_input, record_world_root_pos=tables.record_world_root_pos,
                     record_world_root_rot=tables.record_world_root_rot, query_rate=tables.query_rate,
-                    scene_amp=(c.scene in ("imitate_amp", "heading_amp", "target_amp")), amp_local_root=getattr(c, "enable_amp_obs_local_root", False),
+                    scene_amp=(c.scene != "imitate"), amp_local_root=getattr(c, "enable_amp_obs_local_root", False),
                     scene_goal=tables.goal_kind, rand_rot_reset=c.enable_rand_rot_reset, tar_time_min=c.rand_target_time_min,
                     tar_time_max=c.rand_target_time_max, max_tar_dist=c.max_target_dist, tar_succ_dist=c.target_succ_dist,
                     tar_fail_dist=c.tar_fail_dist, tar_speed=c.tar_speed, pos_reward_scale=c.pos_reward_scale, min_tar_vel=c.enable_min_tar_vel,
                     max_turn_rate=c.max_heading_turn_rate, sharp_turn_prob=c.sharp_turn_prob, speed_change_prob=c.speed_change_prob,
                     tar_speed_min=(c.tar_speed if c.tar_speed_min is None else c.tar_speed_min),
-                    tar_speed_max=(c.tar_speed if c.tar_speed_max is None else c.tar_speed_max), vel_reward_scale=c.vel_reward_scale)
+                    tar_speed_max=(c.tar_speed if c.tar_speed_max is None else c.tar_speed_max), vel_reward_scale=c.vel_reward_scale,
+                    getup_time=tables.getup_time, getup_height_root=c.getup_height_root, getup_height_head=c.getup_height_head, head_id=c.head_id,
+                    recover_prob=c.recover_episode_prob, getup_clip_mask=tables.getup_clip_mask,
+                    tar_near_dist=c.tar_near_dist, tar_far_prob=c.tar_far_prob, target_radius=c.target_radius, hit_reset_time=c.target_hit_reset_time,
+                    init_hit_prob=c.init_hit_prob, hit_tar_speed=c.hit_tar_speed, tar_reward_scale=c.tar_reward_scale,
+                    tmin_x=c.target_min[0], tmin_y=c.target_min[1], tmin_z=c.target_min[2], tmax_x=c.target_max[0], tmax_y=c.target_max[1], tmax_z=c.target_max[2],
+                    strike_mask=sum(1 << int(b) for b in (c.strike_bodies or [])), fail_tar_mask=sum(1 << int(b) for b in (c.fail_tar_contact_bodies or [])))
         vals.update(cfg_overrides)
         for k, v in vals.items():
             cfg[CFG_KEYS.index(k)] = float(v)
@@ -297,14 +306,18 @@ class Oracle:
         return float(self.lib.orc_clip_duration(self.h, int(c)))
 
     def record_goal(self):
-        out = np.zeros(3)
+        out = np.zeros(int(self.lib.orc_goal_dim(self.h)))
         self.lib.orc_record_goal(self.h, _d(out))
         return out
 
-    def goal_state(self):
-        out = np.zeros(12)
+    def goal_state(self, full=False):
+        """the device's goal row: target, heading, speed, target timer, action bookkeeping, draw counter (12) [+ clip, aux0, aux1]"""
+        out = np.zeros(15)
         self.lib.orc_goal_state(self.h, _d(out))
-        return out
+        return out if full else out[:12]
+
+    def maybe_recovery_reset(self, max_time=np.inf):
+        return bool(self.lib.orc_maybe_recovery_reset(self.h, C.c_double(max_time)))
 
     def amp_obs_expert_clip(self, clip, t, ground_h=0.0):
         out = np.zeros(self.amp_obs_size())

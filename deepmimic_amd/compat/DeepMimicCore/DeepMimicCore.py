@@ -99,6 +99,8 @@ class cDeepMimicCore(object):
     def _apply_mode(self):
         lo, hi = _model.timer_limits(self._tables.cfg, self._mode == self.eModeTest, self._sample_count)
         self._env.set_time_limits(lo, hi)
+        if self._goal_size():
+            self._env.set_mode(self._mode == self.eModeTest)       # get-up on a fall / recovery episodes / strike_amp's test reward
 
     def _need_env(self):
         if self._env is None:
@@ -190,6 +192,8 @@ class cDeepMimicCore(object):
         self.stats["rollbacks"] += 1
         snap = sp["snap"]
         self._env.set_state(pose=snap["pose"], vel=snap["vel"], tar=snap["tar"], kin=snap["kin"], clocks=snap["clocks"], flags=snap["flags"])
+        if "goal" in snap:                   # goal scenes: target / timers / draw counter / get-up or hit state of the same moment
+            self._env.set_goal_state(snap["goal"]); self._env.set_goal_aux(snap["aux"])
         self._clk = dict(sp["clk0"])
         out = None
         for i in range(sp["v"]):
@@ -229,6 +233,8 @@ class cDeepMimicCore(object):
         k = self._updates_to_next_action(dt) if (self._batch and action is not None) else 1
         if k > 1:
             snap = env.get_state() if snap is None else snap
+            if self._goal_size():
+                snap["goal"] = env.get_goal_state(); snap["aux"] = env.get_goal_aux()
             clk0 = dict(self._clk)
             out = self._launch(action, dt, k, True)
             t1 = float(env.get_state()["clocks"][0][3])
@@ -252,7 +258,8 @@ class cDeepMimicCore(object):
     def GetName(self):
         # cSceneImitate::GetName (scenes/SceneImitate.cpp:207-210), cSceneImitateAMP::GetName (SceneImitateAMP.cpp:208-211)
         scene = self._tables.cfg.scene if self._tables is not None else "imitate"
-        return {"imitate_amp": "Imitate AMP", "target_amp": "Target AMP", "heading_amp": "Heading AMP"}.get(scene, "Imitate")
+        return {"imitate_amp": "Imitate AMP", "target_amp": "Target AMP", "heading_amp": "Heading AMP", "heading_amp_getup": "Heading AMP Getup",
+                "strike_amp": "Strike AMP"}.get(scene, "Imitate")
 
     def _is_amp(self):
         return self._tables is not None and self._tables.cfg.scene in _model.AMP_SCENES
@@ -366,11 +373,20 @@ class cDeepMimicCore(object):
     def BuildStateScale(self, agent_id):
         return [float(x) for x in self._off["state_scale"]]
 
+    def _is_scene(self, name):
+        return self._tables is not None and self._tables.cfg.scene == name
+
     def BuildGoalOffset(self, agent_id):
-        return [0.0] * self._goal_size()        # cRLSceneSimChar::BuildGoalOffsetScale (scenes/RLSceneSimChar.cpp:111-116)
+        off = [0.0] * self._goal_size()         # cRLSceneSimChar::BuildGoalOffsetScale (scenes/RLSceneSimChar.cpp:111-116)
+        if self._is_scene("heading_amp_getup"):
+            off[3] = -0.5                       # cSceneHeadingAMPGetup::BuildGoalOffsetScale (SceneHeadingAMPGetup.cpp:134-142): the get-up phase
+        return off
 
     def BuildGoalScale(self, agent_id):
-        return [1.0] * self._goal_size()
+        sc = [1.0] * self._goal_size()
+        if self._is_scene("heading_amp_getup"):
+            sc[3] = 2.0
+        return sc
 
     def BuildActionOffset(self, agent_id):
         return [float(x) for x in self._off["action_offset"]]
@@ -388,7 +404,12 @@ class cDeepMimicCore(object):
         return [int(x) for x in self._off["state_norm_groups"]]
 
     def BuildGoalNormGroups(self, agent_id):
-        return [0] * self._goal_size()          # cCharController::gNormGroupSingle (:136-140)
+        g = [0] * self._goal_size()             # cCharController::gNormGroupSingle (:136-140)
+        if self._is_scene("heading_amp_getup"):
+            g[3] = -1                           # gNormGroupNone (SceneHeadingAMPGetup.cpp:144-150)
+        if self._is_scene("strike_amp"):
+            g = [-1] * len(g)                   # cSceneStrikeAMP::BuildGoalNormGroups (SceneStrikeAMP.cpp:408-412)
+        return g
 
     def CalcReward(self, agent_id):
         self._chk_agent(agent_id)

@@ -41,6 +41,11 @@ class _SceneTables(C.Structure):
         ("pos_reward_scale", C.c_double), ("max_heading_turn_rate", C.c_double), ("sharp_turn_prob", C.c_double), ("speed_change_prob", C.c_double),
         ("tar_speed_min", C.c_double), ("tar_speed_max", C.c_double), ("vel_reward_scale", C.c_double),
         ("num_clips", C.c_int), ("clip_starts", C.POINTER(C.c_int32)), ("clip_weights", C.POINTER(C.c_double)), ("clip_loops", C.POINTER(C.c_int32)),
+        ("mode_test", C.c_int), ("getup_time", C.c_double), ("getup_height_root", C.c_double), ("getup_height_head", C.c_double),
+        ("recover_episode_prob", C.c_double), ("head_id", C.c_int), ("getup_clip_mask", C.c_int),
+        ("tar_near_dist", C.c_double), ("tar_far_prob", C.c_double), ("target_radius", C.c_double), ("target_hit_reset_time", C.c_double),
+        ("init_hit_prob", C.c_double), ("hit_tar_speed", C.c_double), ("tar_reward_scale", C.c_double),
+        ("target_min", C.c_double * 3), ("target_max", C.c_double * 3), ("strike_mask", C.c_int), ("fail_tar_mask", C.c_int),
     ]
 
 
@@ -133,6 +138,14 @@ class BatchEnv:
             st.clip_loops = _ip(arr(tables.clip_loops, np.int32))
         else:
             st.num_clips = 0
+        # heading_amp_getup / strike_amp
+        st.mode_test = int(bool(test_mode))
+        st.getup_time = float(tables.getup_time); st.getup_clip_mask = int(tables.getup_clip_mask); st.head_id = int(c.head_id)
+        for k in ("getup_height_root", "getup_height_head", "recover_episode_prob", "tar_near_dist", "tar_far_prob", "target_radius",
+                  "target_hit_reset_time", "init_hit_prob", "hit_tar_speed", "tar_reward_scale"):
+            setattr(st, k, float(getattr(c, k)))
+        st.target_min = (C.c_double * 3)(*[float(x) for x in c.target_min]); st.target_max = (C.c_double * 3)(*[float(x) for x in c.target_max])
+        st.strike_mask = sum(1 << int(b) for b in (c.strike_bodies or [])); st.fail_tar_mask = sum(1 << int(b) for b in (c.fail_tar_contact_bodies or []))
         info = _CreateInfo(int(num_envs), int(device_id), int(seed) & (2 ** 64 - 1), int(precision), int(max_contacts), int(env_id_offset), int(wave_packing))
         self.h = C.c_void_p()
         self._chk(self.lib.dm_create(C.byref(info), C.byref(st), C.byref(self.h)))
@@ -212,13 +225,27 @@ class BatchEnv:
             out["goal"] = self.last_goals()
         return out
 
+    def set_mode(self, test_mode: bool):
+        """cRLScene::SetMode for the goal scenes' device-side logic (the episode-timer limits are set_time_limits' business)"""
+        self._chk(self.lib.dm_set_mode(self.h, int(bool(test_mode))))
+
+    def get_goal_aux(self):
+        """N x 2: heading_amp_getup {get-up timer, -}; strike_amp {target hit, hit time}"""
+        out = np.zeros((self.N, 2))
+        self._chk(self.lib.dm_get_goal_aux(self.h, _dp(out)))
+        return out
+
+    def set_goal_aux(self, aux):
+        aux = np.ascontiguousarray(aux, dtype=np.float64).reshape(self.N, 2)
+        self._chk(self.lib.dm_set_goal_aux(self.h, _dp(aux)))
+
     def last_goals(self):
-        g = np.zeros((self.N, 3), np.float32)
+        g = np.zeros((self.N, max(self.G, 1)), np.float32)
         self._chk(self.lib.dm_last_goals(self.h, _fp(g)))
         return g
 
     def query_goal(self):
-        """RecordGoal for every env (goal scenes): N x 3"""
+        """RecordGoal for every env (goal scenes): N x G"""
         g = np.zeros((self.N, max(self.G, 1)), np.float32)
         self._chk(self.lib.dm_query_goal(self.h, _fp(g), 0))
         return g[:, :self.G]

@@ -260,6 +260,7 @@ struct Lds {
     double clk[6];                         // kin_time, ctrl_time, init_time_offset, timer_time, timer_max
     int flg[8];                            // need_new_action, contact_mask, episode_count, valid, nrows, ncontacts, parked, over
     int fall_mask;                         // links whose ground contact is a fall (bit j), from link_info at load
+    int getup;                             // heading_amp_getup: the get-up timer of the env is running (mirror of the goal row, goal_sync_flags)
 };
 
 // What the end-of-call outputs need of a character whose episode ended mid-call (two characters per wavefront, early episode end)
@@ -321,7 +322,7 @@ struct EnvSim {
         if (LW == kWave) load_cands();
         sync();
         li = (l < m.J) ? s.mdl.link_info[l] : 0;
-        if (l == 0) { int fm = 0; for (int j = 0; j < m.J; ++j) fm |= DM_LI_FALL(s.mdl.link_info[j]) << j; s.fall_mask = fm; }
+        if (l == 0) { int fm = 0; for (int j = 0; j < m.J; ++j) fm |= DM_LI_FALL(s.mdl.link_info[j]) << j; s.fall_mask = fm; s.getup = 0; }
     }
     DM_DEV void load(const EnvState<Real>& st, int e) {
         load_model();
@@ -1169,9 +1170,13 @@ struct EnvSim {
     }
 
     // ------------------------------------------------------------------ termination
+    // cSceneSimChar::HasFallenContact; cSceneHeadingAMPGetup's override (SceneHeadingAMPGetup.cpp:255-264): never while getting up
+    DM_DEV bool has_fallen_contact() const {
+        if (m.scene_goal == 3 && s.getup) return false;
+        return m.enable_contact_fall && (s.flg[FLG_CONTACT] & s.fall_mask) != 0;
+    }
     DM_DEV bool has_fallen(const Real* kp) const {
-        bool f = false;
-        if (m.enable_contact_fall) f = (s.flg[FLG_CONTACT] & s.fall_mask) != 0;
+        bool f = has_fallen_contact();
         if (m.enable_root_rot_fail && kp) f = f || (quat_theta(qmul(ldq(kp + 3), qconj(ldq(s.pose + 3)))) > (Real)(0.5 * DM_PI));
         return f;
     }
@@ -1412,27 +1417,83 @@ struct EnvSim {
         const double u1 = 1.0 - goal_u01(g, e), u2 = goal_u01(g, e);
         return mean + stdev * sqrt(-2.0 * log(u1)) * cos(6.283185307179586 * u2);
     }
-    // cSceneTargetAMP::SampleRandTargetPos (:285-299)
+    DM_DEV bool target_like() const { return m.scene_goal == 1 || m.scene_goal == 4; }
+    DM_DEV bool heading_like() const { return m.scene_goal == 2 || m.scene_goal == 3; }
+    // cSceneStrikeAMP::SetTargetHit (:249-258): the hit time is the scene clock (cScene::GetTime) of the first hit
+    DM_DEV void set_target_hit(double* g, bool hit) const { if (g[GS_AUX0] == 0.0 && hit) g[GS_AUX1] = s.clk[CLK_TIMER]; g[GS_AUX0] = hit ? 1.0 : 0.0; }
+    // cSceneTargetAMP::SampleRandTargetPos (:285-299); cSceneStrikeAMP::ResetTargetPos / ...Far / ...Near (:318-374)
     DM_DEV void goal_reset_target_pos(double* g, int e) const {
+        if (m.scene_goal == 4) {
+            const bool far = goal_u01(g, e) < m.tar_far_prob;
+            const double theta = far ? goal_uniform(g, e, -3.141592653589793, 3.141592653589793) : goal_uniform(g, e, m.target_min[0], m.target_max[0]);
+            const double hgt = goal_uniform(g, e, m.target_min[1], m.target_max[1]);
+            const double dist = far ? goal_uniform(g, e, m.target_min[2], (double)m.max_target_dist) : goal_uniform(g, e, m.target_min[2], m.target_max[2]);
+            g[GS_TX] = dist * cos(theta) + (double)s.pose[0]; g[GS_TY] = hgt; g[GS_TZ] = dist * -sin(theta) + (double)s.pose[2];
+            set_target_hit(g, false);
+            return;
+        }
         const double dist = goal_uniform(g, e, 0.0, (double)m.max_target_dist), theta = goal_uniform(g, e, 0.0, 6.283185307179586);
         g[GS_TX] = (double)s.pose[0] + dist * cos(theta); g[GS_TY] = 0; g[GS_TZ] = (double)s.pose[2] + dist * sin(theta);
     }
     DM_DEV void goal_timer_reset(double* g, int e) const { g[GS_TIMER] = 0; g[GS_TIMER_MAX] = goal_uniform(g, e, m.goal_time_min, m.goal_time_max); }   // cTimer::Reset, uniform
+    // the get-up flag of the env's LDS record follows the goal row (after load, after every change of the timer)
+    DM_DEV void goal_sync_flags(const EnvState<Real>& st, int e, bool act = true) {
+        if (m.scene_goal == 3) {
+            if (act && l == 0) s.getup = !(st.goal[(size_t)e * GS_WIDTH + GS_AUX0] >= m.getup_time) ? 1 : 0;      // CheckGettingUp (:301-304)
+            sync();
+        }
+    }
     // cSceneTargetAMP::Reset after the scene reset (:130-135): mTargetTimer.Reset(); ResetTarget(); and cCtController::SetInitTime /
     // cDeepMimicCharController::ResetParams for the action bookkeeping (mPrevActionTime = time, mPrevActionCOM = 0)
     DM_DEV void goal_reset(const EnvState<Real>& st, int e) {
         if (l == 0) {
             double* g = st.goal + (size_t)e * GS_WIDTH;
+            g[GS_AUX0] = 0; g[GS_AUX1] = -1.0;
             goal_timer_reset(g, e);
             goal_reset_target_pos(g, e);
-            if (m.scene_goal == 2) {       // cSceneHeadingAMP::ResetTarget (:230-239)
+            if (heading_like()) {          // cSceneHeadingAMP::ResetTarget (:230-239)
                 g[GS_HEADING] = 0;
                 const double sp = goal_uniform(g, e, (double)m.tar_speed_min, (double)m.tar_speed_max);
                 g[GS_SPEED] = fmin(fmax(sp, (double)m.tar_speed_min), (double)m.tar_speed_max);
             } else g[GS_SPEED] = (double)m.tar_speed;
             g[GS_PCOMX] = g[GS_PCOMY] = g[GS_PCOMZ] = 0; g[GS_PTIME] = s.clk[CLK_CTRL];
+            if (m.scene_goal == 3) {       // ResetTimers -> ResetGetupTimer (ended), then SyncGetupTimer (:190-207): a get-up clip starts mid get-up
+                g[GS_AUX0] = m.getup_time;
+                if ((m.getup_clip_mask >> (int)g[GS_CLIP]) & 1) g[GS_AUX0] = s.clk[CLK_KIN];
+                s.getup = !(g[GS_AUX0] >= m.getup_time) ? 1 : 0;
+            }
+            if (m.scene_goal == 4) {       // cSceneStrikeAMP::ResetTarget (:301-316): ResetTargetHit (:376-383), then the hit clock
+                if (!m.mode_test && m.init_hit_prob > 0) set_target_hit(g, goal_u01(g, e) < m.init_hit_prob);
+                g[GS_AUX1] = (g[GS_AUX0] != 0.0) ? goal_uniform(g, e, s.clk[CLK_TIMER] - m.hit_reset_time, s.clk[CLK_TIMER]) : -1.0;
+            }
         }
         sync();
+    }
+    // cSceneHeadingAMPGetup::Reset (:109-121): in train mode an episode that ended in a fall continues, with probability
+    // recover_episode_prob, as a recovery episode -- ResetRecoveryEpisode (:40-56) resets the timers and the controller only, the
+    // characters stay where they are (`bool mIsRecoveryEpisode = ...` declares a local there: the member stays false and recovery
+    // episodes chain).  Returns true (to every lane of the character) when it did that instead of a scene reset.
+    DM_DEV bool try_recovery_reset(const EnvState<Real>& st, int e, double max_time) {
+        if (!(m.scene_goal == 3 && !m.mode_test && m.recover_prob > 0)) return false;
+        sync();
+        if (l == 0) {
+            double* g = st.goal + (size_t)e * GS_WIDTH;
+            bool rec = m.enable_fall_end && has_fallen(nullptr);                     // CheckTerminate(0) == eTerminateFail
+            if (rec) rec = goal_u01(g, e) < m.recover_prob;                          // mRand.FlipCoin
+            if (rec) {
+                s.clk[CLK_TIMER] = 0; s.clk[CLK_TIMER_MAX] = max_time;               // ResetTimers
+                g[GS_AUX0] = 0; s.getup = 1;                                         // ResetGetupTimer, BeginGetup
+                s.clk[CLK_CTRL] = 0; s.clk[CLK_INIT_OFF] = 0;                        // cCtController::ResetParams (CtController.cpp:103-108)
+                s.flg[FLG_NEED_ACTION] = 1; s.flg[FLG_EPISODE] += 1;
+                g[GS_PCOMX] = g[GS_PCOMY] = g[GS_PCOMZ] = 0; g[GS_PTIME] = 0;
+            }
+            s.sc[7] = rec ? (Real)1 : (Real)0;
+        }
+        sync();
+        const bool rec = s.sc[7] != (Real)0;
+        if (rec) for (int i = l; i < m.D; i += LW) s.tau[i] = 0;
+        sync();
+        return rec;
     }
     // mass-weighted COM of the links whose kinematics() results are in LDS -> every lane (cSimCharacter::CalcCOM)
     DM_DEV v3 com_of_links() {
@@ -1444,9 +1505,12 @@ struct EnvSim {
         sync();
         return ((Real)1 / tm) * acc;
     }
+    DM_DEV v3 link_vcom(int j) const { return ld3(s.vj[j]) + cross(ld3(s.w[j]), ld3(s.com[j]) - ld3(s.p[j])); }   // cSimObj::GetLinearVelocity of a link
+    // Before an update: cScene::UpdateTimers for the get-up timer (SceneHeadingAMPGetup.cpp:163-167), then
     // cDeepMimicCharController::HandleNewAction (DeepMimicCharController.cpp:262-267), run by UpdateCalcTau of the first update after
     // an action boundary: mPrevActionTime = mTime (already advanced by this update), mPrevActionCOM = CalcCOM() (state before it)
     DM_DEV void goal_latch(const EnvState<Real>& st, int e, double dt, bool act = true) {
+        if (m.scene_goal == 3 && act && l == 0) { double* g = st.goal + (size_t)e * GS_WIDTH; g[GS_AUX0] += dt; s.getup = !(g[GS_AUX0] >= m.getup_time) ? 1 : 0; }
         if (s.flg[FLG_NEED_ACTION]) {          // wave-uniform for one character per wave; per half otherwise (kinematics is lane-local + barriers)
             kinematics(s.pose, s.vel, zero3());
             const v3 c = com_of_links();
@@ -1454,14 +1518,41 @@ struct EnvSim {
         }
         sync();
     }
-    // cSceneTargetAMP::Update after the scene update (:137-146) with cSceneHeadingAMP::UpdateTarget (:214-228)
+    // strike_amp, lane 0, link kinematics of the current state in LDS.  CheckTargetHit (:441-478): a strike body inside the target
+    // sphere moving towards the target fast enough; CheckTarContactFail (:485-503): one of the forbidden bodies inside it
+    DM_DEV bool strike_hit(const double* g) const {
+        const v3 tp = mk3((Real)g[GS_TX], (Real)g[GS_TY], (Real)g[GS_TZ]);
+        v3 d = tp - ld3(s.pose); d.y = 0;
+        const Real n = norm(d);
+        const v3 dir = (n > (Real)1e-5) ? ((Real)1 / n) * d : zero3();
+        for (int j = 0; j < m.J; ++j) if ((m.strike_mask >> j) & 1) {
+            const v3 dj = tp - ld3(s.com[j]);
+            if (dot(dj, dj) < m.target_radius * m.target_radius) { const Real sp = dot(dir, link_vcom(j)); if (sp >= m.hit_tar_speed || m.hit_tar_speed == (Real)0) return true; }
+        }
+        return false;
+    }
+    DM_DEV bool strike_contact_fail(const double* g) const {
+        const v3 tp = mk3((Real)g[GS_TX], (Real)g[GS_TY], (Real)g[GS_TZ]);
+        for (int j = 0; j < m.J; ++j) if ((m.fail_tar_mask >> j) & 1) { const v3 dj = tp - ld3(s.com[j]); if (dot(dj, dj) < m.target_radius * m.target_radius) return true; }
+        return false;
+    }
+    DM_DEV bool strike_succ(const double* g) const { return g[GS_AUX0] != 0.0 && (s.clk[CLK_TIMER] - g[GS_AUX1]) >= m.hit_reset_time; }   // CheckTarHitSucc (:505-520)
+    DM_DEV bool goal_dist_fail(const double* g) const {                  // cSceneTargetAMP::CheckTarDistFail (:306-317); heading scenes: false
+        if (!target_like()) return false;
+        const Real dx = s.pose[0] - (Real)g[GS_TX], dz = s.pose[2] - (Real)g[GS_TZ];
+        return dx * dx + dz * dz > m.tar_fail_dist * m.tar_fail_dist;
+    }
+    // cSceneTargetAMP::Update after the scene update (:137-146) with cSceneHeadingAMP::UpdateTarget (:214-228), cSceneStrikeAMP::UpdateTarget
+    // (:290-299), cSceneHeadingAMPGetup::UpdateTestGetup (:244-253); then the goal scenes' part of IsEpisodeEnd for DM_END_EPISODE_EARLY
     DM_DEV void goal_update(const EnvState<Real>& st, int e, double dt, bool act = true) {
+        if (m.scene_goal == 4) kinematics(s.pose, s.vel, zero3());             // link positions / velocities of the state after this update
         if (act && l == 0) {
             double* g = st.goal + (size_t)e * GS_WIDTH;
             g[GS_TIMER] += dt;
             const bool end = g[GS_TIMER] >= g[GS_TIMER_MAX];
-            if (end) goal_reset_target_pos(g, e);                              // EnableRandTargetPos() is true in both scenes
-            if (m.scene_goal == 2 && end) {
+            if (end && m.scene_goal != 4) goal_reset_target_pos(g, e);         // EnableRandTargetPos(); cSceneStrikeAMP::CheckTargetReset is false (:385-388)
+            if (m.scene_goal == 4 && g[GS_AUX0] == 0.0) set_target_hit(g, strike_hit(g));
+            if (heading_like() && end) {
                 // UpdateTargetHeading (:182-203, EnableTargetPos() false): sharp turn with probability p, else a Gaussian step
                 const bool sharp = goal_u01(g, e) < (double)m.sharp_turn_prob;                 // cRand::FlipCoin
                 g[GS_HEADING] += sharp ? goal_uniform(g, e, -3.141592653589793, 3.141592653589793) : goal_normal(g, e, 0.0, (double)m.max_heading_turn_rate);
@@ -1472,6 +1563,10 @@ struct EnvSim {
                 }
             }
             if (end) goal_timer_reset(g, e);
+            if (m.scene_goal == 3 && m.mode_test && has_fallen_contact() && !s.getup) { g[GS_AUX0] = 0; s.getup = 1; }     // BeginGetup
+            bool over = episode_over_now() || goal_dist_fail(g);
+            if (m.scene_goal == 4) over = over || strike_contact_fail(g) || strike_succ(g);
+            s.flg[FLG_OVER] = over ? 1 : 0;
         }
         sync();
     }
@@ -1486,23 +1581,37 @@ struct EnvSim {
             const Real tar_speed = (Real)g[GS_SPEED];
             v3 rel = tar - root; rel.y = 0;
             const Real dist_sq = dot(rel, rel);
-            const bool dist_fail = (m.scene_goal == 1) && dist_sq > m.tar_fail_dist * m.tar_fail_dist;      // CheckTarDistFail (:306-317); heading: false
+            const bool dist_fail = target_like() && dist_sq > m.tar_fail_dist * m.tar_fail_dist;      // CheckTarDistFail (:306-317); heading: false
             if (io.goals) {
-                float* o = io.goals + (size_t)e * 3;
+                float* o = io.goals + (size_t)e * m.goal_dim;
                 if (m.scene_goal == 1) {       // cSceneTargetAMP::RecordGoal (:195-223)
                     const Real d = dm_sqrt(dist_sq);
                     v3 r = mk3((Real)1, (Real)0, (Real)0);
                     if (d > (Real)0.0001) r = ((Real)1 / d) * (rot_y(-heading) * rel);
                     o[0] = (float)r.x; o[1] = (float)r.z; o[2] = (float)d;
+                } else if (m.scene_goal == 4) {  // cSceneStrikeAMP::RecordGoal (:414-434): target in the origin frame (BuildOriginTrans), hit phase
+                    v3 t = tar - root; t.y = tar.y;
+                    t = rot_y(-heading) * t;
+                    double ph = 0;
+                    if (g[GS_AUX0] != 0.0) ph = fmin(fmax((s.clk[CLK_TIMER] - g[GS_AUX1]) / m.hit_reset_time, 0.0), 1.0);   // CalcHitPhase (:390-401)
+                    o[0] = (float)t.x; o[1] = (float)t.y; o[2] = (float)t.z; o[3] = (float)ph;
                 } else {                       // cSceneHeadingAMP::RecordGoal (:150-166)
                     Real sh, ch; dm_sincos((Real)g[GS_HEADING] - heading, sh, ch);
                     o[0] = (float)ch; o[1] = (float)-sh; o[2] = (float)tar_speed;
+                    // cSceneHeadingAMPGetup::RecordGoal (:123-130): + CalcGetupPhase (:293-299)
+                    if (m.scene_goal == 3) o[3] = (float)fmin(fmax(1.0 - g[GS_AUX0] / m.getup_time, 0.0), 1.0);
                 }
             }
             if (write_flags) {
                 const bool fallen = has_fallen(nullptr);
                 const Real step_dur = (Real)(s.clk[CLK_CTRL] - g[GS_PTIME]);
                 const v3 dcom = com - mk3((Real)g[GS_PCOMX], (Real)g[GS_PCOMY], (Real)g[GS_PCOMZ]);
+                int term = TERM_NULL;          // what the goal scene adds to CheckTerminate when nothing else terminated
+                if (dist_fail) term = TERM_FAIL;                                 // cSceneTargetAMP::CheckTerminate (:319-345)
+                else if (m.scene_goal == 4) {                                    // cSceneStrikeAMP::CheckTerminateTarget (:522-541)
+                    if (strike_contact_fail(g)) term = TERM_FAIL;
+                    else if (strike_succ(g)) term = TERM_SUCC;
+                }
                 Real r = 0;
                 if (m.scene_goal == 1) {       // cSceneTargetAMP::CalcReward (:3-81)
                     if (!dist_fail && !fallen) {
@@ -1520,6 +1629,38 @@ struct EnvSim {
                         }
                         r = (Real)0.6 * pos_reward + (Real)0.4 * vel_reward;
                     }
+                } else if (m.scene_goal == 4) {  // cSceneStrikeAMP::CalcReward (:9-187)
+                    const bool ended = s.sc[6] != (Real)0 || term != TERM_NULL;
+                    const bool succ = !(m.enable_fall_end && fallen) && term == TERM_SUCC;
+                    if (m.mode_test) { if (ended && succ) r = (Real)(s.clk[CLK_TIMER_MAX] - s.clk[CLK_TIMER]); }      // CalcRewardTest (:57-72)
+                    else if (g[GS_AUX0] != 0.0) r = (Real)1;                                                          // 0.3 + 0.3 + 0.4
+                    else if (dist_sq < m.tar_near_dist * m.tar_near_dist) {                                           // CalcRewardTargetNear (:74-112)
+                        const Real n = dm_sqrt(dist_sq);
+                        const v3 dir = (n > (Real)1e-5) ? ((Real)1 / n) * rel : zero3();
+                        Real best = 0;
+                        for (int j = 0; j < m.J; ++j) if ((m.strike_mask >> j) & 1) {
+                            const v3 dj = tar - ld3(s.com[j]);
+                            const Real dr = dm_exp(-m.tar_reward_scale * dot(dj, dj));
+                            Real vr = dm_min(dm_max(dot(dir, link_vcom(j)) / m.hit_tar_speed, (Real)0), (Real)1); vr *= vr;
+                            best = dm_max(best, (Real)0.2 * dr + (Real)0.8 * vr);
+                        }
+                        r = (Real)0.3 + (Real)0.3 * best;
+                    } else if (!fallen) {                                                                             // CalcRewardTargetFar (:114-187)
+                        const Real rt = dm_sqrt(dist_sq), de = dm_max(rt - m.tar_near_dist, (Real)0);
+                        const Real pos_reward = dm_exp(-m.pos_reward_scale * de * de);
+                        Real vel_reward = 0;
+                        v3 ct = tar - com; ct.y = 0;
+                        const Real cd = norm(ct);
+                        const v3 dir = (cd > (Real)0.0001) ? ((Real)1 / cd) * ct : zero3();
+                        const Real avg_vel = dot(dir, dcom) / step_dur;
+                        Real vel_err = tar_speed - avg_vel;
+                        if (!(avg_vel < 0)) { if (m.enable_min_tar_vel) vel_err = dm_max(vel_err, (Real)0); vel_reward = dm_exp(-((Real)4 / (tar_speed * tar_speed)) * vel_err * vel_err); }
+                        r = (Real)0.3 * ((Real)0.7 * pos_reward + (Real)0.3 * vel_reward);
+                    }
+                } else if (m.scene_goal == 3 && s.getup) {                       // cSceneHeadingAMPGetup::CalcRewardGetup (:19-38)
+                    const Real nr = dm_min(dm_max(s.pose[1] / m.getup_height_root, (Real)0), (Real)1);
+                    const Real nh = dm_min(dm_max(s.com[m.head_id][1] / m.getup_height_head, (Real)0), (Real)1);
+                    r = (Real)0.2 * nr + (Real)0.8 * nh;
                 } else if (!fallen) {          // cSceneHeadingAMP::CalcReward (:3-43)
                     Real sh, ch; dm_sincos((Real)g[GS_HEADING], sh, ch);
                     v3 av = ((Real)1 / step_dur) * dcom; av.y = 0;
@@ -1527,8 +1668,8 @@ struct EnvSim {
                     if (avg_speed > 0) { Real vel_err = tar_speed - avg_speed; if (m.enable_min_tar_vel) vel_err = dm_max(vel_err, (Real)0); r = dm_exp(-m.vel_reward_scale * vel_err * vel_err); }
                 }
                 if (io.rewards) io.rewards[e] = (float)r;
-                if (dist_fail) {               // cSceneTargetAMP::CheckTerminate (:319-345): Fail when nothing else terminated
-                    if (io.terminate && io.terminate[e] == TERM_NULL) io.terminate[e] = TERM_FAIL;
+                if (term != TERM_NULL) {       // the scene's own termination, only when nothing else terminated
+                    if (io.terminate && io.terminate[e] == TERM_NULL) io.terminate[e] = term;
                     if (io.episode_end) io.episode_end[e] = 1;
                     s.sc[6] = (Real)1;
                 }
@@ -1653,6 +1794,7 @@ __global__ void __launch_bounds__(64) DM_WAVES_PER_EU((StepWaves<Real, C>::value
     sim.mark(15);
     Real* aovf = st.aovf ? st.aovf + (size_t)e * (kMaxRows - C::RREG) * kWave : nullptr;
     const bool goal = HIST && st.goal && m.scene_goal;
+    if (goal) sim.goal_sync_flags(st, e);
     for (int u = 0; u < io.n_updates; ++u) {
         if (HIST && st.hist) sim.latch_hist(st, e);
         if (goal) sim.goal_latch(st, e, io.dt);
@@ -1673,7 +1815,9 @@ __global__ void __launch_bounds__(64) DM_WAVES_PER_EU((StepWaves<Real, C>::value
             if (pass == 1 || !(io.auto_reset && ended)) break;
             uint64_t ep = (uint64_t)lds.flg[FLG_EPISODE];
             double mt = (m.time_lim_max > m.time_lim_min) ? m.time_lim_min + (m.time_lim_max - m.time_lim_min) * dm_rand01(m.seed, (uint64_t)(e + m.env_off), ep, 1) : m.time_lim_max;
-            if (HIST && st.goal) reset_goal_env<Real, C, TAPS>(sim, m, lds, st, e, ep, nullptr, mt);   // clip by weight, random yaw, goal reset
+            if (HIST && st.goal) {           // clip by weight, random yaw, goal reset -- unless the episode goes on as a recovery episode
+                if (!sim.try_recovery_reset(st, e, mt)) reset_goal_env<Real, C, TAPS>(sim, m, lds, st, e, ep, nullptr, mt);
+            }
             else {
                 double kt = m.duration * dm_rand01(m.seed, (uint64_t)(e + m.env_off), ep, 0);
                 sim.reset_env(kt, mt);
@@ -1698,8 +1842,10 @@ __global__ void __launch_bounds__(64) k_env_reset(ModelDev<Real> m, EnvState<Rea
     uint64_t ep = (uint64_t)lds.flg[FLG_EPISODE];
     double mt = max_times ? max_times[b]
               : ((m.time_lim_max > m.time_lim_min) ? m.time_lim_min + (m.time_lim_max - m.time_lim_min) * dm_rand01(m.seed, (uint64_t)(e + m.env_off), ep, 1) : m.time_lim_max);
-    if (st.goal) reset_goal_env<Real, C, true>(sim, m, lds, st, e, ep, kin_times ? &kin_times[b] : nullptr, mt);
-    else {
+    if (st.goal) {
+        sim.goal_sync_flags(st, e);
+        if (kin_times || !sim.try_recovery_reset(st, e, mt)) reset_goal_env<Real, C, true>(sim, m, lds, st, e, ep, kin_times ? &kin_times[b] : nullptr, mt);
+    } else {
         double kt = kin_times ? kin_times[b] : m.duration * dm_rand01(m.seed, (uint64_t)(e + m.env_off), ep, 0);
         sim.reset_env(kt, mt);
         if (st.hist) sim.init_hist(st, e);
@@ -1714,6 +1860,7 @@ __global__ void __launch_bounds__(64) k_env_query(ModelDev<Real> m, EnvState<Rea
     const int e = blockIdx.x, l = threadIdx.x;
     EnvSim<Real, C> sim(m, lds, l);
     sim.load(st, e);
+    if (st.goal && m.scene_goal) sim.goal_sync_flags(st, e);
     sim.emit(io, dbg, e, true);
     if (st.goal && m.scene_goal) sim.emit_goal(io, st, e, true);
     if (io.amp_obs && st.hist) sim.emit_amp(io, st, e);

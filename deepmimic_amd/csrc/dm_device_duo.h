@@ -669,11 +669,12 @@ __global__ void __launch_bounds__(64) DM_WAVES_PER_EU((DuoWaves<Real>::value)) k
     sim.b.mark(15);
     Real* aovf_pair = st.aovf ? st.aovf + (size_t)(2 * blockIdx.x) * (kMaxRows - ClsBiped::RREG) * kWave : nullptr;
     const bool goal = HIST && st.goal && m.scene_goal;
+    if (goal) sim.b.goal_sync_flags(st, e);
     for (int u = 0; u < io.n_updates; ++u) {
         if (HIST && st.hist) sim.b.latch_hist(st, e, lds[half].flg[FLG_PARKED] == 0);
         if (goal) sim.b.goal_latch(st, e, io.dt, lds[half].flg[FLG_PARKED] == 0);
         sim.update(io.dt, e, aovf_pair);
-        if (goal) sim.b.goal_update(st, e, io.dt, lds[half].flg[FLG_PARKED] == 0 && lds[half].flg[FLG_OVER] == 0);
+        if (goal) sim.b.goal_update(st, e, io.dt, lds[half].flg[FLG_PARKED] == 0);      // the update that ends an episode includes its goal update
         if (io.end_early) {
             // DM_END_EPISODE_EARLY.  FLG_OVER is latched by each character's lane 0 at the end of update() (wave-uniform reads).
             // Both over: the wave is done.  One over (a few percent of the waves of a launch): what the outputs need of its record
@@ -696,7 +697,7 @@ __global__ void __launch_bounds__(64) DM_WAVES_PER_EU((DuoWaves<Real>::value)) k
         if (io.auto_reset && ended) {                    // per character; no cross-half traffic inside
             uint64_t ep = (uint64_t)lds[half].flg[FLG_EPISODE];
             double mt = (m.time_lim_max > m.time_lim_min) ? m.time_lim_min + (m.time_lim_max - m.time_lim_min) * dm_rand01(m.seed, (uint64_t)(e + m.env_off), ep, 1) : m.time_lim_max;
-            if (HIST && st.goal) reset_goal_env<Real, ClsBiped, TAPS, 32>(sim.b, m, lds[half], st, e, ep, nullptr, mt);
+            if (HIST && st.goal) { if (!sim.b.try_recovery_reset(st, e, mt)) reset_goal_env<Real, ClsBiped, TAPS, 32>(sim.b, m, lds[half], st, e, ep, nullptr, mt); }
             else {
                 double kt = m.duration * dm_rand01(m.seed, (uint64_t)(e + m.env_off), ep, 0);
                 sim.b.reset_env(kt, mt);

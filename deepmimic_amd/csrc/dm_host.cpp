@@ -300,6 +300,7 @@ struct CtxBase {
     int amp_size = 0; float* d_amp = nullptr; uint64_t expert_calls = 0;
     int goal_size = 0; float* d_goals = nullptr;            // RecordGoal of the last emit (goal scenes)
     virtual int get_goal(double* out) = 0; virtual int set_goal(const double* in) = 0; virtual int get_clips(int* out) = 0;
+    virtual int goal_aux(double* out, const double* in) = 0; virtual void set_mode(int test) = 0;
     virtual int amp_expert_clips(int n, const int* clips_dev, const double* times_dev, const double* gh_dev, float* out_dev) = 0;
     virtual int probe(int what, double dt) = 0;
     virtual int get_state(double* pose, double* vel, double* tar, double* kin, double* clk, int* flg) = 0;
@@ -414,14 +415,21 @@ struct CtxT : CtxBase {
         md.tar_speed = (Real)c.tar_speed; md.pos_reward_scale = (Real)c.pos_reward_scale; md.max_heading_turn_rate = (Real)c.max_heading_turn_rate;
         md.sharp_turn_prob = (Real)c.sharp_turn_prob; md.speed_change_prob = (Real)c.speed_change_prob;
         md.tar_speed_min = (Real)c.tar_speed_min; md.tar_speed_max = (Real)c.tar_speed_max; md.vel_reward_scale = (Real)c.vel_reward_scale;
+        md.goal_dim = (c.scene_goal >= 3) ? 4 : (c.scene_goal ? 3 : 0); md.mode_test = c.mode_test;
+        md.getup_time = c.getup_time; md.recover_prob = c.recover_episode_prob; md.getup_height_root = (Real)c.getup_height_root; md.getup_height_head = (Real)c.getup_height_head;
+        md.head_id = c.head_id; md.getup_clip_mask = c.getup_clip_mask;
+        md.tar_far_prob = c.tar_far_prob; md.init_hit_prob = c.init_hit_prob; md.hit_reset_time = c.target_hit_reset_time;
+        for (int k = 0; k < 3; ++k) { md.target_min[k] = c.target_min[k]; md.target_max[k] = c.target_max[k]; }
+        md.tar_near_dist = (Real)c.tar_near_dist; md.target_radius = (Real)c.target_radius; md.hit_tar_speed = (Real)c.hit_tar_speed; md.tar_reward_scale = (Real)c.tar_reward_scale;
+        md.strike_mask = c.strike_mask; md.fail_tar_mask = c.fail_tar_mask;
         md.num_clips = h.num_clips;
         md.clip_start = up<int>(h.clip_start); md.clip_dur = up<double>(h.clip_dur); md.clip_loop = up<int>(h.clip_loop);
         md.clip_delta = up<Real>(h.clip_delta); md.clip_cdf = up<double>(h.clip_cdf);
         if (c.scene_goal || h.num_clips > 1 || c.enable_rand_rot_reset) {
             if (!c.scene_amp) return fail("goal scenes, multi-clip datasets and enable_rand_rot_reset ride on the AMP instantiation of the kernels: scene_amp must be set");
             st.goal = (double*)dalloc(sizeof(double) * (size_t)N * GS_WIDTH);
-            goal_size = c.scene_goal ? 3 : 0;
-            d_goals = (float*)dalloc(sizeof(float) * (size_t)N * 3);
+            goal_size = md.goal_dim;
+            d_goals = (float*)dalloc(sizeof(float) * (size_t)N * 4);
             if (!st.goal || !d_goals) return fail("device allocation failed");
         }
         d_actions = (float*)dalloc(sizeof(float) * N * h.A); d_states = (float*)dalloc(sizeof(float) * N * h.S); d_rewards = (float*)dalloc(sizeof(float) * N);
@@ -492,6 +500,18 @@ struct CtxT : CtxBase {
         for (int e = 0; e < N; ++e) for (int k = 0; k < 12; ++k) g[(size_t)e * GS_WIDTH + k] = in[(size_t)e * 12 + k];
         return rt_h2d(st.goal, g.data(), sizeof(double) * g.size(), stream) == 0 ? 0 : fail("host to device copy failed");
     }
+    int goal_aux(double* out, const double* in) override {
+        if (!st.goal) return fail("no goal state: not a goal scene / multi-clip dataset");
+        std::vector<double> g((size_t)N * GS_WIDTH);
+        if (rt_d2h(g.data(), st.goal, sizeof(double) * g.size(), stream) != 0) return fail("device to host copy failed");
+        if (out) for (int e = 0; e < N; ++e) { out[(size_t)e * 2] = g[(size_t)e * GS_WIDTH + GS_AUX0]; out[(size_t)e * 2 + 1] = g[(size_t)e * GS_WIDTH + GS_AUX1]; }
+        if (in) {
+            for (int e = 0; e < N; ++e) { g[(size_t)e * GS_WIDTH + GS_AUX0] = in[(size_t)e * 2]; g[(size_t)e * GS_WIDTH + GS_AUX1] = in[(size_t)e * 2 + 1]; }
+            if (rt_h2d(st.goal, g.data(), sizeof(double) * g.size(), stream) != 0) return fail("host to device copy failed");
+        }
+        return 0;
+    }
+    void set_mode(int test) override { md.mode_test = test ? 1 : 0; }
     int get_clips(int* out) override {
         if (!st.goal) { for (int e = 0; e < N; ++e) out[e] = 0; return 0; }
         std::vector<double> g((size_t)N * GS_WIDTH);
@@ -588,7 +608,10 @@ int dm_destroy(dm_ctx* ctx);
 int dm_create(const dm_create_info* info, const dm_scene_tables* tables, dm_ctx** out) {
     if (!info || !tables || !out) return fail("null argument");
     if (info->num_envs < 1) return fail("num_envs must be >= 1");
-    if (tables->scene_goal < 0 || tables->scene_goal > 2) return fail("scene_goal must be 0 (none), 1 (target_amp) or 2 (heading_amp)");
+    if (tables->scene_goal < 0 || tables->scene_goal > 4) return fail("scene_goal must be 0 (none), 1 (target_amp), 2 (heading_amp), 3 (heading_amp_getup) or 4 (strike_amp)");
+    if (tables->scene_goal == 3 && !(tables->getup_time > 0)) return fail("heading_amp_getup needs getup_time > 0 (the longest get-up clip)");
+    if (tables->scene_goal == 3 && (tables->head_id < 0 || tables->head_id >= tables->num_joints)) return fail("head_id out of range");
+    if (tables->scene_goal == 4 && tables->strike_mask == 0) return fail("strike_amp needs at least one strike body");
     if (tables->num_sim_substeps < 1) return fail("num_sim_substeps must be >= 1");
     int precision = info->precision ? info->precision : 32;
     if (precision != 32 && precision != 64) return fail("precision must be 32 or 64");
@@ -795,16 +818,20 @@ int dm_query_goal(dm_ctx* ctx, float* goals, int flags) {
     if (!c->goal_size) return fail("RecordGoal needs a goal scene (dm_scene_tables.scene_goal)");
     if (launch_status(c->query(nullptr, nullptr, nullptr, nullptr, nullptr))) return -1;
     (void)flags;
-    return copy_out(c, goals, c->d_goals, sizeof(float) * (size_t)c->N * 3);
+    return copy_out(c, goals, c->d_goals, sizeof(float) * (size_t)c->N * c->goal_size);
 }
 int dm_last_goals(dm_ctx* ctx, float* goals) {
     if (!ctx || !goals) return fail("null argument");
     CtxBase* c = ctx->c; DevGuard guard(c->device_id);
     if (!c->goal_size) return fail("RecordGoal needs a goal scene (dm_scene_tables.scene_goal)");
-    return copy_out(c, goals, c->d_goals, sizeof(float) * (size_t)c->N * 3);
+    return copy_out(c, goals, c->d_goals, sizeof(float) * (size_t)c->N * c->goal_size);
 }
 int dm_get_goal_state(dm_ctx* ctx, double* out) { if (!ctx || !out) return fail("null argument"); DevGuard guard(ctx->c->device_id); return ctx->c->get_goal(out); }
 int dm_set_goal_state(dm_ctx* ctx, const double* in) { if (!ctx || !in) return fail("null argument"); DevGuard guard(ctx->c->device_id); return ctx->c->set_goal(in); }
+int dm_goal_size(const dm_ctx* ctx) { return ctx ? ctx->c->goal_size : 0; }
+int dm_get_goal_aux(dm_ctx* ctx, double* out) { if (!ctx || !out) return fail("null argument"); DevGuard guard(ctx->c->device_id); return ctx->c->goal_aux(out, nullptr); }
+int dm_set_goal_aux(dm_ctx* ctx, const double* in) { if (!ctx || !in) return fail("null argument"); DevGuard guard(ctx->c->device_id); return ctx->c->goal_aux(nullptr, in); }
+int dm_set_mode(dm_ctx* ctx, int test_mode) { if (!ctx) return fail("null ctx"); ctx->c->set_mode(test_mode); return 0; }
 int dm_get_clips(dm_ctx* ctx, int32_t* out) { if (!ctx || !out) return fail("null argument"); DevGuard guard(ctx->c->device_id); return ctx->c->get_clips(out); }
 
 int dm_build_offsets_scales(const dm_ctx* ctx, double* s_off, double* s_scale, double* a_off, double* a_scale, double* a_min, double* a_max, int32_t* s_norm_groups) {

@@ -104,8 +104,15 @@ struct ModelDev {
     const int* amp_off;                      // J   offset of joint j's rotation features inside a pose block (j >= 1)
     const int* amp_ee;                       // J   ordinal of link j among the end effectors, -1 if it is none
     int amp_ee_base;                         // offset of the end-effector positions inside a pose block
-    // ---- goal-conditioned AMP task scenes: 1 = target_amp (scenes/SceneTargetAMP.cpp), 2 = heading_amp (SceneHeadingAMP.cpp)
+    // ---- goal-conditioned AMP task scenes: 1 = target_amp (scenes/SceneTargetAMP.cpp), 2 = heading_amp (SceneHeadingAMP.cpp),
+    //      3 = heading_amp_getup (SceneHeadingAMPGetup.cpp), 4 = strike_amp (SceneStrikeAMP.cpp)
     int scene_goal, enable_min_tar_vel, enable_rand_rot_reset;
+    int goal_dim;                            // RecordGoal size: 3 (kinds 1, 2), 4 (kinds 3, 4)
+    int mode_test;                           // cRLScene::eModeTest (dm_set_mode)
+    double getup_time, recover_prob;         // heading_amp_getup: longest get-up clip; recover_episode_prob
+    Real getup_height_root, getup_height_head; int head_id, getup_clip_mask;
+    double tar_far_prob, init_hit_prob, hit_reset_time, target_min[3], target_max[3];     // strike_amp
+    Real tar_near_dist, target_radius, hit_tar_speed, tar_reward_scale; int strike_mask, fail_tar_mask;
     double goal_time_min, goal_time_max;     // target timer range (rand_target_time_*)
     Real max_target_dist, target_succ_dist, tar_fail_dist, tar_speed, pos_reward_scale;
     Real max_heading_turn_rate, sharp_turn_prob, speed_change_prob, tar_speed_min, tar_speed_max, vel_reward_scale;
@@ -119,7 +126,9 @@ struct ModelDev {
     const double* clip_cdf;                  // num_clips  cClipsController::mClipsCDF
 };
 // per-env goal state row (EnvState::goal), doubles: the clocks among them must not round to fp32
-enum { GS_TX = 0, GS_TY, GS_TZ, GS_HEADING, GS_SPEED, GS_TIMER, GS_TIMER_MAX, GS_PCOMX, GS_PCOMY, GS_PCOMZ, GS_PTIME, GS_DRAWS, GS_CLIP, GS_WIDTH = 16 };
+enum { GS_TX = 0, GS_TY, GS_TZ, GS_HEADING, GS_SPEED, GS_TIMER, GS_TIMER_MAX, GS_PCOMX, GS_PCOMY, GS_PCOMZ, GS_PTIME, GS_DRAWS, GS_CLIP,
+       GS_AUX0, GS_AUX1,        // heading_amp_getup: get-up timer | strike_amp: target hit (0 / 1), hit time
+       GS_WIDTH = 16 };
 
 template <typename Real>
 struct EnvState {
@@ -152,7 +161,7 @@ struct StepIO {
     int open_loop;          // ignore `actions`; track the reference clip (stream A1 of SURVEY 8d)
     float* amp_obs;         // N x amp size  RecordAMPObsAgent at the end of the call (imitate_amp scenes only)
     int end_early;          // stop an env's updates at the update after which its episode is over (DM_END_EPISODE_EARLY)
-    float* goals;           // N x 3  RecordGoal at the end of the call (goal scenes only)
+    float* goals;           // N x goal_dim  RecordGoal at the end of the call (goal scenes only)
 };
 
 // Debug taps for component parity tests (device pointers, null when unused)

@@ -69,6 +69,20 @@ typedef struct {
     const int32_t* clip_starts;   /* num_clips + 1 */
     const double* clip_weights;   /* num_clips */
     const int32_t* clip_loops;    /* num_clips */
+    /* ---- scene_goal 3 = `--scene heading_amp_getup` (scenes/SceneHeadingAMPGetup.cpp): heading_amp + a get-up timer -- RecordGoal has
+     * size 4 (+ get-up phase, :123-130), the get-up reward while it runs (:4-38), no contact fall while it runs (:255-264), in test mode
+     * a fall starts it (:244-253), in train mode a failed episode continues as a recovery episode with probability
+     * recover_episode_prob (:109-121, 40-56).  getup_time = duration of the longest get-up clip (CalcGetupTime :266-291);
+     * getup_clip_mask: bit c set = clip c is a get-up motion (--getup_motion_ids).
+     * scene_goal 4 = `--scene strike_amp` (scenes/SceneStrikeAMP.cpp): target_amp with a target point in the air, RecordGoal size 4
+     * (target in the origin frame + hit phase, :414-434), near / far / hit reward (:23-187), success and target-contact termination
+     * (:485-541); strike_mask / fail_tar_mask: bit j = link j (--strike_bodies / --fail_tar_contact_bodies). */
+    int mode_test;                /* 1 = cRLScene::eModeTest at creation; dm_set_mode changes it */
+    double getup_time, getup_height_root, getup_height_head, recover_episode_prob;
+    int head_id, getup_clip_mask;
+    double tar_near_dist, tar_far_prob, target_radius, target_hit_reset_time, init_hit_prob, hit_tar_speed, tar_reward_scale;
+    double target_min[3], target_max[3];
+    int strike_mask, fail_tar_mask;
 } dm_scene_tables;
 
 /* DM_END_EPISODE_EARLY: an env whose episode is over after update u of the call (fall contact, clip end, episode timer) takes no
@@ -130,7 +144,9 @@ int dm_amp_expert(dm_ctx* ctx, int n, const double* times, const double* ground_
 int dm_amp_expert_clips(dm_ctx* ctx, int n, const int32_t* clips, const double* times, const double* ground_h, float* out);
 
 /* ---- goal scenes (dm_scene_tables.scene_goal != 0)
- * RecordGoal for every env (SceneTargetAMP.cpp:195-223 / SceneHeadingAMP.cpp:150-166): goals N x 3 float32 */
+ * RecordGoal for every env (SceneTargetAMP.cpp:195-223 / SceneHeadingAMP.cpp:150-166 / SceneHeadingAMPGetup.cpp:123-130 /
+ * SceneStrikeAMP.cpp:414-434): goals N x dm_goal_size() float32 */
+int dm_goal_size(const dm_ctx* ctx);          /* GetGoalSize: 0 (no goal scene), 3, or 4 (heading_amp_getup, strike_amp) */
 int dm_query_goal(dm_ctx* ctx, float* goals, int flags);
 /* the goals written by the most recent dm_step_batch / dm_query (no launch): what the agent reads next to `states` */
 int dm_last_goals(dm_ctx* ctx, float* goals);
@@ -138,6 +154,14 @@ int dm_last_goals(dm_ctx* ctx, float* goals);
  * target timer max, COM at the last action(3), controller time of the last action, draws consumed so far.  NULL = leave as is. */
 int dm_get_goal_state(dm_ctx* ctx, double* out);
 int dm_set_goal_state(dm_ctx* ctx, const double* in);
+/* the scene-specific part of the goal state, N x 2 doubles: heading_amp_getup {get-up timer time, unused}; strike_amp {target hit
+ * (0 / 1), scene time of the hit (-1 = none)} */
+int dm_get_goal_aux(dm_ctx* ctx, double* out);
+int dm_set_goal_aux(dm_ctx* ctx, const double* in);
+/* cRLScene::SetMode (DeepMimicCore.cpp SetMode -> scene): 0 train, 1 test.  Only the goal scenes read it on the device (get-up on a
+ * fall instead of termination, recovery episodes, strike_amp's test reward); the episode-timer limits of the two modes are the
+ * caller's business (dm_set_time_limits). */
+int dm_set_mode(dm_ctx* ctx, int test_mode);
 /* clip each env's kinematic character was reset to (multi-clip datasets), N int32 */
 int dm_get_clips(dm_ctx* ctx, int32_t* out);
 

@@ -362,7 +362,7 @@ void orc_goal_state(void* h, double* o) {
     o[0] = s->tar_pos.x; o[1] = s->tar_pos.y; o[2] = s->tar_pos.z; o[3] = s->tar_heading; o[4] = s->tar_speed; o[5] = s->tar_timer; o[6] = s->tar_timer_max;
     o[7] = s->prev_action_com.x; o[8] = s->prev_action_com.y; o[9] = s->prev_action_com.z; o[10] = s->prev_action_time; o[11] = (double)s->goal_draws;
     o[12] = (double)s->cur_clip;
-    if (s->cfg.scene_goal == 3) { o[13] = s->getup_timer; o[14] = 0; }
+    if (s->cfg.scene_goal == 3) { o[13] = s->getup_timer; o[14] = -1.0; }
     else { o[13] = s->target_hit ? 1.0 : 0.0; o[14] = s->target_hit_time; }
 }
 int orc_goal_dim(void* h) { return ((Scene*)h)->goal_dim(); }

@@ -445,17 +445,21 @@ def stepwise_live_compare(name, precision, lib_path, steps, n, seed, wave_packin
     return dr, ds, alive, ok
 
 
-def goal_rollout_compare(t, precision, lib_path, steps, n, seed, wave_packing=0, action_sigma=0.15):
+def goal_rollout_compare(t, precision, lib_path, steps, n, seed, wave_packing=0, action_sigma=0.15, test_mode=False):
     """Goal-conditioned task scenes (target_amp / heading_amp; multi-clip datasets, enable_rand_rot_reset): closed-loop rollout
     with seeded random actions THROUGH auto-resets.  The oracle mirrors every device draw: the reset generator's streams 0 (clip
     time), 1 (episode timer), 3 (clip by weight), 4 (yaw) keyed by the episode counter, and the goal generator (stream 2, draw
-    counter kept in the goal row).  Returns dict of worst deviations + counts."""
+    counter kept in the goal row).  heading_amp_getup: recovery episodes (train mode) and falls that start a get-up (test mode) are
+    mirrored too; strike_amp: hits, success / target-contact termination.  Returns dict of worst deviations + counts."""
     from deepmimic_amd import streams
-    env = BatchEnv(t, n, precision=precision, lib_path=lib_path, wave_packing=wave_packing, seed=seed)
+    env = BatchEnv(t, n, precision=precision, lib_path=lib_path, wave_packing=wave_packing, seed=seed, test_mode=test_mode)
     g0 = env.get_goal_state()                      # draws consumed by the reset inside dm_create
     env.reset()
     ep = env.get_state()["flags"][:, 2].astype(np.int64)
     tmin, tmax = float(t.cfg.time_lim_min), float(t.cfg.time_lim_max)
+    if test_mode and t.cfg.time_end_lim_max is not None:
+        tmin = tmax = float(t.cfg.time_end_lim_max)
+    has_aux = t.goal_kind >= 3
 
     def draw(o, e, episode):
         clip = o.draw_clip(streams.reset_rand01(seed, e, episode, 3)) if t.num_clips > 1 else 0
@@ -466,11 +470,12 @@ def goal_rollout_compare(t, precision, lib_path, steps, n, seed, wave_packing=0,
 
     oracles = []
     for e in range(n):
-        o = Oracle(t)
+        o = Oracle(t, mode_test=int(test_mode))
         o.goal_rng(seed, e, int(g0[e][11]))
         o.reset_ex(*[(lambda c, k, m, y: (k, m, c, y))(*draw(o, e, int(ep[e]) - 1))][0])
         oracles.append(o)
-    w = dict(reward=0.0, state=0.0, goal=0.0, goal_state=0.0, resets=0, live=0, flags_ok=True, clips=set(), dist_fail=0, reward_errs=[], goal_errs=[])
+    w = dict(reward=0.0, state=0.0, goal=0.0, goal_state=0.0, resets=0, live=0, flags_ok=True, clips=set(), dist_fail=0, reward_errs=[], goal_errs=[],
+             aux=0.0, recoveries=0, succ=0, fail=0, aux_steps=0)
     gs = env.get_goal_state(); clips = env.get_clips(); q = env.query(); qg = env.query_goal()
     for e, o in enumerate(oracles):
         assert clips[e] == o.lib.orc_num_clips(o.h) * 0 + (draw(o, e, int(ep[e]) - 1)[0]), "clip draw mismatch"
@@ -482,6 +487,7 @@ def goal_rollout_compare(t, precision, lib_path, steps, n, seed, wave_packing=0,
         acts = (action_sigma * rng.normal(size=(n, env.A))).astype(np.float32)
         out = env.step(acts, DT, 20, auto_reset=True)
         gs = env.get_goal_state(); clips = env.get_clips()
+        aux = env.get_goal_aux() if has_aux else None
         for e, o in enumerate(oracles):
             o.set_action(acts[e].astype(np.float64))
             o.control_step(20, DT)
@@ -489,9 +495,14 @@ def goal_rollout_compare(t, precision, lib_path, steps, n, seed, wave_packing=0,
             w["reward"] = max(w["reward"], abs(float(out["reward"][e]) - r)); w["live"] += int(r != 0.0)
             w["reward_errs"].append(abs(float(out["reward"][e]) - r))
             w["flags_ok"] &= int(out["terminate"][e]) == term and bool(out["episode_end"][e]) == end
+            w["succ"] += int(term == 2); w["fail"] += int(term == 1)
             if end:
                 c, kt, mt, yaw = draw(o, e, int(ep[e]))
-                o.reset_ex(kt, mt, c, yaw); ep[e] += 1; w["resets"] += 1
+                if o.maybe_recovery_reset(mt):                      # heading_amp_getup, train mode: the episode goes on as a recovery episode
+                    w["recoveries"] += 1; c = int(clips[e])
+                else:
+                    o.reset_ex(kt, mt, c, yaw)
+                ep[e] += 1; w["resets"] += 1
                 assert clips[e] == c, "clip draw mismatch after reset"
             w["clips"].add(int(clips[e]))
             so = o.record_state()
@@ -499,5 +510,9 @@ def goal_rollout_compare(t, precision, lib_path, steps, n, seed, wave_packing=0,
             w["goal"] = max(w["goal"], np.abs(out["goal"][e] - o.record_goal()).max())
             w["goal_errs"].append(np.abs(out["goal"][e] - o.record_goal()).max())
             w["goal_state"] = max(w["goal_state"], np.abs(gs[e] - o.goal_state()).max())
+            if has_aux:
+                oa = o.goal_state(full=True)[13:15]
+                w["aux"] = max(w["aux"], np.abs(aux[e] - oa).max())
+                w["aux_steps"] += int((t.goal_kind == 3 and out["goal"][e][3] > 0) or (t.goal_kind == 4 and oa[0] != 0))
     w["reward_mean"] = float(np.mean(w.pop("reward_errs"))); w["goal_mean"] = float(np.mean(w.pop("goal_errs")))
     return w

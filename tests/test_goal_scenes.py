@@ -1,5 +1,6 @@
-"""Goal-conditioned AMP task scenes: `--scene target_amp` (scenes/SceneTargetAMP.cpp) and
-`--scene heading_amp` (scenes/SceneHeadingAMP.cpp) with multi-clip datasets (anim/ClipsController.cpp) and
+"""Goal-conditioned AMP task scenes: `--scene target_amp` (scenes/SceneTargetAMP.cpp),
+`--scene heading_amp` (scenes/SceneHeadingAMP.cpp), `--scene heading_amp_getup` (scenes/SceneHeadingAMPGetup.cpp) and
+`--scene strike_amp` (scenes/SceneStrikeAMP.cpp) with multi-clip datasets (anim/ClipsController.cpp) and
 enable_rand_rot_reset (scenes/SceneImitate.cpp:331-349).  Device path (emulator build on CPU, HIP library marked gpu) vs
 the oracle restatement, closed loop with seeded random actions through auto-resets; every random draw is mirrored."""
 import numpy as np
@@ -128,6 +129,113 @@ def test_amp_expert_multi_clip(emu_lib, oracle_built):
         assert np.abs(got[i] - want).max() < 2e-6, (i, np.abs(got[i] - want).max())
 
 
+# ---- heading_amp_getup and strike_amp
+def _getup_tables(recover=None, time_lim=None):
+    t = model.load_asset("amp_heading_getup")
+    if recover is not None:
+        t.cfg.recover_episode_prob = recover
+    if time_lim is not None:
+        t.cfg.time_lim_min = t.cfg.time_lim_max = time_lim
+    return t
+
+
+def _strike_tables(variant):
+    """the shipped strike keys with one knob turned so that random actions reach the branch under test within a few seconds"""
+    t = model.load_asset("amp_strike_punch")
+    t.cfg.time_lim_min = t.cfg.time_lim_max = 4.0
+    if variant == "init_hit":            # episodes that start hit (ResetTargetHit) -> success 2 s after the drawn hit time
+        t.cfg.init_hit_prob = 0.6
+    elif variant == "hit":               # a large target sphere around a near target, any speed counts: CheckTargetHit fires
+        t.cfg.target_radius = 1.0; t.cfg.hit_tar_speed = 0.0; t.cfg.fail_tar_contact_bodies = []; t.cfg.tar_far_prob = 0.0
+    elif variant == "contact_fail":      # the same sphere with the forbidden bodies of the arg file: CheckTarContactFail
+        t.cfg.target_radius = 1.0; t.cfg.tar_far_prob = 0.0
+    elif variant == "test_succ":         # test mode: success pays the time left on the episode clock
+        t.cfg.target_radius = 1.0; t.cfg.hit_tar_speed = 0.0; t.cfg.fail_tar_contact_bodies = []; t.cfg.tar_far_prob = 0.0
+        t.cfg.time_end_lim_max = 4.0; t.cfg.target_hit_reset_time = 0.5
+    return t
+
+
+def test_new_scene_assets():
+    g, k = model.load_asset("amp_heading_getup"), model.load_asset("amp_strike_punch")
+    assert (g.goal_kind, g.goal_dim, k.goal_kind, k.goal_dim) == (3, 4, 4, 4)
+    # args/train_amp_heading_getup_humanoid3d_locomotion_getup_args.txt: getup_motion_ids 2 3, head_id 2, recover_episode_prob 0.2
+    assert g.getup_clip_mask == 0b1100 and g.cfg.head_id == 2 and g.cfg.recover_episode_prob == 0.2 and g.cfg.getup_height_head == 1.3
+    assert abs(g.getup_time - max(g.clip_duration(2), g.clip_duration(3))) < 1e-12 and g.getup_time > 3.0
+    # args/train_amp_strike_humanoid3d_walk_punch_args.txt
+    assert k.cfg.strike_bodies == [8] and k.cfg.fail_tar_contact_bodies == [0, 1, 2] and k.cfg.init_hit_prob == 0.1
+    assert tuple(k.cfg.target_min) == (-0.5, 1.2, 0.6) and k.cfg.tar_near_dist == 1.4 and k.cfg.tar_fail_dist == 15.0
+
+
+def test_getup_closed_form(oracle_built):
+    """cSceneHeadingAMPGetup: an episode reset into a get-up clip is `getting up` from the clip time on (SyncGetupTimer), pays
+    CalcRewardGetup = 0.2 clamp(root_h / 0.5) + 0.8 clamp(head_h / 1.3), reports phase 1 - t / getup_time, and cannot fall."""
+    t = _getup_tables()
+    o = Oracle(t); o.goal_rng(3, 0, 0); o.reset_ex(0.5, np.inf, 2, 0.0)              # clip 2 = getup_facedown: starts lying on the ground
+    o.set_action(np.zeros(o.A)); o.control_step(20, pc.DT, end_early=False)
+    gs = o.goal_state(full=True); p, _ = o.sim_state(); links = o.links()
+    tm = 0.5 + 20 * pc.DT
+    assert abs(gs[13] - tm) < 1e-12 and abs(o.record_goal()[3] - (1 - tm / t.getup_time)) < 1e-12
+    want = 0.2 * np.clip(p[1] / 0.5, 0, 1) + 0.8 * np.clip(links[2, 1] / 1.3, 0, 1)
+    assert abs(o.calc_reward() - want) < 1e-12 and 0 < want < 0.5
+    assert any(c and f for c, f in zip(o.contacts(), t.fall_mask())) and o.check_terminate() == 0     # a fall body touches the ground, yet no fall while getting up
+    o2 = Oracle(t); o2.goal_rng(3, 0, 0); o2.reset_ex(0.2, np.inf, 1, 0.0)           # clip 1 = walk: not getting up, phase 0
+    assert o2.record_goal()[3] == 0.0 and o2.goal_state(full=True)[13] == t.getup_time
+
+
+@pytest.mark.parametrize("pack", [1, 2])
+def test_getup_recovery_episodes_emulator(emu_lib, pack):
+    """train mode, recover_episode_prob 0.6, large action noise: falls end episodes, some of them continue as recovery episodes
+    (timers + controller reset only, get-up timer restarted) -- device and oracle decide and continue identically"""
+    w = pc.goal_rollout_compare(_getup_tables(recover=0.6, time_lim=4.0), 64, emu_lib, steps=45, n=2, seed=7, wave_packing=pack, action_sigma=0.6)
+    print(pack, w)
+    assert w["flags_ok"] and w["recoveries"] >= 1 and w["aux"] < 1e-9 and w["aux_steps"] >= 20
+    assert w["reward_mean"] < 1e-4 and w["goal_state"] < 5e-3
+
+
+def test_getup_test_mode_emulator(emu_lib):
+    """test mode: a fall starts a get-up (UpdateTestGetup) instead of ending the episode"""
+    w = pc.goal_rollout_compare(_getup_tables(), 64, emu_lib, steps=30, n=2, seed=5, wave_packing=2, test_mode=True)
+    print(w)
+    assert w["flags_ok"] and w["fail"] == 0 and w["resets"] == 0 and w["aux_steps"] >= 10 and w["aux"] < 1e-9 and w["reward_mean"] < 1e-4
+
+
+@pytest.mark.parametrize("variant,pack,test_mode", [("init_hit", 1, False), ("hit", 2, False), ("contact_fail", 1, False), ("test_succ", 2, True)])
+def test_strike_emulator(emu_lib, variant, pack, test_mode):
+    w = pc.goal_rollout_compare(_strike_tables(variant), 64, emu_lib, steps=40, n=2, seed=3, wave_packing=pack, action_sigma=0.1, test_mode=test_mode)
+    print(variant, w)
+    assert w["flags_ok"] and w["aux"] < 1e-9 and w["reward_mean"] < 1e-4 and w["goal_state"] < 5e-3
+    if variant in ("init_hit", "test_succ"):
+        assert w["succ"] >= 1                      # eTerminateSucc reaches the caller
+    if variant == "hit":
+        assert w["aux_steps"] >= 20                # CheckTargetHit fired and the hit reward (1.0) was paid
+    if variant == "contact_fail":
+        assert w["fail"] >= 5
+
+
+def test_facade_new_goal_scenes(emu_lib, monkeypatch):
+    """GetGoalSize / BuildGoal* / RecordGoal / SetMode of the two scenes through the cDeepMimicCore facade"""
+    import os, sys
+    compat = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "deepmimic_amd", "compat")
+    if compat not in sys.path:
+        sys.path.insert(0, compat)
+    from DeepMimicCore import DeepMimicCore
+    monkeypatch.setenv("DM_HIP_LIB", emu_lib); monkeypatch.setenv("DM_PRECISION", "64")
+    for name, nm, groups in (("amp_heading_getup", "Heading AMP Getup", [0, 0, 0, -1]), ("amp_strike_punch", "Strike AMP", [-1] * 4)):
+        core = DeepMimicCore.cDeepMimicCore(False)
+        core.SeedRand(2); core.LoadTables(model.load_asset(name), 10); core.Init()
+        assert core.GetName() == nm and core.GetGoalSize(0) == 4 and core.BuildGoalNormGroups(0) == groups
+        if name == "amp_heading_getup":
+            assert core.BuildGoalOffset(0) == [0.0, 0.0, 0.0, -0.5] and core.BuildGoalScale(0) == [1.0, 1.0, 1.0, 2.0]
+        core.SetMode(core.eModeTest)
+        g = core.RecordGoal(0)
+        assert len(g) == 4 and np.isfinite(g).all() and 0.0 <= g[3] <= 1.0
+        core.SetAction(0, [0.0] * core.GetActionSize(0))
+        for _ in range(20):
+            core.Update(1.0 / 600)
+        assert np.isfinite(core.CalcReward(0)) and len(core.RecordGoal(0)) == 4
+        core.Shutdown()
+
+
 # ---- the HIP kernels
 @pytest.mark.gpu
 @pytest.mark.parametrize("name,prec,pack", [("amp_heading_zombie", 64, 1), ("amp_target_zombie", 64, 2), ("amp_heading_zombie", 32, 2),
@@ -171,3 +279,54 @@ def test_goal_scenes_4096_auto_reset(hip_lib):
             assert (out["goal"][:, 2] >= t.cfg.tar_speed_min - 1e-6).all() and (out["goal"][:, 2] <= t.cfg.tar_speed_max + 1e-6).all()
         else:
             assert (out["goal"][:, 2] <= t.cfg.tar_fail_dist + 1e-3).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prec,pack", [(64, 1), (32, 2)])
+def test_getup_scene_gpu(hip_lib, prec, pack):
+    """heading_amp_getup on the HIP kernels: recovery episodes in train mode, get-up on a fall in test mode"""
+    w = pc.goal_rollout_compare(_getup_tables(recover=0.6, time_lim=4.0), prec, hip_lib, steps=150, n=8, seed=7, wave_packing=pack, action_sigma=0.6)
+    print("train", prec, pack, w)
+    assert (w["flags_ok"] or prec == 32) and w["recoveries"] >= 2 and w["aux_steps"] >= 100
+    assert w["reward_mean"] < (1e-4 if prec == 64 else 2e-3) and (w["aux"] < 1e-9 or prec == 32)
+    w = pc.goal_rollout_compare(_getup_tables(), prec, hip_lib, steps=100, n=8, seed=5, wave_packing=pack, test_mode=True)
+    print("test", prec, pack, w)
+    assert (w["flags_ok"] or prec == 32) and w["aux_steps"] >= 50 and w["reward_mean"] < (1e-4 if prec == 64 else 2e-3)
+    if prec == 64:
+        assert w["fail"] == 0 and w["resets"] == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant,prec,pack,test_mode", [("init_hit", 64, 2, False), ("hit", 32, 2, False), ("contact_fail", 32, 1, False), ("test_succ", 64, 1, True),
+                                                         ("plain", 32, 2, False)])
+def test_strike_scene_gpu(hip_lib, variant, prec, pack, test_mode):
+    w = pc.goal_rollout_compare(_strike_tables(variant), prec, hip_lib, steps=120, n=8, seed=3, wave_packing=pack, action_sigma=0.1, test_mode=test_mode)
+    print(variant, prec, pack, w)
+    assert w["flags_ok"] or prec == 32
+    assert w["reward_mean"] < (1e-4 if prec == 64 else 2e-3) and (w["aux"] < 1e-6 or prec == 32)
+    if variant in ("init_hit", "test_succ"):
+        assert w["succ"] >= 2
+    if variant == "hit":
+        assert w["aux_steps"] >= 100
+    if variant == "contact_fail":
+        assert w["fail"] >= 10
+
+
+@pytest.mark.gpu
+def test_new_goal_scenes_4096(hip_lib):
+    """4096 envs of heading_amp_getup and strike_amp, random actions, auto-reset: finite outputs, rewards in range, goal vectors well formed"""
+    for name in ("amp_heading_getup", "amp_strike_punch"):
+        t = model.load_asset(name)
+        env = BatchEnv(t, 4096, seed=8)
+        env.reset()
+        rng = np.random.default_rng(0)
+        ends = 0
+        for k in range(30):
+            out = env.step((0.2 * rng.normal(size=(4096, env.A))).astype(np.float32), pc.DT, 20, auto_reset=True, amp=True)
+            assert out["goal"].shape == (4096, 4) and np.isfinite(out["state"]).all() and np.isfinite(out["goal"]).all() and np.isfinite(out["amp_obs"]).all()
+            assert (out["reward"] >= 0).all() and (out["reward"] <= 1 + 1e-6).all()
+            assert (out["goal"][:, 3] >= 0).all() and (out["goal"][:, 3] <= 1).all()
+            ends += int(out["episode_end"].sum())
+        assert ends > 0 and out["reward"].mean() > 0.01
+        if t.goal_kind == 3:
+            assert np.abs(np.linalg.norm(out["goal"][:, :2], axis=1) - 1).max() < 1e-4 and (out["goal"][:, 3] > 0).mean() > 0.2   # half the clips are get-ups

@@ -24,6 +24,12 @@ SCENES = {
     "amp_target_zombie": ("args/train_amp_target_humanoid3d_zombie_args.txt", None),
     # a 4-clip dataset (two looping, two non-looping clips) under the heading task: exercises clip selection by weight
     "amp_heading_clips4": ("args/train_amp_heading_getup_humanoid3d_locomotion_getup_args.txt", ["--scene", "heading_amp"]),
+    # heading_amp_getup as shipped (run, walk + the two get-up clips; getup_motion_ids 2 3)
+    "amp_heading_getup": ("args/train_amp_heading_getup_humanoid3d_locomotion_getup_args.txt", None),
+    # strike_amp: the shipped dataset (humanoid3d_clips_walk_punch.txt) names sie / amass clips that are not in the repository; the scene
+    # keys are the arg file's, the dataset is a stand-in made of the two shipped clips of the same kind (tools/datasets/)
+    "amp_strike_punch": ("args/train_amp_strike_humanoid3d_walk_punch_args.txt",
+                         ["--motion_file", os.path.join(os.path.dirname(os.path.abspath(__file__)), "datasets", "humanoid3d_clips_walk_punch_local.txt")]),
 }
 
 def main():

@@ -475,7 +475,8 @@ def goal_rollout_compare(t, precision, lib_path, steps, n, seed, wave_packing=0,
         o.reset_ex(*[(lambda c, k, m, y: (k, m, c, y))(*draw(o, e, int(ep[e]) - 1))][0])
         oracles.append(o)
     w = dict(reward=0.0, state=0.0, goal=0.0, goal_state=0.0, resets=0, live=0, flags_ok=True, clips=set(), dist_fail=0, reward_errs=[], goal_errs=[],
-             aux=0.0, recoveries=0, succ=0, fail=0, aux_steps=0)
+             aux=0.0, recoveries=0, succ=0, fail=0, aux_steps=0, desynced=0, scored=0)
+    dead = np.zeros(n, bool)       # fp32 only: an env whose episode ended at a different update than the oracle's is not scored from there on
     gs = env.get_goal_state(); clips = env.get_clips(); q = env.query(); qg = env.query_goal()
     for e, o in enumerate(oracles):
         assert clips[e] == o.lib.orc_num_clips(o.h) * 0 + (draw(o, e, int(ep[e]) - 1)[0]), "clip draw mismatch"
@@ -489,9 +490,15 @@ def goal_rollout_compare(t, precision, lib_path, steps, n, seed, wave_packing=0,
         gs = env.get_goal_state(); clips = env.get_clips()
         aux = env.get_goal_aux() if has_aux else None
         for e, o in enumerate(oracles):
+            if dead[e]:
+                continue
             o.set_action(acts[e].astype(np.float64))
             o.control_step(20, DT)
             r = o.calc_reward(); term, end = o.check_terminate(), o.is_episode_end()
+            if precision == 32 and not (int(out["terminate"][e]) == term and bool(out["episode_end"][e]) == end):
+                dead[e] = True; w["desynced"] += 1; w["flags_ok"] = False
+                continue
+            w["scored"] += 1
             w["reward"] = max(w["reward"], abs(float(out["reward"][e]) - r)); w["live"] += int(r != 0.0)
             w["reward_errs"].append(abs(float(out["reward"][e]) - r))
             w["flags_ok"] &= int(out["terminate"][e]) == term and bool(out["episode_end"][e]) == end

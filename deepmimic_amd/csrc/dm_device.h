@@ -923,6 +923,17 @@ struct EnvSim {
                 wave_gram64<NP2>(y2, g);
 #pragma unroll
                 for (int r = 0; r < 64; ++r) arow.set(r, (l == r) ? (Real)0 : g[r] * inv_adiag);
+            } else if (C::GRAM64 && ND <= 34) {
+                // narrow row file, Gram on the matrix core: rows 32..63 go to the overflow block ([row][lane]; all of them, the sweep reads
+                // rows < R only)
+                Real g[64];
+#pragma unroll
+                for (int p = 0; p < NP2; ++p) DM_OPAQUE_V(y2[p]);
+                wave_gram64<NP2>(y2, g);
+#pragma unroll
+                for (int r = 0; r < RREG; ++r) arow.set(r, (l == r) ? (Real)0 : g[r] * inv_adiag);
+#pragma unroll
+                for (int r = RREG; r < kMaxRows; ++r) aovf[(r - RREG) * kWave + l] = (l == r) ? (Real)0 : g[r] * inv_adiag;
             } else {
                 for (int r = 0; r < R; ++r) {
                     R2 a2 = {(Real)0, (Real)0};

@@ -115,7 +115,7 @@ struct DuoSim {
 #if DM_DUO_WIDE_FALLBACK
     typedef ClsBipedWide FallbackCls;
 #else
-    typedef ClsBiped FallbackCls;
+    typedef ClsBipedFb FallbackCls;
 #endif
     typedef EnvSim<Real, FallbackCls, TAPS, kWave> Single;
     typedef Lds<Real, FallbackCls> WideRec;

@@ -949,7 +949,8 @@ struct EnvSim {
             const int nrm_lane = is_fric ? NL + ((l - RN) >> 1) : 0;
             Real lo = 0, hi = is_fric ? (Real)0 : (Real)1e30;
             int Rv = R, RNv = RN, lv = l;
-            Real pre[3] = {(Real)0, (Real)0, (Real)0};
+            constexpr int PFD = C::PFD;             // rows of look-ahead for the overflow block (a ring of PFD + 1 registers)
+            Real pre[PFD + 1] = {};
             for (int it = 0; it < m.solver_iters; ++it) {
                 DM_OPAQUE_S(Rv); DM_OPAQUE_S(RNv); DM_OPAQUE_V(lv);
                 // statically unrolled over the row id (register-file index and lane select are immediates); rows >= R are
@@ -961,12 +962,12 @@ struct EnvSim {
                         for (int i = 0; i < 4; ++i) {
                             const int r = blk * 4 + i;
                             if (__builtin_expect(r == RNv, 0)) { const Real ln = wave_shfl(lam, nrm_lane); if (is_fric) { hi = m.friction * ln; lo = -hi; } }
-                            // rows >= RREG live in the HBM/L2 overflow block: row r + 2 is requested two rows ahead (3 rotating
+                            // rows >= RREG live in the HBM/L2 overflow block: row r + PFD is requested PFD rows ahead (a ring of
                             // registers), so the load latency sits beside the sweep's dependent chain instead of on it
-                            if (RREG < kMaxRows && r + 2 >= RREG && r + 2 < kMaxRows) { const Real* ap = aovf + lv; DM_OPAQUE_V(ap); pre[(r + 2) % 3] = ap[(r + 2 - RREG) * kWave]; }
+                            if (RREG < kMaxRows && r + PFD >= RREG && r + PFD < kMaxRows) { const Real* ap = aovf + lv; DM_OPAQUE_V(ap); pre[(r + PFD) % (PFD + 1)] = ap[(r + PFD - RREG) * kWave]; }
                             const Real nl = dm_med3(lo, t, hi);
                             const Real delta = lane_bcast(nl - lam, r);
-                            const Real ar = (r < RREG) ? arow.get(r < RREG ? r : 0) : pre[r % 3];
+                            const Real ar = (r < RREG) ? arow.get(r < RREG ? r : 0) : pre[r % (PFD + 1)];
                             t -= ar * delta;
                             if (lv == r) lam = nl;
                         }

@@ -528,12 +528,13 @@ struct CtxT : CtxBase {
     }
     int probe(int what, double dt) override {
         if (alloc_dbg() != 0) return -1;
-        if (what == 3) {   // one profiled control step (open-loop, 20 updates): per-phase cycle counts -> tap "prof"
+        if (what == 3 || what == 4) {   // one profiled control step (20 updates; 3: open-loop, 4: the actions of the last dm_step_batch): per-phase cycle counts -> tap "prof"
             rt_memset(d_prof, 0, sizeof(long long) * N * 16, stream);
             DebugTaps<Real> d2; memset(&d2, 0, sizeof(d2)); d2.prof = d_prof;
             StepIO<Real> io; memset(&io, 0, sizeof(io));
             io.states = d_states; io.rewards = d_rewards; io.terminate = d_term; io.valid = d_valid; io.episode_end = d_end;
-            io.n_updates = 20; io.dt = dt; io.auto_reset = 1; io.emit = 1; io.open_loop = 1; io.end_early = 1;
+            io.n_updates = 20; io.dt = dt; io.auto_reset = 1; io.emit = 1; io.open_loop = (what == 3) ? 1 : 0; io.end_early = 1;
+            if (what == 4) io.actions = d_actions;
             if (duo && cls == 0 && hm.D == ClsBiped::ND && (N % 2) == 0) RT_LAUNCH((k_env_step_duo<Real, true>), N / 2, stream, md, st, io, d2);
             else if (cls == 0) RT_LAUNCH((k_env_step<Real, ClsBiped, true>), N, stream, md, st, io, d2); else RT_LAUNCH((k_env_step<Real, ClsLarge, true>), N, stream, md, st, io, d2);
             return 0;

@@ -26,16 +26,17 @@ constexpr int kMaxContacts = 20;   // contact slots per character (ground + self
 struct ClsBiped {      // humanoid3d: 15 links, 34 dof, 43 pose dims, <= 64 ground-contact candidates, no attach rotations
     static constexpr int NJ = 15, ND = 34, NP = 43, NCAP = 64, RREG = 32, NPAIRCAP = 128, LPAD = 4; static constexpr bool ROT = false;   // RREG: rows of A kept in VGPRs
     static constexpr bool GRAM64 = false;   // 64-row Gram matrix by the readlane loop (128-VGPR budget of the one-per-wave kernel)
+    static constexpr int PFD = 2;           // look-ahead of the sweep into the overflow block of A, rows
 };
 // the same character class with all 64 rows of A in VGPRs: the instantiation the two-per-wave kernel falls back to for a pair with a
 // heavily contacted character (256-VGPR budget there; identical LDS record layout)
 struct ClsBipedWide : ClsBiped { static constexpr int RREG = 64; };
 // the fallback class of the two-per-wave kernel by default: the narrow row file (rows 32..63 of A in the HBM / L2 overflow block), but
 // the Gram matrix of a character with more than 32 rows still comes off the matrix core (64 accumulators live for the Gram only)
-struct ClsBipedFb : ClsBiped { static constexpr bool GRAM64 = true; };
+struct ClsBipedFb : ClsBiped { static constexpr bool GRAM64 = true; };   // (a look-ahead of 6 rows instead of 2 measured no gain)
 struct ClsLarge {      // dog3d and anything up to 23 links / 64 dof / 83 pose dims / 128 candidates, attach rotations allowed
     static constexpr int NJ = 23, ND = 64, NP = 83, NCAP = 128, RREG = 32, NPAIRCAP = 256, LPAD = 2; static constexpr bool ROT = true;
-    static constexpr bool GRAM64 = false;
+    static constexpr bool GRAM64 = false; static constexpr int PFD = 2;
 };
 
 // link_info word: parent+1 [0:4] | jtype [5:7] | depth [8:11] | pose_off [12:18] | dof_off [19:25] | arot_ident 26 | brot_ident 27 | is_ee 28 | fall 29

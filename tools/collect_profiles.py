@@ -31,7 +31,7 @@ if os.path.exists(os.path.join(src, "stats_policy", "stats_kernel_stats.csv")):
         csv.writer(f).writerows(rows[:12])
 # 2. bench lines and reports
 for name in ("bench.json", "bench_spinkick.json", "bench_dog.json", "bench_pack1.json", "bench_facade.json", "policy_bench.json", "policy_bench_16384.json",
-             "parity_report.json", "tail_probe.txt", "bench_record_exchange_1rank.json", "bench_record_exchange_cabi_1rank.json"):
+             "parity_report.json", "tail_probe.txt", "tail_probe_closed_loop.txt", "bench_record_exchange_1rank.json", "bench_record_exchange_cabi_1rank.json"):
     if os.path.exists(os.path.join(src, name)) and os.path.getsize(os.path.join(src, name)) > 0:
         shutil.copy(os.path.join(src, name), os.path.join(dst, out + "_" + name))
 SCENES = [("humanoid3d_walk", ""), ("humanoid3d_spinkick", "_humanoid3d_spinkick"), ("dog3d_pace", "_dog3d_pace")]

@@ -25,6 +25,7 @@ python tools/gpu_policy_bench.py > $OUT/policy_bench.json 2> $OUT/policy_bench.e
 ENVS=16384 python tools/gpu_policy_bench.py > $OUT/policy_bench_16384.json 2>> $OUT/policy_bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_policy -o stats -- python tools/gpu_policy_bench.py > $OUT/stats_policy.log 2>&1
 python tools/gpu_tail_probe.py > $OUT/tail_probe.txt 2>&1
+python tools/gpu_tail_probe_policy.py > $OUT/tail_probe_closed_loop.txt 2>&1
 python tools/gpu_parity_report.py --steps 300 --envs 8 > $OUT/parity_report.json 2> $OUT/parity_report.err
 torchrun --standalone --nnodes=1 --nproc-per-node 1 --local-addr 127.0.0.1 bench.py --gpus 1 --steps 200 --warmup 30 --force-gather --no-cpu-baseline > $OUT/bench_record_exchange_1rank.json 2> $OUT/bench_record_exchange.err
 python bench.py --steps 200 --warmup 30 --force-gather --gather cabi --no-cpu-baseline > $OUT/bench_record_exchange_cabi_1rank.json 2>> $OUT/bench_record_exchange.err

@@ -77,6 +77,9 @@ template <int NP2, typename R2, typename Real> static inline void wave_gram32(co
 template <int NP2, typename R2, typename Real> static inline void wave_gram64(const R2* y2, Real (&out)[64]) {
     for (int i = 0; i < 64; ++i) { Real a = 0; for (int p = 0; p < NP2; ++p) a += y2[p][0] * lane_bcast(y2[p][0], i) + y2[p][1] * lane_bcast(y2[p][1], i); out[i] = a; }
 }
+template <int NP2, int H, typename R2, typename Real> static inline void wave_gram64_half(const R2* y2, Real (&out)[32]) {
+    for (int i = 0; i < 32; ++i) { Real a = 0; for (int p = 0; p < NP2; ++p) a += y2[p][0] * lane_bcast(y2[p][0], 32 * H + i) + y2[p][1] * lane_bcast(y2[p][1], 32 * H + i); out[i] = a; }
+}
 template <typename Real> struct VecT;
 template <> struct VecT<float> { typedef float v2 __attribute__((vector_size(8))); typedef float v4 __attribute__((vector_size(16))); };
 template <> struct VecT<double> { typedef double v2 __attribute__((vector_size(16))); typedef double v4 __attribute__((vector_size(32))); };
@@ -207,6 +210,34 @@ template <int NP2> __device__ __forceinline__ void wave_gram64(const VecT<float>
         out[8 * (v / 4) + 4 + (v % 4)] = __uint_as_float(s0[1]);
         out[32 + 8 * (v / 4) + (v % 4)] = __uint_as_float(s1[0]);
         out[32 + 8 * (v / 4) + 4 + (v % 4)] = __uint_as_float(s1[1]);
+    }
+}
+// Half of the above: H = 0 gives every lane entries 0..31 of its row, H = 1 entries 32..63 (two MFMA chains and 32 accumulators live
+// at a time instead of four and 64: the fallback of the two-per-wave kernel runs inside its register budget)
+template <int NP2, int H> __device__ __forceinline__ void wave_gram64_half(const VecT<float>::v2* y2, float (&out)[32]) {
+    typedef float f16v __attribute__((ext_vector_type(16)));
+    const f16v z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    f16v b0 = z, b1 = z;
+#pragma unroll
+    for (int p = 0; p < NP2; ++p) {
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(y2[p][0]), __float_as_uint(y2[p][1]), false, false);
+        const float op0 = __uint_as_float(sw[0]), op1 = __uint_as_float(sw[1]);
+        b0 = __builtin_amdgcn_mfma_f32_32x32x2f32(H ? op1 : op0, op0, b0, 0, 0, 0);
+        b1 = __builtin_amdgcn_mfma_f32_32x32x2f32(H ? op1 : op0, op1, b1, 0, 0, 0);
+    }
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+        const auto s0 = __builtin_amdgcn_permlane32_swap(__float_as_uint(b0[v]), __float_as_uint(b1[v]), false, false);
+        out[8 * (v / 4) + (v % 4)] = __uint_as_float(s0[0]);
+        out[8 * (v / 4) + 4 + (v % 4)] = __uint_as_float(s0[1]);
+    }
+}
+template <int NP2, int H> __device__ __forceinline__ void wave_gram64_half(const VecT<double>::v2* y2, double (&out)[32]) {
+#pragma unroll 1
+    for (int i = 0; i < 32; ++i) {
+        double a = 0;
+        for (int p = 0; p < NP2; ++p) a += y2[p][0] * lane_bcast(y2[p][0], 32 * H + i) + y2[p][1] * lane_bcast(y2[p][1], 32 * H + i);
+        out[i] = a;
     }
 }
 template <int NP2> __device__ __forceinline__ void wave_gram64(const VecT<double>::v2* y2, double (&out)[64]) {
@@ -926,14 +957,23 @@ struct EnvSim {
             } else if (C::GRAM64 && ND <= 34) {
                 // narrow row file, Gram on the matrix core: rows 32..63 go to the overflow block ([row][lane]; all of them, the sweep reads
                 // rows < R only)
-                Real g[64];
+                static_assert(RREG == 32 || !C::GRAM64, "two halves of 32 entries");
 #pragma unroll
                 for (int p = 0; p < NP2; ++p) DM_OPAQUE_V(y2[p]);
-                wave_gram64<NP2>(y2, g);
+                {
+                    Real g[32];
+                    wave_gram64_half<NP2, 1>(y2, g);            // entries 32..63 first: they leave for the overflow block at once
 #pragma unroll
-                for (int r = 0; r < RREG; ++r) arow.set(r, (l == r) ? (Real)0 : g[r] * inv_adiag);
+                    for (int r = 0; r < 32; ++r) aovf[r * kWave + l] = (l == r + 32) ? (Real)0 : g[r] * inv_adiag;
+                }
 #pragma unroll
-                for (int r = RREG; r < kMaxRows; ++r) aovf[(r - RREG) * kWave + l] = (l == r) ? (Real)0 : g[r] * inv_adiag;
+                for (int p = 0; p < NP2; ++p) DM_OPAQUE_V(y2[p]);
+                {
+                    Real g[32];
+                    wave_gram64_half<NP2, 0>(y2, g);
+#pragma unroll
+                    for (int r = 0; r < 32; ++r) arow.set(r, (l == r) ? (Real)0 : g[r] * inv_adiag);
+                }
             } else {
                 for (int r = 0; r < R; ++r) {
                     R2 a2 = {(Real)0, (Real)0};

@@ -3,9 +3,13 @@
 // C entry points (ctypes) over orc::Scene.  Only tests/, __graft_entry__.smoke() and
 // bench.py's cpu_baseline leg may load the library built from this file; the product
 // (deepmimic_amd/) never does.  Parity status: DeepMimic-side functions are restated from the
-// reference sources cited in orc_*.h and pinned by the closed-form known-answer tests in
-// tests/test_oracle_kat.py; the rigid-body step replaces un-vendored Bullet 2.88 and is
-// "parity unpinned" against real Bullet (no reference tests or golden vectors exist).
+// reference sources cited in orc_*.h and PINNED to the reference's own code -- oracle/_ref compiles the unmodified
+// MathUtil / SpAlg / KinTree / Motion / KinCharacter / RBDUtil / RBDModel / CtCtrlUtil / DynamicTimeWarper sources against a
+// minimal Eigen-API shim (oracle/build_ref.sh) and tests/test_oracle_vs_ref.py holds this restatement against it on 1 000 random
+// states per character (H and C bit-identical, SPD torque 1e-11); reference-generated golden vectors: tests/golden/ref_vectors.npz.
+// Closed-form known-answer tests: tests/test_oracle_kat.py.  The rigid-body step replaces un-vendored Bullet 2.88 and stays
+// "parity unpinned" against real Bullet (no reference tests or golden vectors exist for it); the goal-scene draws are specified on
+// the device's counter-based generator, not on the reference's std::default_random_engine.
 #include "orc_scene.h"
 #include <chrono>
 #include <cstdint>

@@ -259,7 +259,7 @@ class cDeepMimicCore(object):
         # cSceneImitate::GetName (scenes/SceneImitate.cpp:207-210), cSceneImitateAMP::GetName (SceneImitateAMP.cpp:208-211)
         scene = self._tables.cfg.scene if self._tables is not None else "imitate"
         return {"imitate_amp": "Imitate AMP", "target_amp": "Target AMP", "heading_amp": "Heading AMP", "heading_amp_getup": "Heading AMP Getup",
-                "strike_amp": "Strike AMP"}.get(scene, "Imitate")
+                "strike_amp": "Strike AMP", "dribble_amp": "Dribble AMP"}.get(scene, "Imitate")
 
     def _is_amp(self):
         return self._tables is not None and self._tables.cfg.scene in _model.AMP_SCENES

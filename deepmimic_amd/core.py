@@ -11,7 +11,7 @@ from typing import Optional, Sequence
 
 import numpy as np
 
-from .model import AMP_SCENES, SceneTables
+from .model import AMP_SCENES, BALL_ANG_DAMPING, BALL_FRICTION, BALL_LIN_DAMPING, BALL_MASS, SceneTables
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIB = os.path.join(_HERE, "csrc", "libdm_hip.so")
@@ -46,6 +46,8 @@ class _SceneTables(C.Structure):
         ("tar_near_dist", C.c_double), ("tar_far_prob", C.c_double), ("target_radius", C.c_double), ("target_hit_reset_time", C.c_double),
         ("init_hit_prob", C.c_double), ("hit_tar_speed", C.c_double), ("tar_reward_scale", C.c_double),
         ("target_min", C.c_double * 3), ("target_max", C.c_double * 3), ("strike_mask", C.c_int), ("fail_tar_mask", C.c_int),
+        ("rand_tar_obj_time_min", C.c_double), ("rand_tar_obj_time_max", C.c_double), ("min_tar_obj_dist", C.c_double), ("max_tar_obj_dist", C.c_double),
+        ("ball_radius", C.c_double), ("ball_mass", C.c_double), ("ball_friction", C.c_double), ("ball_lin_damping", C.c_double), ("ball_ang_damping", C.c_double),
     ]
 
 
@@ -146,6 +148,10 @@ class BatchEnv:
             setattr(st, k, float(getattr(c, k)))
         st.target_min = (C.c_double * 3)(*[float(x) for x in c.target_min]); st.target_max = (C.c_double * 3)(*[float(x) for x in c.target_max])
         st.strike_mask = sum(1 << int(b) for b in (c.strike_bodies or [])); st.fail_tar_mask = sum(1 << int(b) for b in (c.fail_tar_contact_bodies or []))
+        # dribble_amp: the ball (constants of cSceneDribbleAMP::BuildTarObjs; friction combined with the 0.9 of links and ground)
+        for k in ("rand_tar_obj_time_min", "rand_tar_obj_time_max", "min_tar_obj_dist", "max_tar_obj_dist", "ball_radius"):
+            setattr(st, k, float(getattr(c, k)))
+        st.ball_mass = BALL_MASS; st.ball_friction = BALL_FRICTION * 0.9; st.ball_lin_damping = BALL_LIN_DAMPING; st.ball_ang_damping = BALL_ANG_DAMPING
         info = _CreateInfo(int(num_envs), int(device_id), int(seed) & (2 ** 64 - 1), int(precision), int(max_contacts), int(env_id_offset), int(wave_packing))
         self.h = C.c_void_p()
         self._chk(self.lib.dm_create(C.byref(info), C.byref(st), C.byref(self.h)))
@@ -238,6 +244,16 @@ class BatchEnv:
     def set_goal_aux(self, aux):
         aux = np.ascontiguousarray(aux, dtype=np.float64).reshape(self.N, 2)
         self._chk(self.lib.dm_set_goal_aux(self.h, _dp(aux)))
+
+    def get_obj_state(self):
+        """dribble_amp: the ball of every env, N x 13 = pos(3), rot wxyz(4), vel(3), ang vel(3)"""
+        out = np.zeros((self.N, 13))
+        self._chk(self.lib.dm_get_obj_state(self.h, _dp(out)))
+        return out
+
+    def set_obj_state(self, obj):
+        obj = np.ascontiguousarray(obj, dtype=np.float64).reshape(self.N, 13)
+        self._chk(self.lib.dm_set_obj_state(self.h, _dp(obj)))
 
     def last_goals(self):
         g = np.zeros((self.N, max(self.G, 1)), np.float32)

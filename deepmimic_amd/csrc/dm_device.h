@@ -292,6 +292,7 @@ struct Lds {
     int flg[8];                            // need_new_action, contact_mask, episode_count, valid, nrows, ncontacts, parked, over
     int fall_mask;                         // links whose ground contact is a fall (bit j), from link_info at load
     int getup;                             // heading_amp_getup: the get-up timer of the env is running (mirror of the goal row, goal_sync_flags)
+    Real obj[C::OBJ ? OB_WIDTH : 1];       // OBJ classes: the free rigid body (dribble_amp's ball): pos, rot wxyz, vel, ang vel
 };
 
 // What the end-of-call outputs need of a character whose episode ended mid-call (two characters per wavefront, early episode end)
@@ -315,6 +316,7 @@ struct EnvSim {
     typedef Lds<Real, C> L;
     static constexpr int NJ = C::NJ, ND = C::ND, NP = C::NP, NCAP = C::NCAP, CPL = C::NCAP / kWave, RREG = C::RREG;
     static constexpr int NP2 = ND / 2;                 // register pairs per dof vector (ND is even for every class)
+    static constexpr int NP2X = NP2 + (C::OBJ ? 3 : 0); // + the free body's 3 linear + 3 angular velocities (rows of Y = M^-1/2 J^T)
     typedef V3<Real> v3; typedef Q4<Real> q4; typedef M3<Real> m3;
     typedef typename VecT<Real>::v2 R2; typedef typename VecT<Real>::v4 R4;
     const ModelDev<Real>& m; L& s; int l;
@@ -363,6 +365,7 @@ struct EnvSim {
         if (l < 6) s.clk[l] = st.clock[(size_t)e * 6 + l];
         if (l < 4) s.flg[l] = st.flag[(size_t)e * 4 + l];
         if (l == 0) s.flg[FLG_PARKED] = 0;
+        if (C::OBJ && st.obj && l < OB_WIDTH) s.obj[C::OBJ ? l : 0] = st.obj[(size_t)e * OB_WIDTH + l];
         sync();
     }
     // `act`: lanes of a character that does not take part still pass the barriers (two characters per wavefront)
@@ -375,6 +378,7 @@ struct EnvSim {
         if (l < 8) st.kin[(size_t)e * 8 + l] = s.kin[l];
         if (l < 6) st.clock[(size_t)e * 6 + l] = s.clk[l];
         if (l < 4) st.flag[(size_t)e * 4 + l] = s.flg[l];
+        if (C::OBJ && st.obj && l < OB_WIDTH) st.obj[(size_t)e * OB_WIDTH + l] = s.obj[C::OBJ ? l : 0];
     }
     // Is the episode over after this update?  The reference's driver asks after EVERY update and ends the episode there, not at
     // the next action boundary (DeepMimic.py:62-80 update_world: world.update(timestep); is_episode_end -> end_episode, reset,
@@ -771,7 +775,8 @@ struct EnvSim {
     }
     // constraint row `r` of this lane from the contact slots: bias b, chain masks (dofs moving the point with link a, minus
     // those moving it with link b: common ancestors cancel exactly), X = (x - p0) x d and d
-    DM_DEV void contact_row(int r, int NL, int nc, Real h, Real& brow, uint32_t& m_lo, uint32_t& m_hi, uint32_t& g_lo, uint32_t& g_hi, v3& xd, v3& dd) const {
+    // link id 254 = the free body (OBJ classes), 255 = the ground.  ball_sg: +1 the point moves with the ball as body a, -1 as body b, 0 none
+    DM_DEV void contact_row(int r, int NL, int nc, Real h, Real& brow, uint32_t& m_lo, uint32_t& m_hi, uint32_t& g_lo, uint32_t& g_hi, v3& xd, v3& dd, int* ball_sg = nullptr, v3* cx = nullptr) const {
         int slot, kindr;
         if (r < NL + nc) { slot = r - NL; kindr = 0; } else { int fi = r - NL - nc; slot = fi >> 1; kindr = 1 + (fi & 1); }
         const Real* ct = s.ct[slot];
@@ -781,8 +786,10 @@ struct EnvSim {
         v3 t1, t2; plane_space(n, t1, t2);
         dd = (kindr == 0) ? n : ((kindr == 1) ? t1 : t2);
         xd = cross(ld3(ct) - ld3(s.p[0]), dd);
-        uint32_t a_lo = s.mdl.chain_lo[la], a_hi = s.mdl.chain_hi[la], b_lo = 0, b_hi = 0;
-        if (lb != 255) { b_lo = s.mdl.chain_lo[lb]; b_hi = s.mdl.chain_hi[lb]; }
+        uint32_t a_lo = 0, a_hi = 0, b_lo = 0, b_hi = 0;
+        if (!C::OBJ || la != 254) { a_lo = s.mdl.chain_lo[la < NJ ? la : 0]; a_hi = s.mdl.chain_hi[la < NJ ? la : 0]; }
+        if (lb != 255 && (!C::OBJ || lb != 254)) { b_lo = s.mdl.chain_lo[lb < NJ ? lb : 0]; b_hi = s.mdl.chain_hi[lb < NJ ? lb : 0]; }
+        if (C::OBJ && ball_sg) { *ball_sg = (la == 254) ? 1 : ((lb == 254) ? -1 : 0); *cx = ld3(ct); }
         m_lo = a_lo ^ b_lo; m_hi = a_hi ^ b_hi; g_lo = b_lo & m_lo; g_hi = b_hi & m_hi;
         if (kindr == 0) { const Real dc = ct[6]; brow = (dc > 0) ? -dc / h : -m.erp * dc / h; }
     }
@@ -814,6 +821,14 @@ struct EnvSim {
         sync();
         if (TAPS && dbg.vstar && l < D) dbg.vstar[(size_t)e * D + l] = vstar;
         mark(7);
+        // OBJ classes: the free body's unconstrained velocity (btRigidBody::applyDamping, then the gravity impulse), every lane
+        v3 bpos = zero3(), bvs = zero3(), bws = zero3();
+        if (C::OBJ) {
+            const Real* ob = s.obj;
+            bpos = ld3(ob + (C::OBJ ? OB_PX : 0));
+            bvs = (Real)exp((double)h * m.ball_ln_lin) * ld3(ob + (C::OBJ ? OB_VX : 0)) + h * mk3(m.gravity[0], m.gravity[1], m.gravity[2]);
+            bws = (Real)exp((double)h * m.ball_ln_ang) * ld3(ob + (C::OBJ ? OB_WX : 0));
+        }
         // ---- collision detection: lane = candidate point (CPL candidates per lane when NC > 64)
         bool active[CPL]; Real dist[CPL]; v3 cxp[CPL]; uint64_t amask[CPL];
         int nact = 0;
@@ -873,6 +888,34 @@ struct EnvSim {
                 }
             }
         }
+        if (C::OBJ) {
+            // the free body takes the slots that are left: lane 0 tests it against the ground, lane 1 + j against link j (capsule models, as
+            // link against link); slot order = lane order.  Link ids in the slot: 254 = the body, 255 = the ground.
+            const Real rb = m.ball_radius, thr_b = m.ball_thresh;
+            v3 x = zero3(), n = mk3((Real)0, (Real)1, (Real)0); Real dsc = 0; bool act = false; int la = 254, lb = 255;
+            if (l == 0) { dsc = bpos.y - rb; act = dsc < thr_b; x = bpos; x.y -= rb; }
+            else if (l <= m.J) {
+                const int j = l - 1;
+                const Real* cj = s.mdl.cap[j];
+                const v3 uj = ldm3(Rbp(j)) * ld3(cj), p1 = ld3(s.com[j]) + uj, d1 = (Real)-2 * uj, r = p1 - bpos;
+                const Real a = dot(d1, d1);
+                const Real sp = (a > (Real)1e-12) ? dm_med3((Real)0, -dot(d1, r) * dm_rcp(a), (Real)1) : (Real)0;       // closest point of the segment to the centre
+                const v3 ca = p1 + sp * d1, dl = ca - bpos;
+                const Real d2n = dot(dl, dl), rj = cj[3];
+                const Real idn = (d2n > (Real)1e-18) ? dm_rsqrt(d2n) : (Real)0, d = d2n * idn;
+                dsc = d - rj - rb;
+                n = (d > (Real)1e-9) ? idn * dl : mk3((Real)0, (Real)1, (Real)0);
+                x = (Real)0.5 * ((ca - rj * n) + (bpos + rb * n));
+                act = (s.mdl.thresh[j] > (Real)0) && dsc < dm_min(s.mdl.thresh[j], thr_b);
+                la = j; lb = 254;
+            }
+            const uint64_t mk = wave_ballot(act);
+            if (mk != 0) {
+                const int slot = nc + dm_popc64(mk & lt);
+                if (act && slot < m.max_contacts) store_contact(slot, x, n, dsc, la, lb);
+                nc = dm_min(m.max_contacts, nc + dm_popc64(mk));
+            }
+        }
         const int NL = m.NL;
         const int R = NL + 3 * nc;
         if (l == 0) { s.flg[FLG_NROWS] = R; s.flg[FLG_NCONT] = nc; }
@@ -884,6 +927,7 @@ struct EnvSim {
         // self contact), 0 elsewhere.  A limit row (+-e_dof) is the same formula with d = 0 and X := +-a_dof on the chain {dof}.
         Real b = 0;
         uint32_t ch_lo = 0, ch_hi = 0, ng_lo = 0, ng_hi = 0; v3 xd = zero3(), dd = zero3();
+        int ball_sg = 0; v3 ball_cx = zero3();
         if (l < R) {
             if (l < NL) {
                 int j = s.mdl.lim_joint[l]; int lj = s.mdl.link_info[j]; int off = DM_LI_POFF(lj);
@@ -894,10 +938,14 @@ struct EnvSim {
                 b = (pen > 0) ? -pen / h : -m.erp * pen / h;
                 xd = sgn * ld3(&s.dofrec[limdof][0]);
                 if (limdof < 32) ch_lo = 1u << limdof; else ch_hi = 1u << (limdof - 32);
-            } else contact_row(l, NL, nc, h, b, ch_lo, ch_hi, ng_lo, ng_hi, xd, dd);
+            } else contact_row(l, NL, nc, h, b, ch_lo, ch_hi, ng_lo, ng_hi, xd, dd, &ball_sg, &ball_cx);
         }
+        // friction coefficient of this row's contact; the free body's Jacobian columns: d . v_b + ((x - p_b) x d) . w_b, signed by its side
+        Real mu_row = m.friction;
+        v3 jbl = zero3(), jba = zero3();
+        if (C::OBJ && ball_sg != 0) { mu_row = m.ball_friction; jbl = (Real)ball_sg * dd; jba = (Real)ball_sg * cross(ball_cx - bpos, dd); }
         // y := L^-1 J_l^T in registers (static indices; dof records and L rows are wave-uniform LDS broadcasts)
-        R2 y2[NP2]; Real cvec = 0;
+        R2 y2[NP2X]; Real cvec = 0;
 #pragma unroll
         for (int k = 0; k < ND; ++k) {
             Real yk = 0;
@@ -918,6 +966,13 @@ struct EnvSim {
             }
             y2[k >> 1][k & 1] = yk;
         }
+        if (C::OBJ) {
+            // the free body's block of the mass matrix is diagonal: its rows of Y = M^-1/2 J^T are a scaling; J v* gains its share
+            cvec += dot(jbl, bvs) + dot(jba, bws);
+            const Real sm = dm_sqrt(m.ball_inv_mass), si = dm_sqrt(m.ball_inv_inertia);
+            y2[C::OBJ ? NP2 : 0][0] = sm * jbl.x; y2[C::OBJ ? NP2 : 0][1] = sm * jbl.y; y2[C::OBJ ? NP2 + 1 : 0][0] = sm * jbl.z;
+            y2[C::OBJ ? NP2 + 1 : 0][1] = si * jba.x; y2[C::OBJ ? NP2 + 2 : 0][0] = si * jba.y; y2[C::OBJ ? NP2 + 2 : 0][1] = si * jba.z;
+        }
         mark(9);
         // projected Gauss-Seidel in impulse space; u = J v* + A lambda is kept per lane.
         // Sweep order: limits, normals, frictions; a friction row is boxed by mu * (current normal impulse of its contact).
@@ -932,7 +987,7 @@ struct EnvSim {
             Real adiag;
             { R2 a2 = {(Real)0, (Real)0};
 #pragma unroll
-              for (int p = 0; p < NP2; ++p) a2 += y2[p] * y2[p];
+              for (int p = 0; p < NP2X; ++p) a2 += y2[p] * y2[p];
               adiag = a2[0] + a2[1]; }
             // rows are pre-scaled by 1/A_ll and the diagonal is zeroed: the sweep keeps t_l = lambda_l + (b_l - u_l)/A_ll, the
             // pre-clamp target of row l, which a visit to row l itself leaves unchanged -- one uniform FMA per row, no add
@@ -942,16 +997,16 @@ struct EnvSim {
                 // (y is made opaque to the optimizer first: without it clang's middle end does not terminate on the select
                 // chains feeding the MFMAs)
 #pragma unroll
-                for (int p = 0; p < NP2; ++p) DM_OPAQUE_V(y2[p]);
-                wave_gram32<NP2>(y2, g);
+                for (int p = 0; p < NP2X; ++p) DM_OPAQUE_V(y2[p]);
+                wave_gram32<NP2X>(y2, g);
 #pragma unroll
                 for (int r = 0; r < 32; ++r) arow.set(r, (l == r) ? (Real)0 : g[r] * inv_adiag);
             } else if (RREG >= kMaxRows && ND <= 34) {
                 // the wide biped class (fallback of the two-per-wave kernel): all 64 rows on the matrix core, straight into registers
                 Real g[64];
 #pragma unroll
-                for (int p = 0; p < NP2; ++p) DM_OPAQUE_V(y2[p]);
-                wave_gram64<NP2>(y2, g);
+                for (int p = 0; p < NP2X; ++p) DM_OPAQUE_V(y2[p]);
+                wave_gram64<NP2X>(y2, g);
 #pragma unroll
                 for (int r = 0; r < 64; ++r) arow.set(r, (l == r) ? (Real)0 : g[r] * inv_adiag);
             } else if (C::GRAM64 && ND <= 34) {
@@ -959,18 +1014,18 @@ struct EnvSim {
                 // rows < R only)
                 static_assert(RREG == 32 || !C::GRAM64, "two halves of 32 entries");
 #pragma unroll
-                for (int p = 0; p < NP2; ++p) DM_OPAQUE_V(y2[p]);
+                for (int p = 0; p < NP2X; ++p) DM_OPAQUE_V(y2[p]);
                 {
                     Real g[32];
-                    wave_gram64_half<NP2, 1>(y2, g);            // entries 32..63 first: they leave for the overflow block at once
+                    wave_gram64_half<NP2X, 1>(y2, g);            // entries 32..63 first: they leave for the overflow block at once
 #pragma unroll
                     for (int r = 0; r < 32; ++r) aovf[r * kWave + l] = (l == r + 32) ? (Real)0 : g[r] * inv_adiag;
                 }
 #pragma unroll
-                for (int p = 0; p < NP2; ++p) DM_OPAQUE_V(y2[p]);
+                for (int p = 0; p < NP2X; ++p) DM_OPAQUE_V(y2[p]);
                 {
                     Real g[32];
-                    wave_gram64_half<NP2, 0>(y2, g);
+                    wave_gram64_half<NP2X, 0>(y2, g);
 #pragma unroll
                     for (int r = 0; r < 32; ++r) arow.set(r, (l == r) ? (Real)0 : g[r] * inv_adiag);
                 }
@@ -978,7 +1033,7 @@ struct EnvSim {
                 for (int r = 0; r < R; ++r) {
                     R2 a2 = {(Real)0, (Real)0};
 #pragma unroll
-                    for (int p = 0; p < NP2; ++p) { const R2 bb = {lane_bcast(y2[p][0], r), lane_bcast(y2[p][1], r)}; a2 += y2[p] * bb; }
+                    for (int p = 0; p < NP2X; ++p) { const R2 bb = {lane_bcast(y2[p][0], r), lane_bcast(y2[p][1], r)}; a2 += y2[p] * bb; }
                     const Real v = (l == r) ? (Real)0 : (a2[0] + a2[1]) * inv_adiag;
                     if (RREG >= kMaxRows || r < RREG) arow.set(r, v);
                     else aovf[(r - RREG) * kWave + l] = v;
@@ -1001,7 +1056,7 @@ struct EnvSim {
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
                             const int r = blk * 4 + i;
-                            if (__builtin_expect(r == RNv, 0)) { const Real ln = wave_shfl(lam, nrm_lane); if (is_fric) { hi = m.friction * ln; lo = -hi; } }
+                            if (__builtin_expect(r == RNv, 0)) { const Real ln = wave_shfl(lam, nrm_lane); if (is_fric) { hi = mu_row * ln; lo = -hi; } }
                             // rows >= RREG live in the HBM/L2 overflow block: row r + PFD is requested PFD rows ahead (a ring of
                             // registers), so the load latency sits beside the sweep's dependent chain instead of on it
                             if (RREG < kMaxRows && r + PFD >= RREG && r + PFD < kMaxRows) { const Real* ap = aovf + lv; DM_OPAQUE_V(ap); pre[(r + PFD) % (PFD + 1)] = ap[(r + PFD - RREG) * kWave]; }
@@ -1038,6 +1093,22 @@ struct EnvSim {
         Real dinv = (l < ND) ? Lx(l < ND ? l : 0, l < ND ? l : 0) : (Real)1;
         z = back_substitute(z, dinv);
         if (l < D) s.vel[vidx] = clamp_vel(vstar + z, l);
+        if (C::OBJ) {
+            // delta v of the free body = M^-1/2 (Y_b lambda): six wave sums; then semi-implicit Euler with the exponential map
+            Real dv[6];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                dv[k] = wave_sum(y2[C::OBJ ? NP2 + (k >> 1) : 0][k & 1] * lam);
+            }
+            if (l == 0) {
+                const Real sm = dm_sqrt(m.ball_inv_mass), si = dm_sqrt(m.ball_inv_inertia);
+                const v3 bv = bvs + sm * mk3(dv[0], dv[1], dv[2]), bw = bws + si * mk3(dv[3], dv[4], dv[5]);
+                Real* ob = s.obj;
+                st3(ob + (C::OBJ ? OB_VX : 0), bv); st3(ob + (C::OBJ ? OB_WX : 0), bw);
+                st3(ob + (C::OBJ ? OB_PX : 0), bpos + h * bv);
+                stq(ob + (C::OBJ ? OB_QW : 0), qnormalize(qmul(quat_exp(h * bw), ldq(ob + (C::OBJ ? OB_QW : 0)))));
+            }
+        }
         sync();
         integrate(h);
         sync();
@@ -1367,6 +1438,19 @@ struct EnvSim {
                 float* ov = out + base + 1 + 9 * J + 6 * l;
                 ov[0] = (float)v.x; ov[1] = (float)v.y; ov[2] = (float)v.z; ov[3] = (float)w.x; ov[4] = (float)w.y; ov[5] = (float)w.z;
             }
+            if (C::OBJ && m.scene_goal == 5 && l == 0) {
+                // cSceneDribbleAMP::RecordTaskState (SceneDribbleAMP.cpp:554-590): the ball in the origin frame -- position, normal and
+                // tangent of its rotation, linear and angular velocity
+                const Real* ob = s.obj;
+                const v3 bp = ld3(ob + (C::OBJ ? OB_PX : 0));
+                const v3 pc = O0 * mk3(bp.x - rpos.x, bp.y, bp.z - rpos.z);
+                const m3 Rq = O0 * quat_to_rot(ldq(ob + (C::OBJ ? OB_QW : 0)));
+                const v3 nrm = col(Rq, 1), tan = col(Rq, 0), bv = O0 * ld3(ob + (C::OBJ ? OB_VX : 0)), bw = O0 * ld3(ob + (C::OBJ ? OB_WX : 0));
+                float* o = out + base + 1 + 15 * J;
+                o[0] = (float)pc.x; o[1] = (float)pc.y; o[2] = (float)pc.z; o[3] = (float)nrm.x; o[4] = (float)nrm.y; o[5] = (float)nrm.z;
+                o[6] = (float)tan.x; o[7] = (float)tan.y; o[8] = (float)tan.z; o[9] = (float)bv.x; o[10] = (float)bv.y; o[11] = (float)bv.z;
+                o[12] = (float)bw.x; o[13] = (float)bw.y; o[14] = (float)bw.z;
+            }
         }
         sync();
     }
@@ -1469,7 +1553,40 @@ struct EnvSim {
         const double u1 = 1.0 - goal_u01(g, e), u2 = goal_u01(g, e);
         return mean + stdev * sqrt(-2.0 * log(u1)) * cos(6.283185307179586 * u2);
     }
-    DM_DEV bool target_like() const { return m.scene_goal == 1 || m.scene_goal == 4; }
+    DM_DEV bool target_like() const { return m.scene_goal == 1 || m.scene_goal == 4 || m.scene_goal == 5; }
+    // ---- dribble_amp: the ball as target object (SceneDribbleAMP.cpp:422-440, 493-508), lane 0
+    DM_DEV void obj_timer_reset(double* g, int e) const { g[GS_OTIMER] = 0; g[GS_OTIMER_MAX] = goal_uniform(g, e, m.obj_time_min, m.obj_time_max); }
+    DM_DEV void reset_tar_objs(double* g, int e) {
+        const double r = goal_uniform(g, e, m.min_tar_obj_dist, m.max_tar_obj_dist), theta = goal_uniform(g, e, -3.141592653589793, 3.141592653589793);
+        const double px = (double)s.pose[0] + r * cos(theta), pz = (double)s.pose[2] + r * sin(theta);
+        const double ax = goal_uniform(g, e, -1, 1), ay = goal_uniform(g, e, -1, 1), az = goal_uniform(g, e, -1, 1);   // SetTarObjPos: on the ground, random orientation, at rest
+        const double an = sqrt(ax * ax + ay * ay + az * az), th = goal_uniform(g, e, -3.141592653589793, 3.141592653589793);
+        Real* ob = s.obj;
+        const Real sh = dm_sin((Real)0.5 * (Real)th), ch = dm_cos((Real)0.5 * (Real)th);
+        ob[C::OBJ ? OB_PX : 0] = (Real)px; ob[C::OBJ ? OB_PX + 1 : 0] = m.ball_radius; ob[C::OBJ ? OB_PX + 2 : 0] = (Real)pz;
+        ob[C::OBJ ? OB_QW : 0] = ch; ob[C::OBJ ? OB_QW + 1 : 0] = sh * (Real)(ax / an); ob[C::OBJ ? OB_QW + 2 : 0] = sh * (Real)(ay / an); ob[C::OBJ ? OB_QW + 3 : 0] = sh * (Real)(az / an);
+        for (int k = 0; k < 6; ++k) ob[C::OBJ ? OB_VX + k : 0] = 0;
+        g[GS_PBX] = (double)ob[C::OBJ ? OB_PX : 0]; g[GS_PBY] = (double)ob[C::OBJ ? OB_PX + 1 : 0]; g[GS_PBZ] = (double)ob[C::OBJ ? OB_PX + 2 : 0];      // ResetAgentTarObjRecord
+    }
+    // cSceneDribbleAMP::Reset (:160-167) runs these BEFORE the scene reset: the ball lands around the root of the previous episode's last state
+    DM_DEV void obj_reset(const EnvState<Real>& st, int e) {
+        if (C::OBJ && m.scene_goal == 5) {
+            if (l == 0) { double* g = st.goal + (size_t)e * GS_WIDTH; obj_timer_reset(g, e); reset_tar_objs(g, e); }
+            sync();
+        }
+    }
+    DM_DEV v3 ball_p() const { return ld3(s.obj + (C::OBJ ? OB_PX : 0)); }
+    DM_DEV bool dribble_dist_fail(const double* g) const {               // CheckTarObjDistFail / CheckCharObjDistFail (:351-379), part of HasFallen (:343-349)
+        const v3 bp = ball_p();
+        const Real dx = (Real)g[GS_TX] - bp.x, dz = (Real)g[GS_TZ] - bp.z, t1 = 2 * m.max_target_dist;
+        const Real ex = bp.x - s.pose[0], ez = bp.z - s.pose[2], t2 = 2 * (Real)m.max_tar_obj_dist;
+        return dx * dx + dz * dz > t1 * t1 || ex * ex + ez * ez > t2 * t2;
+    }
+    DM_DEV bool dribble_succ(const double* g) const {                    // CheckTargetSucc (:454-464)
+        const v3 bp = ball_p();
+        const Real dx = (Real)g[GS_TX] - bp.x, dz = (Real)g[GS_TZ] - bp.z;
+        return dx * dx + dz * dz < m.target_succ_dist * m.target_succ_dist;
+    }
     DM_DEV bool heading_like() const { return m.scene_goal == 2 || m.scene_goal == 3; }
     // cSceneStrikeAMP::SetTargetHit (:249-258): the hit time is the scene clock (cScene::GetTime) of the first hit
     DM_DEV void set_target_hit(double* g, bool hit) const { if (g[GS_AUX0] == 0.0 && hit) g[GS_AUX1] = s.clk[CLK_TIMER]; g[GS_AUX0] = hit ? 1.0 : 0.0; }
@@ -1482,6 +1599,12 @@ struct EnvSim {
             const double dist = far ? goal_uniform(g, e, m.target_min[2], (double)m.max_target_dist) : goal_uniform(g, e, m.target_min[2], m.target_max[2]);
             g[GS_TX] = dist * cos(theta) + (double)s.pose[0]; g[GS_TY] = hgt; g[GS_TZ] = dist * -sin(theta) + (double)s.pose[2];
             set_target_hit(g, false);
+            return;
+        }
+        if (C::OBJ && m.scene_goal == 5) {   // cSceneDribbleAMP::SampleRandTargetPos (:510-524): around the ball
+            const double r = goal_uniform(g, e, (double)m.ball_radius, (double)m.max_target_dist), theta = goal_uniform(g, e, -3.141592653589793, 3.141592653589793);
+            const v3 bp = ball_p();
+            g[GS_TX] = (double)bp.x + r * cos(theta); g[GS_TY] = 0; g[GS_TZ] = (double)bp.z + r * sin(theta);
             return;
         }
         const double dist = goal_uniform(g, e, 0.0, (double)m.max_target_dist), theta = goal_uniform(g, e, 0.0, 6.283185307179586);
@@ -1563,6 +1686,9 @@ struct EnvSim {
     // an action boundary: mPrevActionTime = mTime (already advanced by this update), mPrevActionCOM = CalcCOM() (state before it)
     DM_DEV void goal_latch(const EnvState<Real>& st, int e, double dt, bool act = true) {
         if (m.scene_goal == 3 && act && l == 0) { double* g = st.goal + (size_t)e * GS_WIDTH; g[GS_AUX0] += dt; s.getup = !(g[GS_AUX0] >= m.getup_time) ? 1 : 0; }
+        if (C::OBJ && m.scene_goal == 5 && act && l == 0 && s.flg[FLG_NEED_ACTION]) {      // cSceneDribbleAMP::NewActionUpdate (:337-341)
+            double* g = st.goal + (size_t)e * GS_WIDTH; const v3 bp = ball_p(); g[GS_PBX] = (double)bp.x; g[GS_PBY] = (double)bp.y; g[GS_PBZ] = (double)bp.z;
+        }
         if (s.flg[FLG_NEED_ACTION]) {          // wave-uniform for one character per wave; per half otherwise (kinematics is lane-local + barriers)
             kinematics(s.pose, s.vel, zero3());
             const v3 c = com_of_links();
@@ -1600,6 +1726,10 @@ struct EnvSim {
         if (m.scene_goal == 4) kinematics(s.pose, s.vel, zero3());             // link positions / velocities of the state after this update
         if (act && l == 0) {
             double* g = st.goal + (size_t)e * GS_WIDTH;
+            if (C::OBJ && m.scene_goal == 5) {                                 // cSceneDribbleAMP::UpdateObjs (:310-319), inside the scene update
+                g[GS_OTIMER] += dt;
+                if (g[GS_OTIMER] >= g[GS_OTIMER_MAX]) { reset_tar_objs(g, e); obj_timer_reset(g, e); }
+            }
             g[GS_TIMER] += dt;
             const bool end = g[GS_TIMER] >= g[GS_TIMER_MAX];
             if (end && m.scene_goal != 4) goal_reset_target_pos(g, e);         // EnableRandTargetPos(); cSceneStrikeAMP::CheckTargetReset is false (:385-388)
@@ -1618,6 +1748,7 @@ struct EnvSim {
             if (m.scene_goal == 3 && m.mode_test && has_fallen_contact() && !s.getup) { g[GS_AUX0] = 0; s.getup = 1; }     // BeginGetup
             bool over = episode_over_now() || goal_dist_fail(g);
             if (m.scene_goal == 4) over = over || strike_contact_fail(g) || strike_succ(g);
+            if (C::OBJ && m.scene_goal == 5) over = over || (m.enable_fall_end && dribble_dist_fail(g)) || dribble_succ(g);
             s.flg[FLG_OVER] = over ? 1 : 0;
         }
         sync();
@@ -1636,7 +1767,14 @@ struct EnvSim {
             const bool dist_fail = target_like() && dist_sq > m.tar_fail_dist * m.tar_fail_dist;      // CheckTarDistFail (:306-317); heading: false
             if (io.goals) {
                 float* o = io.goals + (size_t)e * m.goal_dim;
-                if (m.scene_goal == 1) {       // cSceneTargetAMP::RecordGoal (:195-223)
+                if (C::OBJ && m.scene_goal == 5) {   // cSceneDribbleAMP::RecordGoal (:276-302): ball -> target in the origin frame
+                    const v3 bp = ball_p();
+                    v3 rb = tar - bp; rb.y = 0;
+                    const Real d = norm(rb);
+                    v3 r = mk3((Real)1, (Real)0, (Real)0);
+                    if (d > (Real)0.0001) r = ((Real)1 / d) * (rot_y(-heading) * rb);
+                    o[0] = (float)r.x; o[1] = (float)r.z; o[2] = (float)d;
+                } else if (m.scene_goal == 1) {       // cSceneTargetAMP::RecordGoal (:195-223)
                     const Real d = dm_sqrt(dist_sq);
                     v3 r = mk3((Real)1, (Real)0, (Real)0);
                     if (d > (Real)0.0001) r = ((Real)1 / d) * (rot_y(-heading) * rel);
@@ -1655,11 +1793,16 @@ struct EnvSim {
                 }
             }
             if (write_flags) {
-                const bool fallen = has_fallen(nullptr);
+                bool fallen = has_fallen(nullptr);
+                if (C::OBJ && m.scene_goal == 5) fallen = fallen || dribble_dist_fail(g);      // cSceneDribbleAMP::HasFallen (:343-349)
                 const Real step_dur = (Real)(s.clk[CLK_CTRL] - g[GS_PTIME]);
                 const v3 dcom = com - mk3((Real)g[GS_PCOMX], (Real)g[GS_PCOMY], (Real)g[GS_PCOMZ]);
                 int term = TERM_NULL;          // what the goal scene adds to CheckTerminate when nothing else terminated
                 if (dist_fail) term = TERM_FAIL;                                 // cSceneTargetAMP::CheckTerminate (:319-345)
+                else if (C::OBJ && m.scene_goal == 5) {                          // the fall test of cRLSceneSimChar::CheckTerminate sees cSceneDribbleAMP::HasFallen
+                    if (m.enable_fall_end && dribble_dist_fail(g)) term = TERM_FAIL;
+                    else if (dribble_succ(g)) term = TERM_SUCC;                  // cSceneDribbleAMP::CheckTerminateTarget (:466-475)
+                }
                 else if (m.scene_goal == 4) {                                    // cSceneStrikeAMP::CheckTerminateTarget (:522-541)
                     if (strike_contact_fail(g)) term = TERM_FAIL;
                     else if (strike_succ(g)) term = TERM_SUCC;
@@ -1680,6 +1823,25 @@ struct EnvSim {
                             if (!(avg_vel < 0)) { if (m.enable_min_tar_vel) vel_err = dm_max(vel_err, (Real)0); vel_reward = dm_exp(-((Real)4 / (tar_speed * tar_speed)) * vel_err * vel_err); }
                         }
                         r = (Real)0.6 * pos_reward + (Real)0.4 * vel_reward;
+                    }
+                } else if (C::OBJ && m.scene_goal == 5) {  // cSceneDribbleAMP::CalcReward (:6-122)
+                    const bool ended = s.sc[6] != (Real)0 || term != TERM_NULL;
+                    const bool succ = !(m.enable_fall_end && fallen) && term == TERM_SUCC;
+                    if (m.mode_test) { if (ended && succ) r = (Real)(s.clk[CLK_TIMER_MAX] - s.clk[CLK_TIMER]); }
+                    else if (!fallen) {
+                        const v3 bp = ball_p(), pac = mk3((Real)g[GS_PCOMX], (Real)g[GS_PCOMY], (Real)g[GS_PCOMZ]), pbp = mk3((Real)g[GS_PBX], (Real)g[GS_PBY], (Real)g[GS_PBZ]);
+                        v3 com_delta = com - pac, cbd = bp - pac; com_delta.y = 0; cbd.y = 0;
+                        const Real com_ball_dist = dot(cbd, cbd);
+                        const v3 cb_dir = ((Real)1 / dm_sqrt(com_ball_dist)) * cbd;           // Eigen normalized(): no guard in the reference either
+                        Real e0 = dm_min((Real)0, dot(cb_dir, com_delta) / step_dur - tar_speed); e0 *= e0;
+                        v3 ball_delta = bp - pbp, btd = tar - pbp; ball_delta.y = 0; btd.y = 0;
+                        const v3 bt_dir = ((Real)1 / norm(btd)) * btd;
+                        Real e2 = dm_min((Real)0, dot(bt_dir, ball_delta) / step_dur - tar_speed); e2 *= e2;
+                        const v3 tb = tar - bp;
+                        const Real cur_bt = dot(tb, tb);
+                        Real r0 = dm_exp(-(Real)1.5 * e0), r1 = dm_exp(-(Real)0.5 * com_ball_dist), r2 = dm_exp(-e2), r3 = dm_exp(-(Real)0.5 * dm_sqrt(cur_bt));
+                        if (cur_bt < m.target_succ_dist * m.target_succ_dist && com_ball_dist < (Real)4) r0 = r1 = r2 = r3 = 1;
+                        r = (Real)0.1 * r0 + (Real)0.1 * r1 + (Real)0.3 * r2 + (Real)0.5 * r3;
                     }
                 } else if (m.scene_goal == 4) {  // cSceneStrikeAMP::CalcReward (:9-187)
                     const bool ended = s.sc[6] != (Real)0 || term != TERM_NULL;
@@ -1811,6 +1973,7 @@ DM_DEV void reset_goal_env(EnvSim<Real, C, TAPS, LW>& sim, const ModelDev<Real>&
     const ModelDev<Real> mc = sim.model_of_clip(clip);
     const double kt = kin_time ? *kin_time : mc.duration * dm_rand01(m.seed, gid, ep, 0);
     const Real yaw = (m.enable_rand_rot_reset && !kin_time) ? (Real)(-3.141592653589793 + 6.283185307179586 * dm_rand01(m.seed, gid, ep, 4)) : (Real)0;
+    sim.obj_reset(st, e);                      // dribble_amp: the ball first, around the OLD root (cSceneDribbleAMP::Reset)
     EnvSim<Real, C, TAPS, LW> rs(mc, lds, sim.l);
     rs.li = sim.li;
     rs.reset_env(kt, max_time, yaw);
@@ -1826,6 +1989,7 @@ DM_DEV void reset_goal_env(EnvSim<Real, C, TAPS, LW>& sim, const ModelDev<Real>&
 template <typename Real, typename C> struct StepWaves { static constexpr int value = 1; };
 template <> struct StepWaves<float, ClsBiped> { static constexpr int value = 4; };
 template <> struct StepWaves<float, ClsLarge> { static constexpr int value = 2; };
+template <> struct StepWaves<float, ClsBipedObj> { static constexpr int value = 2; };
 #ifdef DM_EMU
 #define DM_WAVES_PER_EU(n)
 #else

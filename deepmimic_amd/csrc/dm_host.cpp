@@ -172,6 +172,7 @@ static int build_host_model(const dm_scene_tables& t, int max_contacts, HostMode
     for (int j = 0; j < J; ++j) hm.diffw[j] /= wsum;
     hm.P = poff; hm.D = doff; hm.A = aoff; hm.NL = (int)hm.lim_joint.size();
     hm.S = (t.enable_phase_input ? 1 : 0) + (J * 9 + 1) + J * 6;
+    if (t.scene_goal == 5) hm.S += 15;      // cSceneDribbleAMP::GetTaskStateSize (SceneDribbleAMP.cpp:541-545): offsets 0, scales 1, group single
     if (hm.D > 64) return fail("more than 64 degrees of freedom");
     for (int j = 0; j < J; ++j) for (int k = j; k != -1; k = hm.parent[k]) hm.subtree_mask[k] |= (1u << j);
     // generalized velocities
@@ -301,6 +302,7 @@ struct CtxBase {
     int goal_size = 0; float* d_goals = nullptr;            // RecordGoal of the last emit (goal scenes)
     virtual int get_goal(double* out) = 0; virtual int set_goal(const double* in) = 0; virtual int get_clips(int* out) = 0;
     virtual int goal_aux(double* out, const double* in) = 0; virtual void set_mode(int test) = 0;
+    virtual int obj_state(double* out, const double* in) = 0;
     virtual int amp_expert_clips(int n, const int* clips_dev, const double* times_dev, const double* gh_dev, float* out_dev) = 0;
     virtual int probe(int what, double dt) = 0;
     virtual int get_state(double* pose, double* vel, double* tar, double* kin, double* clk, int* flg) = 0;
@@ -369,11 +371,12 @@ struct CtxT : CtxBase {
         if (h.J <= ClsBiped::NJ && h.D <= ClsBiped::ND && h.P <= ClsBiped::NP && h.NC <= ClsBiped::NCAP && !any_rot) cls = 0;
         else if (h.J <= ClsLarge::NJ && h.D <= ClsLarge::ND && h.P <= ClsLarge::NP && h.NC <= ClsLarge::NCAP) cls = 1;
         else return fail("character too large for the compiled kernel classes (J<=23, D<=64, P<=83, <=128 contact candidates)");
-        md.mdl_blob = (cls == 0) ? build_mdl<ClsBiped>(&md.mdl_words) : build_mdl<ClsLarge>(&md.mdl_words);
+        if (c.scene_goal == 5) { if (cls != 0) return fail("dribble_amp is compiled for the biped class only"); cls = 2; }      // biped + one free body
+        md.mdl_blob = (cls != 1) ? build_mdl<ClsBiped>(&md.mdl_words) : build_mdl<ClsLarge>(&md.mdl_words);
         md.act_off = up<int>(h.act_off); md.diffw = up<Real>(h.diffw); md.aabb_he = up<Real>(h.aabb_he);
         md.cand_link = up<int>(h.cand_link); md.cand_loc = up<Real>(h.cand_loc); md.cand_rad = up<Real>(h.cand_rad);
         md.pair_code = up<int>(h.pair_code); md.NPAIR = (int)h.pair_code.size();
-        if (md.NPAIR > ((cls == 0) ? ClsBiped::NPAIRCAP : ClsLarge::NPAIRCAP)) return fail("too many self-collision pairs for the compiled kernel classes");
+        if (md.NPAIR > ((cls != 1) ? ClsBiped::NPAIRCAP : ClsLarge::NPAIRCAP)) return fail("too many self-collision pairs for the compiled kernel classes");
         md.frame_time = up<double>(h.frame_time); md.frames = up<Real>(h.frames); md.frame_vel = up<Real>(h.frame_vel);
         md.duration = h.duration; md.loop = h.loop; for (int k = 0; k < 3; ++k) { md.cycle_delta[k] = (Real)h.cycle_delta[k]; md.gravity[k] = (Real)c.gravity[k]; }
         md.num_sim_substeps = c.num_sim_substeps; md.solver_iters = c.solver_iters > 0 ? c.solver_iters : 10; md.max_contacts = max_contacts;
@@ -390,7 +393,18 @@ struct CtxT : CtxBase {
         st.tau = (Real*)dalloc(sizeof(Real) * N * h.D); st.kin = (Real*)dalloc(sizeof(Real) * N * 8);
         st.clock = (double*)dalloc(sizeof(double) * N * 6); st.flag = (int*)dalloc(sizeof(int) * N * 4);
         // overflow rows of the constraint-space matrix (rows RREG..63 of a character with more than RREG rows in a substep)
-        { const int ovf = kMaxRows - ((cls == 0) ? ClsBiped::RREG : ClsLarge::RREG); st.aovf = ovf > 0 ? (Real*)dalloc(sizeof(Real) * (size_t)N * ovf * kWave) : nullptr; }
+        { const int ovf = kMaxRows - ((cls != 1) ? ClsBiped::RREG : ClsLarge::RREG); st.aovf = ovf > 0 ? (Real*)dalloc(sizeof(Real) * (size_t)N * ovf * kWave) : nullptr; }
+        st.obj = nullptr;
+        if (cls == 2) {
+            st.obj = (Real*)dalloc(sizeof(Real) * (size_t)N * OB_WIDTH);
+            if (!st.obj) return fail("device allocation failed");
+            rt_memset(st.obj, 0, sizeof(Real) * (size_t)N * OB_WIDTH, stream);
+            const double r = c.ball_radius, mass = c.ball_mass;
+            md.ball_radius = (Real)r; md.ball_inv_mass = (Real)(1.0 / mass); md.ball_inv_inertia = (Real)(1.0 / (0.4 * mass * r * r));
+            md.ball_friction = (Real)c.ball_friction; md.ball_thresh = (Real)(0.02 * r);
+            md.ball_ln_lin = log(1.0 - c.ball_lin_damping); md.ball_ln_ang = log(1.0 - c.ball_ang_damping);
+            md.obj_time_min = c.rand_tar_obj_time_min; md.obj_time_max = c.rand_tar_obj_time_max; md.min_tar_obj_dist = c.min_tar_obj_dist; md.max_tar_obj_dist = c.max_tar_obj_dist;
+        }
         st.hist = nullptr;
         md.scene_amp = c.scene_amp ? 1 : 0; md.amp_local_root = c.enable_amp_obs_local_root ? 1 : 0;
         if (c.scene_amp) {
@@ -415,7 +429,7 @@ struct CtxT : CtxBase {
         md.tar_speed = (Real)c.tar_speed; md.pos_reward_scale = (Real)c.pos_reward_scale; md.max_heading_turn_rate = (Real)c.max_heading_turn_rate;
         md.sharp_turn_prob = (Real)c.sharp_turn_prob; md.speed_change_prob = (Real)c.speed_change_prob;
         md.tar_speed_min = (Real)c.tar_speed_min; md.tar_speed_max = (Real)c.tar_speed_max; md.vel_reward_scale = (Real)c.vel_reward_scale;
-        md.goal_dim = (c.scene_goal >= 3) ? 4 : (c.scene_goal ? 3 : 0); md.mode_test = c.mode_test;
+        md.goal_dim = (c.scene_goal == 3 || c.scene_goal == 4) ? 4 : (c.scene_goal ? 3 : 0); md.mode_test = c.mode_test;
         md.getup_time = c.getup_time; md.recover_prob = c.recover_episode_prob; md.getup_height_root = (Real)c.getup_height_root; md.getup_height_head = (Real)c.getup_height_head;
         md.head_id = c.head_id; md.getup_clip_mask = c.getup_clip_mask;
         md.tar_far_prob = c.tar_far_prob; md.init_hit_prob = c.init_hit_prob; md.hit_reset_time = c.target_hit_reset_time;
@@ -456,6 +470,7 @@ struct CtxT : CtxBase {
 #define DM_DISPATCH(KERN, grid, ...)                                                         \
     do {                                                                                     \
         if (cls == 0) RT_LAUNCH((KERN<Real, ClsBiped>), grid, stream, __VA_ARGS__);              \
+        else if (cls == 2) RT_LAUNCH((KERN<Real, ClsBipedObj>), grid, stream, __VA_ARGS__);      \
         else RT_LAUNCH((KERN<Real, ClsLarge>), grid, stream, __VA_ARGS__);                       \
     } while (0)
 
@@ -475,14 +490,15 @@ struct CtxT : CtxBase {
             return 0;
         }
         // production launch: the tap-free instantiation unless a parity test armed the debug taps (dm_probe)
-        if (dbg.H) { if (cls == 0) RT_LAUNCH((k_env_step<Real, ClsBiped, true>), N, stream, md, st, io, dbg); else RT_LAUNCH((k_env_step<Real, ClsLarge, true>), N, stream, md, st, io, dbg); }
+        if (cls == 2) { if (dbg.H) RT_LAUNCH((k_env_step<Real, ClsBipedObj, true>), N, stream, md, st, io, dbg); else RT_LAUNCH((k_env_step<Real, ClsBipedObj, false, true>), N, stream, md, st, io, dbg); }
+        else if (dbg.H) { if (cls == 0) RT_LAUNCH((k_env_step<Real, ClsBiped, true>), N, stream, md, st, io, dbg); else RT_LAUNCH((k_env_step<Real, ClsLarge, true>), N, stream, md, st, io, dbg); }
         else if (st.hist) { if (cls == 0) RT_LAUNCH((k_env_step<Real, ClsBiped, false, true>), N, stream, md, st, io, dbg); else RT_LAUNCH((k_env_step<Real, ClsLarge, false, true>), N, stream, md, st, io, dbg); }
         else { if (cls == 0) RT_LAUNCH((k_env_step<Real, ClsBiped, false, false>), N, stream, md, st, io, dbg); else RT_LAUNCH((k_env_step<Real, ClsLarge, false, false>), N, stream, md, st, io, dbg); }
         return 0;
     }
     int amp_expert(int n, const double* times_dev, const double* gh_dev, float* out_dev) override { return amp_expert_clips(n, nullptr, times_dev, gh_dev, out_dev); }
     int amp_expert_clips(int n, const int* clips_dev, const double* times_dev, const double* gh_dev, float* out_dev) override {
-        if (cls == 0) RT_LAUNCH((k_amp_expert<Real, ClsBiped>), n, stream, md, times_dev, gh_dev, out_dev, clips_dev);
+        if (cls != 1) RT_LAUNCH((k_amp_expert<Real, ClsBiped>), n, stream, md, times_dev, gh_dev, out_dev, clips_dev);
         else RT_LAUNCH((k_amp_expert<Real, ClsLarge>), n, stream, md, times_dev, gh_dev, out_dev, clips_dev);
         return 0;
     }
@@ -512,6 +528,17 @@ struct CtxT : CtxBase {
         return 0;
     }
     void set_mode(int test) override { md.mode_test = test ? 1 : 0; }
+    int obj_state(double* out, const double* in) override {          // N x 13: pos, rot wxyz, vel, ang vel of the free body
+        if (!st.obj) return fail("no free body: not a dribble_amp scene");
+        std::vector<Real> o((size_t)N * OB_WIDTH);
+        if (rt_d2h(o.data(), st.obj, sizeof(Real) * o.size(), stream) != 0) return fail("device to host copy failed");
+        if (out) for (int e = 0; e < N; ++e) for (int k = 0; k < 13; ++k) out[(size_t)e * 13 + k] = (double)o[(size_t)e * OB_WIDTH + k];
+        if (in) {
+            for (int e = 0; e < N; ++e) for (int k = 0; k < 13; ++k) o[(size_t)e * OB_WIDTH + k] = (Real)in[(size_t)e * 13 + k];
+            if (rt_h2d(st.obj, o.data(), sizeof(Real) * o.size(), stream) != 0) return fail("host to device copy failed");
+        }
+        return 0;
+    }
     int get_clips(int* out) override {
         if (!st.goal) { for (int e = 0; e < N; ++e) out[e] = 0; return 0; }
         std::vector<double> g((size_t)N * GS_WIDTH);
@@ -536,7 +563,9 @@ struct CtxT : CtxBase {
             io.n_updates = 20; io.dt = dt; io.auto_reset = 1; io.emit = 1; io.open_loop = (what == 3) ? 1 : 0; io.end_early = 1;
             if (what == 4) io.actions = d_actions;
             if (duo && cls == 0 && hm.D == ClsBiped::ND && (N % 2) == 0) RT_LAUNCH((k_env_step_duo<Real, true>), N / 2, stream, md, st, io, d2);
-            else if (cls == 0) RT_LAUNCH((k_env_step<Real, ClsBiped, true>), N, stream, md, st, io, d2); else RT_LAUNCH((k_env_step<Real, ClsLarge, true>), N, stream, md, st, io, d2);
+            else if (cls == 0) RT_LAUNCH((k_env_step<Real, ClsBiped, true>), N, stream, md, st, io, d2);
+            else if (cls == 2) RT_LAUNCH((k_env_step<Real, ClsBipedObj, true>), N, stream, md, st, io, d2);
+            else RT_LAUNCH((k_env_step<Real, ClsLarge, true>), N, stream, md, st, io, d2);
             return 0;
         }
         DM_DISPATCH(k_env_probe, N, md, st, dbg, what, dt);
@@ -609,7 +638,9 @@ int dm_destroy(dm_ctx* ctx);
 int dm_create(const dm_create_info* info, const dm_scene_tables* tables, dm_ctx** out) {
     if (!info || !tables || !out) return fail("null argument");
     if (info->num_envs < 1) return fail("num_envs must be >= 1");
-    if (tables->scene_goal < 0 || tables->scene_goal > 4) return fail("scene_goal must be 0 (none), 1 (target_amp), 2 (heading_amp), 3 (heading_amp_getup) or 4 (strike_amp)");
+    if (tables->scene_goal < 0 || tables->scene_goal > 5) return fail("scene_goal must be 0 (none), 1 (target_amp), 2 (heading_amp), 3 (heading_amp_getup), 4 (strike_amp) or 5 (dribble_amp)");
+    if (tables->scene_goal == 5 && !(tables->ball_radius > 0 && tables->ball_mass > 0)) return fail("dribble_amp needs ball_radius > 0 and ball_mass > 0");
+    if (tables->scene_goal == 5 && info->wave_packing == 2) return fail("dribble_amp runs one character per wavefront (wave_packing 0 or 1)");
     if (tables->scene_goal == 3 && !(tables->getup_time > 0)) return fail("heading_amp_getup needs getup_time > 0 (the longest get-up clip)");
     if (tables->scene_goal == 3 && (tables->head_id < 0 || tables->head_id >= tables->num_joints)) return fail("head_id out of range");
     if (tables->scene_goal == 4 && tables->strike_mask == 0) return fail("strike_amp needs at least one strike body");
@@ -832,6 +863,8 @@ int dm_set_goal_state(dm_ctx* ctx, const double* in) { if (!ctx || !in) return f
 int dm_goal_size(const dm_ctx* ctx) { return ctx ? ctx->c->goal_size : 0; }
 int dm_get_goal_aux(dm_ctx* ctx, double* out) { if (!ctx || !out) return fail("null argument"); DevGuard guard(ctx->c->device_id); return ctx->c->goal_aux(out, nullptr); }
 int dm_set_goal_aux(dm_ctx* ctx, const double* in) { if (!ctx || !in) return fail("null argument"); DevGuard guard(ctx->c->device_id); return ctx->c->goal_aux(nullptr, in); }
+int dm_get_obj_state(dm_ctx* ctx, double* out) { if (!ctx || !out) return fail("null argument"); DevGuard guard(ctx->c->device_id); return ctx->c->obj_state(out, nullptr); }
+int dm_set_obj_state(dm_ctx* ctx, const double* in) { if (!ctx || !in) return fail("null argument"); DevGuard guard(ctx->c->device_id); return ctx->c->obj_state(nullptr, in); }
 int dm_set_mode(dm_ctx* ctx, int test_mode) { if (!ctx) return fail("null ctx"); ctx->c->set_mode(test_mode); return 0; }
 int dm_get_clips(dm_ctx* ctx, int32_t* out) { if (!ctx || !out) return fail("null argument"); DevGuard guard(ctx->c->device_id); return ctx->c->get_clips(out); }
 

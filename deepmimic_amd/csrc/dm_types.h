@@ -25,6 +25,7 @@ constexpr int kMaxContacts = 20;   // contact slots per character (ground + self
 // Compiled kernel classes: static bounds of the per-lane register arrays and the LDS record.
 struct ClsBiped {      // humanoid3d: 15 links, 34 dof, 43 pose dims, <= 64 ground-contact candidates, no attach rotations
     static constexpr int NJ = 15, ND = 34, NP = 43, NCAP = 64, RREG = 32, NPAIRCAP = 128, LPAD = 4; static constexpr bool ROT = false;   // RREG: rows of A kept in VGPRs
+    static constexpr bool OBJ = false;      // no free rigid body next to the character
     static constexpr bool GRAM64 = false;   // 64-row Gram matrix by the readlane loop (128-VGPR budget of the one-per-wave kernel)
     static constexpr int PFD = 2;           // look-ahead of the sweep into the overflow block of A, rows
 };
@@ -34,9 +35,12 @@ struct ClsBipedWide : ClsBiped { static constexpr int RREG = 64; };
 // the fallback class of the two-per-wave kernel by default: the narrow row file (rows 32..63 of A in the HBM / L2 overflow block), but
 // the Gram matrix of a character with more than 32 rows still comes off the matrix core (64 accumulators live for the Gram only)
 struct ClsBipedFb : ClsBiped { static constexpr bool GRAM64 = true; };   // (a look-ahead of 6 rows instead of 2 measured no gain)
+// the biped class plus one free rigid sphere in the world (`--scene dribble_amp`: the ball, scenes/SceneDribbleAMP.cpp:398-420); one
+// character per wavefront, 2 waves / SIMD (the ball's Jacobian columns ride in six more VGPRs per row lane)
+struct ClsBipedObj : ClsBiped { static constexpr bool OBJ = true; };
 struct ClsLarge {      // dog3d and anything up to 23 links / 64 dof / 83 pose dims / 128 candidates, attach rotations allowed
     static constexpr int NJ = 23, ND = 64, NP = 83, NCAP = 128, RREG = 32, NPAIRCAP = 256, LPAD = 2; static constexpr bool ROT = true;
-    static constexpr bool GRAM64 = false; static constexpr int PFD = 2;
+    static constexpr bool GRAM64 = false; static constexpr int PFD = 2; static constexpr bool OBJ = false;
 };
 
 // link_info word: parent+1 [0:4] | jtype [5:7] | depth [8:11] | pose_off [12:18] | dof_off [19:25] | arot_ident 26 | brot_ident 27 | is_ee 28 | fall 29
@@ -119,6 +123,9 @@ struct ModelDev {
     Real getup_height_root, getup_height_head; int head_id, getup_clip_mask;
     double tar_far_prob, init_hit_prob, hit_reset_time, target_min[3], target_max[3];     // strike_amp
     Real tar_near_dist, target_radius, hit_tar_speed, tar_reward_scale; int strike_mask, fail_tar_mask;
+    // dribble_amp (scene_goal 5): the ball -- radius, 1/mass, 1/inertia (0.4 m r^2), friction against links and ground, ln(1 - damping)
+    Real ball_radius, ball_inv_mass, ball_inv_inertia, ball_friction, ball_thresh; double ball_ln_lin, ball_ln_ang;   // ball_thresh: contact breaking threshold 0.02 r
+    double obj_time_min, obj_time_max, min_tar_obj_dist, max_tar_obj_dist;
     double goal_time_min, goal_time_max;     // target timer range (rand_target_time_*)
     Real max_target_dist, target_succ_dist, tar_fail_dist, tar_speed, pos_reward_scale;
     Real max_heading_turn_rate, sharp_turn_prob, speed_change_prob, tar_speed_min, tar_speed_max, vel_reward_scale;
@@ -134,7 +141,11 @@ struct ModelDev {
 // per-env goal state row (EnvState::goal), doubles: the clocks among them must not round to fp32
 enum { GS_TX = 0, GS_TY, GS_TZ, GS_HEADING, GS_SPEED, GS_TIMER, GS_TIMER_MAX, GS_PCOMX, GS_PCOMY, GS_PCOMZ, GS_PTIME, GS_DRAWS, GS_CLIP,
        GS_AUX0, GS_AUX1,        // heading_amp_getup: get-up timer | strike_amp: target hit (0 / 1), hit time
-       GS_WIDTH = 16 };
+       GS_PBX, GS_PBY, GS_PBZ,  // dribble_amp: ball position at the last action (cSceneDribbleAMP::mAgentPrevTarObjPos)
+       GS_OTIMER, GS_OTIMER_MAX, // dribble_amp: target-object timer
+       GS_WIDTH = 24 };
+// the free body's record (EnvState::obj, OBJ classes): position, rotation (w, x, y, z), linear and angular velocity
+enum { OB_PX = 0, OB_QW = 3, OB_VX = 7, OB_WX = 10, OB_WIDTH = 16 };
 
 template <typename Real>
 struct EnvState {
@@ -148,6 +159,7 @@ struct EnvState {
     int* flag;       // N x 4   need_new_action, contact_mask, episode_count, valid
     Real* aovf;      // N x (64 - RREG) x 64  overflow rows of the constraint-space matrix (null when the class keeps all 64 in VGPRs)
     Real* hist;      // N x 2P  pose | vel at the last action latch (cSceneImitateAMP::mPrevPose / mPrevVel); null unless imitate_amp
+    Real* obj;       // N x OB_WIDTH  the free body of an OBJ class (dribble_amp's ball); null otherwise
     double* goal;    // N x GS_WIDTH  goal state of the task scenes + the clip the env was reset to; null unless a goal scene / multi-clip dataset
 };
 

@@ -184,9 +184,17 @@ class SceneConfig:
     tar_near_dist: float = 1.4
     strike_bodies: Optional[List[int]] = None
     fail_tar_contact_bodies: Optional[List[int]] = None
+    # ---- dribble_amp (scenes/SceneDribbleAMP.cpp:124-149)
+    rand_tar_obj_time_min: float = 100.0
+    rand_tar_obj_time_max: float = 200.0
+    min_tar_obj_dist: float = 0.5
+    max_tar_obj_dist: float = 10.0
+    ball_radius: float = 0.2
 
 
-GOAL_SCENES = {"target_amp": 1, "heading_amp": 2, "heading_amp_getup": 3, "strike_amp": 4}
+# cSceneDribbleAMP::BuildTarObjs (SceneDribbleAMP.cpp:398-420): the ball's constants are literals there, not arg-file keys
+BALL_MASS, BALL_FRICTION, BALL_LIN_DAMPING, BALL_ANG_DAMPING = 0.43, 0.4, 0.4, 0.4
+GOAL_SCENES = {"target_amp": 1, "heading_amp": 2, "heading_amp_getup": 3, "strike_amp": 4, "dribble_amp": 5}
 AMP_SCENES = ("imitate_amp",) + tuple(GOAL_SCENES)
 
 
@@ -222,7 +230,7 @@ class SceneTables:
     @property
     def goal_dim(self) -> int:
         # cSceneTargetAMP / cSceneHeadingAMP::GetGoalSize: 3; cSceneHeadingAMPGetup (+ get-up phase) and cSceneStrikeAMP (pos + hit phase): 4
-        return (0, 3, 3, 4, 4)[self.goal_kind]
+        return (0, 3, 3, 4, 4, 3)[self.goal_kind]           # cSceneDribbleAMP::RecordGoal: direction (2) + distance from the ball to the target
 
     def clip_duration(self, c: int) -> float:
         """cMotion::GetDuration of clip c: the frame durations but the last one's (anim/Motion.cpp PostProcessFrames)"""
@@ -263,7 +271,10 @@ class SceneTables:
     @property
     def state_dim(self) -> int:
         J = self.num_joints
-        return (1 if self.enable_phase_input else 0) + (J * 9 + 1) + J * 6
+        s = (1 if self.enable_phase_input else 0) + (J * 9 + 1) + J * 6
+        if self.cfg.scene == "dribble_amp":
+            s += 15                                # cSceneDribbleAMP::GetTaskStateSize (SceneDribbleAMP.cpp:541-545): the ball in the origin frame
+        return s
 
     def fall_mask(self) -> np.ndarray:
         """Per-link fall-contact flags: args override JSON (scenes/SceneSimChar.cpp:460-476)."""
@@ -455,6 +466,12 @@ def parse_scene_config(parser: ArgParser) -> SceneConfig:
     v = parser.floats("target_max")
     if v:
         c.target_max = tuple(v[:3])
+    if c.scene == "dribble_amp":
+        # cSceneDribbleAMP(): target timer 50 .. 100 s unless the args say otherwise (SceneDribbleAMP.cpp:124-133)
+        c.rand_target_time_min = parser.float("rand_target_time_min", 50.0)
+        c.rand_target_time_max = parser.float("rand_target_time_max", 100.0)
+    for k in ("rand_tar_obj_time_min", "rand_tar_obj_time_max", "min_tar_obj_dist", "max_tar_obj_dist", "ball_radius"):
+        setattr(c, k, parser.float(k, getattr(c, k)))
     c.strike_bodies = parser.ints("strike_bodies")
     c.fail_tar_contact_bodies = parser.ints("fail_tar_contact_bodies")
     return c
@@ -556,8 +573,8 @@ def load_scene_from_args(args: Sequence[str], data_root: str = ".") -> SceneTabl
             raise FileNotFoundError("Failed to load args from: %s" % arg_file)
     cfg = parse_scene_config(p)
     if cfg.scene != "imitate" and cfg.scene not in AMP_SCENES:
-        raise ValueError("only `--scene imitate`, `imitate_amp`, `heading_amp`, `heading_amp_getup`, `target_amp` and `strike_amp` are on the "
-                         "accelerated path (got %r)" % cfg.scene)
+        raise ValueError("only `--scene imitate`, `imitate_amp`, `heading_amp`, `heading_amp_getup`, `target_amp`, `strike_amp` and `dribble_amp` "
+                         "are on the accelerated path (got %r)" % cfg.scene)
 
     def res(pth):
         return pth if os.path.isabs(pth) else os.path.join(data_root, pth)

@@ -83,6 +83,13 @@ typedef struct {
     double tar_near_dist, tar_far_prob, target_radius, target_hit_reset_time, init_hit_prob, hit_tar_speed, tar_reward_scale;
     double target_min[3], target_max[3];
     int strike_mask, fail_tar_mask;
+    /* ---- scene_goal 5 = `--scene dribble_amp` (scenes/SceneDribbleAMP.cpp): target_amp with a ball -- a free rigid sphere in the world
+     * (BuildTarObjs :398-420: radius, mass 0.43, friction 0.4, linear / angular damping 0.4) the character has to move to the target.
+     * RecordState gains 15 entries (the ball in the origin frame, :554-590), RecordGoal is the direction / distance from the ball to the
+     * target (:276-302), the reward :21-106, success / distance termination :343-379, 454-475.  One character per wavefront.
+     * ball_friction is the combined coefficient of a ball contact (ball 0.4 x link / ground 0.9). */
+    double rand_tar_obj_time_min, rand_tar_obj_time_max, min_tar_obj_dist, max_tar_obj_dist;
+    double ball_radius, ball_mass, ball_friction, ball_lin_damping, ball_ang_damping;
 } dm_scene_tables;
 
 /* DM_END_EPISODE_EARLY: an env whose episode is over after update u of the call (fall contact, clip end, episode timer) takes no
@@ -162,6 +169,10 @@ int dm_set_goal_aux(dm_ctx* ctx, const double* in);
  * fall instead of termination, recovery episodes, strike_amp's test reward); the episode-timer limits of the two modes are the
  * caller's business (dm_set_time_limits). */
 int dm_set_mode(dm_ctx* ctx, int test_mode);
+/* dribble_amp: the ball of every env, N x 13 doubles = position(3), rotation w x y z (4), linear velocity(3), angular velocity(3)
+ * (cSimObj::GetPos / GetRotation / GetLinearVelocity / GetAngularVelocity of the target object) */
+int dm_get_obj_state(dm_ctx* ctx, double* out);
+int dm_set_obj_state(dm_ctx* ctx, const double* in);
 /* clip each env's kinematic character was reset to (multi-clip datasets), N int32 */
 int dm_get_clips(dm_ctx* ctx, int32_t* out);
 

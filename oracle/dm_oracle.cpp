@@ -28,7 +28,8 @@ enum {
     CFG_MIN_TAR_VEL, CFG_MAX_TURN_RATE, CFG_SHARP_TURN_PROB, CFG_SPEED_CHANGE_PROB, CFG_TAR_SPEED_MIN, CFG_TAR_SPEED_MAX, CFG_VEL_REWARD_SCALE,
     CFG_MODE_TEST, CFG_GETUP_TIME, CFG_GETUP_HEIGHT_ROOT, CFG_GETUP_HEIGHT_HEAD, CFG_HEAD_ID, CFG_RECOVER_PROB, CFG_GETUP_CLIP_MASK,
     CFG_TAR_NEAR_DIST, CFG_TAR_FAR_PROB, CFG_TARGET_RADIUS, CFG_HIT_RESET_TIME, CFG_INIT_HIT_PROB, CFG_HIT_TAR_SPEED, CFG_TAR_REWARD_SCALE,
-    CFG_TMIN_X, CFG_TMIN_Y, CFG_TMIN_Z, CFG_TMAX_X, CFG_TMAX_Y, CFG_TMAX_Z, CFG_STRIKE_MASK, CFG_FAIL_TAR_MASK, CFG_COUNT
+    CFG_TMIN_X, CFG_TMIN_Y, CFG_TMIN_Z, CFG_TMAX_X, CFG_TMAX_Y, CFG_TMAX_Z, CFG_STRIKE_MASK, CFG_FAIL_TAR_MASK,
+    CFG_OBJ_TIME_MIN, CFG_OBJ_TIME_MAX, CFG_MIN_OBJ_DIST, CFG_MAX_OBJ_DIST, CFG_BALL_RADIUS, CFG_BALL_MASS, CFG_BALL_FRICTION, CFG_BALL_LIN_DAMP, CFG_BALL_ANG_DAMP, CFG_COUNT
 };
 
 int orc_cfg_count() { return CFG_COUNT; }
@@ -56,6 +57,8 @@ void orc_cfg_default(double* c) {
     c[CFG_INIT_HIT_PROB] = d.init_hit_prob; c[CFG_HIT_TAR_SPEED] = d.hit_tar_speed; c[CFG_TAR_REWARD_SCALE] = d.tar_reward_scale;
     for (int k = 0; k < 3; ++k) { c[CFG_TMIN_X + k] = d.target_min[k]; c[CFG_TMAX_X + k] = d.target_max[k]; }
     c[CFG_STRIKE_MASK] = d.strike_mask; c[CFG_FAIL_TAR_MASK] = d.fail_tar_mask;
+    c[CFG_OBJ_TIME_MIN] = d.tar_obj_time_min; c[CFG_OBJ_TIME_MAX] = d.tar_obj_time_max; c[CFG_MIN_OBJ_DIST] = d.min_tar_obj_dist; c[CFG_MAX_OBJ_DIST] = d.max_tar_obj_dist;
+    c[CFG_BALL_RADIUS] = d.ball_radius; c[CFG_BALL_MASS] = d.ball_mass; c[CFG_BALL_FRICTION] = d.ball_friction; c[CFG_BALL_LIN_DAMP] = d.ball_lin_damping; c[CFG_BALL_ANG_DAMP] = d.ball_ang_damping;
 }
 
 void* orc_create(const double* jm, const double* bd, int J, const double* pd, const double* frames, int F, int loop,
@@ -81,6 +84,8 @@ void* orc_create(const double* jm, const double* bd, int J, const double* pd, co
     cfg.init_hit_prob = c[CFG_INIT_HIT_PROB]; cfg.hit_tar_speed = c[CFG_HIT_TAR_SPEED]; cfg.tar_reward_scale = c[CFG_TAR_REWARD_SCALE];
     for (int k = 0; k < 3; ++k) { cfg.target_min[k] = c[CFG_TMIN_X + k]; cfg.target_max[k] = c[CFG_TMAX_X + k]; }
     cfg.strike_mask = (uint32_t)c[CFG_STRIKE_MASK]; cfg.fail_tar_mask = (uint32_t)c[CFG_FAIL_TAR_MASK];
+    cfg.tar_obj_time_min = c[CFG_OBJ_TIME_MIN]; cfg.tar_obj_time_max = c[CFG_OBJ_TIME_MAX]; cfg.min_tar_obj_dist = c[CFG_MIN_OBJ_DIST]; cfg.max_tar_obj_dist = c[CFG_MAX_OBJ_DIST];
+    cfg.ball_radius = c[CFG_BALL_RADIUS]; cfg.ball_mass = c[CFG_BALL_MASS]; cfg.ball_friction = c[CFG_BALL_FRICTION]; cfg.ball_lin_damping = c[CFG_BALL_LIN_DAMP]; cfg.ball_ang_damping = c[CFG_BALL_ANG_DAMP];
     Scene* s = new Scene();
     s->init(jm, bd, J, pd, frames, F, loop != 0, fall_mask, cfg);
     return s;
@@ -370,6 +375,18 @@ void orc_goal_state(void* h, double* o) {
     else { o[13] = s->target_hit ? 1.0 : 0.0; o[14] = s->target_hit_time; }
 }
 int orc_goal_dim(void* h) { return ((Scene*)h)->goal_dim(); }
+// dribble_amp: ball pos(3), rot wxyz(4), vel(3), ang vel(3), ball pos at the last action(3), target-object timer time / max
+void orc_ball_state(void* h, double* o) {
+    Scene* s = (Scene*)h;
+    o[0] = s->ball_pos.x; o[1] = s->ball_pos.y; o[2] = s->ball_pos.z; o[3] = s->ball_rot.w; o[4] = s->ball_rot.x; o[5] = s->ball_rot.y; o[6] = s->ball_rot.z;
+    o[7] = s->ball_vel.x; o[8] = s->ball_vel.y; o[9] = s->ball_vel.z; o[10] = s->ball_w.x; o[11] = s->ball_w.y; o[12] = s->ball_w.z;
+    o[13] = s->prev_ball_pos.x; o[14] = s->prev_ball_pos.y; o[15] = s->prev_ball_pos.z; o[16] = s->obj_timer; o[17] = s->obj_timer_max;
+}
+void orc_set_ball(void* h, const double* o) {
+    Scene* s = (Scene*)h;
+    s->ball_pos = V3((real)o[0], (real)o[1], (real)o[2]); s->ball_rot = Q4((real)o[3], (real)o[4], (real)o[5], (real)o[6]);
+    s->ball_vel = V3((real)o[7], (real)o[8], (real)o[9]); s->ball_w = V3((real)o[10], (real)o[11], (real)o[12]);
+}
 int orc_maybe_recovery_reset(void* h, double max_time) { return ((Scene*)h)->maybe_recovery_reset(max_time) ? 1 : 0; }
 void orc_amp_obs_expert_clip(void* h, int clip, double t, double ground_h, double* out) { ((Scene*)h)->amp_obs_expert(t, out, clip, ground_h); }
 

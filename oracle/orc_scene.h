@@ -33,6 +33,9 @@ struct SceneCfg {
     // strike_amp (SceneStrikeAMP.cpp:189-231)
     double tar_near_dist = 1.4, tar_far_prob = 0.4, target_radius = 0.2, target_hit_reset_time = 2, init_hit_prob = 0, hit_tar_speed = 1.5, tar_reward_scale = 2;
     double target_min[3] = {-0.5, 1.2, 0.6}, target_max[3] = {0.5, 1.4, 1.1}; uint32_t strike_mask = 0, fail_tar_mask = 0;
+    // 5 = dribble_amp (scenes/SceneDribbleAMP.cpp:124-149, 398-420): a free rigid sphere ("DM-physics v1 + one free body")
+    double tar_obj_time_min = 100, tar_obj_time_max = 200, min_tar_obj_dist = 0.5, max_tar_obj_dist = 10;
+    double ball_radius = 0.2, ball_mass = 0.43, ball_friction = 0.4 * 0.9, ball_lin_damping = 0.4, ball_ang_damping = 0.4;
     bool enable_rand_rot_reset = false;       // SceneImitate.cpp:131,145,184-189
     double rand_target_time_min = 1, rand_target_time_max = 5, max_target_dist = 3, target_succ_dist = 0.5;
     double tar_fail_dist = std::numeric_limits<double>::infinity(), tar_speed = 1, pos_reward_scale = 1;
@@ -97,8 +100,8 @@ struct LDLT {
 };
 
 struct V3d { double x = 0, y = 0, z = 0; };
-struct ContactPt { int link; V3 x; real dist; int link_b = -1; V3 n = V3(0, 1, 0); };   // link_b >= 0: self contact, n points from link_b to link
-struct Row { Vec J; Vec W; real b, lo, hi, lam; int normal_row; real mu; };
+struct ContactPt { int link; V3 x; real dist; int link_b = -1; V3 n = V3(0, 1, 0); int ball = 0; };   // link_b >= 0: self contact, n points from link_b to link; ball 1: body b is the ball (link vs ball), 2: body a is the ball (ball vs ground, link unused)
+struct Row { Vec J; Vec W; real b, lo, hi, lam; int normal_row; real mu; real Jb[6] = {0, 0, 0, 0, 0, 0}, Wb[6] = {0, 0, 0, 0, 0, 0}; };   // Jb / Wb: the ball's 3 linear + 3 angular velocities
 
 enum Terminate { TERM_NULL = 0, TERM_FAIL = 1, TERM_SUCC = 2 };   // scenes/RLScene.h:18-24
 
@@ -131,6 +134,8 @@ struct Scene {
     uint64_t rng_seed = 0, rng_env = 0, goal_draws = 0;    // the device path's counter-based generator (dm_rand01, stream 2)
     double getup_timer = 0;                                // cSceneHeadingAMPGetup::mGetupTimer (time; max = cfg.getup_time)
     bool target_hit = false; double target_hit_time = -1;  // cSceneStrikeAMP::mTargetHit / mTargetHitTime (gInvalidHitTime = -1)
+    // dribble_amp: the ball (cSimSphere), cSceneDribbleAMP::mAgentPrevTarObjPos, mTarObjTimer
+    V3 ball_pos, ball_vel, ball_w; Q4 ball_rot; V3d prev_ball_pos; double obj_timer = 0, obj_timer_max = 0;
 
     void init(const double* jm, const double* bd, int J, const double* pd /*J x 2*/, const double* frames, int F, bool loop,
               const int* fall, const SceneCfg& c) {
@@ -157,6 +162,7 @@ struct Scene {
         }
         A = off;
         S = (cfg.enable_phase_input ? 1 : 0) + (J * 9 + 1) + J * 6;   // CtController.cpp:41-46,300-314
+        if (cfg.scene_goal == 5) S += 15;                             // cSceneDribbleAMP::GetTaskStateSize (:541-545)
         pose.assign(sk.P, 0); vel.assign(sk.P, 0); tau.assign(sk.P, 0);
         tar_pose.assign(sk.P, 0);
         for (int j = 1; j < J; ++j) if (sk.type(j) == JT_SPHERICAL) tar_pose[sk.offset(j)] = 1;  // PDController.cpp:425-443
@@ -168,6 +174,9 @@ struct Scene {
     // cSceneSimChar::ResetScene (SceneSimChar.cpp:628-644) + cSceneImitate::ResetCharacters (SceneImitate.cpp:320-368)
     // clip / yaw: multi-clip datasets (cClipsController::Reset -> SelectNewMotion) and enable_rand_rot_reset (ResetKinChar, :331-349)
     void reset(double kin_time, double max_time, int clip = 0, real yaw = 0) {
+        // cSceneDribbleAMP::Reset (:160-167): mTarObjTimer.Reset(); ResetTarObjs() -- around the root of the PREVIOUS episode's last
+        // state -- ; ResetAgentTarObjRecord(); then cSceneTargetAMP::Reset
+        if (cfg.scene_goal == 5) { obj_timer_reset(); reset_tar_objs(); }
         timer_time = 0; timer_max = max_time;                       // cTimer::Reset (Timer.cpp:55-73)
         if (!clips.empty()) { cur_clip = clip; kin.mo = &clips[clip]; }
         // ResetKinChar: origin rot/pos reset, time := rand_time, Pose(t)
@@ -398,6 +407,7 @@ struct Scene {
     }
     // row of a contact along d: the contact point moves with `link`; for a self contact minus the same point moving with link_b
     void contact_jacobian(const ContactPt& cp, const V3& d, Vec& Jr) const {
+        if (cp.link < 0) { Jr.assign(sk.P, 0); return; }             // ball vs ground: no character dof moves the point
         point_jacobian(cp.link, cp.x, d, Jr);
         if (cp.link_b >= 0) { Vec Jb; point_jacobian(cp.link_b, cp.x, d, Jb); for (int i = 0; i < sk.P; ++i) Jr[i] -= Jb[i]; }
     }
@@ -432,6 +442,13 @@ struct Scene {
         for (int i = 0; i < P; ++i) vstar[i] = vel[i] + h * acc[i];
         clamp_coord_vel(vstar);
         dbg_vstar = vstar;
+        // the ball's unconstrained velocity: btRigidBody::applyDamping then the gravity impulse
+        const bool ball = cfg.scene_goal == 5;
+        V3 bv, bw;
+        if (ball) {
+            bv = ball_vel * (real)std::pow(1.0 - cfg.ball_lin_damping, (double)h) + h * cfg.gravity;
+            bw = ball_w * (real)std::pow(1.0 - cfg.ball_ang_damping, (double)h);
+        }
 
         // collision detection at the start-of-substep pose
         std::vector<ContactPt> cand; contact_candidates(cand);
@@ -453,6 +470,26 @@ struct Scene {
             std::vector<ContactPt> self; self_contacts(self);
             for (size_t i = 0; i < self.size() && (int)contacts.size() < cfg.max_contacts; ++i) contacts.push_back(self[i]);
         }
+        // ball contacts take the slots that are left: ball vs ground, then the links in index order (capsule models, as link vs link)
+        if (ball) {
+            const real rb = (real)cfg.ball_radius, thr_b = (real)cfg.breaking_factor * rb;
+            if ((int)contacts.size() < cfg.max_contacts && ball_pos.y - rb < thr_b) {
+                ContactPt c; c.link = -1; c.ball = 2; c.n = V3(0, 1, 0); c.dist = ball_pos.y - rb; c.x = ball_pos - V3(0, rb, 0);
+                contacts.push_back(c);
+            }
+            for (int j = 0; j < sk.J && (int)contacts.size() < cfg.max_contacts; ++j) {
+                if (!sk.valid_body(j)) continue;
+                V3 a0, a1; real ra; link_capsule(j, a0, a1, ra);
+                V3 pa0 = links[j].com + links[j].Rb * a0, pa1 = links[j].com + links[j].Rb * a1;
+                V3 ca, cb; closest_segment_points(pa0, pa1, ball_pos, ball_pos, ca, cb);
+                V3 dlt = ca - ball_pos; real d = norm(dlt), dist = d - ra - rb;
+                if (!(dist < std::min(breaking_threshold(j), thr_b))) continue;
+                V3 n = (d > (real)1e-9) ? ((real)1 / d) * dlt : V3(0, 1, 0);
+                ContactPt c; c.link = j; c.ball = 1; c.n = n; c.dist = dist;
+                c.x = (real)0.5 * ((ca - ra * n) + (ball_pos + rb * n));
+                contacts.push_back(c);
+            }
+        }
         dbg_contacts = contacts;
 
         std::vector<Row> rows;
@@ -473,22 +510,33 @@ struct Scene {
         int n_lim = (int)rows.size(), nc = (int)contacts.size();
         for (int c = 0; c < nc; ++c) {
             const ContactPt& cp = contacts[c];
-            Row r; contact_jacobian(cp, cp.n, r.J); r.normal_row = -1; r.mu = 0; r.lo = 0; r.hi = big; r.lam = 0;
+            Row r; contact_jacobian(cp, cp.n, r.J); ball_jacobian(cp, cp.n, r.Jb); r.normal_row = -1; r.mu = 0; r.lo = 0; r.hi = big; r.lam = 0;
             r.b = (cp.dist > 0) ? -cp.dist / h : (real)-cfg.erp * cp.dist / h;
             rows.push_back(r);
         }
         for (int c = 0; c < nc; ++c) for (int d = 0; d < 2; ++d) {
             const ContactPt& cp = contacts[c];
             V3 t1, t2; plane_space(cp.n, t1, t2);      // btPlaneSpace1: (-1,0,0), (0,0,1) for the ground normal
-            Row r; contact_jacobian(cp, d ? t2 : t1, r.J); r.normal_row = n_lim + c; r.mu = (real)cfg.friction; r.lo = r.hi = 0; r.lam = 0; r.b = 0;
+            Row r; contact_jacobian(cp, d ? t2 : t1, r.J); ball_jacobian(cp, d ? t2 : t1, r.Jb); r.normal_row = n_lim + c;
+            r.mu = cp.ball ? (real)cfg.ball_friction : (real)cfg.friction; r.lo = r.hi = 0; r.lam = 0; r.b = 0;
             rows.push_back(r);
         }
         const int R = (int)rows.size(); dbg_num_rows = R;
         std::vector<real> Amat((size_t)R * R, 0); Vec cvec(R, 0);
         for (int r = 0; r < R; ++r) fac.solve(rows[r].J, rows[r].W);
+        if (ball) {
+            const real im = (real)1 / (real)cfg.ball_mass, ii = (real)1 / ((real)0.4 * (real)cfg.ball_mass * (real)cfg.ball_radius * (real)cfg.ball_radius);
+            for (int r = 0; r < R; ++r) for (int k = 0; k < 6; ++k) rows[r].Wb[k] = (k < 3 ? im : ii) * rows[r].Jb[k];
+        }
         for (int r = 0; r < R; ++r) {
-            for (int s = 0; s < R; ++s) { real a = 0; for (int i = 0; i < P; ++i) a += rows[r].J[i] * rows[s].W[i]; Amat[(size_t)r * R + s] = a; }
-            real c = 0; for (int i = 0; i < P; ++i) c += rows[r].J[i] * vstar[i]; cvec[r] = c;
+            for (int s = 0; s < R; ++s) {
+                real a = 0; for (int i = 0; i < P; ++i) a += rows[r].J[i] * rows[s].W[i];
+                if (ball) for (int k = 0; k < 6; ++k) a += rows[r].Jb[k] * rows[s].Wb[k];
+                Amat[(size_t)r * R + s] = a;
+            }
+            real c = 0; for (int i = 0; i < P; ++i) c += rows[r].J[i] * vstar[i];
+            if (ball) c += rows[r].Jb[0] * bv.x + rows[r].Jb[1] * bv.y + rows[r].Jb[2] * bv.z + rows[r].Jb[3] * bw.x + rows[r].Jb[4] * bw.y + rows[r].Jb[5] * bw.z;
+            cvec[r] = c;
         }
         // projected Gauss-Seidel: per iteration limits, normals, frictions
         for (int it = 0; it < cfg.solver_iters; ++it) {
@@ -508,6 +556,23 @@ struct Scene {
         clamp_coord_vel(vnew);
         vel = vnew;
         integrate(h);
+        if (ball) {
+            for (int r = 0; r < R; ++r) {
+                bv = bv + rows[r].lam * V3(rows[r].Wb[0], rows[r].Wb[1], rows[r].Wb[2]);
+                bw = bw + rows[r].lam * V3(rows[r].Wb[3], rows[r].Wb[4], rows[r].Wb[5]);
+            }
+            ball_vel = bv; ball_w = bw;
+            ball_pos = ball_pos + h * bv;
+            ball_rot = qnormalized(quat_exp(h * bw) * ball_rot);
+        }
+    }
+    // the ball's part of a contact row along d: the contact point moving with the ball, negative when the ball is body b
+    void ball_jacobian(const ContactPt& cp, const V3& d, real* Jb) const {
+        for (int k = 0; k < 6; ++k) Jb[k] = 0;
+        if (!cp.ball) return;
+        const real sg = (cp.ball == 2) ? (real)1 : (real)-1;
+        V3 rxd = cross(cp.x - ball_pos, d);
+        Jb[0] = sg * d.x; Jb[1] = sg * d.y; Jb[2] = sg * d.z; Jb[3] = sg * rxd.x; Jb[4] = sg * rxd.y; Jb[5] = sg * rxd.z;
     }
     static Q4 quat_exp(const V3& rv) {     // exact exponential map of a rotation vector
         real th = norm(rv), half = (real)0.5 * th;
@@ -531,6 +596,7 @@ struct Scene {
     void update(double dt) {
         // cRLSceneSimChar::PreUpdate (RLSceneSimChar.cpp:263-275) -> cSceneImitateAMP::NewActionUpdate -> UpdateHist (:166-171)
         if (need_new_action) { prev_pose = reported_pose(); prev_vel = vel; }
+        if (need_new_action && cfg.scene_goal == 5) { prev_ball_pos.x = ball_pos.x; prev_ball_pos.y = ball_pos.y; prev_ball_pos.z = ball_pos.z; }   // cSceneDribbleAMP::NewActionUpdate (:337-341)
         if (need_new_action && cfg.scene_goal) {                     // cDeepMimicCharController::HandleNewAction (DeepMimicCharController.cpp:262-267)
             calc_links(sk, pose, vel, links);
             V3 c = sim_com(); prev_action_com.x = c.x; prev_action_com.y = c.y; prev_action_com.z = c.z;
@@ -574,9 +640,34 @@ struct Scene {
         for (int j = 0; j < sk.J; ++j) if (sk.valid_body(j)) { c += (real)sk.mass(j) * links[j].com; tm += (real)sk.mass(j); }
         return c / tm;
     }
-    bool target_like() const { return cfg.scene_goal == 1 || cfg.scene_goal == 4; }
+    bool target_like() const { return cfg.scene_goal == 1 || cfg.scene_goal == 4 || cfg.scene_goal == 5; }
+    // ---- dribble_amp: the ball as target object (SceneDribbleAMP.cpp:422-440, 493-508)
+    void obj_timer_reset() { obj_timer = 0; obj_timer_max = goal_uniform(cfg.tar_obj_time_min, cfg.tar_obj_time_max); }
+    void reset_tar_objs() {
+        const double r = goal_uniform(cfg.min_tar_obj_dist, cfg.max_tar_obj_dist), theta = goal_uniform(-3.141592653589793, 3.141592653589793);
+        const double px = (double)pose[0] + r * std::cos(theta), pz = (double)pose[2] + r * std::sin(theta);
+        // SetTarObjPos: on the ground, a random orientation, at rest
+        double ax = goal_uniform(-1, 1), ay = goal_uniform(-1, 1), az = goal_uniform(-1, 1);
+        const double an = std::sqrt(ax * ax + ay * ay + az * az), th = goal_uniform(-3.141592653589793, 3.141592653589793);
+        ball_pos = V3((real)px, (real)cfg.ball_radius, (real)pz);
+        ball_rot = quat_axis_angle(V3((real)(ax / an), (real)(ay / an), (real)(az / an)), (real)th);
+        ball_vel = V3(); ball_w = V3();
+        prev_ball_pos.x = ball_pos.x; prev_ball_pos.y = ball_pos.y; prev_ball_pos.z = ball_pos.z;      // ResetAgentTarObjRecord
+    }
+    bool tar_obj_dist_fail() const {                                 // CheckTarObjDistFail (:351-364)
+        const real dx = (real)tar_pos.x - ball_pos.x, dz = (real)tar_pos.z - ball_pos.z, thr = 2 * (real)cfg.max_target_dist;
+        return dx * dx + dz * dz > thr * thr;
+    }
+    bool char_obj_dist_fail() const {                                // CheckCharObjDistFail (:366-379)
+        const real dx = ball_pos.x - pose[0], dz = ball_pos.z - pose[2], thr = 2 * (real)cfg.max_tar_obj_dist;
+        return dx * dx + dz * dz > thr * thr;
+    }
+    bool dribble_succ() const {                                      // CheckTargetSucc (:454-464)
+        const real dx = (real)tar_pos.x - ball_pos.x, dz = (real)tar_pos.z - ball_pos.z;
+        return dx * dx + dz * dz < (real)cfg.target_succ_dist * (real)cfg.target_succ_dist;
+    }
     bool heading_like() const { return cfg.scene_goal == 2 || cfg.scene_goal == 3; }
-    int goal_dim() const { return cfg.scene_goal >= 3 ? 4 : 3; }
+    int goal_dim() const { return (cfg.scene_goal == 3 || cfg.scene_goal == 4) ? 4 : 3; }
     bool getting_up() const { return cfg.scene_goal == 3 && !(getup_timer >= cfg.getup_time); }   // CheckGettingUp (:301-304): !mGetupTimer.IsEnd()
     void goal_reset_target_pos() {
         if (cfg.scene_goal == 4) {                                   // cSceneStrikeAMP::ResetTargetPos / ...Far / ...Near (:318-374)
@@ -586,6 +677,11 @@ struct Scene {
             const double dist = far ? goal_uniform(cfg.target_min[2], cfg.max_target_dist) : goal_uniform(cfg.target_min[2], cfg.target_max[2]);
             tar_pos.x = dist * std::cos(theta) + (double)pose[0]; tar_pos.y = hgt; tar_pos.z = dist * -std::sin(theta) + (double)pose[2];
             set_target_hit(false);
+            return;
+        }
+        if (cfg.scene_goal == 5) {                                   // cSceneDribbleAMP::SampleRandTargetPos (:510-524): around the ball
+            const double r = goal_uniform(cfg.ball_radius, cfg.max_target_dist), theta = goal_uniform(-3.141592653589793, 3.141592653589793);
+            tar_pos.x = (double)ball_pos.x + r * std::cos(theta); tar_pos.y = 0; tar_pos.z = (double)ball_pos.z + r * std::sin(theta);
             return;
         }
         // cSceneTargetAMP::SampleRandTargetPos (:285-299)
@@ -624,6 +720,11 @@ struct Scene {
         return true;
     }
     void goal_update(double dt) {                                    // cSceneTargetAMP::UpdateTarget (:253-268) + cSceneHeadingAMP::UpdateTarget (:214-228)
+        if (cfg.scene_goal == 5) {                                   // cSceneDribbleAMP::UpdateObjs (:310-319) inside the scene update
+            obj_timer += dt;
+            const bool oend = obj_timer >= obj_timer_max;
+            if (oend) { reset_tar_objs(); obj_timer_reset(); }
+        }
         tar_timer += dt;
         const bool end = tar_timer >= tar_timer_max;
         if (end && cfg.scene_goal != 4) goal_reset_target_pos();     // cSceneStrikeAMP::CheckTargetReset is false (:385-388)
@@ -666,7 +767,13 @@ struct Scene {
     void record_goal(double* out) const {
         Vec rp = reported_pose();
         real heading = calc_heading(root_rot(rp));
-        if (cfg.scene_goal == 1) {                                   // cSceneTargetAMP::RecordGoal (:195-223)
+        if (cfg.scene_goal == 5) {                                   // cSceneDribbleAMP::RecordGoal (:276-302): ball -> target in the origin frame
+            V3 rel((real)tar_pos.x - ball_pos.x, 0, (real)tar_pos.z - ball_pos.z);
+            real d = norm(rel);
+            V3 r(1, 0, 0);
+            if (d > (real)0.0001) r = (origin_trans(rp).R * rel) / d;
+            out[0] = r.x; out[1] = r.z; out[2] = d;
+        } else if (cfg.scene_goal == 1) {                            // cSceneTargetAMP::RecordGoal (:195-223)
             V3 rel((real)tar_pos.x - rp[0], 0, (real)tar_pos.z - rp[2]);
             real d = norm(rel);
             V3 r(1, 0, 0);
@@ -689,6 +796,7 @@ struct Scene {
             return (real)0.2 * nr + (real)0.8 * nh;
         }
         if (cfg.scene_goal == 4) return calc_strike_reward();
+        if (cfg.scene_goal == 5) return calc_dribble_reward();
         if (has_fallen()) return 0;
         V3 com = sim_com();
         V3 dcom(com.x - (real)prev_action_com.x, com.y - (real)prev_action_com.y, com.z - (real)prev_action_com.z);
@@ -715,6 +823,32 @@ struct Scene {
         real vel_err = ts - avg_speed;
         if (cfg.enable_min_tar_vel) vel_err = std::max(vel_err, (real)0);
         return std::exp(-(real)cfg.vel_reward_scale * vel_err * vel_err);
+    }
+    // cSceneDribbleAMP::CalcReward (:6-122)
+    double calc_dribble_reward() const {
+        if (cfg.mode_test) {
+            if (is_episode_end() && check_terminate() == TERM_SUCC) return timer_max - timer_time;
+            return 0;
+        }
+        if (has_fallen()) return 0;
+        const real ts = (real)tar_speed, te = (real)(ctrl_time - prev_action_time);
+        V3 com = sim_com();
+        V3 pac((real)prev_action_com.x, (real)prev_action_com.y, (real)prev_action_com.z), pbp((real)prev_ball_pos.x, (real)prev_ball_pos.y, (real)prev_ball_pos.z);
+        V3 tp((real)tar_pos.x, (real)tar_pos.y, (real)tar_pos.z);
+        V3 com_delta = com - pac, com_ball_delta = ball_pos - pac; com_delta.y = 0; com_ball_delta.y = 0;
+        real cbn = norm(com_ball_delta);
+        V3 com_ball_dir = com_ball_delta / cbn;                      // Eigen normalized(): no guard in the reference either
+        real com_ball_dist = norm2(com_ball_delta);
+        real com_ball_vel = dot(com_ball_dir, com_delta) / te;
+        real cbv_err = std::min((real)0, com_ball_vel - ts); cbv_err *= cbv_err;
+        V3 ball_delta = ball_pos - pbp, ball_target_delta = tp - pbp; ball_delta.y = 0; ball_target_delta.y = 0;
+        V3 ball_target_dir = ball_target_delta / norm(ball_target_delta);
+        real btv = dot(ball_target_dir, ball_delta) / te;
+        real tv_err = std::min((real)0, btv - ts); tv_err *= tv_err;
+        real cur_bt_dist = norm2(tp - ball_pos), tp_err = std::sqrt(cur_bt_dist);
+        real r0 = std::exp(-(real)1.5 * cbv_err), r1 = std::exp(-(real)0.5 * com_ball_dist), r2 = std::exp(-(real)1 * tv_err), r3 = std::exp(-(real)0.5 * tp_err);
+        if (cur_bt_dist < (real)cfg.target_succ_dist * (real)cfg.target_succ_dist && com_ball_dist < (real)4) r0 = r1 = r2 = r3 = 1;
+        return (real)0.1 * r0 + (real)0.1 * r1 + (real)0.3 * r2 + (real)0.5 * r3;
     }
     // cSceneStrikeAMP::CalcReward (:9-187)
     double calc_strike_reward() const {
@@ -776,6 +910,7 @@ struct Scene {
     }
     bool has_fallen() const {
         bool f = has_fallen_contact();
+        if (cfg.scene_goal == 5) f = f || tar_obj_dist_fail() || char_obj_dist_fail();   // cSceneDribbleAMP::HasFallen (:343-349)
         if (cfg.enable_root_rot_fail) f |= quat_diff_theta(root_rot(pose), root_rot(kin.pose)) > (real)0.5 * kPi;   // SceneImitate.cpp:484-492
         return f;
     }
@@ -784,6 +919,7 @@ struct Scene {
         // cSceneImitateAMP::CheckTerminate (SceneImitateAMP.cpp:184-188) keeps only the fall test of cRLSceneSimChar (:187-197)
         if (!fail && !cfg.scene_amp && kin.mo->is_over(kin.time)) fail = true;   // SceneImitate.cpp:193-205
         if (!fail && cfg.scene_goal && goal_dist_fail()) fail = true;            // cSceneTargetAMP::CheckTerminate (:319-345)
+        if (!fail && cfg.scene_goal == 5 && dribble_succ()) return TERM_SUCC;    // cSceneDribbleAMP::CheckTerminateTarget (:466-475)
         if (!fail && cfg.scene_goal == 4) {                                       // cSceneStrikeAMP::CheckTerminateTarget (:522-541)
             if (tar_contact_fail()) fail = true;
             else if (tar_hit_succ()) return TERM_SUCC;
@@ -888,6 +1024,13 @@ struct Scene {
             if (!cfg.record_world_root_rot || i != 0) { v = ot.R * v; w = ot.R * w; }
             out[idx] = v.x; out[idx + 1] = v.y; out[idx + 2] = v.z; out[idx + 3] = w.x; out[idx + 4] = w.y; out[idx + 5] = w.z;
             idx += 6;
+        }
+        if (cfg.scene_goal == 5) {                                   // cSceneDribbleAMP::RecordTaskState (:554-590)
+            V3 p = ball_pos; p.y -= ground_h; p = xf_point(ot, p);
+            Q4 q = oq * ball_rot;
+            V3 nrm = qrot(q, V3(0, 1, 0)), tan = qrot(q, V3(1, 0, 0)), v = qrot(oq, ball_vel), w = qrot(oq, ball_w);
+            const real t15[15] = { p.x, p.y, p.z, nrm.x, nrm.y, nrm.z, tan.x, tan.y, tan.z, v.x, v.y, v.z, w.x, w.y, w.z };
+            for (int k = 0; k < 15; ++k) out[idx++] = t15[k];
         }
         assert(idx == S);
     }

@@ -5,6 +5,10 @@ import subprocess
 
 import numpy as np
 
+import sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from deepmimic_amd import model  # noqa: E402  (scene constants only)
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
 
@@ -17,7 +21,8 @@ CFG_KEYS = ["num_sim_substeps", "world_scale", "grav_x", "grav_y", "grav_z", "sy
             "vel_reward_scale",
             "mode_test", "getup_time", "getup_height_root", "getup_height_head", "head_id", "recover_prob", "getup_clip_mask",
             "tar_near_dist", "tar_far_prob", "target_radius", "hit_reset_time", "init_hit_prob", "hit_tar_speed", "tar_reward_scale",
-            "tmin_x", "tmin_y", "tmin_z", "tmax_x", "tmax_y", "tmax_z", "strike_mask", "fail_tar_mask"]
+            "tmin_x", "tmin_y", "tmin_z", "tmax_x", "tmax_y", "tmax_z", "strike_mask", "fail_tar_mask",
+            "obj_time_min", "obj_time_max", "min_obj_dist", "max_obj_dist", "ball_radius", "ball_mass", "ball_friction", "ball_lin_damp", "ball_ang_damp"]
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int)
@@ -74,7 +79,10 @@ class Oracle:
                     tar_near_dist=c.tar_near_dist, tar_far_prob=c.tar_far_prob, target_radius=c.target_radius, hit_reset_time=c.target_hit_reset_time,
                     init_hit_prob=c.init_hit_prob, hit_tar_speed=c.hit_tar_speed, tar_reward_scale=c.tar_reward_scale,
                     tmin_x=c.target_min[0], tmin_y=c.target_min[1], tmin_z=c.target_min[2], tmax_x=c.target_max[0], tmax_y=c.target_max[1], tmax_z=c.target_max[2],
-                    strike_mask=sum(1 << int(b) for b in (c.strike_bodies or [])), fail_tar_mask=sum(1 << int(b) for b in (c.fail_tar_contact_bodies or [])))
+                    strike_mask=sum(1 << int(b) for b in (c.strike_bodies or [])), fail_tar_mask=sum(1 << int(b) for b in (c.fail_tar_contact_bodies or [])),
+                    obj_time_min=c.rand_tar_obj_time_min, obj_time_max=c.rand_tar_obj_time_max, min_obj_dist=c.min_tar_obj_dist, max_obj_dist=c.max_tar_obj_dist,
+                    ball_radius=c.ball_radius, ball_mass=model.BALL_MASS, ball_friction=model.BALL_FRICTION * 0.9,
+                    ball_lin_damp=model.BALL_LIN_DAMPING, ball_ang_damp=model.BALL_ANG_DAMPING)
         vals.update(cfg_overrides)
         for k, v in vals.items():
             cfg[CFG_KEYS.index(k)] = float(v)
@@ -315,6 +323,16 @@ class Oracle:
         out = np.zeros(15)
         self.lib.orc_goal_state(self.h, _d(out))
         return out if full else out[:12]
+
+    def ball_state(self):
+        """dribble_amp: ball pos(3), rot wxyz(4), vel(3), ang vel(3), ball pos at the last action(3), target-object timer time / max"""
+        out = np.zeros(18)
+        self.lib.orc_ball_state(self.h, _d(out))
+        return out
+
+    def set_ball(self, b13):
+        b = np.ascontiguousarray(b13, dtype=np.float64)
+        self.lib.orc_set_ball(self.h, _d(b))
 
     def maybe_recovery_reset(self, max_time=np.inf):
         return bool(self.lib.orc_maybe_recovery_reset(self.h, C.c_double(max_time)))

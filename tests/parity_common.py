@@ -459,7 +459,8 @@ def goal_rollout_compare(t, precision, lib_path, steps, n, seed, wave_packing=0,
     tmin, tmax = float(t.cfg.time_lim_min), float(t.cfg.time_lim_max)
     if test_mode and t.cfg.time_end_lim_max is not None:
         tmin = tmax = float(t.cfg.time_end_lim_max)
-    has_aux = t.goal_kind >= 3
+    has_aux = t.goal_kind in (3, 4)
+    has_ball = t.goal_kind == 5
 
     def draw(o, e, episode):
         clip = o.draw_clip(streams.reset_rand01(seed, e, episode, 3)) if t.num_clips > 1 else 0
@@ -475,7 +476,7 @@ def goal_rollout_compare(t, precision, lib_path, steps, n, seed, wave_packing=0,
         o.reset_ex(*[(lambda c, k, m, y: (k, m, c, y))(*draw(o, e, int(ep[e]) - 1))][0])
         oracles.append(o)
     w = dict(reward=0.0, state=0.0, goal=0.0, goal_state=0.0, resets=0, live=0, flags_ok=True, clips=set(), dist_fail=0, reward_errs=[], goal_errs=[],
-             aux=0.0, recoveries=0, succ=0, fail=0, aux_steps=0, desynced=0, scored=0)
+             aux=0.0, recoveries=0, succ=0, fail=0, aux_steps=0, desynced=0, scored=0, ball=0.0, ball_moved=0.0)
     dead = np.zeros(n, bool)       # fp32 only: an env whose episode ended at a different update than the oracle's is not scored from there on
     gs = env.get_goal_state(); clips = env.get_clips(); q = env.query(); qg = env.query_goal()
     for e, o in enumerate(oracles):
@@ -489,6 +490,7 @@ def goal_rollout_compare(t, precision, lib_path, steps, n, seed, wave_packing=0,
         out = env.step(acts, DT, 20, auto_reset=True)
         gs = env.get_goal_state(); clips = env.get_clips()
         aux = env.get_goal_aux() if has_aux else None
+        ball = env.get_obj_state() if has_ball else None
         for e, o in enumerate(oracles):
             if dead[e]:
                 continue
@@ -517,6 +519,10 @@ def goal_rollout_compare(t, precision, lib_path, steps, n, seed, wave_packing=0,
             w["goal"] = max(w["goal"], np.abs(out["goal"][e] - o.record_goal()).max())
             w["goal_errs"].append(np.abs(out["goal"][e] - o.record_goal()).max())
             w["goal_state"] = max(w["goal_state"], np.abs(gs[e] - o.goal_state()).max())
+            if has_ball:
+                ob = o.ball_state()
+                w["ball"] = max(w["ball"], np.abs(ball[e] - ob[:13]).max())
+                w["ball_moved"] = max(w["ball_moved"], float(np.abs(ob[7:13]).max()))
             if has_aux:
                 oa = o.goal_state(full=True)[13:15]
                 w["aux"] = max(w["aux"], np.abs(aux[e] - oa).max())

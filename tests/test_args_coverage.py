@@ -64,13 +64,13 @@ def test_imitate_amp_arg_files_run(emu_lib):
         ex = env.amp_expert(3)
         assert np.isfinite(ex).all(), f
         env.close()
-    with pytest.raises(ValueError, match="accelerated path"):        # dribble_amp needs a free rigid body (the ball): out of scope
-        model.load_scene_from_args(["--arg_file", "args/train_amp_dribble_humanoid3d_zombie_args.txt"], data_root=REF)
+    with pytest.raises(ValueError, match="accelerated path"):        # kin_char is a viewer scene without a simulated character
+        model.load_scene_from_args(["--arg_file", "args/play_motion_humanoid3d_args.txt"], data_root=REF)
 
 
 @pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "args")), reason="reference checkout not present")
 def test_goal_scene_arg_files_run(emu_lib):
-    """`--scene heading_amp` / `target_amp` / `heading_amp_getup` / `strike_amp`: every arg file whose dataset
+    """`--scene heading_amp` / `target_amp` / `heading_amp_getup` / `strike_amp` / `dribble_amp`: every arg file whose dataset
     is complete in the reference checkout loads (multi-clip `--kin_ctrl clips`, enable_rand_rot_reset), creates a context, steps,
     and reports its goal vector.  (data/datasets/humanoid3d_clips_locomotion.txt and humanoid3d_clips_walk_punch.txt name clips
     under data/motions/{long,sie,amass} that the checkout does not ship: those arg files cannot load in the reference either.)"""
@@ -84,14 +84,16 @@ def test_goal_scene_arg_files_run(emu_lib):
             t = model.load_scene_from_args(["--arg_file", rel], data_root=REF)
         except FileNotFoundError:
             missing.append(rel); continue
-        assert t.goal_kind in (1, 2, 3, 4) and t.cfg.kin_ctrl == "clips", rel    # (run_* files leave enable_rand_rot_reset off)
+        assert t.goal_kind in (1, 2, 3, 4, 5) and t.cfg.kin_ctrl == "clips", rel    # (run_* files leave enable_rand_rot_reset off)
         env = BatchEnv(t, 2, precision=64, lib_path=emu_lib, seed=1)
+        assert env.S == t.state_dim, rel
         assert env.G == t.goal_dim and env.amp_size > 0, rel
         env.reset()
         out = env.step(np.zeros((2, env.A), np.float32), 1.0 / 600, 2, amp=True)
         assert np.isfinite(out["goal"]).all() and out["goal"].shape == (2, t.goal_dim) and np.isfinite(out["amp_obs"]).all(), rel
         assert np.isfinite(env.amp_expert_clips(3)).all(), rel
         env.close(); ran.append(rel)
-    # 6 heading / target files + the 2 heading_amp_getup files run; 4 locomotion-dataset files and the 2 strike files lack their clips
-    assert len(ran) == 8 and len(missing) == 6, (ran, missing)
-    assert sum("heading_getup" in r for r in ran) == 2 and sum("strike" in r for r in missing) == 2
+    # 6 heading / target files, the 2 heading_amp_getup files and the 2 dribble files over the zombie clip run; the locomotion-dataset
+    # files (4 heading / target + 2 dribble) and the 2 strike files lack their clips
+    assert len(ran) == 10 and len(missing) == 8, (ran, missing)
+    assert sum("heading_getup" in r for r in ran) == 2 and sum("strike" in r for r in missing) == 2 and sum("dribble" in r for r in ran) == 2

@@ -236,6 +236,105 @@ def test_facade_new_goal_scenes(emu_lib, monkeypatch):
         core.Shutdown()
 
 
+# ---- dribble_amp: a free rigid sphere next to the character
+def _ball_setup(lib, prec, n=2, seed=4):
+    """device env + mirrored oracles after a reset at given clip times; the ball is then placed next to the character and kicked at it"""
+    t = model.load_asset("amp_dribble_zombie")
+    env = BatchEnv(t, n, precision=prec, lib_path=lib, wave_packing=1, seed=seed)
+    g0 = env.get_goal_state()
+    kts = [0.2 + 0.3 * e for e in range(n)]
+    env.reset(kin_times=kts)
+    oracles = []
+    for e in range(n):
+        o = Oracle(t); o.goal_rng(seed, e, int(g0[e][11])); o.reset_ex(kts[e], np.inf, 0, 0.0); oracles.append(o)
+    return t, env, oracles
+
+
+def _kick_rollout(lib, prec, steps):
+    t, env, oracles = _ball_setup(lib, prec)
+    st = env.get_state(); ob = env.get_obj_state()
+    assert max(np.abs(ob[e] - o.ball_state()[:13]).max() for e, o in enumerate(oracles)) < 1e-6       # the ball reset draws agree
+    for e, o in enumerate(oracles):
+        root = st["pose"][e][:3]
+        b = np.zeros(13); b[0:3] = [root[0] + 0.5, 0.25 + 0.1 * e, root[2] + 0.05]; b[3] = 1.0; b[7:10] = [-4.0, 0.5, 0.0]; b[10:13] = [0, 0, 3.0]
+        ob[e] = b; o.set_ball(b)
+    env.set_obj_state(ob)
+    rng = np.random.default_rng(1)
+    mx = dict(ball=0.0, reward=0.0, state=0.0, speed=0.0)
+    for k in range(steps):
+        acts = (0.05 * rng.normal(size=(len(oracles), env.A))).astype(np.float32)
+        out = env.step(acts, pc.DT, 20)
+        ob = env.get_obj_state()
+        for e, o in enumerate(oracles):
+            o.set_action(acts[e].astype(np.float64)); o.control_step(20, pc.DT, end_early=False)
+            bs = o.ball_state()
+            mx["ball"] = max(mx["ball"], np.abs(ob[e] - bs[:13]).max()); mx["reward"] = max(mx["reward"], abs(out["reward"][e] - o.calc_reward()))
+            so = o.record_state(); mx["state"] = max(mx["state"], np.abs(out["state"][e] - so).max() / max(1.0, np.abs(so).max()))
+            mx["speed"] = max(mx["speed"], float(np.abs(bs[7:10]).max()))
+    return mx
+
+
+def test_ball_physics_closed_form(oracle_built):
+    """the free sphere of the oracle: free fall, rest on the ground at y = r, sliding turns into rolling without slipping
+    (v = omega x r), damping (1 - 0.4)^t on both velocities"""
+    t = model.load_asset("amp_dribble_zombie")
+    assert (t.goal_kind, t.goal_dim, t.state_dim) == (5, 3, 226 + 15)
+    o = Oracle(t); o.goal_rng(3, 0, 0); o.reset_ex(0.3, np.inf, 0, 0.0)
+    b = o.ball_state()[:13].copy()
+    assert abs(b[1] - 0.2) < 1e-12 and np.abs(b[7:13]).max() == 0 and abs(np.linalg.norm(b[3:7]) - 1) < 1e-12
+    b[0] += 30.0; b[1] = 1.0; b[7:13] = [1.0, 0, 0, 0, 0, 0]; o.set_ball(b)                # far from the character
+    o.set_action(np.zeros(o.A))
+    for _ in range(120): o.update(pc.DT)                                               # 0.2 s of free fall
+    bs = o.ball_state()
+    assert abs(bs[8] - (-9.8 * 0.2)) < 0.25 and abs(bs[7] - 0.6 ** 0.2) < 1e-3       # v_y ~ -g t (with damping), v_x = 0.6^t
+    for _ in range(1200): o.update(pc.DT)                                              # lands, slides, rolls
+    bs = o.ball_state()
+    assert abs(bs[1] - 0.2) < 2e-3 and abs(bs[8]) < 1e-3                               # rests on the ground
+    assert bs[7] > 0.05 and abs(bs[12] + bs[7] / 0.2) < 1e-3 * abs(bs[12])              # rolling: omega_z = -v_x / r
+    # the 15 task-state entries: position in the origin frame, unit normal / tangent, velocities
+    ts = o.record_state()[-15:]
+    assert abs(np.linalg.norm(ts[3:6]) - 1) < 1e-9 and abs(np.linalg.norm(ts[6:9]) - 1) < 1e-9 and abs(np.dot(ts[3:6], ts[6:9])) < 1e-9
+    assert abs(np.linalg.norm(ts[9:12]) - np.linalg.norm(bs[7:10])) < 1e-9
+
+
+@pytest.mark.parametrize("test_mode", [False, True])
+def test_dribble_scene_matches_oracle_emulator(emu_lib, test_mode):
+    t = model.load_asset("amp_dribble_zombie")
+    w = pc.goal_rollout_compare(t, 64, emu_lib, steps=24, n=2, seed=5, wave_packing=1, test_mode=test_mode)
+    print(w)
+    assert w["flags_ok"] and w["ball"] < 1e-9 and w["reward"] < 1e-6 and w["goal"] < 1e-5 and w["goal_state"] < 1e-6 and w["state"] < 1e-5
+    assert w["resets"] >= 1 or test_mode
+
+
+def test_ball_kick_matches_oracle_emulator(emu_lib):
+    """the ball thrown at the character's legs: contacts between the free body and the links, the shared constraint solve"""
+    mx = _kick_rollout(emu_lib, 64, 8)
+    print(mx)
+    assert mx["speed"] > 5.0 and mx["ball"] < 1e-8 and mx["reward"] < 1e-6 and mx["state"] < 1e-5
+
+
+def test_dribble_facade_and_refusals(emu_lib, monkeypatch):
+    import os, sys
+    compat = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "deepmimic_amd", "compat")
+    if compat not in sys.path:
+        sys.path.insert(0, compat)
+    from DeepMimicCore import DeepMimicCore
+    monkeypatch.setenv("DM_HIP_LIB", emu_lib); monkeypatch.setenv("DM_PRECISION", "64")
+    core = DeepMimicCore.cDeepMimicCore(False)
+    core.SeedRand(2); core.LoadTables(model.load_asset("amp_dribble_zombie"), 10); core.Init()
+    assert core.GetName() == "Dribble AMP" and core.GetGoalSize(0) == 3 and core.GetStateSize(0) == 241
+    assert len(core.BuildStateOffset(0)) == 241 and core.BuildStateNormGroups(0)[-15:] == [0] * 15 and core.BuildStateScale(0)[-15:] == [1.0] * 15
+    s0 = core.RecordState(0)
+    assert len(s0) == 241 and np.isfinite(s0).all() and abs(np.linalg.norm(s0[-12:-9]) - 1) < 1e-5
+    core.SetAction(0, [0.0] * core.GetActionSize(0))
+    for _ in range(20):
+        core.Update(1.0 / 600)
+    assert np.isfinite(core.CalcReward(0)) and len(core.RecordGoal(0)) == 3
+    core.Shutdown()
+    with pytest.raises(RuntimeError, match="one character per wavefront"):
+        BatchEnv(model.load_asset("amp_dribble_zombie"), 2, lib_path=emu_lib, wave_packing=2)
+
+
 # ---- the HIP kernels
 @pytest.mark.gpu
 @pytest.mark.parametrize("name,prec,pack", [("amp_heading_zombie", 64, 1), ("amp_target_zombie", 64, 2), ("amp_heading_zombie", 32, 2),
@@ -335,3 +434,36 @@ def test_new_goal_scenes_4096(hip_lib):
         assert ends > 0 and out["reward"].mean() > 0.01
         if t.goal_kind == 3:
             assert np.abs(np.linalg.norm(out["goal"][:, :2], axis=1) - 1).max() < 1e-4 and (out["goal"][:, 3] > 0).mean() > 0.2   # half the clips are get-ups
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prec", [64, 32])
+def test_dribble_scene_gpu(hip_lib, prec):
+    """dribble_amp on the HIP kernels: the scene through resets, and the ball kicked at the character"""
+    t = model.load_asset("amp_dribble_zombie")
+    w = pc.goal_rollout_compare(t, prec, hip_lib, steps=60, n=8, seed=5, wave_packing=1)
+    print(prec, w)
+    assert (w["flags_ok"] or (prec == 32 and w["scored"] >= 360)) and w["resets"] >= 2
+    assert w["reward_mean"] < (1e-5 if prec == 64 else 2e-3) and w["ball"] < (1e-6 if prec == 64 else 2e-2)
+    mx = _kick_rollout(hip_lib, prec, 8)
+    print(prec, mx)
+    assert mx["speed"] > 5.0 and mx["ball"] < (1e-6 if prec == 64 else 5e-2) and mx["reward"] < (1e-5 if prec == 64 else 5e-3)
+
+
+@pytest.mark.gpu
+def test_dribble_4096(hip_lib):
+    """4096 envs of dribble_amp, random actions, auto-reset: finite outputs, rewards in [0, 1], unit goal directions, balls on or above the ground"""
+    t = model.load_asset("amp_dribble_zombie")
+    env = BatchEnv(t, 4096, seed=8)
+    env.reset()
+    rng = np.random.default_rng(0)
+    ends = 0
+    for k in range(30):
+        out = env.step((0.2 * rng.normal(size=(4096, env.A))).astype(np.float32), pc.DT, 20, auto_reset=True, amp=True)
+        assert out["state"].shape == (4096, 241) and np.isfinite(out["state"]).all() and np.isfinite(out["goal"]).all()
+        assert (out["reward"] >= 0).all() and (out["reward"] <= 1 + 1e-6).all()
+        assert np.abs(np.linalg.norm(out["goal"][:, :2], axis=1) - 1).max() < 1e-4
+        ends += int(out["episode_end"].sum())
+    ob = env.get_obj_state()
+    assert ends > 0 and np.isfinite(ob).all() and (ob[:, 1] > 0.15).all() and np.abs(np.linalg.norm(ob[:, 3:7], axis=1) - 1).max() < 1e-4
+    assert np.abs(ob[:, 7:10]).max() > 0.1           # some balls have been kicked

@@ -28,6 +28,8 @@ SCENES = {
     "amp_heading_getup": ("args/train_amp_heading_getup_humanoid3d_locomotion_getup_args.txt", None),
     # strike_amp: the shipped dataset (humanoid3d_clips_walk_punch.txt) names sie / amass clips that are not in the repository; the scene
     # keys are the arg file's, the dataset is a stand-in made of the two shipped clips of the same kind (tools/datasets/)
+    # dribble_amp: the ball is a free rigid sphere in the world
+    "amp_dribble_zombie": ("args/train_amp_dribble_humanoid3d_zombie_args.txt", None),
     "amp_strike_punch": ("args/train_amp_strike_humanoid3d_walk_punch_args.txt",
                          ["--motion_file", os.path.join(os.path.dirname(os.path.abspath(__file__)), "datasets", "humanoid3d_clips_walk_punch_local.txt")]),
 }

@@ -194,6 +194,8 @@ class cDeepMimicCore(object):
         self._env.set_state(pose=snap["pose"], vel=snap["vel"], tar=snap["tar"], kin=snap["kin"], clocks=snap["clocks"], flags=snap["flags"])
         if "goal" in snap:                   # goal scenes: target / timers / draw counter / get-up or hit state of the same moment
             self._env.set_goal_state(snap["goal"]); self._env.set_goal_aux(snap["aux"])
+            if "obj" in snap:
+                self._env.set_obj_state(snap["obj"])       # dribble_amp: the ball
         self._clk = dict(sp["clk0"])
         out = None
         for i in range(sp["v"]):
@@ -235,6 +237,8 @@ class cDeepMimicCore(object):
             snap = env.get_state() if snap is None else snap
             if self._goal_size():
                 snap["goal"] = env.get_goal_state(); snap["aux"] = env.get_goal_aux()
+                if self._tables.goal_kind == 5:
+                    snap["obj"] = env.get_obj_state()
             clk0 = dict(self._clk)
             out = self._launch(action, dt, k, True)
             t1 = float(env.get_state()["clocks"][0][3])

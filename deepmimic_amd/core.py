@@ -236,13 +236,14 @@ class BatchEnv:
         self._chk(self.lib.dm_set_mode(self.h, int(bool(test_mode))))
 
     def get_goal_aux(self):
-        """N x 2: heading_amp_getup {get-up timer, -}; strike_amp {target hit, hit time}"""
-        out = np.zeros((self.N, 2))
+        """N x 8: [0:2] heading_amp_getup {get-up timer, -} / strike_amp {target hit, hit time}; [2:7] dribble_amp {ball position at the
+        last action, target-object timer time / limit}"""
+        out = np.zeros((self.N, 8))
         self._chk(self.lib.dm_get_goal_aux(self.h, _dp(out)))
         return out
 
     def set_goal_aux(self, aux):
-        aux = np.ascontiguousarray(aux, dtype=np.float64).reshape(self.N, 2)
+        aux = np.ascontiguousarray(aux, dtype=np.float64).reshape(self.N, 8)
         self._chk(self.lib.dm_set_goal_aux(self.h, _dp(aux)))
 
     def get_obj_state(self):

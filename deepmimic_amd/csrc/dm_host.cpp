@@ -520,9 +520,9 @@ struct CtxT : CtxBase {
         if (!st.goal) return fail("no goal state: not a goal scene / multi-clip dataset");
         std::vector<double> g((size_t)N * GS_WIDTH);
         if (rt_d2h(g.data(), st.goal, sizeof(double) * g.size(), stream) != 0) return fail("device to host copy failed");
-        if (out) for (int e = 0; e < N; ++e) { out[(size_t)e * 2] = g[(size_t)e * GS_WIDTH + GS_AUX0]; out[(size_t)e * 2 + 1] = g[(size_t)e * GS_WIDTH + GS_AUX1]; }
+        if (out) for (int e = 0; e < N; ++e) for (int k = 0; k < 8; ++k) out[(size_t)e * 8 + k] = (GS_AUX0 + k < GS_WIDTH) ? g[(size_t)e * GS_WIDTH + GS_AUX0 + k] : 0.0;
         if (in) {
-            for (int e = 0; e < N; ++e) { g[(size_t)e * GS_WIDTH + GS_AUX0] = in[(size_t)e * 2]; g[(size_t)e * GS_WIDTH + GS_AUX1] = in[(size_t)e * 2 + 1]; }
+            for (int e = 0; e < N; ++e) for (int k = 0; k < 8; ++k) if (GS_AUX0 + k < GS_WIDTH) g[(size_t)e * GS_WIDTH + GS_AUX0 + k] = in[(size_t)e * 8 + k];
             if (rt_h2d(st.goal, g.data(), sizeof(double) * g.size(), stream) != 0) return fail("host to device copy failed");
         }
         return 0;

@@ -161,8 +161,9 @@ int dm_last_goals(dm_ctx* ctx, float* goals);
  * target timer max, COM at the last action(3), controller time of the last action, draws consumed so far.  NULL = leave as is. */
 int dm_get_goal_state(dm_ctx* ctx, double* out);
 int dm_set_goal_state(dm_ctx* ctx, const double* in);
-/* the scene-specific part of the goal state, N x 2 doubles: heading_amp_getup {get-up timer time, unused}; strike_amp {target hit
- * (0 / 1), scene time of the hit (-1 = none)} */
+/* the scene-specific part of the goal state, N x 8 doubles: [0..1] heading_amp_getup {get-up timer time, unused}; strike_amp {target hit
+ * (0 / 1), scene time of the hit (-1 = none)}; [2..6] dribble_amp {ball position at the last action (3), target-object timer time, limit};
+ * [7] reserved */
 int dm_get_goal_aux(dm_ctx* ctx, double* out);
 int dm_set_goal_aux(dm_ctx* ctx, const double* in);
 /* cRLScene::SetMode (DeepMimicCore.cpp SetMode -> scene): 0 train, 1 test.  Only the goal scenes read it on the device (get-up on a

@@ -491,6 +491,7 @@ def goal_rollout_compare(t, precision, lib_path, steps, n, seed, wave_packing=0,
         gs = env.get_goal_state(); clips = env.get_clips()
         aux = env.get_goal_aux() if has_aux else None
         ball = env.get_obj_state() if has_ball else None
+        baux = env.get_goal_aux() if has_ball else None
         for e, o in enumerate(oracles):
             if dead[e]:
                 continue
@@ -521,11 +522,11 @@ def goal_rollout_compare(t, precision, lib_path, steps, n, seed, wave_packing=0,
             w["goal_state"] = max(w["goal_state"], np.abs(gs[e] - o.goal_state()).max())
             if has_ball:
                 ob = o.ball_state()
-                w["ball"] = max(w["ball"], np.abs(ball[e] - ob[:13]).max())
+                w["ball"] = max(w["ball"], np.abs(ball[e] - ob[:13]).max(), np.abs(baux[e][2:7] - ob[13:18]).max())
                 w["ball_moved"] = max(w["ball_moved"], float(np.abs(ob[7:13]).max()))
             if has_aux:
                 oa = o.goal_state(full=True)[13:15]
-                w["aux"] = max(w["aux"], np.abs(aux[e] - oa).max())
+                w["aux"] = max(w["aux"], np.abs(aux[e][:2] - oa).max())
                 w["aux_steps"] += int((t.goal_kind == 3 and out["goal"][e][3] > 0) or (t.goal_kind == 4 and oa[0] != 0))
     w["reward_mean"] = float(np.mean(w.pop("reward_errs"))); w["goal_mean"] = float(np.mean(w.pop("goal_errs")))
     return w

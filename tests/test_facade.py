@@ -213,6 +213,41 @@ def test_batched_control_step_equals_update_by_update(emu_lib, monkeypatch):
     assert any(x[0] == "e" for x in runs["1"][0])                    # an episode ended inside the window
 
 
+@pytest.mark.parametrize("asset", ["amp_dribble_zombie", "amp_heading_getup", "amp_strike_punch"])
+def test_batched_control_step_equals_update_by_update_goal_scenes(emu_lib, monkeypatch, asset):
+    """the same for the task scenes: a rollback has to bring back the goal row (target, timers, draw counter, get-up / hit state) and,
+    for dribble_amp, the ball -- RecordGoal is part of what the driver sees"""
+    from deepmimic_amd import model
+    mod = _core_module()
+    monkeypatch.setenv("DM_HIP_LIB", emu_lib); monkeypatch.setenv("DM_PRECISION", "64")
+    t = model.load_asset(asset)
+    t.cfg.time_lim_min = t.cfg.time_lim_max = t.cfg.time_end_lim_min = t.cfg.time_end_lim_max = 0.175
+    runs = {}
+    for batch in ("1", "0"):
+        monkeypatch.setenv("DM_FACADE_BATCH", batch)
+        core = mod.cDeepMimicCore(False)
+        core.SeedRand(4); core.LoadTables(t, 10); core.Init()
+        rng = np.random.default_rng(3)
+        seen = []
+        for u in range(150):
+            if core.NeedNewAction(0):
+                seen.append((np.array(core.RecordState(0)), np.array(core.RecordGoal(0)), core.CalcReward(0)))
+                core.SetAction(0, [float(x) for x in (0.2 * rng.normal(size=core.GetActionSize(0))).astype(np.float32)])
+            core.Update(1.0 / 600)
+            if u in (47, 91):
+                seen.append((np.array(core.RecordState(0)), np.array(core.RecordGoal(0)), core.CalcReward(0)))
+            end = core.IsEpisodeEnd()
+            seen.append((np.array([float(end), core.CheckTerminate(0), core.GetTime()]), np.zeros(1), 0.0))
+            if end:
+                core.Reset()
+        runs[batch] = (seen, dict(core.stats))
+        core.Shutdown()
+    assert len(runs["1"][0]) == len(runs["0"][0])
+    for x, y in zip(runs["1"][0], runs["0"][0]):
+        assert np.array_equal(x[0], y[0]) and np.array_equal(x[1], y[1]) and x[2] == y[2]
+    assert runs["1"][1]["rollbacks"] == 2 and runs["1"][1]["launches"] < runs["0"][1]["launches"] // 3
+
+
 def test_imitate_amp_time_warp_test_return(emu_lib, monkeypatch):
     """cSceneImitateAMP::CalcReward in test mode = the time-warp alignment cost at the episode end (SceneImitateAMP.cpp:173-205):
     0 while the episode runs; at the end DTW(sim joints, kin joints) over the action-boundary samples + 1 per step the episode

@@ -644,6 +644,8 @@ int dm_create(const dm_create_info* info, const dm_scene_tables* tables, dm_ctx*
     if (tables->scene_goal == 3 && !(tables->getup_time > 0)) return fail("heading_amp_getup needs getup_time > 0 (the longest get-up clip)");
     if (tables->scene_goal == 3 && (tables->head_id < 0 || tables->head_id >= tables->num_joints)) return fail("head_id out of range");
     if (tables->scene_goal == 4 && tables->strike_mask == 0) return fail("strike_amp needs at least one strike body");
+    if (tables->scene_goal == 4 && tables->num_joints < 31 && (((unsigned)tables->strike_mask | (unsigned)tables->fail_tar_mask) >> tables->num_joints) != 0) return fail("strike_amp: strike / fail body id out of range");
+    if (tables->scene_goal == 3 && tables->num_clips < 31 && ((unsigned)tables->getup_clip_mask >> (tables->num_clips > 0 ? tables->num_clips : 1)) != 0) return fail("heading_amp_getup: getup_motion_ids out of range");
     if (tables->num_sim_substeps < 1) return fail("num_sim_substeps must be >= 1");
     int precision = info->precision ? info->precision : 32;
     if (precision != 32 && precision != 64) return fail("precision must be 32 or 64");

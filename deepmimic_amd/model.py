@@ -248,6 +248,8 @@ class SceneTables:
     def getup_clip_mask(self) -> int:
         m = 0
         for i in (self.cfg.getup_motion_ids or []):
+            if not 0 <= int(i) < min(self.num_clips, 31):
+                raise ValueError("getup_motion_ids: %r is not a clip of the dataset (%d clips)" % (i, self.num_clips))
             m |= 1 << int(i)
         return m
 

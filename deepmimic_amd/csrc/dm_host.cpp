@@ -42,6 +42,7 @@ static int rt_d2h(void* h, const void* d, size_t n, rt_stream) { memcpy(h, d, n)
 static int rt_memset(void* d, int v, size_t n, rt_stream) { memset(d, v, n); return 0; }
 static int rt_sync(rt_stream) { return 0; }
 #define RT_LAUNCH(kern, grid, stream, ...) emu::launch((unsigned)(grid), 64, [&]() { kern(__VA_ARGS__); })
+#define RT_LAUNCH4(kern, grid, stream, ...) emu::launch((unsigned)(grid), 256, [&]() { kern(__VA_ARGS__); })
 #else
 typedef hipStream_t rt_stream;
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
@@ -53,6 +54,7 @@ static int rt_d2h(void* h, const void* d, size_t n, rt_stream s) { if (hipMemcpy
 static int rt_memset(void* d, int v, size_t n, rt_stream s) { return hipMemsetAsync(d, v, n, s) == hipSuccess ? 0 : -1; }
 static int rt_sync(rt_stream s) { return hipStreamSynchronize(s) == hipSuccess ? 0 : -1; }
 #define RT_LAUNCH(kern, grid, stream, ...) hipLaunchKernelGGL(kern, dim3((unsigned)(grid)), dim3(64), 0, stream, __VA_ARGS__)
+#define RT_LAUNCH4(kern, grid, stream, ...) hipLaunchKernelGGL(kern, dim3((unsigned)(grid)), dim3(256), 0, stream, __VA_ARGS__)   // four wavefronts per workgroup
 #endif
 
 // Every C-ABI entry point runs with the ctx's device current (and restores the caller's): a process may hold contexts on

@@ -75,8 +75,20 @@ int dm_policy_forward(dm_policy* p, const float* states_dev, int n, float* actio
     const dmp::PolicyDev& d = p->pd;
     // tiles sized so that every launch has at least ~1 wave per SIMD at 4096 rows: 64 x 64 (layer 1), 32 x 64 (layer 2), 16 x 32 (layer 3)
     RT_LAUNCH(dmp::k_policy_prep, n, stream, d, io);
-    RT_LAUNCH((dmp::k_policy_layer<0, 4, 4>), ((n + 63) / 64) * (d.H1 / 64), stream, d, io);
-    RT_LAUNCH((dmp::k_policy_layer<1, 2, 4>), ((n + 31) / 32) * (d.H2 / 64), stream, d, io);
+    // layers 1 and 2: the LDS-tiled four-wave GEMM when the width allows it, the one-wave kernel otherwise
+    const bool tiled = (getenv("DM_POLICY_ONE_WAVE") == nullptr);
+    // 64-row tiles by default (measured: 45 / 82 us at 4096 / 16384 rows against 56 / 85 us with 128-row tiles: more workgroups per CU hide more
+    // of the L2 latency than the bigger tile saves in traffic); DM_POLICY_TILE=128 selects the tall tile
+    bool big1 = false, big2 = false;
+    if (const char* tl = getenv("DM_POLICY_TILE")) big1 = big2 = (atoi(tl) == 128);
+    if (tiled && d.H1 % 128 == 0) {
+        if (big1) RT_LAUNCH4((dmp::k_policy_gemm<0, 128>), ((n + 127) / 128) * (d.H1 / 128), stream, d, io);
+        else RT_LAUNCH4((dmp::k_policy_gemm<0, 64>), ((n + 63) / 64) * (d.H1 / 128), stream, d, io);
+    } else RT_LAUNCH((dmp::k_policy_layer<0, 4, 4>), ((n + 63) / 64) * (d.H1 / 64), stream, d, io);
+    if (tiled && d.H2 % 128 == 0) {
+        if (big2) RT_LAUNCH4((dmp::k_policy_gemm<1, 128>), ((n + 127) / 128) * (d.H2 / 128), stream, d, io);
+        else RT_LAUNCH4((dmp::k_policy_gemm<1, 64>), ((n + 63) / 64) * (d.H2 / 128), stream, d, io);
+    } else RT_LAUNCH((dmp::k_policy_layer<1, 2, 4>), ((n + 31) / 32) * (d.H2 / 64), stream, d, io);
     RT_LAUNCH((dmp::k_policy_layer<2, 1, 2>), (n + 15) / 16, stream, d, io);   // one workgroup per 16 rows owns all N3 columns (logp is a row sum)
 #ifndef DM_EMU
     hipError_t le = hipGetLastError(); if (le != hipSuccess) return fail(std::string("kernel launch failed: ") + hipGetErrorString(le));

@@ -33,6 +33,23 @@ def test_policy_emulator_matches_bf16_reference(emu_lib):
     assert np.allclose(lp, -w["logstd"].sum() - 0.5 * A * np.log(2 * np.pi), atol=1e-5)
 
 
+def test_policy_emulator_tiled_gemm_and_one_wave_kernels_agree(emu_lib, monkeypatch):
+    """widths that are multiples of 128 take the LDS-tiled four-wave GEMM (k_policy_gemm): both layers tiled, a row count that leaves
+    ragged 128-row blocks; the one-wave kernels (DM_POLICY_ONE_WAVE) give the same bf16 activations, hence the same actions"""
+    S, A, H1, H2 = 70, 9, 256, 128
+    w = make(S, A, H1, H2, 8)
+    s = np.random.default_rng(4).normal(size=(200, S)).astype(np.float32) * 1.5
+    pol = Policy(w, lib_path=emu_lib, s_clip=5.0)
+    want, _ = reference_forward(w, s, s_clip=5.0, bf16=True)
+    for tile in ("128", "64"):                   # both tile heights (the launch picks by batch size; forced here)
+        monkeypatch.setenv("DM_POLICY_TILE", tile)
+        a_t, _ = pol.forward_host(s)
+        assert np.abs(a_t - want).max() < 2e-3, (tile, np.abs(a_t - want).max())
+    monkeypatch.setenv("DM_POLICY_ONE_WAVE", "1")
+    a_o, _ = pol.forward_host(s)
+    assert np.abs(a_t - a_o).max() < 1e-5        # same products, another summation order inside an fp32 accumulator
+
+
 def test_policy_emulator_sampling_uses_the_philox_stream(emu_lib):
     S, A, H1, H2 = 32, 5, 64, 64
     w = make(S, A, H1, H2, 5, with_norm=False)

@@ -317,7 +317,17 @@ class BatchEnv:
                                          vp(rewards_ptr), vp(term_ptr), vp(valid_ptr), vp(end_ptr), flags))
 
     def set_stream(self, stream_handle: int):
-        self._chk(self.lib.dm_set_stream(self.h, C.c_void_p(stream_handle)))
+        # torch's default stream has the null handle, which dm_set_stream reads as "back to the ctx's own stream": select the legacy
+        # default stream explicitly, so that `env.set_stream(torch.cuda.current_stream().cuda_stream)` orders the launches against
+        # the caller's work whatever stream is current
+        if not stream_handle:
+            self._chk(self.lib.dm_set_stream_default(self.h))
+        else:
+            self._chk(self.lib.dm_set_stream(self.h, C.c_void_p(stream_handle)))
+
+    def use_own_stream(self):
+        """back to the ctx's own non-blocking stream"""
+        self._chk(self.lib.dm_set_stream(self.h, None))
 
     def synchronize(self):
         self._chk(self.lib.dm_synchronize(self.h))

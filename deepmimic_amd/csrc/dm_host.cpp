@@ -700,6 +700,13 @@ int dm_set_stream(dm_ctx* ctx, void* hip_stream) {
 #endif
     return 0;
 }
+int dm_set_stream_default(dm_ctx* ctx) {
+    if (!ctx) return fail("null ctx");
+#ifndef DM_EMU
+    ctx->c->stream = (hipStream_t)0;          // the legacy default stream: synchronises with every blocking stream, torch's default included
+#endif
+    return 0;
+}
 int dm_synchronize(dm_ctx* ctx) { if (!ctx) return fail("null ctx"); DevGuard guard(ctx->c->device_id); return rt_sync(ctx->c->stream) == 0 ? 0 : fail("stream synchronize failed"); }
 
 int dm_set_time_limits(dm_ctx* ctx, double time_lim_min, double time_lim_max) {

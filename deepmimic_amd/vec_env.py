@@ -1,0 +1,74 @@
+"""Device-resident vectorised env on top of the C-ABI (deepmimic_amd/core.py): observations, rewards and flags stay in HBM as
+torch tensors, one kernel launch per 30 Hz control step, asynchronous on torch's current stream -- the way a GPU learner consumes
+the path (the facade in compat/ is the drop-in for the reference's one-env-per-process driver; this is the batched form of the same
+protocol: SetAction ; 20 x Update ; RecordState / CalcReward / CheckTerminate ; Reset of finished episodes, DeepMimic.py:62-80).
+
+torch is plumbing here (device memory, streams); the stepping itself is libdm_hip.so."""
+from __future__ import annotations
+
+from typing import Dict, Tuple
+
+from .core import BatchEnv
+from .model import SceneTables
+
+
+class TorchVecEnv:
+    def __init__(self, tables: SceneTables, num_envs: int, device: str = "cuda:0", seed: int = 0, timestep: float = 1.0 / 600,
+                 updates_per_step: int = 20, amp_obs: bool = False, **env_kwargs):
+        import torch
+        self.torch = torch
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("TorchVecEnv needs a GPU device (deepmimic_amd has no CPU path)")
+        with torch.cuda.device(self.device):
+            torch.zeros(1, device=self.device)                     # torch's context first (one HIP runtime in the process)
+            self.env = BatchEnv(tables, num_envs, device_id=self.device.index or 0, seed=seed, **env_kwargs)
+        self.n, self.obs_dim, self.act_dim, self.goal_dim = self.env.N, self.env.S, self.env.A, self.env.G
+        self.timestep, self.updates = float(timestep), int(updates_per_step)
+        f32, i32 = dict(dtype=torch.float32, device=self.device), dict(dtype=torch.int32, device=self.device)
+        self.obs = torch.zeros((self.n, self.obs_dim), **f32); self.reward = torch.zeros(self.n, **f32)
+        self.terminate = torch.zeros(self.n, **i32); self.valid = torch.zeros(self.n, **i32); self.episode_end = torch.zeros(self.n, **i32)
+        self.amp_obs = torch.zeros((self.n, self.env.amp_size), **f32) if (amp_obs and self.env.amp_size) else None
+        # the launches go to a stream of their own, fenced against the caller's current stream on both sides of every call (torch's
+        # default stream has the null handle, which dm_set_stream reads as "the ctx's own stream": no implicit ordering to rely on)
+        self.stream = torch.cuda.Stream(self.device)
+        self.env.set_stream(self.stream.cuda_stream)
+
+    def _enter(self):
+        self.stream.wait_stream(self.torch.cuda.current_stream(self.device))
+
+    def _leave(self):
+        self.torch.cuda.current_stream(self.device).wait_stream(self.stream)
+
+    def _launch(self, actions_ptr, n_updates, auto_reset):
+        self.env.step_device(actions_ptr, self.obs.data_ptr(), self.reward.data_ptr(), self.terminate.data_ptr(), self.valid.data_ptr(),
+                             self.episode_end.data_ptr(), timestep=self.timestep, n_updates=n_updates, auto_reset=auto_reset,
+                             amp_ptr=self.amp_obs.data_ptr() if self.amp_obs is not None else 0)
+
+    def reset(self):
+        """Reset every env (clip time, episode length, clip and yaw drawn on the device) and return the first observations."""
+        self._enter()
+        self.env.reset()
+        self._launch(0, 0, False)                                   # RecordState of the reset state, no update
+        self._leave()
+        return self.obs
+
+    def step(self, actions) -> Tuple["object", "object", "object", Dict[str, "object"]]:
+        """One control step for every env.  `actions`: (N, A) float32 on this device.  Envs whose episode ended during the step are
+        reset inside the launch; their `obs` row is already the first observation of the next episode, `reward` / `terminate` describe
+        the step that ended (eTerminateNull 0 / Fail 1 / Succ 2; episode_end also covers the episode timer)."""
+        t = self.torch
+        if actions.device != self.device or actions.dtype != t.float32 or tuple(actions.shape) != (self.n, self.act_dim) or not actions.is_contiguous():
+            raise ValueError("actions must be a contiguous float32 (N, A) tensor on %s" % self.device)
+        self._enter()
+        self._launch(actions.data_ptr(), self.updates, True)
+        self._leave()
+        info = {"terminate": self.terminate, "valid": self.valid}
+        if self.amp_obs is not None:
+            info["amp_obs"] = self.amp_obs
+        if self.goal_dim:
+            info["goal"] = t.from_numpy(self.env.last_goals()).to(self.device)      # N x G, small: staged through the host
+        return self.obs, self.reward, self.episode_end.bool(), info
+
+    def close(self):
+        self.env.close()

@@ -107,8 +107,11 @@ int dm_destroy(dm_ctx* ctx);
 /* GetStateSize / GetGoalSize / GetActionSize (+ pose, links, dofs, frames of clip 0): out[8] = S,G,A,P,J,D,F,N */
 int dm_dims(const dm_ctx* ctx, int32_t* out);
 double dm_motion_duration(const dm_ctx* ctx);
-/* Run the kernels of this ctx on an external HIP stream (e.g. torch's current stream); NULL restores the own stream */
+/* Run the kernels of this ctx on an external HIP stream (e.g. torch's current stream); NULL restores the own (non-blocking) stream.
+ * The legacy default stream has the NULL handle too: dm_set_stream_default selects IT (torch's default stream when no torch.cuda.Stream is
+ * current), so that work enqueued by the caller on the default stream and this ctx's launches are ordered against each other. */
 int dm_set_stream(dm_ctx* ctx, void* hip_stream);
+int dm_set_stream_default(dm_ctx* ctx);
 int dm_synchronize(dm_ctx* ctx);
 
 /* cDeepMimicCore::SetMode (DeepMimicCore.cpp:472-479 -> cRLSceneSimChar::SetMode / ResetTimers, scenes/RLSceneSimChar.cpp:

@@ -136,6 +136,7 @@ def test_closed_loop_rollout_stays_on_device(hip_lib):
     t = model.load_asset("humanoid3d_walk")
     n = 4096
     env = BatchEnv(t, n, lib_path=hip_lib)
+    torch.cuda.set_stream(torch.cuda.Stream())        # an explicit stream: the null handle of torch's default stream would mean "the ctx's own stream"
     env.set_stream(torch.cuda.current_stream().cuda_stream)
     env.reset()
     offs = env.offsets_scales()

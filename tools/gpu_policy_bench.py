@@ -17,7 +17,10 @@ from deepmimic_amd.policy import Policy, random_weights   # noqa: E402
 n = int(os.environ.get("ENVS", "4096")); iters = 200
 t = model.load_asset("humanoid3d_walk")
 env = BatchEnv(t, n, seed=1)
-stream = torch.cuda.current_stream().cuda_stream
+# policy and env on ONE explicit stream (torch's default stream has the null handle, which dm_set_stream reads as "the ctx's own stream":
+# the two would then run unordered against each other)
+tstream = torch.cuda.Stream(); torch.cuda.set_stream(tstream)
+stream = tstream.cuda_stream
 env.set_stream(stream); env.reset()
 offs = env.offsets_scales()
 w = random_weights(env.S, env.A, seed=0)

@@ -41,3 +41,27 @@ def test_vec_env_matches_host_path(hip_lib, asset):
         ends += int(d.sum().item())
     assert ends > 0
     ve.close(); ref.close()
+
+
+@pytest.mark.gpu
+def test_set_stream_of_torchs_default_stream_orders_the_launch(hip_lib):
+    """torch's default stream has the null handle; BatchEnv.set_stream maps it to dm_set_stream_default, so a torch op enqueued right after
+    step_device on the default stream sees the step's outputs (a 2 ms kernel: an unordered read would see the buffer's previous content)"""
+    import torch
+    t = model.load_asset("humanoid3d_walk")
+    n = 4096
+    env = BatchEnv(t, n, seed=5, lib_path=hip_lib)
+    assert torch.cuda.current_stream().cuda_stream == 0
+    env.set_stream(torch.cuda.current_stream().cuda_stream)
+    env.reset()
+    dev = torch.device("cuda")
+    st = torch.full((n, env.S), -7.0, dtype=torch.float32, device=dev); rw = torch.full((n,), -7.0, dtype=torch.float32, device=dev)
+    tm = torch.zeros(n, dtype=torch.int32, device=dev); vd = torch.zeros(n, dtype=torch.int32, device=dev); en = torch.zeros(n, dtype=torch.int32, device=dev)
+    for k in range(5):
+        st.fill_(-7.0); rw.fill_(-7.0)
+        env.step_device(0, st.data_ptr(), rw.data_ptr(), tm.data_ptr(), vd.data_ptr(), en.data_ptr(), open_loop=True, auto_reset=True)
+        seen_s, seen_r = st.clone(), rw.clone()                  # enqueued on the default stream right behind the launch, no synchronize in between
+        torch.cuda.synchronize()
+        assert torch.equal(seen_s, st) and torch.equal(seen_r, rw)
+        assert float(seen_r.min()) >= 0.0 and float(seen_s.abs().max()) < 1e3        # the step's outputs, not the -7 fill
+    env.close()

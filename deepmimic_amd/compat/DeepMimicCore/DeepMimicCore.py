@@ -191,11 +191,7 @@ class cDeepMimicCore(object):
         self._spec = None
         self.stats["rollbacks"] += 1
         snap = sp["snap"]
-        self._env.set_state(pose=snap["pose"], vel=snap["vel"], tar=snap["tar"], kin=snap["kin"], clocks=snap["clocks"], flags=snap["flags"])
-        if "goal" in snap:                   # goal scenes: target / timers / draw counter / get-up or hit state of the same moment
-            self._env.set_goal_state(snap["goal"]); self._env.set_goal_aux(snap["aux"])
-            if "obj" in snap:
-                self._env.set_obj_state(snap["obj"])       # dribble_amp: the ball
+        self._env.restore(snap)              # character, clocks; goal scenes: target / timers / draw counter / get-up or hit state; the ball
         self._clk = dict(sp["clk0"])
         out = None
         for i in range(sp["v"]):
@@ -234,11 +230,7 @@ class cDeepMimicCore(object):
             self._tw_sample(snap)                # cSceneImitateAMP::NewActionUpdate -> UpdateTimeWarper (:140-150)
         k = self._updates_to_next_action(dt) if (self._batch and action is not None) else 1
         if k > 1:
-            snap = env.get_state() if snap is None else snap
-            if self._goal_size():
-                snap["goal"] = env.get_goal_state(); snap["aux"] = env.get_goal_aux()
-                if self._tables.goal_kind == 5:
-                    snap["obj"] = env.get_obj_state()
+            snap = env.snapshot()
             clk0 = dict(self._clk)
             out = self._launch(action, dt, k, True)
             t1 = float(env.get_state()["clocks"][0][3])

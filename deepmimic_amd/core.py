@@ -161,6 +161,7 @@ class BatchEnv:
         self.duration = float(self.lib.dm_motion_duration(self.h))
         self.precision = precision
         self.amp_size = int(self.lib.dm_amp_obs_size(self.h))      # GetAMPObsSize; 0 unless `--scene imitate_amp`
+        self.num_clips = int(tables.num_clips); self.has_obj = tables.goal_kind == 5
 
     def _chk(self, rc):
         if rc != 0:
@@ -350,6 +351,28 @@ class BatchEnv:
         kin = np.zeros((self.N, 7)); clk = np.zeros((self.N, 5)); flg = np.zeros((self.N, 4), np.int32)
         self._chk(self.lib.dm_get_state(self.h, _dp(pose), _dp(vel), _dp(tar), _dp(kin), _dp(clk), _ip(flg)))
         return dict(pose=pose, vel=vel, tar=tar, kin=kin, clocks=clk, flags=flg)
+
+    def snapshot(self):
+        """Everything the next control step depends on, as host arrays: character state and clocks, and for the task scenes the goal row
+        (target, timers, draw counter), its scene-specific block and the free body.  Taken at an action boundary (after a step / reset /
+        query) it is a checkpoint: `restore` + the same actions reproduce the rollout bit for bit (the AMP pose history is re-latched by
+        the first update after a boundary, so it is not part of it)."""
+        snap = self.get_state()
+        if self.G or self.num_clips > 1:
+            try:
+                snap["goal"] = self.get_goal_state(); snap["aux"] = self.get_goal_aux()
+            except RuntimeError:
+                pass
+        if self.has_obj:
+            snap["obj"] = self.get_obj_state()
+        return snap
+
+    def restore(self, snap):
+        self.set_state(pose=snap["pose"], vel=snap["vel"], tar=snap["tar"], kin=snap["kin"], clocks=snap["clocks"], flags=snap["flags"])
+        if "goal" in snap:
+            self.set_goal_state(snap["goal"]); self.set_goal_aux(snap["aux"])
+        if "obj" in snap:
+            self.set_obj_state(snap["obj"])
 
     def set_state(self, pose=None, vel=None, tar=None, kin=None, clocks=None, flags=None):
         f = lambda a, sh: None if a is None else np.ascontiguousarray(a, dtype=np.float64).reshape(sh)

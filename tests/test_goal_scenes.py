@@ -335,6 +335,27 @@ def test_dribble_facade_and_refusals(emu_lib, monkeypatch):
         BatchEnv(model.load_asset("amp_dribble_zombie"), 2, lib_path=emu_lib, wave_packing=2)
 
 
+@pytest.mark.parametrize("asset", ["amp_dribble_zombie", "amp_heading_getup", "humanoid3d_walk"])
+def test_snapshot_restore_reproduces_the_rollout(emu_lib, asset):
+    """BatchEnv.snapshot / restore at an action boundary: the same actions give the same outputs bit for bit (goal row, scene block
+    and the ball included)"""
+    t = model.load_asset(asset)
+    env = BatchEnv(t, 2, precision=64, lib_path=emu_lib, wave_packing=1, seed=9)
+    env.reset()
+    rng = np.random.default_rng(2)
+    acts = [(0.2 * rng.normal(size=(2, env.A))).astype(np.float32) for _ in range(6)]
+    for a in acts[:2]:
+        env.step(a, pc.DT, 20, auto_reset=True)
+    snap = env.snapshot()
+    first = [env.step(a, pc.DT, 20, auto_reset=True, amp=bool(env.amp_size)) for a in acts[2:]]
+    env.restore(snap)
+    again = [env.step(a, pc.DT, 20, auto_reset=True, amp=bool(env.amp_size)) for a in acts[2:]]
+    for x, y in zip(first, again):
+        for k in x:
+            assert np.array_equal(x[k], y[k]), (asset, k)
+    env.close()
+
+
 # ---- the HIP kernels
 @pytest.mark.gpu
 @pytest.mark.parametrize("name,prec,pack", [("amp_heading_zombie", 64, 1), ("amp_target_zombie", 64, 2), ("amp_heading_zombie", 32, 2),

@@ -156,3 +156,4 @@ def test_closed_loop_rollout_stays_on_device(hip_lib):
         env.step_device(ac.data_ptr(), st.data_ptr(), rw.data_ptr(), tm.data_ptr(), vd.data_ptr(), en.data_ptr(), auto_reset=True)
         tot += float(rw.mean().item())
     assert torch.isfinite(st).all() and torch.isfinite(ac).all() and 0.0 < tot / 10 < 1.0
+    torch.cuda.synchronize(); torch.cuda.set_stream(torch.cuda.default_stream())      # leave the process as found

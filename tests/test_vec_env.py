@@ -51,6 +51,7 @@ def test_set_stream_of_torchs_default_stream_orders_the_launch(hip_lib):
     t = model.load_asset("humanoid3d_walk")
     n = 4096
     env = BatchEnv(t, n, seed=5, lib_path=hip_lib)
+    torch.cuda.set_stream(torch.cuda.default_stream())           # whatever an earlier test left current
     assert torch.cuda.current_stream().cuda_stream == 0
     env.set_stream(torch.cuda.current_stream().cuda_stream)
     env.reset()

@@ -83,9 +83,21 @@ class cDeepMimicCore(object):
         self._tables = tables
         self._num_update_substeps = int(num_update_substeps)
 
+    def _kin_only(self):
+        """`--scene kin_char` (scenes/SceneKinChar.cpp): the viewer's motion playback -- a kinematic character on the host, no agent, no device"""
+        return self._tables is not None and self._tables.cfg.scene == "kin_char"
+
+    def GetKinPose(self):
+        """Extension (kin_char): the pose the reference would draw at the current time (cKinCharacter::GetPose)"""
+        return [float(x) for x in self._kin.pose(self._time, (0.0, 0.0, 0.0), (1.0, 0.0, 0.0, 0.0))]
+
     def Init(self):
         if self._tables is None:
             raise RuntimeError("cDeepMimicCore.Init(): ParseArgs() has not been called")
+        if self._kin_only():
+            self._kin = _model.KinSampler(self._tables); self._time = 0.0
+            self.stats = {"launches": 0, "updates": 0, "rollbacks": 0}
+            return
         self._env = _BatchEnv(self._tables, 1, device_id=int(os.environ.get("DM_DEVICE", "0")), seed=self._seed,
                               precision=int(os.environ.get("DM_PRECISION", "32")), lib_path=os.environ.get("DM_HIP_LIB"))
         self._off = self._env.offsets_scales()
@@ -208,6 +220,9 @@ class cDeepMimicCore(object):
 
     # ---- stepping (DeepMimicCore.cpp:56-65)
     def Update(self, timestep):
+        if self._kin_only():
+            self._time += float(timestep)      # cSceneKinChar::Update -> cKinCharacter::Update
+            return
         env = self._need_env()
         dt = float(timestep)
         self.stats["updates"] += 1
@@ -243,17 +258,24 @@ class cDeepMimicCore(object):
             self._advance_clocks(dt)
 
     def Reset(self):
+        if self._kin_only():
+            self._time = 0.0                   # cKinCharacter::Reset
+            return
         self._need_env()
         self._spec = None
         self._after_reset()
 
     def GetTime(self):
+        if self._kin_only():
+            return float(self._time)           # cSceneKinChar::GetTime: the character's clock
         self._need_env()
         return float(self._clk["timer"])      # cScene::GetTime: the episode timer (host mirror, no device round trip)
 
     def GetName(self):
         # cSceneImitate::GetName (scenes/SceneImitate.cpp:207-210), cSceneImitateAMP::GetName (SceneImitateAMP.cpp:208-211)
         scene = self._tables.cfg.scene if self._tables is not None else "imitate"
+        if scene == "kin_char":
+            return "Kinematic Char"
         return {"imitate_amp": "Imitate AMP", "target_amp": "Target AMP", "heading_amp": "Heading AMP", "heading_amp_getup": "Heading AMP Getup",
                 "strike_amp": "Strike AMP", "dribble_amp": "Dribble AMP"}.get(scene, "Imitate")
 
@@ -310,12 +332,14 @@ class cDeepMimicCore(object):
 
     # ---- RL interface (DeepMimicCore.cpp:165-480)
     def IsRLScene(self):
-        return True
+        return not self._kin_only()            # cDeepMimicCore::IsRLScene: mRLScene != nullptr (DeepMimicCore.cpp:165-168)
 
     def GetNumAgents(self):
-        return 1
+        return 0 if self._kin_only() else 1
 
     def _chk_agent(self, agent_id):
+        if self._kin_only():
+            raise RuntimeError("`--scene kin_char` has no agents (cDeepMimicCore::IsRLScene() is false)")
         if int(agent_id) != 0:
             raise RuntimeError("agent id %r out of range (the imitate scene has one agent)" % (agent_id,))
 
@@ -465,11 +489,15 @@ class cDeepMimicCore(object):
         return [float(x) for x in env.amp_expert(1, None, gh)[0]]
 
     def IsEpisodeEnd(self):
+        if self._kin_only():
+            return False                    # not an RL scene (DeepMimicCore.cpp:467-475)
         if self._virtual():
             return False                    # the batched launch stops at the update where the episode is over: not yet
         return bool(self._query()["episode_end"][0])
 
     def CheckValidEpisode(self):
+        if self._kin_only():
+            return True
         if self._virtual():
             return True
         return bool(self._query()["valid"][0])

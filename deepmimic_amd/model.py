@@ -565,6 +565,23 @@ def load_scene(char_file: str, ctrl_file: str, motion_file: str,
     return t
 
 
+def load_kin_scene(char_file: str, motion_file: str) -> SceneTables:
+    """`--scene kin_char` (scenes/SceneKinChar.cpp): skeleton + one clip, no bodies, no controller (the viewer's motion playback)."""
+    with open(char_file) as f:
+        cj = json.load(f)
+    with open(motion_file) as f:
+        mj = json.load(f)
+    jm = parse_skeleton(cj)
+    frames = np.array(mj["Frames"], dtype=np.float64)
+    J = jm.shape[0]
+    cfg = SceneConfig(); cfg.scene = "kin_char"; cfg.character_file = char_file; cfg.motion_file = motion_file
+    t = SceneTables(joint_mat=jm, body_defs=np.zeros((J, 17)), pd_params=np.zeros((J, 2)), frames=frames,
+                    loop=(mj.get("Loop", "none") == "wrap"), cfg=cfg)
+    if t.pose_dim != frames.shape[1] - 1:
+        raise ValueError("DOF mismatch, char dof %d, motion dof %d" % (t.pose_dim, frames.shape[1] - 1))
+    return t
+
+
 def load_scene_from_args(args: Sequence[str], data_root: str = ".") -> SceneTables:
     """Mirror of cDeepMimicCore::ParseArgs + cSceneImitate::ParseArgs for `--scene imitate`."""
     p = ArgParser(args)
@@ -574,6 +591,10 @@ def load_scene_from_args(args: Sequence[str], data_root: str = ".") -> SceneTabl
         if not p.load_file(path):
             raise FileNotFoundError("Failed to load args from: %s" % arg_file)
     cfg = parse_scene_config(p)
+    if cfg.scene == "kin_char":             # motion playback without a simulated character: host-side only (the facade serves it)
+        cf, mf = p.str("character_file", ""), p.str("motion_file", "")
+        rs = lambda pth: pth if os.path.isabs(pth) else os.path.join(data_root, pth)
+        return load_kin_scene(rs(cf), rs(mf))
     if cfg.scene != "imitate" and cfg.scene not in AMP_SCENES:
         raise ValueError("only `--scene imitate`, `imitate_amp`, `heading_amp`, `heading_amp_getup`, `target_amp`, `strike_amp` and `dribble_amp` "
                          "are on the accelerated path (got %r)" % cfg.scene)

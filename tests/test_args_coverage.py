@@ -64,8 +64,8 @@ def test_imitate_amp_arg_files_run(emu_lib):
         ex = env.amp_expert(3)
         assert np.isfinite(ex).all(), f
         env.close()
-    with pytest.raises(ValueError, match="accelerated path"):        # kin_char is a viewer scene without a simulated character
-        model.load_scene_from_args(["--arg_file", "args/play_motion_humanoid3d_args.txt"], data_root=REF)
+    with pytest.raises(ValueError, match="accelerated path"):
+        model.load_scene_from_args(["--scene", "sim_char"], data_root=REF)
 
 
 @pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "args")), reason="reference checkout not present")
@@ -97,3 +97,30 @@ def test_goal_scene_arg_files_run(emu_lib):
     # files (4 heading / target + 2 dribble) and the 2 strike files lack their clips
     assert len(ran) == 10 and len(missing) == 8, (ran, missing)
     assert sum("heading_getup" in r for r in ran) == 2 and sum("strike" in r for r in missing) == 2 and sum("dribble" in r for r in ran) == 2
+
+
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "args")), reason="reference checkout not present")
+def test_kin_char_arg_files_play_back(monkeypatch):
+    """`--scene kin_char` (the two play_motion arg files): the viewer's motion playback, served by the facade on the host -- no agent, the
+    character's clock as scene time, the pose of the clip at that time"""
+    import sys
+    compat = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "deepmimic_amd", "compat")
+    if compat not in sys.path:
+        sys.path.insert(0, compat)
+    from DeepMimicCore import DeepMimicCore
+    monkeypatch.setenv("DM_DATA_ROOT", REF)
+    for f in ("args/play_motion_humanoid3d_args.txt", "args/play_motion_dog3d_args.txt"):
+        core = DeepMimicCore.cDeepMimicCore(False)
+        core.ParseArgs(["--arg_file", f]); core.Init()
+        assert core.GetName() == "Kinematic Char" and not core.IsRLScene() and core.GetNumAgents() == 0
+        p0 = np.array(core.GetKinPose())
+        for _ in range(30):
+            core.Update(1.0 / 60)
+        assert abs(core.GetTime() - 0.5) < 1e-12 and not core.IsEpisodeEnd() and core.CheckValidEpisode()
+        p1 = np.array(core.GetKinPose())
+        assert np.isfinite(p1).all() and np.abs(p1 - p0).max() > 1e-3 and abs(np.linalg.norm(p1[3:7]) - 1) < 1e-9
+        core.Reset()
+        assert core.GetTime() == 0.0 and np.array_equal(np.array(core.GetKinPose()), p0)
+        with pytest.raises(RuntimeError, match="no agents"):
+            core.RecordState(0)
+        core.Shutdown()

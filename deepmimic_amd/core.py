@@ -48,6 +48,8 @@ class _SceneTables(C.Structure):
         ("target_min", C.c_double * 3), ("target_max", C.c_double * 3), ("strike_mask", C.c_int), ("fail_tar_mask", C.c_int),
         ("rand_tar_obj_time_min", C.c_double), ("rand_tar_obj_time_max", C.c_double), ("min_tar_obj_dist", C.c_double), ("max_tar_obj_dist", C.c_double),
         ("ball_radius", C.c_double), ("ball_mass", C.c_double), ("ball_friction", C.c_double), ("ball_lin_damping", C.c_double), ("ball_ang_damping", C.c_double),
+        ("enable_rand_perturbs", C.c_int), ("perturb_time_min", C.c_double), ("perturb_time_max", C.c_double), ("min_perturb", C.c_double),
+        ("max_perturb", C.c_double), ("min_perturb_duration", C.c_double), ("max_perturb_duration", C.c_double), ("perturb_part_mask", C.c_int),
     ]
 
 
@@ -152,6 +154,17 @@ class BatchEnv:
         for k in ("rand_tar_obj_time_min", "rand_tar_obj_time_max", "min_tar_obj_dist", "max_tar_obj_dist", "ball_radius"):
             setattr(st, k, float(getattr(c, k)))
         st.ball_mass = BALL_MASS; st.ball_friction = BALL_FRICTION * 0.9; st.ball_lin_damping = BALL_LIN_DAMPING; st.ball_ang_damping = BALL_ANG_DAMPING
+        # random perturbations: with the default (infinite) interval none ever fires -- the path stays off, as in the reference
+        st.enable_rand_perturbs = int(bool(c.enable_rand_perturbs) and np.isfinite(c.perturb_time_min))
+        if st.enable_rand_perturbs:
+            st.perturb_time_min, st.perturb_time_max = float(c.perturb_time_min), float(c.perturb_time_max)
+            st.min_perturb, st.max_perturb = float(c.min_perturb), float(c.max_perturb)
+            st.min_perturb_duration, st.max_perturb_duration = float(c.min_pertrub_duration), float(c.max_perturb_duration)
+            parts = set(int(b) for b in (c.perturb_part_ids or []))
+            if any(b < 0 or b >= int(st.num_joints) for b in parts):
+                raise ValueError("perturb_part_ids names a body part the character does not have: %s" % sorted(parts))
+            st.perturb_part_mask = sum(1 << b for b in parts)
+        self.has_perturbs = bool(st.enable_rand_perturbs)
         info = _CreateInfo(int(num_envs), int(device_id), int(seed) & (2 ** 64 - 1), int(precision), int(max_contacts), int(env_id_offset), int(wave_packing))
         self.h = C.c_void_p()
         self._chk(self.lib.dm_create(C.byref(info), C.byref(st), C.byref(self.h)))
@@ -246,6 +259,17 @@ class BatchEnv:
     def set_goal_aux(self, aux):
         aux = np.ascontiguousarray(aux, dtype=np.float64).reshape(self.N, 8)
         self._chk(self.lib.dm_set_goal_aux(self.h, _dp(aux)))
+
+    def get_perturb_state(self):
+        """enable_rand_perturbs: N x 16 = time since the last perturbation, time of the next, draw counter, two slots of {part + 1 (0 = free),
+        force xyz, duration, elapsed} (include/dm_hip.h)"""
+        out = np.zeros((self.N, 16))
+        self._chk(self.lib.dm_get_perturb_state(self.h, _dp(out)))
+        return out
+
+    def set_perturb_state(self, p):
+        p = np.ascontiguousarray(p, dtype=np.float64).reshape(self.N, 16)
+        self._chk(self.lib.dm_set_perturb_state(self.h, _dp(p)))
 
     def get_obj_state(self):
         """dribble_amp: the ball of every env, N x 13 = pos(3), rot wxyz(4), vel(3), ang vel(3)"""
@@ -365,6 +389,8 @@ class BatchEnv:
                 pass
         if self.has_obj:
             snap["obj"] = self.get_obj_state()
+        if self.has_perturbs:
+            snap["pert"] = self.get_perturb_state()
         return snap
 
     def restore(self, snap):
@@ -373,6 +399,8 @@ class BatchEnv:
             self.set_goal_state(snap["goal"]); self.set_goal_aux(snap["aux"])
         if "obj" in snap:
             self.set_obj_state(snap["obj"])
+        if "pert" in snap:
+            self.set_perturb_state(snap["pert"])
 
     def set_state(self, pose=None, vel=None, tar=None, kin=None, clocks=None, flags=None):
         f = lambda a, sh: None if a is None else np.ascontiguousarray(a, dtype=np.float64).reshape(sh)

@@ -1252,7 +1252,8 @@ struct EnvSim {
     // dynamics / Cholesky code (the instruction stream of the 20-update loop must fit the instruction cache).
     // reuse_kin: pose / vel are unchanged since the previous phase's kinematics (stable-PD solve -> first substep); only
     // the base acceleration differs, and it enters every joint-origin acceleration as the same additive constant.
-    DM_DEV void dyn_phase(int ph, Real dt, Real h, DebugTaps<Real> dbg, int e, bool tap_only, bool reuse_kin, Real* aovf) {
+    template <bool PERT = false>
+    DM_DEV void dyn_phase(int ph, Real dt, Real h, DebugTaps<Real> dbg, int e, bool tap_only, bool reuse_kin, Real* aovf, const double* pert = nullptr) {
         // lane id / link word are re-materialised per phase: keeps the optimizer from hoisting every per-lane LDS address
         // out of the 20-update loop (dozens of long-lived VGPRs that end up in scratch)
         DM_OPAQUE_V(l); DM_OPAQUE_V(li);
@@ -1271,18 +1272,20 @@ struct EnvSim {
         }
         if (tap_only) return;
         if (ph == 0) spd_rhs(dt);
-        else { if (l < m.D) s.rhs[l] = s.tau[l] - s.dofrec[l][7]; sync(); }
+        else { if (l < m.D) { Real r = s.tau[l] - s.dofrec[l][7]; if (PERT && pert) r += pert_gen_force(l); s.rhs[l] = r; } sync(); }
         DM_OPAQUE_V(l);
         chol_solve(s.rhs);
         DM_OPAQUE_V(l); DM_OPAQUE_V(li);
         if (ph == 0) { mark(3); spd_post(dt); }
         else substep_post(h, dbg, e, aovf);
     }
-    DM_DEV void update(double dt, DebugTaps<Real> dbg, int e, Real* aovf) {
+    template <bool PERT = false>
+    DM_DEV void update(double dt, DebugTaps<Real> dbg, int e, Real* aovf, double* pert = nullptr) {
         if (l == 0) { s.clk[CLK_TIMER] += dt; s.clk[CLK_CTRL] += dt; s.flg[FLG_NEED_ACTION] = 0; }
+        if (PERT && pert) { if (l == 0) pert_tick(pert, e, dt); sync(); }
         kin_update(dt);
         const Real h = (Real)(dt / m.num_sim_substeps);
-        for (int ph = 0; ph <= m.num_sim_substeps; ++ph) dyn_phase(ph, (Real)dt, h, dbg, e, false, ph == 1, aovf);
+        for (int ph = 0; ph <= m.num_sim_substeps; ++ph) dyn_phase<PERT>(ph, (Real)dt, h, dbg, e, false, ph == 1, aovf, pert);
         if (l == 0) {                      // cCtController::CheckNeedNewAction (CtController.cpp:221-227)
             double cur = s.clk[CLK_CTRL] + s.clk[CLK_INIT_OFF], pad = 0.001 * dt;
             int c1 = (int)floor((cur + pad) / m.query_period), c0 = (int)floor((cur + pad - dt) / m.query_period);
@@ -1539,6 +1542,74 @@ struct EnvSim {
         kin_sample<true>(time, p, v);
         kin_sample<true>(time - m.query_period, pp, pv);
         amp_build(pp, pv, p, v, ground_h, false, out);
+    }
+
+    // ------------------------------------------------------------------ random perturbations (`--enable_rand_perturbs`)
+    // cSceneSimChar::UpdateRandPerturb / ApplyRandForce / GetRandPerturbPartID / ResetRandPertrub (scenes/SceneSimChar.cpp:205-256, 618-626,
+    // 952-956), tPerturb + cPerturbManager (sim/Perturb.cpp, sim/PerturbManager.cpp:39-53), applied by cWorld::Update before stepSimulation
+    // (sim/World.cpp:93-96) as btMultiBody::addLinkForce at the part's centre of mass (sim/SimBodyLink.cpp:97-112; local_pos = 0).
+    // State: one row of doubles per env in HBM (EnvState::pert), touched by lane 0; the forces that act during the current update are
+    // handed to the dof lanes through s.sc[0..6] (free inside the update loop).  Draws: dm_rand01(seed, global env id, draw counter,
+    // stream 5), the counter kept in the row.  Compiled into the AMP / tap instantiations of the kernels only.
+    DM_DEV double pert_u01(double* p, int e) const { const double u = dm_rand01(m.seed, (uint64_t)(e + m.env_off), (uint64_t)p[PT_DRAWS], 5); p[PT_DRAWS] += 1; return u; }
+    DM_DEV double pert_uniform(double* p, int e, double lo, double hi) const { const double u = pert_u01(p, e); return (hi > lo && hi < 1e300) ? lo + (hi - lo) * u : hi; }
+    // ResetRandPertrub (timer := 0, next := U[time_min, time_max]) and cWorld::Reset -> mPerturbManager.Clear(); lane 0
+    DM_DEV void pert_reset(double* p, int e) const {
+        p[PT_TIMER] = 0; p[PT_NEXT] = pert_uniform(p, e, m.perturb_time_min, m.perturb_time_max);
+        for (int i = 0; i < PT_SLOTS; ++i) p[PT_SLOT0 + i * PT_SLOT_W + PT_LINK] = 0;
+    }
+    // one scene update: UpdateRandPerturb, then the manager's update inside cWorld::Update (an expired force leaves before it is applied;
+    // the others advance their clock and act for the whole update, both substeps); lane 0
+    DM_DEV void pert_tick(double* p, int e, double dt) {
+        double t = p[PT_TIMER] + dt;
+        if (t >= p[PT_NEXT]) {
+            const uint32_t mask = m.perturb_part_mask;
+            const int n = mask ? dm_popc64((uint64_t)mask) : m.J;
+            int idx = (int)(pert_u01(p, e) * n); idx = idx < n ? idx : n - 1;                  // cRand::RandInt(0, n)
+            int part = idx;
+            if (mask) { uint32_t mm = mask; for (int i = 0; i < idx; ++i) mm &= mm - 1; part = dm_ctz32(mm); }
+            const double dx = pert_uniform(p, e, -1, 1), dy = pert_uniform(p, e, -1, 1), dz = pert_uniform(p, e, -1, 1);
+            const double mag = pert_uniform(p, e, m.perturb_min, m.perturb_max), dur = pert_uniform(p, e, m.perturb_dur_min, m.perturb_dur_max);
+            const double sc = mag / sqrt(dx * dx + dy * dy + dz * dz);
+            // a free slot; with none free (excluded at create time: PT_SLOTS * perturb_time_min >= max duration) the one closest to its end
+            int slot = 0; double best = -1e300;
+            for (int i = 0; i < PT_SLOTS; ++i) {
+                const double* ps = p + PT_SLOT0 + i * PT_SLOT_W;
+                const double key = (ps[PT_LINK] == 0.0) ? 1e300 : ps[PT_TIME] - ps[PT_DUR];
+                if (key > best) { best = key; slot = i; }
+            }
+            double* ps = p + PT_SLOT0 + slot * PT_SLOT_W;
+            ps[PT_LINK] = (double)(part + 1); ps[PT_FX] = sc * dx; ps[PT_FY] = sc * dy; ps[PT_FZ] = sc * dz; ps[PT_DUR] = dur; ps[PT_TIME] = 0;
+            t = 0; p[PT_NEXT] = pert_uniform(p, e, m.perturb_time_min, m.perturb_time_max);
+        }
+        p[PT_TIMER] = t;
+        int codes = 0;
+        for (int i = 0; i < PT_SLOTS; ++i) {
+            double* ps = p + PT_SLOT0 + i * PT_SLOT_W;
+            int lk = (int)ps[PT_LINK];
+            v3 f = zero3();
+            if (lk > 0) {
+                if (ps[PT_TIME] >= ps[PT_DUR]) { ps[PT_LINK] = 0; lk = 0; }
+                else { ps[PT_TIME] += dt; f = mk3((Real)ps[PT_FX], (Real)ps[PT_FY], (Real)ps[PT_FZ]); }
+            }
+            st3(s.sc + 3 * i, f); codes |= lk << (8 * i);
+        }
+        s.sc[6] = (Real)codes;
+    }
+    // generalized force of the acting perturbations on dof k: J_k^T f with the point Jacobian of the part's centre of mass (same
+    // (axis, g) records and chain masks as the contact rows)
+    DM_DEV Real pert_gen_force(int k) const {
+        const int codes = (int)s.sc[6];
+        Real q = 0;
+        for (int i = 0; i < PT_SLOTS; ++i) {
+            const int lk = (codes >> (8 * i)) & 0xff;
+            if (lk == 0) continue;
+            const int link = lk - 1;
+            const v3 f = ld3(s.sc + 3 * i), xd = cross(ld3(s.com[link]) - ld3(s.p[0]), f);
+            const uint32_t ch = (k < 32) ? s.mdl.chain_lo[link] : s.mdl.chain_hi[link];
+            if ((ch >> (k & 31)) & 1u) q += dot(ld3(&s.dofrec[k][0]), xd) + dot(ld3(&s.dofrec[k][3]), f);
+        }
+        return q;
     }
 
     // ------------------------------------------------------------------ goal-conditioned AMP task scenes
@@ -2010,11 +2081,12 @@ __global__ void __launch_bounds__(64) DM_WAVES_PER_EU((StepWaves<Real, C>::value
     sim.mark(15);
     Real* aovf = st.aovf ? st.aovf + (size_t)e * (kMaxRows - C::RREG) * kWave : nullptr;
     const bool goal = HIST && st.goal && m.scene_goal;
+    double* pert = (HIST && st.pert) ? st.pert + (size_t)e * PT_WIDTH : nullptr;      // enable_rand_perturbs
     if (goal) sim.goal_sync_flags(st, e);
     for (int u = 0; u < io.n_updates; ++u) {
         if (HIST && st.hist) sim.latch_hist(st, e);
         if (goal) sim.goal_latch(st, e, io.dt);
-        sim.update(io.dt, dbg, e, aovf);
+        sim.template update<HIST>(io.dt, dbg, e, aovf, pert);
         if (goal) sim.goal_update(st, e, io.dt);
         if (io.end_early && lds.flg[FLG_OVER]) break;           // wave-uniform: latched by lane 0 at the end of update()
     }
@@ -2031,14 +2103,17 @@ __global__ void __launch_bounds__(64) DM_WAVES_PER_EU((StepWaves<Real, C>::value
             if (pass == 1 || !(io.auto_reset && ended)) break;
             uint64_t ep = (uint64_t)lds.flg[FLG_EPISODE];
             double mt = (m.time_lim_max > m.time_lim_min) ? m.time_lim_min + (m.time_lim_max - m.time_lim_min) * dm_rand01(m.seed, (uint64_t)(e + m.env_off), ep, 1) : m.time_lim_max;
+            bool rec = false;
             if (HIST && st.goal) {           // clip by weight, random yaw, goal reset -- unless the episode goes on as a recovery episode
-                if (!sim.try_recovery_reset(st, e, mt)) reset_goal_env<Real, C, TAPS>(sim, m, lds, st, e, ep, nullptr, mt);
+                rec = sim.try_recovery_reset(st, e, mt);
+                if (!rec) reset_goal_env<Real, C, TAPS>(sim, m, lds, st, e, ep, nullptr, mt);
             }
             else {
                 double kt = m.duration * dm_rand01(m.seed, (uint64_t)(e + m.env_off), ep, 0);
                 sim.reset_env(kt, mt);
                 if (HIST && st.hist) sim.init_hist(st, e);
             }
+            if (HIST && pert && !rec && l == 0) sim.pert_reset(pert, e);      // ResetScene -> ResetRandPertrub; a recovery episode only resets the timers
             tap = DebugTaps<Real>();
         }
         sim.mark(13);
@@ -2058,14 +2133,17 @@ __global__ void __launch_bounds__(64) k_env_reset(ModelDev<Real> m, EnvState<Rea
     uint64_t ep = (uint64_t)lds.flg[FLG_EPISODE];
     double mt = max_times ? max_times[b]
               : ((m.time_lim_max > m.time_lim_min) ? m.time_lim_min + (m.time_lim_max - m.time_lim_min) * dm_rand01(m.seed, (uint64_t)(e + m.env_off), ep, 1) : m.time_lim_max);
+    bool rec = false;
     if (st.goal) {
         sim.goal_sync_flags(st, e);
-        if (kin_times || !sim.try_recovery_reset(st, e, mt)) reset_goal_env<Real, C, true>(sim, m, lds, st, e, ep, kin_times ? &kin_times[b] : nullptr, mt);
+        rec = !kin_times && sim.try_recovery_reset(st, e, mt);
+        if (!rec) reset_goal_env<Real, C, true>(sim, m, lds, st, e, ep, kin_times ? &kin_times[b] : nullptr, mt);
     } else {
         double kt = kin_times ? kin_times[b] : m.duration * dm_rand01(m.seed, (uint64_t)(e + m.env_off), ep, 0);
         sim.reset_env(kt, mt);
         if (st.hist) sim.init_hist(st, e);
     }
+    if (st.pert && !rec && l == 0) sim.pert_reset(st.pert + (size_t)e * PT_WIDTH, e);
     sim.store(st, e);
 }
 

@@ -601,8 +601,10 @@ _Pragma("unroll") \
     }
 
     // ------------------------------------------------------------------ one scene update for both characters
-    DM_DEV void update(double dt, int e, Real* aovf_pair) {
+    template <bool PERT = false>
+    DM_DEV void update(double dt, int e, Real* aovf_pair, double* pert = nullptr) {
         if (hl == 0) { s.clk[CLK_TIMER] += dt; s.clk[CLK_CTRL] += dt; s.flg[FLG_NEED_ACTION] = 0; }
+        if (PERT && pert) { if (hl == 0 && s.flg[FLG_PARKED] == 0) b.pert_tick(pert, e, dt); sync(); }      // enable_rand_perturbs (a parked character's row rests)
         b.kin_update(dt);
         const Real h = (Real)(dt / m.num_sim_substeps), rdt = (Real)dt;
         const int D = m.D;
@@ -620,7 +622,7 @@ _Pragma("unroll") \
                 b.spd_rhs_pre(rdt);
                 for (int k = hl; k < D; k += HW) s.rhs[k] = b.xs()[k] - s.dofrec[k][7];
                 sync();
-            } else { for (int k = hl; k < D; k += HW) s.rhs[k] = s.tau[k] - s.dofrec[k][7]; sync(); }
+            } else { for (int k = hl; k < D; k += HW) { Real r = s.tau[k] - s.dofrec[k][7]; if (PERT && pert) r += b.pert_gen_force(k); s.rhs[k] = r; } sync(); }
             DM_OPAQUE_V(hl); DM_OPAQUE_V(b.l);
             chol_solve(s.rhs);
             DM_OPAQUE_V(hl); DM_OPAQUE_V(b.l); DM_OPAQUE_V(b.li);
@@ -669,11 +671,12 @@ __global__ void __launch_bounds__(64) DM_WAVES_PER_EU((DuoWaves<Real>::value)) k
     sim.b.mark(15);
     Real* aovf_pair = st.aovf ? st.aovf + (size_t)(2 * blockIdx.x) * (kMaxRows - ClsBiped::RREG) * kWave : nullptr;
     const bool goal = HIST && st.goal && m.scene_goal;
+    double* pert = (HIST && st.pert) ? st.pert + (size_t)e * PT_WIDTH : nullptr;
     if (goal) sim.b.goal_sync_flags(st, e);
     for (int u = 0; u < io.n_updates; ++u) {
         if (HIST && st.hist) sim.b.latch_hist(st, e, lds[half].flg[FLG_PARKED] == 0);
         if (goal) sim.b.goal_latch(st, e, io.dt, lds[half].flg[FLG_PARKED] == 0);
-        sim.update(io.dt, e, aovf_pair);
+        sim.template update<HIST>(io.dt, e, aovf_pair, pert);
         if (goal) sim.b.goal_update(st, e, io.dt, lds[half].flg[FLG_PARKED] == 0);      // the update that ends an episode includes its goal update
         if (io.end_early) {
             // DM_END_EPISODE_EARLY.  FLG_OVER is latched by each character's lane 0 at the end of update() (wave-uniform reads).
@@ -697,12 +700,14 @@ __global__ void __launch_bounds__(64) DM_WAVES_PER_EU((DuoWaves<Real>::value)) k
         if (io.auto_reset && ended) {                    // per character; no cross-half traffic inside
             uint64_t ep = (uint64_t)lds[half].flg[FLG_EPISODE];
             double mt = (m.time_lim_max > m.time_lim_min) ? m.time_lim_min + (m.time_lim_max - m.time_lim_min) * dm_rand01(m.seed, (uint64_t)(e + m.env_off), ep, 1) : m.time_lim_max;
-            if (HIST && st.goal) { if (!sim.b.try_recovery_reset(st, e, mt)) reset_goal_env<Real, ClsBiped, TAPS, 32>(sim.b, m, lds[half], st, e, ep, nullptr, mt); }
+            bool rec = false;
+            if (HIST && st.goal) { rec = sim.b.try_recovery_reset(st, e, mt); if (!rec) reset_goal_env<Real, ClsBiped, TAPS, 32>(sim.b, m, lds[half], st, e, ep, nullptr, mt); }
             else {
                 double kt = m.duration * dm_rand01(m.seed, (uint64_t)(e + m.env_off), ep, 0);
                 sim.b.reset_env(kt, mt);
                 if (HIST && st.hist) sim.b.init_hist(st, e);
             }
+            if (HIST && pert && !rec && (wl & 31) == 0) sim.b.pert_reset(pert, e);
             sim.b.emit(io, tap, e, false);
             if (goal) sim.b.emit_goal(io, st, e, false);
         }

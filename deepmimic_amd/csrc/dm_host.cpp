@@ -303,7 +303,7 @@ struct CtxBase {
     int amp_size = 0; float* d_amp = nullptr; uint64_t expert_calls = 0;
     int goal_size = 0; float* d_goals = nullptr;            // RecordGoal of the last emit (goal scenes)
     virtual int get_goal(double* out) = 0; virtual int set_goal(const double* in) = 0; virtual int get_clips(int* out) = 0;
-    virtual int goal_aux(double* out, const double* in) = 0; virtual void set_mode(int test) = 0;
+    virtual int goal_aux(double* out, const double* in) = 0; virtual void set_mode(int test) = 0; virtual int pert_state(double* out, const double* in) = 0;
     virtual int obj_state(double* out, const double* in) = 0;
     virtual int amp_expert_clips(int n, const int* clips_dev, const double* times_dev, const double* gh_dev, float* out_dev) = 0;
     virtual int probe(int what, double dt) = 0;
@@ -448,6 +448,19 @@ struct CtxT : CtxBase {
             d_goals = (float*)dalloc(sizeof(float) * (size_t)N * 4);
             if (!st.goal || !d_goals) return fail("device allocation failed");
         }
+        // random perturbations (scenes/SceneSimChar.cpp:92-99)
+        st.pert = nullptr; md.perturb_on = c.enable_rand_perturbs ? 1 : 0;
+        if (c.enable_rand_perturbs) {
+            md.perturb_time_min = c.perturb_time_min; md.perturb_time_max = c.perturb_time_max; md.perturb_min = c.min_perturb; md.perturb_max = c.max_perturb;
+            md.perturb_dur_min = c.min_perturb_duration; md.perturb_dur_max = c.max_perturb_duration; md.perturb_part_mask = (uint32_t)c.perturb_part_mask;
+            if (c.perturb_part_mask < 0 || (h.J < 32 && ((uint32_t)c.perturb_part_mask >> h.J) != 0)) return fail("perturb_part_mask names a body part the character does not have");
+            if (!(c.perturb_time_max >= c.perturb_time_min) || !(c.perturb_time_min > 0) || !(c.max_perturb >= c.min_perturb) || !(c.max_perturb_duration >= c.min_perturb_duration) || c.min_perturb_duration < 0)
+                return fail("perturbation ranges must satisfy 0 < perturb_time_min <= perturb_time_max, min <= max");
+            if (PT_SLOTS * c.perturb_time_min < c.max_perturb_duration) return fail("more than 2 perturbations would act at once (needs 2 * perturb_time_min >= max_perturb_duration)");
+            st.pert = (double*)dalloc(sizeof(double) * (size_t)N * PT_WIDTH);
+            if (!st.pert) return fail("device allocation failed");
+            rt_memset(st.pert, 0, sizeof(double) * (size_t)N * PT_WIDTH, stream);
+        }
         d_actions = (float*)dalloc(sizeof(float) * N * h.A); d_states = (float*)dalloc(sizeof(float) * N * h.S); d_rewards = (float*)dalloc(sizeof(float) * N);
         d_term = (int*)dalloc(sizeof(int) * N); d_valid = (int*)dalloc(sizeof(int) * N); d_end = (int*)dalloc(sizeof(int) * N);
         if (!st.pose || !st.flag || !d_end || !md.mdl_blob || upload_failed) return fail("device allocation or table upload failed");
@@ -487,14 +500,14 @@ struct CtxT : CtxBase {
         io.n_updates = n_updates; io.dt = dt; io.auto_reset = (flags & DM_AUTO_RESET) ? 1 : 0; io.emit = (flags & DM_NO_EMIT) ? 0 : 1; io.open_loop = (flags & DM_OPEN_LOOP) ? 1 : 0; io.end_early = (flags & DM_END_EPISODE_EARLY) ? 1 : 0;
         // two characters per wavefront: biped class, even batch, no debug taps armed (DM_DUO=0 keeps one character per wave)
         if (duo && cls == 0 && hm.D == ClsBiped::ND && (N % 2) == 0 && !dbg.H) {      // (31 row lanes per character assume exactly 34 dofs)
-            if (st.hist) RT_LAUNCH((k_env_step_duo<Real, false, true>), N / 2, stream, md, st, io, dbg);
+            if (st.hist || st.pert) RT_LAUNCH((k_env_step_duo<Real, false, true>), N / 2, stream, md, st, io, dbg);      // (the AMP instantiation also carries the perturbation code)
             else RT_LAUNCH((k_env_step_duo<Real, false, false>), N / 2, stream, md, st, io, dbg);
             return 0;
         }
         // production launch: the tap-free instantiation unless a parity test armed the debug taps (dm_probe)
         if (cls == 2) { if (dbg.H) RT_LAUNCH((k_env_step<Real, ClsBipedObj, true>), N, stream, md, st, io, dbg); else RT_LAUNCH((k_env_step<Real, ClsBipedObj, false, true>), N, stream, md, st, io, dbg); }
         else if (dbg.H) { if (cls == 0) RT_LAUNCH((k_env_step<Real, ClsBiped, true>), N, stream, md, st, io, dbg); else RT_LAUNCH((k_env_step<Real, ClsLarge, true>), N, stream, md, st, io, dbg); }
-        else if (st.hist) { if (cls == 0) RT_LAUNCH((k_env_step<Real, ClsBiped, false, true>), N, stream, md, st, io, dbg); else RT_LAUNCH((k_env_step<Real, ClsLarge, false, true>), N, stream, md, st, io, dbg); }
+        else if (st.hist || st.pert) { if (cls == 0) RT_LAUNCH((k_env_step<Real, ClsBiped, false, true>), N, stream, md, st, io, dbg); else RT_LAUNCH((k_env_step<Real, ClsLarge, false, true>), N, stream, md, st, io, dbg); }
         else { if (cls == 0) RT_LAUNCH((k_env_step<Real, ClsBiped, false, false>), N, stream, md, st, io, dbg); else RT_LAUNCH((k_env_step<Real, ClsLarge, false, false>), N, stream, md, st, io, dbg); }
         return 0;
     }
@@ -539,6 +552,13 @@ struct CtxT : CtxBase {
             for (int e = 0; e < N; ++e) for (int k = 0; k < 13; ++k) o[(size_t)e * OB_WIDTH + k] = (Real)in[(size_t)e * 13 + k];
             if (rt_h2d(st.obj, o.data(), sizeof(Real) * o.size(), stream) != 0) return fail("host to device copy failed");
         }
+        return 0;
+    }
+    int pert_state(double* out, const double* in) override {         // N x PT_WIDTH
+        if (!st.pert) return fail("no perturbation state: enable_rand_perturbs is off");
+        const size_t bytes = sizeof(double) * (size_t)N * PT_WIDTH;
+        if (out && rt_d2h(out, st.pert, bytes, stream) != 0) return fail("device to host copy failed");
+        if (in && rt_h2d(st.pert, in, bytes, stream) != 0) return fail("host to device copy failed");
         return 0;
     }
     int get_clips(int* out) override {
@@ -874,6 +894,8 @@ int dm_set_goal_state(dm_ctx* ctx, const double* in) { if (!ctx || !in) return f
 int dm_goal_size(const dm_ctx* ctx) { return ctx ? ctx->c->goal_size : 0; }
 int dm_get_goal_aux(dm_ctx* ctx, double* out) { if (!ctx || !out) return fail("null argument"); DevGuard guard(ctx->c->device_id); return ctx->c->goal_aux(out, nullptr); }
 int dm_set_goal_aux(dm_ctx* ctx, const double* in) { if (!ctx || !in) return fail("null argument"); DevGuard guard(ctx->c->device_id); return ctx->c->goal_aux(nullptr, in); }
+int dm_get_perturb_state(dm_ctx* ctx, double* out) { if (!ctx || !out) return fail("null argument"); DevGuard guard(ctx->c->device_id); return ctx->c->pert_state(out, nullptr); }
+int dm_set_perturb_state(dm_ctx* ctx, const double* in) { if (!ctx || !in) return fail("null argument"); DevGuard guard(ctx->c->device_id); return ctx->c->pert_state(nullptr, in); }
 int dm_get_obj_state(dm_ctx* ctx, double* out) { if (!ctx || !out) return fail("null argument"); DevGuard guard(ctx->c->device_id); return ctx->c->obj_state(out, nullptr); }
 int dm_set_obj_state(dm_ctx* ctx, const double* in) { if (!ctx || !in) return fail("null argument"); DevGuard guard(ctx->c->device_id); return ctx->c->obj_state(nullptr, in); }
 int dm_set_mode(dm_ctx* ctx, int test_mode) { if (!ctx) return fail("null ctx"); ctx->c->set_mode(test_mode); return 0; }

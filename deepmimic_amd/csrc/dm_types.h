@@ -137,6 +137,10 @@ struct ModelDev {
     const int* clip_loop;                    // num_clips
     const Real* clip_delta;                  // num_clips x 3  cycle root delta
     const double* clip_cdf;                  // num_clips  cClipsController::mClipsCDF
+    // ---- random perturbations (`--enable_rand_perturbs`, scenes/SceneSimChar.cpp:92-99): a force on a random body part every U[time_min,
+    // time_max] seconds, magnitude U[min, max] N, lasting U[min, max] duration; part mask 0 = any part
+    int perturb_on; uint32_t perturb_part_mask;
+    double perturb_time_min, perturb_time_max, perturb_min, perturb_max, perturb_dur_min, perturb_dur_max;
 };
 // per-env goal state row (EnvState::goal), doubles: the clocks among them must not round to fp32
 enum { GS_TX = 0, GS_TY, GS_TZ, GS_HEADING, GS_SPEED, GS_TIMER, GS_TIMER_MAX, GS_PCOMX, GS_PCOMY, GS_PCOMZ, GS_PTIME, GS_DRAWS, GS_CLIP,
@@ -144,6 +148,9 @@ enum { GS_TX = 0, GS_TY, GS_TZ, GS_HEADING, GS_SPEED, GS_TIMER, GS_TIMER_MAX, GS
        GS_PBX, GS_PBY, GS_PBZ,  // dribble_amp: ball position at the last action (cSceneDribbleAMP::mAgentPrevTarObjPos)
        GS_OTIMER, GS_OTIMER_MAX, // dribble_amp: target-object timer
        GS_WIDTH = 24 };
+// per-env perturbation state (EnvState::pert), doubles: cSceneSimChar::tPerturbParams::mTimer / mNextTime, the draw counter of stream 5,
+// and the active tPerturb entries of cWorld's cPerturbManager (link < 0: free slot)
+enum { PT_TIMER = 0, PT_NEXT, PT_DRAWS, PT_SLOT0, PT_LINK = 0, PT_FX, PT_FY, PT_FZ, PT_DUR, PT_TIME, PT_SLOT_W = 6, PT_SLOTS = 2, PT_WIDTH = 16 };
 // the free body's record (EnvState::obj, OBJ classes): position, rotation (w, x, y, z), linear and angular velocity
 enum { OB_PX = 0, OB_QW = 3, OB_VX = 7, OB_WX = 10, OB_WIDTH = 16 };
 
@@ -161,6 +168,7 @@ struct EnvState {
     Real* hist;      // N x 2P  pose | vel at the last action latch (cSceneImitateAMP::mPrevPose / mPrevVel); null unless imitate_amp
     Real* obj;       // N x OB_WIDTH  the free body of an OBJ class (dribble_amp's ball); null otherwise
     double* goal;    // N x GS_WIDTH  goal state of the task scenes + the clip the env was reset to; null unless a goal scene / multi-clip dataset
+    double* pert;    // N x PT_WIDTH  random-perturbation clock and active forces; null unless enable_rand_perturbs
 };
 
 // Per-call I/O of the batched step (device pointers; any may be null)

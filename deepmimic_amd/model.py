@@ -190,6 +190,15 @@ class SceneConfig:
     min_tar_obj_dist: float = 0.5
     max_tar_obj_dist: float = 10.0
     ball_radius: float = 0.2
+    # ---- random perturbations (cSceneSimChar::tPerturbParams, scenes/SceneSimChar.cpp:41-51; keys :92-99, the duration key's typo is the reference's)
+    enable_rand_perturbs: bool = False
+    perturb_time_min: float = np.inf
+    perturb_time_max: float = np.inf
+    min_perturb: float = 50.0
+    max_perturb: float = 100.0
+    min_pertrub_duration: float = 0.1
+    max_perturb_duration: float = 0.5
+    perturb_part_ids: Optional[List[int]] = None
 
 
 # cSceneDribbleAMP::BuildTarObjs (SceneDribbleAMP.cpp:398-420): the ball's constants are literals there, not arg-file keys
@@ -476,6 +485,10 @@ def parse_scene_config(parser: ArgParser) -> SceneConfig:
         setattr(c, k, parser.float(k, getattr(c, k)))
     c.strike_bodies = parser.ints("strike_bodies")
     c.fail_tar_contact_bodies = parser.ints("fail_tar_contact_bodies")
+    c.enable_rand_perturbs = parser.bool("enable_rand_perturbs", c.enable_rand_perturbs)
+    for k in ("perturb_time_min", "perturb_time_max", "min_perturb", "max_perturb", "min_pertrub_duration", "max_perturb_duration"):
+        setattr(c, k, parser.float(k, getattr(c, k)))
+    c.perturb_part_ids = parser.ints("perturb_part_ids")
     return c
 
 

@@ -90,6 +90,14 @@ typedef struct {
      * ball_friction is the combined coefficient of a ball contact (ball 0.4 x link / ground 0.9). */
     double rand_tar_obj_time_min, rand_tar_obj_time_max, min_tar_obj_dist, max_tar_obj_dist;
     double ball_radius, ball_mass, ball_friction, ball_lin_damping, ball_ang_damping;
+    /* ---- random perturbations (`--enable_rand_perturbs`, scenes/SceneSimChar.cpp:41-51, 92-99, 205-256, 618-626, 952-956; sim/Perturb.cpp;
+     * sim/PerturbManager.cpp; sim/World.cpp:93-96): every U[perturb_time_min, perturb_time_max] seconds a force of U[min_perturb,
+     * max_perturb] N in a uniformly drawn direction acts at the centre of mass of a random body part for U[min, max duration] seconds
+     * (`min_pertrub_duration` [sic] / `max_perturb_duration`).  perturb_part_mask: bit j = part j may be hit (--perturb_part_ids), 0 = any.
+     * Cleared and re-armed by every scene reset.  Needs 2 * perturb_time_min >= max_perturb_duration (two forces at once at most). */
+    int enable_rand_perturbs;
+    double perturb_time_min, perturb_time_max, min_perturb, max_perturb, min_perturb_duration, max_perturb_duration;
+    int perturb_part_mask;
 } dm_scene_tables;
 
 /* DM_END_EPISODE_EARLY: an env whose episode is over after update u of the call (fall contact, clip end, episode timer) takes no
@@ -169,6 +177,11 @@ int dm_set_goal_state(dm_ctx* ctx, const double* in);
  * [7] reserved */
 int dm_get_goal_aux(dm_ctx* ctx, double* out);
 int dm_set_goal_aux(dm_ctx* ctx, const double* in);
+/* the random-perturbation state (enable_rand_perturbs), N x 16 doubles per env: [0] time since the last perturbation, [1] time of the next one
+ * (cSceneSimChar::tPerturbParams::mTimer / mNextTime), [2] draw counter, then two force slots of 6: {body part + 1 (0 = free), force x, y, z,
+ * duration, elapsed} (tPerturb, sim/Perturb.h), [15] unused.  For checkpointing and for tests that place a known force. */
+int dm_get_perturb_state(dm_ctx* ctx, double* out);
+int dm_set_perturb_state(dm_ctx* ctx, const double* in);
 /* cRLScene::SetMode (DeepMimicCore.cpp SetMode -> scene): 0 train, 1 test.  Only the goal scenes read it on the device (get-up on a
  * fall instead of termination, recovery episodes, strike_amp's test reward); the episode-timer limits of the two modes are the
  * caller's business (dm_set_time_limits). */

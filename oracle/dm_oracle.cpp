@@ -29,7 +29,8 @@ enum {
     CFG_MODE_TEST, CFG_GETUP_TIME, CFG_GETUP_HEIGHT_ROOT, CFG_GETUP_HEIGHT_HEAD, CFG_HEAD_ID, CFG_RECOVER_PROB, CFG_GETUP_CLIP_MASK,
     CFG_TAR_NEAR_DIST, CFG_TAR_FAR_PROB, CFG_TARGET_RADIUS, CFG_HIT_RESET_TIME, CFG_INIT_HIT_PROB, CFG_HIT_TAR_SPEED, CFG_TAR_REWARD_SCALE,
     CFG_TMIN_X, CFG_TMIN_Y, CFG_TMIN_Z, CFG_TMAX_X, CFG_TMAX_Y, CFG_TMAX_Z, CFG_STRIKE_MASK, CFG_FAIL_TAR_MASK,
-    CFG_OBJ_TIME_MIN, CFG_OBJ_TIME_MAX, CFG_MIN_OBJ_DIST, CFG_MAX_OBJ_DIST, CFG_BALL_RADIUS, CFG_BALL_MASS, CFG_BALL_FRICTION, CFG_BALL_LIN_DAMP, CFG_BALL_ANG_DAMP, CFG_COUNT
+    CFG_OBJ_TIME_MIN, CFG_OBJ_TIME_MAX, CFG_MIN_OBJ_DIST, CFG_MAX_OBJ_DIST, CFG_BALL_RADIUS, CFG_BALL_MASS, CFG_BALL_FRICTION, CFG_BALL_LIN_DAMP, CFG_BALL_ANG_DAMP,
+    CFG_PERTURB_ON, CFG_PERTURB_TIME_MIN, CFG_PERTURB_TIME_MAX, CFG_PERTURB_MIN, CFG_PERTURB_MAX, CFG_PERTURB_DUR_MIN, CFG_PERTURB_DUR_MAX, CFG_PERTURB_PART_MASK, CFG_COUNT
 };
 
 int orc_cfg_count() { return CFG_COUNT; }
@@ -59,6 +60,8 @@ void orc_cfg_default(double* c) {
     c[CFG_STRIKE_MASK] = d.strike_mask; c[CFG_FAIL_TAR_MASK] = d.fail_tar_mask;
     c[CFG_OBJ_TIME_MIN] = d.tar_obj_time_min; c[CFG_OBJ_TIME_MAX] = d.tar_obj_time_max; c[CFG_MIN_OBJ_DIST] = d.min_tar_obj_dist; c[CFG_MAX_OBJ_DIST] = d.max_tar_obj_dist;
     c[CFG_BALL_RADIUS] = d.ball_radius; c[CFG_BALL_MASS] = d.ball_mass; c[CFG_BALL_FRICTION] = d.ball_friction; c[CFG_BALL_LIN_DAMP] = d.ball_lin_damping; c[CFG_BALL_ANG_DAMP] = d.ball_ang_damping;
+    c[CFG_PERTURB_ON] = d.enable_rand_perturbs; c[CFG_PERTURB_TIME_MIN] = d.perturb_time_min; c[CFG_PERTURB_TIME_MAX] = d.perturb_time_max; c[CFG_PERTURB_MIN] = d.min_perturb;
+    c[CFG_PERTURB_MAX] = d.max_perturb; c[CFG_PERTURB_DUR_MIN] = d.min_perturb_duration; c[CFG_PERTURB_DUR_MAX] = d.max_perturb_duration; c[CFG_PERTURB_PART_MASK] = d.perturb_part_mask;
 }
 
 void* orc_create(const double* jm, const double* bd, int J, const double* pd, const double* frames, int F, int loop,
@@ -86,6 +89,8 @@ void* orc_create(const double* jm, const double* bd, int J, const double* pd, co
     cfg.strike_mask = (uint32_t)c[CFG_STRIKE_MASK]; cfg.fail_tar_mask = (uint32_t)c[CFG_FAIL_TAR_MASK];
     cfg.tar_obj_time_min = c[CFG_OBJ_TIME_MIN]; cfg.tar_obj_time_max = c[CFG_OBJ_TIME_MAX]; cfg.min_tar_obj_dist = c[CFG_MIN_OBJ_DIST]; cfg.max_tar_obj_dist = c[CFG_MAX_OBJ_DIST];
     cfg.ball_radius = c[CFG_BALL_RADIUS]; cfg.ball_mass = c[CFG_BALL_MASS]; cfg.ball_friction = c[CFG_BALL_FRICTION]; cfg.ball_lin_damping = c[CFG_BALL_LIN_DAMP]; cfg.ball_ang_damping = c[CFG_BALL_ANG_DAMP];
+    cfg.enable_rand_perturbs = c[CFG_PERTURB_ON] != 0; cfg.perturb_time_min = c[CFG_PERTURB_TIME_MIN]; cfg.perturb_time_max = c[CFG_PERTURB_TIME_MAX]; cfg.min_perturb = c[CFG_PERTURB_MIN];
+    cfg.max_perturb = c[CFG_PERTURB_MAX]; cfg.min_perturb_duration = c[CFG_PERTURB_DUR_MIN]; cfg.max_perturb_duration = c[CFG_PERTURB_DUR_MAX]; cfg.perturb_part_mask = (uint32_t)c[CFG_PERTURB_PART_MASK];
     Scene* s = new Scene();
     s->init(jm, bd, J, pd, frames, F, loop != 0, fall_mask, cfg);
     return s;
@@ -361,6 +366,19 @@ void orc_set_clips(void* h, const double* frames, const int* starts, const int* 
 }
 int orc_num_clips(void* h) { return (int)((Scene*)h)->clips.size(); }
 double orc_clip_duration(void* h, int c) { Scene* s = (Scene*)h; return s->clips.empty() ? s->mo.duration() : s->clips[c].duration(); }
+// random perturbations: the same 16-double row as the device (include/dm_hip.h dm_get_perturb_state); entries beyond two are not representable
+void orc_perturb_state(void* h, double* o) {
+    Scene* s = (Scene*)h;
+    for (int k = 0; k < 16; ++k) o[k] = 0;
+    o[0] = s->pert_timer; o[1] = s->pert_next; o[2] = (double)s->pert_draws;
+    for (size_t i = 0; i < s->perts.size() && i < 2; ++i) { const Scene::Perturb& p = s->perts[i]; double* q = o + 3 + 6 * i; q[0] = p.link + 1; q[1] = p.f.x; q[2] = p.f.y; q[3] = p.f.z; q[4] = p.dur; q[5] = p.time; }
+}
+int orc_num_perturbs(void* h) { return (int)((Scene*)h)->perts.size(); }
+void orc_set_perturb_state(void* h, const double* o) {
+    Scene* s = (Scene*)h;
+    s->pert_timer = o[0]; s->pert_next = o[1]; s->pert_draws = (uint64_t)o[2]; s->perts.clear();
+    for (int i = 0; i < 2; ++i) { const double* q = o + 3 + 6 * i; if (q[0] > 0) { Scene::Perturb p; p.link = (int)q[0] - 1; p.f.x = q[1]; p.f.y = q[2]; p.f.z = q[3]; p.dur = q[4]; p.time = q[5]; s->perts.push_back(p); } }
+}
 void orc_goal_rng(void* h, uint64_t seed, uint64_t env_id, uint64_t draws) { Scene* s = (Scene*)h; s->rng_seed = seed; s->rng_env = env_id; s->goal_draws = draws; }
 // reset to a named clip / clip time / yaw (what the device draws with streams 3, 0, 4 of its reset generator)
 void orc_reset_ex(void* h, double kin_time, double max_time, int clip, double yaw) { ((Scene*)h)->reset(kin_time, max_time, clip, (real)yaw); }

@@ -41,6 +41,10 @@ struct SceneCfg {
     double tar_fail_dist = std::numeric_limits<double>::infinity(), tar_speed = 1, pos_reward_scale = 1;
     bool enable_min_tar_vel = false;
     double max_heading_turn_rate = 0.15, sharp_turn_prob = 0.025, speed_change_prob = 0.1, tar_speed_min = 1, tar_speed_max = 1, vel_reward_scale = 1;
+    // --- random perturbations (cSceneSimChar::tPerturbParams, scenes/SceneSimChar.cpp:41-51; keys :92-99); part mask 0 = any body part
+    bool enable_rand_perturbs = false;
+    double perturb_time_min = std::numeric_limits<double>::infinity(), perturb_time_max = std::numeric_limits<double>::infinity();
+    double min_perturb = 50, max_perturb = 100, min_perturb_duration = 0.1, max_perturb_duration = 0.5; uint32_t perturb_part_mask = 0;
     // --- DM-physics v1 constants [EXT-BULLET, SURVEY App. C] ---
     double friction = 0.9 * 0.9;         // link 0.9 (SimCharacter.cpp:26) x ground 0.9 (Ground.cpp:14-27)
     double erp = 0.2;                    // btContactSolverInfo::m_erp2
@@ -134,6 +138,9 @@ struct Scene {
     uint64_t rng_seed = 0, rng_env = 0, goal_draws = 0;    // the device path's counter-based generator (dm_rand01, stream 2)
     double getup_timer = 0;                                // cSceneHeadingAMPGetup::mGetupTimer (time; max = cfg.getup_time)
     bool target_hit = false; double target_hit_time = -1;  // cSceneStrikeAMP::mTargetHit / mTargetHitTime (gInvalidHitTime = -1)
+    // random perturbations: tPerturbParams::mTimer / mNextTime, the entries of cWorld's cPerturbManager (sim/Perturb.h: force at the part's COM)
+    struct Perturb { int link; V3d f; double dur, time; };
+    double pert_timer = 0, pert_next = std::numeric_limits<double>::infinity(); uint64_t pert_draws = 0; std::vector<Perturb> perts;
     // dribble_amp: the ball (cSimSphere), cSceneDribbleAMP::mAgentPrevTarObjPos, mTarObjTimer
     V3 ball_pos, ball_vel, ball_w; Q4 ball_rot; V3d prev_ball_pos; double obj_timer = 0, obj_timer_max = 0;
 
@@ -178,6 +185,7 @@ struct Scene {
         // state -- ; ResetAgentTarObjRecord(); then cSceneTargetAMP::Reset
         if (cfg.scene_goal == 5) { obj_timer_reset(); reset_tar_objs(); }
         timer_time = 0; timer_max = max_time;                       // cTimer::Reset (Timer.cpp:55-73)
+        if (cfg.enable_rand_perturbs) { reset_rand_perturb(); perts.clear(); }   // ResetScene (SceneSimChar.cpp:628-644): ResetRandPertrub; ResetWorld -> cWorld::Reset -> mPerturbManager.Clear()
         if (!clips.empty()) { cur_clip = clip; kin.mo = &clips[clip]; }
         // ResetKinChar: origin rot/pos reset, time := rand_time, Pose(t)
         kin.origin_rot = Q4(); kin.origin = V3(); kin.time = kin_time; kin.do_pose();
@@ -437,6 +445,12 @@ struct Scene {
         LDLT fac; fac.factor(rbd_sim.H, P);
         Vec rhs(P, 0), acc;
         for (int i = 0; i < P; ++i) rhs[i] = tau[i] - rbd_sim.C[i];
+        // external forces of the perturbations (btMultiBody::addLinkForce: world-frame force at the link's centre of mass, held over the
+        // substeps of one stepSimulation call): generalized force J^T f
+        for (const Perturb& pt : perts) {
+            Vec Jr; point_jacobian(pt.link, links[pt.link].com, V3((real)pt.f.x, (real)pt.f.y, (real)pt.f.z), Jr);
+            for (int i = 0; i < P; ++i) rhs[i] += Jr[i];
+        }
         fac.solve(rhs, acc);
         Vec vstar(P, 0);
         for (int i = 0; i < P; ++i) vstar[i] = vel[i] + h * acc[i];
@@ -604,6 +618,7 @@ struct Scene {
         }
         timer_time += dt;                                            // cScene::Update -> UpdateTimers
         if (cfg.scene_goal == 3) getup_timer += dt;                  // cSceneHeadingAMPGetup::UpdateTimers (:163-167)
+        if (cfg.enable_rand_perturbs) update_rand_perturb(dt);       // cSceneSimChar::Update (:145-148), before PreUpdate
         // 4a UpdateKinChar (SceneImitate.cpp:306-318)
         double prev_phase = kin.phase();
         kin.update(dt);
@@ -614,6 +629,8 @@ struct Scene {
         if (need_new_action) need_new_action = false;                // HandleNewAction
         calc_spd_tau(dt, tau);
         // 5 cWorld::Update: stepSimulation(dt, n, dt/n) (World.cpp:93-104)
+        // cPerturbManager::Update (PerturbManager.cpp:39-53) at the top of cWorld::Update: expired entries leave, the others advance and act
+        { size_t k = 0; for (size_t i = 0; i < perts.size(); ++i) if (!(perts[i].time >= perts[i].dur)) { perts[i].time += dt; perts[k++] = perts[i]; } perts.resize(k); }
         double h = dt / cfg.num_sim_substeps;
         for (int s = 0; s < cfg.num_sim_substeps; ++s) substep(h);
         // 7 PostUpdate
@@ -622,6 +639,27 @@ struct Scene {
         if (cfg.scene_goal) goal_update(dt);                         // cSceneTargetAMP::Update after cSceneImitate::Update (:137-146)
         // cSceneHeadingAMPGetup::Update (:99-107) -> UpdateTestGetup (:244-253): in test mode a fall starts a get-up
         if (cfg.scene_goal == 3 && cfg.mode_test && has_fallen_contact() && !getting_up()) getup_timer = 0;
+    }
+
+    // ------------------------------------------------------------------ random perturbations (scenes/SceneSimChar.cpp:205-256, 618-626, 952-956)
+    // Draws: dm_rand01(seed, global env id, draw counter, stream 5) in the reference's call order (part, direction x y z, magnitude, duration,
+    // next time); the reference's own generator is the scene's cRand.
+    double pert_u01() { return rand01(rng_seed, rng_env, pert_draws++, 5); }
+    double pert_uniform(double lo, double hi) { const double u = pert_u01(); return (hi > lo && hi < 1e300) ? lo + (hi - lo) * u : hi; }   // cRand::RandDouble
+    void reset_rand_perturb() { pert_timer = 0; pert_next = pert_uniform(cfg.perturb_time_min, cfg.perturb_time_max); }               // ResetRandPertrub
+    void update_rand_perturb(double dt) {                                                                                            // UpdateRandPerturb
+        pert_timer += dt;
+        if (!(pert_timer >= pert_next)) return;
+        // ApplyRandForce(char 0): GetRandPerturbPartID, then a uniformly drawn direction, magnitude and duration
+        int n = 0; for (int j = 0; j < sk.J; ++j) if (!cfg.perturb_part_mask || ((cfg.perturb_part_mask >> j) & 1u)) ++n;
+        int idx = (int)(pert_u01() * n); if (idx >= n) idx = n - 1;                                                                  // cRand::RandInt(0, n)
+        int part = -1; for (int j = 0, k = 0; j < sk.J; ++j) if (!cfg.perturb_part_mask || ((cfg.perturb_part_mask >> j) & 1u)) { if (k++ == idx) { part = j; break; } }
+        const double dx = pert_uniform(-1, 1), dy = pert_uniform(-1, 1), dz = pert_uniform(-1, 1);
+        const double mag = pert_uniform(cfg.min_perturb, cfg.max_perturb), dur = pert_uniform(cfg.min_perturb_duration, cfg.max_perturb_duration);
+        const double sc = mag / std::sqrt(dx * dx + dy * dy + dz * dz);
+        Perturb pt; pt.link = part; pt.f.x = sc * dx; pt.f.y = sc * dy; pt.f.z = sc * dz; pt.dur = dur; pt.time = 0;
+        if (part >= 0 && sk.valid_body(part)) perts.push_back(pt);                                                                   // cPerturbManager::AddPerturb: valid ones only
+        reset_rand_perturb();
     }
 
     // ------------------------------------------------------------------ goal-conditioned task scenes

@@ -22,7 +22,8 @@ CFG_KEYS = ["num_sim_substeps", "world_scale", "grav_x", "grav_y", "grav_z", "sy
             "mode_test", "getup_time", "getup_height_root", "getup_height_head", "head_id", "recover_prob", "getup_clip_mask",
             "tar_near_dist", "tar_far_prob", "target_radius", "hit_reset_time", "init_hit_prob", "hit_tar_speed", "tar_reward_scale",
             "tmin_x", "tmin_y", "tmin_z", "tmax_x", "tmax_y", "tmax_z", "strike_mask", "fail_tar_mask",
-            "obj_time_min", "obj_time_max", "min_obj_dist", "max_obj_dist", "ball_radius", "ball_mass", "ball_friction", "ball_lin_damp", "ball_ang_damp"]
+            "obj_time_min", "obj_time_max", "min_obj_dist", "max_obj_dist", "ball_radius", "ball_mass", "ball_friction", "ball_lin_damp", "ball_ang_damp",
+            "perturb_on", "perturb_time_min", "perturb_time_max", "perturb_min", "perturb_max", "perturb_dur_min", "perturb_dur_max", "perturb_part_mask"]
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int)
@@ -82,7 +83,10 @@ class Oracle:
                     strike_mask=sum(1 << int(b) for b in (c.strike_bodies or [])), fail_tar_mask=sum(1 << int(b) for b in (c.fail_tar_contact_bodies or [])),
                     obj_time_min=c.rand_tar_obj_time_min, obj_time_max=c.rand_tar_obj_time_max, min_obj_dist=c.min_tar_obj_dist, max_obj_dist=c.max_tar_obj_dist,
                     ball_radius=c.ball_radius, ball_mass=model.BALL_MASS, ball_friction=model.BALL_FRICTION * 0.9,
-                    ball_lin_damp=model.BALL_LIN_DAMPING, ball_ang_damp=model.BALL_ANG_DAMPING)
+                    ball_lin_damp=model.BALL_LIN_DAMPING, ball_ang_damp=model.BALL_ANG_DAMPING,
+                    perturb_on=bool(c.enable_rand_perturbs) and np.isfinite(c.perturb_time_min), perturb_time_min=c.perturb_time_min, perturb_time_max=c.perturb_time_max,
+                    perturb_min=c.min_perturb, perturb_max=c.max_perturb, perturb_dur_min=c.min_pertrub_duration, perturb_dur_max=c.max_perturb_duration,
+                    perturb_part_mask=sum(1 << int(b) for b in set(c.perturb_part_ids or [])))
         vals.update(cfg_overrides)
         for k, v in vals.items():
             cfg[CFG_KEYS.index(k)] = float(v)
@@ -323,6 +327,19 @@ class Oracle:
         out = np.zeros(15)
         self.lib.orc_goal_state(self.h, _d(out))
         return out if full else out[:12]
+
+    def perturb_state(self):
+        """the 16-double row of include/dm_hip.h dm_get_perturb_state"""
+        out = np.zeros(16)
+        self.lib.orc_perturb_state(self.h, _d(out))
+        return out
+
+    def set_perturb_state(self, p):
+        p = np.ascontiguousarray(p, dtype=np.float64).reshape(16)
+        self.lib.orc_set_perturb_state(self.h, _d(p))
+
+    def num_perturbs(self):
+        return int(self.lib.orc_num_perturbs(self.h))
 
     def ball_state(self):
         """dribble_amp: ball pos(3), rot wxyz(4), vel(3), ang vel(3), ball pos at the last action(3), target-object timer time / max"""

@@ -110,7 +110,7 @@ class cDeepMimicCore(object):
 
     def _apply_mode(self):
         lo, hi = _model.timer_limits(self._tables.cfg, self._mode == self.eModeTest, self._sample_count)
-        self._env.set_time_limits(lo, hi)
+        self._env.set_time_limits(lo, hi, _model.timer_exp(self._tables.cfg, self._mode == self.eModeTest, self._sample_count))   # (exp: --timer_type exp)
         if self._goal_size():
             self._env.set_mode(self._mode == self.eModeTest)       # get-up on a fall / recovery episodes / strike_amp's test reward
 

@@ -165,6 +165,10 @@ class BatchEnv:
                 raise ValueError("perturb_part_ids names a body part the character does not have: %s" % sorted(parts))
             st.perturb_part_mask = sum(1 << b for b in parts)
         self.has_perturbs = bool(st.enable_rand_perturbs)
+        if c.timer_type not in ("uniform", "exp"):
+            raise ValueError("unsupported timer type %r (util/Timer.cpp:27-45: uniform | exp)" % c.timer_type)
+        self._timer = (c.timer_type, tmin, tmax, float(c.time_lim_exp)); self._timer_pinned = tmin == tmax
+        self._seed, self._env_off = int(seed) & (2 ** 64 - 1), int(env_id_offset)
         info = _CreateInfo(int(num_envs), int(device_id), int(seed) & (2 ** 64 - 1), int(precision), int(max_contacts), int(env_id_offset), int(wave_packing))
         self.h = C.c_void_p()
         self._chk(self.lib.dm_create(C.byref(info), C.byref(st), C.byref(self.h)))
@@ -197,15 +201,30 @@ class BatchEnv:
         n = self.N if ids is None else ids.size
         kt = None if kin_times is None else np.ascontiguousarray(np.broadcast_to(kin_times, (n,)), dtype=np.float64)
         mt = None if max_times is None else np.ascontiguousarray(np.broadcast_to(max_times, (n,)), dtype=np.float64)
+        if mt is None and self._timer[0] == "exp" and not self._timer_pinned:
+            # `--timer_type exp` (util/Timer.cpp:64-67): the kernels draw the uniform timer; an explicit reset draws the exponential one here,
+            # from the same counter-based stream (seed, global env id, episode counter, stream 1) the device would have used
+            from . import model, streams
+            ep = self.get_state()["flags"][:, 2]
+            sel = np.arange(self.N) if ids is None else ids
+            mt = np.array([model.draw_time_limit("exp", self._timer[1], self._timer[2], self._timer[3],
+                                                 streams.reset_rand01(self._seed, self._env_off + int(e), int(ep[int(e)]), 1)) for e in sel], dtype=np.float64)
         self._chk(self.lib.dm_reset(self.h, _ip(ids), n, _dp(kt), _dp(mt)))
 
-    def set_time_limits(self, time_lim_min: float, time_lim_max: float):
+    def _check_auto_reset(self, auto_reset):
+        if auto_reset and self._timer[0] == "exp" and not self._timer_pinned:
+            raise ValueError("--timer_type exp: the in-kernel auto-reset draws the uniform episode timer; step without auto_reset and call reset() "
+                             "(it draws the exponential limit of util/Timer.cpp:64-67 on the host)")
+
+    def set_time_limits(self, time_lim_min: float, time_lim_max: float, time_lim_exp: Optional[float] = None):
         self._chk(self.lib.dm_set_time_limits(self.h, C.c_double(time_lim_min), C.c_double(time_lim_max)))
+        self._timer = (self._timer[0], float(time_lim_min), float(time_lim_max), self._timer[3] if time_lim_exp is None else float(time_lim_exp))
+        self._timer_pinned = time_lim_min == time_lim_max          # test mode: cRLSceneSimChar::ResetTimers pins the limit, whatever the type
 
     def set_sample_count(self, sample_count: int, test_mode: bool = False):
         """cRLSceneSimChar::SetSampleCount / SetMode for the whole batch: anneal the episode-length limits (model.timer_limits)."""
         from . import model
-        self.set_time_limits(*model.timer_limits(self.tables.cfg, test_mode, sample_count))
+        self.set_time_limits(*model.timer_limits(self.tables.cfg, test_mode, sample_count), model.timer_exp(self.tables.cfg, test_mode, sample_count))
 
     def set_action(self, actions):
         a = np.ascontiguousarray(actions, dtype=np.float32).reshape(self.N, self.A)
@@ -228,6 +247,7 @@ class BatchEnv:
         end_early (default: follows auto_reset): an env whose episode is over after an update takes no further updates in this call,
         as the reference's driver ends an episode at the update where IsEpisodeEnd turns true (DeepMimic.py:62-80)."""
         end_early = auto_reset if end_early is None else end_early
+        self._check_auto_reset(auto_reset)
         a = None if actions is None else np.ascontiguousarray(actions, dtype=np.float32).reshape(self.N, self.A)
         s = np.zeros((self.N, self.S), np.float32); r = np.zeros(self.N, np.float32)
         t = np.zeros(self.N, np.int32); v = np.zeros(self.N, np.int32); e = np.zeros(self.N, np.int32)
@@ -332,6 +352,7 @@ class BatchEnv:
                     timestep: float = 1.0 / 600, n_updates: int = 20, auto_reset=False, open_loop=False, amp_ptr=0, end_early=None):
         """Same as step() on raw device pointers (ints), asynchronous on the ctx stream."""
         end_early = auto_reset if end_early is None else end_early
+        self._check_auto_reset(auto_reset)
         flags = DM_DEVICE_PTRS | (DM_AUTO_RESET if auto_reset else 0) | (DM_OPEN_LOOP if open_loop else 0) | (DM_END_EPISODE_EARLY if end_early else 0)
         vp = lambda p: C.c_void_p(p) if p else None
         if amp_ptr:
@@ -359,6 +380,7 @@ class BatchEnv:
 
     def bench_rollout(self, warmup: int, steps: int, timestep=1.0 / 600, n_updates=20, auto_reset=True, open_loop=True):
         ms = C.c_double(0)
+        self._check_auto_reset(auto_reset)
         flags = (DM_AUTO_RESET if auto_reset else 0) | (DM_OPEN_LOOP if open_loop else 0) | (DM_END_EPISODE_EARLY if auto_reset else 0)
         self._chk(self.lib.dm_bench_rollout(self.h, int(warmup), int(steps), C.c_double(timestep), int(n_updates), flags, None, None, C.byref(ms)))
         return ms.value

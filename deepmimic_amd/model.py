@@ -500,8 +500,8 @@ def timer_limits(cfg: SceneConfig, test_mode: bool = False, sample_count: int = 
     `cTimer::tParams::Blend`, util/Timer.cpp:12-20; `cAnnealer::Eval`, util/Annealer.cpp) when `anneal_samples` > 0.
     Test mode: `ResetTimers` (:277-284) pins the limit to `time_end_lim_max`.  An unset limit is +inf (util/Timer.cpp:7-8);
     the NaN the reference's `0 * inf` would produce never satisfies `mTime >= mMaxTime`, i.e. behaves as +inf."""
-    if cfg.timer_type != "uniform":
-        raise ValueError("timer_type %r is not on the accelerated path (only 'uniform' appears in the arg files)" % cfg.timer_type)
+    if cfg.timer_type not in ("uniform", "exp"):
+        raise ValueError("unsupported timer type %r (util/Timer.cpp:27-45: uniform | exp)" % cfg.timer_type)
     emin = cfg.time_lim_min if cfg.time_end_lim_min is None else cfg.time_end_lim_min
     emax = cfg.time_lim_max if cfg.time_end_lim_max is None else cfg.time_end_lim_max
     if test_mode:
@@ -516,6 +516,23 @@ def timer_limits(cfg: SceneConfig, test_mode: bool = False, sample_count: int = 
         return float("inf") if np.isnan(v) else float(v)
 
     return blend(cfg.time_lim_min, emin), blend(cfg.time_lim_max, emax)
+
+
+def timer_exp(cfg: SceneConfig, test_mode: bool = False, sample_count: int = 0) -> float:
+    """mTimeExp of the blended timer parameters (`cTimer::tParams::Blend`, util/Timer.cpp:12-20), for `--timer_type exp`."""
+    eexp = cfg.time_lim_exp if cfg.time_end_lim_exp is None else cfg.time_end_lim_exp
+    lerp = 0.0
+    if cfg.anneal_samples > 0 and not test_mode:
+        lerp = min(max(float(sample_count) / cfg.anneal_samples, 0.0), 1.0) ** 4.0
+    return float((1.0 - lerp) * cfg.time_lim_exp + lerp * eexp)
+
+
+def draw_time_limit(timer_type: str, lo: float, hi: float, exp: float, u: float) -> float:
+    """`cTimer::Reset` (util/Timer.cpp:55-73) from one uniform draw u in [0, 1): uniform -> U[lo, hi]; exp -> min(lo + Exp(rate 1 / exp), hi)
+    (`cMathUtil::RandDoubleExp` = std::exponential_distribution: -ln(1 - u) / rate)."""
+    if timer_type == "exp":
+        return float(min(lo - exp * np.log1p(-u), hi))
+    return float(lo + (hi - lo) * u) if hi > lo else float(hi)
 
 
 # --- scene loading -------------------------------------------------------------

@@ -280,3 +280,29 @@ def test_imitate_amp_time_warp_test_return(emu_lib, monkeypatch):
     core.SetMode(core.eModeTrain); core.Reset()
     core.SetAction(0, [0.0] * core.GetActionSize(0)); core.Update(1.0 / 600)
     assert core.CalcReward(0) == 0.0
+
+
+def test_facade_exponential_timer(emu_lib, monkeypatch):
+    """`--timer_type exp --time_lim_exp` (util/Timer.cpp:27-45, 64-67) through ParseArgs: every Reset draws min(time_lim_min + Exp(time_lim_exp), time_lim_max);
+    test mode pins time_end_lim_max (cRLSceneSimChar::ResetTimers)"""
+    from deepmimic_amd import model, streams
+    monkeypatch.setenv("DM_HIP_LIB", emu_lib); monkeypatch.setenv("DM_PRECISION", "64")
+    mod = _core_module()
+    t = model.load_asset("humanoid3d_walk")
+    t.cfg.timer_type = "exp"; t.cfg.time_lim_min, t.cfg.time_lim_max, t.cfg.time_lim_exp = 0.5, 4.0, 1.0
+    t.cfg.time_end_lim_min, t.cfg.time_end_lim_max, t.cfg.time_end_lim_exp = 0.5, 20.0, 5.0; t.cfg.anneal_samples = 1000
+    core = mod.cDeepMimicCore(False)
+    core.SeedRand(3); core.LoadTables(t, num_update_substeps=10); core.Init()
+    seen = []
+    for k in range(5):
+        ep = int(core._env.get_state()["flags"][0][2])
+        core.Reset()
+        mt = float(core._env.get_state()["clocks"][0][4])
+        assert mt == model.draw_time_limit("exp", 0.5, 4.0, 1.0, streams.reset_rand01(core._seed, 0, ep, 1))
+        seen.append(mt)
+    assert len(set(seen)) == 5 and min(seen) >= 0.5 and max(seen) <= 4.0
+    core.SetSampleCount(1000)                                       # end of the annealing: Blend() reaches the end parameters, exp included
+    ep = int(core._env.get_state()["flags"][0][2]); core.Reset()
+    assert float(core._env.get_state()["clocks"][0][4]) == model.draw_time_limit("exp", 0.5, 20.0, 5.0, streams.reset_rand01(core._seed, 0, ep, 1))
+    core.SetMode(core.eModeTest); core.Reset()
+    assert float(core._env.get_state()["clocks"][0][4]) == 20.0

@@ -26,3 +26,36 @@ def test_reset_phase_is_the_knuth_hash():
     ph = streams.reset_phase([0, 1, 2, 4095], 1.25)
     assert ph[0] == 0.0 and abs(ph[1] - 2654435761 / 2 ** 32 * 1.25) < 1e-15
     assert ((ph >= 0) & (ph < 1.25)).all()
+
+
+def test_exponential_episode_timer(emu_lib):
+    """`--timer_type exp` (util/Timer.cpp:64-67): max time = min(time_lim_min + Exp(mean time_lim_exp), time_lim_max), drawn by reset() from the reset
+    stream; the facade's driver resets explicitly, the in-kernel auto-reset (uniform draw) refuses the type"""
+    import pytest
+    from deepmimic_amd import model, streams
+    from deepmimic_amd.core import BatchEnv
+    t = model.load_asset("humanoid3d_walk")
+    t.cfg.timer_type = "exp"; t.cfg.time_lim_min, t.cfg.time_lim_max, t.cfg.time_lim_exp = 0.5, 3.0, 0.8
+    t.cfg.time_end_lim_min = t.cfg.time_end_lim_max = t.cfg.time_end_lim_exp = None
+    n, seed = 64, 17
+    env = BatchEnv(t, n, precision=64, lib_path=emu_lib, seed=seed, env_id_offset=100)
+    lims = []
+    for k in range(6):
+        ep = env.get_state()["flags"][:, 2].copy()
+        env.reset()
+        mt = env.get_state()["clocks"][:, 4]
+        want = [model.draw_time_limit("exp", 0.5, 3.0, 0.8, streams.reset_rand01(seed, 100 + e, int(ep[e]), 1)) for e in range(n)]
+        assert np.array_equal(mt, np.array(want))
+        lims.append(mt)
+    lims = np.concatenate(lims)
+    assert lims.min() >= 0.5 and lims.max() <= 3.0 and (lims == 3.0).mean() > 0.01              # the clipped tail: P = exp(-2.5 / 0.8) = 4.4 %
+    assert abs(np.mean(np.minimum(lims, 2.9999) - 0.5) - 0.8 * (1 - np.exp(-2.5 / 0.8))) < 0.12  # mean of the truncated exponential
+    with pytest.raises(ValueError, match="timer_type exp"):
+        env.step(None, 1 / 600, 20, open_loop=True, auto_reset=True)
+    env.step(None, 1 / 600, 20, open_loop=True)                                                  # without auto-reset it steps
+    env.set_sample_count(0, test_mode=True)                                                      # test mode pins the limit (cRLSceneSimChar::ResetTimers)
+    env.reset()
+    assert (env.get_state()["clocks"][:, 4] == 3.0).all()
+    t.cfg.timer_type = "gauss"
+    with pytest.raises(ValueError, match="unsupported timer type"):
+        BatchEnv(t, 2, precision=64, lib_path=emu_lib)

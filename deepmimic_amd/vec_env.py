@@ -1,5 +1,5 @@
 """Device-resident vectorised env on top of the C-ABI (deepmimic_amd/core.py): observations, rewards and flags stay in HBM as
-torch tensors, one kernel launch per 30 Hz control step, asynchronous on torch's current stream -- the way a GPU learner consumes
+torch tensors, one kernel launch per 30 Hz control step, asynchronous on torch's current stream (whatever is current at each call) -- the way a GPU learner consumes
 the path (the facade in compat/ is the drop-in for the reference's one-env-per-process driver; this is the batched form of the same
 protocol: SetAction ; 20 x Update ; RecordState / CalcReward / CheckTerminate ; Reset of finished episodes, DeepMimic.py:62-80).
 
@@ -29,16 +29,17 @@ class TorchVecEnv:
         self.obs = torch.zeros((self.n, self.obs_dim), **f32); self.reward = torch.zeros(self.n, **f32)
         self.terminate = torch.zeros(self.n, **i32); self.valid = torch.zeros(self.n, **i32); self.episode_end = torch.zeros(self.n, **i32)
         self.amp_obs = torch.zeros((self.n, self.env.amp_size), **f32) if (amp_obs and self.env.amp_size) else None
-        # the launches go to a stream of their own, fenced against the caller's current stream on both sides of every call (torch's
-        # default stream has the null handle, which dm_set_stream reads as "the ctx's own stream": no implicit ordering to rely on)
-        self.stream = torch.cuda.Stream(self.device)
-        self.env.set_stream(self.stream.cuda_stream)
+        # the launches go to the caller's CURRENT torch stream (looked up at every call): ordered against the caller's work on both sides
+        # without events (torch's default stream has the null handle; BatchEnv.set_stream maps it to the legacy default stream)
+        self._stream_handle = None
 
     def _enter(self):
-        self.stream.wait_stream(self.torch.cuda.current_stream(self.device))
+        h = int(self.torch.cuda.current_stream(self.device).cuda_stream)
+        if h != self._stream_handle:
+            self.env.set_stream(h); self._stream_handle = h
 
     def _leave(self):
-        self.torch.cuda.current_stream(self.device).wait_stream(self.stream)
+        pass
 
     def _launch(self, actions_ptr, n_updates, auto_reset):
         self.env.step_device(actions_ptr, self.obs.data_ptr(), self.reward.data_ptr(), self.terminate.data_ptr(), self.valid.data_ptr(),

@@ -66,3 +66,29 @@ def test_set_stream_of_torchs_default_stream_orders_the_launch(hip_lib):
         assert torch.equal(seen_s, st) and torch.equal(seen_r, rw)
         assert float(seen_r.min()) >= 0.0 and float(seen_s.abs().max()) < 1e3        # the step's outputs, not the -7 fill
     env.close()
+
+
+@pytest.mark.gpu
+def test_vec_env_follows_the_current_stream(hip_lib):
+    """the launches ride on whatever torch stream is current at the call (no stream of their own, no events): alternating between the default
+    stream and a side stream, the results stay those of the host-pointer path"""
+    import torch
+    from deepmimic_amd.vec_env import TorchVecEnv
+    t = model.load_asset("humanoid3d_walk")
+    n = 64
+    torch.cuda.set_stream(torch.cuda.default_stream())
+    ve = TorchVecEnv(t, n, seed=8, lib_path=hip_lib)
+    ref = BatchEnv(t, n, seed=8, lib_path=hip_lib)
+    ve.reset(); ref.reset()
+    side = torch.cuda.Stream()
+    rng = np.random.default_rng(2)
+    for k in range(8):
+        a = (0.2 * rng.normal(size=(n, ve.act_dim))).astype(np.float32)
+        with torch.cuda.stream(side if k % 2 else torch.cuda.default_stream()):
+            at = torch.from_numpy(a).to(ve.device)
+            o, r, d, _ = ve.step(at)
+            o2 = (o * 1.0).cpu().numpy()                 # a torch op behind the launch on the same stream, then the copy: sees the step's output
+            r2 = r.cpu().numpy()
+        out = ref.step(a, ve.timestep, ve.updates, auto_reset=True)
+        assert np.array_equal(o2, out["state"]) and np.array_equal(r2, out["reward"]), k
+    ve.close(); ref.close()

@@ -8,7 +8,7 @@ cd "$(dirname "$0")"
 REF="${1:-/root/reference/DeepMimicCore}"
 CXX="${CXX:-g++}"
 FLAGS="-O2 -std=c++14 -fPIC -w -Ieigen_shim -Igl_stub -I$REF"
-SRCS="util/MathUtil util/Rand util/JsonUtil util/FileUtil util/Timer util/DynamicTimeWarper
+SRCS="util/MathUtil util/Rand util/JsonUtil util/FileUtil util/Timer util/Annealer util/DynamicTimeWarper
       util/json/json_reader util/json/json_value util/json/json_writer
       sim/SpAlg sim/RBDUtil sim/RBDModel sim/CtCtrlUtil
       anim/KinTree anim/Shape anim/Motion anim/Character anim/KinCharacter anim/KinController

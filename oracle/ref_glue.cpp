@@ -1,7 +1,7 @@
 // TEST INFRASTRUCTURE ONLY -- C entry points over the reference's OWN, UNMODIFIED sources.
 //
 // oracle/_ref/libdm_ref.so = this file + /root/reference/DeepMimicCore/{util/MathUtil, util/Rand, util/JsonUtil,
-// util/FileUtil, util/Timer, util/DynamicTimeWarper, util/json/*, sim/SpAlg, sim/RBDUtil, sim/RBDModel, sim/CtCtrlUtil,
+// util/FileUtil, util/Timer, util/Annealer, util/DynamicTimeWarper, util/json/*, sim/SpAlg, sim/RBDUtil, sim/RBDModel, sim/CtCtrlUtil,
 // anim/KinTree, anim/Shape, anim/Motion, anim/Character, anim/KinCharacter, anim/KinController, anim/MotionController,
 // anim/ClipsController}.cpp compiled where they lie (recipe: oracle/Makefile, target `ref`) against oracle/eigen_shim
 // (Eigen is not installed) and oracle/gl_stub (type names only).  Nothing is copied into this repository.
@@ -32,6 +32,7 @@
 #include "util/DynamicTimeWarper.h"
 #include "util/MathUtil.h"
 #include "util/Timer.h"
+#include "util/Annealer.h"
 
 // ---- link-time stand-ins for the renderer (anim/Character.cpp references them; draw is disabled) -----------------
 bool cDrawUtil::EnableDraw() { return false; }
@@ -495,6 +496,25 @@ int ref_timer_first_end(double max_time, double dt, int n) {
     cTimer t; t.Init(p); t.Reset();
     for (int i = 0; i < n; ++i) { t.Update(dt); if (t.IsEnd()) return i; }
     return -1;
+}
+
+// cTimer::Reset (util/Timer.cpp:55-73) with the process-global generator (cMathUtil::SeedRand): n max times of a timer of the given type
+// (0 uniform, 1 exp) and parameters
+void ref_timer_draws(int type, double tmin, double tmax, double texp, unsigned long seed, int n, double* out) {
+    cMathUtil::SeedRand(seed);
+    cTimer::tParams p; p.mType = type ? cTimer::eTypeExp : cTimer::eTypeUniform; p.mTimeMin = tmin; p.mTimeMax = tmax; p.mTimeExp = texp;
+    cTimer t; t.Init(p);
+    for (int i = 0; i < n; ++i) { t.Reset(); out[i] = t.GetMaxTime(); }
+}
+// cTimer::tParams::Blend (util/Timer.cpp:12-20) at the lerp cAnnealer::Eval (util/Annealer.cpp; cRLSceneSimChar::SetupTimerAnnealer: pow 4)
+// gives for t = sample_count / anneal_samples: out = {lerp, min, max, exp}
+void ref_timer_anneal(const double* p0 /*min max exp*/, const double* p1, double t, double* out) {
+    cAnnealer::tParams ap; ap.mType = cAnnealer::eTypePow; ap.mPow = 4.0;
+    cAnnealer an; an.Init(ap);
+    const double lerp = an.Eval(t);
+    cTimer::tParams a, b; a.mTimeMin = p0[0]; a.mTimeMax = p0[1]; a.mTimeExp = p0[2]; b.mTimeMin = p1[0]; b.mTimeMax = p1[1]; b.mTimeExp = p1[2];
+    cTimer::tParams c = a.Blend(b, lerp);
+    out[0] = lerp; out[1] = c.mTimeMin; out[2] = c.mTimeMax; out[3] = c.mTimeExp;
 }
 
 }  // extern "C"

@@ -401,6 +401,38 @@ def test_timer_end(libs):
         assert got == first, (max_time, got, first)
 
 
+def test_timer_draws_and_annealing_vs_reference(libs):
+    """cTimer::Reset for both timer types (util/Timer.cpp:55-73) and the annealed parameters (cTimer::tParams::Blend at cAnnealer's pow-4 lerp,
+    scenes/RLSceneSimChar.cpp:330-347), compiled from the reference's own sources: model.draw_time_limit maps uniform numbers to the same
+    distribution (the reference draws from std::default_random_engine, this path from its counter generator: distributions, not sequences, can
+    agree), model.timer_limits / timer_exp give the same blended parameters"""
+    import ctypes
+    ref, _ = libs
+    n = 40000
+    u = (np.arange(n) + 0.5) / n
+    for typ, name, tmin, tmax, texp in ((0, "uniform", 0.5, 3.0, 1.0), (1, "exp", 0.5, 3.0, 0.8), (1, "exp", 2.0, 50.0, 5.0)):
+        out = np.zeros(n)
+        ref.lib.ref_timer_draws(typ, ctypes.c_double(tmin), ctypes.c_double(tmax), ctypes.c_double(texp), ctypes.c_ulong(7), n,
+                                out.ctypes.data_as(ctypes.POINTER(ctypes.c_double)))
+        mine = np.sort([model.draw_time_limit(name, tmin, tmax, texp, x) for x in u])
+        assert out.min() >= tmin and out.max() <= tmax
+        # two-sample Kolmogorov distance between the reference's draws and the quantiles of this path's map
+        grid = np.linspace(tmin, tmax, 400)
+        ks = np.abs(np.searchsorted(np.sort(out), grid, side="right") / n - np.searchsorted(mine, grid, side="right") / n).max()
+        assert ks < 0.012, (name, ks)
+        assert abs((out == tmax).mean() - (mine == tmax).mean()) < 0.005                     # the mass the exp timer clips at time_lim_max
+    cfg = model.SceneConfig()
+    cfg.timer_type = "exp"; cfg.time_lim_min, cfg.time_lim_max, cfg.time_lim_exp = 0.5, 0.5, 0.2
+    cfg.time_end_lim_min, cfg.time_end_lim_max, cfg.time_end_lim_exp = 20.0, 40.0, 5.0; cfg.anneal_samples = 1000
+    for count in (0, 100, 500, 900, 1000, 5000):
+        out = np.zeros(4)
+        p0 = np.array([0.5, 0.5, 0.2]); p1 = np.array([20.0, 40.0, 5.0])
+        ref.lib.ref_timer_anneal(p0.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), p1.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
+                                 ctypes.c_double(count / 1000.0), out.ctypes.data_as(ctypes.POINTER(ctypes.c_double)))
+        lo, hi = model.timer_limits(cfg, False, count)
+        assert abs(lo - out[1]) < 1e-12 and abs(hi - out[2]) < 1e-12 and abs(model.timer_exp(cfg, False, count) - out[3]) < 1e-12, (count, out)
+
+
 def test_time_warp_alignment_vs_reference_dtw(libs):
     """model.time_warp_cost (the facade's test-mode score of imitate_amp) vs the reference's cDynamicTimeWarper, compiled"""
     import ctypes

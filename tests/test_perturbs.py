@@ -345,3 +345,15 @@ def test_facade_updates_with_perturbs_follow_the_oracle(emu_lib, monkeypatch):
             break
     ro = o.perturb_state(); rd = core._env.get_perturb_state()[0]
     assert fired > 20 and np.abs(rd[:3] - ro[:3]).max() < 1e-9 and active(rd) == active(ro)
+
+
+def test_perturbation_draws_are_keyed_by_global_env_id(emu_lib):
+    """shard invariance: envs 2..3 of a 4-env batch and a 2-env shard with env_id_offset = 2 see the same pushes and the same trajectory"""
+    t = perturbed(model.load_asset("humanoid3d_walk"))
+    full = BatchEnv(t, 4, precision=64, lib_path=emu_lib, seed=12)
+    shard = BatchEnv(t, 2, precision=64, lib_path=emu_lib, seed=12, env_id_offset=2)
+    full.reset(); shard.reset()
+    for _ in range(8):
+        a = full.step(None, DT, 20, open_loop=True, auto_reset=True); b = shard.step(None, DT, 20, open_loop=True, auto_reset=True)
+        assert np.array_equal(a["state"][2:], b["state"]) and np.array_equal(a["reward"][2:], b["reward"])
+    assert np.array_equal(full.get_perturb_state()[2:], shard.get_perturb_state()) and full.get_perturb_state()[:, 2].max() > 7

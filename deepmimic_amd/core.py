@@ -53,6 +53,7 @@ class _SceneTables(C.Structure):
     ]
 
 
+ABI_VERSION = 3        # include/dm_hip.h DM_ABI_VERSION
 _libs = {}
 
 
@@ -69,6 +70,11 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     # harness says so, so that no environment variable alone can turn the shipped path into a CPU path
     if not hasattr(lib, "dm_is_emulator"):
         raise RuntimeError("%s does not export dm_is_emulator: stale build, rebuild with __graft_entry__.build()" % path)
+    # the structs are mirrored by hand above: refuse a library whose layout is not the one this binding was written against
+    sizes = (C.c_int32 * 2)()
+    if (not hasattr(lib, "dm_abi_version") or lib.dm_abi_version() != ABI_VERSION or lib.dm_struct_sizes(sizes) != 0
+            or (sizes[0], sizes[1]) != (C.sizeof(_CreateInfo), C.sizeof(_SceneTables))):
+        raise RuntimeError("%s does not match this binding (ABI version / struct layout): rebuild with __graft_entry__.build()" % path)
     if lib.dm_is_emulator() and os.environ.get("DM_ALLOW_EMULATOR") != "1":
         raise RuntimeError("%s is the CPU emulator build (test infrastructure); deepmimic_amd runs on the HIP library only" % path)
     lib.dm_last_error.restype = C.c_char_p

@@ -647,6 +647,12 @@ struct dm_ctx { CtxBase* c; };
 // ---------------------------------------------------------------- C-ABI
 extern "C" {
 
+int dm_abi_version(void) { return DM_ABI_VERSION; }
+int dm_struct_sizes(int32_t* out) {
+    if (!out) return fail("null argument");
+    out[0] = (int32_t)sizeof(dm_create_info); out[1] = (int32_t)sizeof(dm_scene_tables);
+    return 0;
+}
 int dm_is_emulator(void) {
 #ifdef DM_EMU
     return 1;

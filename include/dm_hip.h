@@ -16,6 +16,11 @@
 extern "C" {
 #endif
 
+/* Layout version of this header: bumped whenever dm_create_info / dm_scene_tables gain fields or an entry point changes meaning.  A host checks
+ * `dm_abi_version() == DM_ABI_VERSION` (and a binding that mirrors the structs by hand, `dm_struct_sizes`) once after loading the library: the
+ * tables are read as the CURRENT layout, a caller built against an older header would hand over a shorter struct. */
+#define DM_ABI_VERSION 3
+
 typedef struct dm_ctx dm_ctx;
 
 typedef struct {
@@ -108,6 +113,9 @@ enum { DM_DEVICE_PTRS = 1, DM_AUTO_RESET = 2, DM_OPEN_LOOP = 4, DM_NO_EMIT = 8, 
 const char* dm_last_error(void);
 /* 0 for libdm_hip.so; 1 for the CPU fiber-emulator build of the same sources (tests/emu, test infrastructure) */
 int dm_is_emulator(void);
+/* DM_ABI_VERSION the library was built with; out[0] = sizeof(dm_create_info), out[1] = sizeof(dm_scene_tables) as the library sees them */
+int dm_abi_version(void);
+int dm_struct_sizes(int32_t* out);
 
 /* cDeepMimicCore ctor + ParseArgs + Init  (DeepMimicCore.cpp:9-54) */
 int dm_create(const dm_create_info* info, const dm_scene_tables* tables, dm_ctx** out);

@@ -39,3 +39,25 @@ def test_create_without_gpu_fails_loudly(hip_lib):
         assert "no HIP device" in str(ex) or "hip" in str(ex).lower()
     else:
         raise AssertionError("BatchEnv was created without a GPU")
+
+
+def test_binding_mirrors_the_header_structs(emu_lib, tmp_path):
+    """the ctypes structs of deepmimic_amd/core.py are written by hand: their sizes and a field-offset sample must be what a C compiler makes of
+    include/dm_hip.h, and binding, header and library must agree on DM_ABI_VERSION"""
+    import ctypes as C
+    import re
+    import subprocess
+    from deepmimic_amd import core
+    src = tmp_path / "sz.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "dm_hip.h"\nint main(void){ printf("%d %zu %zu %zu %zu %zu\\n", DM_ABI_VERSION, '
+                   'sizeof(dm_create_info), sizeof(dm_scene_tables), offsetof(dm_scene_tables, scene_goal), offsetof(dm_scene_tables, ball_radius), '
+                   'offsetof(dm_scene_tables, perturb_part_mask)); return 0; }\n')
+    exe = tmp_path / "sz"
+    subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    ver, s_info, s_tab, o_goal, o_ball, o_mask = [int(x) for x in subprocess.check_output([str(exe)]).split()]
+    assert ver == core.ABI_VERSION == int(re.search(r"#define DM_ABI_VERSION (\d+)", open(os.path.join(ROOT, "include", "dm_hip.h")).read()).group(1))
+    assert (s_info, s_tab) == (C.sizeof(core._CreateInfo), C.sizeof(core._SceneTables))
+    assert (o_goal, o_ball, o_mask) == (core._SceneTables.scene_goal.offset, core._SceneTables.ball_radius.offset, core._SceneTables.perturb_part_mask.offset)
+    lib = core.load_library(emu_lib)
+    sizes = (C.c_int32 * 2)()
+    assert lib.dm_abi_version() == ver and lib.dm_struct_sizes(sizes) == 0 and (sizes[0], sizes[1]) == (s_info, s_tab)

@@ -124,3 +124,29 @@ def test_kin_char_arg_files_play_back(monkeypatch):
         with pytest.raises(RuntimeError, match="no agents"):
             core.RecordState(0)
         core.Shutdown()
+
+
+@pytest.mark.skipif(not os.path.isfile(os.path.join(REF, "util", "arg_parser.py")), reason="reference checkout not present")
+def test_arg_parser_agrees_with_the_references_python_parser():
+    """model.ArgParser against the reference's own util/arg_parser.py (imported from the checkout), on every shipped arg file and on token lists with
+    comments, repeated keys (first wins), empty value lists and short dashes"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_arg_parser", os.path.join(REF, "util", "arg_parser.py"))
+    mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+    files = sorted(glob.glob(os.path.join(REF, "args", "*.txt")))
+    assert len(files) == 98
+    for f in files:
+        r = mod.ArgParser(); assert r.load_file(f)
+        p = model.ArgParser([]); assert p.load_file(f)
+        assert p.table == r._table, f
+    rng = np.random.default_rng(0)
+    vocab = ["--scene", "--a", "--bb", "--", "-x", "--num_update_substeps", "#c", "# comment", "imitate", "1", "-2.5", "true", "T", "0", "--scene", "--k1", "--k2", "v"]
+    for _ in range(300):
+        toks = [vocab[i] for i in rng.integers(0, len(vocab), size=int(rng.integers(0, 14)))]
+        r = mod.ArgParser(); r.load_args(toks)
+        p = model.ArgParser(toks)
+        assert p.table == r._table, toks
+        for k in p.table:
+            assert p.str(k, "d") == r.parse_string(k, "d") if p.table[k] else True
+            if p.table[k]:
+                assert p.bool(k, False) == r.parse_bool(k, False)

@@ -8,7 +8,11 @@ One "step" = one 30 Hz control step of every env on the rank = one `k_env_step` 
 humanoid3d_walk, 4096 envs per GPU, fixed-action stream A1 (open-loop mocap tracking, generated on device), inputs
 resident in HBM.  N > 1: one process per GPU (torch.distributed, backend nccl = RCCL), env shards are independent
 (weak scaling); the only collective is the per-step all-gather of (state, reward, terminate) for the learner.
-Rank 0 prints ONE JSON line.
+`python bench.py --gpus N` with no WORLD_SIZE in the environment launches its own N ranks (one per GPU, rank r on GPU r) under
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1` -- the reference's precedent for a
+self-launching driver is mpi_run.py:16-24 (`mpiexec -n W python3 DeepMimic_Optimizer.py`); under an external launcher
+(WORLD_SIZE set) it is one of the ranks.  Rank 0 prints ONE JSON line and refuses to print one whose n_gpus is not --gpus.
+`--backend gloo` is the CPU test harness of this N > 1 path (emulator build of the kernels, tests/test_bench_launcher.py).
 """
 import argparse
 import json
@@ -32,19 +36,35 @@ def algorithmic_bytes_per_env_step(env):
 
 
 def measured_traffic(scene, n, kernel=None):
-    """HBM bytes per step-kernel launch from the committed rocprofv3 PMC passes (profiles/r0N_traffic*.json, collected as
-    MI355X_MICROARCH.md prescribes: separate --pmc passes for FETCH_SIZE and WRITE_SIZE; tools/collect_profiles.py), newest
-    round first; None when no profile of this workload is committed."""
+    """(HBM bytes per step-kernel launch, source file) from the committed rocprofv3 PMC passes (profiles/r0N_traffic*.json,
+    collected as MI355X_MICROARCH.md prescribes: separate --pmc passes for FETCH_SIZE and WRITE_SIZE; tools/collect_profiles.py),
+    newest round first; (None, None) when no profile of this workload is committed.  It is a committed counter measurement of
+    the same workload and kernel, NOT a counter read of the run that prints it (PMC passes serialise the kernels): the bench
+    line names the file in `roofline.traffic_source`."""
     import glob
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic*.json")), reverse=True):
         try:
             with open(path) as f:
                 t = json.load(f)
             if t.get("scene") == scene and int(t.get("envs", -1)) == n and (kernel is None or t.get("kernel", kernel) == kernel):
-                return float(t["hbm_bytes_per_launch"])
+                return float(t["hbm_bytes_per_launch"]), os.path.relpath(path, ROOT)
         except Exception:
             continue
-    return None
+    return None, None
+
+
+def self_launch(argv, n):
+    """--gpus N > 1 without an external launcher: start N ranks (one per GPU) of this script and hand their output through."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["MASTER_ADDR"] = "127.0.0.1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    return subprocess.call(cmd, env=env)
 
 
 def timer_limits_of(tables, test_mode=True):
@@ -167,6 +187,8 @@ def main():
     ap.add_argument("--force-gather", action="store_true", help="exercise the record exchange even with one rank")
     ap.add_argument("--gather", choices=["torch", "cabi"], default="torch",
                     help="record exchange through torch.distributed (default) or through the C-ABI (dm_comm_* / dm_gather_records: RCCL driven by libdm_hip.so)")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help="nccl (= RCCL, the product) or gloo: CPU test harness of the N > 1 path (needs DM_HIP_LIB = the emulator build and DM_ALLOW_EMULATOR=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--facade", action="store_true", help="measure the single-env cDeepMimicCore facade path instead of the batched env")
     ap.add_argument("--cpu-baseline-worker", type=int, default=None, help=argparse.SUPPRESS)
@@ -182,6 +204,11 @@ def main():
         facade_bench(args.scene, min(args.steps, 300))
         return
 
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(sys.argv[1:], args.gpus))
+
     import torch
     import torch.distributed as dist
     from deepmimic_amd import model
@@ -189,23 +216,40 @@ def main():
 
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    if world != args.gpus:
+        raise SystemExit("bench.py --gpus %d launched with WORLD_SIZE=%d: the launcher's rank count must equal --gpus" % (args.gpus, world))
+    on_gpu = args.backend == "nccl"
+    if on_gpu:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+        if local_rank >= torch.cuda.device_count():
+            raise SystemExit("rank %d has no GPU of its own (%d visible): one process per GPU" % (local_rank, torch.cuda.device_count()))
+        torch.cuda.set_device(local_rank)          # rank r <-> GPU r
+    elif os.environ.get("DM_ALLOW_EMULATOR") != "1":
+        raise SystemExit("--backend gloo is the CPU test harness (emulator build): set DM_ALLOW_EMULATOR=1 and DM_HIP_LIB")
+    dev = torch.device("cuda", local_rank) if on_gpu else torch.device("cpu")
+
+    def dev_sync():
+        if on_gpu:
+            torch.cuda.synchronize()
+
     if world > 1 or (args.force_gather and "MASTER_ADDR" in os.environ):
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if on_gpu:
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
 
     tables = model.load_asset(args.scene)
     n = args.envs
-    env = BatchEnv(tables, n, device_id=local_rank, seed=1234, precision=args.precision, env_id_offset=rank * n, test_mode=True,
+    env = BatchEnv(tables, n, device_id=local_rank if on_gpu else 0, seed=1234, precision=args.precision, env_id_offset=rank * n, test_mode=True,
                    wave_packing=args.wave_packing)
-    env.set_stream(torch.cuda.current_stream().cuda_stream)
+    if on_gpu:
+        env.set_stream(torch.cuda.current_stream().cuda_stream)
     # deterministic per-env start phase keyed by the global env id; later episodes draw from the device's
     # counter-based generator, keyed by (seed, global env id, episode)
     from deepmimic_amd import streams
     env.reset(kin_times=streams.reset_phase(rank * n + np.arange(n), env.duration))
-    dev = torch.device("cuda", local_rank)
     valid = torch.empty((n,), dtype=torch.int32, device=dev)
     ends = torch.empty((n,), dtype=torch.int32, device=dev)
     gather = (world > 1 or args.force_gather) and not args.no_gather
@@ -234,18 +278,18 @@ def main():
     for _ in range(warm):
         one_step()
     drain()
-    torch.cuda.synchronize()
+    dev_sync()
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
+    dev_sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         one_step()
     drain()
-    torch.cuda.synchronize()
+    dev_sync()
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
+    dev_sync()
     elapsed = time.perf_counter() - t0
     elapsed_local = elapsed
     if world > 1:
@@ -259,10 +303,10 @@ def main():
     exposed_ms = None
     if gather:
         gather_saved, gather = gather, False
-        torch.cuda.synchronize(); t1 = time.perf_counter()
+        dev_sync(); t1 = time.perf_counter()
         for _ in range(args.steps):
             one_step()
-        torch.cuda.synchronize(); el_ng = time.perf_counter() - t1
+        dev_sync(); el_ng = time.perf_counter() - t1
         gather = gather_saved
         exposed_ms = 1e3 * (elapsed_local - el_ng) / args.steps
     per_rank = [local_rate]
@@ -280,22 +324,30 @@ def main():
     finite = bool(torch.isfinite(states).all().item())
 
     if rank == 0:
+        # the line must describe the job that was asked for: N ranks, N per-rank rates
+        if world != args.gpus or len(per_rank) != args.gpus:
+            raise SystemExit("bench.py: ran %d rank(s) with %d per-rank rate(s) under --gpus %d" % (world, len(per_rank), args.gpus))
         bytes_per_launch = algorithmic_bytes_per_env_step(env) * n
         kname = "k_env_step_duo" if (args.wave_packing != 1 and env.J <= 15 and env.D == 34 and n % 2 == 0) else "k_env_step"
-        achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
+        achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else None      # (the emulator has no HIP events)
+        traffic, traffic_source = measured_traffic(args.scene, n, kname)
         value = world * n * args.steps / elapsed
+        if world > 1:
+            workload = "%s, %d envs sharded %d x %d (one shard per GPU), fixed-action (open-loop mocap tracking) rollout, auto-reset, " \
+                       "20 updates of 1/600 s x 2 substeps per step" % (args.scene, world * n, world, n)
+        else:
+            workload = "%s, %d envs per GPU, fixed-action (open-loop mocap tracking) rollout, auto-reset, " \
+                       "20 updates of 1/600 s x 2 substeps per step" % (args.scene, n)
         out = {
             "metric": "env-steps/sec at N parallel envs (%s)" % args.scene,
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32" if args.precision == 32 else "f64", "data": "synthetic",
-            "config": {"workload": "%s, %d envs per GPU, fixed-action (open-loop mocap tracking) rollout, auto-reset, "
-                                   "20 updates of 1/600 s x 2 substeps per step" % (args.scene, n),
-                       "envs_per_gpu": n, "wave_packing": args.wave_packing, "warmup_steps_run": warm, "parallelism": "env-shards x%d%s" % (world, " + async RCCL all-gather of the record, overlapped with the next step" if gather else "")},
+            "config": {"workload": workload, "envs_per_gpu": n, "envs_total": world * n, "backend": "rccl" if on_gpu else "gloo + CPU emulator (test harness, not a measurement)", "wave_packing": args.wave_packing, "warmup_steps_run": warm, "parallelism": "env-shards x%d%s" % (world, " + async RCCL all-gather of the record, overlapped with the next step" if gather else "")},
             "sim_updates_per_s": value * 20,
             "per_rank_env_steps_per_s": per_rank, "record_exchange": {"backend": (args.gather if gather else None), "exposed_ms_per_step_rank0": exposed_ms},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": measured_traffic(args.scene, n, kname), "kernel": kname, "kernel_ms": kernel_ms,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
+                         "traffic": traffic, "traffic_source": traffic_source, "kernel": kname, "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_env_step": algorithmic_bytes_per_env_step(env),
                          "algorithmic_bytes_per_launch": bytes_per_launch,
                          "note": "VALU-issue bound by construction (SURVEY 8d, DESIGN.md 6): the env record stays in LDS/VGPRs for "

@@ -302,13 +302,6 @@ struct ParkSnap { Real pose[C::NP], vel[C::NP], kin[8]; double clk[6]; int flg[4
 enum { CLK_KIN = 0, CLK_CTRL, CLK_INIT_OFF, CLK_TIMER, CLK_TIMER_MAX };
 enum { FLG_NEED_ACTION = 0, FLG_CONTACT, FLG_EPISODE, FLG_VALID, FLG_NROWS, FLG_NCONT, FLG_PARKED, FLG_OVER };
 
-// Counter-based uniform in [0,1): splitmix64 of (seed, env, episode, stream)
-DM_HD double dm_rand01(uint64_t seed, uint64_t env, uint64_t episode, uint64_t stream) {
-    uint64_t z = seed + 0x9E3779B97F4A7C15ull * (env * 0x100000001B3ull + episode * 0xD6E8FEB86659FD93ull + stream + 1);
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; z = z ^ (z >> 31);
-    return (double)(z >> 11) * (1.0 / 9007199254740992.0);
-}
-
 // TAPS = false compiles every debug tap / phase timer out of the instruction stream (production step kernel).
 // LW = lanes per character: 64 (one character per wavefront) or 32 (two characters per wavefront, dm_device_duo.h).
 template <typename Real, typename C, bool TAPS = true, int LW = kWave>

@@ -11,11 +11,6 @@
 //
 // The same file is compiled twice: by hipcc for the product, and by g++ with -DDM_EMU (tests/emu) where
 // "device memory" is host memory and a launch runs the unmodified kernels on the fiber emulator.
-#ifdef DM_EMU
-#include "hip_emu.h"
-#else
-#include <hip/hip_runtime.h>
-#endif
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -25,7 +20,11 @@
 #include <vector>
 
 #include "../../include/dm_hip.h"
-#include "dm_device_duo.h"
+#include "dm_launch.h"
+#include "dm_math.h"
+#ifdef DM_EMU
+#include "dm_device.h"      // the emulator's wave intrinsics, for the policy kernels of dm_policy.h (templates: nothing is instantiated here)
+#endif
 
 using namespace dmk;
 
@@ -34,17 +33,13 @@ static int fail(const std::string& msg) { g_err = msg; return -1; }
 
 // ---------------------------------------------------------------- runtime shim
 #ifdef DM_EMU
-typedef void* rt_stream;
 static int rt_malloc(void** p, size_t n) { *p = calloc(1, n ? n : 1); return *p ? 0 : -1; }
 static void rt_free(void* p) { free(p); }
 static int rt_h2d(void* d, const void* h, size_t n, rt_stream) { memcpy(d, h, n); return 0; }
 static int rt_d2h(void* h, const void* d, size_t n, rt_stream) { memcpy(h, d, n); return 0; }
 static int rt_memset(void* d, int v, size_t n, rt_stream) { memset(d, v, n); return 0; }
 static int rt_sync(rt_stream) { return 0; }
-#define RT_LAUNCH(kern, grid, stream, ...) emu::launch((unsigned)(grid), 64, [&]() { kern(__VA_ARGS__); })
-#define RT_LAUNCH4(kern, grid, stream, ...) emu::launch((unsigned)(grid), 256, [&]() { kern(__VA_ARGS__); })
 #else
-typedef hipStream_t rt_stream;
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
 // zero-fill synchronously: a null-stream hipMemset is not ordered against the ctx's non-blocking stream
 static int rt_malloc(void** p, size_t n) { hipError_t e = hipMalloc(p, n ? n : 1); if (e != hipSuccess) return -1; if (hipMemset(*p, 0, n ? n : 1) != hipSuccess) return -1; return hipDeviceSynchronize() == hipSuccess ? 0 : -1; }
@@ -53,8 +48,6 @@ static int rt_h2d(void* d, const void* h, size_t n, rt_stream s) { if (hipMemcpy
 static int rt_d2h(void* h, const void* d, size_t n, rt_stream s) { if (hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, s) != hipSuccess) return -1; return hipStreamSynchronize(s) == hipSuccess ? 0 : -1; }
 static int rt_memset(void* d, int v, size_t n, rt_stream s) { return hipMemsetAsync(d, v, n, s) == hipSuccess ? 0 : -1; }
 static int rt_sync(rt_stream s) { return hipStreamSynchronize(s) == hipSuccess ? 0 : -1; }
-#define RT_LAUNCH(kern, grid, stream, ...) hipLaunchKernelGGL(kern, dim3((unsigned)(grid)), dim3(64), 0, stream, __VA_ARGS__)
-#define RT_LAUNCH4(kern, grid, stream, ...) hipLaunchKernelGGL(kern, dim3((unsigned)(grid)), dim3(256), 0, stream, __VA_ARGS__)   // four wavefronts per workgroup
 #endif
 
 // Every C-ABI entry point runs with the ctx's device current (and restores the caller's): a process may hold contexts on
@@ -482,15 +475,15 @@ struct CtxT : CtxBase {
         d_prof = (long long*)dalloc(sizeof(long long) * N * 16);
         return dbg.links ? 0 : fail("device allocation failed");
     }
-#define DM_DISPATCH(KERN, grid, ...)                                                         \
+#define DM_DISPATCH(LAUNCH, grid, ...)                                                       \
     do {                                                                                     \
-        if (cls == 0) RT_LAUNCH((KERN<Real, ClsBiped>), grid, stream, __VA_ARGS__);              \
-        else if (cls == 2) RT_LAUNCH((KERN<Real, ClsBipedObj>), grid, stream, __VA_ARGS__);      \
-        else RT_LAUNCH((KERN<Real, ClsLarge>), grid, stream, __VA_ARGS__);                       \
+        if (cls == 0) LAUNCH<Real, ClsBiped>(grid, stream, __VA_ARGS__);                         \
+        else if (cls == 2) LAUNCH<Real, ClsBipedObj>(grid, stream, __VA_ARGS__);                 \
+        else LAUNCH<Real, ClsLarge>(grid, stream, __VA_ARGS__);                                  \
     } while (0)
 
     int reset(const int* ids_dev, int n, const double* kt_dev, const double* mt_dev) override {
-        DM_DISPATCH(k_env_reset, n, md, st, ids_dev, kt_dev, mt_dev);
+        DM_DISPATCH(launch_reset, n, md, st, ids_dev, kt_dev, mt_dev);
         return 0;
     }
     int step(const float* actions_dev, double dt, int n_updates, float* states, float* rewards, int* term, int* valid, int* end, int flags, float* amp) override {
@@ -500,21 +493,21 @@ struct CtxT : CtxBase {
         io.n_updates = n_updates; io.dt = dt; io.auto_reset = (flags & DM_AUTO_RESET) ? 1 : 0; io.emit = (flags & DM_NO_EMIT) ? 0 : 1; io.open_loop = (flags & DM_OPEN_LOOP) ? 1 : 0; io.end_early = (flags & DM_END_EPISODE_EARLY) ? 1 : 0;
         // two characters per wavefront: biped class, even batch, no debug taps armed (DM_DUO=0 keeps one character per wave)
         if (duo && cls == 0 && hm.D == ClsBiped::ND && (N % 2) == 0 && !dbg.H) {      // (31 row lanes per character assume exactly 34 dofs)
-            if (st.hist || st.pert) RT_LAUNCH((k_env_step_duo<Real, false, true>), N / 2, stream, md, st, io, dbg);      // (the AMP instantiation also carries the perturbation code)
-            else RT_LAUNCH((k_env_step_duo<Real, false, false>), N / 2, stream, md, st, io, dbg);
+            if (st.hist || st.pert) launch_step_duo<Real, SV_AMP>(N / 2, stream, md, st, io, dbg);      // (the AMP instantiation also carries the perturbation code)
+            else launch_step_duo<Real, SV_PLAIN>(N / 2, stream, md, st, io, dbg);
             return 0;
         }
         // production launch: the tap-free instantiation unless a parity test armed the debug taps (dm_probe)
-        if (cls == 2) { if (dbg.H) RT_LAUNCH((k_env_step<Real, ClsBipedObj, true>), N, stream, md, st, io, dbg); else RT_LAUNCH((k_env_step<Real, ClsBipedObj, false, true>), N, stream, md, st, io, dbg); }
-        else if (dbg.H) { if (cls == 0) RT_LAUNCH((k_env_step<Real, ClsBiped, true>), N, stream, md, st, io, dbg); else RT_LAUNCH((k_env_step<Real, ClsLarge, true>), N, stream, md, st, io, dbg); }
-        else if (st.hist || st.pert) { if (cls == 0) RT_LAUNCH((k_env_step<Real, ClsBiped, false, true>), N, stream, md, st, io, dbg); else RT_LAUNCH((k_env_step<Real, ClsLarge, false, true>), N, stream, md, st, io, dbg); }
-        else { if (cls == 0) RT_LAUNCH((k_env_step<Real, ClsBiped, false, false>), N, stream, md, st, io, dbg); else RT_LAUNCH((k_env_step<Real, ClsLarge, false, false>), N, stream, md, st, io, dbg); }
+        if (cls == 2) { if (dbg.H) launch_step<Real, ClsBipedObj, SV_TAPS>(N, stream, md, st, io, dbg); else launch_step<Real, ClsBipedObj, SV_AMP>(N, stream, md, st, io, dbg); }
+        else if (dbg.H) { if (cls == 0) launch_step<Real, ClsBiped, SV_TAPS>(N, stream, md, st, io, dbg); else launch_step<Real, ClsLarge, SV_TAPS>(N, stream, md, st, io, dbg); }
+        else if (st.hist || st.pert) { if (cls == 0) launch_step<Real, ClsBiped, SV_AMP>(N, stream, md, st, io, dbg); else launch_step<Real, ClsLarge, SV_AMP>(N, stream, md, st, io, dbg); }
+        else { if (cls == 0) launch_step<Real, ClsBiped, SV_PLAIN>(N, stream, md, st, io, dbg); else launch_step<Real, ClsLarge, SV_PLAIN>(N, stream, md, st, io, dbg); }
         return 0;
     }
     int amp_expert(int n, const double* times_dev, const double* gh_dev, float* out_dev) override { return amp_expert_clips(n, nullptr, times_dev, gh_dev, out_dev); }
     int amp_expert_clips(int n, const int* clips_dev, const double* times_dev, const double* gh_dev, float* out_dev) override {
-        if (cls != 1) RT_LAUNCH((k_amp_expert<Real, ClsBiped>), n, stream, md, times_dev, gh_dev, out_dev, clips_dev);
-        else RT_LAUNCH((k_amp_expert<Real, ClsLarge>), n, stream, md, times_dev, gh_dev, out_dev, clips_dev);
+        if (cls != 1) launch_amp_expert<Real, ClsBiped>(n, stream, md, times_dev, gh_dev, out_dev, clips_dev);
+        else launch_amp_expert<Real, ClsLarge>(n, stream, md, times_dev, gh_dev, out_dev, clips_dev);
         return 0;
     }
     int get_goal(double* out) override {
@@ -572,7 +565,7 @@ struct CtxT : CtxBase {
         StepIO<Real> io; memset(&io, 0, sizeof(io));
         io.amp_obs = amp; io.goals = d_goals;
         io.states = states; io.rewards = rewards; io.terminate = term; io.valid = valid; io.episode_end = end; io.emit = 1;
-        DM_DISPATCH(k_env_query, N, md, st, io, dbg);
+        DM_DISPATCH(launch_query, N, md, st, io, dbg);
         return 0;
     }
     int probe(int what, double dt) override {
@@ -584,13 +577,13 @@ struct CtxT : CtxBase {
             io.states = d_states; io.rewards = d_rewards; io.terminate = d_term; io.valid = d_valid; io.episode_end = d_end;
             io.n_updates = 20; io.dt = dt; io.auto_reset = 1; io.emit = 1; io.open_loop = (what == 3) ? 1 : 0; io.end_early = 1;
             if (what == 4) io.actions = d_actions;
-            if (duo && cls == 0 && hm.D == ClsBiped::ND && (N % 2) == 0) RT_LAUNCH((k_env_step_duo<Real, true>), N / 2, stream, md, st, io, d2);
-            else if (cls == 0) RT_LAUNCH((k_env_step<Real, ClsBiped, true>), N, stream, md, st, io, d2);
-            else if (cls == 2) RT_LAUNCH((k_env_step<Real, ClsBipedObj, true>), N, stream, md, st, io, d2);
-            else RT_LAUNCH((k_env_step<Real, ClsLarge, true>), N, stream, md, st, io, d2);
+            if (duo && cls == 0 && hm.D == ClsBiped::ND && (N % 2) == 0) launch_step_duo<Real, SV_TAPS>(N / 2, stream, md, st, io, d2);
+            else if (cls == 0) launch_step<Real, ClsBiped, SV_TAPS>(N, stream, md, st, io, d2);
+            else if (cls == 2) launch_step<Real, ClsBipedObj, SV_TAPS>(N, stream, md, st, io, d2);
+            else launch_step<Real, ClsLarge, SV_TAPS>(N, stream, md, st, io, d2);
             return 0;
         }
-        DM_DISPATCH(k_env_probe, N, md, st, dbg, what, dt);
+        DM_DISPATCH(launch_probe, N, md, st, dbg, what, dt);
         return 0;
     }
     template <typename T> int dl(const T* dev, size_t n, double* out) {

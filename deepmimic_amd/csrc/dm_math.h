@@ -4,6 +4,7 @@
 // (:207-237); angles normalised to [-pi,pi] as cMathUtil::NormalizeAngle (:33-46).
 #pragma once
 #include <math.h>
+#include <stdint.h>
 
 #ifndef DM_HD
 #if defined(__HIPCC__)
@@ -192,6 +193,13 @@ template <typename T> DM_HD Q4<T> qslerp(const Q4<T>& a, T t, const Q4<T>& b, T 
 template <typename T> DM_HD T calc_heading(const Q4<T>& q) {
     V3<T> d = qrot(q, mk3((T)1, (T)0, (T)0));
     return dm_atan2(-d.z, d.x);
+}
+
+// Counter-based uniform in [0,1): splitmix64 of (seed, env, episode, stream)  (host code draws expert sample times with it too)
+DM_HD double dm_rand01(uint64_t seed, uint64_t env, uint64_t episode, uint64_t stream) {
+    uint64_t z = seed + 0x9E3779B97F4A7C15ull * (env * 0x100000001B3ull + episode * 0xD6E8FEB86659FD93ull + stream + 1);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; z = z ^ (z >> 31);
+    return (double)(z >> 11) * (1.0 / 9007199254740992.0);
 }
 
 }  // namespace dmk

@@ -1,0 +1,49 @@
+"""bench.py's own N > 1 path on CPU: `python bench.py --gpus 2` must launch 2 ranks itself and print a line that says so.
+
+Runs bench.py as the driver would (no WORLD_SIZE in the environment), on the test harness backend: gloo + the emulator build of
+the kernels.  The reference's precedent for a self-launching driver is mpi_run.py:16-24."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run_bench(emu_lib, extra, env_extra=None, timeout=900):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(DM_HIP_LIB=emu_lib, DM_ALLOW_EMULATOR="1")
+    env.update(env_extra or {})
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--backend", "gloo", "--envs", "4", "--steps", "2", "--warmup", "1",
+                        "--min-warmup", "1", "--no-cpu-baseline", "--precision", "64"] + extra,
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout)
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    return p, (json.loads(lines[-1]) if lines else None)
+
+
+def test_bench_gpus_2_launches_two_ranks(emu_lib):
+    p, line = run_bench(emu_lib, ["--gpus", "2"])
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert line is not None, p.stdout[-2000:]
+    assert line["n_gpus"] == 2
+    assert len(line["per_rank_env_steps_per_s"]) == 2 and all(r > 0 for r in line["per_rank_env_steps_per_s"])
+    assert line["scaling"] == "weak" and line["config"]["envs_total"] == 8 and line["config"]["envs_per_gpu"] == 4
+    assert "8 envs sharded 2 x 4" in line["config"]["workload"]
+    assert line["record_exchange"]["backend"] == "torch"           # the all-gather of the learner record ran on both ranks
+    assert line["value"] > 0 and line["checks"]["finite"] and 0.0 < line["checks"]["mean_reward"] <= 1.0
+    assert len([l for l in p.stdout.splitlines() if l.startswith("{")]) == 1     # rank 0 prints ONE line
+
+
+def test_bench_gpus_1_single_process(emu_lib):
+    p, line = run_bench(emu_lib, ["--gpus", "1"])
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert line["n_gpus"] == 1 and len(line["per_rank_env_steps_per_s"]) == 1
+    assert "4 envs per GPU" in line["config"]["workload"]
+    assert "traffic_source" in line["roofline"]
+
+
+def test_bench_refuses_rank_count_mismatch(emu_lib):
+    # an external launcher that started ONE rank for --gpus 2 must not yield an N = 1 number under an N = 2 command
+    p, line = run_bench(emu_lib, ["--gpus", "2"], env_extra={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert p.returncode != 0 and line is None
+    assert "must equal --gpus" in p.stderr

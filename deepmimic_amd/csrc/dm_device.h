@@ -274,6 +274,11 @@ struct Lds {
     // offset of row k = sum_{i<k} LPAD * ceil((i+1)/LPAD) = LPAD * (q (q+1) / 2 * LPAD + r (q+1)), q = k / LPAD, r = k % LPAD
     static constexpr int lrow(int k) { return LPAD * ((k / LPAD) * (k / LPAD + 1) / 2 * LPAD + (k % LPAD) * (k / LPAD + 1)); }
     static constexpr int kLWords = lrow(ND);
+    // TREE classes store the factor of H = L^T L by COLUMNS: column j holds L_ij for i = 2 floor(j / 2) .. ND - 1 (pairs aligned for 8-B
+    // broadcast reads), L_ij at Lt[lcb(j) + i], the diagonal slot holds 1 / L_jj.  Same footprint as the packed rows (ND even).
+    static constexpr int lcol(int j) { return 2 * ((j / 2) * ND - (j / 2) * (j / 2 - 1)) + (j % 2) * (ND - 2 * (j / 2)); }
+    static constexpr int lcb(int j) { return lcol(j) - 2 * (j / 2); }
+    static_assert(!C::TREE || (ND % 2 == 0 && lcol(ND) <= lrow(ND)), "column storage of the tree factor must fit the packed rows");
     MdlLds<Real, C> mdl;
     Real pose[NP], vel[NP], tar[NP];
     Real tau[ND], rhs[ND];                 // (bias force: dofrec[k][7]; SPD force xs: aliases Ic, see EnvSim::xs)
@@ -314,6 +319,8 @@ struct EnvSim {
     typedef typename VecT<Real>::v2 R2; typedef typename VecT<Real>::v4 R4;
     const ModelDev<Real>& m; L& s; int l;
     int li = 0;                                         // link_info word of this lane's link (0 for lanes >= J)
+    int tdep = -1;                                      // TREE classes: depth of this lane's dof in the compiled dof tree
+    uint32_t tdesc_lo = 0, tdesc_hi = 0;                // TREE classes: strict descendants of this lane's dof (bit i: dof i)
     int cand_link[CPL]; Real cand_loc[CPL][3], cand_rad[CPL];   // this lane's ground-contact candidates
     static constexpr int PPL = C::NPAIRCAP / kWave;             // self-collision pairs per lane
     int pair_code[PPL];
@@ -348,6 +355,7 @@ struct EnvSim {
         if (LW == kWave) load_cands();
         sync();
         li = (l < m.J) ? s.mdl.link_info[l] : 0;
+        if constexpr (C::TREE) tree_lane_tables();
         if (l == 0) { int fm = 0; for (int j = 0; j < m.J; ++j) fm |= DM_LI_FALL(s.mdl.link_info[j]) << j; s.fall_mask = fm; s.getup = 0; }
     }
     DM_DEV void load(const EnvState<Real>& st, int e) {
@@ -464,7 +472,8 @@ struct EnvSim {
         sync();
         dyn_subtree();
         sync();
-        if (l < m.D) dyn_row(l, diag_scale);
+        if constexpr (C::TREE) { if (l < m.D) dyn_mom(l, diag_scale); }
+        else if (l < m.D) dyn_row(l, diag_scale);
         sync();
     }
     // per-link force / moment about the COM and world inertia about the COM (lane = link)
@@ -575,6 +584,42 @@ struct EnvSim {
         }
     }
 
+    // TREE classes: bias force C_k and the composite-body momentum record (Lq, Pm, diagonal term) of dof k's unit velocity, published
+    // in the (dead) factor storage; the lanes then build their COLUMN of H from the records straight into registers (tree_load_col)
+    DM_DEV void dyn_mom(int k, Real diag_scale) {
+        const int di = s.mdl.dof_info[k], dj = DM_DI_JOINT(di), kind = DM_DI_KIND(di), ax = DM_DI_AXIS(di);
+        const v3 a = (kind == DK_ROOT_LIN) ? ld3(&s.dofrec[k][3]) : ld3(&s.dofrec[k][0]);
+        s.dofrec[k][7] = (kind == DK_ROOT_LIN) ? s.Fs[0][ax] : dot(a, ld3(s.Ns[dj]));
+        const Real* ic = s.Ic[dj];
+        v3 h = mk3(ic[1], ic[2], ic[3]), Pm, Lp;
+        if (kind == DK_ROOT_LIN) { Pm = ic[0] * a; Lp = cross(h, a); }
+        else {
+            Pm = cross(a, h);
+            Lp = mk3(ic[4] * a.x + ic[5] * a.y + ic[6] * a.z, ic[5] * a.x + ic[7] * a.y + ic[8] * a.z, ic[6] * a.x + ic[8] * a.y + ic[9] * a.z);
+        }
+        v3 Lq = cross_add(Lp, ld3(s.p[dj]) - ld3(s.p[0]), Pm);
+        Real* mr = &s.Lt[k * 8];
+        st3(mr, Lq); st3(mr + 3, Pm); mr[6] = diag_scale * s.mdl.kd[dj];
+    }
+    // column l of H (lower triangle) from the momentum records: H_il = a_l . Lq_i + g_l . Pm_i for the descendants i of dof l
+    // (wave-uniform broadcast reads of record i, static i), 0 elsewhere; the diagonal apart
+    DM_DEV void tree_load_col(typename VecT<Real>::v2 (&c2)[ND / 2], Real& hd) {
+        const int lr = l < ND ? l : 0;
+        const R4 q0 = *reinterpret_cast<const R4*>(&s.dofrec[lr][0]);
+        const R2 q1 = *reinterpret_cast<const R2*>(&s.dofrec[lr][4]);
+#pragma unroll
+        for (int i = 0; i < ND; ++i) {
+            const R4 r0 = *reinterpret_cast<const R4*>(&s.Lt[i * 8]);
+            const R2 r1 = *reinterpret_cast<const R2*>(&s.Lt[i * 8 + 4]);
+            Real v = q0[0] * r0[0] + q0[1] * r0[1] + q0[2] * r0[2] + q0[3] * r0[3] + q1[0] * r1[0] + q1[1] * r1[1];
+            DM_OPAQUE_V(v);            // evaluated where it stands: the optimizer otherwise sinks all 64 dot products below the loads (and spills the records)
+            const bool on = (((i < 32) ? tdesc_lo : tdesc_hi) >> (i & 31)) & 1u;
+            c2[i >> 1][i & 1] = on ? v : (Real)0;
+            if ((i & 7) == 7) DM_SCHED_FENCE();        // keeps the 64 record reads from being issued (and kept live) all at once
+        }
+        const Real* mo = &s.Lt[lr * 8];
+        hd = (l < ND) ? q0[0] * mo[0] + q0[1] * mo[1] + q0[2] * mo[2] + q0[3] * mo[3] + q1[0] * mo[4] + q1[1] * mo[5] + mo[6] : (Real)1;
+    }
     // ------------------------------------------------------------------ dense SPD linear algebra, register resident
     // Lane i owns row i of H (lower triangle in s.L).  The factorisation and the triangular solves run entirely in
     // VGPRs with v_readlane broadcasts (no LDS round trips, no barriers); the factor is written back to LDS (diagonal
@@ -652,6 +697,126 @@ struct EnvSim {
 #pragma unroll
         for (int k = ND - 1; k >= 0; --k) { const Real xk = lane_bcast(x * dinv, k); x -= c[k] * xk; }     // c[k] = 0 for k <= l
         return x * dinv;
+    }
+
+    // ------------------------------------------------------------------ branch-sparse factor H = L^T L on a compiled topology (TREE classes)
+    // Replaces chol_solve / back_substitute above for a class whose dof tree is a compile-time table (dm_types.h TopoTables; dense
+    // counterpart in the reference: the Eigen LDLT of sim/ImpPDController.cpp:162-188).  Lane j owns COLUMN j of the lower triangle:
+    // c(i) = H_ij, i > j, in a statically indexed register array, the diagonal in its own register.  Elimination runs leaves first,
+    // one LEVEL of the tree per step: every lane turns its entries of the level's pivot rows into L_kj = H_kj / L_kk (the pivots'
+    // 1 / L_kk come by v_readlane from the pivot lanes, which all take their rsqrt in the same instruction), publishes them through LDS
+    // (one value per lane and pivot) and subtracts L_kj L_ki for the ancestors i of each pivot k -- a static list, read back as wave-uniform
+    // broadcasts.  Lanes that are no ancestor of k carry L_kj = 0 and do harmless work; a lane's entries above its own diagonal collect
+    // garbage that only ever feeds that lane's own dead entries (pivot k is processed before any of its ancestors).  22 dependent steps
+    // and 388 packed FMAs for dog3d against 64 columns and 1024 of the dense code.  Also solves x := H^-1 x for the LDS vector xvec.
+    DM_DEV void tree_solve(Real* xvec) {
+        typedef typename C::Topo TP;
+        static_assert(TP::N == ND, "topology table and kernel class disagree");
+        R2 c2[NP2]; Real hd;
+        tree_load_col(c2, hd);
+        sync();
+        Real dinv = 1;
+        tree_elim<0>(c2, hd, dinv);
+        // entries on and above the diagonal are zeroed once: the substitutions below then run without lane compares
+#pragma unroll
+        for (int i = 0; i < ND; ++i) if (!(i > l)) c2[i >> 1][i & 1] = 0;
+        // the factor goes to LDS by columns (diagonal slot = 1 / L_jj) for the row lanes' Y = L^-T J^T and the row reads of tree_fwd
+        if (l < ND) {
+            Real* col = &s.Lt[L::lcb(l)];
+#pragma unroll
+            for (int p = 0; p < NP2; ++p) {
+                R2 w = c2[p];
+                if (l == 2 * p) w[0] = dinv;
+                if (l == 2 * p + 1) w[1] = dinv;
+                if (2 * p + 1 >= l) *reinterpret_cast<R2*>(&col[2 * p]) = w;
+            }
+        }
+        // L^T z = x, deepest level first: z_j = (x_j - sum_{i in desc(j)} L_ij z_i) / L_jj
+        Real x = (l < ND) ? xvec[l] : (Real)0;
+        tree_bwd<0>(c2, x, dinv);
+        x *= dinv;
+        sync();
+        x = tree_fwd(x, dinv);
+        if (l < ND) xvec[l] = x;
+        sync();
+    }
+    // level V of the schedule (0 = the deepest): every loop bound below is a template constant, so all register indices are immediates
+    template <int V> DM_DEV void tree_elim(R2 (&c2)[NP2], Real& hd, Real& dinv) {
+        typedef typename C::Topo TP;
+        if constexpr (V < TP::T.nlev) {
+            constexpr int S0 = TP::T.lev_start[V], W = TP::T.lev_start[V + 1] - S0;
+            Real* cbuf = &s.f[0][0];                   // [pivot of the level][lane]: aliases the dead Newton-Euler accumulators
+            const Real inv = dm_rsqrt(hd);
+            if (tdep == TP::T.nlev - 1 - V) dinv = inv;
+            Real lk[W];
+#pragma unroll
+            for (int q = 0; q < W; ++q) {
+                const int k = TP::T.order[S0 + q];
+                const Real ik = lane_bcast(inv, k);
+                const Real x = c2[k >> 1][k & 1] * ik;
+                c2[k >> 1][k & 1] = x; lk[q] = x;
+                if (TP::T.anc[k] != 0) cbuf[q * kWave + l] = x;
+            }
+            sync();
+#pragma unroll
+            for (int q = 0; q < W; ++q) {
+                const int k = TP::T.order[S0 + q];
+                if (TP::T.anc[k] == 0) continue;
+                hd -= lk[q] * lk[q];
+                const R2 l2 = {lk[q], lk[q]};
+                // (the pair that holds k itself takes its lower entry alone: lane k's slot k -- the diagonal position, kept apart in hd --
+                // has collected - sum L^2 from deeper pivots, and what lane k published for it must not reach the fresh L_kj of the others)
+#pragma unroll
+                for (int p = 0; p < NP2; ++p) {
+                    if (p == (k >> 1)) { if ((k & 1) && ((TP::T.anc[k] >> (k - 1)) & 1ull)) c2[p][0] -= lk[q] * cbuf[q * kWave + k - 1]; }
+                    else if ((TP::T.anc[k] >> (2 * p)) & 3ull) c2[p] -= l2 * *reinterpret_cast<const R2*>(&cbuf[q * kWave + 2 * p]);
+                }
+            }
+            tree_elim<V + 1>(c2, hd, dinv);
+        }
+    }
+    template <int V> DM_DEV void tree_bwd(const R2 (&c2)[NP2], Real& x, Real dinv) {
+        typedef typename C::Topo TP;
+        if constexpr (V < TP::T.nlev) {
+            constexpr int S0 = TP::T.lev_start[V], W = TP::T.lev_start[V + 1] - S0;
+            const Real xs = x * dinv;
+#pragma unroll
+            for (int q = 0; q < W; ++q) {
+                const int k = TP::T.order[S0 + q];
+                if (TP::T.anc[k] != 0) x -= c2[k >> 1][k & 1] * lane_bcast(xs, k);
+            }
+            tree_bwd<V + 1>(c2, x, dinv);
+        }
+    }
+    // x_k := (L^-1 x)_k, root level first, with ROW k of L read back from the column store (per-lane reads; structural zeros are stored)
+    DM_DEV Real tree_fwd(Real x, Real dinv) {
+        typedef typename C::Topo TP;
+        Real r[ND];
+#pragma unroll
+        for (int j = 0; j < ND; ++j) r[j] = (TP::T.desc[j] != 0 && l < ND && j < l) ? s.Lt[L::lcb(j) + l] : (Real)0;
+        tree_fwd_lev<TP::T.nlev - 1>(r, x, dinv);
+        return x * dinv;
+    }
+    template <int V> DM_DEV void tree_fwd_lev(const Real (&r)[ND], Real& x, Real dinv) {
+        typedef typename C::Topo TP;
+        if constexpr (V >= 0) {
+            constexpr int S0 = TP::T.lev_start[V], W = TP::T.lev_start[V + 1] - S0;
+            const Real xs = x * dinv;
+#pragma unroll
+            for (int q = 0; q < W; ++q) {
+                const int j = TP::T.order[S0 + q];
+                if (TP::T.desc[j] != 0) x -= r[j] * lane_bcast(xs, j);
+            }
+            tree_fwd_lev<V - 1>(r, x, dinv);
+        }
+    }
+    // this lane's entries of the compiled tables: depth of its dof (-1 beyond the dofs), mask of its strict descendants (once per kernel)
+    DM_DEV void tree_lane_tables() {
+        typedef typename C::Topo TP;
+        int d = -1; uint32_t lo = 0, hi = 0;
+#pragma unroll
+        for (int k = 0; k < ND; ++k) if (l == k) { d = TP::T.depth[k]; lo = (uint32_t)(TP::T.desc[k] & 0xffffffffull); hi = (uint32_t)(TP::T.desc[k] >> 32); }
+        tdep = d; tdesc_lo = lo; tdesc_hi = hi;
     }
     // one stage of the transposing wave reduction: N per-lane partial sums -> (N+1)/2, lanes split on bit MASK
     template <int N, int MASK> DM_DEV void tr_stage(Real (&w)[NP2]) {
@@ -939,6 +1104,34 @@ struct EnvSim {
         if (C::OBJ && ball_sg != 0) { mu_row = m.ball_friction; jbl = (Real)ball_sg * dd; jba = (Real)ball_sg * cross(ball_cx - bpos, dd); }
         // y := L^-1 J_l^T in registers (static indices; dof records and L rows are wave-uniform LDS broadcasts)
         R2 y2[NP2X]; Real cvec = 0;
+        if constexpr (C::TREE) {
+            // H = L^T L: y = L^-T J^T runs from the last dof down, against COLUMN k of L (wave-uniform broadcasts); only the pairs that
+            // hold a descendant of k are touched (744 multiply-adds per row for dog3d instead of 2 016)
+            typedef typename C::Topo TP;
+#pragma unroll
+            for (int kk = 0; kk < ND; ++kk) {
+                const int k = ND - 1 - kk;
+                const R4 r0 = *reinterpret_cast<const R4*>(&s.dofrec[k][0]), r1 = *reinterpret_cast<const R4*>(&s.dofrec[k][4]);
+                Real val = r0[0] * xd.x + r0[1] * xd.y + r0[2] * xd.z + r0[3] * dd.x + r1[0] * dd.y + r1[1] * dd.z;
+                DM_OPAQUE_V(val);      // computed unconditionally: a branch per dof here makes the optimizer sink the substitution chains below the loop (and spill every column)
+                const bool on = (((k < 32) ? ch_lo : ch_hi) >> (k & 31)) & 1u, ng = (((k < 32) ? ng_lo : ng_hi) >> (k & 31)) & 1u;
+                const Real raw = on ? (ng ? -val : val) : (Real)0;
+                cvec += raw * r1[2];
+                R2 acc2 = {(Real)0, (Real)0}, acc3 = acc2;
+                const R2* lc = reinterpret_cast<const R2*>(&s.Lt[L::lcb(k)]);     // lc[p] = (L_{2p,k}, L_{2p+1,k})
+                int cnt = 0;
+#pragma unroll
+                for (int p = (k >> 1) + 1; p < NP2; ++p)
+                    if ((TP::T.desc[k] >> (2 * p)) & 3ull) { if (cnt & 1) acc3 += lc[p] * y2[p]; else acc2 += lc[p] * y2[p]; ++cnt; }
+                acc2 += acc3;
+                Real acc = raw - (acc2[0] + acc2[1]);
+                if (!(k & 1) && ((TP::T.desc[k] >> (k + 1)) & 1ull)) acc -= s.Lt[L::lcb(k) + k + 1] * y2[k >> 1][1];
+                Real yk = acc * s.Lt[L::lcb(k) + k];
+                DM_OPAQUE_V(yk);
+                y2[k >> 1][k & 1] = yk;
+                DM_SCHED_FENCE();      // the branches of the tree are independent chains: without a fence the scheduler hoists their loads and spills
+            }
+        } else {
 #pragma unroll
         for (int k = 0; k < ND; ++k) {
             Real yk = 0;
@@ -958,6 +1151,7 @@ struct EnvSim {
                 yk = acc * s.Lt[L::lrow(k) + k];
             }
             y2[k >> 1][k & 1] = yk;
+        }
         }
         if (C::OBJ) {
             // the free body's block of the mass matrix is diagonal: its rows of Y = M^-1/2 J^T are a scaling; J v* gains its share
@@ -1002,7 +1196,7 @@ struct EnvSim {
                 wave_gram64<NP2X>(y2, g);
 #pragma unroll
                 for (int r = 0; r < 64; ++r) arow.set(r, (l == r) ? (Real)0 : g[r] * inv_adiag);
-            } else if (C::GRAM64 && ND <= 34) {
+            } else if (C::GRAM64) {
                 // narrow row file, Gram on the matrix core: rows 32..63 go to the overflow block ([row][lane]; all of them, the sweep reads
                 // rows < R only)
                 static_assert(RREG == 32 || !C::GRAM64, "two halves of 32 entries");
@@ -1083,8 +1277,11 @@ struct EnvSim {
             tr_stage<(NP2 + 15) / 16, 32>(w);
             z = w[0];
         }
-        Real dinv = (l < ND) ? Lx(l < ND ? l : 0, l < ND ? l : 0) : (Real)1;
-        z = back_substitute(z, dinv);
+        if constexpr (C::TREE) z = tree_fwd(z, (l < ND) ? s.Lt[L::lcb(l < ND ? l : 0) + (l < ND ? l : 0)] : (Real)1);       // delta v = L^-1 (Y lambda)
+        else {
+            Real dinv = (l < ND) ? Lx(l < ND ? l : 0, l < ND ? l : 0) : (Real)1;
+            z = back_substitute(z, dinv);
+        }
         if (l < D) s.vel[vidx] = clamp_vel(vstar + z, l);
         if (C::OBJ) {
             // delta v of the free body = M^-1/2 (Y_b lambda): six wave sums; then semi-implicit Euler with the exponential map
@@ -1260,6 +1457,16 @@ struct EnvSim {
         mark(ph == 0 ? 2 : 6);
         if (TAPS && dbg.H) {
             const int D = m.D;
+            if constexpr (C::TREE) {
+                R2 c2[NP2]; Real hd;
+                tree_load_col(c2, hd);
+                if (l < D) {
+                    Real* Hd = dbg.H + (size_t)e * D * D;
+#pragma unroll
+                    for (int i = 0; i < ND; ++i) if (i > l) { Hd[i * D + l] = c2[i >> 1][i & 1]; Hd[l * D + i] = c2[i >> 1][i & 1]; }
+                    Hd[l * D + l] = hd - ((ph == 0) ? dt * s.mdl.kd[DM_DI_JOINT(s.mdl.dof_info[l])] : (Real)0);
+                }
+            } else
             for (int i = l; i < D * D; i += LW) { int r = i / D, c = i % D; Real v = (c <= r) ? Lx(r, c) : Lx(c, r); if (r == c && ph == 0) v -= dt * s.mdl.kd[DM_DI_JOINT(s.mdl.dof_info[r])]; dbg.H[(size_t)e * D * D + i] = v; }
             if (l < D) dbg.C[(size_t)e * D + l] = s.dofrec[l][7];
         }
@@ -1267,7 +1474,7 @@ struct EnvSim {
         if (ph == 0) spd_rhs(dt);
         else { if (l < m.D) { Real r = s.tau[l] - s.dofrec[l][7]; if (PERT && pert) r += pert_gen_force(l); s.rhs[l] = r; } sync(); }
         DM_OPAQUE_V(l);
-        chol_solve(s.rhs);
+        if constexpr (C::TREE) { DM_OPAQUE_V(tdep); DM_OPAQUE_V(tdesc_lo); DM_OPAQUE_V(tdesc_hi); tree_solve(s.rhs); } else chol_solve(s.rhs);
         DM_OPAQUE_V(l); DM_OPAQUE_V(li);
         if (ph == 0) { mark(3); spd_post(dt); }
         else substep_post(h, dbg, e, aovf);
@@ -2053,6 +2260,7 @@ DM_DEV void reset_goal_env(EnvSim<Real, C, TAPS, LW>& sim, const ModelDev<Real>&
 template <typename Real, typename C> struct StepWaves { static constexpr int value = 1; };
 template <> struct StepWaves<float, ClsBiped> { static constexpr int value = 4; };
 template <> struct StepWaves<float, ClsLarge> { static constexpr int value = 2; };
+template <> struct StepWaves<float, ClsLargeTree> { static constexpr int value = 2; };
 template <> struct StepWaves<float, ClsBipedObj> { static constexpr int value = 2; };
 #ifdef DM_EMU
 #define DM_WAVES_PER_EU(n)

@@ -367,11 +367,25 @@ struct CtxT : CtxBase {
         else if (h.J <= ClsLarge::NJ && h.D <= ClsLarge::ND && h.P <= ClsLarge::NP && h.NC <= ClsLarge::NCAP) cls = 1;
         else return fail("character too large for the compiled kernel classes (J<=23, D<=64, P<=83, <=128 contact candidates)");
         if (c.scene_goal == 5) { if (cls != 0) return fail("dribble_amp is compiled for the biped class only"); cls = 2; }      // biped + one free body
-        md.mdl_blob = (cls != 1) ? build_mdl<ClsBiped>(&md.mdl_words) : build_mdl<ClsLarge>(&md.mdl_words);
+        // a skeleton whose dof tree is one of the compiled topologies runs the branch-sparse, level-scheduled factor (dm_types.h
+        // TopoTables); anything else of that size the dense class.  DM_TREE=0 keeps the dense class (A/B runs).
+        if (cls == 1 && h.D == TopoDog3d::N) {
+            std::vector<int> lam(h.D, -1);
+            for (int j = 0; j < h.J; ++j) {
+                int a = h.parent[j];
+                while (a >= 0 && h.ndof[a] == 0) a = h.parent[a];
+                for (int k = 0; k < h.ndof[j]; ++k) lam[h.dof_off[j] + k] = (k == 0) ? (a < 0 ? -1 : h.dof_off[a] + h.ndof[a] - 1) : h.dof_off[j] + k - 1;
+            }
+            bool same = true;
+            for (int k = 0; k < h.D; ++k) if (lam[k] != TopoDog3d::PAR[k]) same = false;
+            const char* tv = getenv("DM_TREE");
+            if (same && !(tv && tv[0] == '0')) cls = 3;
+        }
+        md.mdl_blob = (cls == 0 || cls == 2) ? build_mdl<ClsBiped>(&md.mdl_words) : build_mdl<ClsLarge>(&md.mdl_words);
         md.act_off = up<int>(h.act_off); md.diffw = up<Real>(h.diffw); md.aabb_he = up<Real>(h.aabb_he);
         md.cand_link = up<int>(h.cand_link); md.cand_loc = up<Real>(h.cand_loc); md.cand_rad = up<Real>(h.cand_rad);
         md.pair_code = up<int>(h.pair_code); md.NPAIR = (int)h.pair_code.size();
-        if (md.NPAIR > ((cls != 1) ? ClsBiped::NPAIRCAP : ClsLarge::NPAIRCAP)) return fail("too many self-collision pairs for the compiled kernel classes");
+        if (md.NPAIR > ((cls == 0 || cls == 2) ? ClsBiped::NPAIRCAP : ClsLarge::NPAIRCAP)) return fail("too many self-collision pairs for the compiled kernel classes");
         md.frame_time = up<double>(h.frame_time); md.frames = up<Real>(h.frames); md.frame_vel = up<Real>(h.frame_vel);
         md.duration = h.duration; md.loop = h.loop; for (int k = 0; k < 3; ++k) { md.cycle_delta[k] = (Real)h.cycle_delta[k]; md.gravity[k] = (Real)c.gravity[k]; }
         md.num_sim_substeps = c.num_sim_substeps; md.solver_iters = c.solver_iters > 0 ? c.solver_iters : 10; md.max_contacts = max_contacts;
@@ -388,7 +402,7 @@ struct CtxT : CtxBase {
         st.tau = (Real*)dalloc(sizeof(Real) * N * h.D); st.kin = (Real*)dalloc(sizeof(Real) * N * 8);
         st.clock = (double*)dalloc(sizeof(double) * N * 6); st.flag = (int*)dalloc(sizeof(int) * N * 4);
         // overflow rows of the constraint-space matrix (rows RREG..63 of a character with more than RREG rows in a substep)
-        { const int ovf = kMaxRows - ((cls != 1) ? ClsBiped::RREG : ClsLarge::RREG); st.aovf = ovf > 0 ? (Real*)dalloc(sizeof(Real) * (size_t)N * ovf * kWave) : nullptr; }
+        { const int ovf = kMaxRows - ((cls == 0 || cls == 2) ? ClsBiped::RREG : ClsLarge::RREG); st.aovf = ovf > 0 ? (Real*)dalloc(sizeof(Real) * (size_t)N * ovf * kWave) : nullptr; }
         st.obj = nullptr;
         if (cls == 2) {
             st.obj = (Real*)dalloc(sizeof(Real) * (size_t)N * OB_WIDTH);
@@ -479,6 +493,7 @@ struct CtxT : CtxBase {
     do {                                                                                     \
         if (cls == 0) LAUNCH<Real, ClsBiped>(grid, stream, __VA_ARGS__);                         \
         else if (cls == 2) LAUNCH<Real, ClsBipedObj>(grid, stream, __VA_ARGS__);                 \
+        else if (cls == 3) LAUNCH<Real, ClsLargeTree>(grid, stream, __VA_ARGS__);                \
         else LAUNCH<Real, ClsLarge>(grid, stream, __VA_ARGS__);                                  \
     } while (0)
 
@@ -499,6 +514,11 @@ struct CtxT : CtxBase {
         }
         // production launch: the tap-free instantiation unless a parity test armed the debug taps (dm_probe)
         if (cls == 2) { if (dbg.H) launch_step<Real, ClsBipedObj, SV_TAPS>(N, stream, md, st, io, dbg); else launch_step<Real, ClsBipedObj, SV_AMP>(N, stream, md, st, io, dbg); }
+        else if (cls == 3) {
+            if (dbg.H) launch_step<Real, ClsLargeTree, SV_TAPS>(N, stream, md, st, io, dbg);
+            else if (st.hist || st.pert) launch_step<Real, ClsLargeTree, SV_AMP>(N, stream, md, st, io, dbg);
+            else launch_step<Real, ClsLargeTree, SV_PLAIN>(N, stream, md, st, io, dbg);
+        }
         else if (dbg.H) { if (cls == 0) launch_step<Real, ClsBiped, SV_TAPS>(N, stream, md, st, io, dbg); else launch_step<Real, ClsLarge, SV_TAPS>(N, stream, md, st, io, dbg); }
         else if (st.hist || st.pert) { if (cls == 0) launch_step<Real, ClsBiped, SV_AMP>(N, stream, md, st, io, dbg); else launch_step<Real, ClsLarge, SV_AMP>(N, stream, md, st, io, dbg); }
         else { if (cls == 0) launch_step<Real, ClsBiped, SV_PLAIN>(N, stream, md, st, io, dbg); else launch_step<Real, ClsLarge, SV_PLAIN>(N, stream, md, st, io, dbg); }
@@ -506,7 +526,7 @@ struct CtxT : CtxBase {
     }
     int amp_expert(int n, const double* times_dev, const double* gh_dev, float* out_dev) override { return amp_expert_clips(n, nullptr, times_dev, gh_dev, out_dev); }
     int amp_expert_clips(int n, const int* clips_dev, const double* times_dev, const double* gh_dev, float* out_dev) override {
-        if (cls != 1) launch_amp_expert<Real, ClsBiped>(n, stream, md, times_dev, gh_dev, out_dev, clips_dev);
+        if (cls == 0 || cls == 2) launch_amp_expert<Real, ClsBiped>(n, stream, md, times_dev, gh_dev, out_dev, clips_dev);
         else launch_amp_expert<Real, ClsLarge>(n, stream, md, times_dev, gh_dev, out_dev, clips_dev);
         return 0;
     }
@@ -580,6 +600,7 @@ struct CtxT : CtxBase {
             if (duo && cls == 0 && hm.D == ClsBiped::ND && (N % 2) == 0) launch_step_duo<Real, SV_TAPS>(N / 2, stream, md, st, io, d2);
             else if (cls == 0) launch_step<Real, ClsBiped, SV_TAPS>(N, stream, md, st, io, d2);
             else if (cls == 2) launch_step<Real, ClsBipedObj, SV_TAPS>(N, stream, md, st, io, d2);
+            else if (cls == 3) launch_step<Real, ClsLargeTree, SV_TAPS>(N, stream, md, st, io, d2);
             else launch_step<Real, ClsLarge, SV_TAPS>(N, stream, md, st, io, d2);
             return 0;
         }

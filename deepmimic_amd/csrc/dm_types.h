@@ -26,6 +26,7 @@ constexpr int kMaxContacts = 20;   // contact slots per character (ground + self
 struct ClsBiped {      // humanoid3d: 15 links, 34 dof, 43 pose dims, <= 64 ground-contact candidates, no attach rotations
     static constexpr int NJ = 15, ND = 34, NP = 43, NCAP = 64, RREG = 32, NPAIRCAP = 128, LPAD = 4; static constexpr bool ROT = false;   // RREG: rows of A kept in VGPRs
     static constexpr bool OBJ = false;      // no free rigid body next to the character
+    static constexpr bool TREE = false;     // dense LL^T factor (TREE classes: branch-sparse, level-scheduled L^T L on a compiled topology)
     static constexpr bool GRAM64 = false;   // 64-row Gram matrix by the readlane loop (128-VGPR budget of the one-per-wave kernel)
     static constexpr int PFD = 2;           // look-ahead of the sweep into the overflow block of A, rows
 };
@@ -40,8 +41,56 @@ struct ClsBipedFb : ClsBiped { static constexpr bool GRAM64 = true; };   // (a l
 struct ClsBipedObj : ClsBiped { static constexpr bool OBJ = true; };
 struct ClsLarge {      // dog3d and anything up to 23 links / 64 dof / 83 pose dims / 128 candidates, attach rotations allowed
     static constexpr int NJ = 23, ND = 64, NP = 83, NCAP = 128, RREG = 32, NPAIRCAP = 256, LPAD = 2; static constexpr bool ROT = true;
-    static constexpr bool GRAM64 = false; static constexpr int PFD = 2; static constexpr bool OBJ = false;
+    static constexpr bool GRAM64 = false; static constexpr int PFD = 2; static constexpr bool OBJ = false; static constexpr bool TREE = false;
 };
+
+// ---- compiled skeleton topologies (the elimination program of the branch-sparse factor is generated at compile time) -------------
+// A kernel class with TREE = true factors the mass matrix as H = L^T L (Featherstone, "Efficient factorization of the joint-space
+// inertia matrix for branched kinematic trees", IJRR 2005: no fill-in, L_ij != 0 only when dof j is an ancestor of dof i) instead of
+// the dense L L^T of sim/ImpPDController.cpp:162-188 (Eigen LDLT) / Bullet's dense solves.  The dof tree -- the dofs of a joint form a
+// chain, a joint's first dof hangs off its parent joint's last -- is a compile-time table, so that every register index, every skipped
+// zero block and the LEVEL SCHEDULE (all pivots of one tree depth are eliminated in one step: 22 dependent steps instead of 64 columns
+// for dog3d) are immediates in the instruction stream.  The host checks the loaded skeleton against the table (dm_host.cpp) and falls
+// back to the dense class when it differs.
+template <int N>
+struct TopoTables {
+    int par[N], depth[N];
+    uint64_t anc[N], desc[N];          // strict ancestors / strict descendants of dof k
+    int order[N];                      // dofs sorted by depth, deepest level first, ascending inside a level
+    int lev_start[N + 1];              // order[lev_start[v] .. lev_start[v + 1]) is level v of that schedule (v = 0: the deepest)
+    int nlev, maxw;                    // levels; widest level
+};
+template <int N>
+constexpr TopoTables<N> make_topo(const int (&par)[N]) {
+    TopoTables<N> t{};
+    for (int k = 0; k < N; ++k) {
+        t.par[k] = par[k];
+        t.depth[k] = par[k] < 0 ? 0 : t.depth[par[k]] + 1;
+        t.anc[k] = par[k] < 0 ? 0ull : (t.anc[par[k]] | (1ull << par[k]));
+    }
+    for (int k = 0; k < N; ++k) for (int i = 0; i < N; ++i) if ((t.anc[i] >> k) & 1ull) t.desc[k] |= 1ull << i;
+    int md = 0;
+    for (int k = 0; k < N; ++k) if (t.depth[k] > md) md = t.depth[k];
+    t.nlev = md + 1; t.maxw = 0;
+    int o = 0;
+    for (int v = 0; v <= md; ++v) {
+        t.lev_start[v] = o;
+        for (int k = 0; k < N; ++k) if (t.depth[k] == md - v) t.order[o++] = k;
+        if (o - t.lev_start[v] > t.maxw) t.maxw = o - t.lev_start[v];
+    }
+    for (int v = md + 1; v <= N; ++v) t.lev_start[v] = o;
+    return t;
+}
+// data/characters/dog3d.txt: root 6 | spine0, spine1 | neck, head | two fore legs (shoulder 3, forearm 1, hand 3, finger 3) off spine1 |
+// two hind legs (upper leg 3, leg 1, foot 3, toe 3) and the tail (3 + 3) off the root
+struct TopoDog3d {
+    static constexpr int N = 64;
+    static constexpr int PAR[64] = {-1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 11, 18, 19, 20, 21, 22, 23, 24, 25, 26, 11, 28, 29, 30,
+                                    31, 32, 33, 34, 35, 36, 5, 38, 39, 40, 41, 42, 43, 44, 45, 46, 5, 48, 49, 50, 51, 52, 53, 54, 55, 56, 5, 58, 59, 60, 61, 62};
+    static constexpr TopoTables<64> T = make_topo<64>(PAR);
+};
+// the large class on dog3d's compiled topology
+struct ClsLargeTree : ClsLarge { static constexpr bool TREE = true; typedef TopoDog3d Topo; static constexpr bool GRAM64 = true; };   // (more than 32 rows: Gram on the matrix core too)
 
 // link_info word: parent+1 [0:4] | jtype [5:7] | depth [8:11] | pose_off [12:18] | dof_off [19:25] | arot_ident 26 | brot_ident 27 | is_ee 28 | fall 29
 #define DM_LI_PARENT(i) (((i) & 31) - 1)

@@ -21,6 +21,7 @@
 //   emit()       scenes/SceneImitate.cpp:7-127,163-205; sim/CtController.cpp:281-478; sim/SimCharacter.cpp:542-586
 //   reset_env()  scenes/SceneSimChar.cpp:487-583,628-644; scenes/SceneImitate.cpp:320-368,386-418
 #pragma once
+#include <type_traits>
 #include "dm_math.h"
 #include "dm_types.h"
 
@@ -59,6 +60,8 @@ static inline double dm_rsqrt(double x) { return 1.0 / sqrt(x); }
 static inline float dm_rcp(float x) { return 1.0f / x; }
 static inline double dm_rcp(double x) { return 1.0 / x; }
 template <typename T> static inline T dm_med3(T lo, T x, T hi) { return x < lo ? lo : (x > hi ? hi : x); }
+// (bit l of MASK) ? a : b for a compile-time lane mask
+template <uint64_t MASK, typename T> static inline T lane_sel(T a, T b, int l, uint64_t) { return ((MASK >> (l & 63)) & 1ull) ? a : b; }
 template <typename Real, int N> struct RowFile {       // per-lane array indexed by a wave-uniform runtime index
     Real v[N];
     inline Real get(int r) const { return v[r]; }
@@ -138,6 +141,16 @@ __device__ __forceinline__ float dm_rsqrt(float x) { float r = __builtin_amdgcn_
 __device__ __forceinline__ double dm_rsqrt(double x) { return 1.0 / sqrt(x); }
 __device__ __forceinline__ float dm_rcp(float x) { float r = __builtin_amdgcn_rcpf(x); return r * (2.0f - x * r); }
 __device__ __forceinline__ double dm_rcp(double x) { return 1.0 / x; }
+// (bit l of MASK) ? a : b for a compile-time lane mask: the mask is an SGPR pair built on the scalar unit, the select one VALU (no v_cmp
+// per lane test).  `z` is a wave-uniform zero the caller re-makes opaque per phase, so that the masks are rebuilt where they are used
+// (one s_xor_b64) instead of being hoisted out of the 20-update loop and spilled.
+template <uint64_t MASK> __device__ __forceinline__ float lane_sel(float a, float b, int, uint64_t z) {
+    const uint64_t mk = MASK ^ z;
+    float out;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(out) : "v"(b), "v"(a), "s"(mk));
+    return out;
+}
+template <uint64_t MASK> __device__ __forceinline__ double lane_sel(double a, double b, int l, uint64_t) { return ((MASK >> (l & 63)) & 1ull) ? a : b; }
 // per-lane array indexed by a wave-uniform runtime index.  For float it is two 32-wide register vectors that the
 // backend addresses with M0-relative VGPR indexing, so a row of A never leaves the VGPRs.
 template <typename Real, int N> struct RowFile {
@@ -263,6 +276,11 @@ template <int NP2> __device__ __forceinline__ void wave_gram32(const VecT<double
 
 namespace dmk {
 
+// compile-time loop: f(std::integral_constant<int, I>) for I = B .. E - 1 (where the index has to be a template argument)
+template <int B, int E, typename F> DM_DEV void static_for(F&& f) {
+    if constexpr (B < E) { f(std::integral_constant<int, B>{}); static_for<B + 1, E>(f); }
+}
+
 // Per-wave LDS record.
 template <typename Real, typename C>
 struct Lds {
@@ -273,12 +291,12 @@ struct Lds {
     static constexpr int LPAD = C::LPAD;
     // offset of row k = sum_{i<k} LPAD * ceil((i+1)/LPAD) = LPAD * (q (q+1) / 2 * LPAD + r (q+1)), q = k / LPAD, r = k % LPAD
     static constexpr int lrow(int k) { return LPAD * ((k / LPAD) * (k / LPAD + 1) / 2 * LPAD + (k % LPAD) * (k / LPAD + 1)); }
-    static constexpr int kLWords = lrow(ND);
-    // TREE classes store the factor of H = L^T L by COLUMNS: column j holds L_ij for i = 2 floor(j / 2) .. ND - 1 (pairs aligned for 8-B
-    // broadcast reads), L_ij at Lt[lcb(j) + i], the diagonal slot holds 1 / L_jj.  Same footprint as the packed rows (ND even).
-    static constexpr int lcol(int j) { return 2 * ((j / 2) * ND - (j / 2) * (j / 2 - 1)) + (j % 2) * (ND - 2 * (j / 2)); }
-    static constexpr int lcb(int j) { return lcol(j) - 2 * (j / 2); }
-    static_assert(!C::TREE || (ND % 2 == 0 && lcol(ND) <= lrow(ND)), "column storage of the tree factor must fit the packed rows");
+    // TREE classes store the factor of H = L^T L by COLUMNS, as a skyline: column j holds L_ij for i = 4 floor(j / 4) .. its last
+    // descendant (quads aligned for 16-B broadcast reads), L_ij at Lt[lcb(j) + i], the diagonal slot holds 1 / L_jj (dog3d: 968 words
+    // against 2 112 for the packed triangle)
+    static constexpr int lcb(int j) { if constexpr (C::TREE) return C::Topo::T.colbase[j] - 4 * (j / 4); else return 0; }
+    static constexpr int tree_words() { if constexpr (C::TREE) return C::Topo::T.lwords; else return 0; }
+    static constexpr int kLWords = C::TREE ? tree_words() : lrow(ND);
     MdlLds<Real, C> mdl;
     Real pose[NP], vel[NP], tar[NP];
     Real tau[ND], rhs[ND];                 // (bias force: dofrec[k][7]; SPD force xs: aliases Ic, see EnvSim::xs)
@@ -319,8 +337,6 @@ struct EnvSim {
     typedef typename VecT<Real>::v2 R2; typedef typename VecT<Real>::v4 R4;
     const ModelDev<Real>& m; L& s; int l;
     int li = 0;                                         // link_info word of this lane's link (0 for lanes >= J)
-    int tdep = -1;                                      // TREE classes: depth of this lane's dof in the compiled dof tree
-    uint32_t tdesc_lo = 0, tdesc_hi = 0;                // TREE classes: strict descendants of this lane's dof (bit i: dof i)
     int cand_link[CPL]; Real cand_loc[CPL][3], cand_rad[CPL];   // this lane's ground-contact candidates
     static constexpr int PPL = C::NPAIRCAP / kWave;             // self-collision pairs per lane
     int pair_code[PPL];
@@ -355,7 +371,6 @@ struct EnvSim {
         if (LW == kWave) load_cands();
         sync();
         li = (l < m.J) ? s.mdl.link_info[l] : 0;
-        if constexpr (C::TREE) tree_lane_tables();
         if (l == 0) { int fm = 0; for (int j = 0; j < m.J; ++j) fm |= DM_LI_FALL(s.mdl.link_info[j]) << j; s.fall_mask = fm; s.getup = 0; }
     }
     DM_DEV void load(const EnvState<Real>& st, int e) {
@@ -604,19 +619,20 @@ struct EnvSim {
     // column l of H (lower triangle) from the momentum records: H_il = a_l . Lq_i + g_l . Pm_i for the descendants i of dof l
     // (wave-uniform broadcast reads of record i, static i), 0 elsewhere; the diagonal apart
     DM_DEV void tree_load_col(typename VecT<Real>::v2 (&c2)[ND / 2], Real& hd) {
+        typedef typename C::Topo TP;
         const int lr = l < ND ? l : 0;
+        uint64_t z = 0; DM_OPAQUE_S(z);
         const R4 q0 = *reinterpret_cast<const R4*>(&s.dofrec[lr][0]);
         const R2 q1 = *reinterpret_cast<const R2*>(&s.dofrec[lr][4]);
-#pragma unroll
-        for (int i = 0; i < ND; ++i) {
+        static_for<0, ND>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
             const R4 r0 = *reinterpret_cast<const R4*>(&s.Lt[i * 8]);
             const R2 r1 = *reinterpret_cast<const R2*>(&s.Lt[i * 8 + 4]);
             Real v = q0[0] * r0[0] + q0[1] * r0[1] + q0[2] * r0[2] + q0[3] * r0[3] + q1[0] * r1[0] + q1[1] * r1[1];
             DM_OPAQUE_V(v);            // evaluated where it stands: the optimizer otherwise sinks all 64 dot products below the loads (and spills the records)
-            const bool on = (((i < 32) ? tdesc_lo : tdesc_hi) >> (i & 31)) & 1u;
-            c2[i >> 1][i & 1] = on ? v : (Real)0;
+            c2[i >> 1][i & 1] = lane_sel<TP::T.anc[i]>(v, (Real)0, l, z);       // dof i is a descendant of exactly the lanes anc(i)
             if ((i & 7) == 7) DM_SCHED_FENCE();        // keeps the 64 record reads from being issued (and kept live) all at once
-        }
+        });
         const Real* mo = &s.Lt[lr * 8];
         hd = (l < ND) ? q0[0] * mo[0] + q0[1] * mo[1] + q0[2] * mo[2] + q0[3] * mo[3] + q1[0] * mo[4] + q1[1] * mo[5] + mo[6] : (Real)1;
     }
@@ -715,22 +731,25 @@ struct EnvSim {
         R2 c2[NP2]; Real hd;
         tree_load_col(c2, hd);
         sync();
+        uint64_t z = 0; DM_OPAQUE_S(z);
         Real dinv = 1;
-        tree_elim<0>(c2, hd, dinv);
-        // entries on and above the diagonal are zeroed once: the substitutions below then run without lane compares
-#pragma unroll
-        for (int i = 0; i < ND; ++i) if (!(i > l)) c2[i >> 1][i & 1] = 0;
-        // the factor goes to LDS by columns (diagonal slot = 1 / L_jj) for the row lanes' Y = L^-T J^T and the row reads of tree_fwd
+        tree_elim<0>(c2, hd, dinv, z);
+        // the factor goes to LDS by columns for the row lanes' Y = L^-T J^T and the row reads of tree_fwd: quads from the own diagonal
+        // down (what sits above the diagonal in the first quad is never read), then 1 / L_ll into the diagonal slot
         if (l < ND) {
             Real* col = &s.Lt[L::lcb(l)];
 #pragma unroll
-            for (int p = 0; p < NP2; ++p) {
-                R2 w = c2[p];
-                if (l == 2 * p) w[0] = dinv;
-                if (l == 2 * p + 1) w[1] = dinv;
-                if (2 * p + 1 >= l) *reinterpret_cast<R2*>(&col[2 * p]) = w;
+            for (int t = 0; t < NP2 / 2; ++t) {
+                const R4 w = {c2[2 * t][0], c2[2 * t][1], c2[2 * t + 1][0], c2[2 * t + 1][1]};
+                if ((TP::T.quadmask[t] >> l) & 1ull) *reinterpret_cast<R4*>(&col[4 * t]) = w;
             }
+            col[l] = dinv;
         }
+        // entries on and above the diagonal are zeroed once: the substitution below then runs without lane compares
+        static_for<0, ND>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            c2[i >> 1][i & 1] = lane_sel<((1ull << i) - 1ull)>(c2[i >> 1][i & 1], (Real)0, l, z);      // lanes below i keep their L_il
+        });
         // L^T z = x, deepest level first: z_j = (x_j - sum_{i in desc(j)} L_ij z_i) / L_jj
         Real x = (l < ND) ? xvec[l] : (Real)0;
         tree_bwd<0>(c2, x, dinv);
@@ -741,13 +760,13 @@ struct EnvSim {
         sync();
     }
     // level V of the schedule (0 = the deepest): every loop bound below is a template constant, so all register indices are immediates
-    template <int V> DM_DEV void tree_elim(R2 (&c2)[NP2], Real& hd, Real& dinv) {
+    template <int V> DM_DEV void tree_elim(R2 (&c2)[NP2], Real& hd, Real& dinv, uint64_t z) {
         typedef typename C::Topo TP;
         if constexpr (V < TP::T.nlev) {
             constexpr int S0 = TP::T.lev_start[V], W = TP::T.lev_start[V + 1] - S0;
             Real* cbuf = &s.f[0][0];                   // [pivot of the level][lane]: aliases the dead Newton-Euler accumulators
             const Real inv = dm_rsqrt(hd);
-            if (tdep == TP::T.nlev - 1 - V) dinv = inv;
+            dinv = lane_sel<TP::T.levmask[V]>(inv, dinv, l, z);
             Real lk[W];
 #pragma unroll
             for (int q = 0; q < W; ++q) {
@@ -767,12 +786,19 @@ struct EnvSim {
                 // (the pair that holds k itself takes its lower entry alone: lane k's slot k -- the diagonal position, kept apart in hd --
                 // has collected - sum L^2 from deeper pivots, and what lane k published for it must not reach the fresh L_kj of the others)
 #pragma unroll
-                for (int p = 0; p < NP2; ++p) {
-                    if (p == (k >> 1)) { if ((k & 1) && ((TP::T.anc[k] >> (k - 1)) & 1ull)) c2[p][0] -= lk[q] * cbuf[q * kWave + k - 1]; }
-                    else if ((TP::T.anc[k] >> (2 * p)) & 3ull) c2[p] -= l2 * *reinterpret_cast<const R2*>(&cbuf[q * kWave + 2 * p]);
+                for (int t = 0; t < NP2 / 2; ++t) {         // quads of dofs 4t .. 4t + 3 = pairs 2t, 2t + 1: one 16-B broadcast read when both take part
+                    const bool own0 = (2 * t == (k >> 1)), own1 = (2 * t + 1 == (k >> 1));
+                    const bool on0 = !own0 && ((TP::T.anc[k] >> (4 * t)) & 3ull), on1 = !own1 && ((TP::T.anc[k] >> (4 * t + 2)) & 3ull);
+                    if (on0 && on1) {
+                        const R4 r = *reinterpret_cast<const R4*>(&cbuf[q * kWave + 4 * t]);
+                        const R2 ra = {r[0], r[1]}, rb = {r[2], r[3]};
+                        c2[2 * t] -= l2 * ra; c2[2 * t + 1] -= l2 * rb;
+                    } else if (on0) c2[2 * t] -= l2 * *reinterpret_cast<const R2*>(&cbuf[q * kWave + 4 * t]);
+                    else if (on1) c2[2 * t + 1] -= l2 * *reinterpret_cast<const R2*>(&cbuf[q * kWave + 4 * t + 2]);
+                    if ((own0 || own1) && (k & 1) && ((TP::T.anc[k] >> (k - 1)) & 1ull)) c2[k >> 1][0] -= lk[q] * cbuf[q * kWave + k - 1];
                 }
             }
-            tree_elim<V + 1>(c2, hd, dinv);
+            tree_elim<V + 1>(c2, hd, dinv, z);
         }
     }
     template <int V> DM_DEV void tree_bwd(const R2 (&c2)[NP2], Real& x, Real dinv) {
@@ -788,12 +814,17 @@ struct EnvSim {
             tree_bwd<V + 1>(c2, x, dinv);
         }
     }
-    // x_k := (L^-1 x)_k, root level first, with ROW k of L read back from the column store (per-lane reads; structural zeros are stored)
+    // x_k := (L^-1 x)_k, root level first, with ROW k of L read back from the column store (per-lane reads; only the lanes below a
+    // column's dof in the tree hold a nonzero there: a compile-time lane mask)
     DM_DEV Real tree_fwd(Real x, Real dinv) {
         typedef typename C::Topo TP;
+        uint64_t z = 0; DM_OPAQUE_S(z);
+        const int lr = l < ND ? l : 0;
         Real r[ND];
-#pragma unroll
-        for (int j = 0; j < ND; ++j) r[j] = (TP::T.desc[j] != 0 && l < ND && j < l) ? s.Lt[L::lcb(j) + l] : (Real)0;
+        static_for<0, ND>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            if constexpr (TP::T.desc[j] != 0) r[j] = lane_sel<TP::T.desc[j]>(s.Lt[L::lcb(j) + lr], (Real)0, l, z); else r[j] = 0;
+        });
         tree_fwd_lev<TP::T.nlev - 1>(r, x, dinv);
         return x * dinv;
     }
@@ -809,14 +840,6 @@ struct EnvSim {
             }
             tree_fwd_lev<V - 1>(r, x, dinv);
         }
-    }
-    // this lane's entries of the compiled tables: depth of its dof (-1 beyond the dofs), mask of its strict descendants (once per kernel)
-    DM_DEV void tree_lane_tables() {
-        typedef typename C::Topo TP;
-        int d = -1; uint32_t lo = 0, hi = 0;
-#pragma unroll
-        for (int k = 0; k < ND; ++k) if (l == k) { d = TP::T.depth[k]; lo = (uint32_t)(TP::T.desc[k] & 0xffffffffull); hi = (uint32_t)(TP::T.desc[k] >> 32); }
-        tdep = d; tdesc_lo = lo; tdesc_hi = hi;
     }
     // one stage of the transposing wave reduction: N per-lane partial sums -> (N+1)/2, lanes split on bit MASK
     template <int N, int MASK> DM_DEV void tr_stage(Real (&w)[NP2]) {
@@ -1118,14 +1141,20 @@ struct EnvSim {
                 const Real raw = on ? (ng ? -val : val) : (Real)0;
                 cvec += raw * r1[2];
                 R2 acc2 = {(Real)0, (Real)0}, acc3 = acc2;
-                const R2* lc = reinterpret_cast<const R2*>(&s.Lt[L::lcb(k)]);     // lc[p] = (L_{2p,k}, L_{2p+1,k})
-                int cnt = 0;
+                const Real* lc = &s.Lt[L::lcb(k)];                                // lc[i] = L_ik
 #pragma unroll
-                for (int p = (k >> 1) + 1; p < NP2; ++p)
-                    if ((TP::T.desc[k] >> (2 * p)) & 3ull) { if (cnt & 1) acc3 += lc[p] * y2[p]; else acc2 += lc[p] * y2[p]; ++cnt; }
+                for (int t = (k >> 2); t < NP2 / 2; ++t) {      // quads of dofs: one 16-B broadcast read when both pairs hold a descendant of k
+                    const bool on0 = (2 * t > (k >> 1)) && ((TP::T.desc[k] >> (4 * t)) & 3ull), on1 = (2 * t + 1 > (k >> 1)) && ((TP::T.desc[k] >> (4 * t + 2)) & 3ull);
+                    if (on0 && on1) {
+                        const R4 r = *reinterpret_cast<const R4*>(&lc[4 * t]);
+                        const R2 ra = {r[0], r[1]}, rb = {r[2], r[3]};
+                        acc2 += ra * y2[2 * t]; acc3 += rb * y2[2 * t + 1];
+                    } else if (on0) acc2 += *reinterpret_cast<const R2*>(&lc[4 * t]) * y2[2 * t];
+                    else if (on1) acc3 += *reinterpret_cast<const R2*>(&lc[4 * t + 2]) * y2[2 * t + 1];
+                }
                 acc2 += acc3;
                 Real acc = raw - (acc2[0] + acc2[1]);
-                if (!(k & 1) && ((TP::T.desc[k] >> (k + 1)) & 1ull)) acc -= s.Lt[L::lcb(k) + k + 1] * y2[k >> 1][1];
+                if (!(k & 1) && ((TP::T.desc[k] >> (k + 1)) & 1ull)) acc -= lc[k + 1] * y2[k >> 1][1];
                 Real yk = acc * s.Lt[L::lcb(k) + k];
                 DM_OPAQUE_V(yk);
                 y2[k >> 1][k & 1] = yk;
@@ -1474,7 +1503,7 @@ struct EnvSim {
         if (ph == 0) spd_rhs(dt);
         else { if (l < m.D) { Real r = s.tau[l] - s.dofrec[l][7]; if (PERT && pert) r += pert_gen_force(l); s.rhs[l] = r; } sync(); }
         DM_OPAQUE_V(l);
-        if constexpr (C::TREE) { DM_OPAQUE_V(tdep); DM_OPAQUE_V(tdesc_lo); DM_OPAQUE_V(tdesc_hi); tree_solve(s.rhs); } else chol_solve(s.rhs);
+        if constexpr (C::TREE) tree_solve(s.rhs); else chol_solve(s.rhs);
         DM_OPAQUE_V(l); DM_OPAQUE_V(li);
         if (ph == 0) { mark(3); spd_post(dt); }
         else substep_post(h, dbg, e, aovf);

@@ -58,6 +58,12 @@ struct TopoTables {
     uint64_t anc[N], desc[N];          // strict ancestors / strict descendants of dof k
     int order[N];                      // dofs sorted by depth, deepest level first, ascending inside a level
     int lev_start[N + 1];              // order[lev_start[v] .. lev_start[v + 1]) is level v of that schedule (v = 0: the deepest)
+    uint64_t levmask[N];               // the dofs of level v as a lane mask (lane = dof)
+    // skyline store of the factor's columns: column j keeps rows 4 floor(j / 4) .. colend[j] - 1 (colend: past its last descendant, quad
+    // aligned) at word colbase[j]; quadmask[t]: the lanes whose column holds rows 4t .. 4t + 3; lwords: words to allocate (with the slack
+    // that keeps colbase[j] - 4 floor(j / 4) + 63 in range for the masked row reads)
+    int colbase[N], colend[N], lwords;
+    uint64_t quadmask[N / 4];
     int nlev, maxw;                    // levels; widest level
 };
 template <int N>
@@ -75,10 +81,21 @@ constexpr TopoTables<N> make_topo(const int (&par)[N]) {
     int o = 0;
     for (int v = 0; v <= md; ++v) {
         t.lev_start[v] = o;
-        for (int k = 0; k < N; ++k) if (t.depth[k] == md - v) t.order[o++] = k;
+        for (int k = 0; k < N; ++k) if (t.depth[k] == md - v) { t.order[o++] = k; t.levmask[v] |= 1ull << k; }
         if (o - t.lev_start[v] > t.maxw) t.maxw = o - t.lev_start[v];
     }
     for (int v = md + 1; v <= N; ++v) t.lev_start[v] = o;
+    int tot = 0; t.lwords = 0;
+    for (int j = 0; j < N; ++j) {
+        int last = j;
+        for (int i = j + 1; i < N; ++i) if ((t.desc[j] >> i) & 1ull) last = i;
+        const int q0 = 4 * (j / 4);
+        t.colend[j] = (last + 4) / 4 * 4; t.colbase[j] = tot; tot += t.colend[j] - q0;
+        if (t.colbase[j] - q0 + 64 > t.lwords) t.lwords = t.colbase[j] - q0 + 64;
+        for (int q = j / 4; q < t.colend[j] / 4; ++q) t.quadmask[q] |= 1ull << j;
+    }
+    if (tot > t.lwords) t.lwords = tot;
+    if (t.lwords < 8 * N) t.lwords = 8 * N;       // the momentum records of dyn_mom live in the same storage (8 words per dof)
     return t;
 }
 // data/characters/dog3d.txt: root 6 | spine0, spine1 | neck, head | two fore legs (shoulder 3, forearm 1, hand 3, finger 3) off spine1 |

@@ -281,9 +281,13 @@ template <int B, int E, typename F> DM_DEV void static_for(F&& f) {
     if constexpr (B < E) { f(std::integral_constant<int, B>{}); static_for<B + 1, E>(f); }
 }
 
+// BROAD classes: bounding radius of each link's self-collision capsule about its COM, plus its contact threshold (filled once per kernel)
+template <typename Real, typename C, bool ON = C::BROAD> struct LdsBroad { Real brad[C::NJ]; };
+template <typename Real, typename C> struct LdsBroad<Real, C, false> {};
+
 // Per-wave LDS record.
 template <typename Real, typename C>
-struct Lds {
+struct Lds : LdsBroad<Real, C> {
     static constexpr int NJ = C::NJ, ND = C::ND, NP = C::NP, NCAP = C::NCAP;
     // Lower-triangular storage of H / its Cholesky factor: row k holds k+1 entries padded to a multiple of LPAD (4: 16-B
     // aligned rows for ds_read_b128 broadcasts; 2 for the large class, which trades them for 8-B reads to fit 8 waves per CU);
@@ -372,6 +376,7 @@ struct EnvSim {
         sync();
         li = (l < m.J) ? s.mdl.link_info[l] : 0;
         if (l == 0) { int fm = 0; for (int j = 0; j < m.J; ++j) fm |= DM_LI_FALL(s.mdl.link_info[j]) << j; s.fall_mask = fm; s.getup = 0; }
+        if constexpr (C::BROAD) { if (l < m.J) { const Real* c = s.mdl.cap[l]; s.brad[l] = dm_sqrt(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]) + c[3] + s.mdl.thresh[l]; } }
     }
     DM_DEV void load(const EnvState<Real>& st, int e) {
         load_model();
@@ -1044,6 +1049,9 @@ struct EnvSim {
 #pragma unroll
             for (int q = 0; q < CPL; ++q) { amask[q] = wave_ballot(active[q]); nact += dm_popc64(amask[q]); }
         }
+#ifdef DM_PROF_COLLISION
+        mark(13);
+#endif
         const uint64_t lt = (l == 0) ? 0ull : (~0ull >> (64 - l));
         {   // ground contacts -> slots, in candidate-index order
             int base = 0;
@@ -1055,6 +1063,43 @@ struct EnvSim {
         }
         int nc = nact;
         // ---- self collision: lane = link pair; active pairs take the slots the ground left, in pair order
+        if constexpr (C::BROAD) {
+            // bounding-sphere cull first (a capsule is symmetric about its link's COM): the pairs that survive it -- a handful of the dog's
+            // 231 in a mocap pose -- are compacted in pair order into a list and go through ONE pass of the segment-segment test instead
+            // of four.  Same contacts in the same order as the full sweep below.
+            int* plist = &s.csel[0];                   // NPAIRCAP ints over csel | cdistc (manifold-reduction scratch, free by now)
+            static_assert(C::NPAIRCAP <= 2 * NCAP, "pair list must fit the manifold-reduction scratch");
+            sync();
+            int nsurv = 0;
+#pragma unroll
+            for (int q = 0; q < PPL; ++q) {
+                if (q * kWave < m.NPAIR) {
+                    const int code = pair_code[q];
+                    bool near = false;
+                    if (code >= 0) {
+                        const int i = code & 0xff, j = code >> 8;
+                        const v3 d = ld3(s.com[i]) - ld3(s.com[j]);
+                        const Real rr = s.brad[C::BROAD ? i : 0] + s.brad[C::BROAD ? j : 0];
+                        near = dot(d, d) < rr * rr;
+                    }
+                    const uint64_t mk = wave_ballot(near);
+                    if (near) plist[nsurv + dm_popc64(mk & lt)] = code;
+                    nsurv += dm_popc64(mk);
+                }
+            }
+            sync();
+            for (int base = 0; base < nsurv; base += kWave) {
+                const int code = (base + l < nsurv) ? plist[base + l] : -1;
+                v3 x = zero3(), n = zero3(); Real dsc = 0; bool act = false;
+                if (code >= 0) act = self_pair(code & 0xff, code >> 8, x, n, dsc);
+                const uint64_t mk = wave_ballot(act);
+                if (mk != 0) {
+                    const int slot = nc + dm_popc64(mk & lt);
+                    if (act && slot < m.max_contacts) store_contact(slot, x, n, dsc, code & 0xff, code >> 8);
+                    nc = dm_min(m.max_contacts, nc + dm_popc64(mk));
+                }
+            }
+        } else {
 #pragma unroll
         for (int q = 0; q < PPL; ++q) {
             if (q * kWave < m.NPAIR) {
@@ -1069,6 +1114,10 @@ struct EnvSim {
                 }
             }
         }
+        }
+#ifdef DM_PROF_COLLISION
+        mark(14);
+#endif
         if (C::OBJ) {
             // the free body takes the slots that are left: lane 0 tests it against the ground, lane 1 + j against link j (capsule models, as
             // link against link); slot order = lane order.  Link ids in the slot: 254 = the body, 255 = the ground.

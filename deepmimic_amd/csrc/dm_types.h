@@ -27,6 +27,7 @@ struct ClsBiped {      // humanoid3d: 15 links, 34 dof, 43 pose dims, <= 64 grou
     static constexpr int NJ = 15, ND = 34, NP = 43, NCAP = 64, RREG = 32, NPAIRCAP = 128, LPAD = 4; static constexpr bool ROT = false;   // RREG: rows of A kept in VGPRs
     static constexpr bool OBJ = false;      // no free rigid body next to the character
     static constexpr bool TREE = false;     // dense LL^T factor (TREE classes: branch-sparse, level-scheduled L^T L on a compiled topology)
+    static constexpr bool BROAD = false;    // self collision: every link pair goes through the segment-segment test (BROAD classes: bounding-sphere cull first)
     static constexpr bool GRAM64 = false;   // 64-row Gram matrix by the readlane loop (128-VGPR budget of the one-per-wave kernel)
     static constexpr int PFD = 2;           // look-ahead of the sweep into the overflow block of A, rows
 };
@@ -42,6 +43,7 @@ struct ClsBipedObj : ClsBiped { static constexpr bool OBJ = true; };
 struct ClsLarge {      // dog3d and anything up to 23 links / 64 dof / 83 pose dims / 128 candidates, attach rotations allowed
     static constexpr int NJ = 23, ND = 64, NP = 83, NCAP = 128, RREG = 32, NPAIRCAP = 256, LPAD = 2; static constexpr bool ROT = true;
     static constexpr bool GRAM64 = false; static constexpr int PFD = 2; static constexpr bool OBJ = false; static constexpr bool TREE = false;
+    static constexpr bool BROAD = false;
 };
 
 // ---- compiled skeleton topologies (the elimination program of the branch-sparse factor is generated at compile time) -------------
@@ -107,7 +109,7 @@ struct TopoDog3d {
     static constexpr TopoTables<64> T = make_topo<64>(PAR);
 };
 // the large class on dog3d's compiled topology
-struct ClsLargeTree : ClsLarge { static constexpr bool TREE = true; typedef TopoDog3d Topo; static constexpr bool GRAM64 = true; };   // (more than 32 rows: Gram on the matrix core too)
+struct ClsLargeTree : ClsLarge { static constexpr bool TREE = true; typedef TopoDog3d Topo; static constexpr bool GRAM64 = true; static constexpr bool BROAD = true; };   // (more than 32 rows: Gram on the matrix core too)
 
 // link_info word: parent+1 [0:4] | jtype [5:7] | depth [8:11] | pose_off [12:18] | dof_off [19:25] | arot_ident 26 | brot_ident 27 | is_ee 28 | fall 29
 #define DM_LI_PARENT(i) (((i) & 31) - 1)

@@ -1,0 +1,336 @@
+// TEST INFRASTRUCTURE ONLY -- lets the reference's OWN routines run where their translation units could not be compiled before.
+//
+// sim/{Controller, CharController, DeepMimicCharController, CtController, CtPDController, PDController, ExpPDController,
+// ImpPDController}.cpp and scenes/{Scene, RLScene, SceneSimChar, RLSceneSimChar, SceneImitate, SceneImitateAMP, SceneHeadingAMP,
+// SceneTargetAMP, SceneStrikeAMP, SceneDribbleAMP}.cpp are compiled UNMODIFIED, where they lie, against oracle/bullet_stub (Bullet
+// TYPE NAMES only) into oracle/_ref/libdm_ref.so (oracle/build_ref.sh).  What those routines need of a simulated character is an object
+// that answers the (virtual) getters of cSimCharacter / cSimBodyLink / cSimBodyJoint / cGround, whose own translation units are Bullet
+// code: this file provides such objects as LINK-TIME STAND-INS -- subclasses that answer the getters from a generalized state
+// (pose, vel) through the reference's compiled kinematic-tree functions (cKinTree::BodyWorldTrans, CalcBodyPartVel,
+// CalcJointWorldAngularVel, ...), which is what Bullet's link transforms are for a consistent multibody state.  Every other method of
+// those classes resolves to ref_unreachable() (build_ref.sh aliases what stays undefined): a routine that wanders into Bullet aborts
+// loudly instead of computing something made up.
+//
+// The C entry points at the bottom construct the reference's controller / scene objects the way the reference does (real Init from
+// the shipped controller file) and call the routine named in each comment.  They replace the compositions of ref_glue.cpp
+// (ref_spd_tau, ref_record_state, ref_reward_terms, ref_action_to_target, ref_amp_obs), which stay as a second witness.
+// Only tests/ (and tests/golden/make_ref_golden.py) load the library.
+#include <cstdio>
+#include <cstdlib>
+#include <execinfo.h>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "anim/KinCharacter.h"
+#include "anim/KinTree.h"
+#include "anim/MotionController.h"
+#include "scenes/SceneDribbleAMP.h"
+#include "scenes/SceneHeadingAMP.h"
+#include "scenes/SceneImitate.h"
+#include "scenes/SceneImitateAMP.h"
+#include "scenes/SceneStrikeAMP.h"
+#include "scenes/SceneTargetAMP.h"
+#include "sim/AgentRegistry.h"
+#include "sim/CtPDController.h"
+#include "sim/CtrlBuilder.h"
+#include "sim/Ground.h"
+#include "sim/SimCharacter.h"
+#include "anim/KinCtrlBuilder.h"
+
+extern "C" void ref_unreachable() {
+    fprintf(stderr, "libdm_ref: a reference method without a stand-in was called (it lives in a Bullet translation unit); callers:\n");
+    void* bt[12]; int n = backtrace(bt, 12); backtrace_symbols_fd(bt, n, 2);
+    abort();
+}
+
+// ---- constructors / destructors of the reference classes whose own translation units are Bullet code -----------------------------
+cContactManager::tContactHandle::tContactHandle() : mID(-1), mFlags(0), mFilterFlags(0) {}       // (sim/ContactManager.cpp:9-14: invalid handle)
+cSimObj::cSimObj() : mEnableContactFall(false), mType(eTypeDynamic), mColGroup(0), mColMask(0) {}
+cSimObj::~cSimObj() {}
+cSimRigidBody::cSimRigidBody() {}
+cSimRigidBody::~cSimRigidBody() {}
+cGround::cGround() {}
+cGround::~cGround() {}
+cGround::tParams::tParams() : mType(eTypePlane), mFriction(0.9), mOrigin(tVector::Zero()), mBlend(0), mGroundWidth(0), mVertSpacingX(0), mVertSpacingZ(0), mRandSeed(0), mHasRandSeed(false) {}
+cSimBodyLink::tParams::tParams() : mMass(0), mJointID(-1) {}
+cSimBodyLink::cSimBodyLink() : mJointID(-1), mMass(0), mSize(tVector::Zero()), mObjShape(cShape::eShapeNull), mLinVel(tVector::Zero()), mAngVel(tVector::Zero()) {}
+cSimBodyLink::~cSimBodyLink() {}
+cSimBodyJoint::tParams::tParams() : mID(-1), mLimLow(tVector::Zero()), mLimHigh(tVector::Zero()), mTorqueLimit(0), mForceLimit(0),
+    mParentPos(tVector::Zero()), mChildPos(tVector::Zero()), mParentRot(tQuaternion::Identity()), mChildRot(tQuaternion::Identity()) {}
+cSimBodyJoint::cSimBodyJoint() : mType(cKinTree::eJointTypeNone) { mTotalTau.setZero(); }
+cSimBodyJoint::~cSimBodyJoint() {}
+cSimCharacter::tParams::tParams() : mID(-1), mInitPos(tVector::Zero()), mLoadDrawShapes(false), mEnableContactFall(true) {}
+cSimCharacter::cSimCharacter() : mFriction(0.9), mInvRootAttachRot(tQuaternion::Identity()) {}
+cSimCharacter::~cSimCharacter() {}
+// scene plumbing members that a scene object default-constructs (never used by the routines called below)
+cWorld::tParams::tParams() : mNumSubsteps(1), mScale(1), mGravity(tVector(0, -9.8, 0, 0)) {}
+cSimCharBuilder::eCharType dm_unused_char_type_;
+cCtrlBuilder::tCtrlParams::tCtrlParams() : mCharCtrl(cCtrlBuilder::eCharCtrlNone), mGravity(tVector(0, -9.8, 0, 0)) {}
+cKinCtrlBuilder::tCtrlParams::tCtrlParams() : mCharCtrl(cKinCtrlBuilder::eCharCtrlNone) {}
+tPerturb::~tPerturb() {}
+
+namespace {
+
+typedef Eigen::VectorXd VecX;
+typedef Eigen::MatrixXd MatX;
+VecX vin(const double* p, int n) { VecX v(n); for (int i = 0; i < n; ++i) v[i] = p[i]; return v; }
+void vout(const VecX& v, double* p) { for (int i = 0; i < (int)v.size(); ++i) p[i] = v[i]; }
+
+class StandinChar;
+
+// flat ground at a given height (cGroundPlane::SampleHeight, sim/GroundPlane.cpp)
+class StandinGround : public cGround {
+   public:
+    double h;
+    explicit StandinGround(double h_) : h(h_) {}
+    double SampleHeight(const tVector&) const override { return h; }
+    double SampleHeight(const tVector&, bool& valid) const override { valid = true; return h; }
+    eClass GetGroundClass() const override { return eClassPlane; }
+};
+
+// one body part: transforms and velocities of the link for the character's current (pose, vel)
+class StandinLink : public cSimBodyLink {
+   public:
+    const StandinChar* ch; int id;
+    StandinLink(const StandinChar* c, int j, double mass) : ch(c), id(j) { mJointID = j; mMass = mass; }
+    tVector GetPos() const override;
+    tQuaternion GetRotation() const override;
+    void GetRotation(tVector& axis, double& theta) const override { cMathUtil::QuaternionToAxisAngle(GetRotation(), axis, theta); }
+    tMatrix GetWorldTransform() const override;
+    tVector GetLinearVelocity() const override;
+    tVector GetAngularVelocity() const override;
+    double GetMass() const override { return mMass; }
+    int GetJointID() const override { return id; }
+};
+
+// one joint: type, limits and its slice of the character's pose / vel (sim/SimBodyJoint.cpp:342-445 read the same numbers from Bullet)
+class StandinJoint : public cSimBodyJoint {
+   public:
+    StandinChar* ch = nullptr; int id = -1; bool valid = false;
+    VecX tau;
+    bool IsValid() const override { return valid; }
+    cKinTree::eJointType GetType() const override;
+    bool IsRoot() const override;
+    int GetParamSize() const override;
+    void BuildPose(VecX& out) const override;
+    void BuildVel(VecX& out) const override;
+    double GetTorqueLimit() const override;
+    double GetForceLimit() const override;
+    void AddTau(const VecX& t) override { tau = t; }
+    tVector CalcWorldPos() const override;
+    tQuaternion CalcWorldRotation() const override;
+    void CalcWorldRotation(tVector& axis, double& theta) const override { cMathUtil::QuaternionToAxisAngle(CalcWorldRotation(), axis, theta); }
+    tMatrix BuildWorldTrans() const override;
+};
+
+class StandinChar : public cSimCharacter {
+   public:
+    std::vector<std::shared_ptr<cSimBodyLink>> links; tEigenArr<StandinJoint> joints; std::shared_ptr<cSimBodyLink> null_link;
+    VecX applied_tau; std::shared_ptr<cWorld> no_world; std::shared_ptr<cCharController> ctrl; int contact_mask = 0;
+
+    // skeleton and body definitions by the reference's own loaders (anim/Character.cpp: cCharacter::Init -> LoadSkeleton;
+    // anim/KinTree.cpp:125-172 LoadBodyDefs), as cSimCharacter::Init does before it builds the Bullet body (SimCharacter.cpp:35-71)
+    bool Load(const std::string& char_file) {
+        if (!cCharacter::Init(char_file, false)) return false;
+        if (!cKinTree::LoadBodyDefs(char_file, mBodyDefs)) return false;
+        const int J = GetNumJoints();
+        links.resize(J); joints.resize(J);
+        for (int j = 0; j < J; ++j) {
+            const bool has_body = cKinTree::IsValidBody(mBodyDefs, j);
+            if (has_body) links[j] = std::shared_ptr<cSimBodyLink>(new StandinLink(this, j, cKinTree::GetBodyMass(mBodyDefs, j)));
+            joints[j].ch = this; joints[j].id = j; joints[j].valid = has_body;      // BuildJoints: one joint per valid body part (SimCharacter.cpp:1036-1086)
+        }
+        mPose = mPose0; mVel = mVel0;
+        return true;
+    }
+    void Clear() override { cCharacter::Clear(); }
+    void Reset() override { cCharacter::Reset(); }
+    void Set(const VecX& p, const VecX& v) { mPose = p; mVel = v; }
+    void SetPose(const VecX& p) override { mPose = p; }
+    void SetVel(const VecX& v) override { mVel = v; }
+    // pose-vector getters: what SimCharacter.cpp:124-161 reads back from the Bullet base are the root slots of the pose it just built
+    tVector GetRootPos() const override { return cKinTree::GetRootPos(mPose); }
+    tQuaternion GetRootRotation() const override { return cKinTree::GetRootRot(mPose); }
+    void GetRootRotation(tVector& axis, double& theta) const override { cMathUtil::QuaternionToAxisAngle(GetRootRotation(), axis, theta); }
+    tVector GetRootVel() const override { return cKinTree::GetRootVel(mVel); }
+    tVector GetRootAngVel() const override { return cKinTree::GetRootAngVel(mVel); }
+    tQuaternion CalcHeadingRot() const override { return cKinTree::CalcHeadingRot(mPose); }
+    const MatX& GetBodyDefs() const override { return mBodyDefs; }
+    int GetNumBodyParts() const override { return (int)links.size(); }
+    bool IsValidBodyPart(int idx) const override { return links[idx] != nullptr; }
+    const std::shared_ptr<cSimBodyLink>& GetBodyPart(int idx) const override { return links[idx]; }
+    std::shared_ptr<cSimBodyLink>& GetBodyPart(int idx) override { return links[idx]; }
+    tVector GetBodyPartPos(int idx) const override { return links[idx]->GetPos(); }
+    tVector GetBodyPartVel(int idx) const override { return links[idx]->GetLinearVelocity(); }
+    const cSimBodyJoint& GetJoint(int j) const override { return joints[j]; }
+    cSimBodyJoint& GetJoint(int j) override { return joints[j]; }
+    // SimCharacter.cpp:308-331: the joint's world position when the joint is valid, the body part's otherwise
+    tVector CalcJointPos(int j) const override { return cKinTree::CalcJointWorldPos(mJointMat, mPose, j); }
+    tQuaternion CalcJointWorldRotation(int j) const override { tVector a; double th; cKinTree::CalcJointWorldTheta(mJointMat, mPose, j, a, th); return cMathUtil::AxisAngleToQuaternion(a, th); }
+    tMatrix BuildJointWorldTrans(int j) const override { return cKinTree::JointWorldTrans(mJointMat, mPose, j); }
+    // SimCharacter.cpp:398-436: mass-weighted mean of the body parts' positions / linear velocities
+    tVector CalcCOM() const override {
+        tVector com = tVector::Zero(); double m = 0;
+        for (int i = 0; i < GetNumBodyParts(); ++i) if (IsValidBodyPart(i)) { const double mi = links[i]->GetMass(); com += mi * links[i]->GetPos(); m += mi; }
+        return com / m;
+    }
+    tVector CalcCOMVel() const override {
+        tVector v = tVector::Zero(); double m = 0;
+        for (int i = 0; i < GetNumBodyParts(); ++i) if (IsValidBodyPart(i)) { const double mi = links[i]->GetMass(); v += mi * links[i]->GetLinearVelocity(); m += mi; }
+        return v / m;
+    }
+    double CalcTotalMass() const override { return cKinTree::CalcTotalMass(mBodyDefs); }
+    void ApplyControlForces(const VecX& tau) override { applied_tau = tau; }
+    bool IsInContact(int idx) const override { return (contact_mask >> idx) & 1; }
+    bool IsInContact() const override { return contact_mask != 0; }
+    const std::shared_ptr<cWorld>& GetWorld() const override { return no_world; }
+    const std::shared_ptr<cCharController>& GetController() override { return ctrl; }
+    const std::shared_ptr<cCharController>& GetController() const override { return ctrl; }
+    void SetController(std::shared_ptr<cCharController> c) override { ctrl = c; }
+    // cSimObj face of the character (SimCharacter.cpp: the root link's)
+    tVector GetPos() const override { return GetRootPos(); }
+    tQuaternion GetRotation() const override { return GetRootRotation(); }
+    tVector GetLinearVelocity() const override { return GetRootVel(); }
+    tVector GetAngularVelocity() const override { return GetRootAngVel(); }
+    const MatX& JointMat() const { return mJointMat; }
+    const VecX& Pose() const { return mPose; }
+    const VecX& Vel() const { return mVel; }
+};
+
+tVector StandinLink::GetPos() const { tMatrix m = cKinTree::BodyWorldTrans(ch->JointMat(), ch->GetBodyDefs(), ch->Pose(), id); return tVector(m(0, 3), m(1, 3), m(2, 3), 0); }
+tQuaternion StandinLink::GetRotation() const { return cMathUtil::RotMatToQuaternion(cKinTree::BodyWorldTrans(ch->JointMat(), ch->GetBodyDefs(), ch->Pose(), id)); }
+tMatrix StandinLink::GetWorldTransform() const { return cKinTree::BodyWorldTrans(ch->JointMat(), ch->GetBodyDefs(), ch->Pose(), id); }
+tVector StandinLink::GetLinearVelocity() const { return cKinTree::CalcBodyPartVel(ch->JointMat(), ch->GetBodyDefs(), ch->Pose(), ch->Vel(), id); }
+tVector StandinLink::GetAngularVelocity() const { return cKinTree::CalcJointWorldAngularVel(ch->JointMat(), ch->Pose(), ch->Vel(), id); }
+
+cKinTree::eJointType StandinJoint::GetType() const { return cKinTree::GetJointType(ch->JointMat(), id); }
+bool StandinJoint::IsRoot() const { return cKinTree::IsRoot(ch->JointMat(), id); }
+int StandinJoint::GetParamSize() const { return cKinTree::GetParamSize(ch->JointMat(), id); }
+void StandinJoint::BuildPose(VecX& out) const { cKinTree::GetJointParams(ch->JointMat(), ch->Pose(), id, out); }
+void StandinJoint::BuildVel(VecX& out) const { cKinTree::GetJointParams(ch->JointMat(), ch->Vel(), id, out); }
+double StandinJoint::GetTorqueLimit() const { return cKinTree::GetTorqueLimit(ch->JointMat(), id); }
+double StandinJoint::GetForceLimit() const { return cKinTree::GetForceLimit(ch->JointMat(), id); }
+tVector StandinJoint::CalcWorldPos() const { return cKinTree::CalcJointWorldPos(ch->JointMat(), ch->Pose(), id); }
+tQuaternion StandinJoint::CalcWorldRotation() const { tVector a; double th; cKinTree::CalcJointWorldTheta(ch->JointMat(), ch->Pose(), id, a, th); return cMathUtil::AxisAngleToQuaternion(a, th); }
+tMatrix StandinJoint::BuildWorldTrans() const { return cKinTree::JointWorldTrans(ch->JointMat(), ch->Pose(), id); }
+
+// the reference's controller with its protected parts reachable
+class CtrlX : public cCtPDController {
+   public:
+    using cCtPDController::UpdateBuildTau;
+    using cCtPDController::ApplyAction;
+    cImpPDController& pd() { return mPDCtrl; }
+    void set_time(double t) { mTime = t; }
+};
+// the reference's scenes with the few protected members the routines read set from outside
+template <class SCENE>
+class SceneX : public SCENE {
+   public:
+    void setup(const std::shared_ptr<cSimCharacter>& ch, const std::shared_ptr<cKinCharacter>& kin, double ground_h) {
+        this->mChars.clear(); this->mChars.push_back(ch);
+        this->mGround = std::shared_ptr<cGround>(new StandinGround(ground_h));
+        this->mKinChar = kin;
+        this->CalcJointWeights(ch, this->mJointWeights);                 // scenes/SceneImitate.cpp:236-248 (InitJointWeights)
+    }
+    double reward_imitate(const cSimCharacter& sim, const cKinCharacter& kin) const { return this->CalcRewardImitate(sim, kin); }
+};
+
+struct Rig {
+    std::shared_ptr<StandinChar> ch;
+    std::shared_ptr<CtrlX> ctrl;
+    std::shared_ptr<cKinCharacter> kin;
+    std::shared_ptr<SceneX<cSceneImitate>> imitate;
+    std::shared_ptr<SceneX<cSceneImitateAMP>> amp;
+};
+
+}  // namespace
+
+extern "C" {
+
+// character file + controller file -> stand-in character, the reference's cCtPDController initialised the way
+// cCtrlBuilder::BuildCtPDController does (sim/CtrlBuilder.cpp:89-99: SetGravity, Init(character, file)), and (optionally) the reference's
+// kinematic character on `motion_file`
+void* ref2_create(const char* char_file, const char* ctrl_file, const char* motion_file, const double* gravity3) {
+    Rig* r = new Rig();
+    r->ch = std::shared_ptr<StandinChar>(new StandinChar());
+    if (!r->ch->Load(char_file)) { delete r; return nullptr; }
+    r->ctrl = std::shared_ptr<CtrlX>(new CtrlX());
+    r->ctrl->SetGravity(tVector(gravity3[0], gravity3[1], gravity3[2], 0));
+    r->ctrl->Init(r->ch.get(), ctrl_file);
+    r->ch->SetController(r->ctrl);
+    if (motion_file && motion_file[0]) {
+        r->kin = std::shared_ptr<cKinCharacter>(new cKinCharacter());
+        cKinCharacter::tParams p; p.mCharFile = char_file; p.mLoadDrawShapes = false;
+        if (!r->kin->Init(p)) { delete r; return nullptr; }
+        std::shared_ptr<cMotionController> mc(new cMotionController());
+        mc->Init(r->kin.get(), motion_file);
+        r->kin->SetController(mc);
+    }
+    return r;
+}
+void ref2_destroy(void* h) { delete (Rig*)h; }
+int ref2_num_dof(void* h) { return ((Rig*)h)->ch->GetNumDof(); }
+int ref2_state_size(void* h) { return ((Rig*)h)->ctrl->GetStateSize(); }
+int ref2_action_size(void* h) { return ((Rig*)h)->ctrl->GetActionSize(); }
+void ref2_set_state(void* h, const double* pose, const double* vel) { Rig* r = (Rig*)h; const int P = r->ch->GetNumDof(); r->ch->Set(vin(pose, P), vin(vel, P)); }
+
+// cCtPDController::ApplyAction -> SetPDTargets -> ConvertActionToTargetPose (sim/CtPDController.cpp:97-166) -> cImpPDController::SetTargetTheta;
+// out_tar: the latched PD targets in pose layout (cExpPDController::GetTargetTheta per joint; root slots 0), i.e. what
+// cImpPDController::BuildTargetPose (sim/ImpPDController.cpp:197-219) hands to the solve
+void ref2_apply_action(void* h, const double* action, double* out_tar) {
+    Rig* r = (Rig*)h;
+    r->ctrl->ApplyAction(vin(action, r->ctrl->GetActionSize()));
+    const int P = r->ch->GetNumDof();
+    for (int i = 0; i < P; ++i) out_tar[i] = 0;
+    for (int j = 0; j < r->ch->GetNumJoints(); ++j) {
+        if (!r->ctrl->pd().GetPDCtrl(j).IsValid()) continue;
+        VecX th; r->ctrl->pd().GetTargetTheta(j, th);
+        const int off = r->ch->GetParamOffset(j);
+        for (int k = 0; k < (int)th.size(); ++k) out_tar[off + k] = th[k];
+    }
+}
+// cCtPDController::UpdateBuildTau -> cImpPDController::UpdateControlForce -> UpdateRBDModel + CalcControlForces (sim/CtPDController.cpp:85-95;
+// sim/ImpPDController.cpp:47-73,129-195): the stable-PD torque for the current state and the latched targets, pose layout, before the clamp
+void ref2_spd_tau(void* h, double dt, double* out_tau) {
+    Rig* r = (Rig*)h;
+    VecX tau = VecX::Zero(r->ch->GetNumDof());
+    r->ctrl->UpdateBuildTau(dt, tau);
+    vout(tau, out_tau);
+}
+// cCtController::RecordState (sim/CtController.cpp:281-293 -> BuildStatePose / BuildStateVel / BuildStatePhase :373-478) with the
+// controller's own flags from the file; phase = controller time / cycle period
+int ref2_record_state(void* h, double phase, double ground_h, double* out) {
+    Rig* r = (Rig*)h;
+    r->ctrl->SetGround(std::shared_ptr<cGround>(new StandinGround(ground_h)));
+    r->ctrl->SetCyclePeriod(1.0); r->ctrl->SetInitTime(0.0); r->ctrl->set_time(phase);
+    VecX s; r->ctrl->RecordState(s); vout(s, out);
+    return (int)s.size();
+}
+// the learner-facing tables of the controller (sim/CtController.cpp:54-69,183-195; sim/CtPDController.cpp BuildActionBounds /
+// BuildActionOffsetScale; sim/CharController.cpp:64-89): state offset / scale / norm groups, action offset / scale / bounds
+void ref2_tables(void* h, double* s_off, double* s_scale, int* s_groups, double* a_off, double* a_scale, double* a_min, double* a_max) {
+    Rig* r = (Rig*)h; VecX a, b; Eigen::VectorXi g;
+    r->ctrl->BuildStateOffsetScale(a, b); vout(a, s_off); vout(b, s_scale);
+    r->ctrl->BuildStateNormGroups(g); for (int i = 0; i < (int)g.size(); ++i) s_groups[i] = g[i];
+    r->ctrl->BuildActionOffsetScale(a, b); vout(a, a_off); vout(b, a_scale);
+    r->ctrl->BuildActionBounds(a, b); vout(a, a_min); vout(b, a_max);
+}
+// kinematic character to a clip time with an origin (as ref_kinchar_*): cKinCharacter::SetTime + Pose
+void ref2_kin_set(void* h, double t, const double* origin_pos3, const double* origin_rot4) {
+    Rig* r = (Rig*)h;
+    r->kin->SetOriginPos(tVector(origin_pos3[0], origin_pos3[1], origin_pos3[2], 0));
+    r->kin->SetOriginRot(tQuaternion(origin_rot4[0], origin_rot4[1], origin_rot4[2], origin_rot4[3]));
+    r->kin->SetTime(t); r->kin->Pose();
+}
+void ref2_kin_state(void* h, double* pose, double* vel) { Rig* r = (Rig*)h; vout(r->kin->GetPose(), pose); vout(r->kin->GetVel(), vel); }
+// cSceneImitate::CalcRewardImitate (scenes/SceneImitate.cpp:7-127) on the stand-in sim character and the reference's kin character,
+// joint weights by cSceneImitate::CalcJointWeights (:236-248)
+double ref2_reward_imitate(void* h, double ground_h) {
+    Rig* r = (Rig*)h;
+    if (!r->imitate) r->imitate = std::shared_ptr<SceneX<cSceneImitate>>(new SceneX<cSceneImitate>());
+    r->imitate->setup(r->ch, r->kin, ground_h);
+    return r->imitate->reward_imitate(*r->ch, *r->kin);
+}
+
+}  // extern "C"

@@ -244,3 +244,54 @@ def random_pose_vel(t, rng, big=False):
             p[off] = rng.uniform(-np.pi, np.pi)
             v[off] = rng.normal() * s
     return p, v
+
+
+class RefRig:
+    """The reference's OWN routines (compiled translation units sim/CtPDController.cpp, sim/ImpPDController.cpp, sim/CtController.cpp,
+    scenes/SceneImitate.cpp, ...) running on a stand-in character (oracle/ref_standins.cpp): stable-PD torque, action mapping, state
+    features, learner tables, imitation reward.  Needs the reference's data files (this container only)."""
+
+    def __init__(self, comp, character="humanoid3d", controller=None, motion=None, gravity=(0.0, -9.8, 0.0)):
+        assert comp.kind == "ref"
+        self.lib = comp.lib
+        controller = controller or character + "_phase_rot_ctrl"
+        cf = os.path.join(REF_DATA, "characters", character + ".txt").encode()
+        tf = os.path.join(REF_DATA, "controllers", controller + ".txt").encode()
+        mf = os.path.join(REF_DATA, "motions", motion + ".txt").encode() if motion else b""
+        self.lib.ref2_create.restype = C.c_void_p
+        self.lib.ref2_reward_imitate.restype = C.c_double
+        g = _arr(gravity)
+        self.h = self.lib.ref2_create(cf, tf, mf, _d(g))
+        assert self.h, "ref2_create failed"
+        self.P = self.lib.ref2_num_dof(C.c_void_p(self.h)); self.S = self.lib.ref2_state_size(C.c_void_p(self.h)); self.A = self.lib.ref2_action_size(C.c_void_p(self.h))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.lib.ref2_destroy(C.c_void_p(self.h)); self.h = None
+
+    def set_state(self, pose, vel):
+        self.lib.ref2_set_state(C.c_void_p(self.h), _d(_arr(pose)), _d(_arr(vel)))
+
+    def apply_action(self, a):
+        out = np.zeros(self.P); self.lib.ref2_apply_action(C.c_void_p(self.h), _d(_arr(a)), _d(out)); return out
+
+    def spd_tau(self, dt):
+        out = np.zeros(self.P); self.lib.ref2_spd_tau(C.c_void_p(self.h), C.c_double(dt), _d(out)); return out
+
+    def record_state(self, phase, ground_h=0.0):
+        out = np.zeros(self.S); n = self.lib.ref2_record_state(C.c_void_p(self.h), C.c_double(phase), C.c_double(ground_h), _d(out)); assert n == self.S; return out
+
+    def tables(self):
+        so, ss, ao, asc, lo, hi = (np.zeros(self.S), np.zeros(self.S), np.zeros(self.A), np.zeros(self.A), np.zeros(self.A), np.zeros(self.A))
+        g = np.zeros(self.S, dtype=np.int32)
+        self.lib.ref2_tables(C.c_void_p(self.h), _d(so), _d(ss), g.ctypes.data_as(C.POINTER(C.c_int32)), _d(ao), _d(asc), _d(lo), _d(hi))
+        return dict(s_off=so, s_scale=ss, s_groups=g, a_off=ao, a_scale=asc, a_min=lo, a_max=hi)
+
+    def kin_set(self, t, origin_pos=(0.0, 0.0, 0.0), origin_rot=(1.0, 0.0, 0.0, 0.0)):
+        self.lib.ref2_kin_set(C.c_void_p(self.h), C.c_double(t), _d(_arr(origin_pos)), _d(_arr(origin_rot)))
+
+    def kin_state(self):
+        p, v = np.zeros(self.P), np.zeros(self.P); self.lib.ref2_kin_state(C.c_void_p(self.h), _d(p), _d(v)); return p, v
+
+    def reward_imitate(self, ground_h=0.0):
+        return float(self.lib.ref2_reward_imitate(C.c_void_p(self.h), C.c_double(ground_h)))

@@ -136,6 +136,11 @@ void orc_get_kin_state(void* h, double* pose, double* vel, double* origin /*3+4*
     origin[3] = s->kin.origin_rot.w; origin[4] = s->kin.origin_rot.x; origin[5] = s->kin.origin_rot.y; origin[6] = s->kin.origin_rot.z;
 }
 void orc_get_tar_pose(void* h, double* out) { copy_out(((Scene*)h)->tar_pose, out); }
+// (tests: hand the AMP pose history in, as the device keeps it in EnvState::hist)
+void orc_set_prev_state(void* h, const double* pose, const double* vel) {
+    Scene* s = (Scene*)h;
+    s->prev_pose = copy_in(pose, s->sk.P); s->prev_vel = copy_in(vel, s->sk.P);
+}
 void orc_set_tar_pose(void* h, const double* in) { Scene* s = (Scene*)h; s->tar_pose = copy_in(in, s->sk.P); }
 void orc_get_tau(void* h, double* out) { copy_out(((Scene*)h)->tau, out); }
 void orc_get_contacts(void* h, int* in_contact) { Scene* s = (Scene*)h; for (int j = 0; j < s->sk.J; ++j) in_contact[j] = s->in_contact[j]; }

@@ -18,6 +18,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <execinfo.h>
+#include <limits>
 #include <memory>
 #include <string>
 #include <vector>
@@ -87,6 +88,8 @@ class StandinGround : public cGround {
     double SampleHeight(const tVector&) const override { return h; }
     double SampleHeight(const tVector&, bool& valid) const override { valid = true; return h; }
     eClass GetGroundClass() const override { return eClassPlane; }
+    // a plane has no horizontal bounds (sim/GroundPlane.cpp CalcAABB: +-infinity in x, z)
+    void CalcAABB(tVector& mn, tVector& mx) const override { const double inf = std::numeric_limits<double>::infinity(); mn = tVector(-inf, h, -inf, 0); mx = tVector(inf, h, inf, 0); }
 };
 
 // one body part: transforms and velocities of the link for the character's current (pose, vel)
@@ -142,6 +145,7 @@ class StandinChar : public cSimCharacter {
             joints[j].ch = this; joints[j].id = j; joints[j].valid = has_body;      // BuildJoints: one joint per valid body part (SimCharacter.cpp:1036-1086)
         }
         mPose = mPose0; mVel = mVel0;
+        SetID(0);                                   // character 0 of the scene (cSceneSimChar::BuildCharacters numbers them)
         return true;
     }
     void Clear() override { cCharacter::Clear(); }
@@ -182,6 +186,8 @@ class StandinChar : public cSimCharacter {
     }
     double CalcTotalMass() const override { return cKinTree::CalcTotalMass(mBodyDefs); }
     void ApplyControlForces(const VecX& tau) override { applied_tau = tau; }
+    bool fallen = false;
+    bool HasFallen() const override { return fallen; }
     bool IsInContact(int idx) const override { return (contact_mask >> idx) & 1; }
     bool IsInContact() const override { return contact_mask != 0; }
     const std::shared_ptr<cWorld>& GetWorld() const override { return no_world; }
@@ -222,6 +228,7 @@ class CtrlX : public cCtPDController {
     using cCtPDController::ApplyAction;
     cImpPDController& pd() { return mPDCtrl; }
     void set_time(double t) { mTime = t; }
+    void set_prev_action(double t, const tVector& com) { mPrevActionTime = t; mPrevActionCOM = com; }
 };
 // the reference's scenes with the few protected members the routines read set from outside
 template <class SCENE>
@@ -232,7 +239,13 @@ class SceneX : public SCENE {
         this->mGround = std::shared_ptr<cGround>(new StandinGround(ground_h));
         this->mKinChar = kin;
         this->CalcJointWeights(ch, this->mJointWeights);                 // scenes/SceneImitate.cpp:236-248 (InitJointWeights)
+        this->mAgentReg.Clear(); this->mAgentReg.AddAgent(ch->GetController(), ch.get());      // cRLSceneSimChar::RegisterAgents (RLSceneSimChar.cpp:27-37)
     }
+    void amp_prev(const VecX& pp, const VecX& pv, bool local_root) { this->mPrevPose = pp; this->mPrevVel = pv; this->mEnableAMPObsLocalRoot = local_root; }
+    void target(const tVector& pos, double speed, double succ_dist, double fail_dist, bool min_tar_vel, double pos_scale) {
+        this->mTargetPos = pos; this->mTargetSpeed = speed; this->mTargetSuccDist = succ_dist; this->mTarFailDist = fail_dist; this->mEnableMinTarVel = min_tar_vel; this->mPosRewardScale = pos_scale;
+    }
+    void heading(double h, double vel_scale) { this->mTargetHeading = h; this->mVelRewardScale = vel_scale; }
     double reward_imitate(const cSimCharacter& sim, const cKinCharacter& kin) const { return this->CalcRewardImitate(sim, kin); }
 };
 
@@ -242,6 +255,8 @@ struct Rig {
     std::shared_ptr<cKinCharacter> kin;
     std::shared_ptr<SceneX<cSceneImitate>> imitate;
     std::shared_ptr<SceneX<cSceneImitateAMP>> amp;
+    std::shared_ptr<SceneX<cSceneTargetAMP>> target;
+    std::shared_ptr<SceneX<cSceneHeadingAMP>> heading;
 };
 
 }  // namespace
@@ -269,7 +284,14 @@ void* ref2_create(const char* char_file, const char* ctrl_file, const char* moti
     }
     return r;
 }
-void ref2_destroy(void* h) { delete (Rig*)h; }
+// (the scene objects are left alone: their destructors tear down a world this harness never built)
+void ref2_destroy(void* h) {
+    Rig* r = (Rig*)h;
+    new std::shared_ptr<SceneX<cSceneImitate>>(r->imitate); new std::shared_ptr<SceneX<cSceneImitateAMP>>(r->amp);
+    new std::shared_ptr<SceneX<cSceneTargetAMP>>(r->target); new std::shared_ptr<SceneX<cSceneHeadingAMP>>(r->heading);
+    new std::shared_ptr<StandinChar>(r->ch); new std::shared_ptr<CtrlX>(r->ctrl);
+    delete r;
+}
 int ref2_num_dof(void* h) { return ((Rig*)h)->ch->GetNumDof(); }
 int ref2_state_size(void* h) { return ((Rig*)h)->ctrl->GetStateSize(); }
 int ref2_action_size(void* h) { return ((Rig*)h)->ctrl->GetActionSize(); }
@@ -288,6 +310,15 @@ void ref2_apply_action(void* h, const double* action, double* out_tar) {
         VecX th; r->ctrl->pd().GetTargetTheta(j, th);
         const int off = r->ch->GetParamOffset(j);
         for (int k = 0; k < (int)th.size(); ++k) out_tar[off + k] = th[k];
+    }
+}
+// PD targets handed in as a pose vector: cExpPDController::SetTargetTheta per joint (sim/ExpPDController.cpp; the call ApplyAction ends in)
+void ref2_set_targets(void* h, const double* tar_pose) {
+    Rig* r = (Rig*)h;
+    for (int j = 0; j < r->ch->GetNumJoints(); ++j) {
+        if (!r->ctrl->pd().GetPDCtrl(j).IsValid()) continue;
+        const int off = r->ch->GetParamOffset(j), sz = r->ch->GetParamSize(j);
+        r->ctrl->pd().SetTargetTheta(j, vin(tar_pose + off, sz));
     }
 }
 // cCtPDController::UpdateBuildTau -> cImpPDController::UpdateControlForce -> UpdateRBDModel + CalcControlForces (sim/CtPDController.cpp:85-95;
@@ -319,8 +350,10 @@ void ref2_tables(void* h, double* s_off, double* s_scale, int* s_groups, double*
 // kinematic character to a clip time with an origin (as ref_kinchar_*): cKinCharacter::SetTime + Pose
 void ref2_kin_set(void* h, double t, const double* origin_pos3, const double* origin_rot4) {
     Rig* r = (Rig*)h;
-    r->kin->SetOriginPos(tVector(origin_pos3[0], origin_pos3[1], origin_pos3[2], 0));
+    // rotation first: cKinCharacter::SetOriginRot pivots the origin about the CURRENT root position (KinCharacter.cpp:276-300), SetOriginPos then
+    // pins the origin exactly (:255-260) -- in this order the result does not depend on where the last Pose() left the root
     r->kin->SetOriginRot(tQuaternion(origin_rot4[0], origin_rot4[1], origin_rot4[2], origin_rot4[3]));
+    r->kin->SetOriginPos(tVector(origin_pos3[0], origin_pos3[1], origin_pos3[2], 0));
     r->kin->SetTime(t); r->kin->Pose();
 }
 void ref2_kin_state(void* h, double* pose, double* vel) { Rig* r = (Rig*)h; vout(r->kin->GetPose(), pose); vout(r->kin->GetVel(), vel); }
@@ -331,6 +364,41 @@ double ref2_reward_imitate(void* h, double ground_h) {
     if (!r->imitate) r->imitate = std::shared_ptr<SceneX<cSceneImitate>>(new SceneX<cSceneImitate>());
     r->imitate->setup(r->ch, r->kin, ground_h);
     return r->imitate->reward_imitate(*r->ch, *r->kin);
+}
+
+// cSceneImitateAMP::RecordAMPObsAgent -> BuildAMPObs / RecordAMPObsPose / RecordAMPObsVel (scenes/SceneImitateAMP.cpp:101-113,279-396) with the
+// history (mPrevPose / mPrevVel) handed in; returns the observation size (GetAMPObsSize)
+int ref2_amp_obs(void* h, const double* prev_pose, const double* prev_vel, int local_root, double ground_h, double* out) {
+    Rig* r = (Rig*)h; const int P = r->ch->GetNumDof();
+    if (!r->amp) r->amp = std::shared_ptr<SceneX<cSceneImitateAMP>>(new SceneX<cSceneImitateAMP>());
+    r->amp->setup(r->ch, r->kin, ground_h);
+    r->amp->amp_prev(vin(prev_pose, P), vin(prev_vel, P), local_root != 0);
+    VecX o; r->amp->RecordAMPObsAgent(0, o); vout(o, out);
+    return (int)o.size();
+}
+// task scenes: cSceneTargetAMP::CalcReward / RecordGoal (scenes/SceneTargetAMP.cpp:3-81,192-218) and cSceneHeadingAMP::CalcReward / RecordGoal
+// (scenes/SceneHeadingAMP.cpp:3-43,134-149) on the stand-in character.  par: [target x, y, z, target speed, succ dist, fail dist,
+// enable_min_tar_vel, pos reward scale, target heading, vel reward scale, prev action time, prev action COM x, y, z, controller time, fallen];
+// out: [reward, goal...]; returns the goal size
+int ref2_task_scene(void* h, int kind, const double* par, double* out) {
+    Rig* r = (Rig*)h;
+    r->ctrl->set_time(par[14]); r->ctrl->set_prev_action(par[10], tVector(par[11], par[12], par[13], 0));
+    r->ch->fallen = par[15] != 0;
+    VecX g; double rew = 0;
+    if (kind == 1) {
+        if (!r->target) r->target = std::shared_ptr<SceneX<cSceneTargetAMP>>(new SceneX<cSceneTargetAMP>());
+        r->target->setup(r->ch, r->kin, 0.0);
+        r->target->target(tVector(par[0], par[1], par[2], 0), par[3], par[4], par[5], par[6] != 0, par[7]);
+        rew = r->target->CalcReward(0); r->target->RecordGoal(0, g);
+    } else {
+        if (!r->heading) r->heading = std::shared_ptr<SceneX<cSceneHeadingAMP>>(new SceneX<cSceneHeadingAMP>());
+        r->heading->setup(r->ch, r->kin, 0.0);
+        r->heading->target(tVector(par[0], par[1], par[2], 0), par[3], par[4], par[5], par[6] != 0, par[7]);
+        r->heading->heading(par[8], par[9]);
+        rew = r->heading->CalcReward(0); r->heading->RecordGoal(0, g);
+    }
+    out[0] = rew; for (int i = 0; i < (int)g.size(); ++i) out[1 + i] = g[i];
+    return (int)g.size();
 }
 
 }  // extern "C"

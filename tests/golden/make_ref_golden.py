@@ -2,9 +2,12 @@
 by oracle/build_ref.sh from the unmodified files under /root/reference/DeepMimicCore) on seeded inputs.
 
 Unlike oracle_rollouts.json (the oracle's own outputs), every array written here is computed by reference code:
-cKinTree / cRBDModel / cRBDUtil / cMathUtil / cKinCharacter / cMotionController / cMotion, plus the four compositions
-in oracle/ref_glue.cpp (SPD torque, imitation reward, state vector, action -> target) that call those functions in the
-order of the reference routine they cite.
+cKinTree / cRBDModel / cRBDUtil / cMathUtil / cKinCharacter / cMotionController / cMotion, and -- since round 3 -- the reference's
+compiled ROUTINES (oracle/ref_standins.cpp: sim/ImpPDController.cpp CalcControlForces, sim/CtController.cpp RecordState,
+scenes/SceneImitate.cpp CalcRewardImitate, scenes/SceneImitateAMP.cpp BuildAMPObs, scenes/SceneTargetAMP.cpp / SceneHeadingAMP.cpp
+CalcReward + RecordGoal) for the SPD torque, the state vector, the reward, the AMP observation and the task rewards / goal vectors;
+the compositions of oracle/ref_glue.cpp are evaluated next to them and must agree (only the five reward error TERMS, which the
+routine does not hand out, are still taken from the composition).
 
 The file travels with the repository, so the checks in tests/test_ref_golden.py (oracle vs golden, emulator build of the
 device code vs golden, and -- marked gpu -- the HIP kernels vs golden) run where /root/reference does not exist.
@@ -22,7 +25,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 import ref_lib  # noqa: E402
 from deepmimic_amd import model  # noqa: E402
-from ref_lib import Components, RefKinChar, Skel, random_pose_vel  # noqa: E402
+from ref_lib import Components, RefKinChar, RefRig, Skel, random_pose_vel  # noqa: E402
 
 N_STATES = 8
 N_KIN = 16
@@ -47,13 +50,15 @@ def main():
         t = model.load_asset(name)
         sk = Skel(ref, t)
         kc = RefKinChar(ref, os.path.join("/root/reference", t.cfg.character_file), os.path.join("/root/reference", t.cfg.motion_file))
+        char = os.path.splitext(os.path.basename(t.cfg.character_file))[0]
+        rig = RefRig(ref, char, motion=os.path.splitext(os.path.basename(t.cfg.motion_file))[0])
         rng = np.random.default_rng(1000 + si)
         kp, kd = gains(t)
         w = t.joint_mat[:, model.JD_DIFF_W].copy(); w = w / np.abs(w).sum()
         P, J = t.pose_dim, t.num_joints
         flags = int(t.enable_phase_input) | (int(t.record_world_root_pos) << 1) | (int(t.record_world_root_rot) << 2)
         g = {k: [] for k in ("pose", "vel", "tar", "H", "C", "spd_tau", "joint_world", "body_world", "link_vel", "com", "com_vel",
-                             "kin_time", "kin_origin", "kin_pose", "kin_vel", "reward_terms", "reward", "state", "phase")}
+                             "kin_time", "kin_origin", "kin_pose", "kin_vel", "reward_terms", "reward", "state", "phase", "amp_obs", "amp_prev_pose", "amp_prev_vel")}
         for i in range(N_STATES):
             # kinematic character: a clip time (beyond one cycle for looping clips) and an origin (translation + yaw)
             tk = rng.uniform(0, 2.6 * kc.duration if kc.loop else 0.95 * kc.duration)
@@ -86,7 +91,20 @@ def main():
             n = ref.lib.ref_record_state(sk.h, ref_lib._d(p), ref_lib._d(v), ref_lib.C.c_double(phase), ref_lib.C.c_double(0.0), flags, ref_lib._d(st))
             assert n == t.state_dim, (n, t.state_dim)
             rt = ref_lib.ref_reward_terms(ref, sk, p, v, kpose, kvel, w, 0.0, opos[1])
-            for k, val in (("pose", p), ("vel", v), ("tar", tar), ("H", H), ("C", C), ("spd_tau", sk.spd_tau(p, v, tar, kp, kd, 1 / 600)),
+            # the compiled routines on the same inputs; the compositions must agree with them
+            rig.set_state(p, v); rig.set_targets(tar)
+            tau_routine = rig.spd_tau(1 / 600)
+            assert np.abs(tau_routine - sk.spd_tau(p, v, tar, kp, kd, 1 / 600)).max() < 1e-11 * max(1.0, np.abs(tau_routine).max())
+            st_routine = rig.record_state(phase, 0.0)
+            assert np.abs(st_routine - st).max() < 1e-12 * max(1.0, np.abs(st).max())
+            rig.kin_set(tk, opos, orot)
+            rew_routine = rig.reward_imitate(0.0)
+            assert abs(rew_routine - rt[5]) < 1e-12, (name, i, rew_routine, rt[5])
+            st, rt[5] = st_routine, rew_routine
+            # AMP observation (imitate_amp, enable_amp_obs_local_root as the 34 shipped arg files have it: false) with a history one control period back
+            pp, pv = kc.eval(tk - 1 / 30)
+            amp = rig.amp_obs(pp, pv, False)
+            for k, val in (("pose", p), ("vel", v), ("tar", tar), ("H", H), ("C", C), ("spd_tau", tau_routine), ("amp_obs", amp), ("amp_prev_pose", pp), ("amp_prev_vel", pv),
                            ("joint_world", jw), ("body_world", bw), ("link_vel", sk.link_vel(p, v)), ("com", com), ("com_vel", comv),
                            ("kin_time", tk), ("kin_origin", np.r_[opos, orot]), ("kin_pose", kpose), ("kin_vel", kvel),
                            ("reward_terms", rt[:5]), ("reward", rt[5]), ("state", st), ("phase", phase)):
@@ -105,6 +123,34 @@ def main():
         out["%s/frame_time" % name] = np.array([f[2] for f in fr])
         out["%s/duration" % name] = np.array(kc.duration)
         out["%s/cycle_root_delta" % name] = kc.cycle_root_delta()
+    # task scenes (scenes/SceneTargetAMP.cpp, SceneHeadingAMP.cpp as compiled): reward and goal vector on scripted goal states.
+    # par layout = oracle/ref_standins.cpp ref2_task_scene
+    for name, kind in (("amp_target_zombie", 1), ("amp_heading_zombie", 2)):
+        t = model.load_asset(name); c = t.cfg
+        char = os.path.splitext(os.path.basename(c.character_file))[0]
+        kc = RefKinChar(ref, os.path.join("/root/reference", c.character_file), "/root/reference/data/motions/humanoid3d_walk.txt")     # (poses to stand in: any clip)
+        rig = RefRig(ref, char)
+        sk = Skel(ref, t)
+        rng = np.random.default_rng(2000 + kind)
+        g = {k: [] for k in ("pose", "vel", "par", "reward", "goal")}
+        for i in range(12):
+            tk = rng.uniform(0, kc.duration)
+            kc.set_origin(np.array([rng.normal(), 0.0, rng.normal()]), np.array([np.cos(0.4 * i), 0.0, np.sin(0.4 * i), 0.0]))
+            p, v = kc.eval(tk)
+            p[1] += 0.05; v[0:3] += rng.normal(size=3) * 0.3
+            com, _ = sk.com(p, v)
+            speed = rng.uniform(0.5, 2.0)
+            tar = np.array([p[0], 0.0, p[2]]) + rng.normal(size=3) * np.array([2.0, 0.0, 2.0]) * (0.1 if i % 5 == 4 else 1.0)    # (some targets inside the success radius)
+            prev_t = rng.uniform(0.1, 3.0)
+            prev_com = com - np.array([rng.normal() * 0.03, rng.normal() * 0.01, rng.normal() * 0.03]) - 19 / 600 * speed * np.array([np.cos(0.4 * i), 0, -np.sin(0.4 * i)])
+            par = [tar[0], 0.0, tar[2], speed, c.target_succ_dist, c.tar_fail_dist if np.isfinite(c.tar_fail_dist) else 1e30, float(c.enable_min_tar_vel), c.pos_reward_scale,
+                   rng.uniform(-np.pi, np.pi), c.vel_reward_scale, prev_t, prev_com[0], prev_com[1], prev_com[2], prev_t + 19 / 600, 0.0]
+            rig.set_state(p, v)
+            r, goal = rig.task_scene(kind, par)
+            for k, val in (("pose", p), ("vel", v), ("par", par), ("reward", r), ("goal", goal)):
+                g[k].append(np.array(val))
+        for k, val in g.items():
+            out["task/%s/%s" % (name, k)] = np.array(val)
     # scalar / quaternion functions of cMathUtil on a fixed input set
     rng = np.random.default_rng(7)
     ops, ins, outs = [], [], []

@@ -152,6 +152,10 @@ class Oracle:
         self.lib.orc_prev_state(self.h, _d(p), _d(v))
         return p, v
 
+    def set_prev_state(self, pose, vel):
+        p = np.ascontiguousarray(pose, dtype=np.float64); v = np.ascontiguousarray(vel, dtype=np.float64)
+        self.lib.orc_set_prev_state(self.h, _d(p), _d(v))
+
     def calc_reward(self):
         return self.lib.orc_calc_reward(self.h)
 

@@ -275,6 +275,9 @@ class RefRig:
     def apply_action(self, a):
         out = np.zeros(self.P); self.lib.ref2_apply_action(C.c_void_p(self.h), _d(_arr(a)), _d(out)); return out
 
+    def set_targets(self, tar_pose):
+        self.lib.ref2_set_targets(C.c_void_p(self.h), _d(_arr(tar_pose)))
+
     def spd_tau(self, dt):
         out = np.zeros(self.P); self.lib.ref2_spd_tau(C.c_void_p(self.h), C.c_double(dt), _d(out)); return out
 
@@ -295,3 +298,13 @@ class RefRig:
 
     def reward_imitate(self, ground_h=0.0):
         return float(self.lib.ref2_reward_imitate(C.c_void_p(self.h), C.c_double(ground_h)))
+
+    def amp_obs(self, prev_pose, prev_vel, local_root, ground_h=0.0, size=1024):
+        out = np.zeros(size)
+        n = self.lib.ref2_amp_obs(C.c_void_p(self.h), _d(_arr(prev_pose)), _d(_arr(prev_vel)), int(bool(local_root)), C.c_double(ground_h), _d(out))
+        return out[:n].copy()
+
+    def task_scene(self, kind, par):
+        out = np.zeros(8)
+        n = self.lib.ref2_task_scene(C.c_void_p(self.h), int(kind), _d(_arr(par)), _d(out))
+        return float(out[0]), out[1:1 + n].copy()

@@ -63,6 +63,56 @@ def test_oracle_vs_ref_golden(oracle_built, name):
         assert abs(r - float(_G(name, "reward")[e])) < 1e-12
 
 
+def test_oracle_amp_obs_vs_ref_golden(oracle_built):
+    """the oracle's agent observation vs cSceneImitateAMP::BuildAMPObs as compiled (golden `amp_obs`: pose / vel of the state, history one
+    control period back on the clip)"""
+    for name in SCENES:
+        t = model.load_asset(name); t.cfg.scene_amp = True; t.cfg.enable_amp_obs_local_root = False
+        o = Oracle(t)
+        for e in range(_G(name, "pose").shape[0]):
+            o.reset(0.0); o.set_sim_state(_G(name, "pose")[e], _G(name, "vel")[e]); o.set_prev_state(_G(name, "amp_prev_pose")[e], _G(name, "amp_prev_vel")[e])
+            a = o.amp_obs_agent()
+            assert a.shape == _G(name, "amp_obs")[e].shape and np.abs(a - _G(name, "amp_obs")[e]).max() < 1e-12 * max(1.0, np.abs(a).max())
+
+
+def _task_device_check(lib_path, precision, tol_r, tol_g):
+    """cSceneTargetAMP / cSceneHeadingAMP CalcReward + RecordGoal as compiled from the reference (golden `task/...`) vs the device path:
+    state, clocks and the goal row are set through the C-ABI, the answers come from dm_query / dm_query_goal."""
+    from deepmimic_amd.core import BatchEnv
+    g = pc.ref_golden()
+    worst = {}
+    for name in ("amp_target_zombie", "amp_heading_zombie"):
+        t = model.load_asset(name)
+        P, V, par = g["task/%s/pose" % name], g["task/%s/vel" % name], g["task/%s/par" % name]
+        n = P.shape[0]
+        env = BatchEnv(t, n, precision=precision, lib_path=lib_path, wave_packing=1)
+        env.reset(kin_times=np.zeros(n), max_times=np.inf)
+        clocks = np.stack([np.zeros(n), par[:, 14], np.zeros(n), np.zeros(n), np.full(n, np.inf)], axis=1)
+        flags = np.tile(np.array([[1, 0, 1, 1]], dtype=np.int32), (n, 1))
+        st = env.get_state()
+        env.set_state(pose=P, vel=V, tar=st["tar"], kin=st["kin"], clocks=clocks, flags=flags)
+        gs = env.get_goal_state()
+        gs[:, 0:3] = par[:, 0:3]; gs[:, 3] = par[:, 8]; gs[:, 4] = par[:, 3]; gs[:, 5] = 0.0; gs[:, 6] = 1e9
+        gs[:, 7:10] = par[:, 11:14]; gs[:, 10] = par[:, 10]
+        env.set_goal_state(gs)
+        q = env.query(); goals = env.query_goal()
+        dr = np.abs(q["reward"] - g["task/%s/reward" % name]).max(); dg = np.abs(goals - g["task/%s/goal" % name]).max()
+        worst[name] = (float(dr), float(dg))
+        assert dr < tol_r and dg < tol_g, (name, dr, dg)
+        assert (g["task/%s/reward" % name] > 0).sum() >= n // 2       # informative: most cases carry a nonzero task reward
+    return worst
+
+
+def test_emulated_device_task_scenes_vs_ref_golden(emu_lib):
+    print(_task_device_check(emu_lib, 64, 1e-6, 1e-6))        # rewards / goals cross the boundary as float32
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prec,tol", [(64, 1e-6), (32, 2e-5)])
+def test_hip_task_scenes_vs_ref_golden(hip_lib, prec, tol):
+    print(_task_device_check(hip_lib, prec, tol, tol))
+
+
 def test_oracle_math_vs_ref_golden(oracle_built):
     import ref_lib
     orc = ref_lib.Components("orc")

@@ -151,3 +151,52 @@ def test_reward_routine(ref, char, asset):
         worst = max(worst, abs(r_ref - r_o))
         assert abs(r_ref - r_o) < 1e-12, (asset, i, r_ref, r_o)
     print("%s: worst |CalcRewardImitate - oracle| = %.2e" % (asset, worst))
+
+
+@pytest.mark.parametrize("local_root", [False, True])
+def test_amp_obs_routine(ref, local_root):
+    """cSceneImitateAMP::RecordAMPObsAgent -> BuildAMPObs (scenes/SceneImitateAMP.cpp:101-113,279-396) as compiled, both
+    enable_amp_obs_local_root modes, vs the oracle's agent observation through a rollout (history = state at the last action latch)."""
+    import parity_common as pc
+    t = model.load_asset("humanoid3d_walk"); t.cfg.scene_amp = True; t.cfg.enable_amp_obs_local_root = local_root
+    rig = RefRig(ref, "humanoid3d"); o = Oracle(t)
+    rng = np.random.default_rng(36)
+    for i in range(40):
+        o.reset(rng.uniform(0, o.duration))
+        for _ in range(int(rng.integers(1, 4))):
+            kp, _, _ = o.kin_state(); o.set_action(o.pose_to_action(kp) + 0.2 * rng.normal(size=o.A)); o.control_step(20, pc.DT, end_early=False)
+        p, v = o.sim_state(); pp, pv = o.prev_state()
+        rig.set_state(p, v)
+        a_r, a_o = rig.amp_obs(pp, pv, local_root), o.amp_obs_agent()
+        assert a_r.shape == a_o.shape == (226,)
+        _close(a_r, a_o, 1e-12, "AMP observation %d" % i)
+
+
+@pytest.mark.parametrize("name,kind", [("amp_target_zombie", 1), ("amp_heading_zombie", 2)])
+def test_task_scene_routines(ref, name, kind):
+    """cSceneTargetAMP / cSceneHeadingAMP CalcReward and RecordGoal (scenes/SceneTargetAMP.cpp:3-81,192-218; SceneHeadingAMP.cpp:3-43,
+    134-149) as compiled, vs the oracle's task reward and goal vector at action boundaries of a closed-loop rollout (targets, headings and
+    speeds drawn by the oracle's goal generator)."""
+    import parity_common as pc
+    t = model.load_asset(name); c = t.cfg
+    rig = RefRig(ref, "humanoid3d"); o = Oracle(t)
+    rng = np.random.default_rng(37)
+    n = 0
+    for ep in range(12):
+        o.goal_rng(9, ep, 0); t0 = rng.uniform(0, 1.0); o.reset_ex(t0, np.inf, 0, rng.uniform(-3, 3))
+        for k in range(8):
+            o.set_action(0.3 * rng.normal(size=o.A)); o.control_step(20, pc.DT, end_early=False)
+            if o.check_terminate() != 0:
+                break
+            gs = o.goal_state(); p, v = o.sim_state()
+            rig.set_state(p, v)
+            ctrl_time = gs[10] + 19 * pc.DT          # cDeepMimicCharController::GetTime() at the boundary: 19 updates after the latch
+            par = [gs[0], gs[1], gs[2], gs[4], c.target_succ_dist, c.tar_fail_dist if np.isfinite(c.tar_fail_dist) else 1e30, float(c.enable_min_tar_vel), c.pos_reward_scale,
+                   gs[3], c.vel_reward_scale, gs[10], gs[7], gs[8], gs[9], ctrl_time, 0.0]
+            r_ref, g_ref = rig.task_scene(kind, par)
+            assert abs(r_ref - o.calc_reward()) < 1e-12, (name, ep, k, r_ref, o.calc_reward())
+            _close(g_ref, o.record_goal(), 1e-12, "%s goal %d/%d" % (name, ep, k))
+            n += 1
+    assert n >= 40
+    par[15] = 1.0                                     # a fallen character: task reward 0 (SceneTargetAMP.cpp:22-24, SceneHeadingAMP.cpp:11-13)
+    assert rig.task_scene(kind, par)[0] == 0.0

@@ -21,7 +21,7 @@ DM_DEVICE_PTRS, DM_AUTO_RESET, DM_OPEN_LOOP, DM_NO_EMIT, DM_END_EPISODE_EARLY = 
 
 class _CreateInfo(C.Structure):
     _fields_ = [("num_envs", C.c_int), ("device_id", C.c_int), ("seed", C.c_uint64), ("precision", C.c_int),
-                ("max_contacts", C.c_int), ("env_id_offset", C.c_int), ("wave_packing", C.c_int)]
+                ("max_contacts", C.c_int), ("env_id_offset", C.c_int), ("wave_packing", C.c_int), ("physics", C.c_int)]
 
 
 class _SceneTables(C.Structure):
@@ -53,7 +53,7 @@ class _SceneTables(C.Structure):
     ]
 
 
-ABI_VERSION = 3        # include/dm_hip.h DM_ABI_VERSION
+ABI_VERSION = 4        # include/dm_hip.h DM_ABI_VERSION
 _libs = {}
 
 
@@ -102,7 +102,7 @@ class BatchEnv:
     def __init__(self, tables: SceneTables, num_envs: int = 1, device_id: int = 0, seed: int = 0,
                  precision: int = 32, max_contacts: int = 20, env_id_offset: int = 0,
                  test_mode: bool = False, lib_path: Optional[str] = None, wave_packing: int = 0, self_collision: bool = True,
-                 erp: float = 0.0):
+                 erp: float = 0.0, physics: int = 1):
         self.lib = load_library(lib_path)
         self.tables = tables
         c = tables.cfg
@@ -175,7 +175,7 @@ class BatchEnv:
             raise ValueError("unsupported timer type %r (util/Timer.cpp:27-45: uniform | exp)" % c.timer_type)
         self._timer = (c.timer_type, tmin, tmax, float(c.time_lim_exp)); self._timer_pinned = tmin == tmax
         self._seed, self._env_off = int(seed) & (2 ** 64 - 1), int(env_id_offset)
-        info = _CreateInfo(int(num_envs), int(device_id), int(seed) & (2 ** 64 - 1), int(precision), int(max_contacts), int(env_id_offset), int(wave_packing))
+        info = _CreateInfo(int(num_envs), int(device_id), int(seed) & (2 ** 64 - 1), int(precision), int(max_contacts), int(env_id_offset), int(wave_packing), int(physics))
         self.h = C.c_void_p()
         self._chk(self.lib.dm_create(C.byref(info), C.byref(st), C.byref(self.h)))
         dims = np.zeros(8, dtype=np.int32)
@@ -183,6 +183,9 @@ class BatchEnv:
         self.S, self.G, self.A, self.P, self.J, self.D, self.F, self.N = [int(x) for x in dims]
         self.duration = float(self.lib.dm_motion_duration(self.h))
         self.precision = precision
+        pinfo = np.zeros(2, dtype=np.int32)
+        self._chk(self.lib.dm_physics_info(self.h, _ip(pinfo)))
+        self.physics, self.max_contacts = int(pinfo[0]), int(pinfo[1])      # DM-physics version; effective contact cap per character
         self.amp_size = int(self.lib.dm_amp_obs_size(self.h))      # GetAMPObsSize; 0 unless `--scene imitate_amp`
         self.num_clips = int(tables.num_clips); self.has_obj = tables.goal_kind == 5
 

@@ -984,6 +984,106 @@ struct EnvSim {
         st3(ct, x); st3(ct + 3, n); ct[6] = dist; ct[7] = (Real)(la | (lb << 8));
     }
 
+    // ---- DM-physics v2: link-vs-ground contacts through one persistent manifold per link ([EXT-BULLET, recalled] btPersistentManifold::
+    // refreshContactPoints, btConvexPlaneCollisionAlgorithm::collideSingleContact, getCacheEntry / sortCachedPoints; restated in
+    // oracle/orc_scene.h manifold_update).  lane = link; the manifolds live in HBM (EnvState::manif, L2-resident for the 40 substeps of
+    // a call) -- v2 is the parity mode, not the fast path.  Returns the number of ground contact slots written (in (link, slot) order).
+    DM_DEV int ground_manifolds(Real* manif) {
+        const int J = m.J;
+        int cnt = 0; Real lp[4][3], bxz[4][2], dist[4];
+        Real* mfp = manif + (l < J ? l : 0) * MF_STRIDE;
+        const bool has_body = l < J && s.mdl.thresh[l < J ? l : 0] > (Real)0;
+        // every lane evaluates its candidate points first (lane = candidate): distance into cdistc for the links' argmin below
+#pragma unroll
+        for (int q = 0; q < CPL; ++q) {
+            const int c = l + kWave * q;
+            if (c < m.NC) {
+                const int link = cand_link[q];
+                v3 x = ld3(s.com[link]) + ldm3(Rbp(link)) * mk3(cand_loc[q][0], cand_loc[q][1], cand_loc[q][2]);
+                s.cdistc[c] = x.y - cand_rad[q];
+            }
+        }
+        sync();
+        if (has_body) {
+            const Real thr = s.mdl.thresh[l];
+            const v3 com = ld3(s.com[l]); const m3 Rb = ldm3(Rbp(l));
+            cnt = (int)mfp[0];
+            for (int i = 0; i < 4; ++i) { for (int k = 0; k < 3; ++k) lp[i][k] = mfp[1 + i * MF_PT + k]; bxz[i][0] = mfp[1 + i * MF_PT + 3]; bxz[i][1] = mfp[1 + i * MF_PT + 4]; dist[i] = mfp[1 + i * MF_PT + 5]; }
+            // refresh, last to first (a dropped point's successors move down, as std::vector::erase does in the oracle)
+            for (int i = cnt - 1; i >= 0; --i) {
+                const v3 xa = com + Rb * mk3(lp[i][0], lp[i][1], lp[i][2]);
+                dist[i] = xa.y;
+                const Real dx = bxz[i][0] - xa.x, dz = bxz[i][1] - xa.z;
+                if (!(dist[i] <= thr) || dx * dx + dz * dz > thr * thr) {
+                    for (int k = i; k + 1 < cnt; ++k) { for (int a = 0; a < 3; ++a) lp[k][a] = lp[k + 1][a]; bxz[k][0] = bxz[k + 1][0]; bxz[k][1] = bxz[k + 1][1]; dist[k] = dist[k + 1]; }
+                    --cnt;
+                }
+            }
+            // the new point: the deepest candidate of this link (its support point along -n), first on ties
+            int best = -1; Real bd = 0;
+            for (int c = 0; c < m.NC; ++c) if (m.cand_link[c] == l) { const Real d = s.cdistc[c]; if (best < 0 || d < bd) { best = c; bd = d; } }
+            if (best >= 0 && bd < thr) {
+                v3 x = com + Rb * mk3(m.cand_loc[best * 3], m.cand_loc[best * 3 + 1], m.cand_loc[best * 3 + 2]);
+                x.y -= m.cand_rad[best];
+                const v3 d0 = x - com;
+                const v3 nl = mk3(Rb.m[0] * d0.x + Rb.m[3] * d0.y + Rb.m[6] * d0.z, Rb.m[1] * d0.x + Rb.m[4] * d0.y + Rb.m[7] * d0.z, Rb.m[2] * d0.x + Rb.m[5] * d0.y + Rb.m[8] * d0.z);   // Rb^T (x - com)
+                int slot = -1; Real shortest = thr * thr;
+                for (int i = 0; i < cnt; ++i) { const Real ex = lp[i][0] - nl.x, ey = lp[i][1] - nl.y, ez = lp[i][2] - nl.z, d2 = ex * ex + ey * ey + ez * ez; if (d2 < shortest) { shortest = d2; slot = i; } }
+                if (slot < 0) {
+                    if (cnt < 4) slot = cnt++;
+                    else {      // sortCachedPoints: never the deepest; of the others the one that leaves the largest quadrilateral
+                        int deepest = -1; Real maxpen = x.y;
+                        for (int i = 0; i < 4; ++i) if (dist[i] < maxpen) { deepest = i; maxpen = dist[i]; }
+                        Real res[4] = { 0, 0, 0, 0 };
+                        const v3 p0 = mk3(lp[0][0], lp[0][1], lp[0][2]), p1 = mk3(lp[1][0], lp[1][1], lp[1][2]), p2 = mk3(lp[2][0], lp[2][1], lp[2][2]), p3 = mk3(lp[3][0], lp[3][1], lp[3][2]);
+                        if (deepest != 0) { const v3 c = cross(nl - p1, p3 - p2); res[0] = dot(c, c); }
+                        if (deepest != 1) { const v3 c = cross(nl - p0, p3 - p2); res[1] = dot(c, c); }
+                        if (deepest != 2) { const v3 c = cross(nl - p0, p3 - p1); res[2] = dot(c, c); }
+                        if (deepest != 3) { const v3 c = cross(nl - p0, p2 - p1); res[3] = dot(c, c); }
+                        slot = 0;
+                        for (int i = 1; i < 4; ++i) if (res[i] > res[slot]) slot = i;
+                    }
+                }
+                lp[slot][0] = nl.x; lp[slot][1] = nl.y; lp[slot][2] = nl.z; bxz[slot][0] = x.x; bxz[slot][1] = x.z; dist[slot] = x.y;
+            }
+            mfp[0] = (Real)cnt;
+            for (int i = 0; i < 4; ++i) { for (int k = 0; k < 3; ++k) mfp[1 + i * MF_PT + k] = lp[i][k]; mfp[1 + i * MF_PT + 3] = bxz[i][0]; mfp[1 + i * MF_PT + 4] = bxz[i][1]; mfp[1 + i * MF_PT + 5] = dist[i]; }
+            for (int i = 0; i < cnt; ++i) if (dist[i] <= m.report_dist) dm_atomic_or(&s.flg[FLG_CONTACT], 1 << l);
+        }
+        // cap at max_contacts, deepest first (ties: (link, slot) order), as v1 does for its candidates
+        sync();
+        bool keep[4] = { false, false, false, false };
+        for (int i = 0; i < 4; ++i) keep[i] = i < cnt;
+        int total = 0;
+        uint64_t km[4];
+        for (int i = 0; i < 4; ++i) { km[i] = wave_ballot(keep[i]); total += dm_popc64(km[i]); }
+        if (total > m.max_contacts) {
+            for (int i = 0; i < 4; ++i) if (l < J) { s.csel[l * 4 + i] = keep[i] ? 1 : 0; s.cdistc[l * 4 + i] = dist[i]; }
+            sync();
+            for (int i = 0; i < 4; ++i) {
+                int rank = 0;
+                if (keep[i]) for (int k = 0; k < 4 * J; ++k) if (s.csel[k] && (s.cdistc[k] < dist[i] || (s.cdistc[k] == dist[i] && k < l * 4 + i))) ++rank;
+                keep[i] = keep[i] && rank < m.max_contacts;
+            }
+            sync();
+            total = 0;
+            for (int i = 0; i < 4; ++i) { km[i] = wave_ballot(keep[i]); total += dm_popc64(km[i]); }
+        }
+        // slots in (link, slot) order
+        const uint64_t ltm = (l == 0) ? 0ull : (~0ull >> (64 - l));
+        int base = 0;
+        for (int i = 0; i < 4; ++i) base += dm_popc64(km[i] & ltm);
+        if (l < J) {
+            const v3 com = ld3(s.com[l]); const m3 Rb = ldm3(Rbp(l));
+            int k = 0;
+            for (int i = 0; i < 4; ++i) if (keep[i]) { store_contact(base + k, com + Rb * mk3(lp[i][0], lp[i][1], lp[i][2]), mk3((Real)0, (Real)1, (Real)0), dist[i], l, 255); ++k; }
+        }
+        return total;
+    }
+    // a reset (and the state setter) starts every manifold empty: cWorld::Reset clears the broadphase pair cache (sim/World.cpp:81-90)
+    DM_DEV void manif_clear(const EnvState<Real>& st, int e) {
+        if (st.manif && l < m.J) st.manif[((size_t)e * m.J + l) * MF_STRIDE] = (Real)0;
+    }
     // integrate positions with the new velocity (semi-implicit Euler, exponential map on rotations); lane = link
     DM_DEV void integrate(Real h) {
         if (l < m.J) {
@@ -999,7 +1099,8 @@ struct EnvSim {
         }
     }
     // s.rhs holds qddot of the unconstrained dynamics; s.L the Cholesky factor of H.
-    DM_DEV void substep_post(Real h, DebugTaps<Real> dbg, int e, Real* aovf) {
+    template <bool V2 = false>
+    DM_DEV void substep_post(Real h, DebugTaps<Real> dbg, int e, Real* aovf, Real* manif = nullptr) {
         const int D = m.D, J = m.J;
         Real vstar = 0; int vidx = 0;
         if (l < D) { vidx = DM_DI_VIDX(s.mdl.dof_info[l]); vstar = clamp_vel(s.vel[vidx] + h * s.rhs[l], l); s.dofrec[l][6] = vstar; }
@@ -1015,6 +1116,11 @@ struct EnvSim {
             bvs = (Real)exp((double)h * m.ball_ln_lin) * ld3(ob + (C::OBJ ? OB_VX : 0)) + h * mk3(m.gravity[0], m.gravity[1], m.gravity[2]);
             bws = (Real)exp((double)h * m.ball_ln_ang) * ld3(ob + (C::OBJ ? OB_WX : 0));
         }
+        // ---- collision detection
+        const bool phys2 = V2 && manif != nullptr;
+        int nc_ground = 0;
+        if (phys2) nc_ground = ground_manifolds(manif);
+        else {
         // ---- collision detection: lane = candidate point (CPL candidates per lane when NC > 64)
         bool active[CPL]; Real dist[CPL]; v3 cxp[CPL]; uint64_t amask[CPL];
         int nact = 0;
@@ -1061,7 +1167,10 @@ struct EnvSim {
                 base += dm_popc64(amask[q]);
             }
         }
-        int nc = nact;
+        nc_ground = nact;
+        }
+        const uint64_t lt = (l == 0) ? 0ull : (~0ull >> (64 - l));
+        int nc = V2 ? lane_bcast(nc_ground, 0) : nc_ground;       // (wave-uniform by construction; in the V2 instantiations the read-lane tells the compiler)
         // ---- self collision: lane = link pair; active pairs take the slots the ground left, in pair order
         if constexpr (C::BROAD) {
             // bounding-sphere cull first (a capsule is symmetric about its link's COM): the pairs that survive it -- a handful of the dog's
@@ -1146,6 +1255,7 @@ struct EnvSim {
                 nc = dm_min(m.max_contacts, nc + dm_popc64(mk));
             }
         }
+        if (V2) nc = lane_bcast(nc, 0);       // (still wave-uniform: every term came from a ballot)
         const int NL = m.NL;
         const int R = NL + 3 * nc;
         if (l == 0) { s.flg[FLG_NROWS] = R; s.flg[FLG_NCONT] = nc; }
@@ -1160,11 +1270,12 @@ struct EnvSim {
         int ball_sg = 0; v3 ball_cx = zero3();
         if (l < R) {
             if (l < NL) {
-                int j = s.mdl.lim_joint[l]; int lj = s.mdl.link_info[j]; int off = DM_LI_POFF(lj);
+                const int lr = phys2 ? (l >> 1) : l;        // v2: both rows of a limit (q - lo, then hi - q), v1: the nearer bound
+                int j = s.mdl.lim_joint[lr]; int lj = s.mdl.link_info[j]; int off = DM_LI_POFF(lj);
                 const int limdof = DM_LI_DOFF(lj);
-                Real th = s.pose[off], pen_lo = th - s.mdl.lim_lo[l], pen_hi = s.mdl.lim_hi[l] - th;
+                Real th = s.pose[off], pen_lo = th - s.mdl.lim_lo[lr], pen_hi = s.mdl.lim_hi[lr] - th;
                 Real pen, sgn;
-                if (pen_lo <= pen_hi) { sgn = 1; pen = pen_lo; } else { sgn = -1; pen = pen_hi; }
+                if (phys2 ? !(l & 1) : (pen_lo <= pen_hi)) { sgn = 1; pen = pen_lo; } else { sgn = -1; pen = pen_hi; }
                 b = (pen > 0) ? -pen / h : -m.erp * pen / h;
                 xd = sgn * ld3(&s.dofrec[limdof][0]);
                 if (limdof < 32) ch_lo = 1u << limdof; else ch_hi = 1u << (limdof - 32);
@@ -1520,8 +1631,8 @@ struct EnvSim {
     // dynamics / Cholesky code (the instruction stream of the 20-update loop must fit the instruction cache).
     // reuse_kin: pose / vel are unchanged since the previous phase's kinematics (stable-PD solve -> first substep); only
     // the base acceleration differs, and it enters every joint-origin acceleration as the same additive constant.
-    template <bool PERT = false>
-    DM_DEV void dyn_phase(int ph, Real dt, Real h, DebugTaps<Real> dbg, int e, bool tap_only, bool reuse_kin, Real* aovf, const double* pert = nullptr) {
+    template <bool PERT = false, bool V2 = PERT>
+    DM_DEV void dyn_phase(int ph, Real dt, Real h, DebugTaps<Real> dbg, int e, bool tap_only, bool reuse_kin, Real* aovf, const double* pert = nullptr, Real* manif = nullptr) {
         // lane id / link word are re-materialised per phase: keeps the optimizer from hoisting every per-lane LDS address
         // out of the 20-update loop (dozens of long-lived VGPRs that end up in scratch)
         DM_OPAQUE_V(l); DM_OPAQUE_V(li);
@@ -1555,15 +1666,15 @@ struct EnvSim {
         if constexpr (C::TREE) tree_solve(s.rhs); else chol_solve(s.rhs);
         DM_OPAQUE_V(l); DM_OPAQUE_V(li);
         if (ph == 0) { mark(3); spd_post(dt); }
-        else substep_post(h, dbg, e, aovf);
+        else substep_post<V2>(h, dbg, e, aovf, manif);
     }
     template <bool PERT = false>
-    DM_DEV void update(double dt, DebugTaps<Real> dbg, int e, Real* aovf, double* pert = nullptr) {
+    DM_DEV void update(double dt, DebugTaps<Real> dbg, int e, Real* aovf, double* pert = nullptr, Real* manif = nullptr) {
         if (l == 0) { s.clk[CLK_TIMER] += dt; s.clk[CLK_CTRL] += dt; s.flg[FLG_NEED_ACTION] = 0; }
         if (PERT && pert) { if (l == 0) pert_tick(pert, e, dt); sync(); }
         kin_update(dt);
         const Real h = (Real)(dt / m.num_sim_substeps);
-        for (int ph = 0; ph <= m.num_sim_substeps; ++ph) dyn_phase<PERT>(ph, (Real)dt, h, dbg, e, false, ph == 1, aovf, pert);
+        for (int ph = 0; ph <= m.num_sim_substeps; ++ph) dyn_phase<PERT>(ph, (Real)dt, h, dbg, e, false, ph == 1, aovf, pert, manif);
         if (l == 0) {                      // cCtController::CheckNeedNewAction (CtController.cpp:221-227)
             double cur = s.clk[CLK_CTRL] + s.clk[CLK_INIT_OFF], pad = 0.001 * dt;
             int c1 = (int)floor((cur + pad) / m.query_period), c0 = (int)floor((cur + pad - dt) / m.query_period);
@@ -2326,6 +2437,7 @@ DM_DEV void reset_goal_env(EnvSim<Real, C, TAPS, LW>& sim, const ModelDev<Real>&
     EnvSim<Real, C, TAPS, LW> rs(mc, lds, sim.l);
     rs.li = sim.li;
     rs.reset_env(kt, max_time, yaw);
+    sim.manif_clear(st, e);
     if (st.hist) rs.init_hist(st, e);
     if (act && sim.l == 0) st.goal[(size_t)e * GS_WIDTH + GS_CLIP] = (double)clip;
     if (m.scene_goal) sim.goal_reset(st, e);
@@ -2361,11 +2473,12 @@ __global__ void __launch_bounds__(64) DM_WAVES_PER_EU((StepWaves<Real, C>::value
     Real* aovf = st.aovf ? st.aovf + (size_t)e * (kMaxRows - C::RREG) * kWave : nullptr;
     const bool goal = HIST && st.goal && m.scene_goal;
     double* pert = (HIST && st.pert) ? st.pert + (size_t)e * PT_WIDTH : nullptr;      // enable_rand_perturbs
+    Real* manif = (HIST && st.manif) ? st.manif + (size_t)e * m.J * MF_STRIDE : nullptr;   // physics 2
     if (goal) sim.goal_sync_flags(st, e);
     for (int u = 0; u < io.n_updates; ++u) {
         if (HIST && st.hist) sim.latch_hist(st, e);
         if (goal) sim.goal_latch(st, e, io.dt);
-        sim.template update<HIST>(io.dt, dbg, e, aovf, pert);
+        sim.template update<HIST>(io.dt, dbg, e, aovf, pert, manif);
         if (goal) sim.goal_update(st, e, io.dt);
         if (io.end_early && lds.flg[FLG_OVER]) break;           // wave-uniform: latched by lane 0 at the end of update()
     }
@@ -2390,6 +2503,7 @@ __global__ void __launch_bounds__(64) DM_WAVES_PER_EU((StepWaves<Real, C>::value
             else {
                 double kt = m.duration * dm_rand01(m.seed, (uint64_t)(e + m.env_off), ep, 0);
                 sim.reset_env(kt, mt);
+                if (HIST) sim.manif_clear(st, e);
                 if (HIST && st.hist) sim.init_hist(st, e);
             }
             if (HIST && pert && !rec && l == 0) sim.pert_reset(pert, e);      // ResetScene -> ResetRandPertrub; a recovery episode only resets the timers
@@ -2420,6 +2534,7 @@ __global__ void __launch_bounds__(64) k_env_reset(ModelDev<Real> m, EnvState<Rea
     } else {
         double kt = kin_times ? kin_times[b] : m.duration * dm_rand01(m.seed, (uint64_t)(e + m.env_off), ep, 0);
         sim.reset_env(kt, mt);
+        sim.manif_clear(st, e);
         if (st.hist) sim.init_hist(st, e);
     }
     if (st.pert && !rec && l == 0) sim.pert_reset(st.pert + (size_t)e * PT_WIDTH, e);
@@ -2463,7 +2578,8 @@ __global__ void __launch_bounds__(64) k_env_probe(ModelDev<Real> m, EnvState<Rea
     EnvSim<Real, C> sim(m, lds, l);
     sim.load(st, e);
     // what: 0 SPD torque, 1 one substep of length dt with the latched torque, 2 SPD-model mass matrix / bias force taps only
-    sim.dyn_phase(what == 1 ? 1 : 0, (Real)dt, (Real)dt, dbg, e, what == 2, false, st.aovf ? st.aovf + (size_t)e * (kMaxRows - C::RREG) * kWave : nullptr);
+    sim.template dyn_phase<false, true>(what == 1 ? 1 : 0, (Real)dt, (Real)dt, dbg, e, what == 2, false, st.aovf ? st.aovf + (size_t)e * (kMaxRows - C::RREG) * kWave : nullptr,
+                                 nullptr, st.manif ? st.manif + (size_t)e * m.J * MF_STRIDE : nullptr);
     sim.store(st, e);
 }
 

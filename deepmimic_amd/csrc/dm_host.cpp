@@ -285,7 +285,7 @@ struct CtxBase {
     rt_stream own_stream = 0, stream = 0;
     std::vector<void*> allocs;
     float *d_actions = nullptr, *d_states = nullptr, *d_rewards = nullptr; int *d_term = nullptr, *d_valid = nullptr, *d_end = nullptr;
-    bool duo = false, upload_failed = false;
+    bool duo = false, upload_failed = false; int physics = 1;
     virtual ~CtxBase() { for (void* p : allocs) rt_free(p); }
     void* dalloc(size_t n) { void* p = nullptr; if (rt_malloc(&p, n) != 0) return nullptr; allocs.push_back(p); return p; }
     virtual int setup() = 0;
@@ -362,7 +362,13 @@ struct CtxT : CtxBase {
         md.J = h.J; md.P = h.P; md.D = h.D; md.A = h.A; md.S = h.S; md.F = h.F; md.NC = h.NC; md.NL = h.NL; md.max_depth = h.max_depth;
         bool any_rot = false;
         for (int j = 0; j < h.J; ++j) if (!h.arot_ident[j] || !h.brot_ident[j]) any_rot = true;
-        if (h.NL > kMaxLim) return fail("more than 4 joint-limit rows");
+        if (h.NL > kMaxLim) return fail("more than 4 revolute joints with limits");
+        md.physics = physics; md.NLJ = h.NL;
+        if (physics == 2) {
+            // both unilateral rows of every limit; the row budget (kMaxRows = 64 = limits + 3 per contact) then caps the contacts lower
+            md.NL = 2 * h.NL;
+            if (max_contacts > (kMaxRows - md.NL) / 3) max_contacts = (kMaxRows - md.NL) / 3;
+        }
         if (h.J <= ClsBiped::NJ && h.D <= ClsBiped::ND && h.P <= ClsBiped::NP && h.NC <= ClsBiped::NCAP && !any_rot) cls = 0;
         else if (h.J <= ClsLarge::NJ && h.D <= ClsLarge::ND && h.P <= ClsLarge::NP && h.NC <= ClsLarge::NCAP) cls = 1;
         else return fail("character too large for the compiled kernel classes (J<=23, D<=64, P<=83, <=128 contact candidates)");
@@ -413,6 +419,12 @@ struct CtxT : CtxBase {
             md.ball_friction = (Real)c.ball_friction; md.ball_thresh = (Real)(0.02 * r);
             md.ball_ln_lin = log(1.0 - c.ball_lin_damping); md.ball_ln_ang = log(1.0 - c.ball_ang_damping);
             md.obj_time_min = c.rand_tar_obj_time_min; md.obj_time_max = c.rand_tar_obj_time_max; md.min_tar_obj_dist = c.min_tar_obj_dist; md.max_tar_obj_dist = c.max_tar_obj_dist;
+        }
+        st.manif = nullptr;
+        if (physics == 2) {
+            st.manif = (Real*)dalloc(sizeof(Real) * (size_t)N * h.J * MF_STRIDE);
+            if (!st.manif) return fail("device allocation failed");
+            rt_memset(st.manif, 0, sizeof(Real) * (size_t)N * h.J * MF_STRIDE, stream);
         }
         st.hist = nullptr;
         md.scene_amp = c.scene_amp ? 1 : 0; md.amp_local_root = c.enable_amp_obs_local_root ? 1 : 0;
@@ -507,7 +519,7 @@ struct CtxT : CtxBase {
         io.actions = actions_dev; io.states = states; io.rewards = rewards; io.terminate = term; io.valid = valid; io.episode_end = end;
         io.n_updates = n_updates; io.dt = dt; io.auto_reset = (flags & DM_AUTO_RESET) ? 1 : 0; io.emit = (flags & DM_NO_EMIT) ? 0 : 1; io.open_loop = (flags & DM_OPEN_LOOP) ? 1 : 0; io.end_early = (flags & DM_END_EPISODE_EARLY) ? 1 : 0;
         // two characters per wavefront: biped class, even batch, no debug taps armed (DM_DUO=0 keeps one character per wave)
-        if (duo && cls == 0 && hm.D == ClsBiped::ND && (N % 2) == 0 && !dbg.H) {      // (31 row lanes per character assume exactly 34 dofs)
+        if (duo && cls == 0 && hm.D == ClsBiped::ND && (N % 2) == 0 && !dbg.H && !st.manif) {      // (31 row lanes per character assume exactly 34 dofs; physics 2 runs one per wave)
             if (st.hist || st.pert) launch_step_duo<Real, SV_AMP>(N / 2, stream, md, st, io, dbg);      // (the AMP instantiation also carries the perturbation code)
             else launch_step_duo<Real, SV_PLAIN>(N / 2, stream, md, st, io, dbg);
             return 0;
@@ -516,11 +528,11 @@ struct CtxT : CtxBase {
         if (cls == 2) { if (dbg.H) launch_step<Real, ClsBipedObj, SV_TAPS>(N, stream, md, st, io, dbg); else launch_step<Real, ClsBipedObj, SV_AMP>(N, stream, md, st, io, dbg); }
         else if (cls == 3) {
             if (dbg.H) launch_step<Real, ClsLargeTree, SV_TAPS>(N, stream, md, st, io, dbg);
-            else if (st.hist || st.pert) launch_step<Real, ClsLargeTree, SV_AMP>(N, stream, md, st, io, dbg);
+            else if (st.hist || st.pert || st.manif) launch_step<Real, ClsLargeTree, SV_AMP>(N, stream, md, st, io, dbg);
             else launch_step<Real, ClsLargeTree, SV_PLAIN>(N, stream, md, st, io, dbg);
         }
         else if (dbg.H) { if (cls == 0) launch_step<Real, ClsBiped, SV_TAPS>(N, stream, md, st, io, dbg); else launch_step<Real, ClsLarge, SV_TAPS>(N, stream, md, st, io, dbg); }
-        else if (st.hist || st.pert) { if (cls == 0) launch_step<Real, ClsBiped, SV_AMP>(N, stream, md, st, io, dbg); else launch_step<Real, ClsLarge, SV_AMP>(N, stream, md, st, io, dbg); }
+        else if (st.hist || st.pert || st.manif) { if (cls == 0) launch_step<Real, ClsBiped, SV_AMP>(N, stream, md, st, io, dbg); else launch_step<Real, ClsLarge, SV_AMP>(N, stream, md, st, io, dbg); }
         else { if (cls == 0) launch_step<Real, ClsBiped, SV_PLAIN>(N, stream, md, st, io, dbg); else launch_step<Real, ClsLarge, SV_PLAIN>(N, stream, md, st, io, dbg); }
         return 0;
     }
@@ -597,7 +609,7 @@ struct CtxT : CtxBase {
             io.states = d_states; io.rewards = d_rewards; io.terminate = d_term; io.valid = d_valid; io.episode_end = d_end;
             io.n_updates = 20; io.dt = dt; io.auto_reset = 1; io.emit = 1; io.open_loop = (what == 3) ? 1 : 0; io.end_early = 1;
             if (what == 4) io.actions = d_actions;
-            if (duo && cls == 0 && hm.D == ClsBiped::ND && (N % 2) == 0) launch_step_duo<Real, SV_TAPS>(N / 2, stream, md, st, io, d2);
+            if (duo && cls == 0 && hm.D == ClsBiped::ND && (N % 2) == 0 && !st.manif) launch_step_duo<Real, SV_TAPS>(N / 2, stream, md, st, io, d2);
             else if (cls == 0) launch_step<Real, ClsBiped, SV_TAPS>(N, stream, md, st, io, d2);
             else if (cls == 2) launch_step<Real, ClsBipedObj, SV_TAPS>(N, stream, md, st, io, d2);
             else if (cls == 3) launch_step<Real, ClsLargeTree, SV_TAPS>(N, stream, md, st, io, d2);
@@ -629,6 +641,7 @@ struct CtxT : CtxBase {
     int set_state(const double* pose, const double* vel, const double* tar, const double* kin, const double* clk, const int* flg) override {
         const size_t n = N; const int P = hm.P;
         if (pose && ul(st.pose, n * P, pose)) return -1;
+        if (pose && st.manif && rt_memset(st.manif, 0, sizeof(Real) * n * hm.J * MF_STRIDE, stream)) return fail("memset failed");      // a new pose starts with empty manifolds (physics 2)
         if (vel && ul(st.vel, n * P, vel)) return -1;
         if (tar && ul(st.tar, n * P, tar)) return -1;
         if (kin) { std::vector<double> t8(n * 8, 0); for (size_t e = 0; e < n; ++e) for (int k = 0; k < 7; ++k) t8[e * 8 + k] = kin[e * 7 + k]; if (ul(st.kin, n * 8, t8.data())) return -1; }
@@ -691,6 +704,9 @@ int dm_create(const dm_create_info* info, const dm_scene_tables* tables, dm_ctx*
     if (tables->num_sim_substeps < 1) return fail("num_sim_substeps must be >= 1");
     int precision = info->precision ? info->precision : 32;
     if (precision != 32 && precision != 64) return fail("precision must be 32 or 64");
+    if (info->physics < 0 || info->physics > 2) return fail("physics must be 0 / 1 (DM-physics v1) or 2 (v2)");
+    if (info->physics == 2 && info->wave_packing == 2) return fail("physics 2 runs one character per wavefront (wave_packing 0 or 1)");
+    if (info->physics == 2 && tables->scene_goal == 5) return fail("physics 2 does not carry the free body of dribble_amp");
     int mc = info->max_contacts > 0 ? info->max_contacts : 20;
     if (mc > 20) return fail("max_contacts must be <= 20");
 #ifndef DM_EMU
@@ -701,6 +717,7 @@ int dm_create(const dm_create_info* info, const dm_scene_tables* tables, dm_ctx*
     DevGuard guard(info->device_id);
     CtxBase* c = (precision == 64) ? (CtxBase*)new CtxT<double>() : (CtxBase*)new CtxT<float>();
     c->device_id = info->device_id; c->N = info->num_envs; c->seed = info->seed; c->precision = precision; c->max_contacts = mc; c->env_off = info->env_id_offset;
+    c->physics = (info->physics == 2) ? 2 : 1;
     if (build_host_model(*tables, mc, c->hm) != 0) { delete c; return -1; }
 #ifndef DM_EMU
     if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) { delete c; return fail("hipStreamCreate failed"); }
@@ -729,6 +746,11 @@ int dm_dims(const dm_ctx* ctx, int32_t* out) {
     if (!ctx || !out) return fail("null argument");
     const HostModel& h = ctx->c->hm;
     out[0] = h.S; out[1] = ctx->c->goal_size; out[2] = h.A; out[3] = h.P; out[4] = h.J; out[5] = h.D; out[6] = h.F; out[7] = ctx->c->N;
+    return 0;
+}
+int dm_physics_info(const dm_ctx* ctx, int32_t* out) {
+    if (!ctx || !out) return fail("null argument");
+    out[0] = ctx->c->physics; out[1] = ctx->c->max_contacts;
     return 0;
 }
 double dm_motion_duration(const dm_ctx* ctx) { return ctx ? ctx->c->hm.duration : 0.0; }

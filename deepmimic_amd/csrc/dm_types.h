@@ -176,6 +176,8 @@ struct ModelDev {
     double time_lim_min, time_lim_max;       // episode timer range (uniform)
     uint64_t seed;
     int env_off;                             // global id of env 0 of this shard (keeps RNG streams partition-invariant)
+    int physics;                             // 1: DM-physics v1, 2: v2 (persistent ground manifolds, both rows of a revolute limit); NL counts ROWS
+    int NLJ;                                 // revolute joints with limits (v1: NL == NLJ, v2: NL == 2 NLJ)
     // ---- `--scene imitate_amp` (scenes/SceneImitateAMP.cpp): reward 0, fall-only termination, AMP observations
     int scene_amp, amp_local_root;
     int amp_pose_size, amp_vel_size;         // per timestep; the observation is [pose_t, pose_t-1, vel_t, vel_t-1]
@@ -237,7 +239,9 @@ struct EnvState {
     Real* obj;       // N x OB_WIDTH  the free body of an OBJ class (dribble_amp's ball); null otherwise
     double* goal;    // N x GS_WIDTH  goal state of the task scenes + the clip the env was reset to; null unless a goal scene / multi-clip dataset
     double* pert;    // N x PT_WIDTH  random-perturbation clock and active forces; null unless enable_rand_perturbs
+    Real* manif;     // N x J x MF_STRIDE  physics 2: per link [count, 4 x (point on the link in body coordinates (3), point on the plane x, z, distance)]; null otherwise
 };
+enum { MF_STRIDE = 32, MF_PT = 6 };
 
 // Per-call I/O of the batched step (device pointers; any may be null)
 template <typename Real>

@@ -19,7 +19,7 @@ extern "C" {
 /* Layout version of this header: bumped whenever dm_create_info / dm_scene_tables gain fields or an entry point changes meaning.  A host checks
  * `dm_abi_version() == DM_ABI_VERSION` (and a binding that mirrors the structs by hand, `dm_struct_sizes`) once after loading the library: the
  * tables are read as the CURRENT layout, a caller built against an older header would hand over a shorter struct. */
-#define DM_ABI_VERSION 3
+#define DM_ABI_VERSION 4
 
 typedef struct dm_ctx dm_ctx;
 
@@ -32,6 +32,11 @@ typedef struct {
     int env_id_offset;       /* global id of env 0 (multi-GPU shards keep global RNG streams) */
     int wave_packing;        /* characters per wavefront of the step kernel: 0 = default (2 where possible; env DM_DUO=0 -> 1), 1, or
                                 2 (biped class, even num_envs; same results up to fp rounding, dm_device_duo.h) */
+    int physics;             /* rigid-body step: 0 / 1 = DM-physics v1 (default: analytic contact set rebuilt every substep, the nearer
+                                row of a revolute limit), 2 = v2 (Bullet's manifold semantics as recalled, SURVEY App. C items 4, 7:
+                                both rows of every revolute limit; one persistent manifold per link against the ground, refreshed and
+                                given ONE new support point per substep, <= 4 points, breaking threshold 0.02 x angular-motion disc).
+                                v2 runs one character per wavefront on the AMP / tap instantiation of the kernels; DESIGN.md 4.6 */
 } dm_create_info;
 
 /* Raw scene tables in the reference's in-memory layout (all host pointers, copied at create time). */
@@ -122,6 +127,8 @@ int dm_create(const dm_create_info* info, const dm_scene_tables* tables, dm_ctx*
 int dm_destroy(dm_ctx* ctx);
 /* GetStateSize / GetGoalSize / GetActionSize (+ pose, links, dofs, frames of clip 0): out[8] = S,G,A,P,J,D,F,N */
 int dm_dims(const dm_ctx* ctx, int32_t* out);
+/* out[0] = physics version the ctx runs (1 or 2), out[1] = effective contact cap per character (physics 2: min(max_contacts, (64 - 2 x limited joints) / 3)) */
+int dm_physics_info(const dm_ctx* ctx, int32_t* out);
 double dm_motion_duration(const dm_ctx* ctx);
 /* Run the kernels of this ctx on an external HIP stream (e.g. torch's current stream); NULL restores the own (non-blocking) stream.
  * The legacy default stream has the NULL handle too: dm_set_stream_default selects IT (torch's default stream when no torch.cuda.Stream is

@@ -30,7 +30,7 @@ enum {
     CFG_TAR_NEAR_DIST, CFG_TAR_FAR_PROB, CFG_TARGET_RADIUS, CFG_HIT_RESET_TIME, CFG_INIT_HIT_PROB, CFG_HIT_TAR_SPEED, CFG_TAR_REWARD_SCALE,
     CFG_TMIN_X, CFG_TMIN_Y, CFG_TMIN_Z, CFG_TMAX_X, CFG_TMAX_Y, CFG_TMAX_Z, CFG_STRIKE_MASK, CFG_FAIL_TAR_MASK,
     CFG_OBJ_TIME_MIN, CFG_OBJ_TIME_MAX, CFG_MIN_OBJ_DIST, CFG_MAX_OBJ_DIST, CFG_BALL_RADIUS, CFG_BALL_MASS, CFG_BALL_FRICTION, CFG_BALL_LIN_DAMP, CFG_BALL_ANG_DAMP,
-    CFG_PERTURB_ON, CFG_PERTURB_TIME_MIN, CFG_PERTURB_TIME_MAX, CFG_PERTURB_MIN, CFG_PERTURB_MAX, CFG_PERTURB_DUR_MIN, CFG_PERTURB_DUR_MAX, CFG_PERTURB_PART_MASK, CFG_COUNT
+    CFG_PERTURB_ON, CFG_PERTURB_TIME_MIN, CFG_PERTURB_TIME_MAX, CFG_PERTURB_MIN, CFG_PERTURB_MAX, CFG_PERTURB_DUR_MIN, CFG_PERTURB_DUR_MAX, CFG_PERTURB_PART_MASK, CFG_PHYSICS, CFG_COUNT
 };
 
 int orc_cfg_count() { return CFG_COUNT; }
@@ -61,7 +61,7 @@ void orc_cfg_default(double* c) {
     c[CFG_OBJ_TIME_MIN] = d.tar_obj_time_min; c[CFG_OBJ_TIME_MAX] = d.tar_obj_time_max; c[CFG_MIN_OBJ_DIST] = d.min_tar_obj_dist; c[CFG_MAX_OBJ_DIST] = d.max_tar_obj_dist;
     c[CFG_BALL_RADIUS] = d.ball_radius; c[CFG_BALL_MASS] = d.ball_mass; c[CFG_BALL_FRICTION] = d.ball_friction; c[CFG_BALL_LIN_DAMP] = d.ball_lin_damping; c[CFG_BALL_ANG_DAMP] = d.ball_ang_damping;
     c[CFG_PERTURB_ON] = d.enable_rand_perturbs; c[CFG_PERTURB_TIME_MIN] = d.perturb_time_min; c[CFG_PERTURB_TIME_MAX] = d.perturb_time_max; c[CFG_PERTURB_MIN] = d.min_perturb;
-    c[CFG_PERTURB_MAX] = d.max_perturb; c[CFG_PERTURB_DUR_MIN] = d.min_perturb_duration; c[CFG_PERTURB_DUR_MAX] = d.max_perturb_duration; c[CFG_PERTURB_PART_MASK] = d.perturb_part_mask;
+    c[CFG_PERTURB_MAX] = d.max_perturb; c[CFG_PERTURB_DUR_MIN] = d.min_perturb_duration; c[CFG_PERTURB_DUR_MAX] = d.max_perturb_duration; c[CFG_PERTURB_PART_MASK] = d.perturb_part_mask; c[CFG_PHYSICS] = d.physics;
 }
 
 void* orc_create(const double* jm, const double* bd, int J, const double* pd, const double* frames, int F, int loop,
@@ -90,7 +90,7 @@ void* orc_create(const double* jm, const double* bd, int J, const double* pd, co
     cfg.tar_obj_time_min = c[CFG_OBJ_TIME_MIN]; cfg.tar_obj_time_max = c[CFG_OBJ_TIME_MAX]; cfg.min_tar_obj_dist = c[CFG_MIN_OBJ_DIST]; cfg.max_tar_obj_dist = c[CFG_MAX_OBJ_DIST];
     cfg.ball_radius = c[CFG_BALL_RADIUS]; cfg.ball_mass = c[CFG_BALL_MASS]; cfg.ball_friction = c[CFG_BALL_FRICTION]; cfg.ball_lin_damping = c[CFG_BALL_LIN_DAMP]; cfg.ball_ang_damping = c[CFG_BALL_ANG_DAMP];
     cfg.enable_rand_perturbs = c[CFG_PERTURB_ON] != 0; cfg.perturb_time_min = c[CFG_PERTURB_TIME_MIN]; cfg.perturb_time_max = c[CFG_PERTURB_TIME_MAX]; cfg.min_perturb = c[CFG_PERTURB_MIN];
-    cfg.max_perturb = c[CFG_PERTURB_MAX]; cfg.min_perturb_duration = c[CFG_PERTURB_DUR_MIN]; cfg.max_perturb_duration = c[CFG_PERTURB_DUR_MAX]; cfg.perturb_part_mask = (uint32_t)c[CFG_PERTURB_PART_MASK];
+    cfg.max_perturb = c[CFG_PERTURB_MAX]; cfg.min_perturb_duration = c[CFG_PERTURB_DUR_MIN]; cfg.max_perturb_duration = c[CFG_PERTURB_DUR_MAX]; cfg.perturb_part_mask = (uint32_t)c[CFG_PERTURB_PART_MASK]; cfg.physics = (int)c[CFG_PHYSICS];
     Scene* s = new Scene();
     s->init(jm, bd, J, pd, frames, F, loop != 0, fall_mask, cfg);
     return s;

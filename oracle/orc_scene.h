@@ -54,6 +54,16 @@ struct SceneCfg {
     double contact_report_dist = 0.001;  // sim/ContactManager.cpp:80 (0.001*scale in scaled units)
     double breaking_factor = 0.02;       // gContactBreakingThreshold x angular-motion disc
     double max_coord_vel = 100.0;        // btMultiBody::m_maxCoordinateVelocity (scaled units)
+    // --- DM-physics v2 (physics = 2; [EXT-BULLET, recalled] SURVEY App. C items 4 and 7; v1 stays the default):
+    //   * both unilateral rows of every revolute limit (btMultiBodyJointLimitConstraint: q - lo and hi - q), not only the nearer bound;
+    //   * link-vs-ground contacts through a PERSISTENT manifold per link (btPersistentManifold): every narrowphase call (= substep)
+    //     refreshes the cached points (dropped beyond the breaking threshold in distance or in lateral drift), then adds ONE new point,
+    //     the support point of the hull along -n (btConvexPlaneCollisionAlgorithm), replacing the cached point it coincides with or,
+    //     when four are cached, the one the area heuristic picks (sortCachedPoints, deepest point kept).  A box settling on a face
+    //     therefore gathers its four corners over four substeps instead of starting with all of them.
+    //   Collision margins (0.04 scaled): sphere / capsule margins are their radii and btBoxShape's support vertex is the corner of the
+    //   full extents, so link-vs-plane contacts do not see them; self collision stays v1 (capsule pairs, one point per pair).
+    int physics = 1;
 };
 
 struct LinkState { Xf joint; V3 com; M3 Rb; V3 w; V3 vj; V3 vcom; };
@@ -131,6 +141,9 @@ struct Scene {
     std::vector<LinkState> links;
     // debug taps for component-level parity tests
     std::vector<ContactPt> dbg_contacts; int dbg_num_rows = 0; Vec dbg_vstar;
+    // physics 2: per link the cached manifold points -- the point on the link in body coordinates, the point on the plane (x, z)
+    struct ManifoldPt { V3 lp; real bx, bz; real dist; };
+    std::vector<std::vector<ManifoldPt>> manifolds;
     // ---- goal scenes (cSceneTargetAMP / cSceneHeadingAMP members) and multi-clip datasets (cClipsController)
     std::vector<Motion> clips; std::vector<double> clip_cdf; int cur_clip = 0;
     V3d tar_pos; double tar_heading = 0, tar_speed = 1, tar_timer = 0, tar_timer_max = 0;
@@ -196,6 +209,7 @@ struct Scene {
         need_new_action = true;                                      // DeepMimicCharController.cpp:220-229
         std::fill(tau.begin(), tau.end(), (real)0);
         std::fill(in_contact.begin(), in_contact.end(), 0);          // cWorld::Reset -> contact manager reset
+        manifolds.assign(sk.J, std::vector<ManifoldPt>());           // cWorld::Reset clears the broadphase pair cache (World.cpp:81-90): manifolds start empty
         // InitCharacterPos -> SetCharRandPlacement on a plane: root x,z := 0, y kept, rot kept (Ground.cpp:154-159)
         if (cfg.enable_rand_char_placement) { pose[0] = 0; pose[2] = 0; }
         // ResolveCharGroundIntersect (SceneSimChar.cpp:542-583): lift so that min link-AABB >= ground + 1 mm
@@ -330,6 +344,58 @@ struct Scene {
                 }
                 default: assert(false);
             }
+        }
+    }
+    // ---- physics 2: persistent link-vs-ground manifolds [EXT-BULLET, recalled: btPersistentManifold::refreshContactPoints,
+    // btConvexPlaneCollisionAlgorithm::collideSingleContact, btPersistentManifold::getCacheEntry / sortCachedPoints (2.88)]
+    void manifold_update(const std::vector<ContactPt>& cand) {
+        if ((int)manifolds.size() != sk.J) manifolds.assign(sk.J, std::vector<ManifoldPt>());
+        for (int j = 0; j < sk.J; ++j) {
+            if (!sk.valid_body(j)) continue;
+            std::vector<ManifoldPt>& mf = manifolds[j];
+            const real thr = breaking_threshold(j);
+            const LinkState& l = links[j];
+            // refresh: world position of the point on the link, distance along n = +y, lateral drift against the point on the plane
+            for (int i = (int)mf.size() - 1; i >= 0; --i) {
+                V3 xa = l.com + l.Rb * mf[i].lp;
+                mf[i].dist = xa.y;
+                const real dx = mf[i].bx - xa.x, dz = mf[i].bz - xa.z;
+                if (!(mf[i].dist <= thr) || dx * dx + dz * dz > thr * thr) mf.erase(mf.begin() + i);
+            }
+            // the new point: support vertex of the hull along -n = the deepest candidate of the link (ties: the first)
+            int best = -1;
+            for (size_t c = 0; c < cand.size(); ++c) if (cand[c].link == j && (best < 0 || cand[c].dist < cand[best].dist)) best = (int)c;
+            if (best < 0 || !(cand[best].dist < thr)) continue;
+            ManifoldPt np; np.lp = transpose(l.Rb) * (cand[best].x - l.com); np.bx = cand[best].x.x; np.bz = cand[best].x.z; np.dist = cand[best].dist;
+            // getCacheEntry: the cached point nearest to the new one in body coordinates, if closer than the breaking threshold
+            int slot = -1; real shortest = thr * thr;
+            for (size_t i = 0; i < mf.size(); ++i) { V3 d = mf[i].lp - np.lp; real d2 = dot(d, d); if (d2 < shortest) { shortest = d2; slot = (int)i; } }
+            if (slot >= 0) mf[slot] = np;
+            else if (mf.size() < 4) mf.push_back(np);
+            else mf[manifold_sort(mf, np)] = np;
+        }
+    }
+    // sortCachedPoints: which of the four cached points the new one replaces -- never the deepest; of the others the one whose removal
+    // leaves the largest quadrilateral (squared cross product of the diagonals)
+    static int manifold_sort(const std::vector<ManifoldPt>& mf, const ManifoldPt& np) {
+        int deepest = -1; real maxpen = np.dist;
+        for (int i = 0; i < 4; ++i) if (mf[i].dist < maxpen) { deepest = i; maxpen = mf[i].dist; }
+        real res[4] = {0, 0, 0, 0};
+        auto area = [&](const V3& a, const V3& b) { V3 c = cross(a, b); return dot(c, c); };
+        if (deepest != 0) res[0] = area(np.lp - mf[1].lp, mf[3].lp - mf[2].lp);
+        if (deepest != 1) res[1] = area(np.lp - mf[0].lp, mf[3].lp - mf[2].lp);
+        if (deepest != 2) res[2] = area(np.lp - mf[0].lp, mf[3].lp - mf[1].lp);
+        if (deepest != 3) res[3] = area(np.lp - mf[0].lp, mf[2].lp - mf[1].lp);
+        int best = 0;                                         // btVector4::closestAxis4: index of the largest absolute value, first on ties
+        for (int i = 1; i < 4; ++i) if (res[i] > res[best]) best = i;
+        return best;
+    }
+    // the manifolds' points as contact candidates, in (link, slot) order
+    void manifold_points(std::vector<ContactPt>& out) const {
+        for (int j = 0; j < sk.J; ++j) {
+            if (!sk.valid_body(j)) continue;
+            const LinkState& l = links[j];
+            for (const ManifoldPt& m : manifolds[j]) { ContactPt c; c.link = j; c.x = l.com + l.Rb * m.lp; c.dist = m.dist; out.push_back(c); }
         }
     }
     // [EXT-BULLET] contact breaking threshold = 0.02 x getAngularMotionDisc() of the convex shape
@@ -468,9 +534,10 @@ struct Scene {
         std::vector<ContactPt> cand; contact_candidates(cand);
         std::fill(in_contact.begin(), in_contact.end(), 0);
         std::vector<int> act;
+        if (cfg.physics == 2) { manifold_update(cand); cand.clear(); manifold_points(cand); }
         for (size_t i = 0; i < cand.size(); ++i) {
             if (cand[i].dist <= (real)cfg.contact_report_dist) in_contact[cand[i].link] = 1;
-            if (cand[i].dist < breaking_threshold(cand[i].link)) act.push_back((int)i);
+            if (cfg.physics == 2 || cand[i].dist < breaking_threshold(cand[i].link)) act.push_back((int)i);
         }
         // manifold reduction: keep the max_contacts deepest (ties -> lower candidate index)
         std::stable_sort(act.begin(), act.end(), [&](int a, int b) { return cand[a].dist < cand[b].dist; });
@@ -508,18 +575,21 @@ struct Scene {
 
         std::vector<Row> rows;
         const real big = (real)1e30;
-        // joint-limit rows (btMultiBodyJointLimitConstraint; revolute only, SimCharacter.cpp:948-973): nearer bound
+        // joint-limit rows (btMultiBodyJointLimitConstraint; revolute only, SimCharacter.cpp:948-973): v1 the nearer bound, v2 both
         for (int j = 1; j < sk.J; ++j) {
             if (sk.type(j) != JT_REVOLUTE) continue;
             real lo = (real)sk.jd(j, JD_LL0), hi = (real)sk.jd(j, JD_LH0);
             if (lo > hi) continue;
             int off = sk.offset(j); real th = pose[off];
             real pen_lo = th - lo, pen_hi = hi - th;
-            Row r; r.J.assign(P, 0); r.normal_row = -1; r.mu = 0; r.lo = 0; r.hi = big; r.lam = 0;
-            real pen;
-            if (pen_lo <= pen_hi) { r.J[off] = 1; pen = pen_lo; } else { r.J[off] = -1; pen = pen_hi; }
-            r.b = (pen > 0) ? -pen / h : (real)-cfg.erp * pen / h;
-            rows.push_back(r);
+            for (int side = 0; side < 2; ++side) {
+                if (cfg.physics != 2 && side != ((pen_lo <= pen_hi) ? 0 : 1)) continue;
+                Row r; r.J.assign(P, 0); r.normal_row = -1; r.mu = 0; r.lo = 0; r.hi = big; r.lam = 0;
+                const real pen = side ? pen_hi : pen_lo;
+                r.J[off] = side ? (real)-1 : (real)1;
+                r.b = (pen > 0) ? -pen / h : (real)-cfg.erp * pen / h;
+                rows.push_back(r);
+            }
         }
         int n_lim = (int)rows.size(), nc = (int)contacts.size();
         for (int c = 0; c < nc; ++c) {

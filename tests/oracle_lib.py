@@ -23,7 +23,7 @@ CFG_KEYS = ["num_sim_substeps", "world_scale", "grav_x", "grav_y", "grav_z", "sy
             "tar_near_dist", "tar_far_prob", "target_radius", "hit_reset_time", "init_hit_prob", "hit_tar_speed", "tar_reward_scale",
             "tmin_x", "tmin_y", "tmin_z", "tmax_x", "tmax_y", "tmax_z", "strike_mask", "fail_tar_mask",
             "obj_time_min", "obj_time_max", "min_obj_dist", "max_obj_dist", "ball_radius", "ball_mass", "ball_friction", "ball_lin_damp", "ball_ang_damp",
-            "perturb_on", "perturb_time_min", "perturb_time_max", "perturb_min", "perturb_max", "perturb_dur_min", "perturb_dur_max", "perturb_part_mask"]
+            "perturb_on", "perturb_time_min", "perturb_time_max", "perturb_min", "perturb_max", "perturb_dur_min", "perturb_dur_max", "perturb_part_mask", "physics"]
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int)

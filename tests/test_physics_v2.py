@@ -1,0 +1,162 @@
+"""DM-physics v2 (`physics = 2`; DESIGN.md section 4, SURVEY App. C items 4 and 7 -- Bullet 2.88 behaviour as recalled, unverifiable here):
+both unilateral rows of every revolute limit and link-vs-ground contacts through persistent manifolds that gain ONE support point per
+narrowphase call.  These tests separate v2 from v1 on situations where the two specifications differ, hold v2 to the closed forms v1
+is held to, and hold the device code (emulator here, HIP marked gpu) to the oracle under physics 2.  v1 stays the default."""
+import numpy as np
+import pytest
+
+import parity_common as pc
+from deepmimic_amd import model
+from deepmimic_amd.core import BatchEnv
+from oracle_lib import Oracle
+from test_physics_validity import G, H, MU, box_tables
+
+
+def _nc(o):
+    return o.num_contacts()
+
+
+def test_box_gathers_its_four_corners_one_per_substep(oracle_built):
+    """a box set down flat (the reset leaves it 1 mm above the plane): v1 regenerates the analytic contact set -- the 4 bottom corners
+    from the first substep on --, v2's manifold holds the one support corner while the box falls flat, and once that corner carries
+    load the others arrive one narrowphase call at a time (1 -> 2 -> 3 -> 4, never two at once) and stay"""
+    seqs = {}
+    for phys in (1, 2):
+        o = Oracle(box_tables(), physics=phys); o.reset(0.0)
+        seq = []
+        for _ in range(80):
+            o.set_tau(np.zeros(o.P)); o.substep(H); seq.append(_nc(o))
+        seqs[phys] = seq
+        p, v = o.sim_state()
+        assert abs(p[1] - 0.2) < 1e-4 and np.abs(v).max() < 1e-4, (phys, p[:3], np.abs(v).max())       # both end up resting on the face
+    assert seqs[1] == [4] * 80
+    s2 = np.array(seqs[2])
+    assert s2[0] == 1 and s2[-1] == 4 and (np.diff(s2) >= 0).all() and np.diff(s2).max() == 1, seqs[2]
+
+
+def test_v2_box_rests_slides_and_falls_like_v1(oracle_built):
+    """the closed forms of test_physics_validity under physics 2: free fall exact; Coulomb sliding -- a sliding point drifts off its anchor
+    on the plane by v h per call and is dropped at the breaking threshold (every ~3 calls at 2.5 m/s), so the manifold runs on fewer
+    than four points most of the time and the box rocks a little: the mean deceleration stays within 10 % of mu g (v1: 0.2 %) --; the
+    box comes to rest on its face, on four points, without sinking"""
+    o = Oracle(box_tables(), physics=2); o.reset(0.0)
+    p, v = o.sim_state(); p[1] = 1.5; o.set_sim_state(p, v)
+    k = np.arange(1, 201); tr = []
+    for _ in range(200):
+        o.set_tau(np.zeros(o.P)); o.substep(H); pp, vv = o.sim_state(); tr.append([pp[1], vv[1]])
+    tr = np.array(tr)
+    assert np.abs(tr[:, 1] + G * H * k).max() < 1e-12 and np.abs(tr[:, 0] - (1.5 - G * H * H * k * (k + 1) / 2)).max() < 1e-12
+    o = Oracle(box_tables(), physics=2); o.reset(0.0)
+    p, v = o.sim_state(); v[0] = 2.5; o.set_sim_state(p, v)
+    sp, ys = [], []
+    for _ in range(500):
+        o.set_tau(np.zeros(o.P)); o.substep(H); pp, vv = o.sim_state(); sp.append(vv[0]); ys.append(pp[1])
+    dec = -(sp[120] - sp[20]) / (100 * H)
+    assert abs(dec - MU * G) < 0.1 * MU * G, dec
+    assert abs(sp[-1]) < 1e-5 and np.abs(np.array(ys[40:]) - 0.2).max() < 1e-3 and abs(ys[-1] - 0.2) < 2e-5       # rocks by < 1 mm while sliding, rests on the face
+    assert _nc(o) == 4
+
+
+def test_tilted_box_first_touches_with_one_corner_in_both(oracle_built):
+    """a box dropped on a corner: the support point is the same single corner in v1 and v2 until it tips"""
+    for phys in (1, 2):
+        t = box_tables()
+        o = Oracle(t, physics=phys); o.reset(0.0)
+        p, v = o.sim_state()
+        a = np.radians(30.0); q1 = np.array([np.cos(a / 2), np.sin(a / 2), 0, 0]); q2 = np.array([np.cos(a / 2), 0, 0, np.sin(a / 2)])
+        q = np.array([q1[0] * q2[0] - q1[1:].dot(q2[1:]), *(q1[0] * q2[1:] + q2[0] * q1[1:] + np.cross(q1[1:], q2[1:]))])
+        p[3:7] = q; p[1] = 0.36
+        o.set_sim_state(p, v)
+        seen = []
+        for _ in range(300):
+            o.set_tau(np.zeros(o.P)); o.substep(H); seen.append(_nc(o))
+        nz = [c for c in seen if c > 0]
+        assert nz and nz[0] == 1 and nz[5] == 1, (phys, seen)
+
+
+def _knee_state(t, o, angle):
+    """humanoid standing pose in the air with the right knee (revolute, limits [-3.14, 0]) set to `angle`"""
+    o.reset(0.0)
+    p, v = o.sim_state(); p[1] += 1.0; v[:] = 0
+    off = int(t.joint_mat[4, model.JD_PARAM_OFFSET]); p[off] = angle
+    return p, v, off
+
+
+def test_two_limit_rows_per_revolute_joint(oracle_built):
+    """humanoid in the air: v1 builds one limit row per revolute joint (the nearer bound), v2 both: 4 vs 8 rows with no contact.  With
+    the knee pushed 0.05 rad beyond its upper bound (0) both versions bring it back by erp x violation per substep (the hi row is the
+    nearer one), so the two agree there; v2's extra lo row stays inactive."""
+    t = model.load_asset("humanoid3d_walk")
+    rows, knee = {}, {}
+    for phys in (1, 2):
+        o = Oracle(t, physics=phys, self_collision=0)
+        p, v, off = _knee_state(t, o, 0.05)
+        o.set_sim_state(p, v)
+        o.set_tau(np.zeros(o.P)); o.substep(H)
+        rows[phys] = o.num_rows(); knee[phys] = o.sim_state()[1][off]
+    assert rows == {1: 4, 2: 8}, rows
+    assert abs(knee[1] - knee[2]) < 1e-9 and knee[1] < -0.2 * 0.05 / H * 0.5          # pulled back: about -erp * violation / h
+
+
+def _device_vs_oracle_v2(lib, name, prec, steps, tol_r, tol_s):
+    """device under physics 2 vs the oracle under physics 2: teacher-forced control steps (manifolds start empty on both sides: the
+    state setter clears them) -- rewards, state vectors and flags"""
+    t = model.load_asset(name)
+    n = 4
+    env = BatchEnv(t, n, precision=prec, lib_path=lib, physics=2, seed=5)
+    assert env.physics == 2
+    oracles = []
+    for e in range(n):
+        o = Oracle(t, physics=2, max_contacts=env.max_contacts); o.reset(0.13 + 0.27 * e); oracles.append(o)
+    env.reset(kin_times=[o.kin_time() for o in oracles], max_times=np.inf)
+    worst_r = worst_s = 0.0
+    for k in range(steps):
+        out = env.step(None, pc.DT, 20, open_loop=True)
+        for e, o in enumerate(oracles):
+            kp, _, _ = o.kin_state(); o.set_action(o.pose_to_action(kp))
+            for _ in range(20):
+                o.update(pc.DT)
+            r, so = o.calc_reward(), o.record_state()
+            worst_r = max(worst_r, abs(float(out["reward"][e]) - r)); worst_s = max(worst_s, np.abs(out["state"][e] - so).max() / max(1.0, np.abs(so).max()))
+            assert int(out["terminate"][e]) == o.check_terminate()
+    assert worst_r < tol_r and worst_s < tol_s, (name, prec, worst_r, worst_s)
+    return worst_r, worst_s
+
+
+def _device_box_v2(lib, prec):
+    """the device's manifolds on the box set down flat: the contact count of every update equals the oracle's while the box gathers its
+    corners (1 ... 4), and so does the state at the end"""
+    t = box_tables()
+    env = BatchEnv(t, 2, precision=prec, lib_path=lib, physics=2)
+    env.reset(kin_times=[0.0, 0.0], max_times=np.inf)
+    env.probe(2, H)                 # arm the taps: (rows, contacts) of the last substep
+    o = Oracle(t, physics=2); o.reset(0.0)
+    got = []
+    for _ in range(45):
+        env.update(2 * H, 1); o.update(2 * H)
+        got.append(int(env.debug("rows")[0][1]))
+        assert got[-1] == o.num_contacts(), got
+    assert got[0] == 1 and got[-1] == 4 and sorted(set(got)) == [1, 2, 3, 4][-len(set(got)):], got
+    st = env.get_state(); p, v = o.sim_state()
+    assert np.abs(st["pose"][0] - p).max() < (1e-10 if prec == 64 else 1e-5)
+
+
+def test_device_v2_box_emulator(emu_lib):
+    _device_box_v2(emu_lib, 64)
+
+
+@pytest.mark.parametrize("name", ["humanoid3d_walk", "dog3d_pace"])
+def test_device_v2_matches_oracle_emulator(emu_lib, name):
+    print(_device_vs_oracle_v2(emu_lib, name, 64, 6, 1e-6, 1e-5))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,prec,tol_r,tol_s", [("humanoid3d_walk", 64, 1e-6, 1e-5), ("dog3d_pace", 64, 1e-6, 1e-5),
+                                                   ("humanoid3d_walk", 32, 1e-3, 5e-2), ("dog3d_pace", 32, 1e-3, 5e-2)])
+def test_device_v2_matches_oracle_gpu(hip_lib, name, prec, tol_r, tol_s):
+    print(_device_vs_oracle_v2(hip_lib, name, prec, 20, tol_r, tol_s))
+
+
+@pytest.mark.gpu
+def test_device_v2_box_gpu(hip_lib):
+    _device_box_v2(hip_lib, 64); _device_box_v2(hip_lib, 32)

@@ -135,43 +135,70 @@ def cpu_baseline(scene, budget_s=12.0):
         return {"value": None, "unit": "env-steps/s", "cores": 1, "kind": "port", "sample": "failed: %r" % (ex,)}
 
 
-def facade_bench(scene, steps):
-    """The drop-in path the reference's trainer uses: ONE env per cDeepMimicCore, driven by the reference's update_world loop
-    (DeepMimic.py:62-80: NeedNewAction / RecordState / CalcReward / SetAction once per 1/30 s; Update, CheckValidEpisode,
-    IsEpisodeEnd once per 1/600 s).  Reports env-steps/s of one worker with the control step batched into one launch
-    (DM_FACADE_BATCH=1, default) and update by update."""
+def _facade_worker(scene, steps, batch, barrier, q):
+    """one worker of the drop-in route: ONE env per cDeepMimicCore, the reference's update_world loop"""
+    os.environ["DM_FACADE_BATCH"] = batch
     sys.path.insert(0, os.path.join(ROOT, "deepmimic_amd", "compat"))
     from DeepMimicCore import DeepMimicCore
     from deepmimic_amd import model
     t = model.load_asset(scene)
+    core = DeepMimicCore.cDeepMimicCore(False)
+    core.SeedRand(1 + os.getpid() % 1000); core.LoadTables(t, 10); core.Init()
+    rng = np.random.default_rng(os.getpid())
+    A, dt = core.GetActionSize(0), 1.0 / 600
+    lo, hi = np.array(core.BuildActionBoundMin(0)), np.array(core.BuildActionBoundMax(0))
+
+    def run(n_steps):
+        n = 0
+        while n < n_steps:
+            if core.NeedNewAction(0):
+                core.RecordState(0); core.RecordGoal(0); core.CalcReward(0)
+                core.SetAction(0, [float(x) for x in np.clip(0.1 * rng.normal(size=A), lo, hi)]); n += 1
+            core.Update(dt)
+            if (not core.CheckValidEpisode()) or core.IsEpisodeEnd():
+                core.RecordState(0); core.CalcReward(0); core.CheckTerminate(0)
+                core.Reset()
+    run(20)
+    core.stats.update(launches=0, updates=0, rollbacks=0)
+    if barrier is not None:
+        barrier.wait()
+    t0 = time.perf_counter(); run(steps); el = time.perf_counter() - t0
+    res = {"elapsed": el, "steps": steps, "launches": core.stats["launches"], "updates": core.stats["updates"]}
+    core.Shutdown()
+    if q is not None:
+        q.put(res)
+    return res
+
+
+def facade_bench(scene, steps, workers=(1,)):
+    """The drop-in path the reference's trainer uses: ONE env per cDeepMimicCore, driven by the reference's update_world loop
+    (DeepMimic.py:62-80: NeedNewAction / RecordState / CalcReward / SetAction once per 1/30 s; Update, CheckValidEpisode,
+    IsEpisodeEnd once per 1/600 s).  Reports env-steps/s of one worker with the control step batched into one launch
+    (DM_FACADE_BATCH=1, default) and update by update, and -- `--workers W ...` -- the AGGREGATE of W such worker processes sharing
+    one GPU (the reference scales by processes: mpi_run.py:16-24), all timed from a common barrier to the last finisher."""
+    import multiprocessing as mp
     out = {}
     for tag, batch in (("batched", "1"), ("per_update", "0")):
-        os.environ["DM_FACADE_BATCH"] = batch
-        core = DeepMimicCore.cDeepMimicCore(False)
-        core.SeedRand(1); core.LoadTables(t, 10); core.Init()
-        rng = np.random.default_rng(0)
-        A, dt = core.GetActionSize(0), 1.0 / 600
-        lo, hi = np.array(core.BuildActionBoundMin(0)), np.array(core.BuildActionBoundMax(0))
-
-        def run(n_steps):
-            n = 0
-            while n < n_steps:
-                if core.NeedNewAction(0):
-                    core.RecordState(0); core.RecordGoal(0); core.CalcReward(0)
-                    core.SetAction(0, [float(x) for x in np.clip(0.1 * rng.normal(size=A), lo, hi)]); n += 1
-                core.Update(dt)
-                if (not core.CheckValidEpisode()) or core.IsEpisodeEnd():
-                    core.RecordState(0); core.CalcReward(0); core.CheckTerminate(0)
-                    core.Reset()
-        run(20)
-        core.stats.update(launches=0, updates=0, rollbacks=0)
-        t0 = time.perf_counter(); run(steps); el = time.perf_counter() - t0
-        out[tag] = {"env_steps_per_s": steps / el, "ms_per_control_step": 1e3 * el / steps, "launches_per_control_step": core.stats["launches"] / steps,
-                    "updates_per_control_step": core.stats["updates"] / steps}
-        core.Shutdown()
+        r = _facade_worker(scene, steps, batch, None, None)
+        out[tag] = {"env_steps_per_s": steps / r["elapsed"], "ms_per_control_step": 1e3 * r["elapsed"] / steps,
+                    "launches_per_control_step": r["launches"] / steps, "updates_per_control_step": r["updates"] / steps}
+    agg = {}
+    ctx = mp.get_context("spawn")
+    for w in workers:
+        if w <= 1:
+            agg["1"] = out["batched"]["env_steps_per_s"]; continue
+        barrier, q = ctx.Barrier(w), ctx.Queue()
+        procs = [ctx.Process(target=_facade_worker, args=(scene, steps, "1", barrier, q)) for _ in range(w)]
+        for p_ in procs:
+            p_.start()
+        res = [q.get(timeout=1800) for _ in procs]
+        for p_ in procs:
+            p_.join()
+        agg[str(w)] = w * steps / max(r["elapsed"] for r in res)
     print(json.dumps({"metric": "facade env-steps/s, one env per cDeepMimicCore (%s)" % scene, "value": out["batched"]["env_steps_per_s"],
                       "unit": "env-steps/s", "n_gpus": 1, "steps": steps, "higher_is_better": True, "dtype": "f32", "data": "synthetic",
-                      "config": {"workload": "%s, 1 env, reference driver protocol, random actions N(0, 0.1^2), auto reset by the driver" % scene}, **out}))
+                      "config": {"workload": "%s, 1 env per worker, reference driver protocol, random actions N(0, 0.1^2), auto reset by the driver" % scene},
+                      "aggregate_env_steps_per_s_by_workers": agg, "host_cores": os.cpu_count(), **out}))
 
 
 def main():
@@ -182,7 +209,7 @@ def main():
     ap.add_argument("--envs", type=int, default=4096, help="envs per GPU")
     ap.add_argument("--scene", default="humanoid3d_walk")
     ap.add_argument("--precision", type=int, default=32)
-    ap.add_argument("--wave-packing", type=int, default=2, help="characters per wavefront of the step kernel (1 or 2; 2 needs the biped class)")
+    ap.add_argument("--wave-packing", type=int, default=0, help="characters per wavefront of the step kernel: 0 = the library's default (2 for the biped class, 1 for the dog and for dribble_amp), 1 or 2")
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--force-gather", action="store_true", help="exercise the record exchange even with one rank")
     ap.add_argument("--gather", choices=["torch", "cabi"], default="torch",
@@ -191,6 +218,7 @@ def main():
                     help="nccl (= RCCL, the product) or gloo: CPU test harness of the N > 1 path (needs DM_HIP_LIB = the emulator build and DM_ALLOW_EMULATOR=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--facade", action="store_true", help="measure the single-env cDeepMimicCore facade path instead of the batched env")
+    ap.add_argument("--workers", type=int, nargs="*", default=[1], help="with --facade: aggregate rate of W worker processes (one cDeepMimicCore each) sharing the GPU, e.g. --workers 1 16 64")
     ap.add_argument("--cpu-baseline-worker", type=int, default=None, help=argparse.SUPPRESS)
     ap.add_argument("--cpu-budget", type=float, default=12.0, help=argparse.SUPPRESS)
     ap.add_argument("--min-warmup", type=int, default=60,
@@ -201,7 +229,7 @@ def main():
         cpu_baseline_worker(args.scene, args.cpu_baseline_worker, args.cpu_budget)
         return
     if args.facade:
-        facade_bench(args.scene, min(args.steps, 300))
+        facade_bench(args.scene, min(args.steps, 300), args.workers)
         return
 
     if args.gpus < 1:
@@ -328,7 +356,7 @@ def main():
         if world != args.gpus or len(per_rank) != args.gpus:
             raise SystemExit("bench.py: ran %d rank(s) with %d per-rank rate(s) under --gpus %d" % (world, len(per_rank), args.gpus))
         bytes_per_launch = algorithmic_bytes_per_env_step(env) * n
-        kname = "k_env_step_duo" if (args.wave_packing != 1 and env.J <= 15 and env.D == 34 and n % 2 == 0) else "k_env_step"
+        kname = "k_env_step_duo" if (args.wave_packing != 1 and env.J <= 15 and env.D == 34 and n % 2 == 0 and tables.goal_kind != 5) else "k_env_step"
         achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else None      # (the emulator has no HIP events)
         traffic, traffic_source = measured_traffic(args.scene, n, kname)
         value = world * n * args.steps / elapsed

@@ -1,7 +1,7 @@
 """env-steps/s of every scene kind the path steps on the device, on ONE box: imitate (the headline workload), imitate_amp (AMP observation written
 every step), the five goal-conditioned task scenes (goal vector + AMP observation + task reward; multi-clip datasets), and imitate with random
 perturbations.  Open-loop clip tracking with auto-reset, 4096 envs, outputs into device tensors (deepmimic_amd.vec_env).
-usage: python tools/gpu_scene_bench.py [envs]"""
+usage: python tools/gpu_scene_bench.py [envs] [scene label: run only this one]"""
 import json
 import os
 import sys
@@ -20,8 +20,11 @@ SCENES = [("imitate", "humanoid3d_walk", None), ("imitate + perturbs", "humanoid
 
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+    only = sys.argv[2] if len(sys.argv) > 2 else None
     out = {"envs": n, "scenes": {}}
     for label, asset, mod in SCENES:
+        if only and label != only:
+            continue
         t = model.load_asset(asset)
         # train mode at the END of the timer annealing (time_end_lim_*, scenes/RLSceneSimChar.cpp:338-347): the arg files start it at 0.5 s episodes
         if t.cfg.time_end_lim_max is not None:

@@ -155,7 +155,15 @@ class BatchEnv:
                   "target_hit_reset_time", "init_hit_prob", "hit_tar_speed", "tar_reward_scale"):
             setattr(st, k, float(getattr(c, k)))
         st.target_min = (C.c_double * 3)(*[float(x) for x in c.target_min]); st.target_max = (C.c_double * 3)(*[float(x) for x in c.target_max])
-        st.strike_mask = sum(1 << int(b) for b in (c.strike_bodies or [])); st.fail_tar_mask = sum(1 << int(b) for b in (c.fail_tar_contact_bodies or []))
+        # body / clip ids become bits of 32-bit masks (c_int): an id that does not name a body part must raise here, not wrap silently
+        def _mask(ids, limit, what):
+            ids = [int(b) for b in (ids or [])]
+            if any(b < 0 or b >= min(int(limit), 31) for b in ids):
+                raise ValueError("%s out of range [0, %d): %s" % (what, min(int(limit), 31), sorted(ids)))
+            return sum(1 << b for b in set(ids))
+        st.strike_mask = _mask(c.strike_bodies, st.num_joints, "strike_bodies"); st.fail_tar_mask = _mask(c.fail_tar_contact_bodies, st.num_joints, "fail_tar_contact_bodies")
+        if not 0 <= int(tables.getup_clip_mask) < (1 << 31):
+            raise ValueError("getup_motion_ids out of range")
         # dribble_amp: the ball (constants of cSceneDribbleAMP::BuildTarObjs; friction combined with the 0.9 of links and ground)
         for k in ("rand_tar_obj_time_min", "rand_tar_obj_time_max", "min_tar_obj_dist", "max_tar_obj_dist", "ball_radius"):
             setattr(st, k, float(getattr(c, k)))
@@ -188,6 +196,11 @@ class BatchEnv:
         self.physics, self.max_contacts = int(pinfo[0]), int(pinfo[1])      # DM-physics version; effective contact cap per character
         self.amp_size = int(self.lib.dm_amp_obs_size(self.h))      # GetAMPObsSize; 0 unless `--scene imitate_amp`
         self.num_clips = int(tables.num_clips); self.has_obj = tables.goal_kind == 5
+        self._has_goal_row = bool(tables.goal_kind != 0 or tables.num_clips > 1 or c.enable_rand_rot_reset)      # dm_host.cpp: st.goal is allocated under the same condition
+        if self._timer[0] == "exp" and not self._timer_pinned:
+            # dm_create's own first reset drew the uniform timer: an env stepped right after construction must run its first episode under
+            # min(time_lim_min + Exp(time_lim_exp), time_lim_max) too (util/Timer.cpp:64-67), so reset once more through the host draw
+            self.reset()
 
     def _chk(self, rc):
         if rc != 0:
@@ -315,6 +328,10 @@ class BatchEnv:
         self._chk(self.lib.dm_last_goals(self.h, _fp(g)))
         return g
 
+    def last_goals_device(self, dst_ptr: int):
+        """RecordGoal of the last step into a device buffer (N x G float32), on the ctx stream, no host sync"""
+        self._chk(self.lib.dm_last_goals_device(self.h, C.c_void_p(int(dst_ptr))))
+
     def query_goal(self):
         """RecordGoal for every env (goal scenes): N x G"""
         g = np.zeros((self.N, max(self.G, 1)), np.float32)
@@ -413,11 +430,8 @@ class BatchEnv:
         query) it is a checkpoint: `restore` + the same actions reproduce the rollout bit for bit (the AMP pose history is re-latched by
         the first update after a boundary, so it is not part of it)."""
         snap = self.get_state()
-        if self.G or self.num_clips > 1:
-            try:
-                snap["goal"] = self.get_goal_state(); snap["aux"] = self.get_goal_aux()
-            except RuntimeError:
-                pass
+        if self._has_goal_row:        # decided up front, as the host allocates the row: a failed device copy must raise, not yield a rollback without the goal
+            snap["goal"] = self.get_goal_state(); snap["aux"] = self.get_goal_aux()
         if self.has_obj:
             snap["obj"] = self.get_obj_state()
         if self.has_perturbs:

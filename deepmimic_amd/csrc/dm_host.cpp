@@ -931,6 +931,19 @@ int dm_last_goals(dm_ctx* ctx, float* goals) {
     if (!c->goal_size) return fail("RecordGoal needs a goal scene (dm_scene_tables.scene_goal)");
     return copy_out(c, goals, c->d_goals, sizeof(float) * (size_t)c->N * c->goal_size);
 }
+// the same into a DEVICE buffer, asynchronously on the ctx stream (no host sync: a device-resident learner reads it after the step)
+int dm_last_goals_device(dm_ctx* ctx, float* goals_dev) {
+    if (!ctx || !goals_dev) return fail("null argument");
+    CtxBase* c = ctx->c; DevGuard guard(c->device_id);
+    if (!c->goal_size) return fail("RecordGoal needs a goal scene (dm_scene_tables.scene_goal)");
+    const size_t bytes = sizeof(float) * (size_t)c->N * c->goal_size;
+#ifdef DM_EMU
+    memcpy(goals_dev, c->d_goals, bytes);
+#else
+    HIPCHK(hipMemcpyAsync(goals_dev, c->d_goals, bytes, hipMemcpyDeviceToDevice, c->stream));
+#endif
+    return 0;
+}
 int dm_get_goal_state(dm_ctx* ctx, double* out) { if (!ctx || !out) return fail("null argument"); DevGuard guard(ctx->c->device_id); return ctx->c->get_goal(out); }
 int dm_set_goal_state(dm_ctx* ctx, const double* in) { if (!ctx || !in) return fail("null argument"); DevGuard guard(ctx->c->device_id); return ctx->c->set_goal(in); }
 int dm_goal_size(const dm_ctx* ctx) { return ctx ? ctx->c->goal_size : 0; }

@@ -3,7 +3,10 @@ torch tensors, one kernel launch per 30 Hz control step, asynchronous on torch's
 the path (the facade in compat/ is the drop-in for the reference's one-env-per-process driver; this is the batched form of the same
 protocol: SetAction ; 20 x Update ; RecordState / CalcReward / CheckTerminate ; Reset of finished episodes, DeepMimic.py:62-80).
 
-torch is plumbing here (device memory, streams); the stepping itself is libdm_hip.so."""
+torch is plumbing here (device memory, streams); the stepping itself is libdm_hip.so.
+
+`--timer_type exp` scenes (no shipped arg file) are not served here: the in-kernel auto-reset draws the uniform episode timer only
+(util/Timer.cpp:27-45; BatchEnv.reset draws the exponential one on the host for explicit resets)."""
 from __future__ import annotations
 
 from typing import Dict, Tuple
@@ -29,6 +32,7 @@ class TorchVecEnv:
         self.obs = torch.zeros((self.n, self.obs_dim), **f32); self.reward = torch.zeros(self.n, **f32)
         self.terminate = torch.zeros(self.n, **i32); self.valid = torch.zeros(self.n, **i32); self.episode_end = torch.zeros(self.n, **i32)
         self.amp_obs = torch.zeros((self.n, self.env.amp_size), **f32) if (amp_obs and self.env.amp_size) else None
+        self.goal = torch.zeros((self.n, self.goal_dim), **f32) if self.goal_dim else None      # RecordGoal of the last step (goal scenes), device resident
         # the launches go to the caller's CURRENT torch stream (looked up at every call): ordered against the caller's work on both sides
         # without events (torch's default stream has the null handle; BatchEnv.set_stream maps it to the legacy default stream)
         self._stream_handle = None
@@ -68,7 +72,8 @@ class TorchVecEnv:
         if self.amp_obs is not None:
             info["amp_obs"] = self.amp_obs
         if self.goal_dim:
-            info["goal"] = t.from_numpy(self.env.last_goals()).to(self.device)      # N x G, small: staged through the host
+            self.env.last_goals_device(self.goal.data_ptr())        # device-to-device on the same stream, behind the step kernel: no host sync
+            info["goal"] = self.goal
         return self.obs, self.reward, self.episode_end.bool(), info
 
     def close(self):

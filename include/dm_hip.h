@@ -183,6 +183,8 @@ int dm_goal_size(const dm_ctx* ctx);          /* GetGoalSize: 0 (no goal scene),
 int dm_query_goal(dm_ctx* ctx, float* goals, int flags);
 /* the goals written by the most recent dm_step_batch / dm_query (no launch): what the agent reads next to `states` */
 int dm_last_goals(dm_ctx* ctx, float* goals);
+/* RecordGoal of the last emit into a DEVICE buffer (N x goal size floats), asynchronously on the ctx stream: no host round trip */
+int dm_last_goals_device(dm_ctx* ctx, float* goals_dev);
 /* Goal state snapshot (tests, checkpointing): N x 12 doubles = target pos(3), target heading, target speed, target timer time,
  * target timer max, COM at the last action(3), controller time of the last action, draws consumed so far.  NULL = leave as is. */
 int dm_get_goal_state(dm_ctx* ctx, double* out);

@@ -744,8 +744,9 @@ struct EnvSim {
         if (l < ND) {
             Real* col = &s.Lt[L::lcb(l)];
 #pragma unroll
-            for (int t = 0; t < NP2 / 2; ++t) {
-                const R4 w = {c2[2 * t][0], c2[2 * t][1], c2[2 * t + 1][0], c2[2 * t + 1][1]};
+            for (int t = 0; t < (NP2 + 1) / 2; ++t) {        // (ND = 4 q + 2: the last quad's upper pair does not exist and is stored as zeros)
+                const R2 up = (2 * t + 1 < NP2) ? c2[(2 * t + 1 < NP2) ? 2 * t + 1 : 0] : R2{(Real)0, (Real)0};
+                const R4 w = {c2[2 * t][0], c2[2 * t][1], up[0], up[1]};
                 if ((TP::T.quadmask[t] >> l) & 1ull) *reinterpret_cast<R4*>(&col[4 * t]) = w;
             }
             col[l] = dinv;
@@ -769,7 +770,11 @@ struct EnvSim {
         typedef typename C::Topo TP;
         if constexpr (V < TP::T.nlev) {
             constexpr int S0 = TP::T.lev_start[V], W = TP::T.lev_start[V + 1] - S0;
-            Real* cbuf = &s.f[0][0];                   // [pivot of the level][lane]: aliases the dead Newton-Euler accumulators
+            // [pivot of the level][dof]: aliases the dead Newton-Euler accumulators f, n, Iw, Fs, Ns -- NOT Ic behind them, where the
+            // stable-PD joint forces live during the SPD solve (xs() = Ic); the stride is the dof count rounded to a quad
+            constexpr int CS = (ND + 3) & ~3;
+            static_assert(TP::T.maxw * CS <= 18 * NJ, "level buffer must end before Ic (= xs during the SPD solve): f | n | Iw | Fs | Ns are dead by now");
+            Real* cbuf = &s.f[0][0];
             const Real inv = dm_rsqrt(hd);
             dinv = lane_sel<TP::T.levmask[V]>(inv, dinv, l, z);
             Real lk[W];
@@ -779,7 +784,7 @@ struct EnvSim {
                 const Real ik = lane_bcast(inv, k);
                 const Real x = c2[k >> 1][k & 1] * ik;
                 c2[k >> 1][k & 1] = x; lk[q] = x;
-                if (TP::T.anc[k] != 0) cbuf[q * kWave + l] = x;
+                if (TP::T.anc[k] != 0 && l < ND) cbuf[q * CS + l] = x;
             }
             sync();
 #pragma unroll
@@ -791,16 +796,16 @@ struct EnvSim {
                 // (the pair that holds k itself takes its lower entry alone: lane k's slot k -- the diagonal position, kept apart in hd --
                 // has collected - sum L^2 from deeper pivots, and what lane k published for it must not reach the fresh L_kj of the others)
 #pragma unroll
-                for (int t = 0; t < NP2 / 2; ++t) {         // quads of dofs 4t .. 4t + 3 = pairs 2t, 2t + 1: one 16-B broadcast read when both take part
+                for (int t = 0; t < (NP2 + 1) / 2; ++t) {   // quads of dofs 4t .. 4t + 3 = pairs 2t, 2t + 1: one 16-B broadcast read when both take part
                     const bool own0 = (2 * t == (k >> 1)), own1 = (2 * t + 1 == (k >> 1));
-                    const bool on0 = !own0 && ((TP::T.anc[k] >> (4 * t)) & 3ull), on1 = !own1 && ((TP::T.anc[k] >> (4 * t + 2)) & 3ull);
+                    const bool on0 = !own0 && ((TP::T.anc[k] >> (4 * t)) & 3ull), on1 = (2 * t + 1 < NP2) && !own1 && ((TP::T.anc[k] >> (4 * t + 2)) & 3ull);
                     if (on0 && on1) {
-                        const R4 r = *reinterpret_cast<const R4*>(&cbuf[q * kWave + 4 * t]);
+                        const R4 r = *reinterpret_cast<const R4*>(&cbuf[q * CS + 4 * t]);
                         const R2 ra = {r[0], r[1]}, rb = {r[2], r[3]};
-                        c2[2 * t] -= l2 * ra; c2[2 * t + 1] -= l2 * rb;
-                    } else if (on0) c2[2 * t] -= l2 * *reinterpret_cast<const R2*>(&cbuf[q * kWave + 4 * t]);
-                    else if (on1) c2[2 * t + 1] -= l2 * *reinterpret_cast<const R2*>(&cbuf[q * kWave + 4 * t + 2]);
-                    if ((own0 || own1) && (k & 1) && ((TP::T.anc[k] >> (k - 1)) & 1ull)) c2[k >> 1][0] -= lk[q] * cbuf[q * kWave + k - 1];
+                        c2[2 * t] -= l2 * ra; c2[(2 * t + 1 < NP2) ? 2 * t + 1 : 0] -= l2 * rb;
+                    } else if (on0) c2[2 * t] -= l2 * *reinterpret_cast<const R2*>(&cbuf[q * CS + 4 * t]);
+                    else if (on1) c2[(2 * t + 1 < NP2) ? 2 * t + 1 : 0] -= l2 * *reinterpret_cast<const R2*>(&cbuf[q * CS + 4 * t + 2]);
+                    if ((own0 || own1) && (k & 1) && ((TP::T.anc[k] >> (k - 1)) & 1ull)) c2[k >> 1][0] -= lk[q] * cbuf[q * CS + k - 1];
                 }
             }
             tree_elim<V + 1>(c2, hd, dinv, z);
@@ -1303,14 +1308,14 @@ struct EnvSim {
                 R2 acc2 = {(Real)0, (Real)0}, acc3 = acc2;
                 const Real* lc = &s.Lt[L::lcb(k)];                                // lc[i] = L_ik
 #pragma unroll
-                for (int t = (k >> 2); t < NP2 / 2; ++t) {      // quads of dofs: one 16-B broadcast read when both pairs hold a descendant of k
-                    const bool on0 = (2 * t > (k >> 1)) && ((TP::T.desc[k] >> (4 * t)) & 3ull), on1 = (2 * t + 1 > (k >> 1)) && ((TP::T.desc[k] >> (4 * t + 2)) & 3ull);
+                for (int t = (k >> 2); t < (NP2 + 1) / 2; ++t) {      // quads of dofs: one 16-B broadcast read when both pairs hold a descendant of k
+                    const bool on0 = (2 * t > (k >> 1)) && ((TP::T.desc[k] >> (4 * t)) & 3ull), on1 = (2 * t + 1 < NP2) && (2 * t + 1 > (k >> 1)) && ((TP::T.desc[k] >> (4 * t + 2)) & 3ull);
                     if (on0 && on1) {
                         const R4 r = *reinterpret_cast<const R4*>(&lc[4 * t]);
                         const R2 ra = {r[0], r[1]}, rb = {r[2], r[3]};
-                        acc2 += ra * y2[2 * t]; acc3 += rb * y2[2 * t + 1];
+                        acc2 += ra * y2[2 * t]; acc3 += rb * y2[(2 * t + 1 < NP2) ? 2 * t + 1 : 0];
                     } else if (on0) acc2 += *reinterpret_cast<const R2*>(&lc[4 * t]) * y2[2 * t];
-                    else if (on1) acc3 += *reinterpret_cast<const R2*>(&lc[4 * t + 2]) * y2[2 * t + 1];
+                    else if (on1) acc3 += *reinterpret_cast<const R2*>(&lc[4 * t + 2]) * y2[(2 * t + 1 < NP2) ? 2 * t + 1 : 0];
                 }
                 acc2 += acc3;
                 Real acc = raw - (acc2[0] + acc2[1]);
@@ -2451,6 +2456,10 @@ template <typename Real, typename C> struct StepWaves { static constexpr int val
 template <> struct StepWaves<float, ClsBiped> { static constexpr int value = 4; };
 template <> struct StepWaves<float, ClsLarge> { static constexpr int value = 2; };
 template <> struct StepWaves<float, ClsLargeTree> { static constexpr int value = 2; };
+#ifndef DM_BT_WAVES
+#define DM_BT_WAVES 4
+#endif
+template <> struct StepWaves<float, ClsBipedTree> { static constexpr int value = DM_BT_WAVES; };
 template <> struct StepWaves<float, ClsBipedObj> { static constexpr int value = 2; };
 #ifdef DM_EMU
 #define DM_WAVES_PER_EU(n)

@@ -387,11 +387,28 @@ struct CtxT : CtxBase {
             const char* tv = getenv("DM_TREE");
             if (same && !(tv && tv[0] == '0')) cls = 3;
         }
-        md.mdl_blob = (cls == 0 || cls == 2) ? build_mdl<ClsBiped>(&md.mdl_words) : build_mdl<ClsLarge>(&md.mdl_words);
+        // humanoid3d one character per wavefront (wave_packing 1): the same factor on its compiled topology.  The two-per-wave kernel (the
+        // default for this class) keeps the dense factor.
+        if (cls == 0 && (!duo || physics == 2 || (N % 2) != 0) && h.D == TopoHumanoid3d::N) {
+            std::vector<int> lam(h.D, -1);
+            for (int j = 0; j < h.J; ++j) {
+                int a = h.parent[j];
+                while (a >= 0 && h.ndof[a] == 0) a = h.parent[a];
+                for (int k = 0; k < h.ndof[j]; ++k) lam[h.dof_off[j] + k] = (k == 0) ? (a < 0 ? -1 : h.dof_off[a] + h.ndof[a] - 1) : h.dof_off[j] + k - 1;
+            }
+            bool same = true;
+            for (int k = 0; k < h.D; ++k) if (lam[k] != TopoHumanoid3d::PAR[k]) same = false;
+            // opt-in (DM_TREE_BIPED=1): on humanoid3d the sparse factor saves too little (154 of 289 packed FMAs per factorisation) to pay for
+            // the column build and the level bookkeeping inside a 128-VGPR budget -- measured 1.00 M env-steps/s at 4 waves / SIMD, 1.31 M
+            // at 2, against 1.66 M for the dense one-per-wave kernel and 2.06 M two-per-wave (same box, profiles/r03_ab_biped_tree.json)
+            const char* tv = getenv("DM_TREE_BIPED");
+            if (same && tv && tv[0] == '1') cls = 4;
+        }
+        md.mdl_blob = (cls == 0 || cls == 2 || cls == 4) ? build_mdl<ClsBiped>(&md.mdl_words) : build_mdl<ClsLarge>(&md.mdl_words);
         md.act_off = up<int>(h.act_off); md.diffw = up<Real>(h.diffw); md.aabb_he = up<Real>(h.aabb_he);
         md.cand_link = up<int>(h.cand_link); md.cand_loc = up<Real>(h.cand_loc); md.cand_rad = up<Real>(h.cand_rad);
         md.pair_code = up<int>(h.pair_code); md.NPAIR = (int)h.pair_code.size();
-        if (md.NPAIR > ((cls == 0 || cls == 2) ? ClsBiped::NPAIRCAP : ClsLarge::NPAIRCAP)) return fail("too many self-collision pairs for the compiled kernel classes");
+        if (md.NPAIR > ((cls == 0 || cls == 2 || cls == 4) ? ClsBiped::NPAIRCAP : ClsLarge::NPAIRCAP)) return fail("too many self-collision pairs for the compiled kernel classes");
         md.frame_time = up<double>(h.frame_time); md.frames = up<Real>(h.frames); md.frame_vel = up<Real>(h.frame_vel);
         md.duration = h.duration; md.loop = h.loop; for (int k = 0; k < 3; ++k) { md.cycle_delta[k] = (Real)h.cycle_delta[k]; md.gravity[k] = (Real)c.gravity[k]; }
         md.num_sim_substeps = c.num_sim_substeps; md.solver_iters = c.solver_iters > 0 ? c.solver_iters : 10; md.max_contacts = max_contacts;
@@ -408,7 +425,7 @@ struct CtxT : CtxBase {
         st.tau = (Real*)dalloc(sizeof(Real) * N * h.D); st.kin = (Real*)dalloc(sizeof(Real) * N * 8);
         st.clock = (double*)dalloc(sizeof(double) * N * 6); st.flag = (int*)dalloc(sizeof(int) * N * 4);
         // overflow rows of the constraint-space matrix (rows RREG..63 of a character with more than RREG rows in a substep)
-        { const int ovf = kMaxRows - ((cls == 0 || cls == 2) ? ClsBiped::RREG : ClsLarge::RREG); st.aovf = ovf > 0 ? (Real*)dalloc(sizeof(Real) * (size_t)N * ovf * kWave) : nullptr; }
+        { const int ovf = kMaxRows - ((cls == 0 || cls == 2 || cls == 4) ? ClsBiped::RREG : ClsLarge::RREG); st.aovf = ovf > 0 ? (Real*)dalloc(sizeof(Real) * (size_t)N * ovf * kWave) : nullptr; }
         st.obj = nullptr;
         if (cls == 2) {
             st.obj = (Real*)dalloc(sizeof(Real) * (size_t)N * OB_WIDTH);
@@ -506,6 +523,7 @@ struct CtxT : CtxBase {
         if (cls == 0) LAUNCH<Real, ClsBiped>(grid, stream, __VA_ARGS__);                         \
         else if (cls == 2) LAUNCH<Real, ClsBipedObj>(grid, stream, __VA_ARGS__);                 \
         else if (cls == 3) LAUNCH<Real, ClsLargeTree>(grid, stream, __VA_ARGS__);                \
+        else if (cls == 4) LAUNCH<Real, ClsBipedTree>(grid, stream, __VA_ARGS__);                \
         else LAUNCH<Real, ClsLarge>(grid, stream, __VA_ARGS__);                                  \
     } while (0)
 
@@ -526,6 +544,11 @@ struct CtxT : CtxBase {
         }
         // production launch: the tap-free instantiation unless a parity test armed the debug taps (dm_probe)
         if (cls == 2) { if (dbg.H) launch_step<Real, ClsBipedObj, SV_TAPS>(N, stream, md, st, io, dbg); else launch_step<Real, ClsBipedObj, SV_AMP>(N, stream, md, st, io, dbg); }
+        else if (cls == 4) {
+            if (dbg.H) launch_step<Real, ClsBipedTree, SV_TAPS>(N, stream, md, st, io, dbg);
+            else if (st.hist || st.pert || st.manif) launch_step<Real, ClsBipedTree, SV_AMP>(N, stream, md, st, io, dbg);
+            else launch_step<Real, ClsBipedTree, SV_PLAIN>(N, stream, md, st, io, dbg);
+        }
         else if (cls == 3) {
             if (dbg.H) launch_step<Real, ClsLargeTree, SV_TAPS>(N, stream, md, st, io, dbg);
             else if (st.hist || st.pert || st.manif) launch_step<Real, ClsLargeTree, SV_AMP>(N, stream, md, st, io, dbg);
@@ -538,7 +561,7 @@ struct CtxT : CtxBase {
     }
     int amp_expert(int n, const double* times_dev, const double* gh_dev, float* out_dev) override { return amp_expert_clips(n, nullptr, times_dev, gh_dev, out_dev); }
     int amp_expert_clips(int n, const int* clips_dev, const double* times_dev, const double* gh_dev, float* out_dev) override {
-        if (cls == 0 || cls == 2) launch_amp_expert<Real, ClsBiped>(n, stream, md, times_dev, gh_dev, out_dev, clips_dev);
+        if (cls == 0 || cls == 2 || cls == 4) launch_amp_expert<Real, ClsBiped>(n, stream, md, times_dev, gh_dev, out_dev, clips_dev);
         else launch_amp_expert<Real, ClsLarge>(n, stream, md, times_dev, gh_dev, out_dev, clips_dev);
         return 0;
     }
@@ -613,6 +636,7 @@ struct CtxT : CtxBase {
             else if (cls == 0) launch_step<Real, ClsBiped, SV_TAPS>(N, stream, md, st, io, d2);
             else if (cls == 2) launch_step<Real, ClsBipedObj, SV_TAPS>(N, stream, md, st, io, d2);
             else if (cls == 3) launch_step<Real, ClsLargeTree, SV_TAPS>(N, stream, md, st, io, d2);
+            else if (cls == 4) launch_step<Real, ClsBipedTree, SV_TAPS>(N, stream, md, st, io, d2);
             else launch_step<Real, ClsLarge, SV_TAPS>(N, stream, md, st, io, d2);
             return 0;
         }

@@ -55,14 +55,17 @@ void launch_amp_expert(unsigned grid, rt_stream s, const ModelDev<Real>& m, cons
 #define DM_FAMILY_8(Real) DM_INST_STEP(Real, ClsLarge, SV_TAPS)
 #define DM_FAMILY_9(Real) DM_INST_STEP(Real, ClsBipedObj, SV_AMP)
 #define DM_FAMILY_10(Real) DM_INST_STEP(Real, ClsBipedObj, SV_TAPS)
-#define DM_FAMILY_11(Real) DM_INST_MISC(Real, ClsBiped) DM_INST_MISC(Real, ClsBipedObj) DM_INST_MISC(Real, ClsLarge) DM_INST_MISC(Real, ClsLargeTree) DM_INST_EXPERT(Real, ClsBiped) DM_INST_EXPERT(Real, ClsLarge)
+#define DM_FAMILY_11(Real) DM_INST_MISC(Real, ClsBiped) DM_INST_MISC(Real, ClsBipedObj) DM_INST_MISC(Real, ClsLarge) DM_INST_MISC(Real, ClsLargeTree) DM_INST_MISC(Real, ClsBipedTree) DM_INST_EXPERT(Real, ClsBiped) DM_INST_EXPERT(Real, ClsLarge)
 #define DM_FAMILY_12(Real) DM_INST_STEP(Real, ClsLargeTree, SV_PLAIN)
 #define DM_FAMILY_13(Real) DM_INST_STEP(Real, ClsLargeTree, SV_AMP)
 #define DM_FAMILY_14(Real) DM_INST_STEP(Real, ClsLargeTree, SV_TAPS)
+#define DM_FAMILY_15(Real) DM_INST_STEP(Real, ClsBipedTree, SV_PLAIN)
+#define DM_FAMILY_16(Real) DM_INST_STEP(Real, ClsBipedTree, SV_AMP)
+#define DM_FAMILY_17(Real) DM_INST_STEP(Real, ClsBipedTree, SV_TAPS)
 
 #ifdef DM_TU_ALL
 #define DM_ALL(Real) DM_FAMILY_0(Real) DM_FAMILY_1(Real) DM_FAMILY_2(Real) DM_FAMILY_3(Real) DM_FAMILY_4(Real) DM_FAMILY_5(Real) \
-    DM_FAMILY_6(Real) DM_FAMILY_7(Real) DM_FAMILY_8(Real) DM_FAMILY_9(Real) DM_FAMILY_10(Real) DM_FAMILY_11(Real) DM_FAMILY_12(Real) DM_FAMILY_13(Real) DM_FAMILY_14(Real)
+    DM_FAMILY_6(Real) DM_FAMILY_7(Real) DM_FAMILY_8(Real) DM_FAMILY_9(Real) DM_FAMILY_10(Real) DM_FAMILY_11(Real) DM_FAMILY_12(Real) DM_FAMILY_13(Real) DM_FAMILY_14(Real) DM_FAMILY_15(Real) DM_FAMILY_16(Real) DM_FAMILY_17(Real)
 DM_ALL(float)
 DM_ALL(double)
 #else

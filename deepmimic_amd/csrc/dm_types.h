@@ -65,7 +65,7 @@ struct TopoTables {
     // aligned) at word colbase[j]; quadmask[t]: the lanes whose column holds rows 4t .. 4t + 3; lwords: words to allocate (with the slack
     // that keeps colbase[j] - 4 floor(j / 4) + 63 in range for the masked row reads)
     int colbase[N], colend[N], lwords;
-    uint64_t quadmask[N / 4];
+    uint64_t quadmask[(N + 3) / 4];
     int nlev, maxw;                    // levels; widest level
 };
 template <int N>
@@ -108,6 +108,15 @@ struct TopoDog3d {
                                     31, 32, 33, 34, 35, 36, 5, 38, 39, 40, 41, 42, 43, 44, 45, 46, 5, 48, 49, 50, 51, 52, 53, 54, 55, 56, 5, 58, 59, 60, 61, 62};
     static constexpr TopoTables<64> T = make_topo<64>(PAR);
 };
+// data/characters/humanoid3d.txt: root 6 | chest (neck; right / left shoulder 3 + elbow 1) | right / left hip 3, knee 1, ankle 3 off the root
+struct TopoHumanoid3d {
+    static constexpr int N = 34;
+    static constexpr int PAR[34] = {-1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 5, 12, 13, 14, 15, 16, 17, 8, 19, 20, 21, 5, 23, 24, 25, 26, 27, 28, 8, 30, 31, 32};
+    static constexpr TopoTables<34> T = make_topo<34>(PAR);
+};
+// the biped class on humanoid3d's compiled topology (one character per wavefront: `wave_packing 1`; the two-per-wave kernel keeps the dense
+// factor -- its 31 row lanes per character have no room for the root-translation columns, which an L^T L elimination finishes LAST)
+struct ClsBipedTree : ClsBiped { static constexpr bool TREE = true; typedef TopoHumanoid3d Topo; };
 // the large class on dog3d's compiled topology
 struct ClsLargeTree : ClsLarge { static constexpr bool TREE = true; typedef TopoDog3d Topo; static constexpr bool GRAM64 = true; static constexpr bool BROAD = true; };   // (more than 32 rows: Gram on the matrix core too)
 

@@ -1,0 +1,21 @@
+"""Same-box timing of several builds of libdm_hip.so (paths relative to the repo root) on one scene / wave packing.
+usage: python tools/gpu_ab_libs.py scene envs wave_packing lib [lib ...]"""
+import ctypes as C, json, os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from deepmimic_amd import core, model, streams  # noqa: E402
+scene, n, pack = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+t = model.load_asset(scene)
+envs = {}
+for p in sys.argv[4:]:
+    path = os.path.join(ROOT, p)
+    env = core.BatchEnv(t, n, seed=1234, test_mode=True, wave_packing=pack, lib_path=path)
+    env.reset(kin_times=streams.reset_phase(np.arange(n), env.duration))
+    env.bench_rollout(60, 1)
+    envs[p] = env
+res = {k: [] for k in envs}
+for rep in range(5):
+    for tag, env in envs.items():
+        res[tag].append(env.bench_rollout(0, 100) / 100)
+print(json.dumps({"scene": scene, "envs": n, "wave_packing": pack, **{tag: {"kernel_ms_median": float(np.median(v)), "env_steps_per_s": n / (float(np.median(v)) * 1e-3)} for tag, v in res.items()}}))

@@ -132,3 +132,14 @@ def test_episode_ends_at_the_update_of_the_fall(emu_lib, pack):
     dr, ds, alive, resets, ok = pc.auto_reset_rollout_compare("humanoid3d_walk", 64, emu_lib, steps=36, n=2, seed=7, wave_packing=pack)
     assert ok and resets >= 2, resets
     assert dr.max() < 1e-6 and ds.max() < 1e-5, (dr.max(), ds.max())
+
+
+def test_biped_tree_class_fp64(emu_lib, monkeypatch):
+    """ClsBipedTree: humanoid3d one per wavefront with the branch-sparse, level-scheduled factor on its compiled dof tree (opt-in,
+    DM_TREE_BIPED=1; profiles/r03_ab_biped_tree.json has the negative A/B): component and rollout parity as for the dense class"""
+    monkeypatch.setenv("DM_TREE_BIPED", "1")
+    pc.check_dynamics("humanoid3d_walk", 64, emu_lib, 1e-11)
+    pc.check_spd("humanoid3d_walk", 64, emu_lib, 1e-9)
+    pc.check_substep("humanoid3d_walk", 64, emu_lib, 1e-8, 1e-10, lift=-0.03)
+    dr, ds, ok = pc.rollout_compare("humanoid3d_walk", 64, emu_lib, steps=6)
+    assert ok and dr.max() < 1e-6 and ds.max() < 1e-5

@@ -80,7 +80,8 @@ def test_rollout_300_steps_live_through_resets(hip_lib, name, prec, pack):
     if prec == 64:
         assert live.mean() < 1e-5 and np.quantile(live, 0.9) < 1e-6 and ds.mean() < 2e-3
     else:
-        assert live.mean() < 1e-4 and np.quantile(live, 0.9) < 1e-4 and ds.mean() < 2e-2
+        # fixed bounds one notch above profiles/r03_parity_report.json (walk: MAE 5.4e-5, p99 1.1e-3, state mean 3.4e-3, p99 4.3e-2)
+        assert live.mean() < 1e-4 and np.quantile(live, 0.9) < 1e-4 and np.quantile(live, 0.99) < 3e-3 and ds.mean() < 1e-2 and np.quantile(ds, 0.99) < 0.1
 
 
 @pytest.mark.parametrize("name,prec,pack", LIVE_CASES)
@@ -194,7 +195,7 @@ def test_facade_protocol_matches_oracle(hip_lib):
 
 
 # ---- two characters per wavefront (dm_device_duo.h): same checks through the batch entry point
-@pytest.mark.parametrize("prec,tol_r,tol_s", [(64, 1e-6, 1e-5), (32, 1e-3, 0.5)])
+@pytest.mark.parametrize("prec,tol_r,tol_s", [(64, 1e-6, 1e-5), (32, 1e-3, 5e-2)])
 def test_duo_rollout_matches_oracle(hip_lib, prec, tol_r, tol_s):
     """10 free-running steps of six envs (three pairs); fp32: every env inside 1e-3, all but one inside 1e-4 (the env started at
     0.11 crosses a step on which a contact candidate sits on its activation threshold), mean inside 1e-4."""

@@ -30,16 +30,18 @@ if os.path.exists(os.path.join(src, "stats_policy", "stats_kernel_stats.csv")):
     with open(os.path.join(dst, out + "_rocprofv3_kernel_stats_closed_loop.csv"), "w", newline="") as f:
         csv.writer(f).writerows(rows[:12])
 # 2. bench lines and reports
-for name in ("bench.json", "bench_spinkick.json", "bench_dog.json", "bench_pack1.json", "bench_facade.json", "policy_bench.json", "policy_bench_16384.json",
+for name in ("bench.json", "bench_spinkick.json", "bench_dog.json", "bench_dog_dense.json", "bench_pack1.json", "bench_facade.json", "policy_bench.json", "policy_bench_16384.json",
+             "bench_amp_heading_zombie.json", "bench_amp_dribble_zombie.json", "bench_scenes.json",
              "parity_report.json", "tail_probe.txt", "tail_probe_closed_loop.txt", "bench_record_exchange_1rank.json", "bench_record_exchange_cabi_1rank.json"):
     if os.path.exists(os.path.join(src, name)) and os.path.getsize(os.path.join(src, name)) > 0:
         shutil.copy(os.path.join(src, name), os.path.join(dst, out + "_" + name))
-SCENES = [("humanoid3d_walk", ""), ("humanoid3d_spinkick", "_humanoid3d_spinkick"), ("dog3d_pace", "_dog3d_pace")]
+SCENES = [("humanoid3d_walk", ""), ("humanoid3d_spinkick", "_humanoid3d_spinkick"), ("dog3d_pace", "_dog3d_pace"),
+          ("amp_heading_zombie", "_amp_heading_zombie"), ("amp_dribble_zombie", "_amp_dribble_zombie")]
 summary = {}
 for scene, sfx in SCENES:
     if os.path.exists(os.path.join(src, "phases%s.json" % sfx)):
         shutil.copy(os.path.join(src, "phases%s.json" % sfx), os.path.join(dst, out + "_phase_cycles%s.json" % sfx))
-    bname = {"": "bench.json", "_humanoid3d_spinkick": "bench_spinkick.json", "_dog3d_pace": "bench_dog.json"}[sfx]
+    bname = {"": "bench.json", "_humanoid3d_spinkick": "bench_spinkick.json", "_dog3d_pace": "bench_dog.json"}.get(sfx, "bench%s.json" % sfx)
     b = json.load(open(os.path.join(src, bname)))
     n = b["config"]["envs_per_gpu"]
     # 3. PMC passes
@@ -78,4 +80,29 @@ for scene, sfx in SCENES:
         open(dstb, "w").write(json.dumps(_b) + "\n")
     except Exception as ex:
         print("traffic of", scene, "skipped:", ex)
+# 5. counted fp32 arithmetic of the headline kernel (SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F32, SQ_INSTS_VALU_MFMA_MOPS_*: wave-level instruction
+# counts; a wave instruction is 64 lane operations, an FMA two flops, one MFMA "MOP" 512 flops)
+try:
+    a = agg(os.path.join(src, "pmc_flops", "pmc_counter_collection.csv"))
+    b = json.load(open(os.path.join(src, "bench.json")))
+    n = b["config"]["envs_per_gpu"]
+    m = {k: float(np.mean([v[k] for v in a])) / n for k in a[0] if k != "dur_ns"}
+    valu = 64.0 * (m["SQ_INSTS_VALU_ADD_F32"] + m["SQ_INSTS_VALU_MUL_F32"] + 2 * m["SQ_INSTS_VALU_FMA_F32"] + m["SQ_INSTS_VALU_TRANS_F32"])
+    mfma = 512.0 * (m["SQ_INSTS_VALU_MFMA_MOPS_F32"] + m["SQ_INSTS_VALU_MFMA_MOPS_F64"])
+    rate = b["value"]
+    json.dump({"scene": "humanoid3d_walk", "envs": n, "kernel": b["roofline"]["kernel"], "per_env_step_wave_instructions": m,
+               "issued_fp32_valu_lane_flops_per_env_step": valu, "matrix_core_flops_per_env_step": mfma,
+               "issued_flops_per_env_step": valu + mfma, "env_steps_per_s": rate,
+               "issued_tflops": (valu + mfma) * rate / 1e12, "valu_tflops": valu * rate / 1e12,
+               "fraction_of_fp32_vector_peak_157_3": (valu + mfma) * rate / 157.3e12,
+               "note": "ISSUED lane operations (all 64 lanes of every fp32 VALU instruction, masked / idle lanes included; v_pk_fma_f32 counted once "
+                       "by the counter, i.e. a lower bound on packed work): an upper bound on useful flops per env-step (SURVEY 8d estimated 7 M useful)"},
+              open(os.path.join(dst, out + "_flops.json"), "w"), indent=1)
+    summary["flops"] = valu + mfma
+except Exception as ex:
+    print("flop counters skipped:", ex)
+if os.path.exists(os.path.join(src, "stats_dog", "stats_kernel_stats.csv")):
+    rows = list(csv.reader(open(os.path.join(src, "stats_dog", "stats_kernel_stats.csv"))))
+    with open(os.path.join(dst, out + "_rocprofv3_kernel_stats_dog3d_pace.csv"), "w", newline="") as f:
+        csv.writer(f).writerows(rows[:6])
 print(json.dumps(summary, indent=1))

@@ -210,6 +210,7 @@ def main():
     ap.add_argument("--scene", default="humanoid3d_walk")
     ap.add_argument("--precision", type=int, default=32)
     ap.add_argument("--wave-packing", type=int, default=0, help="characters per wavefront of the step kernel: 0 = the library's default (2 for the biped class, 1 for the dog and for dribble_amp), 1 or 2")
+    ap.add_argument("--physics", type=int, default=1, choices=[1, 2], help="contact model: 1 = DM-physics v1 (default, the headline), 2 = v2 (DESIGN.md 4.6; one character per wavefront)")
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--force-gather", action="store_true", help="exercise the record exchange even with one rank")
     ap.add_argument("--gather", choices=["torch", "cabi"], default="torch",
@@ -271,7 +272,7 @@ def main():
     tables = model.load_asset(args.scene)
     n = args.envs
     env = BatchEnv(tables, n, device_id=local_rank if on_gpu else 0, seed=1234, precision=args.precision, env_id_offset=rank * n, test_mode=True,
-                   wave_packing=args.wave_packing)
+                   wave_packing=1 if args.physics == 2 else args.wave_packing, physics=args.physics)
     if on_gpu:
         env.set_stream(torch.cuda.current_stream().cuda_stream)
     # deterministic per-env start phase keyed by the global env id; later episodes draw from the device's
@@ -356,7 +357,7 @@ def main():
         if world != args.gpus or len(per_rank) != args.gpus:
             raise SystemExit("bench.py: ran %d rank(s) with %d per-rank rate(s) under --gpus %d" % (world, len(per_rank), args.gpus))
         bytes_per_launch = algorithmic_bytes_per_env_step(env) * n
-        kname = "k_env_step_duo" if (args.wave_packing != 1 and env.J <= 15 and env.D == 34 and n % 2 == 0 and tables.goal_kind != 5) else "k_env_step"
+        kname = "k_env_step_duo" if (args.wave_packing != 1 and args.physics == 1 and env.J <= 15 and env.D == 34 and n % 2 == 0 and tables.goal_kind != 5) else "k_env_step"
         achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else None      # (the emulator has no HIP events)
         traffic, traffic_source = measured_traffic(args.scene, n, kname)
         value = world * n * args.steps / elapsed
@@ -371,7 +372,7 @@ def main():
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32" if args.precision == 32 else "f64", "data": "synthetic",
-            "config": {"workload": workload, "envs_per_gpu": n, "envs_total": world * n, "backend": "rccl" if on_gpu else "gloo + CPU emulator (test harness, not a measurement)", "wave_packing": args.wave_packing, "warmup_steps_run": warm, "parallelism": "env-shards x%d%s" % (world, " + async RCCL all-gather of the record, overlapped with the next step" if gather else "")},
+            "config": {"workload": workload, "envs_per_gpu": n, "envs_total": world * n, "backend": "rccl" if on_gpu else "gloo + CPU emulator (test harness, not a measurement)", "wave_packing": args.wave_packing, "physics": args.physics, "warmup_steps_run": warm, "parallelism": "env-shards x%d%s" % (world, " + async RCCL all-gather of the record, overlapped with the next step" if gather else "")},
             "sim_updates_per_s": value * 20,
             "per_rank_env_steps_per_s": per_rank, "record_exchange": {"backend": (args.gather if gather else None), "exposed_ms_per_step_rank0": exposed_ms},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None,

@@ -99,10 +99,12 @@ class cDeepMimicCore(object):
             self.stats = {"launches": 0, "updates": 0, "rollbacks": 0}
             return
         self._env = _BatchEnv(self._tables, 1, device_id=int(os.environ.get("DM_DEVICE", "0")), seed=self._seed,
-                              precision=int(os.environ.get("DM_PRECISION", "32")), lib_path=os.environ.get("DM_HIP_LIB"))
+                              precision=int(os.environ.get("DM_PRECISION", "32")), lib_path=os.environ.get("DM_HIP_LIB"),
+                              physics=int(os.environ.get("DM_PHYSICS", "1")))
         self._off = self._env.offsets_scales()
         self._apply_mode()
-        self._batch = os.environ.get("DM_FACADE_BATCH", "1") != "0"
+        # (DM-physics v2: the ground manifolds are device state outside the snapshot the batched step rolls back to, so v2 steps update by update)
+        self._batch = os.environ.get("DM_FACADE_BATCH", "1") != "0" and self._env.physics != 2
         self._period = 1.0 / float(self._tables.query_rate)
         self.stats = {"launches": 0, "updates": 0, "rollbacks": 0}     # kernel launches of the stepping path vs Update() calls
         self._build_time_warper()

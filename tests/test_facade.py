@@ -69,6 +69,21 @@ def test_facade_protocol_emulator(emu_lib, monkeypatch):
         mod.cDeepMimicCore(True)
 
 
+def test_facade_protocol_physics_v2_emulator(emu_lib, monkeypatch):
+    """DM_PHYSICS=2: the same driver protocol against the oracle under cfg.physics = 2"""
+    from deepmimic_amd import model
+    from oracle_lib import Oracle
+    monkeypatch.setenv("DM_HIP_LIB", emu_lib); monkeypatch.setenv("DM_PRECISION", "64"); monkeypatch.setenv("DM_PHYSICS", "2")
+    mod = _core_module()
+    t = model.load_asset("humanoid3d_walk")
+    core = mod.cDeepMimicCore(False)
+    core.SeedRand(5); core.LoadTables(t, num_update_substeps=10); core.Init()
+    assert core._env.physics == 2 and not core._batch
+    kin_t = float(core._env.get_state()["clocks"][0][0])
+    o = Oracle(t, physics=2, max_contacts=core._env.max_contacts); o.reset(kin_t)
+    assert _run_protocol(core, o, 41, np.random.default_rng(0)) == 3
+
+
 @pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "env")), reason="reference checkout not present")
 def test_reference_env_wrapper_runs_unmodified(emu_lib, monkeypatch):
     """The reference's own env/deepmimic_env.py (imported from /root/reference, unmodified) on top of the facade."""

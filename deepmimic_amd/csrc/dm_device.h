@@ -31,6 +31,7 @@ static inline long long dm_clock() { return 0; }
 #define DM_DEV inline
 #define DM_OPAQUE_S(x) ((void)0)
 #define DM_OPAQUE_V(x) ((void)0)
+#define DM_OPAQUE_D(x) ((void)0)
 #define DM_SCHED_FENCE() ((void)0)
 static inline int dm_atomic_or(int* p, int v) { int o = *p; *p = o | v; return o; }
 static inline int dm_popc64(uint64_t v) { return __builtin_popcountll(v); }
@@ -93,6 +94,9 @@ template <> struct VecT<double> { typedef double v2 __attribute__((vector_size(1
 // hundreds of compare masks an unrolled sweep would otherwise keep live (and spill)
 #define DM_OPAQUE_S(x) asm volatile("" : "+s"(x))
 #define DM_OPAQUE_V(x) asm volatile("" : "+v"(x))
+// a double (or pointer) pinned where it stands: keeps the optimizer from hoisting the rare-path f64 arithmetic on scene parameters
+// (range widths of the random draws, ...) out of the 20-update loop into VGPR pairs that then live -- and spill -- across the whole kernel
+#define DM_OPAQUE_D(x) asm volatile("" : "+v"(x))
 // nothing is scheduled across this point (keeps the rank-1 updates of one Cholesky column next to the loads that feed them)
 #define DM_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 __device__ __forceinline__ long long dm_clock() { return (long long)__builtin_readcyclecounter(); }
@@ -784,7 +788,7 @@ struct EnvSim {
                 const Real ik = lane_bcast(inv, k);
                 const Real x = c2[k >> 1][k & 1] * ik;
                 c2[k >> 1][k & 1] = x; lk[q] = x;
-                if (TP::T.anc[k] != 0 && l < ND) cbuf[q * CS + l] = x;
+                if (TP::T.anc[k] != 0 && (ND >= kWave || l < ND)) cbuf[q * CS + l] = x;       // (no lane test when every lane is a dof: a divergent store here makes the optimizer sink the level's arithmetic behind it)
             }
             sync();
 #pragma unroll
@@ -1636,7 +1640,7 @@ struct EnvSim {
     // dynamics / Cholesky code (the instruction stream of the 20-update loop must fit the instruction cache).
     // reuse_kin: pose / vel are unchanged since the previous phase's kinematics (stable-PD solve -> first substep); only
     // the base acceleration differs, and it enters every joint-origin acceleration as the same additive constant.
-    template <bool PERT = false, bool V2 = PERT>
+    template <bool PERT = false, bool V2 = false>
     DM_DEV void dyn_phase(int ph, Real dt, Real h, DebugTaps<Real> dbg, int e, bool tap_only, bool reuse_kin, Real* aovf, const double* pert = nullptr, Real* manif = nullptr) {
         // lane id / link word are re-materialised per phase: keeps the optimizer from hoisting every per-lane LDS address
         // out of the 20-update loop (dozens of long-lived VGPRs that end up in scratch)
@@ -1673,13 +1677,13 @@ struct EnvSim {
         if (ph == 0) { mark(3); spd_post(dt); }
         else substep_post<V2>(h, dbg, e, aovf, manif);
     }
-    template <bool PERT = false>
+    template <bool PERT = false, bool V2 = false>
     DM_DEV void update(double dt, DebugTaps<Real> dbg, int e, Real* aovf, double* pert = nullptr, Real* manif = nullptr) {
         if (l == 0) { s.clk[CLK_TIMER] += dt; s.clk[CLK_CTRL] += dt; s.flg[FLG_NEED_ACTION] = 0; }
         if (PERT && pert) { if (l == 0) pert_tick(pert, e, dt); sync(); }
         kin_update(dt);
         const Real h = (Real)(dt / m.num_sim_substeps);
-        for (int ph = 0; ph <= m.num_sim_substeps; ++ph) dyn_phase<PERT>(ph, (Real)dt, h, dbg, e, false, ph == 1, aovf, pert, manif);
+        for (int ph = 0; ph <= m.num_sim_substeps; ++ph) dyn_phase<PERT, V2>(ph, (Real)dt, h, dbg, e, false, ph == 1, aovf, pert, V2 ? manif : nullptr);
         if (l == 0) {                      // cCtController::CheckNeedNewAction (CtController.cpp:221-227)
             double cur = s.clk[CLK_CTRL] + s.clk[CLK_INIT_OFF], pad = 0.001 * dt;
             int c1 = (int)floor((cur + pad) / m.query_period), c0 = (int)floor((cur + pad - dt) / m.query_period);
@@ -1946,7 +1950,7 @@ struct EnvSim {
     // handed to the dof lanes through s.sc[0..6] (free inside the update loop).  Draws: dm_rand01(seed, global env id, draw counter,
     // stream 5), the counter kept in the row.  Compiled into the AMP / tap instantiations of the kernels only.
     DM_DEV double pert_u01(double* p, int e) const { const double u = dm_rand01(m.seed, (uint64_t)(e + m.env_off), (uint64_t)p[PT_DRAWS], 5); p[PT_DRAWS] += 1; return u; }
-    DM_DEV double pert_uniform(double* p, int e, double lo, double hi) const { const double u = pert_u01(p, e); return (hi > lo && hi < 1e300) ? lo + (hi - lo) * u : hi; }
+    DM_DEV double pert_uniform(double* p, int e, double lo, double hi) const { const double u = pert_u01(p, e); DM_OPAQUE_D(lo); DM_OPAQUE_D(hi); return (hi > lo && hi < 1e300) ? lo + (hi - lo) * u : hi; }
     // ResetRandPertrub (timer := 0, next := U[time_min, time_max]) and cWorld::Reset -> mPerturbManager.Clear(); lane 0
     DM_DEV void pert_reset(double* p, int e) const {
         p[PT_TIMER] = 0; p[PT_NEXT] = pert_uniform(p, e, m.perturb_time_min, m.perturb_time_max);
@@ -2013,7 +2017,7 @@ struct EnvSim {
     // std::default_random_engine (cRand); here every draw is dm_rand01(seed, global env id, draw counter, stream 2), the counter
     // kept in the goal row, so that a trajectory depends neither on the batch nor on the partition.
     DM_DEV double goal_u01(double* g, int e) const { const double u = dm_rand01(m.seed, (uint64_t)(e + m.env_off), (uint64_t)g[GS_DRAWS], 2); g[GS_DRAWS] += 1; return u; }
-    DM_DEV double goal_uniform(double* g, int e, double lo, double hi) const { return lo + (hi - lo) * goal_u01(g, e); }       // cRand::RandDouble(min, max)
+    DM_DEV double goal_uniform(double* g, int e, double lo, double hi) const { const double u = goal_u01(g, e); DM_OPAQUE_D(lo); DM_OPAQUE_D(hi); return lo + (hi - lo) * u; }       // cRand::RandDouble(min, max)
     DM_DEV double goal_normal(double* g, int e, double mean, double stdev) const {                                              // cRand::RandDoubleNorm: Box-Muller here
         const double u1 = 1.0 - goal_u01(g, e), u2 = goal_u01(g, e);
         return mean + stdev * sqrt(-2.0 * log(u1)) * cos(6.283185307179586 * u2);
@@ -2468,9 +2472,10 @@ template <> struct StepWaves<float, ClsBipedObj> { static constexpr int value = 
 #endif
 // AMP: the `--scene imitate_amp` instantiation (pose history latch inside the update loop, AMP observation at the end); the
 // plain production kernel carries none of it.  The tap build (tests, profiling) serves both scene kinds.
-template <typename Real, typename C, bool TAPS, bool AMP = false>
+// PHYS2: DM-physics v2 -- its own instantiation, so that the AMP kernels of the shipped scenes do not carry it
+template <typename Real, typename C, bool TAPS, bool AMP = false, bool PHYS2 = false>
 __global__ void __launch_bounds__(64) DM_WAVES_PER_EU((StepWaves<Real, C>::value)) k_env_step(ModelDev<Real> m, EnvState<Real> st, StepIO<Real> io, DebugTaps<Real> dbg) {
-    constexpr bool HIST = TAPS || AMP;
+    constexpr bool HIST = TAPS || AMP, V2 = TAPS || PHYS2;
     __shared__ Lds<Real, C> lds;
     const int e = blockIdx.x, l = threadIdx.x;
     EnvSim<Real, C, TAPS> sim(m, lds, l);
@@ -2482,13 +2487,17 @@ __global__ void __launch_bounds__(64) DM_WAVES_PER_EU((StepWaves<Real, C>::value
     Real* aovf = st.aovf ? st.aovf + (size_t)e * (kMaxRows - C::RREG) * kWave : nullptr;
     const bool goal = HIST && st.goal && m.scene_goal;
     double* pert = (HIST && st.pert) ? st.pert + (size_t)e * PT_WIDTH : nullptr;      // enable_rand_perturbs
-    Real* manif = (HIST && st.manif) ? st.manif + (size_t)e * m.J * MF_STRIDE : nullptr;   // physics 2
+    Real* manif = (V2 && st.manif) ? st.manif + (size_t)e * m.J * MF_STRIDE : nullptr;   // physics 2
     if (goal) sim.goal_sync_flags(st, e);
     for (int u = 0; u < io.n_updates; ++u) {
-        if (HIST && st.hist) sim.latch_hist(st, e);
-        if (goal) sim.goal_latch(st, e, io.dt);
-        sim.template update<HIST>(io.dt, dbg, e, aovf, pert, manif);
-        if (goal) sim.goal_update(st, e, io.dt);
+        // (AMP / tap builds: the env id is re-materialised per update, so the per-env HBM addresses of the rare paths -- history row, goal
+        // row, perturbation state -- and the keys of their counter-based draws are formed where they are used instead of living across the loop)
+        int eo = e; if (HIST) DM_OPAQUE_S(eo);
+        double* po = (HIST && st.pert) ? st.pert + (size_t)eo * PT_WIDTH : nullptr;
+        if (HIST && st.hist) sim.latch_hist(st, eo);
+        if (goal) sim.goal_latch(st, eo, io.dt);
+        sim.template update<HIST, V2>(io.dt, dbg, eo, aovf, po, manif);
+        if (goal) sim.goal_update(st, eo, io.dt);
         if (io.end_early && lds.flg[FLG_OVER]) break;           // wave-uniform: latched by lane 0 at the end of update()
     }
     if (io.emit) {
@@ -2512,7 +2521,7 @@ __global__ void __launch_bounds__(64) DM_WAVES_PER_EU((StepWaves<Real, C>::value
             else {
                 double kt = m.duration * dm_rand01(m.seed, (uint64_t)(e + m.env_off), ep, 0);
                 sim.reset_env(kt, mt);
-                if (HIST) sim.manif_clear(st, e);
+                if (V2) sim.manif_clear(st, e);
                 if (HIST && st.hist) sim.init_hist(st, e);
             }
             if (HIST && pert && !rec && l == 0) sim.pert_reset(pert, e);      // ResetScene -> ResetRandPertrub; a recovery episode only resets the timers

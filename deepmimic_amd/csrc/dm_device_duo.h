@@ -674,10 +674,12 @@ __global__ void __launch_bounds__(64) DM_WAVES_PER_EU((DuoWaves<Real>::value)) k
     double* pert = (HIST && st.pert) ? st.pert + (size_t)e * PT_WIDTH : nullptr;
     if (goal) sim.b.goal_sync_flags(st, e);
     for (int u = 0; u < io.n_updates; ++u) {
-        if (HIST && st.hist) sim.b.latch_hist(st, e, lds[half].flg[FLG_PARKED] == 0);
-        if (goal) sim.b.goal_latch(st, e, io.dt, lds[half].flg[FLG_PARKED] == 0);
-        sim.template update<HIST>(io.dt, e, aovf_pair, pert);
-        if (goal) sim.b.goal_update(st, e, io.dt, lds[half].flg[FLG_PARKED] == 0);      // the update that ends an episode includes its goal update
+        int eo = e; if (HIST) DM_OPAQUE_V(eo);          // see k_env_step: per-env addresses and draw keys of the rare paths are formed at their use
+        double* po = (HIST && st.pert) ? st.pert + (size_t)eo * PT_WIDTH : nullptr;
+        if (HIST && st.hist) sim.b.latch_hist(st, eo, lds[half].flg[FLG_PARKED] == 0);
+        if (goal) sim.b.goal_latch(st, eo, io.dt, lds[half].flg[FLG_PARKED] == 0);
+        sim.template update<HIST>(io.dt, eo, aovf_pair, po);
+        if (goal) sim.b.goal_update(st, eo, io.dt, lds[half].flg[FLG_PARKED] == 0);      // the update that ends an episode includes its goal update
         if (io.end_early) {
             // DM_END_EPISODE_EARLY.  FLG_OVER is latched by each character's lane 0 at the end of update() (wave-uniform reads).
             // Both over: the wave is done.  One over (a few percent of the waves of a launch): what the outputs need of its record

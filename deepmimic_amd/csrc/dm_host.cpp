@@ -546,16 +546,19 @@ struct CtxT : CtxBase {
         if (cls == 2) { if (dbg.H) launch_step<Real, ClsBipedObj, SV_TAPS>(N, stream, md, st, io, dbg); else launch_step<Real, ClsBipedObj, SV_AMP>(N, stream, md, st, io, dbg); }
         else if (cls == 4) {
             if (dbg.H) launch_step<Real, ClsBipedTree, SV_TAPS>(N, stream, md, st, io, dbg);
-            else if (st.hist || st.pert || st.manif) launch_step<Real, ClsBipedTree, SV_AMP>(N, stream, md, st, io, dbg);
+            else if (st.manif) launch_step<Real, ClsBipedTree, SV_V2>(N, stream, md, st, io, dbg);
+            else if (st.hist || st.pert) launch_step<Real, ClsBipedTree, SV_AMP>(N, stream, md, st, io, dbg);
             else launch_step<Real, ClsBipedTree, SV_PLAIN>(N, stream, md, st, io, dbg);
         }
         else if (cls == 3) {
             if (dbg.H) launch_step<Real, ClsLargeTree, SV_TAPS>(N, stream, md, st, io, dbg);
-            else if (st.hist || st.pert || st.manif) launch_step<Real, ClsLargeTree, SV_AMP>(N, stream, md, st, io, dbg);
+            else if (st.manif) launch_step<Real, ClsLargeTree, SV_V2>(N, stream, md, st, io, dbg);
+            else if (st.hist || st.pert) launch_step<Real, ClsLargeTree, SV_AMP>(N, stream, md, st, io, dbg);
             else launch_step<Real, ClsLargeTree, SV_PLAIN>(N, stream, md, st, io, dbg);
         }
         else if (dbg.H) { if (cls == 0) launch_step<Real, ClsBiped, SV_TAPS>(N, stream, md, st, io, dbg); else launch_step<Real, ClsLarge, SV_TAPS>(N, stream, md, st, io, dbg); }
-        else if (st.hist || st.pert || st.manif) { if (cls == 0) launch_step<Real, ClsBiped, SV_AMP>(N, stream, md, st, io, dbg); else launch_step<Real, ClsLarge, SV_AMP>(N, stream, md, st, io, dbg); }
+        else if (st.manif) { if (cls == 0) launch_step<Real, ClsBiped, SV_V2>(N, stream, md, st, io, dbg); else launch_step<Real, ClsLarge, SV_V2>(N, stream, md, st, io, dbg); }      // DM-physics v2: its own instantiation (AMP code + manifolds)
+        else if (st.hist || st.pert) { if (cls == 0) launch_step<Real, ClsBiped, SV_AMP>(N, stream, md, st, io, dbg); else launch_step<Real, ClsLarge, SV_AMP>(N, stream, md, st, io, dbg); }
         else { if (cls == 0) launch_step<Real, ClsBiped, SV_PLAIN>(N, stream, md, st, io, dbg); else launch_step<Real, ClsLarge, SV_PLAIN>(N, stream, md, st, io, dbg); }
         return 0;
     }

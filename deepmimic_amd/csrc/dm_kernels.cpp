@@ -13,7 +13,7 @@ void launch_step_duo(unsigned grid, rt_stream s, const ModelDev<Real>& m, const 
 }
 template <typename Real, typename C, int V>
 void launch_step(unsigned grid, rt_stream s, const ModelDev<Real>& m, const EnvState<Real>& st, const StepIO<Real>& io, const DebugTaps<Real>& dbg) {
-    RT_LAUNCH((k_env_step<Real, C, V == SV_TAPS, V == SV_AMP>), grid, s, m, st, io, dbg);
+    RT_LAUNCH((k_env_step<Real, C, V == SV_TAPS, V == SV_AMP || V == SV_V2, V == SV_V2>), grid, s, m, st, io, dbg);
 }
 template <typename Real, typename C>
 void launch_reset(unsigned grid, rt_stream s, const ModelDev<Real>& m, const EnvState<Real>& st, const int* env_ids, const double* kin_times, const double* max_times) {
@@ -62,10 +62,14 @@ void launch_amp_expert(unsigned grid, rt_stream s, const ModelDev<Real>& m, cons
 #define DM_FAMILY_15(Real) DM_INST_STEP(Real, ClsBipedTree, SV_PLAIN)
 #define DM_FAMILY_16(Real) DM_INST_STEP(Real, ClsBipedTree, SV_AMP)
 #define DM_FAMILY_17(Real) DM_INST_STEP(Real, ClsBipedTree, SV_TAPS)
+#define DM_FAMILY_18(Real) DM_INST_STEP(Real, ClsBiped, SV_V2)
+#define DM_FAMILY_19(Real) DM_INST_STEP(Real, ClsLarge, SV_V2)
+#define DM_FAMILY_20(Real) DM_INST_STEP(Real, ClsLargeTree, SV_V2)
+#define DM_FAMILY_21(Real) DM_INST_STEP(Real, ClsBipedTree, SV_V2)
 
 #ifdef DM_TU_ALL
 #define DM_ALL(Real) DM_FAMILY_0(Real) DM_FAMILY_1(Real) DM_FAMILY_2(Real) DM_FAMILY_3(Real) DM_FAMILY_4(Real) DM_FAMILY_5(Real) \
-    DM_FAMILY_6(Real) DM_FAMILY_7(Real) DM_FAMILY_8(Real) DM_FAMILY_9(Real) DM_FAMILY_10(Real) DM_FAMILY_11(Real) DM_FAMILY_12(Real) DM_FAMILY_13(Real) DM_FAMILY_14(Real) DM_FAMILY_15(Real) DM_FAMILY_16(Real) DM_FAMILY_17(Real)
+    DM_FAMILY_6(Real) DM_FAMILY_7(Real) DM_FAMILY_8(Real) DM_FAMILY_9(Real) DM_FAMILY_10(Real) DM_FAMILY_11(Real) DM_FAMILY_12(Real) DM_FAMILY_13(Real) DM_FAMILY_14(Real) DM_FAMILY_15(Real) DM_FAMILY_16(Real) DM_FAMILY_17(Real) DM_FAMILY_18(Real) DM_FAMILY_19(Real) DM_FAMILY_20(Real) DM_FAMILY_21(Real)
 DM_ALL(float)
 DM_ALL(double)
 #else

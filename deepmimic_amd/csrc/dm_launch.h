@@ -22,7 +22,7 @@ typedef hipStream_t rt_stream;
 namespace dmk {
 
 // step-kernel variants: the plain production instantiation, the AMP / goal / perturbation instantiation, the tap build
-enum { SV_PLAIN = 0, SV_AMP = 1, SV_TAPS = 2 };
+enum { SV_PLAIN = 0, SV_AMP = 1, SV_TAPS = 2, SV_V2 = 3 };      // SV_V2: the AMP instantiation + DM-physics v2 (one character per wavefront only)
 
 template <typename Real, int V>
 void launch_step_duo(unsigned grid, rt_stream s, const ModelDev<Real>& m, const EnvState<Real>& st, const StepIO<Real>& io, const DebugTaps<Real>& dbg);

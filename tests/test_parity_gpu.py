@@ -195,15 +195,17 @@ def test_facade_protocol_matches_oracle(hip_lib):
 
 
 # ---- two characters per wavefront (dm_device_duo.h): same checks through the batch entry point
-@pytest.mark.parametrize("prec,tol_r,tol_s", [(64, 1e-6, 1e-5), (32, 1e-3, 5e-2)])
+@pytest.mark.parametrize("prec,tol_r,tol_s", [(64, 1e-6, 1e-5), (32, 1e-3, 0.5)])
 def test_duo_rollout_matches_oracle(hip_lib, prec, tol_r, tol_s):
     """10 free-running steps of six envs (three pairs); fp32: every env inside 1e-3, all but one inside 1e-4 (the env started at
-    0.11 crosses a step on which a contact candidate sits on its activation threshold), mean inside 1e-4."""
+    0.11 crosses a control step over which the contact problem amplifies its input by > 1e4: profiles/r03_fp32_outlier_diagnosis.json --
+    that env sets the maxima, reward 1e-3 / state 0.5), mean inside 1e-4; the other five envs hold the state vector to 5e-2."""
     t0s = [0.0, 0.37, 0.8, 0.11, 0.5, 0.9]
     dr, ds, ok = pc.batch_rollout_compare("humanoid3d_walk", prec, hip_lib, steps=10, t0s=t0s, wave_packing=2)
     assert ok and dr.max() < tol_r and ds.max() < tol_s, (dr, ds)
     if prec == 32:
         assert np.sort(dr)[-2] < 1e-4 and dr.mean() < 1e-4, dr
+        assert np.sort(ds)[-2] < 5e-2, ds
 
 
 def test_duo_heavy_contact_fallback(hip_lib):

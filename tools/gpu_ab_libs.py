@@ -1,5 +1,5 @@
 """Same-box timing of several builds of libdm_hip.so (paths relative to the repo root) on one scene / wave packing.
-usage: python tools/gpu_ab_libs.py scene envs wave_packing lib [lib ...]"""
+usage: [DM_AB_AMP=1] python tools/gpu_ab_libs.py scene envs wave_packing lib [lib ...]"""
 import ctypes as C, json, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -7,6 +7,7 @@ sys.path.insert(0, ROOT)
 from deepmimic_amd import core, model, streams  # noqa: E402
 scene, n, pack = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
 t = model.load_asset(scene)
+if os.environ.get("DM_AB_AMP") == "1": t.cfg.scene = "imitate_amp"          # the same asset as --scene imitate_amp (AMP instantiation of the kernel)
 envs = {}
 for p in sys.argv[4:]:
     path = os.path.join(ROOT, p)

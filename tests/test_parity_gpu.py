@@ -89,8 +89,8 @@ def test_stepwise_300_steps_live(hip_lib, name, prec, pack):
     """teacher-forced: each of 300 x 8 control steps (20 updates, 40 substeps) starts from the oracle's state; live steps only.
     This is the per-step precision of the kernels.  Fixed bounds -- fp32 production kernels: reward MAE < 1e-5 (measured
     3.4e-6), 99th percentile < 1e-4 (3.2e-5), fewer than 1 % of steps beyond 1e-4 (0.56 %), maximum < 5e-3 (1.1e-3 walk,
-    3.9e-3 dog: a contact candidate crosses its activation threshold inside the step and the two sides pick different
-    manifolds -- the fp64 build has the same kind of step at 2.7e-4); state vector: mean relative error < 5e-3, 99th
+    3.5e-3 dog: states at which one control step of the contact problem amplifies its input by 1e4 ... 5e6 -- rows and contacts agree
+    at every update of every such step, profiles/r03_fp32_outlier_diagnosis.json; the fp64 build has the same kind of step at 2.7e-4); state vector: mean relative error < 5e-3, 99th
     percentile < 5e-2.  fp64 algorithm build: MAE < 1e-6, 99th percentile < 1e-6, maximum < 1e-3."""
     dr, ds, alive, ok = pc.stepwise_live_compare(name, prec, hip_lib, steps=300, n=8, seed=12, wave_packing=pack)
     live, sl = dr[alive], ds[alive]

@@ -2464,7 +2464,10 @@ template <> struct StepWaves<float, ClsLargeTree> { static constexpr int value =
 #define DM_BT_WAVES 4
 #endif
 template <> struct StepWaves<float, ClsBipedTree> { static constexpr int value = DM_BT_WAVES; };
-template <> struct StepWaves<float, ClsBipedObj> { static constexpr int value = 2; };
+#ifndef DM_OBJ_WAVES
+#define DM_OBJ_WAVES 2
+#endif
+template <> struct StepWaves<float, ClsBipedObj> { static constexpr int value = DM_OBJ_WAVES; };
 #ifdef DM_EMU
 #define DM_WAVES_PER_EU(n)
 #else

@@ -24,7 +24,7 @@ SRCS="util/MathUtil util/Rand util/JsonUtil util/FileUtil util/Timer util/Anneal
       sim/Controller sim/CharController sim/DeepMimicCharController sim/CtController sim/CtPDController
       sim/PDController sim/ExpPDController sim/ImpPDController sim/AgentRegistry util/IndexManager
       scenes/Scene scenes/RLScene scenes/SceneSimChar scenes/RLSceneSimChar scenes/SceneImitate scenes/SceneImitateAMP
-      scenes/SceneHeadingAMP scenes/SceneTargetAMP scenes/SceneStrikeAMP scenes/SceneDribbleAMP"
+      scenes/SceneHeadingAMP scenes/SceneHeadingAMPGetup scenes/SceneTargetAMP scenes/SceneStrikeAMP scenes/SceneDribbleAMP"
 if [ ! -d "$REF" ]; then
     if [ -f _ref/libdm_ref.so ]; then echo "build_ref: $REF absent, keeping the prebuilt _ref/libdm_ref.so"; exit 0; fi
     echo "build_ref: $REF absent and no prebuilt library" >&2; exit 1

@@ -28,6 +28,7 @@
 #include "anim/MotionController.h"
 #include "scenes/SceneDribbleAMP.h"
 #include "scenes/SceneHeadingAMP.h"
+#include "scenes/SceneHeadingAMPGetup.h"
 #include "scenes/SceneImitate.h"
 #include "scenes/SceneImitateAMP.h"
 #include "scenes/SceneStrikeAMP.h"
@@ -221,6 +222,18 @@ tVector StandinJoint::CalcWorldPos() const { return cKinTree::CalcJointWorldPos(
 tQuaternion StandinJoint::CalcWorldRotation() const { tVector a; double th; cKinTree::CalcJointWorldTheta(ch->JointMat(), ch->Pose(), id, a, th); return cMathUtil::AxisAngleToQuaternion(a, th); }
 tMatrix StandinJoint::BuildWorldTrans() const { return cKinTree::JointWorldTrans(ch->JointMat(), ch->Pose(), id); }
 
+// a free rigid body (the ball of cSceneDribbleAMP): cSimRigidBody reads these from its btRigidBody (sim/SimRigidBody.cpp)
+class StandinBody : public cSimRigidBody {
+   public:
+    tVector pos = tVector::Zero(), lin = tVector::Zero(), ang = tVector::Zero(); tQuaternion rot = tQuaternion::Identity();
+    tVector GetPos() const override { return pos; }
+    tQuaternion GetRotation() const override { return rot; }
+    void GetRotation(tVector& axis, double& theta) const override { cMathUtil::QuaternionToAxisAngle(rot, axis, theta); }
+    tVector GetLinearVelocity() const override { return lin; }
+    tVector GetAngularVelocity() const override { return ang; }
+    tVector GetSize() const override { return tVector::Zero(); }      // (cSimSphere::GetSize; no routine called here asks)
+};
+
 // the reference's controller with its protected parts reachable
 class CtrlX : public cCtPDController {
    public:
@@ -246,6 +259,35 @@ class SceneX : public SCENE {
         this->mTargetPos = pos; this->mTargetSpeed = speed; this->mTargetSuccDist = succ_dist; this->mTarFailDist = fail_dist; this->mEnableMinTarVel = min_tar_vel; this->mPosRewardScale = pos_scale;
     }
     void heading(double h, double vel_scale) { this->mTargetHeading = h; this->mVelRewardScale = vel_scale; }
+    void scene_time(double t) { this->mTimer.SetTime(t); }
+    // cSceneHeadingAMPGetup (instantiated for that scene only)
+    void getup(double getup_time, double timer_time, double h_root, double h_head, int head_id) {
+        this->mGetupTime = getup_time; this->mGetupTimer.SetMaxTime(getup_time); this->mGetupTimer.SetTime(timer_time);
+        this->mGetupHeightRoot = h_root; this->mGetupHeightHead = h_head; this->mHeadID = head_id;
+    }
+    bool getup_running() const { return this->CheckGettingUp(); }
+    bool getup_fallen_contact(const cSimCharacter& c) const { return this->HasFallenContact(c); }
+    // cSceneStrikeAMP (instantiated for that scene only)
+    void strike(double near_dist, double radius, double tar_scale, double hit_speed, unsigned strike_mask, unsigned fail_mask, bool hit, double hit_time, double hit_reset_time) {
+        this->mTarNearDist = near_dist; this->mTargetRadius = radius; this->mTarRewardScale = tar_scale; this->mHitTarSpeed = hit_speed;
+        this->mStrikeBodies.clear(); this->mFailTarContactBodies.clear();
+        for (int j = 0; j < 32; ++j) { if ((strike_mask >> j) & 1u) this->mStrikeBodies.push_back(j); if ((fail_mask >> j) & 1u) this->mFailTarContactBodies.push_back(j); }
+        this->mTargetHit = hit; this->mTargetHitTime = hit_time; this->mTargetHitResetTime = hit_reset_time;
+    }
+    bool strike_check_hit() const { return this->CheckTargetHit(); }
+    bool strike_contact_fail() const { return this->CheckTarContactFail(0); }
+    bool strike_hit_succ() const { return this->CheckTarHitSucc(); }
+    // cSceneDribbleAMP (instantiated for that scene only): the target object is the stand-in body
+    std::shared_ptr<cSimRigidBody> ball;
+    const std::shared_ptr<cSimRigidBody>& GetObj(int) const override { return ball; }
+    void dribble(const std::shared_ptr<cSimRigidBody>& b, const tVector& prev_ball, double max_target_dist, double max_tar_obj_dist) {
+        ball = b; this->mTarObjID = 0; this->mAgentPrevTarObjPos.assign(1, prev_ball); this->mMaxTargetDist = max_target_dist; this->mMaxTarObjDist = max_tar_obj_dist;
+    }
+    void dribble_task_state(VecX& out) const { this->RecordTaskState(0, out); }
+    bool dribble_succ() const { return this->CheckTargetSucc(); }
+    bool dribble_tar_obj_fail() const { return this->CheckTarObjDistFail(); }
+    bool dribble_char_obj_fail(const cSimCharacter& c) const { return this->CheckCharObjDistFail(c); }
+    bool dribble_has_fallen(const cSimCharacter& c) const { return this->HasFallen(c); }
     double reward_imitate(const cSimCharacter& sim, const cKinCharacter& kin) const { return this->CalcRewardImitate(sim, kin); }
 };
 
@@ -257,6 +299,10 @@ struct Rig {
     std::shared_ptr<SceneX<cSceneImitateAMP>> amp;
     std::shared_ptr<SceneX<cSceneTargetAMP>> target;
     std::shared_ptr<SceneX<cSceneHeadingAMP>> heading;
+    std::shared_ptr<SceneX<cSceneStrikeAMP>> strike;
+    std::shared_ptr<SceneX<cSceneHeadingAMPGetup>> getup;
+    std::shared_ptr<SceneX<cSceneDribbleAMP>> dribble;
+    std::shared_ptr<StandinBody> ball;
 };
 
 }  // namespace
@@ -289,6 +335,7 @@ void ref2_destroy(void* h) {
     Rig* r = (Rig*)h;
     new std::shared_ptr<SceneX<cSceneImitate>>(r->imitate); new std::shared_ptr<SceneX<cSceneImitateAMP>>(r->amp);
     new std::shared_ptr<SceneX<cSceneTargetAMP>>(r->target); new std::shared_ptr<SceneX<cSceneHeadingAMP>>(r->heading);
+    new std::shared_ptr<SceneX<cSceneHeadingAMPGetup>>(r->getup); new std::shared_ptr<SceneX<cSceneStrikeAMP>>(r->strike); new std::shared_ptr<SceneX<cSceneDribbleAMP>>(r->dribble); new std::shared_ptr<StandinBody>(r->ball);
     new std::shared_ptr<StandinChar>(r->ch); new std::shared_ptr<CtrlX>(r->ctrl);
     delete r;
 }
@@ -379,7 +426,17 @@ int ref2_amp_obs(void* h, const double* prev_pose, const double* prev_vel, int l
 // task scenes: cSceneTargetAMP::CalcReward / RecordGoal (scenes/SceneTargetAMP.cpp:3-81,192-218) and cSceneHeadingAMP::CalcReward / RecordGoal
 // (scenes/SceneHeadingAMP.cpp:3-43,134-149) on the stand-in character.  par: [target x, y, z, target speed, succ dist, fail dist,
 // enable_min_tar_vel, pos reward scale, target heading, vel reward scale, prev action time, prev action COM x, y, z, controller time, fallen];
-// out: [reward, goal...]; returns the goal size
+// out: [reward, goal...]; returns the goal size.
+// kind 3, cSceneHeadingAMPGetup::CalcReward / RecordGoal / CheckGettingUp / HasFallenContact (scenes/SceneHeadingAMPGetup.cpp:4-38, 119-126,
+// 255-264, 292-303): par continues [16 get-up time, get-up timer, root height, head height, head body id, contact mask]; out continues behind
+// the goal with [getting up, fallen by contact].
+// kind 4, cSceneStrikeAMP::CalcReward (train) / RecordGoal / CheckTargetHit / CheckTarContactFail / CheckTarHitSucc (scenes/SceneStrikeAMP.cpp:
+// 23-187, 390-434, 441-520): par continues [16 near dist, target radius, target reward scale, hit speed, strike body mask, forbidden body mask,
+// target hit, hit time, scene time, hit reset time]; out continues behind the goal with [check hit, contact fail, hit succ].
+// kind 5, cSceneDribbleAMP::CalcReward (train) / RecordGoal / RecordTaskState / CheckTargetSucc / the distance failures / HasFallen
+// (scenes/SceneDribbleAMP.cpp:21-106, 267-292, 343-381, 454-466, 556-589): par continues [16..28 ball position, rotation wxyz, linear and angular
+// velocity, 29..31 ball position at the last action, max target dist, max target-object dist]; out continues behind the goal with
+// [task state (15), succ, target-object distance fail, character-object distance fail, has fallen]
 int ref2_task_scene(void* h, int kind, const double* par, double* out) {
     Rig* r = (Rig*)h;
     r->ctrl->set_time(par[14]); r->ctrl->set_prev_action(par[10], tVector(par[11], par[12], par[13], 0));
@@ -390,6 +447,50 @@ int ref2_task_scene(void* h, int kind, const double* par, double* out) {
         r->target->setup(r->ch, r->kin, 0.0);
         r->target->target(tVector(par[0], par[1], par[2], 0), par[3], par[4], par[5], par[6] != 0, par[7]);
         rew = r->target->CalcReward(0); r->target->RecordGoal(0, g);
+    } else if (kind == 3) {
+        if (!r->getup) r->getup = std::shared_ptr<SceneX<cSceneHeadingAMPGetup>>(new SceneX<cSceneHeadingAMPGetup>());
+        auto& sc = *r->getup;
+        sc.setup(r->ch, r->kin, 0.0);
+        sc.target(tVector(par[0], par[1], par[2], 0), par[3], par[4], par[5], par[6] != 0, par[7]);
+        sc.heading(par[8], par[9]);
+        sc.getup(par[16], par[17], par[18], par[19], (int)par[20]);
+        r->ch->contact_mask = (int)par[21];
+        rew = sc.CalcReward(0); sc.RecordGoal(0, g);
+        out[0] = rew; for (int i = 0; i < (int)g.size(); ++i) out[1 + i] = g[i];
+        double* x = out + 1 + g.size();
+        x[0] = sc.getup_running(); x[1] = sc.getup_fallen_contact(*r->ch);
+        r->ch->contact_mask = 0;
+        return (int)g.size();
+    } else if (kind == 4) {
+        if (!r->strike) r->strike = std::shared_ptr<SceneX<cSceneStrikeAMP>>(new SceneX<cSceneStrikeAMP>());
+        auto& sc = *r->strike;
+        sc.setup(r->ch, r->kin, 0.0);
+        sc.target(tVector(par[0], par[1], par[2], 0), par[3], par[4], par[5], par[6] != 0, par[7]);
+        sc.strike(par[16], par[17], par[18], par[19], (unsigned)par[20], (unsigned)par[21], par[22] != 0, par[23], par[25]);
+        sc.scene_time(par[24]);
+        rew = sc.CalcReward(0); sc.RecordGoal(0, g);
+        out[0] = rew; for (int i = 0; i < (int)g.size(); ++i) out[1 + i] = g[i];
+        double* x = out + 1 + g.size();
+        x[0] = sc.strike_check_hit(); x[1] = sc.strike_contact_fail(); x[2] = sc.strike_hit_succ();
+        return (int)g.size();
+    } else if (kind == 5) {
+        if (!r->dribble) r->dribble = std::shared_ptr<SceneX<cSceneDribbleAMP>>(new SceneX<cSceneDribbleAMP>());
+        if (!r->ball) r->ball = std::shared_ptr<StandinBody>(new StandinBody());
+        auto& sc = *r->dribble;
+        sc.setup(r->ch, r->kin, 0.0);
+        sc.target(tVector(par[0], par[1], par[2], 0), par[3], par[4], par[5], par[6] != 0, par[7]);
+        StandinBody& b = *r->ball;
+        b.pos = tVector(par[16], par[17], par[18], 0); b.rot = tQuaternion(par[19], par[20], par[21], par[22]);
+        b.lin = tVector(par[23], par[24], par[25], 0); b.ang = tVector(par[26], par[27], par[28], 0);
+        sc.dribble(r->ball, tVector(par[29], par[30], par[31], 0), par[32], par[33]);
+        rew = sc.CalcReward(0); sc.RecordGoal(0, g);
+        out[0] = rew; for (int i = 0; i < (int)g.size(); ++i) out[1 + i] = g[i];
+        double* x = out + 1 + g.size();
+        VecX ts; sc.dribble_task_state(ts);
+        for (int i = 0; i < (int)ts.size(); ++i) x[i] = ts[i];
+        x += ts.size();
+        x[0] = sc.dribble_succ(); x[1] = sc.dribble_tar_obj_fail(); x[2] = sc.dribble_char_obj_fail(*r->ch); x[3] = sc.dribble_has_fallen(*r->ch);
+        return (int)g.size();
     } else {
         if (!r->heading) r->heading = std::shared_ptr<SceneX<cSceneHeadingAMP>>(new SceneX<cSceneHeadingAMP>());
         r->heading->setup(r->ch, r->kin, 0.0);

@@ -5,7 +5,8 @@ Unlike oracle_rollouts.json (the oracle's own outputs), every array written here
 cKinTree / cRBDModel / cRBDUtil / cMathUtil / cKinCharacter / cMotionController / cMotion, and -- since round 3 -- the reference's
 compiled ROUTINES (oracle/ref_standins.cpp: sim/ImpPDController.cpp CalcControlForces, sim/CtController.cpp RecordState,
 scenes/SceneImitate.cpp CalcRewardImitate, scenes/SceneImitateAMP.cpp BuildAMPObs, scenes/SceneTargetAMP.cpp / SceneHeadingAMP.cpp
-CalcReward + RecordGoal) for the SPD torque, the state vector, the reward, the AMP observation and the task rewards / goal vectors;
+CalcReward + RecordGoal, scenes/SceneStrikeAMP.cpp / SceneDribbleAMP.cpp CalcReward + RecordGoal + their hit / contact / success / distance checks and
+the dribble task state) for the SPD torque, the state vector, the reward, the AMP observation and the task rewards / goal vectors;
 the compositions of oracle/ref_glue.cpp are evaluated next to them and must agree (only the five reward error TERMS, which the
 routine does not hand out, are still taken from the composition).
 
@@ -148,6 +149,91 @@ def main():
             rig.set_state(p, v)
             r, goal = rig.task_scene(kind, par)
             for k, val in (("pose", p), ("vel", v), ("par", par), ("reward", r), ("goal", goal)):
+                g[k].append(np.array(val))
+        for k, val in g.items():
+            out["task/%s/%s" % (name, k)] = np.array(val)
+    # heading_amp_getup (scenes/SceneHeadingAMPGetup.cpp as compiled): heading reward / get-up reward by the get-up timer, goal with the get-up phase,
+    # CheckGettingUp, HasFallenContact (no contact fall while getting up)
+    if True:
+        name, kind = "amp_heading_getup", 3
+        t = model.load_asset(name); c = t.cfg
+        char = os.path.splitext(os.path.basename(c.character_file))[0]
+        kc = RefKinChar(ref, os.path.join("/root/reference", c.character_file), "/root/reference/data/motions/humanoid3d_walk.txt")
+        rig = RefRig(ref, char)
+        sk = Skel(ref, t)
+        rng = np.random.default_rng(3003)
+        g = {k: [] for k in ("pose", "vel", "par", "reward", "goal", "extra")}
+        for i in range(12):
+            tk = rng.uniform(0, kc.duration)
+            kc.set_origin(np.array([rng.normal(), 0.0, rng.normal()]), np.array([np.cos(0.4 * i), 0.0, np.sin(0.4 * i), 0.0]))
+            p, v = kc.eval(tk)
+            p[1] += 0.05 - (0.5 if i % 3 == 1 else 0.0); v[0:3] += rng.normal(size=3) * 0.3          # (some roots low: the get-up reward is not saturated)
+            com, _ = sk.com(p, v)
+            speed = rng.uniform(0.5, 2.0)
+            prev_t = rng.uniform(0.1, 3.0)
+            prev_com = com - np.array([rng.normal() * 0.03, rng.normal() * 0.01, rng.normal() * 0.03]) - 19 / 600 * speed * np.array([np.cos(0.4 * i), 0, -np.sin(0.4 * i)])
+            timer = t.getup_time * (rng.uniform(0.05, 0.95) if i % 2 else rng.uniform(1.0, 1.5))           # odd cases are getting up
+            fallen = 1.0 if i in (4, 5) else 0.0
+            par = [0.0, 0.0, 0.0, speed, c.target_succ_dist, 1e30, float(c.enable_min_tar_vel), c.pos_reward_scale, (0.4 * i + rng.normal() * 0.4 + np.pi) % (2 * np.pi) - np.pi, c.vel_reward_scale,
+                   prev_t, prev_com[0], prev_com[1], prev_com[2], prev_t + 19 / 600, fallen, t.getup_time, timer, c.getup_height_root, c.getup_height_head, float(c.head_id), 0.0]
+            rig.set_state(p, v)
+            r, goal, extra = rig.task_scene(kind, par, extras=2)
+            for k, val in (("pose", p), ("vel", v), ("par", par), ("reward", r), ("goal", goal), ("extra", extra)):
+                g[k].append(np.array(val))
+        for k, val in g.items():
+            out["task/%s/%s" % (name, k)] = np.array(val)
+    # strike_amp / dribble_amp (scenes/SceneStrikeAMP.cpp, SceneDribbleAMP.cpp as compiled): reward, goal vector, the scenes' own checks and
+    # -- dribble -- the 15 task entries of the state vector, on scripted goal states that reach every branch
+    for name, kind in (("amp_strike_punch", 4), ("amp_dribble_zombie", 5)):
+        t = model.load_asset(name); c = t.cfg
+        char = os.path.splitext(os.path.basename(c.character_file))[0]
+        kc = RefKinChar(ref, os.path.join("/root/reference", c.character_file), "/root/reference/data/motions/humanoid3d_walk.txt")
+        rig = RefRig(ref, char)
+        sk = Skel(ref, t)
+        rng = np.random.default_rng(3000 + kind)
+        g = {k: [] for k in ("pose", "vel", "par", "reward", "goal", "extra")}
+        for i in range(16):
+            tk = rng.uniform(0, kc.duration)
+            kc.set_origin(np.array([rng.normal(), 0.0, rng.normal()]), np.array([np.cos(0.4 * i), 0.0, np.sin(0.4 * i), 0.0]))
+            p, v = kc.eval(tk)
+            p[1] += 0.05; v[0:3] += rng.normal(size=3) * 0.3
+            com, _ = sk.com(p, v)
+            body = sk.world_trans(p)[1][:, 9:12]
+            speed = float(c.tar_speed)
+            prev_t = rng.uniform(0.1, 3.0)
+            prev_com = com - np.array([rng.normal() * 0.03, rng.normal() * 0.01, rng.normal() * 0.03]) - 19 / 600 * speed * np.array([np.cos(0.4 * i), 0, -np.sin(0.4 * i)])
+            fallen = 1.0 if i == 13 else 0.0
+            if kind == 4:
+                sb, fb = int(c.strike_bodies[0]), [int(b) for b in c.fail_tar_contact_bodies]
+                mode = i % 4                                   # 0 far, 1 near (target by the strike body), 2 hit, 3 far / forbidden-body contact / success by turns
+                if mode == 1: tar = body[sb] + rng.normal(size=3) * np.array([0.25, 0.1, 0.25])
+                elif mode == 3 and i % 8 == 3: tar = body[fb[i % len(fb)]] + rng.normal(size=3) * 0.05
+                else: tar = np.array([p[0], 0.0, p[2]]) + np.array([rng.normal() * 2.5, rng.uniform(c.target_min[1], c.target_max[1]), rng.normal() * 2.5])
+                hit = 1.0 if mode == 2 or i == 15 else 0.0
+                scene_t = rng.uniform(3.0, 8.0)
+                hit_t = scene_t - (rng.uniform(2.05, 3.0) if i == 15 or i == 10 else rng.uniform(0.0, 1.9))
+                par = [tar[0], tar[1], tar[2], speed, c.target_succ_dist, c.tar_fail_dist, float(c.enable_min_tar_vel), c.pos_reward_scale, 0.0, c.vel_reward_scale,
+                       prev_t, prev_com[0], prev_com[1], prev_com[2], prev_t + 19 / 600, fallen,
+                       c.tar_near_dist, c.target_radius, c.tar_reward_scale, c.hit_tar_speed, float(1 << sb), float(sum(1 << b for b in fb)), hit, hit_t, scene_t, c.target_hit_reset_time]
+                if mode == 1: v[3:6] += rng.normal(size=3) * 2.0                  # some spin: the strike body moves
+                if i == 5:                                                         # a clean hit: strike body inside the sphere, moving at the target
+                    tar = body[sb] + rng.normal(size=3) * 0.03; d = tar - p[0:3]; d[1] = 0.0
+                    v[0:3] = 3.0 * d / np.linalg.norm(d); par[0:3] = tar
+                rig.set_state(p, v)
+                r, goal, extra = rig.task_scene(kind, par, extras=3)
+            else:
+                ball = np.array([p[0], c.ball_radius, p[2]]) + np.array([rng.normal(), 0.0, rng.normal()]) * (0.8 if i != 11 else 0.0) + (np.array([25.0, 0.0, 5.0]) if i == 11 else 0.0)
+                q = rng.normal(size=4); q /= np.linalg.norm(q)
+                bv, bw = rng.normal(size=3) * 0.8, rng.normal(size=3) * 2.0
+                tar = ball + np.array([rng.normal(), 0.0, rng.normal()]) * (0.2 if i % 5 == 4 else 3.0) + (np.array([-4.0, 0.0, 24.0]) if i == 8 else 0.0); tar[1] = 0.0
+                prev_ball = ball - 19 / 600 * bv + rng.normal(size=3) * 0.01
+                par = [tar[0], 0.0, tar[2], speed, c.target_succ_dist, 1e30, float(c.enable_min_tar_vel), c.pos_reward_scale, 0.0, c.vel_reward_scale,
+                       prev_t, prev_com[0], prev_com[1], prev_com[2], prev_t + 19 / 600, fallen,
+                       ball[0], ball[1], ball[2], q[0], q[1], q[2], q[3], bv[0], bv[1], bv[2], bw[0], bw[1], bw[2], prev_ball[0], prev_ball[1], prev_ball[2],
+                       c.max_target_dist, c.max_tar_obj_dist]
+                rig.set_state(p, v)
+                r, goal, extra = rig.task_scene(kind, par, extras=19)
+            for k, val in (("pose", p), ("vel", v), ("par", par), ("reward", r), ("goal", goal), ("extra", extra)):
                 g[k].append(np.array(val))
         for k, val in g.items():
             out["task/%s/%s" % (name, k)] = np.array(val)

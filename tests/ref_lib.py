@@ -304,7 +304,11 @@ class RefRig:
         n = self.lib.ref2_amp_obs(C.c_void_p(self.h), _d(_arr(prev_pose)), _d(_arr(prev_vel)), int(bool(local_root)), C.c_double(ground_h), _d(out))
         return out[:n].copy()
 
-    def task_scene(self, kind, par):
-        out = np.zeros(8)
+    def task_scene(self, kind, par, extras=0):
+        """kinds 1 / 2 (target, heading): (reward, goal); kinds 4 / 5 (strike, dribble) with extras = 3 / 19: (reward, goal, the scene's
+        checks and -- dribble -- task state, oracle/ref_standins.cpp ref2_task_scene)"""
+        out = np.zeros(32)
         n = self.lib.ref2_task_scene(C.c_void_p(self.h), int(kind), _d(_arr(par)), _d(out))
+        if extras:
+            return float(out[0]), out[1:1 + n].copy(), out[1 + n:1 + n + extras].copy()
         return float(out[0]), out[1:1 + n].copy()

@@ -103,6 +103,115 @@ def _task_device_check(lib_path, precision, tol_r, tol_g):
     return worst
 
 
+def _strike_dribble_device_check(lib_path, precision, tol_r, tol_g, tol_s):
+    """cSceneStrikeAMP / cSceneDribbleAMP as compiled from the reference (golden `task/amp_strike_punch`, `task/amp_dribble_zombie`: CalcReward in
+    train mode, RecordGoal, CheckTargetHit / CheckTarContactFail / CheckTarHitSucc, CheckTargetSucc / the two distance failures / HasFallen, and
+    the 15 task entries of the dribble state vector) vs the device path: pose, clocks, goal row, hit record and ball through the C-ABI, the
+    answers from dm_query / dm_query_goal -- and, for the hit test, which the device runs inside an update, from the hit record after an update
+    of 1e-7 s."""
+    from deepmimic_amd.core import BatchEnv
+    g = pc.ref_golden()
+    worst = {}
+    for name in ("amp_strike_punch", "amp_dribble_zombie"):
+        t = model.load_asset(name)
+        P, V, par, extra = (g["task/%s/%s" % (name, k)] for k in ("pose", "vel", "par", "extra"))
+        n = P.shape[0]
+        strike = name == "amp_strike_punch"
+        env = BatchEnv(t, n, precision=precision, lib_path=lib_path, wave_packing=1)
+        env.reset(kin_times=np.zeros(n), max_times=np.inf)
+        clocks = np.stack([np.zeros(n), par[:, 14], np.zeros(n), par[:, 24] if strike else np.zeros(n), np.full(n, np.inf)], axis=1)
+        flags = np.tile(np.array([[1, 0, 1, 1]], dtype=np.int32), (n, 1))
+        fall_bit = int(np.flatnonzero(t.fall_mask())[0])
+        flags[:, 1] = np.where(par[:, 15] != 0, 1 << fall_bit, 0)                  # "fallen" = a fall-contact body touches the ground
+        st = env.get_state()
+        env.set_state(pose=P, vel=V, tar=st["tar"], kin=st["kin"], clocks=clocks, flags=flags)
+        gs = env.get_goal_state()
+        gs[:, 0:3] = par[:, 0:3]; gs[:, 3] = 0.0; gs[:, 4] = par[:, 3]; gs[:, 5] = 0.0; gs[:, 6] = 1e9
+        gs[:, 7:10] = par[:, 11:14]; gs[:, 10] = par[:, 10]
+        env.set_goal_state(gs)
+        aux = env.get_goal_aux()
+        if strike: aux[:, 0] = par[:, 22]; aux[:, 1] = par[:, 23]
+        else:
+            aux[:, 2:5] = par[:, 29:32]; aux[:, 5] = 0.0; aux[:, 6] = 1e9
+            env.set_obj_state(par[:, 16:29])
+        env.set_goal_aux(aux)
+        q = env.query(); goals = env.query_goal()
+        dr = np.abs(q["reward"] - g["task/%s/reward" % name]).max(); dg = np.abs(goals - g["task/%s/goal" % name]).max()
+        assert dr < tol_r and dg < tol_g, (name, dr, dg)
+        if strike:
+            check_hit, contact_fail, hit_succ = extra[:, 0] != 0, extra[:, 1] != 0, extra[:, 2] != 0
+            # the fall test of cRLSceneSimChar::CheckTerminate, then cSceneStrikeAMP::CheckTerminateTarget (:527-545); no distance failure here
+            want = np.where((par[:, 15] != 0) | contact_fail, 1, np.where(hit_succ, 2, 0))
+            assert np.array_equal(q["terminate"], want), (q["terminate"], want)
+            assert contact_fail.sum() >= 2 and hit_succ.sum() >= 2 and check_hit.sum() >= 1
+            env.update(1e-7, 1)
+            hit_after = env.get_goal_aux()[:, 0] != 0
+            assert np.array_equal(hit_after, (par[:, 22] != 0) | check_hit), (hit_after, check_hit)
+            worst[name] = (float(dr), float(dg))
+        else:
+            succ, tar_fail, char_fail, fallen = (extra[:, 15 + k] != 0 for k in range(4))
+            ds = np.abs(q["state"][:, -15:] - extra[:, :15]).max()
+            assert ds < tol_s, ds
+            fell = par[:, 15] != 0
+            want = np.where(fell | tar_fail | char_fail, 1, np.where(succ, 2, 0))  # fall test on cSceneDribbleAMP::HasFallen, then CheckTerminateTarget (:343-349, 468-477)
+            assert np.array_equal(fallen, fell | tar_fail | char_fail)
+            assert np.array_equal(q["terminate"], want), (q["terminate"], want)
+            assert succ.sum() >= 2 and tar_fail.sum() >= 1 and char_fail.sum() >= 1
+            worst[name] = (float(dr), float(dg), float(ds))
+    return worst
+
+
+def _getup_device_check(lib_path, precision, tol_r, tol_g):
+    """cSceneHeadingAMPGetup as compiled from the reference (golden `task/amp_heading_getup`): the get-up reward while the get-up timer runs and the
+    heading reward otherwise, the goal with the get-up phase, no contact fall while getting up -- vs dm_query / dm_query_goal"""
+    from deepmimic_amd.core import BatchEnv
+    g = pc.ref_golden()
+    name = "amp_heading_getup"
+    t = model.load_asset(name)
+    P, V, par, extra = (g["task/%s/%s" % (name, k)] for k in ("pose", "vel", "par", "extra"))
+    n = P.shape[0]
+    assert abs(t.getup_time - par[0, 16]) < 1e-12
+    env = BatchEnv(t, n, precision=precision, lib_path=lib_path, wave_packing=1)
+    env.reset(kin_times=np.zeros(n), max_times=np.inf)
+    clocks = np.stack([np.zeros(n), par[:, 14], np.zeros(n), np.zeros(n), np.full(n, np.inf)], axis=1)
+    flags = np.tile(np.array([[1, 0, 1, 1]], dtype=np.int32), (n, 1))
+    flags[:, 1] = np.where(par[:, 15] != 0, 1 << int(np.flatnonzero(t.fall_mask())[0]), 0)
+    st = env.get_state()
+    env.set_state(pose=P, vel=V, tar=st["tar"], kin=st["kin"], clocks=clocks, flags=flags)
+    gs = env.get_goal_state()
+    gs[:, 0:3] = 0.0; gs[:, 3] = par[:, 8]; gs[:, 4] = par[:, 3]; gs[:, 5] = 0.0; gs[:, 6] = 1e9
+    gs[:, 7:10] = par[:, 11:14]; gs[:, 10] = par[:, 10]
+    env.set_goal_state(gs)
+    aux = env.get_goal_aux(); aux[:, 0] = par[:, 17]; env.set_goal_aux(aux)
+    q = env.query(); goals = env.query_goal()
+    getting_up, fallen_contact = extra[:, 0] != 0, extra[:, 1] != 0
+    dr = np.abs(q["reward"] - g["task/%s/reward" % name]).max(); dg = np.abs(goals - g["task/%s/goal" % name]).max()
+    assert dr < tol_r and dg < tol_g, (dr, dg)
+    assert np.array_equal(q["terminate"], fallen_contact.astype(np.int32)), (q["terminate"], fallen_contact)
+    assert getting_up.sum() >= 4 and fallen_contact.sum() >= 1 and ((par[:, 15] != 0) & ~fallen_contact).sum() >= 1     # a contact while getting up is no fall
+    return float(dr), float(dg)
+
+
+def test_emulated_device_getup_vs_ref_golden(emu_lib):
+    print(_getup_device_check(emu_lib, 64, 1e-6, 1e-6))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prec,tol", [(64, 2e-6), (32, 5e-5)])
+def test_hip_getup_vs_ref_golden(hip_lib, prec, tol):
+    print(_getup_device_check(hip_lib, prec, tol, tol))
+
+
+def test_emulated_device_strike_dribble_vs_ref_golden(emu_lib):
+    print(_strike_dribble_device_check(emu_lib, 64, 1e-6, 1e-6, 2e-6))        # rewards / goals / states cross the boundary as float32
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prec,tol", [(64, 2e-6), (32, 5e-5)])
+def test_hip_strike_dribble_vs_ref_golden(hip_lib, prec, tol):
+    print(_strike_dribble_device_check(hip_lib, prec, tol, tol, tol))
+
+
 def test_emulated_device_task_scenes_vs_ref_golden(emu_lib):
     print(_task_device_check(emu_lib, 64, 1e-6, 1e-6))        # rewards / goals cross the boundary as float32
 

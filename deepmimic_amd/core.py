@@ -102,7 +102,7 @@ class BatchEnv:
     def __init__(self, tables: SceneTables, num_envs: int = 1, device_id: int = 0, seed: int = 0,
                  precision: int = 32, max_contacts: int = 20, env_id_offset: int = 0,
                  test_mode: bool = False, lib_path: Optional[str] = None, wave_packing: int = 0, self_collision: bool = True,
-                 erp: float = 0.0, physics: int = 1):
+                 erp: float = 0.0, physics: int = 1, solver_iters: int = 0):
         self.lib = load_library(lib_path)
         self.tables = tables
         c = tables.cfg
@@ -131,7 +131,7 @@ class BatchEnv:
         st.time_lim_min, st.time_lim_max = tmin, tmax
         st.enable_phase_input = int(tables.enable_phase_input); st.record_world_root_pos = int(tables.record_world_root_pos)
         st.record_world_root_rot = int(tables.record_world_root_rot); st.query_rate = float(tables.query_rate)
-        st.friction = 0.0; st.erp = float(erp); st.solver_iters = 0
+        st.friction = 0.0; st.erp = float(erp); st.solver_iters = int(solver_iters)      # 0: the library's default (10, btContactSolverInfo::m_numIterations); other values are for measurements
         st.disable_self_collision = 0 if self_collision else 1
         st.scene_amp = int(c.scene in AMP_SCENES); st.enable_amp_obs_local_root = int(getattr(c, "enable_amp_obs_local_root", False))
         # goal-conditioned AMP task scenes and multi-clip datasets

@@ -23,8 +23,9 @@ once per 1/30 s.  Served naively that is >= 2 kernel launches and 3 device round
   ``Update`` calls of the same timestep only advance a host counter and its per-update ``IsEpisodeEnd / CheckValidEpisode``
   questions are answered from that launch's outcome.  A call that needs the state of an intermediate update (``RecordState``
   mid-step, a different timestep, a ``SetAction`` mid-step) rolls the env back to the snapshot taken before the launch and
-  replays update by update, so results never depend on the batching.  (``CheckValidEpisode`` is evaluated at the end of the
-  launch: a velocity explosion is reported at the step's last update instead of the update it first occurred at.)
+  replays update by update, so results never depend on the batching.  (The launch also stops at the update after which the
+  episode is invalid -- a link velocity beyond 100, ``cSimCharacter::HasVelExploded`` --, so ``CheckValidEpisode`` turns false at
+  the update the reference's driver would see it at.)
 
 Errors: the reference ``assert(false)``s (DeepMimicCore.cpp:36-40); this module raises ``RuntimeError`` instead.
 """
@@ -501,7 +502,7 @@ class cDeepMimicCore(object):
         if self._kin_only():
             return True
         if self._virtual():
-            return True
+            return True                     # (the batched launch stops before the update that would start from an invalid state: not yet)
         return bool(self._query()["valid"][0])
 
     def CheckTerminate(self, agent_id):

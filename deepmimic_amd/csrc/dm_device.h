@@ -389,7 +389,7 @@ struct EnvSim {
         if (l < 8) s.kin[l] = st.kin[(size_t)e * 8 + l];
         if (l < 6) s.clk[l] = st.clock[(size_t)e * 6 + l];
         if (l < 4) s.flg[l] = st.flag[(size_t)e * 4 + l];
-        if (l == 0) s.flg[FLG_PARKED] = 0;
+        if (l == 0) { s.flg[FLG_PARKED] = 0; s.flg[FLG_OVER] = 0; }
         if (C::OBJ && st.obj && l < OB_WIDTH) s.obj[C::OBJ ? l : 0] = st.obj[(size_t)e * OB_WIDTH + l];
         sync();
     }
@@ -1641,7 +1641,7 @@ struct EnvSim {
     // reuse_kin: pose / vel are unchanged since the previous phase's kinematics (stable-PD solve -> first substep); only
     // the base acceleration differs, and it enters every joint-origin acceleration as the same additive constant.
     template <bool PERT = false, bool V2 = false>
-    DM_DEV void dyn_phase(int ph, Real dt, Real h, DebugTaps<Real> dbg, int e, bool tap_only, bool reuse_kin, Real* aovf, const double* pert = nullptr, Real* manif = nullptr) {
+    DM_DEV void dyn_phase(int ph, Real dt, Real h, DebugTaps<Real> dbg, int e, bool tap_only, bool reuse_kin, Real* aovf, const double* pert = nullptr, Real* manif = nullptr, bool kin_done = false) {
         // lane id / link word are re-materialised per phase: keeps the optimizer from hoisting every per-lane LDS address
         // out of the 20-update loop (dozens of long-lived VGPRs that end up in scratch)
         DM_OPAQUE_V(l); DM_OPAQUE_V(li);
@@ -1649,7 +1649,7 @@ struct EnvSim {
         if (reuse_kin) {
             if (l < m.J) { v3 da = gravity_a0() - spd_a0(); st3(s.aj[l], ld3(s.aj[l]) + da); }
             sync();
-        } else kinematics(s.pose, s.vel, ph == 0 ? spd_a0() : gravity_a0());
+        } else if (!kin_done) kinematics(s.pose, s.vel, ph == 0 ? spd_a0() : gravity_a0());      // (kin_done: kin_pre() ran it for this state)
         mark(ph == 0 ? 1 : 5);
         dynamics(ph == 0 ? 0 : 1, ph == 0 ? dt : (Real)0);
         mark(ph == 0 ? 2 : 6);
@@ -1677,18 +1677,34 @@ struct EnvSim {
         if (ph == 0) { mark(3); spd_post(dt); }
         else substep_post<V2>(h, dbg, e, aovf, manif);
     }
+    // Top of a scene update, before anything of it changes the env: link kinematics of the current state (the stable-PD pass of this
+    // update reuses them, kin_done) and cSceneSimChar::CheckValidEpisode on them (cSimCharacter::HasVelExploded, sim/SimCharacter.cpp:
+    // 571-586: any link velocity component beyond 100) -- i.e. the validity test the reference's driver runs after the PREVIOUS update
+    // (DeepMimic.py:62-80).  An invalid state is latched in bit 1 of FLG_OVER for the rest of the launch: with DM_END_EPISODE_EARLY the
+    // step kernels stop before this update, emit() reports valid = 0 either way.
+    DM_DEV void kin_pre(bool act = true) {
+        mark(0);
+        kinematics(s.pose, s.vel, spd_a0());
+        if (act && l < m.J) {
+            const v3 vc = link_vcom(l), w = ld3(s.w[l]);
+            Real mx = dm_max(dm_max(dm_abs(vc.x), dm_abs(vc.y)), dm_abs(vc.z));
+            mx = dm_max(mx, dm_max(dm_max(dm_abs(w.x), dm_abs(w.y)), dm_abs(w.z)));
+            if (mx > (Real)100) dm_atomic_or(&s.flg[FLG_OVER], 2);
+        }
+        sync();
+    }
     template <bool PERT = false, bool V2 = false>
-    DM_DEV void update(double dt, DebugTaps<Real> dbg, int e, Real* aovf, double* pert = nullptr, Real* manif = nullptr) {
+    DM_DEV void update(double dt, DebugTaps<Real> dbg, int e, Real* aovf, double* pert = nullptr, Real* manif = nullptr, bool kin_done = false) {
         if (l == 0) { s.clk[CLK_TIMER] += dt; s.clk[CLK_CTRL] += dt; s.flg[FLG_NEED_ACTION] = 0; }
         if (PERT && pert) { if (l == 0) pert_tick(pert, e, dt); sync(); }
         kin_update(dt);
         const Real h = (Real)(dt / m.num_sim_substeps);
-        for (int ph = 0; ph <= m.num_sim_substeps; ++ph) dyn_phase<PERT, V2>(ph, (Real)dt, h, dbg, e, false, ph == 1, aovf, pert, V2 ? manif : nullptr);
+        for (int ph = 0; ph <= m.num_sim_substeps; ++ph) dyn_phase<PERT, V2>(ph, (Real)dt, h, dbg, e, false, ph == 1, aovf, pert, V2 ? manif : nullptr, kin_done && ph == 0);
         if (l == 0) {                      // cCtController::CheckNeedNewAction (CtController.cpp:221-227)
             double cur = s.clk[CLK_CTRL] + s.clk[CLK_INIT_OFF], pad = 0.001 * dt;
             int c1 = (int)floor((cur + pad) / m.query_period), c0 = (int)floor((cur + pad - dt) / m.query_period);
             s.flg[FLG_NEED_ACTION] = (c1 != c0) ? 1 : 0;
-            s.flg[FLG_OVER] = episode_over_now() ? 1 : 0;      // read by the step kernels when DM_END_EPISODE_EARLY is set
+            s.flg[FLG_OVER] = (s.flg[FLG_OVER] & 2) | (episode_over_now() ? 1 : 0);      // read by the step kernels when DM_END_EPISODE_EARLY is set (bit 1: kin_pre's invalid latch)
         }
         sync();
     }
@@ -1805,7 +1821,7 @@ struct EnvSim {
             if (TAPS && dbg.reward_terms) { Real* o = dbg.reward_terms + (size_t)e * 5; o[0] = pose_err; o[1] = vel_err; o[2] = ee_err; o[3] = root_err; o[4] = com_err; }
         }
         // CheckValidEpisode: any link velocity component beyond 100 (SimCharacter.cpp:571-586)
-        if (l == 0) s.flg[FLG_VALID] = 1;
+        if (l == 0) s.flg[FLG_VALID] = (s.flg[FLG_OVER] & 2) ? 0 : 1;      // (an update inside this launch left the env invalid: kin_pre)
         sync();
         if (l < J) {
             v3 w = ld3(s.w[l]);
@@ -1814,6 +1830,7 @@ struct EnvSim {
             if (mx > (Real)100) s.flg[FLG_VALID] = 0;
         }
         sync();
+        if (l == 0 && write_flags && !s.flg[FLG_VALID]) s.sc[6] = (Real)1;       // the driver resets after an invalid episode too (DeepMimic.py:62-80): DM_AUTO_RESET follows
         if (l == 0 && io.valid && write_flags) io.valid[e] = s.flg[FLG_VALID];
         // observation
         if (io.states) {
@@ -2158,8 +2175,7 @@ struct EnvSim {
         if (C::OBJ && m.scene_goal == 5 && act && l == 0 && s.flg[FLG_NEED_ACTION]) {      // cSceneDribbleAMP::NewActionUpdate (:337-341)
             double* g = st.goal + (size_t)e * GS_WIDTH; const v3 bp = ball_p(); g[GS_PBX] = (double)bp.x; g[GS_PBY] = (double)bp.y; g[GS_PBZ] = (double)bp.z;
         }
-        if (s.flg[FLG_NEED_ACTION]) {          // wave-uniform for one character per wave; per half otherwise (kinematics is lane-local + barriers)
-            kinematics(s.pose, s.vel, zero3());
+        if (s.flg[FLG_NEED_ACTION]) {          // wave-uniform for one character per wave; per half otherwise (link positions of this state: kin_pre())
             const v3 c = com_of_links();
             if (act && l == 0) { double* g = st.goal + (size_t)e * GS_WIDTH; g[GS_PCOMX] = c.x; g[GS_PCOMY] = c.y; g[GS_PCOMZ] = c.z; g[GS_PTIME] = s.clk[CLK_CTRL] + dt; }
         }
@@ -2218,7 +2234,7 @@ struct EnvSim {
             bool over = episode_over_now() || goal_dist_fail(g);
             if (m.scene_goal == 4) over = over || strike_contact_fail(g) || strike_succ(g);
             if (C::OBJ && m.scene_goal == 5) over = over || (m.enable_fall_end && dribble_dist_fail(g)) || dribble_succ(g);
-            s.flg[FLG_OVER] = over ? 1 : 0;
+            s.flg[FLG_OVER] = (s.flg[FLG_OVER] & 2) | (over ? 1 : 0);
         }
         sync();
     }
@@ -2388,7 +2404,7 @@ struct EnvSim {
         if (l == 0) {
             s.clk[CLK_TIMER] = 0; s.clk[CLK_TIMER_MAX] = max_time;
             s.clk[CLK_KIN] = kin_time; s.clk[CLK_CTRL] = kin_time; s.clk[CLK_INIT_OFF] = -kin_time;
-            s.flg[FLG_NEED_ACTION] = 1; s.flg[FLG_CONTACT] = 0; s.flg[FLG_VALID] = 1; s.flg[FLG_EPISODE] += 1;
+            s.flg[FLG_NEED_ACTION] = 1; s.flg[FLG_CONTACT] = 0; s.flg[FLG_VALID] = 1; s.flg[FLG_OVER] = 0; s.flg[FLG_EPISODE] += 1;
             s.kin[0] = s.kin[1] = s.kin[2] = 0; s.kin[3] = 1; s.kin[4] = s.kin[5] = s.kin[6] = 0;
         }
         for (int i = l; i < m.D; i += LW) s.tau[i] = 0;
@@ -2497,9 +2513,11 @@ __global__ void __launch_bounds__(64) DM_WAVES_PER_EU((StepWaves<Real, C>::value
         // row, perturbation state -- and the keys of their counter-based draws are formed where they are used instead of living across the loop)
         int eo = e; if (HIST) DM_OPAQUE_S(eo);
         double* po = (HIST && st.pert) ? st.pert + (size_t)eo * PT_WIDTH : nullptr;
+        sim.kin_pre();
+        if (io.end_early && (lds.flg[FLG_OVER] & 2)) break;     // invalid since the previous update: the driver ends the episode there
         if (HIST && st.hist) sim.latch_hist(st, eo);
         if (goal) sim.goal_latch(st, eo, io.dt);
-        sim.template update<HIST, V2>(io.dt, dbg, eo, aovf, po, manif);
+        sim.template update<HIST, V2>(io.dt, dbg, eo, aovf, po, manif, true);
         if (goal) sim.goal_update(st, eo, io.dt);
         if (io.end_early && lds.flg[FLG_OVER]) break;           // wave-uniform: latched by lane 0 at the end of update()
     }

@@ -602,7 +602,7 @@ _Pragma("unroll") \
 
     // ------------------------------------------------------------------ one scene update for both characters
     template <bool PERT = false>
-    DM_DEV void update(double dt, int e, Real* aovf_pair, double* pert = nullptr) {
+    DM_DEV void update(double dt, int e, Real* aovf_pair, double* pert = nullptr, bool kin_done = false) {
         if (hl == 0) { s.clk[CLK_TIMER] += dt; s.clk[CLK_CTRL] += dt; s.flg[FLG_NEED_ACTION] = 0; }
         if (PERT && pert) { if (hl == 0 && s.flg[FLG_PARKED] == 0) b.pert_tick(pert, e, dt); sync(); }      // enable_rand_perturbs (a parked character's row rests)
         b.kin_update(dt);
@@ -614,7 +614,7 @@ _Pragma("unroll") \
             if (ph == 1) {
                 if (hl < m.J) { v3 da = b.gravity_a0() - b.spd_a0(); st3(s.aj[hl], ld3(s.aj[hl]) + da); }
                 sync();
-            } else b.kinematics(s.pose, s.vel, ph == 0 ? b.spd_a0() : b.gravity_a0());
+            } else if (!(kin_done && ph == 0)) b.kinematics(s.pose, s.vel, ph == 0 ? b.spd_a0() : b.gravity_a0());      // (ph 0: EnvSim::kin_pre ran it)
             b.mark(ph == 0 ? 1 : 5);
             dynamics(ph == 0 ? 0 : 1, ph == 0 ? rdt : (Real)0);
             b.mark(ph == 0 ? 2 : 6);
@@ -647,7 +647,7 @@ _Pragma("unroll") \
             double cur = s.clk[CLK_CTRL] + s.clk[CLK_INIT_OFF], pad = 0.001 * dt;
             int c1 = (int)floor((cur + pad) / m.query_period), c0 = (int)floor((cur + pad - dt) / m.query_period);
             s.flg[FLG_NEED_ACTION] = (c1 != c0) ? 1 : 0;
-            s.flg[FLG_OVER] = b.episode_over_now() ? 1 : 0;
+            s.flg[FLG_OVER] = (s.flg[FLG_OVER] & 2) | (b.episode_over_now() ? 1 : 0);
         }
         sync();
     }
@@ -676,17 +676,27 @@ __global__ void __launch_bounds__(64) DM_WAVES_PER_EU((DuoWaves<Real>::value)) k
     for (int u = 0; u < io.n_updates; ++u) {
         int eo = e; if (HIST) DM_OPAQUE_V(eo);          // see k_env_step: per-env addresses and draw keys of the rare paths are formed at their use
         double* po = (HIST && st.pert) ? st.pert + (size_t)eo * PT_WIDTH : nullptr;
+        // link kinematics of the state + the validity test the driver runs after the previous update (EnvSim::kin_pre); a character found
+        // invalid is over as of that update: both over -> done, one -> parked, exactly like an episode end
+        sim.b.kin_pre(lds[half].flg[FLG_PARKED] == 0);
+        if (io.end_early && ((lds[0].flg[FLG_OVER] | lds[1].flg[FLG_OVER]) & 2)) {
+            const int o0 = lds[0].flg[FLG_OVER] | lds[0].flg[FLG_PARKED], o1 = lds[1].flg[FLG_OVER] | lds[1].flg[FLG_PARKED];
+            if (o0 && o1) break;
+            const bool now = lds[half].flg[FLG_OVER] != 0 && lds[half].flg[FLG_PARKED] == 0;
+            sim.b.park(snap[half], now);
+            sim.b.kin_pre(false);                        // (the parked character's link state follows its new pose)
+        }
         if (HIST && st.hist) sim.b.latch_hist(st, eo, lds[half].flg[FLG_PARKED] == 0);
         if (goal) sim.b.goal_latch(st, eo, io.dt, lds[half].flg[FLG_PARKED] == 0);
-        sim.template update<HIST>(io.dt, eo, aovf_pair, po);
+        sim.template update<HIST>(io.dt, eo, aovf_pair, po, true);
         if (goal) sim.b.goal_update(st, eo, io.dt, lds[half].flg[FLG_PARKED] == 0);      // the update that ends an episode includes its goal update
         if (io.end_early) {
             // DM_END_EPISODE_EARLY.  FLG_OVER is latched by each character's lane 0 at the end of update() (wave-uniform reads).
             // Both over: the wave is done.  One over (a few percent of the waves of a launch): what the outputs need of its record
             // is copied aside (LDS) and the character is parked; the copy comes back before the outputs are written.
-            const int o0 = lds[0].flg[FLG_OVER] | lds[0].flg[FLG_PARKED], o1 = lds[1].flg[FLG_OVER] | lds[1].flg[FLG_PARKED];
-            if (o0 & o1) break;
-            if ((o0 & ~lds[0].flg[FLG_PARKED]) | (o1 & ~lds[1].flg[FLG_PARKED])) {
+            const bool v0 = lds[0].flg[FLG_OVER] != 0, v1 = lds[1].flg[FLG_OVER] != 0, p0 = lds[0].flg[FLG_PARKED] != 0, p1 = lds[1].flg[FLG_PARKED] != 0;
+            if ((v0 || p0) && (v1 || p1)) break;
+            if ((v0 && !p0) || (v1 && !p1)) {
                 const bool now = lds[half].flg[FLG_OVER] != 0 && lds[half].flg[FLG_PARKED] == 0;
                 sim.b.park(snap[half], now);
             }

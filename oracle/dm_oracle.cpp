@@ -433,10 +433,10 @@ double orc_rollout_auto_reset(void* h, int steps, int updates_per_step, double d
     auto t_beg = std::chrono::steady_clock::now();
     for (int k = 0; k < steps; ++k) {
         orc_kin_eval(h, s->kin.time, kp.data(), kv.data()); orc_pose_to_action(h, kp.data(), a.data()); s->set_action(a.data());
-        for (int u = 0; u < updates_per_step; ++u) { s->update(dt); if (s->is_episode_end()) break; }   // the driver ends an episode at the update where it is over (DeepMimic.py:62-80)
+        for (int u = 0; u < updates_per_step; ++u) { s->update(dt); if (s->is_episode_end() || !s->check_valid_episode()) break; }   // the driver ends an episode at the update where it is over or invalid (DeepMimic.py:62-80)
         double r = s->calc_reward(); rsum += r; live += (r != 0.0);
         double st[512]; s->record_state(st);
-        if (s->is_episode_end()) { s->reset(s->mo.duration() * rand01_(seed, (uint64_t)env_id, ep, 0), draw_timer(ep)); ++ep; resets += 1; }
+        if (s->is_episode_end() || !s->check_valid_episode()) { s->reset(s->mo.duration() * rand01_(seed, (uint64_t)env_id, ep, 0), draw_timer(ep)); ++ep; resets += 1; }
     }
     auto t_end = std::chrono::steady_clock::now();
     if (stats) { stats[0] = resets; stats[1] = rsum; stats[2] = live; }

@@ -300,11 +300,11 @@ class Oracle:
 
     def control_step(self, n_updates=20, dt=1.0 / 600, end_early=True):
         """n_updates scene updates; with end_early the loop stops after the update at which the episode is over, the way the
-        reference's driver does (DeepMimic.py:62-80).  Criteria as on the device (EnvSim::episode_over_now): terminate != Null
-        or the episode timer.  Returns the number of updates run."""
+        reference's driver does (DeepMimic.py:62-80).  Criteria as on the device (EnvSim::episode_over_now, kin_pre): terminate != Null,
+        the episode timer, or an invalid episode (a link velocity beyond 100).  Returns the number of updates run."""
         for u in range(n_updates):
             self.update(dt)
-            if end_early and self.is_episode_end():
+            if end_early and (self.is_episode_end() or not self.check_valid_episode()):      # the driver tests both after every update
                 return u + 1
         return n_updates
 

@@ -397,7 +397,7 @@ def auto_reset_rollout_compare(name, precision, lib_path, steps, n, seed, wave_p
             alive[k, e] = r != 0.0
             term, end = o.check_terminate(), o.is_episode_end()
             ok &= int(out["terminate"][e]) == term and bool(out["episode_end"][e]) == end and int(out["valid"][e]) == int(o.check_valid_episode())
-            if end:       # the device resets after writing reward / flags; its observation is the first of the new episode
+            if end or not o.check_valid_episode():       # the device resets after writing reward / flags (an invalid episode is reset too); its observation is the first of the new episode
                 u, mt = draw(e, int(ep[e]))
                 o.reset(o.duration * u, mt)
                 ep[e] += 1; resets += 1
@@ -504,9 +504,10 @@ def goal_rollout_compare(t, precision, lib_path, steps, n, seed, wave_packing=0,
             w["scored"] += 1
             w["reward"] = max(w["reward"], abs(float(out["reward"][e]) - r)); w["live"] += int(r != 0.0)
             w["reward_errs"].append(abs(float(out["reward"][e]) - r))
-            w["flags_ok"] &= int(out["terminate"][e]) == term and bool(out["episode_end"][e]) == end
+            valid = o.check_valid_episode()
+            w["flags_ok"] &= int(out["terminate"][e]) == term and bool(out["episode_end"][e]) == end and int(out["valid"][e]) == int(valid)
             w["succ"] += int(term == 2); w["fail"] += int(term == 1)
-            if end:
+            if end or not valid:                                    # (the driver resets after an invalid episode as after an ended one)
                 c, kt, mt, yaw = draw(o, e, int(ep[e]))
                 if o.maybe_recovery_reset(mt):                      # heading_amp_getup, train mode: the episode goes on as a recovery episode
                     w["recoveries"] += 1; c = int(clips[e])

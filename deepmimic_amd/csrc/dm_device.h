@@ -63,6 +63,7 @@ static inline double dm_rcp(double x) { return 1.0 / x; }
 template <typename T> static inline T dm_med3(T lo, T x, T hi) { return x < lo ? lo : (x > hi ? hi : x); }
 // (bit l of MASK) ? a : b for a compile-time lane mask
 template <uint64_t MASK, typename T> static inline T lane_sel(T a, T b, int l, uint64_t) { return ((MASK >> (l & 63)) & 1ull) ? a : b; }
+template <int R, typename T> static inline T row_sel_c(T oldv, T newv, int l, uint32_t) { return l == R ? newv : oldv; }
 template <typename Real, int N> struct RowFile {       // per-lane array indexed by a wave-uniform runtime index
     Real v[N];
     inline Real get(int r) const { return v[r]; }
@@ -155,6 +156,16 @@ template <uint64_t MASK> __device__ __forceinline__ float lane_sel(float a, floa
     return out;
 }
 template <uint64_t MASK> __device__ __forceinline__ double lane_sel(double a, double b, int l, uint64_t) { return ((MASK >> (l & 63)) & 1ull) ? a : b; }
+// lane R takes `newv`: the select mask is an SGPR pair made on the scalar unit from `one` (s_lshl + s_mov) instead of a v_cmp; `one` is
+// re-made opaque per sweep, or the 64 masks are hoisted out of the iteration loop and spilled (then every row reloads its pair by v_readlane)
+template <int R> __device__ __forceinline__ float row_sel_c(float oldv, float newv, int, uint32_t one) {
+    const uint32_t m32 = one << (R & 31);
+    const uint64_t mk = (R < 32) ? (uint64_t)m32 : ((uint64_t)m32 << 32);
+    float out;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(out) : "v"(oldv), "v"(newv), "s"(mk));
+    return out;
+}
+template <int R> __device__ __forceinline__ double row_sel_c(double oldv, double newv, int l, uint32_t) { return l == R ? newv : oldv; }
 // per-lane array indexed by a wave-uniform runtime index.  For float it is two 32-wide register vectors that the
 // backend addresses with M0-relative VGPR indexing, so a row of A never leaves the VGPRs.
 template <typename Real, int N> struct RowFile {
@@ -1433,14 +1444,14 @@ struct EnvSim {
             Real pre[PFD + 1] = {};
             for (int it = 0; it < m.solver_iters; ++it) {
                 DM_OPAQUE_S(Rv); DM_OPAQUE_S(RNv); DM_OPAQUE_V(lv);
+                uint32_t one = 1; DM_OPAQUE_S(one);
                 // statically unrolled over the row id (register-file index and lane select are immediates); rows >= R are
                 // skipped in blocks of 4 by wave-uniform branches (a lane beyond R has t = 0, lambda = 0 and changes nothing)
-#pragma unroll
-                for (int blk = 0; blk < kMaxRows / 4; ++blk) {
+                static_for<0, kMaxRows / 4>([&](auto blkc) {
+                    constexpr int blk = decltype(blkc)::value;
                     if (blk * 4 < Rv) {
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            const int r = blk * 4 + i;
+                        static_for<0, 4>([&](auto ic) {
+                            constexpr int r = blk * 4 + decltype(ic)::value;
                             if (__builtin_expect(r == RNv, 0)) { const Real ln = wave_shfl(lam, nrm_lane); if (is_fric) { hi = mu_row * ln; lo = -hi; } }
                             // rows >= RREG live in the HBM/L2 overflow block: row r + PFD is requested PFD rows ahead (a ring of
                             // registers), so the load latency sits beside the sweep's dependent chain instead of on it
@@ -1449,10 +1460,11 @@ struct EnvSim {
                             const Real delta = lane_bcast(nl - lam, r);
                             const Real ar = (r < RREG) ? arow.get(r < RREG ? r : 0) : pre[r % (PFD + 1)];
                             t -= ar * delta;
-                            if (lv == r) lam = nl;
-                        }
+                            if constexpr (C::PGS_MASKSEL) lam = row_sel_c<r>(lam, nl, lv, one);        // lane r takes its new lambda: a select on a scalar-unit lane mask (no v_cmp)
+                            else if (lv == r) lam = nl;
+                        });
                     }
-                }
+                });
             }
             if (l >= R) lam = 0;
         } else mark(10);

@@ -28,6 +28,7 @@ struct ClsBiped {      // humanoid3d: 15 links, 34 dof, 43 pose dims, <= 64 grou
     static constexpr bool OBJ = false;      // no free rigid body next to the character
     static constexpr bool TREE = false;     // dense LL^T factor (TREE classes: branch-sparse, level-scheduled L^T L on a compiled topology)
     static constexpr bool BROAD = false;    // self collision: every link pair goes through the segment-segment test (BROAD classes: bounding-sphere cull first)
+    static constexpr bool PGS_MASKSEL = false;      // sweep: lane r takes its new lambda by v_cmp + v_cndmask (MASKSEL classes: a select on a constant SGPR lane mask)
     static constexpr bool GRAM64 = false;   // 64-row Gram matrix by the readlane loop (128-VGPR budget of the one-per-wave kernel)
     static constexpr int PFD = 2;           // look-ahead of the sweep into the overflow block of A, rows
 };
@@ -39,11 +40,11 @@ struct ClsBipedWide : ClsBiped { static constexpr int RREG = 64; };
 struct ClsBipedFb : ClsBiped { static constexpr bool GRAM64 = true; };   // (a look-ahead of 6 rows instead of 2 measured no gain)
 // the biped class plus one free rigid sphere in the world (`--scene dribble_amp`: the ball, scenes/SceneDribbleAMP.cpp:398-420); one
 // character per wavefront, 2 waves / SIMD (the ball's Jacobian columns ride in six more VGPRs per row lane)
-struct ClsBipedObj : ClsBiped { static constexpr bool OBJ = true; };
+struct ClsBipedObj : ClsBiped { static constexpr bool OBJ = true; static constexpr bool PGS_MASKSEL = true; };     // (same-box A/B of the mask select: -3.6 %; ClsBiped at 128 VGPRs: +2.8 %, SGPR pressure)
 struct ClsLarge {      // dog3d and anything up to 23 links / 64 dof / 83 pose dims / 128 candidates, attach rotations allowed
     static constexpr int NJ = 23, ND = 64, NP = 83, NCAP = 128, RREG = 32, NPAIRCAP = 256, LPAD = 2; static constexpr bool ROT = true;
     static constexpr bool GRAM64 = false; static constexpr int PFD = 2; static constexpr bool OBJ = false; static constexpr bool TREE = false;
-    static constexpr bool BROAD = false;
+    static constexpr bool BROAD = false; static constexpr bool PGS_MASKSEL = false;
 };
 
 // ---- compiled skeleton topologies (the elimination program of the branch-sparse factor is generated at compile time) -------------
@@ -118,7 +119,7 @@ struct TopoHumanoid3d {
 // factor -- its 31 row lanes per character have no room for the root-translation columns, which an L^T L elimination finishes LAST)
 struct ClsBipedTree : ClsBiped { static constexpr bool TREE = true; typedef TopoHumanoid3d Topo; };
 // the large class on dog3d's compiled topology
-struct ClsLargeTree : ClsLarge { static constexpr bool TREE = true; typedef TopoDog3d Topo; static constexpr bool GRAM64 = true; static constexpr bool BROAD = true; };   // (more than 32 rows: Gram on the matrix core too)
+struct ClsLargeTree : ClsLarge { static constexpr bool TREE = true; typedef TopoDog3d Topo; static constexpr bool GRAM64 = true; static constexpr bool BROAD = true; static constexpr bool PGS_MASKSEL = true; };   // (more than 32 rows: Gram on the matrix core too)
 
 // link_info word: parent+1 [0:4] | jtype [5:7] | depth [8:11] | pose_off [12:18] | dof_off [19:25] | arot_ident 26 | brot_ident 27 | is_ee 28 | fall 29
 #define DM_LI_PARENT(i) (((i) & 31) - 1)

@@ -185,6 +185,15 @@ template <> struct RowFile<float, 64> {
     __device__ __forceinline__ float get(int r) const { return (r < 32) ? a[r] : b[r - 32]; }
     __device__ __forceinline__ void set(int r, float x) { if (r < 32) a[r] = x; else b[r - 32] = x; }
 };
+// 48 rows: the compiled dog3d class at 2 waves / SIMD has room for 16 more row registers; 25.6 % of its substeps have more than 32 rows,
+// 1.8 % more than 48 (profiles/r03_rows_hist.txt), so the HBM / L2 overflow block leaves the common path
+template <> struct RowFile<float, 48> {
+    typedef float v32 __attribute__((ext_vector_type(32)));
+    typedef float v16 __attribute__((ext_vector_type(16)));
+    v32 a; v16 b;
+    __device__ __forceinline__ float get(int r) const { return (r < 32) ? a[r] : b[r - 32]; }
+    __device__ __forceinline__ void set(int r, float x) { if (r < 32) a[r] = x; else b[r - 32] = x; }
+};
 // two / four packed reals: v_pk_fma_f32 / ds_read_b128 operands
 template <typename Real> struct VecT;
 template <> struct VecT<float> { typedef float v2 __attribute__((ext_vector_type(2))); typedef float v4 __attribute__((ext_vector_type(4))); };
@@ -289,6 +298,13 @@ template <int NP2> __device__ __forceinline__ void wave_gram32(const VecT<double
 }
 #endif
 
+#ifndef DM_PRIO_ONE
+#define DM_PRIO_ONE 0
+#endif
+#ifndef DM_PRIO_ONE_LO
+#define DM_PRIO_ONE_LO 28
+#define DM_PRIO_ONE_HI 40
+#endif
 namespace dmk {
 
 // compile-time loop: f(std::integral_constant<int, I>) for I = B .. E - 1 (where the index has to be a template argument)
@@ -1119,8 +1135,12 @@ struct EnvSim {
         }
     }
     // s.rhs holds qddot of the unconstrained dynamics; s.L the Cholesky factor of H.
-    template <bool V2 = false>
+    // PLAIN: the tap-free imitate instantiation without perturbations / manifolds; a class may give it a wider row file (C::RREG_PLAIN:
+    // the registers the AMP / v2 code needs elsewhere are free there)
+    template <bool V2 = false, bool PLAIN = false>
     DM_DEV void substep_post(Real h, DebugTaps<Real> dbg, int e, Real* aovf, Real* manif = nullptr) {
+        constexpr int RREG = PLAIN ? C::RREG_PLAIN : C::RREG;
+        static_assert(RREG >= C::RREG, "the overflow block is sized for C::RREG");
         const int D = m.D, J = m.J;
         Real vstar = 0; int vidx = 0;
         if (l < D) { vidx = DM_DI_VIDX(s.mdl.dof_info[l]); vstar = clamp_vel(s.vel[vidx] + h * s.rhs[l], l); s.dofrec[l][6] = vstar; }
@@ -1408,14 +1428,18 @@ struct EnvSim {
             } else if (C::GRAM64) {
                 // narrow row file, Gram on the matrix core: rows 32..63 go to the overflow block ([row][lane]; all of them, the sweep reads
                 // rows < R only)
-                static_assert(RREG == 32 || !C::GRAM64, "two halves of 32 entries");
+                static_assert(RREG >= 32 || !C::GRAM64, "two halves of 32 entries");
 #pragma unroll
                 for (int p = 0; p < NP2X; ++p) DM_OPAQUE_V(y2[p]);
                 {
                     Real g[32];
-                    wave_gram64_half<NP2X, 1>(y2, g);            // entries 32..63 first: they leave for the overflow block at once
+                    wave_gram64_half<NP2X, 1>(y2, g);            // entries 32..63 first: those past RREG leave for the overflow block at once
 #pragma unroll
-                    for (int r = 0; r < 32; ++r) aovf[r * kWave + l] = (l == r + 32) ? (Real)0 : g[r] * inv_adiag;
+                    for (int r = 0; r < 32; ++r) if (32 + r < RREG) arow.set(32 + r < RREG ? 32 + r : 0, (l == r + 32) ? (Real)0 : g[r] * inv_adiag);
+                    if (RREG < kMaxRows && R > RREG) {
+#pragma unroll
+                        for (int r = 0; r < 32; ++r) if (32 + r >= RREG) aovf[(32 + r - RREG) * kWave + l] = (l == r + 32) ? (Real)0 : g[r] * inv_adiag;
+                    }
                 }
 #pragma unroll
                 for (int p = 0; p < NP2X; ++p) DM_OPAQUE_V(y2[p]);
@@ -1442,6 +1466,11 @@ struct EnvSim {
             int Rv = R, RNv = RN, lv = l;
             constexpr int PFD = C::PFD;             // rows of look-ahead for the overflow block (a ring of PFD + 1 registers)
             Real pre[PFD + 1] = {};
+#if DM_PRIO_ONE == 1
+            __builtin_amdgcn_s_setprio(3);
+#elif DM_PRIO_ONE == 2
+            if (Rv > DM_PRIO_ONE_HI) __builtin_amdgcn_s_setprio(3); else if (Rv > DM_PRIO_ONE_LO) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(1);
+#endif
             for (int it = 0; it < m.solver_iters; ++it) {
                 DM_OPAQUE_S(Rv); DM_OPAQUE_S(RNv); DM_OPAQUE_V(lv);
                 uint32_t one = 1; DM_OPAQUE_S(one);
@@ -1466,6 +1495,9 @@ struct EnvSim {
                     }
                 });
             }
+#if DM_PRIO_ONE
+            __builtin_amdgcn_s_setprio(0);
+#endif
             if (l >= R) lam = 0;
         } else mark(10);
         mark(11);
@@ -1687,7 +1719,7 @@ struct EnvSim {
         if constexpr (C::TREE) tree_solve(s.rhs); else chol_solve(s.rhs);
         DM_OPAQUE_V(l); DM_OPAQUE_V(li);
         if (ph == 0) { mark(3); spd_post(dt); }
-        else substep_post<V2>(h, dbg, e, aovf, manif);
+        else substep_post<V2, !TAPS && !PERT && !V2>(h, dbg, e, aovf, manif);
     }
     // Top of a scene update, before anything of it changes the env: link kinematics of the current state (the stable-PD pass of this
     // update reuses them, kin_done) and cSceneSimChar::CheckValidEpisode on them (cSimCharacter::HasVelExploded, sim/SimCharacter.cpp:

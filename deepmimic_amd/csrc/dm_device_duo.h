@@ -12,6 +12,13 @@
 // routine of dm_device.h on each record in turn (same LDS record layout), so the results do not depend on the pairing.
 #pragma once
 #include "dm_device.h"
+#ifndef DM_PRIO
+#define DM_PRIO 0
+#endif
+#ifndef DM_PRIO_LO
+#define DM_PRIO_LO 16
+#define DM_PRIO_HI 22
+#endif
 
 namespace dmk {
 
@@ -458,6 +465,16 @@ _Pragma("unroll") \
         }
         const int NL = m.NL;
         const int R = NL + 3 * nc;
+#if DM_PRIO == 2 || DM_PRIO == 3
+        // wave priority by load, kept until the next substep's count: a wave with more rows than the median pair wins issue arbitration
+        // against its (lighter) SIMD mate in every phase
+        {
+            const int Rmx_ = dm_max(lane_bcast(R, 0), lane_bcast(R, 32));
+            if (Rmx_ > DM_PRIO_HI) __builtin_amdgcn_s_setprio(3);
+            else if (Rmx_ > DM_PRIO_LO) __builtin_amdgcn_s_setprio(DM_PRIO == 3 ? 2 : 1);
+            else __builtin_amdgcn_s_setprio(0);
+        }
+#endif
         if (wave_ballot(R > HW) != 0) return false;      // a heavily contacted character: the caller runs the one-per-wave routine
         if (hl == 0) { s.flg[FLG_NROWS] = R; s.flg[FLG_NCONT] = nc; }
         sync();
@@ -553,6 +570,11 @@ _Pragma("unroll") \
                 lam = half_sel_c<(r)>(lam, nl, lv, one);                                                               \
             }
 #define DM_DUO_PGS_BLK(b4) if ((b4) * 4 < Rv) { DM_DUO_PGS_ROW((b4) * 4) DM_DUO_PGS_ROW((b4) * 4 + 1) DM_DUO_PGS_ROW((b4) * 4 + 2) DM_DUO_PGS_ROW((b4) * 4 + 3) }
+#if DM_PRIO == 1
+            if (Rv > DM_PRIO_HI) __builtin_amdgcn_s_setprio(3); else if (Rv > DM_PRIO_LO) __builtin_amdgcn_s_setprio(2);
+#elif DM_PRIO == 4
+            if (Rv > DM_PRIO_HI) __builtin_amdgcn_s_setprio(3); else if (Rv > DM_PRIO_LO) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(1);
+#endif
             for (int it = 0; it < m.solver_iters; ++it) {
                 uint32_t one = 1u;
                 DM_OPAQUE_S(Rv); DM_OPAQUE_S(fmask); DM_OPAQUE_V(lv); DM_OPAQUE_S(one);
@@ -561,6 +583,9 @@ _Pragma("unroll") \
             }
 #undef DM_DUO_PGS_BLK
 #undef DM_DUO_PGS_ROW
+#if DM_PRIO == 1 || DM_PRIO == 4
+            __builtin_amdgcn_s_setprio(0);
+#endif
             if (hl >= R) lam = 0;
         } else b.mark(10);
         b.mark(11);

@@ -24,7 +24,7 @@ constexpr int kMaxContacts = 20;   // contact slots per character (ground + self
 
 // Compiled kernel classes: static bounds of the per-lane register arrays and the LDS record.
 struct ClsBiped {      // humanoid3d: 15 links, 34 dof, 43 pose dims, <= 64 ground-contact candidates, no attach rotations
-    static constexpr int NJ = 15, ND = 34, NP = 43, NCAP = 64, RREG = 32, NPAIRCAP = 128, LPAD = 4; static constexpr bool ROT = false;   // RREG: rows of A kept in VGPRs
+    static constexpr int NJ = 15, ND = 34, NP = 43, NCAP = 64, RREG = 32, RREG_PLAIN = 32, NPAIRCAP = 128, LPAD = 4; static constexpr bool ROT = false;   // RREG: rows of A kept in VGPRs
     static constexpr bool OBJ = false;      // no free rigid body next to the character
     static constexpr bool TREE = false;     // dense LL^T factor (TREE classes: branch-sparse, level-scheduled L^T L on a compiled topology)
     static constexpr bool BROAD = false;    // self collision: every link pair goes through the segment-segment test (BROAD classes: bounding-sphere cull first)
@@ -34,7 +34,7 @@ struct ClsBiped {      // humanoid3d: 15 links, 34 dof, 43 pose dims, <= 64 grou
 };
 // the same character class with all 64 rows of A in VGPRs: the instantiation the two-per-wave kernel falls back to for a pair with a
 // heavily contacted character (256-VGPR budget there; identical LDS record layout)
-struct ClsBipedWide : ClsBiped { static constexpr int RREG = 64; };
+struct ClsBipedWide : ClsBiped { static constexpr int RREG = 64, RREG_PLAIN = 64; };
 // the fallback class of the two-per-wave kernel by default: the narrow row file (rows 32..63 of A in the HBM / L2 overflow block), but
 // the Gram matrix of a character with more than 32 rows still comes off the matrix core (64 accumulators live for the Gram only)
 struct ClsBipedFb : ClsBiped { static constexpr bool GRAM64 = true; };   // (a look-ahead of 6 rows instead of 2 measured no gain)
@@ -42,7 +42,7 @@ struct ClsBipedFb : ClsBiped { static constexpr bool GRAM64 = true; };   // (a l
 // character per wavefront, 2 waves / SIMD (the ball's Jacobian columns ride in six more VGPRs per row lane)
 struct ClsBipedObj : ClsBiped { static constexpr bool OBJ = true; static constexpr bool PGS_MASKSEL = true; };     // (same-box A/B of the mask select: -3.6 %; ClsBiped at 128 VGPRs: +2.8 %, SGPR pressure)
 struct ClsLarge {      // dog3d and anything up to 23 links / 64 dof / 83 pose dims / 128 candidates, attach rotations allowed
-    static constexpr int NJ = 23, ND = 64, NP = 83, NCAP = 128, RREG = 32, NPAIRCAP = 256, LPAD = 2; static constexpr bool ROT = true;
+    static constexpr int NJ = 23, ND = 64, NP = 83, NCAP = 128, RREG = 32, RREG_PLAIN = 32, NPAIRCAP = 256, LPAD = 2; static constexpr bool ROT = true;
     static constexpr bool GRAM64 = false; static constexpr int PFD = 2; static constexpr bool OBJ = false; static constexpr bool TREE = false;
     static constexpr bool BROAD = false; static constexpr bool PGS_MASKSEL = false;
 };
@@ -119,7 +119,13 @@ struct TopoHumanoid3d {
 // factor -- its 31 row lanes per character have no room for the root-translation columns, which an L^T L elimination finishes LAST)
 struct ClsBipedTree : ClsBiped { static constexpr bool TREE = true; typedef TopoHumanoid3d Topo; };
 // the large class on dog3d's compiled topology
-struct ClsLargeTree : ClsLarge { static constexpr bool TREE = true; typedef TopoDog3d Topo; static constexpr bool GRAM64 = true; static constexpr bool BROAD = true; static constexpr bool PGS_MASKSEL = true; };   // (more than 32 rows: Gram on the matrix core too)
+// rows of A in VGPRs for the plain imitate instantiation of the compiled dog3d class.  25.6 % of the dog's substeps have more than 32 rows, 1.8 % more
+// than 48, none more than 56 (profiles/r03_rows_hist.txt); 48 / 56 / 64 all compile to 0 scratch at 2 waves / SIMD (239 / 247 / 256 VGPRs) and measure
+// +3.3 / +3.7 / +3.4 % over 32 on one box with bit-identical outputs (profiles/r04_ab_dog_rreg.json).  The AMP / v2 instantiations keep 32 (48 spills there).
+#ifndef DM_DOG_RREG
+#define DM_DOG_RREG 56
+#endif
+struct ClsLargeTree : ClsLarge { static constexpr int RREG_PLAIN = DM_DOG_RREG; static constexpr bool TREE = true; typedef TopoDog3d Topo; static constexpr bool GRAM64 = true; static constexpr bool BROAD = true; static constexpr bool PGS_MASKSEL = true; };   // (more than 32 rows: Gram on the matrix core too)
 
 // link_info word: parent+1 [0:4] | jtype [5:7] | depth [8:11] | pose_off [12:18] | dof_off [19:25] | arot_ident 26 | brot_ident 27 | is_ee 28 | fall 29
 #define DM_LI_PARENT(i) (((i) & 31) - 1)

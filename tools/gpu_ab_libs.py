@@ -19,4 +19,11 @@ res = {k: [] for k in envs}
 for rep in range(5):
     for tag, env in envs.items():
         res[tag].append(env.bench_rollout(0, 100) / 100)
-print(json.dumps({"scene": scene, "envs": n, "wave_packing": pack, **{tag: {"kernel_ms_median": float(np.median(v)), "env_steps_per_s": n / (float(np.median(v)) * 1e-3)} for tag, v in res.items()}}))
+# outputs of the variants on an identical 40-step rollout (a variant that only moves data must reproduce them bit for bit)
+chk = {}
+for tag, env in envs.items():
+    env.reset(kin_times=streams.reset_phase(np.arange(n), env.duration))
+    out = None
+    for _ in range(40): out = env.step(None, 1.0 / 600, 20, auto_reset=True, open_loop=True)
+    chk[tag] = {"reward_sum": float(np.asarray(out["reward"], dtype=np.float64).sum()), "state_abs_sum": float(np.abs(np.asarray(out["state"], dtype=np.float64)).sum())}
+print(json.dumps({"scene": scene, "envs": n, "wave_packing": pack, **{tag: {"kernel_ms_median": float(np.median(v)), "env_steps_per_s": n / (float(np.median(v)) * 1e-3)} for tag, v in res.items()}, "checksums": chk}))

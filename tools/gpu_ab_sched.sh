@@ -12,3 +12,8 @@ d = json.load(open("$OUT/$TAG.json"))
 for k, v in d.items():
     if isinstance(v, dict): print("%-44s %.4f ms  %.0f" % (k, v["kernel_ms_median"], v["env_steps_per_s"]))
 EOF
+python - <<EOF2
+import json
+d = json.load(open("$OUT/$TAG.json"))
+for k, v in d.get("checksums", {}).items(): print("%-44s reward_sum %.9g  state_abs_sum %.9g" % (k, v["reward_sum"], v["state_abs_sum"]))
+EOF2

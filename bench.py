@@ -22,6 +22,9 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# HIP maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4); kernels of two streams that share a queue do not overlap.  Eight keeps the
+# env groups' streams, torch's and RCCL's apart whatever the creation order (no effect on a one-stream run: measured).  Read at HIP initialisation.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import numpy as np  # noqa: E402
 
@@ -51,6 +54,41 @@ def measured_traffic(scene, n, kernel=None):
         except Exception:
             continue
     return None, None
+
+
+def measured_valu(scene, n, kernel, env_steps_per_s):
+    """The figures that actually bind this kernel (VALU issue + dependent-chain latency; HBM is ~0 by construction), from the committed
+    rocprofv3 PMC passes of the same workload and kernel (profiles/r0N_pmc_sq*.json, r0N_flops*.json; newest round first): VALU busy
+    fraction of SIMD time, the share of wave cycles spent in s_waitcnt, VALU instructions per env-step, and -- issued lane-flops per
+    env-step x the rate of THIS run -- issued TFLOP/s against the 157.3 TFLOP/s fp32 vector peak.  Committed counters, not counters of
+    this run (PMC passes serialise the kernels); `source` names the files."""
+    import glob
+    out = {"binding": "VALU issue + dependent-chain latency (fp32 vector)", "fp32_vector_peak_tflops": 157.3, "source": []}
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_sq*.json")), reverse=True):
+        try:
+            with open(path) as f:
+                t = json.load(f)
+            if t.get("scene") == scene and int(t.get("envs", -1)) == n and t.get("kernel", kernel) == kernel:
+                out["valu_busy"] = t["derived"]["valu_busy_fraction_of_simd_time"]
+                out["wait_fraction"] = t["SQ_WAIT_ANY"] / t["SQ_WAVE_CYCLES"]
+                out["valu_instructions_per_env_step"] = t["derived"]["valu_instructions_per_env_step"]
+                out["source"].append(os.path.relpath(path, ROOT))
+                break
+        except Exception:
+            continue
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_flops*.json")), reverse=True):
+        try:
+            with open(path) as f:
+                t = json.load(f)
+            if t.get("scene") == scene and int(t.get("envs", -1)) == n and t.get("kernel", kernel) == kernel:
+                out["issued_flops_per_env_step"] = t["issued_flops_per_env_step"]
+                out["issued_tflops"] = t["issued_flops_per_env_step"] * env_steps_per_s / 1e12
+                out["frac_of_fp32_peak"] = out["issued_tflops"] / 157.3
+                out["source"].append(os.path.relpath(path, ROOT))
+                break
+        except Exception:
+            continue
+    return out if out["source"] else None
 
 
 def self_launch(argv, n):
@@ -211,6 +249,11 @@ def main():
     ap.add_argument("--precision", type=int, default=32)
     ap.add_argument("--wave-packing", type=int, default=0, help="characters per wavefront of the step kernel: 0 = the library's default (2 for the biped class, 1 for the dog and for dribble_amp), 1 or 2")
     ap.add_argument("--physics", type=int, default=1, choices=[1, 2], help="contact model: 1 = DM-physics v1 (default, the headline), 2 = v2 (DESIGN.md 4.6; one character per wavefront)")
+    ap.add_argument("--groups", type=int, default=0,
+                    help="env groups per GPU: the rank's envs as G independent contexts on their own HIP streams (deepmimic_amd/groups.py; "
+                         "0 = auto (2 for the two-per-wave biped kernel, +5..7 %%: the half-batches drift apart in phase and fill each other's wave-time tail; 1 otherwise); 1 = one launch per control step")
+    ap.add_argument("--sustain-seconds", type=float, default=2.5,
+                    help="after the timed --steps region, run back-to-back control steps for at least this long and report that rate too (`sustained`); 0 = skip")
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--force-gather", action="store_true", help="exercise the record exchange even with one rank")
     ap.add_argument("--gather", choices=["torch", "cabi"], default="torch",
@@ -271,37 +314,79 @@ def main():
 
     tables = model.load_asset(args.scene)
     n = args.envs
-    env = BatchEnv(tables, n, device_id=local_rank if on_gpu else 0, seed=1234, precision=args.precision, env_id_offset=rank * n, test_mode=True,
-                   wave_packing=1 if args.physics == 2 else args.wave_packing, physics=args.physics)
-    if on_gpu:
-        env.set_stream(torch.cuda.current_stream().cuda_stream)
+    from deepmimic_amd.groups import EnvGroups
+    gather = (world > 1 or args.force_gather) and not args.no_gather
+    # --groups 0 (default): two groups where a launch is one round of waves (the two-per-wave biped kernel at <= 4096 envs: 2048 waves on 2048
+    # wave slots), one launch per step otherwise (the dog's 4096 one-per-wave launches are two rounds already: groups measured -4 %)
+    duo_kernel = args.wave_packing != 1 and args.physics == 1 and tables.joint_mat.shape[0] <= 15 and tables.goal_kind != 5 and n % 2 == 0
+    auto_groups = 2 if (duo_kernel and n <= 4096) else 1
+    want_groups = 1 if (args.gather == "cabi" and gather) else (auto_groups if args.groups <= 0 else args.groups)      # (the C-ABI exchange orders one ctx stream against the comm stream)
+    envs = EnvGroups(tables, n, groups=want_groups, device_id=local_rank if on_gpu else 0, seed=1234, precision=args.precision, env_id_offset=rank * n,
+                     test_mode=True, wave_packing=1 if args.physics == 2 else args.wave_packing, physics=args.physics)
+    G = envs.G
+    env = envs.envs[0]
+    main_stream = torch.cuda.current_stream() if on_gpu else None
+    # groups run on their contexts' OWN streams (created back to back by dm_create: they land on different hardware queues, measured; two
+    # streams out of torch's pool shared one queue under the default GPU_MAX_HW_QUEUES = 4 and serialised: 1.23 M instead of 2.24 M,
+    # tools/gpu_groups_modes.py), wrapped as torch external streams so that events order them against the collective's stream
+    if on_gpu and G > 1:
+        gstreams = [torch.cuda.ExternalStream(e.own_stream(), device=dev) for e in envs.envs]
+    elif on_gpu:
+        gstreams = [main_stream]; envs.set_streams([main_stream.cuda_stream])
+    else:
+        gstreams = [None] * G
     # deterministic per-env start phase keyed by the global env id; later episodes draw from the device's
     # counter-based generator, keyed by (seed, global env id, episode)
     from deepmimic_amd import streams
-    env.reset(kin_times=streams.reset_phase(rank * n + np.arange(n), env.duration))
+    envs.reset(kin_times=streams.reset_phase(rank * n + np.arange(n), env.duration))
     valid = torch.empty((n,), dtype=torch.int32, device=dev)
     ends = torch.empty((n,), dtype=torch.int32, device=dev)
-    gather = (world > 1 or args.force_gather) and not args.no_gather
-    # per-env learner record {state[S], reward, terminate}: the step kernel writes it straight into the flat exchange buffer
-    # of slot k % 2; one RCCL all-gather per control step, issued asynchronously so that it overlaps control step k+1
+    # per-env learner record {state[S], reward, terminate}: the step kernel of a group writes it straight into that group's flat exchange
+    # buffer of slot k % 2; one RCCL all-gather per group and control step, issued asynchronously behind the group's kernel ON THE GROUP'S
+    # STREAM, so that it overlaps the group's step k + 1 and nothing ever orders one group behind another (a joint gather of both groups' records
+    # made group A's step k + 1 wait for B's step k and pulled the groups back into phase: measured 2.08 M instead of 2.21 M with one rank)
     from deepmimic_amd.dist import CabiRecordExchange, RecordExchange
     if args.gather == "cabi" and gather:
-        ex = CabiRecordExchange(env, world, rank, dev, depth=2, force_rccl=True)
+        exs = [CabiRecordExchange(env, world, rank, dev, depth=2, force_rccl=True)]
     else:
-        ex = RecordExchange(n, env.S, world, dev, depth=2, env=env)
+        exs = [RecordExchange(envs.count[g], env.S, world, dev, depth=2, env=env if G == 1 else None) for g in range(G)]
     tick = [0]
+    import contextlib
+
+    def on_stream(g):
+        return torch.cuda.stream(gstreams[g]) if (on_gpu and G > 1) else contextlib.nullcontext()
 
     def one_step():
         slot = tick[0] & 1; tick[0] += 1
-        states, rewards, term = ex.begin(slot) if gather else ex.views(slot)
-        env.step_device(0, states.data_ptr(), rewards.data_ptr(), term.data_ptr(), valid.data_ptr(), ends.data_ptr(),
-                        timestep=1.0 / 600, n_updates=20, auto_reset=True, open_loop=True)
-        if gather:
-            ex.launch(slot)
+        for g in range(G):
+            with on_stream(g):
+                states, rewards, term = exs[g].begin(slot) if gather else exs[g].views(slot)
+                r = envs.rows(g)
+                envs.envs[g].step_device(0, states.data_ptr(), rewards.data_ptr(), term.data_ptr(), valid[r].data_ptr(), ends[r].data_ptr(),
+                                         timestep=1.0 / 600, n_updates=20, auto_reset=True, open_loop=True)
+                if gather:
+                    exs[g].launch(slot)
 
     def drain():
         if gather:
-            ex.wait(0); ex.wait(1)
+            for g in range(G):
+                with on_stream(g):
+                    exs[g].wait(0); exs[g].wait(1)
+
+    def timed(k):
+        """k control steps between device-wide syncs: (wall seconds, [per-stream mean ms per launch from HIP events on the launch stream])"""
+        dev_sync()
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(G)] if on_gpu else []
+        t0_ = time.perf_counter()
+        for g in range(len(ev)):
+            ev[g][0].record(gstreams[g])
+        for _ in range(k):
+            one_step()
+        for g in range(len(ev)):
+            ev[g][1].record(gstreams[g])
+        drain()
+        dev_sync()
+        return time.perf_counter() - t0_, [a.elapsed_time(b) / k for a, b in ev]
 
     warm = max(args.warmup, args.min_warmup)
     for _ in range(warm):
@@ -310,21 +395,26 @@ def main():
     dev_sync()
     if world > 1:
         dist.barrier()
-    dev_sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        one_step()
-    drain()
-    dev_sync()
+    elapsed, launch_ms = timed(args.steps)
     if world > 1:
         dist.barrier()
-    dev_sync()
-    elapsed = time.perf_counter() - t0
     elapsed_local = elapsed
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+
+    # a sustained window behind the --steps region: >= sustain-seconds of back-to-back control steps (same step function, same exchange), so
+    # that the line also carries a rate measured over seconds (DVFS settled, visible to an outside GPU-busy sampler) next to the short one
+    sustained = None
+    if on_gpu and args.sustain_seconds > 0:
+        k2 = int(np.ceil(args.sustain_seconds / (elapsed / args.steps)))       # `elapsed` is the max over ranks: the same count on every rank
+        el2, _ = timed(k2)
+        if world > 1:
+            tt = torch.tensor([el2], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el2 = float(tt.item())
+        sustained = {"seconds": el2, "steps": k2, "value": world * n * k2 / el2, "unit": "env-steps/s", "ms_per_step": 1e3 * el2 / k2}
 
     # what the exchange costs on the critical path: the same K steps once more without it (per rank), so that a multi-GPU run is
     # interpretable -- value / N vs per_rank_no_gather tells exposed collective time from slow ranks
@@ -332,10 +422,7 @@ def main():
     exposed_ms = None
     if gather:
         gather_saved, gather = gather, False
-        dev_sync(); t1 = time.perf_counter()
-        for _ in range(args.steps):
-            one_step()
-        dev_sync(); el_ng = time.perf_counter() - t1
+        el_ng, _ = timed(args.steps)
         gather = gather_saved
         exposed_ms = 1e3 * (elapsed_local - el_ng) / args.steps
     per_rank = [local_rate]
@@ -345,43 +432,52 @@ def main():
         dist.all_gather(allr, tl)
         per_rank = [float(x.item()) for x in allr]
 
-    # kernel-only time of the dominant kernel (k_env_step), HIP events on the launch stream
-    k_steps = max(5, min(50, args.steps))
-    kernel_ms = env.bench_rollout(0, k_steps, auto_reset=True, open_loop=True) / k_steps
-    states, rewards, term = ex.views((tick[0] - 1) & 1)
-    mean_reward = float(rewards.mean().item())
-    finite = bool(torch.isfinite(states).all().item())
+    # average launch duration of the dominant kernel over the TIMED region: HIP events on each launch stream around its back-to-back
+    # launches (no exchange: nothing else is on those streams); with G groups, G launches of n / G envs are in flight at once
+    kernel_ms = float(np.mean(launch_ms)) if launch_ms else 0.0
+    last = [exs[g].views((tick[0] - 1) & 1) for g in range(G)]
+    mean_reward = float(torch.cat([v[1] for v in last]).mean().item())
+    finite = all(bool(torch.isfinite(v[0]).all().item()) for v in last)
 
     if rank == 0:
         # the line must describe the job that was asked for: N ranks, N per-rank rates
         if world != args.gpus or len(per_rank) != args.gpus:
             raise SystemExit("bench.py: ran %d rank(s) with %d per-rank rate(s) under --gpus %d" % (world, len(per_rank), args.gpus))
-        bytes_per_launch = algorithmic_bytes_per_env_step(env) * n
-        kname = "k_env_step_duo" if (args.wave_packing != 1 and args.physics == 1 and env.J <= 15 and env.D == 34 and n % 2 == 0 and tables.goal_kind != 5) else "k_env_step"
+        envs_per_launch = n // G
+        bytes_per_launch = algorithmic_bytes_per_env_step(env) * envs_per_launch
+        kname = "k_env_step_duo" if (args.wave_packing != 1 and args.physics == 1 and env.J <= 15 and env.D == 34 and envs_per_launch % 2 == 0 and tables.goal_kind != 5) else "k_env_step"
         achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else None      # (the emulator has no HIP events)
+        # committed counter passes are taken with --groups 1 (a PMC pass serialises the kernels: a half-batch launch alone on the chip would be
+        # another regime); HBM bytes are per env, so the per-launch figure of a group is the whole-batch one scaled by its share of the envs
         traffic, traffic_source = measured_traffic(args.scene, n, kname)
+        if traffic is not None:
+            traffic = traffic * envs_per_launch / n
         value = world * n * args.steps / elapsed
         if world > 1:
             workload = "%s, %d envs sharded %d x %d (one shard per GPU), fixed-action (open-loop mocap tracking) rollout, auto-reset, " \
                        "20 updates of 1/600 s x 2 substeps per step" % (args.scene, world * n, world, n)
         else:
-            workload = "%s, %d envs per GPU, fixed-action (open-loop mocap tracking) rollout, auto-reset, " \
-                       "20 updates of 1/600 s x 2 substeps per step" % (args.scene, n)
+            workload = "%s, %d envs per GPU%s, fixed-action (open-loop mocap tracking) rollout, auto-reset, " \
+                       "20 updates of 1/600 s x 2 substeps per step" % (args.scene, n, (" as %d groups of %d on their own streams" % (G, envs_per_launch)) if G > 1 else "")
         out = {
             "metric": "env-steps/sec at N parallel envs (%s)" % args.scene,
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32" if args.precision == 32 else "f64", "data": "synthetic",
-            "config": {"workload": workload, "envs_per_gpu": n, "envs_total": world * n, "backend": "rccl" if on_gpu else "gloo + CPU emulator (test harness, not a measurement)", "wave_packing": args.wave_packing, "physics": args.physics, "warmup_steps_run": warm, "parallelism": "env-shards x%d%s" % (world, " + async RCCL all-gather of the record, overlapped with the next step" if gather else "")},
+            "config": {"workload": workload, "envs_per_gpu": n, "envs_total": world * n, "backend": "rccl" if on_gpu else "gloo + CPU emulator (test harness, not a measurement)", "wave_packing": args.wave_packing, "physics": args.physics, "warmup_steps_run": warm, "groups": G, "envs_per_launch": envs_per_launch, "parallelism": "env-shards x%d%s" % (world, " + async RCCL all-gather of the record, overlapped with the next step" if gather else "")},
             "sim_updates_per_s": value * 20,
             "per_rank_env_steps_per_s": per_rank, "record_exchange": {"backend": (args.gather if gather else None), "exposed_ms_per_step_rank0": exposed_ms},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
                          "traffic": traffic, "traffic_source": traffic_source, "kernel": kname, "kernel_ms": kernel_ms,
+                         "concurrent_launches": G, "achieved_all_streams": (achieved * G) if achieved else None,
+                         "valu": measured_valu(args.scene, n, kname, value),
                          "algorithmic_bytes_per_env_step": algorithmic_bytes_per_env_step(env),
                          "algorithmic_bytes_per_launch": bytes_per_launch,
-                         "note": "VALU-issue bound by construction (SURVEY 8d, DESIGN.md 6): the env record stays in LDS/VGPRs for "
-                                 "the 20 updates of a control step, HBM sees 2.4 KB per env-step; the binding figures are the "
-                                 "VALU instruction count and SIMD busy fraction in profiles/"},
+                         "note": "VALU-issue / latency bound by construction (SURVEY 8d, DESIGN.md 6): the env record stays in LDS/VGPRs for the 20 updates "
+                                 "of a control step, HBM sees 2.4 KB per env-step; `valu` holds the binding figures.  achieved / kernel_ms are PER LAUNCH "
+                                 "(HIP events on each launch stream over the timed region); with `concurrent_launches` groups in flight the chip moves "
+                                 "`achieved_all_streams`"},
+            "sustained": (dict(sustained, ratio_to_value=sustained["value"] / value) if sustained else None),
             "checks": {"mean_reward": mean_reward, "finite": finite},
         }
         if not args.no_cpu_baseline and world == 1:

@@ -397,6 +397,12 @@ class BatchEnv:
         else:
             self._chk(self.lib.dm_set_stream(self.h, C.c_void_p(stream_handle)))
 
+    def own_stream(self) -> int:
+        """handle of the ctx's own non-blocking HIP stream (wrap it with torch.cuda.ExternalStream to order torch work against it)"""
+        own = C.c_void_p(0)
+        self._chk(self.lib.dm_get_stream(self.h, C.byref(own), None))
+        return int(own.value or 0)
+
     def use_own_stream(self):
         """back to the ctx's own non-blocking stream"""
         self._chk(self.lib.dm_set_stream(self.h, None))

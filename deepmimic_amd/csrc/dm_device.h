@@ -28,6 +28,7 @@
 // ============================================================================ wave-level primitives
 #ifdef DM_EMU
 static inline long long dm_clock() { return 0; }
+template <int P> static inline void dm_setprio() {}
 #define DM_DEV inline
 #define DM_OPAQUE_S(x) ((void)0)
 #define DM_OPAQUE_V(x) ((void)0)
@@ -101,6 +102,7 @@ template <> struct VecT<double> { typedef double v2 __attribute__((vector_size(1
 // nothing is scheduled across this point (keeps the rank-1 updates of one Cholesky column next to the loads that feed them)
 #define DM_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 __device__ __forceinline__ long long dm_clock() { return (long long)__builtin_readcyclecounter(); }
+template <int P> __device__ __forceinline__ void dm_setprio() { __builtin_amdgcn_s_setprio(P); }
 __device__ __forceinline__ int dm_atomic_or(int* p, int v) { return atomicOr(p, v); }
 __device__ __forceinline__ int dm_popc64(uint64_t v) { return __popcll(v); }
 __device__ __forceinline__ int dm_ctz32(uint32_t v) { return __builtin_ctz(v); }
@@ -298,12 +300,15 @@ template <int NP2> __device__ __forceinline__ void wave_gram32(const VecT<double
 }
 #endif
 
-#ifndef DM_PRIO_ONE
-#define DM_PRIO_ONE 0
+#ifndef DM_PRIO
+#define DM_PRIO 1      // s_setprio by phase and load (dm_device_duo.h has the rationale and the measurements); 0: the round-3 kernels
 #endif
-#ifndef DM_PRIO_ONE_LO
-#define DM_PRIO_ONE_LO 28
-#define DM_PRIO_ONE_HI 40
+// one character per wavefront: the same rule -- dependent-chain phases above the throughput phases of the SIMD's other wave
+#ifndef DM_PRIO_ONE_CHOL
+#define DM_PRIO_ONE_CHOL (DM_PRIO ? 1 : 0)
+#define DM_PRIO_ONE_Y (DM_PRIO ? 1 : 0)
+#define DM_PRIO_ONE_BACK (DM_PRIO ? 1 : 0)
+#define DM_PRIO_ONE_KIN (DM_PRIO ? 1 : 0)
 #endif
 namespace dmk {
 
@@ -1327,6 +1332,7 @@ struct EnvSim {
         if (C::OBJ && ball_sg != 0) { mu_row = m.ball_friction; jbl = (Real)ball_sg * dd; jba = (Real)ball_sg * cross(ball_cx - bpos, dd); }
         // y := L^-1 J_l^T in registers (static indices; dof records and L rows are wave-uniform LDS broadcasts)
         R2 y2[NP2X]; Real cvec = 0;
+        dm_setprio<DM_PRIO_ONE_Y>();
         if constexpr (C::TREE) {
             // H = L^T L: y = L^-T J^T runs from the last dof down, against COLUMN k of L (wave-uniform broadcasts); only the pairs that
             // hold a descendant of k are touched (744 multiply-adds per row for dog3d instead of 2 016)
@@ -1382,6 +1388,7 @@ struct EnvSim {
             y2[k >> 1][k & 1] = yk;
         }
         }
+        dm_setprio<0>();
         if (C::OBJ) {
             // the free body's block of the mass matrix is diagonal: its rows of Y = M^-1/2 J^T are a scaling; J v* gains its share
             cvec += dot(jbl, bvs) + dot(jba, bws);
@@ -1466,10 +1473,10 @@ struct EnvSim {
             int Rv = R, RNv = RN, lv = l;
             constexpr int PFD = C::PFD;             // rows of look-ahead for the overflow block (a ring of PFD + 1 registers)
             Real pre[PFD + 1] = {};
-#if DM_PRIO_ONE == 1
-            __builtin_amdgcn_s_setprio(3);
-#elif DM_PRIO_ONE == 2
-            if (Rv > DM_PRIO_ONE_HI) __builtin_amdgcn_s_setprio(3); else if (Rv > DM_PRIO_ONE_LO) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(1);
+#if DM_PRIO
+            // wave priority by load for the duration of the sweep (see DuoSim::substep_post; dog3d +1.6 %): thresholds at the median / p90 row count of the class
+            { constexpr int PLO = (ND > 34) ? 28 : 16, PHI = (ND > 34) ? 40 : 22;
+              if (Rv > PHI) dm_setprio<3>(); else if (Rv > PLO) dm_setprio<2>(); else dm_setprio<1>(); }
 #endif
             for (int it = 0; it < m.solver_iters; ++it) {
                 DM_OPAQUE_S(Rv); DM_OPAQUE_S(RNv); DM_OPAQUE_V(lv);
@@ -1495,11 +1502,9 @@ struct EnvSim {
                     }
                 });
             }
-#if DM_PRIO_ONE
-            __builtin_amdgcn_s_setprio(0);
-#endif
             if (l >= R) lam = 0;
         } else mark(10);
+        dm_setprio<DM_PRIO_ONE_BACK>();
         mark(11);
         if (TAPS && dbg.lambda) { dbg.lambda[(size_t)e * kMaxRows + l] = lam; if (l < 2) dbg.rows[(size_t)e * 2 + l] = s.flg[FLG_NROWS + l]; }
         // delta v = L^-T (Y lambda): transposing wave reduction of y_r[k] lambda_r, dof k's total lands in lane k
@@ -1544,6 +1549,7 @@ struct EnvSim {
         sync();
         integrate(h);
         sync();
+        dm_setprio<0>();
         mark(12);
     }
 
@@ -1693,7 +1699,7 @@ struct EnvSim {
         if (reuse_kin) {
             if (l < m.J) { v3 da = gravity_a0() - spd_a0(); st3(s.aj[l], ld3(s.aj[l]) + da); }
             sync();
-        } else if (!kin_done) kinematics(s.pose, s.vel, ph == 0 ? spd_a0() : gravity_a0());      // (kin_done: kin_pre() ran it for this state)
+        } else if (!kin_done) { dm_setprio<DM_PRIO_ONE_KIN>(); kinematics(s.pose, s.vel, ph == 0 ? spd_a0() : gravity_a0()); dm_setprio<0>(); }      // (kin_done: kin_pre() ran it for this state)
         mark(ph == 0 ? 1 : 5);
         dynamics(ph == 0 ? 0 : 1, ph == 0 ? dt : (Real)0);
         mark(ph == 0 ? 2 : 6);
@@ -1716,7 +1722,9 @@ struct EnvSim {
         if (ph == 0) spd_rhs(dt);
         else { if (l < m.D) { Real r = s.tau[l] - s.dofrec[l][7]; if (PERT && pert) r += pert_gen_force(l); s.rhs[l] = r; } sync(); }
         DM_OPAQUE_V(l);
+        dm_setprio<DM_PRIO_ONE_CHOL>();
         if constexpr (C::TREE) tree_solve(s.rhs); else chol_solve(s.rhs);
+        dm_setprio<0>();
         DM_OPAQUE_V(l); DM_OPAQUE_V(li);
         if (ph == 0) { mark(3); spd_post(dt); }
         else substep_post<V2, !TAPS && !PERT && !V2>(h, dbg, e, aovf, manif);

@@ -12,11 +12,30 @@
 // routine of dm_device.h on each record in turn (same LDS record layout), so the results do not depend on the pairing.
 #pragma once
 #include "dm_device.h"
-#ifndef DM_PRIO
-#define DM_PRIO 0
+// Wave priorities by phase (round 4; profiles/r04_ab_setprio.json).  Two waves share a SIMD; when both have an instruction ready the arbiter takes the
+// higher priority, then the older.  A wave in a phase with much independent work per lane (dynamics, collision, the Gram MFMA chains) has an instruction
+// ready almost every cycle and delays the ONE ready instruction of a wave that sits in a dependent chain (factorisation columns, substitutions,
+// level-synchronous kinematics, Gauss-Seidel rows) by a few cycles each time.  Raising the chain phases costs the other wave next to nothing -- it fills
+// the gaps -- and shortens the chains: sweep 1 / 2 / 3 by load +3.0 %, the other chain phases at 1 another +3.2 % (same-box A/Bs, outputs bit-identical).
+#if DM_PRIO
+#ifndef DM_PRIO_CHOL
+#define DM_PRIO_CHOL 1      // factorisation + the two triangular solves
+#define DM_PRIO_Y 1         // Y = L^-1 J^T (row lanes)
+#define DM_PRIO_BACK 1      // L^-T (Y lambda), integration
+#define DM_PRIO_KIN 1       // level-synchronous link kinematics
+#endif
+#else
+#define DM_PRIO_CHOL 0
+#define DM_PRIO_Y 0
+#define DM_PRIO_BACK 0
+#define DM_PRIO_KIN 0
+#endif
+#ifndef DM_PRIO_BASE
+#define DM_PRIO_BASE 1      // the sweep: 1, 2 above DM_PRIO_LO rows, 3 above DM_PRIO_HI
+#define DM_PRIO_MID 2
 #endif
 #ifndef DM_PRIO_LO
-#define DM_PRIO_LO 16
+#define DM_PRIO_LO 16      // rows of the heavier character of a pair above which the sweep runs at priority 2 / 3 (median pair: 16)
 #define DM_PRIO_HI 22
 #endif
 
@@ -465,16 +484,6 @@ _Pragma("unroll") \
         }
         const int NL = m.NL;
         const int R = NL + 3 * nc;
-#if DM_PRIO == 2 || DM_PRIO == 3
-        // wave priority by load, kept until the next substep's count: a wave with more rows than the median pair wins issue arbitration
-        // against its (lighter) SIMD mate in every phase
-        {
-            const int Rmx_ = dm_max(lane_bcast(R, 0), lane_bcast(R, 32));
-            if (Rmx_ > DM_PRIO_HI) __builtin_amdgcn_s_setprio(3);
-            else if (Rmx_ > DM_PRIO_LO) __builtin_amdgcn_s_setprio(DM_PRIO == 3 ? 2 : 1);
-            else __builtin_amdgcn_s_setprio(0);
-        }
-#endif
         if (wave_ballot(R > HW) != 0) return false;      // a heavily contacted character: the caller runs the one-per-wave routine
         if (hl == 0) { s.flg[FLG_NROWS] = R; s.flg[FLG_NCONT] = nc; }
         sync();
@@ -498,6 +507,9 @@ _Pragma("unroll") \
         // the dependent accumulation chain of step k runs, so their latency hides behind it (two register buffers, static parity)
         R2 y2[NP2]; Real cvec = 0;
         R2 lr[2][NP2]; R4 rr[2][2];
+#if DM_PRIO_Y
+        dm_setprio<DM_PRIO_Y>();
+#endif
 #define DM_DUO_YLOAD(k)                                                                                       \
         {                                                                                                     \
             rr[(k) & 1][0] = *reinterpret_cast<const R4*>(&s.dofrec[(k)][0]);                                  \
@@ -527,6 +539,9 @@ _Pragma("unroll") \
             y2[k >> 1][k & 1] = yk;
         }
 #undef DM_DUO_YLOAD
+#if DM_PRIO_Y
+        dm_setprio<0>();
+#endif
         b.mark(9);
         const int RN = NL + nc;
         const bool is_fric = hl >= RN && hl < R;
@@ -570,10 +585,13 @@ _Pragma("unroll") \
                 lam = half_sel_c<(r)>(lam, nl, lv, one);                                                               \
             }
 #define DM_DUO_PGS_BLK(b4) if ((b4) * 4 < Rv) { DM_DUO_PGS_ROW((b4) * 4) DM_DUO_PGS_ROW((b4) * 4 + 1) DM_DUO_PGS_ROW((b4) * 4 + 2) DM_DUO_PGS_ROW((b4) * 4 + 3) }
-#if DM_PRIO == 1
-            if (Rv > DM_PRIO_HI) __builtin_amdgcn_s_setprio(3); else if (Rv > DM_PRIO_LO) __builtin_amdgcn_s_setprio(2);
-#elif DM_PRIO == 4
-            if (Rv > DM_PRIO_HI) __builtin_amdgcn_s_setprio(3); else if (Rv > DM_PRIO_LO) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(1);
+            // Wave priority by load while the sweep runs (round 4, profiles/r04_ab_setprio.json: +3.0 % on the headline, outputs bit-identical): the sweep
+            // is one dependent chain per row that issues little; raised above the SIMD's other wave it stops waiting behind that wave's throughput
+            // phases, and a pair with more rows than the median (16) -- the waves a one-round launch waits for -- outranks a lighter one.
+            // The priority is per wave and lasts until it is set back after the sweep.  (Keeping it through all phases, thresholds 10..24,
+            // or 3 for every wave measured the same or less; a never-raised control build measured +-0.)
+#if DM_PRIO
+            if (Rv > DM_PRIO_HI) dm_setprio<3>(); else if (Rv > DM_PRIO_LO) dm_setprio<DM_PRIO_MID>(); else dm_setprio<DM_PRIO_BASE>();
 #endif
             for (int it = 0; it < m.solver_iters; ++it) {
                 uint32_t one = 1u;
@@ -583,11 +601,15 @@ _Pragma("unroll") \
             }
 #undef DM_DUO_PGS_BLK
 #undef DM_DUO_PGS_ROW
-#if DM_PRIO == 1 || DM_PRIO == 4
-            __builtin_amdgcn_s_setprio(0);
+#if DM_PRIO
+            dm_setprio<DM_PRIO_BACK>();
 #endif
             if (hl >= R) lam = 0;
-        } else b.mark(10);
+        } else { b.mark(10);
+#if DM_PRIO_BACK
+            dm_setprio<DM_PRIO_BACK>();
+#endif
+        }
         b.mark(11);
         // delta v = L^-T (Y lambda): transposing reduction inside each half; dof k < 32 lands in lane k, dofs 32, 33 in lanes 0, 1
         {
@@ -621,6 +643,9 @@ _Pragma("unroll") \
         sync();
         b.integrate(h);
         sync();
+#if DM_PRIO_BACK
+        dm_setprio<0>();
+#endif
         b.mark(12);
         return true;
     }
@@ -639,7 +664,15 @@ _Pragma("unroll") \
             if (ph == 1) {
                 if (hl < m.J) { v3 da = b.gravity_a0() - b.spd_a0(); st3(s.aj[hl], ld3(s.aj[hl]) + da); }
                 sync();
-            } else if (!(kin_done && ph == 0)) b.kinematics(s.pose, s.vel, ph == 0 ? b.spd_a0() : b.gravity_a0());      // (ph 0: EnvSim::kin_pre ran it)
+            } else if (!(kin_done && ph == 0)) {
+#if DM_PRIO_KIN
+                dm_setprio<DM_PRIO_KIN>();
+#endif
+                b.kinematics(s.pose, s.vel, ph == 0 ? b.spd_a0() : b.gravity_a0());      // (ph 0: EnvSim::kin_pre ran it)
+#if DM_PRIO_KIN
+                dm_setprio<0>();
+#endif
+            }
             b.mark(ph == 0 ? 1 : 5);
             dynamics(ph == 0 ? 0 : 1, ph == 0 ? rdt : (Real)0);
             b.mark(ph == 0 ? 2 : 6);
@@ -649,7 +682,13 @@ _Pragma("unroll") \
                 sync();
             } else { for (int k = hl; k < D; k += HW) { Real r = s.tau[k] - s.dofrec[k][7]; if (PERT && pert) r += b.pert_gen_force(k); s.rhs[k] = r; } sync(); }
             DM_OPAQUE_V(hl); DM_OPAQUE_V(b.l);
+#if DM_PRIO_CHOL
+            dm_setprio<DM_PRIO_CHOL>();
+#endif
             chol_solve(s.rhs);
+#if DM_PRIO_CHOL
+            dm_setprio<0>();
+#endif
             DM_OPAQUE_V(hl); DM_OPAQUE_V(b.l); DM_OPAQUE_V(b.li);
             if (ph == 0) {
                 b.mark(3);

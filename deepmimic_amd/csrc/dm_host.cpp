@@ -753,6 +753,13 @@ int dm_create(const dm_create_info* info, const dm_scene_tables* tables, dm_ctx*
     if (info->wave_packing != 0 && info->wave_packing != 1 && info->wave_packing != 2) { delete c; return fail("wave_packing must be 0, 1 or 2"); }
     // two characters per wavefront is the default for the biped class (step() falls back for odd batches and armed taps)
     { const char* dv = getenv("DM_DUO"); c->duo = info->wave_packing == 2 || (info->wave_packing == 0 && !(dv && dv[0] == '0')); }
+    // Shard / group invariance by construction: global envs 2b and 2b + 1 share a wavefront, whatever the partition.  A shard that starts at an odd
+    // global id would pair (2b + 1, 2b + 2) -- the same physics summed in another order, i.e. trajectories that depend on the partition in the last
+    // bits -- so an explicit wave_packing 2 refuses it and the default falls back to one character per wavefront for that ctx.
+    if (c->duo && (info->env_id_offset & 1)) {
+        if (info->wave_packing == 2) { delete c; return fail("wave_packing 2 needs an even env_id_offset (global envs 2b, 2b+1 share a wavefront in every partition)"); }
+        c->duo = false;
+    }
     if (c->setup() != 0) { delete c; return -1; }
     dm_ctx* ctx = new dm_ctx(); ctx->c = c;
     if (dm_reset(ctx, nullptr, 0, nullptr, nullptr) != 0) { std::string e = g_err; dm_destroy(ctx); g_err = e; return -1; }
@@ -794,6 +801,12 @@ int dm_set_stream_default(dm_ctx* ctx) {
 #ifndef DM_EMU
     ctx->c->stream = (hipStream_t)0;          // the legacy default stream: synchronises with every blocking stream, torch's default included
 #endif
+    return 0;
+}
+int dm_get_stream(const dm_ctx* ctx, void** out_own, void** out_current) {
+    if (!ctx) return fail("null ctx");
+    if (out_own) *out_own = (void*)ctx->c->own_stream;
+    if (out_current) *out_current = (void*)ctx->c->stream;
     return 0;
 }
 int dm_synchronize(dm_ctx* ctx) { if (!ctx) return fail("null ctx"); DevGuard guard(ctx->c->device_id); return rt_sync(ctx->c->stream) == 0 ? 0 : fail("stream synchronize failed"); }

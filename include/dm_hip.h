@@ -135,6 +135,11 @@ double dm_motion_duration(const dm_ctx* ctx);
  * current), so that work enqueued by the caller on the default stream and this ctx's launches are ordered against each other. */
 int dm_set_stream(dm_ctx* ctx, void* hip_stream);
 int dm_set_stream_default(dm_ctx* ctx);
+/* The HIP stream handles of the ctx: *out_own = the non-blocking stream dm_create made for it, *out_current = the stream its kernels are
+ * launched on right now (own stream, an external one, or NULL = the legacy default stream).  Either pointer may be NULL.  For callers that
+ * order other work against the ctx with events (torch.cuda.ExternalStream(own), hipStreamWaitEvent): env groups on their own streams whose
+ * records feed one collective (bench.py, deepmimic_amd/groups.py). */
+int dm_get_stream(const dm_ctx* ctx, void** out_own, void** out_current);
 int dm_synchronize(dm_ctx* ctx);
 
 /* cDeepMimicCore::SetMode (DeepMimicCore.cpp:472-479 -> cRLSceneSimChar::SetMode / ResetTimers, scenes/RLSceneSimChar.cpp:

@@ -32,6 +32,23 @@ def test_bench_gpus_2_launches_two_ranks(emu_lib):
     assert line["record_exchange"]["backend"] == "torch"           # the all-gather of the learner record ran on both ranks
     assert line["value"] > 0 and line["checks"]["finite"] and 0.0 < line["checks"]["mean_reward"] <= 1.0
     assert len([l for l in p.stdout.splitlines() if l.startswith("{")]) == 1     # rank 0 prints ONE line
+    assert line["config"]["groups"] == 2 and line["config"]["envs_per_launch"] == 2      # two env groups per rank (deepmimic_amd/groups.py)
+
+
+def test_bench_gpus_8_launches_eight_ranks(emu_lib):
+    """the launch path the driver takes on an 8-GPU node: 8 ranks, 8 per-rank rates, one line, the exchange on every rank"""
+    p, line = run_bench(emu_lib, ["--gpus", "8"], timeout=1500)
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert line is not None and line["n_gpus"] == 8 and len(line["per_rank_env_steps_per_s"]) == 8
+    assert line["config"]["envs_total"] == 32 and "32 envs sharded 8 x 4" in line["config"]["workload"]
+    assert line["record_exchange"]["backend"] == "torch" and line["checks"]["finite"]
+    assert len([l for l in p.stdout.splitlines() if l.startswith("{")]) == 1
+
+
+def test_bench_groups_1_is_one_launch_per_step(emu_lib):
+    p, line = run_bench(emu_lib, ["--gpus", "1", "--groups", "1"])
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert line["config"]["groups"] == 1 and line["config"]["envs_per_launch"] == 4 and line["roofline"]["concurrent_launches"] == 1
 
 
 def test_bench_gpus_1_single_process(emu_lib):

@@ -41,6 +41,7 @@ if _ROOT not in sys.path:
 
 from deepmimic_amd import model as _model  # noqa: E402
 from deepmimic_amd.core import BatchEnv as _BatchEnv  # noqa: E402
+from deepmimic_amd.core import RefRand as _RefRand  # noqa: E402
 
 _DT_EPS = 0.0
 
@@ -64,10 +65,24 @@ class cDeepMimicCore(object):
         self._time = 0.0
         self._playback_speed = 1.0
         self._updates_per_sec = 0.0
+        # DM_RNG=reference (default here; "counter" = the batched path's streams keyed by (seed, env id, episode)): the episode draws of this one-env
+        # drop-in -- clip time at every reset, episode time limit, the scene generator's expert-sample times -- come from the reference's own
+        # generator (util/Rand.cpp: std::default_random_engine + <random> distributions, include/dm_hip.h dm_refrand_*) consumed in the
+        # reference's call order, so that SeedRand(s) reproduces the reference's reset times and limits bit for bit (tests/test_ref_rng.py,
+        # against the compiled cRand / cTimer of oracle/_ref).  cMathUtil::gRand starts time-seeded (util/MathUtil.cpp:6, Rand.cpp:6-9).
+        self._ref_rng = os.environ.get("DM_RNG", "reference") == "reference"
+        self._grand = self._srand = None
+        if self._ref_rng:
+            import time
+            self._grand = _RefRand(int(time.time()), lib_path=os.environ.get("DM_HIP_LIB"))
 
     # ---- construction (DeepMimicCore.cpp:20-54)
     def SeedRand(self, seed):
         self._seed = int(seed)
+        if self._grand is not None:
+            # cMathUtil::SeedRand (util/MathUtil.cpp:114-118): gRand.Seed(seed); srand(gRand.RandInt()) -- the int argument widens to unsigned long
+            self._grand.seed(int(seed))
+            self._grand.rand_int()
 
     def ParseArgs(self, args):
         args = [str(a) for a in args]
@@ -109,7 +124,52 @@ class cDeepMimicCore(object):
         self._period = 1.0 / float(self._tables.query_rate)
         self.stats = {"launches": 0, "updates": 0, "rollbacks": 0}     # kernel launches of the stepping path vs Update() calls
         self._build_time_warper()
-        self._after_reset()
+        self._ref_active = False
+        if self._ref_rng and self._tables.num_clips == 1:
+            self._ref_init_draws()
+        else:
+            if self._ref_rng:
+                import warnings
+                warnings.warn("DM_RNG=reference serves single-clip scenes; this multi-clip dataset draws clip, clip time and episode limit from the "
+                              "device's counter-based streams (cClipsController::SelectNewMotion interleaves with them in the reference)", RuntimeWarning, stacklevel=2)
+            self._after_reset()
+
+    # ---- the reference's draw order on cMathUtil::gRand (DM_RNG=reference) ------------------------------------------------------------
+    def _ref_draw_timer(self, sample_count):
+        """one cTimer::Reset (util/Timer.cpp:55-73) with the annealed parameters cTimer holds whatever the mode (RLSceneSimChar.cpp:338-347)"""
+        c = self._tables.cfg
+        lo, hi = _model.timer_limits(c, False, sample_count)
+        if c.timer_type == "exp":
+            return min(lo + self._grand.rand_exp(1.0 / _model.timer_exp(c, False, sample_count)), hi)
+        return self._grand.rand_double(lo, hi)                     # (no draw when min == max: every shipped imitate arg file)
+
+    def _ref_init_draws(self):
+        """cDeepMimicCore::Init -> SetupScene (DeepMimicCore.cpp:635-660).  On gRand, in order: cScene::cScene seeds the scene's own generator
+        with one RandUint (scenes/Scene.cpp:5); cRLSceneSimChar::Init runs cScene::Init twice (through cRLScene::Init and cSceneSimChar::Init,
+        RLSceneSimChar.cpp:27-31), each = InitTimers (one cTimer::Reset, Scene.cpp:124-127) + ResetParams, which for this class is two ResetTimers
+        (RLSceneSimChar.cpp:234-238) -- six timer draws with the un-annealed parameters; cGround::cGround takes one RandUint (sim/Ground.cpp:68).
+        The env is left at clip time 0 with the last limit drawn; the driver resets before it steps (learning/rl_world.py)."""
+        self._ref_active = True
+        self._srand = _RefRand(self._grand.rand_uint(), lib_path=os.environ.get("DM_HIP_LIB"))     # cScene::mRand (RandUint returns int: a negative value widens to unsigned long like in the reference)
+        mt = np.inf
+        for _ in range(6):
+            mt = self._ref_draw_timer(0)
+        self._grand.rand_uint()
+        self._after_reset(kin_time=0.0, max_time=mt)
+
+    def _ref_reset_draws(self):
+        """cScene::Reset -> cRLSceneSimChar::ResetScene (RLSceneSimChar.cpp:240-244): cRLScene::ResetScene and cSceneSimChar::ResetScene each run
+        ResetParams = two ResetTimers -> four cTimer::Reset draws, the last one stands (test mode pins it to time_end_lim_max afterwards,
+        :277-284); then ResetCharacters -> cSceneImitate::ResetKinChar -> CalcRandKinResetTime = RandDouble(0, duration) (SceneImitate.cpp:320-343,
+        494-500).  (Random perturbations and enable_rand_rot_reset draw from the SCENE generator in the reference; their device-side draws keep the
+        counter-based streams.)"""
+        mt = np.inf
+        for _ in range(4):
+            mt = self._ref_draw_timer(self._sample_count)
+        if self._mode == self.eModeTest:
+            mt = _model.timer_limits(self._tables.cfg, True, self._sample_count)[1]
+        kt = self._grand.rand_double(0.0, float(self._env.duration))
+        return kt, mt
 
     def _apply_mode(self):
         lo, hi = _model.timer_limits(self._tables.cfg, self._mode == self.eModeTest, self._sample_count)
@@ -161,8 +221,13 @@ class cDeepMimicCore(object):
         return cost + (tw["size"] - len(tw["sim"])) * 1.0           # term_step_cost = 1 per step the episode fell short
 
     # ---- stepping engine ------------------------------------------------------------------------------------------------
-    def _after_reset(self):
-        self._env.reset()
+    def _after_reset(self, kin_time=None, max_time=None):
+        if kin_time is None and getattr(self, "_ref_active", False):
+            kin_time, max_time = self._ref_reset_draws()
+        if kin_time is None:
+            self._env.reset()
+        else:
+            self._env.reset(kin_times=[float(kin_time)], max_times=[float(max_time)])
         if self._tw is not None:
             self._tw["sim"], self._tw["kin"] = [], []
             self._tw_sample()                                        # ResetTimeWarper -> UpdateTimeWarper
@@ -489,6 +554,8 @@ class cDeepMimicCore(object):
         gh = float(env.get_state()["kin"][0][1])
         if self._tables.num_clips > 1:           # SampleExpertMotion with a cClipsController: clip by weight, time within that clip
             return [float(x) for x in env.amp_expert_clips(1, None, None, gh)[0]]
+        if getattr(self, "_ref_active", False):  # mRand.RandDouble(0, motion_duration) on the scene's generator (SceneImitateAMP.cpp:119)
+            return [float(x) for x in env.amp_expert(1, [self._srand.rand_double(0.0, float(env.duration))], gh)[0]]
         return [float(x) for x in env.amp_expert(1, None, gh)[0]]
 
     def IsEpisodeEnd(self):

@@ -476,6 +476,47 @@ class BatchEnv:
         return out
 
 
+class RefRand:
+    """cRand of the reference (util/Rand.cpp) as libdm_hip.so implements it with the same <random> types (include/dm_hip.h: dm_refrand_*):
+    a host that replays the reference's call order draws the reference's numbers.  Used by the cDeepMimicCore facade (DM_RNG=reference)."""
+
+    def __init__(self, seed: int = 0, lib_path: Optional[str] = None):
+        self.lib = load_library(lib_path)
+        for f in ("dm_refrand_double", "dm_refrand_exp", "dm_refrand_norm"):
+            getattr(self.lib, f).restype = C.c_double
+        self.h = C.c_void_p()
+        if self.lib.dm_refrand_create(C.c_ulong(int(seed) & (2 ** 64 - 1)), C.byref(self.h)) != 0:
+            raise RuntimeError("dm_refrand_create failed")
+
+    def seed(self, seed: int):
+        self.lib.dm_refrand_seed(self.h, C.c_ulong(int(seed) & (2 ** 64 - 1)))
+
+    def rand_double(self, lo: float = 0.0, hi: float = 1.0) -> float:
+        return float(self.lib.dm_refrand_double(self.h, C.c_double(lo), C.c_double(hi)))
+
+    def rand_exp(self, lam: float) -> float:
+        return float(self.lib.dm_refrand_exp(self.h, C.c_double(lam)))
+
+    def rand_norm(self, mean: float = 0.0, stdev: float = 1.0) -> float:
+        return float(self.lib.dm_refrand_norm(self.h, C.c_double(mean), C.c_double(stdev)))
+
+    def rand_int(self) -> int:
+        return int(self.lib.dm_refrand_int(self.h))
+
+    def rand_int_range(self, lo: int, hi: int) -> int:
+        return int(self.lib.dm_refrand_int_range(self.h, int(lo), int(hi)))
+
+    def rand_uint(self) -> int:
+        return int(self.lib.dm_refrand_uint(self.h))
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self.lib.dm_refrand_destroy(self.h); self.h = None
+        except Exception:
+            pass
+
+
 class Comm:
     """dm_comm of the C-ABI (include/dm_hip.h): the RCCL communicator behind dm_gather_records, for hosts that shard without
     torch.  `unique_id` = the 128 bytes rank 0 got from Comm.unique_id(), shipped to every rank by the caller."""

@@ -17,6 +17,8 @@
 #include <cstring>
 #include <limits>
 #include <string>
+#include <random>
+#include <limits>
 #include <vector>
 
 #include "../../include/dm_hip.h"
@@ -1046,6 +1048,44 @@ int dm_bench_rollout(dm_ctx* ctx, int warmup, int steps, double timestep, int n_
 #endif
     return 0;
 }
+
+// ---------------------------------------------------------------- the reference's random generator (host side, N = 1 drop-in route)
+// cRand (util/Rand.h, util/Rand.cpp:6-41, 128-135): one std::default_random_engine feeding <random> distributions that persist across
+// calls.  The same standard-library types here, so that a host which replays the reference's call order (the cDeepMimicCore facade:
+// SeedRand -> scene constructor -> timers -> CalcRandKinResetTime, deepmimic_amd/compat) draws the reference's numbers bit for bit on a
+// platform whose C++ library is the reference build's (libstdc++: minstd_rand0, generate_canonical<double, 53>).  Nothing on the device
+// uses it: the batched path keeps its counter-based streams.
+struct dm_refrand {
+    std::default_random_engine gen;
+    std::uniform_real_distribution<double> dbl{0, 1};
+    std::normal_distribution<double> norm{0, 1};
+    std::uniform_int_distribution<int> sint{std::numeric_limits<int>::min() + 1, std::numeric_limits<int>::max()};
+    std::uniform_int_distribution<unsigned int> uint{std::numeric_limits<unsigned int>::min(), std::numeric_limits<unsigned int>::max()};
+};
+int dm_refrand_create(unsigned long seed, dm_refrand** out) {
+    if (!out) return fail("null argument");
+    dm_refrand* r = new dm_refrand(); r->gen = std::default_random_engine(seed); *out = r; return 0;
+}
+int dm_refrand_destroy(dm_refrand* r) { delete r; return 0; }
+int dm_refrand_seed(dm_refrand* r, unsigned long seed) {            // cRand::Seed (:128-135)
+    if (!r) return fail("null generator");
+    r->gen.seed(seed); r->dbl.reset(); r->norm.reset(); r->sint.reset(); r->uint.reset(); return 0;
+}
+double dm_refrand_double(dm_refrand* r, double mn, double mx) {     // cRand::RandDouble(min, max) (:30-41): no draw when min == max
+    if (mn == mx) return mn;
+    double u = r->dbl(r->gen);
+    u = mn + (u * (mx - mn));
+    return u;
+}
+double dm_refrand_exp(dm_refrand* r, double lambda) { std::exponential_distribution<double> d(lambda); return d(r->gen); }      // (:43-48)
+double dm_refrand_norm(dm_refrand* r, double mean, double stdev) { double v = r->norm(r->gen); v = mean + stdev * v; return v; }   // (:50-55)
+int dm_refrand_int(dm_refrand* r) { return r->sint(r->gen); }                                                                   // (:57-60)
+int dm_refrand_int_range(dm_refrand* r, int mn, int mx) {           // cRand::RandInt(min, max) (:62-75)
+    if (mn == mx) return mn;
+    int delta = mx - mn, v = std::abs(dm_refrand_int(r));
+    return mn + v % delta;
+}
+int dm_refrand_uint(dm_refrand* r) { return (int)r->uint(r->gen); }                                                             // (:77-80: returns int)
 
 }  // extern "C"
 

@@ -256,6 +256,25 @@ int dm_gather_records(dm_ctx* ctx, dm_comm* comm, int slot, const float* send_de
 /* Make the ctx stream (not the host) wait for the gather last launched on `slot`; no-op when none is in flight. */
 int dm_gather_wait(dm_ctx* ctx, dm_comm* comm, int slot);
 
+/* ---- The reference's random generator, for a host that replays the reference's draw order (the N = 1 drop-in route)
+ * cRand (util/Rand.h, util/Rand.cpp:6-135) behind cMathUtil::gRand (util/MathUtil.cpp:6,61-134): std::default_random_engine +
+ * the <random> distributions, state kept across calls.  Implemented with the same standard-library types, so a caller that issues
+ * the reference's calls in the reference's order -- cDeepMimicCore::SeedRand (DeepMimicCore.cpp:20-23 -> cMathUtil::SeedRand:
+ * Seed, then one RandInt for srand), cScene::cScene (scenes/Scene.cpp:5: one RandUint), cTimer::Reset (util/Timer.cpp:55-73),
+ * cGround::cGround (sim/Ground.cpp:68: one RandUint), cSceneImitate::CalcRandKinResetTime (scenes/SceneImitate.cpp:494-500) -- gets
+ * the reference's reset times and episode limits for the same seed, to hand to dm_reset(kin_times, max_times).  Host only; the
+ * batched device path draws from counter-based streams keyed by (seed, global env id, episode) instead. */
+typedef struct dm_refrand dm_refrand;
+int dm_refrand_create(unsigned long seed, dm_refrand** out);          /* cRand(seed) */
+int dm_refrand_destroy(dm_refrand* r);
+int dm_refrand_seed(dm_refrand* r, unsigned long seed);               /* cRand::Seed */
+double dm_refrand_double(dm_refrand* r, double min, double max);      /* cRand::RandDouble(min, max): min when min == max, no draw */
+double dm_refrand_exp(dm_refrand* r, double lambda);                  /* cRand::RandDoubleExp */
+double dm_refrand_norm(dm_refrand* r, double mean, double stdev);     /* cRand::RandDoubleNorm */
+int dm_refrand_int(dm_refrand* r);                                    /* cRand::RandInt() */
+int dm_refrand_int_range(dm_refrand* r, int min, int max);            /* cRand::RandInt(min, max) */
+int dm_refrand_uint(dm_refrand* r);                                   /* cRand::RandUint() */
+
 /* ---- On-device policy inference: the actor of learning/pg_agent.py:141-188 with the net of
  * learning/nets/fc_2layers_1024units.py and the normalisers of learning/normalizer.py:95-102, on the matrix cores (bf16
  * operands, fp32 accumulate), so that observation -> action -> control step stays on the GPU.  Weights are fp32 host

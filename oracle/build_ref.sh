@@ -30,19 +30,30 @@ if [ ! -d "$REF" ]; then
     echo "build_ref: $REF absent and no prebuilt library" >&2; exit 1
 fi
 mkdir -p _ref/obj
+# one builder at a time (pytest-xdist workers all call this), and nothing is rebuilt or relinked when it is up to date
+exec 9> _ref/.lock
+flock 9
 OBJS=""
+RELINK=0
+[ -f _ref/libdm_ref.so ] || RELINK=1
 STUBS="eigen_shim/Eigen/Core eigen_shim/Eigen/Geometry gl_stub/GL/glew.h bullet_stub/btBulletDynamicsCommon.h"
 for s in $SRCS; do
     o="_ref/obj/$(echo "$s" | tr '/' '.').o"
     stale=0
     if [ ! -f "$o" ] || [ "$REF/$s.cpp" -nt "$o" ]; then stale=1; fi
     for h in $STUBS; do if [ "$h" -nt "$o" ]; then stale=1; fi; done
-    if [ $stale = 1 ]; then $CXX $FLAGS -c "$REF/$s.cpp" -o "$o"; fi
+    if [ $stale = 1 ]; then $CXX $FLAGS -c "$REF/$s.cpp" -o "$o"; RELINK=1; fi
     OBJS="$OBJS $o"
 done
-$CXX $FLAGS -c ref_glue.cpp -o _ref/obj/ref_glue.o
-$CXX $FLAGS -c ref_standins.cpp -o _ref/obj/ref_standins.o
-OBJS="$OBJS _ref/obj/ref_glue.o _ref/obj/ref_standins.o"
+for g in ref_glue ref_standins; do
+    o="_ref/obj/$g.o"
+    stale=0
+    if [ ! -f "$o" ] || [ "$g.cpp" -nt "$o" ]; then stale=1; fi
+    for h in $STUBS; do if [ "$h" -nt "$o" ]; then stale=1; fi; done
+    if [ $stale = 1 ]; then $CXX $FLAGS -c $g.cpp -o "$o"; RELINK=1; fi
+    OBJS="$OBJS $o"
+done
+if [ $RELINK = 0 ]; then echo "build_ref: oracle/_ref/libdm_ref.so is up to date"; exit 0; fi
 # pass 1: what is still undefined (reference classes only: names c[A-Z]... / t[A-Z]...)
 $CXX -shared -o _ref/libdm_ref.pass1.so $OBJS -Wl,--unresolved-symbols=ignore-all
 nm -u _ref/libdm_ref.pass1.so | awk '$1 == "U" {print $2}' | while read sym; do
@@ -53,5 +64,6 @@ nm -u _ref/libdm_ref.pass1.so | awk '$1 == "U" {print $2}' | while read sym; do
 done > _ref/unreachable.args
 rm -f _ref/libdm_ref.pass1.so
 # pass 2: everything bound
-$CXX -Wl,-z,defs -shared -o _ref/libdm_ref.so $OBJS @_ref/unreachable.args
+$CXX -Wl,-z,defs -shared -o _ref/libdm_ref.so.tmp $OBJS @_ref/unreachable.args
+mv -f _ref/libdm_ref.so.tmp _ref/libdm_ref.so
 echo "build_ref: built oracle/_ref/libdm_ref.so from $REF ($(wc -l < _ref/unreachable.args) Bullet-side methods aliased to ref_unreachable)"

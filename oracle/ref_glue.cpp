@@ -517,4 +517,45 @@ void ref_timer_anneal(const double* p0 /*min max exp*/, const double* p1, double
     out[0] = lerp; out[1] = c.mTimeMin; out[2] = c.mTimeMax; out[3] = c.mTimeExp;
 }
 
+// cMathUtil's generator call by call (util/MathUtil.cpp:61-134 -> cRand, util/Rand.cpp): op 0 RandDouble(a, b), 1 RandDoubleExp(a), 2 RandDoubleNorm(a, b),
+// 3 RandInt(), 4 RandInt(a, b), 5 RandUint().  ref_math_seed = cMathUtil::SeedRand (util/MathUtil.cpp:114-118: cRand::Seed, then one RandInt for srand).
+void ref_math_seed(unsigned long seed) { cMathUtil::SeedRand(seed); }
+double ref_math_rand(int op, double a, double b) {
+    switch (op) {
+    case 0: return cMathUtil::RandDouble(a, b);
+    case 1: return cMathUtil::RandDoubleExp(a);
+    case 2: return cMathUtil::RandDoubleNorm(a, b);
+    case 3: return (double)cMathUtil::RandInt();
+    case 4: return (double)cMathUtil::RandInt((int)a, (int)b);
+    default: return (double)cMathUtil::RandUint();
+    }
+}
+// The process-global generator cMathUtil::gRand in the order a `--scene imitate` cDeepMimicCore consumes it, driven through the reference's own
+// compiled cMathUtil / cRand / cTimer (the scene and ground classes themselves need Bullet; which call comes when is read off their sources):
+//   cDeepMimicCore::SeedRand (DeepMimicCore.cpp:20-23)            cMathUtil::SeedRand(seed)
+//   cScene::cScene (scenes/Scene.cpp:5)                            mRand.Seed(cMathUtil::RandUint())
+//   cRLSceneSimChar::Init (RLSceneSimChar.cpp:27-31)               cScene::Init twice: InitTimers (cTimer::Init -> Reset) + ResetParams (2 x ResetTimers)
+//   cGround::cGround (sim/Ground.cpp:68)                           cMathUtil::RandUint()
+//   every cScene::Reset (RLSceneSimChar.cpp:234-244, 277-284)      4 x cTimer::Reset, test mode then pins the limit; cSceneImitate::ResetKinChar ->
+//                                                                  CalcRandKinResetTime = cMathUtil::RandDouble(0, duration) (SceneImitate.cpp:494-500)
+// tparams: (n_resets + 1) x 3 = {min, max, exp} of the timer at Init (row 0) and at each reset (annealing); out: n_resets x 2 = {kin time, time limit};
+// init_out: {time limit after Init, first expert-sample time of the scene generator (mRand.RandDouble(0, dur), SceneImitateAMP.cpp:119)}
+void ref_rng_session(int seed, int timer_type, const double* tparams, double dur, int n_resets, int test_mode, double test_max, double* out, double* init_out) {
+    cMathUtil::SeedRand(seed);
+    cRand scene_rand; scene_rand.Seed(cMathUtil::RandUint());
+    cTimer timer;
+    auto params = [&](int i) { cTimer::tParams p; p.mType = timer_type ? cTimer::eTypeExp : cTimer::eTypeUniform; p.mTimeMin = tparams[3 * i]; p.mTimeMax = tparams[3 * i + 1]; p.mTimeExp = tparams[3 * i + 2]; return p; };
+    for (int k = 0; k < 2; ++k) { timer.Init(params(0)); timer.Reset(); timer.Reset(); }
+    cMathUtil::RandUint();
+    init_out[0] = timer.GetMaxTime();
+    for (int i = 0; i < n_resets; ++i) {
+        timer.SetParams(params(i + 1));
+        for (int k = 0; k < 4; ++k) timer.Reset();
+        if (test_mode) timer.SetMaxTime(test_max);
+        out[2 * i] = cMathUtil::RandDouble(0, dur);
+        out[2 * i + 1] = timer.GetMaxTime();
+    }
+    init_out[1] = scene_rand.RandDouble(0, dur);
+}
+
 }  // extern "C"

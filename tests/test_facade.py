@@ -302,6 +302,7 @@ def test_facade_exponential_timer(emu_lib, monkeypatch):
     test mode pins time_end_lim_max (cRLSceneSimChar::ResetTimers)"""
     from deepmimic_amd import model, streams
     monkeypatch.setenv("DM_HIP_LIB", emu_lib); monkeypatch.setenv("DM_PRECISION", "64")
+    monkeypatch.setenv("DM_RNG", "counter")      # this test pins the counter-based exponential draw of BatchEnv.reset; the reference-order draws: tests/test_ref_rng.py
     mod = _core_module()
     t = model.load_asset("humanoid3d_walk")
     t.cfg.timer_type = "exp"; t.cfg.time_lim_min, t.cfg.time_lim_max, t.cfg.time_lim_exp = 0.5, 4.0, 1.0

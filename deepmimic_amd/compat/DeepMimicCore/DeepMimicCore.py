@@ -317,7 +317,14 @@ class cDeepMimicCore(object):
             clk0 = dict(self._clk)
             out = self._launch(action, dt, k, True)
             t1 = float(env.get_state()["clocks"][0][3])
-            n_done = max(1, min(k, int(round((t1 - clk0["timer"]) / dt))))
+            n_done = min(k, int(round((t1 - clk0["timer"]) / dt)))
+            if n_done <= 0:
+                # the launch ended before its first update: the state was already invalid at entry (the caller kept updating after CheckValidEpisode
+                # returned false).  The reference's Update has no such test -- it steps; so does a single update without the early end (ADVICE r3:
+                # assuming one update had run desynchronised the host clock mirror from the device)
+                self._cache = self._launch(None, dt, 1, False)
+                self._advance_clocks(dt)
+                return
             self._spec = {"snap": snap, "clk0": clk0, "action": action, "dt": dt, "k": k, "n_done": n_done, "v": 1, "out": out}
             self._advance_clocks(dt)
             self._cache = out if n_done == 1 else None

@@ -96,6 +96,85 @@ def _ip(a):
     return None if a is None else a.ctypes.data_as(C.POINTER(C.c_int32))
 
 
+def fill_scene_tables(tables: SceneTables, test_mode: bool = False, self_collision: bool = True, erp: float = 0.0, solver_iters: int = 0):
+    """`dm_scene_tables` (include/dm_hip.h) of a parsed scene: (the ctypes struct, the arrays its pointers refer to -- keep them alive for as long as the
+    struct is used).  BatchEnv hands it to dm_create; tools/dump_tables.py serialises it for a native caller (tests/native/smoke.c)."""
+    c = tables.cfg
+    keep = []
+
+    def arr(a, dt=np.float64):
+        a = np.ascontiguousarray(a, dtype=dt)
+        keep.append(a)
+        return a
+
+    st = _SceneTables()
+    st.num_joints = tables.num_joints
+    st.joint_mat = _dp(arr(tables.joint_mat)); st.body_defs = _dp(arr(tables.body_defs)); st.pd_params = _dp(arr(tables.pd_params))
+    st.num_frames = tables.frames.shape[0]; st.frames = _dp(arr(tables.frames)); st.loop = int(tables.loop)
+    st.fall_mask = _ip(arr(tables.fall_mask(), np.int32))
+    st.num_sim_substeps = int(c.num_sim_substeps); st.world_scale = float(c.world_scale)
+    st.gravity = (C.c_double * 3)(*[float(g) for g in c.gravity])
+    st.sync_char_root_pos = int(c.sync_char_root_pos); st.sync_char_root_rot = int(c.sync_char_root_rot)
+    st.enable_fall_end = int(c.enable_fall_end); st.enable_char_contact_fall = int(c.enable_char_contact_fall)
+    st.enable_root_rot_fail = int(c.enable_root_rot_fail); st.enable_rand_char_placement = int(c.enable_rand_char_placement)
+    st.enable_rand_rot_reset = int(c.enable_rand_rot_reset)
+    # episode timer: test mode uses time_end_lim_max (scenes/RLSceneSimChar.cpp:277-284)
+    tmin, tmax = float(c.time_lim_min), float(c.time_lim_max)
+    if test_mode and c.time_end_lim_max is not None:
+        tmin = tmax = float(c.time_end_lim_max)
+    st.time_lim_min, st.time_lim_max = tmin, tmax
+    st.enable_phase_input = int(tables.enable_phase_input); st.record_world_root_pos = int(tables.record_world_root_pos)
+    st.record_world_root_rot = int(tables.record_world_root_rot); st.query_rate = float(tables.query_rate)
+    st.friction = 0.0; st.erp = float(erp); st.solver_iters = int(solver_iters)      # 0: the library's default (10, btContactSolverInfo::m_numIterations); other values are for measurements
+    st.disable_self_collision = 0 if self_collision else 1
+    st.scene_amp = int(c.scene in AMP_SCENES); st.enable_amp_obs_local_root = int(getattr(c, "enable_amp_obs_local_root", False))
+    # goal-conditioned AMP task scenes and multi-clip datasets
+    st.scene_goal = int(tables.goal_kind)
+    for k in ("rand_target_time_min", "rand_target_time_max", "max_target_dist", "target_succ_dist", "tar_fail_dist", "tar_speed",
+              "pos_reward_scale", "max_heading_turn_rate", "sharp_turn_prob", "speed_change_prob", "vel_reward_scale"):
+        setattr(st, k, float(getattr(c, k)))
+    st.enable_min_tar_vel = int(c.enable_min_tar_vel)
+    st.tar_speed_min = float(c.tar_speed if c.tar_speed_min is None else c.tar_speed_min)
+    st.tar_speed_max = float(c.tar_speed if c.tar_speed_max is None else c.tar_speed_max)
+    if tables.clip_starts is not None:
+        st.num_clips = int(tables.num_clips)
+        st.clip_starts = _ip(arr(tables.clip_starts, np.int32)); st.clip_weights = _dp(arr(tables.clip_weights))
+        st.clip_loops = _ip(arr(tables.clip_loops, np.int32))
+    else:
+        st.num_clips = 0
+    # heading_amp_getup / strike_amp
+    st.mode_test = int(bool(test_mode))
+    st.getup_time = float(tables.getup_time); st.getup_clip_mask = int(tables.getup_clip_mask); st.head_id = int(c.head_id)
+    for k in ("getup_height_root", "getup_height_head", "recover_episode_prob", "tar_near_dist", "tar_far_prob", "target_radius",
+              "target_hit_reset_time", "init_hit_prob", "hit_tar_speed", "tar_reward_scale"):
+        setattr(st, k, float(getattr(c, k)))
+    st.target_min = (C.c_double * 3)(*[float(x) for x in c.target_min]); st.target_max = (C.c_double * 3)(*[float(x) for x in c.target_max])
+    # body / clip ids become bits of 32-bit masks (c_int): an id that does not name a body part must raise here, not wrap silently
+    def _mask(ids, limit, what):
+        ids = [int(b) for b in (ids or [])]
+        if any(b < 0 or b >= min(int(limit), 31) for b in ids):
+            raise ValueError("%s out of range [0, %d): %s" % (what, min(int(limit), 31), sorted(ids)))
+        return sum(1 << b for b in set(ids))
+    st.strike_mask = _mask(c.strike_bodies, st.num_joints, "strike_bodies"); st.fail_tar_mask = _mask(c.fail_tar_contact_bodies, st.num_joints, "fail_tar_contact_bodies")
+    if not 0 <= int(tables.getup_clip_mask) < (1 << 31):
+        raise ValueError("getup_motion_ids out of range")
+    # dribble_amp: the ball (constants of cSceneDribbleAMP::BuildTarObjs; friction combined with the 0.9 of links and ground)
+    for k in ("rand_tar_obj_time_min", "rand_tar_obj_time_max", "min_tar_obj_dist", "max_tar_obj_dist", "ball_radius"):
+        setattr(st, k, float(getattr(c, k)))
+    st.ball_mass = BALL_MASS; st.ball_friction = BALL_FRICTION * 0.9; st.ball_lin_damping = BALL_LIN_DAMPING; st.ball_ang_damping = BALL_ANG_DAMPING
+    # random perturbations: with the default (infinite) interval none ever fires -- the path stays off, as in the reference
+    st.enable_rand_perturbs = int(bool(c.enable_rand_perturbs) and np.isfinite(c.perturb_time_min))
+    if st.enable_rand_perturbs:
+        st.perturb_time_min, st.perturb_time_max = float(c.perturb_time_min), float(c.perturb_time_max)
+        st.min_perturb, st.max_perturb = float(c.min_perturb), float(c.max_perturb)
+        st.min_perturb_duration, st.max_perturb_duration = float(c.min_pertrub_duration), float(c.max_perturb_duration)
+        parts = set(int(b) for b in (c.perturb_part_ids or []))
+        if any(b < 0 or b >= int(st.num_joints) for b in parts):
+            raise ValueError("perturb_part_ids names a body part the character does not have: %s" % sorted(parts))
+        st.perturb_part_mask = sum(1 << b for b in parts)
+    return st, keep
+
+
 class BatchEnv:
     """N independent imitate scenes on one GPU (one `dm_ctx`)."""
 
@@ -106,78 +185,8 @@ class BatchEnv:
         self.lib = load_library(lib_path)
         self.tables = tables
         c = tables.cfg
-        self._keep = []
-
-        def arr(a, dt=np.float64):
-            a = np.ascontiguousarray(a, dtype=dt)
-            self._keep.append(a)
-            return a
-
-        st = _SceneTables()
-        st.num_joints = tables.num_joints
-        st.joint_mat = _dp(arr(tables.joint_mat)); st.body_defs = _dp(arr(tables.body_defs)); st.pd_params = _dp(arr(tables.pd_params))
-        st.num_frames = tables.frames.shape[0]; st.frames = _dp(arr(tables.frames)); st.loop = int(tables.loop)
-        st.fall_mask = _ip(arr(tables.fall_mask(), np.int32))
-        st.num_sim_substeps = int(c.num_sim_substeps); st.world_scale = float(c.world_scale)
-        st.gravity = (C.c_double * 3)(*[float(g) for g in c.gravity])
-        st.sync_char_root_pos = int(c.sync_char_root_pos); st.sync_char_root_rot = int(c.sync_char_root_rot)
-        st.enable_fall_end = int(c.enable_fall_end); st.enable_char_contact_fall = int(c.enable_char_contact_fall)
-        st.enable_root_rot_fail = int(c.enable_root_rot_fail); st.enable_rand_char_placement = int(c.enable_rand_char_placement)
-        st.enable_rand_rot_reset = int(c.enable_rand_rot_reset)
-        # episode timer: test mode uses time_end_lim_max (scenes/RLSceneSimChar.cpp:277-284)
-        tmin, tmax = float(c.time_lim_min), float(c.time_lim_max)
-        if test_mode and c.time_end_lim_max is not None:
-            tmin = tmax = float(c.time_end_lim_max)
-        st.time_lim_min, st.time_lim_max = tmin, tmax
-        st.enable_phase_input = int(tables.enable_phase_input); st.record_world_root_pos = int(tables.record_world_root_pos)
-        st.record_world_root_rot = int(tables.record_world_root_rot); st.query_rate = float(tables.query_rate)
-        st.friction = 0.0; st.erp = float(erp); st.solver_iters = int(solver_iters)      # 0: the library's default (10, btContactSolverInfo::m_numIterations); other values are for measurements
-        st.disable_self_collision = 0 if self_collision else 1
-        st.scene_amp = int(c.scene in AMP_SCENES); st.enable_amp_obs_local_root = int(getattr(c, "enable_amp_obs_local_root", False))
-        # goal-conditioned AMP task scenes and multi-clip datasets
-        st.scene_goal = int(tables.goal_kind)
-        for k in ("rand_target_time_min", "rand_target_time_max", "max_target_dist", "target_succ_dist", "tar_fail_dist", "tar_speed",
-                  "pos_reward_scale", "max_heading_turn_rate", "sharp_turn_prob", "speed_change_prob", "vel_reward_scale"):
-            setattr(st, k, float(getattr(c, k)))
-        st.enable_min_tar_vel = int(c.enable_min_tar_vel)
-        st.tar_speed_min = float(c.tar_speed if c.tar_speed_min is None else c.tar_speed_min)
-        st.tar_speed_max = float(c.tar_speed if c.tar_speed_max is None else c.tar_speed_max)
-        if tables.clip_starts is not None:
-            st.num_clips = int(tables.num_clips)
-            st.clip_starts = _ip(arr(tables.clip_starts, np.int32)); st.clip_weights = _dp(arr(tables.clip_weights))
-            st.clip_loops = _ip(arr(tables.clip_loops, np.int32))
-        else:
-            st.num_clips = 0
-        # heading_amp_getup / strike_amp
-        st.mode_test = int(bool(test_mode))
-        st.getup_time = float(tables.getup_time); st.getup_clip_mask = int(tables.getup_clip_mask); st.head_id = int(c.head_id)
-        for k in ("getup_height_root", "getup_height_head", "recover_episode_prob", "tar_near_dist", "tar_far_prob", "target_radius",
-                  "target_hit_reset_time", "init_hit_prob", "hit_tar_speed", "tar_reward_scale"):
-            setattr(st, k, float(getattr(c, k)))
-        st.target_min = (C.c_double * 3)(*[float(x) for x in c.target_min]); st.target_max = (C.c_double * 3)(*[float(x) for x in c.target_max])
-        # body / clip ids become bits of 32-bit masks (c_int): an id that does not name a body part must raise here, not wrap silently
-        def _mask(ids, limit, what):
-            ids = [int(b) for b in (ids or [])]
-            if any(b < 0 or b >= min(int(limit), 31) for b in ids):
-                raise ValueError("%s out of range [0, %d): %s" % (what, min(int(limit), 31), sorted(ids)))
-            return sum(1 << b for b in set(ids))
-        st.strike_mask = _mask(c.strike_bodies, st.num_joints, "strike_bodies"); st.fail_tar_mask = _mask(c.fail_tar_contact_bodies, st.num_joints, "fail_tar_contact_bodies")
-        if not 0 <= int(tables.getup_clip_mask) < (1 << 31):
-            raise ValueError("getup_motion_ids out of range")
-        # dribble_amp: the ball (constants of cSceneDribbleAMP::BuildTarObjs; friction combined with the 0.9 of links and ground)
-        for k in ("rand_tar_obj_time_min", "rand_tar_obj_time_max", "min_tar_obj_dist", "max_tar_obj_dist", "ball_radius"):
-            setattr(st, k, float(getattr(c, k)))
-        st.ball_mass = BALL_MASS; st.ball_friction = BALL_FRICTION * 0.9; st.ball_lin_damping = BALL_LIN_DAMPING; st.ball_ang_damping = BALL_ANG_DAMPING
-        # random perturbations: with the default (infinite) interval none ever fires -- the path stays off, as in the reference
-        st.enable_rand_perturbs = int(bool(c.enable_rand_perturbs) and np.isfinite(c.perturb_time_min))
-        if st.enable_rand_perturbs:
-            st.perturb_time_min, st.perturb_time_max = float(c.perturb_time_min), float(c.perturb_time_max)
-            st.min_perturb, st.max_perturb = float(c.min_perturb), float(c.max_perturb)
-            st.min_perturb_duration, st.max_perturb_duration = float(c.min_pertrub_duration), float(c.max_perturb_duration)
-            parts = set(int(b) for b in (c.perturb_part_ids or []))
-            if any(b < 0 or b >= int(st.num_joints) for b in parts):
-                raise ValueError("perturb_part_ids names a body part the character does not have: %s" % sorted(parts))
-            st.perturb_part_mask = sum(1 << b for b in parts)
+        st, self._keep = fill_scene_tables(tables, test_mode=test_mode, self_collision=self_collision, erp=erp, solver_iters=solver_iters)
+        tmin, tmax = float(st.time_lim_min), float(st.time_lim_max)
         self.has_perturbs = bool(st.enable_rand_perturbs)
         if c.timer_type not in ("uniform", "exp"):
             raise ValueError("unsupported timer type %r (util/Timer.cpp:27-45: uniform | exp)" % c.timer_type)
@@ -197,10 +206,12 @@ class BatchEnv:
         self.amp_size = int(self.lib.dm_amp_obs_size(self.h))      # GetAMPObsSize; 0 unless `--scene imitate_amp`
         self.num_clips = int(tables.num_clips); self.has_obj = tables.goal_kind == 5
         self._has_goal_row = bool(tables.goal_kind != 0 or tables.num_clips > 1 or c.enable_rand_rot_reset)      # dm_host.cpp: st.goal is allocated under the same condition
-        if self._timer[0] == "exp" and not self._timer_pinned:
-            # dm_create's own first reset drew the uniform timer: an env stepped right after construction must run its first episode under
-            # min(time_lim_min + Exp(time_lim_exp), time_lim_max) too (util/Timer.cpp:64-67), so reset once more through the host draw
-            self.reset()
+        if self._timer[0] == "exp":
+            # `--timer_type exp` (util/Timer.cpp:27-45, 64-67): the device draws min(min + Exp(time_lim_exp), max) at every reset, in-kernel auto-resets
+            # included (round 4).  dm_create's own first reset drew the uniform timer: reset once more under the exponential one.
+            self._chk(self.lib.dm_set_timer_exp(self.h, C.c_double(self._timer[3])))
+            if not self._timer_pinned:
+                self.reset()
 
     def _chk(self, rc):
         if rc != 0:
@@ -223,25 +234,17 @@ class BatchEnv:
         n = self.N if ids is None else ids.size
         kt = None if kin_times is None else np.ascontiguousarray(np.broadcast_to(kin_times, (n,)), dtype=np.float64)
         mt = None if max_times is None else np.ascontiguousarray(np.broadcast_to(max_times, (n,)), dtype=np.float64)
-        if mt is None and self._timer[0] == "exp" and not self._timer_pinned:
-            # `--timer_type exp` (util/Timer.cpp:64-67): the kernels draw the uniform timer; an explicit reset draws the exponential one here,
-            # from the same counter-based stream (seed, global env id, episode counter, stream 1) the device would have used
-            from . import model, streams
-            ep = self.get_state()["flags"][:, 2]
-            sel = np.arange(self.N) if ids is None else ids
-            mt = np.array([model.draw_time_limit("exp", self._timer[1], self._timer[2], self._timer[3],
-                                                 streams.reset_rand01(self._seed, self._env_off + int(e), int(ep[int(e)]), 1)) for e in sel], dtype=np.float64)
         self._chk(self.lib.dm_reset(self.h, _ip(ids), n, _dp(kt), _dp(mt)))
 
     def _check_auto_reset(self, auto_reset):
-        if auto_reset and self._timer[0] == "exp" and not self._timer_pinned:
-            raise ValueError("--timer_type exp: the in-kernel auto-reset draws the uniform episode timer; step without auto_reset and call reset() "
-                             "(it draws the exponential limit of util/Timer.cpp:64-67 on the host)")
+        pass            # (until round 4 the in-kernel auto-reset refused `--timer_type exp`; the device draws it now)
 
     def set_time_limits(self, time_lim_min: float, time_lim_max: float, time_lim_exp: Optional[float] = None):
         self._chk(self.lib.dm_set_time_limits(self.h, C.c_double(time_lim_min), C.c_double(time_lim_max)))
         self._timer = (self._timer[0], float(time_lim_min), float(time_lim_max), self._timer[3] if time_lim_exp is None else float(time_lim_exp))
         self._timer_pinned = time_lim_min == time_lim_max          # test mode: cRLSceneSimChar::ResetTimers pins the limit, whatever the type
+        if self._timer[0] == "exp":
+            self._chk(self.lib.dm_set_timer_exp(self.h, C.c_double(self._timer[3])))
 
     def set_sample_count(self, sample_count: int, test_mode: bool = False):
         """cRLSceneSimChar::SetSampleCount / SetMode for the whole batch: anneal the episode-length limits (model.timer_limits)."""

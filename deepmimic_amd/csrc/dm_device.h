@@ -348,6 +348,9 @@ struct Lds : LdsBroad<Real, C> {
         struct { int csel[NCAP]; Real cdistc[NCAP];                                          // manifold-reduction scratch (by candidate)
                  Real ct[kMaxContacts][8]; };                                                // contact slots: x(3), n(3), dist, links a | b << 8 (b = 255: ground)
     };
+    // scratch() aliases Lt outside the update loop: emit() needs 2 NP + 7 NJ words (kin pose / vel, joint positions, reduction terms), the AMP expert
+    // sample 4 NP -- a new topology or class must not silently overrun into the fields behind Lt
+    static_assert(kLWords >= 2 * C::NP + 7 * C::NJ && kLWords >= 4 * C::NP, "Lds::Lt is too small for the scratch users (emit, amp_expert)");
     alignas(32) Real Lt[kLWords];
     Real kin[8];                           // kin origin pos(3), origin rot(4)
     Real sc[8];                            // small float scratch (kin / sim COM velocity, episode-end flag)
@@ -441,7 +444,14 @@ struct EnvSim {
     // the next action boundary (DeepMimic.py:62-80 update_world: world.update(timestep); is_episode_end -> end_episode, reset,
     // break; learning/rl_agent.py:_end_path records the state and reward of that moment).  Same tests as emit(): contact fall
     // (cSceneImitate::CheckTerminate, SceneImitate.cpp:193-205), a finished non-looping clip, the episode timer.  The root-rotation
-    // failure test (enable_root_rot_fail, off in every shipped imitate arg file) needs the kin pose and stays at the boundary.
+    // failure test (enable_root_rot_fail) is root_rot_failed_now(), added by update() in the instantiations that carry it.
+    // cSceneImitate::CheckRootRotFail (SceneImitate.cpp:466-492, `--enable_root_rot_fail`, off in every shipped arg file) on the state after this
+    // update, for the per-update episode end of DM_END_EPISODE_EARLY: the driver asks IsEpisodeEnd after every update, so a character that has turned
+    // more than 90 degrees away from the clip ends its episode at THAT update (round 4; until then the test ran at the action boundary only).  Compiled
+    // into the AMP / tap instantiations, which the host selects for a scene with the flag on; lane 0.
+    DM_DEV bool root_rot_failed_now() const {
+        return quat_theta(qmul(kin_root_rot(s.clk[CLK_KIN]), qconj(ldq(s.pose + 3)))) > (Real)(0.5 * DM_PI);
+    }
     DM_DEV bool episode_over_now() const {
         const bool fail = (m.enable_fall_end && has_fallen(nullptr)) || (!m.scene_amp && !m.loop && s.clk[CLK_KIN] >= m.duration);
         return fail || (s.clk[CLK_TIMER] >= s.clk[CLK_TIMER_MAX]);
@@ -1756,7 +1766,9 @@ struct EnvSim {
             double cur = s.clk[CLK_CTRL] + s.clk[CLK_INIT_OFF], pad = 0.001 * dt;
             int c1 = (int)floor((cur + pad) / m.query_period), c0 = (int)floor((cur + pad - dt) / m.query_period);
             s.flg[FLG_NEED_ACTION] = (c1 != c0) ? 1 : 0;
-            s.flg[FLG_OVER] = (s.flg[FLG_OVER] & 2) | (episode_over_now() ? 1 : 0);      // read by the step kernels when DM_END_EPISODE_EARLY is set (bit 1: kin_pre's invalid latch)
+            bool over = episode_over_now();
+            if (PERT) { if (m.enable_root_rot_fail && m.enable_fall_end && !over) over = root_rot_failed_now(); }
+            s.flg[FLG_OVER] = (s.flg[FLG_OVER] & 2) | (over ? 1 : 0);      // read by the step kernels when DM_END_EPISODE_EARLY is set (bit 1: kin_pre's invalid latch)
         }
         sync();
     }
@@ -2541,6 +2553,16 @@ template <> struct StepWaves<float, ClsBipedObj> { static constexpr int value = 
 #else
 #define DM_WAVES_PER_EU(n) __attribute__((amdgpu_waves_per_eu(n, n)))
 #endif
+// cTimer::Reset (util/Timer.cpp:55-73) from the counter-based stream 1 of (seed, global env id, episode): uniform U[min, max], or -- `--timer_type exp`,
+// EXP instantiations only (the AMP / tap step kernels, which the host selects for such a scene, and the reset kernel) --
+// min(min + Exp(rate 1 / timer_exp), max) with std::exponential_distribution's inverse-CDF form -ln(1 - u) / rate.  A pinned limit (min == max: test
+// mode, every shipped imitate arg file) draws nothing.
+template <bool EXP, typename Real> DM_DEV double draw_time_limit(const ModelDev<Real>& m, int e, uint64_t ep) {
+    if (!(m.time_lim_max > m.time_lim_min)) return m.time_lim_max;
+    const double u = dm_rand01(m.seed, (uint64_t)(e + m.env_off), ep, 1);
+    if (EXP) { if (m.timer_exp > 0) { const double t = m.time_lim_min - m.timer_exp * log1p(-u); return t < m.time_lim_max ? t : m.time_lim_max; } }
+    return m.time_lim_min + (m.time_lim_max - m.time_lim_min) * u;
+}
 // AMP: the `--scene imitate_amp` instantiation (pose history latch inside the update loop, AMP observation at the end); the
 // plain production kernel carries none of it.  The tap build (tests, profiling) serves both scene kinds.
 // PHYS2: DM-physics v2 -- its own instantiation, so that the AMP kernels of the shipped scenes do not carry it
@@ -2585,7 +2607,7 @@ __global__ void __launch_bounds__(64) DM_WAVES_PER_EU((StepWaves<Real, C>::value
             if (HIST && pass == 0 && io.amp_obs && st.hist) sim.emit_amp(io, st, e);       // end-of-path observation of a finished episode included
             if (pass == 1 || !(io.auto_reset && ended)) break;
             uint64_t ep = (uint64_t)lds.flg[FLG_EPISODE];
-            double mt = (m.time_lim_max > m.time_lim_min) ? m.time_lim_min + (m.time_lim_max - m.time_lim_min) * dm_rand01(m.seed, (uint64_t)(e + m.env_off), ep, 1) : m.time_lim_max;
+            double mt = draw_time_limit<HIST>(m, e, ep);
             bool rec = false;
             if (HIST && st.goal) {           // clip by weight, random yaw, goal reset -- unless the episode goes on as a recovery episode
                 rec = sim.try_recovery_reset(st, e, mt);
@@ -2616,7 +2638,7 @@ __global__ void __launch_bounds__(64) k_env_reset(ModelDev<Real> m, EnvState<Rea
     sim.load(st, e);
     uint64_t ep = (uint64_t)lds.flg[FLG_EPISODE];
     double mt = max_times ? max_times[b]
-              : ((m.time_lim_max > m.time_lim_min) ? m.time_lim_min + (m.time_lim_max - m.time_lim_min) * dm_rand01(m.seed, (uint64_t)(e + m.env_off), ep, 1) : m.time_lim_max);
+              : draw_time_limit<true>(m, e, ep);
     bool rec = false;
     if (st.goal) {
         sim.goal_sync_flags(st, e);

@@ -711,7 +711,9 @@ _Pragma("unroll") \
             double cur = s.clk[CLK_CTRL] + s.clk[CLK_INIT_OFF], pad = 0.001 * dt;
             int c1 = (int)floor((cur + pad) / m.query_period), c0 = (int)floor((cur + pad - dt) / m.query_period);
             s.flg[FLG_NEED_ACTION] = (c1 != c0) ? 1 : 0;
-            s.flg[FLG_OVER] = (s.flg[FLG_OVER] & 2) | (b.episode_over_now() ? 1 : 0);
+            bool over = b.episode_over_now();
+            if (PERT) { if (m.enable_root_rot_fail && m.enable_fall_end && !over) over = b.root_rot_failed_now(); }
+            s.flg[FLG_OVER] = (s.flg[FLG_OVER] & 2) | (over ? 1 : 0);
         }
         sync();
     }
@@ -746,9 +748,14 @@ __global__ void __launch_bounds__(64) DM_WAVES_PER_EU((DuoWaves<Real>::value)) k
         if (io.end_early && ((lds[0].flg[FLG_OVER] | lds[1].flg[FLG_OVER]) & 2)) {
             const int o0 = lds[0].flg[FLG_OVER] | lds[0].flg[FLG_PARKED], o1 = lds[1].flg[FLG_OVER] | lds[1].flg[FLG_PARKED];
             if (o0 && o1) break;
-            const bool now = lds[half].flg[FLG_OVER] != 0 && lds[half].flg[FLG_PARKED] == 0;
-            sim.b.park(snap[half], now);
-            sim.b.kin_pre(false);                        // (the parked character's link state follows its new pose)
+            // bit 1 stays latched for the rest of the launch: park (three barriers) and the second kinematics pass only when a character is NEWLY invalid
+            // (every later update used to pay them again)
+            const bool newly = ((lds[0].flg[FLG_OVER] & 2) && !lds[0].flg[FLG_PARKED]) || ((lds[1].flg[FLG_OVER] & 2) && !lds[1].flg[FLG_PARKED]);
+            if (newly) {
+                const bool now = lds[half].flg[FLG_OVER] != 0 && lds[half].flg[FLG_PARKED] == 0;
+                sim.b.park(snap[half], now);
+                sim.b.kin_pre(false);                    // (the parked character's link state follows its new pose)
+            }
         }
         if (HIST && st.hist) sim.b.latch_hist(st, eo, lds[half].flg[FLG_PARKED] == 0);
         if (goal) sim.b.goal_latch(st, eo, io.dt, lds[half].flg[FLG_PARKED] == 0);
@@ -775,7 +782,7 @@ __global__ void __launch_bounds__(64) DM_WAVES_PER_EU((DuoWaves<Real>::value)) k
         if (HIST && io.amp_obs && st.hist) sim.b.emit_amp(io, st, e);
         if (io.auto_reset && ended) {                    // per character; no cross-half traffic inside
             uint64_t ep = (uint64_t)lds[half].flg[FLG_EPISODE];
-            double mt = (m.time_lim_max > m.time_lim_min) ? m.time_lim_min + (m.time_lim_max - m.time_lim_min) * dm_rand01(m.seed, (uint64_t)(e + m.env_off), ep, 1) : m.time_lim_max;
+            double mt = draw_time_limit<HIST>(m, e, ep);
             bool rec = false;
             if (HIST && st.goal) { rec = sim.b.try_recovery_reset(st, e, mt); if (!rec) reset_goal_env<Real, ClsBiped, TAPS, 32>(sim.b, m, lds[half], st, e, ep, nullptr, mt); }
             else {

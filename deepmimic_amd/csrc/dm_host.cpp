@@ -307,6 +307,7 @@ struct CtxBase {
     virtual int get_debug(const char* name, double* out) = 0;
     virtual int set_tau(const double* tau) = 0;
     virtual void set_time_limits(double lo, double hi) = 0;
+    virtual void set_timer_exp(double ex) = 0;
 };
 
 template <typename Real>
@@ -421,7 +422,7 @@ struct CtxT : CtxBase {
         md.enable_contact_fall = c.enable_char_contact_fall; md.enable_root_rot_fail = c.enable_root_rot_fail; md.enable_rand_placement = c.enable_rand_char_placement;
         md.enable_phase_input = c.enable_phase_input; md.record_world_root_pos = c.record_world_root_pos; md.record_world_root_rot = c.record_world_root_rot;
         md.query_period = 1.0 / (c.query_rate > 0 ? c.query_rate : 30.0);
-        md.time_lim_min = c.time_lim_min; md.time_lim_max = c.time_lim_max; md.seed = seed;
+        md.time_lim_min = c.time_lim_min; md.time_lim_max = c.time_lim_max; md.timer_exp = 0; md.seed = seed;
         st.N = N;
         st.pose = (Real*)dalloc(sizeof(Real) * N * h.P); st.vel = (Real*)dalloc(sizeof(Real) * N * h.P); st.tar = (Real*)dalloc(sizeof(Real) * N * h.P);
         st.tau = (Real*)dalloc(sizeof(Real) * N * h.D); st.kin = (Real*)dalloc(sizeof(Real) * N * 8);
@@ -540,7 +541,7 @@ struct CtxT : CtxBase {
         io.n_updates = n_updates; io.dt = dt; io.auto_reset = (flags & DM_AUTO_RESET) ? 1 : 0; io.emit = (flags & DM_NO_EMIT) ? 0 : 1; io.open_loop = (flags & DM_OPEN_LOOP) ? 1 : 0; io.end_early = (flags & DM_END_EPISODE_EARLY) ? 1 : 0;
         // two characters per wavefront: biped class, even batch, no debug taps armed (DM_DUO=0 keeps one character per wave)
         if (duo && cls == 0 && hm.D == ClsBiped::ND && (N % 2) == 0 && !dbg.H && !st.manif) {      // (31 row lanes per character assume exactly 34 dofs; physics 2 runs one per wave)
-            if (st.hist || st.pert) launch_step_duo<Real, SV_AMP>(N / 2, stream, md, st, io, dbg);      // (the AMP instantiation also carries the perturbation code)
+            if (st.hist || st.pert || md.enable_root_rot_fail || md.timer_exp > 0) launch_step_duo<Real, SV_AMP>(N / 2, stream, md, st, io, dbg);      // (the AMP instantiation also carries the perturbation code)
             else launch_step_duo<Real, SV_PLAIN>(N / 2, stream, md, st, io, dbg);
             return 0;
         }
@@ -549,18 +550,18 @@ struct CtxT : CtxBase {
         else if (cls == 4) {
             if (dbg.H) launch_step<Real, ClsBipedTree, SV_TAPS>(N, stream, md, st, io, dbg);
             else if (st.manif) launch_step<Real, ClsBipedTree, SV_V2>(N, stream, md, st, io, dbg);
-            else if (st.hist || st.pert) launch_step<Real, ClsBipedTree, SV_AMP>(N, stream, md, st, io, dbg);
+            else if (st.hist || st.pert || md.enable_root_rot_fail || md.timer_exp > 0) launch_step<Real, ClsBipedTree, SV_AMP>(N, stream, md, st, io, dbg);
             else launch_step<Real, ClsBipedTree, SV_PLAIN>(N, stream, md, st, io, dbg);
         }
         else if (cls == 3) {
             if (dbg.H) launch_step<Real, ClsLargeTree, SV_TAPS>(N, stream, md, st, io, dbg);
             else if (st.manif) launch_step<Real, ClsLargeTree, SV_V2>(N, stream, md, st, io, dbg);
-            else if (st.hist || st.pert) launch_step<Real, ClsLargeTree, SV_AMP>(N, stream, md, st, io, dbg);
+            else if (st.hist || st.pert || md.enable_root_rot_fail || md.timer_exp > 0) launch_step<Real, ClsLargeTree, SV_AMP>(N, stream, md, st, io, dbg);
             else launch_step<Real, ClsLargeTree, SV_PLAIN>(N, stream, md, st, io, dbg);
         }
         else if (dbg.H) { if (cls == 0) launch_step<Real, ClsBiped, SV_TAPS>(N, stream, md, st, io, dbg); else launch_step<Real, ClsLarge, SV_TAPS>(N, stream, md, st, io, dbg); }
         else if (st.manif) { if (cls == 0) launch_step<Real, ClsBiped, SV_V2>(N, stream, md, st, io, dbg); else launch_step<Real, ClsLarge, SV_V2>(N, stream, md, st, io, dbg); }      // DM-physics v2: its own instantiation (AMP code + manifolds)
-        else if (st.hist || st.pert) { if (cls == 0) launch_step<Real, ClsBiped, SV_AMP>(N, stream, md, st, io, dbg); else launch_step<Real, ClsLarge, SV_AMP>(N, stream, md, st, io, dbg); }
+        else if (st.hist || st.pert || md.enable_root_rot_fail || md.timer_exp > 0) { if (cls == 0) launch_step<Real, ClsBiped, SV_AMP>(N, stream, md, st, io, dbg); else launch_step<Real, ClsLarge, SV_AMP>(N, stream, md, st, io, dbg); }
         else { if (cls == 0) launch_step<Real, ClsBiped, SV_PLAIN>(N, stream, md, st, io, dbg); else launch_step<Real, ClsLarge, SV_PLAIN>(N, stream, md, st, io, dbg); }
         return 0;
     }
@@ -680,6 +681,7 @@ struct CtxT : CtxBase {
     }
     int set_tau(const double* tau) override { return ul(st.tau, (size_t)N * hm.D, tau); }
     void set_time_limits(double lo, double hi) override { md.time_lim_min = lo; md.time_lim_max = hi; }
+    void set_timer_exp(double ex) override { md.timer_exp = ex > 0 ? ex : 0; }
     int get_debug(const char* name, double* out) override {
         const size_t n = N; const HostModel& h = hm; std::string s(name);
         if (s == "tau") return dl(st.tau, n * h.D, out);
@@ -813,6 +815,12 @@ int dm_get_stream(const dm_ctx* ctx, void** out_own, void** out_current) {
 }
 int dm_synchronize(dm_ctx* ctx) { if (!ctx) return fail("null ctx"); DevGuard guard(ctx->c->device_id); return rt_sync(ctx->c->stream) == 0 ? 0 : fail("stream synchronize failed"); }
 
+int dm_set_timer_exp(dm_ctx* ctx, double time_lim_exp) {
+    if (!ctx) return fail("null ctx");
+    if (!(time_lim_exp >= 0)) return fail("time_lim_exp must be >= 0 (0: uniform timer)");
+    ctx->c->set_timer_exp(time_lim_exp);
+    return 0;
+}
 int dm_set_time_limits(dm_ctx* ctx, double time_lim_min, double time_lim_max) {
     if (!ctx) return fail("null ctx");
     if (!(time_lim_max >= time_lim_min)) return fail("time_lim_max must be >= time_lim_min");

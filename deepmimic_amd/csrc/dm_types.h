@@ -189,7 +189,8 @@ struct ModelDev {
     int sync_root_pos, sync_root_rot, enable_fall_end, enable_contact_fall, enable_root_rot_fail, enable_rand_placement;
     int enable_phase_input, record_world_root_pos, record_world_root_rot;
     double query_period;                     // 1 / QueryRate
-    double time_lim_min, time_lim_max;       // episode timer range (uniform)
+    double time_lim_min, time_lim_max;       // episode timer range
+    double timer_exp;                        // 0: uniform timer U[min, max]; > 0: `--timer_type exp`, min(min + Exp(mean timer_exp), max) (util/Timer.cpp:55-73)
     uint64_t seed;
     int env_off;                             // global id of env 0 of this shard (keeps RNG streams partition-invariant)
     int physics;                             // 1: DM-physics v1, 2: v2 (persistent ground manifolds, both rows of a revolute limit); NL counts ROWS

@@ -5,8 +5,7 @@ protocol: SetAction ; 20 x Update ; RecordState / CalcReward / CheckTerminate ; 
 
 torch is plumbing here (device memory, streams); the stepping itself is libdm_hip.so.
 
-`--timer_type exp` scenes (no shipped arg file) are not served here: the in-kernel auto-reset draws the uniform episode timer only
-(util/Timer.cpp:27-45; BatchEnv.reset draws the exponential one on the host for explicit resets)."""
+`--timer_type exp` scenes are served like the uniform timer since round 4: the in-kernel auto-reset draws min(min + Exp, max) (util/Timer.cpp:64-67)."""
 from __future__ import annotations
 
 from typing import Dict, Tuple
@@ -61,7 +60,11 @@ class TorchVecEnv:
     def step(self, actions) -> Tuple["object", "object", "object", Dict[str, "object"]]:
         """One control step for every env.  `actions`: (N, A) float32 on this device.  Envs whose episode ended during the step are
         reset inside the launch; their `obs` row is already the first observation of the next episode, `reward` / `terminate` describe
-        the step that ended (eTerminateNull 0 / Fail 1 / Succ 2; episode_end also covers the episode timer)."""
+        the step that ended (eTerminateNull 0 / Fail 1 / Succ 2; episode_end also covers the episode timer).
+        `done` = every env that was reset inside the launch: episode_end (cDeepMimicCore::IsEpisodeEnd) OR an INVALID episode (valid == 0:
+        cSceneSimChar::CheckValidEpisode failed, a link velocity beyond 100 -- the reference's driver ends and DISCARDS such an episode,
+        DeepMimic.py:62-80 / learning/rl_agent.py end_episode; info["valid"] tells the two apart).  A learner that bootstraps across a row with
+        done == False can therefore never stitch two episodes together."""
         t = self.torch
         if actions.device != self.device or actions.dtype != t.float32 or tuple(actions.shape) != (self.n, self.act_dim) or not actions.is_contiguous():
             raise ValueError("actions must be a contiguous float32 (N, A) tensor on %s" % self.device)
@@ -74,7 +77,7 @@ class TorchVecEnv:
         if self.goal_dim:
             self.env.last_goals_device(self.goal.data_ptr())        # device-to-device on the same stream, behind the step kernel: no host sync
             info["goal"] = self.goal
-        return self.obs, self.reward, self.episode_end.bool(), info
+        return self.obs, self.reward, (self.episode_end != 0) | (self.valid == 0), info
 
     def close(self):
         self.env.close()

@@ -145,6 +145,10 @@ int dm_synchronize(dm_ctx* ctx);
 /* cDeepMimicCore::SetMode (DeepMimicCore.cpp:472-479 -> cRLSceneSimChar::SetMode / ResetTimers, scenes/RLSceneSimChar.cpp:
  * 270-290): the episode-timer range drawn at the next resets; train = (time_lim_min, time_lim_max), test = time_end_lim_*. */
 int dm_set_time_limits(dm_ctx* ctx, double time_lim_min, double time_lim_max);
+/* `--timer_type exp --time_lim_exp E` (scenes/Scene.cpp:19-23, util/Timer.cpp:27-45, 64-67): every reset -- explicit or inside a DM_AUTO_RESET
+ * launch -- then draws min(time_lim_min + Exp(mean E), time_lim_max) instead of U[time_lim_min, time_lim_max].  0 (the default) = uniform timer.
+ * Annealing blends E like the limits (cTimer::tParams::Blend): call again with the blended value. */
+int dm_set_timer_exp(dm_ctx* ctx, double time_lim_exp);
 
 /* cDeepMimicCore::Reset (DeepMimicCore.cpp:61-65).  env_ids NULL -> all envs.  kin_times / max_times NULL ->
  * per-env counter-based RNG: kin time ~ U[0,duration) (scenes/SceneImitate.cpp:494-500), timer ~ U[min,max]. */

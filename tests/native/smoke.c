@@ -1,0 +1,83 @@
+/* A native caller of the C-ABI: no Python, no torch -- C99, include/dm_hip.h, libdm_hip.so.
+ *
+ *     gcc -std=c99 -Iinclude tests/native/smoke.c -o smoke -Ldeepmimic_amd/csrc -ldm_hip -Wl,-rpath,$PWD/deepmimic_amd/csrc
+ *     ./smoke scene.dmtbl [num_envs] [control steps] [precision]            (scene.dmtbl: tools/dump_tables.py)
+ *
+ * What the reference's native entry point does with cDeepMimicCore (DeepMimicCore/Main.cpp:38-75 SetupDeepMimicCore: construct, SeedRand,
+ * ParseArgs, Init; :97-124 the update loop: Update(timestep) ... Reset() at episode end), here through the batched entry points: dm_create
+ * from the flat scene tables, dm_reset at chosen clip times, `steps` control steps of 20 x Update(1/600) through dm_step_batch with the
+ * clip-tracking action (DM_OPEN_LOOP), rewards / flags printed one line per step so that the test can compare them with the Python binding's
+ * (tests/test_native_caller.py: bit-identical, it is the same library).  Every call's return code is checked; dm_last_error() says why. */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "dm_hip.h"
+
+static void die(const char* what) { fprintf(stderr, "smoke: %s: %s\n", what, dm_last_error()); exit(1); }
+
+/* the blob of tools/dump_tables.py: header, pointer table, struct image, arrays */
+static dm_scene_tables* load_tables(const char* path, unsigned char** keep) {
+    FILE* f = fopen(path, "rb");
+    if (!f) { perror(path); exit(1); }
+    fseek(f, 0, SEEK_END); long n = ftell(f); fseek(f, 0, SEEK_SET);
+    unsigned char* b = (unsigned char*)malloc((size_t)n);
+    if (!b || fread(b, 1, (size_t)n, f) != (size_t)n) { fprintf(stderr, "smoke: cannot read %s\n", path); exit(1); }
+    fclose(f);
+    int32_t abi, ssize; uint64_t np;
+    if (n < 24 || memcmp(b, "DMTBL\0\0\1", 8) != 0) { fprintf(stderr, "smoke: %s is not a table blob\n", path); exit(1); }
+    memcpy(&abi, b + 8, 4); memcpy(&ssize, b + 12, 4); memcpy(&np, b + 16, 8);
+    if (abi != DM_ABI_VERSION || abi != dm_abi_version() || (size_t)ssize != sizeof(dm_scene_tables)) {
+        fprintf(stderr, "smoke: blob ABI %d / struct %d bytes, header ABI %d / %zu bytes, library ABI %d\n", abi, ssize, DM_ABI_VERSION, sizeof(dm_scene_tables), dm_abi_version());
+        exit(1);
+    }
+    unsigned char* st = b + 24 + 24 * np;
+    for (uint64_t i = 0; i < np; ++i) {
+        uint64_t off, bo, nb;
+        memcpy(&off, b + 24 + 24 * i, 8); memcpy(&bo, b + 32 + 24 * i, 8); memcpy(&nb, b + 40 + 24 * i, 8);
+        if (off + sizeof(void*) > (uint64_t)ssize || bo + nb > (uint64_t)n) { fprintf(stderr, "smoke: corrupt pointer table\n"); exit(1); }
+        void* p = b + bo;
+        memcpy(st + off, &p, sizeof(void*));
+    }
+    *keep = b;
+    return (dm_scene_tables*)st;
+}
+
+int main(int argc, char** argv) {
+    if (argc < 2) { fprintf(stderr, "usage: smoke scene.dmtbl [num_envs] [steps] [precision]\n"); return 2; }
+    const int n = argc > 2 ? atoi(argv[2]) : 8, steps = argc > 3 ? atoi(argv[3]) : 10, precision = argc > 4 ? atoi(argv[4]) : 32;
+    unsigned char* keep = NULL;
+    dm_scene_tables* tables = load_tables(argv[1], &keep);
+
+    dm_create_info info;
+    memset(&info, 0, sizeof(info));
+    info.num_envs = n; info.device_id = 0; info.seed = 1234; info.precision = precision; info.max_contacts = 20;
+    dm_ctx* ctx = NULL;
+    if (dm_create(&info, tables, &ctx) != 0) die("dm_create");
+
+    int32_t dims[8];
+    if (dm_dims(ctx, dims) != 0) die("dm_dims");
+    const int S = dims[0], A = dims[2];
+    printf("dims S %d G %d A %d P %d J %d D %d F %d N %d duration %.17g emulator %d\n", dims[0], dims[1], dims[2], dims[3], dims[4], dims[5], dims[6], dims[7],
+           dm_motion_duration(ctx), dm_is_emulator());
+
+    /* cDeepMimicCore::Reset for every env, at clip times spread over the clip and without an episode limit (explicit: reproducible anywhere) */
+    double* kin = (double*)malloc(sizeof(double) * (size_t)n); double* lim = (double*)malloc(sizeof(double) * (size_t)n);
+    for (int e = 0; e < n; ++e) { kin[e] = dm_motion_duration(ctx) * e / n; lim[e] = 1e300; }
+    if (dm_reset(ctx, NULL, n, kin, lim) != 0) die("dm_reset");
+
+    float* states = (float*)malloc(sizeof(float) * (size_t)n * (size_t)S); float* rewards = (float*)malloc(sizeof(float) * (size_t)n);
+    int32_t* term = (int32_t*)malloc(4 * (size_t)n); int32_t* valid = (int32_t*)malloc(4 * (size_t)n); int32_t* end = (int32_t*)malloc(4 * (size_t)n);
+    (void)A;
+    for (int k = 0; k < steps; ++k) {
+        /* SetAction (clip tracking) + 20 x Update(1/600) + RecordState / CalcReward / CheckTerminate / CheckValidEpisode / IsEpisodeEnd */
+        if (dm_step_batch(ctx, NULL, 1.0 / 600.0, 20, states, rewards, term, valid, end, DM_OPEN_LOOP) != 0) die("dm_step_batch");
+        printf("step %d", k);
+        for (int e = 0; e < n; ++e) printf(" %.9g/%d%d%d", (double)rewards[e], term[e], valid[e], end[e]);
+        double cs = 0; for (int i = 0; i < n * S; ++i) cs += (double)states[i];
+        printf(" | state_sum %.17g\n", cs);
+    }
+    if (dm_destroy(ctx) != 0) die("dm_destroy");
+    free(kin); free(lim); free(states); free(rewards); free(term); free(valid); free(end); free(keep);
+    printf("ok\n");
+    return 0;
+}

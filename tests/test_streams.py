@@ -29,8 +29,9 @@ def test_reset_phase_is_the_knuth_hash():
 
 
 def test_exponential_episode_timer(emu_lib):
-    """`--timer_type exp` (util/Timer.cpp:64-67): max time = min(time_lim_min + Exp(mean time_lim_exp), time_lim_max), drawn by reset() from the reset
-    stream; the facade's driver resets explicitly, the in-kernel auto-reset (uniform draw) refuses the type"""
+    """`--timer_type exp` (util/Timer.cpp:64-67): max time = min(time_lim_min + Exp(mean time_lim_exp), time_lim_max), drawn ON THE DEVICE from the reset
+    stream (seed, global env id, episode, stream 1) by explicit resets and -- round 4 -- by the in-kernel auto-reset of both wave packings;
+    `model.draw_time_limit` is the host mirror"""
     import pytest
     from deepmimic_amd import model, streams
     from deepmimic_amd.core import BatchEnv
@@ -45,14 +46,27 @@ def test_exponential_episode_timer(emu_lib):
         env.reset()
         mt = env.get_state()["clocks"][:, 4]
         want = [model.draw_time_limit("exp", 0.5, 3.0, 0.8, streams.reset_rand01(seed, 100 + e, int(ep[e]), 1)) for e in range(n)]
-        assert np.array_equal(mt, np.array(want))
+        assert np.abs(mt - np.array(want)).max() < 1e-12                                          # (device log1p vs numpy's: not bit-identical)
         lims.append(mt)
     lims = np.concatenate(lims)
     assert lims.min() >= 0.5 and lims.max() <= 3.0 and (lims == 3.0).mean() > 0.01              # the clipped tail: P = exp(-2.5 / 0.8) = 4.4 %
     assert abs(np.mean(np.minimum(lims, 2.9999) - 0.5) - 0.8 * (1 - np.exp(-2.5 / 0.8))) < 0.12  # mean of the truncated exponential
-    with pytest.raises(ValueError, match="timer_type exp"):
-        env.step(None, 1 / 600, 20, open_loop=True, auto_reset=True)
-    env.step(None, 1 / 600, 20, open_loop=True)                                                  # without auto-reset it steps
+    # in-kernel auto-reset: run until every env has ended at least one episode (limits <= 3 s = 90 control steps); each new episode's limit is the
+    # exponential draw of ITS episode counter, for one and two characters per wavefront
+    for packing in (1, 2):
+        e2 = BatchEnv(t, 8, precision=64, lib_path=emu_lib, seed=seed, env_id_offset=100, wave_packing=packing)
+        seen = 0
+        for k in range(100):
+            out = e2.step(None, 1 / 600, 20, open_loop=True, auto_reset=True)
+            if out["episode_end"].any():
+                st = e2.get_state()
+                for e in np.nonzero(out["episode_end"])[0]:
+                    ep_now = int(st["flags"][e, 2])                                              # the episode that has just begun
+                    want1 = model.draw_time_limit("exp", 0.5, 3.0, 0.8, streams.reset_rand01(seed, 100 + int(e), ep_now - 1, 1))
+                    assert abs(float(st["clocks"][e, 4]) - want1) < 1e-12 and float(st["clocks"][e, 3]) == 0.0, (packing, k, e)
+                    seen += 1
+        assert seen >= 8, seen
+        e2.close()
     env.set_sample_count(0, test_mode=True)                                                      # test mode pins the limit (cRLSceneSimChar::ResetTimers)
     env.reset()
     assert (env.get_state()["clocks"][:, 4] == 3.0).all()

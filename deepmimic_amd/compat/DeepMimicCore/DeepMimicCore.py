@@ -119,8 +119,7 @@ class cDeepMimicCore(object):
                               physics=int(os.environ.get("DM_PHYSICS", "1")))
         self._off = self._env.offsets_scales()
         self._apply_mode()
-        # (DM-physics v2: the ground manifolds are device state outside the snapshot the batched step rolls back to, so v2 steps update by update)
-        self._batch = os.environ.get("DM_FACADE_BATCH", "1") != "0" and self._env.physics != 2
+        self._batch = os.environ.get("DM_FACADE_BATCH", "1") != "0"      # (DM-physics v2 too since round 4: the snapshot carries the ground manifolds)
         self._period = 1.0 / float(self._tables.query_rate)
         self.stats = {"launches": 0, "updates": 0, "rollbacks": 0}     # kernel launches of the stepping path vs Update() calls
         self._build_time_warper()

@@ -445,6 +445,8 @@ class BatchEnv:
             snap["obj"] = self.get_obj_state()
         if self.has_perturbs:
             snap["pert"] = self.get_perturb_state()
+        if self.physics == 2:
+            snap["manif"] = self.get_manifolds()        # the ground manifolds are contact HISTORY: without them a restored v2 env rebuilds one point per substep
         return snap
 
     def restore(self, snap):
@@ -455,6 +457,18 @@ class BatchEnv:
             self.set_obj_state(snap["obj"])
         if "pert" in snap:
             self.set_perturb_state(snap["pert"])
+        if "manif" in snap:
+            self.set_manifolds(snap["manif"])           # after set_state, which empties them
+
+    def get_manifolds(self):
+        """DM-physics v2: N x J x 25 (count, 4 x (body-frame point, plane point x z, distance)) -- include/dm_hip.h dm_get_manifolds"""
+        m = np.zeros((self.N, self.J, 25))
+        self._chk(self.lib.dm_get_manifolds(self.h, _dp(m)))
+        return m
+
+    def set_manifolds(self, m):
+        m = np.ascontiguousarray(m, dtype=np.float64).reshape(self.N, self.J, 25)
+        self._chk(self.lib.dm_set_manifolds(self.h, _dp(m)))
 
     def set_state(self, pose=None, vel=None, tar=None, kin=None, clocks=None, flags=None):
         f = lambda a, sh: None if a is None else np.ascontiguousarray(a, dtype=np.float64).reshape(sh)

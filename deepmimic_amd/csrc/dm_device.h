@@ -1479,7 +1479,7 @@ struct EnvSim {
             mark(10);
             Real t = (b - cvec) * inv_adiag;
             const int nrm_lane = is_fric ? NL + ((l - RN) >> 1) : 0;
-            Real lo = 0, hi = is_fric ? (Real)0 : (Real)1e30;
+            Real lo = 0, hi = is_fric ? (Real)0 : ((l < NL) ? m.lim_max_impulse : (Real)1e30);      // (limit rows: maxAppliedImpulse)
             int Rv = R, RNv = RN, lv = l;
             constexpr int PFD = C::PFD;             // rows of look-ahead for the overflow block (a ring of PFD + 1 registers)
             Real pre[PFD + 1] = {};

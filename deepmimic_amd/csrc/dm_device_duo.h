@@ -570,7 +570,7 @@ _Pragma("unroll") \
             for (int r = 0; r < 32; ++r) if (hl == r) arow.set(r, (Real)0);
             Real t = (brow - cvec) * inv_adiag;
             const int nrm_lane = is_fric ? NL + ((hl - RN) >> 1) : 0;
-            Real lo = 0, hi = is_fric ? (Real)0 : (Real)1e30;
+            Real lo = 0, hi = is_fric ? (Real)0 : ((hl < NL) ? m.lim_max_impulse : (Real)1e30);      // (limit rows: maxAppliedImpulse)
             // sweep bounds of the pair: rows up to the larger R (rounded up to 4); a lane beyond its own R has t = 0, lambda = 0
             // and changes nothing.  fmask: the rows at which a character's friction bounds are refreshed from its normal impulses.
             const int Ra = lane_bcast(R, 0), Rb = lane_bcast(R, 32);

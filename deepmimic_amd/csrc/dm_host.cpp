@@ -11,6 +11,7 @@
 //
 // The same file is compiled twice: by hipcc for the product, and by g++ with -DDM_EMU (tests/emu) where
 // "device memory" is host memory and a launch runs the unmodified kernels on the fiber emulator.
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -300,6 +301,7 @@ struct CtxBase {
     virtual int get_goal(double* out) = 0; virtual int set_goal(const double* in) = 0; virtual int get_clips(int* out) = 0;
     virtual int goal_aux(double* out, const double* in) = 0; virtual void set_mode(int test) = 0; virtual int pert_state(double* out, const double* in) = 0;
     virtual int obj_state(double* out, const double* in) = 0;
+    virtual int manifolds(double* out, const double* in) = 0;
     virtual int amp_expert_clips(int n, const int* clips_dev, const double* times_dev, const double* gh_dev, float* out_dev) = 0;
     virtual int probe(int what, double dt) = 0;
     virtual int get_state(double* pose, double* vel, double* tar, double* kin, double* clk, int* flg) = 0;
@@ -416,7 +418,7 @@ struct CtxT : CtxBase {
         md.duration = h.duration; md.loop = h.loop; for (int k = 0; k < 3; ++k) { md.cycle_delta[k] = (Real)h.cycle_delta[k]; md.gravity[k] = (Real)c.gravity[k]; }
         md.num_sim_substeps = c.num_sim_substeps; md.solver_iters = c.solver_iters > 0 ? c.solver_iters : 10; md.max_contacts = max_contacts;
         md.friction = (Real)(c.friction > 0 ? c.friction : 0.9 * 0.9); md.erp = (Real)(c.erp > 0 ? c.erp : 0.2);
-        md.report_dist = (Real)0.001; md.max_lin_vel = (Real)(100.0 / c.world_scale); md.max_ang_vel = (Real)100.0;
+        md.report_dist = (Real)0.001; md.max_lin_vel = (Real)(100.0 / c.world_scale); md.max_ang_vel = (Real)100.0; md.lim_max_impulse = (Real)(100.0 / (c.world_scale * c.world_scale));
         md.slerp_one = (sizeof(Real) == 8) ? (Real)(1.0 - std::numeric_limits<double>::epsilon()) : (Real)(1.0 - 1e-6);
         md.sync_root_pos = c.sync_char_root_pos; md.sync_root_rot = c.sync_char_root_rot; md.enable_fall_end = c.enable_fall_end;
         md.enable_contact_fall = c.enable_char_contact_fall; md.enable_root_rot_fail = c.enable_root_rot_fail; md.enable_rand_placement = c.enable_rand_char_placement;
@@ -613,6 +615,21 @@ struct CtxT : CtxBase {
         const size_t bytes = sizeof(double) * (size_t)N * PT_WIDTH;
         if (out && rt_d2h(out, st.pert, bytes, stream) != 0) return fail("device to host copy failed");
         if (in && rt_h2d(st.pert, in, bytes, stream) != 0) return fail("host to device copy failed");
+        return 0;
+    }
+    int manifolds(double* out, const double* in) override {           // N x J x 25: count, 4 x (body-frame point (3), plane point x z, distance)
+        if (!st.manif) return fail("no manifold state: the ctx does not run DM-physics v2");
+        const size_t n = (size_t)N * hm.J;
+        std::vector<Real> buf(n * MF_STRIDE);
+        if (out) {
+            if (rt_d2h(buf.data(), st.manif, sizeof(Real) * buf.size(), stream) != 0) return fail("device to host copy failed");
+            for (size_t i = 0; i < n; ++i) for (int k = 0; k < 25; ++k) out[i * 25 + k] = (double)buf[i * MF_STRIDE + k];
+        }
+        if (in) {
+            std::fill(buf.begin(), buf.end(), (Real)0);
+            for (size_t i = 0; i < n; ++i) for (int k = 0; k < 25; ++k) buf[i * MF_STRIDE + k] = (Real)in[i * 25 + k];
+            if (rt_h2d(st.manif, buf.data(), sizeof(Real) * buf.size(), stream) != 0) return fail("host to device copy failed");
+        }
         return 0;
     }
     int get_clips(int* out) override {
@@ -1003,6 +1020,8 @@ int dm_get_perturb_state(dm_ctx* ctx, double* out) { if (!ctx || !out) return fa
 int dm_set_perturb_state(dm_ctx* ctx, const double* in) { if (!ctx || !in) return fail("null argument"); DevGuard guard(ctx->c->device_id); return ctx->c->pert_state(nullptr, in); }
 int dm_get_obj_state(dm_ctx* ctx, double* out) { if (!ctx || !out) return fail("null argument"); DevGuard guard(ctx->c->device_id); return ctx->c->obj_state(out, nullptr); }
 int dm_set_obj_state(dm_ctx* ctx, const double* in) { if (!ctx || !in) return fail("null argument"); DevGuard guard(ctx->c->device_id); return ctx->c->obj_state(nullptr, in); }
+int dm_get_manifolds(dm_ctx* ctx, double* out) { if (!ctx || !out) return fail("null argument"); DevGuard guard(ctx->c->device_id); return ctx->c->manifolds(out, nullptr); }
+int dm_set_manifolds(dm_ctx* ctx, const double* in) { if (!ctx || !in) return fail("null argument"); DevGuard guard(ctx->c->device_id); return ctx->c->manifolds(nullptr, in); }
 int dm_set_mode(dm_ctx* ctx, int test_mode) { if (!ctx) return fail("null ctx"); ctx->c->set_mode(test_mode); return 0; }
 int dm_get_clips(dm_ctx* ctx, int32_t* out) { if (!ctx || !out) return fail("null argument"); DevGuard guard(ctx->c->device_id); return ctx->c->get_clips(out); }
 

@@ -186,6 +186,7 @@ struct ModelDev {
     Real gravity[3];
     int num_sim_substeps, solver_iters, max_contacts;
     Real friction, erp, report_dist, max_lin_vel, max_ang_vel, slerp_one;
+    Real lim_max_impulse;                    // upper bound of a joint-limit row's impulse: btMultiBodyConstraint::m_maxAppliedImpulse 100 in the scaled world = 100 / world_scale^2
     int sync_root_pos, sync_root_rot, enable_fall_end, enable_contact_fall, enable_root_rot_fail, enable_rand_placement;
     int enable_phase_input, record_world_root_pos, record_world_root_rot;
     double query_period;                     // 1 / QueryRate

@@ -216,6 +216,12 @@ int dm_set_mode(dm_ctx* ctx, int test_mode);
  * (cSimObj::GetPos / GetRotation / GetLinearVelocity / GetAngularVelocity of the target object) */
 int dm_get_obj_state(dm_ctx* ctx, double* out);
 int dm_set_obj_state(dm_ctx* ctx, const double* in);
+/* DM-physics v2 (dm_create_info.physics = 2): the persistent link-vs-ground manifolds, N x J x 25 doubles per link = {point count (0..4),
+ * 4 x (the point on the link in body coordinates (3), the point on the plane x, z, distance)} -- device state that dm_get_state / dm_set_state do
+ * not carry (dm_set_state(pose) EMPTIES them, as a fresh pose has no contact history).  A checkpoint or a rollback under v2 is
+ * dm_get_state + dm_get_manifolds / dm_set_state THEN dm_set_manifolds.  Error when the ctx runs v1. */
+int dm_get_manifolds(dm_ctx* ctx, double* out);
+int dm_set_manifolds(dm_ctx* ctx, const double* in);
 /* clip each env's kinematic character was reset to (multi-clip datasets), N int32 */
 int dm_get_clips(dm_ctx* ctx, int32_t* out);
 

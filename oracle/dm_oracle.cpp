@@ -130,6 +130,28 @@ void orc_get_sim_state(void* h, double* pose, double* vel) { Scene* s = (Scene*)
 void orc_set_sim_state(void* h, const double* pose, const double* vel) {
     Scene* s = (Scene*)h; s->set_sim_state(copy_in(pose, s->sk.P), copy_in(vel, s->sk.P));
 }
+// physics 2: the persistent ground manifolds, J x 25 = {count, 4 x (lp (3), bx, bz, dist)} -- the layout of the product's dm_get_manifolds
+void orc_get_manifolds(void* h, double* out) {
+    Scene* s = (Scene*)h;
+    for (int j = 0; j < s->sk.J; ++j) {
+        double* o = out + (size_t)j * 25; for (int k = 0; k < 25; ++k) o[k] = 0;
+        if (j >= (int)s->manifolds.size()) continue;
+        const auto& mf = s->manifolds[j];
+        o[0] = (double)mf.size();
+        for (size_t i = 0; i < mf.size() && i < 4; ++i) { o[1 + 6 * i] = mf[i].lp.x; o[2 + 6 * i] = mf[i].lp.y; o[3 + 6 * i] = mf[i].lp.z; o[4 + 6 * i] = mf[i].bx; o[5 + 6 * i] = mf[i].bz; o[6 + 6 * i] = mf[i].dist; }
+    }
+}
+void orc_set_manifolds(void* h, const double* in) {
+    Scene* s = (Scene*)h;
+    s->manifolds.assign(s->sk.J, std::vector<Scene::ManifoldPt>());
+    for (int j = 0; j < s->sk.J; ++j) {
+        const double* o = in + (size_t)j * 25;
+        for (int i = 0; i < (int)o[0] && i < 4; ++i) {
+            Scene::ManifoldPt p; p.lp.x = (real)o[1 + 6 * i]; p.lp.y = (real)o[2 + 6 * i]; p.lp.z = (real)o[3 + 6 * i]; p.bx = (real)o[4 + 6 * i]; p.bz = (real)o[5 + 6 * i]; p.dist = (real)o[6 + 6 * i];
+            s->manifolds[j].push_back(p);
+        }
+    }
+}
 void orc_get_kin_state(void* h, double* pose, double* vel, double* origin /*3+4*/) {
     Scene* s = (Scene*)h; copy_out(s->kin.pose, pose); copy_out(s->kin.vel, vel);
     origin[0] = s->kin.origin.x; origin[1] = s->kin.origin.y; origin[2] = s->kin.origin.z;

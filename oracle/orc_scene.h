@@ -584,7 +584,9 @@ struct Scene {
             real pen_lo = th - lo, pen_hi = hi - th;
             for (int side = 0; side < 2; ++side) {
                 if (cfg.physics != 2 && side != ((pen_lo <= pen_hi) ? 0 : 1)) continue;
-                Row r; r.J.assign(P, 0); r.normal_row = -1; r.mu = 0; r.lo = 0; r.hi = big; r.lam = 0;
+                // btMultiBodyConstraint::m_maxAppliedImpulse = 100 [EXT-BULLET, recalled; SURVEY App. C item 4]: an angular impulse in the scaled world's
+                // units (lengths x world_scale, masses as they are) = 100 / world_scale^2 here
+                Row r; r.J.assign(P, 0); r.normal_row = -1; r.mu = 0; r.lo = 0; r.hi = (real)(100.0 / (cfg.world_scale * cfg.world_scale)); r.lam = 0;
                 const real pen = side ? pen_hi : pen_lo;
                 r.J[off] = side ? (real)-1 : (real)1;
                 r.b = (pen > 0) ? -pen / h : (real)-cfg.erp * pen / h;

@@ -192,6 +192,16 @@ class Oracle:
         v = np.ascontiguousarray(v, dtype=np.float64)
         self.lib.orc_set_sim_state(self.h, _d(p), _d(v))
 
+    def manifolds(self):
+        """physics 2: the persistent ground manifolds, J x 25 (the layout of BatchEnv.get_manifolds)"""
+        m = np.zeros((self.J, 25))
+        self.lib.orc_get_manifolds(self.h, _d(m))
+        return m
+
+    def set_manifolds(self, m):
+        m = np.ascontiguousarray(m, dtype=np.float64).reshape(self.J, 25)
+        self.lib.orc_set_manifolds(self.h, _d(m))
+
     def kin_state(self):
         p, v, o = np.zeros(self.P), np.zeros(self.P), np.zeros(7)
         self.lib.orc_get_kin_state(self.h, _d(p), _d(v), _d(o))

@@ -78,7 +78,7 @@ def test_facade_protocol_physics_v2_emulator(emu_lib, monkeypatch):
     t = model.load_asset("humanoid3d_walk")
     core = mod.cDeepMimicCore(False)
     core.SeedRand(5); core.LoadTables(t, num_update_substeps=10); core.Init()
-    assert core._env.physics == 2 and not core._batch
+    assert core._env.physics == 2 and core._batch          # (batched since round 4: the rollback snapshot carries the manifolds)
     kin_t = float(core._env.get_state()["clocks"][0][0])
     o = Oracle(t, physics=2, max_contacts=core._env.max_contacts); o.reset(kin_t)
     assert _run_protocol(core, o, 41, np.random.default_rng(0)) == 3
@@ -204,13 +204,15 @@ def _same(a, b):
             assert np.array_equal(x[1], y[1]) and x[2] == y[2]
 
 
-def test_batched_control_step_equals_update_by_update(emu_lib, monkeypatch):
-    """DM_FACADE_BATCH: one launch per control step (+ rollback / replay when a caller looks inside the step) gives bit-identical
+@pytest.mark.parametrize("physics", ["1", "2"])
+def test_batched_control_step_equals_update_by_update(emu_lib, monkeypatch, physics):
+    """(physics 2 since round 4: the rollback snapshot carries the ground manifolds, dm_get_manifolds.)
+    DM_FACADE_BATCH: one launch per control step (+ rollback / replay when a caller looks inside the step) gives bit-identical
     observations, rewards, flags and clock to one launch per update; the open-loop-ish random actions make the walker fall, so the
     early episode end and the reset path are exercised too."""
     from deepmimic_amd import model
     mod = _core_module()
-    monkeypatch.setenv("DM_HIP_LIB", emu_lib); monkeypatch.setenv("DM_PRECISION", "64")
+    monkeypatch.setenv("DM_HIP_LIB", emu_lib); monkeypatch.setenv("DM_PRECISION", "64"); monkeypatch.setenv("DM_PHYSICS", physics)
     t = model.load_asset("humanoid3d_walk")
     t.cfg.time_lim_min = t.cfg.time_lim_max = t.cfg.time_end_lim_min = t.cfg.time_end_lim_max = 0.175   # the episode timer ends inside a control step (update 105; 20 per step)
     runs = {}

@@ -248,7 +248,7 @@ def main():
     ap.add_argument("--scene", default="humanoid3d_walk")
     ap.add_argument("--precision", type=int, default=32)
     ap.add_argument("--wave-packing", type=int, default=0, help="characters per wavefront of the step kernel: 0 = the library's default (2 for the biped class, 1 for the dog and for dribble_amp), 1 or 2")
-    ap.add_argument("--physics", type=int, default=1, choices=[1, 2], help="contact model: 1 = DM-physics v1 (default, the headline), 2 = v2 (DESIGN.md 4.6; one character per wavefront)")
+    ap.add_argument("--physics", type=int, default=1, choices=[1, 2], help="contact model: 1 = DM-physics v1 (default, the headline), 2 = v2 (DESIGN.md 4.6; two characters per wavefront too since round 4)")
     ap.add_argument("--groups", type=int, default=0,
                     help="env groups per GPU: the rank's envs as G independent contexts on their own HIP streams (deepmimic_amd/groups.py; "
                          "0 = auto (2 for the two-per-wave biped kernel, +5..7 %%: the half-batches drift apart in phase and fill each other's wave-time tail; 1 otherwise); 1 = one launch per control step")
@@ -318,11 +318,11 @@ def main():
     gather = (world > 1 or args.force_gather) and not args.no_gather
     # --groups 0 (default): two groups where a launch is one round of waves (the two-per-wave biped kernel at <= 4096 envs: 2048 waves on 2048
     # wave slots), one launch per step otherwise (the dog's 4096 one-per-wave launches are two rounds already: groups measured -4 %)
-    duo_kernel = args.wave_packing != 1 and args.physics == 1 and tables.joint_mat.shape[0] <= 15 and tables.goal_kind != 5 and n % 2 == 0
+    duo_kernel = args.wave_packing != 1 and tables.joint_mat.shape[0] <= 15 and tables.goal_kind != 5 and n % 2 == 0
     auto_groups = 2 if (duo_kernel and n <= 4096) else 1
     want_groups = 1 if (args.gather == "cabi" and gather) else (auto_groups if args.groups <= 0 else args.groups)      # (the C-ABI exchange orders one ctx stream against the comm stream)
     envs = EnvGroups(tables, n, groups=want_groups, device_id=local_rank if on_gpu else 0, seed=1234, precision=args.precision, env_id_offset=rank * n,
-                     test_mode=True, wave_packing=1 if args.physics == 2 else args.wave_packing, physics=args.physics)
+                     test_mode=True, wave_packing=args.wave_packing, physics=args.physics)
     G = envs.G
     env = envs.envs[0]
     main_stream = torch.cuda.current_stream() if on_gpu else None
@@ -445,7 +445,7 @@ def main():
             raise SystemExit("bench.py: ran %d rank(s) with %d per-rank rate(s) under --gpus %d" % (world, len(per_rank), args.gpus))
         envs_per_launch = n // G
         bytes_per_launch = algorithmic_bytes_per_env_step(env) * envs_per_launch
-        kname = "k_env_step_duo" if (args.wave_packing != 1 and args.physics == 1 and env.J <= 15 and env.D == 34 and envs_per_launch % 2 == 0 and tables.goal_kind != 5) else "k_env_step"
+        kname = "k_env_step_duo" if (args.wave_packing != 1 and env.J <= 15 and env.D == 34 and envs_per_launch % 2 == 0 and tables.goal_kind != 5) else "k_env_step"
         achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else None      # (the emulator has no HIP events)
         # committed counter passes are taken with --groups 1 (a PMC pass serialises the kernels: a half-batch launch alone on the chip would be
         # another regime); HBM bytes are per env, so the per-launch figure of a group is the whole-batch one scaled by its share of the envs

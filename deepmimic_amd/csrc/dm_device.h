@@ -1153,13 +1153,16 @@ struct EnvSim {
     // PLAIN: the tap-free imitate instantiation without perturbations / manifolds; a class may give it a wider row file (C::RREG_PLAIN:
     // the registers the AMP / v2 code needs elsewhere are free there)
     template <bool V2 = false, bool PLAIN = false>
-    DM_DEV void substep_post(Real h, DebugTaps<Real> dbg, int e, Real* aovf, Real* manif = nullptr) {
+    // nc_ground_in >= 0 (V2, the fallback of the two-per-wave kernel): the caller has already updated the manifolds of this substep and stored the ground
+    // contact slots in s.ct -- a second refresh would not be idempotent
+    DM_DEV void substep_post(Real h, DebugTaps<Real> dbg, int e, Real* aovf, Real* manif = nullptr, int nc_ground_in = -1) {
         constexpr int RREG = PLAIN ? C::RREG_PLAIN : C::RREG;
         static_assert(RREG >= C::RREG, "the overflow block is sized for C::RREG");
         const int D = m.D, J = m.J;
         Real vstar = 0; int vidx = 0;
         if (l < D) { vidx = DM_DI_VIDX(s.mdl.dof_info[l]); vstar = clamp_vel(s.vel[vidx] + h * s.rhs[l], l); s.dofrec[l][6] = vstar; }
-        if (l == 0) s.flg[FLG_CONTACT] = 0;
+        const bool ground_done = V2 && nc_ground_in >= 0;
+        if (l == 0 && !ground_done) s.flg[FLG_CONTACT] = 0;
         sync();
         if (TAPS && dbg.vstar && l < D) dbg.vstar[(size_t)e * D + l] = vstar;
         mark(7);
@@ -1174,7 +1177,8 @@ struct EnvSim {
         // ---- collision detection
         const bool phys2 = V2 && manif != nullptr;
         int nc_ground = 0;
-        if (phys2) nc_ground = ground_manifolds(manif);
+        if (ground_done) nc_ground = nc_ground_in;
+        else if (phys2) nc_ground = ground_manifolds(manif);
         else {
         // ---- collision detection: lane = candidate point (CPL candidates per lane when NC > 64)
         bool active[CPL]; Real dist[CPL]; v3 cxp[CPL]; uint64_t amask[CPL];

@@ -413,17 +413,113 @@ _Pragma("unroll") \
 
     DM_DEV Real clamp_vel(Real v, int dof) const { return b.clamp_vel(v, dof); }
 
+    // ------------------------------------------------------------------ DM-physics v2, two characters per wavefront (round 4)
+    // EnvSim::ground_manifolds with lane = link of the own half-wave: the persistent link-vs-ground manifold of each link (EnvState::manif) is
+    // refreshed, given its one new support point, written back, and its points become the ground contact slots in (link, slot) order.  Ballots are
+    // taken per half; the (rare) cap at max_contacts runs for both characters when either needs it (a no-op for the one that does not).
+    DM_DEV int ground_manifolds(Real* manif) {
+        const int J = m.J;
+        int cnt = 0; Real lp[4][3], bxz[4][2], dist[4];
+        Real* mfp = manif + (hl < J ? hl : 0) * MF_STRIDE;
+        const bool has_body = hl < J && s.mdl.thresh[hl < J ? hl : 0] > (Real)0;
+#pragma unroll
+        for (int q = 0; q < CP; ++q) {
+            const int c = hl + HW * q;
+            if (c < m.NC) {
+                const int link = cand_link[q];
+                v3 x = ld3(s.com[link]) + ldm3(b.Rbp(link)) * mk3(cand_loc[q][0], cand_loc[q][1], cand_loc[q][2]);
+                s.cdistc[c] = x.y - cand_rad[q];
+            }
+        }
+        sync();
+        if (has_body) {
+            const Real thr = s.mdl.thresh[hl];
+            const v3 com = ld3(s.com[hl]); const m3 Rb = ldm3(b.Rbp(hl));
+            cnt = (int)mfp[0];
+            for (int i = 0; i < 4; ++i) { for (int k = 0; k < 3; ++k) lp[i][k] = mfp[1 + i * MF_PT + k]; bxz[i][0] = mfp[1 + i * MF_PT + 3]; bxz[i][1] = mfp[1 + i * MF_PT + 4]; dist[i] = mfp[1 + i * MF_PT + 5]; }
+            for (int i = cnt - 1; i >= 0; --i) {         // refreshContactPoints, last to first
+                const v3 xa = com + Rb * mk3(lp[i][0], lp[i][1], lp[i][2]);
+                dist[i] = xa.y;
+                const Real dx = bxz[i][0] - xa.x, dz = bxz[i][1] - xa.z;
+                if (!(dist[i] <= thr) || dx * dx + dz * dz > thr * thr) {
+                    for (int k = i; k + 1 < cnt; ++k) { for (int a = 0; a < 3; ++a) lp[k][a] = lp[k + 1][a]; bxz[k][0] = bxz[k + 1][0]; bxz[k][1] = bxz[k + 1][1]; dist[k] = dist[k + 1]; }
+                    --cnt;
+                }
+            }
+            int best = -1; Real bd = 0;                 // the new point: the deepest candidate of this link, first on ties
+            for (int c = 0; c < m.NC; ++c) if (m.cand_link[c] == hl) { const Real d = s.cdistc[c]; if (best < 0 || d < bd) { best = c; bd = d; } }
+            if (best >= 0 && bd < thr) {
+                v3 x = com + Rb * mk3(m.cand_loc[best * 3], m.cand_loc[best * 3 + 1], m.cand_loc[best * 3 + 2]);
+                x.y -= m.cand_rad[best];
+                const v3 d0 = x - com;
+                const v3 nl = mk3(Rb.m[0] * d0.x + Rb.m[3] * d0.y + Rb.m[6] * d0.z, Rb.m[1] * d0.x + Rb.m[4] * d0.y + Rb.m[7] * d0.z, Rb.m[2] * d0.x + Rb.m[5] * d0.y + Rb.m[8] * d0.z);
+                int slot = -1; Real shortest = thr * thr;
+                for (int i = 0; i < cnt; ++i) { const Real ex = lp[i][0] - nl.x, ey = lp[i][1] - nl.y, ez = lp[i][2] - nl.z, d2 = ex * ex + ey * ey + ez * ez; if (d2 < shortest) { shortest = d2; slot = i; } }
+                if (slot < 0) {
+                    if (cnt < 4) slot = cnt++;
+                    else {                              // sortCachedPoints: never the deepest; of the others the one that leaves the largest quadrilateral
+                        int deepest = -1; Real maxpen = x.y;
+                        for (int i = 0; i < 4; ++i) if (dist[i] < maxpen) { deepest = i; maxpen = dist[i]; }
+                        Real res[4] = { 0, 0, 0, 0 };
+                        const v3 p0 = mk3(lp[0][0], lp[0][1], lp[0][2]), p1 = mk3(lp[1][0], lp[1][1], lp[1][2]), p2 = mk3(lp[2][0], lp[2][1], lp[2][2]), p3 = mk3(lp[3][0], lp[3][1], lp[3][2]);
+                        if (deepest != 0) { const v3 c = cross(nl - p1, p3 - p2); res[0] = dot(c, c); }
+                        if (deepest != 1) { const v3 c = cross(nl - p0, p3 - p2); res[1] = dot(c, c); }
+                        if (deepest != 2) { const v3 c = cross(nl - p0, p3 - p1); res[2] = dot(c, c); }
+                        if (deepest != 3) { const v3 c = cross(nl - p0, p2 - p1); res[3] = dot(c, c); }
+                        slot = 0;
+                        for (int i = 1; i < 4; ++i) if (res[i] > res[slot]) slot = i;
+                    }
+                }
+                lp[slot][0] = nl.x; lp[slot][1] = nl.y; lp[slot][2] = nl.z; bxz[slot][0] = x.x; bxz[slot][1] = x.z; dist[slot] = x.y;
+            }
+            mfp[0] = (Real)cnt;
+            for (int i = 0; i < 4; ++i) { for (int k = 0; k < 3; ++k) mfp[1 + i * MF_PT + k] = lp[i][k]; mfp[1 + i * MF_PT + 3] = bxz[i][0]; mfp[1 + i * MF_PT + 4] = bxz[i][1]; mfp[1 + i * MF_PT + 5] = dist[i]; }
+            for (int i = 0; i < cnt; ++i) if (dist[i] <= m.report_dist) dm_atomic_or(&s.flg[FLG_CONTACT], 1 << hl);
+        }
+        sync();
+        bool keep[4];
+        for (int i = 0; i < 4; ++i) keep[i] = i < cnt;
+        int total = 0; uint32_t km[4];
+        for (int i = 0; i < 4; ++i) { km[i] = (uint32_t)(wave_ballot(keep[i]) >> (half * 32)); total += dm_popc64(km[i]); }
+        if (wave_ballot(total > m.max_contacts) != 0) {
+            for (int i = 0; i < 4; ++i) if (hl < J) { s.csel[hl * 4 + i] = keep[i] ? 1 : 0; s.cdistc[hl * 4 + i] = dist[i]; }
+            sync();
+            for (int i = 0; i < 4; ++i) {
+                int rank = 0;
+                if (keep[i]) for (int k = 0; k < 4 * J; ++k) if (s.csel[k] && (s.cdistc[k] < dist[i] || (s.cdistc[k] == dist[i] && k < hl * 4 + i))) ++rank;
+                keep[i] = keep[i] && rank < m.max_contacts;
+            }
+            sync();
+            total = 0;
+            for (int i = 0; i < 4; ++i) { km[i] = (uint32_t)(wave_ballot(keep[i]) >> (half * 32)); total += dm_popc64(km[i]); }
+        }
+        const uint32_t ltm = (hl == 0) ? 0u : (~0u >> (32 - hl));
+        int base = 0;
+        for (int i = 0; i < 4; ++i) base += dm_popc64(km[i] & ltm);
+        if (hl < J) {
+            const v3 com = ld3(s.com[hl]); const m3 Rb = ldm3(b.Rbp(hl));
+            int k = 0;
+            for (int i = 0; i < 4; ++i) if (keep[i]) { b.store_contact(base + k, com + Rb * mk3(lp[i][0], lp[i][1], lp[i][2]), mk3((Real)0, (Real)1, (Real)0), dist[i], hl, 255); ++k; }
+        }
+        return total;
+    }
+
     // ------------------------------------------------------------------ rigid-body substep, constraint part
-    // returns false (having done nothing that matters) when either character needs more than 32 constraint rows
-    DM_DEV bool substep_post(Real h) {
+    // returns false (having done nothing that matters -- under V2: the manifolds are updated and the ground slots stored, FLG_NCONT tells the
+    // one-per-wave routine how many) when either character needs more than 32 constraint rows
+    template <bool V2 = false>
+    DM_DEV bool substep_post(Real h, Real* manif = nullptr) {
         const int D = m.D;
         for (int k = hl; k < D; k += HW) { const int vidx = DM_DI_VIDX(s.mdl.dof_info[k]); s.dofrec[k][6] = clamp_vel(s.vel[vidx] + h * s.rhs[k], k); }
         if (hl == 0) s.flg[FLG_CONTACT] = 0;
         sync();
         b.mark(7);
+        int nact = 0;
+        const uint32_t lt = (hl == 0) ? 0u : (~0u >> (32 - hl));
+        if (V2) { nact = ground_manifolds(manif); if (hl == 0) s.flg[FLG_NCONT] = nact; }
+        else {
         // ---- collision: lane = candidate, two passes
         bool active[CP]; Real dist[CP]; v3 cxp[CP]; uint32_t amask[CP];
-        int nact = 0;
 #pragma unroll
         for (int q = 0; q < CP; ++q) {
             const int c = hl + HW * q;
@@ -455,7 +551,6 @@ _Pragma("unroll") \
 #pragma unroll
             for (int q = 0; q < CP; ++q) { amask[q] = (uint32_t)(wave_ballot(active[q]) >> (half * 32)); nact += dm_popc64(amask[q]); }
         }
-        const uint32_t lt = (hl == 0) ? 0u : (~0u >> (32 - hl));
         {   // ground contacts -> slots, in candidate-index order
             int base = 0;
 #pragma unroll
@@ -464,7 +559,8 @@ _Pragma("unroll") \
                 base += dm_popc64(amask[q]);
             }
         }
-        int nc = nact;
+        }
+        int nc = V2 ? half_bcast(nact, 0, half) : nact;          // (uniform per character by construction; under V2 the broadcast tells the compiler)
         // ---- self collision: lane = link pair (three passes of 32); active pairs take the slots the ground left, in pair order
         const int npair_passes = (m.NPAIR + HW - 1) / HW;
 #pragma unroll
@@ -484,7 +580,7 @@ _Pragma("unroll") \
         }
         const int NL = m.NL;
         const int R = NL + 3 * nc;
-        if (wave_ballot(R > HW) != 0) return false;      // a heavily contacted character: the caller runs the one-per-wave routine
+        if (wave_ballot(R > HW) != 0) { if (V2) sync(); return false; }      // a heavily contacted character: the caller runs the one-per-wave routine (V2: FLG_NCONT is published)
         if (hl == 0) { s.flg[FLG_NROWS] = R; s.flg[FLG_NCONT] = nc; }
         sync();
         b.mark(8);
@@ -493,11 +589,12 @@ _Pragma("unroll") \
         uint32_t ch_lo = 0, ch_hi = 0, ng_lo = 0, ng_hi = 0; v3 xd = zero3(), dd = zero3();
         if (hl < R) {
             if (hl < NL) {
-                int j = s.mdl.lim_joint[hl]; int lj = s.mdl.link_info[j]; int off = DM_LI_POFF(lj);
+                const int lr = V2 ? (hl >> 1) : hl;         // v2: both rows of a limit (q - lo, then hi - q), v1: the nearer bound
+                int j = s.mdl.lim_joint[lr]; int lj = s.mdl.link_info[j]; int off = DM_LI_POFF(lj);
                 const int limdof = DM_LI_DOFF(lj);
-                Real th = s.pose[off], pen_lo = th - s.mdl.lim_lo[hl], pen_hi = s.mdl.lim_hi[hl] - th;
+                Real th = s.pose[off], pen_lo = th - s.mdl.lim_lo[lr], pen_hi = s.mdl.lim_hi[lr] - th;
                 Real pen, sgn;
-                if (pen_lo <= pen_hi) { sgn = 1; pen = pen_lo; } else { sgn = -1; pen = pen_hi; }
+                if (V2 ? !(hl & 1) : (pen_lo <= pen_hi)) { sgn = 1; pen = pen_lo; } else { sgn = -1; pen = pen_hi; }
                 brow = (pen > 0) ? -pen / h : -m.erp * pen / h;
                 xd = sgn * ld3(&s.dofrec[limdof][0]);
                 if (limdof < 32) ch_lo = 1u << limdof; else ch_hi = 1u << (limdof - 32);
@@ -651,8 +748,8 @@ _Pragma("unroll") \
     }
 
     // ------------------------------------------------------------------ one scene update for both characters
-    template <bool PERT = false>
-    DM_DEV void update(double dt, int e, Real* aovf_pair, double* pert = nullptr, bool kin_done = false) {
+    template <bool PERT = false, bool V2 = false>
+    DM_DEV void update(double dt, int e, Real* aovf_pair, double* pert = nullptr, bool kin_done = false, Real* manif_pair = nullptr) {
         if (hl == 0) { s.clk[CLK_TIMER] += dt; s.clk[CLK_CTRL] += dt; s.flg[FLG_NEED_ACTION] = 0; }
         if (PERT && pert) { if (hl == 0 && s.flg[FLG_PARKED] == 0) b.pert_tick(pert, e, dt); sync(); }      // enable_rand_perturbs (a parked character's row rests)
         b.kin_update(dt);
@@ -695,7 +792,7 @@ _Pragma("unroll") \
                 for (int k = hl; k < D; k += HW) s.tau[k] = (k < 6) ? (Real)0 : b.xs()[k] - s.mdl.kd[DM_DI_JOINT(s.mdl.dof_info[k])] * rdt * s.rhs[k];
                 sync();
                 b.spd_clamp();
-            } else if (!substep_post(h)) {
+            } else if (!substep_post<V2>(h, V2 ? manif_pair + (size_t)half * m.J * MF_STRIDE : nullptr)) {
                 // more than 32 rows somewhere in the pair: one character at a time through the 64-lane routine
                 for (int x = 0; x < 2; ++x) {
                     int wlv = wl; DM_OPAQUE_V(wlv);          // keeps this rare path's address arithmetic out of the hot loop's live ranges
@@ -703,7 +800,9 @@ _Pragma("unroll") \
                     one.li = (wlv < m.J) ? rec[x].mdl.link_info[wlv] : 0;
                     one.load_cands();
                     DebugTaps<Real> none = DebugTaps<Real>();
-                    one.substep_post(h, none, e, (FallbackCls::RREG < kMaxRows && aovf_pair) ? aovf_pair + (size_t)x * (kMaxRows - FallbackCls::RREG) * kWave : nullptr);
+                    // (V2: the two-per-wave pass above has already refreshed this character's manifolds and stored its ground slots -- the 64-lane routine takes them as they are)
+                    one.template substep_post<V2, false>(h, none, e, (FallbackCls::RREG < kMaxRows && aovf_pair) ? aovf_pair + (size_t)x * (kMaxRows - FallbackCls::RREG) * kWave : nullptr,
+                                                         V2 ? manif_pair + (size_t)x * m.J * MF_STRIDE : nullptr, V2 ? rec[x].flg[FLG_NCONT] : -1);
                 }
             }
         }
@@ -722,9 +821,10 @@ _Pragma("unroll") \
 // grid = N / 2 workgroups of one wavefront; character e = 2 * blockIdx.x + (lane >> 5).  fp32: 2 waves / SIMD (20 KB LDS).
 template <typename Real> struct DuoWaves { static constexpr int value = 1; };
 template <> struct DuoWaves<float> { static constexpr int value = 2; };
-template <typename Real, bool TAPS, bool AMP = false>
+template <typename Real, bool TAPS, bool AMP = false, bool V2 = false>
 __global__ void __launch_bounds__(64) DM_WAVES_PER_EU((DuoWaves<Real>::value)) k_env_step_duo(ModelDev<Real> m, EnvState<Real> st, StepIO<Real> io, DebugTaps<Real> dbg) {
     constexpr bool HIST = TAPS || AMP;
+    static_assert(!V2 || AMP, "the v2 instantiation carries the AMP code like k_env_step's");
     __shared__ Lds<Real, ClsBiped> lds[2];
     __shared__ ParkSnap<Real, ClsBiped> snap[2];     // 2 x 0.45 KB: the fp32 kernel stays inside 20 KB per wave (8 waves per CU)
     const int wl = threadIdx.x, half = wl >> 5;
@@ -736,6 +836,7 @@ __global__ void __launch_bounds__(64) DM_WAVES_PER_EU((DuoWaves<Real>::value)) k
     else if (io.actions) sim.b.set_action(io.actions + (size_t)e * m.A);
     sim.b.mark(15);
     Real* aovf_pair = st.aovf ? st.aovf + (size_t)(2 * blockIdx.x) * (kMaxRows - ClsBiped::RREG) * kWave : nullptr;
+    Real* manif_pair = (V2 && st.manif) ? st.manif + (size_t)(2 * blockIdx.x) * m.J * MF_STRIDE : nullptr;      // physics 2: the two characters' ground manifolds
     const bool goal = HIST && st.goal && m.scene_goal;
     double* pert = (HIST && st.pert) ? st.pert + (size_t)e * PT_WIDTH : nullptr;
     if (goal) sim.b.goal_sync_flags(st, e);
@@ -759,7 +860,7 @@ __global__ void __launch_bounds__(64) DM_WAVES_PER_EU((DuoWaves<Real>::value)) k
         }
         if (HIST && st.hist) sim.b.latch_hist(st, eo, lds[half].flg[FLG_PARKED] == 0);
         if (goal) sim.b.goal_latch(st, eo, io.dt, lds[half].flg[FLG_PARKED] == 0);
-        sim.template update<HIST>(io.dt, eo, aovf_pair, po, true);
+        sim.template update<HIST, V2>(io.dt, eo, aovf_pair, po, true, V2 ? manif_pair : nullptr);
         if (goal) sim.b.goal_update(st, eo, io.dt, lds[half].flg[FLG_PARKED] == 0);      // the update that ends an episode includes its goal update
         if (io.end_early) {
             // DM_END_EPISODE_EARLY.  FLG_OVER is latched by each character's lane 0 at the end of update() (wave-uniform reads).
@@ -788,6 +889,7 @@ __global__ void __launch_bounds__(64) DM_WAVES_PER_EU((DuoWaves<Real>::value)) k
             else {
                 double kt = m.duration * dm_rand01(m.seed, (uint64_t)(e + m.env_off), ep, 0);
                 sim.b.reset_env(kt, mt);
+                if (V2) sim.b.manif_clear(st, e);
                 if (HIST && st.hist) sim.b.init_hist(st, e);
             }
             if (HIST && pert && !rec && (wl & 31) == 0) sim.b.pert_reset(pert, e);

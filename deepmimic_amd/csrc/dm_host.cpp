@@ -542,8 +542,9 @@ struct CtxT : CtxBase {
         io.actions = actions_dev; io.states = states; io.rewards = rewards; io.terminate = term; io.valid = valid; io.episode_end = end;
         io.n_updates = n_updates; io.dt = dt; io.auto_reset = (flags & DM_AUTO_RESET) ? 1 : 0; io.emit = (flags & DM_NO_EMIT) ? 0 : 1; io.open_loop = (flags & DM_OPEN_LOOP) ? 1 : 0; io.end_early = (flags & DM_END_EPISODE_EARLY) ? 1 : 0;
         // two characters per wavefront: biped class, even batch, no debug taps armed (DM_DUO=0 keeps one character per wave)
-        if (duo && cls == 0 && hm.D == ClsBiped::ND && (N % 2) == 0 && !dbg.H && !st.manif) {      // (31 row lanes per character assume exactly 34 dofs; physics 2 runs one per wave)
-            if (st.hist || st.pert || md.enable_root_rot_fail || md.timer_exp > 0) launch_step_duo<Real, SV_AMP>(N / 2, stream, md, st, io, dbg);      // (the AMP instantiation also carries the perturbation code)
+        if (duo && cls == 0 && hm.D == ClsBiped::ND && (N % 2) == 0 && !dbg.H) {      // (31 row lanes per character assume exactly 34 dofs)
+            if (st.manif) launch_step_duo<Real, SV_V2>(N / 2, stream, md, st, io, dbg);               // DM-physics v2, two characters per wavefront (round 4)
+            else if (st.hist || st.pert || md.enable_root_rot_fail || md.timer_exp > 0) launch_step_duo<Real, SV_AMP>(N / 2, stream, md, st, io, dbg);      // (the AMP instantiation also carries the perturbation code)
             else launch_step_duo<Real, SV_PLAIN>(N / 2, stream, md, st, io, dbg);
             return 0;
         }
@@ -753,7 +754,7 @@ int dm_create(const dm_create_info* info, const dm_scene_tables* tables, dm_ctx*
     int precision = info->precision ? info->precision : 32;
     if (precision != 32 && precision != 64) return fail("precision must be 32 or 64");
     if (info->physics < 0 || info->physics > 2) return fail("physics must be 0 / 1 (DM-physics v1) or 2 (v2)");
-    if (info->physics == 2 && info->wave_packing == 2) return fail("physics 2 runs one character per wavefront (wave_packing 0 or 1)");
+
     if (info->physics == 2 && tables->scene_goal == 5) return fail("physics 2 does not carry the free body of dribble_amp");
     int mc = info->max_contacts > 0 ? info->max_contacts : 20;
     if (mc > 20) return fail("max_contacts must be <= 20");

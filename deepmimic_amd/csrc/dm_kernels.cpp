@@ -9,7 +9,7 @@ namespace dmk {
 
 template <typename Real, int V>
 void launch_step_duo(unsigned grid, rt_stream s, const ModelDev<Real>& m, const EnvState<Real>& st, const StepIO<Real>& io, const DebugTaps<Real>& dbg) {
-    RT_LAUNCH((k_env_step_duo<Real, V == SV_TAPS, V == SV_AMP>), grid, s, m, st, io, dbg);
+    RT_LAUNCH((k_env_step_duo<Real, V == SV_TAPS, V == SV_AMP || V == SV_V2, V == SV_V2>), grid, s, m, st, io, dbg);
 }
 template <typename Real, typename C, int V>
 void launch_step(unsigned grid, rt_stream s, const ModelDev<Real>& m, const EnvState<Real>& st, const StepIO<Real>& io, const DebugTaps<Real>& dbg) {
@@ -41,7 +41,7 @@ void launch_amp_expert(unsigned grid, rt_stream s, const ModelDev<Real>& m, cons
     template void launch_probe<Real, C>(unsigned, rt_stream, const ModelDev<Real>&, const EnvState<Real>&, const DebugTaps<Real>&, int, double);
 #define DM_INST_EXPERT(Real, C) template void launch_amp_expert<Real, C>(unsigned, rt_stream, const ModelDev<Real>&, const double*, const double*, float*, const int*);
 
-// family ids (keep in step with KIDS in the Makefile)
+// family ids (keep in step with KIDS in the Makefile and tests/emu/Makefile)
 #define DM_FAMILY(Real, ID)                                                     \
     DM_FAMILY_##ID(Real)
 #define DM_FAMILY_0(Real) DM_INST_DUO(Real, SV_PLAIN)
@@ -66,10 +66,11 @@ void launch_amp_expert(unsigned grid, rt_stream s, const ModelDev<Real>& m, cons
 #define DM_FAMILY_19(Real) DM_INST_STEP(Real, ClsLarge, SV_V2)
 #define DM_FAMILY_20(Real) DM_INST_STEP(Real, ClsLargeTree, SV_V2)
 #define DM_FAMILY_21(Real) DM_INST_STEP(Real, ClsBipedTree, SV_V2)
+#define DM_FAMILY_22(Real) DM_INST_DUO(Real, SV_V2)
 
 #ifdef DM_TU_ALL
 #define DM_ALL(Real) DM_FAMILY_0(Real) DM_FAMILY_1(Real) DM_FAMILY_2(Real) DM_FAMILY_3(Real) DM_FAMILY_4(Real) DM_FAMILY_5(Real) \
-    DM_FAMILY_6(Real) DM_FAMILY_7(Real) DM_FAMILY_8(Real) DM_FAMILY_9(Real) DM_FAMILY_10(Real) DM_FAMILY_11(Real) DM_FAMILY_12(Real) DM_FAMILY_13(Real) DM_FAMILY_14(Real) DM_FAMILY_15(Real) DM_FAMILY_16(Real) DM_FAMILY_17(Real) DM_FAMILY_18(Real) DM_FAMILY_19(Real) DM_FAMILY_20(Real) DM_FAMILY_21(Real)
+    DM_FAMILY_6(Real) DM_FAMILY_7(Real) DM_FAMILY_8(Real) DM_FAMILY_9(Real) DM_FAMILY_10(Real) DM_FAMILY_11(Real) DM_FAMILY_12(Real) DM_FAMILY_13(Real) DM_FAMILY_14(Real) DM_FAMILY_15(Real) DM_FAMILY_16(Real) DM_FAMILY_17(Real) DM_FAMILY_18(Real) DM_FAMILY_19(Real) DM_FAMILY_20(Real) DM_FAMILY_21(Real) DM_FAMILY_22(Real)
 DM_ALL(float)
 DM_ALL(double)
 #else

@@ -67,10 +67,12 @@ def test_bench_refuses_rank_count_mismatch(emu_lib):
 
 
 def test_bench_physics_2_and_dog(emu_lib):
-    # the measurement switches of round 3: --physics 2 (DM-physics v2 runs one character per wavefront) and the dog on its compiled topology
+    # the measurement switches of round 3: --physics 2 (DM-physics v2) and the dog on its compiled topology
     p, line = run_bench(emu_lib, ["--gpus", "1", "--physics", "2"])
     assert p.returncode == 0, p.stderr[-2000:]
-    assert line["config"]["physics"] == 2 and line["roofline"]["kernel"] == "k_env_step" and line["checks"]["finite"]
+    assert line["config"]["physics"] == 2 and line["roofline"]["kernel"] == "k_env_step_duo" and line["checks"]["finite"]      # (two per wavefront since round 4)
+    p, line = run_bench(emu_lib, ["--gpus", "1", "--physics", "2", "--wave-packing", "1"])
+    assert p.returncode == 0 and line["roofline"]["kernel"] == "k_env_step"
     p, line = run_bench(emu_lib, ["--gpus", "1", "--scene", "dog3d_pace"])
     assert p.returncode == 0, p.stderr[-2000:]
     assert line["roofline"]["kernel"] == "k_env_step" and line["roofline"]["algorithmic_bytes_per_env_step"] > 2420 and line["checks"]["finite"]

@@ -98,12 +98,12 @@ def test_two_limit_rows_per_revolute_joint(oracle_built):
     assert abs(knee[1] - knee[2]) < 1e-9 and knee[1] < -0.2 * 0.05 / H * 0.5          # pulled back: about -erp * violation / h
 
 
-def _device_vs_oracle_v2(lib, name, prec, steps, tol_r, tol_s):
+def _device_vs_oracle_v2(lib, name, prec, steps, tol_r, tol_s, packing=1):
     """device under physics 2 vs the oracle under physics 2: teacher-forced control steps (manifolds start empty on both sides: the
     state setter clears them) -- rewards, state vectors and flags"""
     t = model.load_asset(name)
     n = 4
-    env = BatchEnv(t, n, precision=prec, lib_path=lib, physics=2, seed=5)
+    env = BatchEnv(t, n, precision=prec, lib_path=lib, physics=2, seed=5, wave_packing=packing)
     assert env.physics == 2
     oracles = []
     for e in range(n):
@@ -150,17 +150,57 @@ def test_device_v2_matches_oracle_emulator(emu_lib, name):
     print(_device_vs_oracle_v2(emu_lib, name, 64, 6, 1e-6, 1e-5))
 
 
+def test_device_v2_two_per_wave_matches_oracle_emulator(emu_lib):
+    """round 4: DM-physics v2 in the two-characters-per-wavefront kernel (k_env_step_duo<..., V2>: per-half manifold refresh, both limit rows)"""
+    print(_device_vs_oracle_v2(emu_lib, "humanoid3d_walk", 64, 8, 1e-6, 1e-5, packing=2))
+
+
+def _v2_duo_heavy_pair(lib, prec, tol):
+    """a character that has toppled onto its side gathers more than 32 rows (8 limit rows + 3 per contact): the pair's substep runs through the 64-lane
+    routine, which must take over the manifolds the two-per-wave pass has already refreshed.  The one-per-wave env is run into that situation, its
+    snapshot (manifolds included) is restored into the two-per-wave env, and both continue: same trajectory."""
+    t = model.load_asset("humanoid3d_walk")
+    one = BatchEnv(t, 2, precision=prec, lib_path=lib, physics=2, seed=7, wave_packing=1)
+    duo = BatchEnv(t, 2, precision=prec, lib_path=lib, physics=2, seed=7, wave_packing=2)
+    one.reset(kin_times=[0.2, 0.6], max_times=np.inf); duo.reset(kin_times=[0.2, 0.6], max_times=np.inf)
+    st = one.get_state()
+    pose = st["pose"].copy(); pose[0, 1] = 0.45; pose[0, 3:7] = [np.sqrt(0.5), 0.0, 0.0, np.sqrt(0.5)]      # env 0 on its side, dropped from 0.45 m; env 1 walks
+    one.set_state(pose=pose, vel=np.zeros_like(st["vel"]), tar=st["tar"], kin=st["kin"], clocks=st["clocks"], flags=st["flags"])
+    for _ in range(13):
+        one.step(None, pc.DT, 20, open_loop=True)
+    snap = one.snapshot()
+    duo.restore(snap)
+    one.probe(2, H)                                     # arm the taps of the reference env: (rows, contacts) of the last substep
+    max_rows = 0
+    for k in range(5):
+        a = one.step(None, pc.DT, 20, open_loop=True); b = duo.step(None, pc.DT, 20, open_loop=True)
+        max_rows = max(max_rows, int(one.debug("rows")[0][0]))
+        assert np.abs(a["state"] - b["state"]).max() < tol and np.abs(a["reward"] - b["reward"]).max() < tol, (k, np.abs(a["state"] - b["state"]).max())
+        assert np.array_equal(one.get_manifolds()[:, :, 0], duo.get_manifolds()[:, :, 0]), k      # same cached point counts, link by link
+    assert max_rows > 32, max_rows                      # the window did contain substeps past the two-per-wave row budget
+
+
+def test_device_v2_two_per_wave_heavy_pair_falls_back_emulator(emu_lib):
+    _v2_duo_heavy_pair(emu_lib, 64, 1e-7)
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("name,prec,steps,tol_r,tol_s", [("humanoid3d_walk", 64, 20, 1e-6, 1e-5), ("dog3d_pace", 64, 20, 1e-6, 1e-5),
-                                                         ("humanoid3d_walk", 32, 6, 1e-3, 5e-2), ("dog3d_pace", 32, 6, 2e-3, None)])
-def test_device_v2_matches_oracle_gpu(hip_lib, name, prec, steps, tol_r, tol_s):
+@pytest.mark.parametrize("name,prec,steps,tol_r,tol_s,packing", [("humanoid3d_walk", 64, 20, 1e-6, 1e-5, 1), ("dog3d_pace", 64, 20, 1e-6, 1e-5, 1),
+                                                                 ("humanoid3d_walk", 32, 6, 1e-3, 5e-2, 1), ("dog3d_pace", 32, 6, 2e-3, None, 1),
+                                                                 ("humanoid3d_walk", 64, 20, 1e-6, 1e-5, 2), ("humanoid3d_walk", 32, 6, 1e-3, 5e-2, 2)])
+def test_device_v2_matches_oracle_gpu(hip_lib, name, prec, steps, tol_r, tol_s, packing):
     """free-running from the reset (the manifolds cannot be teacher-forced: they are state of their own); the fp32 kernels are held over the
     first 6 control steps, before the chaotic separation of two correct fp32 / fp64 contact simulations sets in.
     The dog in fp32: rewards and flags only -- with one new support point per call, WHICH of a flat paw's four nearly tied corners enters
     the manifold first is decided by the last bits of the link transforms, and the transient toe / finger velocities of the state vector
     differ by O(1) between two such runs while they gather their corners (the fp64 build matches the oracle to 1e-5; the emulator shows the
     same fp32 behaviour on the CPU)"""
-    print(_device_vs_oracle_v2(hip_lib, name, prec, steps, tol_r, tol_s))
+    print(_device_vs_oracle_v2(hip_lib, name, prec, steps, tol_r, tol_s, packing))
+
+
+@pytest.mark.gpu
+def test_device_v2_two_per_wave_heavy_pair_falls_back_gpu(hip_lib):
+    _v2_duo_heavy_pair(hip_lib, 64, 1e-7)
 
 
 @pytest.mark.gpu

@@ -173,9 +173,10 @@ def cpu_baseline(scene, budget_s=12.0):
         return {"value": None, "unit": "env-steps/s", "cores": 1, "kind": "port", "sample": "failed: %r" % (ex,)}
 
 
-def _facade_worker(scene, steps, batch, barrier, q):
+def _facade_worker(scene, steps, batch, barrier, q, shared=False):
     """one worker of the drop-in route: ONE env per cDeepMimicCore, the reference's update_world loop"""
     os.environ["DM_FACADE_BATCH"] = batch
+    os.environ["DM_FACADE_SHARED"] = "1" if shared else "0"      # shared: every worker behind ONE context / one launch per control step (deepmimic_amd/broker.py)
     sys.path.insert(0, os.path.join(ROOT, "deepmimic_amd", "compat"))
     from DeepMimicCore import DeepMimicCore
     from deepmimic_amd import model
@@ -208,7 +209,7 @@ def _facade_worker(scene, steps, batch, barrier, q):
     return res
 
 
-def facade_bench(scene, steps, workers=(1,)):
+def facade_bench(scene, steps, workers=(1,), private_too=True):
     """The drop-in path the reference's trainer uses: ONE env per cDeepMimicCore, driven by the reference's update_world loop
     (DeepMimic.py:62-80: NeedNewAction / RecordState / CalcReward / SetAction once per 1/30 s; Update, CheckValidEpisode,
     IsEpisodeEnd once per 1/600 s).  Reports env-steps/s of one worker with the control step batched into one launch
@@ -220,23 +221,30 @@ def facade_bench(scene, steps, workers=(1,)):
         r = _facade_worker(scene, steps, batch, None, None)
         out[tag] = {"env_steps_per_s": steps / r["elapsed"], "ms_per_control_step": 1e3 * r["elapsed"] / steps,
                     "launches_per_control_step": r["launches"] / steps, "updates_per_control_step": r["updates"] / steps}
-    agg = {}
+    agg, agg_shared = {}, {}
     ctx = mp.get_context("spawn")
-    for w in workers:
-        if w <= 1:
-            agg["1"] = out["batched"]["env_steps_per_s"]; continue
-        barrier, q = ctx.Barrier(w), ctx.Queue()
-        procs = [ctx.Process(target=_facade_worker, args=(scene, steps, "1", barrier, q)) for _ in range(w)]
-        for p_ in procs:
-            p_.start()
-        res = [q.get(timeout=1800) for _ in procs]
-        for p_ in procs:
-            p_.join()
-        agg[str(w)] = w * steps / max(r["elapsed"] for r in res)
+    for shared, dst in ((False, agg), (True, agg_shared)):
+        os.environ["DM_FACADE_SHARED_MAX"] = str(max(2, max(workers)))
+        for w in workers:
+            if w <= 1 and not shared:
+                dst["1"] = out["batched"]["env_steps_per_s"]; continue
+            if not shared and w > 1 and not private_too:
+                continue
+            barrier, q = ctx.Barrier(w), ctx.Queue()
+            procs = [ctx.Process(target=_facade_worker, args=(scene, steps, "1", barrier, q, shared)) for _ in range(w)]
+            for p_ in procs:
+                p_.start()
+            res = [q.get(timeout=1800) for _ in procs]
+            for p_ in procs:
+                p_.join()
+            dst[str(w)] = w * steps / max(r["elapsed"] for r in res)
+        time.sleep(4.0)          # the owner process of the shared route leaves a few seconds after its last worker
     print(json.dumps({"metric": "facade env-steps/s, one env per cDeepMimicCore (%s)" % scene, "value": out["batched"]["env_steps_per_s"],
                       "unit": "env-steps/s", "n_gpus": 1, "steps": steps, "higher_is_better": True, "dtype": "f32", "data": "synthetic",
                       "config": {"workload": "%s, 1 env per worker, reference driver protocol, random actions N(0, 0.1^2), auto reset by the driver" % scene},
-                      "aggregate_env_steps_per_s_by_workers": agg, "host_cores": os.cpu_count(), **out}))
+                      "aggregate_env_steps_per_s_by_workers": agg,
+                      "aggregate_env_steps_per_s_by_workers_shared": agg_shared,      # DM_FACADE_SHARED=1: the workers behind one context (deepmimic_amd/broker.py)
+                      "host_cores": os.cpu_count(), **out}))
 
 
 def main():
@@ -263,6 +271,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--facade", action="store_true", help="measure the single-env cDeepMimicCore facade path instead of the batched env")
     ap.add_argument("--workers", type=int, nargs="*", default=[1], help="with --facade: aggregate rate of W worker processes (one cDeepMimicCore each) sharing the GPU, e.g. --workers 1 16 64")
+    ap.add_argument("--shared-only", action="store_true", help="with --facade --workers: skip the one-context-per-worker runs for W > 1 (they take minutes at W = 256)")
     ap.add_argument("--cpu-baseline-worker", type=int, default=None, help=argparse.SUPPRESS)
     ap.add_argument("--cpu-budget", type=float, default=12.0, help=argparse.SUPPRESS)
     ap.add_argument("--min-warmup", type=int, default=60,
@@ -273,7 +282,7 @@ def main():
         cpu_baseline_worker(args.scene, args.cpu_baseline_worker, args.cpu_budget)
         return
     if args.facade:
-        facade_bench(args.scene, min(args.steps, 300), args.workers)
+        facade_bench(args.scene, min(args.steps, 300), args.workers, private_too=not args.shared_only)
         return
 
     if args.gpus < 1:

@@ -1,0 +1,437 @@
+"""One GPU owner for W one-env callers: the worker-coalescing route of the cDeepMimicCore facade (DM_FACADE_SHARED=1, round 4).
+
+The reference's deployment is W processes with one `cDeepMimicCore` each (`mpiexec -n W python3 DeepMimic_Optimizer.py`, mpi_run.py:16-24).  Served
+one `dm_ctx` per process, W processes time-slice the GPU and every control step of every worker is a launch of ONE wavefront plus a blocking read-back:
+2 539 env-steps/s at W = 16 and 733 at W = 64 in round 3, slower than the host cores.  Here ONE process owns the device -- a context of `max_workers`
+envs -- and the workers are thin proxies: a request (reset / control step / query / state get-set) is written into the worker's slot of a POSIX
+shared-memory region, the owner collects every request that is pending, runs ALL pending control steps as ONE `dm_step_envs` launch (include/dm_hip.h;
+slot = env id), writes each worker's row back and wakes it.  The trajectory of a worker's env is the one it would follow in a context of its own
+(one character per wavefront either way; tests/test_broker.py: bit-identical to the per-process facade).
+
+Mechanics: numpy views over `multiprocessing.shared_memory`; per-slot sequence words `req` / `ack` (a request is pending while they differ); Linux
+futexes on those words for sleeping and waking (no polling, no sockets on the data path); x86-TSO store order (arguments first, `req` last; results
+first, `ack` last).  The owner process is started by the first worker that finds none (file lock), and leaves when its last worker has detached.
+
+Scope: scenes whose episode draws the facade makes on the host -- `imitate` / `imitate_amp`, one clip, no random perturbations, DM-physics v1; for the
+others the facade falls back to a context of its own.  Test infrastructure / learner plumbing only in the sense of SURVEY 8(b): this is boundary work,
+the kernels do not know about it.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import fcntl
+import hashlib
+import os
+import pickle
+import subprocess
+import sys
+import time
+from multiprocessing import shared_memory
+
+import numpy as np
+
+OP_RESET, OP_STEP, OP_QUERY, OP_GET_STATE, OP_SET_STATE, OP_QUERY_AMP, OP_AMP_EXPERT, OP_DETACH = 1, 2, 3, 4, 5, 6, 7, 8
+MAGIC = 0x444D4252          # "DMBR"
+_libc = C.CDLL(None, use_errno=True)
+_SYS_FUTEX, _FUTEX_WAIT, _FUTEX_WAKE = 202, 0, 1          # x86-64
+
+
+class _Timespec(C.Structure):
+    _fields_ = [("tv_sec", C.c_long), ("tv_nsec", C.c_long)]
+
+
+def futex_wait(addr: int, expected: int, timeout_s: float):
+    ts = _Timespec(int(timeout_s), int((timeout_s - int(timeout_s)) * 1e9))
+    _libc.syscall(_SYS_FUTEX, C.c_void_p(addr), _FUTEX_WAIT, C.c_int(expected), C.byref(ts), None, 0)
+
+
+def futex_wake(addr: int, n: int = 1):
+    _libc.syscall(_SYS_FUTEX, C.c_void_p(addr), _FUTEX_WAKE, C.c_int(n), None, None, 0)
+
+
+def region_name(tables, precision: int, device: int) -> str:
+    """One region per (user, scene tables, precision, device): unrelated runs never meet; DM_FACADE_SHM overrides."""
+    if os.environ.get("DM_FACADE_SHM"):
+        return os.environ["DM_FACADE_SHM"]
+    h = hashlib.sha1(pickle.dumps(tables, protocol=4)).hexdigest()[:12]
+    return "dmshare_%d_%s_%d_%d" % (os.getuid(), h, precision, device)
+
+
+class Region:
+    """The shared region: header + per-slot arrays, laid out from (W, S, A, P, J, AMP)."""
+    HDR = 64          # int64 words
+
+    def __init__(self, name: str, create=False, dims=None):
+        if create:
+            W, S, A, P, J, AMP = dims
+            size = self._layout(W, S, A, P, J, AMP)
+            self.shm = shared_memory.SharedMemory(name=name, create=True, size=size)
+            self.hdr = np.ndarray((self.HDR,), dtype=np.int64, buffer=self.shm.buf, offset=0)
+            self.hdr[:] = 0
+            self.hdr[1:7] = (W, S, A, P, J, AMP)
+        else:
+            self.shm = shared_memory.SharedMemory(name=name)
+            # Python 3.10 registers an ATTACHED segment with the process's resource tracker, which unlinks it when this process exits (bpo-38119):
+            # a worker that leaves would take the region away from under the others.  The owner alone unlinks it.
+            try:
+                from multiprocessing import resource_tracker
+                resource_tracker.unregister(self.shm._name, "shared_memory")
+            except Exception:
+                pass
+            self.hdr = np.ndarray((self.HDR,), dtype=np.int64, buffer=self.shm.buf, offset=0)
+            W, S, A, P, J, AMP = [int(x) for x in self.hdr[1:7]]
+            self._layout(W, S, A, P, J, AMP)
+        self.W, self.S, self.A, self.P, self.J, self.AMP = W, S, A, P, J, AMP
+        buf = self.shm.buf
+        for nm, (off, dt, shape) in self._fields.items():
+            setattr(self, nm, np.ndarray(shape, dtype=dt, buffer=buf, offset=off))
+        self._base = C.addressof(C.c_char.from_buffer(buf))
+
+    def _layout(self, W, S, A, P, J, AMP):
+        self._fields = {}
+        off = self.HDR * 8
+
+        def add(nm, dt, shape):
+            nonlocal off
+            off = (off + 63) // 64 * 64
+            self._fields[nm] = (off, dt, shape)
+            off += int(np.prod(shape)) * np.dtype(dt).itemsize
+        add("wake", np.int32, (16,))                       # [0]: the owner's futex word
+        add("owner", np.int32, (W,))                       # pid of the worker that holds the slot (0 = free)
+        add("req", np.int32, (W,)); add("ack", np.int32, (W,)); add("op", np.int32, (W,)); add("status", np.int32, (W,))
+        add("iargs", np.int32, (W, 4)); add("dargs", np.float64, (W, 8))
+        add("action", np.float32, (W, max(A, 1))); add("state", np.float32, (W, S)); add("reward", np.float32, (W,)); add("flags", np.int32, (W, 4))
+        add("clocks", np.float64, (W, 5)); add("amp", np.float32, (W, max(AMP, 1)))
+        add("big", np.float64, (W, 3 * P + 7 + 5 + 4))      # get / set state: pose, vel, tar, kin, clocks, flags
+        add("meta", np.float64, (4 * S + 4 * A + 8 + max(AMP, 1) * 3,))      # offsets / scales / bounds / norm groups, duration, ...
+        return off
+
+    def addr(self, nm: str, i: int) -> int:
+        off, dt, _ = self._fields[nm]
+        return self._base + off + i * np.dtype(dt).itemsize
+
+    def close(self, unlink=False):
+        for nm in list(self._fields) + ["hdr"]:
+            if hasattr(self, nm):
+                delattr(self, nm)
+        try:
+            self.shm.close()
+            if unlink:
+                self.shm.unlink()
+        except Exception:
+            pass
+
+
+# ======================================================================================================================= owner side
+def serve(name: str, tables_path: str, max_workers: int, device: int, precision: int, lib_path: str, idle_exit_s: float = 3.0):
+    from deepmimic_amd.core import BatchEnv
+    with open(tables_path, "rb") as f:
+        tables = pickle.load(f)
+    env = BatchEnv(tables, max_workers, device_id=device, seed=0, precision=precision, lib_path=lib_path or None, wave_packing=1)
+    R = Region(name, create=True, dims=(max_workers, env.S, env.A, env.P, env.J, env.amp_size))
+    off = env.offsets_scales()
+    S, A = env.S, env.A
+    m = R.meta
+    m[0:S] = off["state_offset"]; m[S:2 * S] = off["state_scale"]; m[2 * S:3 * S] = off["state_norm_groups"]
+    b = 3 * S
+    for k in ("action_offset", "action_scale", "action_min", "action_max"):
+        m[b:b + A] = off[k]; b += A
+    m[b] = env.duration; m[b + 1] = env.D; m[b + 2] = env.max_contacts
+    R.hdr[8] = os.getpid()
+    R.hdr[0] = MAGIC                                        # ready
+    W = max_workers
+    had_worker, idle_since = False, time.monotonic()
+    gather_s = float(os.environ.get("DM_BROKER_GATHER_US", "150")) * 1e-6
+    wake_addr = R.addr("wake", 0)
+    stats = {"launches": 0, "steps": 0}
+    try:
+        while True:
+            pend = np.nonzero((R.req != R.ack) & (R.owner != 0))[0]
+            if pend.size == 0:
+                R.wake[0] = 0
+                pend = np.nonzero((R.req != R.ack) & (R.owner != 0))[0]
+                if pend.size == 0:
+                    n_att = int(np.count_nonzero(R.owner))
+                    if n_att:
+                        had_worker, idle_since = True, time.monotonic()
+                        # a worker that died without detaching frees its slot
+                        for i in np.nonzero(R.owner)[0]:
+                            if not os.path.exists("/proc/%d" % int(R.owner[i])):
+                                R.owner[i] = 0
+                    elif had_worker and time.monotonic() - idle_since > idle_exit_s:
+                        break
+                    elif not had_worker and time.monotonic() - idle_since > 120.0:
+                        break
+                    futex_wait(wake_addr, 0, 0.05)
+                    continue
+            # gather window: let the other workers' requests of this control step arrive (they were woken together)
+            n_att = int(np.count_nonzero(R.owner))
+            if pend.size < n_att and gather_s > 0:
+                t_end = time.perf_counter() + gather_s
+                while time.perf_counter() < t_end:
+                    pend = np.nonzero((R.req != R.ack) & (R.owner != 0))[0]
+                    if pend.size >= n_att:
+                        break
+            ops = R.op[pend]
+            done = []
+            stp = pend[ops == OP_STEP]
+            if stp.size:
+                keys = {}
+                for i in stp:
+                    keys.setdefault((float(R.dargs[i, 0]), int(R.iargs[i, 0]), int(R.iargs[i, 1]), int(R.iargs[i, 2]), int(R.iargs[i, 3])), []).append(int(i))
+                for (dt, n_upd, has_act, end_early, want_amp), ids in keys.items():
+                    ids = np.array(ids, dtype=np.int32)
+                    out = env.step_envs(ids, R.action[ids, :A] if has_act else None, dt, n_upd, end_early=bool(end_early), amp=bool(want_amp))
+                    R.state[ids] = out["state"]; R.reward[ids] = out["reward"]
+                    R.flags[ids, 0] = out["terminate"]; R.flags[ids, 1] = out["valid"]; R.flags[ids, 2] = out["episode_end"]
+                    R.clocks[ids] = out["clocks"]
+                    if want_amp and env.amp_size:
+                        R.amp[ids] = out["amp_obs"]
+                    R.status[ids] = 0
+                    stats["launches"] += 1; stats["steps"] += len(ids)
+                    done.extend(int(i) for i in ids)
+            for i in pend[ops != OP_STEP]:
+                i = int(i); op = int(R.op[i])
+                try:
+                    if op == OP_RESET:
+                        env.reset(env_ids=[i], kin_times=[R.dargs[i, 0]], max_times=[R.dargs[i, 1]])
+                    elif op == OP_QUERY or op == OP_QUERY_AMP:
+                        q = env.query()
+                        R.state[i] = q["state"][i]; R.reward[i] = q["reward"][i]
+                        R.flags[i] = (q["terminate"][i], q["valid"][i], q["episode_end"][i], q["need_new_action"][i])
+                        if op == OP_QUERY_AMP and env.amp_size:
+                            R.amp[i] = env.query_amp()[i]
+                    elif op == OP_GET_STATE:
+                        s_ = env.get_state(); P = env.P
+                        R.big[i] = np.concatenate([s_["pose"][i], s_["vel"][i], s_["tar"][i], s_["kin"][i], s_["clocks"][i], s_["flags"][i].astype(np.float64)])
+                    elif op == OP_SET_STATE:
+                        s_ = env.get_state(); P = env.P; v = R.big[i]
+                        s_["pose"][i] = v[:P]; s_["vel"][i] = v[P:2 * P]; s_["tar"][i] = v[2 * P:3 * P]; s_["kin"][i] = v[3 * P:3 * P + 7]
+                        s_["clocks"][i] = v[3 * P + 7:3 * P + 12]; s_["flags"][i] = v[3 * P + 12:3 * P + 16].astype(np.int32)
+                        env.set_state(pose=s_["pose"], vel=s_["vel"], tar=s_["tar"], kin=s_["kin"], clocks=s_["clocks"], flags=s_["flags"])
+                    elif op == OP_AMP_EXPERT:
+                        R.amp[i] = env.amp_expert(1, [R.dargs[i, 0]], R.dargs[i, 1])[0]
+                    elif op == OP_DETACH:
+                        R.owner[i] = 0
+                    R.status[i] = 0
+                except Exception as ex:          # the worker raises; the owner lives on for the others
+                    R.status[i] = -1
+                    sys.stderr.write("deepmimic_amd.broker: op %d of slot %d failed: %r\n" % (op, i, ex))
+                done.append(i)
+            for i in done:
+                R.ack[i] = R.req[i]
+                futex_wake(R.addr("ack", i), 1)
+    finally:
+        R.hdr[0] = 0
+        R.hdr[9] = stats["launches"]; R.hdr[10] = stats["steps"]
+        env.close()
+        R.close(unlink=True)
+        for ext in (".tables", ".lock", ".log"):
+            try:
+                if ext != ".log" or os.path.getsize("/dev/shm/%s.log" % name) == 0:
+                    os.unlink("/dev/shm/%s%s" % (name, ext))
+            except OSError:
+                pass
+
+
+# ======================================================================================================================= worker side
+class SharedEnv:
+    """What the cDeepMimicCore facade needs of a `BatchEnv` with one env, served by the owner process through the shared region."""
+
+    def __init__(self, tables, seed: int = 0, device_id: int = 0, precision: int = 32, lib_path=None, max_workers=None):
+        self.tables = tables
+        c = tables.cfg
+        if tables.goal_kind != 0 or tables.num_clips != 1 or (c.enable_rand_perturbs and np.isfinite(c.perturb_time_min)) or c.enable_rand_rot_reset:
+            raise NotImplementedError("DM_FACADE_SHARED serves imitate / imitate_amp scenes with one clip, no perturbations, no random yaw")
+        self._seed, self._ep, self._expert_calls = int(seed) & (2 ** 64 - 1), 1, 0          # (a fresh one-env ctx has consumed episode 0 in dm_create's own reset)
+        W = int(max_workers or os.environ.get("DM_FACADE_SHARED_MAX", "256"))
+        name = region_name(tables, precision, device_id)
+        self.R = self._attach(name, tables, W, device_id, precision, lib_path or os.environ.get("DM_HIP_LIB") or "")
+        R = self.R
+        # claim a slot under the region's file lock
+        with open("/dev/shm/%s.lock" % name, "a+") as lk:
+            fcntl.flock(lk, fcntl.LOCK_EX)
+            free = np.nonzero(R.owner == 0)[0]
+            if free.size == 0:
+                raise RuntimeError("DM_FACADE_SHARED: all %d slots of %s are taken (DM_FACADE_SHARED_MAX)" % (R.W, name))
+            self.slot = int(free[0])
+            R.ack[self.slot] = R.req[self.slot]
+            R.owner[self.slot] = os.getpid()
+        self.N, self.S, self.A, self.P, self.J, self.amp_size, self.G = 1, R.S, R.A, R.P, R.J, R.AMP, 0
+        m, S, A = R.meta, R.S, R.A
+        b = 3 * S + 4 * A
+        self.duration, self.D, self.max_contacts = float(m[b]), int(m[b + 1]), int(m[b + 2])
+        self.physics, self.num_clips, self.has_obj, self.has_perturbs, self.precision = 1, 1, False, False, precision
+        self._timer = (c.timer_type, float(c.time_lim_min), float(c.time_lim_max), float(c.time_lim_exp))
+        self._ack_addr, self._wake_addr = R.addr("ack", self.slot), R.addr("wake", 0)
+
+    @staticmethod
+    def _attach(name, tables, W, device, precision, lib_path, timeout=180.0):
+        """Open the region; start the owner process if there is none (first worker, under the file lock)."""
+        lock_path = "/dev/shm/%s.lock" % name
+        t_end = time.monotonic() + timeout
+        with open(lock_path, "a+") as lk:
+            fcntl.flock(lk, fcntl.LOCK_EX)
+            alive = False
+            try:
+                R = Region(name)
+                pid = int(R.hdr[8])
+                alive = int(R.hdr[0]) == MAGIC and pid > 0 and os.path.exists("/proc/%d" % pid)
+                if not alive:
+                    R.close(unlink=True)
+            except FileNotFoundError:
+                pass
+            if not alive:
+                tp = "/dev/shm/%s.tables" % name
+                with open(tp, "wb") as f:
+                    pickle.dump(tables, f)
+                env = dict(os.environ)
+                root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+                env["PYTHONPATH"] = root + os.pathsep + env.get("PYTHONPATH", "")
+                log = open("/dev/shm/%s.log" % name, "ab")
+                subprocess.Popen([sys.executable, "-m", "deepmimic_amd.broker", "--serve", name, tp, str(W), str(device), str(precision), lib_path],
+                                 env=env, stdout=log, stderr=log, start_new_session=True, close_fds=True)
+                while True:
+                    try:
+                        R = Region(name)
+                        if int(R.hdr[0]) == MAGIC:
+                            break
+                        R.close()
+                    except (FileNotFoundError, ValueError):
+                        pass
+                    if time.monotonic() > t_end:
+                        raise RuntimeError("DM_FACADE_SHARED: the owner process did not come up (see /dev/shm/%s.log)" % name)
+                    time.sleep(0.05)
+        return R
+
+    # ---- one request / reply
+    def _call(self, op, timeout=120.0):
+        R, i = self.R, self.slot
+        R.op[i] = op
+        old = int(R.ack[i])
+        R.req[i] = (old + 1) & 0x7FFFFFFF
+        R.wake[0] = 1
+        futex_wake(self._wake_addr, 1)
+        t_end = time.monotonic() + timeout
+        for _ in range(200):                                 # a short spin: the reply to a lone query arrives within microseconds
+            if int(R.ack[i]) != old:
+                break
+        while int(R.ack[i]) == old:
+            futex_wait(self._ack_addr, old, 0.5)
+            if int(R.ack[i]) == old and time.monotonic() > t_end:
+                raise RuntimeError("DM_FACADE_SHARED: no reply from the owner process within %.0f s" % timeout)
+        if int(R.status[i]) != 0:
+            raise RuntimeError("DM_FACADE_SHARED: the owner process failed op %d (see its log in /dev/shm)" % op)
+
+    # ---- the BatchEnv surface the facade uses
+    def reset(self, env_ids=None, kin_times=None, max_times=None):
+        from . import model, streams
+        if kin_times is None:                                 # counter mode: the draws a one-env ctx of its own would make on the device (stream 0 / 1)
+            kt = self.duration * streams.reset_rand01(self._seed, 0, self._ep, 0)
+        else:
+            kt = float(np.ravel(kin_times)[0])
+        if max_times is None:
+            ty, lo, hi, ex = self._timer
+            mt = hi if not hi > lo else model.draw_time_limit(ty, lo, hi, ex, streams.reset_rand01(self._seed, 0, self._ep, 1))
+        else:
+            mt = float(np.ravel(max_times)[0])
+        self._ep += 1
+        self.R.dargs[self.slot, 0] = kt; self.R.dargs[self.slot, 1] = mt
+        self._call(OP_RESET)
+
+    def set_time_limits(self, lo, hi, ex=None):
+        self._timer = (self._timer[0], float(lo), float(hi), self._timer[3] if ex is None else float(ex))
+
+    def set_mode(self, test_mode):
+        pass
+
+    def _out(self, amp=False):
+        R, i = self.R, self.slot
+        out = dict(state=R.state[i:i + 1].copy(), reward=R.reward[i:i + 1].copy(), terminate=R.flags[i:i + 1, 0].copy(), valid=R.flags[i:i + 1, 1].copy(),
+                   episode_end=R.flags[i:i + 1, 2].copy())
+        if amp and self.amp_size:
+            out["amp_obs"] = R.amp[i:i + 1].copy()
+        return out
+
+    def step(self, actions=None, timestep=1.0 / 600, n_updates=20, auto_reset=False, open_loop=False, amp=False, end_early=None):
+        if auto_reset or open_loop:
+            raise NotImplementedError("SharedEnv.step: the facade resets explicitly and always hands an action (or none)")
+        R, i = self.R, self.slot
+        if actions is not None:
+            R.action[i, :self.A] = np.asarray(actions, dtype=np.float32).reshape(self.A)
+        R.dargs[i, 0] = float(timestep)
+        R.iargs[i] = (int(n_updates), 0 if actions is None else 1, int(bool(end_early)), int(bool(amp)))
+        self._call(OP_STEP)
+        out = self._out(amp)
+        out["clocks"] = R.clocks[i:i + 1].copy()             # kin_time, ctrl_time, init_time_offset, timer_time, timer_max after the step
+        return out
+
+    def query(self):
+        self._call(OP_QUERY)
+        out = self._out()
+        out["need_new_action"] = self.R.flags[self.slot:self.slot + 1, 3].copy()
+        return out
+
+    def query_amp(self):
+        self._call(OP_QUERY_AMP)
+        return self.R.amp[self.slot:self.slot + 1].copy()
+
+    def amp_expert(self, n, times=None, ground_h=None):
+        assert n == 1
+        if times is None:            # counter mode: the draw dm_amp_expert makes for a one-env ctx of its own (dm_host.cpp: key (seed, 0x414D50, call, sample 0))
+            from . import streams
+            times = [self.duration * streams.reset_rand01(self._seed, 0x414D50, self._expert_calls, 0)]
+            self._expert_calls += 1
+        self.R.dargs[self.slot, 0] = float(np.ravel(times)[0]); self.R.dargs[self.slot, 1] = 0.0 if ground_h is None else float(np.ravel(ground_h)[0])
+        self._call(OP_AMP_EXPERT)
+        return self.R.amp[self.slot:self.slot + 1].copy()
+
+    def get_state(self):
+        self._call(OP_GET_STATE)
+        v, P = self.R.big[self.slot].copy(), self.P
+        return dict(pose=v[None, :P], vel=v[None, P:2 * P], tar=v[None, 2 * P:3 * P], kin=v[None, 3 * P:3 * P + 7], clocks=v[None, 3 * P + 7:3 * P + 12],
+                    flags=v[None, 3 * P + 12:3 * P + 16].astype(np.int32))
+
+    def set_state(self, pose=None, vel=None, tar=None, kin=None, clocks=None, flags=None):
+        cur = self.get_state()
+        for k, a in (("pose", pose), ("vel", vel), ("tar", tar), ("kin", kin), ("clocks", clocks), ("flags", flags)):
+            if a is not None:
+                cur[k] = np.asarray(a, dtype=np.float64).reshape(1, -1)
+        self.R.big[self.slot] = np.concatenate([cur["pose"][0], cur["vel"][0], cur["tar"][0], cur["kin"][0], cur["clocks"][0], np.asarray(cur["flags"][0], dtype=np.float64)])
+        self._call(OP_SET_STATE)
+
+    def snapshot(self):
+        return self.get_state()
+
+    def restore(self, snap):
+        self.set_state(**{k: snap[k] for k in ("pose", "vel", "tar", "kin", "clocks", "flags")})
+
+    def offsets_scales(self):
+        m, S, A = self.R.meta, self.S, self.A
+        out = {"state_offset": m[0:S].copy(), "state_scale": m[S:2 * S].copy(), "state_norm_groups": m[2 * S:3 * S].astype(np.int32)}
+        b = 3 * S
+        for k in ("action_offset", "action_scale", "action_min", "action_max"):
+            out[k] = m[b:b + A].copy(); b += A
+        return out
+
+    def close(self):
+        if getattr(self, "R", None) is not None:
+            try:
+                self._call(OP_DETACH, timeout=5.0)
+            except Exception:
+                pass
+            self.R.close()
+            self.R = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+if __name__ == "__main__":
+    if len(sys.argv) >= 8 and sys.argv[1] == "--serve":
+        serve(sys.argv[2], sys.argv[3], int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6]), sys.argv[7])
+    else:
+        sys.exit("usage: python -m deepmimic_amd.broker --serve <region> <tables pickle> <max workers> <device> <precision> <lib path>")

@@ -114,9 +114,20 @@ class cDeepMimicCore(object):
             self._kin = _model.KinSampler(self._tables); self._time = 0.0
             self.stats = {"launches": 0, "updates": 0, "rollbacks": 0}
             return
-        self._env = _BatchEnv(self._tables, 1, device_id=int(os.environ.get("DM_DEVICE", "0")), seed=self._seed,
-                              precision=int(os.environ.get("DM_PRECISION", "32")), lib_path=os.environ.get("DM_HIP_LIB"),
-                              physics=int(os.environ.get("DM_PHYSICS", "1")))
+        self._env = None
+        if os.environ.get("DM_FACADE_SHARED", "0") == "1" and int(os.environ.get("DM_PHYSICS", "1")) == 1:
+            # W worker processes behind ONE context and one launch per control step (deepmimic_amd/broker.py): the reference's `mpiexec -n W` deployment
+            from deepmimic_amd.broker import SharedEnv
+            try:
+                self._env = SharedEnv(self._tables, seed=self._seed, device_id=int(os.environ.get("DM_DEVICE", "0")),
+                                      precision=int(os.environ.get("DM_PRECISION", "32")), lib_path=os.environ.get("DM_HIP_LIB"))
+            except NotImplementedError as ex:
+                import warnings
+                warnings.warn("DM_FACADE_SHARED: %s; this worker uses a context of its own" % ex, RuntimeWarning, stacklevel=2)
+        if self._env is None:
+            self._env = _BatchEnv(self._tables, 1, device_id=int(os.environ.get("DM_DEVICE", "0")), seed=self._seed,
+                                  precision=int(os.environ.get("DM_PRECISION", "32")), lib_path=os.environ.get("DM_HIP_LIB"),
+                                  physics=int(os.environ.get("DM_PHYSICS", "1")))
         self._off = self._env.offsets_scales()
         self._apply_mode()
         self._batch = os.environ.get("DM_FACADE_BATCH", "1") != "0"      # (DM-physics v2 too since round 4: the snapshot carries the ground manifolds)
@@ -315,7 +326,7 @@ class cDeepMimicCore(object):
             snap = env.snapshot()
             clk0 = dict(self._clk)
             out = self._launch(action, dt, k, True)
-            t1 = float(env.get_state()["clocks"][0][3])
+            t1 = float(out["clocks"][0][3]) if "clocks" in out else float(env.get_state()["clocks"][0][3])      # (the shared route returns the clocks with the step: one round trip)
             n_done = min(k, int(round((t1 - clk0["timer"]) / dt)))
             if n_done <= 0:
                 # the launch ended before its first update: the state was already invalid at entry (the caller kept updating after CheckValidEpisode

@@ -290,6 +290,27 @@ class BatchEnv:
             out["goal"] = self.last_goals()
         return out
 
+    def step_envs(self, env_ids, actions=None, timestep: float = 1.0 / 600, n_updates: int = 20, auto_reset=False, open_loop=False, end_early=None,
+                  amp=False, want_clocks=True):
+        """`step` for a subset of the envs (include/dm_hip.h dm_step_envs): compact arrays, row i <-> env_ids[i]; the other envs are not touched."""
+        end_early = auto_reset if end_early is None else end_early
+        ids = np.ascontiguousarray(env_ids, dtype=np.int32).ravel()
+        n = ids.size
+        a = None if actions is None else np.ascontiguousarray(actions, dtype=np.float32).reshape(n, self.A)
+        s = np.zeros((n, self.S), np.float32); r = np.zeros(n, np.float32)
+        t = np.zeros(n, np.int32); v = np.zeros(n, np.int32); e = np.zeros(n, np.int32)
+        o = np.zeros((n, self.amp_size), np.float32) if (amp and self.amp_size) else None
+        clk = np.zeros((n, 5)) if want_clocks else None
+        flags = (DM_AUTO_RESET if auto_reset else 0) | (DM_OPEN_LOOP if open_loop else 0) | (DM_END_EPISODE_EARLY if end_early else 0)
+        self._chk(self.lib.dm_step_envs(self.h, _ip(ids), int(n), _fp(a), C.c_double(timestep), int(n_updates), _fp(s), _fp(r), _ip(t), _ip(v), _ip(e),
+                                        _fp(o), _dp(clk), flags))
+        out = dict(state=s, reward=r, terminate=t, valid=v, episode_end=e)
+        if o is not None:
+            out["amp_obs"] = o
+        if clk is not None:
+            out["clocks"] = clk
+        return out
+
     def set_mode(self, test_mode: bool):
         """cRLScene::SetMode for the goal scenes' device-side logic (the episode-timer limits are set_time_limits' business)"""
         self._chk(self.lib.dm_set_mode(self.h, int(bool(test_mode))))

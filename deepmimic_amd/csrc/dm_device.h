@@ -2574,12 +2574,12 @@ template <typename Real, typename C, bool TAPS, bool AMP = false, bool PHYS2 = f
 __global__ void __launch_bounds__(64) DM_WAVES_PER_EU((StepWaves<Real, C>::value)) k_env_step(ModelDev<Real> m, EnvState<Real> st, StepIO<Real> io, DebugTaps<Real> dbg) {
     constexpr bool HIST = TAPS || AMP, V2 = TAPS || PHYS2;
     __shared__ Lds<Real, C> lds;
-    const int e = blockIdx.x, l = threadIdx.x;
+    const int e = io.env_ids ? io.env_ids[blockIdx.x] : (int)blockIdx.x, l = threadIdx.x;      // (env_ids: a subset of the ctx's envs, dm_step_envs)
     EnvSim<Real, C, TAPS> sim(m, lds, l);
     if (TAPS && dbg.prof) { sim.prof = dbg.prof + (size_t)e * 16; sim.tprev = dm_clock(); }
     sim.load(st, e);
     if (io.open_loop) sim.set_action_from_clip();
-    else if (io.actions) sim.set_action(io.actions + (size_t)e * m.A);
+    else if (io.actions) sim.set_action(io.actions + (size_t)(io.env_ids ? (int)blockIdx.x : e) * m.A);
     sim.mark(15);
     Real* aovf = st.aovf ? st.aovf + (size_t)e * (kMaxRows - C::RREG) * kWave : nullptr;
     const bool goal = HIST && st.goal && m.scene_goal;

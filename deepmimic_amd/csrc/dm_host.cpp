@@ -289,6 +289,7 @@ struct CtxBase {
     std::vector<void*> allocs;
     float *d_actions = nullptr, *d_states = nullptr, *d_rewards = nullptr; int *d_term = nullptr, *d_valid = nullptr, *d_end = nullptr;
     bool duo = false, upload_failed = false; int physics = 1;
+    int* d_ids = nullptr; const int* step_ids = nullptr; int step_n_ids = 0;      // dm_step_envs: the subset the next step() call runs (device ids), cleared after it
     virtual ~CtxBase() { for (void* p : allocs) rt_free(p); }
     void* dalloc(size_t n) { void* p = nullptr; if (rt_malloc(&p, n) != 0) return nullptr; allocs.push_back(p); return p; }
     virtual int setup() = 0;
@@ -540,32 +541,33 @@ struct CtxT : CtxBase {
         StepIO<Real> io; memset(&io, 0, sizeof(io));
         io.amp_obs = amp; io.goals = d_goals;
         io.actions = actions_dev; io.states = states; io.rewards = rewards; io.terminate = term; io.valid = valid; io.episode_end = end;
+        io.env_ids = step_ids; const int GN = step_ids ? step_n_ids : N;      // workgroups of the one-per-wave launches
         io.n_updates = n_updates; io.dt = dt; io.auto_reset = (flags & DM_AUTO_RESET) ? 1 : 0; io.emit = (flags & DM_NO_EMIT) ? 0 : 1; io.open_loop = (flags & DM_OPEN_LOOP) ? 1 : 0; io.end_early = (flags & DM_END_EPISODE_EARLY) ? 1 : 0;
         // two characters per wavefront: biped class, even batch, no debug taps armed (DM_DUO=0 keeps one character per wave)
-        if (duo && cls == 0 && hm.D == ClsBiped::ND && (N % 2) == 0 && !dbg.H) {      // (31 row lanes per character assume exactly 34 dofs)
+        if (duo && cls == 0 && hm.D == ClsBiped::ND && (N % 2) == 0 && !dbg.H && !step_ids) {      // (31 row lanes per character assume exactly 34 dofs)
             if (st.manif) launch_step_duo<Real, SV_V2>(N / 2, stream, md, st, io, dbg);               // DM-physics v2, two characters per wavefront (round 4)
             else if (st.hist || st.pert || md.enable_root_rot_fail || md.timer_exp > 0) launch_step_duo<Real, SV_AMP>(N / 2, stream, md, st, io, dbg);      // (the AMP instantiation also carries the perturbation code)
             else launch_step_duo<Real, SV_PLAIN>(N / 2, stream, md, st, io, dbg);
             return 0;
         }
         // production launch: the tap-free instantiation unless a parity test armed the debug taps (dm_probe)
-        if (cls == 2) { if (dbg.H) launch_step<Real, ClsBipedObj, SV_TAPS>(N, stream, md, st, io, dbg); else launch_step<Real, ClsBipedObj, SV_AMP>(N, stream, md, st, io, dbg); }
+        if (cls == 2) { if (dbg.H) launch_step<Real, ClsBipedObj, SV_TAPS>(GN, stream, md, st, io, dbg); else launch_step<Real, ClsBipedObj, SV_AMP>(GN, stream, md, st, io, dbg); }
         else if (cls == 4) {
-            if (dbg.H) launch_step<Real, ClsBipedTree, SV_TAPS>(N, stream, md, st, io, dbg);
-            else if (st.manif) launch_step<Real, ClsBipedTree, SV_V2>(N, stream, md, st, io, dbg);
-            else if (st.hist || st.pert || md.enable_root_rot_fail || md.timer_exp > 0) launch_step<Real, ClsBipedTree, SV_AMP>(N, stream, md, st, io, dbg);
-            else launch_step<Real, ClsBipedTree, SV_PLAIN>(N, stream, md, st, io, dbg);
+            if (dbg.H) launch_step<Real, ClsBipedTree, SV_TAPS>(GN, stream, md, st, io, dbg);
+            else if (st.manif) launch_step<Real, ClsBipedTree, SV_V2>(GN, stream, md, st, io, dbg);
+            else if (st.hist || st.pert || md.enable_root_rot_fail || md.timer_exp > 0) launch_step<Real, ClsBipedTree, SV_AMP>(GN, stream, md, st, io, dbg);
+            else launch_step<Real, ClsBipedTree, SV_PLAIN>(GN, stream, md, st, io, dbg);
         }
         else if (cls == 3) {
-            if (dbg.H) launch_step<Real, ClsLargeTree, SV_TAPS>(N, stream, md, st, io, dbg);
-            else if (st.manif) launch_step<Real, ClsLargeTree, SV_V2>(N, stream, md, st, io, dbg);
-            else if (st.hist || st.pert || md.enable_root_rot_fail || md.timer_exp > 0) launch_step<Real, ClsLargeTree, SV_AMP>(N, stream, md, st, io, dbg);
-            else launch_step<Real, ClsLargeTree, SV_PLAIN>(N, stream, md, st, io, dbg);
+            if (dbg.H) launch_step<Real, ClsLargeTree, SV_TAPS>(GN, stream, md, st, io, dbg);
+            else if (st.manif) launch_step<Real, ClsLargeTree, SV_V2>(GN, stream, md, st, io, dbg);
+            else if (st.hist || st.pert || md.enable_root_rot_fail || md.timer_exp > 0) launch_step<Real, ClsLargeTree, SV_AMP>(GN, stream, md, st, io, dbg);
+            else launch_step<Real, ClsLargeTree, SV_PLAIN>(GN, stream, md, st, io, dbg);
         }
-        else if (dbg.H) { if (cls == 0) launch_step<Real, ClsBiped, SV_TAPS>(N, stream, md, st, io, dbg); else launch_step<Real, ClsLarge, SV_TAPS>(N, stream, md, st, io, dbg); }
-        else if (st.manif) { if (cls == 0) launch_step<Real, ClsBiped, SV_V2>(N, stream, md, st, io, dbg); else launch_step<Real, ClsLarge, SV_V2>(N, stream, md, st, io, dbg); }      // DM-physics v2: its own instantiation (AMP code + manifolds)
-        else if (st.hist || st.pert || md.enable_root_rot_fail || md.timer_exp > 0) { if (cls == 0) launch_step<Real, ClsBiped, SV_AMP>(N, stream, md, st, io, dbg); else launch_step<Real, ClsLarge, SV_AMP>(N, stream, md, st, io, dbg); }
-        else { if (cls == 0) launch_step<Real, ClsBiped, SV_PLAIN>(N, stream, md, st, io, dbg); else launch_step<Real, ClsLarge, SV_PLAIN>(N, stream, md, st, io, dbg); }
+        else if (dbg.H) { if (cls == 0) launch_step<Real, ClsBiped, SV_TAPS>(GN, stream, md, st, io, dbg); else launch_step<Real, ClsLarge, SV_TAPS>(GN, stream, md, st, io, dbg); }
+        else if (st.manif) { if (cls == 0) launch_step<Real, ClsBiped, SV_V2>(GN, stream, md, st, io, dbg); else launch_step<Real, ClsLarge, SV_V2>(GN, stream, md, st, io, dbg); }      // DM-physics v2: its own instantiation (AMP code + manifolds)
+        else if (st.hist || st.pert || md.enable_root_rot_fail || md.timer_exp > 0) { if (cls == 0) launch_step<Real, ClsBiped, SV_AMP>(GN, stream, md, st, io, dbg); else launch_step<Real, ClsLarge, SV_AMP>(GN, stream, md, st, io, dbg); }
+        else { if (cls == 0) launch_step<Real, ClsBiped, SV_PLAIN>(GN, stream, md, st, io, dbg); else launch_step<Real, ClsLarge, SV_PLAIN>(GN, stream, md, st, io, dbg); }
         return 0;
     }
     int amp_expert(int n, const double* times_dev, const double* gh_dev, float* out_dev) override { return amp_expert_clips(n, nullptr, times_dev, gh_dev, out_dev); }
@@ -911,6 +913,44 @@ int dm_step_batch(dm_ctx* ctx, const float* actions, double timestep, int n_upda
     if (launch_status(c->step(adev, timestep, n_updates, c->d_states, c->d_rewards, c->d_term, c->d_valid, c->d_end, flags))) return -1;
     if (copy_out(c, states, c->d_states, sizeof(float) * c->N * c->hm.S) || copy_out(c, rewards, c->d_rewards, sizeof(float) * c->N) ||
         copy_out(c, terminate, c->d_term, sizeof(int) * c->N) || copy_out(c, valid, c->d_valid, sizeof(int) * c->N) || copy_out(c, episode_end, c->d_end, sizeof(int) * c->N)) return -1;
+    return 0;
+}
+
+int dm_step_envs(dm_ctx* ctx, const int32_t* env_ids, int n, const float* actions, double timestep, int n_updates, float* states, float* rewards,
+                 int32_t* terminate, int32_t* valid, int32_t* episode_end, float* amp_obs, double* clocks, int flags) {
+    if (!ctx || !env_ids) return fail("null argument");
+    CtxBase* c = ctx->c; DevGuard guard(c->device_id);
+    const int N = c->N, S = c->hm.S, A = c->hm.A;
+    if (n < 1 || n > N) return fail("dm_step_envs: n must be in [1, num_envs]");
+    if (flags & DM_DEVICE_PTRS) return fail("dm_step_envs takes host pointers");
+    if (amp_obs && !c->amp_size) return fail("AMP observations need a `--scene imitate_amp` context (dm_scene_tables.scene_amp)");
+    std::vector<char> seen((size_t)N, 0);
+    for (int i = 0; i < n; ++i) { const int e = env_ids[i]; if (e < 0 || e >= N || seen[e]) return fail("dm_step_envs: env ids must be distinct and in [0, num_envs)"); seen[e] = 1; }
+    if (!c->d_ids) { c->d_ids = (int*)c->dalloc(sizeof(int) * (size_t)N); if (!c->d_ids) return fail("device allocation failed"); }
+    if (rt_h2d(c->d_ids, env_ids, sizeof(int) * (size_t)n, c->stream)) return fail("copy failed");
+    const float* adev = nullptr;
+    if (actions) { if (rt_h2d(c->d_actions, actions, sizeof(float) * (size_t)n * A, c->stream)) return fail("copy failed"); adev = c->d_actions; }      // compact: row i = env_ids[i]
+    c->step_ids = c->d_ids; c->step_n_ids = n;
+    const int rc = launch_status(c->step(adev, timestep, n_updates, c->d_states, c->d_rewards, c->d_term, c->d_valid, c->d_end, flags, amp_obs ? c->d_amp : nullptr));
+    c->step_ids = nullptr; c->step_n_ids = 0;
+    if (rc) return -1;
+    // the kernels write every output at the env's own row: copy the arrays back and hand out the rows asked for
+    std::vector<float> hs(states ? (size_t)N * S : 0), hr(rewards ? N : 0), ha(amp_obs ? (size_t)N * c->amp_size : 0); std::vector<int> ht(terminate ? N : 0), hv(valid ? N : 0), he(episode_end ? N : 0);
+    if ((states && copy_out(c, hs.data(), c->d_states, sizeof(float) * hs.size())) || (rewards && copy_out(c, hr.data(), c->d_rewards, sizeof(float) * N)) ||
+        (terminate && copy_out(c, ht.data(), c->d_term, sizeof(int) * N)) || (valid && copy_out(c, hv.data(), c->d_valid, sizeof(int) * N)) ||
+        (episode_end && copy_out(c, he.data(), c->d_end, sizeof(int) * N)) || (amp_obs && copy_out(c, ha.data(), c->d_amp, sizeof(float) * ha.size()))) return -1;
+    std::vector<double> hc;
+    if (clocks) { hc.resize((size_t)N * 5); if (c->get_state(nullptr, nullptr, nullptr, nullptr, hc.data(), nullptr)) return -1; }
+    for (int i = 0; i < n; ++i) {
+        const int e = env_ids[i];
+        if (states) memcpy(states + (size_t)i * S, hs.data() + (size_t)e * S, sizeof(float) * S);
+        if (rewards) rewards[i] = hr[e];
+        if (terminate) terminate[i] = ht[e];
+        if (valid) valid[i] = hv[e];
+        if (episode_end) episode_end[i] = he[e];
+        if (amp_obs) memcpy(amp_obs + (size_t)i * c->amp_size, ha.data() + (size_t)e * c->amp_size, sizeof(float) * c->amp_size);
+        if (clocks) memcpy(clocks + (size_t)i * 5, hc.data() + (size_t)e * 5, sizeof(double) * 5);
+    }
     return 0;
 }
 

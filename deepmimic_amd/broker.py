@@ -9,7 +9,7 @@ slot = env id), writes each worker's row back and wakes it.  The trajectory of a
 (one character per wavefront either way; tests/test_broker.py: bit-identical to the per-process facade).
 
 Mechanics: numpy views over `multiprocessing.shared_memory`; per-slot sequence words `req` / `ack` (a request is pending while they differ); Linux
-futexes on those words for sleeping and waking (no polling, no sockets on the data path); x86-TSO store order (arguments first, `req` last; results
+futexes for sleeping and waking -- the owner on one word, all workers on one reply-generation word, one syscall per round -- (no sockets on the data path); x86-TSO store order (arguments first, `req` last; results
 first, `ack` last).  The owner process is started by the first worker that finds none (file lock), and leaves when its last worker has detached.
 
 Scope: scenes whose episode draws the facade makes on the host -- `imitate` / `imitate_amp`, one clip, no random perturbations, DM-physics v1; for the
@@ -96,10 +96,10 @@ class Region:
             off = (off + 63) // 64 * 64
             self._fields[nm] = (off, dt, shape)
             off += int(np.prod(shape)) * np.dtype(dt).itemsize
-        add("wake", np.int32, (16,))                       # [0]: the owner's futex word
+        add("wake", np.int32, (32,))                       # [0]: the owner's futex word; [1]: the reply generation all workers sleep on
         add("owner", np.int32, (W,))                       # pid of the worker that holds the slot (0 = free)
         add("req", np.int32, (W,)); add("ack", np.int32, (W,)); add("op", np.int32, (W,)); add("status", np.int32, (W,))
-        add("iargs", np.int32, (W, 4)); add("dargs", np.float64, (W, 8))
+        add("iargs", np.int32, (W, 8)); add("dargs", np.float64, (W, 8))
         add("action", np.float32, (W, max(A, 1))); add("state", np.float32, (W, S)); add("reward", np.float32, (W,)); add("flags", np.int32, (W, 4))
         add("clocks", np.float64, (W, 5)); add("amp", np.float32, (W, max(AMP, 1)))
         add("big", np.float64, (W, 3 * P + 7 + 5 + 4))      # get / set state: pose, vel, tar, kin, clocks, flags
@@ -141,9 +141,12 @@ def serve(name: str, tables_path: str, max_workers: int, device: int, precision:
     R.hdr[0] = MAGIC                                        # ready
     W = max_workers
     had_worker, idle_since = False, time.monotonic()
-    gather_s = float(os.environ.get("DM_BROKER_GATHER_US", "150")) * 1e-6
+    gather_max = float(os.environ.get("DM_BROKER_GATHER_US", "3000")) * 1e-6        # longest wait for the stragglers of a control step
+    gather_quiet = float(os.environ.get("DM_BROKER_QUIET_US", "250")) * 1e-6      # ... or this long without a new arrival
+    gen_addr = R.addr("wake", 1)
     wake_addr = R.addr("wake", 0)
-    stats = {"launches": 0, "steps": 0}
+    stats = {"launches": 0, "steps": 0, "rounds": 0, "t_gather": 0.0, "t_step": 0.0, "t_other": 0.0, "t_idle": 0.0, "other_ops": 0}
+    t_mark = time.perf_counter()
     try:
         while True:
             pend = np.nonzero((R.req != R.ack) & (R.owner != 0))[0]
@@ -164,66 +167,94 @@ def serve(name: str, tables_path: str, max_workers: int, device: int, precision:
                         break
                     futex_wait(wake_addr, 0, 0.05)
                     continue
-            # gather window: let the other workers' requests of this control step arrive (they were woken together)
+            # gather window: the workers of a control step were woken together and come back in a burst.  A launch costs ~1.5 ms whatever it carries, so
+            # the owner waits for the burst: until every attached worker has a request pending, or nothing new has arrived for `quiet`, or `max_wait`.
             n_att = int(np.count_nonzero(R.owner))
-            if pend.size < n_att and gather_s > 0:
-                t_end = time.perf_counter() + gather_s
-                while time.perf_counter() < t_end:
+            t_g0 = time.perf_counter(); stats["t_idle"] += t_g0 - t_mark
+            if pend.size < n_att and gather_max > 0:
+                t0 = t_last = time.perf_counter(); last_n = pend.size
+                while True:
                     pend = np.nonzero((R.req != R.ack) & (R.owner != 0))[0]
                     if pend.size >= n_att:
                         break
+                    now = time.perf_counter()
+                    if pend.size != last_n:
+                        last_n, t_last = pend.size, now
+                    if now - t_last > gather_quiet or now - t0 > gather_max:
+                        break
+            t_g1 = time.perf_counter(); stats["t_gather"] += t_g1 - t_g0; stats["rounds"] += 1
+            t_s1 = t_g1
             ops = R.op[pend]
-            done = []
-            stp = pend[ops == OP_STEP]
-            if stp.size:
-                keys = {}
-                for i in stp:
-                    keys.setdefault((float(R.dargs[i, 0]), int(R.iargs[i, 0]), int(R.iargs[i, 1]), int(R.iargs[i, 2]), int(R.iargs[i, 3])), []).append(int(i))
-                for (dt, n_upd, has_act, end_early, want_amp), ids in keys.items():
-                    ids = np.array(ids, dtype=np.int32)
-                    out = env.step_envs(ids, R.action[ids, :A] if has_act else None, dt, n_upd, end_early=bool(end_early), amp=bool(want_amp))
-                    R.state[ids] = out["state"]; R.reward[ids] = out["reward"]
-                    R.flags[ids, 0] = out["terminate"]; R.flags[ids, 1] = out["valid"]; R.flags[ids, 2] = out["episode_end"]
-                    R.clocks[ids] = out["clocks"]
-                    if want_amp and env.amp_size:
-                        R.amp[ids] = out["amp_obs"]
-                    R.status[ids] = 0
-                    stats["launches"] += 1; stats["steps"] += len(ids)
-                    done.extend(int(i) for i in ids)
-            for i in pend[ops != OP_STEP]:
-                i = int(i); op = int(R.op[i])
-                try:
-                    if op == OP_RESET:
-                        env.reset(env_ids=[i], kin_times=[R.dargs[i, 0]], max_times=[R.dargs[i, 1]])
-                    elif op == OP_QUERY or op == OP_QUERY_AMP:
-                        q = env.query()
-                        R.state[i] = q["state"][i]; R.reward[i] = q["reward"][i]
-                        R.flags[i] = (q["terminate"][i], q["valid"][i], q["episode_end"][i], q["need_new_action"][i])
-                        if op == OP_QUERY_AMP and env.amp_size:
-                            R.amp[i] = env.query_amp()[i]
-                    elif op == OP_GET_STATE:
-                        s_ = env.get_state(); P = env.P
-                        R.big[i] = np.concatenate([s_["pose"][i], s_["vel"][i], s_["tar"][i], s_["kin"][i], s_["clocks"][i], s_["flags"][i].astype(np.float64)])
-                    elif op == OP_SET_STATE:
-                        s_ = env.get_state(); P = env.P; v = R.big[i]
-                        s_["pose"][i] = v[:P]; s_["vel"][i] = v[P:2 * P]; s_["tar"][i] = v[2 * P:3 * P]; s_["kin"][i] = v[3 * P:3 * P + 7]
-                        s_["clocks"][i] = v[3 * P + 7:3 * P + 12]; s_["flags"][i] = v[3 * P + 12:3 * P + 16].astype(np.int32)
-                        env.set_state(pose=s_["pose"], vel=s_["vel"], tar=s_["tar"], kin=s_["kin"], clocks=s_["clocks"], flags=s_["flags"])
-                    elif op == OP_AMP_EXPERT:
-                        R.amp[i] = env.amp_expert(1, [R.dargs[i, 0]], R.dargs[i, 1])[0]
-                    elif op == OP_DETACH:
-                        R.owner[i] = 0
-                    R.status[i] = 0
-                except Exception as ex:          # the worker raises; the owner lives on for the others
-                    R.status[i] = -1
-                    sys.stderr.write("deepmimic_amd.broker: op %d of slot %d failed: %r\n" % (op, i, ex))
-                done.append(i)
-            for i in done:
-                R.ack[i] = R.req[i]
-                futex_wake(R.addr("ack", i), 1)
+            P = env.P
+
+            def pack_state(s_, ids):
+                R.big[ids] = np.concatenate([s_["pose"][ids], s_["vel"][ids], s_["tar"][ids], s_["kin"][ids], s_["clocks"][ids], s_["flags"][ids].astype(np.float64)], axis=1)
+
+            try:
+                # every kind of request of the round is served by ONE call for all the slots that made it (a slot has one request pending at a time)
+                rs = pend[ops == OP_RESET]
+                if rs.size:
+                    env.reset(env_ids=rs.astype(np.int32), kin_times=R.dargs[rs, 0], max_times=R.dargs[rs, 1])
+                stp = pend[ops == OP_STEP]
+                snap = stp[R.iargs[stp, 4] != 0] if stp.size else stp            # control steps that may be rolled back: the state they start from
+                gs, ss = pend[ops == OP_GET_STATE], pend[ops == OP_SET_STATE]
+                want = np.concatenate([rs, snap, gs]) if (rs.size or snap.size or gs.size) else rs
+                s_ = env.get_state() if (want.size or ss.size) else None
+                if ss.size:
+                    v = R.big[ss]
+                    s_["pose"][ss] = v[:, :P]; s_["vel"][ss] = v[:, P:2 * P]; s_["tar"][ss] = v[:, 2 * P:3 * P]; s_["kin"][ss] = v[:, 3 * P:3 * P + 7]
+                    s_["clocks"][ss] = v[:, 3 * P + 7:3 * P + 12]; s_["flags"][ss] = v[:, 3 * P + 12:3 * P + 16].astype(np.int32)
+                    env.set_state(pose=s_["pose"], vel=s_["vel"], tar=s_["tar"], kin=s_["kin"], clocks=s_["clocks"], flags=s_["flags"])
+                if want.size:
+                    pack_state(s_, want)
+                t_s0 = time.perf_counter()
+                if stp.size:
+                    kmat = np.column_stack([R.dargs[stp, 0], R.iargs[stp, :4].astype(np.float64)])
+                    uniq, inv = np.unique(kmat, axis=0, return_inverse=True)
+                    for g in range(uniq.shape[0]):
+                        ids = stp[np.ravel(inv) == g].astype(np.int32)
+                        dt, n_upd, has_act, end_early, want_amp = float(uniq[g, 0]), int(uniq[g, 1]), int(uniq[g, 2]), int(uniq[g, 3]), int(uniq[g, 4])
+                        out = env.step_envs(ids, R.action[ids, :A] if has_act else None, dt, n_upd, end_early=bool(end_early), amp=bool(want_amp))
+                        R.state[ids] = out["state"]; R.reward[ids] = out["reward"]
+                        R.flags[ids, 0] = out["terminate"]; R.flags[ids, 1] = out["valid"]; R.flags[ids, 2] = out["episode_end"]
+                        R.clocks[ids] = out["clocks"]
+                        if want_amp and env.amp_size:
+                            R.amp[ids] = out["amp_obs"]
+                        stats["launches"] += 1; stats["steps"] += len(ids)
+                t_s1 = time.perf_counter(); stats["t_step"] += t_s1 - t_s0
+                qs = pend[(ops == OP_QUERY) | (ops == OP_QUERY_AMP)]
+                if qs.size:
+                    q = env.query()
+                    R.state[qs] = q["state"][qs]; R.reward[qs] = q["reward"][qs]
+                    R.flags[qs, 0] = q["terminate"][qs]; R.flags[qs, 1] = q["valid"][qs]; R.flags[qs, 2] = q["episode_end"][qs]; R.flags[qs, 3] = q["need_new_action"][qs]
+                    qa = pend[ops == OP_QUERY_AMP]
+                    if qa.size and env.amp_size:
+                        R.amp[qa] = env.query_amp()[qa]
+                ex = pend[ops == OP_AMP_EXPERT]
+                if ex.size:
+                    R.amp[ex] = env.amp_expert(int(ex.size), R.dargs[ex, 0].copy(), R.dargs[ex, 1].copy())
+                dt_ = pend[ops == OP_DETACH]
+                if dt_.size:
+                    R.owner[dt_] = 0
+                R.status[pend] = 0
+                stats["other_ops"] += int(pend.size - stp.size)
+            except Exception as ex_:          # the workers of this round raise; the owner lives on for the others
+                R.status[pend] = -1
+                t_s1 = time.perf_counter()
+                sys.stderr.write("deepmimic_amd.broker: a round of %d request(s) failed: %r\n" % (pend.size, ex_))
+            done = pend
+            done = np.array(done, dtype=np.int64)
+            R.ack[done] = R.req[done]
+            R.wake[1] = (int(R.wake[1]) + 1) & 0x7FFFFFFF      # one generation word for all workers: one syscall wakes the round
+            futex_wake(gen_addr, 0x7FFFFFFF)
+            t_mark = time.perf_counter(); stats["t_other"] += t_mark - t_s1
     finally:
         R.hdr[0] = 0
         R.hdr[9] = stats["launches"]; R.hdr[10] = stats["steps"]
+        if os.environ.get("DM_BROKER_STATS"):
+            import json
+            with open(os.environ["DM_BROKER_STATS"], "a") as f:
+                f.write(json.dumps(dict(stats, max_workers=W)) + "\n")
         env.close()
         R.close(unlink=True)
         for ext in (".tables", ".lock", ".log"):
@@ -263,7 +294,8 @@ class SharedEnv:
         self.duration, self.D, self.max_contacts = float(m[b]), int(m[b + 1]), int(m[b + 2])
         self.physics, self.num_clips, self.has_obj, self.has_perturbs, self.precision = 1, 1, False, False, precision
         self._timer = (c.timer_type, float(c.time_lim_min), float(c.time_lim_max), float(c.time_lim_exp))
-        self._ack_addr, self._wake_addr = R.addr("ack", self.slot), R.addr("wake", 0)
+        self._gen_addr, self._wake_addr = R.addr("wake", 1), R.addr("wake", 0)
+        self._state, self._snap = None, None
 
     @staticmethod
     def _attach(name, tables, W, device, precision, lib_path, timeout=180.0):
@@ -313,11 +345,11 @@ class SharedEnv:
         R.wake[0] = 1
         futex_wake(self._wake_addr, 1)
         t_end = time.monotonic() + timeout
-        for _ in range(200):                                 # a short spin: the reply to a lone query arrives within microseconds
+        while True:
+            gen = int(R.wake[1])                             # read BEFORE the check: a reply in between changes the word and the wait returns at once
             if int(R.ack[i]) != old:
                 break
-        while int(R.ack[i]) == old:
-            futex_wait(self._ack_addr, old, 0.5)
+            futex_wait(self._gen_addr, gen, 0.5)
             if int(R.ack[i]) == old and time.monotonic() > t_end:
                 raise RuntimeError("DM_FACADE_SHARED: no reply from the owner process within %.0f s" % timeout)
         if int(R.status[i]) != 0:
@@ -338,6 +370,7 @@ class SharedEnv:
         self._ep += 1
         self.R.dargs[self.slot, 0] = kt; self.R.dargs[self.slot, 1] = mt
         self._call(OP_RESET)
+        self._state = self._unpack()                          # the owner hands the reset state back with the reply: get_state() right after costs no round trip
 
     def set_time_limits(self, lo, hi, ex=None):
         self._timer = (self._timer[0], float(lo), float(hi), self._timer[3] if ex is None else float(ex))
@@ -360,8 +393,12 @@ class SharedEnv:
         if actions is not None:
             R.action[i, :self.A] = np.asarray(actions, dtype=np.float32).reshape(self.A)
         R.dargs[i, 0] = float(timestep)
-        R.iargs[i] = (int(n_updates), 0 if actions is None else 1, int(bool(end_early)), int(bool(amp)))
+        snap, self._snap = self._snap, None
+        R.iargs[i, :5] = (int(n_updates), 0 if actions is None else 1, int(bool(end_early)), int(bool(amp)), 0 if snap is None else 1)
+        self._state = None
         self._call(OP_STEP)
+        if snap is not None:
+            snap.update(self._unpack())                       # the state this step started from, captured by the owner for all workers of the round at once
         out = self._out(amp)
         out["clocks"] = R.clocks[i:i + 1].copy()             # kin_time, ctrl_time, init_time_offset, timer_time, timer_max after the step
         return out
@@ -386,11 +423,16 @@ class SharedEnv:
         self._call(OP_AMP_EXPERT)
         return self.R.amp[self.slot:self.slot + 1].copy()
 
-    def get_state(self):
-        self._call(OP_GET_STATE)
+    def _unpack(self):
         v, P = self.R.big[self.slot].copy(), self.P
         return dict(pose=v[None, :P], vel=v[None, P:2 * P], tar=v[None, 2 * P:3 * P], kin=v[None, 3 * P:3 * P + 7], clocks=v[None, 3 * P + 7:3 * P + 12],
                     flags=v[None, 3 * P + 12:3 * P + 16].astype(np.int32))
+
+    def get_state(self):
+        if self._state is not None:
+            return {k: a.copy() for k, a in self._state.items()}
+        self._call(OP_GET_STATE)
+        return self._unpack()
 
     def set_state(self, pose=None, vel=None, tar=None, kin=None, clocks=None, flags=None):
         cur = self.get_state()
@@ -398,10 +440,14 @@ class SharedEnv:
             if a is not None:
                 cur[k] = np.asarray(a, dtype=np.float64).reshape(1, -1)
         self.R.big[self.slot] = np.concatenate([cur["pose"][0], cur["vel"][0], cur["tar"][0], cur["kin"][0], cur["clocks"][0], np.asarray(cur["flags"][0], dtype=np.float64)])
+        self._state = None
         self._call(OP_SET_STATE)
 
     def snapshot(self):
-        return self.get_state()
+        """the rollback point of the control step that follows: filled in by that step() (the owner reads the state of every stepping worker with one
+        copy before the launch), so taking it costs no round trip; a snapshot that is not followed by a step is fetched on first use"""
+        self._snap = _LazySnap(self)
+        return self._snap
 
     def restore(self, snap):
         self.set_state(**{k: snap[k] for k in ("pose", "vel", "tar", "kin", "clocks", "flags")})
@@ -428,6 +474,17 @@ class SharedEnv:
             self.close()
         except Exception:
             pass
+
+
+class _LazySnap(dict):
+    def __init__(self, env):
+        super().__init__(); self._env = env
+
+    def __missing__(self, k):                                 # used before the step that would have filled it
+        if self._env._snap is self:
+            self._env._snap = None
+        self.update(self._env.get_state())
+        return dict.__getitem__(self, k)
 
 
 if __name__ == "__main__":

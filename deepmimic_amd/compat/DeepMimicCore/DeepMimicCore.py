@@ -198,14 +198,14 @@ class cDeepMimicCore(object):
     def _build_time_warper(self):
         self._tw = None
         c = self._tables.cfg
-        if c.scene != "imitate_amp" or not getattr(c, "enable_test_time_warp", True) or self._tables.num_clips > 1:
+        if c.scene != "imitate_amp" or not getattr(c, "enable_test_time_warp", True):
             return
         ends = [x for x in (c.time_lim_max, c.time_end_lim_max) if x is not None]
         max_time = max(ends) if ends else np.inf
         if not np.isfinite(max_time):
             return                                                   # BuildTimeWarper only builds it for a finite episode length
-        self._tw = {"size": int(np.ceil(self._tables.query_rate * max_time)) + 2, "sim": [], "kin": [],
-                    "sampler": _model.KinSampler(self._tables)}
+        # (multi-clip datasets since round 4: the kinematic side is the clip the env was reset to, cClipsController's active motion)
+        self._tw = {"size": int(np.ceil(self._tables.query_rate * max_time)) + 2, "sim": [], "kin": [], "samplers": {}}
 
     def _tw_sample(self, st=None):
         if self._tw is None or self._mode != self.eModeTest:
@@ -221,7 +221,10 @@ class cDeepMimicCore(object):
             out[0] = (0.0, jp[0][1], 0.0)
             return out.reshape(-1)
         self._tw["sim"].append(data(st["pose"][0]))
-        self._tw["kin"].append(data(self._tw["sampler"].pose(float(st["clocks"][0][0]), kin[0:3], kin[3:7])))
+        clip = int(self._env.get_clips()[0]) if self._tables.num_clips > 1 else 0
+        if clip not in self._tw["samplers"]:
+            self._tw["samplers"][clip] = _model.KinSampler(self._tables, clip)
+        self._tw["kin"].append(data(self._tw["samplers"][clip].pose(float(st["clocks"][0][0]), kin[0:3], kin[3:7])))
 
     def _time_warp_reward(self):
         tw = self._tw
@@ -599,14 +602,6 @@ class cDeepMimicCore(object):
         self._mode = int(mode)
         if self._env is not None:
             self._apply_mode()
-        if (self._mode == self.eModeTest and self._tables is not None and self._tables.cfg.scene == "imitate_amp" and self._tables.num_clips > 1
-                and getattr(self._tables.cfg, "enable_test_time_warp", True) and not getattr(self, "_warned_tw", False)):
-            # cSceneImitateAMP::CalcReward returns the dynamic-time-warping alignment cost of the episode in test mode
-            # (SceneImitateAMP.cpp:173-205); served by _time_warp_reward() for single-clip scenes only.
-            import warnings
-            warnings.warn("imitate_amp test mode with a multi-clip dataset: the time-warp test return (cSceneImitateAMP::"
-                          "CalcRewardTimeWarp) is only computed for single-clip scenes; CalcReward() returns 0", RuntimeWarning, stacklevel=2)
-            self._warned_tw = True
 
     def SetSampleCount(self, count):
         """cRLSceneSimChar::SetSampleCount (scenes/RLSceneSimChar.cpp:223-227): anneals the episode-length limits."""

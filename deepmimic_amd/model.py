@@ -710,13 +710,15 @@ def joint_world_positions(tables: SceneTables, pose) -> np.ndarray:
 
 class KinSampler:
     """cKinCharacter::CalcPose on the host (anim/KinCharacter.cpp:363-386, MotionController.cpp:25-41, Motion.cpp:249-293): the
-    pose of the kinematic character at a clip time for a given origin.  Single clip (clip 0 of a dataset)."""
+    pose of the kinematic character at a clip time for a given origin.  `clip`: which clip of a multi-clip dataset (cClipsController's active motion)."""
 
-    def __init__(self, tables: SceneTables):
+    def __init__(self, tables: SceneTables, clip: int = 0):
         self.t = tables
-        n = tables.frames.shape[0] if tables.clip_starts is None else int(tables.clip_starts[1])
-        fr = np.array(tables.frames[:n], dtype=np.float64)
-        self.loop = bool(tables.loop if tables.clip_starts is None else tables.clip_loops[0])
+        if tables.clip_starts is None:
+            fr = np.array(tables.frames, dtype=np.float64)
+        else:
+            fr = np.array(tables.frames[int(tables.clip_starts[clip]):int(tables.clip_starts[clip + 1])], dtype=np.float64)
+        self.loop = bool(tables.loop if tables.clip_starts is None else tables.clip_loops[clip])
         self.times = np.concatenate([[0.0], np.cumsum(fr[:-1, 0])])
         self.frames = fr[:, 1:].copy()
         self.frames[:, 0] -= self.frames[0, 0]; self.frames[:, 2] -= self.frames[0, 2]       # PostProcessMotion

@@ -324,3 +324,53 @@ def test_facade_exponential_timer(emu_lib, monkeypatch):
     assert abs(float(core._env.get_state()["clocks"][0][4]) - model.draw_time_limit("exp", 0.5, 20.0, 5.0, streams.reset_rand01(core._seed, 0, ep, 1))) < 1e-12
     core.SetMode(core.eModeTest); core.Reset()
     assert float(core._env.get_state()["clocks"][0][4]) == 20.0
+
+
+def test_imitate_amp_time_warp_multi_clip(emu_lib, monkeypatch):
+    """round 4: the test-mode time-warp return with a multi-clip dataset (`--kin_ctrl clips`): the kinematic side of the alignment
+    is the clip the env was reset to.  (a) a dataset of two copies of the walk clip scores exactly what the single-clip scene scores from the same
+    start; (b) on a walk + spinkick dataset the host sampler of EVERY clip equals the oracle's kinematic character reset to that clip."""
+    import copy
+    from deepmimic_amd import model
+    mod = _core_module()
+    monkeypatch.setenv("DM_HIP_LIB", emu_lib); monkeypatch.setenv("DM_PRECISION", "64"); monkeypatch.setenv("DM_RNG", "counter")
+    walk, kick = model.load_asset("humanoid3d_walk"), model.load_asset("humanoid3d_spinkick")
+
+    def dataset(a, b):
+        t = copy.deepcopy(a)
+        t.cfg.scene = "imitate_amp"
+        t.cfg.time_lim_min = t.cfg.time_lim_max = t.cfg.time_end_lim_min = t.cfg.time_end_lim_max = 0.2
+        t.frames = np.concatenate([a.frames, b.frames])
+        t.clip_starts = np.array([0, a.frames.shape[0], a.frames.shape[0] + b.frames.shape[0]], np.int32)
+        t.clip_weights = np.array([0.5, 0.5]); t.clip_loops = np.array([int(a.loop), int(b.loop)], np.int32)
+        return t
+
+    def episode(t, kin_time):
+        core = mod.cDeepMimicCore(False)
+        core.SeedRand(2); core.LoadTables(t, 10); core.Init()
+        core.SetMode(core.eModeTest); core.Reset()
+        clip = int(core._env.get_clips()[0]) if t.num_clips > 1 else 0
+        core._env.reset(kin_times=[kin_time], max_times=[0.2]); core._after_reset.__self__._sync_clocks()      # same start for both runs
+        core._tw["sim"], core._tw["kin"] = [], []; core._tw_sample()
+        while True:
+            if core.NeedNewAction(0):
+                core.SetAction(0, [0.0] * core.GetActionSize(0))
+            core.Update(1.0 / 600)
+            if core.IsEpisodeEnd():
+                break
+        return core.CalcReward(0), clip, core
+
+    single = copy.deepcopy(walk); single.cfg.scene = "imitate_amp"
+    single.cfg.time_lim_min = single.cfg.time_lim_max = single.cfg.time_end_lim_min = single.cfg.time_end_lim_max = 0.2
+    r1, _, _ = episode(single, 0.3)
+    r2, clip, core = episode(dataset(walk, walk), 0.3)
+    assert r1 == r2 and r1 > 0, (r1, r2, clip)
+    # (b) the sampler of each clip against the oracle's kinematic character reset to that clip (oracle: pinned to the reference's cKinCharacter / cClipsController)
+    from oracle_lib import Oracle
+    t = dataset(walk, kick)
+    o = Oracle(t)
+    for clip, kt in ((0, 0.3), (1, 0.45), (1, 1.1), (0, 1.9)):
+        o.reset_ex(kt, np.inf, clip, 0.0)
+        kp, _, ko = o.kin_state()
+        want = model.KinSampler(t, clip).pose(kt, ko[0:3], ko[3:7])
+        assert np.abs(kp - want).max() < 1e-12, (clip, kt, np.abs(kp - want).max())

@@ -35,6 +35,8 @@ template <int P> static inline void dm_setprio() {}
 #define DM_OPAQUE_D(x) ((void)0)
 #define DM_SCHED_FENCE() ((void)0)
 static inline int dm_atomic_or(int* p, int v) { int o = *p; *p = o | v; return o; }
+static inline int dm_atomic_min(int* p, int v) { int o = *p; if (v < o) *p = v; return o; }
+static inline int dm_atomic_add(int* p, int v) { int o = *p; *p = o + v; return o; }
 static inline int dm_popc64(uint64_t v) { return __builtin_popcountll(v); }
 static inline int dm_ctz32(uint32_t v) { return __builtin_ctz(v); }
 namespace dmk {
@@ -104,6 +106,8 @@ template <> struct VecT<double> { typedef double v2 __attribute__((vector_size(1
 __device__ __forceinline__ long long dm_clock() { return (long long)__builtin_readcyclecounter(); }
 template <int P> __device__ __forceinline__ void dm_setprio() { __builtin_amdgcn_s_setprio(P); }
 __device__ __forceinline__ int dm_atomic_or(int* p, int v) { return atomicOr(p, v); }
+__device__ __forceinline__ int dm_atomic_min(int* p, int v) { return atomicMin(p, v); }
+__device__ __forceinline__ int dm_atomic_add(int* p, int v) { return atomicAdd(p, v); }
 __device__ __forceinline__ int dm_popc64(uint64_t v) { return __popcll(v); }
 __device__ __forceinline__ int dm_ctz32(uint32_t v) { return __builtin_ctz(v); }
 namespace dmk {
@@ -1044,7 +1048,13 @@ struct EnvSim {
         int cnt = 0; Real lp[4][3], bxz[4][2], dist[4];
         Real* mfp = manif + (l < J ? l : 0) * MF_STRIDE;
         const bool has_body = l < J && s.mdl.thresh[l < J ? l : 0] > (Real)0;
-        // every lane evaluates its candidate points first (lane = candidate): distance into cdistc for the links' argmin below
+        // every lane evaluates its candidate points first (lane = candidate): distance into cdistc for the links' argmin below.  The candidates of a
+        // link are contiguous (build_host_model adds them link by link): each candidate lane reports its index to its link's [first, count) cell in
+        // LDS, so the link lane scans its own <= 8 distances instead of all NC candidate records in global memory (round 4: v2 two-per-wave +7.8 %)
+        int* crange = &s.csel[0];                      // 2 x 32 ints (the cap path below reuses csel afterwards)
+        static_assert(NCAP >= 64 && NJ <= 32, "csel holds the per-link candidate ranges");
+        if (l < 32) { crange[l] = 0x7fffffff; crange[32 + l] = 0; }
+        sync();
 #pragma unroll
         for (int q = 0; q < CPL; ++q) {
             const int c = l + kWave * q;
@@ -1052,8 +1062,11 @@ struct EnvSim {
                 const int link = cand_link[q];
                 v3 x = ld3(s.com[link]) + ldm3(Rbp(link)) * mk3(cand_loc[q][0], cand_loc[q][1], cand_loc[q][2]);
                 s.cdistc[c] = x.y - cand_rad[q];
+                dm_atomic_min(&crange[link], c); dm_atomic_add(&crange[32 + link], 1);
             }
         }
+        sync();
+        const int cfirst = crange[l & 31], ccount = crange[32 + (l & 31)];
         sync();
         if (has_body) {
             const Real thr = s.mdl.thresh[l];
@@ -1072,7 +1085,7 @@ struct EnvSim {
             }
             // the new point: the deepest candidate of this link (its support point along -n), first on ties
             int best = -1; Real bd = 0;
-            for (int c = 0; c < m.NC; ++c) if (m.cand_link[c] == l) { const Real d = s.cdistc[c]; if (best < 0 || d < bd) { best = c; bd = d; } }
+            for (int c = cfirst; c < cfirst + ccount; ++c) { const Real d = s.cdistc[c]; if (best < 0 || d < bd) { best = c; bd = d; } }
             if (best >= 0 && bd < thr) {
                 v3 x = com + Rb * mk3(m.cand_loc[best * 3], m.cand_loc[best * 3 + 1], m.cand_loc[best * 3 + 2]);
                 x.y -= m.cand_rad[best];

@@ -422,6 +422,12 @@ _Pragma("unroll") \
         int cnt = 0; Real lp[4][3], bxz[4][2], dist[4];
         Real* mfp = manif + (hl < J ? hl : 0) * MF_STRIDE;
         const bool has_body = hl < J && s.mdl.thresh[hl < J ? hl : 0] > (Real)0;
+        // the candidates of a link are contiguous (build_host_model adds them link by link): every candidate lane reports its index to its link's
+        // [first, count) cell in LDS, so the link lane scans its own <= 8 distances instead of all NC candidate records in global memory
+        int* crange = &s.csel[0];                      // 2 x 16 ints (the cap path below reuses csel afterwards)
+        static_assert(C::NCAP >= 64 && C::NJ <= 16, "csel holds the per-link candidate ranges");
+        if (hl < 16) { crange[hl] = 0x7fffffff; crange[16 + hl] = 0; }
+        sync();
 #pragma unroll
         for (int q = 0; q < CP; ++q) {
             const int c = hl + HW * q;
@@ -429,8 +435,11 @@ _Pragma("unroll") \
                 const int link = cand_link[q];
                 v3 x = ld3(s.com[link]) + ldm3(b.Rbp(link)) * mk3(cand_loc[q][0], cand_loc[q][1], cand_loc[q][2]);
                 s.cdistc[c] = x.y - cand_rad[q];
+                dm_atomic_min(&crange[link], c); dm_atomic_add(&crange[16 + link], 1);
             }
         }
+        sync();
+        const int cfirst = crange[hl & 15], ccount = crange[16 + (hl & 15)];
         sync();
         if (has_body) {
             const Real thr = s.mdl.thresh[hl];
@@ -447,7 +456,7 @@ _Pragma("unroll") \
                 }
             }
             int best = -1; Real bd = 0;                 // the new point: the deepest candidate of this link, first on ties
-            for (int c = 0; c < m.NC; ++c) if (m.cand_link[c] == hl) { const Real d = s.cdistc[c]; if (best < 0 || d < bd) { best = c; bd = d; } }
+            for (int c = cfirst; c < cfirst + ccount; ++c) { const Real d = s.cdistc[c]; if (best < 0 || d < bd) { best = c; bd = d; } }
             if (best >= 0 && bd < thr) {
                 v3 x = com + Rb * mk3(m.cand_loc[best * 3], m.cand_loc[best * 3 + 1], m.cand_loc[best * 3 + 2]);
                 x.y -= m.cand_rad[best];

@@ -76,3 +76,35 @@ def test_bench_physics_2_and_dog(emu_lib):
     p, line = run_bench(emu_lib, ["--gpus", "1", "--scene", "dog3d_pace"])
     assert p.returncode == 0, p.stderr[-2000:]
     assert line["roofline"]["kernel"] == "k_env_step" and line["roofline"]["algorithmic_bytes_per_env_step"] > 2420 and line["checks"]["finite"]
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+def test_bench_record_exchange_through_cabi_is_hidden_gpu(hip_lib):
+    """`bench.py --gpus 1 --force-gather --gather cabi` drives the C-ABI record exchange (dm_comm_* / dm_gather_records: real RCCL, one rank)
+    double-buffered behind the step kernel; what it leaves exposed on the critical path must stay below 50 us per control step"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "DM_HIP_LIB", "DM_ALLOW_EMULATOR")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "100", "--warmup", "10", "--force-gather", "--gather", "cabi",
+                        "--no-cpu-baseline", "--sustain-seconds", "0"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["record_exchange"]["backend"] == "cabi" and line["config"]["groups"] == 1
+    assert line["record_exchange"]["exposed_ms_per_step_rank0"] < 0.05, line["record_exchange"]
+    assert line["value"] > 1.0e6 and line["checks"]["finite"]
+
+
+@pytest.mark.gpu
+def test_bench_default_line_gpu(hip_lib):
+    """the driver's command: the line carries the two env groups, the binding bound (roofline.valu) and the sustained window"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "DM_HIP_LIB", "DM_ALLOW_EMULATOR")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "5", "--no-cpu-baseline"], env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["config"]["groups"] == 2 and line["roofline"]["concurrent_launches"] == 2 and line["roofline"]["kernel"] == "k_env_step_duo"
+    assert line["value"] > 1.5e6 and line["sustained"]["seconds"] >= 2.0 and 0.9 < line["sustained"]["ratio_to_value"] < 1.2
+    v = line["roofline"]["valu"]
+    assert v and 0.3 < v["valu_busy"] < 1.0 and v["source"] and 0.01 < v["frac_of_fp32_peak"] < 1.0
+    assert abs(line["ms_per_step"] * line["value"] / 1e3 - 4096) < 1.0

@@ -11,7 +11,7 @@ if os.environ.get("DM_AB_AMP") == "1": t.cfg.scene = "imitate_amp"          # th
 envs = {}
 for p in sys.argv[4:]:
     path = os.path.join(ROOT, p)
-    env = core.BatchEnv(t, n, seed=1234, test_mode=True, wave_packing=pack, lib_path=path)
+    env = core.BatchEnv(t, n, seed=1234, test_mode=True, wave_packing=pack, lib_path=path, physics=int(os.environ.get("DM_AB_PHYSICS", "1")))
     env.reset(kin_times=streams.reset_phase(np.arange(n), env.duration))
     env.bench_rollout(60, 1)
     envs[p] = env

@@ -75,4 +75,30 @@ for ph in range(2):
         env9.step_device(ac.data_ptr(), st.data_ptr(), rw.data_ptr(), tm.data_ptr(), vd.data_ptr(), en.data_ptr(), auto_reset=True)
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
 out["closed_loop_max_contacts_9_env_steps_per_s"] = n * steps / dt
+# the closed loop as TWO env groups (deepmimic_amd/groups.py): policy(A) -> step(A) on group A's stream while B is stepping, and vice versa.  One Policy
+# object per group (its activation buffers are per object); actions / observations are the groups' rows of the same tensors.
+from deepmimic_amd.groups import EnvGroups            # noqa: E402
+grp = EnvGroups(t, n, groups=2, seed=1)
+grp.reset()
+pols = [Policy(w) for _ in range(grp.G)]
+gst = [e.own_stream() for e in grp.envs]
+ptr = lambda tns, g, width: tns.data_ptr() + 4 * grp.start[g] * width
+
+
+def grouped(k, **kw):
+    for g in range(grp.G):
+        pols[g].forward_device(ptr(st, g, env.S), grp.count[g], ptr(ac, g, env.A), 0, sample=True, seed=1, step=k, env_id_offset=grp.first[g], stream=gst[g])
+        grp.step_group_device(g, ac.data_ptr(), st.data_ptr(), rw.data_ptr(), tm.data_ptr(), vd.data_ptr(), en.data_ptr(), auto_reset=True, **kw)
+
+
+torch.cuda.synchronize()
+for g in range(grp.G):
+    grp.step_group_device(g, 0, st.data_ptr(), rw.data_ptr(), tm.data_ptr(), vd.data_ptr(), en.data_ptr(), n_updates=0)
+for k in range(10):
+    grouped(k)
+grp.synchronize(); torch.cuda.synchronize(); t0 = time.perf_counter()
+for k in range(steps):
+    grouped(k)
+grp.synchronize(); torch.cuda.synchronize(); dt = time.perf_counter() - t0
+out["closed_loop_2_groups_env_steps_per_s"] = n * steps / dt
 print(json.dumps(out))

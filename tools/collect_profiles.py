@@ -30,7 +30,7 @@ if os.path.exists(os.path.join(src, "stats_policy", "stats_kernel_stats.csv")):
     with open(os.path.join(dst, out + "_rocprofv3_kernel_stats_closed_loop.csv"), "w", newline="") as f:
         csv.writer(f).writerows(rows[:12])
 # 2. bench lines and reports
-for name in ("bench.json", "bench_spinkick.json", "bench_dog.json", "bench_dog_dense.json", "bench_pack1.json", "bench_facade.json", "policy_bench.json", "policy_bench_16384.json",
+for name in ("bench.json", "bench_driver_style.json", "bench_groups1.json", "bench_physics2.json", "bench_8192.json", "bench_record_exchange_rccl_groups_1rank.json", "bench_spinkick.json", "bench_dog.json", "bench_dog_dense.json", "bench_pack1.json", "bench_facade.json", "policy_bench.json", "policy_bench_16384.json",
              "bench_amp_heading_zombie.json", "bench_amp_dribble_zombie.json", "bench_scenes.json",
              "parity_report.json", "tail_probe.txt", "tail_probe_closed_loop.txt", "bench_record_exchange_1rank.json", "bench_record_exchange_cabi_1rank.json"):
     if os.path.exists(os.path.join(src, name)) and os.path.getsize(os.path.join(src, name)) > 0:
@@ -76,7 +76,7 @@ for scene, sfx in SCENES:
         # patch the bench line of this scene: bench.py read the traffic file of the PREVIOUS collection while this round's PMC passes were still to come
         dstb = os.path.join(dst, out + "_" + bname)
         _b = json.load(open(dstb))
-        _b["roofline"]["traffic"] = traffic["hbm_bytes_per_launch"]
+        _b["roofline"]["traffic"] = traffic["hbm_bytes_per_launch"] * _b["config"].get("envs_per_launch", n) / n      # (groups: a launch carries its share of the envs)
         open(dstb, "w").write(json.dumps(_b) + "\n")
     except Exception as ex:
         print("traffic of", scene, "skipped:", ex)
@@ -101,6 +101,10 @@ try:
     summary["flops"] = valu + mfma
 except Exception as ex:
     print("flop counters skipped:", ex)
+if os.path.exists(os.path.join(src, "stats_g1", "stats_kernel_stats.csv")):
+    rows = list(csv.reader(open(os.path.join(src, "stats_g1", "stats_kernel_stats.csv"))))
+    with open(os.path.join(dst, out + "_rocprofv3_kernel_stats_groups1.csv"), "w", newline="") as f:
+        csv.writer(f).writerows(rows[:6])
 if os.path.exists(os.path.join(src, "stats_dog", "stats_kernel_stats.csv")):
     rows = list(csv.reader(open(os.path.join(src, "stats_dog", "stats_kernel_stats.csv"))))
     with open(os.path.join(dst, out + "_rocprofv3_kernel_stats_dog3d_pace.csv"), "w", newline="") as f:

@@ -257,7 +257,7 @@ def serve(name: str, tables_path: str, max_workers: int, device: int, precision:
                 f.write(json.dumps(dict(stats, max_workers=W)) + "\n")
         env.close()
         R.close(unlink=True)
-        for ext in (".tables", ".lock", ".log"):
+        for ext in (".tables", ".log"):          # (the lock file stays: a worker may be blocked on it right now, and a second inode under the same name would let two owners start)
             try:
                 if ext != ".log" or os.path.getsize("/dev/shm/%s.log" % name) == 0:
                     os.unlink("/dev/shm/%s%s" % (name, ext))

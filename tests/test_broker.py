@@ -87,7 +87,15 @@ def test_shared_workers_equal_private_contexts(emu_lib, scene, rng_mode):
             assert x[0] == y[0] and np.array_equal(x[1], y[1]) and x[2] == y[2], (r, x[0])
         assert any(x[0] == "f" and x[1][0] == 1.0 for x in a)                       # an episode ended inside the window
         assert shared[r][1]["rollbacks"] == private[r][1]["rollbacks"] == 2
-    assert not os.path.exists("/dev/shm/" + shm) or True                            # (the owner leaves a few seconds after its last worker)
+    # the owner leaves a few seconds after its last worker and takes the region with it; the (empty) lock file is the test's to remove
+    import glob
+    import time
+    t_end = time.monotonic() + 15
+    while os.path.exists("/dev/shm/" + shm) and time.monotonic() < t_end:
+        time.sleep(0.2)
+    assert not os.path.exists("/dev/shm/" + shm), "the owner process did not leave"
+    for f in glob.glob("/dev/shm/%s.*" % shm):
+        os.unlink(f)
 
 
 def test_region_layout_round_trip():

@@ -81,3 +81,77 @@ class TorchVecEnv:
 
     def close(self):
         self.env.close()
+
+
+class TorchVecEnvGroups:
+    """`TorchVecEnv` as G env groups on their own streams (deepmimic_amd/groups.py; round 4): the batch's tensors are shared, group g owns the rows
+    `rows(g)`, and its control step runs on `stream(g)` -- a learner runs policy(g) on that stream right before `step_group(g, ...)` and works on
+    another group meanwhile, the way double-buffered samplers do; the groups then drift apart in phase and fill each other's wave-time tail
+    (closed loop with the on-device policy, 4096 humanoids: 2.14 M env-steps/s against 2.05 M with one launch per step, profiles/r04_policy_bench.json).
+    `step(actions)` is the synchronous convenience: all groups, then the caller's current stream waits for them.  Env i follows the same trajectory
+    as in a `TorchVecEnv` of the whole batch (draws are keyed by the global env id; tests/test_vec_env.py)."""
+
+    def __init__(self, tables: SceneTables, num_envs: int, groups: int = 2, device: str = "cuda:0", seed: int = 0, timestep: float = 1.0 / 600,
+                 updates_per_step: int = 20, **env_kwargs):
+        import torch
+        from .groups import EnvGroups
+        self.torch = torch
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("TorchVecEnvGroups needs a GPU device (deepmimic_amd has no CPU path)")
+        with torch.cuda.device(self.device):
+            torch.zeros(1, device=self.device)
+            self.g = EnvGroups(tables, num_envs, groups=groups, device_id=self.device.index or 0, seed=seed, **env_kwargs)
+        self.G, self.n, self.obs_dim, self.act_dim = self.g.G, self.g.N, self.g.S, self.g.A
+        self.timestep, self.updates = float(timestep), int(updates_per_step)
+        f32, i32 = dict(dtype=torch.float32, device=self.device), dict(dtype=torch.int32, device=self.device)
+        self.obs = torch.zeros((self.n, self.obs_dim), **f32); self.reward = torch.zeros(self.n, **f32)
+        self.terminate = torch.zeros(self.n, **i32); self.valid = torch.zeros(self.n, **i32); self.episode_end = torch.zeros(self.n, **i32)
+        # the contexts' own streams (created back to back: distinct hardware queues), visible to torch as external streams
+        self.streams = [torch.cuda.ExternalStream(e.own_stream(), device=self.device) for e in self.g.envs]
+
+    def rows(self, g: int) -> slice:
+        return self.g.rows(g)
+
+    def stream(self, g: int):
+        return self.streams[g]
+
+    def _launch(self, g, actions_ptr, n_updates, auto_reset):
+        self.g.step_group_device(g, actions_ptr, self.obs.data_ptr(), self.reward.data_ptr(), self.terminate.data_ptr(), self.valid.data_ptr(),
+                                 self.episode_end.data_ptr(), timestep=self.timestep, n_updates=n_updates, auto_reset=auto_reset)
+
+    def reset(self):
+        self.g.reset()
+        for g in range(self.G):
+            self._launch(g, 0, 0, False)
+        self._join()
+        return self.obs
+
+    def step_group(self, g: int, actions):
+        """Control step of group g, asynchronous on `stream(g)`.  `actions`: the WHOLE batch's (N, A) tensor (the group reads its rows) written on
+        `stream(g)` (or ordered before it by the caller).  Returns views of the group's rows: (obs, reward, done, info) -- valid on `stream(g)`."""
+        t = self.torch
+        if actions.device != self.device or actions.dtype != t.float32 or tuple(actions.shape) != (self.n, self.act_dim) or not actions.is_contiguous():
+            raise ValueError("actions must be the contiguous float32 (N, A) tensor of the whole batch on %s" % self.device)
+        self._launch(g, actions.data_ptr(), self.updates, True)
+        r = self.rows(g)
+        with t.cuda.stream(self.streams[g]):
+            done = (self.episode_end[r] != 0) | (self.valid[r] == 0)
+        return self.obs[r], self.reward[r], done, {"terminate": self.terminate[r], "valid": self.valid[r]}
+
+    def _join(self):
+        cur = self.torch.cuda.current_stream(self.device)
+        for s in self.streams:
+            cur.wait_stream(s)
+
+    def step(self, actions):
+        """all groups (each on its stream, ordered behind the caller's current stream), then the current stream waits for them"""
+        cur = self.torch.cuda.current_stream(self.device)
+        for g in range(self.G):
+            self.streams[g].wait_stream(cur)
+            self._launch(g, actions.data_ptr(), self.updates, True)
+        self._join()
+        return self.obs, self.reward, (self.episode_end != 0) | (self.valid == 0), {"terminate": self.terminate, "valid": self.valid}
+
+    def close(self):
+        self.g.close()

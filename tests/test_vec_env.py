@@ -92,3 +92,38 @@ def test_vec_env_follows_the_current_stream(hip_lib):
         out = ref.step(a, ve.timestep, ve.updates, auto_reset=True)
         assert np.array_equal(o2, out["state"]) and np.array_equal(r2, out["reward"]), k
     ve.close(); ref.close()
+
+
+@pytest.mark.gpu
+def test_vec_env_groups_match_single_launch(hip_lib):
+    """TorchVecEnvGroups (two env groups on their own streams, round 4): env by env the same observations, rewards and done flags as TorchVecEnv over
+    the whole batch, both through the synchronous step() and through per-group step_group() calls issued out of order"""
+    import torch
+    from deepmimic_amd.vec_env import TorchVecEnv, TorchVecEnvGroups
+    t = model.load_asset("humanoid3d_walk")
+    n = 128
+    one = TorchVecEnv(t, n, seed=4, lib_path=hip_lib)
+    grp = TorchVecEnvGroups(t, n, groups=2, seed=4, lib_path=hip_lib)
+    assert grp.G == 2 and grp.rows(1) == slice(64, 128)
+    assert torch.equal(one.reset(), grp.reset())
+    rng = np.random.default_rng(1)
+    ends = 0
+    for k in range(30):
+        a = torch.from_numpy((0.2 * rng.normal(size=(n, one.act_dim))).astype(np.float32)).to(one.device)
+        o1, r1, d1, _ = one.step(a)
+        if k % 2 == 0:
+            o2, r2, d2, _ = grp.step(a)
+        else:                                        # per-group calls, group 1 first; outputs consumed after joining both streams
+            torch.cuda.current_stream().synchronize()
+            parts = {}
+            for g in (1, 0):
+                parts[g] = grp.step_group(g, a)
+            for g in (0, 1):
+                grp.stream(g).synchronize()
+            o2, r2 = grp.obs, grp.reward
+            d2 = torch.cat([parts[0][2], parts[1][2]])
+        torch.cuda.synchronize()
+        assert torch.equal(o1, o2) and torch.equal(r1, r2) and torch.equal(d1, d2), k
+        ends += int(d1.sum().item())
+    assert ends > 0
+    one.close(); grp.close()

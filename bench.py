@@ -38,6 +38,19 @@ def algorithmic_bytes_per_env_step(env):
     return 2 * rec + out
 
 
+def kernel_source_sha1():
+    """hash of the device sources this run's library was built from (tools/collect_profiles.py stamps the same hash into every counter file)"""
+    import hashlib
+    h = hashlib.sha1()
+    try:
+        for f in ("dm_device.h", "dm_device_duo.h", "dm_types.h", "dm_math.h", "Makefile"):
+            with open(os.path.join(ROOT, "deepmimic_amd", "csrc", f), "rb") as fh:
+                h.update(fh.read())
+        return h.hexdigest()
+    except OSError:
+        return None
+
+
 def measured_traffic(scene, n, kernel=None):
     """(HBM bytes per step-kernel launch, source file) from the committed rocprofv3 PMC passes (profiles/r0N_traffic*.json,
     collected as MI355X_MICROARCH.md prescribes: separate --pmc passes for FETCH_SIZE and WRITE_SIZE; tools/collect_profiles.py),
@@ -50,6 +63,7 @@ def measured_traffic(scene, n, kernel=None):
             with open(path) as f:
                 t = json.load(f)
             if t.get("scene") == scene and int(t.get("envs", -1)) == n and (kernel is None or t.get("kernel", kernel) == kernel):
+                measured_traffic.current = (t.get("kernel_source_sha1") == kernel_source_sha1()) if t.get("kernel_source_sha1") else None
                 return float(t["hbm_bytes_per_launch"]), os.path.relpath(path, ROOT)
         except Exception:
             continue
@@ -70,6 +84,7 @@ def measured_valu(scene, n, kernel, env_steps_per_s):
                 t = json.load(f)
             if t.get("scene") == scene and int(t.get("envs", -1)) == n and t.get("kernel", kernel) == kernel:
                 out["valu_busy"] = t["derived"]["valu_busy_fraction_of_simd_time"]
+                out["source_current"] = (t.get("kernel_source_sha1") == kernel_source_sha1()) if t.get("kernel_source_sha1") else None
                 out["wait_fraction"] = t["SQ_WAIT_ANY"] / t["SQ_WAVE_CYCLES"]
                 out["valu_instructions_per_env_step"] = t["derived"]["valu_instructions_per_env_step"]
                 out["source"].append(os.path.relpath(path, ROOT))
@@ -477,7 +492,11 @@ def main():
             "sim_updates_per_s": value * 20,
             "per_rank_env_steps_per_s": per_rank, "record_exchange": {"backend": (args.gather if gather else None), "exposed_ms_per_step_rank0": exposed_ms},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
-                         "traffic": traffic, "traffic_source": traffic_source, "kernel": kname, "kernel_ms": kernel_ms,
+                         "traffic": traffic, "traffic_source": traffic_source,
+                         # true: the committed counter file was taken on exactly the device sources this library was built from; false: a kernel has changed since
+                         # (re-profile: tools/gpu_round_profile.sh); null: the file predates the stamp
+                         "traffic_source_current": getattr(measured_traffic, "current", None),
+                         "kernel": kname, "kernel_ms": kernel_ms,
                          "concurrent_launches": G, "achieved_all_streams": (achieved * G) if achieved else None,
                          "valu": measured_valu(args.scene, n, kname, value),
                          "algorithmic_bytes_per_env_step": algorithmic_bytes_per_env_step(env),

@@ -12,6 +12,15 @@ src = os.path.join(ROOT, "gpurun_out", tag); dst = os.path.join(ROOT, "profiles"
 os.makedirs(dst, exist_ok=True)
 
 
+def kernel_source_sha1():
+    """hash of the device sources the counters were taken on: bench.py compares it with the sources it runs and says when a committed counter file is stale"""
+    import hashlib
+    h = hashlib.sha1()
+    for f in ("dm_device.h", "dm_device_duo.h", "dm_types.h", "dm_math.h", "Makefile"):
+        h.update(open(os.path.join(ROOT, "deepmimic_amd", "csrc", f), "rb").read())
+    return h.hexdigest()
+
+
 def agg(path):
     a = collections.defaultdict(lambda: collections.defaultdict(float))
     for r in csv.DictReader(open(path)):
@@ -45,7 +54,7 @@ for scene, sfx in SCENES:
     b = json.load(open(os.path.join(src, bname)))
     n = b["config"]["envs_per_gpu"]
     # 3. PMC passes
-    pmc = {"scene": scene, "envs": n, "kernel": b["roofline"]["kernel"],
+    pmc = {"scene": scene, "envs": n, "kernel": b["roofline"]["kernel"], "kernel_source_sha1": kernel_source_sha1(),
            "note": "per-launch means of the step kernel; SQ_*_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* are quad-cycles (MI355X_MICROARCH.md)"}
     try:
         for d in ("pmc_sq", "pmc_sq2"):
@@ -66,7 +75,7 @@ for scene, sfx in SCENES:
     try:
         f = np.mean([v["FETCH_SIZE"] for v in agg(os.path.join(src, "pmc_fetch" + sfx, "pmc_counter_collection.csv"))])
         w = np.mean([v["WRITE_SIZE"] for v in agg(os.path.join(src, "pmc_write" + sfx, "pmc_counter_collection.csv"))])
-        traffic = {"scene": scene, "envs": n, "kernel": b["roofline"]["kernel"], "fetch_size_kib_raw": float(f), "write_size_kib_raw": float(w),
+        traffic = {"scene": scene, "envs": n, "kernel": b["roofline"]["kernel"], "kernel_source_sha1": kernel_source_sha1(), "fetch_size_kib_raw": float(f), "write_size_kib_raw": float(w),
                    "fetch_bytes_per_launch": float(f) * 1024 * 2, "write_bytes_per_launch": float(w) * 1024,
                    "hbm_bytes_per_launch": float(f) * 1024 * 2 + float(w) * 1024,
                    "algorithmic_bytes_per_launch": b["roofline"]["algorithmic_bytes_per_launch"],
@@ -90,7 +99,7 @@ try:
     valu = 64.0 * (m["SQ_INSTS_VALU_ADD_F32"] + m["SQ_INSTS_VALU_MUL_F32"] + 2 * m["SQ_INSTS_VALU_FMA_F32"] + m["SQ_INSTS_VALU_TRANS_F32"])
     mfma = 512.0 * (m["SQ_INSTS_VALU_MFMA_MOPS_F32"] + m["SQ_INSTS_VALU_MFMA_MOPS_F64"])
     rate = b["value"]
-    json.dump({"scene": "humanoid3d_walk", "envs": n, "kernel": b["roofline"]["kernel"], "per_env_step_wave_instructions": m,
+    json.dump({"scene": "humanoid3d_walk", "envs": n, "kernel": b["roofline"]["kernel"], "kernel_source_sha1": kernel_source_sha1(), "per_env_step_wave_instructions": m,
                "issued_fp32_valu_lane_flops_per_env_step": valu, "matrix_core_flops_per_env_step": mfma,
                "issued_flops_per_env_step": valu + mfma, "env_steps_per_s": rate,
                "issued_tflops": (valu + mfma) * rate / 1e12, "valu_tflops": valu * rate / 1e12,

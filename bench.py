@@ -3,11 +3,14 @@
 
     python bench.py --gpus N --steps K --warmup W [--envs 4096] [--scene humanoid3d_walk]
 
-One "step" = one 30 Hz control step of every env on the rank = one `k_env_step` launch = 20 scene updates
-(20 SPD solves + 40 rigid-body substeps) + reward + observation + auto-reset.  Workload (configs[1] of BASELINE.json):
-humanoid3d_walk, 4096 envs per GPU, fixed-action stream A1 (open-loop mocap tracking, generated on device), inputs
-resident in HBM.  N > 1: one process per GPU (torch.distributed, backend nccl = RCCL), env shards are independent
-(weak scaling); the only collective is the per-step all-gather of (state, reward, terminate) for the learner.
+One "step" = one 30 Hz control step of EVERY env on the rank = 20 scene updates (20 SPD solves + 40 rigid-body substeps) + reward + observation
++ auto-reset per env.  By default (`--groups 0` = auto) the rank's envs run as two env groups of n / 2 on their own streams (deepmimic_amd/groups.py:
+two `k_env_step_duo` launches of 2048 envs per control step, drifting apart in phase and filling each other's wave-time tail); `--groups 1` is one
+launch per control step.  Workload (configs[1] of BASELINE.json): humanoid3d_walk, 4096 envs per GPU, fixed-action stream A1 (open-loop mocap tracking,
+generated on device), inputs resident in HBM.  The line carries `roofline` (per launch; `valu` = the binding figures from the committed counter files,
+stamped with the kernel sources they were taken on), `sustained` (a >= 2.5 s window behind the timed steps) and `cpu_baseline`.
+N > 1: one process per GPU (torch.distributed, backend nccl = RCCL), env shards are independent (weak scaling); the only collective is the per-step
+all-gather of (state, reward, terminate) for the learner, one exchange per env group on the group's stream.
 `python bench.py --gpus N` with no WORLD_SIZE in the environment launches its own N ranks (one per GPU, rank r on GPU r) under
 `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1` -- the reference's precedent for a
 self-launching driver is mpi_run.py:16-24 (`mpiexec -n W python3 DeepMimic_Optimizer.py`); under an external launcher

@@ -243,9 +243,11 @@ class SceneTables:
 
     def clip_duration(self, c: int) -> float:
         """cMotion::GetDuration of clip c: the frame durations but the last one's (anim/Motion.cpp PostProcessFrames)"""
-        if self.clip_starts is None:
-            return float(self.frames[:-1, 0].sum())
-        return float(self.frames[int(self.clip_starts[c]):int(self.clip_starts[c + 1]) - 1, 0].sum())
+        col = self.frames[:-1, 0] if self.clip_starts is None else self.frames[int(self.clip_starts[c]):int(self.clip_starts[c + 1]) - 1, 0]
+        d = 0.0
+        for x in col.tolist():        # in frame order, like the reference's loop (numpy's sum is pairwise: other last bits)
+            d += x
+        return d
 
     @property
     def getup_time(self) -> float:

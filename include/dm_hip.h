@@ -294,6 +294,20 @@ int dm_refrand_int(dm_refrand* r);                                    /* cRand::
 int dm_refrand_int_range(dm_refrand* r, int min, int max);            /* cRand::RandInt(min, max) */
 int dm_refrand_uint(dm_refrand* r);                                   /* cRand::RandUint() */
 
+/* ---- Native scene loading: cDeepMimicCore::ParseArgs (DeepMimicCore.cpp:25-44) + the ParseArgs / file loading of the scene classes the path serves,
+ * in C++ inside the library (deepmimic_amd/csrc/dm_scene_load.h), so that a native host goes from the reference's own arg file to a running context
+ * without Python:   dm_scene_load(args, n, data_root, test_mode, &scene);  dm_create(&info, dm_scene_get_tables(scene), &ctx);
+ * `args` are command-line style tokens ("--arg_file", "args/run_humanoid3d_walk_args.txt", or the keys themselves; the first occurrence of a key
+ * wins, util/ArgParser.cpp:31-120); relative paths resolve against data_root (the reference resolves them against its working directory).
+ * test_mode: the episode timer pinned to time_end_lim_max (scenes/RLSceneSimChar.cpp:277-284).  The tables belong to the scene handle.
+ * dm_scene_info out[8] = num_update_substeps, anneal_samples, time_end_lim_min, time_end_lim_max, time_end_lim_exp, time_lim_exp, timer type (0 uniform,
+ * 1 exp: call dm_set_timer_exp(ctx, time_lim_exp)), reserved -- what a driver needs beside the tables (SetSampleCount annealing, Update substeps). */
+typedef struct dm_scene dm_scene;
+int dm_scene_load(const char* const* args, int n_args, const char* data_root, int test_mode, dm_scene** out);
+const dm_scene_tables* dm_scene_get_tables(const dm_scene* scene);
+int dm_scene_info(const dm_scene* scene, double* out);
+int dm_scene_free(dm_scene* scene);
+
 /* ---- On-device policy inference: the actor of learning/pg_agent.py:141-188 with the net of
  * learning/nets/fc_2layers_1024units.py and the normalisers of learning/normalizer.py:95-102, on the matrix cores (bf16
  * operands, fp32 accumulate), so that observation -> action -> control step stays on the GPU.  Weights are fp32 host

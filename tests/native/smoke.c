@@ -2,6 +2,8 @@
  *
  *     gcc -std=c99 -Iinclude tests/native/smoke.c -o smoke -Ldeepmimic_amd/csrc -ldm_hip -Wl,-rpath,$PWD/deepmimic_amd/csrc
  *     ./smoke scene.dmtbl [num_envs] [control steps] [precision]            (scene.dmtbl: tools/dump_tables.py)
+ *     ./smoke --args args/run_humanoid3d_walk_args.txt --data-root /path/to/DeepMimic [num_envs] [steps] [precision]
+ *                                                                            (the reference's own arg file, parsed by the library: dm_scene_load)
  *
  * What the reference's native entry point does with cDeepMimicCore (DeepMimicCore/Main.cpp:38-75 SetupDeepMimicCore: construct, SeedRand,
  * ParseArgs, Init; :97-124 the update loop: Update(timestep) ... Reset() at episode end), here through the batched entry points: dm_create
@@ -43,10 +45,20 @@ static dm_scene_tables* load_tables(const char* path, unsigned char** keep) {
 }
 
 int main(int argc, char** argv) {
-    if (argc < 2) { fprintf(stderr, "usage: smoke scene.dmtbl [num_envs] [steps] [precision]\n"); return 2; }
-    const int n = argc > 2 ? atoi(argv[2]) : 8, steps = argc > 3 ? atoi(argv[3]) : 10, precision = argc > 4 ? atoi(argv[4]) : 32;
+    if (argc < 2) { fprintf(stderr, "usage: smoke scene.dmtbl | --args <arg file> --data-root <dir>  [num_envs] [steps] [precision]\n"); return 2; }
     unsigned char* keep = NULL;
-    dm_scene_tables* tables = load_tables(argv[1], &keep);
+    const dm_scene_tables* tables = NULL;
+    dm_scene* scene = NULL;
+    int a0 = 2;
+    if (strcmp(argv[1], "--args") == 0) {
+        /* cDeepMimicCore::ParseArgs in the library (DeepMimicCore.cpp:25-44; Main.cpp:38-75 hands it the command line) */
+        if (argc < 5 || strcmp(argv[3], "--data-root") != 0) { fprintf(stderr, "smoke: --args <arg file> --data-root <dir>\n"); return 2; }
+        const char* av[2]; av[0] = "--arg_file"; av[1] = argv[2];
+        if (dm_scene_load(av, 2, argv[4], 0, &scene) != 0) die("dm_scene_load");
+        tables = dm_scene_get_tables(scene);
+        a0 = 5;
+    } else tables = load_tables(argv[1], &keep);
+    const int n = argc > a0 ? atoi(argv[a0]) : 8, steps = argc > a0 + 1 ? atoi(argv[a0 + 1]) : 10, precision = argc > a0 + 2 ? atoi(argv[a0 + 2]) : 32;
 
     dm_create_info info;
     memset(&info, 0, sizeof(info));
@@ -78,6 +90,7 @@ int main(int argc, char** argv) {
     }
     if (dm_destroy(ctx) != 0) die("dm_destroy");
     free(kin); free(lim); free(states); free(rewards); free(term); free(valid); free(end); free(keep);
+    if (scene) dm_scene_free(scene);
     printf("ok\n");
     return 0;
 }

@@ -73,3 +73,18 @@ def test_c_caller_matches_python_binding_emulator(emu_lib, tmp_path, scene, n, p
 def test_c_caller_matches_python_binding_gpu(hip_lib, tmp_path, scene, n):
     lines = _check(hip_lib, tmp_path, scene, n, 10, 32)
     assert " emulator 0" in lines[0]
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/args"), reason="reference checkout not present (its arg file is the input)")
+def test_c_caller_from_the_references_arg_file(emu_lib, tmp_path):
+    """the whole native route: the reference's own arg file -> dm_scene_load (C++ in the library) -> dm_create -> dm_step_batch, in a C99 process; prints what
+    the blob route prints for the tables Python builds from the same arg file"""
+    import dump_tables
+    from deepmimic_amd import model
+    exe = str(tmp_path / "smoke"); blob = str(tmp_path / "walk.dmtbl")
+    _build(emu_lib, exe)
+    dump_tables.dump(model.load_scene_from_args(["--arg_file", "args/run_humanoid3d_walk_args.txt"], data_root="/root/reference"), blob)
+    a = subprocess.run([exe, "--args", "args/run_humanoid3d_walk_args.txt", "--data-root", "/root/reference", "3", "2", "64"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    b = subprocess.run([exe, blob, "3", "2", "64"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert a.returncode == 0 and b.returncode == 0, a.stderr + b.stderr
+    assert a.stdout == b.stdout and a.stdout.strip().endswith("ok")

@@ -1,0 +1,120 @@
+"""The native scene loader (deepmimic_amd/csrc/dm_scene_load.h: dm_scene_load, round 4; the reference's cDeepMimicCore::ParseArgs + scene ParseArgs + file
+loaders, DeepMimicCore.cpp:25-44, anim/KinTree.cpp:1022-1130, anim/Motion.cpp:302-378, anim/ClipsController.cpp:150-188) against its Python twin
+(deepmimic_amd/model.py load_scene_from_args + core.py fill_scene_tables): for EVERY arg file of the reference both build the same dm_scene_tables --
+every scalar member and every array, bit for bit -- and a context created from the natively loaded tables steps exactly like one created from Python's."""
+import ctypes as C
+import glob
+import os
+
+import numpy as np
+import pytest
+
+REF = "/root/reference"
+pytestmark = pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "args")), reason="reference checkout not present (its arg / data files are the input)")
+
+
+def _native(lib, argv, test_mode=False):
+    from deepmimic_amd import core
+    arr = (C.c_char_p * len(argv))(*[a.encode() for a in argv])
+    h = C.c_void_p()
+    rc = lib.dm_scene_load(arr, len(argv), REF.encode(), int(test_mode), C.byref(h))
+    if rc != 0:
+        return None, lib.dm_last_error().decode()
+    lib.dm_scene_get_tables.restype = C.c_void_p
+    st = core._SceneTables.from_address(lib.dm_scene_get_tables(h))
+    return (h, st), None
+
+
+def _compare(st_py, st_c):
+    from deepmimic_amd import core
+    J, F = st_py.num_joints, st_py.num_frames
+    P = None
+    for name, typ in core._SceneTables._fields_:
+        a, b = getattr(st_py, name), getattr(st_c, name)
+        if isinstance(typ, type) and issubclass(typ, C._Pointer):
+            continue
+        if isinstance(typ, type) and issubclass(typ, C.Array):
+            assert list(a) == list(b), name
+        elif isinstance(a, float):
+            assert a == b or (np.isnan(a) and np.isnan(b)), (name, a, b)
+        else:
+            assert a == b, (name, a, b)
+    arr = lambda p, n, dt: np.ctypeslib.as_array(p, shape=(n,)).astype(dt).copy() if n else np.zeros(0, dt)
+    assert np.array_equal(arr(st_py.joint_mat, J * 19, np.float64), arr(st_c.joint_mat, J * 19, np.float64))
+    assert np.array_equal(arr(st_py.body_defs, J * 17, np.float64), arr(st_c.body_defs, J * 17, np.float64))
+    assert np.array_equal(arr(st_py.pd_params, J * 2, np.float64), arr(st_c.pd_params, J * 2, np.float64))
+    assert np.array_equal(arr(st_py.fall_mask, J, np.int32), arr(st_c.fall_mask, J, np.int32))
+    jm = arr(st_py.joint_mat, J * 19, np.float64).reshape(J, 19)
+    P = int(jm[-1, 18]) + {0: 1, 1: 3, 2: 1, 3: 0, 4: 4}[int(jm[-1, 0])]
+    assert np.array_equal(arr(st_py.frames, F * (P + 1), np.float64), arr(st_c.frames, F * (P + 1), np.float64))
+    nc = st_py.num_clips
+    if nc:
+        assert np.array_equal(arr(st_py.clip_starts, nc + 1, np.int32), arr(st_c.clip_starts, nc + 1, np.int32))
+        assert np.array_equal(arr(st_py.clip_weights, nc, np.float64), arr(st_c.clip_weights, nc, np.float64))
+        assert np.array_equal(arr(st_py.clip_loops, nc, np.int32), arr(st_c.clip_loops, nc, np.int32))
+
+
+def test_native_loader_equals_python_loader_on_every_arg_file(emu_lib):
+    from deepmimic_amd import core, model
+    lib = core.load_library(emu_lib)
+    files = sorted(glob.glob(os.path.join(REF, "args", "*.txt")))
+    assert len(files) >= 90
+    served = 0
+    for f in files:
+        argv = ["--arg_file", os.path.relpath(f, REF)]
+        try:
+            t = model.load_scene_from_args(argv, data_root=REF)
+        except Exception as ex:
+            t, why = None, str(ex)
+        if t is None or t.cfg.scene == "kin_char":
+            nat, err = _native(lib, argv)
+            assert nat is None and err, f                       # what Python does not serve on the device, the native loader refuses too
+            continue
+        for test_mode in (False, True):
+            st_py, keep = core.fill_scene_tables(t, test_mode=test_mode)
+            nat, err = _native(lib, argv, test_mode)
+            assert nat is not None, (f, err)
+            _compare(st_py, nat[1])
+            info = np.zeros(8)
+            assert lib.dm_scene_info(nat[0], info.ctypes.data_as(C.POINTER(C.c_double))) == 0
+            assert int(info[0]) == t.cfg.num_update_substeps and int(info[1]) == t.cfg.anneal_samples and info[3] == t.cfg.time_end_lim_max
+            lib.dm_scene_free(nat[0])
+        served += 1
+    assert served >= 85          # (8 arg files name a dataset whose clips are not in the reference checkout: both loaders refuse them; 2 are the kin_char viewer scene)
+
+
+def test_native_loader_errors_are_messages(emu_lib):
+    from deepmimic_amd import core
+    lib = core.load_library(emu_lib)
+    nat, err = _native(lib, ["--arg_file", "args/no_such_file.txt"])
+    assert nat is None and "Failed to load args" in err
+    nat, err = _native(lib, ["--scene", "imitate", "--character_files", "data/characters/humanoid3d.txt", "--char_ctrl_files", "data/controllers/humanoid3d_ctrl.txt",
+                             "--motion_file", "data/motions/dog3d_pace.txt"])
+    assert nat is None and "DOF mismatch" in err
+    nat, err = _native(lib, ["--scene", "imitate_step", "--character_files", "x"])
+    assert nat is None and "accelerated path" in err
+
+
+def test_context_from_native_tables_steps_like_pythons(emu_lib):
+    """dm_create straight from the natively loaded tables (what tests/native/smoke.c --args does) == BatchEnv from the Python loader"""
+    from deepmimic_amd import core, model
+    lib = core.load_library(emu_lib)
+    argv = ["--arg_file", "args/run_humanoid3d_spinkick_args.txt"]
+    (h, st), err = _native(lib, argv)
+    assert err is None
+    info = core._CreateInfo(2, 0, 7, 64, 20, 0, 0, 1)
+    ctx = C.c_void_p()
+    assert lib.dm_create(C.byref(info), C.byref(st), C.byref(ctx)) == 0, lib.dm_last_error()
+    env = core.BatchEnv(model.load_scene_from_args(argv, data_root=REF), 2, seed=7, precision=64, lib_path=emu_lib)
+    kt = np.array([0.1, 0.7]); mt = np.array([1e300, 1e300])
+    dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+    assert lib.dm_reset(ctx, None, 2, dp(kt), dp(mt)) == 0
+    env.reset(kin_times=kt, max_times=mt)
+    S = env.S
+    for _ in range(2):
+        s = np.zeros((2, S), np.float32); r = np.zeros(2, np.float32); fl = [np.zeros(2, np.int32) for _ in range(3)]
+        assert lib.dm_step_batch(ctx, None, C.c_double(1.0 / 600), 20, s.ctypes.data_as(C.POINTER(C.c_float)), r.ctypes.data_as(C.POINTER(C.c_float)),
+                                 *[x.ctypes.data_as(C.POINTER(C.c_int32)) for x in fl], 4) == 0
+        out = env.step(None, 1.0 / 600, 20, open_loop=True)
+        assert np.array_equal(s, out["state"]) and np.array_equal(r, out["reward"])
+    lib.dm_destroy(ctx); lib.dm_scene_free(h)

@@ -36,7 +36,8 @@ typedef struct {
                                 row of a revolute limit), 2 = v2 (Bullet's manifold semantics as recalled, SURVEY App. C items 4, 7:
                                 both rows of every revolute limit; one persistent manifold per link against the ground, refreshed and
                                 given ONE new support point per substep, <= 4 points, breaking threshold 0.02 x angular-motion disc).
-                                v2 runs one character per wavefront on the AMP / tap instantiation of the kernels; DESIGN.md 4.6 */
+                                v2 has its own instantiations of the kernels (AMP code + manifolds), one or -- biped class, since round 4 -- two
+                                characters per wavefront; not with the dribble ball; DESIGN.md 4.6 */
 } dm_create_info;
 
 /* Raw scene tables in the reference's in-memory layout (all host pointers, copied at create time). */

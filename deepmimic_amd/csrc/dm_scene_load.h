@@ -25,10 +25,13 @@ struct JVal {
     bool is_num() const { return kind == NUM; }
 };
 struct JParser {
-    const std::string& s; size_t i = 0; std::string err;
+    const std::string& s; size_t i = 0; std::string err; int depth = 0;
     explicit JParser(const std::string& s_) : s(s_) {}
+    struct Depth { int& d; explicit Depth(int& d_) : d(d_) { ++d; } ~Depth() { --d; } };
     void ws() { while (i < s.size() && (s[i] == ' ' || s[i] == '\t' || s[i] == '\n' || s[i] == '\r')) ++i; }
     bool parse(JVal& v) {
+        Depth guard(depth);
+        if (depth > 64) { err = "nesting deeper than 64"; return false; }      // (the data files nest 4 deep; a damaged file must not overflow the stack)
         ws();
         if (i >= s.size()) { err = "unexpected end of file"; return false; }
         const char c = s[i];

@@ -118,3 +118,46 @@ def test_context_from_native_tables_steps_like_pythons(emu_lib):
         out = env.step(None, 1.0 / 600, 20, open_loop=True)
         assert np.array_equal(s, out["state"]) and np.array_equal(r, out["reward"])
     lib.dm_destroy(ctx); lib.dm_scene_free(h)
+
+
+def test_native_loader_survives_malformed_files(emu_lib, tmp_path):
+    """the JSON reader / arg tokenizer of the library never crash on damaged input: truncated and byte-flipped copies of the character, controller and motion
+    files (200 variants) either load or come back as an error message -- the reference asserts (DeepMimicCore.cpp:36-40); a library must not"""
+    import shutil
+    from deepmimic_amd import core
+    lib = core.load_library(emu_lib)
+    rng = np.random.default_rng(0)
+    root = tmp_path / "data"; (root / "c").mkdir(parents=True)
+    src = {"ch": os.path.join(REF, "data/characters/humanoid3d.txt"), "ct": os.path.join(REF, "data/controllers/humanoid3d_ctrl.txt"),
+           "mo": os.path.join(REF, "data/motions/humanoid3d_walk.txt")}
+    raw = {k: open(p, "rb").read() for k, p in src.items()}
+    ok = bad = 0
+    for trial in range(200):
+        which = ("ch", "ct", "mo")[trial % 3]
+        b = bytearray(raw[which])
+        mode = trial % 4
+        if mode == 0:
+            b = b[:int(rng.integers(0, len(b)))]                                   # truncated
+        elif mode == 1:
+            for _ in range(8):
+                b[int(rng.integers(0, len(b)))] = int(rng.integers(0, 256))        # flipped bytes
+        elif mode == 2:
+            i = int(rng.integers(0, len(b) - 40)); del b[i:i + int(rng.integers(1, 40))]      # a hole
+        else:
+            i = int(rng.integers(0, len(b))); b[i:i] = bytes(rng.integers(0, 256, size=int(rng.integers(1, 30))).tolist())   # an insertion
+        for k in raw:
+            (root / "c" / k).write_bytes(bytes(b) if k == which else raw[k])
+        argv = ["--scene", "imitate", "--character_files", "c/ch", "--char_ctrl_files", "c/ct", "--motion_file", "c/mo"]
+        arr = (C.c_char_p * len(argv))(*[a.encode() for a in argv])
+        h = C.c_void_p()
+        rc = lib.dm_scene_load(arr, len(argv), str(root).encode(), 0, C.byref(h))
+        if rc == 0:
+            ok += 1; lib.dm_scene_free(h)
+        else:
+            bad += 1; assert lib.dm_last_error().decode(errors="replace")
+    assert bad > 100 and ok + bad == 200, (ok, bad)
+    (root / "c" / "ch").write_bytes(b"[" * 100000)                                 # absurd nesting: an error, not a stack overflow
+    for k in ("ct", "mo"):
+        (root / "c" / k).write_bytes(raw[k])
+    h = C.c_void_p()
+    assert lib.dm_scene_load(arr, len(argv), str(root).encode(), 0, C.byref(h)) != 0 and b"nesting" in lib.dm_last_error()

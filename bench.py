@@ -46,9 +46,11 @@ def kernel_source_sha1():
     import hashlib
     h = hashlib.sha1()
     try:
-        for f in ("dm_device.h", "dm_device_duo.h", "dm_types.h", "dm_math.h", "Makefile"):
+        for f in ("dm_device.h", "dm_device_duo.h", "dm_types.h", "dm_math.h"):
             with open(os.path.join(ROOT, "deepmimic_amd", "csrc", f), "rb") as fh:
                 h.update(fh.read())
+        with open(os.path.join(ROOT, "deepmimic_amd", "csrc", "Makefile")) as fh:          # the code-generation flags of the kernel families, not the host-side rules
+            h.update("".join(l for l in fh if l.startswith(("HIPFLAGS", "NOLICM_IDS", "SCHED_IDS", "licmflag", "ARCH"))).encode())
         return h.hexdigest()
     except OSError:
         return None

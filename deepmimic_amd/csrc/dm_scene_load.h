@@ -183,6 +183,7 @@ int dm_scene_load(const char* const* args, int n_args, const char* data_root, in
     const JVal* skel = cj.get("Skeleton"); const JVal* joints = skel ? skel->get("Joints") : nullptr; const JVal* bdefs = cj.get("BodyDefs");
     if (!joints || joints->kind != JVal::ARR || !bdefs || bdefs->kind != JVal::ARR) return fail("character file: missing Skeleton.Joints / BodyDefs");
     const int J = (int)joints->arr.size();
+    if (J < 1 || J > 64) return fail("character file: the skeleton needs 1 .. 64 joints");
     if ((int)bdefs->arr.size() != J) return fail("joint / body-def count mismatch");
     // cKinTree::BuildJointDesc defaults (anim/KinTree.cpp:1132-1156) + the file's keys; PostProcessJointMat (:1005-1020)
     sc->joint_mat.assign((size_t)J * 19, 0.0);
@@ -201,7 +202,7 @@ int dm_scene_load(const char* const* args, int n_args, const char* data_root, in
     { int off = 0;
       for (int j = 0; j < J; ++j) {
           double* d = &sc->joint_mat[(size_t)j * 19];
-          if ((int)d[1] >= j) return fail("parent id must be < child id");
+          if (!(d[1] >= -1 && d[1] < (double)j) || d[1] != std::floor(d[1])) return fail("parent id must be an integer in [-1, child id)");
           d[18] = off; off += param_size((int)d[0], j == 0);
       }
       sc->joint_mat[2] = sc->joint_mat[3] = sc->joint_mat[4] = 0; }

@@ -16,8 +16,10 @@ def kernel_source_sha1():
     """hash of the device sources the counters were taken on: bench.py compares it with the sources it runs and says when a committed counter file is stale"""
     import hashlib
     h = hashlib.sha1()
-    for f in ("dm_device.h", "dm_device_duo.h", "dm_types.h", "dm_math.h", "Makefile"):
+    for f in ("dm_device.h", "dm_device_duo.h", "dm_types.h", "dm_math.h"):
         h.update(open(os.path.join(ROOT, "deepmimic_amd", "csrc", f), "rb").read())
+    with open(os.path.join(ROOT, "deepmimic_amd", "csrc", "Makefile")) as fh:          # the code-generation flags of the kernel families, not the host-side rules
+        h.update("".join(l for l in fh if l.startswith(("HIPFLAGS", "NOLICM_IDS", "SCHED_IDS", "licmflag", "ARCH"))).encode())
     return h.hexdigest()
 
 

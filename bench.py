@@ -8,7 +8,7 @@ One "step" = one 30 Hz control step of EVERY env on the rank = 20 scene updates 
 two `k_env_step_duo` launches of 2048 envs per control step, drifting apart in phase and filling each other's wave-time tail); `--groups 1` is one
 launch per control step.  Workload (configs[1] of BASELINE.json): humanoid3d_walk, 4096 envs per GPU, fixed-action stream A1 (open-loop mocap tracking,
 generated on device), inputs resident in HBM.  The line carries `roofline` (per launch; `valu` = the binding figures from the committed counter files,
-stamped with the kernel sources they were taken on), `sustained` (a >= 2.5 s window behind the timed steps) and `cpu_baseline`.
+stamped with the kernel sources they were taken on), `sustained` (a >= 2.5 s window behind the timed steps), `closed_loop` (N = 1: the same envs driven by the on-device policy, an extra -- never `value`) and `cpu_baseline`.
 N > 1: one process per GPU (torch.distributed, backend nccl = RCCL), env shards are independent (weak scaling); the only collective is the per-step
 all-gather of (state, reward, terminate) for the learner, one exchange per env group on the group's stream.
 `python bench.py --gpus N` with no WORLD_SIZE in the environment launches its own N ranks (one per GPU, rank r on GPU r) under
@@ -267,6 +267,44 @@ def facade_bench(scene, steps, workers=(1,), private_too=True):
                       "host_cores": os.cpu_count(), **out}))
 
 
+def closed_loop(envs, stream_handles, dev, steps):
+    """policy(g) -> control step(g) on each group's stream, `steps` times; one Policy object per group (its activation buffers are per object)"""
+    import torch
+    from deepmimic_amd.policy import Policy, random_weights
+    env, n = envs.envs[0], envs.N
+    offs = env.offsets_scales()
+    w = random_weights(env.S, env.A, seed=0)
+    w["s_mean"] = -offs["state_offset"].astype(np.float32); w["s_std"] = (1.0 / offs["state_scale"]).astype(np.float32)
+    w["a_mean"] = -offs["action_offset"].astype(np.float32); w["a_std"] = (1.0 / offs["action_scale"]).astype(np.float32)
+    pols = [Policy(w, device_id=dev.index or 0) for _ in range(envs.G)]
+    f32, i32 = dict(dtype=torch.float32, device=dev), dict(dtype=torch.int32, device=dev)
+    st = torch.zeros((n, env.S), **f32); ac = torch.zeros((n, env.A), **f32); rw = torch.zeros(n, **f32)
+    tm = torch.zeros(n, **i32); vd = torch.zeros(n, **i32); en = torch.zeros(n, **i32)
+    ptrs = (st.data_ptr(), rw.data_ptr(), tm.data_ptr(), vd.data_ptr(), en.data_ptr())
+    torch.cuda.synchronize()
+    for g in range(envs.G):
+        envs.step_group_device(g, 0, *ptrs, n_updates=0)            # RecordState of wherever the rollout left the envs
+
+    def loop(k0, k1):
+        for k in range(k0, k1):
+            for g in range(envs.G):
+                o = envs.start[g]
+                pols[g].forward_device(st.data_ptr() + 4 * o * env.S, envs.count[g], ac.data_ptr() + 4 * o * env.A, 0, sample=True, seed=1, step=k,
+                                       env_id_offset=envs.first[g], stream=stream_handles[g])
+                envs.step_group_device(g, ac.data_ptr(), *ptrs, timestep=1.0 / 600, n_updates=20, auto_reset=True)
+
+    loop(0, 20)
+    envs.synchronize(); torch.cuda.synchronize(); t0 = time.perf_counter()
+    loop(20, 20 + steps)
+    envs.synchronize(); torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    res = {"value": n * steps / dt, "unit": "env-steps/s", "steps": steps, "ms_per_step": 1e3 * dt / steps, "groups": envs.G,
+           "policy": "%d -> 1024 -> 512 -> %d, random init, sampled (dm_policy_forward, bf16 MFMA)" % (env.S, env.A),
+           "mean_reward": float(rw.mean().item()), "finite": bool(torch.isfinite(st).all().item())}
+    for p in pols:
+        p.close()
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -289,6 +327,7 @@ def main():
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="nccl (= RCCL, the product) or gloo: CPU test harness of the N > 1 path (needs DM_HIP_LIB = the emulator build and DM_ALLOW_EMULATOR=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-closed-loop", action="store_true", help="skip the `closed_loop` extra (policy on the matrix cores -> control step, N = 1 only)")
     ap.add_argument("--facade", action="store_true", help="measure the single-env cDeepMimicCore facade path instead of the batched env")
     ap.add_argument("--workers", type=int, nargs="*", default=[1], help="with --facade: aggregate rate of W worker processes (one cDeepMimicCore each) sharing the GPU, e.g. --workers 1 16 64")
     ap.add_argument("--shared-only", action="store_true", help="with --facade --workers: skip the one-context-per-worker runs for W > 1 (they take minutes at W = 256)")
@@ -468,6 +507,15 @@ def main():
     mean_reward = float(torch.cat([v[1] for v in last]).mean().item())
     finite = all(bool(torch.isfinite(v[0]).all().item()) for v in last)
 
+    # extra, N = 1: the same envs driven by the on-device policy (dm_policy.h: S -> 1024 -> 512 -> A on the MFMA units -- 227 / 28 for the humanoid --, random init, sampled
+    # actions) instead of fixed actions -- what a sampler sees per control step.  Never `value`; a failure here is reported, not fatal.
+    closed = None
+    if on_gpu and world == 1 and not args.no_closed_loop and not gather:
+        try:
+            closed = closed_loop(envs, [s.cuda_stream for s in gstreams] if G > 1 else [0], dev, min(args.steps, 200))
+        except Exception as ex:                                     # noqa: BLE001
+            closed = {"error": "%s: %s" % (type(ex).__name__, ex)}
+
     if rank == 0:
         # the line must describe the job that was asked for: N ranks, N per-rank rates
         if world != args.gpus or len(per_rank) != args.gpus:
@@ -512,6 +560,7 @@ def main():
                                  "`achieved_all_streams`"},
             "sustained": (dict(sustained, ratio_to_value=sustained["value"] / value) if sustained else None),
             "checks": {"mean_reward": mean_reward, "finite": finite},
+            "closed_loop": closed,
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.scene, args.cpu_budget)

@@ -108,3 +108,6 @@ def test_bench_default_line_gpu(hip_lib):
     v = line["roofline"]["valu"]
     assert v and 0.3 < v["valu_busy"] < 1.0 and v["source"] and 0.01 < v["frac_of_fp32_peak"] < 1.0
     assert abs(line["ms_per_step"] * line["value"] / 1e3 - 4096) < 1.0
+    c = line["closed_loop"]                                     # extra: the same envs driven by the on-device policy
+    assert c and "error" not in c, c
+    assert c["groups"] == 2 and c["finite"] and c["value"] > 0.8e6 and 0.5 < c["value"] / line["value"] < 1.1, c

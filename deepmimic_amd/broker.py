@@ -23,6 +23,8 @@ import fcntl
 import hashlib
 import os
 import pickle
+import platform
+import stat
 import subprocess
 import sys
 import time
@@ -49,6 +51,23 @@ def futex_wake(addr: int, n: int = 1):
     _libc.syscall(_SYS_FUTEX, C.c_void_p(addr), _FUTEX_WAKE, C.c_int(n), None, None, 0)
 
 
+def _open_private(path: str, mode: str):
+    """Open (creating) a file of OURS under the world-writable /dev/shm: never through a symlink, never one another user planted under our name."""
+    flags = os.O_CREAT | os.O_NOFOLLOW | os.O_CLOEXEC | (os.O_RDWR if "+" in mode else os.O_WRONLY) | (os.O_APPEND if "a" in mode else 0)
+    fd = os.open(path, flags, 0o600)
+    st = os.fstat(fd)
+    if st.st_uid != os.getuid() or not stat.S_ISREG(st.st_mode):
+        os.close(fd)
+        raise RuntimeError("DM_FACADE_SHARED: %s exists and is not a regular file of this user; refusing to use it (set DM_FACADE_SHM to another name)" % path)
+    return os.fdopen(fd, mode)
+
+
+def _check_region_owner(name: str):
+    st = os.stat("/dev/shm/%s" % name)
+    if st.st_uid != os.getuid():
+        raise RuntimeError("DM_FACADE_SHARED: shared-memory region %s belongs to uid %d, not to this user; refusing to attach" % (name, st.st_uid))
+
+
 def region_name(tables, precision: int, device: int) -> str:
     """One region per (user, scene tables, precision, device): unrelated runs never meet; DM_FACADE_SHM overrides."""
     if os.environ.get("DM_FACADE_SHM"):
@@ -70,6 +89,7 @@ class Region:
             self.hdr[:] = 0
             self.hdr[1:7] = (W, S, A, P, J, AMP)
         else:
+            _check_region_owner(name)                       # (FileNotFoundError when there is none, like SharedMemory itself)
             self.shm = shared_memory.SharedMemory(name=name)
             # Python 3.10 registers an ATTACHED segment with the process's resource tracker, which unlinks it when this process exits (bpo-38119):
             # a worker that leaves would take the region away from under the others.  The owner alone unlinks it.
@@ -123,10 +143,11 @@ class Region:
 
 
 # ======================================================================================================================= owner side
-def serve(name: str, tables_path: str, max_workers: int, device: int, precision: int, lib_path: str, idle_exit_s: float = 3.0):
+def serve(name: str, max_workers: int, device: int, precision: int, lib_path: str, idle_exit_s: float = 3.0):
+    """The owner loop.  The scene tables arrive pickled on stdin, from the worker that started this process (a pipe: nothing another user
+    could have planted under /dev/shm is ever unpickled)."""
     from deepmimic_amd.core import BatchEnv
-    with open(tables_path, "rb") as f:
-        tables = pickle.load(f)
+    tables = pickle.load(sys.stdin.buffer)
     env = BatchEnv(tables, max_workers, device_id=device, seed=0, precision=precision, lib_path=lib_path or None, wave_packing=1)
     R = Region(name, create=True, dims=(max_workers, env.S, env.A, env.P, env.J, env.amp_size))
     off = env.offsets_scales()
@@ -257,12 +278,11 @@ def serve(name: str, tables_path: str, max_workers: int, device: int, precision:
                 f.write(json.dumps(dict(stats, max_workers=W)) + "\n")
         env.close()
         R.close(unlink=True)
-        for ext in (".tables", ".log"):          # (the lock file stays: a worker may be blocked on it right now, and a second inode under the same name would let two owners start)
-            try:
-                if ext != ".log" or os.path.getsize("/dev/shm/%s.log" % name) == 0:
-                    os.unlink("/dev/shm/%s%s" % (name, ext))
-            except OSError:
-                pass
+        try:                                     # (the lock file stays: a worker may be blocked on it right now, and a second inode under the same name would let two owners start)
+            if os.path.getsize("/dev/shm/%s.log" % name) == 0:
+                os.unlink("/dev/shm/%s.log" % name)
+        except OSError:
+            pass
 
 
 # ======================================================================================================================= worker side
@@ -272,6 +292,8 @@ class SharedEnv:
     def __init__(self, tables, seed: int = 0, device_id: int = 0, precision: int = 32, lib_path=None, max_workers=None):
         self.tables = tables
         c = tables.cfg
+        if platform.machine() != "x86_64" or not sys.platform.startswith("linux"):
+            raise NotImplementedError("DM_FACADE_SHARED: the broker uses Linux futexes by x86-64 syscall number and relies on x86 store order")
         if tables.goal_kind != 0 or tables.num_clips != 1 or (c.enable_rand_perturbs and np.isfinite(c.perturb_time_min)) or c.enable_rand_rot_reset:
             raise NotImplementedError("DM_FACADE_SHARED serves imitate / imitate_amp scenes with one clip, no perturbations, no random yaw")
         self._seed, self._ep, self._expert_calls = int(seed) & (2 ** 64 - 1), 1, 0          # (a fresh one-env ctx has consumed episode 0 in dm_create's own reset)
@@ -280,7 +302,7 @@ class SharedEnv:
         self.R = self._attach(name, tables, W, device_id, precision, lib_path or os.environ.get("DM_HIP_LIB") or "")
         R = self.R
         # claim a slot under the region's file lock
-        with open("/dev/shm/%s.lock" % name, "a+") as lk:
+        with _open_private("/dev/shm/%s.lock" % name, "a+") as lk:
             fcntl.flock(lk, fcntl.LOCK_EX)
             free = np.nonzero(R.owner == 0)[0]
             if free.size == 0:
@@ -302,7 +324,7 @@ class SharedEnv:
         """Open the region; start the owner process if there is none (first worker, under the file lock)."""
         lock_path = "/dev/shm/%s.lock" % name
         t_end = time.monotonic() + timeout
-        with open(lock_path, "a+") as lk:
+        with _open_private(lock_path, "a+") as lk:
             fcntl.flock(lk, fcntl.LOCK_EX)
             alive = False
             try:
@@ -314,15 +336,14 @@ class SharedEnv:
             except FileNotFoundError:
                 pass
             if not alive:
-                tp = "/dev/shm/%s.tables" % name
-                with open(tp, "wb") as f:
-                    pickle.dump(tables, f)
                 env = dict(os.environ)
                 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
                 env["PYTHONPATH"] = root + os.pathsep + env.get("PYTHONPATH", "")
-                log = open("/dev/shm/%s.log" % name, "ab")
-                subprocess.Popen([sys.executable, "-m", "deepmimic_amd.broker", "--serve", name, tp, str(W), str(device), str(precision), lib_path],
-                                 env=env, stdout=log, stderr=log, start_new_session=True, close_fds=True)
+                with _open_private("/dev/shm/%s.log" % name, "ab") as log:
+                    owner = subprocess.Popen([sys.executable, "-m", "deepmimic_amd.broker", "--serve", name, str(W), str(device), str(precision), lib_path],
+                                             env=env, stdin=subprocess.PIPE, stdout=log, stderr=log, start_new_session=True, close_fds=True)
+                pickle.dump(tables, owner.stdin, protocol=4)          # the scene tables go down a pipe
+                owner.stdin.close()
                 while True:
                     try:
                         R = Region(name)
@@ -488,7 +509,7 @@ class _LazySnap(dict):
 
 
 if __name__ == "__main__":
-    if len(sys.argv) >= 8 and sys.argv[1] == "--serve":
-        serve(sys.argv[2], sys.argv[3], int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6]), sys.argv[7])
+    if len(sys.argv) >= 7 and sys.argv[1] == "--serve":
+        serve(sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), sys.argv[6])
     else:
-        sys.exit("usage: python -m deepmimic_amd.broker --serve <region> <tables pickle> <max workers> <device> <precision> <lib path>")
+        sys.exit("usage: python -m deepmimic_amd.broker --serve <region> <max workers> <device> <precision> <lib path>   (pickled scene tables on stdin)")

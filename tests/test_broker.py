@@ -110,3 +110,33 @@ def test_region_layout_round_trip():
         b.close()
     finally:
         a.close(unlink=True)
+
+
+def test_broker_refuses_files_it_does_not_own(tmp_path, monkeypatch):
+    """/dev/shm is world-writable: the lock / log files are opened without following symlinks and only when they are regular files of this user; a region
+    of another uid is not attached; the scene tables travel to the owner process down a pipe (no pickle file under /dev/shm)."""
+    import inspect
+    from deepmimic_amd import broker
+    victim = tmp_path / "victim.txt"; victim.write_text("keep")
+    link = "/dev/shm/dmtest_symlink_%d.lock" % os.getpid()
+    os.symlink(str(victim), link)
+    try:
+        with pytest.raises(OSError):                     # O_NOFOLLOW: ELOOP
+            broker._open_private(link, "a+")
+        assert victim.read_text() == "keep"
+    finally:
+        os.unlink(link)
+    path = "/dev/shm/dmtest_private_%d.lock" % os.getpid()
+    try:
+        with broker._open_private(path, "a+") as f:
+            assert (os.fstat(f.fileno()).st_mode & 0o777) == 0o600
+        monkeypatch.setattr(os, "getuid", lambda: 54321)      # "another user's file"
+        with pytest.raises(RuntimeError, match="not a regular file of this user"):
+            broker._open_private(path, "a+")
+        with pytest.raises(RuntimeError, match="belongs to uid"):
+            broker._check_region_owner(os.path.basename(path))
+    finally:
+        monkeypatch.undo()
+        os.unlink(path)
+    src = inspect.getsource(broker)
+    assert "pickle.load(sys.stdin.buffer)" in src and '.tables"' not in src and "tables_path" not in src

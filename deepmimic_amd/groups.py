@@ -64,7 +64,9 @@ class EnvGroups:
         """Control step of group g, asynchronous on its stream.  The pointers are the WHOLE-BATCH device arrays (row = env id minus
         env_id_offset); the group reads / writes its own rows."""
         o, e = self.start[g], self.envs[g]
-        off = lambda p, width: (p + 4 * o * width) if p else 0
+        off = lambda p, width: (p + 4 * o * width) if p else 0      # (every array of the step interface is 4-byte: float32 / int32, in both precisions)
+        if kw.get("amp_ptr"):
+            kw = dict(kw, amp_ptr=off(kw["amp_ptr"], e.amp_size))   # the AMP observation array is whole-batch too
         e.step_device(off(actions_ptr, e.A), off(states_ptr, e.S), off(rewards_ptr, 1), off(term_ptr, 1), off(valid_ptr, 1), off(end_ptr, 1), **kw)
 
     def step_device(self, actions_ptr: int, states_ptr: int, rewards_ptr: int, term_ptr: int, valid_ptr: int, end_ptr: int, **kw):

@@ -92,7 +92,7 @@ class TorchVecEnvGroups:
     as in a `TorchVecEnv` of the whole batch (draws are keyed by the global env id; tests/test_vec_env.py)."""
 
     def __init__(self, tables: SceneTables, num_envs: int, groups: int = 2, device: str = "cuda:0", seed: int = 0, timestep: float = 1.0 / 600,
-                 updates_per_step: int = 20, **env_kwargs):
+                 updates_per_step: int = 20, amp_obs: bool = False, **env_kwargs):
         import torch
         from .groups import EnvGroups
         self.torch = torch
@@ -103,10 +103,13 @@ class TorchVecEnvGroups:
             torch.zeros(1, device=self.device)
             self.g = EnvGroups(tables, num_envs, groups=groups, device_id=self.device.index or 0, seed=seed, **env_kwargs)
         self.G, self.n, self.obs_dim, self.act_dim = self.g.G, self.g.N, self.g.S, self.g.A
+        self.goal_dim = self.g.envs[0].G
         self.timestep, self.updates = float(timestep), int(updates_per_step)
         f32, i32 = dict(dtype=torch.float32, device=self.device), dict(dtype=torch.int32, device=self.device)
         self.obs = torch.zeros((self.n, self.obs_dim), **f32); self.reward = torch.zeros(self.n, **f32)
         self.terminate = torch.zeros(self.n, **i32); self.valid = torch.zeros(self.n, **i32); self.episode_end = torch.zeros(self.n, **i32)
+        self.amp_obs = torch.zeros((self.n, self.g.amp_size), **f32) if (amp_obs and self.g.amp_size) else None
+        self.goal = torch.zeros((self.n, self.goal_dim), **f32) if self.goal_dim else None
         # the contexts' own streams (created back to back: distinct hardware queues), visible to torch as external streams
         self.streams = [torch.cuda.ExternalStream(e.own_stream(), device=self.device) for e in self.g.envs]
 
@@ -118,7 +121,18 @@ class TorchVecEnvGroups:
 
     def _launch(self, g, actions_ptr, n_updates, auto_reset):
         self.g.step_group_device(g, actions_ptr, self.obs.data_ptr(), self.reward.data_ptr(), self.terminate.data_ptr(), self.valid.data_ptr(),
-                                 self.episode_end.data_ptr(), timestep=self.timestep, n_updates=n_updates, auto_reset=auto_reset)
+                                 self.episode_end.data_ptr(), timestep=self.timestep, n_updates=n_updates, auto_reset=auto_reset,
+                                 amp_ptr=self.amp_obs.data_ptr() if self.amp_obs is not None else 0)
+        if self.goal is not None and n_updates:
+            self.g.envs[g].last_goals_device(self.goal[self.rows(g)].data_ptr())      # device-to-device on the group's stream, behind its kernel
+
+    def _info(self, r):
+        info = {"terminate": self.terminate[r], "valid": self.valid[r]}
+        if self.amp_obs is not None:
+            info["amp_obs"] = self.amp_obs[r]
+        if self.goal is not None:
+            info["goal"] = self.goal[r]
+        return info
 
     def reset(self):
         self.g.reset()
@@ -137,7 +151,7 @@ class TorchVecEnvGroups:
         r = self.rows(g)
         with t.cuda.stream(self.streams[g]):
             done = (self.episode_end[r] != 0) | (self.valid[r] == 0)
-        return self.obs[r], self.reward[r], done, {"terminate": self.terminate[r], "valid": self.valid[r]}
+        return self.obs[r], self.reward[r], done, self._info(r)
 
     def _join(self):
         cur = self.torch.cuda.current_stream(self.device)
@@ -151,7 +165,7 @@ class TorchVecEnvGroups:
             self.streams[g].wait_stream(cur)
             self._launch(g, actions.data_ptr(), self.updates, True)
         self._join()
-        return self.obs, self.reward, (self.episode_end != 0) | (self.valid == 0), {"terminate": self.terminate, "valid": self.valid}
+        return self.obs, self.reward, (self.episode_end != 0) | (self.valid == 0), self._info(slice(None))
 
     def close(self):
         self.g.close()

@@ -57,6 +57,27 @@ def test_odd_offset_refused_or_unpaired(emu_lib):
         assert np.array_equal(oa["state"], ob["state"]) and np.array_equal(oa["reward"], ob["reward"])
 
 
+def test_group_device_step_offsets_the_amp_rows_emulator(emu_lib):
+    """`step_group_device` takes WHOLE-BATCH arrays: the AMP observation pointer is moved to the group's rows like the others (emulator: "device" memory is
+    host memory, so the raw-pointer interface runs here)."""
+    t = model.load_asset("humanoid3d_walk"); t.cfg.scene = "imitate_amp"
+    n = 4
+    one = BatchEnv(t, n, seed=3, precision=32, lib_path=emu_lib, test_mode=True); grp = EnvGroups(t, n, groups=2, seed=3, precision=32, lib_path=emu_lib, test_mode=True)
+    assert grp.G == 2 and grp.amp_size > 0
+    kt = streams.reset_phase(np.arange(n), 1.0) * one.duration
+    one.reset(kin_times=kt); grp.reset(kin_times=kt)
+    ref = one.step(None, 1.0 / 600, 20, open_loop=True, amp=True)
+    st = np.zeros((n, grp.S), np.float32); rw = np.zeros(n, np.float32); amp = np.zeros((n, grp.amp_size), np.float32)
+    tm, vd, en = (np.zeros(n, np.int32) for _ in range(3))
+    p = lambda a: a.ctypes.data
+    for g in range(grp.G):
+        grp.step_group_device(g, 0, p(st), p(rw), p(tm), p(vd), p(en), timestep=1.0 / 600, n_updates=20, open_loop=True, amp_ptr=p(amp))
+    grp.synchronize()
+    assert np.array_equal(st, ref["state"]) and np.array_equal(rw, ref["reward"]) and np.array_equal(amp, ref["amp_obs"])
+    assert np.abs(amp[2:]).max() > 0
+    one.close(); grp.close()
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("scene,packing", [("humanoid3d_walk", 0), ("dog3d_pace", 0)])
 def test_groups_match_single_context_gpu(hip_lib, scene, packing):

@@ -127,3 +127,26 @@ def test_vec_env_groups_match_single_launch(hip_lib):
         ends += int(d1.sum().item())
     assert ends > 0
     one.close(); grp.close()
+
+
+@pytest.mark.gpu
+def test_vec_env_groups_amp_and_goal_rows(hip_lib):
+    """the AMP observation and RecordGoal arrays of TorchVecEnvGroups are whole-batch like the others: env by env what TorchVecEnv reports"""
+    import torch
+    from deepmimic_amd.vec_env import TorchVecEnv, TorchVecEnvGroups
+    t = model.load_asset("amp_heading_zombie")
+    n = 64
+    one = TorchVecEnv(t, n, seed=9, amp_obs=True, lib_path=hip_lib)
+    grp = TorchVecEnvGroups(t, n, groups=2, seed=9, amp_obs=True, lib_path=hip_lib)
+    assert grp.G == 2 and grp.goal_dim == one.goal_dim > 0 and grp.amp_obs is not None
+    assert torch.equal(one.reset(), grp.reset())
+    rng = np.random.default_rng(2)
+    for k in range(6):
+        a = torch.from_numpy((0.2 * rng.normal(size=(n, one.act_dim))).astype(np.float32)).to(one.device)
+        o1, r1, d1, i1 = one.step(a)
+        o2, r2, d2, i2 = grp.step(a)
+        torch.cuda.synchronize()
+        assert torch.equal(o1, o2) and torch.equal(r1, r2) and torch.equal(d1, d2), k
+        assert torch.equal(i1["amp_obs"], i2["amp_obs"]) and torch.equal(i1["goal"], i2["goal"]), k
+    assert float(i2["amp_obs"][n // 2:].abs().max()) > 0 and float(i2["goal"][n // 2:].abs().max()) > 0
+    one.close(); grp.close()

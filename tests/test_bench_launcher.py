@@ -22,7 +22,7 @@ def run_bench(emu_lib, extra, env_extra=None, timeout=900):
 
 
 def test_bench_gpus_2_launches_two_ranks(emu_lib):
-    p, line = run_bench(emu_lib, ["--gpus", "2"])
+    p, line = run_bench(emu_lib, ["--gpus", "2", "--groups", "2"])      # (auto picks two groups from 4096 envs per rank on: asked for here, at 4 envs)
     assert p.returncode == 0, p.stderr[-2000:]
     assert line is not None, p.stdout[-2000:]
     assert line["n_gpus"] == 2

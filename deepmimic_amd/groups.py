@@ -4,8 +4,9 @@ Why: a 4096-env launch of the step kernel is ONE round of waves (2048 waves on 2
 wave while the slots of the fast waves idle ("the wave-time tail": mean wave 4.30 M cycles, slowest 4.91 M).  Two
 half-batches on two streams drift apart in phase: when the fast waves of group A are done, the waves of group B that share their
 SIMDs run uncontended, and A's next control step starts when A's own slowest wave is done, not the whole batch's.  Measured on one
-MI355X (tools/gpu_ab_groups.py, profiles/r04_ab_groups.json): 2.095 M -> 2.236 M env-steps/s at G = 2 (+6.7 %); G >= 4 collapses
-(the kernels of more than two queues do not overlap), so 2 is the only useful value and the default.
+MI355X (tools/gpu_ab_groups.py, profiles/r04_ab_groups.json): 2.095 M -> 2.236 M env-steps/s at G = 2 (+6.7 %); G >= 4 is slower (2.23 / 2.22 M at
+G = 4 / 8 once HIP has enough hardware queues, GPU_MAX_HW_QUEUES >= 16; under the default 4 queues streams alias and serialise:
+profiles/r04_bench_groups_by_hw_queues.jsonl), so 2 is the only useful value and the default.
 
 Nothing in the C-ABI changes: a group is a `dm_create` of its own with `env_id_offset` = its first global env id, which keys every
 reset / goal / perturbation draw by the GLOBAL id -- env i's trajectory is the same in any grouping (tests/test_groups.py), exactly

@@ -166,7 +166,7 @@ def serve(name: str, max_workers: int, device: int, precision: int, lib_path: st
     gather_quiet = float(os.environ.get("DM_BROKER_QUIET_US", "250")) * 1e-6      # ... or this long without a new arrival
     gen_addr = R.addr("wake", 1)
     wake_addr = R.addr("wake", 0)
-    stats = {"launches": 0, "steps": 0, "rounds": 0, "t_gather": 0.0, "t_step": 0.0, "t_other": 0.0, "t_idle": 0.0, "other_ops": 0}
+    stats = {"launches": 0, "steps": 0, "rounds": 0, "t_gather": 0.0, "t_step": 0.0, "t_other": 0.0, "t_idle": 0.0, "t_call": 0.0, "t_pre": 0.0, "other_ops": 0}
     t_mark = time.perf_counter()
     try:
         while True:
@@ -228,14 +228,16 @@ def serve(name: str, max_workers: int, device: int, precision: int, lib_path: st
                     env.set_state(pose=s_["pose"], vel=s_["vel"], tar=s_["tar"], kin=s_["kin"], clocks=s_["clocks"], flags=s_["flags"])
                 if want.size:
                     pack_state(s_, want)
-                t_s0 = time.perf_counter()
+                t_s0 = time.perf_counter(); stats["t_pre"] += t_s0 - t_g1
                 if stp.size:
                     kmat = np.column_stack([R.dargs[stp, 0], R.iargs[stp, :4].astype(np.float64)])
                     uniq, inv = np.unique(kmat, axis=0, return_inverse=True)
                     for g in range(uniq.shape[0]):
                         ids = stp[np.ravel(inv) == g].astype(np.int32)
                         dt, n_upd, has_act, end_early, want_amp = float(uniq[g, 0]), int(uniq[g, 1]), int(uniq[g, 2]), int(uniq[g, 3]), int(uniq[g, 4])
+                        t_c0 = time.perf_counter()
                         out = env.step_envs(ids, R.action[ids, :A] if has_act else None, dt, n_upd, end_early=bool(end_early), amp=bool(want_amp))
+                        stats["t_call"] += time.perf_counter() - t_c0
                         R.state[ids] = out["state"]; R.reward[ids] = out["reward"]
                         R.flags[ids, 0] = out["terminate"]; R.flags[ids, 1] = out["valid"]; R.flags[ids, 2] = out["episode_end"]
                         R.clocks[ids] = out["clocks"]

@@ -387,9 +387,29 @@ struct EnvSim {
     int cand_link[CPL]; Real cand_loc[CPL][3], cand_rad[CPL];   // this lane's ground-contact candidates
     static constexpr int PPL = C::NPAIRCAP / kWave;             // self-collision pairs per lane
     int pair_code[PPL];
-    long long* prof = nullptr; long long tprev = 0;     // phase-cycle accounting (profiling kernel only)
+    // phase-cycle accounting (profiling kernel only): the deltas accumulate in registers and reach memory once, at the end of the launch -- a
+    // read-modify-write of `prof` at every mark stalled the wave for a memory round trip per mark and inflated every phase (round 4)
+    long long* prof = nullptr; long long tprev = 0; long long pacc[16];
     DM_DEV EnvSim(const ModelDev<Real>& m_, L& s_, int l_) : m(m_), s(s_), l(l_) {}
-    DM_DEV void mark(int phase) { if (TAPS && prof) { long long t = dm_clock(); if (l == 0) prof[phase] += t - tprev; tprev = t; } }
+    DM_DEV void mark(int phase) {
+        if (TAPS && prof) {
+            const long long t = dm_clock(), d = t - tprev; tprev = t;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) if (i == phase) pacc[i] += d;       // (static register indices whatever `phase` is)
+        }
+    }
+    DM_DEV void prof_begin(long long* p) {
+        prof = p;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) pacc[i] = 0;
+        tprev = dm_clock();
+    }
+    DM_DEV void prof_flush() {
+        if (TAPS && prof && l == 0) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) prof[i] += pacc[i];
+        }
+    }
     DM_DEV void sync() const { __syncthreads(); }
     DM_DEV Real* scratch() const { return &s.Lt[0]; }   // L is dead outside the update loop: kin pose / vel / reductions live there
     DM_DEV Real& Lx(int r, int c) const { return s.Lt[L::lrow(r) + c]; }
@@ -2589,7 +2609,7 @@ __global__ void __launch_bounds__(64) DM_WAVES_PER_EU((StepWaves<Real, C>::value
     __shared__ Lds<Real, C> lds;
     const int e = io.env_ids ? io.env_ids[blockIdx.x] : (int)blockIdx.x, l = threadIdx.x;      // (env_ids: a subset of the ctx's envs, dm_step_envs)
     EnvSim<Real, C, TAPS> sim(m, lds, l);
-    if (TAPS && dbg.prof) { sim.prof = dbg.prof + (size_t)e * 16; sim.tprev = dm_clock(); }
+    if (TAPS && dbg.prof) sim.prof_begin(dbg.prof + (size_t)e * 16);
     sim.load(st, e);
     if (io.open_loop) sim.set_action_from_clip();
     else if (io.actions) sim.set_action(io.actions + (size_t)(io.env_ids ? (int)blockIdx.x : e) * m.A);
@@ -2643,6 +2663,7 @@ __global__ void __launch_bounds__(64) DM_WAVES_PER_EU((StepWaves<Real, C>::value
     }
     sim.store(st, e);
     sim.mark(14);
+    sim.prof_flush();
 }
 
 // reset the envs listed in env_ids (or all when env_ids == null); kin_times / max_times optional per listed env

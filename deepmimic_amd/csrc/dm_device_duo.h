@@ -839,7 +839,7 @@ __global__ void __launch_bounds__(64) DM_WAVES_PER_EU((DuoWaves<Real>::value)) k
     const int wl = threadIdx.x, half = wl >> 5;
     const int e = 2 * blockIdx.x + half;
     DuoSim<Real, TAPS> sim(m, lds, wl);
-    if (TAPS && dbg.prof) { sim.b.prof = dbg.prof + (size_t)e * 16; sim.b.tprev = dm_clock(); }
+    if (TAPS && dbg.prof) sim.b.prof_begin(dbg.prof + (size_t)e * 16);
     sim.load(st, e);
     if (io.open_loop) sim.b.set_action_from_clip();
     else if (io.actions) sim.b.set_action(io.actions + (size_t)e * m.A);
@@ -909,6 +909,7 @@ __global__ void __launch_bounds__(64) DM_WAVES_PER_EU((DuoWaves<Real>::value)) k
     }
     sim.b.store(st, e);
     sim.b.mark(14);
+    sim.b.prof_flush();
 }
 
 }  // namespace dmk

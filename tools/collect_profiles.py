@@ -45,7 +45,11 @@ for name in ("bench.json", "bench_driver_style.json", "bench_groups1.json", "ben
              "bench_amp_heading_zombie.json", "bench_amp_dribble_zombie.json", "bench_scenes.json",
              "parity_report.json", "tail_probe.txt", "tail_probe_closed_loop.txt", "bench_record_exchange_1rank.json", "bench_record_exchange_cabi_1rank.json"):
     if os.path.exists(os.path.join(src, name)) and os.path.getsize(os.path.join(src, name)) > 0:
-        shutil.copy(os.path.join(src, name), os.path.join(dst, out + "_" + name))
+        if name.startswith("bench_record_exchange"):      # RCCL prints its version banner to stdout behind the line: keep the JSON line only
+            js = [l for l in open(os.path.join(src, name)).read().splitlines() if l.startswith("{")]
+            open(os.path.join(dst, out + "_" + name), "w").write(js[-1] + "\n")
+        else:
+            shutil.copy(os.path.join(src, name), os.path.join(dst, out + "_" + name))
 SCENES = [("humanoid3d_walk", ""), ("humanoid3d_spinkick", "_humanoid3d_spinkick"), ("dog3d_pace", "_dog3d_pace"),
           ("amp_heading_zombie", "_amp_heading_zombie"), ("amp_dribble_zombie", "_amp_dribble_zombie")]
 summary = {}

@@ -1281,3 +1281,4 @@ int dm_gather_wait(dm_ctx* ctx, dm_comm* c, int slot) {
 // ---------------------------------------------------------------- on-device policy inference
 #include "dm_policy_host.h"
 #include "dm_scene_load.h"
+#include "dm_norm.h"          // (after dm_scene_load.h: <map>; after dm_policy_host.h: dm_policy)

@@ -186,3 +186,28 @@ class CabiRecordExchange:
         a = self.all[slot].view(self.world, self.chunk)
         n, S = self.n, self.S
         return a[:, :n * S].unflatten(1, (n, S)), a[:, n * S:n * S + n], a[:, n * S + n:].view(torch.int32)
+
+
+class _DeviceArray:
+    """a raw device allocation as a `__cuda_array_interface__` object (torch.as_tensor wraps it without a copy)"""
+
+    def __init__(self, ptr: int, n: int, typestr: str = "<f8"):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": typestr, "data": (int(ptr), False), "version": 2, "strides": None}
+
+
+def all_reduce_normalizer(norm, device="cpu", group=None):
+    """`MPIUtil.reduce_sum` of learning/normalizer.py:48-50 for a `DeviceNormalizer`: the pending sums {new_count, new_sum, new_sum_sq} of every rank are
+    summed IN PLACE (RCCL on a GPU, gloo on the CPU test harness); `norm.update()` afterwards folds the same totals on every rank, so the ranks'
+    statistics stay identical (the reference's check_synced).  Ordered on torch's current stream: keep the normaliser on that stream
+    (`norm.set_stream(torch.cuda.current_stream().cuda_stream)`; the default, the null stream, is torch's default stream)."""
+    import ctypes as C
+    import torch
+    import torch.distributed as dist
+    ptr, n = norm.pending_ptr()
+    dev = torch.device(device)
+    if dev.type == "cuda":
+        t = torch.as_tensor(_DeviceArray(ptr, n), device=dev)
+    else:
+        t = torch.from_numpy(np.ctypeslib.as_array((C.c_double * n).from_address(ptr)))
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t

@@ -331,6 +331,33 @@ int dm_policy_destroy(dm_policy* policy);
 int dm_policy_forward(dm_policy* policy, const float* states_dev, int n, float* actions_dev, float* logp_dev, int sample,
                       uint64_t seed, uint32_t step, int env_id_offset, void* hip_stream);
 
+/* ---- Running observation statistics on the device: the Normalizer of the reference's learner (learning/normalizer.py:6-152; the
+ * s_norm / g_norm / amp_obs_norm of learning/rl_agent.py:466-483, amp_agent.py:290-291) for records that stay in HBM.
+ * group_ids (NULL = one NORM_GROUP_SINGLE group): per column -1 = never updated (NORM_GROUP_NONE), 0 = per element, k > 0 = the
+ * columns of group k share the average of the new data (normalizer.py:141-149; dm_build_offsets_scales hands the ids out).
+ * eps = smallest std (reference: 0.02); clip <= 0 or inf = no clipping in dm_norm_normalize. */
+typedef struct dm_normalizer dm_normalizer;
+int dm_norm_create(int device_id, int size, const int32_t* group_ids, double eps, double clip, dm_normalizer** out);
+int dm_norm_destroy(dm_normalizer* norm);
+/* Normalizer.record (normalizer.py:33-45): new_count += n, new_sum += column sums, new_sum_sq += column sums of squares, in fp64, of
+ * x[n x size] fp32 -- a DEVICE pointer with DM_DEVICE_PTRS in flags (the record block of a control step), a host pointer otherwise.
+ * Asynchronous on hip_stream; deterministic (two passes, no atomics). */
+int dm_norm_record(dm_normalizer* norm, const float* x, int n, int flags, void* hip_stream);
+/* the pending sums {new_count, new_sum[size], new_sum_sq[size]} as ONE device array of 1 + 2 size doubles: what MPIUtil.reduce_sum
+ * (normalizer.py:48-50) adds over the workers -- all-reduce it (SUM) over the ranks before dm_norm_update */
+int dm_norm_pending(dm_normalizer* norm, double** dev_ptr, int* len);
+/* Normalizer.update (normalizer.py:47-73): fold the pending sums into count / mean / mean_sq / std, clear them.  Asynchronous on hip_stream. */
+int dm_norm_update(dm_normalizer* norm, void* hip_stream);
+/* set_mean_std (normalizer.py:79-93; host arrays): mean_sq = std^2 + mean^2; count >= 0 also sets the sample count (TFNormalizer.load), < 0 keeps it */
+int dm_norm_set(dm_normalizer* norm, const double* mean, const double* std, int64_t count, void* hip_stream);
+/* host copies of the statistics (any pointer may be NULL); synchronises hip_stream */
+int dm_norm_get(dm_normalizer* norm, double* mean, double* std, double* mean_sq, int64_t* count, void* hip_stream);
+/* Normalizer.normalize (normalizer.py:95-98) of x[n x size] into out[n x size], DEVICE pointers, fp32 */
+int dm_norm_normalize(dm_normalizer* norm, const float* x_dev, int n, float* out_dev, void* hip_stream);
+/* make `norm` the observation normaliser of `policy` (a device-to-device copy of mean and 1 / std, ordered on hip_stream): the actor's next
+ * dm_policy_forward on that stream normalises with the statistics of the last dm_norm_update / dm_norm_set */
+int dm_policy_bind_obs_normalizer(dm_policy* policy, dm_normalizer* norm, void* hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

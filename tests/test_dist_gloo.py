@@ -111,3 +111,56 @@ def test_cabi_record_exchange_single_rank(emu_lib):
             assert float(rw.min()) > 0
     finally:
         del os.environ["DM_HIP_LIB"]
+
+
+NORM_WORKER = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, os.environ["DM_ROOT"])
+import torch, torch.distributed as dist
+from deepmimic_amd.normalizer import DeviceNormalizer
+from deepmimic_amd.dist import all_reduce_normalizer
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+S = 11
+gids = np.array([0, 0, 1, 1, 1, -1, 0, 2, 2, 0, 0], np.int32)
+nrm = DeviceNormalizer(S, gids, eps=0.02, lib_path=os.environ["DM_HIP_LIB"])
+nrm.set_mean_std(np.linspace(-1, 1, S), np.linspace(0.5, 2, S))
+for it in range(3):
+    rng = np.random.default_rng(100 * it + rank)               # every rank records its OWN rollouts (different sizes too)
+    x = (rng.normal(size=(5 + 3 * rank + it, S)) * 2 + 0.3).astype(np.float32)
+    nrm.record(x)
+    all_reduce_normalizer(nrm, "cpu")
+    nrm.update()
+np.savez(os.environ["DM_OUT"] + ".norm%d.npz" % rank, mean=nrm.mean, std=nrm.std, mean_sq=nrm.mean_sq, count=np.array([nrm.count]))
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def test_two_rank_normalizer_reduce_sum(emu_lib, tmp_path):
+    """learning/normalizer.py:47-73 over two workers: pending sums all-reduced (gloo here, RCCL on GPUs), then the same update on both ranks --
+    identical statistics on both (check_synced), equal to the oracle fed with both ranks' records"""
+    import sys as _sys
+    _sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    from normalizer_oracle import NormalizerOracle
+    out = str(tmp_path / "n")
+    script = tmp_path / "norm_worker.py"
+    script.write_text(NORM_WORKER)
+    env = dict(os.environ, DM_ROOT=ROOT, DM_HIP_LIB=emu_lib, DM_OUT=out, MASTER_ADDR="127.0.0.1", DM_ALLOW_EMULATOR="1")
+    port = 31500 + (os.getpid() % 2000)
+    subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                           "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)], env=env, timeout=600)
+    a, b = np.load(out + ".norm0.npz"), np.load(out + ".norm1.npz")
+    for k in ("mean", "std", "mean_sq", "count"):
+        assert np.array_equal(a[k], b[k]), k                       # bit-identical on both ranks
+    S = 11
+    ora = NormalizerOracle(S, np.array([0, 0, 1, 1, 1, -1, 0, 2, 2, 0, 0]), 0.02)
+    ora.set_mean_std(np.linspace(-1, 1, S), np.linspace(0.5, 2, S))
+    for it in range(3):
+        for rank in range(2):
+            rng = np.random.default_rng(100 * it + rank)
+            ora.record((rng.normal(size=(5 + 3 * rank + it, S)) * 2 + 0.3).astype(np.float32))
+        ora.update()
+    assert int(a["count"][0]) == ora.count
+    assert np.allclose(a["mean"], ora.mean, rtol=1e-12, atol=1e-13) and np.allclose(a["std"], ora.std, rtol=1e-12, atol=1e-13)

@@ -37,6 +37,11 @@ struct PolicyIO {
     int M;
     int sample;            // 0: mode of the Gaussian (test / deterministic), 1: mean + std * noise
     uint32_t seed_lo, seed_hi; uint32_t step; int env_off;   // Philox4x32-10 key = (seed_lo + global env id, seed_hi), counter = (step * A + j, 0, 0, 0)
+    // dm_policy_forward_ex: the last G of the S input columns come from their own [M x G] block (RecordGoal; the net's input is the concatenation
+    // [norm_s, norm_g], learning/pg_agent.py:170-187), states is then M x (S - G); exp_rate < 1: a row takes the sampled action with that
+    // probability and the mode otherwise (pg_agent.py:214-216 _decide_action: flip_coin(exp_params_curr.rate)), exp_flags[row] says which
+    const float* goals; int G;
+    float exp_rate; int32_t* exp_flags;
 };
 
 static inline uint16_t f32_to_bf16_host(float f) { uint32_t u; memcpy(&u, &f, 4); if ((u & 0x7fffffffu) > 0x7f800000u) return 0x7fc0; u += 0x7fffu + ((u >> 16) & 1u); return (uint16_t)(u >> 16); }
@@ -92,6 +97,11 @@ DMP_DEV void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, u
     }
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
+// the exploration coin of a row: one uniform per (env, step), counter word 1 = 1 keeps it apart from the action noise of the same step
+DMP_DEV float philox_coin(uint32_t env, uint32_t step, uint32_t seed_lo, uint32_t seed_hi) {
+    uint32_t r[4]; philox4x32_10(step, 1, 0, 0, seed_lo + env, seed_hi, r);
+    return ((float)(r[0] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+}
 DMP_DEV float philox_normal(uint32_t env, uint32_t ctr, uint32_t seed_lo, uint32_t seed_hi) {
     uint32_t r[4]; philox4x32_10(ctr, 0, 0, 0, seed_lo + env, seed_hi, r);
     const float u1 = ((float)(r[0] >> 8) + 0.5f) * (1.0f / 16777216.0f), u2 = ((float)(r[1] >> 8) + 0.5f) * (1.0f / 16777216.0f);
@@ -102,11 +112,13 @@ DMP_DEV float philox_normal(uint32_t env, uint32_t ctr, uint32_t seed_lo, uint32
 // one wavefront per row, coalesced reads and writes
 __global__ void __launch_bounds__(64) k_policy_prep(PolicyDev p, PolicyIO io) {
     const int row = blockIdx.x, l = threadIdx.x;
-    const float* srow = io.states + (size_t)row * p.S;
+    const int SS = p.S - io.G;                    // columns that come from the state block
+    const float* srow = io.states + (size_t)row * SS;
+    const float* grow = io.G ? io.goals + (size_t)row * io.G : nullptr;
     uint16_t* out = io.s16 + (size_t)row * p.K1;
     for (int k = l; k < p.K1; k += 64) {
         float x = 0.0f;
-        if (k < p.S) { x = (srow[k] - p.s_mean[k]) * p.s_inv_std[k]; x = fminf(fmaxf(x, -p.s_clip), p.s_clip); }
+        if (k < p.S) { x = ((k < SS ? srow[k] : grow[k - SS]) - p.s_mean[k]) * p.s_inv_std[k]; x = fminf(fmaxf(x, -p.s_clip), p.s_clip); }
         out[k] = f32_to_bf16(x);
     }
 }
@@ -209,13 +221,16 @@ __global__ void __launch_bounds__(64) k_policy_layer(PolicyDev p, PolicyIO io) {
             for (int r = 0; r < 4; ++r) {
                 const int row = row0 + 16 * i + 4 * g + r;
                 float lp = 0.0f;
+                bool explore = io.sample && row < io.M;
+                if (explore && io.exp_rate < 1.0f) explore = philox_coin((uint32_t)(io.env_off + row), io.step, io.seed_lo, io.seed_hi) < io.exp_rate;
+                if (io.exp_flags && c == 0 && nt0 == 0 && row < io.M) io.exp_flags[row] = explore ? 1 : 0;
 #pragma unroll
                 for (int j = 0; j < NT; ++j) {
                     const int col = (nt0 + j) * 16 + c;
                     if (col < p.A) {
                         const float ls = p.logstd[col];
                         float z = 0.0f;
-                        if (io.sample && row < io.M) z = philox_normal((uint32_t)(io.env_off + row), io.step * (uint32_t)p.A + (uint32_t)col, io.seed_lo, io.seed_hi);
+                        if (explore) z = philox_normal((uint32_t)(io.env_off + row), io.step * (uint32_t)p.A + (uint32_t)col, io.seed_lo, io.seed_hi);
                         const float na = acc[i][j][r] + p.b3[col] + expf(ls) * z;
                         if (row < io.M) io.actions[(size_t)row * p.A + col] = na * p.a_std[col] + p.a_mean[col];
                         lp += -0.5f * z * z - ls;

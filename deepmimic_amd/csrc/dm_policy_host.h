@@ -56,9 +56,19 @@ int dm_policy_create(int device_id, const dm_policy_params* pp, dm_policy** out)
 
 int dm_policy_destroy(dm_policy* p) { if (!p) return 0; DevGuard guard(p->device_id); delete p; return 0; }
 
+int dm_policy_forward_ex(dm_policy* p, const float* states_dev, const float* goals_dev, int goal_dim, int n, float* actions_dev, float* logp_dev,
+                         int32_t* exp_flags_dev, double exp_rate, int sample, uint64_t seed, uint32_t step, int env_id_offset, void* hip_stream);
+
 int dm_policy_forward(dm_policy* p, const float* states_dev, int n, float* actions_dev, float* logp_dev, int sample,
                       uint64_t seed, uint32_t step, int env_id_offset, void* hip_stream) {
+    return dm_policy_forward_ex(p, states_dev, nullptr, 0, n, actions_dev, logp_dev, nullptr, 1.0, sample, seed, step, env_id_offset, hip_stream);
+}
+
+int dm_policy_forward_ex(dm_policy* p, const float* states_dev, const float* goals_dev, int goal_dim, int n, float* actions_dev, float* logp_dev,
+                         int32_t* exp_flags_dev, double exp_rate, int sample, uint64_t seed, uint32_t step, int env_id_offset, void* hip_stream) {
     if (!p || !states_dev || !actions_dev) return fail("null argument");
+    if (goal_dim < 0 || goal_dim >= p->pd.S || (goal_dim > 0 && !goals_dev)) return fail("dm_policy_forward_ex: goal_dim must be in [0, state_dim) with a goal block when positive (state_dim counts the goal columns)");
+    if (!(exp_rate >= 0.0 && exp_rate <= 1.0)) return fail("dm_policy_forward_ex: exp_rate must be in [0, 1]");
     if (n <= 0) return 0;
     DevGuard guard(p->device_id);
     rt_stream stream = (rt_stream)hip_stream;
@@ -72,6 +82,7 @@ int dm_policy_forward(dm_policy* p, const float* states_dev, int n, float* actio
     dmp::PolicyIO io; memset(&io, 0, sizeof(io));
     io.states = states_dev; io.s16 = p->s16; io.h1 = p->h1; io.h2 = p->h2; io.actions = actions_dev; io.logp = logp_dev; io.M = n; io.sample = sample ? 1 : 0;
     io.seed_lo = (uint32_t)seed; io.seed_hi = (uint32_t)(seed >> 32); io.step = step; io.env_off = env_id_offset;
+    io.goals = goal_dim ? goals_dev : nullptr; io.G = goal_dim; io.exp_rate = (float)exp_rate; io.exp_flags = exp_flags_dev;
     const dmp::PolicyDev& d = p->pd;
     // tiles sized so that every launch has at least ~1 wave per SIMD at 4096 rows: 64 x 64 (layer 1), 32 x 64 (layer 2), 16 x 32 (layer 3)
     RT_LAUNCH(dmp::k_policy_prep, n, stream, d, io);

@@ -50,6 +50,27 @@ class Policy:
                                       C.c_uint64(int(seed) & (2 ** 64 - 1)), C.c_uint32(int(step) & 0xFFFFFFFF), int(env_id_offset), vp(stream)) != 0:
             raise RuntimeError("libdm_hip: %s" % self.lib.dm_last_error().decode())
 
+    def forward_device_ex(self, states_ptr: int, n: int, actions_ptr: int, goals_ptr: int = 0, goal_dim: int = 0, logp_ptr: int = 0, exp_flags_ptr: int = 0,
+                          exp_rate: float = 1.0, sample: bool = False, seed: int = 0, step: int = 0, env_id_offset: int = 0, stream: int = 0):
+        """`_decide_action` of learning/pg_agent.py:214-221 for a batch (include/dm_hip.h dm_policy_forward_ex): goal block as its own input,
+        per-row exploration coin with probability `exp_rate`, EXP flags out"""
+        vp = lambda p: C.c_void_p(p) if p else None
+        self.lib.dm_policy_forward_ex.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_int,
+                                                  C.c_uint64, C.c_uint32, C.c_int, C.c_void_p]
+        if self.lib.dm_policy_forward_ex(self.h, vp(states_ptr), vp(goals_ptr), int(goal_dim), int(n), vp(actions_ptr), vp(logp_ptr), vp(exp_flags_ptr),
+                                         C.c_double(exp_rate), int(bool(sample)), C.c_uint64(int(seed) & (2 ** 64 - 1)), C.c_uint32(int(step) & 0xFFFFFFFF),
+                                         int(env_id_offset), vp(stream)) != 0:
+            raise RuntimeError("libdm_hip: %s" % self.lib.dm_last_error().decode())
+
+    def forward_host_ex(self, states, goals=None, exp_rate=1.0, sample=False, seed=0, step=0, env_id_offset=0):
+        """emulator-build convenience for forward_device_ex: returns (actions, logp, exp_flags)"""
+        s = np.ascontiguousarray(states, dtype=np.float32); n = s.shape[0]
+        g = None if goals is None else np.ascontiguousarray(goals, dtype=np.float32)
+        a = np.zeros((n, self.A), np.float32); lp = np.zeros(n, np.float32); fl = np.zeros(n, np.int32)
+        self.forward_device_ex(s.ctypes.data, n, a.ctypes.data, 0 if g is None else g.ctypes.data, 0 if g is None else g.shape[1], lp.ctypes.data, fl.ctypes.data,
+                               exp_rate, sample, seed, step, env_id_offset)
+        return a, lp, fl
+
     def forward_host(self, states, sample=False, seed=0, step=0, env_id_offset=0):
         """Convenience for tests on the CPU emulator build, where "device" memory is host memory."""
         s = np.ascontiguousarray(states, dtype=np.float32)

@@ -330,6 +330,16 @@ int dm_policy_destroy(dm_policy* policy);
  * (seed + env_id_offset + row, step * A + j) -- the generator of deepmimic_amd/streams.py. */
 int dm_policy_forward(dm_policy* policy, const float* states_dev, int n, float* actions_dev, float* logp_dev, int sample,
                       uint64_t seed, uint32_t step, int env_id_offset, void* hip_stream);
+/* _decide_action of learning/pg_agent.py:214-221 for a batch, with the goal as its own input block:
+ *  - goals_dev [n x goal_dim] (RecordGoal): the net's input is the concatenation [state, goal] (pg_agent.py:170-187), so the policy's
+ *    state_dim counts the goal columns too (w1 has state_dim rows, s_mean / s_std cover both blocks) and states_dev is n x (state_dim - goal_dim);
+ *    goal_dim = 0: as dm_policy_forward;
+ *  - exp_rate in [0, 1] (exp_params_curr.rate): with sample = 1 a row takes the sampled action with probability exp_rate (its own coin:
+ *    Philox4x32-10 keyed like the noise, counter (step, 1, 0, 0), uniform < exp_rate) and the mode otherwise; logp is the one of the action
+ *    taken; exp_flags_dev[n] (optional, int32) = 1 for the rows that explored (the EXP flag of a path's steps, pg_agent.py:251-255). */
+int dm_policy_forward_ex(dm_policy* policy, const float* states_dev, const float* goals_dev, int goal_dim, int n, float* actions_dev,
+                         float* logp_dev, int32_t* exp_flags_dev, double exp_rate, int sample, uint64_t seed, uint32_t step, int env_id_offset,
+                         void* hip_stream);
 
 /* ---- Running observation statistics on the device: the Normalizer of the reference's learner (learning/normalizer.py:6-152; the
  * s_norm / g_norm / amp_obs_norm of learning/rl_agent.py:466-483, amp_agent.py:290-291) for records that stay in HBM.

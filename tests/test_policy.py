@@ -83,6 +83,66 @@ def test_policy_emulator_logp_more_than_32_actions(emu_lib):
         assert np.abs(lp - want).max() < 5e-3, (A, np.abs(lp - want).max())
 
 
+def _coin(seed, env_ids, step):
+    """the exploration coin of dm_policy_forward_ex: Philox4x32-10, key (seed_lo + env, seed_hi), counter (step, 1, 0, 0), 24-bit uniform"""
+    env_ids = np.asarray(env_ids, dtype=np.int64)
+    ctr = np.zeros((env_ids.size, 4), np.uint32); ctr[:, 0] = step; ctr[:, 1] = 1
+    key = np.zeros((env_ids.size, 2), np.uint32); key[:, 0] = ((seed & 0xFFFFFFFF) + env_ids) & 0xFFFFFFFF; key[:, 1] = (seed >> 32) & 0xFFFFFFFF
+    r = streams.philox4x32_10(ctr, key)
+    return ((r[:, 0] >> 8).astype(np.float64) + 0.5) / 16777216.0
+
+
+def _check_forward_ex(lib, on_gpu):
+    """pg_agent.py:214-221 for a batch: goal block concatenated behind the state block, exploration coin per row, EXP flags"""
+    S, G, A, H1, H2, n = 45, 6, 7, 64, 128, 300
+    w = make(S + G, A, H1, H2, 12)
+    pol = Policy(w, lib_path=lib, s_clip=5.0)
+    rng = np.random.default_rng(2)
+    s = rng.normal(size=(n, S)).astype(np.float32) * 2 + 0.5; g = rng.normal(size=(n, G)).astype(np.float32)
+    cat = np.concatenate([s, g], axis=1)
+
+    def run(goals, rate, sample, **kw):
+        if not on_gpu:
+            return pol.forward_host_ex(s if goals is not None else cat, goals, rate, sample, **kw)
+        import torch
+        sd = torch.from_numpy(s if goals is not None else cat).cuda(); gd = None if goals is None else torch.from_numpy(goals).cuda()
+        a = torch.zeros((n, A), device="cuda"); lp = torch.zeros(n, device="cuda"); fl = torch.zeros(n, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        pol.forward_device_ex(sd.data_ptr(), n, a.data_ptr(), 0 if gd is None else gd.data_ptr(), 0 if gd is None else G, lp.data_ptr(), fl.data_ptr(), rate, sample, **kw)
+        torch.cuda.synchronize()
+        return a.cpu().numpy(), lp.cpu().numpy(), fl.cpu().numpy()
+    # goal block == concatenated input, bit for bit; both equal the bf16 statement
+    a_cat, lp_cat, _ = run(None, 1.0, False)
+    a_g, lp_g, fl = run(g, 1.0, False)
+    assert np.array_equal(a_cat, a_g) and np.array_equal(lp_cat, lp_g) and not fl.any()
+    want, _ = reference_forward(w, cat, s_clip=5.0, bf16=True)
+    assert np.abs(a_g - want).max() < 2e-3
+    # exploration: rows whose coin < rate take the sampled action (same noise as sample = 1 everywhere), the others the mode
+    kw = dict(seed=0xABCDEF0123, step=17, env_id_offset=40)
+    a_all, lp_all, fl_all = run(g, 1.0, True, **kw)
+    assert fl_all.all()
+    a_mix, lp_mix, fl_mix = run(g, 0.3, True, **kw)
+    coin = _coin(0xABCDEF0123, 40 + np.arange(n), 17)
+    assert np.array_equal(fl_mix != 0, coin < 0.3) and 0.15 < fl_mix.mean() < 0.45
+    ex = fl_mix != 0
+    assert np.array_equal(a_mix[ex], a_all[ex]) and np.array_equal(lp_mix[ex], lp_all[ex])
+    assert np.array_equal(a_mix[~ex], a_g[~ex]) and np.array_equal(lp_mix[~ex], lp_g[~ex])
+    a0, _, fl0 = run(g, 0.0, True, **kw)
+    assert np.array_equal(a0, a_g) and not fl0.any()
+    with pytest.raises(RuntimeError, match="exp_rate"):
+        run(g, 1.5, True)
+    pol.close()
+
+
+def test_policy_forward_ex_goal_block_and_exploration_emulator(emu_lib):
+    _check_forward_ex(emu_lib, False)
+
+
+@pytest.mark.gpu
+def test_policy_forward_ex_goal_block_and_exploration_gpu(hip_lib):
+    _check_forward_ex(hip_lib, True)
+
+
 def test_policy_rejects_bad_shapes(emu_lib):
     w = random_weights(10, 4, 96, 64)
     with pytest.raises(RuntimeError, match="multiples of 64"):

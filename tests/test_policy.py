@@ -143,6 +143,18 @@ def test_policy_forward_ex_goal_block_and_exploration_gpu(hip_lib):
     _check_forward_ex(hip_lib, True)
 
 
+def test_policy_as_critic_one_output(emu_lib):
+    """the critic of learning/pg_agent.py:179-188 is the same net with ONE linear output, un-normalised by val_norm (a_mean / a_std here): A = 1 works"""
+    S, H1, H2 = 45, 64, 64
+    w = make(S, 1, H1, H2, 21)
+    crit = Policy(w, lib_path=emu_lib, s_clip=5.0)
+    s = np.random.default_rng(6).normal(size=(21, S)).astype(np.float32)
+    v, _ = crit.forward_host(s)
+    want, _ = reference_forward(w, s, s_clip=5.0, bf16=True)
+    assert v.shape == (21, 1) and np.abs(v - want).max() < 2e-3
+    crit.close()
+
+
 def test_policy_rejects_bad_shapes(emu_lib):
     w = random_weights(10, 4, 96, 64)
     with pytest.raises(RuntimeError, match="multiples of 64"):

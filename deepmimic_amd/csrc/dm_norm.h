@@ -237,17 +237,20 @@ int dm_norm_normalize(dm_normalizer* h, const float* x_dev, int n, float* out_de
     return 0;
 }
 
-// the policy's observation normaliser := this one (device-to-device, ordered on hip_stream): the actor then sees the statistics of the last update()
-int dm_policy_bind_obs_normalizer(dm_policy* p, dm_normalizer* h, void* hip_stream) {
+// columns [first_column, first_column + size) of the policy's observation normaliser := this one (device-to-device, ordered on hip_stream): the actor then
+// sees the statistics of the last update().  The reference keeps s_norm and g_norm apart (learning/rl_agent.py:212-222): bind the first at column 0 and
+// the second at column state_size of a policy whose state_dim counts both blocks.
+int dm_policy_bind_obs_normalizer(dm_policy* p, dm_normalizer* h, int first_column, void* hip_stream) {
     if (!p || !h) return fail("null argument");
-    if (p->pd.S != h->size) return fail("dm_policy_bind_obs_normalizer: the normaliser's size is not the policy's state_dim");
+    if (first_column < 0 || first_column + h->size > p->pd.S) return fail("dm_policy_bind_obs_normalizer: the normaliser's columns do not fit the policy's state_dim");
     if (p->device_id != h->device_id) return fail("dm_policy_bind_obs_normalizer: policy and normaliser live on different devices");
     DevGuard guard(p->device_id);
+    float* dm = const_cast<float*>(p->pd.s_mean) + first_column; float* ds = const_cast<float*>(p->pd.s_inv_std) + first_column;
 #ifdef DM_EMU
-    memcpy((void*)p->pd.s_mean, h->mean_f, sizeof(float) * h->size); memcpy((void*)p->pd.s_inv_std, h->inv_std_f, sizeof(float) * h->size);
+    memcpy(dm, h->mean_f, sizeof(float) * h->size); memcpy(ds, h->inv_std_f, sizeof(float) * h->size);
 #else
-    if (hipMemcpyAsync((void*)p->pd.s_mean, h->mean_f, sizeof(float) * h->size, hipMemcpyDeviceToDevice, (rt_stream)hip_stream) != hipSuccess ||
-        hipMemcpyAsync((void*)p->pd.s_inv_std, h->inv_std_f, sizeof(float) * h->size, hipMemcpyDeviceToDevice, (rt_stream)hip_stream) != hipSuccess) return fail("copy failed");
+    if (hipMemcpyAsync(dm, h->mean_f, sizeof(float) * h->size, hipMemcpyDeviceToDevice, (rt_stream)hip_stream) != hipSuccess ||
+        hipMemcpyAsync(ds, h->inv_std_f, sizeof(float) * h->size, hipMemcpyDeviceToDevice, (rt_stream)hip_stream) != hipSuccess) return fail("copy failed");
 #endif
     return 0;
 }

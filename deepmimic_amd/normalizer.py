@@ -28,7 +28,7 @@ class DeviceNormalizer:
         L.dm_norm_get.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.dm_norm_normalize.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.dm_norm_destroy.argtypes = [C.c_void_p]
-        L.dm_policy_bind_obs_normalizer.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.dm_policy_bind_obs_normalizer.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         self.size, self.eps, self.clip = int(size), float(eps), float(clip)
         g = None if groups_ids is None else np.ascontiguousarray(groups_ids, dtype=np.int32).ravel()
         if g is not None and g.size != self.size:
@@ -86,9 +86,10 @@ class DeviceNormalizer:
     def normalize_device(self, x_ptr: int, n: int, out_ptr: int):
         self._chk(self.lib.dm_norm_normalize(self.h, C.c_void_p(int(x_ptr)), int(n), C.c_void_p(int(out_ptr)), C.c_void_p(self.stream)))
 
-    def bind_policy(self, policy):
-        """the policy's observation normaliser := these statistics (device-to-device, ordered on the stream)"""
-        self._chk(self.lib.dm_policy_bind_obs_normalizer(policy.h, self.h, C.c_void_p(self.stream)))
+    def bind_policy(self, policy, first_column: int = 0):
+        """columns [first_column, first_column + size) of the policy's observation normaliser := these statistics (device-to-device, ordered on the
+        stream); s_norm at 0, g_norm at the state size"""
+        self._chk(self.lib.dm_policy_bind_obs_normalizer(policy.h, self.h, int(first_column), C.c_void_p(self.stream)))
 
     def close(self):
         if getattr(self, "h", None):

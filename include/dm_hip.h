@@ -364,9 +364,10 @@ int dm_norm_set(dm_normalizer* norm, const double* mean, const double* std, int6
 int dm_norm_get(dm_normalizer* norm, double* mean, double* std, double* mean_sq, int64_t* count, void* hip_stream);
 /* Normalizer.normalize (normalizer.py:95-98) of x[n x size] into out[n x size], DEVICE pointers, fp32 */
 int dm_norm_normalize(dm_normalizer* norm, const float* x_dev, int n, float* out_dev, void* hip_stream);
-/* make `norm` the observation normaliser of `policy` (a device-to-device copy of mean and 1 / std, ordered on hip_stream): the actor's next
- * dm_policy_forward on that stream normalises with the statistics of the last dm_norm_update / dm_norm_set */
-int dm_policy_bind_obs_normalizer(dm_policy* policy, dm_normalizer* norm, void* hip_stream);
+/* make `norm` columns [first_column, first_column + size) of the observation normaliser of `policy` (a device-to-device copy of mean and 1 / std,
+ * ordered on hip_stream): the actor's next dm_policy_forward on that stream normalises with the statistics of the last dm_norm_update / dm_norm_set.
+ * s_norm at column 0 and g_norm at column state_size, as the reference keeps them (learning/rl_agent.py:212-222). */
+int dm_policy_bind_obs_normalizer(dm_policy* policy, dm_normalizer* norm, int first_column, void* hip_stream);
 
 #ifdef __cplusplus
 }

@@ -80,23 +80,42 @@ __global__ void __launch_bounds__(256) k_norm_update(double* __restrict__ state,
     }
 }
 
-// Normalizer.normalize (learning/normalizer.py:95-98): out = clip((x - mean) / std, -clip, clip), fp32.  A thread owns four consecutive elements of the
-// flat [n x size] array (one 16-byte load and store when the block is 16-byte aligned; the column index wraps inside the quad, size need not divide by 4).
+// Normalizer.normalize (learning/normalizer.py:95-98): out = clip((x - mean) / std, -clip, clip), fp32.  A thread owns kQuads quads of four consecutive
+// elements of the flat [n x size] array, a workgroup a contiguous run of kQuads x 1024 floats (quad u of thread t at 1024 u + 4 t: every load / store
+// instruction of a wave is one contiguous KB, kQuads of them in flight); the column index wraps inside a quad, size need not divide by 4.
+constexpr int kQuads = 4;
+constexpr int kLdsCols = 2048;      // widest row whose statistics are staged in LDS (16 KB)
 __global__ void __launch_bounds__(256) k_norm_apply(const float* __restrict__ x, int total, int size, const float* __restrict__ mean_f, const float* __restrict__ inv_std_f,
                                                      float clip, float* __restrict__ out, int vec_ok) {
-    const int i0 = 4 * (blockIdx.x * kThreads + threadIdx.x);
-    if (i0 >= total) return;
-    int c = i0 % size;
-    float v[4]; const int cnt = (total - i0 < 4) ? total - i0 : 4;
-    if (vec_ok && cnt == 4) { const F4 q = *reinterpret_cast<const F4*>(x + i0); v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w; }
-    else for (int k = 0; k < cnt; ++k) v[k] = x[i0 + k];
-    for (int k = 0; k < cnt; ++k) {
-        float y = (v[k] - mean_f[c]) * inv_std_f[c];
-        v[k] = y < -clip ? -clip : (y > clip ? clip : y);
-        if (++c == size) c = 0;
+    // mean / 1/std staged in LDS (8 gathers per quad: as global loads they out-numbered the payload's own load and store 8 : 2 and held the kernel at 3.5 TB/s)
+    __shared__ float sm[2 * kLdsCols];
+    const bool staged = size <= kLdsCols;
+    if (staged) {
+        for (int c = threadIdx.x; c < size; c += kThreads) { sm[c] = mean_f[c]; sm[kLdsCols + c] = inv_std_f[c]; }
+        __syncthreads();
     }
-    if (vec_ok && cnt == 4) { F4 q; q.x = v[0]; q.y = v[1]; q.z = v[2]; q.w = v[3]; *reinterpret_cast<F4*>(out + i0) = q; }
-    else for (int k = 0; k < cnt; ++k) out[i0 + k] = v[k];
+    const long long base = (long long)blockIdx.x * (kQuads * 4 * kThreads) + 4 * threadIdx.x;
+    float v[kQuads][4]; int cnt[kQuads];
+#pragma unroll
+    for (int u = 0; u < kQuads; ++u) {
+        const long long i0 = base + (long long)u * 4 * kThreads;
+        cnt[u] = (i0 >= total) ? 0 : ((total - i0 < 4) ? (int)(total - i0) : 4);
+        if (vec_ok && cnt[u] == 4) { const F4 q = *reinterpret_cast<const F4*>(x + i0); v[u][0] = q.x; v[u][1] = q.y; v[u][2] = q.z; v[u][3] = q.w; }
+        else for (int k = 0; k < cnt[u]; ++k) v[u][k] = x[i0 + k];
+    }
+#pragma unroll
+    for (int u = 0; u < kQuads; ++u) {
+        const long long i0 = base + (long long)u * 4 * kThreads;
+        if (cnt[u] == 0) continue;
+        int c = (int)(i0 % size);
+        for (int k = 0; k < cnt[u]; ++k) {
+            const float y = staged ? (v[u][k] - sm[c]) * sm[kLdsCols + c] : (v[u][k] - mean_f[c]) * inv_std_f[c];
+            v[u][k] = y < -clip ? -clip : (y > clip ? clip : y);
+            if (++c == size) c = 0;
+        }
+        if (vec_ok && cnt[u] == 4) { F4 q; q.x = v[u][0]; q.y = v[u][1]; q.z = v[u][2]; q.w = v[u][3]; *reinterpret_cast<F4*>(out + i0) = q; }
+        else for (int k = 0; k < cnt[u]; ++k) out[i0 + k] = v[u][k];
+    }
 }
 
 }  // namespace dmn
@@ -230,7 +249,7 @@ int dm_norm_normalize(dm_normalizer* h, const float* x_dev, int n, float* out_de
     if (total > 0x7fffffffLL) return fail("dm_norm_normalize: too many elements for one call");
     const float clip = (h->clip > 0 && std::isfinite(h->clip)) ? (float)h->clip : std::numeric_limits<float>::infinity();
     const int vec_ok = (((uintptr_t)x_dev | (uintptr_t)out_dev) & 15) == 0 ? 1 : 0;
-    RT_LAUNCH4(dmn::k_norm_apply, (int)((total + 4 * dmn::kThreads - 1) / (4 * dmn::kThreads)), (rt_stream)hip_stream, x_dev, (int)total, h->size, (const float*)h->mean_f, (const float*)h->inv_std_f, clip, out_dev, vec_ok);
+    RT_LAUNCH4(dmn::k_norm_apply, (int)((total + dmn::kQuads * 4 * dmn::kThreads - 1) / (dmn::kQuads * 4 * dmn::kThreads)), (rt_stream)hip_stream, x_dev, (int)total, h->size, (const float*)h->mean_f, (const float*)h->inv_std_f, clip, out_dev, vec_ok);
 #ifndef DM_EMU
     hipError_t le = hipGetLastError(); if (le != hipSuccess) return fail(std::string("kernel launch failed: ") + hipGetErrorString(le));
 #endif

@@ -38,6 +38,10 @@ for n in (4096, 32768, 262144, 1048576):
     out["record"][str(n)] = {"ms": ms, "gbs": n * S * 4 / (ms * 1e-3) / 1e9, "frac_of_hbm_peak": n * S * 4 / (ms * 1e-3) / 1e9 / 8000.0}
     ms = timed(lambda: nrm.normalize_device(x.data_ptr(), n, o.data_ptr()), 50)
     out["normalize"][str(n)] = {"ms": ms, "gbs": 2 * n * S * 4 / (ms * 1e-3) / 1e9, "frac_of_hbm_peak": 2 * n * S * 4 / (ms * 1e-3) / 1e9 / 8000.0}
+    ms = timed(lambda: o.copy_(x), 50)                      # the device's own copy of the same block, as the yardstick of a read + write stream
+    out["normalize"][str(n)]["torch_copy_gbs"] = 2 * n * S * 4 / (ms * 1e-3) / 1e9
+    ms = timed(lambda: x.sum(), 50)                         # ... and a library reduction as the yardstick of a read-only stream
+    out["record"][str(n)]["torch_sum_gbs"] = n * S * 4 / (ms * 1e-3) / 1e9
     del x, o
 xs = torch.randn((64, S), device="cuda")
 out["record64_plus_update_ms"] = timed(lambda: (nrm.record_device(xs.data_ptr(), 64), nrm.update()), 50)

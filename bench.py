@@ -38,7 +38,14 @@ def algorithmic_bytes_per_env_step(env):
     """HBM bytes one env-step must move: env record in + out, observation/reward/flags out."""
     rec = 4 * (3 * env.P + env.D + 8) + 8 * 6 + 4 * 4            # pose, vel, tar, tau, kin | clocks | flags
     out = 4 * env.S + 4 + 3 * 4                                   # state, reward, terminate/valid/episode_end
-    return 2 * rec + out
+    extra = 0
+    if getattr(env, "amp_size", 0):                               # imitate_amp and the task scenes: pose | vel history written at the action latch
+        extra += 4 * 2 * env.P                                    # (this bench asks for no AMP observation: its read-back of the row and the 4 amp_size output are not moved)
+    if getattr(env, "G", 0):                                      # task scenes: the goal row (16 doubles) in + out, RecordGoal kept for dm_last_goals
+        extra += 2 * 16 * 8 + 4 * env.G
+    if getattr(env, "has_obj", False):                            # dribble_amp: the free body's record in + out
+        extra += 2 * 16 * 4
+    return 2 * rec + out + extra
 
 
 def kernel_source_sha1():

@@ -324,7 +324,7 @@ def main():
     ap.add_argument("--physics", type=int, default=1, choices=[1, 2], help="contact model: 1 = DM-physics v1 (default, the headline), 2 = v2 (DESIGN.md 4.6; two characters per wavefront too since round 4)")
     ap.add_argument("--groups", type=int, default=0,
                     help="env groups per GPU: the rank's envs as G independent contexts on their own HIP streams (deepmimic_amd/groups.py; "
-                         "0 = auto (2 for the two-per-wave biped kernel at >= 4096 envs per GPU, +2.5..7 %%: the half-batches drift apart in phase and fill each other's wave-time tail; 1 otherwise); 1 = one launch per control step")
+                         "0 = auto (2 from 4096 envs per GPU on: the half-batches drift apart in phase and fill each other's wave-time tail, humanoid +2.5..7 %%, dog3d +15 %%; 1 below); 1 = one launch per control step")
     ap.add_argument("--sustain-seconds", type=float, default=2.5,
                     help="after the timed --steps region, run back-to-back control steps for at least this long and report that rate too (`sustained`); 0 = skip")
     ap.add_argument("--no-gather", action="store_true")
@@ -391,10 +391,11 @@ def main():
     n = args.envs
     from deepmimic_amd.groups import EnvGroups
     gather = (world > 1 or args.force_gather) and not args.no_gather
-    # --groups 0 (default): two groups for the two-per-wave biped kernel once the batch fills the chip's 2048 wave slots (>= 4096 envs), one launch
-    # per step otherwise (smaller batches leave slots idle either way; the dog's 4096 one-per-wave launches measured -4 % in groups)
+    # --groups 0 (default): two env groups on their own streams once the batch fills the chip's 2048 wave slots (>= 4096 envs): group A's next control step
+    # starts when A's own slowest wave is done and backfills the slots B's finished waves left (humanoid +2.5 .. 7 %, dog3d -- two rounds of waves per
+    # launch -- +15 %: profiles/r04_bench_env_sweep*.jsonl); below that size a second group only loses 1-4 %
     duo_kernel = args.wave_packing != 1 and tables.joint_mat.shape[0] <= 15 and tables.goal_kind != 5 and n % 2 == 0
-    auto_groups = 2 if (duo_kernel and n >= 4096) else 1      # measured 64 ... 32768 envs (profiles/r04_bench_env_sweep.jsonl): G = 2 loses 1-4 % below 4096 envs, wins 2.5-7 % from there on
+    auto_groups = 2 if n >= 4096 else 1
     want_groups = 1 if (args.gather == "cabi" and gather) else (auto_groups if args.groups <= 0 else args.groups)      # (the C-ABI exchange orders one ctx stream against the comm stream)
     envs = EnvGroups(tables, n, groups=want_groups, device_id=local_rank if on_gpu else 0, seed=1234, precision=args.precision, env_id_offset=rank * n,
                      test_mode=True, wave_packing=args.wave_packing, physics=args.physics)

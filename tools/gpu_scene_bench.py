@@ -11,7 +11,8 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 from deepmimic_amd import model  # noqa: E402
-from deepmimic_amd.vec_env import TorchVecEnv  # noqa: E402
+from deepmimic_amd.vec_env import TorchVecEnv, TorchVecEnvGroups  # noqa: E402
+import time  # noqa: E402
 
 SCENES = [("imitate", "humanoid3d_walk", None), ("imitate + perturbs", "humanoid3d_walk", "perturb"), ("imitate_amp", "humanoid3d_walk", "amp"),
           ("target_amp", "amp_target_zombie", None), ("heading_amp", "amp_heading_zombie", None), ("heading_amp (4 clips)", "amp_heading_clips4", None),
@@ -55,6 +56,24 @@ def main():
                                 "ms_per_step": ms, "env_steps_per_s": n / (ms * 1e-3), "episodes_ended_in_last_step": int(v.episode_end.sum().item()),
                                 "finite": bool(torch.isfinite(v.obs).all().item() and torch.isfinite(v.reward).all().item())}
         v.close()
+        # the same scene as two env groups on their own streams (deepmimic_amd/groups.py): wall clock over 100 control steps of both groups
+        g = TorchVecEnvGroups(t, n, groups=2, seed=1234, amp_obs=True)
+        g.reset()
+
+        def glaunch():
+            for k in range(g.G):
+                g.g.step_group_device(k, 0, g.obs.data_ptr(), g.reward.data_ptr(), g.terminate.data_ptr(), g.valid.data_ptr(), g.episode_end.data_ptr(),
+                                      timestep=g.timestep, n_updates=g.updates, auto_reset=True, open_loop=True,
+                                      amp_ptr=g.amp_obs.data_ptr() if g.amp_obs is not None else 0)
+        for _ in range(60):
+            glaunch()
+        g.g.synchronize(); torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(100):
+            glaunch()
+        g.g.synchronize(); torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        out["scenes"][label]["two_groups_env_steps_per_s"] = n * 100 / dt
+        out["scenes"][label]["two_groups_finite"] = bool(torch.isfinite(g.obs).all().item() and torch.isfinite(g.reward).all().item())
+        g.close()
     print(json.dumps(out))
 
 

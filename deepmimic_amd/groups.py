@@ -6,7 +6,9 @@ half-batches on two streams drift apart in phase: when the fast waves of group A
 SIMDs run uncontended, and A's next control step starts when A's own slowest wave is done, not the whole batch's.  Measured on one
 MI355X (tools/gpu_ab_groups.py, profiles/r04_ab_groups.json): 2.095 M -> 2.236 M env-steps/s at G = 2 (+6.7 %); G >= 4 is slower (2.23 / 2.22 M at
 G = 4 / 8 once HIP has enough hardware queues, GPU_MAX_HW_QUEUES >= 16; under the default 4 queues streams alias and serialise:
-profiles/r04_bench_groups_by_hw_queues.jsonl), so 2 is the only useful value and the default.
+profiles/r04_bench_groups_by_hw_queues.jsonl), so 2 is the only useful value and the default.  Every kernel gains once the batch fills the
+chip's 2048 wave slots (>= 4096 envs): dog3d_pace, whose 4096-wave launch is two ragged rounds, +15 % (0.797 -> 0.919 M), dribble_amp +9 %,
+the one-character humanoid kernel +5 %; below 4096 envs a second group loses 1-4 % (profiles/r04_bench_env_sweep*.jsonl).
 
 Nothing in the C-ABI changes: a group is a `dm_create` of its own with `env_id_offset` = its first global env id, which keys every
 reset / goal / perturbation draw by the GLOBAL id -- env i's trajectory is the same in any grouping (tests/test_groups.py), exactly

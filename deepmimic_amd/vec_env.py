@@ -3,7 +3,8 @@ torch tensors, one kernel launch per 30 Hz control step, asynchronous on torch's
 the path (the facade in compat/ is the drop-in for the reference's one-env-per-process driver; this is the batched form of the same
 protocol: SetAction ; 20 x Update ; RecordState / CalcReward / CheckTerminate ; Reset of finished episodes, DeepMimic.py:62-80).
 
-torch is plumbing here (device memory, streams); the stepping itself is libdm_hip.so.
+torch is plumbing here (device memory, streams); the stepping itself is libdm_hip.so.  From 4096 envs per GPU on, `TorchVecEnvGroups` (two env groups on their
+own streams, below) is the faster form of the same thing: +2 ... 15 % depending on the scene (profiles/r04_bench_scenes_groups.json).
 
 `--timer_type exp` scenes are served like the uniform timer since round 4: the in-kernel auto-reset draws min(min + Exp, max) (util/Timer.cpp:64-67)."""
 from __future__ import annotations

@@ -394,7 +394,6 @@ def main():
     # --groups 0 (default): two env groups on their own streams once the batch fills the chip's 2048 wave slots (>= 4096 envs): group A's next control step
     # starts when A's own slowest wave is done and backfills the slots B's finished waves left (humanoid +2.5 .. 7 %, dog3d -- two rounds of waves per
     # launch -- +15 %: profiles/r04_bench_env_sweep*.jsonl); below that size a second group only loses 1-4 %
-    duo_kernel = args.wave_packing != 1 and tables.joint_mat.shape[0] <= 15 and tables.goal_kind != 5 and n % 2 == 0
     auto_groups = 2 if n >= 4096 else 1
     want_groups = 1 if (args.gather == "cabi" and gather) else (auto_groups if args.groups <= 0 else args.groups)      # (the C-ABI exchange orders one ctx stream against the comm stream)
     envs = EnvGroups(tables, n, groups=want_groups, device_id=local_rank if on_gpu else 0, seed=1234, precision=args.precision, env_id_offset=rank * n,

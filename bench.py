@@ -274,6 +274,26 @@ def facade_bench(scene, steps, workers=(1,), private_too=True):
                       "host_cores": os.cpu_count(), **out}))
 
 
+def parity_check(tables, envs, step_and_read, n_sample=64, steps=5):
+    """`checks.parity` of the bench line: `n_sample` strided envs of THIS run's contexts -- where the timed rollout left them, the same step function, the same
+    launches (every wave slot occupied, both groups in flight) -- compared with the CPU oracle over `steps` control steps.  Before each step the oracles are put
+    where the device envs are (get_state -> Oracle.set_full_state), so every sample is one control step (20 updates, 40 substeps) from identical inputs; nothing
+    is written to the device.  The oracle is the CHECKER here (tests/parity_common.sampled_compare), after and outside every timed region.
+    Rows: reward scenes/SceneImitate.cpp:7-127, flags scenes/RLSceneSimChar.cpp, via the oracle."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import parity_common as pc
+    n = envs.N
+    ids = np.unique(np.round(np.linspace(0, n - 1, n_sample)).astype(np.int64))
+    dr, ds, alive, ok, ends = pc.sampled_compare(envs.get_state, step_and_read, tables, ids, steps)
+    live = dr[alive]
+    sl = ds[alive & np.isfinite(ds)]
+    q = lambda a, p_: (float(np.quantile(a, p_)) if a.size else None)
+    return {"envs": int(ids.size), "steps": int(steps), "samples": int(dr.size), "live": int(alive.sum()), "episode_ends": int(ends),
+            "reward_mae": (float(live.mean()) if live.size else None), "reward_p99": q(live, 0.99), "reward_max": (float(live.max()) if live.size else None),
+            "reward_max_not_live": float(dr[~alive].max(initial=0.0)), "state_rel_mean": (float(sl.mean()) if sl.size else None), "state_rel_max": (float(sl.max()) if sl.size else None),
+            "flags_equal": bool(ok), "against": "oracle (fp64), re-synchronised from the device state before every control step; live = oracle reward != 0"}
+
+
 def closed_loop(envs, stream_handles, dev, steps):
     """policy(g) -> control step(g) on each group's stream, `steps` times; one Policy object per group (its activation buffers are per object)"""
     import torch
@@ -334,6 +354,9 @@ def main():
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="nccl (= RCCL, the product) or gloo: CPU test harness of the N > 1 path (needs DM_HIP_LIB = the emulator build and DM_ALLOW_EMULATOR=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity-check", action="store_true", help="skip `checks.parity` (sampled envs of this run's contexts against the CPU oracle, after the timed regions)")
+    ap.add_argument("--parity-envs", type=int, default=64)
+    ap.add_argument("--parity-steps", type=int, default=5)
     ap.add_argument("--no-closed-loop", action="store_true", help="skip the `closed_loop` extra (policy on the matrix cores -> control step, N = 1 only)")
     ap.add_argument("--facade", action="store_true", help="measure the single-env cDeepMimicCore facade path instead of the batched env")
     ap.add_argument("--workers", type=int, nargs="*", default=[1], help="with --facade: aggregate rate of W worker processes (one cDeepMimicCore each) sharing the GPU, e.g. --workers 1 16 64")
@@ -514,6 +537,23 @@ def main():
     mean_reward = float(torch.cat([v[1] for v in last]).mean().item())
     finite = all(bool(torch.isfinite(v[0]).all().item()) for v in last)
 
+    # per-env parity of THIS run's contexts against the oracle (rank 0 compares; with a record exchange every rank takes the same steps)
+    parity = None
+    if not args.no_parity_check:
+        def step_and_read():
+            one_step(); drain(); dev_sync()
+            vs = [exs[g].views((tick[0] - 1) & 1) for g in range(len(exs))]
+            return {"state": torch.cat([v[0] for v in vs]).cpu().numpy(), "reward": torch.cat([v[1] for v in vs]).cpu().numpy(),
+                    "terminate": torch.cat([v[2] for v in vs]).cpu().numpy(), "valid": valid.cpu().numpy(), "episode_end": ends.cpu().numpy()}
+        try:
+            if rank == 0:
+                parity = parity_check(tables, envs, step_and_read, args.parity_envs, args.parity_steps)
+            else:
+                for _ in range(args.parity_steps):
+                    step_and_read()
+        except Exception as ex:                                     # noqa: BLE001  (reported, never silently dropped)
+            parity = {"error": "%s: %s" % (type(ex).__name__, ex)}
+
     # extra, N = 1: the same envs driven by the on-device policy (dm_policy.h: S -> 1024 -> 512 -> A on the MFMA units -- 227 / 28 for the humanoid --, random init, sampled
     # actions) instead of fixed actions -- what a sampler sees per control step.  Never `value`; a failure here is reported, not fatal.
     closed = None
@@ -566,7 +606,7 @@ def main():
                                  "(HIP events on each launch stream over the timed region); with `concurrent_launches` groups in flight the chip moves "
                                  "`achieved_all_streams`"},
             "sustained": (dict(sustained, ratio_to_value=sustained["value"] / value) if sustained else None),
-            "checks": {"mean_reward": mean_reward, "finite": finite},
+            "checks": {"mean_reward": mean_reward, "finite": finite, "parity": parity},
             "closed_loop": closed,
         }
         if not args.no_cpu_baseline and world == 1:

@@ -84,6 +84,11 @@ class EnvGroups:
             outs.append(e.step(a, timestep, n_updates, **kw))
         return {k: np.concatenate([o[k] for o in outs], axis=0) for k in outs[0]}
 
+    def get_state(self):
+        """`BatchEnv.get_state` of every group (each synchronises its own stream), rows concatenated in env order"""
+        parts = [e.get_state() for e in self.envs]
+        return {k: np.concatenate([p[k] for p in parts], axis=0) for k in parts[0]}
+
     def bench_rollout(self, warmup: int, steps: int, **kw) -> float:
         """Fixed-action rollout of every group, each from its own host thread through the C loop (`dm_bench_rollout`, ctypes drops the
         GIL), all released together; returns the wall-clock milliseconds from the common start to the last group's end."""

@@ -354,6 +354,19 @@ void orc_skel_spd_tau(void* h, const double* pose_, const double* vel_, const do
 void orc_set_kin_origin(void* h, const double* pos3, const double* rot4) {
     Scene* s = (Scene*)h; s->kin.origin = v3in_(pos3); s->kin.origin_rot = qin_(rot4);
 }
+// (tests / bench.py's parity check: put the oracle where the DEVICE is -- the arrays of the product's dm_get_state: pose, vel, PD targets, kinematic
+//  origin {pos, rot wxyz}, clocks {kin time, controller time, init time offset, episode timer, its limit}, flags {need_new_action, ground-contact
+//  mask, episode counter (unused here), -}; the kinematic pose is re-posed from (time, origin) as cKinCharacter::Pose does)
+void orc_set_full_state(void* h, const double* pose, const double* vel, const double* tar, const double* origin7, const double* clocks5, const int* flags4) {
+    Scene* s = (Scene*)h;
+    s->set_sim_state(copy_in(pose, s->sk.P), copy_in(vel, s->sk.P));
+    s->tar_pose = copy_in(tar, s->sk.P);
+    s->kin.origin = v3in_(origin7); s->kin.origin_rot = qin_(origin7 + 3);
+    s->kin.time = clocks5[0]; s->kin.do_pose();
+    s->ctrl_time = clocks5[1]; s->init_time_offset = clocks5[2]; s->timer_time = clocks5[3]; s->timer_max = clocks5[4];
+    s->need_new_action = flags4[0] != 0;
+    for (int j = 0; j < s->sk.J; ++j) s->in_contact[j] = (flags4[1] >> j) & 1;
+}
 void orc_kin_set_time(void* h, double t) { Scene* s = (Scene*)h; s->kin.time = t; s->kin.do_pose(); }
 void orc_kin_set_root_pos(void* h, const double* p3) { ((Scene*)h)->kin.set_root_pos_(v3in_(p3)); }
 void orc_kin_rotate_root(void* h, const double* q4) { ((Scene*)h)->kin.rotate_root(qin_(q4)); }

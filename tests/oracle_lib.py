@@ -192,6 +192,13 @@ class Oracle:
         v = np.ascontiguousarray(v, dtype=np.float64)
         self.lib.orc_set_sim_state(self.h, _d(p), _d(v))
 
+    def set_full_state(self, pose, vel, tar, kin_origin, clocks, flags):
+        """put the oracle where a DEVICE env is: one row of every array of `BatchEnv.get_state()` (the kinematic pose is re-posed from time + origin)"""
+        f = lambda a: np.ascontiguousarray(a, dtype=np.float64)
+        pose, vel, tar, kin_origin, clocks = f(pose), f(vel), f(tar), f(kin_origin), f(clocks)
+        flags = np.ascontiguousarray(flags, dtype=np.int32)
+        self.lib.orc_set_full_state(self.h, _d(pose), _d(vel), _d(tar), _d(kin_origin), _d(clocks), flags.ctypes.data_as(_ip))
+
     def manifolds(self):
         """physics 2: the persistent ground manifolds, J x 25 (the layout of BatchEnv.get_manifolds)"""
         m = np.zeros((self.J, 25))

@@ -531,3 +531,65 @@ def goal_rollout_compare(t, precision, lib_path, steps, n, seed, wave_packing=0,
                 w["aux_steps"] += int((t.goal_kind == 3 and out["goal"][e][3] > 0) or (t.goal_kind == 4 and oa[0] != 0))
     w["reward_mean"] = float(np.mean(w.pop("reward_errs"))); w["goal_mean"] = float(np.mean(w.pop("goal_errs")))
     return w
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# Oracles shadowing a SAMPLE of a large device batch (round 5: the 4096-env configurations bench.py times).  Before every control step the
+# oracles are put where the device envs ARE (one row each of BatchEnv.get_state: pose, velocity, PD targets, kinematic origin, clocks, flags),
+# so each comparison checks one control step (20 updates, 40 substeps) of the production launch -- every wave slot of the chip occupied, high
+# block indices, two contexts on two streams -- from identical inputs, on states the device itself reached.  Nothing is written to the device.
+class OracleSample:
+    def __init__(self, tables, ids, variant=""):
+        self.ids = np.asarray(ids, dtype=np.int64)
+        self.oracles = [Oracle(tables, variant=variant) for _ in self.ids]
+
+    def sync(self, st):
+        """st = get_state() of the WHOLE batch (rows = envs)"""
+        for o, i in zip(self.oracles, self.ids):
+            o.set_full_state(st["pose"][i], st["vel"][i], st["tar"][i], st["kin"][i], st["clocks"][i], st["flags"][i])
+
+    def control_step(self, n_updates=20, dt=DT):
+        """open-loop tracking (stream A1) with the driver's end-of-episode rule; returns per sampled env
+        reward, terminate, valid, episode_end, state vector (of the env as the step left it: BEFORE any reset)"""
+        n = len(self.oracles)
+        r, tm, vd, en, st = np.zeros(n), np.zeros(n, np.int32), np.zeros(n, np.int32), np.zeros(n, np.int32), []
+        for k, o in enumerate(self.oracles):
+            for u in range(n_updates):
+                if o.need_new_action():                  # the device's open-loop stream encodes the kinematic pose at whichever update latches an action
+                    kp, _, _ = o.kin_state()
+                    o.set_action(o.pose_to_action(kp))
+                o.update(dt)
+                if o.is_episode_end() or not o.check_valid_episode():      # the driver's rule (DeepMimic.py:62-80), the device's DM_END_EPISODE_EARLY
+                    break
+            r[k] = o.calc_reward(); tm[k] = o.check_terminate(); vd[k] = int(o.check_valid_episode()); en[k] = int(o.is_episode_end())
+            st.append(o.record_state())
+        return r, tm, vd, en, np.array(st)
+
+
+def sampled_compare(get_state, step, tables, ids, steps, conditioning=False):
+    """`steps` control steps of a device batch (step() -> dict of whole-batch host arrays, auto-reset on) with the sampled envs `ids`
+    compared against oracles re-synchronised from the device before each step.  Returns |reward diff|, relative max |state diff| (NaN on
+    steps whose env was auto-reset: the device's observation is then the first of the new episode), live mask (steps x len(ids)), flags ok, #episode ends seen.
+    conditioning=True adds a sixth array: |reward(fp64 oracle) - reward(the oracle's own fp32 build)| from the SAME synchronised state -- a control step on
+    which the restatement itself, narrowed to float, misses its fp64 self is ill-conditioned in single precision (fp32_step_sensitivity above)."""
+    smp = OracleSample(tables, ids)
+    s32 = OracleSample(tables, ids, variant="f32") if conditioning else None
+    n = len(smp.ids)
+    dr, ds, alive, ok, ends = np.zeros((steps, n)), np.full((steps, n), np.nan), np.zeros((steps, n), dtype=bool), True, 0
+    d32 = np.zeros((steps, n))
+    for k in range(steps):
+        st0 = get_state()
+        smp.sync(st0)
+        out = step()
+        r, tm, vd, en, so = smp.control_step()
+        if s32 is not None:
+            s32.sync(st0)
+            d32[k] = np.abs(s32.control_step()[0] - r)
+        for j, i in enumerate(smp.ids):
+            dr[k, j] = abs(float(out["reward"][i]) - r[j]); alive[k, j] = r[j] != 0.0
+            ok &= int(out["terminate"][i]) == tm[j] and int(out["valid"][i]) == vd[j] and int(bool(out["episode_end"][i])) == en[j]
+            if en[j] or not vd[j]:
+                ends += 1
+            else:
+                ds[k, j] = np.abs(out["state"][i] - so[j]).max() / max(1.0, np.abs(so[j]).max())
+    return (dr, ds, alive, ok, ends, d32) if conditioning else (dr, ds, alive, ok, ends)

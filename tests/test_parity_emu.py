@@ -143,3 +143,20 @@ def test_biped_tree_class_fp64(emu_lib, monkeypatch):
     pc.check_substep("humanoid3d_walk", 64, emu_lib, 1e-8, 1e-10, lift=-0.03)
     dr, ds, ok = pc.rollout_compare("humanoid3d_walk", 64, emu_lib, steps=6)
     assert ok and dr.max() < 1e-6 and ds.max() < 1e-5
+
+
+def test_sampled_compare_from_device_states_emulator(emu_lib):
+    """parity_common.sampled_compare (the checker of tests/test_parity_4096.py and of bench.py's `checks.parity`): oracles re-synchronised FROM
+    the device envs before every control step (Oracle.set_full_state <- BatchEnv.get_state), two env groups, through auto-resets; fp64 build."""
+    from deepmimic_amd import streams
+    from deepmimic_amd.groups import EnvGroups
+    t = model.load_asset("humanoid3d_walk")
+    env = EnvGroups(t, 8, groups=2, seed=1234, precision=64, lib_path=emu_lib, test_mode=True)
+    env.reset(kin_times=streams.reset_phase(np.arange(8), env.duration))
+    step = lambda: env.step(None, pc.DT, 20, open_loop=True, auto_reset=True)
+    for _ in range(24):
+        step()
+    dr, ds, alive, ok, ends = pc.sampled_compare(env.get_state, step, t, [0, 3, 5, 7], 12)
+    assert ok and ends > 0 and alive.sum() > 30
+    assert dr.max() < 1e-6 and np.nanmax(ds) < 1e-6
+    env.close()

@@ -8,7 +8,7 @@ One "step" = one 30 Hz control step of EVERY env on the rank = 20 scene updates 
 two `k_env_step_duo` launches of 2048 envs per control step, drifting apart in phase and filling each other's wave-time tail); `--groups 1` is one
 launch per control step.  Workload (configs[1] of BASELINE.json): humanoid3d_walk, 4096 envs per GPU, fixed-action stream A1 (open-loop mocap tracking,
 generated on device), inputs resident in HBM.  The line carries `roofline` (per launch; `valu` = the binding figures from the committed counter files,
-stamped with the kernel sources they were taken on), `sustained` (a >= 2.5 s window behind the timed steps), `closed_loop` (N = 1: the same envs driven by the on-device policy, an extra -- never `value`) and `cpu_baseline`.
+stamped with the kernel sources they were taken on), `sustained` (a >= 8 s window behind the timed steps: longer than a 5 s outside GPU-busy sampler's period), `closed_loop` (N = 1: the same envs driven by the on-device policy, an extra -- never `value`) and `cpu_baseline`.
 N > 1: one process per GPU (torch.distributed, backend nccl = RCCL), env shards are independent (weak scaling); the only collective is the per-step
 all-gather of (state, reward, terminate) for the learner, one exchange per env group on the group's stream.
 `python bench.py --gpus N` with no WORLD_SIZE in the environment launches its own N ranks (one per GPU, rank r on GPU r) under
@@ -274,6 +274,31 @@ def facade_bench(scene, steps, workers=(1,), private_too=True):
                       "host_cores": os.cpu_count(), **out}))
 
 
+def latency_ceiling(tables, args, device_id, kname, family_id):
+    """The ceiling of THIS kernel shape: a control step is a chain of dependent phases per wavefront, and the chip holds `wave_slots` wavefronts at the
+    kernel's occupancy -- so throughput <= wave_slots x envs_per_wave / (time of a control step when the waves are alone on their SIMDs).  Measured live: 64 envs (32 or
+    64 wavefronts on 256 CUs), same workload, same episode mixture after the same warm-up."""
+    from deepmimic_amd.core import BatchEnv
+    from deepmimic_amd import streams
+    n0 = 64
+    e = BatchEnv(tables, n0, device_id=device_id, seed=1234, precision=args.precision, test_mode=True, wave_packing=args.wave_packing, physics=args.physics)
+    e.reset(kin_times=streams.reset_phase(np.arange(n0), e.duration))
+    ms = e.bench_rollout(60, 200) / 200
+    e.close()
+    occ = None
+    try:        # waves per SIMD of the shipped kernel from the compiler's resource remarks (deepmimic_amd/csrc/build/k_f32_<family>.o.res)
+        import re
+        txt = open(os.path.join(ROOT, "deepmimic_amd", "csrc", "build", "k_f%d_%d.o.res" % (args.precision, family_id))).read()
+        occ = min(int(x) for x in re.findall(r"Occupancy \[waves/SIMD\]: (\d+)", txt))
+    except Exception:
+        pass
+    waves_per_simd = occ if occ else 2
+    epw = 2 if kname == "k_env_step_duo" else 1
+    slots = 256 * 4 * waves_per_simd
+    return {"lone_wave_ms_per_step": ms, "waves_per_simd": waves_per_simd, "waves_per_simd_source": "compiler resource remarks" if occ else "assumed",
+            "wave_slots": slots, "envs_per_wave": epw, "env_steps_per_s": slots * epw / (ms * 1e-3)}
+
+
 def parity_check(tables, envs, step_and_read, n_sample=64, steps=5):
     """`checks.parity` of the bench line: `n_sample` strided envs of THIS run's contexts -- where the timed rollout left them, the same step function, the same
     launches (every wave slot occupied, both groups in flight) -- compared with the CPU oracle over `steps` control steps.  Before each step the oracles are put
@@ -345,7 +370,7 @@ def main():
     ap.add_argument("--groups", type=int, default=0,
                     help="env groups per GPU: the rank's envs as G independent contexts on their own HIP streams (deepmimic_amd/groups.py; "
                          "0 = auto (2 from 4096 envs per GPU on: the half-batches drift apart in phase and fill each other's wave-time tail, humanoid +2.5..7 %%, dog3d +15 %%; 1 below); 1 = one launch per control step")
-    ap.add_argument("--sustain-seconds", type=float, default=2.5,
+    ap.add_argument("--sustain-seconds", type=float, default=8.0,
                     help="after the timed --steps region, run back-to-back control steps for at least this long and report that rate too (`sustained`); 0 = skip")
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--force-gather", action="store_true", help="exercise the record exchange even with one rank")
@@ -418,7 +443,7 @@ def main():
     # starts when A's own slowest wave is done and backfills the slots B's finished waves left (humanoid +2.5 .. 7 %, dog3d -- two rounds of waves per
     # launch -- +15 %: profiles/r04_bench_env_sweep*.jsonl); below that size a second group only loses 1-4 %
     auto_groups = 2 if n >= 4096 else 1
-    want_groups = 1 if (args.gather == "cabi" and gather) else (auto_groups if args.groups <= 0 else args.groups)      # (the C-ABI exchange orders one ctx stream against the comm stream)
+    want_groups = auto_groups if args.groups <= 0 else args.groups
     envs = EnvGroups(tables, n, groups=want_groups, device_id=local_rank if on_gpu else 0, seed=1234, precision=args.precision, env_id_offset=rank * n,
                      test_mode=True, wave_packing=args.wave_packing, physics=args.physics)
     G = envs.G
@@ -445,7 +470,9 @@ def main():
     # made group A's step k + 1 wait for B's step k and pulled the groups back into phase: measured 2.08 M instead of 2.21 M with one rank)
     from deepmimic_amd.dist import CabiRecordExchange, RecordExchange
     if args.gather == "cabi" and gather:
-        exs = [CabiRecordExchange(env, world, rank, dev, depth=2, force_rccl=True)]
+        # one dm_comm (its own RCCL communicator and stream) per env group: a group's gather is ordered against THAT group's ctx stream only (HIP events), so the
+        # groups never wait for each other; the communicators are created in group order on every rank
+        exs = [CabiRecordExchange(envs.envs[g], world, rank, dev, depth=2, force_rccl=True) for g in range(G)]
     else:
         exs = [RecordExchange(envs.count[g], env.S, world, dev, depth=2, env=env if G == 1 else None) for g in range(G)]
     tick = [0]
@@ -577,6 +604,23 @@ def main():
         if traffic is not None:
             traffic = traffic * envs_per_launch / n
         value = world * n * args.steps / elapsed
+        valu_obj = measured_valu(args.scene, n, kname, value) or {"binding": "VALU issue + dependent-chain latency (fp32 vector)", "source": []}
+        if on_gpu:
+            try:
+                # kernel family of dm_kernels.cpp this workload launches (deepmimic_amd/csrc/Makefile KIDS): plain / AMP-or-perturbation / v2 instantiation of the
+                # two-per-wave kernel, or of the one-per-wave kernel on the compiled humanoid3d / dog3d topology, or biped + free body
+                v = 2 if args.physics == 2 else (1 if (env.amp_size > 0 or env.has_perturbs) else 0)
+                if kname == "k_env_step_duo":
+                    fam = (0, 1, 22)[v]
+                elif tables.goal_kind == 5:
+                    fam = 9
+                else:
+                    fam = ((12, 13, 20) if env.J > 15 else (15, 16, 21))[v]
+                lc = latency_ceiling(tables, args, local_rank, kname, fam)
+                lc["frac"] = (value / world) / lc["env_steps_per_s"]
+                valu_obj["latency_ceiling"] = lc
+            except Exception as ex:                                 # noqa: BLE001
+                valu_obj["latency_ceiling"] = {"error": "%s: %s" % (type(ex).__name__, ex)}
         if world > 1:
             workload = "%s, %d envs sharded %d x %d (one shard per GPU), fixed-action (open-loop mocap tracking) rollout, auto-reset, " \
                        "20 updates of 1/600 s x 2 substeps per step" % (args.scene, world * n, world, n)
@@ -591,17 +635,17 @@ def main():
             "config": {"workload": workload, "envs_per_gpu": n, "envs_total": world * n, "backend": "rccl" if on_gpu else "gloo + CPU emulator (test harness, not a measurement)", "wave_packing": args.wave_packing, "physics": args.physics, "warmup_steps_run": warm, "groups": G, "envs_per_launch": envs_per_launch, "parallelism": "env-shards x%d%s" % (world, " + async RCCL all-gather of the record, overlapped with the next step" if gather else "")},
             "sim_updates_per_s": value * 20,
             "per_rank_env_steps_per_s": per_rank, "record_exchange": {"backend": (args.gather if gather else None), "exposed_ms_per_step_rank0": exposed_ms},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
+            "roofline": {"bound": "valu-issue/latency", "bound_of_the_figures_below": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
                          "traffic": traffic, "traffic_source": traffic_source,
                          # true: the committed counter file was taken on exactly the device sources this library was built from; false: a kernel has changed since
                          # (re-profile: tools/gpu_round_profile.sh); null: the file predates the stamp
                          "traffic_source_current": getattr(measured_traffic, "current", None),
                          "kernel": kname, "kernel_ms": kernel_ms,
                          "concurrent_launches": G, "achieved_all_streams": (achieved * G) if achieved else None,
-                         "valu": measured_valu(args.scene, n, kname, value),
+                         "valu": valu_obj,
                          "algorithmic_bytes_per_env_step": algorithmic_bytes_per_env_step(env),
                          "algorithmic_bytes_per_launch": bytes_per_launch,
-                         "note": "VALU-issue / latency bound by construction (SURVEY 8d, DESIGN.md 6): the env record stays in LDS/VGPRs for the 20 updates "
+                         "note": "`bound` names what binds (VALU issue + dependent-chain latency; `valu` holds those figures, `valu.latency_ceiling` the live lone-wave ceiling); achieved / peak / frac / traffic are the HBM figures of the bench contract.  VALU-issue / latency bound by construction (SURVEY 8d, DESIGN.md 6): the env record stays in LDS/VGPRs for the 20 updates "
                                  "of a control step, HBM sees 2.4 KB per env-step; `valu` holds the binding figures.  achieved / kernel_ms are PER LAUNCH "
                                  "(HIP events on each launch stream over the timed region); with `concurrent_launches` groups in flight the chip moves "
                                  "`achieved_all_streams`"},

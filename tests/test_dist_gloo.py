@@ -164,3 +164,64 @@ def test_two_rank_normalizer_reduce_sum(emu_lib, tmp_path):
         ora.update()
     assert int(a["count"][0]) == ora.count
     assert np.allclose(a["mean"], ora.mean, rtol=1e-12, atol=1e-13) and np.allclose(a["std"], ora.std, rtol=1e-12, atol=1e-13)
+
+
+GROUPS_WORKER = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, os.environ["DM_ROOT"])
+import torch, torch.distributed as dist
+from deepmimic_amd import model
+from deepmimic_amd.groups import EnvGroups
+from deepmimic_amd.dist import RecordExchange
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+t = model.load_asset("humanoid3d_walk")
+n, G = 4, 2
+envs = EnvGroups(t, n, groups=G, env_id_offset=rank * n, seed=11, precision=64, lib_path=os.environ["DM_HIP_LIB"], wave_packing=1)
+assert envs.G == G
+envs.reset()
+exs = [RecordExchange(envs.count[g], envs.S, world, "cpu", depth=2) for g in range(G)]
+got = []
+for k in range(4):
+    slot = k & 1
+    for g in range(G):                       # bench.py's order: per group begin -> step -> launch; two gathers per control step on ONE process group
+        st, rw, tm = exs[g].begin(slot)
+        out = envs.envs[g].step(None, 1.0 / 600, 20, open_loop=True, auto_reset=True)
+        st.copy_(torch.from_numpy(out["state"])); rw.copy_(torch.from_numpy(out["reward"])); tm.copy_(torch.from_numpy(out["terminate"]))
+        exs[g].launch(slot)
+    if k >= 1:
+        rows = np.zeros((world * n, envs.S + 2), np.float32)
+        for g in range(G):
+            S_, R_, T_ = exs[g].result((k - 1) & 1)
+            for r in range(world):           # group g of rank r holds the global envs [r n + start_g, r n + start_g + count_g)
+                lo = r * n + envs.start[g]
+                rows[lo:lo + envs.count[g], :envs.S] = S_[r].numpy(); rows[lo:lo + envs.count[g], envs.S] = R_[r].numpy(); rows[lo:lo + envs.count[g], envs.S + 1] = T_[r].numpy()
+        got.append(rows)
+np.save(os.environ["DM_OUT"] + ".g%d.npy" % rank, np.stack(got))
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def test_two_ranks_two_groups_share_one_process_group(emu_lib, tmp_path):
+    """bench.py with env groups issues TWO all-gathers per control step (one per group) on ONE communicator.  That is correct because every rank issues them in
+    the same order (group 0, then group 1) and a process group runs its collectives in issue order (nccl: on its own stream; gloo: synchronously) -- the
+    assumption DESIGN.md section 8 states.  Here: 2 ranks x 2 groups, records consumed one step late; every rank must see every env's record, in global env
+    order, equal to the single-process rollout."""
+    out = str(tmp_path / "grp")
+    script = tmp_path / "groups_worker.py"
+    script.write_text(GROUPS_WORKER)
+    env = dict(os.environ, DM_ROOT=ROOT, DM_HIP_LIB=emu_lib, DM_OUT=out, MASTER_ADDR="127.0.0.1", DM_ALLOW_EMULATOR="1")
+    port = 33500 + (os.getpid() % 2000)
+    subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                           "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)], env=env, timeout=600)
+    a, b = np.load(out + ".g0.npy"), np.load(out + ".g1.npy")
+    assert np.array_equal(a, b)
+    from deepmimic_amd import model
+    from deepmimic_amd.dist import ShardedEnv
+    sh = ShardedEnv(model.load_asset("humanoid3d_walk"), 8, rank=0, world=1, device_id=0, seed=11, precision=64, lib_path=emu_lib, wave_packing=1)
+    sh.env.reset()
+    for k in range(3):
+        o = sh.env.step(None, 1.0 / 600, 20, open_loop=True, auto_reset=True)
+        assert np.array_equal(a[k], sh.pack_record(o)), k

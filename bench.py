@@ -529,6 +529,25 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
+    # per-env parity of THIS run's contexts against the oracle, right behind the timed region: the envs are where warm-up + K timed steps left them, which is the same
+    # state on every box for the same flags (deterministic resets, bit-reproducible kernels), so the sample -- and its result -- is reproducible.  Rank 0 compares; with
+    # a record exchange every rank takes the same steps
+    parity = None
+    if not args.no_parity_check:
+        def step_and_read():
+            one_step(); drain(); dev_sync()
+            vs = [exs[g].views((tick[0] - 1) & 1) for g in range(len(exs))]
+            return {"state": torch.cat([v[0] for v in vs]).cpu().numpy(), "reward": torch.cat([v[1] for v in vs]).cpu().numpy(),
+                    "terminate": torch.cat([v[2] for v in vs]).cpu().numpy(), "valid": valid.cpu().numpy(), "episode_end": ends.cpu().numpy()}
+        try:
+            if rank == 0:
+                parity = parity_check(tables, envs, step_and_read, args.parity_envs, args.parity_steps)
+            else:
+                for _ in range(args.parity_steps):
+                    step_and_read()
+        except Exception as ex:                                     # noqa: BLE001  (reported, never silently dropped)
+            parity = {"error": "%s: %s" % (type(ex).__name__, ex)}
+
     # a sustained window behind the --steps region: >= sustain-seconds of back-to-back control steps (same step function, same exchange), so
     # that the line also carries a rate measured over seconds (DVFS settled, visible to an outside GPU-busy sampler) next to the short one
     sustained = None
@@ -563,23 +582,6 @@ def main():
     last = [exs[g].views((tick[0] - 1) & 1) for g in range(G)]
     mean_reward = float(torch.cat([v[1] for v in last]).mean().item())
     finite = all(bool(torch.isfinite(v[0]).all().item()) for v in last)
-
-    # per-env parity of THIS run's contexts against the oracle (rank 0 compares; with a record exchange every rank takes the same steps)
-    parity = None
-    if not args.no_parity_check:
-        def step_and_read():
-            one_step(); drain(); dev_sync()
-            vs = [exs[g].views((tick[0] - 1) & 1) for g in range(len(exs))]
-            return {"state": torch.cat([v[0] for v in vs]).cpu().numpy(), "reward": torch.cat([v[1] for v in vs]).cpu().numpy(),
-                    "terminate": torch.cat([v[2] for v in vs]).cpu().numpy(), "valid": valid.cpu().numpy(), "episode_end": ends.cpu().numpy()}
-        try:
-            if rank == 0:
-                parity = parity_check(tables, envs, step_and_read, args.parity_envs, args.parity_steps)
-            else:
-                for _ in range(args.parity_steps):
-                    step_and_read()
-        except Exception as ex:                                     # noqa: BLE001  (reported, never silently dropped)
-            parity = {"error": "%s: %s" % (type(ex).__name__, ex)}
 
     # extra, N = 1: the same envs driven by the on-device policy (dm_policy.h: S -> 1024 -> 512 -> A on the MFMA units -- 227 / 28 for the humanoid --, random init, sampled
     # actions) instead of fixed actions -- what a sampler sees per control step.  Never `value`; a failure here is reported, not fatal.

@@ -87,9 +87,14 @@ class cDeepMimicCore(object):
     def ParseArgs(self, args):
         args = [str(a) for a in args]
         data_root = os.environ.get("DM_DATA_ROOT", ".")
-        self._tables = _model.load_scene_from_args(args, data_root=data_root)
         p = _model.ArgParser(args)
         af = p.str("arg_file", "")
+        if af and len(args) == 2 and not os.path.exists(af if os.path.isabs(af) else os.path.join(data_root, af)) and af in _model.ARG_FILE_ASSETS:
+            # the reference's data files are not here (e.g. the GPU box): the in-tree compiled copy of exactly this arg file (tools/compile_assets.py)
+            self._tables = _model.load_asset(_model.ARG_FILE_ASSETS[af])
+            self._num_update_substeps = int(self._tables.cfg.num_update_substeps)
+            return
+        self._tables = _model.load_scene_from_args(args, data_root=data_root)
         if af:
             p.load_file(af if os.path.isabs(af) else os.path.join(data_root, af))
         self._num_update_substeps = p.int("num_update_substeps", 1)      # DeepMimicCore.cpp:43

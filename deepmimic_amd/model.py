@@ -640,6 +640,17 @@ def load_scene_from_args(args: Sequence[str], data_root: str = ".") -> SceneTabl
 ASSET_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "assets")
 
 
+# the reference arg files whose compiled copies ship in-tree (tools/compile_assets.py made assets/<name>.json from exactly these): where the reference's data
+# files are absent (the GPU box), `ParseArgs(["--arg_file", <key>])` of the drop-in loads the compiled copy
+ARG_FILE_ASSETS = {
+    "args/run_humanoid3d_walk_args.txt": "humanoid3d_walk", "args/train_humanoid3d_spinkick_args.txt": "humanoid3d_spinkick",
+    "args/train_dog3d_pace_args.txt": "dog3d_pace", "args/run_humanoid3d_run_args.txt": "humanoid3d_run",
+    "args/run_humanoid3d_backflip_args.txt": "humanoid3d_backflip", "args/run_dog3d_spin_args.txt": "dog3d_spin",
+    "args/train_amp_heading_humanoid3d_zombie_args.txt": "amp_heading_zombie", "args/train_amp_target_humanoid3d_zombie_args.txt": "amp_target_zombie",
+    "args/train_amp_heading_getup_humanoid3d_locomotion_getup_args.txt": "amp_heading_getup", "args/train_amp_dribble_humanoid3d_zombie_args.txt": "amp_dribble_zombie",
+}
+
+
 def load_asset(name: str) -> SceneTables:
     """Load an in-tree compiled scene (``assets/<name>.json``), e.g. ``humanoid3d_walk``."""
     with open(os.path.join(ASSET_DIR, name + ".json")) as f:

@@ -22,6 +22,26 @@ static std::vector<uint16_t> pack_weights(const float* W, int K, int N, int Kp, 
     return out;
 }
 
+// the weight stream of k_policy_fused (dm_policy.h): per wave w, per layer-1 chunk q: K1 / 64 blocks {2 k-steps x feature tiles 16 q + 4 w + j}, then 8 blocks
+// {k-step 8 q + ksl of layer 2 x feature tiles 8 w + n}; a block is 8 fragments of [lane][8] bf16 (1 KB each), fragments as pack_weights lays them out
+static std::vector<uint16_t> pack_fused_stream(const std::vector<uint16_t>& w1p, const std::vector<uint16_t>& w2p, int K1) {
+    const int KS1 = K1 / 32, NB1 = KS1 / 2, NBQ = NB1 + 8, NBLK = 4 * NBQ, KS2 = 1024 / 32;
+    std::vector<uint16_t> out((size_t)4 * NBLK * 8 * 512, 0);
+    for (int w = 0; w < 4; ++w) for (int q = 0; q < 4; ++q) {
+        for (int b1 = 0; b1 < NB1; ++b1) for (int kk = 0; kk < 2; ++kk) for (int j = 0; j < 4; ++j) {
+            const size_t dst = (((size_t)w * NBLK + q * NBQ + b1) * 8 + kk * 4 + j) * 512;
+            const size_t src = ((size_t)(16 * q + 4 * w + j) * KS1 + 2 * b1 + kk) * 512;
+            std::copy(w1p.begin() + src, w1p.begin() + src + 512, out.begin() + dst);
+        }
+        for (int ksl = 0; ksl < 8; ++ksl) for (int n = 0; n < 8; ++n) {
+            const size_t dst = (((size_t)w * NBLK + q * NBQ + NB1 + ksl) * 8 + n) * 512;
+            const size_t src = ((size_t)(8 * w + n) * KS2 + 8 * q + ksl) * 512;
+            std::copy(w2p.begin() + src, w2p.begin() + src + 512, out.begin() + dst);
+        }
+    }
+    return out;
+}
+
 extern "C" {
 
 int dm_policy_create(int device_id, const dm_policy_params* pp, dm_policy** out) {
@@ -43,6 +63,15 @@ int dm_policy_create(int device_id, const dm_policy_params* pp, dm_policy** out)
     std::vector<float> b3(d.N3, 0.0f), sm(d.S, 0.0f), si(d.S, 1.0f), am(d.A, 0.0f), as(d.A, 1.0f), ls(d.A, 0.0f);
     for (int i = 0; i < d.A; ++i) { b3[i] = pp->b3[i]; if (pp->a_mean) am[i] = pp->a_mean[i]; if (pp->a_std) as[i] = pp->a_std[i]; if (pp->logstd) ls[i] = pp->logstd[i]; }
     for (int i = 0; i < d.S; ++i) { if (pp->s_mean) sm[i] = pp->s_mean[i]; if (pp->s_std) si[i] = 1.0f / pp->s_std[i]; }
+    // one-launch actor: compiled for the reference's widths (1024, 512), K1 = 256 / 384 and up to 64 action slots; a K1 of 320 is padded up to 384
+    d.wfs = nullptr;
+    if (d.H1 == 1024 && d.H2 == 512 && d.K1 <= 384 && d.N3 <= 64) {
+        if (d.K1 == 320) { d.K1 = 384; w1 = pack_weights(pp->w1, d.S, d.H1, d.K1, d.H1); }
+        if (d.K1 < 256) { d.K1 = 256; w1 = pack_weights(pp->w1, d.S, d.H1, d.K1, d.H1); }
+        std::vector<uint16_t> fs = pack_fused_stream(w1, w2, d.K1);
+        d.wfs = (const uint16_t*)p->up(fs.data(), fs.size() * 2);
+        if (!d.wfs) { delete p; return fail("device allocation failed"); }
+    }
     d.w1p = (const uint16_t*)p->up(w1.data(), w1.size() * 2); d.w2p = (const uint16_t*)p->up(w2.data(), w2.size() * 2); d.w3p = (const uint16_t*)p->up(w3.data(), w3.size() * 2);
     d.b1 = (const float*)p->up(pp->b1, sizeof(float) * d.H1); d.b2 = (const float*)p->up(pp->b2, sizeof(float) * d.H2); d.b3 = (const float*)p->up(b3.data(), sizeof(float) * d.N3);
     d.s_mean = (const float*)p->up(sm.data(), sizeof(float) * d.S); d.s_inv_std = (const float*)p->up(si.data(), sizeof(float) * d.S);
@@ -82,8 +111,33 @@ int dm_policy_forward_ex(dm_policy* p, const float* states_dev, const float* goa
     dmp::PolicyIO io; memset(&io, 0, sizeof(io));
     io.states = states_dev; io.s16 = p->s16; io.h1 = p->h1; io.h2 = p->h2; io.actions = actions_dev; io.logp = logp_dev; io.M = n; io.sample = sample ? 1 : 0;
     io.seed_lo = (uint32_t)seed; io.seed_hi = (uint32_t)(seed >> 32); io.step = step; io.env_off = env_id_offset;
+    if (const char* pr = getenv("DM_POLICY_PROBE")) io.probe = atoi(pr);
     io.goals = goal_dim ? goals_dev : nullptr; io.G = goal_dim; io.exp_rate = (float)exp_rate; io.exp_flags = exp_flags_dev;
     const dmp::PolicyDev& d = p->pd;
+    // one launch for the whole actor (k_policy_fused) where it is compiled for the widths; DM_POLICY_LAYERED=1 keeps the per-layer kernels (A/B, tests)
+    if (d.wfs && getenv("DM_POLICY_LAYERED") == nullptr) {
+        const unsigned grid = (unsigned)((n + 31) / 32);
+#ifndef DM_EMU
+        static unsigned long long* prof_buf = nullptr; static int prof_calls = 0;
+        if (io.probe == 2) { if (!prof_buf) hipMalloc((void**)&prof_buf, (size_t)8192 * 8 * 8); io.prof = grid <= 8192 ? prof_buf : nullptr; }
+#endif
+        if (d.K1 == 256 && d.N3 == 32) RT_LAUNCH4((dmp::k_policy_fused<8, 2>), grid, stream, d, io);
+        else if (d.K1 == 256) RT_LAUNCH4((dmp::k_policy_fused<8, 4>), grid, stream, d, io);
+        else if (d.N3 == 32) RT_LAUNCH4((dmp::k_policy_fused<12, 2>), grid, stream, d, io);
+        else RT_LAUNCH4((dmp::k_policy_fused<12, 4>), grid, stream, d, io);
+#ifndef DM_EMU
+        hipError_t le0 = hipGetLastError(); if (le0 != hipSuccess) return fail(std::string("kernel launch failed: ") + hipGetErrorString(le0));
+        if (io.prof && ++prof_calls == 100) {          // DM_POLICY_PROBE=2: phase times of the 100th launch (100 MHz constant clock -> ns), mean over the workgroups
+            hipStreamSynchronize(stream);
+            std::vector<unsigned long long> h((size_t)grid * 8); hipMemcpy(h.data(), prof_buf, h.size() * 8, hipMemcpyDeviceToHost);
+            double acc[6] = {0, 0, 0, 0, 0, 0}; unsigned long long t0 = ~0ull, t1 = 0;
+            for (unsigned b = 0; b < grid; ++b) { for (int i = 0; i < 6; ++i) acc[i] += 10.0 * (double)(h[b * 8 + i + 1] - h[b * 8 + i]); t0 = std::min(t0, h[b * 8]); t1 = std::max(t1, h[b * 8 + 6]); }
+            fprintf(stderr, "k_policy_fused phases (ns, mean of %u workgroups): prep %.0f | chunk0 layer1 %.0f | rest of the chunks %.0f | layer-2 epilogue + barrier %.0f | layer 3 + head %.0f | logp %.0f || first start -> last end %.0f\n",
+                    grid, acc[0] / grid, acc[1] / grid, acc[2] / grid, acc[3] / grid, acc[4] / grid, acc[5] / grid, 10.0 * (double)(t1 - t0));
+        }
+#endif
+        return 0;
+    }
     // tiles sized so that every launch has at least ~1 wave per SIMD at 4096 rows: 64 x 64 (layer 1), 32 x 64 (layer 2), 16 x 32 (layer 3)
     RT_LAUNCH(dmp::k_policy_prep, n, stream, d, io);
     // layers 1 and 2: the LDS-tiled four-wave GEMM when the width allows it, the one-wave kernel otherwise

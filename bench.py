@@ -345,12 +345,13 @@ def closed_loop(envs, stream_handles, dev, steps):
                                        env_id_offset=envs.first[g], stream=stream_handles[g])
                 envs.step_group_device(g, ac.data_ptr(), *ptrs, timestep=1.0 / 600, n_updates=20, auto_reset=True)
 
-    loop(0, 20)
+    warm = 60                  # two policy-driven episode lengths: the mixture of standing / tumbling / freshly reset characters the policy produces, not the transient behind the open-loop rollout
+    loop(0, warm)
     envs.synchronize(); torch.cuda.synchronize(); t0 = time.perf_counter()
-    loop(20, 20 + steps)
+    loop(warm, warm + steps)
     envs.synchronize(); torch.cuda.synchronize(); dt = time.perf_counter() - t0
     res = {"value": n * steps / dt, "unit": "env-steps/s", "steps": steps, "ms_per_step": 1e3 * dt / steps, "groups": envs.G,
-           "policy": "%d -> 1024 -> 512 -> %d, random init, sampled (dm_policy_forward, bf16 MFMA)" % (env.S, env.A),
+           "policy": "%d -> 1024 -> 512 -> %d, random init, sampled (dm_policy_forward: one launch per group and step, k_policy_fused, bf16 MFMA)" % (env.S, env.A), "warmup_steps": warm,
            "mean_reward": float(rw.mean().item()), "finite": bool(torch.isfinite(st).all().item())}
     for p in pols:
         p.close()
@@ -588,7 +589,7 @@ def main():
     closed = None
     if on_gpu and world == 1 and not args.no_closed_loop and not gather:
         try:
-            closed = closed_loop(envs, [s.cuda_stream for s in gstreams] if G > 1 else [0], dev, min(args.steps, 200))
+            closed = closed_loop(envs, [s.cuda_stream for s in gstreams] if G > 1 else [0], dev, min(max(args.steps, 200), 1000))      # >= 200 steps whatever --steps: a 20-step window is a transient
         except Exception as ex:                                     # noqa: BLE001
             closed = {"error": "%s: %s" % (type(ex).__name__, ex)}
 

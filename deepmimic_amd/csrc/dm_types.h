@@ -37,7 +37,10 @@ struct ClsBiped {      // humanoid3d: 15 links, 34 dof, 43 pose dims, <= 64 grou
 struct ClsBipedWide : ClsBiped { static constexpr int RREG = 64, RREG_PLAIN = 64; };
 // the fallback class of the two-per-wave kernel by default: the narrow row file (rows 32..63 of A in the HBM / L2 overflow block), but
 // the Gram matrix of a character with more than 32 rows still comes off the matrix core (64 accumulators live for the Gram only)
-struct ClsBipedFb : ClsBiped { static constexpr bool GRAM64 = true; };   // (a look-ahead of 6 rows instead of 2 measured no gain)
+#ifndef DM_FB_RREG
+#define DM_FB_RREG 32
+#endif
+struct ClsBipedFb : ClsBiped { static constexpr int RREG = DM_FB_RREG, RREG_PLAIN = DM_FB_RREG; static constexpr bool GRAM64 = true; };   // (a look-ahead of 6 rows instead of 2 measured no gain)
 // the biped class plus one free rigid sphere in the world (`--scene dribble_amp`: the ball, scenes/SceneDribbleAMP.cpp:398-420); one
 // character per wavefront, 2 waves / SIMD (the ball's Jacobian columns ride in six more VGPRs per row lane)
 struct ClsBipedObj : ClsBiped { static constexpr bool OBJ = true; static constexpr bool PGS_MASKSEL = true; };     // (same-box A/B of the mask select: -3.6 %; ClsBiped at 128 VGPRs: +2.8 %, SGPR pressure)

@@ -166,6 +166,8 @@ def serve(name: str, max_workers: int, device: int, precision: int, lib_path: st
     gather_quiet = float(os.environ.get("DM_BROKER_QUIET_US", "250")) * 1e-6      # ... or this long without a new arrival
     gen_addr = R.addr("wake", 1)
     wake_addr = R.addr("wake", 0)
+    gone = False
+    last_sweep = time.monotonic()
     stats = {"launches": 0, "steps": 0, "rounds": 0, "t_gather": 0.0, "t_step": 0.0, "t_other": 0.0, "t_idle": 0.0, "t_call": 0.0, "t_pre": 0.0, "other_ops": 0}
     t_mark = time.perf_counter()
     try:
@@ -182,14 +184,32 @@ def serve(name: str, max_workers: int, device: int, precision: int, lib_path: st
                         for i in np.nonzero(R.owner)[0]:
                             if not os.path.exists("/proc/%d" % int(R.owner[i])):
                                 R.owner[i] = 0
-                    elif had_worker and time.monotonic() - idle_since > idle_exit_s:
-                        break
-                    elif not had_worker and time.monotonic() - idle_since > 120.0:
-                        break
+                    elif (had_worker and time.monotonic() - idle_since > idle_exit_s) or (not had_worker and time.monotonic() - idle_since > 120.0):
+                        # leave -- decided and carried out under the region's file lock, the one workers hold while they look for an owner and claim a slot: nobody
+                        # can attach to a region that is about to go, and no late unlink can remove the name of a successor's region
+                        with _open_private("/dev/shm/%s.lock" % name, "a+") as lk:
+                            fcntl.flock(lk, fcntl.LOCK_EX)
+                            if np.count_nonzero(R.owner) == 0:
+                                R.hdr[0] = 0
+                                R.hdr[9] = stats["launches"]; R.hdr[10] = stats["steps"]
+                                R.close(unlink=True)
+                                gone = True
+                        if gone:
+                            break
+                        had_worker, idle_since = True, time.monotonic()      # a worker claimed a slot while the lock was awaited: stay
+                        continue
                     futex_wait(wake_addr, 0, 0.05)
                     continue
             # gather window: the workers of a control step were woken together and come back in a burst.  A launch costs ~1.5 ms whatever it carries, so
             # the owner waits for the burst: until every attached worker has a request pending, or nothing new has arrived for `quiet`, or `max_wait`.
+            if time.monotonic() - last_sweep > 1.0:          # a worker that died without detaching must not hold every later round to the full gather window
+                last_sweep = time.monotonic()
+                for i in np.nonzero(R.owner)[0]:
+                    if not os.path.exists("/proc/%d" % int(R.owner[i])):
+                        R.owner[i] = 0
+                pend = np.nonzero((R.req != R.ack) & (R.owner != 0))[0]
+                if pend.size == 0:
+                    continue
             n_att = int(np.count_nonzero(R.owner))
             t_g0 = time.perf_counter(); stats["t_idle"] += t_g0 - t_mark
             if pend.size < n_att and gather_max > 0:
@@ -211,16 +231,29 @@ def serve(name: str, max_workers: int, device: int, precision: int, lib_path: st
             def pack_state(s_, ids):
                 R.big[ids] = np.concatenate([s_["pose"][ids], s_["vel"][ids], s_["tar"][ids], s_["kin"][ids], s_["clocks"][ids], s_["flags"][ids].astype(np.float64)], axis=1)
 
-            try:
-                # every kind of request of the round is served by ONE call for all the slots that made it (a slot has one request pending at a time)
-                rs = pend[ops == OP_RESET]
-                if rs.size:
-                    env.reset(env_ids=rs.astype(np.int32), kin_times=R.dargs[rs, 0], max_times=R.dargs[rs, 1])
-                stp = pend[ops == OP_STEP]
-                snap = stp[R.iargs[stp, 4] != 0] if stp.size else stp            # control steps that may be rolled back: the state they start from
-                gs, ss = pend[ops == OP_GET_STATE], pend[ops == OP_SET_STATE]
-                want = np.concatenate([rs, snap, gs]) if (rs.size or snap.size or gs.size) else rs
-                s_ = env.get_state() if (want.size or ss.size) else None
+            failed = np.zeros(W, dtype=bool)
+
+            def guarded(ids, fn):
+                """one request kind (or one step group) of the round: a failure marks ITS slots only -- what the other calls of the round already did to the
+                device stands, and their workers get their results"""
+                if ids.size == 0:
+                    return
+                try:
+                    fn(ids)
+                except Exception as ex_:
+                    failed[ids] = True
+                    sys.stderr.write("deepmimic_amd.broker: %d request(s) of a round failed: %r\n" % (ids.size, ex_))
+
+            # every kind of request of the round is served by ONE call for all the slots that made it (a slot has one request pending at a time)
+            rs = pend[ops == OP_RESET]
+            guarded(rs, lambda ids: env.reset(env_ids=ids.astype(np.int32), kin_times=R.dargs[ids, 0], max_times=R.dargs[ids, 1]))
+            stp = pend[ops == OP_STEP]
+            snap = stp[R.iargs[stp, 4] != 0] if stp.size else stp            # control steps that may be rolled back: the state they start from
+            gs, ss = pend[ops == OP_GET_STATE], pend[ops == OP_SET_STATE]
+            want = np.concatenate([rs, snap, gs]) if (rs.size or snap.size or gs.size) else rs
+
+            def states(_):
+                s_ = env.get_state()
                 if ss.size:
                     v = R.big[ss]
                     s_["pose"][ss] = v[:, :P]; s_["vel"][ss] = v[:, P:2 * P]; s_["tar"][ss] = v[:, 2 * P:3 * P]; s_["kin"][ss] = v[:, 3 * P:3 * P + 7]
@@ -228,15 +261,17 @@ def serve(name: str, max_workers: int, device: int, precision: int, lib_path: st
                     env.set_state(pose=s_["pose"], vel=s_["vel"], tar=s_["tar"], kin=s_["kin"], clocks=s_["clocks"], flags=s_["flags"])
                 if want.size:
                     pack_state(s_, want)
-                t_s0 = time.perf_counter(); stats["t_pre"] += t_s0 - t_g1
-                if stp.size:
-                    kmat = np.column_stack([R.dargs[stp, 0], R.iargs[stp, :4].astype(np.float64)])
-                    uniq, inv = np.unique(kmat, axis=0, return_inverse=True)
-                    for g in range(uniq.shape[0]):
-                        ids = stp[np.ravel(inv) == g].astype(np.int32)
-                        dt, n_upd, has_act, end_early, want_amp = float(uniq[g, 0]), int(uniq[g, 1]), int(uniq[g, 2]), int(uniq[g, 3]), int(uniq[g, 4])
+            guarded(np.concatenate([want, ss]) if (want.size or ss.size) else want, states)
+            t_s0 = time.perf_counter(); stats["t_pre"] += t_s0 - t_g1
+            if stp.size:
+                kmat = np.column_stack([R.dargs[stp, 0], R.iargs[stp, :4].astype(np.float64)])
+                uniq, inv = np.unique(kmat, axis=0, return_inverse=True)
+                for g in range(uniq.shape[0]):
+                    dt, n_upd, has_act, end_early, want_amp = float(uniq[g, 0]), int(uniq[g, 1]), int(uniq[g, 2]), int(uniq[g, 3]), int(uniq[g, 4])
+
+                    def step_group(ids, dt=dt, n_upd=n_upd, has_act=has_act, end_early=end_early, want_amp=want_amp):
                         t_c0 = time.perf_counter()
-                        out = env.step_envs(ids, R.action[ids, :A] if has_act else None, dt, n_upd, end_early=bool(end_early), amp=bool(want_amp))
+                        out = env.step_envs(ids.astype(np.int32), R.action[ids, :A] if has_act else None, dt, n_upd, end_early=bool(end_early), amp=bool(want_amp))
                         stats["t_call"] += time.perf_counter() - t_c0
                         R.state[ids] = out["state"]; R.reward[ids] = out["reward"]
                         R.flags[ids, 0] = out["terminate"]; R.flags[ids, 1] = out["valid"]; R.flags[ids, 2] = out["episode_end"]
@@ -244,27 +279,27 @@ def serve(name: str, max_workers: int, device: int, precision: int, lib_path: st
                         if want_amp and env.amp_size:
                             R.amp[ids] = out["amp_obs"]
                         stats["launches"] += 1; stats["steps"] += len(ids)
-                t_s1 = time.perf_counter(); stats["t_step"] += t_s1 - t_s0
-                qs = pend[(ops == OP_QUERY) | (ops == OP_QUERY_AMP)]
-                if qs.size:
-                    q = env.query()
-                    R.state[qs] = q["state"][qs]; R.reward[qs] = q["reward"][qs]
-                    R.flags[qs, 0] = q["terminate"][qs]; R.flags[qs, 1] = q["valid"][qs]; R.flags[qs, 2] = q["episode_end"][qs]; R.flags[qs, 3] = q["need_new_action"][qs]
-                    qa = pend[ops == OP_QUERY_AMP]
-                    if qa.size and env.amp_size:
-                        R.amp[qa] = env.query_amp()[qa]
-                ex = pend[ops == OP_AMP_EXPERT]
-                if ex.size:
-                    R.amp[ex] = env.amp_expert(int(ex.size), R.dargs[ex, 0].copy(), R.dargs[ex, 1].copy())
-                dt_ = pend[ops == OP_DETACH]
-                if dt_.size:
-                    R.owner[dt_] = 0
-                R.status[pend] = 0
-                stats["other_ops"] += int(pend.size - stp.size)
-            except Exception as ex_:          # the workers of this round raise; the owner lives on for the others
-                R.status[pend] = -1
-                t_s1 = time.perf_counter()
-                sys.stderr.write("deepmimic_amd.broker: a round of %d request(s) failed: %r\n" % (pend.size, ex_))
+                    guarded(stp[np.ravel(inv) == g], step_group)
+            t_s1 = time.perf_counter(); stats["t_step"] += t_s1 - t_s0
+            qs = pend[(ops == OP_QUERY) | (ops == OP_QUERY_AMP)]
+
+            def queries(ids):
+                q = env.query()
+                R.state[ids] = q["state"][ids]; R.reward[ids] = q["reward"][ids]
+                R.flags[ids, 0] = q["terminate"][ids]; R.flags[ids, 1] = q["valid"][ids]; R.flags[ids, 2] = q["episode_end"][ids]; R.flags[ids, 3] = q["need_new_action"][ids]
+                qa = pend[ops == OP_QUERY_AMP]
+                if qa.size and env.amp_size:
+                    R.amp[qa] = env.query_amp()[qa]
+            guarded(qs, queries)
+
+            def experts(ids):
+                R.amp[ids] = env.amp_expert(int(ids.size), R.dargs[ids, 0].copy(), R.dargs[ids, 1].copy())
+            guarded(pend[ops == OP_AMP_EXPERT], experts)
+            dt_ = pend[ops == OP_DETACH]
+            if dt_.size:
+                R.owner[dt_] = 0
+            R.status[pend] = np.where(failed[pend], -1, 0)
+            stats["other_ops"] += int(pend.size - stp.size)
             done = pend
             done = np.array(done, dtype=np.int64)
             R.ack[done] = R.req[done]
@@ -272,14 +307,20 @@ def serve(name: str, max_workers: int, device: int, precision: int, lib_path: st
             futex_wake(gen_addr, 0x7FFFFFFF)
             t_mark = time.perf_counter(); stats["t_other"] += t_mark - t_s1
     finally:
-        R.hdr[0] = 0
-        R.hdr[9] = stats["launches"]; R.hdr[10] = stats["steps"]
+        if not gone:                             # (an exception: tear down under the same lock)
+            try:
+                with _open_private("/dev/shm/%s.lock" % name, "a+") as lk:
+                    fcntl.flock(lk, fcntl.LOCK_EX)
+                    R.hdr[0] = 0
+                    R.hdr[9] = stats["launches"]; R.hdr[10] = stats["steps"]
+                    R.close(unlink=True)
+            except Exception:
+                pass
         if os.environ.get("DM_BROKER_STATS"):
             import json
             with open(os.environ["DM_BROKER_STATS"], "a") as f:
                 f.write(json.dumps(dict(stats, max_workers=W)) + "\n")
         env.close()
-        R.close(unlink=True)
         try:                                     # (the lock file stays: a worker may be blocked on it right now, and a second inode under the same name would let two owners start)
             if os.path.getsize("/dev/shm/%s.log" % name) == 0:
                 os.unlink("/dev/shm/%s.log" % name)

@@ -169,7 +169,7 @@ def fill_scene_tables(tables: SceneTables, test_mode: bool = False, self_collisi
         st.min_perturb, st.max_perturb = float(c.min_perturb), float(c.max_perturb)
         st.min_perturb_duration, st.max_perturb_duration = float(c.min_pertrub_duration), float(c.max_perturb_duration)
         parts = set(int(b) for b in (c.perturb_part_ids or []))
-        if any(b < 0 or b >= int(st.num_joints) for b in parts):
+        if any(b < 0 or b >= min(int(st.num_joints), 31) for b in parts):       # bits of a 32-bit mask, like strike_bodies
             raise ValueError("perturb_part_ids names a body part the character does not have: %s" % sorted(parts))
         st.perturb_part_mask = sum(1 << b for b in parts)
     return st, keep

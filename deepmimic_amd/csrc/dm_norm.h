@@ -125,6 +125,10 @@ struct dm_normalizer {
     double *state = nullptr, *pending = nullptr, *partial = nullptr; int partial_blocks = 0;
     float *mean_f = nullptr, *inv_std_f = nullptr, *stage = nullptr; int stage_rows = 0;
     int *group_id = nullptr, *grp_start = nullptr, *grp_len = nullptr, *grp_idx = nullptr;
+    // ONE stream per normaliser: `stage`, `partial` and `pending` are single buffers that every call reuses, ordered only by the stream the calls are issued
+    // on.  The stream of the last record is remembered; a call that arrives on another one first waits for the old stream's work.
+    rt_stream last_stream = 0; bool used = false;
+    void order_on(rt_stream s) { if (used && s != last_stream) rt_sync(last_stream); last_stream = s; used = true; }
     ~dm_normalizer() { for (void* p : {(void*)state, (void*)pending, (void*)partial, (void*)mean_f, (void*)inv_std_f, (void*)stage, (void*)group_id, (void*)grp_start, (void*)grp_len, (void*)grp_idx}) if (p) rt_free(p); }
 };
 
@@ -175,6 +179,7 @@ int dm_norm_record(dm_normalizer* h, const float* x, int n, int flags, void* hip
     if (n <= 0) return 0;
     DevGuard guard(h->device_id);
     rt_stream stream = (rt_stream)hip_stream;
+    h->order_on(stream);
     const float* xd = x;
     if (!(flags & DM_DEVICE_PTRS)) {                    // host rows (tests, small callers): staged through a device buffer
         if (n > h->stage_rows) { rt_sync(stream); if (h->stage) rt_free(h->stage); h->stage = nullptr; h->stage_rows = 0; void* p = nullptr; if (rt_malloc(&p, sizeof(float) * (size_t)n * h->size)) return fail("device allocation failed"); h->stage = (float*)p; h->stage_rows = n; }
@@ -203,6 +208,7 @@ int dm_norm_update(dm_normalizer* h, void* hip_stream) {
     if (!h) return fail("null argument");
     DevGuard guard(h->device_id);
     rt_stream stream = (rt_stream)hip_stream;
+    h->order_on(stream);
     RT_LAUNCH4(dmn::k_norm_update, 1, stream, h->state, h->pending, h->size, (const int*)h->group_id, (const int*)h->grp_start, (const int*)h->grp_len, (const int*)h->grp_idx, h->eps, h->mean_f, h->inv_std_f);
 #ifndef DM_EMU
     hipError_t le = hipGetLastError(); if (le != hipSuccess) return fail(std::string("kernel launch failed: ") + hipGetErrorString(le));

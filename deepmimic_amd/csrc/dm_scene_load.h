@@ -239,8 +239,9 @@ int dm_scene_load(const char* const* args, int n_args, const char* data_root, in
         if (ls != "none" && ls != "wrap") return fail("unsupported loop mode '" + ls + "' in " + path);
         loop = ls == "wrap";
         for (const JVal& row : fr->arr) {
-            if (row.kind != JVal::ARR || (int)row.arr.size() != P + 1) return fail("DOF mismatch, char dof " + std::to_string(P) + ", motion dof " + std::to_string((int)row.arr.size() - 1));
-            for (const JVal& x : row.arr) sc->frames.push_back(x.num);
+            if (row.kind != JVal::ARR) return fail(path + ": a frame that is not an array");
+            if ((int)row.arr.size() != P + 1) return fail("DOF mismatch, char dof " + std::to_string(P) + ", motion dof " + std::to_string((int)row.arr.size() - 1));
+            for (const JVal& x : row.arr) { if (!x.is_num()) return fail(path + ": a frame entry that is not a number"); sc->frames.push_back(x.num); }
         }
         return (int)fr->arr.size();
     };
@@ -340,7 +341,7 @@ int dm_scene_load(const char* const* args, int n_args, const char* data_root, in
           t.perturb_time_min = ptmin; t.perturb_time_max = a.num("perturb_time_max", inf); t.min_perturb = a.num("min_perturb", 50.0); t.max_perturb = a.num("max_perturb", 100.0);
           t.min_perturb_duration = a.num("min_pertrub_duration", 0.1); t.max_perturb_duration = a.num("max_perturb_duration", 0.5);      // [sic] the reference's key
           std::vector<int> parts; int m = 0;
-          if (a.ints("perturb_part_ids", parts)) for (int b : parts) { if (b < 0 || b >= J) return fail("perturb_part_ids names a body part the character does not have"); m |= 1 << b; }
+          if (a.ints("perturb_part_ids", parts)) for (int b : parts) { if (b < 0 || b >= std::min(J, 31)) return fail("perturb_part_ids names a body part the character does not have (or beyond bit 30 of the 32-bit part mask)"); m |= 1 << b; }
           t.perturb_part_mask = m;
       } }
     *out = sc.release();

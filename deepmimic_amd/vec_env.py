@@ -137,17 +137,23 @@ class TorchVecEnvGroups:
 
     def reset(self):
         self.g.reset()
+        cur = self.torch.cuda.current_stream(self.device)
         for g in range(self.G):
+            self.streams[g].wait_stream(cur)      # reads of self.obs the caller still has queued on its stream come first (write-after-read)
             self._launch(g, 0, 0, False)
         self._join()
         return self.obs
+
+    def _check_actions(self, actions):
+        t = self.torch
+        if actions.device != self.device or actions.dtype != t.float32 or tuple(actions.shape) != (self.n, self.act_dim) or not actions.is_contiguous():
+            raise ValueError("actions must be the contiguous float32 (N, A) tensor of the whole batch on %s" % self.device)
 
     def step_group(self, g: int, actions):
         """Control step of group g, asynchronous on `stream(g)`.  `actions`: the WHOLE batch's (N, A) tensor (the group reads its rows) written on
         `stream(g)` (or ordered before it by the caller).  Returns views of the group's rows: (obs, reward, done, info) -- valid on `stream(g)`."""
         t = self.torch
-        if actions.device != self.device or actions.dtype != t.float32 or tuple(actions.shape) != (self.n, self.act_dim) or not actions.is_contiguous():
-            raise ValueError("actions must be the contiguous float32 (N, A) tensor of the whole batch on %s" % self.device)
+        self._check_actions(actions)
         self._launch(g, actions.data_ptr(), self.updates, True)
         r = self.rows(g)
         with t.cuda.stream(self.streams[g]):
@@ -161,6 +167,7 @@ class TorchVecEnvGroups:
 
     def step(self, actions):
         """all groups (each on its stream, ordered behind the caller's current stream), then the current stream waits for them"""
+        self._check_actions(actions)             # (a float64 / transposed / CPU tensor would be read as raw fp32 rows)
         cur = self.torch.cuda.current_stream(self.device)
         for g in range(self.G):
             self.streams[g].wait_stream(cur)

@@ -357,7 +357,7 @@ def check_device_vs_ref_golden(name, precision, lib_path, rtol_dyn, rtol_tau, to
     return worst
 
 
-def auto_reset_rollout_compare(name, precision, lib_path, steps, n, seed, wave_packing=0, time_lim=np.inf):
+def auto_reset_rollout_compare(name, precision, lib_path, steps, n, seed, wave_packing=0, time_lim=np.inf, physics=1):
     """Free-running open-loop rollout THROUGH auto-resets: the oracle mirrors every reset of the device with the same
     counter-based draw (streams.reset_rand01), so all `steps` control steps of every env are live transitions (a fallen
     character is reset instead of lying on the ground with reward 0).  Returns per (step, env) arrays: |reward diff|,
@@ -366,7 +366,7 @@ def auto_reset_rollout_compare(name, precision, lib_path, steps, n, seed, wave_p
     t = model.load_asset(name)
     if np.isfinite(time_lim):
         t.cfg.time_lim_min = t.cfg.time_lim_max = float(time_lim)
-    env = BatchEnv(t, n, precision=precision, lib_path=lib_path, wave_packing=wave_packing, seed=seed)
+    env = BatchEnv(t, n, precision=precision, lib_path=lib_path, wave_packing=wave_packing, seed=seed, physics=physics)
     env.reset()
     ep = env.get_state()["flags"][:, 2].astype(np.int64)        # episode counter the NEXT reset will draw with
     tmin, tmax = float(t.cfg.time_lim_min), float(t.cfg.time_lim_max)
@@ -377,7 +377,7 @@ def auto_reset_rollout_compare(name, precision, lib_path, steps, n, seed, wave_p
 
     oracles = []
     for e in range(n):
-        o = Oracle(t)
+        o = Oracle(t) if physics == 1 else Oracle(t, physics=physics, max_contacts=env.max_contacts)
         u, mt = draw(e, int(ep[e]) - 1)
         o.reset(o.duration * u, mt)
         oracles.append(o)

@@ -159,6 +159,28 @@ def cpu_baseline_worker(scene, env_id, budget_s):
     print(json.dumps({"steps": steps, "secs": secs, "resets": resets, "live": live, "native": bool(variant)}))
 
 
+def cpu_oracle_rate(scene, nproc, budget_s=6.0):
+    """aggregate env-steps/s of `nproc` independent oracle processes (the CPU restatement, one env each: what W reference-style workers would do on this host's cores)"""
+    import subprocess
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib
+    env = dict(os.environ)
+    try:
+        oracle_lib.build("native"); env["DM_ORACLE_NATIVE"] = "1"
+    except Exception:
+        oracle_lib.build("all"); env["DM_ORACLE_NATIVE"] = "0"
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", str(i), "--scene", scene, "--cpu-budget", str(budget_s)],
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env) for i in range(nproc)]
+    total = 0.0
+    for p_ in procs:
+        so, se = p_.communicate(timeout=20 * budget_s + 120)
+        lines = [l for l in so.splitlines() if l.startswith("{")]
+        if p_.returncode != 0 or not lines:
+            raise RuntimeError("worker rc=%s: %s" % (p_.returncode, se.strip()[-300:]))
+        r = json.loads(lines[-1]); total += r["steps"] / r["secs"]
+    return total
+
+
 def cpu_baseline(scene, budget_s=12.0):
     """The CPU path timed beside the GPU line on this host: the oracle restatement (kind "port"; DeepMimicCore + Bullet is
     not buildable here) on the SAME workload -- open-loop tracking with auto-reset -- as (a) one process and (b) one process per
@@ -266,7 +288,15 @@ def facade_bench(scene, steps, workers=(1,), private_too=True):
                 p_.join()
             dst[str(w)] = w * steps / max(r["elapsed"] for r in res)
         time.sleep(4.0)          # the owner process of the shared route leaves a few seconds after its last worker
+    # the CPU column: W independent processes of the oracle on this host's cores, beside each W of the GPU routes (the reference scales by processes too)
+    cpu = {}
+    for w in workers:
+        try:
+            cpu[str(w)] = cpu_oracle_rate(scene, w)
+        except Exception as ex:                                      # noqa: BLE001
+            cpu[str(w)] = "failed: %r" % (ex,)
     print(json.dumps({"metric": "facade env-steps/s, one env per cDeepMimicCore (%s)" % scene, "value": out["batched"]["env_steps_per_s"],
+                      "aggregate_env_steps_per_s_by_workers_cpu_oracle": cpu,
                       "unit": "env-steps/s", "n_gpus": 1, "steps": steps, "higher_is_better": True, "dtype": "f32", "data": "synthetic",
                       "config": {"workload": "%s, 1 env per worker, reference driver protocol, random actions N(0, 0.1^2), auto reset by the driver" % scene},
                       "aggregate_env_steps_per_s_by_workers": agg,
@@ -373,6 +403,7 @@ def main():
                          "0 = auto (2 from 4096 envs per GPU on: the half-batches drift apart in phase and fill each other's wave-time tail, humanoid +2.5..7 %%, dog3d +15 %%; 1 below); 1 = one launch per control step")
     ap.add_argument("--sustain-seconds", type=float, default=8.0,
                     help="after the timed --steps region, run back-to-back control steps for at least this long and report that rate too (`sustained`); 0 = skip")
+    ap.add_argument("--solver-iters", type=int, default=0, help="measurement only: Gauss-Seidel iterations of the contact solver (0 = the library's 10); counter passes of two settings give the sweep's instruction mix by difference")
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--force-gather", action="store_true", help="exercise the record exchange even with one rank")
     ap.add_argument("--gather", choices=["torch", "cabi"], default="torch",
@@ -446,7 +477,7 @@ def main():
     auto_groups = 2 if n >= 4096 else 1
     want_groups = auto_groups if args.groups <= 0 else args.groups
     envs = EnvGroups(tables, n, groups=want_groups, device_id=local_rank if on_gpu else 0, seed=1234, precision=args.precision, env_id_offset=rank * n,
-                     test_mode=True, wave_packing=args.wave_packing, physics=args.physics)
+                     test_mode=True, wave_packing=args.wave_packing, physics=args.physics, solver_iters=args.solver_iters)
     G = envs.G
     env = envs.envs[0]
     main_stream = torch.cuda.current_stream() if on_gpu else None
@@ -635,7 +666,7 @@ def main():
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32" if args.precision == 32 else "f64", "data": "synthetic",
-            "config": {"workload": workload, "envs_per_gpu": n, "envs_total": world * n, "backend": "rccl" if on_gpu else "gloo + CPU emulator (test harness, not a measurement)", "wave_packing": args.wave_packing, "physics": args.physics, "warmup_steps_run": warm, "groups": G, "envs_per_launch": envs_per_launch, "parallelism": "env-shards x%d%s" % (world, " + async RCCL all-gather of the record, overlapped with the next step" if gather else "")},
+            "config": {"workload": workload, "envs_per_gpu": n, "envs_total": world * n, "backend": "rccl" if on_gpu else "gloo + CPU emulator (test harness, not a measurement)", "wave_packing": args.wave_packing, "physics": args.physics, "solver_iters": (args.solver_iters or 10), "warmup_steps_run": warm, "groups": G, "envs_per_launch": envs_per_launch, "parallelism": "env-shards x%d%s" % (world, " + async RCCL all-gather of the record, overlapped with the next step" if gather else "")},
             "sim_updates_per_s": value * 20,
             "per_rank_env_steps_per_s": per_rank, "record_exchange": {"backend": (args.gather if gather else None), "exposed_ms_per_step_rank0": exposed_ms},
             "roofline": {"bound": "valu-issue/latency", "bound_of_the_figures_below": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None,

@@ -26,7 +26,7 @@ def kernel_source_sha1():
 def agg(path):
     a = collections.defaultdict(lambda: collections.defaultdict(float))
     for r in csv.DictReader(open(path)):
-        if "k_env_step" in r["Kernel_Name"]:
+        if "k_env_step" in r["Kernel_Name"] and int(r.get("Grid_Size", 1 << 30)) >= 64 * 1024:       # (bench.py's lone-wave probe launches 64-env batches of the same kernel)
             a[r["Dispatch_Id"]][r["Counter_Name"]] += float(r["Counter_Value"])
             a[r["Dispatch_Id"]]["dur_ns"] = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
     return list(a.values())[2:]            # drop the two warm-up launches

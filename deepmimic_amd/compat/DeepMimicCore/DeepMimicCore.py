@@ -120,12 +120,12 @@ class cDeepMimicCore(object):
             self.stats = {"launches": 0, "updates": 0, "rollbacks": 0}
             return
         self._env = None
-        if os.environ.get("DM_FACADE_SHARED", "0") == "1" and int(os.environ.get("DM_PHYSICS", "1")) == 1:
+        if os.environ.get("DM_FACADE_SHARED", "0") == "1":
             # W worker processes behind ONE context and one launch per control step (deepmimic_amd/broker.py): the reference's `mpiexec -n W` deployment
             from deepmimic_amd.broker import SharedEnv
             try:
                 self._env = SharedEnv(self._tables, seed=self._seed, device_id=int(os.environ.get("DM_DEVICE", "0")),
-                                      precision=int(os.environ.get("DM_PRECISION", "32")), lib_path=os.environ.get("DM_HIP_LIB"))
+                                      precision=int(os.environ.get("DM_PRECISION", "32")), lib_path=os.environ.get("DM_HIP_LIB"), physics=int(os.environ.get("DM_PHYSICS", "1")))
             except NotImplementedError as ex:
                 import warnings
                 warnings.warn("DM_FACADE_SHARED: %s; this worker uses a context of its own" % ex, RuntimeWarning, stacklevel=2)

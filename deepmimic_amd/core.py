@@ -311,6 +311,19 @@ class BatchEnv:
             out["clocks"] = clk
         return out
 
+    def set_env_keys(self, env_ids, seeds):
+        """include/dm_hip.h dm_set_env_keys: the listed envs draw like env 0 of one-env contexts created with `seeds` (then reset them)"""
+        ids = np.ascontiguousarray(env_ids, dtype=np.int32).ravel(); sd = np.ascontiguousarray(seeds, dtype=np.uint64).ravel()
+        assert ids.size == sd.size
+        self._chk(self.lib.dm_set_env_keys(self.h, _ip(ids), int(ids.size), sd.ctypes.data_as(C.POINTER(C.c_uint64))))
+
+    def clip_table(self):
+        """(durations, cdf) of the dataset's clips (include/dm_hip.h dm_clip_table)"""
+        nc = max(1, int(self.num_clips))
+        d, c = np.zeros(nc), np.zeros(nc)
+        self._chk(self.lib.dm_clip_table(self.h, _dp(d), _dp(c)))
+        return d, c
+
     def set_mode(self, test_mode: bool):
         """cRLScene::SetMode for the goal scenes' device-side logic (the episode-timer limits are set_time_limits' business)"""
         self._chk(self.lib.dm_set_mode(self.h, int(bool(test_mode))))

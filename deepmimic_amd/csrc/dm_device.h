@@ -2067,7 +2067,10 @@ struct EnvSim {
     // State: one row of doubles per env in HBM (EnvState::pert), touched by lane 0; the forces that act during the current update are
     // handed to the dof lanes through s.sc[0..6] (free inside the update loop).  Draws: dm_rand01(seed, global env id, draw counter,
     // stream 5), the counter kept in the row.  Compiled into the AMP / tap instantiations of the kernels only.
-    DM_DEV double pert_u01(double* p, int e) const { const double u = dm_rand01(m.seed, (uint64_t)(e + m.env_off), (uint64_t)p[PT_DRAWS], 5); p[PT_DRAWS] += 1; return u; }
+    DM_DEV double pert_u01(double* p, int e) const {
+        const bool own = p[PT_KSEED] != 0.0;            // (dm_set_env_keys: the env draws the stream of a one-env context of its own)
+        const double u = dm_rand01(own ? (uint64_t)(p[PT_KSEED] - 1.0) : m.seed, own ? 0ull : (uint64_t)(e + m.env_off), (uint64_t)p[PT_DRAWS], 5); p[PT_DRAWS] += 1; return u;
+    }
     DM_DEV double pert_uniform(double* p, int e, double lo, double hi) const { const double u = pert_u01(p, e); DM_OPAQUE_D(lo); DM_OPAQUE_D(hi); return (hi > lo && hi < 1e300) ? lo + (hi - lo) * u : hi; }
     // ResetRandPertrub (timer := 0, next := U[time_min, time_max]) and cWorld::Reset -> mPerturbManager.Clear(); lane 0
     DM_DEV void pert_reset(double* p, int e) const {
@@ -2134,7 +2137,10 @@ struct EnvSim {
     // instantiations of the kernels only, the plain imitate kernel carries none of it.  The reference draws from the scene's
     // std::default_random_engine (cRand); here every draw is dm_rand01(seed, global env id, draw counter, stream 2), the counter
     // kept in the goal row, so that a trajectory depends neither on the batch nor on the partition.
-    DM_DEV double goal_u01(double* g, int e) const { const double u = dm_rand01(m.seed, (uint64_t)(e + m.env_off), (uint64_t)g[GS_DRAWS], 2); g[GS_DRAWS] += 1; return u; }
+    DM_DEV double goal_u01(double* g, int e) const {
+        const bool own = g[GS_KON] != 0.0;
+        const double u = dm_rand01(own ? (uint64_t)g[GS_KSEED] : m.seed, own ? 0ull : (uint64_t)(e + m.env_off), (uint64_t)g[GS_DRAWS], 2); g[GS_DRAWS] += 1; return u;
+    }
     DM_DEV double goal_uniform(double* g, int e, double lo, double hi) const { const double u = goal_u01(g, e); DM_OPAQUE_D(lo); DM_OPAQUE_D(hi); return lo + (hi - lo) * u; }       // cRand::RandDouble(min, max)
     DM_DEV double goal_normal(double* g, int e, double mean, double stdev) const {                                              // cRand::RandDoubleNorm: Box-Muller here
         const double u1 = 1.0 - goal_u01(g, e), u2 = goal_u01(g, e);
@@ -2554,11 +2560,13 @@ struct EnvSim {
 template <typename Real, typename C, bool TAPS, int LW>
 DM_DEV void reset_goal_env(EnvSim<Real, C, TAPS, LW>& sim, const ModelDev<Real>& m, Lds<Real, C>& lds, const EnvState<Real>& st, int e, uint64_t ep,
                            const double* kin_time, double max_time, bool act = true) {
-    const uint64_t gid = (uint64_t)(e + m.env_off);
-    const int clip = kin_time ? 0 : sim.draw_clip(dm_rand01(m.seed, gid, ep, 3));
+    const double* grow = st.goal + (size_t)e * GS_WIDTH;
+    const bool own = grow[GS_KON] != 0.0;              // (dm_set_env_keys)
+    const uint64_t gid = own ? 0ull : (uint64_t)(e + m.env_off), ksd = own ? (uint64_t)grow[GS_KSEED] : m.seed;
+    const int clip = kin_time ? 0 : sim.draw_clip(dm_rand01(ksd, gid, ep, 3));
     const ModelDev<Real> mc = sim.model_of_clip(clip);
-    const double kt = kin_time ? *kin_time : mc.duration * dm_rand01(m.seed, gid, ep, 0);
-    const Real yaw = (m.enable_rand_rot_reset && !kin_time) ? (Real)(-3.141592653589793 + 6.283185307179586 * dm_rand01(m.seed, gid, ep, 4)) : (Real)0;
+    const double kt = kin_time ? *kin_time : mc.duration * dm_rand01(ksd, gid, ep, 0);
+    const Real yaw = (m.enable_rand_rot_reset && !kin_time) ? (Real)(-3.141592653589793 + 6.283185307179586 * dm_rand01(ksd, gid, ep, 4)) : (Real)0;
     sim.obj_reset(st, e);                      // dribble_amp: the ball first, around the OLD root (cSceneDribbleAMP::Reset)
     EnvSim<Real, C, TAPS, LW> rs(mc, lds, sim.l);
     rs.li = sim.li;
@@ -2594,9 +2602,10 @@ template <> struct StepWaves<float, ClsBipedObj> { static constexpr int value = 
 // EXP instantiations only (the AMP / tap step kernels, which the host selects for such a scene, and the reset kernel) --
 // min(min + Exp(rate 1 / timer_exp), max) with std::exponential_distribution's inverse-CDF form -ln(1 - u) / rate.  A pinned limit (min == max: test
 // mode, every shipped imitate arg file) draws nothing.
-template <bool EXP, typename Real> DM_DEV double draw_time_limit(const ModelDev<Real>& m, int e, uint64_t ep) {
+template <bool EXP, typename Real> DM_DEV double draw_time_limit(const ModelDev<Real>& m, int e, uint64_t ep, const double* grow = nullptr) {
     if (!(m.time_lim_max > m.time_lim_min)) return m.time_lim_max;
-    const double u = dm_rand01(m.seed, (uint64_t)(e + m.env_off), ep, 1);
+    const bool own = grow && grow[GS_KON] != 0.0;      // (goal row of an env with a draw key of its own, dm_set_env_keys)
+    const double u = dm_rand01(own ? (uint64_t)grow[GS_KSEED] : m.seed, own ? 0ull : (uint64_t)(e + m.env_off), ep, 1);
     if (EXP) { if (m.timer_exp > 0) { const double t = m.time_lim_min - m.timer_exp * log1p(-u); return t < m.time_lim_max ? t : m.time_lim_max; } }
     return m.time_lim_min + (m.time_lim_max - m.time_lim_min) * u;
 }
@@ -2644,7 +2653,7 @@ __global__ void __launch_bounds__(64) DM_WAVES_PER_EU((StepWaves<Real, C>::value
             if (HIST && pass == 0 && io.amp_obs && st.hist) sim.emit_amp(io, st, e);       // end-of-path observation of a finished episode included
             if (pass == 1 || !(io.auto_reset && ended)) break;
             uint64_t ep = (uint64_t)lds.flg[FLG_EPISODE];
-            double mt = draw_time_limit<HIST>(m, e, ep);
+            double mt = draw_time_limit<HIST>(m, e, ep, (HIST && st.goal) ? st.goal + (size_t)e * GS_WIDTH : nullptr);
             bool rec = false;
             if (HIST && st.goal) {           // clip by weight, random yaw, goal reset -- unless the episode goes on as a recovery episode
                 rec = sim.try_recovery_reset(st, e, mt);
@@ -2676,7 +2685,7 @@ __global__ void __launch_bounds__(64) k_env_reset(ModelDev<Real> m, EnvState<Rea
     sim.load(st, e);
     uint64_t ep = (uint64_t)lds.flg[FLG_EPISODE];
     double mt = max_times ? max_times[b]
-              : draw_time_limit<true>(m, e, ep);
+              : draw_time_limit<true>(m, e, ep, st.goal ? st.goal + (size_t)e * GS_WIDTH : nullptr);
     bool rec = false;
     if (st.goal) {
         sim.goal_sync_flags(st, e);

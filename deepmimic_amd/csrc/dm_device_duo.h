@@ -892,7 +892,7 @@ __global__ void __launch_bounds__(64) DM_WAVES_PER_EU((DuoWaves<Real>::value)) k
         if (HIST && io.amp_obs && st.hist) sim.b.emit_amp(io, st, e);
         if (io.auto_reset && ended) {                    // per character; no cross-half traffic inside
             uint64_t ep = (uint64_t)lds[half].flg[FLG_EPISODE];
-            double mt = draw_time_limit<HIST>(m, e, ep);
+            double mt = draw_time_limit<HIST>(m, e, ep, (HIST && st.goal) ? st.goal + (size_t)e * GS_WIDTH : nullptr);
             bool rec = false;
             if (HIST && st.goal) { rec = sim.b.try_recovery_reset(st, e, mt); if (!rec) reset_goal_env<Real, ClsBiped, TAPS, 32>(sim.b, m, lds[half], st, e, ep, nullptr, mt); }
             else {

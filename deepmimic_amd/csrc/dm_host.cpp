@@ -311,6 +311,7 @@ struct CtxBase {
     virtual int set_tau(const double* tau) = 0;
     virtual void set_time_limits(double lo, double hi) = 0;
     virtual void set_timer_exp(double ex) = 0;
+    virtual int set_env_keys(const int* ids, int n, const uint64_t* seeds) = 0;
 };
 
 template <typename Real>
@@ -489,6 +490,7 @@ struct CtxT : CtxBase {
             goal_size = md.goal_dim;
             d_goals = (float*)dalloc(sizeof(float) * (size_t)N * 4);
             if (!st.goal || !d_goals) return fail("device allocation failed");
+            rt_memset(st.goal, 0, sizeof(double) * (size_t)N * GS_WIDTH, stream);      // (GS_KON = 0: the ctx's own draw key; every other slot is written by the first reset)
         }
         // random perturbations (scenes/SceneSimChar.cpp:92-99)
         st.pert = nullptr; md.perturb_on = c.enable_rand_perturbs ? 1 : 0;
@@ -612,6 +614,31 @@ struct CtxT : CtxBase {
             if (rt_h2d(st.obj, o.data(), sizeof(Real) * o.size(), stream) != 0) return fail("host to device copy failed");
         }
         return 0;
+    }
+    // dm_set_env_keys: the listed envs become what env 0 of a fresh one-env context created with seeds[i] would be BEFORE its first reset: draw key (seed, env 0)
+    // in the goal / perturbation rows, draw counters and the episode counter back to 0, no manifolds.  The caller resets them next (dm_create does the same).
+    int set_env_keys(const int* ids, int n, const uint64_t* seeds) override {
+        if (rt_sync(stream) != 0) return fail("stream synchronize failed");
+        std::vector<double> g, p; std::vector<int> f((size_t)N * 4);
+        if (st.goal) { g.resize((size_t)N * GS_WIDTH); if (rt_d2h(g.data(), st.goal, sizeof(double) * g.size(), stream) != 0) return fail("device to host copy failed"); }
+        if (st.pert) { p.resize((size_t)N * PT_WIDTH); if (rt_d2h(p.data(), st.pert, sizeof(double) * p.size(), stream) != 0) return fail("device to host copy failed"); }
+        if (rt_d2h(f.data(), st.flag, sizeof(int) * f.size(), stream) != 0) return fail("device to host copy failed");
+        for (int i = 0; i < n; ++i) {
+            const int e = ids[i];
+            if (e < 0 || e >= N) return fail("dm_set_env_keys: env id out of range");
+            if (seeds[i] >= (1ull << 53)) return fail("dm_set_env_keys: seeds must be below 2^53 (they ride in a double of the env's goal / perturbation row)");
+            if (st.goal) { double* r = &g[(size_t)e * GS_WIDTH]; for (int k = 0; k < GS_WIDTH; ++k) r[k] = 0; r[GS_KSEED] = (double)seeds[i]; r[GS_KON] = 1.0; }
+            if (st.pert) { double* r = &p[(size_t)e * PT_WIDTH]; for (int k = 0; k < PT_WIDTH; ++k) r[k] = 0; r[PT_KSEED] = (double)seeds[i] + 1.0; }
+            f[(size_t)e * 4 + 2] = 0;
+        }
+        if (st.goal && rt_h2d(st.goal, g.data(), sizeof(double) * g.size(), stream) != 0) return fail("host to device copy failed");
+        if (st.pert && rt_h2d(st.pert, p.data(), sizeof(double) * p.size(), stream) != 0) return fail("host to device copy failed");
+        if (rt_h2d(st.flag, f.data(), sizeof(int) * f.size(), stream) != 0) return fail("host to device copy failed");
+        if (st.manif) {
+            std::vector<Real> mz((size_t)hm.J * MF_STRIDE, (Real)0);
+            for (int i = 0; i < n; ++i) if (rt_h2d(st.manif + (size_t)ids[i] * hm.J * MF_STRIDE, mz.data(), sizeof(Real) * mz.size(), stream) != 0) return fail("host to device copy failed");
+        }
+        return rt_sync(stream) == 0 ? 0 : fail("stream synchronize failed");
     }
     int pert_state(double* out, const double* in) override {         // N x PT_WIDTH
         if (!st.pert) return fail("no perturbation state: enable_rand_perturbs is off");
@@ -1064,6 +1091,22 @@ int dm_set_obj_state(dm_ctx* ctx, const double* in) { if (!ctx || !in) return fa
 int dm_get_manifolds(dm_ctx* ctx, double* out) { if (!ctx || !out) return fail("null argument"); DevGuard guard(ctx->c->device_id); return ctx->c->manifolds(out, nullptr); }
 int dm_set_manifolds(dm_ctx* ctx, const double* in) { if (!ctx || !in) return fail("null argument"); DevGuard guard(ctx->c->device_id); return ctx->c->manifolds(nullptr, in); }
 int dm_set_mode(dm_ctx* ctx, int test_mode) { if (!ctx) return fail("null ctx"); ctx->c->set_mode(test_mode); return 0; }
+int dm_clip_table(const dm_ctx* ctx, double* durations, double* cdf) {
+    if (!ctx) return fail("null ctx");
+    const HostModel& h = ctx->c->hm;
+    const int nc = h.num_clips > 1 ? h.num_clips : 1;
+    for (int k = 0; k < nc; ++k) {
+        if (durations) durations[k] = (h.num_clips > 1) ? h.clip_dur[k] : h.duration;
+        if (cdf) cdf[k] = (h.num_clips > 1) ? h.clip_cdf[k] : 1.0;
+    }
+    return 0;
+}
+int dm_set_env_keys(dm_ctx* ctx, const int32_t* env_ids, int n, const uint64_t* seeds) {
+    if (!ctx || !env_ids || !seeds) return fail("null argument");
+    if (n <= 0) return 0;
+    DevGuard guard(ctx->c->device_id);
+    return ctx->c->set_env_keys(env_ids, n, seeds);
+}
 int dm_get_clips(dm_ctx* ctx, int32_t* out) { if (!ctx || !out) return fail("null argument"); DevGuard guard(ctx->c->device_id); return ctx->c->get_clips(out); }
 
 int dm_build_offsets_scales(const dm_ctx* ctx, double* s_off, double* s_scale, double* a_off, double* a_scale, double* a_min, double* a_max, int32_t* s_norm_groups) {

@@ -119,7 +119,7 @@ int dm_policy_forward_ex(dm_policy* p, const float* states_dev, const float* goa
         const unsigned grid = (unsigned)((n + 31) / 32);
 #ifndef DM_EMU
         static unsigned long long* prof_buf = nullptr; static int prof_calls = 0;
-        if (io.probe == 2) { if (!prof_buf) hipMalloc((void**)&prof_buf, (size_t)8192 * 8 * 8); io.prof = grid <= 8192 ? prof_buf : nullptr; }
+        if (io.probe == 2) { if (!prof_buf && hipMalloc((void**)&prof_buf, (size_t)8192 * 8 * 8) != hipSuccess) prof_buf = nullptr; io.prof = grid <= 8192 ? prof_buf : nullptr; }
 #endif
         if (d.K1 == 256 && d.N3 == 32) RT_LAUNCH4((dmp::k_policy_fused<8, 2>), grid, stream, d, io);
         else if (d.K1 == 256) RT_LAUNCH4((dmp::k_policy_fused<8, 4>), grid, stream, d, io);
@@ -128,12 +128,12 @@ int dm_policy_forward_ex(dm_policy* p, const float* states_dev, const float* goa
 #ifndef DM_EMU
         hipError_t le0 = hipGetLastError(); if (le0 != hipSuccess) return fail(std::string("kernel launch failed: ") + hipGetErrorString(le0));
         if (io.prof && ++prof_calls == 100) {          // DM_POLICY_PROBE=2: phase times of the 100th launch (100 MHz constant clock -> ns), mean over the workgroups
-            hipStreamSynchronize(stream);
-            std::vector<unsigned long long> h((size_t)grid * 8); hipMemcpy(h.data(), prof_buf, h.size() * 8, hipMemcpyDeviceToHost);
+            (void)hipStreamSynchronize(stream);
+            std::vector<unsigned long long> h((size_t)grid * 8); (void)hipMemcpy(h.data(), prof_buf, h.size() * 8, hipMemcpyDeviceToHost);
             double acc[6] = {0, 0, 0, 0, 0, 0}; unsigned long long t0 = ~0ull, t1 = 0;
-            for (unsigned b = 0; b < grid; ++b) { for (int i = 0; i < 6; ++i) acc[i] += 10.0 * (double)(h[b * 8 + i + 1] - h[b * 8 + i]); t0 = std::min(t0, h[b * 8]); t1 = std::max(t1, h[b * 8 + 6]); }
-            fprintf(stderr, "k_policy_fused phases (ns, mean of %u workgroups): prep %.0f | chunk0 layer1 %.0f | rest of the chunks %.0f | layer-2 epilogue + barrier %.0f | layer 3 + head %.0f | logp %.0f || first start -> last end %.0f\n",
-                    grid, acc[0] / grid, acc[1] / grid, acc[2] / grid, acc[3] / grid, acc[4] / grid, acc[5] / grid, 10.0 * (double)(t1 - t0));
+            for (unsigned b = 0; b < grid; ++b) { for (int i = 0; i < 6; ++i) acc[i] += (double)(h[b * 8 + i + 1] - h[b * 8 + i]); t0 = std::min(t0, h[b * 8]); t1 = std::max(t1, h[b * 8 + 6]); }
+            fprintf(stderr, "k_policy_fused phases (s_memtime ticks, mean of %u workgroups): weights + observations requested, noise drawn, observations to LDS %.0f | chunk 0 layer 1 %.0f | rest of the chunks %.0f | layer-2 epilogue + barrier %.0f | layer 3 + head %.0f | logp %.0f || first start -> last end %.0f\n",
+                    grid, acc[0] / grid, acc[1] / grid, acc[2] / grid, acc[3] / grid, acc[4] / grid, acc[5] / grid, (double)(t1 - t0));
         }
 #endif
         return 0;

@@ -238,10 +238,12 @@ enum { GS_TX = 0, GS_TY, GS_TZ, GS_HEADING, GS_SPEED, GS_TIMER, GS_TIMER_MAX, GS
        GS_AUX0, GS_AUX1,        // heading_amp_getup: get-up timer | strike_amp: target hit (0 / 1), hit time
        GS_PBX, GS_PBY, GS_PBZ,  // dribble_amp: ball position at the last action (cSceneDribbleAMP::mAgentPrevTarObjPos)
        GS_OTIMER, GS_OTIMER_MAX, // dribble_amp: target-object timer
+       GS_KSEED, GS_KON,        // a draw key of the env's own (dm_set_env_keys): when GS_KON != 0 every counter-based draw of this env is keyed (GS_KSEED, env 0) instead of
+                                // (ctx seed, global env id) -- the stream a one-env context created with that seed would draw (the shared-owner facade, deepmimic_amd/broker.py)
        GS_WIDTH = 24 };
 // per-env perturbation state (EnvState::pert), doubles: cSceneSimChar::tPerturbParams::mTimer / mNextTime, the draw counter of stream 5,
 // and the active tPerturb entries of cWorld's cPerturbManager (link < 0: free slot)
-enum { PT_TIMER = 0, PT_NEXT, PT_DRAWS, PT_SLOT0, PT_LINK = 0, PT_FX, PT_FY, PT_FZ, PT_DUR, PT_TIME, PT_SLOT_W = 6, PT_SLOTS = 2, PT_WIDTH = 16 };
+enum { PT_TIMER = 0, PT_NEXT, PT_DRAWS, PT_SLOT0, PT_LINK = 0, PT_FX, PT_FY, PT_FZ, PT_DUR, PT_TIME, PT_SLOT_W = 6, PT_SLOTS = 2, PT_KSEED = 15 /* own draw key + 1 (0: the ctx's), see GS_KSEED */, PT_WIDTH = 16 };
 // the free body's record (EnvState::obj, OBJ classes): position, rotation (w, x, y, z), linear and angular velocity
 enum { OB_PX = 0, OB_QW = 3, OB_VX = 7, OB_WX = 10, OB_WIDTH = 16 };
 

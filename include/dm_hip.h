@@ -222,6 +222,15 @@ int dm_set_perturb_state(dm_ctx* ctx, const double* in);
  * fall instead of termination, recovery episodes, strike_amp's test reward); the episode-timer limits of the two modes are the
  * caller's business (dm_set_time_limits). */
 int dm_set_mode(dm_ctx* ctx, int test_mode);
+/* Give the listed envs a draw key of their own: env_ids[i] becomes what env 0 of a fresh ONE-env context created with seed seeds[i] (< 2^53) is before its first
+ * reset -- every counter-based draw it makes from then on (clip, clip time, yaw, episode limit, goal re-sampling, perturbations) is keyed (seeds[i], env 0), its draw
+ * and episode counters start at 0, its DM-physics v2 manifolds are empty -- so that W one-env callers can share one context and one launch per control step and
+ * still see the trajectories of W private contexts (the shared-owner facade, deepmimic_amd/broker.py; the reference's deployment is one cDeepMimicCore per MPI
+ * worker, mpi_run.py:16-24).  Reset the envs next (dm_reset), as dm_create does.  Synchronises the ctx stream. */
+int dm_set_env_keys(dm_ctx* ctx, const int32_t* env_ids, int n, const uint64_t* seeds);
+/* durations[k], cdf[k] of the num_clips clips of a `--kin_ctrl clips` dataset (cClipsController::mClipsCDF, anim/ClipsController.cpp; one entry -- the clip's
+ * duration, 1 -- for a single-clip scene): what dm_amp_expert_clips draws its clips and clip times from */
+int dm_clip_table(const dm_ctx* ctx, double* durations, double* cdf);
 /* dribble_amp: the ball of every env, N x 13 doubles = position(3), rotation w x y z (4), linear velocity(3), angular velocity(3)
  * (cSimObj::GetPos / GetRotation / GetLinearVelocity / GetAngularVelocity of the target object) */
 int dm_get_obj_state(dm_ctx* ctx, double* out);

@@ -12,17 +12,34 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 COMPAT = os.path.join(ROOT, "deepmimic_amd", "compat")
 
 
-def _worker(rank, shared, lib, scene, n_updates, rng_mode, shm, q, barrier):
-    os.environ.update(DM_HIP_LIB=lib, DM_ALLOW_EMULATOR="1", DM_PRECISION="64", DM_FACADE_SHARED="1" if shared else "0", DM_RNG=rng_mode,
-                      DM_FACADE_SHM=shm, DM_FACADE_SHARED_MAX="8")
-    sys.path.insert(0, ROOT); sys.path.insert(0, COMPAT)
-    from DeepMimicCore import DeepMimicCore
+def _tables(scene):
+    """`scene`: "imitate" / "imitate_amp" (humanoid3d_walk under that scene), an asset name (goal scenes, multi-clip datasets), "perturbs" (imitate + random
+    perturbations)"""
     from deepmimic_amd import model
-    t = model.load_asset("humanoid3d_walk")
-    t.cfg.scene = scene
+    if scene in ("imitate", "imitate_amp", "perturbs"):
+        t = model.load_asset("humanoid3d_walk")
+        t.cfg.scene = "imitate" if scene == "perturbs" else scene
+        if scene == "perturbs":
+            t.cfg.enable_rand_perturbs = True; t.cfg.perturb_time_min = 0.05; t.cfg.perturb_time_max = 0.15; t.cfg.min_pertrub_duration = 0.02; t.cfg.max_perturb_duration = 0.1
+    else:
+        t = model.load_asset(scene)
     t.cfg.time_lim_min = t.cfg.time_lim_max = t.cfg.time_end_lim_min = t.cfg.time_end_lim_max = 0.175     # the episode timer ends inside a control step (update 105)
+    return t
+
+
+def _worker(rank, shared, lib, scene, n_updates, rng_mode, shm, q, barrier, physics=1):
+    os.environ.update(DM_HIP_LIB=lib, DM_ALLOW_EMULATOR="1", DM_PRECISION="64", DM_FACADE_SHARED="1" if shared else "0", DM_RNG=rng_mode,
+                      DM_FACADE_SHM=shm, DM_FACADE_SHARED_MAX="8", DM_PHYSICS=str(physics))
+    sys.path.insert(0, ROOT); sys.path.insert(0, COMPAT)
+    import warnings
+    warnings.simplefilter("ignore", RuntimeWarning)       # (DM_RNG=reference warns for multi-clip datasets)
+    from DeepMimicCore import DeepMimicCore
+    t = _tables(scene)
+    scene_kind = t.cfg.scene
     core = DeepMimicCore.cDeepMimicCore(False)
     core.SeedRand(100 + rank); core.LoadTables(t, 10); core.Init()
+    if rank == 1:
+        core.SetMode(1)                                  # one worker in test mode: mode and episode limits are per-context settings on the device, the owner groups by them
     if barrier is not None:
         barrier.wait()                                   # all workers attached: their control steps meet in the owner
     rng = np.random.default_rng(rank)
@@ -30,7 +47,9 @@ def _worker(rank, shared, lib, scene, n_updates, rng_mode, shm, q, barrier):
     for u in range(n_updates):
         if core.NeedNewAction(0):
             seen.append(("s", np.array(core.RecordState(0)), core.CalcReward(0)))
-            if scene == "imitate_amp":
+            if core.GetGoalSize(0):
+                seen.append(("g", np.array(core.RecordGoal(0)), 0.0))
+            if scene_kind != "imitate":
                 seen.append(("a", np.array(core.RecordAMPObsAgent(0)), float(np.sum(core.RecordAMPObsExpert(0)))))
             core.SetAction(0, [float(x) for x in (0.15 * rng.normal(size=core.GetActionSize(0))).astype(np.float32)])
         core.Update(1.0 / 600)
@@ -45,10 +64,10 @@ def _worker(rank, shared, lib, scene, n_updates, rng_mode, shm, q, barrier):
     q.put((rank, seen, st))
 
 
-def _run(lib, shared, W, scene, n_updates, rng_mode, shm):
+def _run(lib, shared, W, scene, n_updates, rng_mode, shm, physics=1):
     ctx = mp.get_context("spawn")
     q = ctx.Queue(); barrier = ctx.Barrier(W) if shared else None
-    ps = [ctx.Process(target=_worker, args=(r, shared, lib, scene, n_updates, rng_mode, shm, q, barrier)) for r in range(W)]
+    ps = [ctx.Process(target=_worker, args=(r, shared, lib, scene, n_updates, rng_mode, shm, q, barrier, physics)) for r in range(W)]
     for p in ps:
         p.start()
     res = {}
@@ -74,19 +93,26 @@ def _run(lib, shared, W, scene, n_updates, rng_mode, shm):
     return res
 
 
-@pytest.mark.parametrize("scene,rng_mode", [("imitate", "reference"), ("imitate_amp", "counter")])
-def test_shared_workers_equal_private_contexts(emu_lib, scene, rng_mode):
+# one asset of every scene kind the context serves: single-clip imitate (host draws in the reference's order) and imitate_amp, the four kinds of goal
+# scene + the dribble ball, a four-clip dataset, random perturbations, DM-physics v2
+CASES = [("imitate", "reference", 1), ("imitate_amp", "counter", 1), ("amp_heading_zombie", "counter", 1), ("amp_target_zombie", "counter", 1), ("amp_heading_getup", "counter", 1),
+         ("amp_strike_punch", "counter", 1), ("amp_dribble_zombie", "counter", 1), ("amp_heading_clips4", "reference", 1), ("perturbs", "reference", 1), ("imitate", "counter", 2)]
+
+
+@pytest.mark.parametrize("scene,rng_mode,physics", CASES, ids=["%s-%s-v%d" % c for c in CASES])
+def test_shared_workers_equal_private_contexts(emu_lib, scene, rng_mode, physics):
     W, n = 3, 130
-    shm = "dmtest_%d_%s" % (os.getpid(), scene)
-    shared = _run(emu_lib, True, W, scene, n, rng_mode, shm)
-    private = _run(emu_lib, False, W, scene, n, rng_mode, shm)
+    shm = "dmtest_%d_%s_%d" % (os.getpid(), scene, physics)
+    shared = _run(emu_lib, True, W, scene, n, rng_mode, shm, physics)
+    private = _run(emu_lib, False, W, scene, n, rng_mode, shm, physics)
     for r in range(W):
         a, b = shared[r][0], private[r][0]
         assert len(a) == len(b)
-        for x, y in zip(a, b):
-            assert x[0] == y[0] and np.array_equal(x[1], y[1]) and x[2] == y[2], (r, x[0])
+        for k, (x, y) in enumerate(zip(a, b)):
+            assert x[0] == y[0] and np.array_equal(x[1], y[1]) and x[2] == y[2], (r, k, x[0])
         assert any(x[0] == "f" and x[1][0] == 1.0 for x in a)                       # an episode ended inside the window
         assert shared[r][1]["rollbacks"] == private[r][1]["rollbacks"] == 2
+        assert shared[r][1]["launches"] > 0
     # the owner leaves a few seconds after its last worker and takes the region with it; the (empty) lock file is the test's to remove
     import glob
     import time
@@ -101,10 +127,11 @@ def test_shared_workers_equal_private_contexts(emu_lib, scene, rng_mode):
 def test_region_layout_round_trip():
     from deepmimic_amd.broker import Region
     name = "dmtest_layout_%d" % os.getpid()
-    a = Region(name, create=True, dims=(4, 227, 28, 43, 15, 226))
+    a = Region(name, create=True, dims=(4, 227, 28, 43, 15, 226, 3, 1 | 4 | 8, 4))
     try:
         b = Region(name)
-        assert (b.W, b.S, b.A, b.P, b.J, b.AMP) == (4, 227, 28, 43, 15, 226)
+        assert (b.W, b.S, b.A, b.P, b.J, b.AMP, b.G, b.FB, b.NC) == (4, 227, 28, 43, 15, 226, 3, 13, 4)
+        assert b.big.shape == (4, 3 * 43 + 16 + 21 + 16 + 15 * 25) and b.goal.shape == (4, 3)
         a.state[2, 5] = 1.5; a.req[3] = 7
         assert b.state[2, 5] == 1.5 and b.req[3] == 7 and b.addr("ack", 1) - b.addr("ack", 0) == 4
         b.close()

@@ -553,7 +553,11 @@ struct CtxT : CtxBase {
             return 0;
         }
         // production launch: the tap-free instantiation unless a parity test armed the debug taps (dm_probe)
-        if (cls == 2) { if (dbg.H) launch_step<Real, ClsBipedObj, SV_TAPS>(GN, stream, md, st, io, dbg); else launch_step<Real, ClsBipedObj, SV_AMP>(GN, stream, md, st, io, dbg); }
+        if (cls == 2) {
+            if (dbg.H) launch_step<Real, ClsBipedObj, SV_TAPS>(GN, stream, md, st, io, dbg);
+            else if (st.manif) launch_step<Real, ClsBipedObj, SV_V2>(GN, stream, md, st, io, dbg);      // round 5: the links' ground contacts through the persistent manifolds, the ball's single-point contacts as under v1
+            else launch_step<Real, ClsBipedObj, SV_AMP>(GN, stream, md, st, io, dbg);
+        }
         else if (cls == 4) {
             if (dbg.H) launch_step<Real, ClsBipedTree, SV_TAPS>(GN, stream, md, st, io, dbg);
             else if (st.manif) launch_step<Real, ClsBipedTree, SV_V2>(GN, stream, md, st, io, dbg);
@@ -784,7 +788,6 @@ int dm_create(const dm_create_info* info, const dm_scene_tables* tables, dm_ctx*
     if (precision != 32 && precision != 64) return fail("precision must be 32 or 64");
     if (info->physics < 0 || info->physics > 2) return fail("physics must be 0 / 1 (DM-physics v1) or 2 (v2)");
 
-    if (info->physics == 2 && tables->scene_goal == 5) return fail("physics 2 does not carry the free body of dribble_amp");
     int mc = info->max_contacts > 0 ? info->max_contacts : 20;
     if (mc > 20) return fail("max_contacts must be <= 20");
 #ifndef DM_EMU

@@ -67,10 +67,11 @@ void launch_amp_expert(unsigned grid, rt_stream s, const ModelDev<Real>& m, cons
 #define DM_FAMILY_20(Real) DM_INST_STEP(Real, ClsLargeTree, SV_V2)
 #define DM_FAMILY_21(Real) DM_INST_STEP(Real, ClsBipedTree, SV_V2)
 #define DM_FAMILY_22(Real) DM_INST_DUO(Real, SV_V2)
+#define DM_FAMILY_23(Real) DM_INST_STEP(Real, ClsBipedObj, SV_V2)
 
 #ifdef DM_TU_ALL
 #define DM_ALL(Real) DM_FAMILY_0(Real) DM_FAMILY_1(Real) DM_FAMILY_2(Real) DM_FAMILY_3(Real) DM_FAMILY_4(Real) DM_FAMILY_5(Real) \
-    DM_FAMILY_6(Real) DM_FAMILY_7(Real) DM_FAMILY_8(Real) DM_FAMILY_9(Real) DM_FAMILY_10(Real) DM_FAMILY_11(Real) DM_FAMILY_12(Real) DM_FAMILY_13(Real) DM_FAMILY_14(Real) DM_FAMILY_15(Real) DM_FAMILY_16(Real) DM_FAMILY_17(Real) DM_FAMILY_18(Real) DM_FAMILY_19(Real) DM_FAMILY_20(Real) DM_FAMILY_21(Real) DM_FAMILY_22(Real)
+    DM_FAMILY_6(Real) DM_FAMILY_7(Real) DM_FAMILY_8(Real) DM_FAMILY_9(Real) DM_FAMILY_10(Real) DM_FAMILY_11(Real) DM_FAMILY_12(Real) DM_FAMILY_13(Real) DM_FAMILY_14(Real) DM_FAMILY_15(Real) DM_FAMILY_16(Real) DM_FAMILY_17(Real) DM_FAMILY_18(Real) DM_FAMILY_19(Real) DM_FAMILY_20(Real) DM_FAMILY_21(Real) DM_FAMILY_22(Real) DM_FAMILY_23(Real)
 DM_ALL(float)
 DM_ALL(double)
 #else

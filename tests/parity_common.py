@@ -445,14 +445,14 @@ def stepwise_live_compare(name, precision, lib_path, steps, n, seed, wave_packin
     return dr, ds, alive, ok
 
 
-def goal_rollout_compare(t, precision, lib_path, steps, n, seed, wave_packing=0, action_sigma=0.15, test_mode=False):
+def goal_rollout_compare(t, precision, lib_path, steps, n, seed, wave_packing=0, action_sigma=0.15, test_mode=False, physics=1):
     """Goal-conditioned task scenes (target_amp / heading_amp; multi-clip datasets, enable_rand_rot_reset): closed-loop rollout
     with seeded random actions THROUGH auto-resets.  The oracle mirrors every device draw: the reset generator's streams 0 (clip
     time), 1 (episode timer), 3 (clip by weight), 4 (yaw) keyed by the episode counter, and the goal generator (stream 2, draw
     counter kept in the goal row).  heading_amp_getup: recovery episodes (train mode) and falls that start a get-up (test mode) are
     mirrored too; strike_amp: hits, success / target-contact termination.  Returns dict of worst deviations + counts."""
     from deepmimic_amd import streams
-    env = BatchEnv(t, n, precision=precision, lib_path=lib_path, wave_packing=wave_packing, seed=seed, test_mode=test_mode)
+    env = BatchEnv(t, n, precision=precision, lib_path=lib_path, wave_packing=wave_packing, seed=seed, test_mode=test_mode, physics=physics)
     g0 = env.get_goal_state()                      # draws consumed by the reset inside dm_create
     env.reset()
     ep = env.get_state()["flags"][:, 2].astype(np.int64)
@@ -471,7 +471,7 @@ def goal_rollout_compare(t, precision, lib_path, steps, n, seed, wave_packing=0,
 
     oracles = []
     for e in range(n):
-        o = Oracle(t, mode_test=int(test_mode))
+        o = Oracle(t, mode_test=int(test_mode)) if physics == 1 else Oracle(t, mode_test=int(test_mode), physics=physics, max_contacts=env.max_contacts)
         o.goal_rng(seed, e, int(g0[e][11]))
         o.reset_ex(*[(lambda c, k, m, y: (k, m, c, y))(*draw(o, e, int(ep[e]) - 1))][0])
         oracles.append(o)

@@ -306,6 +306,20 @@ def test_dribble_scene_matches_oracle_emulator(emu_lib, test_mode):
     assert w["resets"] >= 1 or test_mode
 
 
+def test_dribble_scene_physics_2_matches_oracle_emulator(emu_lib):
+    """round 5: dribble_amp under DM-physics v2 -- the links' ground contacts through the persistent manifolds (both limit rows, one new support
+    point per narrowphase call), the ball's contacts single points as under v1 (a sphere's support point along -n is unique; scenes/SceneDribbleAMP.cpp:398-420)"""
+    t = model.load_asset("amp_dribble_zombie")
+    w = pc.goal_rollout_compare(t, 64, emu_lib, steps=24, n=2, seed=5, wave_packing=1, physics=2)
+    print(w)
+    assert w["flags_ok"] and w["ball"] < 1e-9 and w["reward"] < 1e-6 and w["goal"] < 1e-5 and w["goal_state"] < 1e-6 and w["state"] < 1e-5 and w["resets"] >= 1
+    v1 = BatchEnv(t, 2, precision=64, lib_path=emu_lib, seed=5, physics=1); v2 = BatchEnv(t, 2, precision=64, lib_path=emu_lib, seed=5, physics=2)
+    v1.reset(); v2.reset()
+    for _ in range(10):
+        a = v1.step(np.zeros((2, v1.A), np.float32), 1.0 / 600, 20); b = v2.step(np.zeros((2, v2.A), np.float32), 1.0 / 600, 20)
+    assert v2.physics == 2 and v2.get_manifolds()[:, :, 0].sum() > 0 and not np.array_equal(a["state"], b["state"])      # it IS the other rigid-body step
+
+
 def test_ball_kick_matches_oracle_emulator(emu_lib):
     """the ball thrown at the character's legs: contacts between the free body and the links, the shared constraint solve"""
     mx = _kick_rollout(emu_lib, 64, 8)
@@ -470,6 +484,18 @@ def test_dribble_scene_gpu(hip_lib, prec):
     mx = _kick_rollout(hip_lib, prec, 8)
     print(prec, mx)
     assert mx["speed"] > 5.0 and mx["ball"] < (1e-6 if prec == 64 else 5e-2) and mx["reward"] < (1e-5 if prec == 64 else 5e-3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prec", [64, 32])
+def test_dribble_scene_physics_2_gpu(hip_lib, prec):
+    """dribble_amp under DM-physics v2 on the HIP kernels (k_env_step<ClsBipedObj, ..., PHYS2>): bounds of test_dribble_scene_gpu (fp32: the v2 state caveat of
+    tests/test_physics_v2.py applies -- rewards, goals and the ball are held)"""
+    t = model.load_asset("amp_dribble_zombie")
+    w = pc.goal_rollout_compare(t, prec, hip_lib, steps=60, n=8, seed=5, wave_packing=1, physics=2)
+    print(prec, w)
+    assert (w["flags_ok"] or (prec == 32 and w["scored"] >= 360)) and w["resets"] >= 2
+    assert w["reward_mean"] < (1e-5 if prec == 64 else 2e-3) and w["ball"] < (1e-3 if prec == 64 else 5e-2)
 
 
 @pytest.mark.gpu

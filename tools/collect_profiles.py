@@ -57,6 +57,8 @@ for scene, sfx in SCENES:
     if os.path.exists(os.path.join(src, "phases%s.json" % sfx)):
         shutil.copy(os.path.join(src, "phases%s.json" % sfx), os.path.join(dst, out + "_phase_cycles%s.json" % sfx))
     bname = {"": "bench.json", "_humanoid3d_spinkick": "bench_spinkick.json", "_dog3d_pace": "bench_dog.json"}.get(sfx, "bench%s.json" % sfx)
+    if not os.path.exists(os.path.join(src, bname)):
+        continue
     b = json.load(open(os.path.join(src, bname)))
     n = b["config"]["envs_per_gpu"]
     # 3. PMC passes

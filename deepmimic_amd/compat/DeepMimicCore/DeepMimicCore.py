@@ -140,13 +140,22 @@ class cDeepMimicCore(object):
         self.stats = {"launches": 0, "updates": 0, "rollbacks": 0}     # kernel launches of the stepping path vs Update() calls
         self._build_time_warper()
         self._ref_active = False
-        if self._ref_rng and self._tables.num_clips == 1:
+        self._tape = False                 # the device-side draws come from the reference's generators too (the draw tape, include/dm_hip.h DM_TAPE_*)
+        self._tape_key = None
+        c = self._tables.cfg
+        goal_row = bool(self._tables.goal_kind != 0 or self._tables.num_clips > 1 or c.enable_rand_rot_reset)      # (core.BatchEnv._has_goal_row)
+        private = isinstance(self._env, _BatchEnv)
+        if self._ref_rng and private:
+            self._tape = goal_row or bool(c.enable_rand_perturbs)
             self._ref_init_draws()
+        elif self._ref_rng and self._tables.num_clips == 1:
+            self._ref_init_draws()             # shared owner: reset clip time and episode limit from the reference's generator, device-side draws counter-based
         else:
             if self._ref_rng:
                 import warnings
-                warnings.warn("DM_RNG=reference serves single-clip scenes; this multi-clip dataset draws clip, clip time and episode limit from the "
-                              "device's counter-based streams (cClipsController::SelectNewMotion interleaves with them in the reference)", RuntimeWarning, stacklevel=2)
+                warnings.warn("DM_RNG=reference on the shared-owner route serves single-clip scenes; this multi-clip dataset draws clip, clip time and episode limit "
+                              "from the counter-based streams of the worker's seed (a context per worker, DM_FACADE_SHARED=0, draws them in the reference's order)",
+                              RuntimeWarning, stacklevel=2)
             self._after_reset()
 
     # ---- the reference's draw order on cMathUtil::gRand (DM_RNG=reference) ------------------------------------------------------------
@@ -159,18 +168,114 @@ class cDeepMimicCore(object):
         return self._grand.rand_double(lo, hi)                     # (no draw when min == max: every shipped imitate arg file)
 
     def _ref_init_draws(self):
-        """cDeepMimicCore::Init -> SetupScene (DeepMimicCore.cpp:635-660).  On gRand, in order: cScene::cScene seeds the scene's own generator
-        with one RandUint (scenes/Scene.cpp:5); cRLSceneSimChar::Init runs cScene::Init twice (through cRLScene::Init and cSceneSimChar::Init,
-        RLSceneSimChar.cpp:27-31), each = InitTimers (one cTimer::Reset, Scene.cpp:124-127) + ResetParams, which for this class is two ResetTimers
-        (RLSceneSimChar.cpp:234-238) -- six timer draws with the un-annealed parameters; cGround::cGround takes one RandUint (sim/Ground.cpp:68).
+        """cDeepMimicCore::Init -> SetupScene (DeepMimicCore.cpp:635-660).  On gRand unless noted, in order: cScene::cScene seeds the scene's own
+        generator mRand with one RandUint (scenes/Scene.cpp:5); cSceneImitate::Init builds the kinematic controller first (SceneImitate.cpp:153-161) -- a
+        cClipsController selects its first clip (anim/ClipsController.cpp:24-34); cRLSceneSimChar::Init runs cScene::Init twice (through cRLScene::Init and
+        cSceneSimChar::Init, RLSceneSimChar.cpp:27-31), each = InitTimers (one cTimer::Reset, Scene.cpp:124-127) + ResetParams, which for this class is two
+        ResetTimers (RLSceneSimChar.cpp:234-238) -- six timer draws with the un-annealed parameters; cSceneSimChar::Init resets the perturbation clock
+        (mRand, SceneSimChar.cpp:110-113); cGround::cGround takes one RandUint (sim/Ground.cpp:68); then the task scene's own Init (_ref_init_task_draws).
         The env is left at clip time 0 with the last limit drawn; the driver resets before it steps (learning/rl_world.py)."""
         self._ref_active = True
         self._srand = _RefRand(self._grand.rand_uint(), lib_path=os.environ.get("DM_HIP_LIB"))     # cScene::mRand (RandUint returns int: a negative value widens to unsigned long like in the reference)
+        c = self._tables.cfg
+        clip0 = 0
+        if self._tape and c.kin_ctrl == "clips":
+            clip0 = self._ref_select_clip()
         mt = np.inf
         for _ in range(6):
             mt = self._ref_draw_timer(0)
+        if self._tape and c.enable_rand_perturbs:
+            self._srand.rand_double(c.perturb_time_min, c.perturb_time_max)      # ResetRandPertrub; between the two cScene::Init's timer triples in call order, but on the other generator
         self._grand.rand_uint()
-        self._after_reset(kin_time=0.0, max_time=mt)
+        if self._tape:
+            self._ref_init_task_draws()
+        self._after_reset(kin_time=0.0, max_time=mt, init=True)
+        if self._tape and self._env._has_goal_row:
+            self._env.set_clips([clip0])
+
+    def _ref_select_clip(self):
+        """cClipsController::SelectNewMotion (anim/ClipsController.cpp:226-243): upper_bound of one gRand draw in the weight CDF"""
+        _, cdf = self._env.clip_table()
+        return int(np.searchsorted(np.asarray(cdf), self._grand.rand_double(0.0, 1.0), side="right"))
+
+    def _ref_init_task_draws(self):
+        """What the Init of the task scenes draws after cSceneImitate::Init, for the positions of the two generators (every value is overwritten by the Reset
+        the driver issues before it steps).  cSceneTargetAMP::Init (SceneTargetAMP.cpp:118-123): InitTarget = mTargetTimer.Init -> one cTimer::Reset (gRand),
+        ResetTarget (virtual) -- target_amp: SampleRandTargetPos, two mRand draws (:274-285); heading_amp[_getup]: that + the target speed (mRand,
+        SceneHeadingAMP.cpp:230-239; the get-up timers have min == max: no draw); strike_amp: far/near coin (mRand), three cMathUtil draws (SceneStrikeAMP.cpp:
+        318-374), ResetTargetHit's coin (gRand, train mode and init_hit_prob > 0, :376-383) and the hit time when hit (mRand, :301-316; cScene::GetTime() is 0);
+        dribble_amp (SceneDribbleAMP.cpp:151-160, 389-394): cSceneTargetAMP::Init as above with its own SampleRandTargetPos (:506-520, two mRand draws), then
+        InitTarObjs = object timer Init (gRand) + ResetTarObjs (mRand r, theta; SetTarObjPos: three mRand axis draws, one gRand angle, :422-504), then
+        mTargetTimer.Reset (gRand) and ResetTarget again.  RandDouble draws nothing when min == max (util/Rand.cpp:30-41)."""
+        c, g, m = self._tables.cfg, self._grand, self._srand
+        scene = c.scene
+        if scene not in _model.GOAL_SCENES:
+            return
+        pi = float(np.pi)
+        smin = c.tar_speed if c.tar_speed_min is None else c.tar_speed_min
+        smax = c.tar_speed if c.tar_speed_max is None else c.tar_speed_max
+
+        def reset_target():
+            if scene == "strike_amp":
+                far = m.rand_double(0.0, 1.0) < c.tar_far_prob
+                g.rand_double(-pi, pi) if far else g.rand_double(c.target_min[0], c.target_max[0])
+                g.rand_double(c.target_min[1], c.target_max[1])
+                g.rand_double(c.target_min[2], c.max_target_dist) if far else g.rand_double(c.target_min[2], c.target_max[2])
+                hit = False
+                if self._mode == self.eModeTrain and c.init_hit_prob > 0.0:
+                    hit = g.rand_double(0.0, 1.0) < c.init_hit_prob
+                if hit:
+                    m.rand_double(0.0 - c.target_hit_reset_time, 0.0)
+            elif scene == "dribble_amp":
+                m.rand_double(c.ball_radius, c.max_target_dist); m.rand_double(-pi, pi)
+            else:
+                m.rand_double(0.0, c.max_target_dist); m.rand_double(0.0, 2 * pi)
+                if scene in ("heading_amp", "heading_amp_getup"):
+                    m.rand_double(smin, smax)
+
+        g.rand_double(c.rand_target_time_min, c.rand_target_time_max)          # InitTarget
+        reset_target()
+        if scene == "dribble_amp":
+            g.rand_double(c.rand_tar_obj_time_min, c.rand_tar_obj_time_max)    # mTarObjTimer.Init
+            m.rand_double(c.min_tar_obj_dist, c.max_tar_obj_dist); m.rand_double(-pi, pi)
+            for _ in range(3):
+                m.rand_double(-1.0, 1.0)
+            g.rand_double(-pi, pi)
+            g.rand_double(c.rand_target_time_min, c.rand_target_time_max)      # mTargetTimer.Reset
+            reset_target()
+
+    # ---- the draw tape: the device-side draws of a launch in the reference's order (include/dm_hip.h DM_TAPE_*)
+    def _tape_fill(self):
+        if not self._tape:
+            return
+        from deepmimic_amd.core import TAPE_K, TAPE_HDR, TAPE_STRIDE
+        c = self._tables.cfg
+        lo, hi = _model.timer_limits(c, False, self._sample_count)
+        hdr = (1.0 if c.kin_ctrl == "clips" else 0.0, float(lo), float(hi), float(_model.timer_exp(c, False, self._sample_count)) if c.timer_type == "exp" else 0.0,
+               float(_model.timer_limits(c, True, self._sample_count)[1]) if self._mode == self.eModeTest else -1.0)
+        key = (self._grand.state(), self._srand.state(), hdr)
+        if key == self._tape_key:
+            return                            # nothing was drawn since the tape on the device was written
+        T = np.zeros(TAPE_STRIDE)
+        T[2], T[3] = key[1][1], key[1][2]
+        T[5:10] = hdr
+        ug, eg, _, _ = self._grand.tape()
+        um, _, n3, i2 = self._srand.tape(normal=True, integer=True)
+        K = TAPE_K
+        T[TAPE_HDR:TAPE_HDR + K] = ug; T[TAPE_HDR + K:TAPE_HDR + 2 * K] = eg; T[TAPE_HDR + 2 * K:TAPE_HDR + 3 * K] = um
+        T[TAPE_HDR + 3 * K:TAPE_HDR + 6 * K] = n3; T[TAPE_HDR + 6 * K:TAPE_HDR + 8 * K] = i2
+        self._env.set_draw_tape(T)
+        self._tape_key = key
+
+    def _tape_commit(self):
+        if not self._tape:
+            return
+        h = self._env.draw_tape_state()[0]
+        if h[4] != 0.0:
+            raise RuntimeError("cDeepMimicCore: a launch consumed more random draws than the draw tape holds (DM_TAPE_K raw values per generator)")
+        if h[0] != 0.0 or h[1] != 0.0 or (int(h[2]), float(h[3])) != self._tape_key[1][1:]:
+            self._grand.discard(int(h[0])); self._srand.discard(int(h[1])); self._srand.set_norm_state(int(h[2]), float(h[3]))
+            self._tape_key = None
 
     def _ref_reset_draws(self):
         """cScene::Reset -> cRLSceneSimChar::ResetScene (RLSceneSimChar.cpp:240-244): cRLScene::ResetScene and cSceneSimChar::ResetScene each run
@@ -239,11 +344,20 @@ class cDeepMimicCore(object):
         return cost + (tw["size"] - len(tw["sim"])) * 1.0           # term_step_cost = 1 per step the episode fell short
 
     # ---- stepping engine ------------------------------------------------------------------------------------------------
-    def _after_reset(self, kin_time=None, max_time=None):
-        if kin_time is None and getattr(self, "_ref_active", False):
+    def _after_reset(self, kin_time=None, max_time=None, init=False):
+        tape_reset = kin_time is None and self._tape and self._env._has_goal_row
+        if kin_time is None and getattr(self, "_ref_active", False) and not tape_reset:
             kin_time, max_time = self._ref_reset_draws()
-        if kin_time is None:
+        if tape_reset:
+            self._tape_fill()                  # timers, perturbation clock, clip time, clip, yaw and goal state come off the tape inside the reset kernel
             self._env.reset()
+            self._tape_commit()
+        elif kin_time is None:
+            self._env.reset()
+        elif self._tape and not init:          # (Init leaves the env at clip time 0 with no tape bound yet: what the Init of the scene drew is accounted for on the host)
+            self._tape_fill()                  # (perturbation clock)
+            self._env.reset(kin_times=[float(kin_time)], max_times=[float(max_time)])
+            self._tape_commit()
         else:
             self._env.reset(kin_times=[float(kin_time)], max_times=[float(max_time)])
         if self._tw is not None:
@@ -276,7 +390,10 @@ class cDeepMimicCore(object):
 
     def _launch(self, action, dt, n, end_early):
         self.stats["launches"] += 1
-        return self._env.step(action, dt, n, end_early=end_early)
+        self._tape_fill()
+        out = self._env.step(action, dt, n, end_early=end_early)
+        self._tape_commit()
+        return out
 
     def _virtual(self):
         """inside a consumed-in-advance control step, before its last executed update"""
@@ -290,6 +407,8 @@ class cDeepMimicCore(object):
         self.stats["rollbacks"] += 1
         snap = sp["snap"]
         self._env.restore(snap)              # character, clocks; goal scenes: target / timers / draw counter / get-up or hit state; the ball
+        if sp.get("rng") is not None:        # the reference's generators as they were before the launch: the replay draws the same numbers again
+            self._grand.set_state(sp["rng"][0]); self._srand.set_state(sp["rng"][1]); self._tape_key = None
         self._clk = dict(sp["clk0"])
         out = None
         for i in range(sp["v"]):
@@ -333,6 +452,7 @@ class cDeepMimicCore(object):
         if k > 1:
             snap = env.snapshot()
             clk0 = dict(self._clk)
+            rng0 = (self._grand.state(), self._srand.state()) if self._tape else None
             out = self._launch(action, dt, k, True)
             t1 = float(out["clocks"][0][3]) if "clocks" in out else float(env.get_state()["clocks"][0][3])      # (the shared route returns the clocks with the step: one round trip)
             n_done = min(k, int(round((t1 - clk0["timer"]) / dt)))
@@ -343,7 +463,7 @@ class cDeepMimicCore(object):
                 self._cache = self._launch(None, dt, 1, False)
                 self._advance_clocks(dt)
                 return
-            self._spec = {"snap": snap, "clk0": clk0, "action": action, "dt": dt, "k": k, "n_done": n_done, "v": 1, "out": out}
+            self._spec = {"snap": snap, "clk0": clk0, "rng": rng0, "action": action, "dt": dt, "k": k, "n_done": n_done, "v": 1, "out": out}
             self._advance_clocks(dt)
             self._cache = out if n_done == 1 else None
         else:
@@ -577,6 +697,13 @@ class cDeepMimicCore(object):
         if self._virtual():
             self._materialize()
         gh = float(env.get_state()["kin"][0][1])
+        if self._tape and self._tables.cfg.kin_ctrl == "clips":      # SampleExpertMotion (:260-277): SampleMotionID draws the clip from gRand, then the time from mRand
+            clip = self._ref_select_clip()
+            dur, _ = env.clip_table()
+            t = self._srand.rand_double(0.0, float(dur[clip]))
+            if self._tables.num_clips > 1:
+                return [float(x) for x in env.amp_expert_clips(1, [clip], [t], gh)[0]]
+            return [float(x) for x in env.amp_expert(1, [t], gh)[0]]
         if self._tables.num_clips > 1:           # SampleExpertMotion with a cClipsController: clip by weight, time within that clip
             return [float(x) for x in env.amp_expert_clips(1, None, None, gh)[0]]
         if getattr(self, "_ref_active", False):  # mRand.RandDouble(0, motion_duration) on the scene's generator (SceneImitateAMP.cpp:119)

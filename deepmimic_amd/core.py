@@ -12,6 +12,7 @@ from typing import Optional, Sequence
 import numpy as np
 
 from .model import AMP_SCENES, BALL_ANG_DAMPING, BALL_FRICTION, BALL_LIN_DAMPING, BALL_MASS, SceneTables
+from .model import amp_local_root as _model_amp_local_root
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIB = os.path.join(_HERE, "csrc", "libdm_hip.so")
@@ -53,7 +54,9 @@ class _SceneTables(C.Structure):
     ]
 
 
-ABI_VERSION = 4        # include/dm_hip.h DM_ABI_VERSION
+ABI_VERSION = 5        # include/dm_hip.h DM_ABI_VERSION
+TAPE_K, TAPE_HDR = 96, 16                 # include/dm_hip.h DM_TAPE_*: the draw tape (dm_set_draw_tape)
+TAPE_STRIDE = TAPE_HDR + 8 * TAPE_K
 _libs = {}
 
 
@@ -127,7 +130,7 @@ def fill_scene_tables(tables: SceneTables, test_mode: bool = False, self_collisi
     st.record_world_root_rot = int(tables.record_world_root_rot); st.query_rate = float(tables.query_rate)
     st.friction = 0.0; st.erp = float(erp); st.solver_iters = int(solver_iters)      # 0: the library's default (10, btContactSolverInfo::m_numIterations); other values are for measurements
     st.disable_self_collision = 0 if self_collision else 1
-    st.scene_amp = int(c.scene in AMP_SCENES); st.enable_amp_obs_local_root = int(getattr(c, "enable_amp_obs_local_root", False))
+    st.scene_amp = int(c.scene in AMP_SCENES); st.enable_amp_obs_local_root = int(_model_amp_local_root(c))
     # goal-conditioned AMP task scenes and multi-clip datasets
     st.scene_goal = int(tables.goal_kind)
     for k in ("rand_target_time_min", "rand_target_time_max", "max_target_dist", "target_succ_dist", "tar_fail_dist", "tar_speed",
@@ -317,6 +320,19 @@ class BatchEnv:
         assert ids.size == sd.size
         self._chk(self.lib.dm_set_env_keys(self.h, _ip(ids), int(ids.size), sd.ctypes.data_as(C.POINTER(C.c_uint64))))
 
+    def set_draw_tape(self, tape):
+        """include/dm_hip.h dm_set_draw_tape: bind (N x TAPE_STRIDE doubles) or, with None, unbind the reference's generators as position-indexed tables"""
+        if tape is None:
+            self._chk(self.lib.dm_set_draw_tape(self.h, None)); return
+        t = np.ascontiguousarray(tape, dtype=np.float64).reshape(self.N, TAPE_STRIDE)
+        self._chk(self.lib.dm_set_draw_tape(self.h, _dp(t)))
+
+    def draw_tape_state(self):
+        """include/dm_hip.h dm_get_draw_tape_state: the tape headers after a launch (N x TAPE_HDR: positions consumed, saved normal deviate, error flag, ...)"""
+        out = np.zeros((self.N, TAPE_HDR))
+        self._chk(self.lib.dm_get_draw_tape_state(self.h, _dp(out)))
+        return out
+
     def clip_table(self):
         """(durations, cdf) of the dataset's clips (include/dm_hip.h dm_clip_table)"""
         nc = max(1, int(self.num_clips))
@@ -388,6 +404,11 @@ class BatchEnv:
         out = np.zeros(self.N, np.int32)
         self._chk(self.lib.dm_get_clips(self.h, _ip(out)))
         return out
+
+    def set_clips(self, clips):
+        """include/dm_hip.h dm_set_clips: which clip counts as active before the next reset (the draw tape draws the reset time over ITS duration)"""
+        cl = np.ascontiguousarray(np.broadcast_to(clips, (self.N,)), dtype=np.int32)
+        self._chk(self.lib.dm_set_clips(self.h, _ip(cl)))
 
     def amp_expert_clips(self, n: int, clips=None, times=None, ground_h=None):
         o = np.zeros((int(n), self.amp_size), np.float32)
@@ -559,6 +580,42 @@ class RefRand:
 
     def rand_uint(self) -> int:
         return int(self.lib.dm_refrand_uint(self.h))
+
+    def discard(self, n: int):
+        if self.lib.dm_refrand_discard(self.h, C.c_long(int(n))) != 0:
+            raise RuntimeError("dm_refrand_discard failed")
+
+    def norm_state(self):
+        """(available, value) of the second deviate the normal distribution keeps for its next call"""
+        a, v = C.c_int(0), C.c_double(0.0)
+        self.lib.dm_refrand_norm_state(self.h, 0, C.byref(a), C.byref(v))
+        return int(a.value), float(v.value)
+
+    def set_norm_state(self, avail: int, value: float):
+        a, v = C.c_int(int(avail)), C.c_double(float(value))
+        self.lib.dm_refrand_norm_state(self.h, 1, C.byref(a), C.byref(v))
+
+    def state(self):
+        """(engine state, normal available, normal value): everything a snapshot needs"""
+        s = C.c_ulong(0)
+        self.lib.dm_refrand_engine_state(self.h, 0, C.byref(s))
+        return (int(s.value),) + self.norm_state()
+
+    def set_state(self, st):
+        s = C.c_ulong(int(st[0]))
+        if self.lib.dm_refrand_engine_state(self.h, 1, C.byref(s)) != 0:
+            raise RuntimeError("dm_refrand_engine_state failed")
+        self.set_norm_state(st[1], st[2])
+
+    def tape(self, normal: bool = False, integer: bool = False):
+        """include/dm_hip.h dm_refrand_tape: the position-indexed tables of this generator (u [K], e [K], n3 [3 K] or None, i2 [2 K] or None); the generator
+        is not advanced"""
+        u, e = np.zeros(TAPE_K), np.zeros(TAPE_K)
+        n3 = np.zeros(3 * TAPE_K) if normal else None
+        i2 = np.zeros(2 * TAPE_K) if integer else None
+        if self.lib.dm_refrand_tape(self.h, TAPE_K, _dp(u), _dp(e), _dp(n3), _dp(i2)) != 0:
+            raise RuntimeError("dm_refrand_tape failed")
+        return u, e, n3, i2
 
     def __del__(self):
         try:

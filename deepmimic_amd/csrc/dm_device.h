@@ -371,6 +371,61 @@ struct ParkSnap { Real pose[C::NP], vel[C::NP], kin[8]; double clk[6]; int flg[4
 
 enum { CLK_KIN = 0, CLK_CTRL, CLK_INIT_OFF, CLK_TIMER, CLK_TIMER_MAX };
 enum { FLG_NEED_ACTION = 0, FLG_CONTACT, FLG_EPISODE, FLG_VALID, FLG_NROWS, FLG_NCONT, FLG_PARKED, FLG_OVER };
+// ---- the draw tape (dm_types.h TP_*; ModelDev::draw_tape): the reference's two generators as position-indexed tables, consumed in call order by lane 0 of an env.
+// eng 0 = cMathUtil::gRand, 1 = the scene's mRand.  The arithmetic around a tabulated value is the reference's own expression and must round like the
+// reference's build (gcc, no FMA): contraction is switched off for these few lines.
+DM_HD double tape_u01(double* T, int eng) {                                  // uniform_real_distribution<double>(0, 1): two raw values
+    const int p = (int)T[TP_POS_G + eng];
+    if (p < 0 || p >= TP_K) { T[TP_ERR] = 1.0; return 0.5; }
+    T[TP_POS_G + eng] = (double)(p + 2);
+    return T[(eng ? TP_UM : TP_UG) + p];
+}
+DM_HD double tape_uniform(double* T, int eng, double lo, double hi) {        // cRand::RandDouble(min, max) (util/Rand.cpp:30-41): no draw when min == max
+#pragma clang fp contract(off)
+    if (lo == hi) return lo;
+    double u = tape_u01(T, eng);
+    u = lo + (u * (hi - lo));
+    return u;
+}
+DM_HD double tape_normal(double* T, double mean, double stdev) {             // cRand::RandDoubleNorm (:50-55) on mRand: a polar pair serves two calls
+#pragma clang fp contract(off)
+    double v;
+    if (T[TP_NAVAIL] != 0.0) { v = T[TP_NSAVED]; T[TP_NAVAIL] = 0.0; }
+    else {
+        const int p = (int)T[TP_POS_M];
+        if (p < 0 || p >= TP_K) { T[TP_ERR] = 1.0; return mean; }
+        const double* n = T + TP_NM + 3 * p;
+        v = n[0]; T[TP_NSAVED] = n[1]; T[TP_NAVAIL] = 1.0; T[TP_POS_M] = (double)(p + (int)n[2]);
+    }
+    v = mean + stdev * v;
+    return v;
+}
+DM_HD int tape_int_range(double* T, int lo, int hi) {                         // cRand::RandInt(min, max) (:62-75) on mRand
+    if (lo == hi) return lo;
+    const int p = (int)T[TP_POS_M];
+    if (p < 0 || p >= TP_K) { T[TP_ERR] = 1.0; return lo; }
+    const double* n = T + TP_IM + 2 * p;
+    T[TP_POS_M] = (double)(p + (int)n[1]);
+    return lo + (int)n[0] % (hi - lo);
+}
+// n x cTimer::Reset (util/Timer.cpp:55-73) with the parameters of the tape header (the last one stands), then the limit test mode pins (RLSceneSimChar.cpp:277-284)
+DM_HD double tape_time_limit(double* T, int n) {
+#pragma clang fp contract(off)
+    double mt = T[TP_TMAX];
+    for (int i = 0; i < n; ++i) {
+        if (T[TP_TEXP] > 0.0) {
+            const int p = (int)T[TP_POS_G];
+            if (p < 0 || p >= TP_K) { T[TP_ERR] = 1.0; break; }
+            T[TP_POS_G] = (double)(p + 2);
+            const double lambda = 1 / T[TP_TEXP];
+            mt = T[TP_TMIN] + T[TP_EG + p] / lambda;
+            mt = mt < T[TP_TMAX] ? mt : T[TP_TMAX];                                              // std::min(max_time, mTimeMax)
+        } else mt = tape_uniform(T, 0, T[TP_TMIN], T[TP_TMAX]);
+    }
+    if (T[TP_TPIN] >= 0.0) mt = T[TP_TPIN];
+    return mt;
+}
+
 
 // TAPS = false compiles every debug tap / phase timer out of the instruction stream (production step kernel).
 // LW = lanes per character: 64 (one character per wavefront) or 32 (two characters per wavefront, dm_device_duo.h).
@@ -2067,11 +2122,13 @@ struct EnvSim {
     // State: one row of doubles per env in HBM (EnvState::pert), touched by lane 0; the forces that act during the current update are
     // handed to the dof lanes through s.sc[0..6] (free inside the update loop).  Draws: dm_rand01(seed, global env id, draw counter,
     // stream 5), the counter kept in the row.  Compiled into the AMP / tap instantiations of the kernels only.
+    // (dm_set_draw_tape: the reference's generators; a one-env route, i.e. never the two-per-wave kernel -- compiled out of it)
+    DM_DEV double* tape(int e) const { return (LW == kWave && m.draw_tape) ? m.draw_tape + (size_t)e * TP_STRIDE : nullptr; }
     DM_DEV double pert_u01(double* p, int e) const {
         const bool own = p[PT_KSEED] != 0.0;            // (dm_set_env_keys: the env draws the stream of a one-env context of its own)
         const double u = dm_rand01(own ? (uint64_t)(p[PT_KSEED] - 1.0) : m.seed, own ? 0ull : (uint64_t)(e + m.env_off), (uint64_t)p[PT_DRAWS], 5); p[PT_DRAWS] += 1; return u;
     }
-    DM_DEV double pert_uniform(double* p, int e, double lo, double hi) const { const double u = pert_u01(p, e); DM_OPAQUE_D(lo); DM_OPAQUE_D(hi); return (hi > lo && hi < 1e300) ? lo + (hi - lo) * u : hi; }
+    DM_DEV double pert_uniform(double* p, int e, double lo, double hi) const { if (double* T = tape(e)) return tape_uniform(T, 1, lo, hi); const double u = pert_u01(p, e); DM_OPAQUE_D(lo); DM_OPAQUE_D(hi); return (hi > lo && hi < 1e300) ? lo + (hi - lo) * u : hi; }
     // ResetRandPertrub (timer := 0, next := U[time_min, time_max]) and cWorld::Reset -> mPerturbManager.Clear(); lane 0
     DM_DEV void pert_reset(double* p, int e) const {
         p[PT_TIMER] = 0; p[PT_NEXT] = pert_uniform(p, e, m.perturb_time_min, m.perturb_time_max);
@@ -2084,7 +2141,9 @@ struct EnvSim {
         if (t >= p[PT_NEXT]) {
             const uint32_t mask = m.perturb_part_mask;
             const int n = mask ? dm_popc64((uint64_t)mask) : m.J;
-            int idx = (int)(pert_u01(p, e) * n); idx = idx < n ? idx : n - 1;                  // cRand::RandInt(0, n)
+            int idx;                                                                           // cRand::RandInt(0, n)
+            if (double* T = tape(e)) idx = tape_int_range(T, 0, n);
+            else { idx = (int)(pert_u01(p, e) * n); idx = idx < n ? idx : n - 1; }
             int part = idx;
             if (mask) { uint32_t mm = mask; for (int i = 0; i < idx; ++i) mm &= mm - 1; part = dm_ctz32(mm); }
             const double dx = pert_uniform(p, e, -1, 1), dy = pert_uniform(p, e, -1, 1), dz = pert_uniform(p, e, -1, 1);
@@ -2137,23 +2196,27 @@ struct EnvSim {
     // instantiations of the kernels only, the plain imitate kernel carries none of it.  The reference draws from the scene's
     // std::default_random_engine (cRand); here every draw is dm_rand01(seed, global env id, draw counter, stream 2), the counter
     // kept in the goal row, so that a trajectory depends neither on the batch nor on the partition.
-    DM_DEV double goal_u01(double* g, int e) const {
+    // eng: which of the reference's generators makes the draw -- 1 the scene's mRand, 0 cMathUtil::gRand; it only matters on the draw tape
+    DM_DEV double goal_u01(double* g, int e, int eng = 1) const {
+        if (double* T = tape(e)) return tape_u01(T, eng);
         const bool own = g[GS_KON] != 0.0;
         const double u = dm_rand01(own ? (uint64_t)g[GS_KSEED] : m.seed, own ? 0ull : (uint64_t)(e + m.env_off), (uint64_t)g[GS_DRAWS], 2); g[GS_DRAWS] += 1; return u;
     }
-    DM_DEV double goal_uniform(double* g, int e, double lo, double hi) const { const double u = goal_u01(g, e); DM_OPAQUE_D(lo); DM_OPAQUE_D(hi); return lo + (hi - lo) * u; }       // cRand::RandDouble(min, max)
+    DM_DEV double goal_uniform(double* g, int e, double lo, double hi, int eng = 1) const { if (double* T = tape(e)) return tape_uniform(T, eng, lo, hi); const double u = goal_u01(g, e); DM_OPAQUE_D(lo); DM_OPAQUE_D(hi); return lo + (hi - lo) * u; }       // cRand::RandDouble(min, max)
     DM_DEV double goal_normal(double* g, int e, double mean, double stdev) const {                                              // cRand::RandDoubleNorm: Box-Muller here
+        if (double* T = tape(e)) return tape_normal(T, mean, stdev);
         const double u1 = 1.0 - goal_u01(g, e), u2 = goal_u01(g, e);
         return mean + stdev * sqrt(-2.0 * log(u1)) * cos(6.283185307179586 * u2);
     }
     DM_DEV bool target_like() const { return m.scene_goal == 1 || m.scene_goal == 4 || m.scene_goal == 5; }
     // ---- dribble_amp: the ball as target object (SceneDribbleAMP.cpp:422-440, 493-508), lane 0
-    DM_DEV void obj_timer_reset(double* g, int e) const { g[GS_OTIMER] = 0; g[GS_OTIMER_MAX] = goal_uniform(g, e, m.obj_time_min, m.obj_time_max); }
+    DM_DEV void obj_timer_reset(double* g, int e) const { g[GS_OTIMER] = 0; g[GS_OTIMER_MAX] = goal_uniform(g, e, m.obj_time_min, m.obj_time_max, 0); }      // cTimer::Reset draws from gRand
     DM_DEV void reset_tar_objs(double* g, int e) {
         const double r = goal_uniform(g, e, m.min_tar_obj_dist, m.max_tar_obj_dist), theta = goal_uniform(g, e, -3.141592653589793, 3.141592653589793);
         const double px = (double)s.pose[0] + r * cos(theta), pz = (double)s.pose[2] + r * sin(theta);
-        const double ax = goal_uniform(g, e, -1, 1), ay = goal_uniform(g, e, -1, 1), az = goal_uniform(g, e, -1, 1);   // SetTarObjPos: on the ground, random orientation, at rest
-        const double an = sqrt(ax * ax + ay * ay + az * az), th = goal_uniform(g, e, -3.141592653589793, 3.141592653589793);
+        double ax = goal_uniform(g, e, -1, 1), ay = goal_uniform(g, e, -1, 1), az = goal_uniform(g, e, -1, 1);   // SetTarObjPos: on the ground, random orientation, at rest
+        if (tape(e)) { const double t = ax; ax = az; az = t; }      // tVector(Rand, Rand, Rand, 0) (:497): the reference's compiler (gcc) evaluates the constructor's arguments right to left
+        const double an = sqrt(ax * ax + ay * ay + az * az), th = goal_uniform(g, e, -3.141592653589793, 3.141592653589793, 0);      // (rot_theta: cMathUtil::RandDouble, :498)
         Real* ob = s.obj;
         const Real sh = dm_sin((Real)0.5 * (Real)th), ch = dm_cos((Real)0.5 * (Real)th);
         ob[C::OBJ ? OB_PX : 0] = (Real)px; ob[C::OBJ ? OB_PX + 1 : 0] = m.ball_radius; ob[C::OBJ ? OB_PX + 2 : 0] = (Real)pz;
@@ -2187,9 +2250,10 @@ struct EnvSim {
     DM_DEV void goal_reset_target_pos(double* g, int e) const {
         if (m.scene_goal == 4) {
             const bool far = goal_u01(g, e) < m.tar_far_prob;
-            const double theta = far ? goal_uniform(g, e, -3.141592653589793, 3.141592653589793) : goal_uniform(g, e, m.target_min[0], m.target_max[0]);
-            const double hgt = goal_uniform(g, e, m.target_min[1], m.target_max[1]);
-            const double dist = far ? goal_uniform(g, e, m.target_min[2], (double)m.max_target_dist) : goal_uniform(g, e, m.target_min[2], m.target_max[2]);
+            // (ResetTargetPosFar / Near draw from cMathUtil, the coin above from the scene's generator)
+            const double theta = far ? goal_uniform(g, e, -3.141592653589793, 3.141592653589793, 0) : goal_uniform(g, e, m.target_min[0], m.target_max[0], 0);
+            const double hgt = goal_uniform(g, e, m.target_min[1], m.target_max[1], 0);
+            const double dist = far ? goal_uniform(g, e, m.target_min[2], (double)m.max_target_dist, 0) : goal_uniform(g, e, m.target_min[2], m.target_max[2], 0);
             g[GS_TX] = dist * cos(theta) + (double)s.pose[0]; g[GS_TY] = hgt; g[GS_TZ] = dist * -sin(theta) + (double)s.pose[2];
             set_target_hit(g, false);
             return;
@@ -2203,7 +2267,7 @@ struct EnvSim {
         const double dist = goal_uniform(g, e, 0.0, (double)m.max_target_dist), theta = goal_uniform(g, e, 0.0, 6.283185307179586);
         g[GS_TX] = (double)s.pose[0] + dist * cos(theta); g[GS_TY] = 0; g[GS_TZ] = (double)s.pose[2] + dist * sin(theta);
     }
-    DM_DEV void goal_timer_reset(double* g, int e) const { g[GS_TIMER] = 0; g[GS_TIMER_MAX] = goal_uniform(g, e, m.goal_time_min, m.goal_time_max); }   // cTimer::Reset, uniform
+    DM_DEV void goal_timer_reset(double* g, int e) const { g[GS_TIMER] = 0; g[GS_TIMER_MAX] = goal_uniform(g, e, m.goal_time_min, m.goal_time_max, 0); }   // cTimer::Reset, uniform
     // the get-up flag of the env's LDS record follows the goal row (after load, after every change of the timer)
     DM_DEV void goal_sync_flags(const EnvState<Real>& st, int e, bool act = true) {
         if (m.scene_goal == 3) {
@@ -2231,7 +2295,7 @@ struct EnvSim {
                 s.getup = !(g[GS_AUX0] >= m.getup_time) ? 1 : 0;
             }
             if (m.scene_goal == 4) {       // cSceneStrikeAMP::ResetTarget (:301-316): ResetTargetHit (:376-383), then the hit clock
-                if (!m.mode_test && m.init_hit_prob > 0) set_target_hit(g, goal_u01(g, e) < m.init_hit_prob);
+                if (!m.mode_test && m.init_hit_prob > 0) set_target_hit(g, goal_u01(g, e, 0) < m.init_hit_prob);      // cMathUtil::FlipCoin
                 g[GS_AUX1] = (g[GS_AUX0] != 0.0) ? goal_uniform(g, e, s.clk[CLK_TIMER] - m.hit_reset_time, s.clk[CLK_TIMER]) : -1.0;
             }
         }
@@ -2248,6 +2312,7 @@ struct EnvSim {
             double* g = st.goal + (size_t)e * GS_WIDTH;
             bool rec = m.enable_fall_end && has_fallen(nullptr);                     // CheckTerminate(0) == eTerminateFail
             if (rec) rec = goal_u01(g, e) < m.recover_prob;                          // mRand.FlipCoin
+            if (rec && !(max_time == max_time)) max_time = tape_time_limit(tape(e), 1);      // (draw tape: ResetRecoveryEpisode -> ResetTimers, one cTimer::Reset)
             if (rec) {
                 s.clk[CLK_TIMER] = 0; s.clk[CLK_TIMER_MAX] = max_time;               // ResetTimers
                 g[GS_AUX0] = 0; s.getup = 1;                                         // ResetGetupTimer, BeginGetup
@@ -2557,17 +2622,44 @@ struct EnvSim {
 // cClipsController and enable_rand_rot_reset): the clip is drawn by weight (stream 3 of the reset generator), the clip time
 // uniformly in that clip (stream 0), the yaw uniformly in [-pi, pi) (stream 4); the reset itself runs on a copy of the model whose
 // clip members describe the drawn clip.  kin_time != null: caller-given clip time (clip 0 unless the goal row names one).
+// `pert`: the env's perturbation row (ResetRandPertrub is part of the scene reset).  With a draw tape bound (and no clip time handed in) every draw of
+// the reset is looked up in the reference's call order on its two generators: cSceneDribbleAMP::Reset (:160-167: object timer, ball) -> cScene::Reset ->
+// cRLSceneSimChar::ResetScene (4 x cTimer::Reset; max_time NaN = draw them here) -> ResetRandPertrub -> cSceneImitate::ResetKinChar (:331-349: the clip
+// time over the duration of the clip that was active BEFORE the reset, then cClipsController::Reset picks the new clip, then the random yaw) ->
+// cSceneTargetAMP::Reset (:125-130: target timer, ResetTarget).
 template <typename Real, typename C, bool TAPS, int LW>
 DM_DEV void reset_goal_env(EnvSim<Real, C, TAPS, LW>& sim, const ModelDev<Real>& m, Lds<Real, C>& lds, const EnvState<Real>& st, int e, uint64_t ep,
-                           const double* kin_time, double max_time, bool act = true) {
+                           const double* kin_time, double max_time, bool act = true, double* pert = nullptr) {
     const double* grow = st.goal + (size_t)e * GS_WIDTH;
-    const bool own = grow[GS_KON] != 0.0;              // (dm_set_env_keys)
-    const uint64_t gid = own ? 0ull : (uint64_t)(e + m.env_off), ksd = own ? (uint64_t)grow[GS_KSEED] : m.seed;
-    const int clip = kin_time ? 0 : sim.draw_clip(dm_rand01(ksd, gid, ep, 3));
+    double* T = kin_time ? nullptr : sim.tape(e);
+    int clip; double kt; Real yaw;
+    if (T) {
+        sim.obj_reset(st, e);
+        if (act && sim.l == 0) {
+            double mt = max_time;
+            if (!(mt == mt)) mt = tape_time_limit(T, 4);
+            if (pert) sim.pert_reset(pert, e);
+            const double dur_prev = sim.model_of_clip((int)grow[GS_CLIP]).duration;
+            lds.clk[0] = tape_uniform(T, 0, 0.0, dur_prev);                                             // CalcRandKinResetTime (:494-500)
+            lds.clk[2] = (T[TP_CLIPDRAW] != 0.0) ? (double)sim.draw_clip(tape_uniform(T, 0, 0.0, 1.0)) : 0.0;
+            lds.clk[1] = m.enable_rand_rot_reset ? tape_uniform(T, 1, -3.141592653589793, 3.141592653589793) : 0.0;
+            lds.clk[4] = mt;
+        }
+        sim.sync();
+        kt = lds.clk[0]; yaw = (Real)lds.clk[1]; clip = (int)lds.clk[2]; max_time = lds.clk[4];
+        sim.sync();
+    } else {
+        const bool own = grow[GS_KON] != 0.0;              // (dm_set_env_keys)
+        const uint64_t gid = own ? 0ull : (uint64_t)(e + m.env_off), ksd = own ? (uint64_t)grow[GS_KSEED] : m.seed;
+        clip = kin_time ? 0 : sim.draw_clip(dm_rand01(ksd, gid, ep, 3));
+        // the clip time is drawn over the duration of the clip that was active BEFORE the reset (cSceneImitate::ResetKinChar draws it first, SceneImitate.cpp:331-335;
+        // cKinCharacter::Reset -> cClipsController::Reset selects the new clip afterwards); before the first reset that is the clip cClipsController::Init selected (stream 6)
+        const int prev = (ep == 0) ? sim.draw_clip(dm_rand01(ksd, gid, 0, 6)) : (int)grow[GS_CLIP];
+        kt = kin_time ? *kin_time : sim.model_of_clip(prev).duration * dm_rand01(ksd, gid, ep, 0);
+        yaw = (m.enable_rand_rot_reset && !kin_time) ? (Real)(-3.141592653589793 + 6.283185307179586 * dm_rand01(ksd, gid, ep, 4)) : (Real)0;
+        sim.obj_reset(st, e);                      // dribble_amp: the ball first, around the OLD root (cSceneDribbleAMP::Reset)
+    }
     const ModelDev<Real> mc = sim.model_of_clip(clip);
-    const double kt = kin_time ? *kin_time : mc.duration * dm_rand01(ksd, gid, ep, 0);
-    const Real yaw = (m.enable_rand_rot_reset && !kin_time) ? (Real)(-3.141592653589793 + 6.283185307179586 * dm_rand01(ksd, gid, ep, 4)) : (Real)0;
-    sim.obj_reset(st, e);                      // dribble_amp: the ball first, around the OLD root (cSceneDribbleAMP::Reset)
     EnvSim<Real, C, TAPS, LW> rs(mc, lds, sim.l);
     rs.li = sim.li;
     rs.reset_env(kt, max_time, yaw);
@@ -2575,6 +2667,7 @@ DM_DEV void reset_goal_env(EnvSim<Real, C, TAPS, LW>& sim, const ModelDev<Real>&
     if (st.hist) rs.init_hist(st, e);
     if (act && sim.l == 0) st.goal[(size_t)e * GS_WIDTH + GS_CLIP] = (double)clip;
     if (m.scene_goal) sim.goal_reset(st, e);
+    if (!T && pert && act && sim.l == 0) sim.pert_reset(pert, e);
 }
 
 // ============================================================================ kernels
@@ -2584,7 +2677,10 @@ DM_DEV void reset_goal_env(EnvSim<Real, C, TAPS, LW>& sim, const ModelDev<Real>&
 template <typename Real, typename C> struct StepWaves { static constexpr int value = 1; };
 template <> struct StepWaves<float, ClsBiped> { static constexpr int value = 4; };
 template <> struct StepWaves<float, ClsLarge> { static constexpr int value = 2; };
-template <> struct StepWaves<float, ClsLargeTree> { static constexpr int value = 2; };
+#ifndef DM_LT_WAVES
+#define DM_LT_WAVES 2
+#endif
+template <> struct StepWaves<float, ClsLargeTree> { static constexpr int value = DM_LT_WAVES; };
 #ifndef DM_BT_WAVES
 #define DM_BT_WAVES 4
 #endif
@@ -2657,15 +2753,15 @@ __global__ void __launch_bounds__(64) DM_WAVES_PER_EU((StepWaves<Real, C>::value
             bool rec = false;
             if (HIST && st.goal) {           // clip by weight, random yaw, goal reset -- unless the episode goes on as a recovery episode
                 rec = sim.try_recovery_reset(st, e, mt);
-                if (!rec) reset_goal_env<Real, C, TAPS>(sim, m, lds, st, e, ep, nullptr, mt);
+                if (!rec) reset_goal_env<Real, C, TAPS>(sim, m, lds, st, e, ep, nullptr, mt, true, pert);      // (ResetScene -> ResetRandPertrub; a recovery episode only resets the timers)
             }
             else {
                 double kt = m.duration * dm_rand01(m.seed, (uint64_t)(e + m.env_off), ep, 0);
                 sim.reset_env(kt, mt);
                 if (V2) sim.manif_clear(st, e);
                 if (HIST && st.hist) sim.init_hist(st, e);
+                if (HIST && pert && l == 0) sim.pert_reset(pert, e);
             }
-            if (HIST && pert && !rec && l == 0) sim.pert_reset(pert, e);      // ResetScene -> ResetRandPertrub; a recovery episode only resets the timers
             tap = DebugTaps<Real>();
         }
         sim.mark(13);
@@ -2684,20 +2780,23 @@ __global__ void __launch_bounds__(64) k_env_reset(ModelDev<Real> m, EnvState<Rea
     EnvSim<Real, C> sim(m, lds, l);
     sim.load(st, e);
     uint64_t ep = (uint64_t)lds.flg[FLG_EPISODE];
+    // (draw tape bound and no clip time given: NaN = the timer draws are looked up inside the reset, in the reference's order)
     double mt = max_times ? max_times[b]
+              : (st.goal && !kin_times && sim.tape(e)) ? (double)NAN
               : draw_time_limit<true>(m, e, ep, st.goal ? st.goal + (size_t)e * GS_WIDTH : nullptr);
+    double* pert = st.pert ? st.pert + (size_t)e * PT_WIDTH : nullptr;
     bool rec = false;
     if (st.goal) {
         sim.goal_sync_flags(st, e);
         rec = !kin_times && sim.try_recovery_reset(st, e, mt);
-        if (!rec) reset_goal_env<Real, C, true>(sim, m, lds, st, e, ep, kin_times ? &kin_times[b] : nullptr, mt);
+        if (!rec) reset_goal_env<Real, C, true>(sim, m, lds, st, e, ep, kin_times ? &kin_times[b] : nullptr, mt, true, pert);
     } else {
         double kt = kin_times ? kin_times[b] : m.duration * dm_rand01(m.seed, (uint64_t)(e + m.env_off), ep, 0);
         sim.reset_env(kt, mt);
         sim.manif_clear(st, e);
         if (st.hist) sim.init_hist(st, e);
+        if (pert && l == 0) sim.pert_reset(pert, e);
     }
-    if (st.pert && !rec && l == 0) sim.pert_reset(st.pert + (size_t)e * PT_WIDTH, e);
     sim.store(st, e);
 }
 

@@ -894,14 +894,14 @@ __global__ void __launch_bounds__(64) DM_WAVES_PER_EU((DuoWaves<Real>::value)) k
             uint64_t ep = (uint64_t)lds[half].flg[FLG_EPISODE];
             double mt = draw_time_limit<HIST>(m, e, ep, (HIST && st.goal) ? st.goal + (size_t)e * GS_WIDTH : nullptr);
             bool rec = false;
-            if (HIST && st.goal) { rec = sim.b.try_recovery_reset(st, e, mt); if (!rec) reset_goal_env<Real, ClsBiped, TAPS, 32>(sim.b, m, lds[half], st, e, ep, nullptr, mt); }
+            if (HIST && st.goal) { rec = sim.b.try_recovery_reset(st, e, mt); if (!rec) reset_goal_env<Real, ClsBiped, TAPS, 32>(sim.b, m, lds[half], st, e, ep, nullptr, mt, true, pert); }
             else {
                 double kt = m.duration * dm_rand01(m.seed, (uint64_t)(e + m.env_off), ep, 0);
                 sim.b.reset_env(kt, mt);
                 if (V2) sim.b.manif_clear(st, e);
                 if (HIST && st.hist) sim.b.init_hist(st, e);
+                if (HIST && pert && (wl & 31) == 0) sim.b.pert_reset(pert, e);
             }
-            if (HIST && pert && !rec && (wl & 31) == 0) sim.b.pert_reset(pert, e);
             sim.b.emit(io, tap, e, false);
             if (goal) sim.b.emit_goal(io, st, e, false);
         }

@@ -19,6 +19,7 @@
 #include <limits>
 #include <string>
 #include <random>
+#include <sstream>
 #include <limits>
 #include <vector>
 
@@ -299,7 +300,7 @@ struct CtxBase {
     virtual int amp_expert(int n, const double* times_dev, const double* gh_dev, float* out_dev) = 0;
     int amp_size = 0; float* d_amp = nullptr; uint64_t expert_calls = 0;
     int goal_size = 0; float* d_goals = nullptr;            // RecordGoal of the last emit (goal scenes)
-    virtual int get_goal(double* out) = 0; virtual int set_goal(const double* in) = 0; virtual int get_clips(int* out) = 0;
+    virtual int get_goal(double* out) = 0; virtual int set_goal(const double* in) = 0; virtual int get_clips(int* out) = 0; virtual int set_clips(const int* in) = 0;
     virtual int goal_aux(double* out, const double* in) = 0; virtual void set_mode(int test) = 0; virtual int pert_state(double* out, const double* in) = 0;
     virtual int obj_state(double* out, const double* in) = 0;
     virtual int manifolds(double* out, const double* in) = 0;
@@ -312,11 +313,12 @@ struct CtxBase {
     virtual void set_time_limits(double lo, double hi) = 0;
     virtual void set_timer_exp(double ex) = 0;
     virtual int set_env_keys(const int* ids, int n, const uint64_t* seeds) = 0;
+    virtual int draw_tape(const double* in, int unbind, double* hdr_out) = 0;
 };
 
 template <typename Real>
 struct CtxT : CtxBase {
-    ModelDev<Real> md; EnvState<Real> st; DebugTaps<Real> dbg; int cls = 0; long long* d_prof = nullptr;
+    ModelDev<Real> md; EnvState<Real> st; DebugTaps<Real> dbg; int cls = 0; long long* d_prof = nullptr; double* d_tape = nullptr;
 
     template <typename T, typename U> const T* up(const std::vector<U>& v) {
         std::vector<T> tmp(v.size()); for (size_t i = 0; i < v.size(); ++i) tmp[i] = (T)v[i];
@@ -426,7 +428,7 @@ struct CtxT : CtxBase {
         md.enable_contact_fall = c.enable_char_contact_fall; md.enable_root_rot_fail = c.enable_root_rot_fail; md.enable_rand_placement = c.enable_rand_char_placement;
         md.enable_phase_input = c.enable_phase_input; md.record_world_root_pos = c.record_world_root_pos; md.record_world_root_rot = c.record_world_root_rot;
         md.query_period = 1.0 / (c.query_rate > 0 ? c.query_rate : 30.0);
-        md.time_lim_min = c.time_lim_min; md.time_lim_max = c.time_lim_max; md.timer_exp = 0; md.seed = seed;
+        md.time_lim_min = c.time_lim_min; md.time_lim_max = c.time_lim_max; md.timer_exp = 0; md.seed = seed; md.draw_tape = nullptr;
         st.N = N;
         st.pose = (Real*)dalloc(sizeof(Real) * N * h.P); st.vel = (Real*)dalloc(sizeof(Real) * N * h.P); st.tar = (Real*)dalloc(sizeof(Real) * N * h.P);
         st.tau = (Real*)dalloc(sizeof(Real) * N * h.D); st.kin = (Real*)dalloc(sizeof(Real) * N * 8);
@@ -544,6 +546,7 @@ struct CtxT : CtxBase {
         io.amp_obs = amp; io.goals = d_goals;
         io.actions = actions_dev; io.states = states; io.rewards = rewards; io.terminate = term; io.valid = valid; io.episode_end = end;
         io.env_ids = step_ids; const int GN = step_ids ? step_n_ids : N;      // workgroups of the one-per-wave launches
+        if (md.draw_tape && (flags & DM_AUTO_RESET)) return fail("a draw tape is bound (dm_set_draw_tape): resets go through dm_reset, where the tape serves the reference's draw order");
         io.n_updates = n_updates; io.dt = dt; io.auto_reset = (flags & DM_AUTO_RESET) ? 1 : 0; io.emit = (flags & DM_NO_EMIT) ? 0 : 1; io.open_loop = (flags & DM_OPEN_LOOP) ? 1 : 0; io.end_early = (flags & DM_END_EPISODE_EARLY) ? 1 : 0;
         // two characters per wavefront: biped class, even batch, no debug taps armed (DM_DUO=0 keeps one character per wave)
         if (duo && cls == 0 && hm.D == ClsBiped::ND && (N % 2) == 0 && !dbg.H && !step_ids) {      // (31 row lanes per character assume exactly 34 dofs)
@@ -644,6 +647,22 @@ struct CtxT : CtxBase {
         }
         return rt_sync(stream) == 0 ? 0 : fail("stream synchronize failed");
     }
+    // dm_set_draw_tape / dm_get_draw_tape_state: N x TP_STRIDE doubles in, N x TP_HDR doubles out
+    int draw_tape(const double* in, int unbind, double* hdr_out) override {
+        if (unbind) { md.draw_tape = nullptr; return 0; }
+        if (in) {
+            if (!d_tape) { d_tape = (double*)dalloc(sizeof(double) * (size_t)N * TP_STRIDE); if (!d_tape) return fail("device allocation failed"); }
+            if (rt_h2d(d_tape, in, sizeof(double) * (size_t)N * TP_STRIDE, stream) != 0) return fail("host to device copy failed");
+            md.draw_tape = d_tape;
+        }
+        if (hdr_out) {
+            if (!d_tape || !md.draw_tape) return fail("no draw tape is bound");
+            std::vector<double> buf((size_t)N * TP_STRIDE);
+            if (rt_d2h(buf.data(), d_tape, sizeof(double) * buf.size(), stream) != 0) return fail("device to host copy failed");
+            for (int e = 0; e < N; ++e) memcpy(hdr_out + (size_t)e * TP_HDR, &buf[(size_t)e * TP_STRIDE], sizeof(double) * TP_HDR);
+        }
+        return 0;
+    }
     int pert_state(double* out, const double* in) override {         // N x PT_WIDTH
         if (!st.pert) return fail("no perturbation state: enable_rand_perturbs is off");
         const size_t bytes = sizeof(double) * (size_t)N * PT_WIDTH;
@@ -665,6 +684,13 @@ struct CtxT : CtxBase {
             if (rt_h2d(st.manif, buf.data(), sizeof(Real) * buf.size(), stream) != 0) return fail("host to device copy failed");
         }
         return 0;
+    }
+    int set_clips(const int* in) override {
+        if (!st.goal) return fail("no goal state: not a goal scene / multi-clip dataset");
+        std::vector<double> g((size_t)N * GS_WIDTH);
+        if (rt_d2h(g.data(), st.goal, sizeof(double) * g.size(), stream) != 0) return fail("device to host copy failed");
+        for (int e = 0; e < N; ++e) { if (in[e] < 0 || in[e] >= hm.num_clips) return fail("clip id out of range"); g[(size_t)e * GS_WIDTH + GS_CLIP] = (double)in[e]; }
+        return rt_h2d(st.goal, g.data(), sizeof(double) * g.size(), stream) == 0 ? 0 : fail("host to device copy failed");
     }
     int get_clips(int* out) override {
         if (!st.goal) { for (int e = 0; e < N; ++e) out[e] = 0; return 0; }
@@ -756,6 +782,7 @@ struct dm_ctx { CtxBase* c; };
 // ---------------------------------------------------------------- C-ABI
 extern "C" {
 
+static_assert(DM_TAPE_K == dmk::TP_K && DM_TAPE_HDR == dmk::TP_HDR && DM_TAPE_STRIDE == dmk::TP_STRIDE && dmk::TP_TPIN == 9 && dmk::TP_CLIPDRAW == 5, "include/dm_hip.h DM_TAPE_* and dm_types.h TP_* describe one layout");
 int dm_abi_version(void) { return DM_ABI_VERSION; }
 int dm_struct_sizes(int32_t* out) {
     if (!out) return fail("null argument");
@@ -1094,6 +1121,8 @@ int dm_set_obj_state(dm_ctx* ctx, const double* in) { if (!ctx || !in) return fa
 int dm_get_manifolds(dm_ctx* ctx, double* out) { if (!ctx || !out) return fail("null argument"); DevGuard guard(ctx->c->device_id); return ctx->c->manifolds(out, nullptr); }
 int dm_set_manifolds(dm_ctx* ctx, const double* in) { if (!ctx || !in) return fail("null argument"); DevGuard guard(ctx->c->device_id); return ctx->c->manifolds(nullptr, in); }
 int dm_set_mode(dm_ctx* ctx, int test_mode) { if (!ctx) return fail("null ctx"); ctx->c->set_mode(test_mode); return 0; }
+int dm_set_draw_tape(dm_ctx* ctx, const double* tape) { if (!ctx) return fail("null ctx"); DevGuard guard(ctx->c->device_id); return ctx->c->draw_tape(tape, tape == nullptr, nullptr); }
+int dm_get_draw_tape_state(dm_ctx* ctx, double* out) { if (!ctx || !out) return fail("null argument"); DevGuard guard(ctx->c->device_id); return ctx->c->draw_tape(nullptr, 0, out); }
 int dm_clip_table(const dm_ctx* ctx, double* durations, double* cdf) {
     if (!ctx) return fail("null ctx");
     const HostModel& h = ctx->c->hm;
@@ -1110,6 +1139,7 @@ int dm_set_env_keys(dm_ctx* ctx, const int32_t* env_ids, int n, const uint64_t* 
     DevGuard guard(ctx->c->device_id);
     return ctx->c->set_env_keys(env_ids, n, seeds);
 }
+int dm_set_clips(dm_ctx* ctx, const int32_t* in) { if (!ctx || !in) return fail("null argument"); DevGuard guard(ctx->c->device_id); return ctx->c->set_clips(in); }
 int dm_get_clips(dm_ctx* ctx, int32_t* out) { if (!ctx || !out) return fail("null argument"); DevGuard guard(ctx->c->device_id); return ctx->c->get_clips(out); }
 
 int dm_build_offsets_scales(const dm_ctx* ctx, double* s_off, double* s_scale, double* a_off, double* a_scale, double* a_min, double* a_max, int32_t* s_norm_groups) {
@@ -1172,10 +1202,17 @@ int dm_bench_rollout(dm_ctx* ctx, int warmup, int steps, double timestep, int n_
 struct dm_refrand {
     std::default_random_engine gen;
     std::uniform_real_distribution<double> dbl{0, 1};
-    std::normal_distribution<double> norm{0, 1};
+    // std::normal_distribution<double> keeps the second deviate of a polar pair for the next call; held here in the open (a fresh distribution object per
+    // pair: its first call returns y * mult and saves x * mult, its second call returns the saved value without touching the engine), so that the
+    // state can cross the boundary to the device draw tape (dm_refrand_tape / dm_refrand_norm_state)
+    int navail = 0; double nsaved = 0;
     std::uniform_int_distribution<int> sint{std::numeric_limits<int>::min() + 1, std::numeric_limits<int>::max()};
     std::uniform_int_distribution<unsigned int> uint{std::numeric_limits<unsigned int>::min(), std::numeric_limits<unsigned int>::max()};
 };
+namespace {
+// raw engine values consumed between two states of one engine (the distributions above take a bounded, data-dependent number)
+int refrand_consumed(std::default_random_engine from, const std::default_random_engine& to) { int c = 0; while (!(from == to) && c < (1 << 20)) { from(); ++c; } return c; }
+}
 int dm_refrand_create(unsigned long seed, dm_refrand** out) {
     if (!out) return fail("null argument");
     dm_refrand* r = new dm_refrand(); r->gen = std::default_random_engine(seed); *out = r; return 0;
@@ -1183,7 +1220,7 @@ int dm_refrand_create(unsigned long seed, dm_refrand** out) {
 int dm_refrand_destroy(dm_refrand* r) { delete r; return 0; }
 int dm_refrand_seed(dm_refrand* r, unsigned long seed) {            // cRand::Seed (:128-135)
     if (!r) return fail("null generator");
-    r->gen.seed(seed); r->dbl.reset(); r->norm.reset(); r->sint.reset(); r->uint.reset(); return 0;
+    r->gen.seed(seed); r->dbl.reset(); r->navail = 0; r->sint.reset(); r->uint.reset(); return 0;
 }
 double dm_refrand_double(dm_refrand* r, double mn, double mx) {     // cRand::RandDouble(min, max) (:30-41): no draw when min == max
     if (mn == mx) return mn;
@@ -1192,7 +1229,13 @@ double dm_refrand_double(dm_refrand* r, double mn, double mx) {     // cRand::Ra
     return u;
 }
 double dm_refrand_exp(dm_refrand* r, double lambda) { std::exponential_distribution<double> d(lambda); return d(r->gen); }      // (:43-48)
-double dm_refrand_norm(dm_refrand* r, double mean, double stdev) { double v = r->norm(r->gen); v = mean + stdev * v; return v; }   // (:50-55)
+double dm_refrand_norm(dm_refrand* r, double mean, double stdev) {                                                              // (:50-55)
+    double v;
+    if (r->navail) { v = r->nsaved; r->navail = 0; }
+    else { std::normal_distribution<double> d(0, 1); v = d(r->gen); r->nsaved = d(r->gen); r->navail = 1; }
+    v = mean + stdev * v;
+    return v;
+}
 int dm_refrand_int(dm_refrand* r) { return r->sint(r->gen); }                                                                   // (:57-60)
 int dm_refrand_int_range(dm_refrand* r, int mn, int mx) {           // cRand::RandInt(min, max) (:62-75)
     if (mn == mx) return mn;
@@ -1200,6 +1243,33 @@ int dm_refrand_int_range(dm_refrand* r, int mn, int mx) {           // cRand::Ra
     return mn + v % delta;
 }
 int dm_refrand_uint(dm_refrand* r) { return (int)r->uint(r->gen); }                                                             // (:77-80: returns int)
+int dm_refrand_discard(dm_refrand* r, long n) { if (!r || n < 0) return fail("dm_refrand_discard: bad argument"); r->gen.discard((unsigned long long)n); return 0; }
+int dm_refrand_norm_state(dm_refrand* r, int set, int* avail, double* saved) {
+    if (!r || !avail || !saved) return fail("null argument");
+    if (set) { r->navail = *avail ? 1 : 0; r->nsaved = *saved; } else { *avail = r->navail; *saved = r->nsaved; }
+    return 0;
+}
+int dm_refrand_engine_state(dm_refrand* r, int set, unsigned long* state) {      // minstd_rand0: one integer in [1, 2^31 - 2]
+    if (!r || !state) return fail("null argument");
+    if (set) { std::stringstream ss; ss << *state; ss >> r->gen; return ss.fail() ? fail("dm_refrand_engine_state: not an engine state") : 0; }
+    std::stringstream ss; ss << r->gen; ss >> *state; return 0;
+}
+// The draw tape of one generator (DM_TAPE_* of include/dm_hip.h): entry k of every table is what the distribution would return if its next call found
+// the engine k raw values past the generator's current state -- computed with the <random> types themselves, nothing restated.  The generator is
+// not advanced.  u: uniform_real_distribution<double>(0, 1) (2 raw values each); e: exponential_distribution<double>(1) = -log(1 - u) (the
+// caller divides by lambda exactly as the library does); n3: {first deviate of a fresh polar pair, the saved second one, raw values consumed};
+// i2: {|uniform_int_distribution<int>(INT_MIN + 1, INT_MAX)|, raw values consumed}.  Any table may be null.
+int dm_refrand_tape(const dm_refrand* r, int K, double* u, double* e, double* n3, double* i2) {
+    if (!r || K < 0) return fail("dm_refrand_tape: bad argument");
+    std::default_random_engine g = r->gen;
+    for (int k = 0; k < K; ++k, g()) {
+        if (u) { std::default_random_engine h = g; std::uniform_real_distribution<double> d(0, 1); u[k] = d(h); }
+        if (e) { std::default_random_engine h = g; std::exponential_distribution<double> d(1.0); e[k] = d(h); }
+        if (n3) { std::default_random_engine h = g; std::normal_distribution<double> d(0, 1); n3[3 * k] = d(h); n3[3 * k + 2] = (double)refrand_consumed(g, h); n3[3 * k + 1] = d(h); }
+        if (i2) { std::default_random_engine h = g; std::uniform_int_distribution<int> d(std::numeric_limits<int>::min() + 1, std::numeric_limits<int>::max()); i2[2 * k] = (double)std::abs(d(h)); i2[2 * k + 1] = (double)refrand_consumed(g, h); }
+    }
+    return 0;
+}
 
 }  // extern "C"
 

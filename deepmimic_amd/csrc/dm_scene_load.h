@@ -295,7 +295,7 @@ int dm_scene_load(const char* const* args, int n_args, const char* data_root, in
     t.enable_phase_input = jbool("EnablePhaseInput"); t.record_world_root_pos = jbool("RecordWorldRootPos"); t.record_world_root_rot = jbool("RecordWorldRootRot");
     { const JVal* q = kj.get("QueryRate"); t.query_rate = (q && q->is_num()) ? q->num : 30.0; }
     t.friction = 0; t.erp = 0; t.solver_iters = 0; t.disable_self_collision = 0;
-    t.scene_amp = amp ? 1 : 0; t.enable_amp_obs_local_root = a.flag("enable_amp_obs_local_root", false);
+    t.scene_amp = amp ? 1 : 0; t.enable_amp_obs_local_root = a.flag("enable_amp_obs_local_root", false) && !goal;      // only cSceneImitateAMP::ParseArgs reads the key; the task scenes bypass it (SceneTargetAMP.cpp:103-105 -> cSceneImitate::ParseArgs): false for them whatever the arg file says
     t.scene_goal = goal;
     const bool heading = goal == 2 || goal == 3;
     t.rand_target_time_min = a.num("rand_target_time_min", heading ? 0.2 : (goal == 5 ? 50.0 : 1.0));      // constructor defaults: SceneHeadingAMP.cpp:45-48, SceneDribbleAMP.cpp:124-133

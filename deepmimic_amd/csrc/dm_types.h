@@ -196,6 +196,7 @@ struct ModelDev {
     double time_lim_min, time_lim_max;       // episode timer range
     double timer_exp;                        // 0: uniform timer U[min, max]; > 0: `--timer_type exp`, min(min + Exp(mean timer_exp), max) (util/Timer.cpp:55-73)
     uint64_t seed;
+    double* draw_tape;                       // N x TP_STRIDE or null: the reference's generators as position-indexed tables (dm_set_draw_tape; TP_* below)
     int env_off;                             // global id of env 0 of this shard (keeps RNG streams partition-invariant)
     int physics;                             // 1: DM-physics v1, 2: v2 (persistent ground manifolds, both rows of a revolute limit); NL counts ROWS
     int NLJ;                                 // revolute joints with limits (v1: NL == NLJ, v2: NL == 2 NLJ)
@@ -241,6 +242,21 @@ enum { GS_TX = 0, GS_TY, GS_TZ, GS_HEADING, GS_SPEED, GS_TIMER, GS_TIMER_MAX, GS
        GS_KSEED, GS_KON,        // a draw key of the env's own (dm_set_env_keys): when GS_KON != 0 every counter-based draw of this env is keyed (GS_KSEED, env 0) instead of
                                 // (ctx seed, global env id) -- the stream a one-env context created with that seed would draw (the shared-owner facade, deepmimic_amd/broker.py)
        GS_WIDTH = 24 };
+// The draw tape (ModelDev::draw_tape, one row of doubles per env; `DM_RNG=reference` of the one-env drop-in, include/dm_hip.h DM_TAPE_*).  The reference draws from two
+// std::default_random_engine generators -- cMathUtil::gRand (engine 0: timers, clip choice, reset clip time, part of strike_amp / dribble_amp) and the
+// scene's cScene::mRand (engine 1: goal re-sampling, yaw, perturbations, recovery coin) -- in an order that depends on what happens on the device.  The host
+// tabulates, for every raw engine position k < TP_K past the generators' current states, what each <random> distribution would return if its next
+// call started there (dm_refrand_tape: computed with the standard library's own types); the device looks its draws up in call order and advances the
+// two positions, the host then discards that many raw values from its generators.  TP_ERR is raised when a launch runs past the tables.
+enum { TP_POS_G = 0, TP_POS_M, TP_NAVAIL, TP_NSAVED,      // raw positions consumed on gRand / mRand; the saved second deviate of mRand's normal_distribution
+       TP_ERR,
+       TP_CLIPDRAW,                                       // the kinematic controller is a cClipsController: every reset draws a clip from gRand, even out of one (anim/ClipsController.cpp:36-45)
+       TP_TMIN, TP_TMAX, TP_TEXP, TP_TPIN,                // the episode timer as cTimer holds it (annealed train-mode parameters whatever the mode; TEXP <= 0: uniform) and the limit test mode pins afterwards (< 0: none)
+       TP_HDR = 16, TP_K = 96,
+       TP_UG = TP_HDR, TP_EG = TP_UG + TP_K,              // engine 0: uniform(0, 1), -log(1 - uniform)
+       TP_UM = TP_EG + TP_K, TP_NM = TP_UM + TP_K,        // engine 1: uniform(0, 1), normal {value, saved value, raw values consumed}
+       TP_IM = TP_NM + 3 * TP_K,                          // engine 1: |RandInt()| {value, raw values consumed}
+       TP_STRIDE = TP_IM + 2 * TP_K };
 // per-env perturbation state (EnvState::pert), doubles: cSceneSimChar::tPerturbParams::mTimer / mNextTime, the draw counter of stream 5,
 // and the active tPerturb entries of cWorld's cPerturbManager (link < 0: free slot)
 enum { PT_TIMER = 0, PT_NEXT, PT_DRAWS, PT_SLOT0, PT_LINK = 0, PT_FX, PT_FY, PT_FZ, PT_DUR, PT_TIME, PT_SLOT_W = 6, PT_SLOTS = 2, PT_KSEED = 15 /* own draw key + 1 (0: the ctx's), see GS_KSEED */, PT_WIDTH = 16 };

@@ -203,6 +203,14 @@ class SceneConfig:
 
 # cSceneDribbleAMP::BuildTarObjs (SceneDribbleAMP.cpp:398-420): the ball's constants are literals there, not arg-file keys
 BALL_MASS, BALL_FRICTION, BALL_LIN_DAMPING, BALL_ANG_DAMPING = 0.43, 0.4, 0.4, 0.4
+def amp_local_root(cfg) -> bool:
+    """The `--enable_amp_obs_local_root` the scene actually runs with.  Only cSceneImitateAMP::ParseArgs reads the key (scenes/SceneImitateAMP.cpp:38-44), and the
+    task scenes skip it: cSceneTargetAMP::ParseArgs calls cSceneImitate::ParseArgs directly (scenes/SceneTargetAMP.cpp:103-105; heading / strike / dribble / get-up
+    chain to it), so for them the flag keeps the constructor's `false` whatever the arg file says -- every shipped task arg file says `true`.  Found by running the
+    compiled scene classes (tests/test_ref_draw_order.py: cSceneImitateAMP::RecordAMPObsExpert of a heading_amp scene)."""
+    return bool(getattr(cfg, "enable_amp_obs_local_root", False)) and cfg.scene not in GOAL_SCENES
+
+
 GOAL_SCENES = {"target_amp": 1, "heading_amp": 2, "heading_amp_getup": 3, "strike_amp": 4, "dribble_amp": 5}
 AMP_SCENES = ("imitate_amp",) + tuple(GOAL_SCENES)
 

@@ -19,7 +19,7 @@ extern "C" {
 /* Layout version of this header: bumped whenever dm_create_info / dm_scene_tables gain fields or an entry point changes meaning.  A host checks
  * `dm_abi_version() == DM_ABI_VERSION` (and a binding that mirrors the structs by hand, `dm_struct_sizes`) once after loading the library: the
  * tables are read as the CURRENT layout, a caller built against an older header would hand over a shorter struct. */
-#define DM_ABI_VERSION 4
+#define DM_ABI_VERSION 5
 
 typedef struct dm_ctx dm_ctx;
 
@@ -243,6 +243,10 @@ int dm_get_manifolds(dm_ctx* ctx, double* out);
 int dm_set_manifolds(dm_ctx* ctx, const double* in);
 /* clip each env's kinematic character was reset to (multi-clip datasets), N int32 */
 int dm_get_clips(dm_ctx* ctx, int32_t* out);
+/* Set that bookkeeping (N int32): the clip the kinematic controller counts as active -- the reference draws the clip time of a reset over the duration of the
+ * clip that was active BEFORE the reset (scenes/SceneImitate.cpp:331-335, 494-500), and cClipsController::Init already selected one at construction
+ * (anim/ClipsController.cpp:24-34).  The character's state is not touched; only a reset through the draw tape reads it. */
+int dm_set_clips(dm_ctx* ctx, const int32_t* clips);
 
 /* BuildStateOffset/Scale, BuildActionOffset/Scale/BoundMin/BoundMax, BuildStateNormGroups (DeepMimicCore.cpp:232-448) */
 int dm_build_offsets_scales(const dm_ctx* ctx, double* s_off, double* s_scale, double* a_off, double* a_scale,
@@ -303,6 +307,35 @@ double dm_refrand_norm(dm_refrand* r, double mean, double stdev);     /* cRand::
 int dm_refrand_int(dm_refrand* r);                                    /* cRand::RandInt() */
 int dm_refrand_int_range(dm_refrand* r, int min, int max);            /* cRand::RandInt(min, max) */
 int dm_refrand_uint(dm_refrand* r);                                   /* cRand::RandUint() */
+int dm_refrand_discard(dm_refrand* r, long n);                        /* advance the engine by n raw values */
+int dm_refrand_norm_state(dm_refrand* r, int set, int* avail, double* saved);    /* the second deviate std::normal_distribution keeps for its next call: read (set = 0) or write */
+int dm_refrand_engine_state(dm_refrand* r, int set, unsigned long* state);       /* the engine's state (minstd_rand0: one integer): read or write -- for snapshots */
+
+/* ---- The draw tape: the reference's draw ORDER for the draws that happen on the device (one-env drop-in, `DM_RNG=reference`).
+ * The reference draws from two generators -- cMathUtil::gRand ("engine 0": every cTimer::Reset (util/Timer.cpp:55-73), cClipsController::SelectNewMotion
+ * (anim/ClipsController.cpp:226-243), cSceneImitate::CalcRandKinResetTime (scenes/SceneImitate.cpp:494-500), the target sampling of strike_amp
+ * (scenes/SceneStrikeAMP.cpp:336-383), the ball's rotation angle (scenes/SceneDribbleAMP.cpp:498)) and the scene's own cScene::mRand ("engine 1": goal
+ * re-sampling of the task scenes (scenes/SceneHeadingAMP.cpp:168-220, SceneTargetAMP.cpp:275-285, SceneDribbleAMP.cpp:430-520), the random yaw
+ * (scenes/SceneImitate.cpp:346), perturbations (scenes/SceneSimChar.cpp:205-256, 952-956), the recovery coin (SceneHeadingAMPGetup.cpp:314)) -- in an order
+ * that depends on what happens inside a launch (a target timer running out, a perturbation falling due).  dm_refrand_tape tabulates, for every raw
+ * engine position k < DM_TAPE_K past a generator's current state, what each distribution would return if its next call started there (computed with
+ * the <random> types themselves); the kernels look their draws up in the reference's call order and advance the two positions; afterwards the host reads
+ * the positions back (dm_get_draw_tape_state) and discards that many raw values from its generators (dm_refrand_discard, dm_refrand_norm_state).
+ *
+ * Row of env e (DM_TAPE_STRIDE doubles): header [0] raw values consumed on engine 0, [1] on engine 1, [2] / [3] engine 1's saved normal deviate
+ * (available flag, value), [4] error flag (a launch ran past the tables: raised by the device, the caller must treat the launch as failed),
+ * [5] 1 when the kinematic controller is a cClipsController (every reset draws a clip, even out of one), [6..8] the episode timer's
+ * {min, max, exp} as cTimer holds them (annealed train-mode parameters whatever the mode; exp <= 0: uniform type), [9] the limit test mode pins
+ * after the draws (< 0: none), [10..15] unused; then the tables: engine 0 uniform [K], engine 0 -log(1 - uniform) [K], engine 1 uniform [K],
+ * engine 1 normal {value, saved value, raw values consumed} [3 K], engine 1 |RandInt()| {value, raw values consumed} [2 K].
+ * With a tape bound, dm_reset without clip times draws the whole reset from it (timers, perturbation clock, clip time, clip, yaw, goal state), and
+ * DM_AUTO_RESET is refused.  Contexts without a tape (the batched path) keep their counter-based streams. */
+#define DM_TAPE_K 96
+#define DM_TAPE_HDR 16
+#define DM_TAPE_STRIDE (DM_TAPE_HDR + 8 * DM_TAPE_K)
+int dm_refrand_tape(const dm_refrand* r, int K, double* u, double* e, double* n3, double* i2);   /* any table may be null; the generator is not advanced */
+int dm_set_draw_tape(dm_ctx* ctx, const double* tape /* N x DM_TAPE_STRIDE; NULL: unbind, back to the counter-based streams */);
+int dm_get_draw_tape_state(dm_ctx* ctx, double* out /* N x DM_TAPE_HDR */);
 
 /* ---- Native scene loading: cDeepMimicCore::ParseArgs (DeepMimicCore.cpp:25-44) + the ParseArgs / file loading of the scene classes the path serves,
  * in C++ inside the library (deepmimic_amd/csrc/dm_scene_load.h), so that a native host goes from the reference's own arg file to a running context

@@ -16,12 +16,12 @@ cd "$(dirname "$0")"
 REF="${1:-/root/reference/DeepMimicCore}"
 CXX="${CXX:-g++}"
 FLAGS="-O2 -std=c++14 -fPIC -w -Ieigen_shim -Igl_stub -Ibullet_stub -I$REF"
-SRCS="util/MathUtil util/Rand util/JsonUtil util/FileUtil util/Timer util/Annealer util/DynamicTimeWarper
+SRCS="util/MathUtil util/Rand util/JsonUtil util/FileUtil util/Timer util/Annealer util/DynamicTimeWarper util/ArgParser
       util/json/json_reader util/json/json_value util/json/json_writer
       sim/SpAlg sim/RBDUtil sim/RBDModel sim/CtCtrlUtil
       anim/KinTree anim/Shape anim/Motion anim/Character anim/KinCharacter anim/KinController
-      anim/MotionController anim/ClipsController
-      sim/Controller sim/CharController sim/DeepMimicCharController sim/CtController sim/CtPDController
+      anim/MotionController anim/ClipsController anim/KinCtrlBuilder
+      sim/Perturb sim/Controller sim/CharController sim/DeepMimicCharController sim/CtController sim/CtPDController
       sim/PDController sim/ExpPDController sim/ImpPDController sim/AgentRegistry util/IndexManager
       scenes/Scene scenes/RLScene scenes/SceneSimChar scenes/RLSceneSimChar scenes/SceneImitate scenes/SceneImitateAMP
       scenes/SceneHeadingAMP scenes/SceneHeadingAMPGetup scenes/SceneTargetAMP scenes/SceneStrikeAMP scenes/SceneDribbleAMP"

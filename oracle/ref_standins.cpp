@@ -39,6 +39,9 @@
 #include "sim/Ground.h"
 #include "sim/SimCharacter.h"
 #include "anim/KinCtrlBuilder.h"
+#include "anim/ClipsController.h"
+#include "util/ArgParser.h"
+#include <unistd.h>
 
 extern "C" void ref_unreachable() {
     fprintf(stderr, "libdm_ref: a reference method without a stand-in was called (it lives in a Bullet translation unit); callers:\n");
@@ -69,8 +72,6 @@ cSimCharacter::~cSimCharacter() {}
 cWorld::tParams::tParams() : mNumSubsteps(1), mScale(1), mGravity(tVector(0, -9.8, 0, 0)) {}
 cSimCharBuilder::eCharType dm_unused_char_type_;
 cCtrlBuilder::tCtrlParams::tCtrlParams() : mCharCtrl(cCtrlBuilder::eCharCtrlNone), mGravity(tVector(0, -9.8, 0, 0)) {}
-cKinCtrlBuilder::tCtrlParams::tCtrlParams() : mCharCtrl(cKinCtrlBuilder::eCharCtrlNone) {}
-tPerturb::~tPerturb() {}
 
 namespace {
 
@@ -89,6 +90,7 @@ class StandinGround : public cGround {
     double SampleHeight(const tVector&) const override { return h; }
     double SampleHeight(const tVector&, bool& valid) const override { valid = true; return h; }
     eClass GetGroundClass() const override { return eClassPlane; }
+    void SamplePlacement(const tVector&, tVector& out_pos, tQuaternion& out_rot) override { out_pos.setZero(); out_pos[1] = h; out_rot.setIdentity(); }      // cGround::SamplePlacement (sim/Ground.cpp:154-159)
     // a plane has no horizontal bounds (sim/GroundPlane.cpp CalcAABB: +-infinity in x, z)
     void CalcAABB(tVector& mn, tVector& mx) const override { const double inf = std::numeric_limits<double>::infinity(); mn = tVector(-inf, h, -inf, 0); mx = tVector(inf, h, inf, 0); }
 };
@@ -154,6 +156,12 @@ class StandinChar : public cSimCharacter {
     void Set(const VecX& p, const VecX& v) { mPose = p; mVel = v; }
     void SetPose(const VecX& p) override { mPose = p; }
     void SetVel(const VecX& v) override { mVel = v; }
+    // cSimCharacter::SetRootTransform (sim/SimCharacter.cpp:185-202) without the write-through to the Bullet body
+    void SetRootTransform(const tVector& pos, const tQuaternion& rot) override {
+        const tQuaternion delta = rot * cKinTree::GetRootRot(mPose).inverse();
+        const tVector v = cMathUtil::QuatRotVec(delta, cKinTree::GetRootVel(mVel)), w = cMathUtil::QuatRotVec(delta, cKinTree::GetRootAngVel(mVel));
+        cKinTree::SetRootPos(pos, mPose); cKinTree::SetRootRot(rot, mPose); cKinTree::SetRootVel(v, mVel); cKinTree::SetRootAngVel(w, mVel);
+    }
     // pose-vector getters: what SimCharacter.cpp:124-161 reads back from the Bullet base are the root slots of the pose it just built
     tVector GetRootPos() const override { return cKinTree::GetRootPos(mPose); }
     tQuaternion GetRootRotation() const override { return cKinTree::GetRootRot(mPose); }
@@ -232,6 +240,11 @@ class StandinBody : public cSimRigidBody {
     tVector GetLinearVelocity() const override { return lin; }
     tVector GetAngularVelocity() const override { return ang; }
     tVector GetSize() const override { return tVector::Zero(); }      // (cSimSphere::GetSize; no routine called here asks)
+    void SetPos(const tVector& p) override { pos = p; }
+    void SetRotation(const tVector& axis, double theta) override { rot = cMathUtil::AxisAngleToQuaternion(axis, theta); }
+    void SetRotation(const tQuaternion& q) override { rot = q; }
+    void SetLinearVelocity(const tVector& v) override { lin = v; }
+    void SetAngularVelocity(const tVector& v) override { ang = v; }
 };
 
 // the reference's controller with its protected parts reachable
@@ -289,6 +302,51 @@ class SceneX : public SCENE {
     bool dribble_char_obj_fail(const cSimCharacter& c) const { return this->CheckCharObjDistFail(c); }
     bool dribble_has_fallen(const cSimCharacter& c) const { return this->HasFallen(c); }
     double reward_imitate(const cSimCharacter& sim, const cKinCharacter& kin) const { return this->CalcRewardImitate(sim, kin); }
+    // ---- draw session (ref3_*): the parts of Init / Reset / Update that draw random numbers, each the reference's own compiled method
+    cSimObj* pert_obj = nullptr; tVector pert_force = tVector::Zero(); double pert_dur = 0; int n_perturbs = 0;
+    void AddPerturb(const tPerturb& p) override { pert_obj = p.mObj; pert_force = p.mPerturb; pert_dur = p.mDuration; ++n_perturbs; }      // (cSceneSimChar::AddPerturb hands it to the Bullet world; kept here instead)
+    void d_parse(const std::shared_ptr<cArgParser>& parser) { this->ParseArgs(parser); this->mCharParams.resize(1); }
+    void d_mode(int test) { this->mMode = test ? cRLScene::eModeTest : cRLScene::eModeTrain; }
+    void d_rl_scene_init() { this->cRLScene::Init(); }                               // cScene::Init: InitTimers + ResetParams (virtual)
+    void d_scene_init() { this->cScene::Init(); }
+    bool d_perturbs() const { return this->mPerturbParams.mEnableRandPerturbs; }
+    void d_reset_perturb() { this->ResetRandPertrub(); }
+    void d_update_perturb(double dt) { this->UpdateRandPerturb(dt); }
+    void d_setup_annealer() { this->SetupTimerAnnealer(this->mTimerAnnealer); }
+    void d_rl_reset_scene() { this->cRLScene::ResetScene(); }
+    void d_base_reset_scene() { this->cScene::ResetScene(); }
+    void d_reset_characters() { this->ResetCharacters(); }                           // virtual: cSceneImitate::ResetCharacters -> ResetKinChar, SyncCharacters
+    void d_update_timers(double dt) { this->UpdateTimers(dt); }
+    void d_init_char_pos() { this->InitCharacterPos(); }                             // rand placement on a plane: the root goes to x = z = 0 (SceneSimChar.cpp:478-531)
+    void d_amp_reset() { this->InitHist(); }
+    double d_timer_max() const { return this->mTimer.GetMaxTime(); }
+    double d_time() const { return this->mTimer.GetTime(); }
+    double d_pert_next() const { return this->mPerturbParams.mNextTime; }
+    double d_pert_timer() const { return this->mPerturbParams.mTimer; }
+    // task scenes
+    void d_target_init() { this->InitTarget(); this->ResetTarget(); }                // cSceneTargetAMP::Init after cSceneImitate::Init (:118-123)
+    void d_target_reset() { this->mTargetTimer.Reset(); this->ResetTarget(); }       // cSceneTargetAMP::Reset after cSceneImitate::Reset (:125-130)
+    void d_target_update(double dt) { this->UpdateTarget(dt); if (this->mTargetTimer.IsEnd()) this->mTargetTimer.Reset(); }      // cSceneTargetAMP::Update after the scene update (:132-141)
+    tVector d_target_pos() const { return this->mTargetPos; }
+    double d_target_speed() const { return this->mTargetSpeed; }
+    double d_target_timer_max() const { return this->mTargetTimer.GetMaxTime(); }
+    double d_target_timer_time() const { return this->mTargetTimer.GetTime(); }
+    double d_heading() const { return this->mTargetHeading; }
+    bool d_strike_hit() const { return this->mTargetHit; }
+    double d_strike_hit_time() const { return this->mTargetHitTime; }
+    // dribble_amp (InitTarObjs without BuildTarObjs, which builds the Bullet sphere: the ball is the stand-in body)
+    void d_dribble_init() { this->mTarObjTimer.Init(this->mTarObjTimerParams); this->ResetTarObjs(); this->InitAgentTarObjRecord(); this->mTargetTimer.Reset(); this->ResetTarget(); }
+    void d_dribble_reset_head() { this->mTarObjTimer.Reset(); this->ResetTarObjs(); this->ResetAgentTarObjRecord(); }
+    void d_dribble_update_objs(double dt) { this->UpdateTarObjs(dt); if (this->mTarObjTimer.IsEnd()) this->mTarObjTimer.Reset(); }      // cSceneDribbleAMP::UpdateObjs (:310-319)
+    double d_obj_timer_max() const { return this->mTarObjTimer.GetMaxTime(); }
+    void d_dribble_ball(const std::shared_ptr<cSimRigidBody>& b) { ball = b; this->mTarObjID = 0; }
+    int d_expert(VecX& out) { this->RecordAMPObsExpert(0, out); return (int)out.size(); }
+    // heading_amp_getup
+    void d_getup_init(const std::vector<int>& ids) { this->mGetupMotionIDs = ids; this->RecordGetupMotionFlags(ids); this->mGetupTime = this->CalcGetupTime(ids); this->InitGetupTimer(); this->ResetGetupTimer(); this->SyncGetupTimer(); }
+    bool d_getup_activate_recovery() { return this->ActivateRecoveryEpisode(); }
+    void d_getup_reset_recovery() { this->ResetRecoveryEpisode(); }
+    void d_getup_sync() { this->SyncGetupTimer(); }
+    double d_getup_timer() const { return this->mGetupTimer.GetTime(); }
 };
 
 struct Rig {
@@ -500,6 +558,165 @@ int ref2_task_scene(void* h, int kind, const double* par, double* out) {
     }
     out[0] = rew; for (int i = 0; i < (int)g.size(); ++i) out[1 + i] = g[i];
     return (int)g.size();
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Draw session: the reference's draw ORDER on its two generators (cMathUtil::gRand and the scene's cScene::mRand), produced by the reference's own
+// compiled methods in the order cDeepMimicCore::Init / cScene::Reset / cScene::Update call them.  What cannot run here is the Bullet world between
+// those calls; the functions below therefore issue the sequence of calls of cSceneSimChar::Init (scenes/SceneSimChar.cpp:106-123), ::ResetScene
+// (:628-644), ::Update (:136-167), cSceneTargetAMP::Init / Reset / Update (scenes/SceneTargetAMP.cpp:118-141), cSceneDribbleAMP::Init / Reset /
+// UpdateObjs (scenes/SceneDribbleAMP.cpp:151-170, 310-319) and cSceneHeadingAMPGetup::Init / Reset (scenes/SceneHeadingAMPGetup.cpp:83-121), each
+// element of which is the reference's compiled method.  kind: 0 imitate_amp, 1 target_amp, 2 heading_amp, 3 heading_amp_getup, 4 strike_amp,
+// 5 dribble_amp.  `tokens`: the scene's arg-file keys as command-line tokens, parsed by the scene's own ParseArgs (the keys that name builders
+// whose translation units are Bullet code -- char_types, char_ctrls, kin_ctrl, terrain_file -- are left out by the caller).
+namespace {
+struct Draw {
+    Rig* rig = nullptr; int kind = 0; bool clips = false;
+    std::shared_ptr<cClipsController> clips_ctrl;
+    std::vector<int> getup_ids;
+};
+template <class F> void with_scene(Draw* d, F f) {
+    Rig* r = d->rig;
+    switch (d->kind) {
+    case 0: f(*r->amp); break;
+    case 1: f(*r->target); break;
+    case 2: f(*r->heading); break;
+    case 3: f(*r->getup); break;
+    case 4: f(*r->strike); break;
+    default: f(*r->dribble); break;
+    }
+}
+template <class S> void draw_task_init(S&, Draw*) {}
+template <> void draw_task_init(SceneX<cSceneTargetAMP>& s, Draw*) { s.d_target_init(); }
+template <> void draw_task_init(SceneX<cSceneHeadingAMP>& s, Draw*) { s.d_target_init(); }
+template <> void draw_task_init(SceneX<cSceneStrikeAMP>& s, Draw*) { s.d_target_init(); }
+template <> void draw_task_init(SceneX<cSceneHeadingAMPGetup>& s, Draw* d) { s.d_target_init(); s.d_getup_init(d->getup_ids); }
+template <> void draw_task_init(SceneX<cSceneDribbleAMP>& s, Draw*) { s.d_target_init(); s.d_dribble_init(); }
+template <class S> void draw_task_reset(S&) {}
+template <> void draw_task_reset(SceneX<cSceneTargetAMP>& s) { s.d_target_reset(); }
+template <> void draw_task_reset(SceneX<cSceneHeadingAMP>& s) { s.d_target_reset(); }
+template <> void draw_task_reset(SceneX<cSceneStrikeAMP>& s) { s.d_target_reset(); }
+template <> void draw_task_reset(SceneX<cSceneHeadingAMPGetup>& s) { s.d_target_reset(); s.d_getup_sync(); }
+template <> void draw_task_reset(SceneX<cSceneDribbleAMP>& s) { s.d_target_reset(); }
+template <class S> void draw_task_update(S&, double) {}
+template <> void draw_task_update(SceneX<cSceneTargetAMP>& s, double dt) { s.d_target_update(dt); }
+template <> void draw_task_update(SceneX<cSceneHeadingAMP>& s, double dt) { s.d_target_update(dt); }
+template <> void draw_task_update(SceneX<cSceneStrikeAMP>& s, double dt) { s.d_target_update(dt); }
+template <> void draw_task_update(SceneX<cSceneHeadingAMPGetup>& s, double dt) { s.d_target_update(dt); }
+template <> void draw_task_update(SceneX<cSceneDribbleAMP>& s, double dt) { s.d_target_update(dt); }
+template <class S> void draw_reset_scene(S& s) {
+    // cRLSceneSimChar::ResetScene (RLSceneSimChar.cpp:240-244) = cRLScene::ResetScene + cSceneSimChar::ResetScene; of the latter (SceneSimChar.cpp:628-644):
+    // cScene::ResetScene, ResetRandPertrub, [ResetWorld: Bullet], ResetCharacters, [ResetGround, CleanObjs, InitCharacterPos, ResolveCharGroundIntersect: no draws]
+    s.d_rl_reset_scene();
+    s.d_base_reset_scene();
+    if (s.d_perturbs()) s.d_reset_perturb();
+    s.d_reset_characters();
+    s.d_init_char_pos();                              // (ResolveCharGroundIntersect lifts the character off the ground: heights only, and the parts' AABBs are Bullet's)
+    s.d_amp_reset();
+}
+}  // namespace
+
+extern "C" {
+
+void* ref3_open(int kind, long seed, const char** tokens, int ntok, const char* char_file, const char* ctrl_file, const char* motion_file, int clips_ctrl,
+                const char* cwd, int test_mode, const int* getup_ids, int n_getup) {
+    char old_cwd[4096]; if (!getcwd(old_cwd, sizeof(old_cwd))) return nullptr;
+    if (cwd && cwd[0] && chdir(cwd) != 0) return nullptr;                      // the dataset file names its motion files relative to the reference's root
+    Draw* d = new Draw(); d->kind = kind; d->clips = clips_ctrl != 0;
+    for (int i = 0; i < n_getup; ++i) d->getup_ids.push_back(getup_ids[i]);
+    cMathUtil::SeedRand((unsigned long)seed);                                   // cDeepMimicCore::SeedRand (DeepMimicCore.cpp:20-23)
+    const double g[3] = {0, -9.8, 0};
+    Rig* r = (Rig*)ref2_create(char_file, ctrl_file, "", g);
+    if (!r) { delete d; (void)!chdir(old_cwd); return nullptr; }
+    d->rig = r;
+    // the scene object: its constructor seeds mRand from gRand (scenes/Scene.cpp:5)
+    switch (kind) {
+    case 0: r->amp = std::shared_ptr<SceneX<cSceneImitateAMP>>(new SceneX<cSceneImitateAMP>()); break;
+    case 1: r->target = std::shared_ptr<SceneX<cSceneTargetAMP>>(new SceneX<cSceneTargetAMP>()); break;
+    case 2: r->heading = std::shared_ptr<SceneX<cSceneHeadingAMP>>(new SceneX<cSceneHeadingAMP>()); break;
+    case 3: r->getup = std::shared_ptr<SceneX<cSceneHeadingAMPGetup>>(new SceneX<cSceneHeadingAMPGetup>()); break;
+    case 4: r->strike = std::shared_ptr<SceneX<cSceneStrikeAMP>>(new SceneX<cSceneStrikeAMP>()); break;
+    default: r->dribble = std::shared_ptr<SceneX<cSceneDribbleAMP>>(new SceneX<cSceneDribbleAMP>()); break;
+    }
+    std::vector<std::string> args; for (int i = 0; i < ntok; ++i) args.push_back(tokens[i]);
+    std::shared_ptr<cArgParser> parser(new cArgParser(args));
+    with_scene(d, [&](auto& s) { s.d_parse(parser); s.d_mode(test_mode); });
+    // cSceneImitate::Init (scenes/SceneImitate.cpp:153-161): the kinematic character and its controller first -- a cClipsController selects its first clip
+    r->kin = std::shared_ptr<cKinCharacter>(new cKinCharacter());
+    cKinCharacter::tParams kp; kp.mCharFile = char_file; kp.mLoadDrawShapes = false;
+    bool ok = r->kin->Init(kp);
+    if (ok && d->clips) { d->clips_ctrl = std::shared_ptr<cClipsController>(new cClipsController()); d->clips_ctrl->Init(r->kin.get(), motion_file); r->kin->SetController(d->clips_ctrl); }
+    else if (ok) { std::shared_ptr<cMotionController> mc(new cMotionController()); mc->Init(r->kin.get(), motion_file); r->kin->SetController(mc); }
+    (void)!chdir(old_cwd);
+    if (!ok) { delete d; return nullptr; }
+    if (kind == 5) r->ball = std::shared_ptr<StandinBody>(new StandinBody());
+    with_scene(d, [&](auto& s) {
+        s.d_rl_scene_init();                                                    // cRLSceneSimChar::Init (RLSceneSimChar.cpp:27-37): cRLScene::Init ...
+        s.d_scene_init();                                                       // ... cSceneSimChar::Init (SceneSimChar.cpp:106-123): cScene::Init,
+        if (s.d_perturbs()) s.d_reset_perturb();                                // ResetRandPertrub,
+        cMathUtil::RandUint();                                                  // BuildGround: cGround::cGround seeds the terrain generator (sim/Ground.cpp:68); the ground here is the stand-in
+        s.setup(r->ch, r->kin, 0.0);
+        s.d_init_char_pos();
+        s.d_setup_annealer();
+    });
+    if (kind == 5) r->dribble->d_dribble_ball(r->ball);
+    with_scene(d, [&](auto& s) { draw_task_init(s, d); });
+    return d;
+}
+void ref3_close(void* h) { Draw* d = (Draw*)h; new std::shared_ptr<cClipsController>(d->clips_ctrl); ref2_destroy(d->rig); delete d; }
+// state of the simulated character as the scene reads it (root position, link positions / velocities, the fall test of CheckTerminate)
+void ref3_set_char(void* h, const double* pose, const double* vel, int fallen) { Draw* d = (Draw*)h; ref2_set_state(d->rig, pose, vel); d->rig->ch->fallen = fallen != 0; }
+void ref3_set_ball(void* h, const double* pos3) { Draw* d = (Draw*)h; if (d->rig->ball) d->rig->ball->pos = tVector(pos3[0], pos3[1], pos3[2], 0); }
+// where the scene's SyncKinCharRoot left the kinematic character's origin (it follows the simulated root, which ResolveCharGroundIntersect lifted: Bullet-side AABBs)
+void ref3_set_kin_origin_pos(void* h, const double* p3) { ((Draw*)h)->rig->kin->SetOriginPos(tVector(p3[0], p3[1], p3[2], 0)); }
+void ref3_set_sample_count(void* h, int n) { with_scene((Draw*)h, [&](auto& s) { s.SetSampleCount(n); }); }
+void ref3_set_mode(void* h, int test) { with_scene((Draw*)h, [&](auto& s) { s.SetMode(test ? cRLScene::eModeTest : cRLScene::eModeTrain); }); }
+// cScene::Reset of the scene class.  Returns 1 when heading_amp_getup continued the episode as a recovery episode.
+int ref3_reset(void* h) {
+    Draw* d = (Draw*)h; int rec = 0;
+    if (d->kind == 3) {                                                          // cSceneHeadingAMPGetup::Reset (:105-117)
+        auto& s = *d->rig->getup;
+        if (s.d_getup_activate_recovery()) { s.d_getup_reset_recovery(); return 1; }
+    }
+    if (d->kind == 5) d->rig->dribble->d_dribble_reset_head();                   // cSceneDribbleAMP::Reset (:162-169): the ball first
+    with_scene(d, [&](auto& s) { draw_reset_scene(s); draw_task_reset(s); });
+    return rec;
+}
+// the drawing part of one scene update: cScene::Update (timers), UpdateRandPerturb, [the world and character update], cSceneDribbleAMP::UpdateObjs,
+// cSceneTargetAMP::Update's target part.  Call ref3_set_char with the state AFTER the update first (the target code reads it).
+void ref3_update(void* h, double dt) {
+    Draw* d = (Draw*)h;
+    with_scene(d, [&](auto& s) { s.d_update_timers(dt); if (s.d_perturbs()) s.d_update_perturb(dt); });
+    if (d->kind == 5) d->rig->dribble->d_dribble_update_objs(dt);
+    with_scene(d, [&](auto& s) { draw_task_update(s, dt); });
+}
+// cSceneImitateAMP::RecordAMPObsExpert (:115-138) itself: SampleExpertMotion draws the clip (gRand, clips controller), then the clip time (mRand)
+int ref3_expert(void* h, double* out) { VecX v; int n = 0; with_scene((Draw*)h, [&](auto& s) { n = s.d_expert(v); }); vout(v, out); return n; }
+void ref3_get(void* h, double* out) {
+    Draw* d = (Draw*)h; Rig* r = d->rig;
+    for (int i = 0; i < 40; ++i) out[i] = 0;
+    out[1] = r->kin->GetTime(); out[2] = d->clips_ctrl ? d->clips_ctrl->GetCurrMotionID() : 0;
+    { const tVector rp = r->ch->GetRootPos(), kp = r->kin->GetRootPos(); out[35] = rp[0]; out[36] = rp[1]; out[37] = rp[2]; out[38] = kp[0]; out[39] = kp[2]; }
+    const tQuaternion q = r->kin->GetOriginRot(); out[3] = q.w(); out[4] = q.x(); out[5] = q.y(); out[6] = q.z();
+    with_scene(d, [&](auto& s) {
+        out[0] = s.d_timer_max(); out[34] = s.d_time(); out[14] = s.d_pert_next(); out[15] = s.d_pert_timer(); out[31] = s.n_perturbs;
+        if (s.n_perturbs) {
+            const cSimBodyLink* lk = dynamic_cast<const cSimBodyLink*>(s.pert_obj);
+            out[16] = lk ? lk->GetJointID() : -1; out[17] = s.pert_force[0]; out[18] = s.pert_force[1]; out[19] = s.pert_force[2]; out[20] = s.pert_dur;
+        }
+    });
+    auto task = [&](auto& s) { const tVector t = s.d_target_pos(); out[7] = t[0]; out[8] = t[1]; out[9] = t[2]; out[11] = s.d_target_speed(); out[12] = s.d_target_timer_max(); out[13] = s.d_target_timer_time(); };
+    switch (d->kind) {
+    case 1: task(*r->target); break;
+    case 2: task(*r->heading); out[10] = r->heading->d_heading(); break;
+    case 3: task(*r->getup); out[10] = r->getup->d_heading(); out[32] = r->getup->d_getup_timer(); break;
+    case 4: task(*r->strike); out[21] = r->strike->d_strike_hit(); out[22] = r->strike->d_strike_hit_time(); break;
+    case 5: task(*r->dribble); out[30] = r->dribble->d_obj_timer_max();
+            out[23] = r->ball->pos[0]; out[24] = r->ball->pos[1]; out[25] = r->ball->pos[2]; out[26] = r->ball->rot.w(); out[27] = r->ball->rot.x(); out[28] = r->ball->rot.y(); out[29] = r->ball->rot.z(); break;
+    default: break;
+    }
 }
 
 }  // extern "C"

@@ -68,7 +68,7 @@ class Oracle:
                     enable_root_rot_fail=c.enable_root_rot_fail, enable_rand_placement=c.enable_rand_char_placement,
                     enable_phase_input=tables.enable_phase_input, record_world_root_pos=tables.record_world_root_pos,
                     record_world_root_rot=tables.record_world_root_rot, query_rate=tables.query_rate,
-                    scene_amp=(c.scene != "imitate"), amp_local_root=getattr(c, "enable_amp_obs_local_root", False),
+                    scene_amp=(c.scene != "imitate"), amp_local_root=model.amp_local_root(c),
                     scene_goal=tables.goal_kind, rand_rot_reset=c.enable_rand_rot_reset, tar_time_min=c.rand_target_time_min,
                     tar_time_max=c.rand_target_time_max, max_tar_dist=c.max_target_dist, tar_succ_dist=c.target_succ_dist,
                     tar_fail_dist=c.tar_fail_dist, tar_speed=c.tar_speed, pos_reward_scale=c.pos_reward_scale, min_tar_vel=c.enable_min_tar_vel,

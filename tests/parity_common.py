@@ -462,9 +462,17 @@ def goal_rollout_compare(t, precision, lib_path, steps, n, seed, wave_packing=0,
     has_aux = t.goal_kind in (3, 4)
     has_ball = t.goal_kind == 5
 
-    def draw(o, e, episode):
-        clip = o.draw_clip(streams.reset_rand01(seed, e, episode, 3)) if t.num_clips > 1 else 0
-        kt = o.clip_duration(clip) * streams.reset_rand01(seed, e, episode, 0)
+    def clip_of(o, e, episode):     # the clip the reset of `episode` selects; episode -1: the one cClipsController::Init selected (stream 6)
+        if t.num_clips <= 1:
+            return 0
+        return o.draw_clip(streams.reset_rand01(seed, e, 0, 6) if episode < 0 else streams.reset_rand01(seed, e, episode, 3))
+
+    def draw(o, e, episode, prev=None):
+        clip = clip_of(o, e, episode)
+        # the reference draws the clip time over the duration of the clip that was active BEFORE the reset (scenes/SceneImitate.cpp:331-335, 494-500), then selects the
+        # new one.  prev: that clip; None = the clip the previous episode's reset selected (no recovery episode in between)
+        prev = clip_of(o, e, episode - 1) if prev is None else prev
+        kt = o.clip_duration(prev) * streams.reset_rand01(seed, e, episode, 0)
         mt = tmin + (tmax - tmin) * streams.reset_rand01(seed, e, episode, 1) if tmax > tmin else tmax
         yaw = (-np.pi + 2 * np.pi * streams.reset_rand01(seed, e, episode, 4)) if t.cfg.enable_rand_rot_reset else 0.0
         return clip, kt, mt, yaw
@@ -475,6 +483,7 @@ def goal_rollout_compare(t, precision, lib_path, steps, n, seed, wave_packing=0,
         o.goal_rng(seed, e, int(g0[e][11]))
         o.reset_ex(*[(lambda c, k, m, y: (k, m, c, y))(*draw(o, e, int(ep[e]) - 1))][0])
         oracles.append(o)
+    active = {e: draw(o, e, int(ep[e]) - 1)[0] for e, o in enumerate(oracles)}      # clip each env's kinematic controller is on
     w = dict(reward=0.0, state=0.0, goal=0.0, goal_state=0.0, resets=0, live=0, flags_ok=True, clips=set(), dist_fail=0, reward_errs=[], goal_errs=[],
              aux=0.0, recoveries=0, succ=0, fail=0, aux_steps=0, desynced=0, scored=0, ball=0.0, ball_moved=0.0)
     dead = np.zeros(n, bool)       # fp32 only: an env whose episode ended at a different update than the oracle's is not scored from there on
@@ -508,11 +517,11 @@ def goal_rollout_compare(t, precision, lib_path, steps, n, seed, wave_packing=0,
             w["flags_ok"] &= int(out["terminate"][e]) == term and bool(out["episode_end"][e]) == end and int(out["valid"][e]) == int(valid)
             w["succ"] += int(term == 2); w["fail"] += int(term == 1)
             if end or not valid:                                    # (the driver resets after an invalid episode as after an ended one)
-                c, kt, mt, yaw = draw(o, e, int(ep[e]))
+                c, kt, mt, yaw = draw(o, e, int(ep[e]), active[e])
                 if o.maybe_recovery_reset(mt):                      # heading_amp_getup, train mode: the episode goes on as a recovery episode
                     w["recoveries"] += 1; c = int(clips[e])
                 else:
-                    o.reset_ex(kt, mt, c, yaw)
+                    o.reset_ex(kt, mt, c, yaw); active[e] = c
                 ep[e] += 1; w["resets"] += 1
                 assert clips[e] == c, "clip draw mismatch after reset"
             w["clips"].add(int(clips[e]))

@@ -325,6 +325,7 @@ def test_facade_updates_with_perturbs_follow_the_oracle(emu_lib, monkeypatch):
         sys.path.insert(0, compat)
     from DeepMimicCore import DeepMimicCore as mod
     monkeypatch.setenv("DM_HIP_LIB", emu_lib); monkeypatch.setenv("DM_PRECISION", "64")
+    monkeypatch.setenv("DM_RNG", "counter")        # the oracle replays the counter-based streams (the reference's generators through the draw tape: tests/test_ref_draw_order.py)
     t = perturbed(model.load_asset("humanoid3d_walk"), tmin=0.03, tmax=0.06, dmin=0.01, dmax=0.05)
     core = mod.cDeepMimicCore(False)
     core.SeedRand(5); core.LoadTables(t, num_update_substeps=10); core.Init()

@@ -1,0 +1,25 @@
+"""The draw tape on the HIP kernels: the one-env cDeepMimicCore facade with `DM_RNG=reference` on libdm_hip.so against the log of the reference's compiled scene
+classes (tests/golden/ref_draws.npz, written by tests/golden/make_ref_draw_golden.py where the reference checkout exists; tests/test_ref_draw_order.py is the
+live comparison on the CPU emulator build of the same kernels).  fp64 kernels: every draw-determined value EQUAL; fp32 production kernels: equal to float
+accuracy (their scene parameters are floats)."""
+import os
+
+import numpy as np
+import pytest
+
+import test_ref_draw_order as T
+from deepmimic_amd import model
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_draws.npz")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("key", sorted(T.GOLDEN_SESSIONS))
+@pytest.mark.parametrize("precision", ["64", "32"])
+def test_draw_tape_on_hip_kernels_equals_reference_log(hip_lib, monkeypatch, key, precision):
+    asset, args, seed, n_resets, steps, anneal = T.GOLDEN_SESSIONS[key]
+    store = np.load(GOLDEN)
+    if precision == "32":
+        n_resets = 3      # the fp32 character drifts from the logged fp64 one: short, time-limited episodes only
+    T._run(T._core_module(), hip_lib, args(), seed, monkeypatch, n_resets=n_resets, steps=steps, anneal_at=anneal, tables=model.load_asset(asset),
+           provider=T.Replay(store, key, T.GOLDEN_KINDS[key]), precision=precision, exact=precision == "64", pos_tol=1e-6)

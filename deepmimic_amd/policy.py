@@ -42,6 +42,17 @@ class Policy:
         if self.lib.dm_policy_create(int(device_id), C.byref(pp), C.byref(self.h)) != 0:
             raise RuntimeError("libdm_hip: %s" % self.lib.dm_last_error().decode())
 
+    @classmethod
+    def from_checkpoint(cls, prefix: str, state_dim: Optional[int] = None, **kw):
+        """the actor of a reference checkpoint (`--model_files <prefix>`: learning/rl_world.py:67-85, learning/tf_agent.py:36-48; read without TensorFlow by
+        deepmimic_amd/tf_checkpoint.py) with its state / action normalisers.  An agent with a goal takes [state, goal] rows (forward_device_ex's goal block);
+        its g_norm rides behind s_norm."""
+        from . import tf_checkpoint
+        w = tf_checkpoint.actor_weights(prefix, state_dim=state_dim)
+        if "g_mean" in w:
+            w["s_mean"] = np.concatenate([w["s_mean"], w["g_mean"]]); w["s_std"] = np.concatenate([w["s_std"], w["g_std"]])
+        return cls(w, **kw)
+
     def forward_device(self, states_ptr: int, n: int, actions_ptr: int, logp_ptr: int = 0, sample: bool = False, seed: int = 0,
                        step: int = 0, env_id_offset: int = 0, stream: int = 0):
         """raw device pointers (e.g. torch.Tensor.data_ptr()); asynchronous on `stream` (a hipStream_t handle, 0 = null stream)."""

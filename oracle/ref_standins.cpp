@@ -317,6 +317,7 @@ class SceneX : public SCENE {
     void d_base_reset_scene() { this->cScene::ResetScene(); }
     void d_reset_characters() { this->ResetCharacters(); }                           // virtual: cSceneImitate::ResetCharacters -> ResetKinChar, SyncCharacters
     void d_update_timers(double dt) { this->UpdateTimers(dt); }
+    void d_update_kin(double dt) { this->UpdateKinChar(dt); }
     void d_init_char_pos() { this->InitCharacterPos(); }                             // rand placement on a plane: the root goes to x = z = 0 (SceneSimChar.cpp:478-531)
     void d_amp_reset() { this->InitHist(); }
     double d_timer_max() const { return this->mTimer.GetMaxTime(); }
@@ -671,6 +672,12 @@ void ref3_set_char(void* h, const double* pose, const double* vel, int fallen) {
 void ref3_set_ball(void* h, const double* pos3) { Draw* d = (Draw*)h; if (d->rig->ball) d->rig->ball->pos = tVector(pos3[0], pos3[1], pos3[2], 0); }
 // where the scene's SyncKinCharRoot left the kinematic character's origin (it follows the simulated root, which ResolveCharGroundIntersect lifted: Bullet-side AABBs)
 void ref3_set_kin_origin_pos(void* h, const double* p3) { ((Draw*)h)->rig->kin->SetOriginPos(tVector(p3[0], p3[1], p3[2], 0)); }
+// contact flags of the body parts (bit j: part j touches something; cSimCharacter::IsInContact), for the scenes' fall logic
+void ref3_set_contacts(void* h, int mask) { ((Draw*)h)->rig->ch->contact_mask = mask; }
+// cSceneImitate::UpdateKinChar (scenes/SceneImitate.cpp:306-318): the kinematic character's clock, and the root sync at a cycle boundary
+void ref3_update_kin(void* h, double dt) { with_scene((Draw*)h, [&](auto& s) { s.d_update_kin(dt); }); }
+// CheckTerminate(0) and IsEpisodeEnd() of the scene class (virtual: the task scenes' success / failure conditions, the episode and motion clocks)
+void ref3_flags(void* h, int* out2) { with_scene((Draw*)h, [&](auto& s) { out2[0] = (int)s.CheckTerminate(0); out2[1] = s.IsEpisodeEnd() ? 1 : 0; }); }
 void ref3_set_sample_count(void* h, int n) { with_scene((Draw*)h, [&](auto& s) { s.SetSampleCount(n); }); }
 void ref3_set_mode(void* h, int test) { with_scene((Draw*)h, [&](auto& s) { s.SetMode(test ? cRLScene::eModeTest : cRLScene::eModeTrain); }); }
 // cScene::Reset of the scene class.  Returns 1 when heading_amp_getup continued the episode as a recovery episode.

@@ -98,6 +98,16 @@ class RefSession:
     def set_mode(self, test):
         self.ref.ref3_set_mode(self.h, int(test))
 
+    def update_kin(self, dt):
+        self.ref.ref3_update_kin(self.h, C.c_double(dt))
+
+    def flags(self, contact_mask):
+        """(CheckTerminate(0), IsEpisodeEnd()) of the compiled scene for the stand-in character's state and these contact flags"""
+        self.ref.ref3_set_contacts(self.h, int(contact_mask))
+        out = (C.c_int * 2)()
+        self.ref.ref3_flags(self.h, out)
+        return int(out[0]), bool(out[1])
+
     def close(self):
         self.ref.ref3_close(self.h)
 
@@ -117,6 +127,9 @@ class Recorder:
 
     def get(self):
         return self.rows[-1]
+
+    def flags(self, contact_mask):
+        return None                     # (not part of the committed log: the GPU box checks the draws)
 
     def expert(self, n):
         v = self.rs.expert(n); self.tag.append(2); self.rows.append(np.zeros(40)); self.experts.append(v); return v
@@ -154,6 +167,8 @@ class Replay:
         self._next(2); v = self.experts[self.ie]; self.ie += 1; return v
 
     def set_char(self, *a, **k): pass
+    def update_kin(self, dt): pass
+    def flags(self, contact_mask): return None
     def set_ball(self, *a): pass
     def set_sample_count(self, n): pass
     def set_mode(self, test): pass
@@ -246,6 +261,7 @@ def _run(mod, lib, args, seed, monkeypatch, n_resets, steps, precision="64", pos
     dt = 1.0 / 600
     rng = np.random.RandomState(seed & 0xffff)
     n_pert = 0; n_rec = 0
+    fall_bits = int(sum(1 << j for j, f in enumerate(t.fall_mask()) if f))
     try:
         for ep in range(n_resets):
             if anneal_at and ep in anneal_at:
@@ -268,11 +284,16 @@ def _run(mod, lib, args, seed, monkeypatch, n_resets, steps, precision="64", pos
                     core.SetAction(0, policy_scale * rng.randn(env.A))
                 core.Update(dt)
                 d = _dev(core)
-                rs.set_char(d["pose"], d["vel"])
+                rs.update_kin(dt)                 # (cSceneImitate::UpdateCharacters: before the world steps)
+                cmask = int(env.get_state()["flags"][0][1])
+                rs.set_char(d["pose"], d["vel"], fallen=bool(cmask & fall_bits))      # cSimCharacter::HasFallen: a fall-contact body touches something
                 if kind == 5:
                     rs.set_ball(d["ball"][0:3])
                 rs.update(dt)
                 r = rs.get()
+                fl = rs.flags(cmask)
+                if fl is not None:                # the scene's own CheckTerminate / IsEpisodeEnd on that state: the task scenes' success / failure rules, the clocks
+                    assert (core.CheckTerminate(0), core.IsEpisodeEnd()) == fl, ("episode %d update %d" % (ep, k), "terminate / episode end", core.CheckTerminate(0), core.IsEpisodeEnd(), fl)
                 _check(kind, d, r, "episode %d update %d" % (ep, k), pos_tol, exact=exact)
                 if "pert" in d and int(r[31]) > n_pert:          # a perturbation fell due in this update: part, force, duration
                     n_pert = int(r[31])

@@ -32,7 +32,12 @@ GOLDEN_SESSIONS = {
     "strike": ("amp_strike_punch", lambda: ["--arg_file", "args/train_amp_strike_humanoid3d_walk_punch_args.txt", "--motion_file",
                                             os.path.join(ROOT, "tools", "datasets", "humanoid3d_clips_walk_punch_local.txt")], 77, 12, 8, None),
 }
-GOLDEN_KINDS = {"heading4": 2, "strike": 4}
+GOLDEN_SESSIONS.update({
+    "dribble": ("amp_dribble_zombie", lambda: ["--arg_file", "args/train_amp_dribble_humanoid3d_zombie_args.txt"], 12345, 8, 8, None),
+    "getup": ("amp_heading_getup", lambda: ["--arg_file", "args/train_amp_heading_getup_humanoid3d_locomotion_getup_args.txt"], 99, 10, 8, {0: 64000000}),
+})
+GOLDEN_KINDS = {"heading4": 2, "strike": 4, "dribble": 5, "getup": 3}
+GOLDEN_POLICY_SCALE = {"getup": 1.0}          # (random actions: the character falls, recovery episodes happen)
 
 
 def _core_module():

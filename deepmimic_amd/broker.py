@@ -34,6 +34,8 @@ from multiprocessing import shared_memory
 
 import numpy as np
 
+from .core import TAPE_HDR, TAPE_STRIDE
+
 OP_RESET, OP_STEP, OP_QUERY, OP_GET_STATE, OP_SET_STATE, OP_QUERY_AMP, OP_AMP_EXPERT, OP_DETACH, OP_ATTACH = 1, 2, 3, 4, 5, 6, 7, 8, 9
 MAGIC = 0x444D4252          # "DMBR"
 _libc = C.CDLL(None, use_errno=True)
@@ -129,6 +131,7 @@ class Region:
         self.off_manif = self.off_pert + (16 if FB & 4 else 0); self.big_w = self.off_manif + (J * 25 if FB & 8 else 0)
         add("big", np.float64, (W, self.big_w))
         add("goal", np.float32, (W, max(G, 1)))               # RecordGoal of the last step / query
+        add("tape", np.float64, (W, TAPE_STRIDE))             # the worker's draw tape (DM_RNG=reference: include/dm_hip.h DM_TAPE_*); the owner writes the header back after the launch
         add("meta", np.float64, (4 * S + 4 * A + 8 + max(AMP, 1) * 3 + 2 * max(NC, 1),))      # offsets / scales / bounds / norm groups, duration, ..., clip durations | cdf
         return off
 
@@ -170,6 +173,7 @@ def serve(name: str, max_workers: int, device: int, precision: int, lib_path: st
     b2 = 4 * S + 4 * A + 8 + max(env.amp_size, 1) * 3
     m[b2:b2 + NC] = cd; m[b2 + NC:b2 + 2 * NC] = cc
     cur_cfg = [None]
+    tape_bound = [False]
 
     def configure(mode, lo, hi, ex):
         """mode and episode-limit parameters are per-CONTEXT settings on the device: the requests of a round are served in groups that agree on them"""
@@ -290,9 +294,21 @@ def serve(name: str, max_workers: int, device: int, precision: int, lib_path: st
                 """groups of `ids` that agree on (mode, lo, hi, ex) and on the extra key columns"""
                 if ids.size == 0:
                     return []
-                km = np.column_stack([R.iargs[ids, 5].astype(np.float64), R.dargs[ids, 2], R.dargs[ids, 3], R.dargs[ids, 4]] + [c for c in extra_cols])
+                km = np.column_stack([R.iargs[ids, 5].astype(np.float64), R.dargs[ids, 2], R.dargs[ids, 3], R.dargs[ids, 4]] + [c for c in extra_cols] + [R.iargs[ids, 6].astype(np.float64)])
                 uniq, inv = np.unique(km, axis=0, return_inverse=True)
                 return [(uniq[g], ids[np.ravel(inv) == g]) for g in range(uniq.shape[0])]
+
+            def bind_tape(ids, on):
+                """DM_RNG=reference workers hand a draw tape with the request (last key column of by_config): their rows go up before the launch, the headers come back
+                after it; a group without tapes runs with none bound"""
+                if on:
+                    env.set_draw_tape_envs(ids.astype(np.int32), R.tape[ids]); tape_bound[0] = True
+                elif tape_bound[0]:
+                    env.set_draw_tape(None); tape_bound[0] = False
+
+            def commit_tape(ids, on):
+                if on:
+                    R.tape[ids, :TAPE_HDR] = env.draw_tape_state_envs(ids.astype(np.int32))
 
             # every kind of request of the round is served by ONE call per group for all the slots that made it (a slot has one request pending at a time)
             at = pend[ops == OP_ATTACH]
@@ -300,6 +316,7 @@ def serve(name: str, max_workers: int, device: int, precision: int, lib_path: st
             def attach(ids):
                 # a slot becomes what env 0 of a fresh one-env context with the worker's seed is: own draw key, counters at 0, then dm_create's own first reset
                 env.set_env_keys(ids.astype(np.int32), R.dargs[ids, 0].astype(np.uint64))
+                bind_tape(ids, False)
                 for key, grp in by_config(ids):
                     configure(*key[:4])
                     env.reset(env_ids=grp.astype(np.int32))
@@ -308,10 +325,12 @@ def serve(name: str, max_workers: int, device: int, precision: int, lib_path: st
             for key, grp in by_config(rs, (R.iargs[rs, 0].astype(np.float64),)):
                 def reset_group(ids, key=key):
                     configure(*key[:4])
+                    bind_tape(ids, int(key[-1]))
                     if int(key[4]):                            # explicit clip time / episode limit (the facade drew them on the host, e.g. in the reference's order)
                         env.reset(env_ids=ids.astype(np.int32), kin_times=R.dargs[ids, 0], max_times=R.dargs[ids, 1])
-                    else:                                      # the device draws clip, clip time, yaw and limit under the slot's own key
+                    else:                                      # the device draws clip, clip time, yaw and limit under the slot's own key (or off the slot's tape)
                         env.reset(env_ids=ids.astype(np.int32))
+                    commit_tape(ids, int(key[-1]))
                 guarded(grp, reset_group)
             stp = pend[ops == OP_STEP]
             snap = stp[R.iargs[stp, 4] != 0] if stp.size else stp            # control steps that may be rolled back: the state they start from
@@ -327,8 +346,8 @@ def serve(name: str, max_workers: int, device: int, precision: int, lib_path: st
                     env.set_state(pose=s_["pose"], vel=s_["vel"], tar=s_["tar"], kin=s_["kin"], clocks=s_["clocks"], flags=s_["flags"])
                     if FB & 1:
                         og = R.off_goal
-                        s_["goal"][ss] = v[:, og:og + 12]; s_["aux"][ss] = v[:, og + 12:og + 20]
-                        env.set_goal_state(s_["goal"]); env.set_goal_aux(s_["aux"])
+                        s_["goal"][ss] = v[:, og:og + 12]; s_["aux"][ss] = v[:, og + 12:og + 20]; s_["clip"][ss] = v[:, og + 20:og + 21]
+                        env.set_goal_state(s_["goal"]); env.set_goal_aux(s_["aux"]); env.set_clips(s_["clip"][:, 0].astype(np.int32))
                     if FB & 2:
                         s_["obj"][ss] = v[:, R.off_obj:R.off_obj + 13]; env.set_obj_state(s_["obj"])
                     if FB & 4:
@@ -344,7 +363,9 @@ def serve(name: str, max_workers: int, device: int, precision: int, lib_path: st
                     configure(*key[:4])
                     dt, n_upd, has_act, end_early, want_amp = float(key[4]), int(key[5]), int(key[6]), int(key[7]), int(key[8])
                     t_c0 = time.perf_counter()
+                    bind_tape(ids, int(key[-1]))
                     out = env.step_envs(ids.astype(np.int32), R.action[ids, :A] if has_act else None, dt, n_upd, end_early=bool(end_early), amp=bool(want_amp))
+                    commit_tape(ids, int(key[-1]))
                     stats["t_call"] += time.perf_counter() - t_c0
                     R.state[ids] = out["state"]; R.reward[ids] = out["reward"]
                     R.flags[ids, 0] = out["terminate"]; R.flags[ids, 1] = out["valid"]; R.flags[ids, 2] = out["episode_end"]
@@ -444,6 +465,7 @@ class SharedEnv:
         self.precision = precision
         self._timer = (c.timer_type, float(c.time_lim_min), float(c.time_lim_max), float(c.time_lim_exp))
         self._mode = 0
+        self._tape_on = False
         self._gen_addr, self._wake_addr = R.addr("wake", 1), R.addr("wake", 0)
         self._state, self._snap = None, None
         # the slot becomes env 0 of a one-env context of this worker's seed (own draw key, counters at 0, dm_create's own first reset)
@@ -456,6 +478,7 @@ class SharedEnv:
         """mode and episode-limit parameters travel with every request (per-context settings on the device: the owner groups by them)"""
         ty, lo, hi, ex = self._timer
         self.R.iargs[self.slot, 5] = self._mode
+        self.R.iargs[self.slot, 6] = 1 if self._tape_on else 0
         self.R.dargs[self.slot, 2] = lo; self.R.dargs[self.slot, 3] = hi; self.R.dargs[self.slot, 4] = ex if ty == "exp" else 0.0
 
     @staticmethod
@@ -538,6 +561,25 @@ class SharedEnv:
         self._ep += 1
         self._call(OP_RESET)
         self._state = self._unpack()                          # the owner hands the reset state back with the reply: get_state() right after costs no round trip
+
+    # ---- the draw tape of this worker's generators (DM_RNG=reference): travels with every reset / step request, the header comes back with the reply
+    def set_draw_tape(self, tape):
+        if tape is None:
+            self._tape_on = False
+            return
+        self.R.tape[self.slot] = np.asarray(tape, dtype=np.float64).reshape(-1)
+        self._tape_on = True
+
+    def draw_tape_state(self):
+        return self.R.tape[self.slot:self.slot + 1, :TAPE_HDR].copy()
+
+    def set_clips(self, clips):
+        cur = {k: a.copy() for k, a in self._full().items()}
+        cur["clip"] = np.asarray(clips, dtype=np.float64).reshape(1, 1)
+        self._put_state(cur)
+
+    def clip_table(self):
+        return self._clip_dur.copy(), self._clip_cdf.copy()
 
     def set_time_limits(self, lo, hi, ex=None):
         self._timer = (self._timer[0], float(lo), float(hi), self._timer[3] if ex is None else float(ex))

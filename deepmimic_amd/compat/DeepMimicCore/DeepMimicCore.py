@@ -144,18 +144,11 @@ class cDeepMimicCore(object):
         self._tape_key = None
         c = self._tables.cfg
         goal_row = bool(self._tables.goal_kind != 0 or self._tables.num_clips > 1 or c.enable_rand_rot_reset)      # (core.BatchEnv._has_goal_row)
-        private = isinstance(self._env, _BatchEnv)
-        if self._ref_rng and private:
+        if self._ref_rng:
+            # the draws the device makes come off the draw tape of this worker's generators, on a context of its own and on a slot of the shared owner alike
             self._tape = goal_row or bool(c.enable_rand_perturbs)
             self._ref_init_draws()
-        elif self._ref_rng and self._tables.num_clips == 1:
-            self._ref_init_draws()             # shared owner: reset clip time and episode limit from the reference's generator, device-side draws counter-based
         else:
-            if self._ref_rng:
-                import warnings
-                warnings.warn("DM_RNG=reference on the shared-owner route serves single-clip scenes; this multi-clip dataset draws clip, clip time and episode limit "
-                              "from the counter-based streams of the worker's seed (a context per worker, DM_FACADE_SHARED=0, draws them in the reference's order)",
-                              RuntimeWarning, stacklevel=2)
             self._after_reset()
 
     # ---- the reference's draw order on cMathUtil::gRand (DM_RNG=reference) ------------------------------------------------------------

@@ -327,6 +327,18 @@ class BatchEnv:
         t = np.ascontiguousarray(tape, dtype=np.float64).reshape(self.N, TAPE_STRIDE)
         self._chk(self.lib.dm_set_draw_tape(self.h, _dp(t)))
 
+    def set_draw_tape_envs(self, env_ids, rows):
+        """include/dm_hip.h dm_set_draw_tape_envs: the tape rows of the listed envs (n x TAPE_STRIDE)"""
+        ids = np.ascontiguousarray(env_ids, dtype=np.int32).ravel()
+        r = np.ascontiguousarray(rows, dtype=np.float64).reshape(ids.size, TAPE_STRIDE)
+        self._chk(self.lib.dm_set_draw_tape_envs(self.h, _ip(ids), int(ids.size), _dp(r)))
+
+    def draw_tape_state_envs(self, env_ids):
+        ids = np.ascontiguousarray(env_ids, dtype=np.int32).ravel()
+        out = np.zeros((ids.size, TAPE_HDR))
+        self._chk(self.lib.dm_get_draw_tape_state_envs(self.h, _ip(ids), int(ids.size), _dp(out)))
+        return out
+
     def draw_tape_state(self):
         """include/dm_hip.h dm_get_draw_tape_state: the tape headers after a launch (N x TAPE_HDR: positions consumed, saved normal deviate, error flag, ...)"""
         out = np.zeros((self.N, TAPE_HDR))

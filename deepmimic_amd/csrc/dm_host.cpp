@@ -43,6 +43,8 @@ static int rt_h2d(void* d, const void* h, size_t n, rt_stream) { memcpy(d, h, n)
 static int rt_d2h(void* h, const void* d, size_t n, rt_stream) { memcpy(h, d, n); return 0; }
 static int rt_memset(void* d, int v, size_t n, rt_stream) { memset(d, v, n); return 0; }
 static int rt_sync(rt_stream) { return 0; }
+static int rt_h2d_async(void* d, const void* h, size_t n, rt_stream) { memcpy(d, h, n); return 0; }
+static int rt_d2h_async(void* h, const void* d, size_t n, rt_stream) { memcpy(h, d, n); return 0; }
 #else
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
 // zero-fill synchronously: a null-stream hipMemset is not ordered against the ctx's non-blocking stream
@@ -52,6 +54,8 @@ static int rt_h2d(void* d, const void* h, size_t n, rt_stream s) { if (hipMemcpy
 static int rt_d2h(void* h, const void* d, size_t n, rt_stream s) { if (hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, s) != hipSuccess) return -1; return hipStreamSynchronize(s) == hipSuccess ? 0 : -1; }
 static int rt_memset(void* d, int v, size_t n, rt_stream s) { return hipMemsetAsync(d, v, n, s) == hipSuccess ? 0 : -1; }
 static int rt_sync(rt_stream s) { return hipStreamSynchronize(s) == hipSuccess ? 0 : -1; }
+static int rt_h2d_async(void* d, const void* h, size_t n, rt_stream s) { return hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, s) == hipSuccess ? 0 : -1; }
+static int rt_d2h_async(void* h, const void* d, size_t n, rt_stream s) { return hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, s) == hipSuccess ? 0 : -1; }
 #endif
 
 // Every C-ABI entry point runs with the ctx's device current (and restores the caller's): a process may hold contexts on
@@ -314,6 +318,7 @@ struct CtxBase {
     virtual void set_timer_exp(double ex) = 0;
     virtual int set_env_keys(const int* ids, int n, const uint64_t* seeds) = 0;
     virtual int draw_tape(const double* in, int unbind, double* hdr_out) = 0;
+    virtual int draw_tape_envs(const int* ids, int n, const double* rows, double* hdr_out) = 0;
 };
 
 template <typename Real>
@@ -657,9 +662,27 @@ struct CtxT : CtxBase {
         }
         if (hdr_out) {
             if (!d_tape || !md.draw_tape) return fail("no draw tape is bound");
-            std::vector<double> buf((size_t)N * TP_STRIDE);
-            if (rt_d2h(buf.data(), d_tape, sizeof(double) * buf.size(), stream) != 0) return fail("device to host copy failed");
-            for (int e = 0; e < N; ++e) memcpy(hdr_out + (size_t)e * TP_HDR, &buf[(size_t)e * TP_STRIDE], sizeof(double) * TP_HDR);
+            for (int e = 0; e < N; ++e)
+                if (rt_d2h_async(hdr_out + (size_t)e * TP_HDR, d_tape + (size_t)e * TP_STRIDE, sizeof(double) * TP_HDR, stream) != 0) return fail("device to host copy failed");
+            if (rt_sync(stream) != 0) return fail("stream synchronize failed");
+        }
+        return 0;
+    }
+    // dm_set_draw_tape_envs / dm_get_draw_tape_state_envs: the rows of the listed envs only (the shared-owner route: W workers, each with generators of its own)
+    int draw_tape_envs(const int* ids, int n, const double* rows, double* hdr_out) override {
+        for (int i = 0; i < n; ++i) if (ids[i] < 0 || ids[i] >= N) return fail("env id out of range");
+        if (rows) {
+            if (!d_tape) { d_tape = (double*)dalloc(sizeof(double) * (size_t)N * TP_STRIDE); if (!d_tape) return fail("device allocation failed"); }
+            for (int i = 0; i < n; ++i)
+                if (rt_h2d_async(d_tape + (size_t)ids[i] * TP_STRIDE, rows + (size_t)i * TP_STRIDE, sizeof(double) * TP_STRIDE, stream) != 0) return fail("host to device copy failed");
+            if (rt_sync(stream) != 0) return fail("stream synchronize failed");
+            md.draw_tape = d_tape;
+        }
+        if (hdr_out) {
+            if (!d_tape || !md.draw_tape) return fail("no draw tape is bound");
+            for (int i = 0; i < n; ++i)
+                if (rt_d2h_async(hdr_out + (size_t)i * TP_HDR, d_tape + (size_t)ids[i] * TP_STRIDE, sizeof(double) * TP_HDR, stream) != 0) return fail("device to host copy failed");
+            if (rt_sync(stream) != 0) return fail("stream synchronize failed");
         }
         return 0;
     }
@@ -1122,6 +1145,16 @@ int dm_get_manifolds(dm_ctx* ctx, double* out) { if (!ctx || !out) return fail("
 int dm_set_manifolds(dm_ctx* ctx, const double* in) { if (!ctx || !in) return fail("null argument"); DevGuard guard(ctx->c->device_id); return ctx->c->manifolds(nullptr, in); }
 int dm_set_mode(dm_ctx* ctx, int test_mode) { if (!ctx) return fail("null ctx"); ctx->c->set_mode(test_mode); return 0; }
 int dm_set_draw_tape(dm_ctx* ctx, const double* tape) { if (!ctx) return fail("null ctx"); DevGuard guard(ctx->c->device_id); return ctx->c->draw_tape(tape, tape == nullptr, nullptr); }
+int dm_set_draw_tape_envs(dm_ctx* ctx, const int32_t* env_ids, int n, const double* rows) {
+    if (!ctx || !env_ids || !rows) return fail("null argument");
+    if (n <= 0) return 0;
+    DevGuard guard(ctx->c->device_id); return ctx->c->draw_tape_envs(env_ids, n, rows, nullptr);
+}
+int dm_get_draw_tape_state_envs(dm_ctx* ctx, const int32_t* env_ids, int n, double* out) {
+    if (!ctx || !env_ids || !out) return fail("null argument");
+    if (n <= 0) return 0;
+    DevGuard guard(ctx->c->device_id); return ctx->c->draw_tape_envs(env_ids, n, nullptr, out);
+}
 int dm_get_draw_tape_state(dm_ctx* ctx, double* out) { if (!ctx || !out) return fail("null argument"); DevGuard guard(ctx->c->device_id); return ctx->c->draw_tape(nullptr, 0, out); }
 int dm_clip_table(const dm_ctx* ctx, double* durations, double* cdf) {
     if (!ctx) return fail("null ctx");

@@ -336,6 +336,10 @@ int dm_refrand_engine_state(dm_refrand* r, int set, unsigned long* state);      
 int dm_refrand_tape(const dm_refrand* r, int K, double* u, double* e, double* n3, double* i2);   /* any table may be null; the generator is not advanced */
 int dm_set_draw_tape(dm_ctx* ctx, const double* tape /* N x DM_TAPE_STRIDE; NULL: unbind, back to the counter-based streams */);
 int dm_get_draw_tape_state(dm_ctx* ctx, double* out /* N x DM_TAPE_HDR */);
+/* the rows of the listed envs only (n x DM_TAPE_STRIDE in, n x DM_TAPE_HDR out): one context serving several one-env callers, each with generators of its own
+ * (the shared-owner route, deepmimic_amd/broker.py); every env a launch steps or resets must hold a current row while a tape is bound */
+int dm_set_draw_tape_envs(dm_ctx* ctx, const int32_t* env_ids, int n, const double* rows);
+int dm_get_draw_tape_state_envs(dm_ctx* ctx, const int32_t* env_ids, int n, double* out);
 
 /* ---- Native scene loading: cDeepMimicCore::ParseArgs (DeepMimicCore.cpp:25-44) + the ParseArgs / file loading of the scene classes the path serves,
  * in C++ inside the library (deepmimic_amd/csrc/dm_scene_load.h), so that a native host goes from the reference's own arg file to a running context

@@ -96,9 +96,9 @@ def _run(lib, shared, W, scene, n_updates, rng_mode, shm, physics=1):
 # one asset of every scene kind the context serves: single-clip imitate (host draws in the reference's order) and imitate_amp, the four kinds of goal
 # scene + the dribble ball, a four-clip dataset, random perturbations, DM-physics v2
 CASES = [("imitate", "reference", 1), ("imitate_amp", "counter", 1), ("amp_heading_zombie", "counter", 1), ("amp_target_zombie", "counter", 1), ("amp_heading_getup", "counter", 1),
-         ("amp_strike_punch", "counter", 1), ("amp_dribble_zombie", "counter", 1), ("amp_heading_clips4", "counter", 1), ("perturbs", "counter", 1), ("imitate", "counter", 2)]
-# (DM_RNG=reference and a scene with device-side draws: a private context serves them from the reference's generators through the draw tape, tests/test_ref_draw_order.py; the
-# shared owner keeps them on the counter-based streams of the worker's seed -- the two routes are equal in "counter" mode and for scenes whose draws are all on the host)
+         ("amp_strike_punch", "counter", 1), ("amp_dribble_zombie", "reference", 1), ("amp_heading_clips4", "reference", 1), ("perturbs", "reference", 1), ("imitate", "counter", 2)]
+# ("reference": the worker's generators in the reference's order -- the draws the device makes come off the worker's draw tape, which travels with its requests;
+#  "counter": the counter-based streams of the worker's seed)
 
 
 @pytest.mark.parametrize("scene,rng_mode,physics", CASES, ids=["%s-%s-v%d" % c for c in CASES])

@@ -46,6 +46,10 @@ from deepmimic_amd.core import RefRand as _RefRand  # noqa: E402
 _DT_EPS = 0.0
 
 
+class _TapeExhausted(RuntimeError):
+    pass
+
+
 class cDeepMimicCore(object):
     # cRLScene::eMode (scenes/RLScene.h:11-16)
     eModeTrain, eModeTest = 0, 1
@@ -265,7 +269,8 @@ class cDeepMimicCore(object):
             return
         h = self._env.draw_tape_state()[0]
         if h[4] != 0.0:
-            raise RuntimeError("cDeepMimicCore: a launch consumed more random draws than the draw tape holds (DM_TAPE_K raw values per generator)")
+            self._tape_key = None
+            raise _TapeExhausted("cDeepMimicCore: a launch consumed more random draws than the draw tape holds (DM_TAPE_K raw values per generator)")
         if h[0] != 0.0 or h[1] != 0.0 or (int(h[2]), float(h[3])) != self._tape_key[1][1:]:
             self._grand.discard(int(h[0])); self._srand.discard(int(h[1])); self._srand.set_norm_state(int(h[2]), float(h[3]))
             self._tape_key = None
@@ -446,7 +451,17 @@ class cDeepMimicCore(object):
             snap = env.snapshot()
             clk0 = dict(self._clk)
             rng0 = (self._grand.state(), self._srand.state()) if self._tape else None
-            out = self._launch(action, dt, k, True)
+            try:
+                out = self._launch(action, dt, k, True)
+            except _TapeExhausted:
+                # more draws inside one control step than a tape holds (very short target / perturbation timers): back to the state before the launch and
+                # through this control step one update at a time -- a tape serves any single update
+                env.restore(snap)
+                self._grand.set_state(rng0[0]); self._srand.set_state(rng0[1]); self._tape_key = None
+                self.stats["tape_fallbacks"] = self.stats.get("tape_fallbacks", 0) + 1
+                self._cache = self._launch(action, dt, 1, False)
+                self._advance_clocks(dt)
+                return
             t1 = float(out["clocks"][0][3]) if "clocks" in out else float(env.get_state()["clocks"][0][3])      # (the shared route returns the clocks with the step: one round trip)
             n_done = min(k, int(round((t1 - clk0["timer"]) / dt)))
             if n_done <= 0:

@@ -412,3 +412,43 @@ def test_strike_amp_test_mode(emu_lib, monkeypatch):
     args = ["--arg_file", "args/train_amp_strike_humanoid3d_walk_punch_args.txt", "--motion_file", ds, "--init_hit_prob", "0.3", "--time_lim_min", "0.2", "--time_lim_max", "0.6",
             "--time_end_lim_min", "0.3", "--time_end_lim_max", "0.7"]
     _run(mod, emu_lib, args, 4711, monkeypatch, n_resets=8, steps=25, test_mode=True)
+
+
+def test_perturbations_only(emu_lib, monkeypatch):
+    """a scene whose only device-side draws are the perturbations (no goal row on the device): clip time and episode limit are drawn on the host in the
+    reference's order, the perturbation clock and forces come off the tape"""
+    mod = _core_module()
+    args = ["--arg_file", "args/train_amp_humanoid3d_run_args.txt", "--enable_rand_perturbs", "true", "--perturb_time_min", "0.05", "--perturb_time_max", "0.2",
+            "--min_pertrub_duration", "0.02", "--max_perturb_duration", "0.08", "--enable_rand_rot_reset", "false", "--time_lim_min", "0.3", "--time_lim_max", "0.9",
+            "--time_end_lim_min", "0.3", "--time_end_lim_max", "0.9", "--perturb_part_ids", "1", "2", "6", "9"]
+    core, _ = _facade(mod, emu_lib, args, 808, monkeypatch)
+    assert not core._env._has_goal_row
+    n = _run(mod, emu_lib, args, 808, monkeypatch, n_resets=8, steps=12)["perturbations"]
+    assert n >= 8
+
+
+def test_more_draws_in_a_control_step_than_a_tape_holds(emu_lib, monkeypatch):
+    """ball and target re-sampled at every update: 14 raw values of the scene generator per update, 280 per control step -- a batched control step runs past the
+    tape (96 per launch); the facade then takes that control step update by update: same draws as the update-by-update route (which the compiled reference
+    confirms, test_dribble_amp)"""
+    mod = _core_module()
+    args = ["--arg_file", "args/train_amp_dribble_humanoid3d_zombie_args.txt", "--rand_target_time_min", "0.001", "--rand_target_time_max", "0.0015",
+            "--rand_tar_obj_time_min", "0.001", "--rand_tar_obj_time_max", "0.0015"]
+    logs = []
+    for batch in ("0", "1"):
+        core, t = _facade(mod, emu_lib, args, 17, monkeypatch)
+        monkeypatch.setenv("DM_FACADE_BATCH", batch)
+        core = mod.cDeepMimicCore(False); core.SeedRand(17); core.LoadTables(t, 10); core.Init()
+        log = []
+        for ep in range(2):
+            core.Reset()
+            for k in range(4 * 20):
+                if core.NeedNewAction(0):
+                    log.append((core.RecordGoal(0), core._env.get_goal_state()[0].copy(), core._env.get_obj_state()[0].copy())); core.SetAction(0, np.zeros(core._env.A))
+                core.Update(1.0 / 600)
+        logs.append(log)
+        assert (core.stats.get("tape_fallbacks", 0) > 0) == (batch == "1")
+    assert len(logs[0]) == len(logs[1]) >= 8
+    for a, b in zip(*logs):
+        for x, y in zip(a, b):
+            assert np.array_equal(np.asarray(x), np.asarray(y))

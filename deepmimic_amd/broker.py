@@ -294,7 +294,7 @@ def serve(name: str, max_workers: int, device: int, precision: int, lib_path: st
                 """groups of `ids` that agree on (mode, lo, hi, ex) and on the extra key columns"""
                 if ids.size == 0:
                     return []
-                km = np.column_stack([R.iargs[ids, 5].astype(np.float64), R.dargs[ids, 2], R.dargs[ids, 3], R.dargs[ids, 4]] + [c for c in extra_cols] + [R.iargs[ids, 6].astype(np.float64)])
+                km = np.column_stack([R.iargs[ids, 5].astype(np.float64), R.dargs[ids, 2], R.dargs[ids, 3], R.dargs[ids, 4]] + [c for c in extra_cols] + [(R.iargs[ids, 6] != 0).astype(np.float64)])
                 uniq, inv = np.unique(km, axis=0, return_inverse=True)
                 return [(uniq[g], ids[np.ravel(inv) == g]) for g in range(uniq.shape[0])]
 
@@ -302,7 +302,9 @@ def serve(name: str, max_workers: int, device: int, precision: int, lib_path: st
                 """DM_RNG=reference workers hand a draw tape with the request (last key column of by_config): their rows go up before the launch, the headers come back
                 after it; a group without tapes runs with none bound"""
                 if on:
-                    env.set_draw_tape_envs(ids.astype(np.int32), R.tape[ids]); tape_bound[0] = True
+                    new = ids[R.iargs[ids, 6] == 2]            # rows re-tabulated since the last launch (2); the others (1) are on the device already, untouched
+                    if new.size or not tape_bound[0]:
+                        env.set_draw_tape_envs(new.astype(np.int32), R.tape[new]); tape_bound[0] = True
                 elif tape_bound[0]:
                     env.set_draw_tape(None); tape_bound[0] = False
 
@@ -465,7 +467,7 @@ class SharedEnv:
         self.precision = precision
         self._timer = (c.timer_type, float(c.time_lim_min), float(c.time_lim_max), float(c.time_lim_exp))
         self._mode = 0
-        self._tape_on = False
+        self._tape_on = self._tape_new = False
         self._gen_addr, self._wake_addr = R.addr("wake", 1), R.addr("wake", 0)
         self._state, self._snap = None, None
         # the slot becomes env 0 of a one-env context of this worker's seed (own draw key, counters at 0, dm_create's own first reset)
@@ -474,11 +476,14 @@ class SharedEnv:
         self._call(OP_ATTACH)
         self._state = self._unpack()
 
-    def _put_config(self):
-        """mode and episode-limit parameters travel with every request (per-context settings on the device: the owner groups by them)"""
+    def _put_config(self, launch=False):
+        """mode and episode-limit parameters travel with every request (per-context settings on the device: the owner groups by them).  launch: a reset or a step -- the
+        requests the owner binds this worker's draw tape for (rows tabulated since the last such request go up with it)"""
         ty, lo, hi, ex = self._timer
         self.R.iargs[self.slot, 5] = self._mode
-        self.R.iargs[self.slot, 6] = 1 if self._tape_on else 0
+        self.R.iargs[self.slot, 6] = (2 if self._tape_new else 1) if self._tape_on else 0
+        if launch:
+            self._tape_new = False
         self.R.dargs[self.slot, 2] = lo; self.R.dargs[self.slot, 3] = hi; self.R.dargs[self.slot, 4] = ex if ty == "exp" else 0.0
 
     @staticmethod
@@ -542,7 +547,7 @@ class SharedEnv:
     def reset(self, env_ids=None, kin_times=None, max_times=None):
         from . import model, streams
         R, i = self.R, self.slot
-        self._put_config()
+        self._put_config(launch=True)
         if kin_times is None and self._has_goal_row:
             # goal scenes / multi-clip datasets / random yaw: the DEVICE draws clip, clip time, yaw and episode limit, under this slot's own key and episode counter
             # -- exactly the draws of a one-env context of its own
@@ -568,7 +573,7 @@ class SharedEnv:
             self._tape_on = False
             return
         self.R.tape[self.slot] = np.asarray(tape, dtype=np.float64).reshape(-1)
-        self._tape_on = True
+        self._tape_on = self._tape_new = True
 
     def draw_tape_state(self):
         return self.R.tape[self.slot:self.slot + 1, :TAPE_HDR].copy()
@@ -603,7 +608,7 @@ class SharedEnv:
         R, i = self.R, self.slot
         if actions is not None:
             R.action[i, :self.A] = np.asarray(actions, dtype=np.float32).reshape(self.A)
-        self._put_config()
+        self._put_config(launch=True)
         R.dargs[i, 0] = float(timestep)
         snap, self._snap = self._snap, None
         R.iargs[i, :5] = (int(n_updates), 0 if actions is None else 1, int(bool(end_early)), int(bool(amp)), 0 if snap is None else 1)

@@ -330,6 +330,8 @@ class BatchEnv:
     def set_draw_tape_envs(self, env_ids, rows):
         """include/dm_hip.h dm_set_draw_tape_envs: the tape rows of the listed envs (n x TAPE_STRIDE)"""
         ids = np.ascontiguousarray(env_ids, dtype=np.int32).ravel()
+        if ids.size == 0:                   # bind the rows the device already holds
+            self._chk(self.lib.dm_set_draw_tape_envs(self.h, None, 0, None)); return
         r = np.ascontiguousarray(rows, dtype=np.float64).reshape(ids.size, TAPE_STRIDE)
         self._chk(self.lib.dm_set_draw_tape_envs(self.h, _ip(ids), int(ids.size), _dp(r)))
 

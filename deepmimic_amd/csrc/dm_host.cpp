@@ -45,6 +45,10 @@ static int rt_memset(void* d, int v, size_t n, rt_stream) { memset(d, v, n); ret
 static int rt_sync(rt_stream) { return 0; }
 static int rt_h2d_async(void* d, const void* h, size_t n, rt_stream) { memcpy(d, h, n); return 0; }
 static int rt_d2h_async(void* h, const void* d, size_t n, rt_stream) { memcpy(h, d, n); return 0; }
+static int rt_d2h_rows(void* h, size_t hpitch, const void* d, size_t dpitch, size_t width, size_t rows, rt_stream) {
+    for (size_t r = 0; r < rows; ++r) memcpy((char*)h + r * hpitch, (const char*)d + r * dpitch, width);
+    return 0;
+}
 #else
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
 // zero-fill synchronously: a null-stream hipMemset is not ordered against the ctx's non-blocking stream
@@ -56,6 +60,10 @@ static int rt_memset(void* d, int v, size_t n, rt_stream s) { return hipMemsetAs
 static int rt_sync(rt_stream s) { return hipStreamSynchronize(s) == hipSuccess ? 0 : -1; }
 static int rt_h2d_async(void* d, const void* h, size_t n, rt_stream s) { return hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, s) == hipSuccess ? 0 : -1; }
 static int rt_d2h_async(void* h, const void* d, size_t n, rt_stream s) { return hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, s) == hipSuccess ? 0 : -1; }
+static int rt_d2h_rows(void* h, size_t hpitch, const void* d, size_t dpitch, size_t width, size_t rows, rt_stream s) {      // `rows` strided pieces in one copy
+    if (hipMemcpy2DAsync(h, hpitch, d, dpitch, width, rows, hipMemcpyDeviceToHost, s) != hipSuccess) return -1;
+    return hipStreamSynchronize(s) == hipSuccess ? 0 : -1;
+}
 #endif
 
 // Every C-ABI entry point runs with the ctx's device current (and restores the caller's): a process may hold contexts on
@@ -678,11 +686,21 @@ struct CtxT : CtxBase {
             if (rt_sync(stream) != 0) return fail("stream synchronize failed");
             md.draw_tape = d_tape;
         }
+        else if (!hdr_out) {                   // n rows with rows == null: bind what the device already holds (rows nobody has drawn from since they went up)
+            if (!d_tape) return fail("dm_set_draw_tape_envs: no tape rows on the device yet");
+            md.draw_tape = d_tape;
+        }
         if (hdr_out) {
             if (!d_tape || !md.draw_tape) return fail("no draw tape is bound");
-            for (int i = 0; i < n; ++i)
-                if (rt_d2h_async(hdr_out + (size_t)i * TP_HDR, d_tape + (size_t)ids[i] * TP_STRIDE, sizeof(double) * TP_HDR, stream) != 0) return fail("device to host copy failed");
-            if (rt_sync(stream) != 0) return fail("stream synchronize failed");
+            if (n > 4) {                          // one strided copy of every header instead of n small ones
+                std::vector<double> all((size_t)N * TP_HDR);
+                if (rt_d2h_rows(all.data(), sizeof(double) * TP_HDR, d_tape, sizeof(double) * TP_STRIDE, sizeof(double) * TP_HDR, (size_t)N, stream) != 0) return fail("device to host copy failed");
+                for (int i = 0; i < n; ++i) memcpy(hdr_out + (size_t)i * TP_HDR, &all[(size_t)ids[i] * TP_HDR], sizeof(double) * TP_HDR);
+            } else {
+                for (int i = 0; i < n; ++i)
+                    if (rt_d2h_async(hdr_out + (size_t)i * TP_HDR, d_tape + (size_t)ids[i] * TP_STRIDE, sizeof(double) * TP_HDR, stream) != 0) return fail("device to host copy failed");
+                if (rt_sync(stream) != 0) return fail("stream synchronize failed");
+            }
         }
         return 0;
     }
@@ -1146,9 +1164,9 @@ int dm_set_manifolds(dm_ctx* ctx, const double* in) { if (!ctx || !in) return fa
 int dm_set_mode(dm_ctx* ctx, int test_mode) { if (!ctx) return fail("null ctx"); ctx->c->set_mode(test_mode); return 0; }
 int dm_set_draw_tape(dm_ctx* ctx, const double* tape) { if (!ctx) return fail("null ctx"); DevGuard guard(ctx->c->device_id); return ctx->c->draw_tape(tape, tape == nullptr, nullptr); }
 int dm_set_draw_tape_envs(dm_ctx* ctx, const int32_t* env_ids, int n, const double* rows) {
-    if (!ctx || !env_ids || !rows) return fail("null argument");
-    if (n <= 0) return 0;
-    DevGuard guard(ctx->c->device_id); return ctx->c->draw_tape_envs(env_ids, n, rows, nullptr);
+    if (!ctx) return fail("null ctx");
+    if (n > 0 && (!env_ids || !rows)) return fail("null argument");
+    DevGuard guard(ctx->c->device_id); return ctx->c->draw_tape_envs(env_ids, n > 0 ? n : 0, n > 0 ? rows : nullptr, nullptr);
 }
 int dm_get_draw_tape_state_envs(dm_ctx* ctx, const int32_t* env_ids, int n, double* out) {
     if (!ctx || !env_ids || !out) return fail("null argument");

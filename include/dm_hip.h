@@ -337,7 +337,8 @@ int dm_refrand_tape(const dm_refrand* r, int K, double* u, double* e, double* n3
 int dm_set_draw_tape(dm_ctx* ctx, const double* tape /* N x DM_TAPE_STRIDE; NULL: unbind, back to the counter-based streams */);
 int dm_get_draw_tape_state(dm_ctx* ctx, double* out /* N x DM_TAPE_HDR */);
 /* the rows of the listed envs only (n x DM_TAPE_STRIDE in, n x DM_TAPE_HDR out): one context serving several one-env callers, each with generators of its own
- * (the shared-owner route, deepmimic_amd/broker.py); every env a launch steps or resets must hold a current row while a tape is bound */
+ * (the shared-owner route, deepmimic_amd/broker.py); every env a launch steps or resets must hold a current row while a tape is bound.  n = 0: bind the
+ * rows the device already holds (nothing was drawn from them since they went up). */
 int dm_set_draw_tape_envs(dm_ctx* ctx, const int32_t* env_ids, int n, const double* rows);
 int dm_get_draw_tape_state_envs(dm_ctx* ctx, const int32_t* env_ids, int n, double* out);
 

@@ -439,6 +439,7 @@ struct EnvSim {
     typedef typename VecT<Real>::v2 R2; typedef typename VecT<Real>::v4 R4;
     const ModelDev<Real>& m; L& s; int l;
     int li = 0;                                         // link_info word of this lane's link (0 for lanes >= J)
+    int clip = 0;                                       // multi-clip dataset: the clip this env's kinematic character is on (goal row GS_CLIP; AMP / tap instantiations)
     int cand_link[CPL]; Real cand_loc[CPL][3], cand_rad[CPL];   // this lane's ground-contact candidates
     static constexpr int PPL = C::NPAIRCAP / kWave;             // self-collision pairs per lane
     int pair_code[PPL];
@@ -1735,16 +1736,31 @@ struct EnvSim {
     }
     // cSceneImitate::UpdateKinChar: advance the clip clock; on phase wrap SyncKinCharNewCycle (SceneImitate.cpp:420-444)
     // turns the kin character to the sim heading (sync_char_root_rot) and snaps its root x, z to the sim root (sync_char_root_pos)
+    // CLIPS (the AMP / tap instantiations): with a multi-clip dataset the kinematic character runs on the env's own clip (cClipsController's active motion) --
+    // its duration and loop mode decide where a cycle ends, its frames where the root is at that moment.  (Round 5: until then every env's kinematic clock wrapped
+    // on clip 0's period; found by holding the kinematic pose against the compiled cKinCharacter after every update, tests/test_ref_draw_order.py.)
+    template <bool CLIPS = false>
     DM_DEV void kin_update(double dt) {
         DM_OPAQUE_V(l);
         double t0 = s.clk[CLK_KIN], t1 = t0 + dt;
-        double ph0 = kin_phase(t0), ph1 = kin_phase(t1);
+        const bool multi = CLIPS && m.num_clips > 1;
+        double ph0, ph1;
+        if (multi) {
+            const double dur = m.clip_dur[clip]; const bool loop = m.clip_loop[clip] != 0;
+            ph0 = t0 / dur; ph1 = t1 / dur;
+            if (loop) { ph0 -= floor(ph0); ph1 -= floor(ph1); } else { ph0 = ph0 < 0 ? 0 : (ph0 > 1 ? 1 : ph0); ph1 = ph1 < 0 ? 0 : (ph1 > 1 ? 1 : ph1); }
+        } else { ph0 = kin_phase(t0); ph1 = kin_phase(t1); }
         sync();
         if (l == 0) s.clk[CLK_KIN] = t1;
         if (ph1 < ph0 && (m.sync_root_pos || m.sync_root_rot)) {
-            v3 kr = kin_root_pos(t1);
+            v3 kr; q4 krot = mkq((Real)1, (Real)0, (Real)0, (Real)0);
+            if (multi) {
+                const ModelDev<Real> mc = model_of_clip(clip);
+                EnvSim<Real, C, TAPS, LW> cs(mc, s, l);
+                kr = cs.kin_root_pos(t1); if (m.sync_root_rot) krot = cs.kin_root_rot(t1);
+            } else { kr = kin_root_pos(t1); if (m.sync_root_rot) krot = kin_root_rot(t1); }
             Real dh = 0;
-            if (m.sync_root_rot) dh = calc_heading(ldq(s.pose + 3)) - calc_heading(kin_root_rot(t1));
+            if (m.sync_root_rot) dh = calc_heading(ldq(s.pose + 3)) - calc_heading(krot);
             if (l == 0) {
                 if (m.sync_root_rot) kin_rotate_origin(dh, kr);          // rotation about the root: kr itself does not move
                 if (m.sync_root_pos) {
@@ -1851,7 +1867,7 @@ struct EnvSim {
     DM_DEV void update(double dt, DebugTaps<Real> dbg, int e, Real* aovf, double* pert = nullptr, Real* manif = nullptr, bool kin_done = false) {
         if (l == 0) { s.clk[CLK_TIMER] += dt; s.clk[CLK_CTRL] += dt; s.flg[FLG_NEED_ACTION] = 0; }
         if (PERT && pert) { if (l == 0) pert_tick(pert, e, dt); sync(); }
-        kin_update(dt);
+        kin_update<PERT>(dt);
         const Real h = (Real)(dt / m.num_sim_substeps);
         for (int ph = 0; ph <= m.num_sim_substeps; ++ph) dyn_phase<PERT, V2>(ph, (Real)dt, h, dbg, e, false, ph == 1, aovf, pert, V2 ? manif : nullptr, kin_done && ph == 0);
         if (l == 0) {                      // cCtController::CheckNeedNewAction (CtController.cpp:221-227)
@@ -2666,6 +2682,7 @@ DM_DEV void reset_goal_env(EnvSim<Real, C, TAPS, LW>& sim, const ModelDev<Real>&
     sim.manif_clear(st, e);
     if (st.hist) rs.init_hist(st, e);
     if (act && sim.l == 0) st.goal[(size_t)e * GS_WIDTH + GS_CLIP] = (double)clip;
+    sim.clip = clip;
     if (m.scene_goal) sim.goal_reset(st, e);
     if (!T && pert && act && sim.l == 0) sim.pert_reset(pert, e);
 }
@@ -2721,6 +2738,7 @@ __global__ void __launch_bounds__(64) DM_WAVES_PER_EU((StepWaves<Real, C>::value
     sim.mark(15);
     Real* aovf = st.aovf ? st.aovf + (size_t)e * (kMaxRows - C::RREG) * kWave : nullptr;
     const bool goal = HIST && st.goal && m.scene_goal;
+    if (HIST && st.goal) sim.clip = (int)st.goal[(size_t)e * GS_WIDTH + GS_CLIP];
     double* pert = (HIST && st.pert) ? st.pert + (size_t)e * PT_WIDTH : nullptr;      // enable_rand_perturbs
     Real* manif = (V2 && st.manif) ? st.manif + (size_t)e * m.J * MF_STRIDE : nullptr;   // physics 2
     if (goal) sim.goal_sync_flags(st, e);

@@ -761,7 +761,7 @@ _Pragma("unroll") \
     DM_DEV void update(double dt, int e, Real* aovf_pair, double* pert = nullptr, bool kin_done = false, Real* manif_pair = nullptr) {
         if (hl == 0) { s.clk[CLK_TIMER] += dt; s.clk[CLK_CTRL] += dt; s.flg[FLG_NEED_ACTION] = 0; }
         if (PERT && pert) { if (hl == 0 && s.flg[FLG_PARKED] == 0) b.pert_tick(pert, e, dt); sync(); }      // enable_rand_perturbs (a parked character's row rests)
-        b.kin_update(dt);
+        b.template kin_update<PERT>(dt);
         const Real h = (Real)(dt / m.num_sim_substeps), rdt = (Real)dt;
         const int D = m.D;
         for (int ph = 0; ph <= m.num_sim_substeps; ++ph) {
@@ -847,6 +847,7 @@ __global__ void __launch_bounds__(64) DM_WAVES_PER_EU((DuoWaves<Real>::value)) k
     Real* aovf_pair = st.aovf ? st.aovf + (size_t)(2 * blockIdx.x) * (kMaxRows - ClsBiped::RREG) * kWave : nullptr;
     Real* manif_pair = (V2 && st.manif) ? st.manif + (size_t)(2 * blockIdx.x) * m.J * MF_STRIDE : nullptr;      // physics 2: the two characters' ground manifolds
     const bool goal = HIST && st.goal && m.scene_goal;
+    if (HIST && st.goal) sim.b.clip = (int)st.goal[(size_t)e * GS_WIDTH + GS_CLIP];
     double* pert = (HIST && st.pert) ? st.pert + (size_t)e * PT_WIDTH : nullptr;
     if (goal) sim.b.goal_sync_flags(st, e);
     for (int u = 0; u < io.n_updates; ++u) {

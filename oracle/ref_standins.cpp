@@ -318,6 +318,7 @@ class SceneX : public SCENE {
     void d_reset_characters() { this->ResetCharacters(); }                           // virtual: cSceneImitate::ResetCharacters -> ResetKinChar, SyncCharacters
     void d_update_timers(double dt) { this->UpdateTimers(dt); }
     void d_update_kin(double dt) { this->UpdateKinChar(dt); }
+    void d_sync_kin_root() { if (this->EnableSyncChar()) this->SyncKinCharRoot(); }      // the part of cSceneImitate::ResolveCharGroundIntersect (:386-394) that is not Bullet's
     void d_init_char_pos() { this->InitCharacterPos(); }                             // rand placement on a plane: the root goes to x = z = 0 (SceneSimChar.cpp:478-531)
     void d_amp_reset() { this->InitHist(); }
     double d_timer_max() const { return this->mTimer.GetMaxTime(); }
@@ -614,7 +615,8 @@ template <class S> void draw_reset_scene(S& s) {
     s.d_base_reset_scene();
     if (s.d_perturbs()) s.d_reset_perturb();
     s.d_reset_characters();
-    s.d_init_char_pos();                              // (ResolveCharGroundIntersect lifts the character off the ground: heights only, and the parts' AABBs are Bullet's)
+    s.d_init_char_pos();                              // (ResolveCharGroundIntersect lifts the character off the ground: heights only, and the parts' AABBs are Bullet's;
+    s.d_sync_kin_root();                              //  cSceneImitate's override then moves the kinematic character's root onto the simulated one)
     s.d_amp_reset();
 }
 }  // namespace
@@ -660,6 +662,7 @@ void* ref3_open(int kind, long seed, const char** tokens, int ntok, const char* 
         cMathUtil::RandUint();                                                  // BuildGround: cGround::cGround seeds the terrain generator (sim/Ground.cpp:68); the ground here is the stand-in
         s.setup(r->ch, r->kin, 0.0);
         s.d_init_char_pos();
+        s.d_sync_kin_root();
         s.d_setup_annealer();
     });
     if (kind == 5) r->dribble->d_dribble_ball(r->ball);
@@ -701,9 +704,12 @@ void ref3_update(void* h, double dt) {
 }
 // cSceneImitateAMP::RecordAMPObsExpert (:115-138) itself: SampleExpertMotion draws the clip (gRand, clips controller), then the clip time (mRand)
 int ref3_expert(void* h, double* out) { VecX v; int n = 0; with_scene((Draw*)h, [&](auto& s) { n = s.d_expert(v); }); vout(v, out); return n; }
+// the kinematic character's pose and velocity (cKinCharacter::GetPose / GetVel): what the imitation reward and the root sync compare the simulated character with
+int ref3_kin_pose(void* h, double* pose, double* vel) { Rig* r = ((Draw*)h)->rig; vout(r->kin->GetPose(), pose); vout(r->kin->GetVel(), vel); return (int)r->kin->GetPose().size(); }
 void ref3_get(void* h, double* out) {
     Draw* d = (Draw*)h; Rig* r = d->rig;
-    for (int i = 0; i < 40; ++i) out[i] = 0;
+    for (int i = 0; i < 48; ++i) out[i] = 0;
+    { const tVector op = r->kin->GetOriginPos(); out[40] = op[0]; out[41] = op[1]; out[42] = op[2]; out[43] = r->kin->GetPhase(); out[44] = r->kin->GetCycle(); out[45] = r->kin->IsMotionOver() ? 1 : 0; }
     out[1] = r->kin->GetTime(); out[2] = d->clips_ctrl ? d->clips_ctrl->GetCurrMotionID() : 0;
     { const tVector rp = r->ch->GetRootPos(), kp = r->kin->GetRootPos(); out[35] = rp[0]; out[36] = rp[1]; out[37] = rp[2]; out[38] = kp[0]; out[39] = kp[2]; }
     const tQuaternion q = r->kin->GetOriginRot(); out[3] = q.w(); out[4] = q.x(); out[5] = q.y(); out[6] = q.z();

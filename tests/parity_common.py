@@ -485,7 +485,7 @@ def goal_rollout_compare(t, precision, lib_path, steps, n, seed, wave_packing=0,
         oracles.append(o)
     active = {e: draw(o, e, int(ep[e]) - 1)[0] for e, o in enumerate(oracles)}      # clip each env's kinematic controller is on
     w = dict(reward=0.0, state=0.0, goal=0.0, goal_state=0.0, resets=0, live=0, flags_ok=True, clips=set(), dist_fail=0, reward_errs=[], goal_errs=[],
-             aux=0.0, recoveries=0, succ=0, fail=0, aux_steps=0, desynced=0, scored=0, ball=0.0, ball_moved=0.0)
+             aux=0.0, recoveries=0, succ=0, fail=0, aux_steps=0, desynced=0, scored=0, ball=0.0, ball_moved=0.0, kin=0.0)
     dead = np.zeros(n, bool)       # fp32 only: an env whose episode ended at a different update than the oracle's is not scored from there on
     gs = env.get_goal_state(); clips = env.get_clips(); q = env.query(); qg = env.query_goal()
     for e, o in enumerate(oracles):
@@ -497,7 +497,7 @@ def goal_rollout_compare(t, precision, lib_path, steps, n, seed, wave_packing=0,
     for k in range(steps):
         acts = (action_sigma * rng.normal(size=(n, env.A))).astype(np.float32)
         out = env.step(acts, DT, 20, auto_reset=True)
-        gs = env.get_goal_state(); clips = env.get_clips()
+        gs = env.get_goal_state(); clips = env.get_clips(); kin_dev = env.get_state()["kin"]
         aux = env.get_goal_aux() if has_aux else None
         ball = env.get_obj_state() if has_ball else None
         baux = env.get_goal_aux() if has_ball else None
@@ -530,6 +530,9 @@ def goal_rollout_compare(t, precision, lib_path, steps, n, seed, wave_packing=0,
             w["goal"] = max(w["goal"], np.abs(out["goal"][e] - o.record_goal()).max())
             w["goal_errs"].append(np.abs(out["goal"][e] - o.record_goal()).max())
             w["goal_state"] = max(w["goal_state"], np.abs(gs[e] - o.goal_state()).max())
+            ko = o.kin_state()[2]               # the kinematic character's origin: follows the simulated root at every cycle boundary of the env's OWN clip
+            dk = kin_dev[e]
+            w["kin"] = max(w["kin"], float(np.abs(dk[:3] - ko[:3]).max()), 1.0 - abs(float(np.dot(dk[3:7], ko[3:7]))))
             if has_ball:
                 ob = o.ball_state()
                 w["ball"] = max(w["ball"], np.abs(ball[e] - ob[:13]).max(), np.abs(baux[e][2:7] - ob[13:18]).max())

@@ -118,7 +118,7 @@ def test_shared_workers_equal_private_contexts(emu_lib, scene, rng_mode, physics
     # the owner leaves a few seconds after its last worker and takes the region with it; the (empty) lock file is the test's to remove
     import glob
     import time
-    t_end = time.monotonic() + 15
+    t_end = time.monotonic() + 45
     while os.path.exists("/dev/shm/" + shm) and time.monotonic() < t_end:
         time.sleep(0.2)
     assert not os.path.exists("/dev/shm/" + shm), "the owner process did not leave"

@@ -44,7 +44,7 @@ def test_production_kernels_do_not_spill_vector_registers(family, what, occupanc
     (6, "ClsLarge (dense dog3d, DM_TREE=0), plain: 4 (DESIGN.md section 6)", 8),
     (4, "ClsBiped AMP (odd batches of the task scenes; round 5: + the draw-tape lookups of the one-env drop-in, 11 -> 21, all in the rare draw / reset paths)", 24),
     (9, "ClsBipedObj (dribble_amp)", 16),
-    (18, "ClsBiped, DM-physics v2", 32),
+    (18, "ClsBiped, DM-physics v2 (round 5: 32 -> 35 with the draw-tape lookups and the per-clip cycle boundary of the kinematic character, both in rare paths)", 40),
 ])
 def test_secondary_kernels_stay_inside_their_measured_spill_budget(family, what, spill_max):
     r = _res(family)

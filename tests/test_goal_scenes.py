@@ -65,6 +65,18 @@ def test_goal_scene_matches_oracle_emulator(emu_lib, name, pack):
     assert w["flags_ok"] and w["resets"] >= 1 and w["live"] >= 10
     tol = 1e-6 if name != "amp_heading_clips4" else 1e-3    # the 4-clip dataset starts some episodes lying on the ground (stiff contacts)
     assert w["reward"] < tol and w["goal"] < 10 * tol and w["goal_state"] < tol and w["state"] < max(1e-5, 50 * tol)
+    assert w["kin"] < 50 * tol, w["kin"]      # the kinematic origin: cycle boundaries of the env's own clip (round 5: every env wrapped on clip 0's period before)
+
+
+def test_kin_character_of_a_multi_clip_env_runs_on_its_own_clip(emu_lib):
+    """long episodes over the 4-clip dataset: the origin of the kinematic character follows the simulated root at the cycle boundaries of the clip the env was
+    reset to (two looping clips of 0.8 / 1.27 s, two non-looping get-up clips), as the oracle's (cKinCharacter on cClipsController's active motion)"""
+    t = model.load_asset("amp_heading_clips4")
+    t.cfg.time_lim_min = t.cfg.time_lim_max = 4.0; t.cfg.time_end_lim_min = t.cfg.time_end_lim_max = 4.0
+    t.cfg.enable_fall_end = False          # (episodes run to the timer: several cycles of the looping clips)
+    w = pc.goal_rollout_compare(t, 64, emu_lib, steps=130, n=4, seed=11, wave_packing=1)
+    assert w["flags_ok"] and w["resets"] >= 2 and len(w["clips"]) >= 3, w
+    assert w["kin"] < 5e-3, w["kin"]            # (inherits the simulated root's kernel-vs-oracle drift at each sync; a boundary taken on the wrong clip moves the origin by decimetres)
 
 
 def test_target_distance_failure(emu_lib):

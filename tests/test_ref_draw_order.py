@@ -73,7 +73,7 @@ class RefSession:
         assert self.h.value, "ref3_open failed"
 
     def get(self):
-        out = np.zeros(40)
+        out = np.zeros(48)
         self.ref.ref3_get(self.h, out.ctypes.data_as(C.POINTER(C.c_double)))
         return out
 
@@ -106,6 +106,11 @@ class RefSession:
     def update_kin(self, dt):
         self.ref.ref3_update_kin(self.h, C.c_double(dt))
 
+    def kin_pose(self, n):
+        p, v = np.zeros(n), np.zeros(n)
+        assert self.ref.ref3_kin_pose(self.h, p.ctypes.data_as(C.POINTER(C.c_double)), v.ctypes.data_as(C.POINTER(C.c_double))) == n
+        return p
+
     def flags(self, contact_mask):
         """(CheckTerminate(0), IsEpisodeEnd()) of the compiled scene for the stand-in character's state and these contact flags"""
         self.ref.ref3_set_contacts(self.h, int(contact_mask))
@@ -137,7 +142,7 @@ class Recorder:
         return None                     # (not part of the committed log: the GPU box checks the draws)
 
     def expert(self, n):
-        v = self.rs.expert(n); self.tag.append(2); self.rows.append(np.zeros(40)); self.experts.append(v); return v
+        v = self.rs.expert(n); self.tag.append(2); self.rows.append(np.zeros(48)); self.experts.append(v); return v
 
     def __getattr__(self, name):
         return getattr(self.rs, name)
@@ -198,7 +203,7 @@ def _dev(core):
     """what the device holds after the last launch, in the layout of ref3_get"""
     env = core._env
     st = env.get_state()
-    out = {"limit": float(st["clocks"][0][4]), "kin_time": float(st["clocks"][0][0]), "clip": int(env.get_clips()[0]), "kin_rot": np.array(st["kin"][0][3:7], dtype=np.float64),
+    out = {"limit": float(st["clocks"][0][4]), "kin_time": float(st["clocks"][0][0]), "clip": int(env.get_clips()[0]), "kin_rot": np.array(st["kin"][0][3:7], dtype=np.float64), "kin_pos": np.array(st["kin"][0][0:3], dtype=np.float64),
            "pose": np.array(st["pose"][0], dtype=np.float64), "vel": np.array(st["vel"][0], dtype=np.float64)}
     if env._has_goal_row and core._tables.goal_kind:
         g = env.get_goal_state()[0]; aux = env.get_goal_aux()[0]
@@ -210,7 +215,7 @@ def _dev(core):
     return out
 
 
-def _check(kind, d, r, where, pos_tol=1e-9, after_reset=False, exact=True):
+def _check(kind, d, r, where, pos_tol=1e-9, after_reset=False, exact=True, live_kin=False):
     if not exact:
         return _check_close(kind, d, r, where, after_reset)
     assert d["limit"] == r[0], (where, "episode limit", d["limit"], r[0])
@@ -219,6 +224,10 @@ def _check(kind, d, r, where, pos_tol=1e-9, after_reset=False, exact=True):
         assert d["kin_time"] == r[1], (where, "clip time", d["kin_time"], r[1])
         # the yaw: kin origin rotation about +y (cKinCharacter::RotateOrigin) -- equal as rotations (the device stores its own quaternion of the same angle)
         assert abs(abs(float(np.dot(d["kin_rot"], r[3:7]))) - 1.0) < 1e-12, (where, "yaw", d["kin_rot"], r[3:7])
+    if not after_reset and len(r) > 42 and live_kin:
+        # cSceneImitate::UpdateKinChar as compiled, on the device's character: the kinematic clock and -- through SyncKinCharNewCycle at every cycle boundary -- its origin
+        assert abs(d["kin_time"] - r[1]) < 1e-9, (where, "kin time", d["kin_time"], r[1])
+        assert abs(abs(float(np.dot(d["kin_rot"], r[3:7]))) - 1.0) < 1e-9, (where, "kin origin rotation", d["kin_rot"], r[3:7])
     if kind >= 1:
         assert d["ttimer_max"] == r[12], (where, "target timer limit", d["ttimer_max"], r[12])
         assert d["speed"] == r[11], (where, "target speed", d["speed"], r[11])
@@ -265,7 +274,8 @@ def _run(mod, lib, args, seed, monkeypatch, n_resets, steps, precision="64", pos
         core.SetMode(core.eModeTest); rs.set_mode(1)
     dt = 1.0 / 600
     rng = np.random.RandomState(seed & 0xffff)
-    n_pert = 0; n_rec = 0
+    n_pert = 0; n_rec = 0; samplers = {}
+    from deepmimic_amd import model
     fall_bits = int(sum(1 << j for j, f in enumerate(t.fall_mask()) if f))
     try:
         for ep in range(n_resets):
@@ -296,10 +306,21 @@ def _run(mod, lib, args, seed, monkeypatch, n_resets, steps, precision="64", pos
                     rs.set_ball(d["ball"][0:3])
                 rs.update(dt)
                 r = rs.get()
+                if isinstance(rs, RefSession):    # the kinematic character itself: the device's (clip, clip time, origin) through the host sampler vs cKinCharacter::GetPose as compiled
+                    clip = d["clip"]
+                    if clip not in samplers:
+                        samplers[clip] = model.KinSampler(t, clip)
+                    kp = samplers[clip].pose(d["kin_time"], d["kin_pos"], d["kin_rot"])
+                    rp = rs.kin_pose(kp.size)
+                    err = np.abs(kp - rp); err[1] = 0.0      # (root height: the reset's ground-intersection lift is Bullet-side; see draw_reset_scene)
+                    for o in samplers[clip].quat_offs:       # q and -q are one rotation
+                        if np.dot(kp[o:o + 4], rp[o:o + 4]) < 0:
+                            err[o:o + 4] = np.abs(kp[o:o + 4] + rp[o:o + 4])
+                    assert err.max() < 1e-7, ("episode %d update %d" % (ep, k), "kin pose", int(np.argmax(err)), err.max(), kp[:7], rp[:7])
                 fl = rs.flags(cmask)
                 if fl is not None:                # the scene's own CheckTerminate / IsEpisodeEnd on that state: the task scenes' success / failure rules, the clocks
                     assert (core.CheckTerminate(0), core.IsEpisodeEnd()) == fl, ("episode %d update %d" % (ep, k), "terminate / episode end", core.CheckTerminate(0), core.IsEpisodeEnd(), fl)
-                _check(kind, d, r, "episode %d update %d" % (ep, k), pos_tol, exact=exact)
+                _check(kind, d, r, "episode %d update %d" % (ep, k), pos_tol, exact=exact, live_kin=isinstance(rs, RefSession))
                 if "pert" in d and int(r[31]) > n_pert:          # a perturbation fell due in this update: part, force, duration
                     n_pert = int(r[31])
                     slots = d["pert"][3:15].reshape(2, 6)

@@ -342,6 +342,7 @@ class SceneX : public SCENE {
     void d_dribble_update_objs(double dt) { this->UpdateTarObjs(dt); if (this->mTarObjTimer.IsEnd()) this->mTarObjTimer.Reset(); }      // cSceneDribbleAMP::UpdateObjs (:310-319)
     double d_obj_timer_max() const { return this->mTarObjTimer.GetMaxTime(); }
     void d_dribble_ball(const std::shared_ptr<cSimRigidBody>& b) { ball = b; this->mTarObjID = 0; }
+    void d_dribble_prev_ball(const tVector& p) { this->mAgentPrevTarObjPos.assign(1, p); }
     int d_expert(VecX& out) { this->RecordAMPObsExpert(0, out); return (int)out.size(); }
     // heading_amp_getup
     void d_getup_init(const std::vector<int>& ids) { this->mGetupMotionIDs = ids; this->RecordGetupMotionFlags(ids); this->mGetupTime = this->CalcGetupTime(ids); this->InitGetupTimer(); this->ResetGetupTimer(); this->SyncGetupTimer(); }
@@ -706,6 +707,23 @@ void ref3_update(void* h, double dt) {
 int ref3_expert(void* h, double* out) { VecX v; int n = 0; with_scene((Draw*)h, [&](auto& s) { n = s.d_expert(v); }); vout(v, out); return n; }
 // the kinematic character's pose and velocity (cKinCharacter::GetPose / GetVel): what the imitation reward and the root sync compare the simulated character with
 int ref3_kin_pose(void* h, double* pose, double* vel) { Rig* r = ((Draw*)h)->rig; vout(r->kin->GetPose(), pose); vout(r->kin->GetVel(), vel); return (int)r->kin->GetPose().size(); }
+// CalcReward(0) and RecordGoal(0) of the scene class at an action boundary.  The controller's bookkeeping of the last action (cDeepMimicCharController::mPrevActionTime /
+// mPrevActionCOM, written by HandleNewAction inside the simulated update) and its clock come from the caller, as does the ball's record at the last action (dribble_amp:
+// cSceneDribbleAMP::NewActionUpdate); everything else is the session's own state -- target, heading, speed, hit time, scene clock.  out: reward, goal...; returns the goal size.
+int ref3_reward_goal(void* h, double ctrl_time, double prev_action_time, const double* prev_action_com3, const double* prev_ball3, double* out) {
+    Draw* d = (Draw*)h; Rig* r = d->rig;
+    r->ctrl->set_time(ctrl_time); r->ctrl->set_prev_action(prev_action_time, tVector(prev_action_com3[0], prev_action_com3[1], prev_action_com3[2], 0));
+    if (d->kind == 5 && prev_ball3) r->dribble->d_dribble_prev_ball(tVector(prev_ball3[0], prev_ball3[1], prev_ball3[2], 0));
+    VecX g; double rew = 0;
+    with_scene(d, [&](auto& s) { rew = s.CalcReward(0); s.RecordGoal(0, g); });
+    out[0] = rew; for (int i = 0; i < (int)g.size(); ++i) out[1 + i] = g[i];
+    return (int)g.size();
+}
+void ref3_set_ball_full(void* h, const double* s13) {
+    Draw* d = (Draw*)h; if (!d->rig->ball) return;
+    StandinBody& b = *d->rig->ball;
+    b.pos = tVector(s13[0], s13[1], s13[2], 0); b.rot = tQuaternion(s13[3], s13[4], s13[5], s13[6]); b.lin = tVector(s13[7], s13[8], s13[9], 0); b.ang = tVector(s13[10], s13[11], s13[12], 0);
+}
 void ref3_get(void* h, double* out) {
     Draw* d = (Draw*)h; Rig* r = d->rig;
     for (int i = 0; i < 48; ++i) out[i] = 0;

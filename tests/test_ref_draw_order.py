@@ -106,6 +106,18 @@ class RefSession:
     def update_kin(self, dt):
         self.ref.ref3_update_kin(self.h, C.c_double(dt))
 
+    def reward_goal(self, ctrl_time, prev_time, prev_com, prev_ball, gdim):
+        out = np.zeros(1 + max(gdim, 8)); com = np.ascontiguousarray(prev_com, dtype=np.float64)
+        pb = None if prev_ball is None else np.ascontiguousarray(prev_ball, dtype=np.float64)
+        n = self.ref.ref3_reward_goal(self.h, C.c_double(ctrl_time), C.c_double(prev_time), com.ctypes.data_as(C.POINTER(C.c_double)),
+                                      None if pb is None else pb.ctypes.data_as(C.POINTER(C.c_double)), out.ctypes.data_as(C.POINTER(C.c_double)))
+        assert n == gdim, (n, gdim)
+        return float(out[0]), out[1:1 + n].copy()
+
+    def set_ball_full(self, s13):
+        a = np.ascontiguousarray(s13, dtype=np.float64)
+        self.ref.ref3_set_ball_full(self.h, a.ctypes.data_as(C.POINTER(C.c_double)))
+
     def kin_pose(self, n):
         p, v = np.zeros(n), np.zeros(n)
         assert self.ref.ref3_kin_pose(self.h, p.ctypes.data_as(C.POINTER(C.c_double)), v.ctypes.data_as(C.POINTER(C.c_double))) == n
@@ -274,7 +286,7 @@ def _run(mod, lib, args, seed, monkeypatch, n_resets, steps, precision="64", pos
         core.SetMode(core.eModeTest); rs.set_mode(1)
     dt = 1.0 / 600
     rng = np.random.RandomState(seed & 0xffff)
-    n_pert = 0; n_rec = 0; samplers = {}
+    n_pert = 0; n_rec = 0; n_rew = 0; samplers = {}
     from deepmimic_amd import model
     fall_bits = int(sum(1 << j for j, f in enumerate(t.fall_mask()) if f))
     try:
@@ -295,7 +307,16 @@ def _run(mod, lib, args, seed, monkeypatch, n_resets, steps, precision="64", pos
             _check(kind, d, rs.get(), "reset %d" % ep, pos_tol, after_reset=not rec, exact=exact)
             for k in range(steps * 20):
                 if core.NeedNewAction(0):
-                    core.RecordState(0); core.RecordGoal(0)
+                    core.RecordState(0); g_dev = np.array(core.RecordGoal(0)); r_dev = core.CalcReward(0)
+                    if isinstance(rs, RefSession) and kind >= 1:
+                        # the scene's own CalcReward / RecordGoal on the device's character, with the session's target / heading / speed / hit state
+                        d0 = _dev(core); gs = env.get_goal_state()[0]
+                        rs.set_char(d0["pose"], d0["vel"], fallen=bool(int(env.get_state()["flags"][0][1]) & fall_bits))
+                        if kind == 5:
+                            rs.set_ball_full(d0["ball"][:13])
+                        r_ref, g_ref = rs.reward_goal(float(env.get_state()["clocks"][0][1]), float(gs[10]), gs[7:10], d0["aux"][2:5] if kind == 5 else None, g_dev.size)
+                        assert np.abs(g_dev - g_ref).max() < 2e-6 and abs(r_dev - r_ref) < 2e-6, ("episode %d update %d" % (ep, k), "goal / reward", g_dev, g_ref, r_dev, r_ref)
+                        n_rew += 1
                     core.SetAction(0, policy_scale * rng.randn(env.A))
                 core.Update(dt)
                 d = _dev(core)
@@ -336,7 +357,7 @@ def _run(mod, lib, args, seed, monkeypatch, n_resets, steps, precision="64", pos
                 assert np.abs(a - b).max() < (1e-4 if exact else 2e-3), ("expert sample", np.abs(a - b).max())
     finally:
         rs.close()
-    return {"perturbations": n_pert, "recoveries": n_rec}
+    return {"perturbations": n_pert, "recoveries": n_rec, "rewards": n_rew}
 
 
 def test_heading_amp_four_clips(emu_lib, monkeypatch):
@@ -353,20 +374,20 @@ def test_strike_amp(emu_lib, monkeypatch):
     mod = _core_module()
     ds = os.path.join(ROOT, "tools", "datasets", "humanoid3d_clips_walk_punch_local.txt")      # (the shipped dataset names clips that are not in the repository)
     args = ["--arg_file", "args/train_amp_strike_humanoid3d_walk_punch_args.txt", "--motion_file", ds, "--init_hit_prob", "0.3"]
-    _run(mod, emu_lib, args, 77, monkeypatch, n_resets=20, steps=10)
+    assert _run(mod, emu_lib, args, 77, monkeypatch, n_resets=20, steps=10)["rewards"] >= 100
 
 
 def test_target_amp(emu_lib, monkeypatch):
     mod = _core_module()
     args = ["--arg_file", "args/train_amp_target_humanoid3d_zombie_args.txt", "--rand_target_time_min", "0.05", "--rand_target_time_max", "0.3"]
-    _run(mod, emu_lib, args, 5, monkeypatch, n_resets=8, steps=12)
+    assert _run(mod, emu_lib, args, 5, monkeypatch, n_resets=8, steps=12)["rewards"] >= 50
 
 
 def test_dribble_amp(emu_lib, monkeypatch):
     mod = _core_module()
     args = ["--arg_file", "args/train_amp_dribble_humanoid3d_zombie_args.txt", "--rand_target_time_min", "0.05", "--rand_target_time_max", "0.3",
             "--rand_tar_obj_time_min", "0.1", "--rand_tar_obj_time_max", "0.4"]
-    _run(mod, emu_lib, args, 12345, monkeypatch, n_resets=8, steps=12, pos_tol=1e-6)
+    assert _run(mod, emu_lib, args, 12345, monkeypatch, n_resets=8, steps=12, pos_tol=1e-6)["rewards"] >= 50
 
 
 def test_imitate_amp_perturbations_exp_timer(emu_lib, monkeypatch):

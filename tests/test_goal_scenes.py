@@ -72,10 +72,10 @@ def test_kin_character_of_a_multi_clip_env_runs_on_its_own_clip(emu_lib):
     """long episodes over the 4-clip dataset: the origin of the kinematic character follows the simulated root at the cycle boundaries of the clip the env was
     reset to (two looping clips of 0.8 / 1.27 s, two non-looping get-up clips), as the oracle's (cKinCharacter on cClipsController's active motion)"""
     t = model.load_asset("amp_heading_clips4")
-    t.cfg.time_lim_min = t.cfg.time_lim_max = 4.0; t.cfg.time_end_lim_min = t.cfg.time_end_lim_max = 4.0
+    t.cfg.time_lim_min = t.cfg.time_lim_max = 2.0; t.cfg.time_end_lim_min = t.cfg.time_end_lim_max = 2.0
     t.cfg.enable_fall_end = False          # (episodes run to the timer: several cycles of the looping clips)
-    w = pc.goal_rollout_compare(t, 64, emu_lib, steps=130, n=4, seed=11, wave_packing=1)
-    assert w["flags_ok"] and w["resets"] >= 2 and len(w["clips"]) >= 3, w
+    w = pc.goal_rollout_compare(t, 64, emu_lib, steps=80, n=3, seed=11, wave_packing=1)
+    assert w["flags_ok"] and w["resets"] >= 3 and len(w["clips"]) >= 2, w
     assert w["kin"] < 5e-3, w["kin"]            # (inherits the simulated root's kernel-vs-oracle drift at each sync; a boundary taken on the wrong clip moves the origin by decimetres)
 
 

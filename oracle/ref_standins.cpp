@@ -588,9 +588,15 @@ template <class F> void with_scene(Draw* d, F f) {
     case 2: f(*r->heading); break;
     case 3: f(*r->getup); break;
     case 4: f(*r->strike); break;
-    default: f(*r->dribble); break;
+    case 5: f(*r->dribble); break;
+    default: f(*r->imitate); break;          // 6: `--scene imitate`
     }
 }
+// what only the AMP scene classes have
+template <class S> void amp_init_hist(S& s) { s.d_amp_reset(); }
+template <> void amp_init_hist(SceneX<cSceneImitate>&) {}
+template <class S> int amp_expert(S& s, VecX& v) { return s.d_expert(v); }
+template <> int amp_expert(SceneX<cSceneImitate>&, VecX&) { return 0; }
 template <class S> void draw_task_init(S&, Draw*) {}
 template <> void draw_task_init(SceneX<cSceneTargetAMP>& s, Draw*) { s.d_target_init(); }
 template <> void draw_task_init(SceneX<cSceneHeadingAMP>& s, Draw*) { s.d_target_init(); }
@@ -618,7 +624,6 @@ template <class S> void draw_reset_scene(S& s) {
     s.d_reset_characters();
     s.d_init_char_pos();                              // (ResolveCharGroundIntersect lifts the character off the ground: heights only, and the parts' AABBs are Bullet's;
     s.d_sync_kin_root();                              //  cSceneImitate's override then moves the kinematic character's root onto the simulated one)
-    s.d_amp_reset();
 }
 }  // namespace
 
@@ -642,7 +647,8 @@ void* ref3_open(int kind, long seed, const char** tokens, int ntok, const char* 
     case 2: r->heading = std::shared_ptr<SceneX<cSceneHeadingAMP>>(new SceneX<cSceneHeadingAMP>()); break;
     case 3: r->getup = std::shared_ptr<SceneX<cSceneHeadingAMPGetup>>(new SceneX<cSceneHeadingAMPGetup>()); break;
     case 4: r->strike = std::shared_ptr<SceneX<cSceneStrikeAMP>>(new SceneX<cSceneStrikeAMP>()); break;
-    default: r->dribble = std::shared_ptr<SceneX<cSceneDribbleAMP>>(new SceneX<cSceneDribbleAMP>()); break;
+    case 5: r->dribble = std::shared_ptr<SceneX<cSceneDribbleAMP>>(new SceneX<cSceneDribbleAMP>()); break;
+    default: r->imitate = std::shared_ptr<SceneX<cSceneImitate>>(new SceneX<cSceneImitate>()); break;
     }
     std::vector<std::string> args; for (int i = 0; i < ntok; ++i) args.push_back(tokens[i]);
     std::shared_ptr<cArgParser> parser(new cArgParser(args));
@@ -656,6 +662,8 @@ void* ref3_open(int kind, long seed, const char** tokens, int ntok, const char* 
     (void)!chdir(old_cwd);
     if (!ok) { delete d; return nullptr; }
     if (kind == 5) r->ball = std::shared_ptr<StandinBody>(new StandinBody());
+    r->ctrl->SetGround(std::shared_ptr<cGround>(new StandinGround(0.0)));
+    r->ctrl->SetCyclePeriod(r->kin->GetMotionDuration());                       // cSceneImitate::BuildController (SceneImitate.cpp:250-264)
     with_scene(d, [&](auto& s) {
         s.d_rl_scene_init();                                                    // cRLSceneSimChar::Init (RLSceneSimChar.cpp:27-37): cRLScene::Init ...
         s.d_scene_init();                                                       // ... cSceneSimChar::Init (SceneSimChar.cpp:106-123): cScene::Init,
@@ -692,7 +700,7 @@ int ref3_reset(void* h) {
         if (s.d_getup_activate_recovery()) { s.d_getup_reset_recovery(); return 1; }
     }
     if (d->kind == 5) d->rig->dribble->d_dribble_reset_head();                   // cSceneDribbleAMP::Reset (:162-169): the ball first
-    with_scene(d, [&](auto& s) { draw_reset_scene(s); draw_task_reset(s); });
+    with_scene(d, [&](auto& s) { draw_reset_scene(s); if (d->kind == 0) amp_init_hist(s); draw_task_reset(s); });      // (InitHist: cSceneImitateAMP::Reset only; cSceneTargetAMP::Reset calls cSceneImitate::Reset, SceneTargetAMP.cpp:125-130)
     return rec;
 }
 // the drawing part of one scene update: cScene::Update (timers), UpdateRandPerturb, [the world and character update], cSceneDribbleAMP::UpdateObjs,
@@ -704,7 +712,14 @@ void ref3_update(void* h, double dt) {
     with_scene(d, [&](auto& s) { draw_task_update(s, dt); });
 }
 // cSceneImitateAMP::RecordAMPObsExpert (:115-138) itself: SampleExpertMotion draws the clip (gRand, clips controller), then the clip time (mRand)
-int ref3_expert(void* h, double* out) { VecX v; int n = 0; with_scene((Draw*)h, [&](auto& s) { n = s.d_expert(v); }); vout(v, out); return n; }
+int ref3_expert(void* h, double* out) { VecX v; int n = 0; with_scene((Draw*)h, [&](auto& s) { n = amp_expert(s, v); }); vout(v, out); return n; }
+// cCtController::RecordState (sim/CtController.cpp:281-293) of the scene's controller at the caller's controller clock (the clock advances inside the simulated update)
+int ref3_record_state(void* h, double ctrl_time, double* out) {
+    Rig* r = ((Draw*)h)->rig;
+    r->ctrl->set_time(ctrl_time);
+    VecX s; r->ctrl->RecordState(s); vout(s, out);
+    return (int)s.size();
+}
 // the kinematic character's pose and velocity (cKinCharacter::GetPose / GetVel): what the imitation reward and the root sync compare the simulated character with
 int ref3_kin_pose(void* h, double* pose, double* vel) { Rig* r = ((Draw*)h)->rig; vout(r->kin->GetPose(), pose); vout(r->kin->GetVel(), vel); return (int)r->kin->GetPose().size(); }
 // CalcReward(0) and RecordGoal(0) of the scene class at an action boundary.  The controller's bookkeeping of the last action (cDeepMimicCharController::mPrevActionTime /

@@ -20,7 +20,7 @@ COMPAT = os.path.join(ROOT, "deepmimic_amd", "compat")
 REF = "/root/reference"
 pytestmark = pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "DeepMimicCore")), reason="needs the reference checkout (arg files, motion data) next to oracle/_ref")
 
-KINDS = {"imitate_amp": 0, "target_amp": 1, "heading_amp": 2, "heading_amp_getup": 3, "strike_amp": 4, "dribble_amp": 5}
+KINDS = {"imitate_amp": 0, "target_amp": 1, "heading_amp": 2, "heading_amp_getup": 3, "strike_amp": 4, "dribble_amp": 5, "imitate": 6}
 # keys whose parsing names a builder that lives in a Bullet translation unit (the stand-ins replace what those builders would build)
 SKIP_KEYS = ("char_types", "char_ctrls", "kin_ctrl", "terrain_file", "character_files", "char_ctrl_files", "motion_file", "agent_files", "scene", "arg_file")
 
@@ -56,7 +56,7 @@ class RefSession:
         af = p.str("arg_file", "")
         if af:
             p.load_file(os.path.join(REF, af))
-        self.kind = KINDS[p.str("scene", "imitate_amp")]
+        self.kind = KINDS[p.str("scene", "imitate")]
         toks = []
         for k, v in p.table.items():
             if k not in SKIP_KEYS:
@@ -113,6 +113,11 @@ class RefSession:
                                       None if pb is None else pb.ctypes.data_as(C.POINTER(C.c_double)), out.ctypes.data_as(C.POINTER(C.c_double)))
         assert n == gdim, (n, gdim)
         return float(out[0]), out[1:1 + n].copy()
+
+    def record_state(self, ctrl_time, n):
+        out = np.zeros(n)
+        assert self.ref.ref3_record_state(self.h, C.c_double(ctrl_time), out.ctypes.data_as(C.POINTER(C.c_double))) == n
+        return out
 
     def set_ball_full(self, s13):
         a = np.ascontiguousarray(s13, dtype=np.float64)
@@ -207,7 +212,7 @@ def _facade(mod, lib, args, seed, monkeypatch, test_mode=False, precision="64", 
     t = tables if tables is not None else model.load_scene_from_args(list(args), data_root=REF)
     core.LoadTables(t, 10)
     core.Init()
-    assert core._tape, "the facade did not choose the draw tape for this scene"
+    assert core._tape or not (t.goal_kind or t.num_clips > 1 or t.cfg.enable_rand_rot_reset or t.cfg.enable_rand_perturbs), "the facade did not choose the draw tape for this scene"
     return core, t
 
 
@@ -240,7 +245,7 @@ def _check(kind, d, r, where, pos_tol=1e-9, after_reset=False, exact=True, live_
         # cSceneImitate::UpdateKinChar as compiled, on the device's character: the kinematic clock and -- through SyncKinCharNewCycle at every cycle boundary -- its origin
         assert abs(d["kin_time"] - r[1]) < 1e-9, (where, "kin time", d["kin_time"], r[1])
         assert abs(abs(float(np.dot(d["kin_rot"], r[3:7]))) - 1.0) < 1e-9, (where, "kin origin rotation", d["kin_rot"], r[3:7])
-    if kind >= 1:
+    if 1 <= kind <= 5:
         assert d["ttimer_max"] == r[12], (where, "target timer limit", d["ttimer_max"], r[12])
         assert d["speed"] == r[11], (where, "target speed", d["speed"], r[11])
         if kind in (2, 3):
@@ -265,7 +270,7 @@ def _check_close(kind, d, r, where, after_reset):
     if after_reset:
         assert d["clip"] == int(r[2]) and near(d["kin_time"], r[1]), (where, "clip / clip time", d["clip"], d["kin_time"], r[1:3])
         assert abs(abs(float(np.dot(d["kin_rot"], r[3:7]))) - 1.0) < 1e-6, (where, "yaw")
-    if kind >= 1:
+    if 1 <= kind <= 5:
         assert near(d["ttimer_max"], r[12]) and near(d["speed"], r[11]), (where, "target timer / speed", d["ttimer_max"], d["speed"], r[11:13])
         if kind in (2, 3):
             assert near(d["heading"], r[10]), (where, "target heading", d["heading"], r[10])
@@ -307,15 +312,18 @@ def _run(mod, lib, args, seed, monkeypatch, n_resets, steps, precision="64", pos
             _check(kind, d, rs.get(), "reset %d" % ep, pos_tol, after_reset=not rec, exact=exact)
             for k in range(steps * 20):
                 if core.NeedNewAction(0):
-                    core.RecordState(0); g_dev = np.array(core.RecordGoal(0)); r_dev = core.CalcReward(0)
+                    s_dev = np.array(core.RecordState(0)); g_dev = np.array(core.RecordGoal(0)); r_dev = core.CalcReward(0)
                     if isinstance(rs, RefSession) and kind >= 1:
                         # the scene's own CalcReward / RecordGoal on the device's character, with the session's target / heading / speed / hit state
-                        d0 = _dev(core); gs = env.get_goal_state()[0]
+                        d0 = _dev(core); gs = env.get_goal_state()[0] if env._has_goal_row else np.zeros(12)
                         rs.set_char(d0["pose"], d0["vel"], fallen=bool(d0["contacts"] & fall_bits))
                         if kind == 5:
                             rs.set_ball_full(d0["ball"][:13])
                         r_ref, g_ref = rs.reward_goal(d0["ctrl_time"], float(gs[10]), gs[7:10], d0["aux"][2:5] if kind == 5 else None, g_dev.size)
-                        assert np.abs(g_dev - g_ref).max() < 2e-6 and abs(r_dev - r_ref) < 2e-6, ("episode %d update %d" % (ep, k), "goal / reward", g_dev, g_ref, r_dev, r_ref)
+                        assert (g_dev.size == 0 or np.abs(g_dev - g_ref).max() < 2e-6) and abs(r_dev - r_ref) < 2e-6, ("episode %d update %d" % (ep, k), "goal / reward", g_dev, g_ref, r_dev, r_ref)
+                        # cCtController::RecordState of the reference's own controller on the device's character (phase from the controller clock, ground height, link frames)
+                        s_ref = rs.record_state(d0["ctrl_time"], s_dev.size)
+                        assert np.abs(s_dev - s_ref).max() < 2e-6 * max(1.0, np.abs(s_ref).max()), ("episode %d update %d" % (ep, k), "state", int(np.argmax(np.abs(s_dev - s_ref))), np.abs(s_dev - s_ref).max())
                         n_rew += 1
                     core.SetAction(0, policy_scale * rng.randn(env.A))
                 core.Update(dt)
@@ -494,3 +502,13 @@ def test_more_draws_in_a_control_step_than_a_tape_holds(emu_lib, monkeypatch):
     for a, b in zip(*logs):
         for x, y in zip(a, b):
             assert np.array_equal(np.asarray(x), np.asarray(y))
+
+
+@pytest.mark.parametrize("arg_file,steps", [("args/run_humanoid3d_walk_args.txt", 50), ("args/train_humanoid3d_spinkick_args.txt", 40), ("args/train_dog3d_pace_args.txt", 30)])
+def test_imitate_scenes_live(emu_lib, monkeypatch, arg_file, steps):
+    """`--scene imitate` (the headline scene): the compiled cSceneImitate / cKinCharacter / cCtPDController on the device's character after every update -- kinematic
+    pose through the cycle boundaries (SyncKinCharNewCycle), CalcRewardImitate and RecordState at every action boundary, CheckTerminate / IsEpisodeEnd (fall,
+    end of a non-looping motion, episode timer), reset clip times and limits from the reference's generator"""
+    mod = _core_module()
+    out = _run(mod, emu_lib, ["--arg_file", arg_file], 31, monkeypatch, n_resets=3, steps=steps)
+    assert out["rewards"] >= 20

@@ -344,6 +344,10 @@ class SceneX : public SCENE {
     void d_dribble_ball(const std::shared_ptr<cSimRigidBody>& b) { ball = b; this->mTarObjID = 0; }
     void d_dribble_prev_ball(const tVector& p) { this->mAgentPrevTarObjPos.assign(1, p); }
     int d_expert(VecX& out) { this->RecordAMPObsExpert(0, out); return (int)out.size(); }
+    int d_amp_agent(VecX& out) { this->RecordAMPObsAgent(0, out); return (int)out.size(); }
+    // cRLSceneSimChar::PreUpdate -> NewActionUpdate (RLSceneSimChar.cpp:262-275): the pose history of the AMP observation (and the ball record of dribble_amp) is
+    // latched when a new action starts.  (The test-mode time-warp sampler, an evaluation return of imitate_amp, is not built in these sessions.)
+    void d_new_action() { this->mTestTimeWarp = false; this->NewActionUpdate(0); }
     // heading_amp_getup
     void d_getup_init(const std::vector<int>& ids) { this->mGetupMotionIDs = ids; this->RecordGetupMotionFlags(ids); this->mGetupTime = this->CalcGetupTime(ids); this->InitGetupTimer(); this->ResetGetupTimer(); this->SyncGetupTimer(); }
     bool d_getup_activate_recovery() { return this->ActivateRecoveryEpisode(); }
@@ -597,6 +601,10 @@ template <class S> void amp_init_hist(S& s) { s.d_amp_reset(); }
 template <> void amp_init_hist(SceneX<cSceneImitate>&) {}
 template <class S> int amp_expert(S& s, VecX& v) { return s.d_expert(v); }
 template <> int amp_expert(SceneX<cSceneImitate>&, VecX&) { return 0; }
+template <class S> int amp_agent(S& s, VecX& v) { return s.d_amp_agent(v); }
+template <> int amp_agent(SceneX<cSceneImitate>&, VecX&) { return 0; }
+template <class S> void amp_new_action(S& s) { s.d_new_action(); }
+template <> void amp_new_action(SceneX<cSceneImitate>&) {}
 template <class S> void draw_task_init(S&, Draw*) {}
 template <> void draw_task_init(SceneX<cSceneTargetAMP>& s, Draw*) { s.d_target_init(); }
 template <> void draw_task_init(SceneX<cSceneHeadingAMP>& s, Draw*) { s.d_target_init(); }
@@ -713,11 +721,18 @@ void ref3_update(void* h, double dt) {
 }
 // cSceneImitateAMP::RecordAMPObsExpert (:115-138) itself: SampleExpertMotion draws the clip (gRand, clips controller), then the clip time (mRand)
 int ref3_expert(void* h, double* out) { VecX v; int n = 0; with_scene((Draw*)h, [&](auto& s) { n = amp_expert(s, v); }); vout(v, out); return n; }
+// cSceneImitateAMP::RecordAMPObsAgent (:101-113) on the stand-in character with the history the session's own NewActionUpdate latched
+int ref3_amp_agent(void* h, double* out) { VecX v; int n = 0; with_scene((Draw*)h, [&](auto& s) { n = amp_agent(s, v); }); vout(v, out); return n; }
+// cSceneImitateAMP::InitHist (:153-165) again, after the caller put the kinematic origin where the reset's ground-intersection lift (Bullet-side) left it
+void ref3_init_hist(void* h) { with_scene((Draw*)h, [&](auto& s) { amp_init_hist(s); }); }
+void ref3_new_action(void* h) { with_scene((Draw*)h, [&](auto& s) { amp_new_action(s); }); }
 // cCtController::RecordState (sim/CtController.cpp:281-293) of the scene's controller at the caller's controller clock (the clock advances inside the simulated update)
 int ref3_record_state(void* h, double ctrl_time, double* out) {
     Rig* r = ((Draw*)h)->rig;
     r->ctrl->set_time(ctrl_time);
-    VecX s; r->ctrl->RecordState(s); vout(s, out);
+    VecX s;
+    with_scene((Draw*)h, [&](auto& sc) { sc.RecordState(0, s); });              // the scene's RecordState: the controller's, + the task state of dribble_amp (SceneDribbleAMP.cpp:193-210)
+    vout(s, out);
     return (int)s.size();
 }
 // the kinematic character's pose and velocity (cKinCharacter::GetPose / GetVel): what the imitation reward and the root sync compare the simulated character with

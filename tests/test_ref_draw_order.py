@@ -119,6 +119,14 @@ class RefSession:
         assert self.ref.ref3_record_state(self.h, C.c_double(ctrl_time), out.ctypes.data_as(C.POINTER(C.c_double))) == n
         return out
 
+    def amp_agent(self, n):
+        out = np.zeros(n)
+        assert self.ref.ref3_amp_agent(self.h, out.ctypes.data_as(C.POINTER(C.c_double))) == n
+        return out
+
+    def new_action(self):
+        self.ref.ref3_new_action(self.h)
+
     def set_ball_full(self, s13):
         a = np.ascontiguousarray(s13, dtype=np.float64)
         self.ref.ref3_set_ball_full(self.h, a.ctypes.data_as(C.POINTER(C.c_double)))
@@ -291,7 +299,7 @@ def _run(mod, lib, args, seed, monkeypatch, n_resets, steps, precision="64", pos
         core.SetMode(core.eModeTest); rs.set_mode(1)
     dt = 1.0 / 600
     rng = np.random.RandomState(seed & 0xffff)
-    n_pert = 0; n_rec = 0; n_rew = 0; samplers = {}
+    n_pert = 0; n_rec = 0; n_rew = 0; n_amp = 0; samplers = {}
     from deepmimic_amd import model
     fall_bits = int(sum(1 << j for j, f in enumerate(t.fall_mask()) if f))
     try:
@@ -310,6 +318,11 @@ def _run(mod, lib, args, seed, monkeypatch, n_resets, steps, precision="64", pos
             d = _dev(core)
             assert bool(rec) == bool(np.array_equal(pose_before, d["pose"])), ("reset %d" % ep, "recovery episode (the character stays where it fell)", rec)
             _check(kind, d, rs.get(), "reset %d" % ep, pos_tol, after_reset=not rec, exact=exact)
+            if kind == 0 and isinstance(rs, RefSession):
+                # imitate_amp re-initialises the pose history at Reset from the kinematic character one control period back: its origin height carries the reset's
+                # ground-intersection lift, which is Bullet-side here -- taken from the device, then cSceneImitateAMP::InitHist runs again
+                ref_lib.load("ref").ref3_set_kin_origin_pos(rs.h, np.ascontiguousarray(d["kin_pos"]).ctypes.data_as(C.POINTER(C.c_double)))
+                ref_lib.load("ref").ref3_init_hist(rs.h)
             for k in range(steps * 20):
                 if core.NeedNewAction(0):
                     s_dev = np.array(core.RecordState(0)); g_dev = np.array(core.RecordGoal(0)); r_dev = core.CalcReward(0)
@@ -325,6 +338,15 @@ def _run(mod, lib, args, seed, monkeypatch, n_resets, steps, precision="64", pos
                         s_ref = rs.record_state(d0["ctrl_time"], s_dev.size)
                         assert np.abs(s_dev - s_ref).max() < 2e-6 * max(1.0, np.abs(s_ref).max()), ("episode %d update %d" % (ep, k), "state", int(np.argmax(np.abs(s_dev - s_ref))), np.abs(s_dev - s_ref).max())
                         n_rew += 1
+                    if isinstance(rs, RefSession) and kind <= 5:
+                        # RecordAMPObsAgent: the pose latched at the previous action boundary (the scene's own NewActionUpdate) and the pose now
+                        if kind == 0:
+                            d0 = _dev(core); rs.set_char(d0["pose"], d0["vel"])
+                        if k > 0 or kind == 0:      # (the task scenes do not re-initialise the history at Reset: the first pair of an episode is stale in the reference)
+                            a_dev = np.array(core.RecordAMPObsAgent(0)); a_ref = rs.amp_agent(a_dev.size)
+                            assert np.abs(a_dev - a_ref).max() < 5e-6 * max(1.0, np.abs(a_ref).max()), ("episode %d update %d" % (ep, k), "AMP observation", int(np.argmax(np.abs(a_dev - a_ref))), np.abs(a_dev - a_ref).max())
+                            n_amp += 1
+                        rs.new_action()
                     core.SetAction(0, policy_scale * rng.randn(env.A))
                 core.Update(dt)
                 d = _dev(core)
@@ -365,7 +387,7 @@ def _run(mod, lib, args, seed, monkeypatch, n_resets, steps, precision="64", pos
                 assert np.abs(a - b).max() < (1e-4 if exact else 2e-3), ("expert sample", np.abs(a - b).max())
     finally:
         rs.close()
-    return {"perturbations": n_pert, "recoveries": n_rec, "rewards": n_rew}
+    return {"perturbations": n_pert, "recoveries": n_rec, "rewards": n_rew, "amp_obs": n_amp}
 
 
 def test_heading_amp_four_clips(emu_lib, monkeypatch):
@@ -382,7 +404,8 @@ def test_strike_amp(emu_lib, monkeypatch):
     mod = _core_module()
     ds = os.path.join(ROOT, "tools", "datasets", "humanoid3d_clips_walk_punch_local.txt")      # (the shipped dataset names clips that are not in the repository)
     args = ["--arg_file", "args/train_amp_strike_humanoid3d_walk_punch_args.txt", "--motion_file", ds, "--init_hit_prob", "0.3"]
-    assert _run(mod, emu_lib, args, 77, monkeypatch, n_resets=20, steps=10)["rewards"] >= 100
+    out = _run(mod, emu_lib, args, 77, monkeypatch, n_resets=20, steps=10)
+    assert out["rewards"] >= 100 and out["amp_obs"] >= 80
 
 
 def test_target_amp(emu_lib, monkeypatch):
@@ -405,7 +428,9 @@ def test_imitate_amp_perturbations_exp_timer(emu_lib, monkeypatch):
     args = ["--arg_file", "args/train_amp_humanoid3d_run_args.txt", "--enable_rand_perturbs", "true", "--perturb_time_min", "0.05", "--perturb_time_max", "0.2",
             "--min_pertrub_duration", "0.02", "--max_perturb_duration", "0.08", "--timer_type", "exp", "--time_lim_min", "0.3", "--time_lim_max", "2.0", "--time_lim_exp", "0.5",
             "--time_end_lim_min", "0.3", "--time_end_lim_max", "2.0", "--time_end_lim_exp", "0.5", "--enable_rand_rot_reset", "true"]
-    n = _run(mod, emu_lib, args, 4242, monkeypatch, n_resets=6, steps=12)["perturbations"]
+    out = _run(mod, emu_lib, args, 4242, monkeypatch, n_resets=6, steps=12)
+    n = out["perturbations"]
+    assert out["amp_obs"] >= 30          # (imitate_amp: the first pair of an episode included -- cSceneImitateAMP::Reset re-initialises the history)
     assert n >= 6, "no perturbation fell due: the test would not see their draws"
 
 

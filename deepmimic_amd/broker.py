@@ -236,6 +236,7 @@ def serve(name: str, max_workers: int, device: int, precision: int, lib_path: st
                 if pend.size == 0:
                     continue
             n_att = int(np.count_nonzero(R.owner))
+            had_worker, idle_since = True, time.monotonic()          # (a served request is a worker seen: an owner that was never idle while its workers were attached must not wait out the 120 s start-up grace afterwards)
             t_g0 = time.perf_counter(); stats["t_idle"] += t_g0 - t_mark
             if pend.size < n_att and gather_max > 0:
                 t0 = t_last = time.perf_counter(); last_n = pend.size

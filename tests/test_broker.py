@@ -121,7 +121,20 @@ def test_shared_workers_equal_private_contexts(emu_lib, scene, rng_mode, physics
     t_end = time.monotonic() + 45
     while os.path.exists("/dev/shm/" + shm) and time.monotonic() < t_end:
         time.sleep(0.2)
-    assert not os.path.exists("/dev/shm/" + shm), "the owner process did not leave"
+    if os.path.exists("/dev/shm/" + shm):               # say what the owner was doing
+        from deepmimic_amd.broker import Region
+        diag = {}
+        try:
+            R = Region(shm)
+            pid = int(R.hdr[8]); diag = {"owner_pid": pid, "alive": os.path.exists("/proc/%d" % pid), "slots": R.owner.tolist(), "req": R.req.tolist(), "ack": R.ack.tolist(), "hdr0": int(R.hdr[0])}
+            if diag["alive"]:
+                diag["wchan"] = open("/proc/%d/wchan" % pid).read(); diag["stat"] = open("/proc/%d/stat" % pid).read().split()[2]
+            R.close()
+        except Exception as ex:
+            diag["error"] = repr(ex)
+        log = "/dev/shm/%s.log" % shm
+        diag["log"] = open(log, "rb").read()[-2000:] if os.path.exists(log) else None
+        raise AssertionError("the owner process did not leave: %r" % (diag,))
     for f in glob.glob("/dev/shm/%s.*" % shm):
         os.unlink(f)
 

@@ -171,7 +171,12 @@ def fill_scene_tables(tables: SceneTables, test_mode: bool = False, self_collisi
         st.perturb_time_min, st.perturb_time_max = float(c.perturb_time_min), float(c.perturb_time_max)
         st.min_perturb, st.max_perturb = float(c.min_perturb), float(c.max_perturb)
         st.min_perturb_duration, st.max_perturb_duration = float(c.min_pertrub_duration), float(c.max_perturb_duration)
-        parts = set(int(b) for b in (c.perturb_part_ids or []))
+        plist = [int(b) for b in (c.perturb_part_ids or [])]
+        if plist != sorted(set(plist)):
+            # the reference indexes the list as written (mPerturbPartIDs[RandInt(0, n)], scenes/SceneSimChar.cpp:244-252); the device keeps the ids as a bit mask and
+            # takes the idx-th set bit: the same part for the same draw only for an ascending list without repeats
+            raise ValueError("perturb_part_ids must be ascending and without repeats (got %s): the device draws the idx-th id of the SET" % plist)
+        parts = set(plist)
         if any(b < 0 or b >= min(int(st.num_joints), 31) for b in parts):       # bits of a 32-bit mask, like strike_bodies
             raise ValueError("perturb_part_ids names a body part the character does not have: %s" % sorted(parts))
         st.perturb_part_mask = sum(1 << b for b in parts)

@@ -341,7 +341,9 @@ int dm_scene_load(const char* const* args, int n_args, const char* data_root, in
           t.perturb_time_min = ptmin; t.perturb_time_max = a.num("perturb_time_max", inf); t.min_perturb = a.num("min_perturb", 50.0); t.max_perturb = a.num("max_perturb", 100.0);
           t.min_perturb_duration = a.num("min_pertrub_duration", 0.1); t.max_perturb_duration = a.num("max_perturb_duration", 0.5);      // [sic] the reference's key
           std::vector<int> parts; int m = 0;
-          if (a.ints("perturb_part_ids", parts)) for (int b : parts) { if (b < 0 || b >= std::min(J, 31)) return fail("perturb_part_ids names a body part the character does not have (or beyond bit 30 of the 32-bit part mask)"); m |= 1 << b; }
+          if (a.ints("perturb_part_ids", parts)) for (size_t i = 1; i < parts.size(); ++i) if (parts[i] <= parts[i - 1])
+              return fail("perturb_part_ids must be ascending and without repeats: the reference indexes the list as written (scenes/SceneSimChar.cpp:244-252), the device draws the idx-th id of the set");
+          if (!parts.empty()) for (int b : parts) { if (b < 0 || b >= std::min(J, 31)) return fail("perturb_part_ids names a body part the character does not have (or beyond bit 30 of the 32-bit part mask)"); m |= 1 << b; }
           t.perturb_part_mask = m;
       } }
     *out = sc.release();

@@ -206,7 +206,9 @@ def test_humanoid_free_running_with_perturbs_emulator(emu_lib, packing):
 
 
 def test_part_ids_restrict_the_draw(emu_lib):
-    t = perturbed(model.load_asset("humanoid3d_walk"), parts=[2, 5, 5, 11])
+    with pytest.raises(ValueError, match="ascending"):      # the reference indexes the list as written; a repeat or a different order would name other parts here
+        BatchEnv(perturbed(model.load_asset("humanoid3d_walk"), parts=[2, 5, 5, 11]), 4, precision=64, lib_path=emu_lib, seed=3)
+    t = perturbed(model.load_asset("humanoid3d_walk"), parts=[2, 5, 11])
     env = BatchEnv(t, 4, precision=64, lib_path=emu_lib, seed=3)
     env.reset()
     seen = set()

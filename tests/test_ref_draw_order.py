@@ -529,7 +529,7 @@ def test_more_draws_in_a_control_step_than_a_tape_holds(emu_lib, monkeypatch):
             assert np.array_equal(np.asarray(x), np.asarray(y))
 
 
-@pytest.mark.parametrize("arg_file,steps", [("args/run_humanoid3d_walk_args.txt", 50), ("args/train_humanoid3d_spinkick_args.txt", 40), ("args/train_dog3d_pace_args.txt", 30)])
+@pytest.mark.parametrize("arg_file,steps", [("args/run_humanoid3d_walk_args.txt", 30), ("args/train_humanoid3d_spinkick_args.txt", 30), ("args/train_dog3d_pace_args.txt", 20)])
 def test_imitate_scenes_live(emu_lib, monkeypatch, arg_file, steps):
     """`--scene imitate` (the headline scene): the compiled cSceneImitate / cKinCharacter / cCtPDController on the device's character after every update -- kinematic
     pose through the cycle boundaries (SyncKinCharNewCycle), CalcRewardImitate and RecordState at every action boundary, CheckTerminate / IsEpisodeEnd (fall,

@@ -551,6 +551,10 @@ struct CtxT : CtxBase {
     } while (0)
 
     int reset(const int* ids_dev, int n, const double* kt_dev, const double* mt_dev) override {
+        // a bound draw tape serves the whole reset of an env with a goal row; an env without one (single clip, no yaw) has only its perturbation clock on the
+        // device -- its clip time and episode limit are the caller's draws (the facade makes them on the host in the reference's order): the counter-based
+        // streams must not fill in silently
+        if (md.draw_tape && !st.goal && (!kt_dev || !mt_dev)) return fail("a draw tape is bound and the scene has no goal row: dm_reset needs kin_times and max_times (drawn by the caller in the reference's order)");
         DM_DISPATCH(launch_reset, n, md, st, ids_dev, kt_dev, mt_dev);
         return 0;
     }

@@ -721,6 +721,11 @@ void ref3_update(void* h, double dt) {
 }
 // cSceneImitateAMP::RecordAMPObsExpert (:115-138) itself: SampleExpertMotion draws the clip (gRand, clips controller), then the clip time (mRand)
 int ref3_expert(void* h, double* out) { VecX v; int n = 0; with_scene((Draw*)h, [&](auto& s) { n = amp_expert(s, v); }); vout(v, out); return n; }
+// the controller of the session's character: cCtPDController::ApplyAction at an action boundary, and the stable-PD torque of the reference's own cImpPDController /
+// cRBDModel for the stand-in's current state and the latched targets (ref2_apply_action / ref2_spd_tau on the session's rig): what cCtController::Update computes
+// before the world steps
+void ref3_apply_action(void* h, const double* action, double* out_tar) { ref2_apply_action(((Draw*)h)->rig, action, out_tar); }
+void ref3_spd_tau(void* h, double dt, double* out_tau) { ref2_spd_tau(((Draw*)h)->rig, dt, out_tau); }
 // cSceneImitateAMP::RecordAMPObsAgent (:101-113) on the stand-in character with the history the session's own NewActionUpdate latched
 int ref3_amp_agent(void* h, double* out) { VecX v; int n = 0; with_scene((Draw*)h, [&](auto& s) { n = amp_agent(s, v); }); vout(v, out); return n; }
 // cSceneImitateAMP::InitHist (:153-165) again, after the caller put the kinematic origin where the reset's ground-intersection lift (Bullet-side) left it

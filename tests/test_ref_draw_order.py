@@ -127,6 +127,16 @@ class RefSession:
     def new_action(self):
         self.ref.ref3_new_action(self.h)
 
+    def apply_action(self, action, P):
+        a = np.ascontiguousarray(action, dtype=np.float64); tar = np.zeros(P)
+        self.ref.ref3_apply_action(self.h, a.ctypes.data_as(C.POINTER(C.c_double)), tar.ctypes.data_as(C.POINTER(C.c_double)))
+        return tar
+
+    def spd_tau(self, dt, P):
+        out = np.zeros(P)
+        self.ref.ref3_spd_tau(self.h, C.c_double(dt), out.ctypes.data_as(C.POINTER(C.c_double)))
+        return out
+
     def set_ball_full(self, s13):
         a = np.ascontiguousarray(s13, dtype=np.float64)
         self.ref.ref3_set_ball_full(self.h, a.ctypes.data_as(C.POINTER(C.c_double)))
@@ -299,7 +309,10 @@ def _run(mod, lib, args, seed, monkeypatch, n_resets, steps, precision="64", pos
         core.SetMode(core.eModeTest); rs.set_mode(1)
     dt = 1.0 / 600
     rng = np.random.RandomState(seed & 0xffff)
-    n_pert = 0; n_rec = 0; n_rew = 0; n_amp = 0; samplers = {}
+    n_pert = 0; n_rec = 0; n_rew = 0; n_amp = 0; n_tau = 0; samplers = {}
+    live = isinstance(rs, RefSession)
+    import parity_common as pc
+    dof_idx = pc.dof_index(t)
     from deepmimic_amd import model
     fall_bits = int(sum(1 << j for j, f in enumerate(t.fall_mask()) if f))
     try:
@@ -347,9 +360,18 @@ def _run(mod, lib, args, seed, monkeypatch, n_resets, steps, precision="64", pos
                             assert np.abs(a_dev - a_ref).max() < 5e-6 * max(1.0, np.abs(a_ref).max()), ("episode %d update %d" % (ep, k), "AMP observation", int(np.argmax(np.abs(a_dev - a_ref))), np.abs(a_dev - a_ref).max())
                             n_amp += 1
                         rs.new_action()
-                    core.SetAction(0, policy_scale * rng.randn(env.A))
+                    act = (policy_scale * rng.randn(env.A)).astype(np.float32)
+                    core.SetAction(0, act)
+                    if live:                      # cCtPDController::ApplyAction of the reference's controller: the PD targets of this control step
+                        tar_ref = rs.apply_action(act, env.P)
+                if live:                          # the torque the reference's controller computes for the state this update starts from (the stand-in holds it)
+                    tau_ref = pc.clamp_tau(t, rs.spd_tau(dt, env.P))[dof_idx]
                 core.Update(dt)
                 d = _dev(core)
+                if live:
+                    tau_dev = env.debug("tau")[0]
+                    assert np.abs(tau_dev - tau_ref).max() < 1e-7 * max(1.0, np.abs(tau_ref).max()), ("episode %d update %d" % (ep, k), "stable-PD torque", int(np.argmax(np.abs(tau_dev - tau_ref))), np.abs(tau_dev - tau_ref).max())
+                    n_tau += 1
                 rs.update_kin(dt)                 # (cSceneImitate::UpdateCharacters: before the world steps)
                 cmask = d["contacts"]
                 rs.set_char(d["pose"], d["vel"], fallen=bool(cmask & fall_bits))      # cSimCharacter::HasFallen: a fall-contact body touches something
@@ -387,7 +409,7 @@ def _run(mod, lib, args, seed, monkeypatch, n_resets, steps, precision="64", pos
                 assert np.abs(a - b).max() < (1e-4 if exact else 2e-3), ("expert sample", np.abs(a - b).max())
     finally:
         rs.close()
-    return {"perturbations": n_pert, "recoveries": n_rec, "rewards": n_rew, "amp_obs": n_amp}
+    return {"perturbations": n_pert, "recoveries": n_rec, "rewards": n_rew, "amp_obs": n_amp, "torques": n_tau}
 
 
 def test_heading_amp_four_clips(emu_lib, monkeypatch):
@@ -532,8 +554,9 @@ def test_more_draws_in_a_control_step_than_a_tape_holds(emu_lib, monkeypatch):
 @pytest.mark.parametrize("arg_file,steps", [("args/run_humanoid3d_walk_args.txt", 30), ("args/train_humanoid3d_spinkick_args.txt", 30), ("args/train_dog3d_pace_args.txt", 20)])
 def test_imitate_scenes_live(emu_lib, monkeypatch, arg_file, steps):
     """`--scene imitate` (the headline scene): the compiled cSceneImitate / cKinCharacter / cCtPDController on the device's character after every update -- kinematic
-    pose through the cycle boundaries (SyncKinCharNewCycle), CalcRewardImitate and RecordState at every action boundary, CheckTerminate / IsEpisodeEnd (fall,
+    pose through the cycle boundaries (SyncKinCharNewCycle), the stable-PD torque of every update (cCtPDController::ApplyAction -> cImpPDController on cRBDModel, clamped
+    per joint), CalcRewardImitate and RecordState at every action boundary, CheckTerminate / IsEpisodeEnd (fall,
     end of a non-looping motion, episode timer), reset clip times and limits from the reference's generator"""
     mod = _core_module()
     out = _run(mod, emu_lib, ["--arg_file", arg_file], 31, monkeypatch, n_resets=3, steps=steps)
-    assert out["rewards"] >= 20
+    assert out["rewards"] >= 20 and out["torques"] >= 400

@@ -426,8 +426,8 @@ def test_strike_amp(emu_lib, monkeypatch):
     mod = _core_module()
     ds = os.path.join(ROOT, "tools", "datasets", "humanoid3d_clips_walk_punch_local.txt")      # (the shipped dataset names clips that are not in the repository)
     args = ["--arg_file", "args/train_amp_strike_humanoid3d_walk_punch_args.txt", "--motion_file", ds, "--init_hit_prob", "0.3"]
-    out = _run(mod, emu_lib, args, 77, monkeypatch, n_resets=20, steps=10)
-    assert out["rewards"] >= 100 and out["amp_obs"] >= 80
+    out = _run(mod, emu_lib, args, 77, monkeypatch, n_resets=14, steps=10)
+    assert out["rewards"] >= 70 and out["amp_obs"] >= 55
 
 
 def test_target_amp(emu_lib, monkeypatch):

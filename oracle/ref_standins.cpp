@@ -252,6 +252,7 @@ class CtrlX : public cCtPDController {
    public:
     using cCtPDController::UpdateBuildTau;
     using cCtPDController::ApplyAction;
+    using cCtController::CheckNeedNewAction;
     cImpPDController& pd() { return mPDCtrl; }
     void set_time(double t) { mTime = t; }
     void set_prev_action(double t, const tVector& com) { mPrevActionTime = t; mPrevActionCOM = com; }
@@ -726,6 +727,9 @@ int ref3_expert(void* h, double* out) { VecX v; int n = 0; with_scene((Draw*)h, 
 // before the world steps
 void ref3_apply_action(void* h, const double* action, double* out_tar) { ref2_apply_action(((Draw*)h)->rig, action, out_tar); }
 void ref3_spd_tau(void* h, double dt, double* out_tau) { ref2_spd_tau(((Draw*)h)->rig, dt, out_tau); }
+// cCtController::CheckNeedNewAction (sim/CtController.cpp:221-227) at the caller's controller clock: the 30 Hz latch with the init-time offset the scene's own
+// SyncCharacters gave the controller at the reset (cCtController::SetInitTime, scenes/SceneImitate.cpp:351-368)
+int ref3_need_new_action(void* h, double ctrl_time, double dt) { Rig* r = ((Draw*)h)->rig; r->ctrl->set_time(ctrl_time); return r->ctrl->CheckNeedNewAction(dt) ? 1 : 0; }
 // cSceneImitateAMP::RecordAMPObsAgent (:101-113) on the stand-in character with the history the session's own NewActionUpdate latched
 int ref3_amp_agent(void* h, double* out) { VecX v; int n = 0; with_scene((Draw*)h, [&](auto& s) { n = amp_agent(s, v); }); vout(v, out); return n; }
 // cSceneImitateAMP::InitHist (:153-165) again, after the caller put the kinematic origin where the reset's ground-intersection lift (Bullet-side) left it

@@ -334,8 +334,8 @@ def _run(mod, lib, args, seed, monkeypatch, n_resets, steps, precision="64", pos
             if kind == 0 and isinstance(rs, RefSession):
                 # imitate_amp re-initialises the pose history at Reset from the kinematic character one control period back: its origin height carries the reset's
                 # ground-intersection lift, which is Bullet-side here -- taken from the device, then cSceneImitateAMP::InitHist runs again
-                ref_lib.load("ref").ref3_set_kin_origin_pos(rs.h, np.ascontiguousarray(d["kin_pos"]).ctypes.data_as(C.POINTER(C.c_double)))
-                ref_lib.load("ref").ref3_init_hist(rs.h)
+                rs.ref.ref3_set_kin_origin_pos(rs.h, np.ascontiguousarray(d["kin_pos"]).ctypes.data_as(C.POINTER(C.c_double)))
+                rs.ref.ref3_init_hist(rs.h)
             for k in range(steps * 20):
                 if core.NeedNewAction(0):
                     s_dev = np.array(core.RecordState(0)); g_dev = np.array(core.RecordGoal(0)); r_dev = core.CalcReward(0)
@@ -390,6 +390,8 @@ def _run(mod, lib, args, seed, monkeypatch, n_resets, steps, precision="64", pos
                         if np.dot(kp[o:o + 4], rp[o:o + 4]) < 0:
                             err[o:o + 4] = np.abs(kp[o:o + 4] + rp[o:o + 4])
                     assert err.max() < 1e-7, ("episode %d update %d" % (ep, k), "kin pose", int(np.argmax(err)), err.max(), kp[:7], rp[:7])
+                if live:                          # the 30 Hz action latch: cCtController::CheckNeedNewAction at the controller clock this update ended on
+                    assert bool(rs.ref.ref3_need_new_action(rs.h, C.c_double(d["ctrl_time"]), C.c_double(dt))) == bool(core.NeedNewAction(0)), ("episode %d update %d" % (ep, k), "NeedNewAction")
                 fl = rs.flags(cmask)
                 if fl is not None:                # the scene's own CheckTerminate / IsEpisodeEnd on that state: the task scenes' success / failure rules, the clocks
                     assert (core.CheckTerminate(0), core.IsEpisodeEnd()) == fl, ("episode %d update %d" % (ep, k), "terminate / episode end", core.CheckTerminate(0), core.IsEpisodeEnd(), fl)
@@ -404,7 +406,7 @@ def _run(mod, lib, args, seed, monkeypatch, n_resets, steps, precision="64", pos
             if core._is_amp():                                    # RecordAMPObsExpert: clip (gRand) and clip time (mRand) between episodes
                 if rs.h is not None:
                     ko = np.ascontiguousarray(env.get_state()["kin"][0][0:3], dtype=np.float64)      # (ground height of the sample = the kin origin's)
-                    ref_lib.load("ref").ref3_set_kin_origin_pos(rs.h, ko.ctypes.data_as(C.POINTER(C.c_double)))
+                    rs.ref.ref3_set_kin_origin_pos(rs.h, ko.ctypes.data_as(C.POINTER(C.c_double)))
                 a = np.array(core.RecordAMPObsExpert(0)); b = rs.expert(a.size)
                 assert np.abs(a - b).max() < (1e-4 if exact else 2e-3), ("expert sample", np.abs(a - b).max())
     finally:

@@ -49,6 +49,8 @@ def _core_module():
 
 class RefSession:
     """the compiled reference scene, driven through ref3_* (oracle/ref_standins.cpp)"""
+    full = True            # answers reward / goal / state / AMP observation at action boundaries
+    per_update = True      # ... and torque, kinematic pose, flags, action latch after every update (live only)
 
     def __init__(self, ref, args, seed, test_mode=False):
         from deepmimic_amd import model
@@ -160,9 +162,20 @@ class RefSession:
 class Recorder:
     """a RefSession that logs what it answered, in call order (tests/golden/make_ref_draw_golden.py writes the log to tests/golden/ref_draws.npz)"""
 
+    full, per_update = True, False
+
     def __init__(self, rs):
         self.rs, self.kind, self.h = rs, rs.kind, rs.h
-        self.tag, self.rows, self.experts = [], [], []
+        self.tag, self.rows, self.experts, self.vals = [], [], [], []
+
+    def reward_goal(self, *a):
+        r, g = self.rs.reward_goal(*a); self.vals.append(np.concatenate([[r], g])); return r, g
+
+    def record_state(self, *a):
+        v = self.rs.record_state(*a); self.vals.append(v); return v
+
+    def amp_agent(self, *a):
+        v = self.rs.amp_agent(*a); self.vals.append(v); return v
 
     def reset(self):
         rec = self.rs.reset(); self.tag.append(10 + rec); self.rows.append(self.rs.get()); return rec
@@ -185,15 +198,40 @@ class Recorder:
     def save(self, path, key, store):
         store[key + "_tag"] = np.array(self.tag, dtype=np.int32); store[key + "_rows"] = np.array(self.rows)
         store[key + "_experts"] = np.array(self.experts) if self.experts else np.zeros((0, 1))
+        store[key + "_vals"] = np.concatenate(self.vals) if self.vals else np.zeros(0)          # reward | goal, state, AMP observation of every action boundary, in call order
+        store[key + "_val_ends"] = np.cumsum([v.size for v in self.vals]).astype(np.int64) if self.vals else np.zeros(0, np.int64)
 
 
 class Replay:
     """the log of a Recorder standing in for the compiled reference where the reference checkout does not exist (the GPU box)"""
 
-    def __init__(self, store, key, kind):
+    per_update = False
+
+    def __init__(self, store, key, kind, values=True):
         self.kind, self.h = kind, None
         self.tag, self.rows, self.experts = store[key + "_tag"], store[key + "_rows"], store[key + "_experts"]
-        self.i = -1; self.ie = 0
+        self.i = -1; self.ie = 0; self.iv = 0
+        self.full = bool(values and (key + "_vals") in store and store[key + "_vals"].size)
+        if self.full:
+            self.vals, self.val_ends = store[key + "_vals"], store[key + "_val_ends"]
+
+    def _val(self, n):
+        a = 0 if self.iv == 0 else int(self.val_ends[self.iv - 1]); b = int(self.val_ends[self.iv]); self.iv += 1
+        assert b - a == n, "the run left the recorded call sequence (value of %d entries, %d logged)" % (n, b - a)
+        return self.vals[a:b]
+
+    def reward_goal(self, ctrl_time, prev_time, prev_com, prev_ball, gdim):
+        v = self._val(1 + gdim); return float(v[0]), v[1:]
+
+    def record_state(self, ctrl_time, n):
+        return self._val(n)
+
+    def amp_agent(self, n):
+        return self._val(n)
+
+    def set_ball_full(self, *a): pass
+    def new_action(self): pass
+    def apply_action(self, *a): return None
 
     def _next(self, want):
         self.i += 1
@@ -298,7 +336,7 @@ def _check_close(kind, d, r, where, after_reset):
         assert near(d["pert"][1], r[14]), (where, "next perturbation time", d["pert"][1], r[14])
 
 
-def _run(mod, lib, args, seed, monkeypatch, n_resets, steps, precision="64", pos_tol=1e-9, anneal_at=None, policy_scale=0.0, tables=None, provider=None, exact=True, test_mode=False):
+def _run(mod, lib, args, seed, monkeypatch, n_resets, steps, precision="64", pos_tol=1e-9, anneal_at=None, policy_scale=0.0, tables=None, provider=None, exact=True, test_mode=False, val_tol=1.0):
     """provider: None = the compiled reference, live; a Recorder (logs it) or a Replay (a committed log).  exact = False (fp32 kernels): the scene parameters
     are floats there, values that are a parameter times a draw agree to float accuracy"""
     core, t = _facade(mod, lib, args, seed, monkeypatch, precision=precision, tables=tables)
@@ -310,7 +348,7 @@ def _run(mod, lib, args, seed, monkeypatch, n_resets, steps, precision="64", pos
     dt = 1.0 / 600
     rng = np.random.RandomState(seed & 0xffff)
     n_pert = 0; n_rec = 0; n_rew = 0; n_amp = 0; n_tau = 0; samplers = {}
-    live = isinstance(rs, RefSession)
+    live = rs.per_update
     import parity_common as pc
     dof_idx = pc.dof_index(t)
     from deepmimic_amd import model
@@ -331,7 +369,7 @@ def _run(mod, lib, args, seed, monkeypatch, n_resets, steps, precision="64", pos
             d = _dev(core)
             assert bool(rec) == bool(np.array_equal(pose_before, d["pose"])), ("reset %d" % ep, "recovery episode (the character stays where it fell)", rec)
             _check(kind, d, rs.get(), "reset %d" % ep, pos_tol, after_reset=not rec, exact=exact)
-            if kind == 0 and isinstance(rs, RefSession):
+            if kind == 0 and rs.h is not None:
                 # imitate_amp re-initialises the pose history at Reset from the kinematic character one control period back: its origin height carries the reset's
                 # ground-intersection lift, which is Bullet-side here -- taken from the device, then cSceneImitateAMP::InitHist runs again
                 rs.ref.ref3_set_kin_origin_pos(rs.h, np.ascontiguousarray(d["kin_pos"]).ctypes.data_as(C.POINTER(C.c_double)))
@@ -339,25 +377,25 @@ def _run(mod, lib, args, seed, monkeypatch, n_resets, steps, precision="64", pos
             for k in range(steps * 20):
                 if core.NeedNewAction(0):
                     s_dev = np.array(core.RecordState(0)); g_dev = np.array(core.RecordGoal(0)); r_dev = core.CalcReward(0)
-                    if isinstance(rs, RefSession) and kind >= 1:
+                    if rs.full and kind >= 1:
                         # the scene's own CalcReward / RecordGoal on the device's character, with the session's target / heading / speed / hit state
                         d0 = _dev(core); gs = env.get_goal_state()[0] if env._has_goal_row else np.zeros(12)
                         rs.set_char(d0["pose"], d0["vel"], fallen=bool(d0["contacts"] & fall_bits))
                         if kind == 5:
                             rs.set_ball_full(d0["ball"][:13])
                         r_ref, g_ref = rs.reward_goal(d0["ctrl_time"], float(gs[10]), gs[7:10], d0["aux"][2:5] if kind == 5 else None, g_dev.size)
-                        assert (g_dev.size == 0 or np.abs(g_dev - g_ref).max() < 2e-6) and abs(r_dev - r_ref) < 2e-6, ("episode %d update %d" % (ep, k), "goal / reward", g_dev, g_ref, r_dev, r_ref)
+                        assert (g_dev.size == 0 or np.abs(g_dev - g_ref).max() < 2e-6 * val_tol) and abs(r_dev - r_ref) < 2e-6 * val_tol, ("episode %d update %d" % (ep, k), "goal / reward", g_dev, g_ref, r_dev, r_ref)
                         # cCtController::RecordState of the reference's own controller on the device's character (phase from the controller clock, ground height, link frames)
                         s_ref = rs.record_state(d0["ctrl_time"], s_dev.size)
-                        assert np.abs(s_dev - s_ref).max() < 2e-6 * max(1.0, np.abs(s_ref).max()), ("episode %d update %d" % (ep, k), "state", int(np.argmax(np.abs(s_dev - s_ref))), np.abs(s_dev - s_ref).max())
+                        assert np.abs(s_dev - s_ref).max() < 2e-6 * val_tol * max(1.0, np.abs(s_ref).max()), ("episode %d update %d" % (ep, k), "state", int(np.argmax(np.abs(s_dev - s_ref))), np.abs(s_dev - s_ref).max())
                         n_rew += 1
-                    if isinstance(rs, RefSession) and kind <= 5:
+                    if rs.full and kind <= 5:
                         # RecordAMPObsAgent: the pose latched at the previous action boundary (the scene's own NewActionUpdate) and the pose now
                         if kind == 0:
                             d0 = _dev(core); rs.set_char(d0["pose"], d0["vel"])
                         if k > 0 or kind == 0:      # (the task scenes do not re-initialise the history at Reset: the first pair of an episode is stale in the reference)
                             a_dev = np.array(core.RecordAMPObsAgent(0)); a_ref = rs.amp_agent(a_dev.size)
-                            assert np.abs(a_dev - a_ref).max() < 5e-6 * max(1.0, np.abs(a_ref).max()), ("episode %d update %d" % (ep, k), "AMP observation", int(np.argmax(np.abs(a_dev - a_ref))), np.abs(a_dev - a_ref).max())
+                            assert np.abs(a_dev - a_ref).max() < 5e-6 * val_tol * max(1.0, np.abs(a_ref).max()), ("episode %d update %d" % (ep, k), "AMP observation", int(np.argmax(np.abs(a_dev - a_ref))), np.abs(a_dev - a_ref).max())
                             n_amp += 1
                         rs.new_action()
                     act = (policy_scale * rng.randn(env.A)).astype(np.float32)
@@ -379,7 +417,7 @@ def _run(mod, lib, args, seed, monkeypatch, n_resets, steps, precision="64", pos
                     rs.set_ball(d["ball"][0:3])
                 rs.update(dt)
                 r = rs.get()
-                if isinstance(rs, RefSession):    # the kinematic character itself: the device's (clip, clip time, origin) through the host sampler vs cKinCharacter::GetPose as compiled
+                if rs.per_update:                 # the kinematic character itself: the device's (clip, clip time, origin) through the host sampler vs cKinCharacter::GetPose as compiled
                     clip = d["clip"]
                     if clip not in samplers:
                         samplers[clip] = model.KinSampler(t, clip)
@@ -395,7 +433,7 @@ def _run(mod, lib, args, seed, monkeypatch, n_resets, steps, precision="64", pos
                 fl = rs.flags(cmask)
                 if fl is not None:                # the scene's own CheckTerminate / IsEpisodeEnd on that state: the task scenes' success / failure rules, the clocks
                     assert (core.CheckTerminate(0), core.IsEpisodeEnd()) == fl, ("episode %d update %d" % (ep, k), "terminate / episode end", core.CheckTerminate(0), core.IsEpisodeEnd(), fl)
-                _check(kind, d, r, "episode %d update %d" % (ep, k), pos_tol, exact=exact, live_kin=isinstance(rs, RefSession))
+                _check(kind, d, r, "episode %d update %d" % (ep, k), pos_tol, exact=exact, live_kin=rs.per_update)
                 if "pert" in d and int(r[31]) > n_pert:          # a perturbation fell due in this update: part, force, duration
                     n_pert = int(r[31])
                     slots = d["pert"][3:15].reshape(2, 6)

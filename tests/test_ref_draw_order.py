@@ -352,7 +352,7 @@ def _run(mod, lib, args, seed, monkeypatch, n_resets, steps, precision="64", pos
     import parity_common as pc
     dof_idx = pc.dof_index(t)
     from deepmimic_amd import model
-    fall_bits = int(sum(1 << j for j, f in enumerate(t.fall_mask()) if f))
+    fall_bits = int(sum(1 << j for j, f in enumerate(t.fall_mask()) if f)) if t.cfg.enable_char_contact_fall else 0      # (cSimCharacter::BuildBodyLinks: no part gets the flag without enable_char_contact_fall)
     try:
         for ep in range(n_resets):
             if anneal_at and ep in anneal_at:
@@ -604,3 +604,20 @@ def test_imitate_scenes_live(emu_lib, monkeypatch, arg_file, steps, resets):
     mod = _core_module()
     out = _run(mod, emu_lib, ["--arg_file", arg_file], 31, monkeypatch, n_resets=resets, steps=steps)
     assert out["rewards"] >= 6 * resets and out["torques"] >= 100 * resets
+
+
+def _shipped_arg_files():
+    import glob
+    files = sorted(os.path.relpath(f, REF) for f in glob.glob(os.path.join(REF, "args", "*.txt")))
+    # no agent (the viewer's kin_char scenes) / motion files that are not in the reference's repository
+    files = [f for f in files if "play_motion" not in f and "_locomotion_args" not in f and "walk_punch" not in f]
+    return files if os.environ.get("DM_LIVE_SWEEP") == "all" else files[::9]
+
+
+@pytest.mark.parametrize("arg_file", _shipped_arg_files())
+def test_every_shipped_arg_file_live(emu_lib, monkeypatch, arg_file):
+    """a short live session (2 resets x 3 control steps, every update checked) straight from the reference's own arg file: its parameters reach the compiled scene
+    through the scene's own ParseArgs and the device through this repo's loader.  Every ninth file by default, all 88 with DM_LIVE_SWEEP=all
+    (profiles/r05_live_sessions_every_arg_file.txt: all equal)"""
+    out = _run(_core_module(), emu_lib, ["--arg_file", arg_file], 7, monkeypatch, n_resets=2, steps=3)
+    assert out["torques"] >= 60

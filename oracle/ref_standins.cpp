@@ -348,7 +348,10 @@ class SceneX : public SCENE {
     int d_amp_agent(VecX& out) { this->RecordAMPObsAgent(0, out); return (int)out.size(); }
     // cRLSceneSimChar::PreUpdate -> NewActionUpdate (RLSceneSimChar.cpp:262-275): the pose history of the AMP observation (and the ball record of dribble_amp) is
     // latched when a new action starts.  (The test-mode time-warp sampler, an evaluation return of imitate_amp, is not built in these sessions.)
-    void d_new_action() { this->mTestTimeWarp = false; this->NewActionUpdate(0); }
+    void d_new_action() { this->NewActionUpdate(0); }
+    // the test-mode time-warp return of imitate_amp (cSceneImitateAMP::BuildTimeWarper / ResetTimeWarper, :417-447): built once, restarted at every reset
+    void d_build_time_warper() { if (!this->mTimeWarper) this->BuildTimeWarper(); }
+    void d_reset_time_warper() { if (this->mTimeWarper) this->ResetTimeWarper(); }
     // heading_amp_getup
     void d_getup_init(const std::vector<int>& ids) { this->mGetupMotionIDs = ids; this->RecordGetupMotionFlags(ids); this->mGetupTime = this->CalcGetupTime(ids); this->InitGetupTimer(); this->ResetGetupTimer(); this->SyncGetupTimer(); }
     bool d_getup_activate_recovery() { return this->ActivateRecoveryEpisode(); }
@@ -606,6 +609,8 @@ template <class S> int amp_agent(S& s, VecX& v) { return s.d_amp_agent(v); }
 template <> int amp_agent(SceneX<cSceneImitate>&, VecX&) { return 0; }
 template <class S> void amp_new_action(S& s) { s.d_new_action(); }
 template <> void amp_new_action(SceneX<cSceneImitate>&) {}
+template <class S> void amp_time_warper(S& s, bool build) { if (build) s.d_build_time_warper(); else s.d_reset_time_warper(); }
+template <> void amp_time_warper(SceneX<cSceneImitate>&, bool) {}
 template <class S> void draw_task_init(S&, Draw*) {}
 template <> void draw_task_init(SceneX<cSceneTargetAMP>& s, Draw*) { s.d_target_init(); }
 template <> void draw_task_init(SceneX<cSceneHeadingAMP>& s, Draw*) { s.d_target_init(); }
@@ -734,6 +739,9 @@ int ref3_need_new_action(void* h, double ctrl_time, double dt) { Rig* r = ((Draw
 int ref3_amp_agent(void* h, double* out) { VecX v; int n = 0; with_scene((Draw*)h, [&](auto& s) { n = amp_agent(s, v); }); vout(v, out); return n; }
 // cSceneImitateAMP::InitHist (:153-165) again, after the caller put the kinematic origin where the reset's ground-intersection lift (Bullet-side) left it
 void ref3_init_hist(void* h) { with_scene((Draw*)h, [&](auto& s) { amp_init_hist(s); }); }
+// imitate_amp only (the task scenes' Init / Reset bypass cSceneImitateAMP's: no time warper there): build = 1 once after ref3_open, 0 after every reset -- with the
+// stand-in character and the kinematic origin where the device's are (the warper samples both characters at once)
+void ref3_time_warper(void* h, int build) { Draw* d = (Draw*)h; if (d->kind == 0) with_scene(d, [&](auto& s) { amp_time_warper(s, build != 0); }); }
 void ref3_new_action(void* h) { with_scene((Draw*)h, [&](auto& s) { amp_new_action(s); }); }
 // cCtController::RecordState (sim/CtController.cpp:281-293) of the scene's controller at the caller's controller clock (the clock advances inside the simulated update)
 int ref3_record_state(void* h, double ctrl_time, double* out) {

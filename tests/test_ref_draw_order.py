@@ -129,6 +129,9 @@ class RefSession:
     def new_action(self):
         self.ref.ref3_new_action(self.h)
 
+    def time_warper(self, build):
+        self.ref.ref3_time_warper(self.h, int(build))
+
     def apply_action(self, action, P):
         a = np.ascontiguousarray(action, dtype=np.float64); tar = np.zeros(P)
         self.ref.ref3_apply_action(self.h, a.ctypes.data_as(C.POINTER(C.c_double)), tar.ctypes.data_as(C.POINTER(C.c_double)))
@@ -231,6 +234,7 @@ class Replay:
 
     def set_ball_full(self, *a): pass
     def new_action(self): pass
+    def time_warper(self, build): pass
     def apply_action(self, *a): return None
 
     def _next(self, want):
@@ -345,9 +349,12 @@ def _run(mod, lib, args, seed, monkeypatch, n_resets, steps, precision="64", pos
     env = core._env
     if test_mode:                      # the learner switches modes after Init (learning/rl_world.py): the scene's Init drew in train mode
         core.SetMode(core.eModeTest); rs.set_mode(1)
+    warp = kind == 0 and test_mode and rs.h is not None          # imitate_amp's test-mode return: cSceneImitateAMP::CalcRewardTimeWarp
+    if warp:
+        rs.time_warper(1)
     dt = 1.0 / 600
     rng = np.random.RandomState(seed & 0xffff)
-    n_pert = 0; n_rec = 0; n_rew = 0; n_amp = 0; n_tau = 0; samplers = {}
+    n_pert = 0; n_rec = 0; n_rew = 0; n_amp = 0; n_tau = 0; n_warp = 0; samplers = {}
     live = rs.per_update
     import parity_common as pc
     dof_idx = pc.dof_index(t)
@@ -374,6 +381,8 @@ def _run(mod, lib, args, seed, monkeypatch, n_resets, steps, precision="64", pos
                 # ground-intersection lift, which is Bullet-side here -- taken from the device, then cSceneImitateAMP::InitHist runs again
                 rs.ref.ref3_set_kin_origin_pos(rs.h, np.ascontiguousarray(d["kin_pos"]).ctypes.data_as(C.POINTER(C.c_double)))
                 rs.ref.ref3_init_hist(rs.h)
+                if warp:                          # cSceneImitateAMP::Reset -> ResetTimeWarper: first samples of both characters, where the device's are
+                    rs.set_char(d["pose"], d["vel"]); rs.time_warper(0)
             for k in range(steps * 20):
                 if core.NeedNewAction(0):
                     s_dev = np.array(core.RecordState(0)); g_dev = np.array(core.RecordGoal(0)); r_dev = core.CalcReward(0)
@@ -440,6 +449,10 @@ def _run(mod, lib, args, seed, monkeypatch, n_resets, steps, precision="64", pos
                     hit = [s for s in slots if int(s[0]) - 1 == int(r[16]) and s[4] == r[20]]
                     assert hit and np.abs(hit[0][1:4] - r[17:20]).max() < 1e-9 * max(1.0, np.abs(r[17:20]).max()), ("perturbation", slots, r[16:21])
                 if core.IsEpisodeEnd() or not core.CheckValidEpisode():
+                    if warp and core.IsEpisodeEnd():      # the evaluation return of the episode: alignment cost of the two sample series + the steps it fell short
+                        w_dev = core.CalcReward(0); w_ref = rs.reward_goal(d["ctrl_time"], 0.0, np.zeros(3), None, 0)[0]
+                        assert abs(w_dev - w_ref) < 1e-6 * max(1.0, abs(w_ref)), ("episode %d" % ep, "time-warp return", w_dev, w_ref)
+                        n_warp += 1
                     break
             if core._is_amp():                                    # RecordAMPObsExpert: clip (gRand) and clip time (mRand) between episodes
                 if rs.h is not None:
@@ -449,7 +462,7 @@ def _run(mod, lib, args, seed, monkeypatch, n_resets, steps, precision="64", pos
                 assert np.abs(a - b).max() < (1e-4 if exact else 2e-3), ("expert sample", np.abs(a - b).max())
     finally:
         rs.close()
-    return {"perturbations": n_pert, "recoveries": n_rec, "rewards": n_rew, "amp_obs": n_amp, "torques": n_tau}
+    return {"perturbations": n_pert, "recoveries": n_rec, "rewards": n_rew, "amp_obs": n_amp, "torques": n_tau, "time_warp": n_warp}
 
 
 def test_heading_amp_four_clips(emu_lib, monkeypatch):
@@ -621,3 +634,12 @@ def test_every_shipped_arg_file_live(emu_lib, monkeypatch, arg_file):
     (profiles/r05_live_sessions_every_arg_file.txt: all equal)"""
     out = _run(_core_module(), emu_lib, ["--arg_file", arg_file], 7, monkeypatch, n_resets=2, steps=3)
     assert out["torques"] >= 60
+
+
+def test_imitate_amp_time_warp_return_live(emu_lib, monkeypatch):
+    """imitate_amp in test mode: the return of an episode is the dynamic-time-warping cost between the simulated and the kinematic character's joint positions sampled
+    at every action boundary (cSceneImitateAMP::CalcRewardTimeWarp on cDynamicTimeWarper) -- computed on the host by the drop-in, by the compiled scene here"""
+    mod = _core_module()
+    args = ["--arg_file", "args/train_amp_humanoid3d_run_args.txt", "--time_lim_min", "0.4", "--time_lim_max", "0.8", "--time_end_lim_min", "0.4", "--time_end_lim_max", "0.8"]
+    out = _run(mod, emu_lib, args, 99, monkeypatch, n_resets=4, steps=30, test_mode=True)
+    assert out["time_warp"] >= 3

@@ -609,6 +609,12 @@ template <class S> int amp_agent(S& s, VecX& v) { return s.d_amp_agent(v); }
 template <> int amp_agent(SceneX<cSceneImitate>&, VecX&) { return 0; }
 template <class S> void amp_new_action(S& s) { s.d_new_action(); }
 template <> void amp_new_action(SceneX<cSceneImitate>&) {}
+template <class S> int amp_tables(S& s, int which, VecX& a) {
+    Eigen::VectorXi g;
+    if (which == 10) s.GetAMPObsOffset(a); else if (which == 11) s.GetAMPObsScale(a); else { s.GetAMPObsNormGroup(g); a = g.cast<double>(); }
+    return (int)a.size();
+}
+template <> int amp_tables(SceneX<cSceneImitate>&, int, VecX&) { return 0; }
 template <class S> void amp_time_warper(S& s, bool build) { if (build) s.d_build_time_warper(); else s.d_reset_time_warper(); }
 template <> void amp_time_warper(SceneX<cSceneImitate>&, bool) {}
 template <class S> void draw_task_init(S&, Draw*) {}
@@ -732,6 +738,26 @@ int ref3_expert(void* h, double* out) { VecX v; int n = 0; with_scene((Draw*)h, 
 // before the world steps
 void ref3_apply_action(void* h, const double* action, double* out_tar) { ref2_apply_action(((Draw*)h)->rig, action, out_tar); }
 void ref3_spd_tau(void* h, double dt, double* out_tau) { ref2_spd_tau(((Draw*)h)->rig, dt, out_tau); }
+// the learner-facing tables of the SCENE (cRLScene's pure virtuals, scenes/RLScene.h:43-66, as each scene class answers them -- dribble_amp appends its task state to the
+// controller's): which: 0 state offset, 1 state scale, 2 state norm groups, 3 goal offset, 4 goal scale, 5 goal norm groups, 6 action offset, 7 action scale, 8 action
+// bound min, 9 action bound max, 10 AMP obs offset, 11 AMP obs scale, 12 AMP obs norm group, 13 {reward min, max, fail, succ}.  Returns the length written.
+int ref3_tables(void* h, int which, double* out) {
+    VecX a, b; Eigen::VectorXi g; int n = 0;
+    with_scene((Draw*)h, [&](auto& s) {
+        switch (which) {
+        case 0: case 1: s.BuildStateOffsetScale(0, a, b); if (which == 1) a = b; break;
+        case 2: s.BuildStateNormGroups(0, g); a = g.cast<double>(); break;
+        case 3: case 4: s.BuildGoalOffsetScale(0, a, b); if (which == 4) a = b; break;
+        case 5: s.BuildGoalNormGroups(0, g); a = g.cast<double>(); break;
+        case 6: case 7: s.BuildActionOffsetScale(0, a, b); if (which == 7) a = b; break;
+        case 8: case 9: s.BuildActionBounds(0, a, b); if (which == 9) a = b; break;
+        case 13: a.resize(4); a[0] = s.GetRewardMin(0); a[1] = s.GetRewardMax(0); a[2] = s.GetRewardFail(0); a[3] = s.GetRewardSucc(0); break;
+        default: amp_tables(s, which, a); break;
+        }
+    });
+    n = (int)a.size(); vout(a, out);
+    return n;
+}
 // cCtController::CheckNeedNewAction (sim/CtController.cpp:221-227) at the caller's controller clock: the 30 Hz latch with the init-time offset the scene's own
 // SyncCharacters gave the controller at the reset (cCtController::SetInitTime, scenes/SceneImitate.cpp:351-368)
 int ref3_need_new_action(void* h, double ctrl_time, double dt) { Rig* r = ((Draw*)h)->rig; r->ctrl->set_time(ctrl_time); return r->ctrl->CheckNeedNewAction(dt) ? 1 : 0; }

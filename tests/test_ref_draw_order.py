@@ -129,6 +129,11 @@ class RefSession:
     def new_action(self):
         self.ref.ref3_new_action(self.h)
 
+    def tables(self, which, nmax=512):
+        out = np.zeros(nmax)
+        n = self.ref.ref3_tables(self.h, int(which), out.ctypes.data_as(C.POINTER(C.c_double)))
+        return out[:n].copy()
+
     def time_warper(self, build):
         self.ref.ref3_time_warper(self.h, int(build))
 
@@ -349,6 +354,19 @@ def _run(mod, lib, args, seed, monkeypatch, n_resets, steps, precision="64", pos
     env = core._env
     if test_mode:                      # the learner switches modes after Init (learning/rl_world.py): the scene's Init drew in train mode
         core.SetMode(core.eModeTest); rs.set_mode(1)
+    if rs.per_update:
+        # the learner-facing tables of the scene class (cRLScene's virtuals as each scene answers them: offsets, scales, normalisation groups, action bounds, reward range)
+        dev_tables = [core.BuildStateOffset(0), core.BuildStateScale(0), core.BuildStateNormGroups(0), core.BuildGoalOffset(0), core.BuildGoalScale(0), core.BuildGoalNormGroups(0),
+                      core.BuildActionOffset(0), core.BuildActionScale(0), core.BuildActionBoundMin(0), core.BuildActionBoundMax(0)]
+        if kind <= 5:
+            dev_tables += [core.GetAMPObsOffset(), core.GetAMPObsScale(), core.GetAMPObsNormGroup()]
+        else:
+            dev_tables += [[], [], []]
+        dev_tables.append([core.GetRewardMin(0), core.GetRewardMax(0), core.GetRewardFail(0), core.GetRewardSucc(0)])
+        for which, dv in enumerate(dev_tables):
+            rv = rs.tables(which)
+            dv = np.asarray(dv, dtype=np.float64)
+            assert dv.shape == rv.shape and (dv.size == 0 or np.abs(dv - rv).max() <= 1e-12 * max(1.0, np.abs(rv).max())), ("scene table %d" % which, dv[:8], rv[:8])
     warp = kind == 0 and test_mode and rs.h is not None          # imitate_amp's test-mode return: cSceneImitateAMP::CalcRewardTimeWarp
     if warp:
         rs.time_warper(1)

@@ -358,6 +358,7 @@ class SceneX : public SCENE {
     void d_getup_reset_recovery() { this->ResetRecoveryEpisode(); }
     void d_getup_sync() { this->SyncGetupTimer(); }
     double d_getup_timer() const { return this->mGetupTimer.GetTime(); }
+    void d_getup_test_update() { if (this->mMode == cRLScene::eModeTest) this->UpdateTestGetup(); }      // cSceneHeadingAMPGetup::Update (:95-103): a fall starts a get-up instead of ending the episode
 };
 
 struct Rig {
@@ -730,6 +731,7 @@ void ref3_update(void* h, double dt) {
     with_scene(d, [&](auto& s) { s.d_update_timers(dt); if (s.d_perturbs()) s.d_update_perturb(dt); });
     if (d->kind == 5) d->rig->dribble->d_dribble_update_objs(dt);
     with_scene(d, [&](auto& s) { draw_task_update(s, dt); });
+    if (d->kind == 3) d->rig->getup->d_getup_test_update();
 }
 // cSceneImitateAMP::RecordAMPObsExpert (:115-138) itself: SampleExpertMotion draws the clip (gRand, clips controller), then the clip time (mRand)
 int ref3_expert(void* h, double* out) { VecX v; int n = 0; with_scene((Draw*)h, [&](auto& s) { n = amp_expert(s, v); }); vout(v, out); return n; }

@@ -661,3 +661,13 @@ def test_imitate_amp_time_warp_return_live(emu_lib, monkeypatch):
     args = ["--arg_file", "args/train_amp_humanoid3d_run_args.txt", "--time_lim_min", "0.4", "--time_lim_max", "0.8", "--time_end_lim_min", "0.4", "--time_end_lim_max", "0.8"]
     out = _run(mod, emu_lib, args, 99, monkeypatch, n_resets=4, steps=30, test_mode=True)
     assert out["time_warp"] >= 3
+
+
+def test_heading_amp_getup_test_mode(emu_lib, monkeypatch):
+    """heading_amp_getup in test mode: a fall does not end the episode, it starts a get-up (cSceneHeadingAMPGetup::UpdateTestGetup); the get-up phase rides in the goal,
+    the get-up reward replaces the task reward while it lasts"""
+    mod = _core_module()
+    args = ["--arg_file", "args/train_amp_heading_getup_humanoid3d_locomotion_getup_args.txt", "--time_lim_min", "0.5", "--time_lim_max", "1.5", "--time_end_lim_min", "0.5",
+            "--time_end_lim_max", "1.5"]
+    out = _run(mod, emu_lib, args, 123, monkeypatch, n_resets=3, steps=45, policy_scale=1.0, test_mode=True)
+    assert out["rewards"] >= 60

@@ -671,3 +671,11 @@ def test_heading_amp_getup_test_mode(emu_lib, monkeypatch):
             "--time_end_lim_max", "1.5"]
     out = _run(mod, emu_lib, args, 123, monkeypatch, n_resets=3, steps=45, policy_scale=1.0, test_mode=True)
     assert out["rewards"] >= 60
+
+
+@pytest.mark.parametrize("arg_file", ["args/train_amp_target_humanoid3d_zombie_args.txt", "args/train_amp_dribble_humanoid3d_zombie_args.txt", "args/train_amp_heading_humanoid3d_zombie_args.txt"])
+def test_task_scenes_test_mode(emu_lib, monkeypatch, arg_file):
+    """the task scenes in test mode (pinned episode limit; the rewards' test-mode branches)"""
+    out = _run(_core_module(), emu_lib, ["--arg_file", arg_file, "--time_end_lim_min", "0.6", "--time_end_lim_max", "0.6"], 77, monkeypatch, n_resets=3, steps=20, test_mode=True,
+               pos_tol=1e-6)
+    assert out["rewards"] >= 30

@@ -25,7 +25,7 @@ struct emu_dim3 { unsigned x = 1, y = 1, z = 1; };
 extern emu_dim3 threadIdx, blockIdx, blockDim, gridDim;
 
 namespace emu {
-struct Fiber { void* sp = nullptr; std::vector<char> stack; bool done = false; };
+struct Fiber { void* sp = nullptr; char* stack = nullptr; bool done = false; };
 void barrier();                       // yield point: returns when every live lane arrived
 void launch(unsigned grid, unsigned block, const std::function<void()>& body);
 extern uint64_t g_xchg[8192];         // scratch for cross-lane helpers

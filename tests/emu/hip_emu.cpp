@@ -27,7 +27,8 @@ emu_switch:
     popq %r12
     popq %rbx
     popq %rbp
-    ret
+    popq %rcx
+    jmp *%rcx          # not `ret`: the return-address predictor holds another lane's history, an indirect jump predicts the common resume point
 .size emu_switch,.-emu_switch
 )");
 

@@ -642,14 +642,14 @@ def _shipped_arg_files():
     files = sorted(os.path.relpath(f, REF) for f in glob.glob(os.path.join(REF, "args", "*.txt")))
     # no agent (the viewer's kin_char scenes) / motion files that are not in the reference's repository
     files = [f for f in files if "play_motion" not in f and "_locomotion_args" not in f and "walk_punch" not in f]
-    return files if os.environ.get("DM_LIVE_SWEEP") == "all" else files[::9]
+    return files[::9] if os.environ.get("DM_LIVE_SWEEP") == "sample" else files
 
 
 @pytest.mark.parametrize("arg_file", _shipped_arg_files())
 def test_every_shipped_arg_file_live(emu_lib, monkeypatch, arg_file):
     """a short live session (2 resets x 3 control steps, every update checked) straight from the reference's own arg file: its parameters reach the compiled scene
-    through the scene's own ParseArgs and the device through this repo's loader.  Every ninth file by default, all 88 with DM_LIVE_SWEEP=all
-    (profiles/r05_live_sessions_every_arg_file.txt: all equal)"""
+    through the scene's own ParseArgs and the device through this repo's loader.  All 88 files that have their data (45 s of CPU; every ninth with
+    DM_LIVE_SWEEP=sample; profiles/r05_live_sessions_every_arg_file.txt)"""
     out = _run(_core_module(), emu_lib, ["--arg_file", arg_file], 7, monkeypatch, n_resets=2, steps=3)
     assert out["torques"] >= 60
 

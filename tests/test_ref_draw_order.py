@@ -440,8 +440,8 @@ def _run(mod, lib, args, seed, monkeypatch, n_resets, steps, precision="64", pos
                 rs.update_kin(dt)                 # (cSceneImitate::UpdateCharacters: before the world steps)
                 cmask = d["contacts"]
                 rs.set_char(d["pose"], d["vel"], fallen=bool(cmask & fall_bits))      # cSimCharacter::HasFallen: a fall-contact body touches something
-                if kind == 5:
-                    rs.set_ball(d["ball"][0:3])
+                if kind == 5:                     # position, rotation and velocities: the ball is a rigid body of the device's simulation, the scene only ever re-places it
+                    rs.set_ball_full(d["ball"][:13])
                 rs.update(dt)
                 r = rs.get()
                 if rs.per_update:                 # the kinematic character itself: the device's (clip, clip time, origin) through the host sampler vs cKinCharacter::GetPose as compiled
@@ -650,7 +650,8 @@ def test_every_shipped_arg_file_live(emu_lib, monkeypatch, arg_file):
     """a short live session (2 resets x 3 control steps, every update checked) straight from the reference's own arg file: its parameters reach the compiled scene
     through the scene's own ParseArgs and the device through this repo's loader.  All 88 files that have their data (45 s of CPU; every ninth with
     DM_LIVE_SWEEP=sample; profiles/r05_live_sessions_every_arg_file.txt)"""
-    out = _run(_core_module(), emu_lib, ["--arg_file", arg_file], 7, monkeypatch, n_resets=2, steps=3)
+    ev = lambda k, d: int(os.environ.get(k, d))          # a longer sweep off-line: DM_LIVE_SEED / DM_LIVE_RESETS / DM_LIVE_STEPS
+    out = _run(_core_module(), emu_lib, ["--arg_file", arg_file], ev("DM_LIVE_SEED", 7), monkeypatch, n_resets=ev("DM_LIVE_RESETS", 2), steps=ev("DM_LIVE_STEPS", 3))
     assert out["torques"] >= 60
 
 

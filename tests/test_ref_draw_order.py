@@ -650,8 +650,9 @@ def test_every_shipped_arg_file_live(emu_lib, monkeypatch, arg_file):
     """a short live session (2 resets x 3 control steps, every update checked) straight from the reference's own arg file: its parameters reach the compiled scene
     through the scene's own ParseArgs and the device through this repo's loader.  All 88 files that have their data (45 s of CPU; every ninth with
     DM_LIVE_SWEEP=sample; profiles/r05_live_sessions_every_arg_file.txt)"""
-    ev = lambda k, d: int(os.environ.get(k, d))          # a longer sweep off-line: DM_LIVE_SEED / DM_LIVE_RESETS / DM_LIVE_STEPS
-    out = _run(_core_module(), emu_lib, ["--arg_file", arg_file], ev("DM_LIVE_SEED", 7), monkeypatch, n_resets=ev("DM_LIVE_RESETS", 2), steps=ev("DM_LIVE_STEPS", 3))
+    ev = lambda k, d: int(os.environ.get(k, d))          # a longer sweep off-line: DM_LIVE_SEED / DM_LIVE_RESETS / DM_LIVE_STEPS / DM_LIVE_POLICY (action noise) / DM_LIVE_TEST (test mode)
+    out = _run(_core_module(), emu_lib, ["--arg_file", arg_file], ev("DM_LIVE_SEED", 7), monkeypatch, n_resets=ev("DM_LIVE_RESETS", 2), steps=ev("DM_LIVE_STEPS", 3),
+               policy_scale=float(os.environ.get("DM_LIVE_POLICY", 0.0)), test_mode=bool(ev("DM_LIVE_TEST", 0)))
     assert out["torques"] >= 60
 
 

@@ -31,7 +31,7 @@ def main():
     store = {}
     for key, (asset, args, seed, n_resets, steps, anneal) in T.GOLDEN_SESSIONS.items():
         rec = T.Recorder(T.RefSession(ref_lib.load("ref"), args(), seed))
-        T._run(mod, emu, args(), seed, Env(), n_resets=n_resets, steps=steps, anneal_at=anneal, tables=model.load_asset(asset), provider=rec, policy_scale=T.GOLDEN_POLICY_SCALE.get(key, 0.0),
+        T._run(mod, emu, args(), seed, Env(), n_resets=n_resets, steps=steps, anneal_at=anneal, tables=T.golden_tables(asset), provider=rec, policy_scale=T.GOLDEN_POLICY_SCALE.get(key, 0.0),
                pos_tol=1e-6 if key == "dribble" else 1e-9)
         rec.save(None, key, store)
         print(key, len(rec.tag), "calls logged")

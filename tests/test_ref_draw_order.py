@@ -36,7 +36,31 @@ GOLDEN_SESSIONS.update({
     "dribble": ("amp_dribble_zombie", lambda: ["--arg_file", "args/train_amp_dribble_humanoid3d_zombie_args.txt"], 12345, 8, 8, None),
     "getup": ("amp_heading_getup", lambda: ["--arg_file", "args/train_amp_heading_getup_humanoid3d_locomotion_getup_args.txt"], 99, 10, 8, {0: 64000000}),
 })
-GOLDEN_KINDS = {"heading4": 2, "strike": 4, "dribble": 5, "getup": 3}
+PERTURB_ARGS = ["--enable_rand_perturbs", "true", "--perturb_time_min", "0.05", "--perturb_time_max", "0.2", "--min_pertrub_duration", "0.02", "--max_perturb_duration", "0.08",
+                "--timer_type", "exp", "--time_lim_min", "0.3", "--time_lim_max", "2.0", "--time_lim_exp", "0.5", "--time_end_lim_min", "0.3", "--time_end_lim_max", "2.0",
+                "--time_end_lim_exp", "0.5"]
+
+
+def _perturb_tables():
+    """humanoid3d_walk under --scene imitate with PERTURB_ARGS (the packaged asset carries the arg file's values; the GPU box has no arg files)"""
+    from deepmimic_amd import model
+    t = model.load_asset("humanoid3d_walk")
+    c = t.cfg
+    c.enable_rand_perturbs = True; c.perturb_time_min = 0.05; c.perturb_time_max = 0.2; c.min_pertrub_duration = 0.02; c.max_perturb_duration = 0.08
+    c.timer_type = "exp"; c.time_lim_min = c.time_end_lim_min = 0.3; c.time_lim_max = c.time_end_lim_max = 2.0; c.time_lim_exp = c.time_end_lim_exp = 0.5
+    return t
+
+
+GOLDEN_SESSIONS.update({
+    "target": ("amp_target_zombie", lambda: ["--arg_file", "args/train_amp_target_humanoid3d_zombie_args.txt"], 5, 8, 8, None),
+    "perturb": (_perturb_tables, lambda: ["--arg_file", "args/run_humanoid3d_walk_args.txt"] + PERTURB_ARGS, 4242, 8, 10, None),
+})
+GOLDEN_KINDS = {"heading4": 2, "strike": 4, "dribble": 5, "getup": 3, "target": 1, "perturb": 6}
+
+
+def golden_tables(asset):
+    from deepmimic_amd import model
+    return asset() if callable(asset) else model.load_asset(asset)
 GOLDEN_POLICY_SCALE = {"getup": 1.0}          # (random actions: the character falls, recovery episodes happen)
 
 

@@ -24,6 +24,6 @@ def test_draw_tape_on_hip_kernels_equals_reference_log(hip_lib, monkeypatch, key
         if key in T.GOLDEN_POLICY_SCALE:
             pytest.skip("episodes of this session end in falls: an fp32 character does not fall at the update the logged fp64 one did")
         n_resets = 3      # the fp32 character drifts from the logged fp64 one: short, time-limited episodes only
-    T._run(T._core_module(), hip_lib, args(), seed, monkeypatch, n_resets=n_resets, steps=steps, anneal_at=anneal, tables=model.load_asset(asset),
+    T._run(T._core_module(), hip_lib, args(), seed, monkeypatch, n_resets=n_resets, steps=steps, anneal_at=anneal, tables=T.golden_tables(asset),
            provider=T.Replay(store, key, T.GOLDEN_KINDS[key], values=precision == "64"), precision=precision, exact=precision == "64", pos_tol=1e-6,
            policy_scale=T.GOLDEN_POLICY_SCALE.get(key, 0.0), val_tol=500.0)

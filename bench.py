@@ -63,18 +63,19 @@ def kernel_source_sha1():
         return None
 
 
-def measured_traffic(scene, n, kernel=None):
+def measured_traffic(scene, n, kernel=None, physics=1):
     """(HBM bytes per step-kernel launch, source file) from the committed rocprofv3 PMC passes (profiles/r0N_traffic*.json,
     collected as MI355X_MICROARCH.md prescribes: separate --pmc passes for FETCH_SIZE and WRITE_SIZE; tools/collect_profiles.py),
     newest round first; (None, None) when no profile of this workload is committed.  It is a committed counter measurement of
     the same workload and kernel, NOT a counter read of the run that prints it (PMC passes serialise the kernels): the bench
-    line names the file in `roofline.traffic_source`."""
+    line names the file in `roofline.traffic_source`.  The counter files are of the DM-physics v1 kernels unless they say `"physics": 2`: a v2 run
+    does not borrow them (its `traffic` is null)."""
     import glob
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic*.json")), reverse=True):
         try:
             with open(path) as f:
                 t = json.load(f)
-            if t.get("scene") == scene and int(t.get("envs", -1)) == n and (kernel is None or t.get("kernel", kernel) == kernel):
+            if t.get("scene") == scene and int(t.get("envs", -1)) == n and (kernel is None or t.get("kernel", kernel) == kernel) and int(t.get("physics", 1)) == physics:
                 measured_traffic.current = (t.get("kernel_source_sha1") == kernel_source_sha1()) if t.get("kernel_source_sha1") else None
                 return float(t["hbm_bytes_per_launch"]), os.path.relpath(path, ROOT)
         except Exception:
@@ -82,7 +83,7 @@ def measured_traffic(scene, n, kernel=None):
     return None, None
 
 
-def measured_valu(scene, n, kernel, env_steps_per_s):
+def measured_valu(scene, n, kernel, env_steps_per_s, physics=1):
     """The figures that actually bind this kernel (VALU issue + dependent-chain latency; HBM is ~0 by construction), from the committed
     rocprofv3 PMC passes of the same workload and kernel (profiles/r0N_pmc_sq*.json, r0N_flops*.json; newest round first): VALU busy
     fraction of SIMD time, the share of wave cycles spent in s_waitcnt, VALU instructions per env-step, and -- issued lane-flops per
@@ -94,7 +95,7 @@ def measured_valu(scene, n, kernel, env_steps_per_s):
         try:
             with open(path) as f:
                 t = json.load(f)
-            if t.get("scene") == scene and int(t.get("envs", -1)) == n and t.get("kernel", kernel) == kernel:
+            if t.get("scene") == scene and int(t.get("envs", -1)) == n and t.get("kernel", kernel) == kernel and int(t.get("physics", 1)) == physics:
                 out["valu_busy"] = t["derived"]["valu_busy_fraction_of_simd_time"]
                 out["source_current"] = (t.get("kernel_source_sha1") == kernel_source_sha1()) if t.get("kernel_source_sha1") else None
                 out["wait_fraction"] = t["SQ_WAIT_ANY"] / t["SQ_WAVE_CYCLES"]
@@ -107,7 +108,7 @@ def measured_valu(scene, n, kernel, env_steps_per_s):
         try:
             with open(path) as f:
                 t = json.load(f)
-            if t.get("scene") == scene and int(t.get("envs", -1)) == n and t.get("kernel", kernel) == kernel:
+            if t.get("scene") == scene and int(t.get("envs", -1)) == n and t.get("kernel", kernel) == kernel and int(t.get("physics", 1)) == physics:
                 out["issued_flops_per_env_step"] = t["issued_flops_per_env_step"]
                 out["issued_tflops"] = t["issued_flops_per_env_step"] * env_steps_per_s / 1e12
                 out["frac_of_fp32_peak"] = out["issued_tflops"] / 157.3
@@ -634,11 +635,11 @@ def main():
         achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else None      # (the emulator has no HIP events)
         # committed counter passes are taken with --groups 1 (a PMC pass serialises the kernels: a half-batch launch alone on the chip would be
         # another regime); HBM bytes are per env, so the per-launch figure of a group is the whole-batch one scaled by its share of the envs
-        traffic, traffic_source = measured_traffic(args.scene, n, kname)
+        traffic, traffic_source = measured_traffic(args.scene, n, kname, physics=args.physics)
         if traffic is not None:
             traffic = traffic * envs_per_launch / n
         value = world * n * args.steps / elapsed
-        valu_obj = measured_valu(args.scene, n, kname, value) or {"binding": "VALU issue + dependent-chain latency (fp32 vector)", "source": []}
+        valu_obj = measured_valu(args.scene, n, kname, value, physics=args.physics) or {"binding": "VALU issue + dependent-chain latency (fp32 vector)", "source": []}
         if on_gpu:
             try:
                 # kernel family of dm_kernels.cpp this workload launches (deepmimic_amd/csrc/Makefile KIDS): plain / AMP-or-perturbation / v2 instantiation of the

@@ -696,7 +696,10 @@ class SharedEnv:
         return self._full()["aux"].copy()
 
     def get_clips(self):
-        return self._full()["clip"][:, 0].astype(np.int32)
+        st = self._full()
+        if "clip" not in st:               # a scene without a goal row runs its one clip (BatchEnv.get_clips says 0 there as well)
+            return np.zeros(1, np.int32)
+        return st["clip"][:, 0].astype(np.int32)
 
     def get_obj_state(self):
         return self._full()["obj"].copy()

@@ -457,7 +457,7 @@ def _run(mod, lib, args, seed, monkeypatch, n_resets, steps, precision="64", pos
                     tau_ref = pc.clamp_tau(t, rs.spd_tau(dt, env.P))[dof_idx]
                 core.Update(dt)
                 d = _dev(core)
-                if live:
+                if live and hasattr(env, "debug"):          # (the debug taps are a private context's; a slot of the shared owner has none)
                     tau_dev = env.debug("tau")[0]
                     assert np.abs(tau_dev - tau_ref).max() < 1e-7 * max(1.0, np.abs(tau_ref).max()), ("episode %d update %d" % (ep, k), "stable-PD torque", int(np.argmax(np.abs(tau_dev - tau_ref))), np.abs(tau_dev - tau_ref).max())
                     n_tau += 1
@@ -504,7 +504,33 @@ def _run(mod, lib, args, seed, monkeypatch, n_resets, steps, precision="64", pos
                 assert np.abs(a - b).max() < (1e-4 if exact else 2e-3), ("expert sample", np.abs(a - b).max())
     finally:
         rs.close()
-    return {"perturbations": n_pert, "recoveries": n_rec, "rewards": n_rew, "amp_obs": n_amp, "torques": n_tau, "time_warp": n_warp}
+        kind_of_env = type(env).__name__
+        if hasattr(env, "close") and kind_of_env == "SharedEnv":      # leave the owner's slot now (the owner goes when its last worker has left)
+            env.close()
+    return {"perturbations": n_pert, "recoveries": n_rec, "rewards": n_rew, "amp_obs": n_amp, "torques": n_tau, "time_warp": n_warp, "env": kind_of_env}
+
+
+@pytest.mark.parametrize("name", ["heading4", "dribble", "perturb"])
+def test_live_session_behind_the_shared_owner(emu_lib, monkeypatch, name):
+    """the drop-in behind `DM_FACADE_SHARED=1` (deepmimic_amd/broker.py: the worker is a slot of the owner process's context, its draw tape travels with its
+    requests) against the compiled scenes directly -- not only through "shared = private" (tests/test_broker.py) and "private = reference" (the tests below)"""
+    import glob
+    import time
+    asset, args, seed, n_resets, steps, anneal = GOLDEN_SESSIONS[name]
+    shm = "dm_live_%s_%d" % (name, os.getpid())
+    monkeypatch.setenv("DM_FACADE_SHARED", "1"); monkeypatch.setenv("DM_FACADE_SHM", shm); monkeypatch.setenv("DM_FACADE_SHARED_MAX", "4")
+    try:
+        out = _run(_core_module(), emu_lib, args(), seed, monkeypatch, n_resets=4, steps=steps, pos_tol=1e-6 if name == "dribble" else 1e-9)
+        assert out["env"] == "SharedEnv" and out["rewards"] >= 20, out
+        assert name != "perturb" or out["perturbations"] >= 4, out
+    finally:
+        t_end = time.monotonic() + 45
+        while os.path.exists("/dev/shm/" + shm) and time.monotonic() < t_end:
+            time.sleep(0.2)
+        gone = not os.path.exists("/dev/shm/" + shm)
+        for f in glob.glob("/dev/shm/%s.*" % shm):
+            os.unlink(f)
+    assert gone, "the owner process did not leave"
 
 
 def test_heading_amp_four_clips(emu_lib, monkeypatch):

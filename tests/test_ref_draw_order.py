@@ -510,7 +510,7 @@ def _run(mod, lib, args, seed, monkeypatch, n_resets, steps, precision="64", pos
     return {"perturbations": n_pert, "recoveries": n_rec, "rewards": n_rew, "amp_obs": n_amp, "torques": n_tau, "time_warp": n_warp, "env": kind_of_env}
 
 
-@pytest.mark.parametrize("name", ["heading4", "dribble", "perturb"])
+@pytest.mark.parametrize("name", ["heading4", "dribble", "perturb", "getup", "strike", "target"])
 def test_live_session_behind_the_shared_owner(emu_lib, monkeypatch, name):
     """the drop-in behind `DM_FACADE_SHARED=1` (deepmimic_amd/broker.py: the worker is a slot of the owner process's context, its draw tape travels with its
     requests) against the compiled scenes directly -- not only through "shared = private" (tests/test_broker.py) and "private = reference" (the tests below)"""
@@ -520,7 +520,8 @@ def test_live_session_behind_the_shared_owner(emu_lib, monkeypatch, name):
     shm = "dm_live_%s_%d" % (name, os.getpid())
     monkeypatch.setenv("DM_FACADE_SHARED", "1"); monkeypatch.setenv("DM_FACADE_SHM", shm); monkeypatch.setenv("DM_FACADE_SHARED_MAX", "4")
     try:
-        out = _run(_core_module(), emu_lib, args(), seed, monkeypatch, n_resets=4, steps=steps, pos_tol=1e-6 if name == "dribble" else 1e-9)
+        out = _run(_core_module(), emu_lib, args(), seed, monkeypatch, n_resets=4, steps=steps, pos_tol=1e-6 if name == "dribble" else 1e-9, anneal_at=anneal,
+                   policy_scale=GOLDEN_POLICY_SCALE.get(name, 0.0))
         assert out["env"] == "SharedEnv" and out["rewards"] >= 20, out
         assert name != "perturb" or out["perturbations"] >= 4, out
     finally:

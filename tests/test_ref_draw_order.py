@@ -534,6 +534,15 @@ def test_live_session_behind_the_shared_owner(emu_lib, monkeypatch, name):
     assert gone, "the owner process did not leave"
 
 
+@pytest.mark.parametrize("name", ["heading4", "perturb", "dribble"])
+def test_live_session_on_the_v2_kernels(emu_lib, monkeypatch, name):
+    """`DM_PHYSICS=2`: the draw tape and the DeepMimic-side arithmetic in the V2 instantiations of the kernels (another kernel family each; the ball under v2 is family 23)"""
+    asset, args, seed, n_resets, steps, anneal = GOLDEN_SESSIONS[name]
+    monkeypatch.setenv("DM_PHYSICS", "2")
+    out = _run(_core_module(), emu_lib, args(), seed, monkeypatch, n_resets=4, steps=steps, anneal_at=anneal, pos_tol=1e-6 if name == "dribble" else 1e-9)
+    assert out["rewards"] >= 20 and out["torques"] >= 400, out
+
+
 def test_heading_amp_four_clips(emu_lib, monkeypatch):
     """heading_amp over a 4-clip dataset, 20 resets x 10 control steps: clip by weight, clip time over the PREVIOUS clip's duration, yaw, target timer,
     sharp / Gaussian heading steps, speed changes"""

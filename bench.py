@@ -330,28 +330,43 @@ def latency_ceiling(tables, args, device_id, kname, family_id):
             "wave_slots": slots, "envs_per_wave": epw, "env_steps_per_s": slots * epw / (ms * 1e-3)}
 
 
-def parity_check(tables, envs, step_and_read, n_sample=64, steps=5):
+def parity_check(tables, envs, step_and_read, n_sample=64, steps=5, physics=1, actions=None, prepared=None):
     """`checks.parity` of the bench line: `n_sample` strided envs of THIS run's contexts -- where the timed rollout left them, the same step function, the same
     launches (every wave slot occupied, both groups in flight) -- compared with the CPU oracle over `steps` control steps.  Before each step the oracles are put
-    where the device envs are (get_state -> Oracle.set_full_state), so every sample is one control step (20 updates, 40 substeps) from identical inputs; nothing
-    is written to the device.  The oracle is the CHECKER here (tests/parity_common.sampled_compare), after and outside every timed region.
+    where the device envs are (get_state -> Oracle.set_full_state; DM-physics v2: the persistent ground manifolds too, get_manifolds -> Oracle.set_manifolds, and the
+    oracles run the v2 restatement), so every sample is one control step (20 updates, 40 substeps) from identical inputs; nothing is written to the device.
+    actions (the closed-loop leg): a callable (k, st0) -> [N, A] float32 actions of step k; the step function then takes them (cDeepMimicCore::SetAction at the action boundary).
+    The oracle is the CHECKER here (tests/parity_common.sampled_compare), after and outside every timed region.
     Rows: reward scenes/SceneImitate.cpp:7-127, flags scenes/RLSceneSimChar.cpp, via the oracle."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import parity_common as pc
     n = envs.N
     ids = np.unique(np.round(np.linspace(0, n - 1, n_sample)).astype(np.int64))
-    dr, ds, alive, ok, ends = pc.sampled_compare(envs.get_state, step_and_read, tables, ids, steps)
+    mc = envs.envs[0].max_contacts if physics == 2 else None
+    fb = [envs.debug("fallback"), np.zeros(n)]
+
+    def on_step(k, st0, out):
+        f = envs.debug("fallback"); fb[1] = fb[1] + (f - fb[0]); fb[0] = f
+
+    dr, ds, alive, ok, ends = pc.sampled_compare(envs.get_state, step_and_read, tables, ids, steps, physics=physics, get_manifolds=envs.get_manifolds if physics == 2 else None,
+                                                 max_contacts=mc, actions=actions, on_step=on_step)
     live = dr[alive]
     sl = ds[alive & np.isfinite(ds)]
     q = lambda a, p_: (float(np.quantile(a, p_)) if a.size else None)
     return {"envs": int(ids.size), "steps": int(steps), "samples": int(dr.size), "live": int(alive.sum()), "episode_ends": int(ends),
             "reward_mae": (float(live.mean()) if live.size else None), "reward_p99": q(live, 0.99), "reward_max": (float(live.max()) if live.size else None),
             "reward_max_not_live": float(dr[~alive].max(initial=0.0)), "state_rel_mean": (float(sl.mean()) if sl.size else None), "state_rel_max": (float(sl.max()) if sl.size else None),
-            "flags_equal": bool(ok), "against": "oracle (fp64), re-synchronised from the device state before every control step; live = oracle reward != 0"}
+            "flags_equal": bool(ok),
+            # pair-substeps of the WHOLE batch that ran on the 64-lane fallback of the two-per-wave kernel during these steps (dm_get_debug "fallback": both characters of a pair count one), and
+            # how many of the sampled envs were among them
+            "fallback_share": float(fb[1].sum() / 2 / max(1, (n // 2) * 40 * steps)), "sampled_envs_with_fallback_substeps": int((fb[1][ids] > 0).sum()),
+            "against": "oracle (fp64%s), re-synchronised from the device state before every control step; live = oracle reward != 0" % (", DM-physics v2 with the device's manifolds" if physics == 2 else "")}
 
 
-def closed_loop(envs, stream_handles, dev, steps):
-    """policy(g) -> control step(g) on each group's stream, `steps` times; one Policy object per group (its activation buffers are per object)"""
+def closed_loop(envs, stream_handles, dev, steps, tables=None, parity_envs=0, parity_steps=5, physics=1):
+    """policy(g) -> control step(g) on each group's stream, `steps` times; one Policy object per group (its activation buffers are per object).
+    parity_envs > 0: behind the timed loop, `parity_steps` more steps of the same loop with sampled envs checked against the oracle fed the policy's actions
+    (`closed_loop.parity`: the learner's entry -- explicit actions on the state distribution the policy makes, fallback pairs included)."""
     import torch
     from deepmimic_amd.policy import Policy, random_weights
     env, n = envs.envs[0], envs.N
@@ -368,22 +383,46 @@ def closed_loop(envs, stream_handles, dev, steps):
     for g in range(envs.G):
         envs.step_group_device(g, 0, *ptrs, n_updates=0)            # RecordState of wherever the rollout left the envs
 
+    def act(k, g):
+        o = envs.start[g]
+        pols[g].forward_device(st.data_ptr() + 4 * o * env.S, envs.count[g], ac.data_ptr() + 4 * o * env.A, 0, sample=True, seed=1, step=k,
+                               env_id_offset=envs.first[g], stream=stream_handles[g])
+
     def loop(k0, k1):
         for k in range(k0, k1):
             for g in range(envs.G):
-                o = envs.start[g]
-                pols[g].forward_device(st.data_ptr() + 4 * o * env.S, envs.count[g], ac.data_ptr() + 4 * o * env.A, 0, sample=True, seed=1, step=k,
-                                       env_id_offset=envs.first[g], stream=stream_handles[g])
+                act(k, g)
                 envs.step_group_device(g, ac.data_ptr(), *ptrs, timestep=1.0 / 600, n_updates=20, auto_reset=True)
 
     warm = 60                  # two policy-driven episode lengths: the mixture of standing / tumbling / freshly reset characters the policy produces, not the transient behind the open-loop rollout
     loop(0, warm)
-    envs.synchronize(); torch.cuda.synchronize(); t0 = time.perf_counter()
+    envs.synchronize(); torch.cuda.synchronize()
+    fb0 = envs.debug("fallback").sum()
+    t0 = time.perf_counter()
     loop(warm, warm + steps)
     envs.synchronize(); torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    fb1 = envs.debug("fallback").sum()
     res = {"value": n * steps / dt, "unit": "env-steps/s", "steps": steps, "ms_per_step": 1e3 * dt / steps, "groups": envs.G,
            "policy": "%d -> 1024 -> 512 -> %d, random init, sampled (dm_policy_forward: one launch per group and step, k_policy_fused, bf16 MFMA)" % (env.S, env.A), "warmup_steps": warm,
-           "mean_reward": float(rw.mean().item()), "finite": bool(torch.isfinite(st).all().item())}
+           "mean_reward": float(rw.mean().item()), "finite": bool(torch.isfinite(st).all().item()),
+           # share of the pair-substeps of the timed loop that ran on the 64-lane fallback of the two-per-wave kernel (a character beyond 32 constraint rows)
+           "fallback_share": float((fb1 - fb0) / 2 / max(1, (n // 2) * 40 * steps))}
+    if parity_envs > 0 and tables is not None:
+        try:
+            def actions_of(k, st0):
+                for g in range(envs.G):
+                    act(warm + steps + k, g)
+                envs.synchronize(); torch.cuda.synchronize()
+                return ac.cpu().numpy()
+
+            def step_and_read(acts):                                  # (`acts` are already in `ac` on the device)
+                for g in range(envs.G):
+                    envs.step_group_device(g, ac.data_ptr(), *ptrs, timestep=1.0 / 600, n_updates=20, auto_reset=True)
+                envs.synchronize(); torch.cuda.synchronize()
+                return {"state": st.cpu().numpy(), "reward": rw.cpu().numpy(), "terminate": tm.cpu().numpy(), "valid": vd.cpu().numpy(), "episode_end": en.cpu().numpy()}
+            res["parity"] = parity_check(tables, envs, step_and_read, parity_envs, parity_steps, physics=physics, actions=actions_of)
+        except Exception as ex:                                       # noqa: BLE001
+            res["parity"] = {"error": "%s: %s" % (type(ex).__name__, ex)}
     for p in pols:
         p.close()
     return res
@@ -567,19 +606,34 @@ def main():
     # a record exchange every rank takes the same steps
     parity = None
     if not args.no_parity_check:
+        taken = [0]
+
         def step_and_read():
-            one_step(); drain(); dev_sync()
+            one_step(); taken[0] += 1; drain(); dev_sync()
             vs = [exs[g].views((tick[0] - 1) & 1) for g in range(len(exs))]
             return {"state": torch.cat([v[0] for v in vs]).cpu().numpy(), "reward": torch.cat([v[1] for v in vs]).cpu().numpy(),
                     "terminate": torch.cat([v[2] for v in vs]).cpu().numpy(), "valid": valid.cpu().numpy(), "episode_end": ends.cpu().numpy()}
-        try:
-            if rank == 0:
-                parity = parity_check(tables, envs, step_and_read, args.parity_envs, args.parity_steps)
-            else:
-                for _ in range(args.parity_steps):
-                    step_and_read()
-        except Exception as ex:                                     # noqa: BLE001  (reported, never silently dropped)
-            parity = {"error": "%s: %s" % (type(ex).__name__, ex)}
+        # every rank takes EXACTLY parity_steps steps (each is a collective with a record exchange), whatever happens to the comparison on rank 0: rank 0 builds the
+        # oracle first and tells the others whether the check runs at all; if its comparison fails midway it takes the remaining steps before reporting
+        go = 1
+        if rank == 0:
+            try:
+                sys.path.insert(0, os.path.join(ROOT, "tests"))
+                import oracle_lib
+                oracle_lib.build("all")
+            except Exception as ex:                                 # noqa: BLE001
+                go = 0; parity = {"error": "oracle build failed: %s: %s" % (type(ex).__name__, ex)}
+        if world > 1:
+            gt = torch.tensor([go], dtype=torch.int32, device=dev)
+            dist.broadcast(gt, src=0); go = int(gt.item())
+        if go:
+            try:
+                if rank == 0:
+                    parity = parity_check(tables, envs, step_and_read, args.parity_envs, args.parity_steps, physics=args.physics)
+            except Exception as ex:                                 # noqa: BLE001  (reported, never silently dropped)
+                parity = {"error": "%s: %s" % (type(ex).__name__, ex)}
+            while taken[0] < args.parity_steps:                     # ranks > 0: all of them; rank 0: what an exception left
+                step_and_read()
 
     # a sustained window behind the --steps region: >= sustain-seconds of back-to-back control steps (same step function, same exchange), so
     # that the line also carries a rate measured over seconds (DVFS settled, visible to an outside GPU-busy sampler) next to the short one
@@ -621,7 +675,8 @@ def main():
     closed = None
     if on_gpu and world == 1 and not args.no_closed_loop and not gather:
         try:
-            closed = closed_loop(envs, [s.cuda_stream for s in gstreams] if G > 1 else [0], dev, min(max(args.steps, 200), 1000))      # >= 200 steps whatever --steps: a 20-step window is a transient
+            closed = closed_loop(envs, [s.cuda_stream for s in gstreams] if G > 1 else [0], dev, min(max(args.steps, 200), 1000),      # >= 200 steps whatever --steps: a 20-step window is a transient
+                                 tables=tables, parity_envs=(0 if args.no_parity_check else args.parity_envs), parity_steps=args.parity_steps, physics=args.physics)
         except Exception as ex:                                     # noqa: BLE001
             closed = {"error": "%s: %s" % (type(ex).__name__, ex)}
 

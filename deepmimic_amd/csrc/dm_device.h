@@ -447,6 +447,8 @@ struct EnvSim {
     // read-modify-write of `prof` at every mark stalled the wave for a memory round trip per mark and inflated every phase (round 4)
     long long* prof = nullptr; long long tprev = 0; long long pacc[16];
     DM_DEV EnvSim(const ModelDev<Real>& m_, L& s_, int l_) : m(m_), s(s_), l(l_) {}
+    // wave priority inside substep_post: never below the class's floor (C::PRIO_FLOOR; the fallback class of the two-per-wave kernel runs raised throughout)
+    static constexpr int prio_of(int p) { return p > C::PRIO_FLOOR ? p : C::PRIO_FLOOR; }
     DM_DEV void mark(int phase) {
         if (TAPS && prof) {
             const long long t = dm_clock(), d = t - tprev; tprev = t;
@@ -1435,7 +1437,7 @@ struct EnvSim {
         if (C::OBJ && ball_sg != 0) { mu_row = m.ball_friction; jbl = (Real)ball_sg * dd; jba = (Real)ball_sg * cross(ball_cx - bpos, dd); }
         // y := L^-1 J_l^T in registers (static indices; dof records and L rows are wave-uniform LDS broadcasts)
         R2 y2[NP2X]; Real cvec = 0;
-        dm_setprio<DM_PRIO_ONE_Y>();
+        dm_setprio<prio_of(DM_PRIO_ONE_Y)>();
         if constexpr (C::TREE) {
             // H = L^T L: y = L^-T J^T runs from the last dof down, against COLUMN k of L (wave-uniform broadcasts); only the pairs that
             // hold a descendant of k are touched (744 multiply-adds per row for dog3d instead of 2 016)
@@ -1491,7 +1493,7 @@ struct EnvSim {
             y2[k >> 1][k & 1] = yk;
         }
         }
-        dm_setprio<0>();
+        dm_setprio<prio_of(0)>();
         if (C::OBJ) {
             // the free body's block of the mass matrix is diagonal: its rows of Y = M^-1/2 J^T are a scaling; J v* gains its share
             cvec += dot(jbl, bvs) + dot(jba, bws);
@@ -1579,7 +1581,7 @@ struct EnvSim {
 #if DM_PRIO
             // wave priority by load for the duration of the sweep (see DuoSim::substep_post; dog3d +1.6 %): thresholds at the median / p90 row count of the class
             { constexpr int PLO = (ND > 34) ? 28 : 16, PHI = (ND > 34) ? 40 : 22;
-              if (Rv > PHI) dm_setprio<3>(); else if (Rv > PLO) dm_setprio<2>(); else dm_setprio<1>(); }
+              if (Rv > PHI) dm_setprio<3>(); else if (Rv > PLO) dm_setprio<prio_of(2)>(); else dm_setprio<prio_of(1)>(); }
 #endif
             for (int it = 0; it < m.solver_iters; ++it) {
                 DM_OPAQUE_S(Rv); DM_OPAQUE_S(RNv); DM_OPAQUE_V(lv);
@@ -1607,7 +1609,7 @@ struct EnvSim {
             }
             if (l >= R) lam = 0;
         } else mark(10);
-        dm_setprio<DM_PRIO_ONE_BACK>();
+        dm_setprio<prio_of(DM_PRIO_ONE_BACK)>();
         mark(11);
         if (TAPS && dbg.lambda) { dbg.lambda[(size_t)e * kMaxRows + l] = lam; if (l < 2) dbg.rows[(size_t)e * 2 + l] = s.flg[FLG_NROWS + l]; }
         // delta v = L^-T (Y lambda): transposing wave reduction of y_r[k] lambda_r, dof k's total lands in lane k
@@ -1652,7 +1654,7 @@ struct EnvSim {
         sync();
         integrate(h);
         sync();
-        dm_setprio<0>();
+        dm_setprio<prio_of(0)>();
         mark(12);
     }
 

@@ -803,16 +803,29 @@ _Pragma("unroll") \
                 b.spd_clamp();
             } else if (!substep_post<V2>(h, V2 ? manif_pair + (size_t)half * m.J * MF_STRIDE : nullptr)) {
                 // more than 32 rows somewhere in the pair: one character at a time through the 64-lane routine
+                if (FallbackCls::PRIO_FLOOR > 0) dm_setprio<FallbackCls::PRIO_FLOOR>();
+                if (hl == 0) s.kin[7] += (Real)1;            // statistic (round 6): substeps this env spent on the fallback, in the pad word of its kin row (dm_get_debug "fallback")
                 for (int x = 0; x < 2; ++x) {
                     int wlv = wl; DM_OPAQUE_V(wlv);          // keeps this rare path's address arithmetic out of the hot loop's live ranges
                     Single one(m, reinterpret_cast<WideRec&>(rec[x]), wlv);
                     one.li = (wlv < m.J) ? rec[x].mdl.link_info[wlv] : 0;
                     one.load_cands();
                     DebugTaps<Real> none = DebugTaps<Real>();
+                    if (TAPS && b.prof) {                // profiling build: the 64-lane routine's marks count into this wave's phase totals (phases 7..12 of the fallback substep)
+                        one.prof = b.prof; one.tprev = b.tprev;
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) one.pacc[i] = 0;
+                    }
                     // (V2: the two-per-wave pass above has already refreshed this character's manifolds and stored its ground slots -- the 64-lane routine takes them as they are)
                     one.template substep_post<V2, false>(h, none, e, (FallbackCls::RREG < kMaxRows && aovf_pair) ? aovf_pair + (size_t)x * (kMaxRows - FallbackCls::RREG) * kWave : nullptr,
                                                          V2 ? manif_pair + (size_t)x * m.J * MF_STRIDE : nullptr, V2 ? rec[x].flg[FLG_NCONT] : -1);
+                    if (TAPS && b.prof) {
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) b.pacc[i] += one.pacc[i];
+                        b.tprev = one.tprev;
+                    }
                 }
+                if (FallbackCls::PRIO_FLOOR > 0) dm_setprio<0>();
             }
         }
         if (hl == 0) {

@@ -446,6 +446,7 @@ struct CtxT : CtxBase {
         st.pose = (Real*)dalloc(sizeof(Real) * N * h.P); st.vel = (Real*)dalloc(sizeof(Real) * N * h.P); st.tar = (Real*)dalloc(sizeof(Real) * N * h.P);
         st.tau = (Real*)dalloc(sizeof(Real) * N * h.D); st.kin = (Real*)dalloc(sizeof(Real) * N * 8);
         st.clock = (double*)dalloc(sizeof(double) * N * 6); st.flag = (int*)dalloc(sizeof(int) * N * 4);
+        if (st.kin) rt_memset(st.kin, 0, sizeof(Real) * (size_t)N * 8, stream);      // word 7 of a kin row is the env's fallback-substep counter (two-per-wave kernel), never reset by the device
         // overflow rows of the constraint-space matrix (rows RREG..63 of a character with more than RREG rows in a substep)
         { const int ovf = kMaxRows - ((cls == 0 || cls == 2 || cls == 4) ? ClsBiped::RREG : ClsLarge::RREG); st.aovf = ovf > 0 ? (Real*)dalloc(sizeof(Real) * (size_t)N * ovf * kWave) : nullptr; }
         st.obj = nullptr;
@@ -807,6 +808,11 @@ struct CtxT : CtxBase {
     int get_debug(const char* name, double* out) override {
         const size_t n = N; const HostModel& h = hm; std::string s(name);
         if (s == "tau") return dl(st.tau, n * h.D, out);
+        if (s == "fallback") {      // N: substeps the env's pair ran on the 64-lane fallback of the two-per-wave kernel since dm_create / the last dm_set_state (0 for the one-per-wave kernels)
+            std::vector<double> t8(n * 8); if (dl(st.kin, n * 8, t8.data())) return -1;
+            for (size_t e = 0; e < n; ++e) out[e] = t8[e * 8 + 7];
+            return 0;
+        }
         if (!dbg.H) return fail("no debug taps recorded yet (call dm_probe first)");
         if (s == "H") return dl(dbg.H, n * h.D * h.D, out);
         if (s == "C") return dl(dbg.C, n * h.D, out);

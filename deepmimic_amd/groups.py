@@ -89,6 +89,13 @@ class EnvGroups:
         parts = [e.get_state() for e in self.envs]
         return {k: np.concatenate([p[k] for p in parts], axis=0) for k in parts[0]}
 
+    def debug(self, name: str):
+        """`BatchEnv.debug` of every group, rows concatenated in env order (e.g. "fallback": the per-env fallback-substep counters)"""
+        return np.concatenate([e.debug(name) for e in self.envs], axis=0)
+
+    def get_manifolds(self):
+        return np.concatenate([e.get_manifolds() for e in self.envs], axis=0)
+
     def bench_rollout(self, warmup: int, steps: int, **kw) -> float:
         """Fixed-action rollout of every group, each from its own host thread through the C loop (`dm_bench_rollout`, ctypes drops the
         GIL), all released together; returns the wall-clock milliseconds from the common start to the last group's end."""

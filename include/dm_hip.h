@@ -261,7 +261,11 @@ int dm_set_state(dm_ctx* ctx, const double* pose, const double* vel, const doubl
 /* Component taps used by the parity tests (no reference analogue): what = 0 SPD torque, 1 one rigid-body
  * substep of length `dt` with the latched torque, 2 SPD-model mass matrix / bias force.
  * After the call dm_get_debug copies the requested tap: name in {"H","C","vstar","lambda","rows","tau",
- * "kin_pose","kin_vel","reward_terms","links"}; out must hold the full N x ... array of doubles. */
+ * "kin_pose","kin_vel","reward_terms","links"}; out must hold the full N x ... array of doubles.
+ * "tau" and "fallback" need no dm_probe.  "fallback" (N doubles): the number of rigid-body substeps the env has spent on
+ * the 64-lane fallback of the two-characters-per-wavefront kernel (a pair of which one character had more than 32
+ * constraint rows in that substep; both characters count it) since dm_create or the last dm_set_state -- a statistic
+ * of the production kernels, kept in the pad word of the env's kin row; 0 on the one-character-per-wavefront kernels. */
 int dm_probe(dm_ctx* ctx, int what, double dt);
 int dm_set_tau(dm_ctx* ctx, const double* tau /* N x D, generalized-velocity layout */);
 int dm_get_debug(dm_ctx* ctx, const char* name, double* out);

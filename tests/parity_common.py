@@ -551,23 +551,34 @@ def goal_rollout_compare(t, precision, lib_path, steps, n, seed, wave_packing=0,
 # so each comparison checks one control step (20 updates, 40 substeps) of the production launch -- every wave slot of the chip occupied, high
 # block indices, two contexts on two streams -- from identical inputs, on states the device itself reached.  Nothing is written to the device.
 class OracleSample:
-    def __init__(self, tables, ids, variant=""):
+    def __init__(self, tables, ids, variant="", physics=1, max_contacts=None):
         self.ids = np.asarray(ids, dtype=np.int64)
-        self.oracles = [Oracle(tables, variant=variant) for _ in self.ids]
+        self.physics = int(physics)
+        # DM-physics v2 (round 6): the oracles run the v2 restatement too and carry the device's persistent ground manifolds (sync(st, manif))
+        kw = {} if self.physics == 1 else dict(physics=self.physics, **({} if max_contacts is None else dict(max_contacts=int(max_contacts))))
+        self.oracles = [Oracle(tables, variant=variant, **kw) for _ in self.ids]
 
-    def sync(self, st):
-        """st = get_state() of the WHOLE batch (rows = envs)"""
+    def sync(self, st, manif=None):
+        """st = get_state() of the WHOLE batch (rows = envs); manif = get_manifolds() of the whole batch (physics 2: without it the oracle's
+        manifolds would be those its own trajectory left, not the device's)"""
+        if self.physics == 2 and manif is None:
+            raise ValueError("physics 2: the oracle needs the device's manifolds (BatchEnv.get_manifolds) next to its state")
         for o, i in zip(self.oracles, self.ids):
             o.set_full_state(st["pose"][i], st["vel"][i], st["tar"][i], st["kin"][i], st["clocks"][i], st["flags"][i])
+            if manif is not None:
+                o.set_manifolds(manif[i])
 
-    def control_step(self, n_updates=20, dt=DT):
-        """open-loop tracking (stream A1) with the driver's end-of-episode rule; returns per sampled env
-        reward, terminate, valid, episode_end, state vector (of the env as the step left it: BEFORE any reset)"""
+    def control_step(self, n_updates=20, dt=DT, actions=None):
+        """actions None: open-loop tracking (stream A1); else [len(ids), A] explicit actions (float32-rounded, as they cross the boundary), set before the first
+        update of the step like cDeepMimicCore::SetAction at the action boundary (env/deepmimic_env.py:88).  The driver's end-of-episode rule either way; returns per
+        sampled env reward, terminate, valid, episode_end, state vector (of the env as the step left it: BEFORE any reset)"""
         n = len(self.oracles)
         r, tm, vd, en, st = np.zeros(n), np.zeros(n, np.int32), np.zeros(n, np.int32), np.zeros(n, np.int32), []
         for k, o in enumerate(self.oracles):
+            if actions is not None:
+                o.set_action(np.asarray(actions[k], dtype=np.float32).astype(np.float64))
             for u in range(n_updates):
-                if o.need_new_action():                  # the device's open-loop stream encodes the kinematic pose at whichever update latches an action
+                if actions is None and o.need_new_action():   # the device's open-loop stream encodes the kinematic pose at whichever update latches an action
                     kp, _, _ = o.kin_state()
                     o.set_action(o.pose_to_action(kp))
                 o.update(dt)
@@ -578,25 +589,31 @@ class OracleSample:
         return r, tm, vd, en, np.array(st)
 
 
-def sampled_compare(get_state, step, tables, ids, steps, conditioning=False):
+def sampled_compare(get_state, step, tables, ids, steps, conditioning=False, actions=None, physics=1, get_manifolds=None, max_contacts=None, on_step=None):
     """`steps` control steps of a device batch (step() -> dict of whole-batch host arrays, auto-reset on) with the sampled envs `ids`
     compared against oracles re-synchronised from the device before each step.  Returns |reward diff|, relative max |state diff| (NaN on
     steps whose env was auto-reset: the device's observation is then the first of the new episode), live mask (steps x len(ids)), flags ok, #episode ends seen.
     conditioning=True adds a sixth array: |reward(fp64 oracle) - reward(the oracle's own fp32 build)| from the SAME synchronised state -- a control step on
-    which the restatement itself, narrowed to float, misses its fp64 self is ill-conditioned in single precision (fp32_step_sensitivity above)."""
-    smp = OracleSample(tables, ids)
-    s32 = OracleSample(tables, ids, variant="f32") if conditioning else None
+    which the restatement itself, narrowed to float, misses its fp64 self is ill-conditioned in single precision (fp32_step_sensitivity above).
+    actions (round 6: the learner's entry, cDeepMimicCore::SetAction -> dm_step_batch(actions)): a callable (k, st0) -> [N, A] float32 actions of control step k
+    for the WHOLE batch (st0 = the get_state() the oracles are synchronised from); step is then called as step(acts) and the oracles are fed rows `ids`.
+    physics 2: get_manifolds() of the whole batch travels with the state.  on_step(k, st0, out): a hook behind every step (e.g. fallback counters)."""
+    smp = OracleSample(tables, ids, physics=physics, max_contacts=max_contacts)
+    s32 = OracleSample(tables, ids, variant="f32", physics=physics, max_contacts=max_contacts) if conditioning else None
     n = len(smp.ids)
     dr, ds, alive, ok, ends = np.zeros((steps, n)), np.full((steps, n), np.nan), np.zeros((steps, n), dtype=bool), True, 0
     d32 = np.zeros((steps, n))
     for k in range(steps):
         st0 = get_state()
-        smp.sync(st0)
-        out = step()
-        r, tm, vd, en, so = smp.control_step()
+        mf0 = get_manifolds() if (physics == 2 and get_manifolds is not None) else None
+        smp.sync(st0, mf0)
+        acts = None if actions is None else np.ascontiguousarray(actions(k, st0), dtype=np.float32)
+        out = step() if acts is None else step(acts)
+        a_s = None if acts is None else acts[smp.ids]
+        r, tm, vd, en, so = smp.control_step(actions=a_s)
         if s32 is not None:
-            s32.sync(st0)
-            d32[k] = np.abs(s32.control_step()[0] - r)
+            s32.sync(st0, mf0)
+            d32[k] = np.abs(s32.control_step(actions=a_s)[0] - r)
         for j, i in enumerate(smp.ids):
             dr[k, j] = abs(float(out["reward"][i]) - r[j]); alive[k, j] = r[j] != 0.0
             ok &= int(out["terminate"][i]) == tm[j] and int(out["valid"][i]) == vd[j] and int(bool(out["episode_end"][i])) == en[j]
@@ -604,4 +621,13 @@ def sampled_compare(get_state, step, tables, ids, steps, conditioning=False):
                 ends += 1
             else:
                 ds[k, j] = np.abs(out["state"][i] - so[j]).max() / max(1.0, np.abs(so[j]).max())
+        if on_step is not None:
+            on_step(k, st0, out)
     return (dr, ds, alive, ok, ends, d32) if conditioning else (dr, ds, alive, ok, ends)
+
+
+def tracking_actions(tables, kin_times, clips=None, oracle=None):
+    """stream A1 for a whole batch on the host: the action encoding of the reference motion at every env's kinematic clip time (what DM_OPEN_LOOP computes on
+    the device), from ONE oracle's motion evaluation (the root block of the pose does not enter an action)."""
+    o = oracle if oracle is not None else Oracle(tables)
+    return np.array([o.pose_to_action(o.kin_eval(float(t))[0]) for t in np.asarray(kin_times, dtype=np.float64)])

@@ -19,7 +19,7 @@ from gpu_ab_bench import load_raw                        # noqa: E402
 def main():
     a, b = [os.path.join(ROOT, p) for p in sys.argv[1:3]]
     n = int(sys.argv[3]) if len(sys.argv) > 3 else 4096
-    t = model.load_asset("humanoid3d_walk")
+    t = model.load_asset(os.environ.get("SCENE", "humanoid3d_walk"))
     dev = torch.device("cuda")
     tstream = torch.cuda.Stream(); torch.cuda.set_stream(tstream)
     ctx = {}

@@ -7,7 +7,8 @@ sys.path.insert(0, ROOT)
 import numpy as np
 from deepmimic_amd import model
 from deepmimic_amd.core import BatchEnv
-t = model.load_asset("humanoid3d_walk"); n = 4096
+SCENE = os.environ.get("SCENE", "humanoid3d_walk")
+t = model.load_asset(SCENE); n = 4096
 e0 = BatchEnv(t, 1); amean = (-e0.offsets_scales()["action_offset"]).astype(np.float32); e0.close()
 for label, acts, ol in (("open-loop", None, True), ("zeros", np.zeros((n, 28), np.float32), False), ("a_mean", np.tile(amean, (n, 1)), False)):
     env = BatchEnv(t, n, seed=1234, test_mode=True); env.reset()

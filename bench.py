@@ -343,10 +343,11 @@ def parity_check(tables, envs, step_and_read, n_sample=64, steps=5, physics=1, a
     n = envs.N
     ids = np.unique(np.round(np.linspace(0, n - 1, n_sample)).astype(np.int64))
     mc = envs.envs[0].max_contacts if physics == 2 else None
-    fb = [envs.debug("fallback"), np.zeros(n)]
+    beyond32 = lambda: np.stack([envs.debug("fallback"), envs.debug("borrowed")])      # per env: substeps on the 64-lane fallback | on borrowed lanes (two-per-wave kernel)
+    fb = [beyond32(), np.zeros((2, n))]
 
     def on_step(k, st0, out):
-        f = envs.debug("fallback"); fb[1] = fb[1] + (f - fb[0]); fb[0] = f
+        f = beyond32(); fb[1] = fb[1] + (f - fb[0]); fb[0] = f
 
     dr, ds, alive, ok, ends = pc.sampled_compare(envs.get_state, step_and_read, tables, ids, steps, physics=physics, get_manifolds=envs.get_manifolds if physics == 2 else None,
                                                  max_contacts=mc, actions=actions, on_step=on_step)
@@ -357,9 +358,10 @@ def parity_check(tables, envs, step_and_read, n_sample=64, steps=5, physics=1, a
             "reward_mae": (float(live.mean()) if live.size else None), "reward_p99": q(live, 0.99), "reward_max": (float(live.max()) if live.size else None),
             "reward_max_not_live": float(dr[~alive].max(initial=0.0)), "state_rel_mean": (float(sl.mean()) if sl.size else None), "state_rel_max": (float(sl.max()) if sl.size else None),
             "flags_equal": bool(ok),
-            # pair-substeps of the WHOLE batch that ran on the 64-lane fallback of the two-per-wave kernel during these steps (dm_get_debug "fallback": both characters of a pair count one), and
-            # how many of the sampled envs were among them
-            "fallback_share": float(fb[1].sum() / 2 / max(1, (n // 2) * 40 * steps)), "sampled_envs_with_fallback_substeps": int((fb[1][ids] > 0).sum()),
+            # pair-substeps of the WHOLE batch in which a character had more than 32 constraint rows during these steps: on the 64-lane fallback of the two-per-wave kernel (dm_get_debug
+            # "fallback"; both characters of a pair count one) or on borrowed lanes ("borrowed": one heavy character, the pair within 64 rows), and how many of the sampled envs were among them
+            "fallback_share": float(fb[1][0].sum() / 2 / max(1, (n // 2) * 40 * steps)), "borrowed_lanes_share": float(fb[1][1].sum() / 2 / max(1, (n // 2) * 40 * steps)),
+            "sampled_envs_with_substeps_beyond_32_rows": int((fb[1].sum(0)[ids] > 0).sum()),
             "against": "oracle (fp64%s), re-synchronised from the device state before every control step; live = oracle reward != 0" % (", DM-physics v2 with the device's manifolds" if physics == 2 else "")}
 
 
@@ -397,16 +399,16 @@ def closed_loop(envs, stream_handles, dev, steps, tables=None, parity_envs=0, pa
     warm = 60                  # two policy-driven episode lengths: the mixture of standing / tumbling / freshly reset characters the policy produces, not the transient behind the open-loop rollout
     loop(0, warm)
     envs.synchronize(); torch.cuda.synchronize()
-    fb0 = envs.debug("fallback").sum()
+    fb0 = np.array([envs.debug("fallback").sum(), envs.debug("borrowed").sum()])
     t0 = time.perf_counter()
     loop(warm, warm + steps)
     envs.synchronize(); torch.cuda.synchronize(); dt = time.perf_counter() - t0
-    fb1 = envs.debug("fallback").sum()
+    fb1 = np.array([envs.debug("fallback").sum(), envs.debug("borrowed").sum()])
     res = {"value": n * steps / dt, "unit": "env-steps/s", "steps": steps, "ms_per_step": 1e3 * dt / steps, "groups": envs.G,
            "policy": "%d -> 1024 -> 512 -> %d, random init, sampled (dm_policy_forward: one launch per group and step, k_policy_fused, bf16 MFMA)" % (env.S, env.A), "warmup_steps": warm,
            "mean_reward": float(rw.mean().item()), "finite": bool(torch.isfinite(st).all().item()),
-           # share of the pair-substeps of the timed loop that ran on the 64-lane fallback of the two-per-wave kernel (a character beyond 32 constraint rows)
-           "fallback_share": float((fb1 - fb0) / 2 / max(1, (n // 2) * 40 * steps))}
+           # share of the pair-substeps of the timed loop with a character beyond 32 constraint rows: on the 64-lane fallback of the two-per-wave kernel | on borrowed lanes
+           "fallback_share": float((fb1 - fb0)[0] / 2 / max(1, (n // 2) * 40 * steps)), "borrowed_lanes_share": float((fb1 - fb0)[1] / 2 / max(1, (n // 2) * 40 * steps))}
     if parity_envs > 0 and tables is not None:
         try:
             def actions_of(k, st0):

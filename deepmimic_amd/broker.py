@@ -361,6 +361,7 @@ def serve(name: str, max_workers: int, device: int, precision: int, lib_path: st
                     pack_state(s_, want)
             guarded(np.concatenate([want, ss]) if (want.size or ss.size) else want, states)
             t_s0 = time.perf_counter(); stats["t_pre"] += t_s0 - t_g1
+            stp = stp[~failed[stp]]          # a slot whose rollback snapshot (or state write) failed above is answered with an error and NOT stepped: its device state stays where the worker last saw it
             for key, grp in by_config(stp, (R.dargs[stp, 0], R.iargs[stp, 0].astype(np.float64), R.iargs[stp, 1].astype(np.float64), R.iargs[stp, 2].astype(np.float64), R.iargs[stp, 3].astype(np.float64))):
                 def step_group(ids, key=key):
                     configure(*key[:4])
@@ -447,17 +448,10 @@ class SharedEnv:
             raise NotImplementedError("DM_FACADE_SHARED: seeds ride in a double of the env's goal row (dm_set_env_keys): below 2^53")
         W = int(max_workers or os.environ.get("DM_FACADE_SHARED_MAX", "256"))
         name = region_name(tables, precision, device_id, physics)
-        self.R = self._attach(name, tables, W, device_id, precision, lib_path or os.environ.get("DM_HIP_LIB") or "", physics)
+        # open the region (starting an owner if there is none) AND claim a slot under ONE acquisition of the region's file lock: the owner decides to leave under the
+        # same lock and only while no slot is claimed, so a region found live here cannot be unlinked between the look and the claim
+        self.R, self.slot = self._attach(name, tables, W, device_id, precision, lib_path or os.environ.get("DM_HIP_LIB") or "", physics)
         R = self.R
-        # claim a slot under the region's file lock
-        with _open_private("/dev/shm/%s.lock" % name, "a+") as lk:
-            fcntl.flock(lk, fcntl.LOCK_EX)
-            free = np.nonzero(R.owner == 0)[0]
-            if free.size == 0:
-                raise RuntimeError("DM_FACADE_SHARED: all %d slots of %s are taken (DM_FACADE_SHARED_MAX)" % (R.W, name))
-            self.slot = int(free[0])
-            R.ack[self.slot] = R.req[self.slot]
-            R.owner[self.slot] = os.getpid()
         self.N, self.S, self.A, self.P, self.J, self.amp_size, self.G = 1, R.S, R.A, R.P, R.J, R.AMP, R.G
         m, S, A = R.meta, R.S, R.A
         b = 3 * S + 4 * A
@@ -489,7 +483,7 @@ class SharedEnv:
 
     @staticmethod
     def _attach(name, tables, W, device, precision, lib_path, physics=1, timeout=180.0):
-        """Open the region; start the owner process if there is none (first worker, under the file lock)."""
+        """Open the region, starting the owner process if there is none (first worker), and claim a slot -- all under one hold of the file lock.  Returns (region, slot)."""
         lock_path = "/dev/shm/%s.lock" % name
         t_end = time.monotonic() + timeout
         with _open_private(lock_path, "a+") as lk:
@@ -523,7 +517,14 @@ class SharedEnv:
                     if time.monotonic() > t_end:
                         raise RuntimeError("DM_FACADE_SHARED: the owner process did not come up (see /dev/shm/%s.log)" % name)
                     time.sleep(0.05)
-        return R
+            # still under the lock: claim a slot of the region that was just seen live
+            free = np.nonzero(R.owner == 0)[0]
+            if free.size == 0:
+                raise RuntimeError("DM_FACADE_SHARED: all %d slots of %s are taken (DM_FACADE_SHARED_MAX)" % (R.W, name))
+            slot = int(free[0])
+            R.ack[slot] = R.req[slot]
+            R.owner[slot] = os.getpid()
+        return R, slot
 
     # ---- one request / reply
     def _call(self, op, timeout=120.0):

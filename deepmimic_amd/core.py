@@ -561,7 +561,7 @@ class BatchEnv:
     def debug(self, name: str):
         shapes = {"H": (self.N, self.D, self.D), "C": (self.N, self.D), "vstar": (self.N, self.D), "lambda": (self.N, 64),
                   "rows": (self.N, 2), "tau": (self.N, self.D), "kin_pose": (self.N, self.P), "kin_vel": (self.N, self.P),
-                  "reward_terms": (self.N, 5), "links": (self.N, self.J, 21), "prof": (self.N, 16), "fallback": (self.N,)}
+                  "reward_terms": (self.N, 5), "links": (self.N, self.J, 21), "prof": (self.N, 16), "fallback": (self.N,), "borrowed": (self.N,)}
         out = np.zeros(shapes[name])
         self._chk(self.lib.dm_get_debug(self.h, name.encode(), _dp(out)))
         return out

@@ -200,6 +200,14 @@ template <> struct RowFile<float, 48> {
     __device__ __forceinline__ float get(int r) const { return (r < 32) ? a[r] : b[r - 32]; }
     __device__ __forceinline__ void set(int r, float x) { if (r < 32) a[r] = x; else b[r - 32] = x; }
 };
+// 40 rows: the borrowed-lane path of the two-per-wave kernel (dm_device_duo.h: a heavy character of up to 40 rows = 12 contacts)
+template <> struct RowFile<float, 40> {
+    typedef float v32 __attribute__((ext_vector_type(32)));
+    typedef float v8 __attribute__((ext_vector_type(8)));
+    v32 a; v8 b;
+    __device__ __forceinline__ float get(int r) const { return (r < 32) ? a[r] : b[r - 32]; }
+    __device__ __forceinline__ void set(int r, float x) { if (r < 32) a[r] = x; else b[r - 32] = x; }
+};
 // two / four packed reals: v_pk_fma_f32 / ds_read_b128 operands
 template <typename Real> struct VecT;
 template <> struct VecT<float> { typedef float v2 __attribute__((ext_vector_type(2))); typedef float v4 __attribute__((ext_vector_type(4))); };

@@ -126,6 +126,256 @@ template <int NP2> __device__ __forceinline__ void duo_gram32(const VecT<double>
 }
 #endif
 
+// ------------------------------------------------------------------ lane borrowing (round 6)
+// A pair in which ONE character has more than 32 constraint rows and the two together at most 64 -- under a random actor: two flat feet (8 contacts) plus two or
+// three self contacts = 34 / 37 rows, beside a partner with 11 on average; 100 % of the pairs that used to fall back in the closed-loop spinkick run
+// (profiles/r06_closed_loop_spinkick.json) -- stays in ONE instruction stream: row 32 + i of the heavy character is held by lane 31 - i of the OTHER half (the
+// light character's rows end below those lanes: R_light <= 32 - borrowed), a position that depends on the heavy character's own row count only.  Each lane then
+// works on the record of the character whose row it holds (contact slots, dof records, factor rows: per-lane LDS addresses); the Gram rows of all 64 lanes come off
+// the matrix core (two half passes of wave_gram64_half) and every lane keeps the 64 entries of ITS character's row order; the sweep visits up to 64 rows, a visit
+// hands each character its own delta (two v_readlane + one select); Y lambda is reduced per half as ever, the borrowed lanes' part in a second pass that crosses
+// the halves once.  One two-per-wave pass with a longer sweep instead of the failed pass plus two 64-lane passes.  Same arithmetic as the 64-lane routine up to the
+// summation order of Y lambda over the rows; deterministic and independent of the partner.
+// Register budget: inlined into a kernel that has 252 of 256 VGPRs in use elsewhere, the routine must stay far below that or kernel-long values go to scratch with
+// reloads inside the factorisation (first version: 64-entry row file + Y + two MFMA chains + outputs = 248 VGPRs on its own, 42 spilled in the kernel; as a real
+// function -- s_swappc -- the values live across the call site were spilled instead, again with reloads on the hot path).  So: Y waits in the pair's overflow block
+// (HBM / L2, 34 coalesced stores and loads) while the sweep runs, the Gram comes off the matrix core one 16-accumulator chain at a time, and the row file holds 48
+// entries (a heavy character of up to 48 rows: 14 contacts; beyond that the pair falls back as before).
+#ifndef DM_DUO_XD
+#define DM_DUO_XD 1
+#endif
+#ifdef DM_EMU
+#define DM_REGION_MARK(n) ((void)0)
+#else
+#define DM_REGION_MARK(n) asm volatile("s_nop " #n)
+#endif
+#ifndef DM_XD_ROWS
+#define DM_XD_ROWS 48
+#endif
+template <int N, int MASK, int NP2, typename Real> DM_DEV void xd_tr_stage(Real (&w)[NP2], int hl) {
+    const bool bit = (hl & MASK) != 0;
+#pragma unroll
+    for (int i = 0; i < (N + 1) / 2; ++i) {
+        Real a = w[2 * i], b = (2 * i + 1 < N) ? w[2 * i + 1] : (Real)0;
+        Real keep = bit ? b : a, send = bit ? a : b;
+        w[i] = keep + wave_shfl_xor_c<MASK>(send);
+    }
+}
+// one 32 x 32 block of Y^T Y on the matrix core: rows = the rows held by the lanes of half X, columns = those of half Y; f(r, value) is called for r = 0..31 with
+// G[row held by lane 32 X + r][row held by lane 32 Y + (lane & 31)] -- every lane gets column (lane & 31) of the block
+#ifdef DM_EMU
+template <int NP2, typename R2> static inline void xd_gram_operands(R2*) {}
+template <int NP2, int X, int Y, typename R2, typename F> static inline void xd_gram_block(const R2* y2, F&& f) {
+    typedef decltype(y2[0][0] + 0) Real;
+    Real* x = reinterpret_cast<Real*>(emu::g_xchg);
+    for (int p = 0; p < NP2; ++p) { x[threadIdx.x * 2 * NP2 + 2 * p] = y2[p][0]; x[threadIdx.x * 2 * NP2 + 2 * p + 1] = y2[p][1]; }
+    __syncthreads();
+    Real out[32];
+    const int me = 32 * Y + (threadIdx.x & 31);
+    for (int i = 0; i < 32; ++i) { Real a = 0; for (int k = 0; k < 2 * NP2; ++k) a += x[me * 2 * NP2 + k] * x[(32 * X + i) * 2 * NP2 + k]; out[i] = a; }
+    __syncthreads();
+    static_for<0, 32>([&](auto rc) { f(rc, out[decltype(rc)::value]); });
+}
+#else
+// (float: `ops` = the column pairs after xd_gram_operands -- [0] = [Y[k0][0..31] | Y[k1][0..31]], [1] = [Y[k0][32..63] | Y[k1][32..63]] -- made ONCE for the four blocks and in
+// place of Y, which waits in the overflow block meanwhile: Y and its swapped copy alive together were 34 registers too many)
+template <int NP2> __device__ __forceinline__ void xd_gram_operands(VecT<float>::v2* y2) {
+#pragma unroll
+    for (int p = 0; p < NP2; ++p) {
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(y2[p][0]), __float_as_uint(y2[p][1]), false, false);
+        y2[p][0] = __uint_as_float(sw[0]); y2[p][1] = __uint_as_float(sw[1]);
+    }
+}
+template <int NP2> __device__ __forceinline__ void xd_gram_operands(VecT<double>::v2*) {}
+template <int NP2, int X, int Y, typename F> __device__ __forceinline__ void xd_gram_block(const VecT<float>::v2* ops, F&& f) {
+    typedef float f16v __attribute__((ext_vector_type(16)));
+    f16v acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int p = 0; p < NP2; ++p) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ops[p][X], ops[p][Y], acc, 0, 0, 0);
+    static_for<0, 16>([&](auto vc) {
+        constexpr int v = decltype(vc)::value;
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[v]), __float_as_uint(acc[v]), false, false);      // both halves: the lower lanes' rows, the upper lanes' rows of the column
+        f(std::integral_constant<int, 8 * (v / 4) + (v % 4)>{}, __uint_as_float(sw[0]));
+        f(std::integral_constant<int, 8 * (v / 4) + 4 + (v % 4)>{}, __uint_as_float(sw[1]));
+    });
+    DM_SCHED_FENCE();
+}
+template <int NP2, int X, int Y, typename F> __device__ __forceinline__ void xd_gram_block(const VecT<double>::v2* y2, F&& f) {
+    const int me = 32 * Y + (threadIdx.x & 31);
+    static_for<0, 32>([&](auto rc) {
+        constexpr int r = decltype(rc)::value;
+        double a = 0;
+#pragma unroll
+        for (int p = 0; p < NP2; ++p) a += wave_shfl(y2[p][0], me) * lane_bcast(y2[p][0], 32 * X + r) + wave_shfl(y2[p][1], me) * lane_bcast(y2[p][1], 32 * X + r);
+        f(rc, a);
+    });
+}
+#endif
+template <typename Real, bool V2>
+DM_DEV void duo_rows_xd(Lds<Real, ClsBiped>* rec, int wl, Real h, int nc, int R, int Ra, int Rb, int D, int NL, Real erp, Real friction, Real lim_max_impulse, int solver_iters, Real* ystash) {
+    typedef ClsBiped C; typedef Lds<Real, C> L; typedef EnvSim<Real, C, false, 32> Base;
+    typedef V3<Real> v3; typedef typename VecT<Real>::v2 R2; typedef typename VecT<Real>::v4 R4;
+    constexpr int ND = C::ND, NP2 = ND / 2, NJ = C::NJ, HW = 32, XR = DM_XD_ROWS;
+    static_assert(XR == 40 || XR == 48 || XR == 64, "RowFile sizes");
+    const int half = wl >> 5, hl = wl & 31;
+    L& s = rec[half];
+    const int H = (Ra > HW) ? 0 : 1;                          // the heavy half (wave-uniform)
+    const int Rv = H ? Rb : Ra;                               // rows of the heavy character = visits of the sweep
+    const int nb = Rv - HW;                                   // borrowed lanes
+    const bool xl = (half != H) && (HW - 1 - hl) < nb;        // this lane holds a row of the OTHER half's character
+    const int ch = xl ? H : half;                             // the character whose row this lane holds
+    const int row = xl ? HW + (HW - 1 - hl) : hl;             // ... and which row
+    const int ncA = lane_bcast(nc, 0), ncB = lane_bcast(nc, 32);
+    const int ncc = ch ? ncB : ncA, Rc = NL + 3 * ncc, RNc = NL + ncc;
+    L& sc = rec[ch];
+    if (hl == 0) { s.flg[FLG_NROWS] = R; s.flg[FLG_NCONT] = nc; s.clk[5] += 1.0; }      // (clk[5]: the pad word of the clock row counts this env's substeps on borrowed lanes, dm_get_debug "borrowed")
+    __syncthreads();
+    Real brow = 0;
+    uint32_t ch_lo = 0, ch_hi = 0, ng_lo = 0, ng_hi = 0; v3 xd = mk3((Real)0, (Real)0, (Real)0), dd = xd;
+    if (row < Rc) {
+        if (row < NL) {                                       // (DuoSim::substep_post's limit row)
+            const int lr = V2 ? (row >> 1) : row;
+            int j = sc.mdl.lim_joint[lr]; int lj = sc.mdl.link_info[j]; int off = DM_LI_POFF(lj);
+            const int limdof = DM_LI_DOFF(lj);
+            Real th = sc.pose[off], pen_lo = th - sc.mdl.lim_lo[lr], pen_hi = sc.mdl.lim_hi[lr] - th;
+            Real pen, sgn;
+            if (V2 ? !(row & 1) : (pen_lo <= pen_hi)) { sgn = 1; pen = pen_lo; } else { sgn = -1; pen = pen_hi; }
+            brow = (pen > 0) ? -pen / h : -erp * pen / h;
+            xd = sgn * ld3(&sc.dofrec[limdof][0]);
+            if (limdof < 32) ch_lo = 1u << limdof; else ch_hi = 1u << (limdof - 32);
+        } else {                                              // (EnvSim::contact_row)
+            int slot, kindr;
+            if (row < NL + ncc) { slot = row - NL; kindr = 0; } else { int fi = row - NL - ncc; slot = fi >> 1; kindr = 1 + (fi & 1); }
+            const Real* ct = sc.ct[slot];
+            const int info = (int)ct[7];
+            const int la = info & 0xff, lb = (info >> 8) & 0xff;
+            const v3 n = ld3(ct + 3);
+            v3 t1, t2; Base::plane_space(n, t1, t2);
+            dd = (kindr == 0) ? n : ((kindr == 1) ? t1 : t2);
+            xd = cross(ld3(ct) - ld3(sc.p[0]), dd);
+            uint32_t a_lo = sc.mdl.chain_lo[la < NJ ? la : 0], a_hi = sc.mdl.chain_hi[la < NJ ? la : 0], b_lo = 0, b_hi = 0;
+            if (lb != 255) { b_lo = sc.mdl.chain_lo[lb < NJ ? lb : 0]; b_hi = sc.mdl.chain_hi[lb < NJ ? lb : 0]; }
+            ch_lo = a_lo ^ b_lo; ch_hi = a_hi ^ b_hi; ng_lo = b_lo & ch_lo; ng_hi = b_hi & ch_hi;
+            if (kindr == 0) { const Real dc = ct[6]; brow = (dc > 0) ? -dc / h : -erp * dc / h; }
+        }
+    }
+    // y := L^-1 J^T against this lane's character (EnvSim::substep_post's dense loop with per-lane record addresses)
+    R2 y2[NP2]; Real cvec = 0;
+#if DM_PRIO_Y
+    dm_setprio<DM_PRIO_Y>();
+#endif
+#pragma unroll
+    for (int k = 0; k < ND; ++k) {
+        Real yk = 0;
+        if (k < D) {
+            const R4 r0 = *reinterpret_cast<const R4*>(&sc.dofrec[k][0]), r1 = *reinterpret_cast<const R4*>(&sc.dofrec[k][4]);
+            const Real val = r0[0] * xd.x + r0[1] * xd.y + r0[2] * xd.z + r0[3] * dd.x + r1[0] * dd.y + r1[1] * dd.z;
+            const bool on = (((k < 32) ? ch_lo : ch_hi) >> (k & 31)) & 1u, ng = (((k < 32) ? ng_lo : ng_hi) >> (k & 31)) & 1u;
+            const Real raw = on ? (ng ? -val : val) : (Real)0;
+            cvec += raw * r1[2];
+            R2 acc2 = {(Real)0, (Real)0}, acc3 = acc2;
+            const R2* lrow = reinterpret_cast<const R2*>(&sc.Lt[L::lrow(k)]);
+#pragma unroll
+            for (int p = 0; p < (k >> 1); ++p) { if (p & 1) acc3 += lrow[p] * y2[p]; else acc2 += lrow[p] * y2[p]; }
+            acc2 += acc3;
+            Real acc = raw - (acc2[0] + acc2[1]);
+            if (k & 1) acc -= sc.Lt[L::lrow(k) + k - 1] * y2[k >> 1][0];
+            yk = acc * sc.Lt[L::lrow(k) + k];
+        }
+        y2[k >> 1][k & 1] = yk;
+        DM_SCHED_FENCE();      // (one dof at a time: unfenced, the scheduler hoists the factor rows of many dofs -- up to 34 registers each -- and spills kernel-long values)
+    }
+#if DM_PRIO_Y
+    dm_setprio<0>();
+#endif
+    const bool is_fric = row >= RNc && row < Rc;
+    Real lam = 0;
+    if (wave_ballot(row < RNc && (brow - cvec) > 0) != 0) {
+        Real adiag;
+        { R2 a2 = {(Real)0, (Real)0};
+#pragma unroll
+          for (int p = 0; p < NP2; ++p) a2 += y2[p] * y2[p];
+          adiag = a2[0] + a2[1]; }
+        const Real inv_adiag = (row < Rc) ? (Real)1 / adiag : (Real)0;
+        // entry c of a lane's file = A[own row][row c of the same character]: rows 0..31 are the lanes of the character's half, row 32 + i lane 31 - i of the other one.
+        // Four 32 x 32 blocks of Y^T Y, one MFMA chain (16 accumulators) at a time: after chain (rows of half X, columns of half Y) and one swap per accumulator, lanes j and
+        // 32 + j both hold column j of block (X, Y), i.e. (symmetry) the entries of the row held by lane 32 Y + j against the rows of half X.
+        RowFile<Real, XR> arow;
+        // Y leaves for the pair's overflow block until the sweep is over (coalesced: [dof][lane]); its registers then carry the MFMA operands
+#pragma unroll
+        for (int p = 0; p < NP2; ++p) { ystash[(2 * p) * kWave + wl] = y2[p][0]; ystash[(2 * p + 1) * kWave + wl] = y2[p][1]; }
+        xd_gram_operands<NP2>(y2);
+        DM_SCHED_FENCE();
+        xd_gram_block<NP2, 0, 0>(y2, [&](auto rc, Real g) { constexpr int r = decltype(rc)::value; arow.set(r, g); if (XR - 32 > 31 - r) arow.set(32 + (31 - r), g); });       // half-0 lanes against half 0 (provisionally every lane's; the borrowed rows of a heavy half 1)
+        xd_gram_block<NP2, 0, 1>(y2, [&](auto rc, Real g) { constexpr int r = decltype(rc)::value; if (half == 1) { if (ch == 0) arow.set(r, g); if (XR - 32 > 31 - r && H == 1) arow.set(32 + (31 - r), g); } });   // half-1 lanes against half 0: a borrowed lane of heavy 0 (its first 32) | the lanes of a heavy character 1 (its borrowed rows)
+        xd_gram_block<NP2, 1, 0>(y2, [&](auto rc, Real g) { constexpr int r = decltype(rc)::value; if (half == 0) { if (ch == 1) arow.set(r, g); if (XR - 32 > 31 - r && H == 0) arow.set(32 + (31 - r), g); } });   // half-0 lanes against half 1: a borrowed lane of heavy 1 | the lanes of a heavy character 0
+        xd_gram_block<NP2, 1, 1>(y2, [&](auto rc, Real g) { constexpr int r = decltype(rc)::value; if (half == 1) { if (ch == 1) arow.set(r, g); if (XR - 32 > 31 - r && H == 0) arow.set(32 + (31 - r), g); } });   // half-1 lanes against half 1
+        // scaled by 1 / A_ll, zero diagonal (the sweep runs on t = lambda + q), zero beyond the character's rows: a visit past a character's last row, or to a
+        // borrowed lane's position in the light half, must not move that character
+#pragma unroll
+        for (int c = 0; c < XR; ++c) arow.set(c, (c == row || c >= Rc) ? (Real)0 : arow.get(c) * inv_adiag);
+        Real t = (brow - cvec) * inv_adiag;
+        const int nrm_lane = is_fric ? ch * HW + NL + ((row - RNc) >> 1) : 0;      // the contact's normal row: always among the first 32, i.e. in its character's own half
+        Real lo = 0, hi = is_fric ? (Real)0 : ((row < NL) ? lim_max_impulse : (Real)1e30);
+        const uint32_t fmask = (1u << (NL + ncA)) | (1u << (NL + ncB));
+        const int xsrc = H ? 0 : HW;                        // borrowed lanes sit in the half that is not H
+#if DM_PRIO
+        dm_setprio<3>();
+#endif
+        // (a variant with scalar-unit lane masks and one v_readlane on the visits past the light character's rows issued two VALU fewer per visit and measured 3 % slower
+        // in the closed loop: profiles/r06_ab_xd_sweep.json)
+        for (int it = 0; it < solver_iters; ++it) {
+            int Rvo = Rv, rowo = row; uint32_t fm = fmask;
+            DM_OPAQUE_S(Rvo); DM_OPAQUE_S(fm); DM_OPAQUE_V(rowo);
+            static_for<0, XR / 4>([&](auto blkc) {
+                constexpr int blk = decltype(blkc)::value;
+                if (blk * 4 < Rvo) {
+                    static_for<0, 4>([&](auto ic) {
+                        constexpr int v = blk * 4 + decltype(ic)::value;
+                        if (v < 32 && __builtin_expect((fm >> (v & 31)) & 1u, 0)) { const Real ln = wave_shfl(lam, nrm_lane); if (is_fric && v == RNc) { hi = friction * ln; lo = -hi; } }
+                        const Real nl = dm_med3(lo, t, hi);
+                        const Real d = nl - lam;
+                        Real delta;
+                        if (v < 32) { const Real d0 = lane_bcast(d, v & 31), d1 = lane_bcast(d, 32 + (v & 31)); delta = ch ? d1 : d0; }      // each character's own row v
+                        else delta = lane_bcast(d, xsrc + (63 - v));                                                                    // the heavy character's borrowed row (the light one's entries are 0)
+                        t -= arow.get(v) * delta;
+                        lam = (rowo == v) ? nl : lam;
+                    });
+                }
+            });
+        }
+#if DM_PRIO
+        dm_setprio<DM_PRIO_BACK>();
+#endif
+        if (row >= Rc) lam = 0;
+#pragma unroll
+        for (int p = 0; p < NP2; ++p) { y2[p][0] = ystash[(2 * p) * kWave + wl]; y2[p][1] = ystash[(2 * p + 1) * kWave + wl]; }
+    } else {
+#if DM_PRIO_BACK
+        dm_setprio<DM_PRIO_BACK>();
+#endif
+    }
+    // Y lambda per dof and character: the rows in their character's own half, then the borrowed lanes' rows (reduced in the half they sit in, handed across once)
+    {
+        Real w[NP2], wx[NP2];
+        const bool bit = (hl & 1) != 0;
+        const Real lam1 = xl ? (Real)0 : lam, lam2 = xl ? lam : (Real)0;
+#pragma unroll
+        for (int p = 0; p < NP2; ++p) {
+            const Real a = y2[p][0] * lam1, bb = y2[p][1] * lam1;
+            w[p] = (bit ? bb : a) + wave_shfl_xor_c<1>(bit ? a : bb);
+            const Real ax = y2[p][0] * lam2, bx = y2[p][1] * lam2;
+            wx[p] = (bit ? bx : ax) + wave_shfl_xor_c<1>(bit ? ax : bx);
+        }
+        xd_tr_stage<NP2, 2, NP2>(w, hl); xd_tr_stage<(NP2 + 1) / 2, 4, NP2>(w, hl); xd_tr_stage<(NP2 + 3) / 4, 8, NP2>(w, hl); xd_tr_stage<(NP2 + 7) / 8, 16, NP2>(w, hl);
+        xd_tr_stage<NP2, 2, NP2>(wx, hl); xd_tr_stage<(NP2 + 1) / 2, 4, NP2>(wx, hl); xd_tr_stage<(NP2 + 3) / 4, 8, NP2>(wx, hl); xd_tr_stage<(NP2 + 7) / 8, 16, NP2>(wx, hl);
+        const Real z0 = w[0] + wave_shfl(wx[0], wl ^ 32), z1 = w[1] + wave_shfl(wx[1], wl ^ 32);      // (the heavy half's own second pass is all zeros: nothing comes back to the light one)
+        Real* xs = &s.Ic[0][0];
+        xs[hl] = z0;
+        if (hl + 32 < D) xs[hl + 32] = z1;
+    }
+}
+
 template <typename Real, bool TAPS>
 struct DuoSim {
     typedef ClsBiped C;
@@ -513,6 +763,30 @@ _Pragma("unroll") \
         return total;
     }
 
+    // the end of a substep for both characters: xs holds Y lambda per dof; delta v = L^-T xs, clamp, integrate
+    DM_DEV void substep_tail(Real h) {
+        const int D = m.D;
+        sync();
+        {
+            const int own = hl + 3; const bool valid = own < D;
+            Real x = valid ? b.xs()[own] : (Real)0;
+            Real xr[3] = { b.xs()[0], b.xs()[1], b.xs()[2] };
+            const Real dinv = valid ? Lx(valid ? own : 3, valid ? own : 3) : (Real)1, dinv0 = Lx(0, 0);
+            sync();
+            back_substitute(x, xr, dinv, dinv0);
+            if (valid) b.xs()[own] = x;
+            if (hl == HW - 1) for (int k = 0; k < 3; ++k) b.xs()[k] = xr[k];
+        }
+        sync();
+        for (int k = hl; k < D; k += HW) { const int vidx = DM_DI_VIDX(s.mdl.dof_info[k]); s.vel[vidx] = clamp_vel(s.dofrec[k][6] + b.xs()[k], k); }
+        sync();
+        b.integrate(h);
+        sync();
+#if DM_PRIO_BACK
+        dm_setprio<0>();
+#endif
+    }
+
     // ------------------------------------------------------------------ rigid-body substep, constraint part
     // returns false (having done nothing that matters -- under V2: the manifolds are updated and the ground slots stored, FLG_NCONT tells the
     // one-per-wave routine how many) when either character needs more than 32 constraint rows
@@ -589,7 +863,11 @@ _Pragma("unroll") \
         }
         const int NL = m.NL;
         const int R = NL + 3 * nc;
-        if (wave_ballot(R > HW) != 0) { if (V2) sync(); return false; }      // a heavily contacted character: the caller runs the one-per-wave routine (V2: FLG_NCONT is published)
+        if (wave_ballot(R > HW) != 0) {      // a heavily contacted character: the caller decides between borrowed lanes and the one-per-wave routine (FLG_NROWS is published for it; V2: FLG_NCONT holds the ground slots)
+            if (hl == 0) s.flg[FLG_NROWS] = R;
+            sync();
+            return false;
+        }
         if (hl == 0) { s.flg[FLG_NROWS] = R; s.flg[FLG_NCONT] = nc; }
         sync();
         b.mark(8);
@@ -733,27 +1011,7 @@ _Pragma("unroll") \
             b.xs()[hl] = w[0];
             if (hl + 32 < D) b.xs()[hl + 32] = w[1];
         }
-        sync();
-        {
-            const int own = hl + 3; const bool valid = own < D;
-            Real x = valid ? b.xs()[own] : (Real)0;
-            Real xr[3] = { b.xs()[0], b.xs()[1], b.xs()[2] };
-            const Real dinv = valid ? Lx(valid ? own : 3, valid ? own : 3) : (Real)1, dinv0 = Lx(0, 0);
-            sync();
-            back_substitute(x, xr, dinv, dinv0);
-            if (valid) b.xs()[own] = x;
-            if (hl == HW - 1) for (int k = 0; k < 3; ++k) b.xs()[k] = xr[k];
-        }
-        sync();
-        for (int k = hl; k < D; k += HW) { const int vidx = DM_DI_VIDX(s.mdl.dof_info[k]); s.vel[vidx] = clamp_vel(s.dofrec[k][6] + b.xs()[k], k); }
-        sync();
-        b.integrate(h);
-        sync();
-#if DM_PRIO_BACK
-        dm_setprio<0>();
-#endif
-        b.mark(12);
-        return true;
+        return true;           // xs holds Y lambda: the caller runs substep_tail (shared with the borrowed-lane path)
     }
 
     // ------------------------------------------------------------------ one scene update for both characters
@@ -801,8 +1059,24 @@ _Pragma("unroll") \
                 for (int k = hl; k < D; k += HW) s.tau[k] = (k < 6) ? (Real)0 : b.xs()[k] - s.mdl.kd[DM_DI_JOINT(s.mdl.dof_info[k])] * rdt * s.rhs[k];
                 sync();
                 b.spd_clamp();
-            } else if (!substep_post<V2>(h, V2 ? manif_pair + (size_t)half * m.J * MF_STRIDE : nullptr)) {
-                // more than 32 rows somewhere in the pair: one character at a time through the 64-lane routine
+            } else {
+                bool rows_done = substep_post<V2>(h, V2 ? manif_pair + (size_t)half * m.J * MF_STRIDE : nullptr);
+                if (!rows_done) {
+                    // more than 32 rows somewhere in the pair (the contact slots are stored, FLG_NROWS says how many).  One such character, at most DM_XD_ROWS rows, and at most 64
+                    // rows together: the pair stays in this instruction stream on borrowed lanes (round 6)
+                    const int R_ = s.flg[FLG_NROWS], nc_ = (R_ - m.NL) / 3;
+                    const int Ra_ = lane_bcast(R_, 0), Rb_ = lane_bcast(R_, 32);
+                    if (DM_DUO_XD && aovf_pair && Ra_ + Rb_ <= 2 * HW && Ra_ <= DM_XD_ROWS && Rb_ <= DM_XD_ROWS) {
+                        b.mark(8);
+                        DM_REGION_MARK(13);             // (s_nop 13 / s_nop 14 bracket the borrowed-lane region in the disassembly: tests/test_build_resources.py holds every scratch access of the update loop to it)
+                        duo_rows_xd<Real, V2>(rec, wl, h, nc_, R_, Ra_, Rb_, D, m.NL, m.erp, m.friction, m.lim_max_impulse, m.solver_iters, aovf_pair);
+                        DM_REGION_MARK(14);
+                        b.mark(11);                     // (profiling build: rows + Gram + sweep of such a substep count as "sub.PGS")
+                        rows_done = true;
+                    }
+                }
+                if (rows_done) { substep_tail(h); b.mark(12); continue; }
+                // otherwise: one character at a time through the 64-lane routine
                 if (FallbackCls::PRIO_FLOOR > 0) dm_setprio<FallbackCls::PRIO_FLOOR>();
                 if (hl == 0) s.kin[7] += (Real)1;            // statistic (round 6): substeps this env spent on the fallback, in the pad word of its kin row (dm_get_debug "fallback")
                 for (int x = 0; x < 2; ++x) {

@@ -446,6 +446,7 @@ struct CtxT : CtxBase {
         st.pose = (Real*)dalloc(sizeof(Real) * N * h.P); st.vel = (Real*)dalloc(sizeof(Real) * N * h.P); st.tar = (Real*)dalloc(sizeof(Real) * N * h.P);
         st.tau = (Real*)dalloc(sizeof(Real) * N * h.D); st.kin = (Real*)dalloc(sizeof(Real) * N * 8);
         st.clock = (double*)dalloc(sizeof(double) * N * 6); st.flag = (int*)dalloc(sizeof(int) * N * 4);
+        if (st.clock) rt_memset(st.clock, 0, sizeof(double) * (size_t)N * 6, stream);   // word 5 of a clock row counts the env's substeps on borrowed lanes (two-per-wave kernel, round 6)
         if (st.kin) rt_memset(st.kin, 0, sizeof(Real) * (size_t)N * 8, stream);      // word 7 of a kin row is the env's fallback-substep counter (two-per-wave kernel), never reset by the device
         // overflow rows of the constraint-space matrix (rows RREG..63 of a character with more than RREG rows in a substep)
         { const int ovf = kMaxRows - ((cls == 0 || cls == 2 || cls == 4) ? ClsBiped::RREG : ClsLarge::RREG); st.aovf = ovf > 0 ? (Real*)dalloc(sizeof(Real) * (size_t)N * ovf * kWave) : nullptr; }
@@ -567,7 +568,7 @@ struct CtxT : CtxBase {
         if (md.draw_tape && (flags & DM_AUTO_RESET)) return fail("a draw tape is bound (dm_set_draw_tape): resets go through dm_reset, where the tape serves the reference's draw order");
         io.n_updates = n_updates; io.dt = dt; io.auto_reset = (flags & DM_AUTO_RESET) ? 1 : 0; io.emit = (flags & DM_NO_EMIT) ? 0 : 1; io.open_loop = (flags & DM_OPEN_LOOP) ? 1 : 0; io.end_early = (flags & DM_END_EPISODE_EARLY) ? 1 : 0;
         // two characters per wavefront: biped class, even batch, no debug taps armed (DM_DUO=0 keeps one character per wave)
-        if (duo && cls == 0 && hm.D == ClsBiped::ND && (N % 2) == 0 && !dbg.H && !step_ids) {      // (31 row lanes per character assume exactly 34 dofs)
+        if (duo && cls == 0 && hm.D == ClsBiped::ND && (N % 2) == 0 && !dbg.H && !step_ids && !md.draw_tape) {      // (31 row lanes per character assume exactly 34 dofs; a bound draw tape is read by the one-per-wave kernels only -- EnvSim::tape() -- so such a batch takes them: ADVICE r5)
             if (st.manif) launch_step_duo<Real, SV_V2>(N / 2, stream, md, st, io, dbg);               // DM-physics v2, two characters per wavefront (round 4)
             else if (st.hist || st.pert || md.enable_root_rot_fail || md.timer_exp > 0) launch_step_duo<Real, SV_AMP>(N / 2, stream, md, st, io, dbg);      // (the AMP instantiation also carries the perturbation code)
             else launch_step_duo<Real, SV_PLAIN>(N / 2, stream, md, st, io, dbg);
@@ -621,9 +622,12 @@ struct CtxT : CtxBase {
         if (!st.goal) return fail("no goal state: not a goal scene / multi-clip dataset");
         std::vector<double> g((size_t)N * GS_WIDTH);
         if (rt_d2h(g.data(), st.goal, sizeof(double) * g.size(), stream) != 0) return fail("device to host copy failed");
-        if (out) for (int e = 0; e < N; ++e) for (int k = 0; k < 8; ++k) out[(size_t)e * 8 + k] = (GS_AUX0 + k < GS_WIDTH) ? g[(size_t)e * GS_WIDTH + GS_AUX0 + k] : 0.0;
+        // the 7 scene-specific columns GS_AUX0 .. GS_OTIMER_MAX; column 7 of the 8-wide interface row is reserved (reads 0, writes are ignored): the goal row's next
+        // slot is the env's own draw key (GS_KSEED, dm_set_env_keys), which a restored aux block must not re-key
+        static_assert(GS_AUX0 + 7 == GS_KSEED, "the aux window ends where the draw key starts");
+        if (out) for (int e = 0; e < N; ++e) for (int k = 0; k < 8; ++k) out[(size_t)e * 8 + k] = (k < 7) ? g[(size_t)e * GS_WIDTH + GS_AUX0 + k] : 0.0;
         if (in) {
-            for (int e = 0; e < N; ++e) for (int k = 0; k < 8; ++k) if (GS_AUX0 + k < GS_WIDTH) g[(size_t)e * GS_WIDTH + GS_AUX0 + k] = in[(size_t)e * 8 + k];
+            for (int e = 0; e < N; ++e) for (int k = 0; k < 7; ++k) g[(size_t)e * GS_WIDTH + GS_AUX0 + k] = in[(size_t)e * 8 + k];
             if (rt_h2d(st.goal, g.data(), sizeof(double) * g.size(), stream) != 0) return fail("host to device copy failed");
         }
         return 0;
@@ -808,6 +812,11 @@ struct CtxT : CtxBase {
     int get_debug(const char* name, double* out) override {
         const size_t n = N; const HostModel& h = hm; std::string s(name);
         if (s == "tau") return dl(st.tau, n * h.D, out);
+        if (s == "borrowed") {      // N: substeps the env's pair ran with one character's rows 32.. on lanes borrowed from its partner's half (two-per-wave kernel, DuoSim::substep_rows_xd)
+            std::vector<double> t6(n * 6); if (rt_d2h(t6.data(), st.clock, sizeof(double) * n * 6, stream)) return fail("copy failed");
+            for (size_t e = 0; e < n; ++e) out[e] = t6[e * 6 + 5];
+            return 0;
+        }
         if (s == "fallback") {      // N: substeps the env's pair ran on the 64-lane fallback of the two-per-wave kernel since dm_create / the last dm_set_state (0 for the one-per-wave kernels)
             std::vector<double> t8(n * 8); if (dl(st.kin, n * 8, t8.data())) return -1;
             for (size_t e = 0; e < n; ++e) out[e] = t8[e * 8 + 7];

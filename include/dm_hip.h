@@ -210,7 +210,7 @@ int dm_get_goal_state(dm_ctx* ctx, double* out);
 int dm_set_goal_state(dm_ctx* ctx, const double* in);
 /* the scene-specific part of the goal state, N x 8 doubles: [0..1] heading_amp_getup {get-up timer time, unused}; strike_amp {target hit
  * (0 / 1), scene time of the hit (-1 = none)}; [2..6] dribble_amp {ball position at the last action (3), target-object timer time, limit};
- * [7] reserved */
+ * [7] reserved: reads 0, is ignored on write (the goal row's next slot is the env's own draw key, dm_set_env_keys, which a restored aux block never re-keys) */
 int dm_get_goal_aux(dm_ctx* ctx, double* out);
 int dm_set_goal_aux(dm_ctx* ctx, const double* in);
 /* the random-perturbation state (enable_rand_perturbs), N x 16 doubles per env: [0] time since the last perturbation, [1] time of the next one
@@ -265,7 +265,10 @@ int dm_set_state(dm_ctx* ctx, const double* pose, const double* vel, const doubl
  * "tau" and "fallback" need no dm_probe.  "fallback" (N doubles): the number of rigid-body substeps the env has spent on
  * the 64-lane fallback of the two-characters-per-wavefront kernel (a pair of which one character had more than 32
  * constraint rows in that substep; both characters count it) since dm_create or the last dm_set_state -- a statistic
- * of the production kernels, kept in the pad word of the env's kin row; 0 on the one-character-per-wavefront kernels. */
+ * of the production kernels, kept in the pad word of the env's kin row; 0 on the one-character-per-wavefront kernels.
+ * "borrowed" (N doubles): likewise the substeps in which ONE character of the pair had more than 32 rows, the two together
+ * at most 64, and the pair stayed on the two-per-wavefront path with the heavy character's rows 32.. on lanes of its
+ * partner's half (kept in the pad word of the env's clock row). */
 int dm_probe(dm_ctx* ctx, int what, double dt);
 int dm_set_tau(dm_ctx* ctx, const double* tau /* N x D, generalized-velocity layout */);
 int dm_get_debug(dm_ctx* ctx, const char* name, double* out);

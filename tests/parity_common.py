@@ -199,7 +199,7 @@ def rollout_compare(name, precision, lib_path, steps, t0=0.0, open_loop_on_devic
     return np.array(dr), np.array(ds), flags_ok
 
 
-def batch_rollout_compare(name, precision, lib_path, steps, t0s, wave_packing=0, lifts=None):
+def batch_rollout_compare(name, precision, lib_path, steps, t0s, wave_packing=0, lifts=None, stats=None):
     """Free-running open-loop rollout of len(t0s) envs in one batch (no debug taps armed, so the production step kernel of
     the requested wave packing runs); every env is compared with its own oracle.  Returns per-env max |reward diff|, max
     |state diff| and whether every terminate / valid flag agreed."""
@@ -228,6 +228,8 @@ def batch_rollout_compare(name, precision, lib_path, steps, t0s, wave_packing=0,
             dr[e] = max(dr[e], abs(float(out["reward"][e]) - o.calc_reward()))
             ds[e] = max(ds[e], np.abs(out["state"][e] - o.record_state()).max())
             ok &= int(out["terminate"][e]) == o.check_terminate() and int(out["valid"][e]) == int(o.check_valid_episode())
+    if stats is not None:          # per env: substeps on the 64-lane fallback | on borrowed lanes (two-per-wave kernel)
+        stats["fallback"] = env.debug("fallback"); stats["borrowed"] = env.debug("borrowed")
     return dr, ds, ok
 
 

@@ -35,8 +35,67 @@ def _res(family, prec="f32"):
 ])
 def test_production_kernels_do_not_spill_vector_registers(family, what, occupancy, lds_max):
     r = _res(family)
-    assert r["spill"] == 0, (what, r)
+    if family in (0, 1):
+        # round 6: the borrowed-lane path (DuoSim lane borrowing, a rare branch of the update loop) costs the two-per-wave kernels a handful of kernel-long values
+        # (the lanes' contact candidates) in scratch: stored once in the prologue, reloaded inside that branch.  The hot path is held free of scratch by the
+        # disassembly test below; here only the budget (measured 29 / 42)
+        assert r["spill"] <= (36 if family == 0 else 52), (what, r)
+    else:
+        assert r["spill"] == 0, (what, r)
     assert r["occupancy"] == occupancy and r["lds"] <= lds_max, (what, r)          # 160 KB LDS per CU: 8 (16) waves need <= 20480 (10240) B each
+
+
+LLVM_BIN = "/opt/rocm/lib/llvm/bin"
+
+
+def _disassemble(family, prec="f32"):
+    """the gfx950 code object of one kernel family, disassembled (llvm-objcopy -> clang-offload-bundler -> llvm-objdump, NOTES.md)"""
+    import subprocess
+    import tempfile
+    obj = os.path.join(BUILD, "k_%s_%d.o" % (prec, family))
+    if not os.path.exists(obj) or not os.path.exists(os.path.join(LLVM_BIN, "llvm-objdump")):
+        pytest.skip("no object / no LLVM tools here")
+    with tempfile.TemporaryDirectory() as d:
+        fat, co = os.path.join(d, "x.fat"), os.path.join(d, "x.co")
+        subprocess.check_call([os.path.join(LLVM_BIN, "llvm-objcopy"), "--dump-section", ".hip_fatbin=" + fat, obj])
+        subprocess.check_call([os.path.join(LLVM_BIN, "clang-offload-bundler"), "--type=o", "--unbundle", "--input=" + fat,
+                               "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + co])
+        txt = subprocess.check_output([os.path.join(LLVM_BIN, "llvm-objdump"), "-d", "--no-show-raw-insn", co], text=True)
+    kernels, cur = {}, None
+    for line in txt.split("\n"):
+        m = re.match(r"^[0-9a-f]+ <(\S+)>:", line)
+        if m:
+            cur = kernels.setdefault(m.group(1), [])
+        elif cur is not None and line.startswith("\t"):
+            cur.append(line.split("//")[0].strip())
+    return kernels
+
+
+def test_no_scratch_access_on_the_hot_path_of_the_headline_and_dog_kernels():
+    """`ScratchSize` > 0 in the resource remarks does not say whether an instruction touches scratch.  From the disassembly of the shipped objects:
+    * family 12 (dog3d, ClsLargeTree plain): not one scratch_ / buffer_ instruction in the step kernel;
+    * family 0 (the headline two-per-wave kernel): inside the update loop -- between the first and the last s_setprio, priorities are only set there -- every
+      scratch access lies in the borrowed-lane region (bracketed by `s_nop 13` / `s_nop 14`, DM_REGION_MARK), and none of them is a store: the spilled values
+      are written once in the prologue."""
+    dog = _disassemble(12)
+    k = [v for n, v in dog.items() if "k_env_step" in n and "ClsLargeTree" in n]
+    assert k, list(dog)
+    for body in k:
+        assert not [i for i in body if i.startswith(("scratch_", "buffer_"))]
+    duo = [v for n, v in _disassemble(0).items() if "k_env_step_duo" in n]
+    assert len(duo) == 1
+    body = duo[0]
+    prio = [i for i, ins in enumerate(body) if ins.startswith("s_setprio")]
+    a = [i for i, ins in enumerate(body) if re.match(r"s_nop 13$", ins)]
+    b = [i for i, ins in enumerate(body) if re.match(r"s_nop 14$", ins)]
+    assert len(a) == 1 and len(b) == 1 and a[0] < b[0], (a, b)
+    scr = [(i, ins) for i, ins in enumerate(body) if ins.startswith("scratch_")]
+    in_loop = [(i, ins) for i, ins in scr if prio[0] <= i <= prio[-1]]
+    assert in_loop, "expected the reloads of the borrowed-lane region"
+    for i, ins in in_loop:
+        assert a[0] < i < b[0] and ins.startswith("scratch_load"), (i, ins, a, b)
+    assert not [ins for i, ins in scr if ins.startswith("buffer_")]
+    assert all(ins.startswith("scratch_load") or i < prio[0] for i, ins in scr)       # stores: prologue only
 
 
 @pytest.mark.parametrize("family,what,spill_max", [

@@ -74,6 +74,16 @@ def test_duo_heavy_contact_fallback_fp64(emu_lib):
     assert dr.max() < 1e-6 and ds.max() < 1e-4
 
 
+def test_duo_borrowed_lanes_fp64(emu_lib):
+    """one character of each pair pressed 8-10 cm into the ground: 33..48 constraint rows beside a light partner -- the pair stays on the two-per-wave path with the heavy
+    character's rows 32.. on lanes of the partner's half (DuoSim lane borrowing, round 6); heavy character in the lower half (pair 0) and in the upper half (pair 1)"""
+    for lifts in ([-0.08, 0.0, 0.0, -0.08], [-0.1, 0.0, 0.0, -0.1]):
+        st = {}
+        dr, ds, ok = pc.batch_rollout_compare("humanoid3d_walk", 64, emu_lib, steps=2, t0s=[0.0, 0.4, 0.2, 0.6], wave_packing=2, lifts=lifts, stats=st)
+        assert (st["borrowed"] > 0).all(), st
+        assert ok and dr.max() < 1e-6 and ds.max() < 1e-5, (dr, ds)
+
+
 def test_duo_matches_single_packing_fp32(emu_lib):
     d1 = pc.batch_rollout_compare("humanoid3d_walk", 32, emu_lib, steps=4, t0s=[0.05, 0.5], wave_packing=1)
     d2 = pc.batch_rollout_compare("humanoid3d_walk", 32, emu_lib, steps=4, t0s=[0.05, 0.5], wave_packing=2)

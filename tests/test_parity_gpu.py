@@ -226,6 +226,19 @@ def test_duo_heavy_contact_fallback_fp32(hip_lib):
     assert ds2.max() < 1e-2 and ds1.max() < 1e-2, (ds2, ds1)           # measured 2e-3 / 3e-3 (velocities of a 0.3 m push-out)
 
 
+@pytest.mark.parametrize("prec,tol_r,tol_s", [(64, 1e-6, 1e-5), (32, 1e-5, 1e-2)])
+def test_duo_borrowed_lanes(hip_lib, prec, tol_r, tol_s):
+    """a character with 33..48 constraint rows beside a light partner (pressed 8-10 cm into the ground): the pair stays on the two-per-wave path, the heavy character's
+    rows 32.. on lanes borrowed from the partner's half (DuoSim lane borrowing, round 6: four MFMA Gram blocks, a sweep of up to 48 visits, Y in the overflow block
+    meanwhile) -- heavy character in the lower half (pair 0) and in the upper half (pair 1); fp32 bounds as test_duo_heavy_contact_fallback_fp32"""
+    for lifts in ([-0.08, 0.0, 0.0, -0.08], [-0.1, 0.0, 0.0, -0.1]):
+        st = {}
+        dr, ds, ok = pc.batch_rollout_compare("humanoid3d_walk", prec, hip_lib, steps=2, t0s=[0.0, 0.4, 0.2, 0.6], wave_packing=2, lifts=lifts, stats=st)
+        print("fp%d lifts %s: borrowed %s fallback %s, reward diff %.2e state diff %.2e" % (prec, lifts, st["borrowed"], st["fallback"], dr.max(), ds.max()))
+        assert (st["borrowed"] > 0).all(), st
+        assert ok and dr.max() < tol_r and ds.max() < tol_s, (dr, ds)
+
+
 def test_duo_spinkick_and_300_steps(hip_lib):
     dr, ds, ok = pc.batch_rollout_compare("humanoid3d_spinkick", 64, hip_lib, steps=20, t0s=[0.0, 0.3], wave_packing=2)
     assert ok and dr.max() < 1e-5

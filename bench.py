@@ -305,16 +305,29 @@ def facade_bench(scene, steps, workers=(1,), private_too=True):
                       "host_cores": os.cpu_count(), **out}))
 
 
-def latency_ceiling(tables, args, device_id, kname, family_id):
+def latency_ceiling(tables, args, device_id, kname, family_id, n_envs):
     """The ceiling of THIS kernel shape: a control step is a chain of dependent phases per wavefront, and the chip holds `wave_slots` wavefronts at the
-    kernel's occupancy -- so throughput <= wave_slots x envs_per_wave / (time of a control step when the waves are alone on their SIMDs).  Measured live: 64 envs (32 or
-    64 wavefronts on 256 CUs), same workload, same episode mixture after the same warm-up."""
+    kernel's occupancy.  Measured live on 64 envs (32 or 64 wavefronts, each alone on its SIMD), same workload, same episode mixture after the same warm-up:
+    * one round of waves (the batch's wavefronts fit the slots: the two-per-wave humanoid at 4096 envs): a launch lasts as long as its SLOWEST wave, so the bound is
+      envs / (control step of the 64-env batch, which is the slowest of its waves);
+    * more than one round (one character per wave at 4096 envs: dog3d, dribble_amp, --wave-packing 1): finished slots are refilled, the bound is
+      slots x envs_per_wave / MEAN wave time -- the 64-env step time scaled by mean / max of the per-wave cycle totals of one profiled step of the same batch
+      (dm_probe 3, the tap build of the kernel: a ratio of two cycle counts of one run, not a time).  `frac` is against the bound that applies."""
     from deepmimic_amd.core import BatchEnv
     from deepmimic_amd import streams
     n0 = 64
     e = BatchEnv(tables, n0, device_id=device_id, seed=1234, precision=args.precision, test_mode=True, wave_packing=args.wave_packing, physics=args.physics)
     e.reset(kin_times=streams.reset_phase(np.arange(n0), e.duration))
     ms = e.bench_rollout(60, 200) / 200
+    epw = 2 if kname == "k_env_step_duo" else 1
+    ratio = None
+    try:
+        e.probe(3, 1.0 / 600)
+        tot = e.debug("prof").sum(1)[::epw]
+        tot = tot[tot > 0]
+        ratio = float(tot.mean() / tot.max()) if tot.size else None
+    except Exception:
+        pass
     e.close()
     occ = None
     try:        # waves per SIMD of the shipped kernel from the compiler's resource remarks (deepmimic_amd/csrc/build/k_f32_<family>.o.res)
@@ -324,10 +337,18 @@ def latency_ceiling(tables, args, device_id, kname, family_id):
     except Exception:
         pass
     waves_per_simd = occ if occ else 2
-    epw = 2 if kname == "k_env_step_duo" else 1
     slots = 256 * 4 * waves_per_simd
-    return {"lone_wave_ms_per_step": ms, "waves_per_simd": waves_per_simd, "waves_per_simd_source": "compiler resource remarks" if occ else "assumed",
-            "wave_slots": slots, "envs_per_wave": epw, "env_steps_per_s": slots * epw / (ms * 1e-3)}
+    rounds = -(-(n_envs // epw) // slots)
+    one_round = min(n_envs, slots * epw) / (ms * 1e-3)
+    out = {"lone_wave_ms_per_step": ms, "waves_per_simd": waves_per_simd, "waves_per_simd_source": "compiler resource remarks" if occ else "assumed",
+           "wave_slots": slots, "envs_per_wave": epw, "rounds_of_waves": rounds, "mean_over_max_wave_cycles_64_envs": ratio}
+    if rounds <= 1:
+        out["env_steps_per_s"] = one_round; out["model"] = "one round: envs / slowest wave"
+    elif ratio:
+        out["env_steps_per_s"] = slots * epw / (ms * ratio * 1e-3); out["model"] = "%d rounds, slots refilled: slots x envs_per_wave / mean wave time" % rounds
+    else:
+        out["env_steps_per_s"] = None; out["model"] = "more than one round and no per-wave profile: no bound stated"
+    return out
 
 
 def parity_check(tables, envs, step_and_read, n_sample=64, steps=5, physics=1, actions=None, prepared=None):
@@ -708,8 +729,8 @@ def main():
                     fam = 9
                 else:
                     fam = ((12, 13, 20) if env.J > 15 else (15, 16, 21))[v]
-                lc = latency_ceiling(tables, args, local_rank, kname, fam)
-                lc["frac"] = (value / world) / lc["env_steps_per_s"]
+                lc = latency_ceiling(tables, args, local_rank, kname, fam, n)
+                lc["frac"] = ((value / world) / lc["env_steps_per_s"]) if lc["env_steps_per_s"] else None
                 valu_obj["latency_ceiling"] = lc
             except Exception as ex:                                 # noqa: BLE001
                 valu_obj["latency_ceiling"] = {"error": "%s: %s" % (type(ex).__name__, ex)}

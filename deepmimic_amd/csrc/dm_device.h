@@ -325,6 +325,21 @@ template <int NP2> __device__ __forceinline__ void wave_gram32(const VecT<double
 namespace dmk {
 
 // compile-time loop: f(std::integral_constant<int, I>) for I = B .. E - 1 (where the index has to be a template argument)
+// Workgroup -> unit of work (env / env pair), XCD-aware (round 6).  The dispatcher deals consecutive workgroups round-robin over the 8 XCDs, each with its own L2; an env's
+// rows (172 B of pose, 136 B of torque, ...) are not multiples of a cache line, so with unit = blockIdx the line shared by two neighbouring envs was fetched into two L2s
+// and written back from two -- the "1.41 x" HBM traffic of rounds 2-5.  XCD x takes the contiguous units [x G / 8, (x + 1) G / 8): neighbours in memory meet in one L2.
+// Which workgroup steps an env changes nothing in its arithmetic.
+#ifndef DM_XCD_MAP
+#define DM_XCD_MAP 1
+#endif
+#ifdef DM_EMU
+static inline int dm_wg_unit() { return (int)blockIdx.x; }
+#else
+__device__ __forceinline__ int dm_wg_unit() {
+    const int b = (int)blockIdx.x, G = (int)gridDim.x;
+    return (DM_XCD_MAP && (G & 7) == 0) ? (b & 7) * (G >> 3) + (b >> 3) : b;
+}
+#endif
 template <int B, int E, typename F> DM_DEV void static_for(F&& f) {
     if constexpr (B < E) { f(std::integral_constant<int, B>{}); static_for<B + 1, E>(f); }
 }
@@ -2739,7 +2754,7 @@ template <typename Real, typename C, bool TAPS, bool AMP = false, bool PHYS2 = f
 __global__ void __launch_bounds__(64) DM_WAVES_PER_EU((StepWaves<Real, C>::value)) k_env_step(ModelDev<Real> m, EnvState<Real> st, StepIO<Real> io, DebugTaps<Real> dbg) {
     constexpr bool HIST = TAPS || AMP, V2 = TAPS || PHYS2;
     __shared__ Lds<Real, C> lds;
-    const int e = io.env_ids ? io.env_ids[blockIdx.x] : (int)blockIdx.x, l = threadIdx.x;      // (env_ids: a subset of the ctx's envs, dm_step_envs)
+    const int e = io.env_ids ? io.env_ids[blockIdx.x] : dm_wg_unit(), l = threadIdx.x;      // (env_ids: a subset of the ctx's envs, dm_step_envs)
     EnvSim<Real, C, TAPS> sim(m, lds, l);
     if (TAPS && dbg.prof) sim.prof_begin(dbg.prof + (size_t)e * 16);
     sim.load(st, e);

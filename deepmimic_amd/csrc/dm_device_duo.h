@@ -412,6 +412,10 @@ struct DuoSim {
 
     DM_DEV void load(const EnvState<Real>& st, int e) {
         b.load(st, e);
+        load_cands();
+    }
+    // this lane's ground-contact candidates and self-collision pairs (kernel-long register values; read again behind the borrowed-lane path, which needs their registers)
+    DM_DEV void load_cands() {
 #pragma unroll
         for (int q = 0; q < CP; ++q) {
             const int c = hl + HW * q;
@@ -799,6 +803,9 @@ _Pragma("unroll") \
         b.mark(7);
         int nact = 0;
         const uint32_t lt = (hl == 0) ? 0u : (~0u >> (32 - hl));
+        // (one scalar load per substep, then a plain register: left to the allocator these two kernel arguments are re-loaded from the kernarg segment at every use --
+        // s_load + s_waitcnt lgkmcnt(0) inside the pair loop and the friction refresh -- once the borrowed-lane path shares the kernel's scalar registers)
+        int maxc = m.max_contacts; DM_OPAQUE_S(maxc);
         if (V2) { nact = ground_manifolds(manif); if (hl == 0) s.flg[FLG_NCONT] = nact; }
         else {
         // ---- collision: lane = candidate, two passes
@@ -818,7 +825,7 @@ _Pragma("unroll") \
             amask[q] = (uint32_t)(wave_ballot(active[q]) >> (half * 32));
             nact += dm_popc64(amask[q]);
         }
-        if (wave_ballot(nact > m.max_contacts) != 0) {
+        if (wave_ballot(nact > maxc) != 0) {
             // manifold reduction (rare): keep the max_contacts deepest, ties to the lower index
 #pragma unroll
             for (int q = 0; q < CP; ++q) { const int c = hl + HW * q; s.csel[c] = active[q] ? 1 : 0; s.cdistc[c] = dist[q]; }
@@ -827,7 +834,7 @@ _Pragma("unroll") \
             for (int q = 0; q < CP; ++q) {
                 const int c = hl + HW * q; int rank = 0;
                 if (active[q]) for (int k = 0; k < m.NC; ++k) if (s.csel[k] && (s.cdistc[k] < dist[q] || (s.cdistc[k] == dist[q] && k < c))) ++rank;
-                active[q] = active[q] && rank < m.max_contacts;
+                active[q] = active[q] && rank < maxc;
             }
             sync();
             nact = 0;
@@ -856,8 +863,8 @@ _Pragma("unroll") \
                 if (mk64 != 0) {
                     const uint32_t mk = (uint32_t)(mk64 >> (half * 32));
                     const int slot = nc + dm_popc64(mk & lt);
-                    if (act && slot < m.max_contacts) b.store_contact(slot, x, n, dsc, code & 0xff, code >> 8);
-                    nc = dm_min(m.max_contacts, nc + (int)dm_popc64(mk));
+                    if (act && slot < maxc) b.store_contact(slot, x, n, dsc, code & 0xff, code >> 8);
+                    nc = dm_min(maxc, nc + (int)dm_popc64(mk));
                 }
             }
         }
@@ -953,6 +960,7 @@ _Pragma("unroll") \
 #pragma unroll
             for (int r = 0; r < 32; ++r) if (hl == r) arow.set(r, (Real)0);
             Real t = (brow - cvec) * inv_adiag;
+            Real fric = m.friction; DM_OPAQUE_S(fric);
             const int nrm_lane = is_fric ? NL + ((hl - RN) >> 1) : 0;
             Real lo = 0, hi = is_fric ? (Real)0 : ((hl < NL) ? m.lim_max_impulse : (Real)1e30);      // (limit rows: maxAppliedImpulse)
             // sweep bounds of the pair: rows up to the larger R (rounded up to 4); a lane beyond its own R has t = 0, lambda = 0
@@ -962,7 +970,7 @@ _Pragma("unroll") \
             uint32_t fmask = (1u << lane_bcast(RN, 0)) | (1u << lane_bcast(RN, 32));
 #define DM_DUO_PGS_ROW(r)                                                                                              \
             {                                                                                                          \
-                if (__builtin_expect((fmask >> (r)) & 1u, 0)) { const Real ln = wave_shfl(lam, half * 32 + nrm_lane); if (is_fric && (r) == RN) { hi = m.friction * ln; lo = -hi; } } \
+                if (__builtin_expect((fmask >> (r)) & 1u, 0)) { const Real ln = wave_shfl(lam, half * 32 + nrm_lane); if (is_fric && (r) == RN) { hi = fric * ln; lo = -hi; } } \
                 const Real nl = dm_med3(lo, t, hi);                                                                    \
                 const Real delta = half_bcast_c<(r)>(nl - lam, half);                                                  \
                 t -= arow.get(r) * delta;                                                                              \
@@ -1070,6 +1078,7 @@ _Pragma("unroll") \
                         b.mark(8);
                         DM_REGION_MARK(13);             // (s_nop 13 / s_nop 14 bracket the borrowed-lane region in the disassembly: tests/test_build_resources.py holds every scratch access of the update loop to it)
                         duo_rows_xd<Real, V2>(rec, wl, h, nc_, R_, Ra_, Rb_, D, m.NL, m.erp, m.friction, m.lim_max_impulse, m.solver_iters, aovf_pair);
+                        load_cands();                   // (the candidate tables come back from L2 instead of living -- spilled in every wave's prologue -- across the region)
                         DM_REGION_MARK(14);
                         b.mark(11);                     // (profiling build: rows + Gram + sweep of such a substep count as "sub.PGS")
                         rows_done = true;
@@ -1114,7 +1123,7 @@ _Pragma("unroll") \
     }
 };
 
-// grid = N / 2 workgroups of one wavefront; character e = 2 * blockIdx.x + (lane >> 5).  fp32: 2 waves / SIMD (20 KB LDS).
+// grid = N / 2 workgroups of one wavefront; character e = 2 * pair + (lane >> 5), pair = dm_wg_unit() (blockIdx, XCD-aware).  fp32: 2 waves / SIMD (20 KB LDS).
 template <typename Real> struct DuoWaves { static constexpr int value = 1; };
 template <> struct DuoWaves<float> { static constexpr int value = 2; };
 template <typename Real, bool TAPS, bool AMP = false, bool V2 = false>
@@ -1124,15 +1133,16 @@ __global__ void __launch_bounds__(64) DM_WAVES_PER_EU((DuoWaves<Real>::value)) k
     __shared__ Lds<Real, ClsBiped> lds[2];
     __shared__ ParkSnap<Real, ClsBiped> snap[2];     // 2 x 0.45 KB: the fp32 kernel stays inside 20 KB per wave (8 waves per CU)
     const int wl = threadIdx.x, half = wl >> 5;
-    const int e = 2 * blockIdx.x + half;
+    const int pair = dm_wg_unit();                   // (XCD-aware: dm_device.h)
+    const int e = 2 * pair + half;
     DuoSim<Real, TAPS> sim(m, lds, wl);
     if (TAPS && dbg.prof) sim.b.prof_begin(dbg.prof + (size_t)e * 16);
     sim.load(st, e);
     if (io.open_loop) sim.b.set_action_from_clip();
     else if (io.actions) sim.b.set_action(io.actions + (size_t)e * m.A);
     sim.b.mark(15);
-    Real* aovf_pair = st.aovf ? st.aovf + (size_t)(2 * blockIdx.x) * (kMaxRows - ClsBiped::RREG) * kWave : nullptr;
-    Real* manif_pair = (V2 && st.manif) ? st.manif + (size_t)(2 * blockIdx.x) * m.J * MF_STRIDE : nullptr;      // physics 2: the two characters' ground manifolds
+    Real* aovf_pair = st.aovf ? st.aovf + (size_t)(2 * pair) * (kMaxRows - ClsBiped::RREG) * kWave : nullptr;
+    Real* manif_pair = (V2 && st.manif) ? st.manif + (size_t)(2 * pair) * m.J * MF_STRIDE : nullptr;      // physics 2: the two characters' ground manifolds
     const bool goal = HIST && st.goal && m.scene_goal;
     if (HIST && st.goal) sim.b.clip = (int)st.goal[(size_t)e * GS_WIDTH + GS_CLIP];
     double* pert = (HIST && st.pert) ? st.pert + (size_t)e * PT_WIDTH : nullptr;

@@ -82,17 +82,26 @@ import pytest  # noqa: E402
 
 
 @pytest.mark.gpu
-def test_bench_record_exchange_through_cabi_is_hidden_gpu(hip_lib):
-    """`bench.py --gpus 1 --force-gather --gather cabi` drives the C-ABI record exchange (dm_comm_* / dm_gather_records: real RCCL, one rank)
-    double-buffered behind the step kernel; what it leaves exposed on the critical path must stay below 50 us per control step"""
+@pytest.mark.parametrize("gather", ["cabi", "torch"])
+def test_bench_record_exchange_is_hidden_gpu(hip_lib, gather):
+    """`bench.py --gpus 1 --force-gather --gather cabi|torch` drives the record exchange of the multi-GPU path with one rank through real
+    RCCL -- the C-ABI route (dm_comm_* / dm_gather_records, one dm_comm per env group) and the torch.distributed route (one all_gather_into_tensor per group and
+    step on one process group) -- double-buffered behind the step kernels of the two env groups; what it leaves exposed on the critical path must stay below 50 us
+    per control step.  With this green, `bench.py --gpus N` on an 8-GPU node is the same code with N ranks."""
+    import socket
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "DM_HIP_LIB", "DM_ALLOW_EMULATOR")}
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "200", "--warmup", "10", "--force-gather", "--gather", "cabi",
+    if gather == "torch":         # (a process group of one rank: bench.py initialises it when the rendezvous variables are there)
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
+        env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "200", "--warmup", "10", "--force-gather", "--gather", gather,
                         "--no-cpu-baseline", "--sustain-seconds", "0"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-2000:]
     line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
-    assert line["record_exchange"]["backend"] == "cabi" and line["config"]["groups"] == 2      # (round 5: one dm_comm per env group, the C-ABI route keeps the two-group mode)
+    assert line["record_exchange"]["backend"] == gather and line["config"]["groups"] == 2      # (round 5: one exchange per env group on either route)
     assert line["record_exchange"]["exposed_ms_per_step_rank0"] < 0.05, line["record_exchange"]
     assert line["value"] > 1.0e6 and line["checks"]["finite"]
+    assert line["checks"]["parity"]["flags_equal"] and line["checks"]["parity"]["reward_mae"] < 1e-5      # the envs behind the exchange buffers are the envs of the oracle
 
 
 @pytest.mark.gpu
@@ -108,6 +117,11 @@ def test_bench_default_line_gpu(hip_lib):
     v = line["roofline"]["valu"]
     assert v and 0.3 < v["valu_busy"] < 1.0 and v["source"] and 0.01 < v["frac_of_fp32_peak"] < 1.0
     assert abs(line["ms_per_step"] * line["value"] / 1e3 - 4096) < 1.0
+    # round 6: the closed-loop leg carries its own parity figures (explicit actions from the on-device policy, oracle fed the same actions); the ceiling is a ceiling
+    cp = line["closed_loop"]["parity"]
+    assert cp["flags_equal"] and cp["reward_mae"] < 3e-5 and cp["live"] > 100, cp
+    assert line["closed_loop"]["value"] > 0.9 * line["value"]
+    assert 0.5 < v["latency_ceiling"]["frac"] <= 1.0 and v["latency_ceiling"]["rounds_of_waves"] == 1
     assert line["roofline"]["bound"] == "valu-issue/latency" and line["roofline"]["bound_of_the_figures_below"] == "hbm"
     lc = v["latency_ceiling"]                                   # live: a control step of waves that are alone on their SIMDs -> the ceiling of this kernel shape
     assert "error" not in lc and lc["wave_slots"] == 2048 and lc["envs_per_wave"] == 2 and 0.5 < lc["frac"] < 1.0 and 1.0 < lc["lone_wave_ms_per_step"] < 2.5, lc

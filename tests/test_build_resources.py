@@ -36,10 +36,10 @@ def _res(family, prec="f32"):
 def test_production_kernels_do_not_spill_vector_registers(family, what, occupancy, lds_max):
     r = _res(family)
     if family in (0, 1):
-        # round 6: the borrowed-lane path (DuoSim lane borrowing, a rare branch of the update loop) costs the two-per-wave kernels a handful of kernel-long values
-        # (the lanes' contact candidates) in scratch: stored once in the prologue, reloaded inside that branch.  The hot path is held free of scratch by the
-        # disassembly test below; here only the budget (measured 29 / 42)
-        assert r["spill"] <= (36 if family == 0 else 52), (what, r)
+        # round 6: the borrowed-lane path (DuoSim lane borrowing, a rare branch of the update loop) shares the two-per-wave kernels' register file: measured 1 / 7 spilled
+        # VGPRs (29 / 42 before that path re-read the lanes' candidate tables behind itself: 10 MB of prologue spill stores per 4096-env launch).  The hot path is held
+        # free of scratch by the disassembly test below; here the budget
+        assert r["spill"] <= (4 if family == 0 else 12), (what, r)
     else:
         assert r["spill"] == 0, (what, r)
     assert r["occupancy"] == occupancy and r["lds"] <= lds_max, (what, r)          # 160 KB LDS per CU: 8 (16) waves need <= 20480 (10240) B each
@@ -91,8 +91,7 @@ def test_no_scratch_access_on_the_hot_path_of_the_headline_and_dog_kernels():
     assert len(a) == 1 and len(b) == 1 and a[0] < b[0], (a, b)
     scr = [(i, ins) for i, ins in enumerate(body) if ins.startswith("scratch_")]
     in_loop = [(i, ins) for i, ins in scr if prio[0] <= i <= prio[-1]]
-    assert in_loop, "expected the reloads of the borrowed-lane region"
-    for i, ins in in_loop:
+    for i, ins in in_loop:          # (none at all in the shipped build: the borrowed-lane path re-reads the lanes' candidate tables behind itself instead of keeping them alive)
         assert a[0] < i < b[0] and ins.startswith("scratch_load"), (i, ins, a, b)
     assert not [ins for i, ins in scr if ins.startswith("buffer_")]
     assert all(ins.startswith("scratch_load") or i < prio[0] for i, ins in scr)       # stores: prologue only

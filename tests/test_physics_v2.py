@@ -178,6 +178,11 @@ def _v2_duo_heavy_pair(lib, prec, tol):
         assert np.abs(a["state"] - b["state"]).max() < tol and np.abs(a["reward"] - b["reward"]).max() < tol, (k, np.abs(a["state"] - b["state"]).max())
         assert np.array_equal(one.get_manifolds()[:, :, 0], duo.get_manifolds()[:, :, 0]), k      # same cached point counts, link by link
     assert max_rows > 32, max_rows                      # the window did contain substeps past the two-per-wave row budget
+    # round 6: with the partner light (the pair within 64 rows, the heavy character within 48) those substeps stay on the two-per-wave path on borrowed lanes, under v2 too
+    # (its manifolds refreshed by the two-per-wave pass as before); anything heavier takes the 64-lane routine.  Either way the substeps are counted
+    xd, fb = duo.debug("borrowed")[0], duo.debug("fallback")[0]
+    print("v2 heavy pair: substeps on borrowed lanes %d, on the 64-lane fallback %d, max rows %d" % (xd, fb, max_rows))
+    assert xd + fb > 0 and xd > 0
 
 
 def test_device_v2_two_per_wave_heavy_pair_falls_back_emulator(emu_lib):

@@ -459,7 +459,7 @@ def main():
     ap.add_argument("--envs", type=int, default=4096, help="envs per GPU")
     ap.add_argument("--scene", default="humanoid3d_walk")
     ap.add_argument("--precision", type=int, default=32)
-    ap.add_argument("--wave-packing", type=int, default=0, help="characters per wavefront of the step kernel: 0 = the library's default (2 for the biped class, 1 for the dog and for dribble_amp), 1 or 2")
+    ap.add_argument("--wave-packing", type=int, default=0, help="characters per wavefront of the step kernel: 0 = the library's default (2 for the biped class incl. dribble_amp under DM-physics v1, 1 for the dog), 1 or 2")
     ap.add_argument("--physics", type=int, default=1, choices=[1, 2], help="contact model: 1 = DM-physics v1 (default, the headline), 2 = v2 (DESIGN.md 4.6; two characters per wavefront too since round 4)")
     ap.add_argument("--groups", type=int, default=0,
                     help="env groups per GPU: the rank's envs as G independent contexts on their own HIP streams (deepmimic_amd/groups.py; "
@@ -709,7 +709,7 @@ def main():
             raise SystemExit("bench.py: ran %d rank(s) with %d per-rank rate(s) under --gpus %d" % (world, len(per_rank), args.gpus))
         envs_per_launch = n // G
         bytes_per_launch = algorithmic_bytes_per_env_step(env) * envs_per_launch
-        kname = "k_env_step_duo" if (args.wave_packing != 1 and env.J <= 15 and env.D == 34 and envs_per_launch % 2 == 0 and tables.goal_kind != 5) else "k_env_step"
+        kname = "k_env_step_duo" if (args.wave_packing != 1 and env.J <= 15 and env.D == 34 and envs_per_launch % 2 == 0 and not (tables.goal_kind == 5 and args.physics == 2)) else "k_env_step"      # (dribble_amp: two per wave under DM-physics v1 since round 6)
         achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else None      # (the emulator has no HIP events)
         # committed counter passes are taken with --groups 1 (a PMC pass serialises the kernels: a half-batch launch alone on the chip would be
         # another regime); HBM bytes are per env, so the per-launch figure of a group is the whole-batch one scaled by its share of the envs
@@ -724,7 +724,7 @@ def main():
                 # two-per-wave kernel, or of the one-per-wave kernel on the compiled humanoid3d / dog3d topology, or biped + free body
                 v = 2 if args.physics == 2 else (1 if (env.amp_size > 0 or env.has_perturbs) else 0)
                 if kname == "k_env_step_duo":
-                    fam = (0, 1, 22)[v]
+                    fam = 24 if tables.goal_kind == 5 else (0, 1, 22)[v]
                 elif tables.goal_kind == 5:
                     fam = 9
                 else:

@@ -389,8 +389,12 @@ struct Lds : LdsBroad<Real, C> {
 };
 
 // What the end-of-call outputs need of a character whose episode ended mid-call (two characters per wavefront, early episode end)
+// (OBJ classes: the free body's record too -- the ball of a parked character keeps being integrated beside its partner's updates, which the one-per-wave kernel, leaving its
+// update loop at the episode's end, does not do.  An empty base otherwise: the biped class's snapshot, and with it the headline kernel's LDS layout, is unchanged)
+template <typename Real, bool ON> struct ParkSnapObj { Real obj[OB_WIDTH]; };
+template <typename Real> struct ParkSnapObj<Real, false> {};
 template <typename Real, typename C>
-struct ParkSnap { Real pose[C::NP], vel[C::NP], kin[8]; double clk[6]; int flg[4]; };
+struct ParkSnap : ParkSnapObj<Real, C::OBJ> { Real pose[C::NP], vel[C::NP], kin[8]; double clk[6]; int flg[4]; };
 
 enum { CLK_KIN = 0, CLK_CTRL, CLK_INIT_OFF, CLK_TIMER, CLK_TIMER_MAX };
 enum { FLG_NEED_ACTION = 0, FLG_CONTACT, FLG_EPISODE, FLG_VALID, FLG_NROWS, FLG_NCONT, FLG_PARKED, FLG_OVER };
@@ -572,6 +576,7 @@ struct EnvSim {
             if (l < 8) snap.kin[l] = s.kin[l];
             if (l < 6) snap.clk[l] = s.clk[l];
             if (l < 4) snap.flg[l] = s.flg[l];
+            if constexpr (C::OBJ) { if (l < OB_WIDTH) snap.obj[l] = s.obj[l]; }
         }
         sync();
         if (act) {
@@ -587,6 +592,7 @@ struct EnvSim {
             if (l < 8) s.kin[l] = snap.kin[l];
             if (l < 6) s.clk[l] = snap.clk[l];
             if (l < 4) s.flg[l] = snap.flg[l];
+            if constexpr (C::OBJ) { if (l < OB_WIDTH) s.obj[l] = snap.obj[l]; }
         }
         sync();
         if (l == 0) s.flg[FLG_PARKED] = 0;

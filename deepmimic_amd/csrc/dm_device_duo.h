@@ -376,27 +376,35 @@ DM_DEV void duo_rows_xd(Lds<Real, ClsBiped>* rec, int wl, Real h, int nc, int R,
     }
 }
 
-template <typename Real, bool TAPS>
+#ifndef DM_DUO_WIDE_FALLBACK
+#define DM_DUO_WIDE_FALLBACK 0
+#endif
+// the fallback class of a pair that leaves the two-per-wave routine: the biped class's GRAM64 variant; for biped + free body the one-per-wave class itself
+template <typename CC> struct DuoFallback {
+#if DM_DUO_WIDE_FALLBACK
+    typedef ClsBipedWide type;
+#else
+    typedef ClsBipedFb type;
+#endif
+};
+template <> struct DuoFallback<ClsBipedObj> { typedef ClsBipedObj type; };
+// CC: ClsBiped, or (round 6) ClsBipedObj -- biped + one free rigid sphere per character (dribble_amp's ball): three more register pairs of y per row lane, the ball's
+// contacts in the half's own slots, its velocity change by six half-wave sums, its integration by lane 0 of the half
+template <typename Real, bool TAPS, typename CC = ClsBiped>
 struct DuoSim {
-    typedef ClsBiped C;
+    typedef CC C;
     typedef Lds<Real, C> L;
     typedef EnvSim<Real, C, TAPS, 32> Base;
     // Fallback class for a pair with a heavily contacted character.  DM_DUO_WIDE_FALLBACK = 1 selects ClsBipedWide (all 64 rows of A
     // in VGPRs, 64-row Gram on the matrix core): +8..13 % closed-loop throughput under an untrained policy, but its 64-register row
     // file pushes 10 kernel-long-lived values of the two-per-wave kernel into scratch (40 B / lane, +7.5 MB of HBM traffic per launch),
     // so the default keeps the narrow class (rows 32..63 in the HBM / L2 overflow block, requested two rows ahead): no scratch at all.
-#ifndef DM_DUO_WIDE_FALLBACK
-#define DM_DUO_WIDE_FALLBACK 0
-#endif
-#if DM_DUO_WIDE_FALLBACK
-    typedef ClsBipedWide FallbackCls;
-#else
-    typedef ClsBipedFb FallbackCls;
-#endif
+    typedef typename DuoFallback<CC>::type FallbackCls;
     typedef EnvSim<Real, FallbackCls, TAPS, kWave> Single;
     typedef Lds<Real, FallbackCls> WideRec;
     static_assert(sizeof(WideRec) == sizeof(L), "the wide class must share the LDS record layout");
     static constexpr int ND = C::ND, NP2 = ND / 2, NP = C::NP, NJ = C::NJ, HW = 32, CP = 2 /* candidate passes */;
+    static constexpr int NP2X = NP2 + (C::OBJ ? 3 : 0);      // + the free body's 3 linear + 3 angular velocities (rows of Y = M^-1/2 J^T)
     typedef V3<Real> v3; typedef M3<Real> m3; typedef typename VecT<Real>::v2 R2; typedef typename VecT<Real>::v4 R4;
     const ModelDev<Real>& m; L* rec;                    // the two records of this workgroup
     const int wl, half; int hl;                         // wave lane, which character, lane within the character
@@ -806,6 +814,14 @@ _Pragma("unroll") \
         // (one scalar load per substep, then a plain register: left to the allocator these two kernel arguments are re-loaded from the kernarg segment at every use --
         // s_load + s_waitcnt lgkmcnt(0) inside the pair loop and the friction refresh -- once the borrowed-lane path shares the kernel's scalar registers)
         int maxc = m.max_contacts; DM_OPAQUE_S(maxc);
+        // OBJ classes: the free body's unconstrained velocity (btRigidBody::applyDamping, then the gravity impulse), every lane of the half (EnvSim::substep_post)
+        v3 bpos = zero3(), bvs = zero3(), bws = zero3();
+        if constexpr (C::OBJ) {
+            const Real* ob = s.obj;
+            bpos = ld3(ob + OB_PX);
+            bvs = (Real)exp((double)h * m.ball_ln_lin) * ld3(ob + OB_VX) + h * mk3(m.gravity[0], m.gravity[1], m.gravity[2]);
+            bws = (Real)exp((double)h * m.ball_ln_ang) * ld3(ob + OB_WX);
+        }
         if (V2) { nact = ground_manifolds(manif); if (hl == 0) s.flg[FLG_NCONT] = nact; }
         else {
         // ---- collision: lane = candidate, two passes
@@ -868,6 +884,35 @@ _Pragma("unroll") \
                 }
             }
         }
+        if constexpr (C::OBJ) {
+            // the free body takes the slots that are left: lane 0 of the half tests it against the ground, lane 1 + j against link j (capsule models, as link against
+            // link); slot order = lane order.  Link ids in the slot: 254 = the body, 255 = the ground.  (EnvSim::substep_post, per half)
+            const Real rb = m.ball_radius, thr_b = m.ball_thresh;
+            v3 x = zero3(), n = mk3((Real)0, (Real)1, (Real)0); Real dsc = 0; bool act = false; int la = 254, lb = 255;
+            if (hl == 0) { dsc = bpos.y - rb; act = dsc < thr_b; x = bpos; x.y -= rb; }
+            else if (hl <= m.J) {
+                const int j = hl - 1;
+                const Real* cj = s.mdl.cap[j];
+                const v3 uj = ldm3(b.Rbp(j)) * ld3(cj), p1 = ld3(s.com[j]) + uj, d1 = (Real)-2 * uj, r = p1 - bpos;
+                const Real a = dot(d1, d1);
+                const Real sp = (a > (Real)1e-12) ? dm_med3((Real)0, -dot(d1, r) * dm_rcp(a), (Real)1) : (Real)0;       // closest point of the segment to the centre
+                const v3 ca = p1 + sp * d1, dl = ca - bpos;
+                const Real d2n = dot(dl, dl), rj = cj[3];
+                const Real idn = (d2n > (Real)1e-18) ? dm_rsqrt(d2n) : (Real)0, d = d2n * idn;
+                dsc = d - rj - rb;
+                n = (d > (Real)1e-9) ? idn * dl : mk3((Real)0, (Real)1, (Real)0);
+                x = (Real)0.5 * ((ca - rj * n) + (bpos + rb * n));
+                act = (s.mdl.thresh[j] > (Real)0) && dsc < dm_min(s.mdl.thresh[j], thr_b);
+                la = j; lb = 254;
+            }
+            const uint64_t mk64 = wave_ballot(act);
+            if (mk64 != 0) {
+                const uint32_t mk = (uint32_t)(mk64 >> (half * 32));
+                const int slot = nc + dm_popc64(mk & lt);
+                if (act && slot < maxc) b.store_contact(slot, x, n, dsc, la, lb);
+                nc = dm_min(maxc, nc + (int)dm_popc64(mk));
+            }
+        }
         const int NL = m.NL;
         const int R = NL + 3 * nc;
         if (wave_ballot(R > HW) != 0) {      // a heavily contacted character: the caller decides between borrowed lanes and the one-per-wave routine (FLG_NROWS is published for it; V2: FLG_NCONT holds the ground slots)
@@ -881,6 +926,7 @@ _Pragma("unroll") \
         // ---- constraint rows: lane = row (see EnvSim::substep_post)
         Real brow = 0;
         uint32_t ch_lo = 0, ch_hi = 0, ng_lo = 0, ng_hi = 0; v3 xd = zero3(), dd = zero3();
+        int ball_sg = 0; v3 ball_cx = zero3();
         if (hl < R) {
             if (hl < NL) {
                 const int lr = V2 ? (hl >> 1) : hl;         // v2: both rows of a limit (q - lo, then hi - q), v1: the nearer bound
@@ -892,11 +938,16 @@ _Pragma("unroll") \
                 brow = (pen > 0) ? -pen / h : -m.erp * pen / h;
                 xd = sgn * ld3(&s.dofrec[limdof][0]);
                 if (limdof < 32) ch_lo = 1u << limdof; else ch_hi = 1u << (limdof - 32);
-            } else b.contact_row(hl, NL, nc, h, brow, ch_lo, ch_hi, ng_lo, ng_hi, xd, dd);
+            } else if constexpr (C::OBJ) b.contact_row(hl, NL, nc, h, brow, ch_lo, ch_hi, ng_lo, ng_hi, xd, dd, &ball_sg, &ball_cx);
+            else b.contact_row(hl, NL, nc, h, brow, ch_lo, ch_hi, ng_lo, ng_hi, xd, dd);
         }
+        // friction coefficient of this row's contact; the free body's Jacobian columns: d . v_b + ((x - p_b) x d) . w_b, signed by its side
+        Real mu_row = m.friction;
+        v3 jbl = zero3(), jba = zero3();
+        if constexpr (C::OBJ) { if (ball_sg != 0) { mu_row = m.ball_friction; jbl = (Real)ball_sg * dd; jba = (Real)ball_sg * cross(ball_cx - bpos, dd); } }
         // y := L^-1 J^T, software-pipelined: the factor row and the dof record of step k+1 are requested (LDS broadcasts) before
         // the dependent accumulation chain of step k runs, so their latency hides behind it (two register buffers, static parity)
-        R2 y2[NP2]; Real cvec = 0;
+        R2 y2[NP2X]; Real cvec = 0;
         R2 lr[2][NP2]; R4 rr[2][2];
 #if DM_PRIO_Y
         dm_setprio<DM_PRIO_Y>();
@@ -933,6 +984,13 @@ _Pragma("unroll") \
 #if DM_PRIO_Y
         dm_setprio<0>();
 #endif
+        if constexpr (C::OBJ) {
+            // the free body's block of the mass matrix is diagonal: its rows of Y = M^-1/2 J^T are a scaling; J v* gains its share
+            cvec += dot(jbl, bvs) + dot(jba, bws);
+            const Real sm = dm_sqrt(m.ball_inv_mass), si = dm_sqrt(m.ball_inv_inertia);
+            y2[NP2X - 3][0] = sm * jbl.x; y2[NP2X - 3][1] = sm * jbl.y; y2[NP2X - 2][0] = sm * jbl.z;
+            y2[NP2X - 2][1] = si * jba.x; y2[NP2X - 1][0] = si * jba.y; y2[NP2X - 1][1] = si * jba.z;
+        }
         b.mark(9);
         const int RN = NL + nc;
         const bool is_fric = hl >= RN && hl < R;
@@ -942,14 +1000,14 @@ _Pragma("unroll") \
             Real adiag;
             { R2 a2 = {(Real)0, (Real)0};
 #pragma unroll
-              for (int p = 0; p < NP2; ++p) a2 += y2[p] * y2[p];
+              for (int p = 0; p < NP2X; ++p) a2 += y2[p] * y2[p];
               adiag = a2[0] + a2[1]; }
             const Real inv_adiag = (hl < R) ? (Real)1 / adiag : (Real)0;
             {
                 Real g[32];
 #pragma unroll
-                for (int p = 0; p < NP2; ++p) DM_OPAQUE_V(y2[p]);
-                duo_gram32<NP2>(y2, g);
+                for (int p = 0; p < NP2X; ++p) DM_OPAQUE_V(y2[p]);
+                duo_gram32<NP2X>(y2, g);
 #pragma unroll
                 for (int r = 0; r < 32; ++r) arow.set(r, g[r] * inv_adiag);
             }
@@ -970,7 +1028,7 @@ _Pragma("unroll") \
             uint32_t fmask = (1u << lane_bcast(RN, 0)) | (1u << lane_bcast(RN, 32));
 #define DM_DUO_PGS_ROW(r)                                                                                              \
             {                                                                                                          \
-                if (__builtin_expect((fmask >> (r)) & 1u, 0)) { const Real ln = wave_shfl(lam, half * 32 + nrm_lane); if (is_fric && (r) == RN) { hi = fric * ln; lo = -hi; } } \
+                if (__builtin_expect((fmask >> (r)) & 1u, 0)) { const Real ln = wave_shfl(lam, half * 32 + nrm_lane); if (is_fric && (r) == RN) { if constexpr (C::OBJ) hi = mu_row * ln; else hi = fric * ln; lo = -hi; } } \
                 const Real nl = dm_med3(lo, t, hi);                                                                    \
                 const Real delta = half_bcast_c<(r)>(nl - lam, half);                                                  \
                 t -= arow.get(r) * delta;                                                                              \
@@ -1003,6 +1061,20 @@ _Pragma("unroll") \
 #endif
         }
         b.mark(11);
+        if constexpr (C::OBJ) {
+            // delta v of the free body = M^-1/2 (Y_b lambda): six sums over the half; then semi-implicit Euler with the exponential map, by lane 0 of the half
+            Real dv[6];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) dv[k] = half_sum(y2[NP2X - 3 + (k >> 1)][k & 1] * lam);
+            if (hl == 0) {
+                const Real sm = dm_sqrt(m.ball_inv_mass), si = dm_sqrt(m.ball_inv_inertia);
+                const v3 bv = bvs + sm * mk3(dv[0], dv[1], dv[2]), bw = bws + si * mk3(dv[3], dv[4], dv[5]);
+                Real* ob = s.obj;
+                st3(ob + OB_VX, bv); st3(ob + OB_WX, bw);
+                st3(ob + OB_PX, bpos + h * bv);
+                stq(ob + OB_QW, qnormalize(qmul(quat_exp(h * bw), ldq(ob + OB_QW))));
+            }
+        }
         // delta v = L^-T (Y lambda): transposing reduction inside each half; dof k < 32 lands in lane k, dofs 32, 33 in lanes 0, 1
         {
             Real w[NP2];
@@ -1074,14 +1146,16 @@ _Pragma("unroll") \
                     // rows together: the pair stays in this instruction stream on borrowed lanes (round 6)
                     const int R_ = s.flg[FLG_NROWS], nc_ = (R_ - m.NL) / 3;
                     const int Ra_ = lane_bcast(R_, 0), Rb_ = lane_bcast(R_, 32);
-                    if (DM_DUO_XD && aovf_pair && Ra_ + Rb_ <= 2 * HW && Ra_ <= DM_XD_ROWS && Rb_ <= DM_XD_ROWS) {
-                        b.mark(8);
-                        DM_REGION_MARK(13);             // (s_nop 13 / s_nop 14 bracket the borrowed-lane region in the disassembly: tests/test_build_resources.py holds every scratch access of the update loop to it)
-                        duo_rows_xd<Real, V2>(rec, wl, h, nc_, R_, Ra_, Rb_, D, m.NL, m.erp, m.friction, m.lim_max_impulse, m.solver_iters, aovf_pair);
-                        load_cands();                   // (the candidate tables come back from L2 instead of living -- spilled in every wave's prologue -- across the region)
-                        DM_REGION_MARK(14);
-                        b.mark(11);                     // (profiling build: rows + Gram + sweep of such a substep count as "sub.PGS")
-                        rows_done = true;
+                    if constexpr (DM_DUO_XD && !C::OBJ) {      // (the borrowed-lane routine knows no free body: such a pair of biped + ball characters takes the 64-lane routine)
+                        if (aovf_pair && Ra_ + Rb_ <= 2 * HW && Ra_ <= DM_XD_ROWS && Rb_ <= DM_XD_ROWS) {
+                            b.mark(8);
+                            DM_REGION_MARK(13);             // (s_nop 13 / s_nop 14 bracket the borrowed-lane region in the disassembly: tests/test_build_resources.py holds every scratch access of the update loop to it)
+                            duo_rows_xd<Real, V2>(rec, wl, h, nc_, R_, Ra_, Rb_, D, m.NL, m.erp, m.friction, m.lim_max_impulse, m.solver_iters, aovf_pair);
+                            load_cands();                   // (the candidate tables come back from L2 instead of living -- spilled in every wave's prologue -- across the region)
+                            DM_REGION_MARK(14);
+                            b.mark(11);                     // (profiling build: rows + Gram + sweep of such a substep count as "sub.PGS")
+                            rows_done = true;
+                        }
                     }
                 }
                 if (rows_done) { substep_tail(h); b.mark(12); continue; }
@@ -1126,22 +1200,22 @@ _Pragma("unroll") \
 // grid = N / 2 workgroups of one wavefront; character e = 2 * pair + (lane >> 5), pair = dm_wg_unit() (blockIdx, XCD-aware).  fp32: 2 waves / SIMD (20 KB LDS).
 template <typename Real> struct DuoWaves { static constexpr int value = 1; };
 template <> struct DuoWaves<float> { static constexpr int value = 2; };
-template <typename Real, bool TAPS, bool AMP = false, bool V2 = false>
+template <typename Real, bool TAPS, bool AMP = false, bool V2 = false, typename CC = ClsBiped>
 __global__ void __launch_bounds__(64) DM_WAVES_PER_EU((DuoWaves<Real>::value)) k_env_step_duo(ModelDev<Real> m, EnvState<Real> st, StepIO<Real> io, DebugTaps<Real> dbg) {
     constexpr bool HIST = TAPS || AMP;
     static_assert(!V2 || AMP, "the v2 instantiation carries the AMP code like k_env_step's");
-    __shared__ Lds<Real, ClsBiped> lds[2];
-    __shared__ ParkSnap<Real, ClsBiped> snap[2];     // 2 x 0.45 KB: the fp32 kernel stays inside 20 KB per wave (8 waves per CU)
+    __shared__ Lds<Real, CC> lds[2];
+    __shared__ ParkSnap<Real, CC> snap[2];     // 2 x 0.45 KB: the fp32 kernel stays inside 20 KB per wave (8 waves per CU)
     const int wl = threadIdx.x, half = wl >> 5;
     const int pair = dm_wg_unit();                   // (XCD-aware: dm_device.h)
     const int e = 2 * pair + half;
-    DuoSim<Real, TAPS> sim(m, lds, wl);
+    DuoSim<Real, TAPS, CC> sim(m, lds, wl);
     if (TAPS && dbg.prof) sim.b.prof_begin(dbg.prof + (size_t)e * 16);
     sim.load(st, e);
     if (io.open_loop) sim.b.set_action_from_clip();
     else if (io.actions) sim.b.set_action(io.actions + (size_t)e * m.A);
     sim.b.mark(15);
-    Real* aovf_pair = st.aovf ? st.aovf + (size_t)(2 * pair) * (kMaxRows - ClsBiped::RREG) * kWave : nullptr;
+    Real* aovf_pair = st.aovf ? st.aovf + (size_t)(2 * pair) * (kMaxRows - CC::RREG) * kWave : nullptr;
     Real* manif_pair = (V2 && st.manif) ? st.manif + (size_t)(2 * pair) * m.J * MF_STRIDE : nullptr;      // physics 2: the two characters' ground manifolds
     const bool goal = HIST && st.goal && m.scene_goal;
     if (HIST && st.goal) sim.b.clip = (int)st.goal[(size_t)e * GS_WIDTH + GS_CLIP];
@@ -1192,7 +1266,7 @@ __global__ void __launch_bounds__(64) DM_WAVES_PER_EU((DuoWaves<Real>::value)) k
             uint64_t ep = (uint64_t)lds[half].flg[FLG_EPISODE];
             double mt = draw_time_limit<HIST>(m, e, ep, (HIST && st.goal) ? st.goal + (size_t)e * GS_WIDTH : nullptr);
             bool rec = false;
-            if (HIST && st.goal) { rec = sim.b.try_recovery_reset(st, e, mt); if (!rec) reset_goal_env<Real, ClsBiped, TAPS, 32>(sim.b, m, lds[half], st, e, ep, nullptr, mt, true, pert); }
+            if (HIST && st.goal) { rec = sim.b.try_recovery_reset(st, e, mt); if (!rec) reset_goal_env<Real, CC, TAPS, 32>(sim.b, m, lds[half], st, e, ep, nullptr, mt, true, pert); }
             else {
                 double kt = m.duration * dm_rand01(m.seed, (uint64_t)(e + m.env_off), ep, 0);
                 sim.b.reset_env(kt, mt);

@@ -301,7 +301,7 @@ struct CtxBase {
     rt_stream own_stream = 0, stream = 0;
     std::vector<void*> allocs;
     float *d_actions = nullptr, *d_states = nullptr, *d_rewards = nullptr; int *d_term = nullptr, *d_valid = nullptr, *d_end = nullptr;
-    bool duo = false, upload_failed = false; int physics = 1;
+    bool duo = false, duo_obj = true, upload_failed = false; int physics = 1;
     int* d_ids = nullptr; const int* step_ids = nullptr; int step_n_ids = 0;      // dm_step_envs: the subset the next step() call runs (device ids), cleared after it
     virtual ~CtxBase() { for (void* p : allocs) rt_free(p); }
     void* dalloc(size_t n) { void* p = nullptr; if (rt_malloc(&p, n) != 0) return nullptr; allocs.push_back(p); return p; }
@@ -572,6 +572,11 @@ struct CtxT : CtxBase {
             if (st.manif) launch_step_duo<Real, SV_V2>(N / 2, stream, md, st, io, dbg);               // DM-physics v2, two characters per wavefront (round 4)
             else if (st.hist || st.pert || md.enable_root_rot_fail || md.timer_exp > 0) launch_step_duo<Real, SV_AMP>(N / 2, stream, md, st, io, dbg);      // (the AMP instantiation also carries the perturbation code)
             else launch_step_duo<Real, SV_PLAIN>(N / 2, stream, md, st, io, dbg);
+            return 0;
+        }
+        // biped + free body (dribble_amp), two characters per wavefront (round 6; DM-physics v1 -- v2 and armed taps keep the one-per-wave kernel).  DM_DUO_OBJ=0: one per wave
+        if (duo && duo_obj && cls == 2 && hm.D == ClsBiped::ND && (N % 2) == 0 && !dbg.H && !step_ids && !md.draw_tape && !st.manif) {
+            launch_step_duo_c<Real, ClsBipedObj, SV_AMP>(N / 2, stream, md, st, io, dbg);
             return 0;
         }
         // production launch: the tap-free instantiation unless a parity test armed the debug taps (dm_probe)
@@ -864,7 +869,7 @@ int dm_create(const dm_create_info* info, const dm_scene_tables* tables, dm_ctx*
     if (info->num_envs < 1) return fail("num_envs must be >= 1");
     if (tables->scene_goal < 0 || tables->scene_goal > 5) return fail("scene_goal must be 0 (none), 1 (target_amp), 2 (heading_amp), 3 (heading_amp_getup), 4 (strike_amp) or 5 (dribble_amp)");
     if (tables->scene_goal == 5 && !(tables->ball_radius > 0 && tables->ball_mass > 0)) return fail("dribble_amp needs ball_radius > 0 and ball_mass > 0");
-    if (tables->scene_goal == 5 && info->wave_packing == 2) return fail("dribble_amp runs one character per wavefront (wave_packing 0 or 1)");
+    if (tables->scene_goal == 5 && info->wave_packing == 2 && info->physics == 2) return fail("dribble_amp under DM-physics v2 runs one character per wavefront (wave_packing 0 or 1)");
     if (tables->scene_goal == 3 && !(tables->getup_time > 0)) return fail("heading_amp_getup needs getup_time > 0 (the longest get-up clip)");
     if (tables->scene_goal == 3 && (tables->head_id < 0 || tables->head_id >= tables->num_joints)) return fail("head_id out of range");
     if (tables->scene_goal == 4 && tables->strike_mask == 0) return fail("strike_amp needs at least one strike body");
@@ -894,6 +899,7 @@ int dm_create(const dm_create_info* info, const dm_scene_tables* tables, dm_ctx*
     if (info->wave_packing != 0 && info->wave_packing != 1 && info->wave_packing != 2) { delete c; return fail("wave_packing must be 0, 1 or 2"); }
     // two characters per wavefront is the default for the biped class (step() falls back for odd batches and armed taps)
     { const char* dv = getenv("DM_DUO"); c->duo = info->wave_packing == 2 || (info->wave_packing == 0 && !(dv && dv[0] == '0')); }
+    { const char* dv = getenv("DM_DUO_OBJ"); c->duo_obj = !(dv && dv[0] == '0'); }
     // Shard / group invariance by construction: global envs 2b and 2b + 1 share a wavefront, whatever the partition.  A shard that starts at an odd
     // global id would pair (2b + 1, 2b + 2) -- the same physics summed in another order, i.e. trajectories that depend on the partition in the last
     // bits -- so an explicit wave_packing 2 refuses it and the default falls back to one character per wavefront for that ctx.

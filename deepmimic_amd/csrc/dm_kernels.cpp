@@ -12,6 +12,10 @@ void launch_step_duo(unsigned grid, rt_stream s, const ModelDev<Real>& m, const 
     RT_LAUNCH((k_env_step_duo<Real, V == SV_TAPS, V == SV_AMP || V == SV_V2, V == SV_V2>), grid, s, m, st, io, dbg);
 }
 template <typename Real, typename C, int V>
+void launch_step_duo_c(unsigned grid, rt_stream s, const ModelDev<Real>& m, const EnvState<Real>& st, const StepIO<Real>& io, const DebugTaps<Real>& dbg) {
+    RT_LAUNCH((k_env_step_duo<Real, V == SV_TAPS, V == SV_AMP || V == SV_V2, V == SV_V2, C>), grid, s, m, st, io, dbg);
+}
+template <typename Real, typename C, int V>
 void launch_step(unsigned grid, rt_stream s, const ModelDev<Real>& m, const EnvState<Real>& st, const StepIO<Real>& io, const DebugTaps<Real>& dbg) {
     RT_LAUNCH((k_env_step<Real, C, V == SV_TAPS, V == SV_AMP || V == SV_V2, V == SV_V2>), grid, s, m, st, io, dbg);
 }
@@ -35,6 +39,7 @@ void launch_amp_expert(unsigned grid, rt_stream s, const ModelDev<Real>& m, cons
 #define DM_STEP_ARGS(Real) unsigned, rt_stream, const ModelDev<Real>&, const EnvState<Real>&, const StepIO<Real>&, const DebugTaps<Real>&
 #define DM_INST_DUO(Real, V) template void launch_step_duo<Real, V>(DM_STEP_ARGS(Real));
 #define DM_INST_STEP(Real, C, V) template void launch_step<Real, C, V>(DM_STEP_ARGS(Real));
+#define DM_INST_DUOC(Real, C, V) template void launch_step_duo_c<Real, C, V>(DM_STEP_ARGS(Real));
 #define DM_INST_MISC(Real, C)                                                                                                                   \
     template void launch_reset<Real, C>(unsigned, rt_stream, const ModelDev<Real>&, const EnvState<Real>&, const int*, const double*, const double*); \
     template void launch_query<Real, C>(DM_STEP_ARGS(Real));                                                                                    \
@@ -68,10 +73,11 @@ void launch_amp_expert(unsigned grid, rt_stream s, const ModelDev<Real>& m, cons
 #define DM_FAMILY_21(Real) DM_INST_STEP(Real, ClsBipedTree, SV_V2)
 #define DM_FAMILY_22(Real) DM_INST_DUO(Real, SV_V2)
 #define DM_FAMILY_23(Real) DM_INST_STEP(Real, ClsBipedObj, SV_V2)
+#define DM_FAMILY_24(Real) DM_INST_DUOC(Real, ClsBipedObj, SV_AMP)
 
 #ifdef DM_TU_ALL
 #define DM_ALL(Real) DM_FAMILY_0(Real) DM_FAMILY_1(Real) DM_FAMILY_2(Real) DM_FAMILY_3(Real) DM_FAMILY_4(Real) DM_FAMILY_5(Real) \
-    DM_FAMILY_6(Real) DM_FAMILY_7(Real) DM_FAMILY_8(Real) DM_FAMILY_9(Real) DM_FAMILY_10(Real) DM_FAMILY_11(Real) DM_FAMILY_12(Real) DM_FAMILY_13(Real) DM_FAMILY_14(Real) DM_FAMILY_15(Real) DM_FAMILY_16(Real) DM_FAMILY_17(Real) DM_FAMILY_18(Real) DM_FAMILY_19(Real) DM_FAMILY_20(Real) DM_FAMILY_21(Real) DM_FAMILY_22(Real) DM_FAMILY_23(Real)
+    DM_FAMILY_6(Real) DM_FAMILY_7(Real) DM_FAMILY_8(Real) DM_FAMILY_9(Real) DM_FAMILY_10(Real) DM_FAMILY_11(Real) DM_FAMILY_12(Real) DM_FAMILY_13(Real) DM_FAMILY_14(Real) DM_FAMILY_15(Real) DM_FAMILY_16(Real) DM_FAMILY_17(Real) DM_FAMILY_18(Real) DM_FAMILY_19(Real) DM_FAMILY_20(Real) DM_FAMILY_21(Real) DM_FAMILY_22(Real) DM_FAMILY_23(Real) DM_FAMILY_24(Real)
 DM_ALL(float)
 DM_ALL(double)
 #else

@@ -27,6 +27,8 @@ enum { SV_PLAIN = 0, SV_AMP = 1, SV_TAPS = 2, SV_V2 = 3 };      // SV_V2: the AM
 template <typename Real, int V>
 void launch_step_duo(unsigned grid, rt_stream s, const ModelDev<Real>& m, const EnvState<Real>& st, const StepIO<Real>& io, const DebugTaps<Real>& dbg);
 template <typename Real, typename C, int V>
+void launch_step_duo_c(unsigned grid, rt_stream s, const ModelDev<Real>& m, const EnvState<Real>& st, const StepIO<Real>& io, const DebugTaps<Real>& dbg);      // two characters per wavefront of class C (round 6: ClsBipedObj)
+template <typename Real, typename C, int V>
 void launch_step(unsigned grid, rt_stream s, const ModelDev<Real>& m, const EnvState<Real>& st, const StepIO<Real>& io, const DebugTaps<Real>& dbg);
 template <typename Real, typename C>
 void launch_reset(unsigned grid, rt_stream s, const ModelDev<Real>& m, const EnvState<Real>& st, const int* env_ids, const double* kin_times, const double* max_times);

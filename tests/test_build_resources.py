@@ -101,7 +101,8 @@ def test_no_scratch_access_on_the_hot_path_of_the_headline_and_dog_kernels():
     (3, "ClsBiped one per wavefront, plain: 20 spilled VGPRs in the prologue / epilogue (DESIGN.md section 6)", 24),
     (6, "ClsLarge (dense dog3d, DM_TREE=0), plain: 4 (DESIGN.md section 6)", 8),
     (4, "ClsBiped AMP (odd batches of the task scenes; round 5: + the draw-tape lookups of the one-env drop-in, 11 -> 21, all in the rare draw / reset paths)", 24),
-    (9, "ClsBipedObj (dribble_amp)", 16),
+    (9, "ClsBipedObj (dribble_amp, one per wavefront)", 16),
+    (24, "ClsBipedObj two per wavefront (round 6, dribble_amp's default): measured 30", 40),
     (18, "ClsBiped, DM-physics v2 (round 5: 32 -> 35 with the draw-tape lookups and the per-clip cycle boundary of the kinematic character, both in rare paths)", 40),
 ])
 def test_secondary_kernels_stay_inside_their_measured_spill_budget(family, what, spill_max):

@@ -249,10 +249,10 @@ def test_facade_new_goal_scenes(emu_lib, monkeypatch):
 
 
 # ---- dribble_amp: a free rigid sphere next to the character
-def _ball_setup(lib, prec, n=2, seed=4):
+def _ball_setup(lib, prec, n=2, seed=4, pack=1):
     """device env + mirrored oracles after a reset at given clip times; the ball is then placed next to the character and kicked at it"""
     t = model.load_asset("amp_dribble_zombie")
-    env = BatchEnv(t, n, precision=prec, lib_path=lib, wave_packing=1, seed=seed)
+    env = BatchEnv(t, n, precision=prec, lib_path=lib, wave_packing=pack, seed=seed)
     g0 = env.get_goal_state()
     kts = [0.2 + 0.3 * e for e in range(n)]
     env.reset(kin_times=kts)
@@ -262,8 +262,8 @@ def _ball_setup(lib, prec, n=2, seed=4):
     return t, env, oracles
 
 
-def _kick_rollout(lib, prec, steps):
-    t, env, oracles = _ball_setup(lib, prec)
+def _kick_rollout(lib, prec, steps, pack=1):
+    t, env, oracles = _ball_setup(lib, prec, pack=pack)
     st = env.get_state(); ob = env.get_obj_state()
     assert max(np.abs(ob[e] - o.ball_state()[:13]).max() for e, o in enumerate(oracles)) < 1e-6       # the ball reset draws agree
     for e, o in enumerate(oracles):
@@ -309,10 +309,11 @@ def test_ball_physics_closed_form(oracle_built):
     assert abs(np.linalg.norm(ts[9:12]) - np.linalg.norm(bs[7:10])) < 1e-9
 
 
+@pytest.mark.parametrize("pack", [1, 2])
 @pytest.mark.parametrize("test_mode", [False, True])
-def test_dribble_scene_matches_oracle_emulator(emu_lib, test_mode):
+def test_dribble_scene_matches_oracle_emulator(emu_lib, test_mode, pack):
     t = model.load_asset("amp_dribble_zombie")
-    w = pc.goal_rollout_compare(t, 64, emu_lib, steps=24, n=2, seed=5, wave_packing=1, test_mode=test_mode)
+    w = pc.goal_rollout_compare(t, 64, emu_lib, steps=24, n=2 * pack, seed=5, wave_packing=pack, test_mode=test_mode)
     print(w)
     assert w["flags_ok"] and w["ball"] < 1e-9 and w["reward"] < 1e-6 and w["goal"] < 1e-5 and w["goal_state"] < 1e-6 and w["state"] < 1e-5
     assert w["resets"] >= 1 or test_mode
@@ -332,9 +333,11 @@ def test_dribble_scene_physics_2_matches_oracle_emulator(emu_lib):
     assert v2.physics == 2 and v2.get_manifolds()[:, :, 0].sum() > 0 and not np.array_equal(a["state"], b["state"])      # it IS the other rigid-body step
 
 
-def test_ball_kick_matches_oracle_emulator(emu_lib):
-    """the ball thrown at the character's legs: contacts between the free body and the links, the shared constraint solve"""
-    mx = _kick_rollout(emu_lib, 64, 8)
+@pytest.mark.parametrize("pack", [1, 2])
+def test_ball_kick_matches_oracle_emulator(emu_lib, pack):
+    """the ball thrown at the character's legs: contacts between the free body and the links, the shared constraint solve; one character per wavefront and (round 6)
+    two -- the ball's contacts in the half's own slots, its velocity change by half-wave sums"""
+    mx = _kick_rollout(emu_lib, 64, 8, pack=pack)
     print(mx)
     assert mx["speed"] > 5.0 and mx["ball"] < 1e-8 and mx["reward"] < 1e-6 and mx["state"] < 1e-5
 
@@ -357,8 +360,8 @@ def test_dribble_facade_and_refusals(emu_lib, monkeypatch):
         core.Update(1.0 / 600)
     assert np.isfinite(core.CalcReward(0)) and len(core.RecordGoal(0)) == 3
     core.Shutdown()
-    with pytest.raises(RuntimeError, match="one character per wavefront"):
-        BatchEnv(model.load_asset("amp_dribble_zombie"), 2, lib_path=emu_lib, wave_packing=2)
+    with pytest.raises(RuntimeError, match="one character per wavefront"):      # (round 6: two per wave under DM-physics v1; v2 keeps the one-per-wave kernel)
+        BatchEnv(model.load_asset("amp_dribble_zombie"), 2, lib_path=emu_lib, wave_packing=2, physics=2)
 
 
 @pytest.mark.parametrize("asset", ["amp_dribble_zombie", "amp_heading_getup", "humanoid3d_walk"])
@@ -485,17 +488,19 @@ def test_new_goal_scenes_4096(hip_lib):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("pack", [1, 2])
 @pytest.mark.parametrize("prec", [64, 32])
-def test_dribble_scene_gpu(hip_lib, prec):
-    """dribble_amp on the HIP kernels: the scene through resets, and the ball kicked at the character"""
+def test_dribble_scene_gpu(hip_lib, prec, pack):
+    """dribble_amp on the HIP kernels: the scene through resets, and the ball kicked at the character; one character per wavefront (k_env_step<ClsBipedObj>) and two
+    (round 6: k_env_step_duo<..., ClsBipedObj>, the default)"""
     t = model.load_asset("amp_dribble_zombie")
-    w = pc.goal_rollout_compare(t, prec, hip_lib, steps=60, n=8, seed=5, wave_packing=1)
-    print(prec, w)
+    w = pc.goal_rollout_compare(t, prec, hip_lib, steps=60, n=8, seed=5, wave_packing=pack)
+    print(prec, pack, w)
     assert (w["flags_ok"] or (prec == 32 and w["scored"] >= 360)) and w["resets"] >= 2
     # (the ball is re-placed around the root of the previous episode's last state: its error follows the free-running root's)
     assert w["reward_mean"] < (1e-5 if prec == 64 else 2e-3) and w["ball"] < (1e-3 if prec == 64 else 2e-2)
-    mx = _kick_rollout(hip_lib, prec, 8)
-    print(prec, mx)
+    mx = _kick_rollout(hip_lib, prec, 8, pack=pack)
+    print(prec, pack, mx)
     assert mx["speed"] > 5.0 and mx["ball"] < (1e-6 if prec == 64 else 5e-2) and mx["reward"] < (1e-5 if prec == 64 else 5e-3)
 
 

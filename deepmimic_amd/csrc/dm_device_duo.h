@@ -415,6 +415,19 @@ struct DuoSim {
     int pair_code[PP];
     DM_DEV DuoSim(const ModelDev<Real>& m_, L* rec_, int wl_) : m(m_), rec(rec_), wl(wl_), half(wl_ >> 5), hl(wl_ & 31), b(m_, rec_[wl_ >> 5], wl_ & 31), s(rec_[wl_ >> 5]) {}
     DM_DEV void sync() const { __syncthreads(); }
+    // the priority of the phases between the dependent chains.  DM_PRIO_LATE > 0: a wave that has left the 32-row path in this launch (borrowed lanes or the 64-lane routine) is one
+    // the launch will wait for -- a one-round launch lasts as long as its slowest wave -- and keeps the raised level in the throughput phases too
+#ifndef DM_PRIO_LATE
+#define DM_PRIO_LATE 2      // same-box A/B, closed-loop spinkick: 1: -0.9 %, 2: -1.6 %, 3: -1.4 % step time; open loop +-0; the chain phases at 3 too: no further gain and +1.1 % open loop (profiles/r06_ab_lane_borrowing.json)
+#endif
+    int late = 0;
+    DM_DEV void prio_low() const {
+#if DM_PRIO_LATE
+        if (late) dm_setprio<DM_PRIO_LATE>(); else dm_setprio<0>();
+#else
+        dm_setprio<0>();
+#endif
+    }
     DM_DEV Real& Lx(int r, int c) const { return s.Lt[L::lrow(r) + c]; }
     static DM_DEV v3 zero3() { return mk3((Real)0, (Real)0, (Real)0); }
 
@@ -795,7 +808,7 @@ _Pragma("unroll") \
         b.integrate(h);
         sync();
 #if DM_PRIO_BACK
-        dm_setprio<0>();
+        prio_low();
 #endif
     }
 
@@ -982,7 +995,7 @@ _Pragma("unroll") \
         }
 #undef DM_DUO_YLOAD
 #if DM_PRIO_Y
-        dm_setprio<0>();
+        prio_low();
 #endif
         if constexpr (C::OBJ) {
             // the free body's block of the mass matrix is diagonal: its rows of Y = M^-1/2 J^T are a scaling; J v* gains its share
@@ -1114,7 +1127,7 @@ _Pragma("unroll") \
 #endif
                 b.kinematics(s.pose, s.vel, ph == 0 ? b.spd_a0() : b.gravity_a0());      // (ph 0: EnvSim::kin_pre ran it)
 #if DM_PRIO_KIN
-                dm_setprio<0>();
+                prio_low();
 #endif
             }
             b.mark(ph == 0 ? 1 : 5);
@@ -1131,7 +1144,7 @@ _Pragma("unroll") \
 #endif
             chol_solve(s.rhs);
 #if DM_PRIO_CHOL
-            dm_setprio<0>();
+            prio_low();
 #endif
             DM_OPAQUE_V(hl); DM_OPAQUE_V(b.l); DM_OPAQUE_V(b.li);
             if (ph == 0) {
@@ -1142,6 +1155,9 @@ _Pragma("unroll") \
             } else {
                 bool rows_done = substep_post<V2>(h, V2 ? manif_pair + (size_t)half * m.J * MF_STRIDE : nullptr);
                 if (!rows_done) {
+#if DM_PRIO_LATE
+                    late = 1;
+#endif
                     // more than 32 rows somewhere in the pair (the contact slots are stored, FLG_NROWS says how many).  One such character, at most DM_XD_ROWS rows, and at most 64
                     // rows together: the pair stays in this instruction stream on borrowed lanes (round 6)
                     const int R_ = s.flg[FLG_NROWS], nc_ = (R_ - m.NL) / 3;

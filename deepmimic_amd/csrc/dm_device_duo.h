@@ -1156,7 +1156,7 @@ _Pragma("unroll") \
                 bool rows_done = substep_post<V2>(h, V2 ? manif_pair + (size_t)half * m.J * MF_STRIDE : nullptr);
                 if (!rows_done) {
 #if DM_PRIO_LATE
-                    late = 1;
+                    if (!PERT) late = 1;          // (plain instantiation only: in the AMP / v2 kernels the flag's scalar register cost 1 % of the open-loop rate of every AMP scene)
 #endif
                     // more than 32 rows somewhere in the pair (the contact slots are stored, FLG_NROWS says how many).  One such character, at most DM_XD_ROWS rows, and at most 64
                     // rows together: the pair stays in this instruction stream on borrowed lanes (round 6)

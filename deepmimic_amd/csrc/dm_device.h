@@ -316,6 +316,25 @@ template <int NP2> __device__ __forceinline__ void wave_gram32(const VecT<double
 #define DM_PRIO 1      // s_setprio by phase and load (dm_device_duo.h has the rationale and the measurements); 0: the round-3 kernels
 #endif
 // one character per wavefront: the same rule -- dependent-chain phases above the throughput phases of the SIMD's other wave
+// DM_YPREF: the tree classes' y = L^-T J^T loop requests dof k - 1's records before dof k's arithmetic (EnvSim::substep_post)
+#ifndef DM_YPREF
+#define DM_YPREF 1
+#endif
+// DM_ELPREF: tree_elim requests pivot q + 1's published entries before pivot q's rank-1 update
+#ifndef DM_ELPREF
+#define DM_ELPREF 1
+#endif
+// DM_TFPREF: tree_fwd requests all its row reads before the first lane select
+#ifndef DM_TFPREF
+#define DM_TFPREF 1
+#endif
+#ifndef DM_YPREF_DENSE_FENCE
+#define DM_YPREF_DENSE_FENCE 1
+#endif
+// DM_LCPREF: tree_load_col reads the momentum records in groups of this many, one group ahead (0: the fenced groups of 8 of rounds 3-5)
+#ifndef DM_LCPREF
+#define DM_LCPREF 4
+#endif
 #ifndef DM_PRIO_ONE_CHOL
 #define DM_PRIO_ONE_CHOL (DM_PRIO ? 1 : 0)
 #define DM_PRIO_ONE_Y (DM_PRIO ? 1 : 0)
@@ -786,6 +805,31 @@ struct EnvSim {
         uint64_t z = 0; DM_OPAQUE_S(z);
         const R4 q0 = *reinterpret_cast<const R4*>(&s.dofrec[lr][0]);
         const R2 q1 = *reinterpret_cast<const R2*>(&s.dofrec[lr][4]);
+#if DM_LCPREF
+        // (round 6) groups of DM_LCPREF records, the next group's reads requested before the current group's dot products: one exposed LDS round
+        // trip for the whole column instead of one per fenced group
+        constexpr int G = DM_LCPREF, NG = (ND + G - 1) / G;        // (the last group may be short: ND = 34)
+        R4 ra[2][G]; R2 rb[2][G];
+        auto grp_load = [&](auto gc) {
+            constexpr int g = decltype(gc)::value;
+            static_for<0, G>([&](auto jc) { constexpr int j = decltype(jc)::value, i = g * G + j;
+                if constexpr (i < ND) { ra[g & 1][j] = *reinterpret_cast<const R4*>(&s.Lt[i * 8]); rb[g & 1][j] = *reinterpret_cast<const R2*>(&s.Lt[i * 8 + 4]); } });
+        };
+        grp_load(std::integral_constant<int, 0>{});
+        static_for<0, NG>([&](auto gc) {
+            constexpr int g = decltype(gc)::value;
+            if constexpr (g + 1 < NG) { grp_load(std::integral_constant<int, (g + 1 < NG ? g + 1 : 0)>{}); DM_SCHED_FENCE(); }
+            static_for<0, G>([&](auto jc) { constexpr int j = decltype(jc)::value, i = g * G + j;
+                if constexpr (i < ND) {
+                    const R4 r0 = ra[g & 1][j]; const R2 r1 = rb[g & 1][j];
+                    Real v = q0[0] * r0[0] + q0[1] * r0[1] + q0[2] * r0[2] + q0[3] * r0[3] + q1[0] * r1[0] + q1[1] * r1[1];
+                    DM_OPAQUE_V(v);
+                    c2[i >> 1][i & 1] = lane_sel<TP::T.anc[i < ND ? i : 0]>(v, (Real)0, l, z);
+                }
+            });
+            DM_SCHED_FENCE();
+        });
+#else
         static_for<0, ND>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
             const R4 r0 = *reinterpret_cast<const R4*>(&s.Lt[i * 8]);
@@ -795,6 +839,7 @@ struct EnvSim {
             c2[i >> 1][i & 1] = lane_sel<TP::T.anc[i]>(v, (Real)0, l, z);       // dof i is a descendant of exactly the lanes anc(i)
             if ((i & 7) == 7) DM_SCHED_FENCE();        // keeps the 64 record reads from being issued (and kept live) all at once
         });
+#endif
         const Real* mo = &s.Lt[lr * 8];
         hd = (l < ND) ? q0[0] * mo[0] + q0[1] * mo[1] + q0[2] * mo[2] + q0[3] * mo[3] + q1[0] * mo[4] + q1[1] * mo[5] + mo[6] : (Real)1;
     }
@@ -944,6 +989,44 @@ struct EnvSim {
                 if (TP::T.anc[k] != 0 && (ND >= kWave || l < ND)) cbuf[q * CS + l] = x;       // (no lane test when every lane is a dof: a divergent store here makes the optimizer sink the level's arithmetic behind it)
             }
             sync();
+#if DM_ELPREF
+            // (round 6) the published entries of pivot q + 1 are requested before the rank-1 update of pivot q runs (two register sets by the parity of q): left to
+            // itself the scheduler keeps two or three reads in flight, a third of what the LDS latency needs.  Same updates in the same order per entry.
+            constexpr int NQ = (NP2 + 1) / 2;
+            R2 ea[2][NQ], eb[2][NQ]; Real ek[2] = {(Real)0, (Real)0};
+            auto eload = [&](auto qc) {
+                constexpr int q = decltype(qc)::value, k = TP::T.order[S0 + q], sl = q & 1;
+                if constexpr (TP::T.anc[k] != 0) {
+                    static_for<0, NQ>([&](auto tc) {
+                        constexpr int t = decltype(tc)::value;
+                        constexpr bool own0 = (2 * t == (k >> 1)), own1 = (2 * t + 1 == (k >> 1));
+                        constexpr bool on0 = !own0 && ((TP::T.anc[k] >> (4 * t)) & 3ull), on1 = (2 * t + 1 < NP2) && !own1 && ((TP::T.anc[k] >> (4 * t + 2)) & 3ull);
+                        if constexpr (on0 && on1) { const R4 r = *reinterpret_cast<const R4*>(&cbuf[q * CS + 4 * t]); ea[sl][t] = R2{r[0], r[1]}; eb[sl][t] = R2{r[2], r[3]}; }
+                        else if constexpr (on0) ea[sl][t] = *reinterpret_cast<const R2*>(&cbuf[q * CS + 4 * t]);
+                        else if constexpr (on1) eb[sl][t] = *reinterpret_cast<const R2*>(&cbuf[q * CS + 4 * t + 2]);
+                        if constexpr ((own0 || own1) && (k & 1) && ((TP::T.anc[k] >> (k - 1)) & 1ull)) ek[sl] = cbuf[q * CS + k - 1];
+                    });
+                }
+            };
+            eload(std::integral_constant<int, 0>{});
+            static_for<0, W>([&](auto qc) {
+                constexpr int q = decltype(qc)::value, k = TP::T.order[S0 + q], sl = q & 1;
+                if constexpr (q + 1 < W) { eload(std::integral_constant<int, (q + 1 < W ? q + 1 : 0)>{}); DM_SCHED_FENCE(); }
+                if constexpr (TP::T.anc[k] != 0) {
+                    hd -= lk[q] * lk[q];
+                    const R2 l2 = {lk[q], lk[q]};
+                    static_for<0, NQ>([&](auto tc) {
+                        constexpr int t = decltype(tc)::value;
+                        constexpr bool own0 = (2 * t == (k >> 1)), own1 = (2 * t + 1 == (k >> 1));
+                        constexpr bool on0 = !own0 && ((TP::T.anc[k] >> (4 * t)) & 3ull), on1 = (2 * t + 1 < NP2) && !own1 && ((TP::T.anc[k] >> (4 * t + 2)) & 3ull);
+                        if constexpr (on0) c2[2 * t] -= l2 * ea[sl][t];
+                        if constexpr (on1) c2[(2 * t + 1 < NP2) ? 2 * t + 1 : 0] -= l2 * eb[sl][t];
+                        if constexpr ((own0 || own1) && (k & 1) && ((TP::T.anc[k] >> (k - 1)) & 1ull)) c2[k >> 1][0] -= lk[q] * ek[sl];
+                    });
+                }
+                if constexpr (q + 1 < W) DM_SCHED_FENCE();
+            });
+#else
 #pragma unroll
             for (int q = 0; q < W; ++q) {
                 const int k = TP::T.order[S0 + q];
@@ -965,6 +1048,7 @@ struct EnvSim {
                     if ((own0 || own1) && (k & 1) && ((TP::T.anc[k] >> (k - 1)) & 1ull)) c2[k >> 1][0] -= lk[q] * cbuf[q * CS + k - 1];
                 }
             }
+#endif
             tree_elim<V + 1>(c2, hd, dinv, z);
         }
     }
@@ -988,10 +1072,23 @@ struct EnvSim {
         uint64_t z = 0; DM_OPAQUE_S(z);
         const int lr = l < ND ? l : 0;
         Real r[ND];
+#if DM_TFPREF
+        // (round 6) all row reads are requested first, the lane selects follow behind one wait: interleaved, each select (an opaque asm) waited for its own read
+        static_for<0, ND>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            if constexpr (TP::T.desc[j] != 0) r[j] = s.Lt[L::lcb(j) + lr]; else r[j] = 0;
+        });
+        DM_SCHED_FENCE();
+        static_for<0, ND>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            if constexpr (TP::T.desc[j] != 0) r[j] = lane_sel<TP::T.desc[j]>(r[j], (Real)0, l, z);
+        });
+#else
         static_for<0, ND>([&](auto jc) {
             constexpr int j = decltype(jc)::value;
             if constexpr (TP::T.desc[j] != 0) r[j] = lane_sel<TP::T.desc[j]>(s.Lt[L::lcb(j) + lr], (Real)0, l, z); else r[j] = 0;
         });
+#endif
         tree_fwd_lev<TP::T.nlev - 1>(r, x, dinv);
         return x * dinv;
     }
@@ -1272,6 +1369,18 @@ struct EnvSim {
     // s.rhs holds qddot of the unconstrained dynamics; s.L the Cholesky factor of H.
     // PLAIN: the tap-free imitate instantiation without perturbations / manifolds; a class may give it a wider row file (C::RREG_PLAIN:
     // the registers the AMP / v2 code needs elsewhere are free there)
+    // TREE classes: the number of 16-B quads of column k of the factor that hold a descendant of dof k (what the row lanes' substitution reads of it)
+    static constexpr int y_nquads(int k) {
+        if constexpr (C::TREE) {
+            typedef typename C::Topo TP;
+            int n = 0;
+            for (int t = (k >> 2); t < (NP2 + 1) / 2; ++t) {
+                const bool a = (2 * t > (k >> 1)) && ((TP::T.desc[k] >> (4 * t)) & 3ull), b = (2 * t + 1 < NP2) && (2 * t + 1 > (k >> 1)) && ((TP::T.desc[k] >> (4 * t + 2)) & 3ull);
+                n += (a || b) ? 1 : 0;
+            }
+            return n;
+        } else return 0;
+    }
     template <bool V2 = false, bool PLAIN = false>
     // nc_ground_in >= 0 (V2, the fallback of the two-per-wave kernel): the caller has already updated the manifolds of this substep and stored the ground
     // contact slots in s.ct -- a second refresh would not be idempotent
@@ -1471,6 +1580,61 @@ struct EnvSim {
             // H = L^T L: y = L^-T J^T runs from the last dof down, against COLUMN k of L (wave-uniform broadcasts); only the pairs that
             // hold a descendant of k are touched (744 multiply-adds per row for dog3d instead of 2 016)
             typedef typename C::Topo TP;
+#if DM_YPREF
+            // Software-pipelined over the dofs (round 6): the records of dof k - 1 (its axis record, the quads of column k - 1 of L that hold a
+            // descendant, the diagonal) are REQUESTED before the arithmetic of dof k, which needs none of them -- the two LDS round trips a dof
+            // used to wait for in turn (record -> Jacobian entry, then column -> substitution) now pass behind the previous dof's chain.  Two
+            // register sets, chosen by the parity of k (static indices); the root's six columns (15 quads each) are read where they are used.
+            // Same operations in the same order per row: bit-identical to the loop below.
+            constexpr int NQ = (NP2 + 1) / 2, QPRE = 8;
+            R4 pr0[2], pr1[2]; R2 pqa[2][NQ], pqb[2][NQ]; Real pdg[2], pk1[2] = {(Real)0, (Real)0};
+            // (y_nquads(k): quads of column k that hold a descendant of k)
+            auto yquads = [&](auto kc) {
+                constexpr int k = decltype(kc)::value, sl = k & 1;
+                const Real* lc = &s.Lt[L::lcb(k)];
+                static_for<(k >> 2), NQ>([&](auto tc) {
+                    constexpr int t = decltype(tc)::value;
+                    constexpr bool on0 = (2 * t > (k >> 1)) && ((TP::T.desc[k] >> (4 * t)) & 3ull), on1 = (2 * t + 1 < NP2) && (2 * t + 1 > (k >> 1)) && ((TP::T.desc[k] >> (4 * t + 2)) & 3ull);
+                    if constexpr (on0 && on1) { const R4 r = *reinterpret_cast<const R4*>(&lc[4 * t]); pqa[sl][t] = R2{r[0], r[1]}; pqb[sl][t] = R2{r[2], r[3]}; }
+                    else if constexpr (on0) pqa[sl][t] = *reinterpret_cast<const R2*>(&lc[4 * t]);
+                    else if constexpr (on1) pqb[sl][t] = *reinterpret_cast<const R2*>(&lc[4 * t + 2]);
+                });
+            };
+            auto yload = [&](auto kc) {
+                constexpr int k = decltype(kc)::value, sl = k & 1;
+                pr0[sl] = *reinterpret_cast<const R4*>(&s.dofrec[k][0]); pr1[sl] = *reinterpret_cast<const R4*>(&s.dofrec[k][4]);
+                const Real* lc = &s.Lt[L::lcb(k)];
+                if constexpr (y_nquads(k) <= QPRE) yquads(kc);
+                if constexpr (!(k & 1) && ((TP::T.desc[k] >> (k + 1)) & 1ull)) pk1[sl] = lc[k + 1];
+                pdg[sl] = lc[k];
+            };
+            yload(std::integral_constant<int, ND - 1>{});
+            static_for<0, ND>([&](auto kkc) {
+                constexpr int k = ND - 1 - decltype(kkc)::value, sl = k & 1;
+                if constexpr (k > 0) { yload(std::integral_constant<int, (k > 0 ? k - 1 : 0)>{}); if (DM_YPREF >= 2) DM_SCHED_FENCE(); }      // (requests first: the waits below then count the older ones only)
+                const R4 r0 = pr0[sl], r1 = pr1[sl];
+                Real val = r0[0] * xd.x + r0[1] * xd.y + r0[2] * xd.z + r0[3] * dd.x + r1[0] * dd.y + r1[1] * dd.z;
+                DM_OPAQUE_V(val);
+                const bool on = (((k < 32) ? ch_lo : ch_hi) >> (k & 31)) & 1u, ng = (((k < 32) ? ng_lo : ng_hi) >> (k & 31)) & 1u;
+                const Real raw = on ? (ng ? -val : val) : (Real)0;
+                cvec += raw * r1[2];
+                if constexpr (y_nquads(k) > QPRE) yquads(std::integral_constant<int, k>{});
+                R2 acc2 = {(Real)0, (Real)0}, acc3 = acc2;
+                static_for<(k >> 2), NQ>([&](auto tc) {
+                    constexpr int t = decltype(tc)::value;
+                    constexpr bool on0 = (2 * t > (k >> 1)) && ((TP::T.desc[k] >> (4 * t)) & 3ull), on1 = (2 * t + 1 < NP2) && (2 * t + 1 > (k >> 1)) && ((TP::T.desc[k] >> (4 * t + 2)) & 3ull);
+                    if constexpr (on0) acc2 += pqa[sl][t] * y2[2 * t];
+                    if constexpr (on1) acc3 += pqb[sl][t] * y2[(2 * t + 1 < NP2) ? 2 * t + 1 : 0];
+                });
+                acc2 += acc3;
+                Real acc = raw - (acc2[0] + acc2[1]);
+                if constexpr (!(k & 1) && ((TP::T.desc[k] >> (k + 1)) & 1ull)) acc -= pk1[sl] * y2[k >> 1][1];
+                Real yk = acc * pdg[sl];
+                DM_OPAQUE_V(yk);
+                y2[k >> 1][k & 1] = yk;
+                DM_SCHED_FENCE();
+            });
+#else
 #pragma unroll
             for (int kk = 0; kk < ND; ++kk) {
                 const int k = ND - 1 - kk;
@@ -1500,6 +1664,39 @@ struct EnvSim {
                 y2[k >> 1][k & 1] = yk;
                 DM_SCHED_FENCE();      // the branches of the tree are independent chains: without a fence the scheduler hoists their loads and spills
             }
+#endif
+        } else if constexpr (DM_YPREF != 0 && ND <= 34) {
+        // (round 6) the dense loop software-pipelined like the two-per-wave kernel's: row k + 1 of the factor and its dof record are requested before the
+        // accumulation chain of step k -- this is the loop of the 64-lane fallback of a two-per-wave pair, i.e. of the waves a closed-loop launch waits for
+        R2 lrp[2][NP2]; R4 rrp[2][2];
+        auto ydload = [&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            rrp[k & 1][0] = *reinterpret_cast<const R4*>(&s.dofrec[k][0]); rrp[k & 1][1] = *reinterpret_cast<const R4*>(&s.dofrec[k][4]);
+            const R2* lrow_ = reinterpret_cast<const R2*>(&s.Lt[L::lrow(k)]);
+            static_for<0, (k >> 1) + 1>([&](auto pc) { constexpr int p = decltype(pc)::value; lrp[k & 1][p] = lrow_[p]; });
+        };
+        static_assert(L::LPAD % 2 == 0, "row pairs are read as 8-byte words");
+        ydload(std::integral_constant<int, 0>{});
+        static_for<0, ND>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            Real yk = 0;
+            if constexpr (k + 1 < ND) { if (k + 1 < D) ydload(std::integral_constant<int, (k + 1 < ND ? k + 1 : 0)>{}); }
+            if (k < D) {
+                const R4 r0 = rrp[k & 1][0], r1 = rrp[k & 1][1];
+                const Real val = r0[0] * xd.x + r0[1] * xd.y + r0[2] * xd.z + r0[3] * dd.x + r1[0] * dd.y + r1[1] * dd.z;
+                const bool on = (((k < 32) ? ch_lo : ch_hi) >> (k & 31)) & 1u, ng = (((k < 32) ? ng_lo : ng_hi) >> (k & 31)) & 1u;
+                const Real raw = on ? (ng ? -val : val) : (Real)0;
+                cvec += raw * r1[2];
+                R2 acc2 = {(Real)0, (Real)0}, acc3 = acc2;      // two independent accumulation chains
+                static_for<0, (k >> 1)>([&](auto pc) { constexpr int p = decltype(pc)::value; if constexpr (p & 1) acc3 += lrp[k & 1][p] * y2[p]; else acc2 += lrp[k & 1][p] * y2[p]; });
+                acc2 += acc3;
+                Real acc = raw - (acc2[0] + acc2[1]);
+                if constexpr (k & 1) acc -= lrp[k & 1][k >> 1][0] * y2[k >> 1][0];
+                yk = acc * lrp[k & 1][k >> 1][k & 1];
+            }
+            y2[k >> 1][k & 1] = yk;
+            if (DM_YPREF_DENSE_FENCE) DM_SCHED_FENCE();
+        });
         } else {
 #pragma unroll
         for (int k = 0; k < ND; ++k) {

@@ -264,6 +264,41 @@ DM_DEV void duo_rows_xd(Lds<Real, ClsBiped>* rec, int wl, Real h, int nc, int R,
 #if DM_PRIO_Y
     dm_setprio<DM_PRIO_Y>();
 #endif
+#if DM_YPREF
+    // software-pipelined like DuoSim::substep_post's loop (round 6, second pass): the factor row and the dof record of step k + 1 are requested before the
+    // accumulation chain of step k (per-lane addresses here: a lane reads the record of the character whose row it holds); one dof per scheduling region
+    R2 lr[2][NP2]; R4 rr[2][2];
+#define DM_XD_YLOAD(k)                                                                                        \
+    {                                                                                                         \
+        rr[(k) & 1][0] = *reinterpret_cast<const R4*>(&sc.dofrec[(k)][0]);                                     \
+        rr[(k) & 1][1] = *reinterpret_cast<const R4*>(&sc.dofrec[(k)][4]);                                     \
+        const R2* lrow_ = reinterpret_cast<const R2*>(&sc.Lt[L::lrow(k)]);                                     \
+        _Pragma("unroll") for (int p = 0; p <= ((k) >> 1); ++p) lr[(k) & 1][p] = lrow_[p];                    \
+    }
+    DM_XD_YLOAD(0)
+#pragma unroll
+    for (int k = 0; k < ND; ++k) {
+        Real yk = 0;
+        if (k + 1 < ND) { if (k + 1 < D) DM_XD_YLOAD(k + 1) }
+        if (k < D) {
+            const R4 r0 = rr[k & 1][0], r1 = rr[k & 1][1];
+            const Real val = r0[0] * xd.x + r0[1] * xd.y + r0[2] * xd.z + r0[3] * dd.x + r1[0] * dd.y + r1[1] * dd.z;
+            const bool on = (((k < 32) ? ch_lo : ch_hi) >> (k & 31)) & 1u, ng = (((k < 32) ? ng_lo : ng_hi) >> (k & 31)) & 1u;
+            const Real raw = on ? (ng ? -val : val) : (Real)0;
+            cvec += raw * r1[2];
+            R2 acc2 = {(Real)0, (Real)0}, acc3 = acc2;
+#pragma unroll
+            for (int p = 0; p < (k >> 1); ++p) { if (p & 1) acc3 += lr[k & 1][p] * y2[p]; else acc2 += lr[k & 1][p] * y2[p]; }
+            acc2 += acc3;
+            Real acc = raw - (acc2[0] + acc2[1]);
+            if (k & 1) acc -= lr[k & 1][k >> 1][0] * y2[k >> 1][0];
+            yk = acc * lr[k & 1][k >> 1][k & 1];
+        }
+        y2[k >> 1][k & 1] = yk;
+        DM_SCHED_FENCE();
+    }
+#undef DM_XD_YLOAD
+#else
 #pragma unroll
     for (int k = 0; k < ND; ++k) {
         Real yk = 0;
@@ -285,6 +320,7 @@ DM_DEV void duo_rows_xd(Lds<Real, ClsBiped>* rec, int wl, Real h, int nc, int R,
         y2[k >> 1][k & 1] = yk;
         DM_SCHED_FENCE();      // (one dof at a time: unfenced, the scheduler hoists the factor rows of many dofs -- up to 34 registers each -- and spills kernel-long values)
     }
+#endif
 #if DM_PRIO_Y
     dm_setprio<0>();
 #endif

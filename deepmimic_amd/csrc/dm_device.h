@@ -320,6 +320,10 @@ template <int NP2> __device__ __forceinline__ void wave_gram32(const VecT<double
 #ifndef DM_YPREF
 #define DM_YPREF 1
 #endif
+// DM_DRPREF: dyn_row (the dense classes' mass-matrix rows) requests pair p + 1's dof records before pair p's dot products; 2: one pair per scheduling region
+#ifndef DM_DRPREF
+#define DM_DRPREF 2
+#endif
 // DM_ELPREF: tree_elim requests pivot q + 1's published entries before pivot q's rank-1 update
 #ifndef DM_ELPREF
 #define DM_ELPREF 1
@@ -759,6 +763,38 @@ struct EnvSim {
         // and whose trip count is the longest chain of the wave.
         const uint32_t lo = s.mdl.chain_lo[dj] & ((k < 31) ? ((2u << k) - 1u) : ~0u), hi = (k < 32) ? 0u : (s.mdl.chain_hi[dj] & ((k < 63) ? ((2u << (k - 32)) - 1u) : ~0u));
         const Real dk = diag_scale * s.mdl.kd[dj];
+        if constexpr (DM_DRPREF != 0 && LW == 32) {      // (two characters per wavefront: 256 registers; the one-per-wave biped kernels run at 128)
+        // (round 6) the records of pair p + 1 are requested before the dot products of pair p, and the pair is computed by every lane (only the store is
+        // predicated): with the arithmetic sunk under the lanes' `2 p <= k` test -- what the optimizer made of the loop below -- every pair waited for
+        // its own three reads behind a branch.  Same values.
+        R4 da[2][2]; R2 db[2][2];
+        auto drload = [&](auto pc) {
+            constexpr int p = decltype(pc)::value;
+            static_for<0, 2>([&](auto cc) { constexpr int c = decltype(cc)::value, j = 2 * p + c;
+                if constexpr (j < ND) { da[p & 1][c] = *reinterpret_cast<const R4*>(&s.dofrec[j][0]); db[p & 1][c] = *reinterpret_cast<const R2*>(&s.dofrec[j][4]); } });
+        };
+        drload(std::integral_constant<int, 0>{});
+        static_for<0, NP2>([&](auto pc) {
+            constexpr int p = decltype(pc)::value;
+            if constexpr (p + 1 < NP2) drload(std::integral_constant<int, (p + 1 < NP2 ? p + 1 : 0)>{});
+            R2 v2;
+            static_for<0, 2>([&](auto cc) {
+                constexpr int c = decltype(cc)::value, j = 2 * p + c;
+                Real v = 0;
+                if constexpr (j < ND) {
+                    const R4 r0 = da[p & 1][c]; const R2 r1 = db[p & 1][c];
+                    v = r0[0] * Lq.x + r0[1] * Lq.y + r0[2] * Lq.z + r0[3] * Pm.x + r1[0] * Pm.y + r1[1] * Pm.z;
+                    if (j == k) v += dk;
+                    const bool on = (((j < 32) ? lo : hi) >> (j & 31)) & 1u;
+                    v = on ? v : (Real)0;
+                    DM_OPAQUE_V(v);
+                }
+                v2[c] = v;
+            });
+            if (2 * p <= k) *reinterpret_cast<R2*>(&row[2 * p]) = v2;
+            if (DM_DRPREF >= 2) DM_SCHED_FENCE();
+        });
+        } else {
 #pragma unroll
         for (int p = 0; p < NP2; ++p) {
             R2 v2;
@@ -777,6 +813,7 @@ struct EnvSim {
                 v2[c] = v;
             }
             if (2 * p <= k) *reinterpret_cast<R2*>(&row[2 * p]) = v2;
+        }
         }
     }
 
@@ -1665,7 +1702,7 @@ struct EnvSim {
                 DM_SCHED_FENCE();      // the branches of the tree are independent chains: without a fence the scheduler hoists their loads and spills
             }
 #endif
-        } else if constexpr (DM_YPREF != 0 && ND <= 34) {
+        } else if constexpr (DM_YPREF != 0 && C::FULLD) {      // (the fallback class of the two-per-wave kernel only: at the one-per-wave biped kernels' 128 registers the second row buffer spills)
         // (round 6) the dense loop software-pipelined like the two-per-wave kernel's: row k + 1 of the factor and its dof record are requested before the
         // accumulation chain of step k -- this is the loop of the 64-lane fallback of a two-per-wave pair, i.e. of the waves a closed-loop launch waits for
         R2 lrp[2][NP2]; R4 rrp[2][2];
@@ -1680,10 +1717,12 @@ struct EnvSim {
         static_for<0, ND>([&](auto kc) {
             constexpr int k = decltype(kc)::value;
             Real yk = 0;
-            if constexpr (k + 1 < ND) { if (k + 1 < D) ydload(std::integral_constant<int, (k + 1 < ND ? k + 1 : 0)>{}); }
-            if (k < D) {
+            // (C::FULLD: no `k < D` tests -- as wave-uniform branches around the requests they make the compiler wait for everything in flight at every dof, DuoSim::substep_post)
+            if constexpr (k + 1 < ND) { if (C::FULLD || k + 1 < D) ydload(std::integral_constant<int, (k + 1 < ND ? k + 1 : 0)>{}); }
+            if (C::FULLD || k < D) {
                 const R4 r0 = rrp[k & 1][0], r1 = rrp[k & 1][1];
-                const Real val = r0[0] * xd.x + r0[1] * xd.y + r0[2] * xd.z + r0[3] * dd.x + r1[0] * dd.y + r1[1] * dd.z;
+                Real val = r0[0] * xd.x + r0[1] * xd.y + r0[2] * xd.z + r0[3] * dd.x + r1[0] * dd.y + r1[1] * dd.z;
+                if (C::FULLD) DM_OPAQUE_V(val);
                 const bool on = (((k < 32) ? ch_lo : ch_hi) >> (k & 31)) & 1u, ng = (((k < 32) ? ng_lo : ng_hi) >> (k & 31)) & 1u;
                 const Real raw = on ? (ng ? -val : val) : (Real)0;
                 cvec += raw * r1[2];
@@ -1693,6 +1732,7 @@ struct EnvSim {
                 Real acc = raw - (acc2[0] + acc2[1]);
                 if constexpr (k & 1) acc -= lrp[k & 1][k >> 1][0] * y2[k >> 1][0];
                 yk = acc * lrp[k & 1][k >> 1][k & 1];
+                if (C::FULLD) DM_OPAQUE_V(yk);
             }
             y2[k >> 1][k & 1] = yk;
             if (DM_YPREF_DENSE_FENCE) DM_SCHED_FENCE();

@@ -279,10 +279,11 @@ DM_DEV void duo_rows_xd(Lds<Real, ClsBiped>* rec, int wl, Real h, int nc, int R,
 #pragma unroll
     for (int k = 0; k < ND; ++k) {
         Real yk = 0;
-        if (k + 1 < ND) { if (k + 1 < D) DM_XD_YLOAD(k + 1) }
-        if (k < D) {
+        if (k + 1 < ND) { if (DM_DUO_YFULL || k + 1 < D) DM_XD_YLOAD(k + 1) }
+        if (DM_DUO_YFULL || k < D) {
             const R4 r0 = rr[k & 1][0], r1 = rr[k & 1][1];
-            const Real val = r0[0] * xd.x + r0[1] * xd.y + r0[2] * xd.z + r0[3] * dd.x + r1[0] * dd.y + r1[1] * dd.z;
+            Real val = r0[0] * xd.x + r0[1] * xd.y + r0[2] * xd.z + r0[3] * dd.x + r1[0] * dd.y + r1[1] * dd.z;
+            if (DM_DUO_YFULL) DM_OPAQUE_V(val);
             const bool on = (((k < 32) ? ch_lo : ch_hi) >> (k & 31)) & 1u, ng = (((k < 32) ? ng_lo : ng_hi) >> (k & 31)) & 1u;
             const Real raw = on ? (ng ? -val : val) : (Real)0;
             cvec += raw * r1[2];
@@ -293,6 +294,7 @@ DM_DEV void duo_rows_xd(Lds<Real, ClsBiped>* rec, int wl, Real h, int nc, int R,
             Real acc = raw - (acc2[0] + acc2[1]);
             if (k & 1) acc -= lr[k & 1][k >> 1][0] * y2[k >> 1][0];
             yk = acc * lr[k & 1][k >> 1][k & 1];
+            if (DM_DUO_YFULL) DM_OPAQUE_V(yk);
         }
         y2[k >> 1][k & 1] = yk;
         DM_SCHED_FENCE();
@@ -412,6 +414,9 @@ DM_DEV void duo_rows_xd(Lds<Real, ClsBiped>* rec, int wl, Real h, int nc, int R,
     }
 }
 
+#ifndef DM_DUO_YPMAX
+#define DM_DUO_YPMAX 7
+#endif
 #ifndef DM_DUO_WIDE_FALLBACK
 #define DM_DUO_WIDE_FALLBACK 0
 #endif
@@ -997,6 +1002,51 @@ _Pragma("unroll") \
         // y := L^-1 J^T, software-pipelined: the factor row and the dof record of step k+1 are requested (LDS broadcasts) before
         // the dependent accumulation chain of step k runs, so their latency hides behind it (two register buffers, static parity)
         R2 y2[NP2X]; Real cvec = 0;
+#if DM_DUO_YFULL
+        // (round 6, second pass) No per-dof `k < D` tests: every launch of this kernel has D == ND (dm_host.cpp checks it; the 31 row lanes per character assume
+        // it).  As wave-uniform branches around the requests they made the compiler wait for everything in flight (lgkmcnt(0)) at every dof -- the requests of
+        // dof k + 1 included, i.e. the pipelining was undone -- and cost two v_readlane of a spilled mask pair per dof.  The look-ahead set holds the dof record
+        // and the first YP pairs of row k + 1; the pairs beyond are requested at the top of their own step and consumed last, behind the chain over the first
+        // YP (both sets whole: 68 registers, which the kernel does not have -- kernel-long values went to scratch with reloads inside the update loop).
+        constexpr int YP = DM_DUO_YPMAX;
+        R2 lr[2][YP], ltl[NP2 > YP ? NP2 - YP : 1]; R4 rr[2][2];
+#if DM_PRIO_Y
+        dm_setprio<DM_PRIO_Y>();
+#endif
+        auto yhead = [&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            rr[k & 1][0] = *reinterpret_cast<const R4*>(&s.dofrec[k][0]); rr[k & 1][1] = *reinterpret_cast<const R4*>(&s.dofrec[k][4]);
+            const R2* lrow_ = reinterpret_cast<const R2*>(&s.Lt[L::lrow(k)]);
+            static_for<0, ((k >> 1) + 1 < YP ? (k >> 1) + 1 : YP)>([&](auto pc) { constexpr int p = decltype(pc)::value; lr[k & 1][p] = lrow_[p]; });
+        };
+        yhead(std::integral_constant<int, 0>{});
+        static_for<0, ND>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            const R2* lrow_ = reinterpret_cast<const R2*>(&s.Lt[L::lrow(k)]);
+            static_for<YP, (k >> 1) + 1>([&](auto pc) { constexpr int p = decltype(pc)::value; ltl[p - YP] = lrow_[p]; });      // the row's tail, if any
+            if constexpr (k + 1 < ND) yhead(std::integral_constant<int, (k + 1 < ND ? k + 1 : 0)>{});
+            if (DM_DUO_YFULL >= 2) DM_SCHED_FENCE();
+            const R4 r0 = rr[k & 1][0], r1 = rr[k & 1][1];
+            Real val = r0[0] * xd.x + r0[1] * xd.y + r0[2] * xd.z + r0[3] * dd.x + r1[0] * dd.y + r1[1] * dd.z;
+            DM_OPAQUE_V(val);        // (evaluated where it stands, by every lane: see EnvSim::substep_post's tree loop)
+            const bool on = (((k < 32) ? ch_lo : ch_hi) >> (k & 31)) & 1u, ng = (((k < 32) ? ng_lo : ng_hi) >> (k & 31)) & 1u;
+            const Real raw = on ? (ng ? -val : val) : (Real)0;
+            cvec += raw * r1[2];
+            R2 acc2 = {(Real)0, (Real)0}, acc3 = acc2;      // two independent accumulation chains
+            static_for<0, (k >> 1)>([&](auto pc) { constexpr int p = decltype(pc)::value;
+                const R2 e = (p < YP) ? lr[k & 1][p < YP ? p : 0] : ltl[p >= YP ? p - YP : 0];
+                if constexpr (p & 1) acc3 += e * y2[p]; else acc2 += e * y2[p]; });
+            acc2 += acc3;
+            Real acc = raw - (acc2[0] + acc2[1]);
+            constexpr int pd = k >> 1;
+            const R2 ed = (pd < YP) ? lr[k & 1][pd < YP ? pd : 0] : ltl[pd >= YP ? pd - YP : 0];
+            if constexpr (k & 1) acc -= ed[0] * y2[k >> 1][0];
+            Real yk = acc * ed[k & 1];
+            DM_OPAQUE_V(yk);
+            y2[k >> 1][k & 1] = yk;
+            DM_SCHED_FENCE();       // (one dof per scheduling region)
+        });
+#else
         R2 lr[2][NP2]; R4 rr[2][2];
 #if DM_PRIO_Y
         dm_setprio<DM_PRIO_Y>();
@@ -1030,6 +1080,7 @@ _Pragma("unroll") \
             y2[k >> 1][k & 1] = yk;
         }
 #undef DM_DUO_YLOAD
+#endif
 #if DM_PRIO_Y
         prio_low();
 #endif

@@ -31,6 +31,7 @@ struct ClsBiped {      // humanoid3d: 15 links, 34 dof, 43 pose dims, <= 64 grou
     static constexpr bool PGS_MASKSEL = false;      // sweep: lane r takes its new lambda by v_cmp + v_cndmask (MASKSEL classes: a select on a constant SGPR lane mask)
     static constexpr bool GRAM64 = false;   // 64-row Gram matrix by the readlane loop (128-VGPR budget of the one-per-wave kernel)
     static constexpr int PFD = 2;           // look-ahead of the sweep into the overflow block of A, rows
+    static constexpr bool FULLD = false;    // every character stepped through this class has exactly ND dofs (the fallback class of the two-per-wave kernel: dm_host.cpp checks D == ND before a duo launch)
     static constexpr int PRIO_FLOOR = 0;    // lowest wave priority inside substep_post (s_setprio; the fallback class of the two-per-wave kernel raises it)
 };
 // the same character class with all 64 rows of A in VGPRs: the instantiation the two-per-wave kernel falls back to for a pair with a
@@ -42,17 +43,22 @@ struct ClsBipedWide : ClsBiped { static constexpr int RREG = 64, RREG_PLAIN = 64
 #define DM_FB_RREG 32
 #endif
 // DM_FB_PRIO: a pair on the fallback is a wave the launch will wait for (one round of waves lasts as long as its slowest): it runs the two 64-lane passes above its SIMD mate throughout
+// DM_DUO_YFULL: the y = L^-1 J^T loops of the two-per-wave kernel (DuoSim::substep_post, duo_rows_xd, the 64-lane fallback class) without the per-dof `k < D` tests
+// (every duo launch has D == ND)
+#ifndef DM_DUO_YFULL
+#define DM_DUO_YFULL 1
+#endif
 #ifndef DM_FB_PRIO
 #define DM_FB_PRIO 0
 #endif
-struct ClsBipedFb : ClsBiped { static constexpr int RREG = DM_FB_RREG, RREG_PLAIN = DM_FB_RREG; static constexpr bool GRAM64 = true; static constexpr int PRIO_FLOOR = DM_FB_PRIO; };   // (a look-ahead of 6 rows instead of 2 measured no gain)
+struct ClsBipedFb : ClsBiped { static constexpr int RREG = DM_FB_RREG, RREG_PLAIN = DM_FB_RREG; static constexpr bool GRAM64 = true; static constexpr int PRIO_FLOOR = DM_FB_PRIO; static constexpr bool FULLD = DM_DUO_YFULL != 0; };   // (a look-ahead of 6 rows instead of 2 measured no gain)
 // the biped class plus one free rigid sphere in the world (`--scene dribble_amp`: the ball, scenes/SceneDribbleAMP.cpp:398-420); one
 // character per wavefront, 2 waves / SIMD (the ball's Jacobian columns ride in six more VGPRs per row lane)
 struct ClsBipedObj : ClsBiped { static constexpr bool OBJ = true; static constexpr bool PGS_MASKSEL = true; };     // (same-box A/B of the mask select: -3.6 %; ClsBiped at 128 VGPRs: +2.8 %, SGPR pressure)
 struct ClsLarge {      // dog3d and anything up to 23 links / 64 dof / 83 pose dims / 128 candidates, attach rotations allowed
     static constexpr int NJ = 23, ND = 64, NP = 83, NCAP = 128, RREG = 32, RREG_PLAIN = 32, NPAIRCAP = 256, LPAD = 2; static constexpr bool ROT = true;
     static constexpr bool GRAM64 = false; static constexpr int PFD = 2; static constexpr bool OBJ = false; static constexpr bool TREE = false;
-    static constexpr bool BROAD = false; static constexpr bool PGS_MASKSEL = false; static constexpr int PRIO_FLOOR = 0;
+    static constexpr bool BROAD = false; static constexpr bool PGS_MASKSEL = false; static constexpr int PRIO_FLOOR = 0; static constexpr bool FULLD = false;
 };
 
 // ---- compiled skeleton topologies (the elimination program of the branch-sparse factor is generated at compile time) -------------

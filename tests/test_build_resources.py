@@ -39,7 +39,9 @@ def test_production_kernels_do_not_spill_vector_registers(family, what, occupanc
         # round 6: the borrowed-lane path (DuoSim lane borrowing, a rare branch of the update loop) shares the two-per-wave kernels' register file: measured 1 / 7 spilled
         # VGPRs (29 / 42 before that path re-read the lanes' candidate tables behind itself: 10 MB of prologue spill stores per 4096-env launch).  The hot path is held
         # free of scratch by the disassembly test below; here the budget
-        assert r["spill"] <= (4 if family == 0 else 12), (what, r)
+        # round 6, second pass: the y = L^-1 J^T loop without its per-dof `k < D` branches (DM_DUO_YFULL) keeps both look-ahead sets honest -- measured 33 / 13: spilled
+        # in the prologue, reloaded in the epilogue and inside the beyond-32-rows region only (the disassembly test below holds that), -2 % kernel time in the same-box A/B
+        assert r["spill"] <= (40 if family == 0 else 16), (what, r)
     else:
         assert r["spill"] == 0, (what, r)
     assert r["occupancy"] == occupancy and r["lds"] <= lds_max, (what, r)          # 160 KB LDS per CU: 8 (16) waves need <= 20480 (10240) B each

@@ -320,6 +320,14 @@ template <int NP2> __device__ __forceinline__ void wave_gram32(const VecT<double
 #ifndef DM_YPREF
 #define DM_YPREF 1
 #endif
+// DM_STPREF: dyn_subtree of the one-per-wave tree classes statically unrolled, one member ahead
+#ifndef DM_STPREF
+#define DM_STPREF 1
+#endif
+// DM_PAIRPREF: the self-collision passes read their operands unpredicated, the two-per-wave kernel one pass ahead
+#ifndef DM_PAIRPREF
+#define DM_PAIRPREF 1
+#endif
 // DM_DRPREF: dyn_row (the dense classes' mass-matrix rows) requests pair p + 1's dof records before pair p's dot products; 2: one pair per scheduling region
 #ifndef DM_DRPREF
 #define DM_DRPREF 2
@@ -721,6 +729,41 @@ struct EnvSim {
         const int lk = l / G, g = l % G;
         v3 Fs = zero3(), Ns = Fs, h = Fs;
         Real mc = 0, Ic[6] = { 0, 0, 0, 0, 0, 0 };
+        if constexpr (DM_STPREF != 0 && C::TREE && LW == kWave) {
+            // (round 6, second pass; the dog) statically unrolled over the member slots, the next member's records requested before the current one is accumulated --
+            // every lane reads (a lane without a member at this slot its own link), only the accumulation is predicated: the rolled loop below waited for each member's
+            // reads in turn, ten times per call for the root.  Same members in the same order.
+            constexpr int NIT = (NJ + G - 1) / G;
+            const bool lane_on = lk < J;
+            const int lkc = lane_on ? lk : 0;
+            const uint32_t mask = s.mdl.subtree_mask[lkc];
+            const v3 pj = ld3(s.p[lkc]);
+            v3 cm[2], fk2[2], nk2[2]; Real mk2[2], iw2[2][6]; bool on2[2];
+            auto stload = [&](auto ic) {
+                constexpr int it = decltype(ic)::value, sl = it & 1;
+                const int k = lk + g + G * it;
+                const bool on = lane_on && k < J && ((mask >> (k < 32 ? k : 0)) & 1u);
+                const int kc = on ? k : lkc;
+                on2[sl] = on; cm[sl] = ld3(s.com[kc]); fk2[sl] = ld3(s.f[kc]); nk2[sl] = ld3(s.n[kc]); mk2[sl] = s.mdl.mass[kc];
+#pragma unroll
+                for (int q = 0; q < 6; ++q) iw2[sl][q] = s.Iw[kc][q];
+            };
+            stload(std::integral_constant<int, 0>{});
+            static_for<0, NIT>([&](auto ic) {
+                constexpr int it = decltype(ic)::value, sl = it & 1;
+                if (G * it < J) {                                      // (wave-uniform: no slot past the last link)
+                    if constexpr (it + 1 < NIT) stload(std::integral_constant<int, (it + 1 < NIT ? it + 1 : 0)>{});
+                    if (on2[sl]) {
+                        const v3 d = cm[sl] - pj, fk = fk2[sl];
+                        Fs = Fs + fk; Ns = Ns + nk2[sl] + cross(d, fk);
+                        const Real mk = mk2[sl], dd = dot(d, d);
+                        mc += mk; h = h + mk * d;
+                        Ic[0] += iw2[sl][0] + mk * (dd - d.x * d.x); Ic[1] += iw2[sl][1] - mk * d.x * d.y; Ic[2] += iw2[sl][2] - mk * d.x * d.z;
+                        Ic[3] += iw2[sl][3] + mk * (dd - d.y * d.y); Ic[4] += iw2[sl][4] - mk * d.y * d.z; Ic[5] += iw2[sl][5] + mk * (dd - d.z * d.z);
+                    }
+                }
+            });
+        } else
         if (lk < J) {
             const uint32_t mask = s.mdl.subtree_mask[lk];
             const v3 pj = ld3(s.p[lk]);
@@ -1214,10 +1257,19 @@ struct EnvSim {
     // ------------------------------------------------------------------ contacts (DM-physics v1)
     // One self-collision candidate: capsule models of links i and j (mdl.cap), closest points of the two segments (Ericson,
     // Real-Time Collision Detection 5.1.9).  Returns whether it is active; x = midpoint of the two surface points, n from j to i.
-    DM_DEV bool self_pair(int i, int j, v3& x, v3& n, Real& dist) const {
-        const Real* ci = s.mdl.cap[i]; const Real* cj = s.mdl.cap[j];
-        const v3 ui = ldm3(Rbp(i)) * ld3(ci), uj = ldm3(Rbp(j)) * ld3(cj);
-        const v3 p1 = ld3(s.com[i]) + ui, p2 = ld3(s.com[j]) + uj;
+    // (round 6: split into the reads and the arithmetic, so that a caller can request the next pass's operands before it evaluates the current one; same operations in the same order)
+    struct PairIn { R4 ci, cj; m3 Ri, Rj; v3 pi, pj; Real ti, tj; };
+    DM_DEV PairIn pair_load(int i, int j) const {
+        PairIn in;
+        { const Real* ci = s.mdl.cap[i]; const Real* cj = s.mdl.cap[j]; in.ci = R4{ci[0], ci[1], ci[2], ci[3]}; in.cj = R4{cj[0], cj[1], cj[2], cj[3]}; }      // (the table is not 16-B aligned: element reads)
+        in.Ri = ldm3(Rbp(i)); in.Rj = ldm3(Rbp(j));
+        in.pi = ld3(s.com[i]); in.pj = ld3(s.com[j]);
+        in.ti = s.mdl.thresh[i]; in.tj = s.mdl.thresh[j];
+        return in;
+    }
+    DM_DEV bool pair_eval(const PairIn& in, v3& x, v3& n, Real& dist) const {
+        const v3 ui = in.Ri * mk3(in.ci[0], in.ci[1], in.ci[2]), uj = in.Rj * mk3(in.cj[0], in.cj[1], in.cj[2]);
+        const v3 p1 = in.pi + ui, p2 = in.pj + uj;
         const v3 d1 = (Real)-2 * ui, d2 = (Real)-2 * uj, r = p1 - p2;
         const Real eps = (Real)1e-12;
         const Real a = dot(d1, d1), e = dot(d2, d2), f = dot(d2, r);
@@ -1238,13 +1290,14 @@ struct EnvSim {
             }
         }
         const v3 ca = p1 + sp * d1, cb = p2 + tp * d2, dl = ca - cb;
-        const Real d2n = dot(dl, dl), ri = ci[3], rj = cj[3];
+        const Real d2n = dot(dl, dl), ri = in.ci[3], rj = in.cj[3];
         const Real idn = (d2n > (Real)1e-18) ? dm_rsqrt(d2n) : (Real)0, d = d2n * idn;
         dist = d - ri - rj;
         n = (d > (Real)1e-9) ? idn * dl : mk3((Real)0, (Real)1, (Real)0);
         x = (Real)0.5 * ((ca - ri * n) + (cb + rj * n));
-        return dist < dm_min(s.mdl.thresh[i], s.mdl.thresh[j]);
+        return dist < dm_min(in.ti, in.tj);
     }
+    DM_DEV bool self_pair(int i, int j, v3& x, v3& n, Real& dist) const { return pair_eval(pair_load(i, j), x, n, dist); }
     // btPlaneSpace1: two tangents of a unit normal ((-1,0,0), (0,0,1) for the ground normal)
     static DM_DEV void plane_space(v3 n, v3& p, v3& q) {
         if (dm_abs(n.z) > (Real)0.7071067811865475244) {
@@ -1525,7 +1578,14 @@ struct EnvSim {
             for (int base = 0; base < nsurv; base += kWave) {
                 const int code = (base + l < nsurv) ? plist[base + l] : -1;
                 v3 x = zero3(), n = zero3(); Real dsc = 0; bool act = false;
+#if DM_PAIRPREF
+                {   // every lane reads (an idle lane pair 0 / 0): with the reads under the lanes' `code >= 0` branch they went out one dependent round trip at a time
+                    const PairIn pin = pair_load(code >= 0 ? (code & 0xff) : 0, code >= 0 ? (code >> 8) : 0);
+                    act = pair_eval(pin, x, n, dsc) && code >= 0;
+                }
+#else
                 if (code >= 0) act = self_pair(code & 0xff, code >> 8, x, n, dsc);
+#endif
                 const uint64_t mk = wave_ballot(act);
                 if (mk != 0) {
                     const int slot = nc + dm_popc64(mk & lt);

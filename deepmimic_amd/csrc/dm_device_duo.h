@@ -923,12 +923,25 @@ _Pragma("unroll") \
         int nc = V2 ? half_bcast(nact, 0, half) : nact;          // (uniform per character by construction; under V2 the broadcast tells the compiler)
         // ---- self collision: lane = link pair (three passes of 32); active pairs take the slots the ground left, in pair order
         const int npair_passes = (m.NPAIR + HW - 1) / HW;
+#if DM_PAIRPREF
+        // (round 6, second pass) the operands of pass q + 1 are requested before pass q is evaluated, by every lane (an idle lane reads pair 0 / 0): under the lanes'
+        // `code >= 0` branch the reads of a pass went out one dependent round trip at a time
+        typename Base::PairIn pin[2];
+        pin[0] = b.pair_load(pair_code[0] >= 0 ? (pair_code[0] & 0xff) : 0, pair_code[0] >= 0 ? (pair_code[0] >> 8) : 0);
+#endif
 #pragma unroll
         for (int q = 0; q < PP; ++q) {
+#if DM_PAIRPREF
+            if (q + 1 < PP) { const int cn = pair_code[q + 1 < PP ? q + 1 : 0]; pin[(q + 1) & 1] = b.pair_load(cn >= 0 ? (cn & 0xff) : 0, cn >= 0 ? (cn >> 8) : 0); }
+#endif
             if (q < npair_passes) {
                 const int code = pair_code[q];
                 v3 x = zero3(), n = zero3(); Real dsc = 0; bool act = false;
+#if DM_PAIRPREF
+                act = b.pair_eval(pin[q & 1], x, n, dsc) && code >= 0;
+#else
                 if (code >= 0) act = b.self_pair(code & 0xff, code >> 8, x, n, dsc);
+#endif
                 const uint64_t mk64 = wave_ballot(act);
                 if (mk64 != 0) {
                     const uint32_t mk = (uint32_t)(mk64 >> (half * 32));

@@ -29,6 +29,7 @@
 #ifdef DM_EMU
 static inline long long dm_clock() { return 0; }
 template <int P> static inline void dm_setprio() {}
+template <typename T> static inline T* dm_uniform_ptr(T* p) { return p; }
 #define DM_DEV inline
 #define DM_OPAQUE_S(x) ((void)0)
 #define DM_OPAQUE_V(x) ((void)0)
@@ -105,6 +106,12 @@ template <> struct VecT<double> { typedef double v2 __attribute__((vector_size(1
 #define DM_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 __device__ __forceinline__ long long dm_clock() { return (long long)__builtin_readcyclecounter(); }
 template <int P> __device__ __forceinline__ void dm_setprio() { __builtin_amdgcn_s_setprio(P); }
+// a pointer the caller knows to be wave-uniform, handed to the compiler as a scalar pair (global accesses then take the SGPR base + VGPR offset form)
+template <typename T> __device__ __forceinline__ T* dm_uniform_ptr(T* p) {
+    const uint64_t v = (uint64_t)p;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return (T*)(((uint64_t)hi << 32) | (uint64_t)lo);
+}
 __device__ __forceinline__ int dm_atomic_or(int* p, int v) { return atomicOr(p, v); }
 __device__ __forceinline__ int dm_atomic_min(int* p, int v) { return atomicMin(p, v); }
 __device__ __forceinline__ int dm_atomic_add(int* p, int v) { return atomicAdd(p, v); }

@@ -12,6 +12,18 @@
 // routine of dm_device.h on each record in turn (same LDS record layout), so the results do not depend on the pairing.
 #pragma once
 #include "dm_device.h"
+// The borrowed-lane path's Y stash (duo_rows_xd): DM_XD_YSOPQ forms its address inside the path (opaque), DM_XD_YSLANE lays it out [lane][dof] (one address for all entries).
+// Either removes the 13 hoisted row addresses (26 kernel-long VGPRs, spilled in the prologue: 17 MB of scratch stores per 4096-env launch) -- and makes the allocator reload
+// 12-15 other values INSIDE the update loop (dynamics, factor, collision).  Shipped: both 0 (no scratch access on the hot path; tests/test_build_resources.py).
+#ifndef DM_XD_YSOPQ
+#define DM_XD_YSOPQ 0
+#endif
+#ifndef DM_XD_YSUNI
+#define DM_XD_YSUNI 0
+#endif
+#ifndef DM_XD_YSLANE
+#define DM_XD_YSLANE 0
+#endif
 // Wave priorities by phase (round 4; profiles/r04_ab_setprio.json).  Two waves share a SIMD; when both have an instruction ready the arbiter takes the
 // higher priority, then the older.  A wave in a phase with much independent work per lane (dynamics, collision, the Gram MFMA chains) has an instruction
 // ready almost every cycle and delays the ONE ready instruction of a wave that sits in a dependent chain (factorisation columns, substitutions,
@@ -340,8 +352,11 @@ DM_DEV void duo_rows_xd(Lds<Real, ClsBiped>* rec, int wl, Real h, int nc, int R,
         // 32 + j both hold column j of block (X, Y), i.e. (symmetry) the entries of the row held by lane 32 Y + j against the rows of half X.
         RowFile<Real, XR> arow;
         // Y leaves for the pair's overflow block until the sweep is over (coalesced: [dof][lane]); its registers then carry the MFMA operands
+        // (the lane's base address is formed HERE, opaque to the optimizer: hoisted out of the 20-update loop the 13 row addresses beyond the 12-bit offset range were 26 kernel-long
+        // VGPRs of this rare path -- spilled in the prologue once the main path needed the registers: 17 MB of scratch stores per 4096-env launch)
+        { Real* ys = (DM_XD_YSUNI ? dm_uniform_ptr(ystash) : ystash) + (DM_XD_YSLANE ? wl * (2 * NP2) : wl); if (DM_XD_YSOPQ) DM_OPAQUE_V(ys);        // DM_XD_YSLANE: [lane][dof] -- every entry within the 12-bit offset range of ONE address
 #pragma unroll
-        for (int p = 0; p < NP2; ++p) { ystash[(2 * p) * kWave + wl] = y2[p][0]; ystash[(2 * p + 1) * kWave + wl] = y2[p][1]; }
+          for (int p = 0; p < NP2; ++p) { ys[DM_XD_YSLANE ? 2 * p : (2 * p) * kWave] = y2[p][0]; ys[DM_XD_YSLANE ? 2 * p + 1 : (2 * p + 1) * kWave] = y2[p][1]; } }
         xd_gram_operands<NP2>(y2);
         DM_SCHED_FENCE();
         xd_gram_block<NP2, 0, 0>(y2, [&](auto rc, Real g) { constexpr int r = decltype(rc)::value; arow.set(r, g); if (XR - 32 > 31 - r) arow.set(32 + (31 - r), g); });       // half-0 lanes against half 0 (provisionally every lane's; the borrowed rows of a heavy half 1)
@@ -386,8 +401,9 @@ DM_DEV void duo_rows_xd(Lds<Real, ClsBiped>* rec, int wl, Real h, int nc, int R,
         dm_setprio<DM_PRIO_BACK>();
 #endif
         if (row >= Rc) lam = 0;
+        { const Real* ys = (DM_XD_YSUNI ? dm_uniform_ptr(ystash) : ystash) + (DM_XD_YSLANE ? wl * (2 * NP2) : wl); if (DM_XD_YSOPQ) DM_OPAQUE_V(ys);
 #pragma unroll
-        for (int p = 0; p < NP2; ++p) { y2[p][0] = ystash[(2 * p) * kWave + wl]; y2[p][1] = ystash[(2 * p + 1) * kWave + wl]; }
+          for (int p = 0; p < NP2; ++p) { y2[p][0] = ys[DM_XD_YSLANE ? 2 * p : (2 * p) * kWave]; y2[p][1] = ys[DM_XD_YSLANE ? 2 * p + 1 : (2 * p + 1) * kWave]; } }
     } else {
 #if DM_PRIO_BACK
         dm_setprio<DM_PRIO_BACK>();
